@@ -1,0 +1,66 @@
+#!/bin/bash
+# build_ref.sh -- TEST INFRASTRUCTURE.  Compiles the *real* reference (IMD/lasMD)
+# force path from its own C sources where they lie under $REF (default
+# /root/reference) with plain gcc -- the reference's Makefile is not run; the
+# source list and -D flags below are what its target-name rules
+# (Makefile:141-160,283-296,1000-1050) select for the named target.  Nothing is
+# copied: objects and binaries go to oracle/_ref/ only (git-ignored, but they
+# travel to the GPU box).  The only non-reference TU linked in is
+# oracle/ref_probe.c, a read-only observation probe attached with ld --wrap.
+#
+# usage: oracle/build_ref.sh [target ...]
+#   targets: eam_nve_nbl  nve_nbl  eam_nve  nve  mpi_eam_nve_nbl
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+REF="${IMD_REFERENCE:-/root/reference}"
+OUT="$HERE/_ref"
+CC="${CC:-gcc}"
+# -fcommon: globals.h defines a few structs without EXTERN (GCC >= 10 needs it).
+# No -march=native / -ffast-math: parity is defined against plain IEEE fp64.
+BASEFLAGS="-O2 -fcommon -w -I$REF"
+
+if [ ! -d "$REF" ]; then
+  echo "build_ref: $REF not present (GPU box?) -- using prebuilt oracle/_ref" >&2
+  exit 0
+fi
+mkdir -p "$OUT"
+
+COMMON="imd_maxwell.c imd_integrate.c imd_misc.c imd_param.c imd_alloc.c imd_io.c
+        imd_io_3d.c imd_potential.c imd_time.c imd_generate.c imd_distrib.c
+        imd_main_3d.c imd_geom_3d.c imd_pictures_3d.c imd.c"
+NBLSRC="imd_geom_mpi_3d.c imd_comm_force_3d.c imd_fix_cells_3d.c imd_mpiio.c imd_forces_nbl.c"
+
+build() {
+  local name="$1" defs="$2" srcs="$3" cc="$4" libs="$5"
+  local obj="$OUT/obj_$name"
+  mkdir -p "$obj"
+  local objs=""
+  for s in $srcs; do
+    local o="$obj/${s%.c}.o"
+    if [ ! -f "$o" ] || [ "$REF/$s" -nt "$o" ]; then
+      $cc $BASEFLAGS $defs -c "$REF/$s" -o "$o" &
+    fi
+    objs="$objs $o"
+  done
+  wait
+  $cc $BASEFLAGS $defs -c "$HERE/ref_probe.c" -o "$obj/ref_probe.o"
+  $cc -o "$OUT/imd_$name" $objs "$obj/ref_probe.o" -Wl,--wrap=calc_forces \
+      "$REF/nn_interpol/libnn.a" -lm $libs
+  echo "built $OUT/imd_$name"
+}
+
+TARGETS="${*:-eam_nve_nbl nve_nbl eam_nve}"
+for t in $TARGETS; do
+  case "$t" in
+    eam_nve_nbl) build "$t" "-DNBL -DEAM2 -DNVE" "$COMMON $NBLSRC" "$CC" "" ;;
+    nve_nbl)     build "$t" "-DNBL -DNVE"        "$COMMON $NBLSRC" "$CC" "" ;;
+    eam_nve)     build "$t" "-DEAM2 -DNVE" "$COMMON imd_main_risc_3d.c imd_forces.c imd_forces_eam2.c" "$CC" "" ;;
+    nve)         build "$t" "-DNVE"        "$COMMON imd_main_risc_3d.c imd_forces.c" "$CC" "" ;;
+    mpi_eam_nve_nbl)
+      MPIINC="${MPI_HOME:-/opt/conda}"
+      if [ ! -f "$MPIINC/include/mpi.h" ]; then echo "no MPI at $MPIINC, skipping $t" >&2; continue; fi
+      build "$t" "-DMPI -DNBL -DEAM2 -DNVE" "$COMMON $NBLSRC imd_mpi_util.c" \
+            "$CC -I$MPIINC/include" "-L$MPIINC/lib -Wl,-rpath,$MPIINC/lib -lmpi" ;;
+    *) echo "unknown target $t" >&2; exit 1 ;;
+  esac
+done

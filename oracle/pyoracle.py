@@ -1,0 +1,280 @@
+"""TEST INFRASTRUCTURE -- ctypes front end of the CPU oracle (oracle/imd_oracle.c).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module; the product package imd_amd never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liborcimd.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))
+            and not f.startswith("ref_")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "liborcimd.so"])
+    return so
+
+
+class _Table(C.Structure):
+    _fields_ = [("ncols", C.c_int), ("maxsteps", C.c_int),
+                ("begin", C.POINTER(C.c_double)), ("end", C.POINTER(C.c_double)),
+                ("step", C.POINTER(C.c_double)), ("invstep", C.POINTER(C.c_double)),
+                ("len", C.POINTER(C.c_int)), ("table", C.POINTER(C.c_double))]
+
+
+class _Sys(C.Structure):
+    _fields_ = [("dim", C.c_int * 3), ("gdim", C.c_int * 3), ("pbc", C.c_int * 3),
+                ("ntypes", C.c_int), ("cap", C.c_int), ("nall", C.c_int), ("ninner", C.c_int),
+                ("box", C.c_double * 9), ("tbox", C.c_double * 9),
+                ("cellsz", C.c_double), ("nbl_margin", C.c_double), ("timestep", C.c_double),
+                ("n", C.POINTER(C.c_int)), ("inner", C.POINTER(C.c_int)), ("nq", C.POINTER(C.c_int)),
+                ("ort", C.POINTER(C.c_double)), ("impuls", C.POINTER(C.c_double)),
+                ("kraft", C.POINTER(C.c_double)), ("nbl_pos", C.POINTER(C.c_double)),
+                ("masse", C.POINTER(C.c_double)), ("pot_eng", C.POINTER(C.c_double)),
+                ("rho", C.POINTER(C.c_double)), ("dF", C.POINTER(C.c_double)),
+                ("sorte", C.POINTER(C.c_int)), ("nummer", C.POINTER(C.c_int)),
+                ("numneighs", C.POINTER(C.c_int)),
+                ("cl_off", C.POINTER(C.c_int)), ("tl", C.POINTER(C.c_int)), ("tb", C.POINTER(C.c_int)),
+                ("tl_cap", C.c_int), ("tb_cap", C.c_int), ("tb_len", C.c_int),
+                ("have_valid_nbl", C.c_int), ("nbl_count", C.c_int),
+                ("pair", _Table), ("rhotab", _Table), ("embed", _Table),
+                ("have_pair", C.c_int), ("have_eam", C.c_int), ("count_ttm_neigh", C.c_int),
+                ("tot_pot_energy", C.c_double), ("virial", C.c_double), ("tot_kin_energy", C.c_double),
+                ("is_short", C.c_int), ("restrictions", C.c_double * 3)]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.orc_new.restype = C.POINTER(_Sys)
+        L.orc_new.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_double),
+                              C.POINTER(C.c_int), C.c_double, C.c_double, C.c_double]
+        L.orc_free.argtypes = [C.POINTER(_Sys)]
+        L.orc_set_table.argtypes = [C.POINTER(_Sys), C.c_int, C.c_int, C.c_int] + \
+            [C.POINTER(C.c_double)] * 4 + [C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        for f in ("orc_do_boundaries", "orc_fix_cells", "orc_make_nblist", "orc_check_nblist",
+                  "orc_move_atoms_nve", "orc_make_cell_lists"):
+            getattr(L, f).argtypes = [C.POINTER(_Sys)]
+            getattr(L, f).restype = None
+        L.orc_send_cells.argtypes = [C.POINTER(_Sys), C.c_int, C.c_int]
+        L.orc_send_forces.argtypes = [C.POINTER(_Sys), C.c_int]
+        L.orc_calc_forces.argtypes = [C.POINTER(_Sys), C.c_int]
+        L.orc_global_cell_dim.argtypes = [C.POINTER(C.c_double), C.c_double,
+                                          C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_pair_int.argtypes = [C.POINTER(_Table), C.c_int, C.c_int, C.c_double,
+                                   C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.orc_val_func.restype = C.c_double
+        L.orc_val_func.argtypes = [C.POINTER(_Table), C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int)]
+        L.orc_deriv_func.restype = C.c_double
+        L.orc_deriv_func.argtypes = L.orc_val_func.argtypes
+        L.orc_set_nblist.argtypes = [C.POINTER(_Sys), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.c_int]
+        L.orc_init_threepoint.argtypes = [C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]
+        _LIB = L
+    return _LIB
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def global_cell_dim(box, cellsz, cd=(1, 1, 1)):
+    b = np.ascontiguousarray(box, dtype=np.float64).reshape(9)
+    cdv = np.asarray(cd, dtype=np.int32)
+    out = np.zeros(3, dtype=np.int32)
+    lib().orc_global_cell_dim(_dp(b), float(cellsz), _ip(cdv), _ip(out))
+    return tuple(int(v) for v in out)
+
+
+class OracleSystem:
+    """Padded-cell system; numpy views alias the C arrays (shape (nall, cap[,3]))."""
+
+    def __init__(self, dim, cap, ntypes, box, pbc, cellsz, nbl_margin, timestep):
+        L = lib()
+        d = np.asarray(dim, dtype=np.int32)
+        b = np.ascontiguousarray(box, dtype=np.float64).reshape(9)
+        p = np.asarray(pbc, dtype=np.int32)
+        self._p = L.orc_new(_ip(d), int(cap), int(ntypes), _dp(b), _ip(p),
+                            float(cellsz), float(nbl_margin), float(timestep))
+        self.s = self._p.contents
+        s = self.s
+        self.dim = tuple(int(v) for v in d)
+        self.cap = int(cap)
+        nall, ninner = s.nall, s.ninner
+        as_arr = np.ctypeslib.as_array
+        self.n = as_arr(s.n, (nall,))
+        self.inner = as_arr(s.inner, (ninner,))
+        self.nq = as_arr(s.nq, (ninner, 14))
+        for name in ("ort", "impuls", "kraft", "nbl_pos"):
+            setattr(self, name, as_arr(getattr(s, name), (nall, cap, 3)))
+        for name in ("masse", "pot_eng", "rho", "dF", "sorte", "nummer", "numneighs"):
+            setattr(self, name, as_arr(getattr(s, name), (nall, cap)))
+        self.cl_off = as_arr(s.cl_off, (nall + 1,))
+        self._keep = []
+
+    def close(self):
+        if self._p is not None:
+            lib().orc_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_table(self, which, t):
+        """t: dict with ncols,maxsteps,begin,end,step,invstep,len,table (after init_threepoint)."""
+        a = {k: np.ascontiguousarray(t[k], dtype=np.float64) for k in ("begin", "end", "step", "invstep", "table")}
+        ln = np.ascontiguousarray(t["len"], dtype=np.int32)
+        lib().orc_set_table(self._p, which, int(t["ncols"]), int(t["maxsteps"]), _dp(a["begin"]), _dp(a["end"]),
+                            _dp(a["step"]), _dp(a["invstep"]), _ip(ln), _dp(a["table"]))
+
+    # thin wrappers -----------------------------------------------------------
+    def fix_cells(self): lib().orc_fix_cells(self._p)
+    def send_cells(self, what=0, full_shell=0): lib().orc_send_cells(self._p, what, full_shell)
+    def send_forces(self, what): lib().orc_send_forces(self._p, what)
+    def make_nblist(self): lib().orc_make_nblist(self._p)
+    def calc_forces(self, steps=0): lib().orc_calc_forces(self._p, steps)
+    def check_nblist(self): lib().orc_check_nblist(self._p)
+    def move_atoms_nve(self): lib().orc_move_atoms_nve(self._p)
+
+    def set_nblist(self, tl, tb):
+        tl = np.ascontiguousarray(tl, dtype=np.int32); tb = np.ascontiguousarray(tb, dtype=np.int32)
+        lib().orc_set_nblist(self._p, _ip(tl), len(tl), _ip(tb), len(tb))
+
+    @property
+    def tl(self):
+        nin = int(sum(self.n[c] for c in self.inner))
+        return np.ctypeslib.as_array(self.s.tl, (nin + 1,))
+
+    @property
+    def tb(self):
+        return np.ctypeslib.as_array(self.s.tb, (max(self.s.tb_len, 1),))[: self.s.tb_len]
+
+    # helpers -------------------------------------------------------------------
+    def inner_mask(self):
+        m = np.zeros(self.s.nall, dtype=bool)
+        m[self.inner] = True
+        return m
+
+    def gather_inner(self, name):
+        """Concatenate a per-atom field over inner cells in `cells` order."""
+        arr = getattr(self, name)
+        return np.concatenate([arr[c, : self.n[c]] for c in self.inner], axis=0)
+
+    def load_cells(self, cell_n, per_cell_fields):
+        """Fill cells from per-cell lists: per_cell_fields[name][c] -> array(n_c[,3])."""
+        self.n[:] = cell_n
+        for name, lst in per_cell_fields.items():
+            arr = getattr(self, name)
+            for c, v in enumerate(lst):
+                if len(v):
+                    arr[c, : len(v)] = v
+
+
+# ---------------------------------------------------------------------------
+# reader for the dumps written by oracle/ref_probe.c
+# ---------------------------------------------------------------------------
+
+def read_probe(path):
+    buf = open(path, "rb").read()
+    assert buf[:8] == b"IMDPROBE", "bad magic"
+    assert buf[-8:] == b"ENDPROBE", "truncated probe dump"
+    off = [8]
+
+    def ri(n=1):
+        v = np.frombuffer(buf, dtype="<i4", count=n, offset=off[0]); off[0] += 4 * n
+        return v if n > 1 else int(v[0])
+
+    def rd(n=1):
+        v = np.frombuffer(buf, dtype="<f8", count=n, offset=off[0]); off[0] += 8 * n
+        return v if n > 1 else float(v[0])
+
+    P = {}
+    P["version"] = ri(); P["flags"] = ri(); P["step"] = ri(); P["myid"] = ri()
+    P["ntypes"] = ri(); nall = P["nallcells"] = ri(); ncells = P["ncells"] = ri()
+    P["cell_dim"] = ri(3).copy(); P["global_cell_dim"] = ri(3).copy(); P["pbc_dirs"] = ri(3).copy()
+    P["cpu_dim"] = ri(3).copy(); P["my_coord"] = ri(3).copy()
+    P["natoms"] = ri(); P["have_valid_nbl"] = ri(); P["nbl_count"] = ri(); P["last_nbl_len"] = ri()
+    P["box"] = rd(9).copy().reshape(3, 3)
+    P["cellsz"] = rd(); P["nbl_margin"] = rd(); P["timestep"] = rd()
+    P["tot_pot_energy"] = rd(); P["virial"] = rd(); P["tot_kin_energy"] = rd()
+
+    def rtab():
+        ncols = ri(); maxsteps = ri()
+        if ncols == 0:
+            return None
+        t = {"ncols": ncols, "maxsteps": maxsteps}
+        for k in ("begin", "end", "step", "invstep"):
+            t[k] = np.atleast_1d(rd(ncols)).copy()
+        t["len"] = np.atleast_1d(ri(ncols)).copy()
+        t["table"] = rd((maxsteps + 2) * ncols).copy()
+        return t
+
+    P["pair_pot"] = rtab(); P["rho_h_tab"] = rtab(); P["embed_pot"] = rtab()
+    cn = P["cell_n"] = np.atleast_1d(ri(nall)).copy()
+    ntot = int(cn.sum())
+    rec = np.dtype([("nummer", "<i4"), ("sorte", "<i4"), ("ort", "<f8", 3)])
+    allat = np.frombuffer(buf, dtype=rec, count=ntot, offset=off[0]); off[0] += rec.itemsize * ntot
+    P["all_nummer"] = allat["nummer"].copy(); P["all_sorte"] = allat["sorte"].copy()
+    P["all_ort"] = allat["ort"].copy()
+    P["cells"] = np.atleast_1d(ri(ncells)).copy()
+    nin = P["ninner_atoms"] = ri()
+    rec2 = np.dtype([("masse", "<f8"), ("impuls", "<f8", 3), ("kraft", "<f8", 3), ("pot_eng", "<f8"),
+                     ("eam_rho", "<f8"), ("eam_dF", "<f8"), ("nbl_pos", "<f8", 3), ("numneighs", "<i4")])
+    inn = np.frombuffer(buf, dtype=rec2, count=nin, offset=off[0]); off[0] += rec2.itemsize * nin
+    for k in rec2.names:
+        P[k] = inn[k].copy()
+    if P["flags"] & 2:
+        P["cl_off"] = np.atleast_1d(ri(nall)).copy()
+        P["tl"] = np.atleast_1d(ri(nin + 1)).copy()
+        P["tb"] = np.atleast_1d(ri(int(P["tl"][-1]))).copy() if P["tl"][-1] > 0 else np.zeros(0, np.int32)
+        P["cnbrs"] = ri(ncells * 15).copy().reshape(ncells, 15)
+    assert buf[off[0]:off[0] + 8] == b"ENDPROBE"
+    return P
+
+
+def system_from_probe(P, cap=None, load_outputs=False):
+    """Rebuild the reference's cell arrangement (same slots) inside the oracle."""
+    cn = P["cell_n"]
+    cap = cap or int(max(cn.max() + 8, 16))
+    s = OracleSystem(P["cell_dim"], cap, P["ntypes"], P["box"], P["pbc_dirs"],
+                     P["cellsz"], P["nbl_margin"], P["timestep"])
+    start = np.concatenate([[0], np.cumsum(cn)])
+    s.n[:] = cn
+    for c in range(len(cn)):
+        a, b = start[c], start[c + 1]
+        if b > a:
+            s.ort[c, : b - a] = P["all_ort"][a:b]
+            s.sorte[c, : b - a] = P["all_sorte"][a:b]
+            s.nummer[c, : b - a] = P["all_nummer"][a:b]
+    # inner-only fields
+    k = 0
+    for c in P["cells"]:
+        m = cn[c]
+        s.masse[c, :m] = P["masse"][k:k + m]
+        s.impuls[c, :m] = P["impuls"][k:k + m]
+        s.nbl_pos[c, :m] = P["nbl_pos"][k:k + m]
+        if load_outputs:
+            s.kraft[c, :m] = P["kraft"][k:k + m]
+            s.pot_eng[c, :m] = P["pot_eng"][k:k + m]
+            s.rho[c, :m] = P["eam_rho"][k:k + m]
+            s.dF[c, :m] = P["eam_dF"][k:k + m]
+        k += m
+    for which, key in ((0, "pair_pot"), (1, "rho_h_tab"), (2, "embed_pot")):
+        if P.get(key) is not None:
+            s.set_table(which, P[key])
+    s.s.count_ttm_neigh = 1 if (P["flags"] & 4) else 0
+    return s
