@@ -1,0 +1,231 @@
+"""Potential tables: host-side mirror of IMD's ``pot_table_t`` interface.
+
+The device kernels consume exactly what the reference keeps in memory
+(reference types.h:537-549): per column ``begin/end/step/invstep/len`` and a
+column-interleaved value table ``table[k*ncols+col]`` with two extrapolated
+rows appended (reference imd_potential.c:1260-1276), equidistant in r**2 for
+radial tables and in rho for the embedding table.
+
+This module is host logic (file formats, analytic table creation); evaluation
+happens on the GPU (imd_amd/csrc/imdgpu.hip) and, for tests, in oracle/.
+"""
+from dataclasses import dataclass
+
+import numpy as np
+
+POT_TAIL = 0.05          # reference config.h:124
+
+
+@dataclass
+class PotTable:
+    """Same fields, same meaning as the reference's ``pot_table_t``."""
+    begin: np.ndarray
+    end: np.ndarray
+    step: np.ndarray
+    invstep: np.ndarray
+    len: np.ndarray
+    ncols: int
+    maxsteps: int
+    table: np.ndarray        # flat, (maxsteps+2)*ncols
+
+    def as_dict(self):
+        return dict(begin=self.begin, end=self.end, step=self.step, invstep=self.invstep,
+                    len=self.len, ncols=self.ncols, maxsteps=self.maxsteps, table=self.table)
+
+    @staticmethod
+    def from_dict(d):
+        return PotTable(np.ascontiguousarray(d["begin"], np.float64), np.ascontiguousarray(d["end"], np.float64),
+                        np.ascontiguousarray(d["step"], np.float64), np.ascontiguousarray(d["invstep"], np.float64),
+                        np.ascontiguousarray(d["len"], np.int32), int(d["ncols"]), int(d["maxsteps"]),
+                        np.ascontiguousarray(d["table"], np.float64))
+
+
+def init_threepoint(table, ncols, lens):
+    """Append two rows continuing the last parabola (imd_potential.c:1260-1276)."""
+    t = table.reshape(-1, ncols)
+    for col in range(ncols):
+        n = int(lens[col])
+        a, b, c = t[n - 1, col], t[n - 2, col], t[n - 3, col]
+        t[n, col] = 3 * a - 3 * b + c
+        t[n + 1, col] = 6 * a - 8 * b + 3 * c
+
+
+def _tokens(path):
+    header, body = [], []
+    with open(path) as f:
+        for line in f:
+            if line.startswith("#"):
+                header.append(line)
+            else:
+                body.append(line)
+    return header, " ".join(body).split()
+
+
+def read_pot_table(path, ncols, radial):
+    """Read an IMD potential file (format 1 or 2, imd_potential.c:161-466).
+
+    Returns (PotTable, cellsz) where cellsz is max(end) over columns for radial
+    tables (the r**2 the cell size derives from), else 0.
+    """
+    header, tok = _tokens(path)
+    fmt = 2 if ncols else 1
+    have_fmt = False
+    for h in header:
+        if h[1] == "F":
+            p = h[2:].split()
+            fmt, size = int(p[0]), int(p[1])
+            if size != ncols:
+                raise ValueError("Wrong number of data columns in file %s: should be %d, is %d" % (path, ncols, size))
+            if fmt not in (1, 2):
+                raise ValueError("Unrecognized format specified for file %s" % path)
+            have_fmt = True
+    if header and not have_fmt:
+        raise ValueError("Format not specified in header of file %s" % path)
+    vals = np.array(tok, dtype=np.float64)
+    cellsz = 0.0
+    if fmt == 2:
+        info = vals[: 3 * ncols].reshape(ncols, 3)
+        begin, end, step = info[:, 0].copy(), info[:, 1].copy(), info[:, 2].copy()
+        numstep = 1 + (end - begin) / step
+        lens = (numstep + 0.49).astype(np.int32)
+        maxsteps = int(lens.max())
+        table = np.zeros((maxsteps + 2, ncols))
+        off = 3 * ncols
+        for i in range(ncols):
+            if off + lens[i] > len(vals):
+                raise ValueError("wrong format in file %s." % path)
+            table[: lens[i], i] = vals[off: off + lens[i]]
+            off += lens[i]
+        if radial:
+            for i in range(ncols):
+                delta = table[lens[i] - 1, i]
+                if delta != 0.0:
+                    table[: lens[i], i] -= delta
+            cellsz = float(end.max())
+    else:
+        rows = vals.reshape(-1, ncols + 1)
+        npot = rows.shape[0]
+        r2_start, r2 = rows[0, 0], rows[-1, 0]
+        r2_step = (r2 - r2_start) / (npot - 1)
+        maxsteps = npot
+        table = np.zeros((maxsteps + 2, ncols))
+        table[:npot] = rows[:, 1:]
+        begin = np.full(ncols, r2_start); step = np.full(ncols, r2_step)
+        end = np.zeros(ncols); lens = np.zeros(ncols, np.int32)
+        for i in range(ncols):
+            nz = np.nonzero(rows[:, 1 + i])[0]
+            if len(nz):
+                end[i] = rows[nz[-1], 0]; lens[i] = nz[-1] + 1
+            if radial:
+                delta = table[npot - 1, i]
+                if delta != 0.0:
+                    table[:npot, i] -= delta
+        if radial:
+            cellsz = float(end.max())
+    pt = PotTable(begin, end, step, 1.0 / step, lens.astype(np.int32), ncols, maxsteps, table.reshape(-1).copy())
+    init_threepoint(pt.table, ncols, pt.len)
+    return pt, cellsz
+
+
+def write_pot_table2(path, begin, end, step, columns):
+    """Write format 2 (``#F 2 ncols`` / ``#E`` / info lines / values per column)."""
+    ncols = len(columns)
+    with open(path, "w") as f:
+        f.write("#F 2 %d\n#E\n" % ncols)
+        for i in range(ncols):
+            f.write("%.16e %.16e %.16e\n" % (begin[i], end[i], step[i]))
+        f.write("\n")
+        for col in columns:
+            for v in col:
+                f.write("%.16e\n" % v)
+            f.write("\n")
+
+
+def pair_int_lj(eps, sigma, r2):
+    """IMD's Lennard-Jones form eps*(s^12 - 2 s^6) (imd_potential.c:1437-1449)."""
+    s2 = sigma * sigma / r2
+    s6 = s2 * s2 * s2
+    s12 = s6 * s6
+    return eps * (s12 - 2.0 * s6), -12.0 * eps / r2 * (s12 - s6)
+
+
+def create_lj_table(eps, sigma, r_cut, r_begin=0.0, pot_res=1000):
+    """Tabulate LJ in r**2 the way create_pot_table does for one atom type
+    (imd_potential.c:476-705, shift/tail from init_pre_pot :853-872)."""
+    if r_begin == 0.0:
+        r_begin = 0.1 * sigma
+    r2_cut = r_cut * r_cut
+    shift, tmp = pair_int_lj(eps, sigma, (1.0 - POT_TAIL) * r2_cut)
+    shift += 0.25 * tmp * POT_TAIL * r2_cut
+    aaa = -0.25 * tmp / (POT_TAIL * r2_cut)
+    r2_begin, r2_end = r_begin * r_begin, r2_cut
+    r2_step = (r2_end - r2_begin) / (pot_res - 1)
+    table = np.zeros((pot_res + 2, 1))
+    for n in range(pot_res):
+        r2 = r2_begin + n * r2_step
+        val = 0.0
+        if r2 < (1.0 - POT_TAIL) * r2_cut:
+            pot, _ = pair_int_lj(eps, sigma, r2)
+            val += pot - shift
+        elif r2 <= r2_cut:
+            val += aaa * (r2_cut - r2) ** 2
+        table[n, 0] = val
+    pt = PotTable(np.array([r2_begin]), np.array([r2_end]), np.array([r2_step]), np.array([1.0 / r2_step]),
+                  np.array([pot_res], np.int32), 1, pot_res, table.reshape(-1).copy())
+    init_threepoint(pt.table, 1, pt.len)
+    return pt, r2_end
+
+
+# ---------------------------------------------------------------------------
+# synthetic EAM for Al-like FCC; no real Al tables ship
+# with the reference, so every number in this repo is for these tables.
+# ---------------------------------------------------------------------------
+
+def _cut(r, rc=6.5, w=0.6):
+    x = (r - rc) / w
+    return x ** 4 / (1.0 + x ** 4)
+
+
+def synthetic_eam_functions():
+    phi = lambda r: 0.27 * (np.exp(-2 * 1.16 * (r - 2.86)) - 2 * np.exp(-1.16 * (r - 2.86))) * _cut(r)
+    rho = lambda r: np.exp(-3.0 * (r / 2.86 - 1.0)) * _cut(r)
+    emb = lambda p: -1.6 * np.sqrt(p) + 0.02 * p * p
+    return phi, rho, emb
+
+
+def synthetic_eam_tables(n=4000, r_begin=1.5, r_cut=6.5, rho_max=40.0):
+    """(pair_pot, rho_h_tab, embed_pot, cellsz) tabulated like the reference would
+    hold them after read_pot_table (shifted to zero at r_cut, 2 pad rows)."""
+    phi, rho, emb = synthetic_eam_functions()
+    b2, e2 = r_begin ** 2, r_cut ** 2
+    step = (e2 - b2) / (n - 1)
+    r = np.sqrt(b2 + step * np.arange(n))
+    out = []
+    for fn in (phi, rho):
+        t = np.zeros((n + 2, 1))
+        v = fn(r)
+        t[:n, 0] = v - v[-1] if v[-1] != 0.0 else v
+        pt = PotTable(np.array([b2]), np.array([e2]), np.array([step]), np.array([1.0 / step]),
+                      np.array([n], np.int32), 1, n, t.reshape(-1).copy())
+        init_threepoint(pt.table, 1, pt.len)
+        out.append(pt)
+    ps = rho_max / (n - 1)
+    t = np.zeros((n + 2, 1))
+    t[:n, 0] = emb(ps * np.arange(n))
+    pe = PotTable(np.array([0.0]), np.array([rho_max]), np.array([ps]), np.array([1.0 / ps]),
+                  np.array([n], np.int32), 1, n, t.reshape(-1).copy())
+    init_threepoint(pe.table, 1, pe.len)
+    return out[0], out[1], pe, e2
+
+
+def write_synthetic_eam_files(dirname, n=4000, r_begin=1.5, r_cut=6.5, rho_max=40.0):
+    """phi.pt / rho.pt / F.pt in IMD format 2 for the reference binary."""
+    import os
+    phi, rho, emb = synthetic_eam_functions()
+    b2, e2 = r_begin ** 2, r_cut ** 2
+    step = (e2 - b2) / (n - 1)
+    r = np.sqrt(b2 + step * np.arange(n))
+    write_pot_table2(os.path.join(dirname, "phi.pt"), [b2], [e2], [step], [phi(r)])
+    write_pot_table2(os.path.join(dirname, "rho.pt"), [b2], [e2], [step], [rho(r)])
+    ps = rho_max / (n - 1)
+    write_pot_table2(os.path.join(dirname, "F.pt"), [0.0], [rho_max], [ps], [emb(ps * np.arange(n))])

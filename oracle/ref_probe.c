@@ -140,7 +140,7 @@ static void probe_dump(int step)
   }
 
   /* inner cells, in the order of the reference's `cells` list */
-  for (k = 0; k < ncells; k++) { wi(f, (int) cells[k]); ninner += CELLPTR(k)->n; }
+  for (k = 0; k < ncells; k++) { wi(f, (int) (CELLPTR(k) - cell_array)); ninner += CELLPTR(k)->n; }
   wi(f, ninner);
   for (k = 0; k < ncells; k++) {
     cell *p = CELLPTR(k);
