@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py -- MD-steps/s of the device-resident force(+TTM) loop on MI355X.
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`
+prints ONE JSON line on rank 0.  A "step" is one full MD step of the hot path
+(calc_forces [+ calc_ttm] + move_atoms + check_nblist, list rebuilds included)
+on a synthetic FCC-Al block with the synthetic tabulated EAM of SURVEY.md
+Appendix B, state resident in HBM.  N>1: one rank per GPU, each rank owns an
+equal block of atoms (weak scaling), launched by torch.distributed.run.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--box", type=int, nargs=3, default=[136, 136, 136],
+                    help="FCC unit cells per direction PER GPU (136^3*4 = 10 061 824 atoms)")
+    ap.add_argument("--temp", type=float, default=0.0258)
+    ap.add_argument("--no-ttm", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-box", type=int, default=24, help="unit cells per direction of the CPU sample")
+    ap.add_argument("--cpu-steps", type=int, default=40)
+    return ap.parse_args()
+
+
+def build_system(args, rank, world, device):
+    from imd_amd import lattice, potential
+    from imd_amd.system import GpuSystem, global_cell_dim
+    a = 4.05
+    box = lattice.fcc_box(args.box, a)
+    pair, rho, emb, r2cut = potential.synthetic_eam_tables()
+    nbl_margin = 0.5
+    cellsz = (np.sqrt(r2cut) + nbl_margin) ** 2
+    ttm = not args.no_ttm
+    fd_ext = (2, 2, 2)
+    gdim = global_cell_dim(box, cellsz, fd_ext if ttm else (1, 1, 1))
+    cell_dim = tuple(g + 2 for g in gdim)
+    sysm = GpuSystem(box, (1, 1, 1), cell_dim, 1, cellsz, nbl_margin, 0.1, device=device,
+                     count_ttm_neighbours=ttm)
+    sysm.upload_tables(pair, rho, emb)
+    pos = lattice.fcc_positions(args.box, a)
+    mom = lattice.maxwell_momenta(len(pos), 26.9815, args.temp, seed=12345 + rank)
+    sysm.upload_atoms(pos, mom, 26.9815)
+    if ttm:
+        from imd_amd import ttm as ttm_mod
+        ttm_mod.attach_default(sysm, fd_ext=fd_ext, diff_substeps=100, fd_min_atoms=5)
+    return sysm, len(pos), gdim
+
+
+def cpu_baseline(args):
+    """The REAL reference binary (oracle/_ref, built here from /root/reference and
+    shipped to the GPU box as a binary) on a bounded sample, 1 core; falls back to
+    the oracle port when the binary is absent."""
+    from imd_amd import potential
+    exe = os.path.join(ROOT, "oracle", "_ref", "imd_eam_nve_nbl")
+    nb, steps = args.cpu_box, args.cpu_steps
+    natoms = 4 * nb ** 3
+    if os.path.exists(exe):
+        with tempfile.TemporaryDirectory() as d:
+            potential.write_synthetic_eam_files(d)
+            open(os.path.join(d, "b.param"), "w").write(
+                "coordname _fcc\noutfiles out\nensemble nve\nmaxsteps %d\ntimestep 0.1\nntypes 1\ntotal_types 1\n"
+                "masses 26.9815\ntypes 0\nbox_param %d %d %d\nbox_unit 4.05\npbc_dirs 1 1 1\nstarttemp %g\nseed 12345\n"
+                "core_potential_file phi.pt\nembedding_energy_file F.pt\natomic_e-density_file rho.pt\n"
+                "eng_int 100000\ncheckpt_int 100000\nnbl_margin 0.5\nnbl_size 1.5\ncpu_dim 1 1 1\n"
+                % (steps, nb, nb, nb, args.temp))
+            env = dict(os.environ, IMD_PROBE_STEPS="-1")
+            t0 = time.time()
+            r = subprocess.run([exe, "-p", "b.param"], cwd=d, env=env, stdout=subprocess.PIPE,
+                               stderr=subprocess.STDOUT, text=True)
+            wall = time.time() - t0
+            per = None
+            for line in r.stdout.splitlines():
+                if "cpuseconds per step and atom" in line:
+                    per = float(line.split()[0])
+            if r.returncode == 0 and per:
+                return {"value": 1.0 / per, "unit": "atom-steps/s", "cores": 1, "kind": "reference",
+                        "sample": "reference binary imd_eam_nve_nbl (gcc -O2), %d atoms x %d steps, EAM NVE, "
+                                  "main loop incl. list rebuilds, %.1f s wall" % (natoms, steps + 1, wall)}
+    # port: the oracle restatement
+    from oracle import pyoracle as po
+    from imd_amd import lattice
+    pos = lattice.fcc_positions((nb, nb, nb))
+    box = lattice.fcc_box((nb, nb, nb))
+    pair, rho, emb, r2cut = potential.synthetic_eam_tables()
+    cellsz = (np.sqrt(r2cut) + 0.5) ** 2
+    gd = po.global_cell_dim(box, cellsz)
+    s = po.OracleSystem([g + 2 for g in gd], 48, 1, box, (1, 1, 1), cellsz, 0.5, 0.1)
+    for w, t in enumerate((pair, rho, emb)):
+        s.set_table(w, t.as_dict())
+    mom = lattice.maxwell_momenta(len(pos), 26.9815, args.temp)
+    s.fill_from_positions(pos, mom, 26.9815)
+    t0 = time.time()
+    for st in range(steps):
+        s.calc_forces(st); s.move_atoms_nve(); s.check_nblist()
+    wall = time.time() - t0
+    return {"value": natoms * steps / wall, "unit": "atom-steps/s", "cores": 1, "kind": "port",
+            "sample": "oracle C restatement, %d atoms x %d steps, EAM NVE" % (natoms, steps)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    sysm, natoms, gdim = build_system(args, rank, world, local)
+
+    def barrier():
+        sysm.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    step = 0
+    for _ in range(args.warmup):
+        sysm.md_step(step); step += 1
+    barrier()
+    sysm.profile(True); sysm.profile_reset()
+    nbl0 = sysm.get_sums()["nbl_count"]
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sysm.md_step(step); step += 1
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    sums = sysm.get_sums()
+    rebuilds = sums["nbl_count"] - nbl0
+    entries, maxn = sysm.nblist_stats()
+    M = entries / (2.0 * natoms)                       # half-list entries per atom
+    prof = {k: sysm.profile_get(k) for k in ("pass1", "pass2", "pass3", "ghosts", "nblist", "fix_cells", "integrate",
+                                             "reduce", "ttm_update_fd", "ttm_diff", "ttm_fillmesh")}
+    sysm.profile(False)
+    if rank == 0:
+        # dominant kernel: pass 1 (pair + rho).  Algorithmic bytes per atom = 72 + 4M
+        n1, ms1 = prof["pass1"]
+        bytes_p1 = natoms * (72.0 + 4.0 * M)
+        ach = bytes_p1 / (ms1 / max(n1, 1) * 1e-3) / 1e9 if n1 else 0.0
+        out = {
+            "metric": "MD-steps/sec (and atom-steps/sec) for 10M-atom EAM-Al+TTM at 1/2/4/8 GPU",
+            "value": args.steps / dt, "unit": "MD-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "atom_steps_per_s": natoms * world * args.steps / dt,
+            "config": {"workload": "FCC Al %dx%dx%d unit cells per GPU (%d atoms/GPU), synthetic tabulated EAM "
+                                   "(r_c 6.5 A), nbl_margin 0.5, dt 0.1, T0 %.4f eV, %s" %
+                                   (args.box[0], args.box[1], args.box[2], natoms, args.temp,
+                                    "NVE, no TTM" if args.no_ttm else "3D TTM fd_ext 2 2 2, diff_substeps 100"),
+                       "atoms_per_gpu": natoms, "cells": list(gdim), "half_list_entries_per_atom": M,
+                       "max_neighbours": maxn, "list_rebuilds_in_timed_region": rebuilds,
+                       "parallelism": "1 rank/GPU spatial decomposition" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": "k_pass1 (pair+rho)", "achieved": ach, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": bytes_p1, "avg_launch_ms": ms1 / max(n1, 1)},
+            "kernel_ms_per_step": {k: v[1] / args.steps for k, v in prof.items() if v[0]},
+            "energy": {"epot_per_atom": sums["tot_pot_energy"] / natoms, "ekin_per_atom": sums["tot_kin_energy"] / natoms},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args)
+            out["cpu_baseline"]["gpu_over_cpu_atom_steps"] = out["atom_steps_per_s"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+    sysm.close()
+
+
+if __name__ == "__main__":
+    main()

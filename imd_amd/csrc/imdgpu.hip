@@ -1,0 +1,1295 @@
+// imdgpu.hip -- MI355X (gfx950, CDNA4) kernels + C ABI for the neighbour-list
+// pair/EAM force path of IMD/lasMD.  Written for wave64 / 256 CUs / 160 KB LDS;
+// no CUDA compatibility paths.  Public ABI and reference cross-references:
+// include/imdgpu.h.  Design notes: DESIGN.md.
+//
+// Arithmetic: fp64 throughout.  The file is compiled with -ffp-contract=off so
+// that squared distances, cut-off tests and the table interpolation evaluate
+// with exactly the roundings of the reference CPU build (the reference tests
+// r2 = dx*dx+dy*dy+dz*dz, makros.h:361); only summation ORDER differs from the
+// reference (full-list gather instead of half-list scatter).
+#include "imdgpu_internal.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+// ---------------------------------------------------------------------------
+// errors / profiling helpers
+// ---------------------------------------------------------------------------
+int imdgpu_fail(imdgpu_ctx *c, const char *fmt, ...)
+{
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf;
+  return 1;
+}
+
+ProfScope::ProfScope(imdgpu_ctx *ctx, int id_) : c(ctx), id(id_)
+{
+  if (!c->prof_on) return;
+  auto get = [&]() {
+    hipEvent_t e;
+    if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); }
+    else (void) hipEventCreate(&e);
+    return e;
+  };
+  a = get(); b = get();
+  (void) hipEventRecord(a, c->stream);
+}
+ProfScope::~ProfScope()
+{
+  if (!a) return;
+  (void) hipEventRecord(b, c->stream);
+  c->ev_pending.push_back({a, b, id});
+  if (c->ev_pending.size() > 8192) imdgpu_prof_resolve(c);
+}
+void imdgpu_prof_resolve(imdgpu_ctx *c)
+{
+  for (auto &p : c->ev_pending) {
+    float ms = 0.f;
+    (void) hipEventSynchronize(p.b);
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { c->prof_ms[p.id] += ms; c->prof_n[p.id]++; }
+    c->ev_pool.push_back(p.a); c->ev_pool.push_back(p.b);
+  }
+  c->ev_pending.clear();
+}
+
+static const char *prof_names[PROF_COUNT] = {
+  "pass1", "pass2", "pass3", "ghosts", "nblist", "fix_cells", "integrate", "check", "reduce",
+  "ttm_update_fd", "ttm_diff", "ttm_fillmesh"};
+
+// ---------------------------------------------------------------------------
+// geometry passed to kernels by value
+// ---------------------------------------------------------------------------
+struct Geo {
+  double box[9], tbox[9];
+  int pbc[3], gdim[3], dim[3], my_coord[3];
+  int nx, ny, nz;                   // inner cells per direction (dim-2)
+};
+
+static Geo make_geo(const imdgpu_ctx *c)
+{
+  Geo g;
+  memcpy(g.box, c->box, sizeof(g.box)); memcpy(g.tbox, c->tbox, sizeof(g.tbox));
+  for (int d = 0; d < 3; d++) { g.pbc[d] = c->pbc[d]; g.gdim[d] = c->gdim[d]; g.dim[d] = c->dim[d]; g.my_coord[d] = c->my_coord[d]; }
+  g.nx = c->dim[0] - 2; g.ny = c->dim[1] - 2; g.nz = c->dim[2] - 2;
+  return g;
+}
+
+// device counters (ints) ------------------------------------------------------
+enum { CNT_MAXNBR = 0, CNT_IS_SHORT = 1, CNT_OUTSIDE = 2, CNT_NGHOST = 3, CNT_INVALID = 4, CNT_N = 16 };
+// d_sums slots -------------------------------------------------------------------
+enum { SUM_EPOT = 0, SUM_VIRIAL = 1, SUM_EKIN = 8, SUM_MAXDISP = 9, SUM_N = 16 };
+
+// ---------------------------------------------------------------------------
+// table interpolation (device).  Same expression tree as PAIR_INT2 /
+// VAL_FUNC2 / DERIV_FUNC2 of the reference (potaccess.h:323-354,465-495,
+// 591-621): clamp, truncate, three consecutive rows, quadratic form.
+// ---------------------------------------------------------------------------
+struct Tab3 { double p0, dv, d2v, chi, istep; };
+
+__device__ __forceinline__ Tab3 tab3(const double *t, int inc, int col, double begin, double end,
+                                     double istep, double arg, int &is_short)
+{
+  Tab3 r;
+  double a = (arg < end ? arg : end) - begin;
+  if (a < 0) { a = 0; is_short = 1; }
+  a = a * istep;
+  int k = (int) a;
+  r.chi = a - k;
+  const double *p = t + (size_t) k * inc + col;
+  double p1 = p[inc], p2 = p[2 * inc];
+  r.p0 = p[0];
+  r.dv = p1 - r.p0;
+  r.d2v = p2 - 2 * p1 + r.p0;
+  r.istep = istep;
+  return r;
+}
+__device__ __forceinline__ double tab_val(const Tab3 &r) { return r.p0 + r.chi * r.dv + 0.5 * r.chi * (r.chi - 1) * r.d2v; }
+__device__ __forceinline__ double tab_grad(const Tab3 &r) { return 2 * r.istep * (r.dv + (r.chi - 0.5) * r.d2v); }
+
+// wave64 / block reductions ----------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+  return v;
+}
+// sums `nv` values per thread over the block; result valid in thread 0.
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double *scratch /* >= NV*16 doubles */)
+{
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int q = 0; q < NV; q++) v[q] = wave_sum(v[q]);
+  __syncthreads();
+  if (lane == 0)
+#pragma unroll
+    for (int q = 0; q < NV; q++) scratch[q * 16 + w] = v[q];
+  __syncthreads();
+  if (threadIdx.x == 0)
+#pragma unroll
+    for (int q = 0; q < NV; q++) {
+      double s = 0;
+      for (int i = 0; i < nw; i++) s += scratch[q * 16 + i];
+      v[q] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// re-binning kernels  [fix_cells + do_boundaries]
+// ---------------------------------------------------------------------------
+// Wrap every local atom into the box direction by direction (do_boundaries,
+// imd_main_3d.c:2018-2110), then compute its global cell (cell_coord,
+// imd_geom_3d.c:1077-1097) and from it the rank of its inner cell on this GPU.
+__global__ void k_wrap_key(int n, double4 *pos, Geo g, int *keys, int *perm, int *counters)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double4 r = pos[i];
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    if (g.pbc[d] != 1) continue;
+    const double *t = g.tbox + 3 * d, *b = g.box + 3 * d;
+    double s = -floor(r.x * t[0] + r.y * t[1] + r.z * t[2]);
+    r.x += s * b[0]; r.y += s * b[1]; r.z += s * b[2];
+  }
+  pos[i] = r;
+  int c[3];
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    const double *t = g.tbox + 3 * d;
+    int q = (int) (g.gdim[d] * (r.x * t[0] + r.y * t[1] + r.z * t[2]));
+    if (q >= g.gdim[d]) q = g.gdim[d] - 1; else if (q < 0) q = 0;
+    q -= g.my_coord[d] * (g.dim[d] - 2);            // local_cell_coord - 1
+    if (q < 0 || q >= g.dim[d] - 2) {               // left this rank's domain
+      atomicAdd(&counters[CNT_OUTSIDE], 1);
+      q = q < 0 ? 0 : g.dim[d] - 3;
+    }
+    c[d] = q;
+  }
+  keys[i] = (c[0] * g.ny + c[1]) * g.nz + c[2];
+  perm[i] = i;
+}
+
+__global__ void k_gather_sorted(int n, int cap, const int *perm, const int *keys, const double4 *pos, double4 *pos2,
+                                const int *type, int *type2, const int *id, int *id2, const double *p, double *p2,
+                                const double *mass, double *mass2, int *acell, int *icnt)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int s = perm[i];
+  pos2[i] = pos[s]; type2[i] = type[s]; id2[i] = id[s]; mass2[i] = mass[s];
+  p2[i] = p[s]; p2[cap + i] = p[cap + s]; p2[2 * (size_t) cap + i] = p[2 * (size_t) cap + s];
+  int k = keys[i];
+  acell[i] = k;
+  atomicAdd(&icnt[k], 1);
+}
+
+// inner rank -> linear index in the ghost-including cell array
+__device__ __forceinline__ int inner_to_lin(int r, const Geo &g)
+{
+  int iz = r % g.nz, t = r / g.nz, iy = t % g.ny, ix = t / g.ny;
+  return ((ix + 1) * g.dim[1] + (iy + 1)) * g.dim[2] + (iz + 1);
+}
+
+__global__ void k_cells_inner(int ninner, Geo g, const int *icnt, const int *istart, int *cell_start, int *cell_cnt)
+{
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= ninner) return;
+  int lin = inner_to_lin(r, g);
+  cell_start[lin] = istart[r];
+  cell_cnt[lin] = icnt[r];
+}
+
+__global__ void k_ghost_cnt(int ng, const int *gsrc, const int *icnt, int *gcnt)
+{
+  int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= ng) return;
+  int s = gsrc[g];
+  gcnt[g] = s >= 0 ? icnt[s] : 0;
+}
+
+__global__ void k_ghost_map(int ng, int nlocal, const int *glin, const int *gsrc, const int *gshift, const int *gcnt,
+                            const int *gstart, const int *istart, int *cell_start, int *cell_cnt, int *ghost_src,
+                            int *ghost_code)
+{
+  int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= ng) return;
+  int n = gcnt[g], s = gstart[g], lin = glin[g];
+  cell_start[lin] = nlocal + s;
+  cell_cnt[lin] = n;
+  if (n == 0) return;
+  int base = istart[gsrc[g]], code = gshift[g];
+  for (int t = 0; t < n; t++) { ghost_src[s + t] = base + t; ghost_code[s + t] = code; }
+}
+
+// Ghost atom = periodic image of a local atom: position + box vectors, added in
+// the order of the reference's z, y, x stages (copy_cell, imd_comm_force_3d.c:
+// 726-755, shift vectors :247-266).  Also carries dF (w) and optionally type.
+__global__ void k_ghost_update(int nghost, int nlocal, const int *src, const int *code, double4 *pos, int *type,
+                               Geo g, int copy_type)
+{
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nghost) return;
+  int s = src[t], c = code[t];
+  double4 r = pos[s];
+  int sx = c % 3 - 1, sy = (c / 3) % 3 - 1, sz = c / 9 - 1;
+  if (sz) { r.x += sz * g.box[6]; r.y += sz * g.box[7]; r.z += sz * g.box[8]; }
+  if (sy) { r.x += sy * g.box[3]; r.y += sy * g.box[4]; r.z += sy * g.box[5]; }
+  if (sx) { r.x += sx * g.box[0]; r.y += sx * g.box[1]; r.z += sx * g.box[2]; }
+  pos[nlocal + t] = r;
+  if (copy_type) type[nlocal + t] = type[s];
+}
+
+// ---------------------------------------------------------------------------
+// Verlet list  [make_nblist]
+// ---------------------------------------------------------------------------
+// Full (symmetric) list, one thread per local atom, ELL-transposed so that the
+// force kernels read nbr[k*stride+i] coalesced.  Membership is the reference's
+// predicate r2 < cellsz on the unfused r2 (imd_forces_nbl.c:256-263); (i,j) and
+// (j,i) evaluate bit-identical r2, so the list is exactly the symmetrisation of
+// the reference's half list.  Also stores the reference positions (nbl_pos).
+__global__ void k_nbl_build(int nlocal, const double4 *pos, const int *acell, const int *cell_start,
+                            const int *cell_cnt, Geo g, double cellsz, int *nbr, size_t stride, int W, int *nbr_cnt,
+                            double *ref, int cap, int *counters)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int m = 0;
+  if (i < nlocal) {
+  double4 pi = pos[i];
+  ref[i] = pi.x; ref[cap + i] = pi.y; ref[2 * (size_t) cap + i] = pi.z;
+  int r = acell[i];
+  int iz = r % g.nz, t = r / g.nz, iy = t % g.ny, ix = t / g.ny;
+  for (int dx = -1; dx <= 1; dx++)
+    for (int dy = -1; dy <= 1; dy++)
+      for (int dz = -1; dz <= 1; dz++) {
+        int c = ((ix + 1 + dx) * g.dim[1] + (iy + 1 + dy)) * g.dim[2] + (iz + 1 + dz);
+        int s = cell_start[c], n = cell_cnt[c];
+        for (int j = s; j < s + n; j++) {
+          if (j == i) continue;
+          double4 pj = pos[j];
+          double ex = pj.x - pi.x, ey = pj.y - pi.y, ez = pj.z - pi.z;
+          double r2 = ex * ex + ey * ey + ez * ez;
+          if (r2 < cellsz) {
+            if (m < W) nbr[(size_t) m * stride + i] = j;
+            m++;
+          }
+        }
+      }
+  nbr_cnt[i] = m < W ? m : W;
+  }
+  int mw = m;                                   // one atomic per wave, not per atom
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { int v = __shfl_down(mw, o, 64); mw = v > mw ? v : mw; }
+  if ((threadIdx.x & 63) == 0) atomicMax(&counters[CNT_MAXNBR], mw);
+}
+
+// Reference-format half list (export only): same traversal as the reference
+// (14-cell stencil order of make_cell_lists, imd_geom_3d.c:907-975; j>i in the
+// own cell), numbering n = ref_cl_off[cell]+slot.
+__device__ __forceinline__ bool stencil_cell(int m, int ix, int iy, int iz, const Geo &g, int &c)
+{
+  // slot 0 = self, then (l,m,n) = (0,0,1),(0,1,-1..1),(1,-1..1,-1..1)
+  int l, mm, n;
+  if (m == 0) { l = 0; mm = 0; n = 0; }
+  else if (m == 1) { l = 0; mm = 0; n = 1; }
+  else if (m < 5) { l = 0; mm = 1; n = m - 3; }
+  else { int q = m - 5; l = 1; mm = q / 3 - 1; n = q % 3 - 1; }
+  int r[3] = {ix + 1 + l, iy + 1 + mm, iz + 1 + n};
+  for (int d = 0; d < 3; d++) {
+    int gl = r[d] - 1 + g.my_coord[d] * (g.dim[d] - 2);
+    if ((gl < 0 || gl > g.gdim[d] - 1) && g.pbc[d] != 1) return false;
+  }
+  c = (r[0] * g.dim[1] + r[1]) * g.dim[2] + r[2];
+  return true;
+}
+
+template <bool FILL>
+__global__ void k_export_half(int nlocal, const double4 *pos, const int *acell, const int *cell_start,
+                              const int *cell_cnt, Geo g, double cellsz, const int *ref_cl_off, int *tl_or_cnt,
+                              int *tb)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nlocal) return;
+  double4 pi = pos[i];
+  int r = acell[i];
+  int iz = r % g.nz, t = r / g.nz, iy = t % g.ny, ix = t / g.ny;
+  int m = 0, out = FILL ? tl_or_cnt[i] : 0;
+  for (int q = 0; q < 14; q++) {
+    int c;
+    if (!stencil_cell(q, ix, iy, iz, g, c)) continue;
+    int s = cell_start[c], n = cell_cnt[c];
+    int j0 = (q == 0) ? i + 1 : s;
+    for (int j = j0; j < s + n; j++) {
+      double4 pj = pos[j];
+      double ex = pj.x - pi.x, ey = pj.y - pi.y, ez = pj.z - pi.z;
+      double r2 = ex * ex + ey * ey + ez * ez;
+      if (r2 < cellsz) {
+        if (FILL) tb[out + m] = ref_cl_off[c] + (j - s);
+        m++;
+      }
+    }
+  }
+  if (!FILL) tl_or_cnt[i] = m;
+}
+
+// ---------------------------------------------------------------------------
+// force passes  [calc_forces]
+// ---------------------------------------------------------------------------
+struct ForceArgs {
+  int nlocal, ntypes, cap;
+  const double4 *pos;
+  const int *type;
+  const int *nbr, *nbr_cnt;
+  size_t stride;
+  TabPar pair, rho;
+  double *f, *epot, *rhoh;
+  int *numneighs;
+  double *partials;
+  int *counters;
+};
+
+__device__ __forceinline__ void lds_load_table(double *dst, const TabPar &t)
+{
+  int n = t.nrows * t.ncols;
+  for (int k = threadIdx.x; k < n; k += blockDim.x) dst[k] = t.tab[k];
+}
+
+// Pass 1: pair energy/force, host electron density, TTM neighbour count
+// (imd_forces_nbl.c:418-672), gather form: every local atom sums over its full
+// list, nothing is scattered, ghost atoms are read-only.
+template <bool PAIR, bool EAM, bool TTMN, bool NT1>
+__global__ __launch_bounds__(512) void k_pass1(ForceArgs a)
+{
+  extern __shared__ double lds[];
+  double *tp = lds;
+  double *tr = lds + (PAIR ? a.pair.nrows * a.pair.ncols : 0);
+  double *scratch = tr + (EAM ? a.rho.nrows * a.rho.ncols : 0);
+  if (PAIR) lds_load_table(tp, a.pair);
+  if (EAM) lds_load_table(tr, a.rho);
+  __syncthreads();
+
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int inc = a.ntypes * a.ntypes;
+  double sums[2] = {0.0, 0.0};             // pair energy, virial
+  int is_short = 0;
+  if (i < a.nlocal) {
+    const double4 pi = a.pos[i];
+    const int it = NT1 ? 0 : a.type[i];
+    const int cnt = a.nbr_cnt[i];
+    double fx = 0, fy = 0, fz = 0, ee = 0, rr = 0, vir = 0;
+    int nb = 0;
+    const int *np = a.nbr + i;
+    for (int k = 0; k < cnt; k++) {
+      const int j = np[(size_t) k * a.stride];
+      const double4 pj = a.pos[j];
+      const double dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;
+      const double r2 = dx * dx + dy * dy + dz * dz;
+      const int jt = NT1 ? 0 : a.type[j];
+      const int col = NT1 ? 0 : it * a.ntypes + jt;
+      if (TTMN) { if (r2 <= a.pair.end[0] && it == 0 && jt == 0) nb++; }
+      if (PAIR) {
+        if (r2 <= a.pair.end[col]) {
+          Tab3 q = tab3(tp, inc, col, a.pair.begin[col], a.pair.end[col], a.pair.invstep[col], r2, is_short);
+          double pot = tab_val(q), grad = tab_grad(q);
+          fx += dx * grad; fy += dy * grad; fz += dz * grad;
+          ee += 0.5 * pot;
+          vir -= 0.5 * (r2 * grad);
+        }
+      }
+      if (EAM) {
+        if (r2 < a.rho.end[col]) {
+          Tab3 q = tab3(tr, inc, col, a.rho.begin[col], a.rho.end[col], a.rho.invstep[col], r2, is_short);
+          rr += tab_val(q);
+        }
+      }
+    }
+    a.f[i] = fx; a.f[a.cap + i] = fy; a.f[2 * (size_t) a.cap + i] = fz;
+    a.epot[i] = ee;
+    if (EAM) a.rhoh[i] = rr;
+    if (TTMN) a.numneighs[i] = nb;
+    sums[0] = ee; sums[1] = vir;
+  }
+  block_sum<2>(sums, scratch);
+  if (threadIdx.x == 0) {
+    a.partials[(size_t) blockIdx.x * IMDGPU_NPART + 0] = sums[0];
+    a.partials[(size_t) blockIdx.x * IMDGPU_NPART + 1] = sums[1];
+  }
+  if (is_short) a.counters[CNT_IS_SHORT] = 1;
+}
+
+// Pass 2: embedding energy F(rho_i) and its derivative (stored as twice the
+// derivative exactly like EAM_DF, imd_forces_nbl.c:748-783; the factor is taken
+// out again in pass 3).  dF goes into pos[i].w so that pass 3 gathers it with
+// the position.
+__global__ void k_pass2(int nlocal, int ntypes, double4 *pos, const int *type, const double *rhoh, double *epot,
+                        TabPar emb, double *partials)
+{
+  __shared__ double scratch[16];
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double s[1] = {0.0};
+  if (i < nlocal) {
+    int col = ntypes == 1 ? 0 : type[i], dummy = 0;
+    Tab3 q = tab3(emb.tab, ntypes, col, emb.begin[col], emb.end[col], emb.invstep[col], rhoh[i], dummy);
+    double pot = tab_val(q);
+    pos[i].w = tab_grad(q);
+    epot[i] += pot;
+    s[0] = pot;
+  }
+  block_sum<1>(s, scratch);
+  if (threadIdx.x == 0) partials[(size_t) blockIdx.x * IMDGPU_NPART + 2] = s[0];
+}
+
+// Pass 3: EAM force, grad = 0.5*(dF_i*rho'_j + dF_j*rho'_i)
+// (imd_forces_nbl.c:789-985), gather form.
+template <bool NT1>
+__global__ __launch_bounds__(512) void k_pass3(ForceArgs a)
+{
+  extern __shared__ double lds[];
+  double *tr = lds;
+  double *scratch = tr + a.rho.nrows * a.rho.ncols;
+  lds_load_table(tr, a.rho);
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int inc = a.ntypes * a.ntypes;
+  double sums[1] = {0.0};
+  int is_short = 0;
+  if (i < a.nlocal) {
+    const double4 pi = a.pos[i];
+    const int it = NT1 ? 0 : a.type[i];
+    const int cnt = a.nbr_cnt[i];
+    double fx = 0, fy = 0, fz = 0, vir = 0;
+    const int *np = a.nbr + i;
+    for (int k = 0; k < cnt; k++) {
+      const int j = np[(size_t) k * a.stride];
+      const double4 pj = a.pos[j];
+      const double dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;
+      const double r2 = dx * dx + dy * dy + dz * dz;
+      const int jt = NT1 ? 0 : a.type[j];
+      const int col1 = NT1 ? 0 : jt * a.ntypes + it, col2 = NT1 ? 0 : it * a.ntypes + jt;
+      if (r2 < a.rho.end[col1] || r2 < a.rho.end[col2]) {
+        Tab3 q = tab3(tr, inc, col1, a.rho.begin[col1], a.rho.end[col1], a.rho.invstep[col1], r2, is_short);
+        double ri = tab_grad(q), rj = ri;
+        if (!NT1 && col1 != col2) {
+          Tab3 q2 = tab3(tr, inc, col2, a.rho.begin[col2], a.rho.end[col2], a.rho.invstep[col2], r2, is_short);
+          rj = tab_grad(q2);
+        }
+        double grad = 0.5 * (pi.w * rj + pj.w * ri);
+        double gx = dx * grad, gy = dy * grad, gz = dz * grad;
+        fx += gx; fy += gy; fz += gz;
+        vir -= 0.5 * (dx * gx + dy * gy + dz * gz);
+      }
+    }
+    a.f[i] += fx; a.f[a.cap + i] += fy; a.f[2 * (size_t) a.cap + i] += fz;
+    sums[0] = vir;
+  }
+  block_sum<1>(sums, scratch);
+  if (threadIdx.x == 0) a.partials[(size_t) blockIdx.x * IMDGPU_NPART + 3] = sums[0];
+  if (is_short) a.counters[CNT_IS_SHORT] = 1;
+}
+
+// Deterministic final reduction of the per-block partial sums
+// (tot_pot_energy, virial: imd_forces_nbl.c:319-328,:496,:521,:760,:943).
+__global__ void k_reduce_force_sums(int nb1, int nb2, const double *partials, double *sums)
+{
+  __shared__ double scratch[4 * 16];
+  double v[4] = {0, 0, 0, 0};
+  for (int b = threadIdx.x; b < nb1; b += blockDim.x) {
+    v[0] += partials[(size_t) b * IMDGPU_NPART + 0];
+    v[1] += partials[(size_t) b * IMDGPU_NPART + 1];
+    v[3] += partials[(size_t) b * IMDGPU_NPART + 3];
+  }
+  for (int b = threadIdx.x; b < nb2; b += blockDim.x) v[2] += partials[(size_t) b * IMDGPU_NPART + 2];
+  block_sum<4>(v, scratch);
+  if (threadIdx.x == 0) {
+    sums[SUM_EPOT] = v[0] + v[2];
+    sums[SUM_VIRIAL] = v[1] + v[3];
+    for (int q = 2; q < 8; q++) sums[q] = 0.0;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// integrator + list check  [move_atoms_nve, check_nblist]
+// ---------------------------------------------------------------------------
+template <bool CHECK>
+__global__ void k_move_nve(int n, int cap, double4 *pos, const int *type, double *p, double *f, const double *mass,
+                           const double *restr, int ntypes, double dt, const double *ref, double *partials)
+{
+  __shared__ double scratch[2 * 16];
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double s[2] = {0.0, 0.0};
+  if (i < n) {
+    const size_t c1 = cap, c2 = 2 * (size_t) cap;
+    int t = ntypes == 1 ? 0 : type[i];
+    double fx = f[i] * restr[3 * t], fy = f[c1 + i] * restr[3 * t + 1], fz = f[c2 + i] * restr[3 * t + 2];
+    double px = p[i], py = p[c1 + i], pz = p[c2 + i], m = mass[i];
+    double e1 = px * px + py * py + pz * pz;
+    f[i] = fx; f[c1 + i] = fy; f[c2 + i] = fz;
+    px += dt * fx; py += dt * fy; pz += dt * fz;
+    double e2 = px * px + py * py + pz * pz;
+    s[0] = (e1 + e2) / (4 * m);
+    double tmp = dt / m;
+    double4 r = pos[i];
+    r.x += tmp * px; r.y += tmp * py; r.z += tmp * pz;
+    pos[i] = r;
+    p[i] = px; p[c1 + i] = py; p[c2 + i] = pz;
+    if (CHECK) {
+      double dx = r.x - ref[i], dy = r.y - ref[c1 + i], dz = r.z - ref[c2 + i];
+      s[1] = dx * dx + dy * dy + dz * dz;
+    }
+  }
+  s[0] = wave_sum(s[0]);
+  if (CHECK) s[1] = wave_max(s[1]);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if (lane == 0) { scratch[w] = s[0]; scratch[16 + w] = s[1]; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double e = 0, mx = 0;
+    for (int q = 0; q < nw; q++) { e += scratch[q]; mx = fmax(mx, scratch[16 + q]); }
+    partials[(size_t) blockIdx.x * 2] = e;
+    partials[(size_t) blockIdx.x * 2 + 1] = mx;
+  }
+}
+
+__global__ void k_check_only(int n, int cap, const double4 *pos, const double *ref, double *partials)
+{
+  __shared__ double scratch[16];
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double v = 0.0;
+  if (i < n) {
+    double4 r = pos[i];
+    double dx = r.x - ref[i], dy = r.y - ref[cap + i], dz = r.z - ref[2 * (size_t) cap + i];
+    v = dx * dx + dy * dy + dz * dz;
+  }
+  v = wave_max(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if (lane == 0) scratch[w] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double mx = 0;
+    for (int q = 0; q < nw; q++) mx = fmax(mx, scratch[q]);
+    partials[(size_t) blockIdx.x * 2 + 1] = mx;
+    partials[(size_t) blockIdx.x * 2] = 0.0;
+  }
+}
+
+// sum of kinetic partials, max of displacement partials; decides list validity
+// (max > (0.5*margin)^2  =>  invalid; imd_forces_nbl.c:1091)
+__global__ void k_reduce_move(int nb, const double *partials, double *sums, double limit2, int *counters,
+                              int write_ekin)
+{
+  __shared__ double scratch[2 * 16];
+  double e = 0, mx = 0;
+  for (int b = threadIdx.x; b < nb; b += blockDim.x) { e += partials[(size_t) b * 2]; mx = fmax(mx, partials[(size_t) b * 2 + 1]); }
+  e = wave_sum(e); mx = wave_max(mx);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if (lane == 0) { scratch[w] = e; scratch[16 + w] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double E = 0, M = 0;
+    for (int q = 0; q < nw; q++) { E += scratch[q]; M = fmax(M, scratch[16 + q]); }
+    if (write_ekin) sums[SUM_EKIN] = E;
+    sums[SUM_MAXDISP] = M;
+    counters[CNT_INVALID] = (M > limit2) ? 1 : 0;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+static inline int nblk(long long n, int b) { return (int) ((n + b - 1) / b); }
+
+static void invert_box(const double b[9], double t[9])
+{
+  double cx[3] = {b[4] * b[8] - b[5] * b[7], b[5] * b[6] - b[3] * b[8], b[3] * b[7] - b[4] * b[6]};
+  double cy[3] = {b[7] * b[2] - b[8] * b[1], b[8] * b[0] - b[6] * b[2], b[6] * b[1] - b[7] * b[0]};
+  double cz[3] = {b[1] * b[5] - b[2] * b[4], b[2] * b[3] - b[0] * b[5], b[0] * b[4] - b[1] * b[3]};
+  double det = b[0] * cx[0] + b[1] * cx[1] + b[2] * cx[2];
+  for (int i = 0; i < 3; i++) { t[i] = cx[i] / det; t[3 + i] = cy[i] / det; t[6 + i] = cz[i] / det; }
+}
+
+extern "C" int imdgpu_create(imdgpu_ctx **out, int device)
+{
+  imdgpu_ctx *ctx = new imdgpu_ctx();
+  *out = ctx;
+  ctx->device = device;
+  HIPCHK(hipSetDevice(device));
+  HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  ctx->own_stream = true;
+  HIPCHK(hipMalloc((void **) &ctx->d_counters, CNT_N * sizeof(int)));
+  HIPCHK(hipMemset(ctx->d_counters, 0, CNT_N * sizeof(int)));
+  HIPCHK(hipHostMalloc((void **) &ctx->h_counters, CNT_N * sizeof(int)));
+  HIPCHK(hipMalloc((void **) &ctx->d_sums, SUM_N * sizeof(double)));
+  HIPCHK(hipMemset(ctx->d_sums, 0, SUM_N * sizeof(double)));
+  HIPCHK(hipHostMalloc((void **) &ctx->h_sums, SUM_N * sizeof(double)));
+  return 0;
+}
+
+extern "C" void imdgpu_destroy(imdgpu_ctx *c)
+{
+  if (!c) return;
+  (void) hipSetDevice(c->device);
+  (void) hipDeviceSynchronize();
+  imdgpu_prof_resolve(c);
+  for (auto e : c->ev_pool) (void) hipEventDestroy(e);
+  imdgpu_ttm_free(c);
+  void *ptrs[] = {c->pos, c->type, c->id, c->acell, c->p, c->f, c->ref, c->mass, c->epot, c->rhoh, c->numneighs,
+                  c->pos2, c->type2, c->id2, c->p2, c->mass2, c->nn2, c->keys, c->keys2, c->perm, c->perm2,
+                  c->cub_tmp, c->cell_start, c->cell_cnt, c->icnt, c->istart, c->gcell_lin, c->gcell_src,
+                  c->gcell_shift, c->gcnt, c->gstart, c->ghost_src, c->ghost_code, c->d_counters, c->nbr,
+                  c->nbr_cnt, c->partials, c->d_sums, c->pair.d_tab, c->rho.d_tab, c->emb.d_tab, c->d_restr};
+  for (void *p : ptrs) if (p) (void) hipFree(p);
+  if (c->h_counters) (void) hipHostFree(c->h_counters);
+  if (c->h_sums) (void) hipHostFree(c->h_sums);
+  if (c->own_stream && c->stream) (void) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" const char *imdgpu_last_error(const imdgpu_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+extern "C" int imdgpu_set_stream(imdgpu_ctx *ctx, void *s)
+{
+  if (ctx->own_stream && ctx->stream) { HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipStreamDestroy(ctx->stream)); }
+  ctx->stream = (hipStream_t) s;
+  ctx->own_stream = false;
+  return 0;
+}
+
+extern "C" int imdgpu_synchronize(imdgpu_ctx *ctx)
+{
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+extern "C" int imdgpu_set_geometry(imdgpu_ctx *ctx, const double box[9], const int pbc[3], const int cell_dim[3],
+                                   const int gdim[3], const int cpu_dim[3], const int my_coord[3])
+{
+  HIPCHK(hipSetDevice(ctx->device));
+  memcpy(ctx->box, box, sizeof(ctx->box));
+  invert_box(ctx->box, ctx->tbox);
+  for (int d = 0; d < 3; d++) {
+    ctx->pbc[d] = pbc[d]; ctx->dim[d] = cell_dim[d]; ctx->gdim[d] = gdim[d];
+    ctx->cpu_dim[d] = cpu_dim[d]; ctx->my_coord[d] = my_coord[d];
+    if (cell_dim[d] < 3) return imdgpu_fail(ctx, "cell_dim[%d]=%d: need at least one inner cell", d, cell_dim[d]);
+    if ((cell_dim[d] - 2) * cpu_dim[d] != gdim[d])
+      return imdgpu_fail(ctx, "cell_dim/global_cell_dim/cpu_dim inconsistent in direction %d", d);
+    if (cpu_dim[d] == 1 && pbc[d] == 1 && gdim[d] < 3)
+      return imdgpu_fail(ctx, "periodic direction %d needs >= 3 cells (has %d)", d, gdim[d]);
+  }
+  const int *D = ctx->dim;
+  ctx->nall_cells = D[0] * D[1] * D[2];
+  ctx->ninner_cells = (D[0] - 2) * (D[1] - 2) * (D[2] - 2);
+  ctx->nghost_cells = ctx->nall_cells - ctx->ninner_cells;
+  // static ghost-cell tables: source inner cell (periodic wrap on this rank) and shift code
+  std::vector<int> lin, src, sh;
+  const int ny = D[1] - 2, nz = D[2] - 2;
+  for (int i = 0; i < D[0]; i++)
+    for (int j = 0; j < D[1]; j++)
+      for (int k = 0; k < D[2]; k++) {
+        int c[3] = {i, j, k}, s[3], sc[3] = {0, 0, 0};
+        bool ghost = false, active = true;
+        for (int d = 0; d < 3; d++) {
+          s[d] = c[d];
+          if (c[d] == 0) { ghost = true; s[d] = D[d] - 2; sc[d] = -1; }
+          else if (c[d] == D[d] - 1) { ghost = true; s[d] = 1; sc[d] = +1; }
+          if (sc[d] != 0) {
+            if (cpu_dim[d] > 1) active = false;        // filled by the halo exchange, not by local images
+            else if (pbc[d] != 1) active = false;      // open boundary: nothing beyond it
+          }
+        }
+        if (!ghost) continue;
+        lin.push_back((i * D[1] + j) * D[2] + k);
+        src.push_back(active ? ((s[0] - 1) * ny + (s[1] - 1)) * nz + (s[2] - 1) : -1);
+        sh.push_back((sc[0] + 1) + 3 * (sc[1] + 1) + 9 * (sc[2] + 1));
+      }
+  int ng = ctx->nghost_cells;
+  if (dev_alloc(ctx, &ctx->gcell_lin, ng) || dev_alloc(ctx, &ctx->gcell_src, ng) || dev_alloc(ctx, &ctx->gcell_shift, ng) ||
+      dev_alloc(ctx, &ctx->gcnt, ng + 1) || dev_alloc(ctx, &ctx->gstart, ng + 1) ||
+      dev_alloc(ctx, &ctx->cell_start, ctx->nall_cells) || dev_alloc(ctx, &ctx->cell_cnt, ctx->nall_cells) ||
+      dev_alloc(ctx, &ctx->icnt, ctx->ninner_cells + 1) || dev_alloc(ctx, &ctx->istart, ctx->ninner_cells + 1))
+    return 1;
+  HIPCHK(hipMemcpy(ctx->gcell_lin, lin.data(), ng * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ctx->gcell_src, src.data(), ng * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ctx->gcell_shift, sh.data(), ng * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(ctx->cell_start, 0, ctx->nall_cells * sizeof(int)));
+  HIPCHK(hipMemset(ctx->cell_cnt, 0, ctx->nall_cells * sizeof(int)));
+  ctx->have_geometry = true;
+  ctx->have_valid_nbl = 0;
+  return 0;
+}
+
+extern "C" int imdgpu_set_params(imdgpu_ctx *ctx, int ntypes, double cellsz, double nbl_margin, double timestep,
+                                 int count_ttm)
+{
+  if (ntypes < 1 || ntypes * ntypes > IMDGPU_MAXCOL) return imdgpu_fail(ctx, "ntypes=%d unsupported (max 4)", ntypes);
+  ctx->ntypes = ntypes; ctx->cellsz = cellsz; ctx->nbl_margin = nbl_margin; ctx->timestep = timestep;
+  ctx->count_ttm = count_ttm;
+  std::vector<double> ones(3 * ntypes, 1.0);
+  if (dev_alloc(ctx, &ctx->d_restr, 3 * ntypes)) return 1;
+  HIPCHK(hipMemcpy(ctx->d_restr, ones.data(), ones.size() * sizeof(double), hipMemcpyHostToDevice));
+  ctx->have_valid_nbl = 0;
+  return 0;
+}
+
+extern "C" int imdgpu_set_restrictions(imdgpu_ctx *ctx, const double *r)
+{
+  if (!ctx->d_restr) return imdgpu_fail(ctx, "set_params first");
+  HIPCHK(hipMemcpy(ctx->d_restr, r, 3 * ctx->ntypes * sizeof(double), hipMemcpyHostToDevice));
+  return 0;
+}
+
+static int upload_table(imdgpu_ctx *ctx, DevTable &T, const imdgpu_pot_table *pt, const char *name)
+{
+  if (T.d_tab) { (void) hipFree(T.d_tab); T.d_tab = nullptr; }
+  T.present = false;
+  if (!pt) return 0;
+  if (pt->ncols < 1 || pt->ncols > IMDGPU_MAXCOL) return imdgpu_fail(ctx, "%s: ncols=%d unsupported", name, pt->ncols);
+  size_t n = (size_t) (pt->maxsteps + 2) * pt->ncols;
+  HIPCHK(hipMalloc((void **) &T.d_tab, n * sizeof(double)));
+  HIPCHK(hipMemcpy(T.d_tab, pt->table, n * sizeof(double), hipMemcpyHostToDevice));
+  T.par.tab = T.d_tab; T.par.ncols = pt->ncols; T.par.nrows = pt->maxsteps + 2;
+  for (int c = 0; c < pt->ncols; c++) { T.par.begin[c] = pt->begin[c]; T.par.end[c] = pt->end[c]; T.par.invstep[c] = pt->invstep[c]; }
+  T.present = true;
+  return 0;
+}
+
+extern "C" int imdgpu_upload_tables(imdgpu_ctx *ctx, const imdgpu_pot_table *pair, const imdgpu_pot_table *rho,
+                                    const imdgpu_pot_table *emb)
+{
+  HIPCHK(hipSetDevice(ctx->device));
+  if ((rho == nullptr) != (emb == nullptr)) return imdgpu_fail(ctx, "rho_h_tab and embed_pot must be given together");
+  if (upload_table(ctx, ctx->pair, pair, "pair_pot") || upload_table(ctx, ctx->rho, rho, "rho_h_tab") ||
+      upload_table(ctx, ctx->emb, emb, "embed_pot")) return 1;
+  int nn = ctx->ntypes * ctx->ntypes;
+  if (pair && pair->ncols != nn) return imdgpu_fail(ctx, "pair_pot has %d columns, expected ntypes^2=%d", pair->ncols, nn);
+  if (rho && rho->ncols != nn) return imdgpu_fail(ctx, "rho_h_tab has %d columns, expected %d", rho->ncols, nn);
+  if (emb && emb->ncols != ctx->ntypes) return imdgpu_fail(ctx, "embed_pot has %d columns, expected %d", emb->ncols, ctx->ntypes);
+  size_t lds = ((pair ? ctx->pair.par.nrows * pair->ncols : 0) + (rho ? ctx->rho.par.nrows * rho->ncols : 0) + 64) * sizeof(double);
+  if (lds > 150 * 1024) return imdgpu_fail(ctx, "potential tables need %zu B of LDS (limit 150 KB)", lds);
+  return 0;
+}
+
+static int ensure_atom_capacity(imdgpu_ctx *ctx, int nlocal, int ntot)
+{
+  if (nlocal > ctx->cap_local) {
+    int cap = (int) (nlocal * 1.1) + 1024;
+    cap = (cap + 63) / 64 * 64;
+    if (dev_alloc(ctx, &ctx->id, cap) || dev_alloc(ctx, &ctx->acell, cap) || dev_alloc(ctx, &ctx->p, 3 * (size_t) cap) ||
+        dev_alloc(ctx, &ctx->f, 3 * (size_t) cap) || dev_alloc(ctx, &ctx->ref, 3 * (size_t) cap) ||
+        dev_alloc(ctx, &ctx->mass, cap) || dev_alloc(ctx, &ctx->epot, cap) || dev_alloc(ctx, &ctx->rhoh, cap) ||
+        dev_alloc(ctx, &ctx->numneighs, cap) || dev_alloc(ctx, &ctx->id2, cap) || dev_alloc(ctx, &ctx->p2, 3 * (size_t) cap) ||
+        dev_alloc(ctx, &ctx->mass2, cap) || dev_alloc(ctx, &ctx->keys, cap) || dev_alloc(ctx, &ctx->keys2, cap) ||
+        dev_alloc(ctx, &ctx->perm, cap) || dev_alloc(ctx, &ctx->perm2, cap) || dev_alloc(ctx, &ctx->nbr_cnt, cap))
+      return 1;
+    HIPCHK(hipMemset(ctx->f, 0, 3 * (size_t) cap * sizeof(double)));
+    HIPCHK(hipMemset(ctx->epot, 0, cap * sizeof(double)));
+    HIPCHK(hipMemset(ctx->rhoh, 0, cap * sizeof(double)));
+    HIPCHK(hipMemset(ctx->numneighs, 0, cap * sizeof(int)));
+    HIPCHK(hipMemset(ctx->ref, 0, 3 * (size_t) cap * sizeof(double)));
+    ctx->cap_local = cap;
+    int nb = nblk(cap, 256) + 8;
+    if (dev_alloc(ctx, &ctx->partials, (size_t) nb * IMDGPU_NPART)) return 1;
+    ctx->npart_blocks = nb;
+    ctx->nbr_cap = 0;                        // list must be re-allocated for the new stride
+  }
+  if (ntot > ctx->cap_tot) {
+    int cap = (int) (ntot * 1.1) + 4096;
+    double4 *np = nullptr, *np2 = nullptr; int *nt = nullptr, *nt2 = nullptr;
+    HIPCHK(hipMalloc((void **) &np, (size_t) cap * sizeof(double4)));
+    HIPCHK(hipMalloc((void **) &np2, (size_t) cap * sizeof(double4)));
+    HIPCHK(hipMalloc((void **) &nt, (size_t) cap * sizeof(int)));
+    HIPCHK(hipMalloc((void **) &nt2, (size_t) cap * sizeof(int)));
+    if (ctx->pos && ctx->nlocal > 0) {
+      HIPCHK(hipMemcpy(np, ctx->pos, (size_t) ctx->nlocal * sizeof(double4), hipMemcpyDeviceToDevice));
+      HIPCHK(hipMemcpy(nt, ctx->type, (size_t) ctx->nlocal * sizeof(int), hipMemcpyDeviceToDevice));
+    }
+    if (ctx->pos) { (void) hipFree(ctx->pos); (void) hipFree(ctx->pos2); (void) hipFree(ctx->type); (void) hipFree(ctx->type2); }
+    ctx->pos = np; ctx->pos2 = np2; ctx->type = nt; ctx->type2 = nt2;
+    ctx->cap_tot = cap;
+  }
+  return 0;
+}
+
+// scan + ghost bookkeeping from per-inner-cell counts already in ctx->icnt
+static int build_cells_from_counts(imdgpu_ctx *ctx)
+{
+  Geo g = make_geo(ctx);
+  const int ni = ctx->ninner_cells, ng = ctx->nghost_cells;
+  size_t need = 0;
+  HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, ctx->icnt, ctx->istart, ni + 1, ctx->stream));
+  size_t need2 = 0;
+  HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, need2, ctx->gcnt, ctx->gstart, ng + 1, ctx->stream));
+  if (need2 > need) need = need2;
+  if (need > ctx->cub_tmp_bytes) {
+    if (ctx->cub_tmp) (void) hipFree(ctx->cub_tmp);
+    HIPCHK(hipMalloc(&ctx->cub_tmp, need * 2 + 1024));
+    ctx->cub_tmp_bytes = need * 2 + 1024;
+  }
+  size_t tb = ctx->cub_tmp_bytes;
+  HIPCHK(hipcub::DeviceScan::ExclusiveSum(ctx->cub_tmp, tb, ctx->icnt, ctx->istart, ni + 1, ctx->stream));
+  hipLaunchKernelGGL(k_cells_inner, dim3(nblk(ni, 256)), dim3(256), 0, ctx->stream, ni, g, ctx->icnt, ctx->istart,
+                     ctx->cell_start, ctx->cell_cnt);
+  hipLaunchKernelGGL(k_ghost_cnt, dim3(nblk(ng, 256)), dim3(256), 0, ctx->stream, ng, ctx->gcell_src, ctx->icnt, ctx->gcnt);
+  tb = ctx->cub_tmp_bytes;
+  HIPCHK(hipcub::DeviceScan::ExclusiveSum(ctx->cub_tmp, tb, ctx->gcnt, ctx->gstart, ng + 1, ctx->stream));
+  int nghost = 0;
+  HIPCHK(hipMemcpyAsync(&nghost, ctx->gstart + ng, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->nghost = nghost;
+  if (ensure_atom_capacity(ctx, ctx->nlocal, ctx->nlocal + nghost)) return 1;
+  if (nghost > ctx->cap_ghost) {
+    int cap = (int) (nghost * 1.1) + 4096;
+    if (dev_alloc(ctx, &ctx->ghost_src, cap) || dev_alloc(ctx, &ctx->ghost_code, cap)) return 1;
+    ctx->cap_ghost = cap;
+  }
+  hipLaunchKernelGGL(k_ghost_map, dim3(nblk(ng, 256)), dim3(256), 0, ctx->stream, ng, ctx->nlocal, ctx->gcell_lin,
+                     ctx->gcell_src, ctx->gcell_shift, ctx->gcnt, ctx->gstart, ctx->istart, ctx->cell_start,
+                     ctx->cell_cnt, ctx->ghost_src, ctx->ghost_code);
+  if (nghost > 0)
+    hipLaunchKernelGGL(k_ghost_update, dim3(nblk(nghost, 256)), dim3(256), 0, ctx->stream, nghost, ctx->nlocal,
+                       ctx->ghost_src, ctx->ghost_code, ctx->pos, ctx->type, g, 1);
+  HIPCHK(hipGetLastError());
+  ctx->have_valid_nbl = 0;
+  ctx->need_fix_cells = 0;
+  return 0;
+}
+
+static int upload_common(imdgpu_ctx *ctx, int n, const double *ort, const double *impuls, const double *masse,
+                         const int *sorte, const int *nummer)
+{
+  if (!ctx->have_geometry) return imdgpu_fail(ctx, "imdgpu_set_geometry must be called first");
+  HIPCHK(hipSetDevice(ctx->device));
+  ctx->nlocal = 0;
+  if (ensure_atom_capacity(ctx, n, n)) return 1;
+  const int cap = ctx->cap_local;
+  std::vector<double4> hp(n);
+  std::vector<double> hm(3 * (size_t) n);
+  std::vector<int> ht(n), hid(n);
+  for (int i = 0; i < n; i++) {
+    hp[i] = make_double4(ort[3 * i], ort[3 * i + 1], ort[3 * i + 2], 0.0);
+    hm[i] = impuls ? impuls[3 * i] : 0.0;
+    hm[(size_t) n + i] = impuls ? impuls[3 * i + 1] : 0.0;
+    hm[2 * (size_t) n + i] = impuls ? impuls[3 * i + 2] : 0.0;
+    ht[i] = sorte ? sorte[i] : 0;
+    hid[i] = nummer ? nummer[i] : i;
+    if (ht[i] < 0 || ht[i] >= ctx->ntypes) return imdgpu_fail(ctx, "atom %d has type %d outside [0,%d)", i, ht[i], ctx->ntypes);
+  }
+  HIPCHK(hipMemcpy(ctx->pos, hp.data(), n * sizeof(double4), hipMemcpyHostToDevice));
+  for (int d = 0; d < 3; d++)
+    HIPCHK(hipMemcpy(ctx->p + (size_t) d * cap, hm.data() + (size_t) d * n, n * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ctx->mass, masse, n * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ctx->type, ht.data(), n * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ctx->id, hid.data(), n * sizeof(int), hipMemcpyHostToDevice));
+  ctx->nlocal = n;
+  return 0;
+}
+
+extern "C" int imdgpu_upload_cells(imdgpu_ctx *ctx, const int *cell_n, int natoms, const double *ort,
+                                   const double *impuls, const double *masse, const int *sorte, const int *nummer)
+{
+  if (upload_common(ctx, natoms, ort, impuls, masse, sorte, nummer)) return 1;
+  const int *D = ctx->dim;
+  std::vector<int> icnt(ctx->ninner_cells + 1, 0), acell(natoms);
+  int r = 0, at = 0;
+  for (int i = 1; i < D[0] - 1; i++)
+    for (int j = 1; j < D[1] - 1; j++)
+      for (int k = 1; k < D[2] - 1; k++) {
+        int n = cell_n[(i * D[1] + j) * D[2] + k];
+        if (n < 0 || at + n > natoms) return imdgpu_fail(ctx, "cell_n does not add up to natoms=%d", natoms);
+        icnt[r] = n;
+        for (int t = 0; t < n; t++) acell[at + t] = r;
+        at += n; r++;
+      }
+  if (at != natoms) return imdgpu_fail(ctx, "cell_n sums to %d, natoms=%d", at, natoms);
+  HIPCHK(hipMemcpy(ctx->icnt, icnt.data(), icnt.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ctx->acell, acell.data(), natoms * sizeof(int), hipMemcpyHostToDevice));
+  return build_cells_from_counts(ctx);
+}
+
+extern "C" int imdgpu_upload_atoms(imdgpu_ctx *ctx, int natoms, const double *ort, const double *impuls,
+                                   const double *masse, const int *sorte, const int *nummer)
+{
+  if (upload_common(ctx, natoms, ort, impuls, masse, sorte, nummer)) return 1;
+  return imdgpu_fix_cells(ctx);
+}
+
+extern "C" int imdgpu_num_atoms(imdgpu_ctx *ctx, int *nlocal, int *nghost)
+{
+  if (nlocal) *nlocal = ctx->nlocal;
+  if (nghost) *nghost = ctx->nghost;
+  return 0;
+}
+
+extern "C" int imdgpu_fix_cells(imdgpu_ctx *ctx)
+{
+  HIPCHK(hipSetDevice(ctx->device));
+  const int n = ctx->nlocal, cap = ctx->cap_local;
+  if (n == 0) return imdgpu_fail(ctx, "no atoms uploaded");
+  Geo g = make_geo(ctx);
+  {
+    ProfScope ps(ctx, PROF_FIXCELLS);
+    HIPCHK(hipMemsetAsync(ctx->d_counters + CNT_OUTSIDE, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_wrap_key, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, n, ctx->pos, g, ctx->keys, ctx->perm,
+                       ctx->d_counters);
+    int bits = 1;
+    while ((1 << bits) < ctx->ninner_cells) bits++;
+    size_t need = 0;
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, need, ctx->keys, ctx->keys2, ctx->perm, ctx->perm2, n, 0, bits, ctx->stream));
+    if (need > ctx->cub_tmp_bytes) {
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      if (ctx->cub_tmp) (void) hipFree(ctx->cub_tmp);
+      HIPCHK(hipMalloc(&ctx->cub_tmp, need + 1024));
+      ctx->cub_tmp_bytes = need + 1024;
+    }
+    size_t tb = ctx->cub_tmp_bytes;
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cub_tmp, tb, ctx->keys, ctx->keys2, ctx->perm, ctx->perm2, n, 0, bits, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->icnt, 0, (ctx->ninner_cells + 1) * sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_gather_sorted, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, n, cap, ctx->perm2, ctx->keys2,
+                       ctx->pos, ctx->pos2, ctx->type, ctx->type2, ctx->id, ctx->id2, ctx->p, ctx->p2, ctx->mass,
+                       ctx->mass2, ctx->acell, ctx->icnt);
+    std::swap(ctx->pos, ctx->pos2); std::swap(ctx->type, ctx->type2); std::swap(ctx->id, ctx->id2);
+    std::swap(ctx->p, ctx->p2); std::swap(ctx->mass, ctx->mass2);
+  }
+  if (build_cells_from_counts(ctx)) return 1;
+  HIPCHK(hipMemcpy(ctx->h_counters, ctx->d_counters, CNT_N * sizeof(int), hipMemcpyDeviceToHost));
+  if (ctx->h_counters[CNT_OUTSIDE] > 0 && (ctx->cpu_dim[0] * ctx->cpu_dim[1] * ctx->cpu_dim[2] > 1))
+    return imdgpu_fail(ctx, "%d atoms left this rank's domain: migrate them with the halo layer before fix_cells",
+                       ctx->h_counters[CNT_OUTSIDE]);
+  return 0;
+}
+
+extern "C" int imdgpu_fill_ghosts(imdgpu_ctx *ctx)
+{
+  if (ctx->nghost <= 0) return 0;
+  ProfScope ps(ctx, PROF_GHOSTS);
+  Geo g = make_geo(ctx);
+  hipLaunchKernelGGL(k_ghost_update, dim3(nblk(ctx->nghost, 256)), dim3(256), 0, ctx->stream, ctx->nghost, ctx->nlocal,
+                     ctx->ghost_src, ctx->ghost_code, ctx->pos, ctx->type, g, 0);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int imdgpu_make_nblist(imdgpu_ctx *ctx)
+{
+  HIPCHK(hipSetDevice(ctx->device));
+  const int n = ctx->nlocal;
+  if (n == 0) return imdgpu_fail(ctx, "no atoms uploaded");
+  if (ctx->cellsz <= 0) return imdgpu_fail(ctx, "cellsz not set");
+  Geo g = make_geo(ctx);
+  if (imdgpu_fill_ghosts(ctx)) return 1;
+  size_t stride = (size_t) ctx->cap_local;
+  if (ctx->W == 0) ctx->W = 96;
+  for (int attempt = 0; attempt < 3; attempt++) {
+    if (ctx->nbr_cap < (size_t) ctx->W * stride) {
+      if (dev_alloc(ctx, &ctx->nbr, (size_t) ctx->W * stride)) return 1;
+      ctx->nbr_cap = (size_t) ctx->W * stride;
+    }
+    ctx->stride = stride;
+    {
+      ProfScope ps(ctx, PROF_NBLIST);
+      HIPCHK(hipMemsetAsync(ctx->d_counters + CNT_MAXNBR, 0, sizeof(int), ctx->stream));
+      hipLaunchKernelGGL(k_nbl_build, dim3(nblk(n, 128)), dim3(128), 0, ctx->stream, n, ctx->pos, ctx->acell,
+                         ctx->cell_start, ctx->cell_cnt, g, ctx->cellsz, ctx->nbr, stride, ctx->W, ctx->nbr_cnt, ctx->ref,
+                         ctx->cap_local, ctx->d_counters);
+    }
+    HIPCHK(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, CNT_N * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    int mx = ctx->h_counters[CNT_MAXNBR];
+    if (mx <= ctx->W) {
+      ctx->have_valid_nbl = 1;
+      ctx->nbl_count++;
+      HIPCHK(hipMemsetAsync(ctx->d_counters + CNT_INVALID, 0, sizeof(int), ctx->stream));
+      return 0;
+    }
+    ctx->W = (int) (mx * 1.15) + 8;             // "neighbor table full": grow and rebuild
+    ctx->nbr_cap = 0;
+  }
+  return imdgpu_fail(ctx, "neighbor table full");
+}
+
+extern "C" int imdgpu_nblist_stats(imdgpu_ctx *ctx, long long *entries, int *maxn)
+{
+  std::vector<int> c(ctx->nlocal);
+  HIPCHK(hipMemcpy(c.data(), ctx->nbr_cnt, ctx->nlocal * sizeof(int), hipMemcpyDeviceToHost));
+  long long s = 0; int m = 0;
+  for (int v : c) { s += v; if (v > m) m = v; }
+  if (entries) *entries = s;
+  if (maxn) *maxn = m;
+  return 0;
+}
+
+extern "C" int imdgpu_check_nblist(imdgpu_ctx *ctx, int *valid)
+{
+  HIPCHK(hipSetDevice(ctx->device));
+  const int n = ctx->nlocal, nb = nblk(n, 256);
+  double h = 0.5 * ctx->nbl_margin;
+  {
+    ProfScope ps(ctx, PROF_CHECK);
+    hipLaunchKernelGGL(k_check_only, dim3(nb), dim3(256), 0, ctx->stream, n, ctx->cap_local, ctx->pos, ctx->ref, ctx->partials);
+    hipLaunchKernelGGL(k_reduce_move, dim3(1), dim3(1024), 0, ctx->stream, nb, ctx->partials, ctx->d_sums, h * h,
+                       ctx->d_counters, 0);
+  }
+  HIPCHK(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, CNT_N * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (ctx->h_counters[CNT_INVALID]) { ctx->have_valid_nbl = 0; ctx->need_fix_cells = 1; }
+  if (valid) *valid = ctx->have_valid_nbl;
+  return 0;
+}
+
+// launches the three passes; assumes ghosts/list are current
+static int launch_forces(imdgpu_ctx *ctx)
+{
+  const int n = ctx->nlocal;
+  const bool PAIR = ctx->pair.present, EAM = ctx->rho.present, NT1 = ctx->ntypes == 1, TT = ctx->count_ttm != 0;
+  if (!PAIR && !EAM) return imdgpu_fail(ctx, "no potential tables uploaded");
+  if (TT && !PAIR) return imdgpu_fail(ctx, "TTM neighbour count needs pair_pot.end[0]");
+  ForceArgs a;
+  a.nlocal = n; a.ntypes = ctx->ntypes; a.cap = ctx->cap_local;
+  a.pos = ctx->pos; a.type = ctx->type; a.nbr = ctx->nbr; a.nbr_cnt = ctx->nbr_cnt; a.stride = ctx->stride;
+  a.pair = ctx->pair.par; a.rho = ctx->rho.par;
+  a.f = ctx->f; a.epot = ctx->epot; a.rhoh = ctx->rhoh; a.numneighs = ctx->numneighs;
+  a.partials = ctx->partials; a.counters = ctx->d_counters;
+  const int B = 512, nb = nblk(n, B);
+  if (nb > ctx->npart_blocks) return imdgpu_fail(ctx, "internal: partials too small");
+  size_t lds1 = ((PAIR ? a.pair.nrows * a.pair.ncols : 0) + (EAM ? a.rho.nrows * a.rho.ncols : 0) + 64) * sizeof(double);
+  HIPCHK(hipMemsetAsync(ctx->d_counters + CNT_IS_SHORT, 0, sizeof(int), ctx->stream));
+  {
+    ProfScope ps(ctx, PROF_PASS1);
+#define L1(P, E, T, N) hipLaunchKernelGGL((k_pass1<P, E, T, N>), dim3(nb), dim3(B), lds1, ctx->stream, a)
+#define L1T(P, E, T) do { if (NT1) L1(P, E, T, true); else L1(P, E, T, false); } while (0)
+#define L1E(P, E) do { if (TT) L1T(P, E, true); else L1T(P, E, false); } while (0)
+    if (PAIR && EAM) L1E(true, true); else if (PAIR) L1E(true, false); else L1E(false, true);
+#undef L1E
+#undef L1T
+#undef L1
+  }
+  int nb2 = 0;
+  if (EAM) {
+    nb2 = nblk(n, 256);
+    {
+      ProfScope ps(ctx, PROF_PASS2);
+      hipLaunchKernelGGL(k_pass2, dim3(nb2), dim3(256), 0, ctx->stream, n, ctx->ntypes, ctx->pos, ctx->type, ctx->rhoh,
+                         ctx->epot, ctx->emb.par, ctx->partials);
+    }
+    if (imdgpu_fill_ghosts(ctx)) return 1;            // dF of the images  [send_cells(copy_dF), :786]
+    size_t lds3 = ((size_t) a.rho.nrows * a.rho.ncols + 64) * sizeof(double);
+    ProfScope ps(ctx, PROF_PASS3);
+    if (NT1) hipLaunchKernelGGL((k_pass3<true>), dim3(nb), dim3(B), lds3, ctx->stream, a);
+    else hipLaunchKernelGGL((k_pass3<false>), dim3(nb), dim3(B), lds3, ctx->stream, a);
+  }
+  {
+    ProfScope ps(ctx, PROF_REDUCE);
+    hipLaunchKernelGGL(k_reduce_force_sums, dim3(1), dim3(1024), 0, ctx->stream, nb, EAM ? nb2 : 0, ctx->partials, ctx->d_sums);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int zero_eam_partials(imdgpu_ctx *ctx)
+{
+  // slots 2 and 3 are only written by the EAM passes
+  HIPCHK(hipMemsetAsync(ctx->partials, 0, (size_t) ctx->npart_blocks * IMDGPU_NPART * sizeof(double), ctx->stream));
+  return 0;
+}
+
+extern "C" int imdgpu_calc_forces(imdgpu_ctx *ctx, int steps, double sums[8], int *is_short)
+{
+  (void) steps;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (!ctx->have_valid_nbl) {
+    if (ctx->need_fix_cells && imdgpu_fix_cells(ctx)) return 1;    // :300-308 (after an upload: arrangement as given)
+    if (imdgpu_make_nblist(ctx)) return 1;                         // :315
+  } else if (imdgpu_fill_ghosts(ctx)) return 1;                    // :311
+  if (!ctx->rho.present && zero_eam_partials(ctx)) return 1;
+  if (launch_forces(ctx)) return 1;
+  HIPCHK(hipMemcpyAsync(ctx->h_sums, ctx->d_sums, SUM_N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, CNT_N * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (sums) for (int q = 0; q < 8; q++) sums[q] = ctx->h_sums[q];
+  if (is_short) *is_short = ctx->h_counters[CNT_IS_SHORT];
+  return 0;
+}
+
+extern "C" int imdgpu_move_atoms_nve(imdgpu_ctx *ctx, double *ekin)
+{
+  HIPCHK(hipSetDevice(ctx->device));
+  const int n = ctx->nlocal, nb = nblk(n, 256);
+  double h = 0.5 * ctx->nbl_margin;
+  {
+    ProfScope ps(ctx, PROF_INTEGRATE);
+    hipLaunchKernelGGL((k_move_nve<false>), dim3(nb), dim3(256), 0, ctx->stream, n, ctx->cap_local, ctx->pos, ctx->type,
+                       ctx->p, ctx->f, ctx->mass, ctx->d_restr, ctx->ntypes, ctx->timestep, ctx->ref, ctx->partials);
+    hipLaunchKernelGGL(k_reduce_move, dim3(1), dim3(1024), 0, ctx->stream, nb, ctx->partials, ctx->d_sums, h * h + 1e300,
+                       ctx->d_counters, 1);
+  }
+  HIPCHK(hipMemcpyAsync(ctx->h_sums, ctx->d_sums, SUM_N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (ekin) *ekin = ctx->h_sums[SUM_EKIN];
+  return 0;
+}
+
+extern "C" int imdgpu_md_step(imdgpu_ctx *ctx, int steps)
+{
+  HIPCHK(hipSetDevice(ctx->device));
+  if (!ctx->have_valid_nbl) {
+    if (ctx->need_fix_cells && imdgpu_fix_cells(ctx)) return 1;
+    if (imdgpu_make_nblist(ctx)) return 1;
+  } else if (imdgpu_fill_ghosts(ctx)) return 1;
+  if (!ctx->rho.present && zero_eam_partials(ctx)) return 1;
+  if (launch_forces(ctx)) return 1;
+  if (ctx->ttm) { if (imdgpu_ttm_step_internal(ctx, steps)) return 1; }
+  else {
+    const int n = ctx->nlocal, nb = nblk(n, 256);
+    double h = 0.5 * ctx->nbl_margin;
+    ProfScope ps(ctx, PROF_INTEGRATE);
+    hipLaunchKernelGGL((k_move_nve<true>), dim3(nb), dim3(256), 0, ctx->stream, n, ctx->cap_local, ctx->pos, ctx->type,
+                       ctx->p, ctx->f, ctx->mass, ctx->d_restr, ctx->ntypes, ctx->timestep, ctx->ref, ctx->partials);
+    hipLaunchKernelGGL(k_reduce_move, dim3(1), dim3(1024), 0, ctx->stream, nb, ctx->partials, ctx->d_sums, h * h,
+                       ctx->d_counters, 1);
+  }
+  // the only per-step host round trip: one int that says whether the list survived
+  HIPCHK(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, CNT_N * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (ctx->h_counters[CNT_INVALID]) { ctx->have_valid_nbl = 0; ctx->need_fix_cells = 1; }
+  return 0;
+}
+
+extern "C" int imdgpu_get_sums(imdgpu_ctx *ctx, double sums[8], double *ekin, int *nbl_count)
+{
+  HIPCHK(hipMemcpy(ctx->h_sums, ctx->d_sums, SUM_N * sizeof(double), hipMemcpyDeviceToHost));
+  if (sums) for (int q = 0; q < 8; q++) sums[q] = ctx->h_sums[q];
+  if (ekin) *ekin = ctx->h_sums[SUM_EKIN];
+  if (nbl_count) *nbl_count = ctx->nbl_count;
+  return 0;
+}
+
+extern "C" int imdgpu_download_atoms(imdgpu_ctx *ctx, int *cell_n, double *ort, double *impuls, double *kraft,
+                                     double *pot_eng, double *eam_rho, double *eam_dF, int *numneighs, int *nummer,
+                                     int *sorte, double *nbl_pos)
+{
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const int n = ctx->nlocal, cap = ctx->cap_local;
+  if (cell_n) {
+    std::vector<int> cc(ctx->nall_cells);
+    HIPCHK(hipMemcpy(cc.data(), ctx->cell_cnt, cc.size() * sizeof(int), hipMemcpyDeviceToHost));
+    const int *D = ctx->dim;
+    for (int c = 0; c < ctx->nall_cells; c++) cell_n[c] = 0;
+    for (int i = 1; i < D[0] - 1; i++) for (int j = 1; j < D[1] - 1; j++) for (int k = 1; k < D[2] - 1; k++) {
+      int c = (i * D[1] + j) * D[2] + k; cell_n[c] = cc[c];
+    }
+  }
+  if (ort || eam_dF) {
+    std::vector<double4> hp(n);
+    HIPCHK(hipMemcpy(hp.data(), ctx->pos, n * sizeof(double4), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) {
+      if (ort) { ort[3 * i] = hp[i].x; ort[3 * i + 1] = hp[i].y; ort[3 * i + 2] = hp[i].z; }
+      if (eam_dF) eam_dF[i] = hp[i].w;
+    }
+  }
+  auto planes = [&](const double *dev, double *out) -> int {
+    std::vector<double> h(3 * (size_t) n);
+    for (int d = 0; d < 3; d++)
+      HIPCHK(hipMemcpy(h.data() + (size_t) d * n, dev + (size_t) d * cap, n * sizeof(double), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) for (int d = 0; d < 3; d++) out[3 * i + d] = h[(size_t) d * n + i];
+    return 0;
+  };
+  if (impuls && planes(ctx->p, impuls)) return 1;
+  if (kraft && planes(ctx->f, kraft)) return 1;
+  if (nbl_pos && planes(ctx->ref, nbl_pos)) return 1;
+  if (pot_eng) HIPCHK(hipMemcpy(pot_eng, ctx->epot, n * sizeof(double), hipMemcpyDeviceToHost));
+  if (eam_rho) HIPCHK(hipMemcpy(eam_rho, ctx->rhoh, n * sizeof(double), hipMemcpyDeviceToHost));
+  if (numneighs) HIPCHK(hipMemcpy(numneighs, ctx->numneighs, n * sizeof(int), hipMemcpyDeviceToHost));
+  if (nummer) HIPCHK(hipMemcpy(nummer, ctx->id, n * sizeof(int), hipMemcpyDeviceToHost));
+  if (sorte) HIPCHK(hipMemcpy(sorte, ctx->type, n * sizeof(int), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// Reference cl_off: prefix sum over ALL cells in linear order where a ghost cell
+// holds a copy of the inner cell it images, except the x=0 wall which the
+// reference's AR mode leaves empty (send_cells, imd_comm_force_3d.c:356-377).
+extern "C" int imdgpu_export_nblist(imdgpu_ctx *ctx, int *tl, int *tb, int *cl_off, int *ntb)
+{
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (ctx->cpu_dim[0] * ctx->cpu_dim[1] * ctx->cpu_dim[2] != 1)
+    return imdgpu_fail(ctx, "export_nblist: single-rank arrangements only");
+  const int n = ctx->nlocal, nall = ctx->nall_cells;
+  const int *D = ctx->dim;
+  std::vector<int> cc(nall), off(nall);
+  HIPCHK(hipMemcpy(cc.data(), ctx->cell_cnt, nall * sizeof(int), hipMemcpyDeviceToHost));
+  int at = 0;
+  for (int i = 0; i < D[0]; i++) for (int j = 0; j < D[1]; j++) for (int k = 0; k < D[2]; k++) {
+    int c = (i * D[1] + j) * D[2] + k;
+    int si = i == 0 ? D[0] - 2 : (i == D[0] - 1 ? 1 : i), sj = j == 0 ? D[1] - 2 : (j == D[1] - 1 ? 1 : j),
+        sk = k == 0 ? D[2] - 2 : (k == D[2] - 1 ? 1 : k);
+    int cnt = (i == 0) ? 0 : cc[(si * D[1] + sj) * D[2] + sk];
+    off[c] = at; at += cnt;
+  }
+  if (cl_off) memcpy(cl_off, off.data(), nall * sizeof(int));
+  int *d_off = nullptr, *d_tl = nullptr, *d_tb = nullptr;
+  Geo g = make_geo(ctx);
+  HIPCHK(hipMalloc((void **) &d_off, nall * sizeof(int)));
+  HIPCHK(hipMalloc((void **) &d_tl, (n + 1) * sizeof(int)));
+  HIPCHK(hipMemcpy(d_off, off.data(), nall * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(d_tl, 0, (n + 1) * sizeof(int)));
+  hipLaunchKernelGGL((k_export_half<false>), dim3(nblk(n, 128)), dim3(128), 0, ctx->stream, n, ctx->pos, ctx->acell,
+                     ctx->cell_start, ctx->cell_cnt, g, ctx->cellsz, d_off, d_tl, (int *) nullptr);
+  size_t need = 0;
+  HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, d_tl, d_tl, n + 1, ctx->stream));
+  void *tmp = nullptr;
+  HIPCHK(hipMalloc(&tmp, need + 16));
+  HIPCHK(hipcub::DeviceScan::ExclusiveSum(tmp, need, d_tl, d_tl, n + 1, ctx->stream));
+  int total = 0;
+  HIPCHK(hipMemcpyAsync(&total, d_tl + n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (ntb) *ntb = total;
+  if (tl) HIPCHK(hipMemcpy(tl, d_tl, (n + 1) * sizeof(int), hipMemcpyDeviceToHost));
+  if (tb) {
+    HIPCHK(hipMalloc((void **) &d_tb, (size_t) (total + 1) * sizeof(int)));
+    hipLaunchKernelGGL((k_export_half<true>), dim3(nblk(n, 128)), dim3(128), 0, ctx->stream, n, ctx->pos, ctx->acell,
+                       ctx->cell_start, ctx->cell_cnt, g, ctx->cellsz, d_off, d_tl, d_tb);
+    HIPCHK(hipMemcpy(tb, d_tb, (size_t) total * sizeof(int), hipMemcpyDeviceToHost));
+    (void) hipFree(d_tb);
+  }
+  (void) hipFree(tmp); (void) hipFree(d_off); (void) hipFree(d_tl);
+  return 0;
+}
+
+extern "C" int imdgpu_profile_enable(imdgpu_ctx *ctx, int on)
+{
+  if (!on) imdgpu_prof_resolve(ctx);
+  ctx->prof_on = on != 0;
+  return 0;
+}
+extern "C" int imdgpu_profile_reset(imdgpu_ctx *ctx)
+{
+  imdgpu_prof_resolve(ctx);
+  for (int i = 0; i < PROF_COUNT; i++) { ctx->prof_n[i] = 0; ctx->prof_ms[i] = 0; }
+  return 0;
+}
+extern "C" int imdgpu_profile_get(imdgpu_ctx *ctx, const char *name, long long *launches, double *ms)
+{
+  imdgpu_prof_resolve(ctx);
+  for (int i = 0; i < PROF_COUNT; i++)
+    if (!strcmp(name, prof_names[i])) {
+      if (launches) *launches = ctx->prof_n[i];
+      if (ms) *ms = ctx->prof_ms[i];
+      return 0;
+    }
+  return imdgpu_fail(ctx, "unknown profile name %s", name);
+}

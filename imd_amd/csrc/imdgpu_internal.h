@@ -1,0 +1,128 @@
+// imdgpu_internal.h -- context and helpers shared by the HIP translation units
+// of libimdgpu.so (gfx950 only).  Public ABI: include/imdgpu.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/imdgpu.h"
+
+#define IMDGPU_MAXCOL 16          // ntypes <= 4
+#define IMDGPU_NPART 4            // partial sums per block: e_pair, vir1, e_embed / vir3, spare
+
+struct TabPar {                   // one potential table as kernel argument
+  const double *tab;              // device, (maxsteps+2)*ncols
+  int ncols, nrows;               // nrows = maxsteps+2
+  double begin[IMDGPU_MAXCOL], end[IMDGPU_MAXCOL], invstep[IMDGPU_MAXCOL];
+};
+
+struct DevTable {
+  double *d_tab = nullptr;
+  TabPar par{};
+  bool present = false;
+};
+
+enum ProfId {
+  PROF_PASS1 = 0, PROF_PASS2, PROF_PASS3, PROF_GHOSTS, PROF_NBLIST, PROF_FIXCELLS,
+  PROF_INTEGRATE, PROF_CHECK, PROF_REDUCE, PROF_TTM_UPDATE, PROF_TTM_DIFF,
+  PROF_TTM_FILL, PROF_COUNT
+};
+
+struct ProfPending { hipEvent_t a, b; int id; };
+
+struct imdgpu_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+
+  // geometry -------------------------------------------------------------
+  double box[9]{}, tbox[9]{};
+  int pbc[3]{1, 1, 1}, dim[3]{}, gdim[3]{}, cpu_dim[3]{1, 1, 1}, my_coord[3]{};
+  int nall_cells = 0, ninner_cells = 0, nghost_cells = 0;
+  bool have_geometry = false;
+
+  // parameters -------------------------------------------------------------
+  int ntypes = 1, count_ttm = 0;
+  double cellsz = 0, nbl_margin = 0, timestep = 0;
+  DevTable pair, rho, emb;
+  double *d_restr = nullptr;      // ntypes*3
+
+  // atoms (device).  local atoms [0,nlocal) sorted by inner-cell rank, ghost
+  // atoms [nlocal,ntot) grouped by ghost cell in linear cell order ----------
+  int nlocal = 0, nghost = 0, cap_local = 0, cap_tot = 0;
+  double4 *pos = nullptr;         // x,y,z,dF   [cap_tot]
+  int *type = nullptr;            // [cap_tot]
+  int *id = nullptr;              // nummer [cap_local]
+  int *acell = nullptr;           // inner-cell rank of each local atom [cap_local]
+  double *p = nullptr;            // momenta 3 planes [3*cap_local]
+  double *f = nullptr;            // forces  3 planes
+  double *ref = nullptr;          // nbl_pos 3 planes
+  double *mass = nullptr, *epot = nullptr, *rhoh = nullptr;
+  int *numneighs = nullptr;
+  // double buffers for re-binning
+  double4 *pos2 = nullptr; int *type2 = nullptr, *id2 = nullptr; double *p2 = nullptr, *mass2 = nullptr;
+  int *nn2 = nullptr;
+  int *keys = nullptr, *keys2 = nullptr, *perm = nullptr, *perm2 = nullptr;
+  void *cub_tmp = nullptr; size_t cub_tmp_bytes = 0;
+
+  // cells -----------------------------------------------------------------
+  int *cell_start = nullptr, *cell_cnt = nullptr;   // [nall_cells], linear (ghost incl.) index
+  int *icnt = nullptr, *istart = nullptr;           // [ninner_cells+1], inner rank order
+  int *gcell_lin = nullptr, *gcell_src = nullptr, *gcell_shift = nullptr;  // [nghost_cells] static
+  int *gcnt = nullptr, *gstart = nullptr;           // [nghost_cells+1]
+  int *ghost_src = nullptr, *ghost_code = nullptr;  // [cap ghost]
+  int cap_ghost = 0;
+  int *d_counters = nullptr;                        // misc device ints (see kernels)
+  int *h_counters = nullptr;                        // pinned mirror
+
+  // neighbour list (full, ELL transposed: nbr[k*stride+i]) -------------------
+  int *nbr = nullptr, *nbr_cnt = nullptr;
+  int W = 0; size_t stride = 0; size_t nbr_cap = 0;
+  int have_valid_nbl = 0, nbl_count = 0, need_fix_cells = 0;
+
+  // reductions -----------------------------------------------------------------
+  double *partials = nullptr; int npart_blocks = 0;
+  double *d_sums = nullptr;        // [16]: 0..7 force sums, 8 ekin, 9 maxdisp2 bits
+  double *h_sums = nullptr;        // pinned
+
+  // profiling ------------------------------------------------------------------
+  bool prof_on = false;
+  std::vector<hipEvent_t> ev_pool;
+  std::vector<ProfPending> ev_pending;
+  long long prof_n[PROF_COUNT]{};
+  double prof_ms[PROF_COUNT]{};
+
+  // TTM state lives in imdgpu_ttm.hip
+  struct TtmState *ttm = nullptr;
+};
+
+int imdgpu_fail(imdgpu_ctx *c, const char *fmt, ...);
+
+#define HIPCHK(call)                                                              \
+  do {                                                                            \
+    hipError_t e_ = (call);                                                       \
+    if (e_ != hipSuccess)                                                         \
+      return imdgpu_fail(ctx, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+struct ProfScope {
+  imdgpu_ctx *c; int id; hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(imdgpu_ctx *ctx, int id_);
+  ~ProfScope();
+};
+void imdgpu_prof_resolve(imdgpu_ctx *c);
+
+template <typename T>
+static inline int dev_alloc(imdgpu_ctx *ctx, T **p, size_t n)
+{
+  if (*p) { (void) hipFree(*p); *p = nullptr; }
+  HIPCHK(hipMalloc((void **) p, (n ? n : 1) * sizeof(T)));
+  return 0;
+}
+
+// TTM entry points called from imdgpu_md_step
+int imdgpu_ttm_step_internal(imdgpu_ctx *ctx, int steps);
+void imdgpu_ttm_free(imdgpu_ctx *ctx);

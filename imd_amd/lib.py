@@ -1,0 +1,88 @@
+"""ctypes binding of libimdgpu.so (C ABI: include/imdgpu.h).
+
+There is deliberately no CPU fallback: if the HIP library is missing or a call
+fails, an exception is raised (the product path never routes through oracle/).
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_CSRC, "libimdgpu.so")
+
+SYMBOLS = [
+    "imdgpu_create", "imdgpu_destroy", "imdgpu_last_error", "imdgpu_set_stream", "imdgpu_synchronize",
+    "imdgpu_set_geometry", "imdgpu_set_params", "imdgpu_upload_tables", "imdgpu_set_restrictions",
+    "imdgpu_upload_cells", "imdgpu_upload_atoms", "imdgpu_num_atoms", "imdgpu_download_atoms",
+    "imdgpu_fix_cells", "imdgpu_fill_ghosts", "imdgpu_make_nblist", "imdgpu_check_nblist",
+    "imdgpu_calc_forces", "imdgpu_move_atoms_nve", "imdgpu_md_step", "imdgpu_get_sums",
+    "imdgpu_export_nblist", "imdgpu_nblist_stats",
+    "imdgpu_profile_enable", "imdgpu_profile_reset", "imdgpu_profile_get",
+]
+
+
+class ImdGpuError(RuntimeError):
+    pass
+
+
+class PotTableC(C.Structure):
+    """imdgpu_pot_table == reference pot_table_t (types.h:537-549)."""
+    _fields_ = [("begin", C.POINTER(C.c_double)), ("end", C.POINTER(C.c_double)),
+                ("step", C.POINTER(C.c_double)), ("invstep", C.POINTER(C.c_double)),
+                ("len", C.POINTER(C.c_int)), ("ncols", C.c_int), ("maxsteps", C.c_int),
+                ("table", C.POINTER(C.c_double))]
+
+
+def build(force=False):
+    """Compile libimdgpu.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "imdgpu.h"))
+    if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs):
+        subprocess.check_call(["make", "-s", "-C", _CSRC, "libimdgpu.so"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImdGpuError("libimdgpu.so not built (%s): run __graft_entry__.build() / make -C imd_amd/csrc" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p
+    L.imdgpu_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.imdgpu_destroy.argtypes = [vp]
+    L.imdgpu_destroy.restype = None
+    L.imdgpu_last_error.argtypes = [vp]
+    L.imdgpu_last_error.restype = C.c_char_p
+    L.imdgpu_set_stream.argtypes = [vp, vp]
+    L.imdgpu_synchronize.argtypes = [vp]
+    L.imdgpu_set_geometry.argtypes = [vp, dp, ip, ip, ip, ip, ip]
+    L.imdgpu_set_params.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int]
+    L.imdgpu_upload_tables.argtypes = [vp, C.POINTER(PotTableC), C.POINTER(PotTableC), C.POINTER(PotTableC)]
+    L.imdgpu_set_restrictions.argtypes = [vp, dp]
+    L.imdgpu_upload_cells.argtypes = [vp, ip, C.c_int, dp, dp, dp, ip, ip]
+    L.imdgpu_upload_atoms.argtypes = [vp, C.c_int, dp, dp, dp, ip, ip]
+    L.imdgpu_num_atoms.argtypes = [vp, ip, ip]
+    L.imdgpu_download_atoms.argtypes = [vp, ip, dp, dp, dp, dp, dp, dp, ip, ip, ip, dp]
+    for f in ("imdgpu_fix_cells", "imdgpu_fill_ghosts", "imdgpu_make_nblist"):
+        getattr(L, f).argtypes = [vp]
+    L.imdgpu_check_nblist.argtypes = [vp, ip]
+    L.imdgpu_calc_forces.argtypes = [vp, C.c_int, dp, ip]
+    L.imdgpu_move_atoms_nve.argtypes = [vp, dp]
+    L.imdgpu_md_step.argtypes = [vp, C.c_int]
+    L.imdgpu_get_sums.argtypes = [vp, dp, dp, ip]
+    L.imdgpu_export_nblist.argtypes = [vp, ip, ip, ip, ip]
+    L.imdgpu_nblist_stats.argtypes = [vp, C.POINTER(C.c_longlong), ip]
+    L.imdgpu_profile_enable.argtypes = [vp, C.c_int]
+    L.imdgpu_profile_reset.argtypes = [vp]
+    L.imdgpu_profile_get.argtypes = [vp, C.c_char_p, C.POINTER(C.c_longlong), dp]
+    for s in SYMBOLS:
+        if s not in ("imdgpu_destroy", "imdgpu_last_error"):
+            getattr(L, s).restype = C.c_int
+    _lib = L
+    return L

@@ -1,0 +1,211 @@
+"""Host-side mirror of the reference's entry points for the force path.
+
+``GpuSystem`` exposes the reference's function names (calc_forces, make_nblist,
+check_nblist, fix_cells, move_atoms_nve; imd_forces_nbl.c, imd_integrate.c)
+with the reference's argument meaning, on top of the C ABI of libimdgpu.so.
+Errors raise ``ImdGpuError`` where the reference would call error().
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _lib
+from .lib import ImdGpuError, PotTableC
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def global_cell_dim(box, cellsz, cd=(1, 1, 1)):
+    """Cells per direction: floor(1/sqrt(cellsz/height)), rounded down to a
+    multiple of cd = cpu_dim[*fd_ext] (init_cells, imd_geom_3d.c:141-188)."""
+    b = np.asarray(box, dtype=np.float64).reshape(3, 3)
+    t = np.linalg.inv(b).T              # rows tbox_x, tbox_y, tbox_z
+    out = []
+    for d in range(3):
+        height = 1.0 / float(t[d] @ t[d])
+        g = int(1.0 / np.sqrt(cellsz / height))
+        if g % cd[d]:
+            g = (g // cd[d]) * cd[d]
+        out.append(g)
+    return tuple(out)
+
+
+class GpuSystem:
+    def __init__(self, box, pbc_dirs, cell_dim, ntypes, cellsz, nbl_margin, timestep, device=0,
+                 global_cell_dim=None, cpu_dim=(1, 1, 1), my_coord=(0, 0, 0), count_ttm_neighbours=False):
+        self.L = _lib.load()
+        h = C.c_void_p()
+        if self.L.imdgpu_create(C.byref(h), int(device)):
+            msg = self.L.imdgpu_last_error(h).decode() if h else "imdgpu_create failed"
+            raise ImdGpuError(msg)
+        self.h = h
+        self.box = np.ascontiguousarray(box, dtype=np.float64).reshape(9)
+        self.cell_dim = np.asarray(cell_dim, dtype=np.int32)
+        self.pbc = np.asarray(pbc_dirs, dtype=np.int32)
+        gd = np.asarray(global_cell_dim if global_cell_dim is not None
+                        else (self.cell_dim - 2) * np.asarray(cpu_dim), dtype=np.int32)
+        self.nallcells = int(np.prod(self.cell_dim))
+        self.ntypes = int(ntypes)
+        self._keep = []
+        self._ck(self.L.imdgpu_set_geometry(self.h, _dp(self.box), _ip(self.pbc), _ip(self.cell_dim), _ip(gd),
+                                            _ip(np.asarray(cpu_dim, dtype=np.int32)),
+                                            _ip(np.asarray(my_coord, dtype=np.int32))))
+        self._ck(self.L.imdgpu_set_params(self.h, int(ntypes), float(cellsz), float(nbl_margin), float(timestep),
+                                          1 if count_ttm_neighbours else 0))
+
+    # -- plumbing --------------------------------------------------------------
+    def _ck(self, rc):
+        if rc:
+            raise ImdGpuError(self.L.imdgpu_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.imdgpu_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _tab(self, t):
+        if t is None:
+            return None
+        d = t.as_dict() if hasattr(t, "as_dict") else t
+        arrs = {k: np.ascontiguousarray(d[k], dtype=np.float64) for k in ("begin", "end", "step", "invstep", "table")}
+        ln = np.ascontiguousarray(d["len"], dtype=np.int32)
+        self._keep.append((arrs, ln))
+        return PotTableC(_dp(arrs["begin"]), _dp(arrs["end"]), _dp(arrs["step"]), _dp(arrs["invstep"]), _ip(ln),
+                         int(d["ncols"]), int(d["maxsteps"]), _dp(arrs["table"]))
+
+    def upload_tables(self, pair_pot=None, rho_h_tab=None, embed_pot=None):
+        ts = [self._tab(t) for t in (pair_pot, rho_h_tab, embed_pot)]
+        ptr = [C.byref(t) if t is not None else None for t in ts]
+        self._ck(self.L.imdgpu_upload_tables(self.h, *ptr))
+
+    def set_stream(self, hip_stream):
+        self._ck(self.L.imdgpu_set_stream(self.h, C.c_void_p(int(hip_stream))))
+
+    def synchronize(self):
+        self._ck(self.L.imdgpu_synchronize(self.h))
+
+    # -- atoms -------------------------------------------------------------------
+    @staticmethod
+    def _atoms(ort, impuls, masse, sorte, nummer):
+        ort = np.ascontiguousarray(ort, dtype=np.float64).reshape(-1, 3)
+        n = len(ort)
+        impuls = np.zeros((n, 3)) if impuls is None else np.ascontiguousarray(impuls, dtype=np.float64).reshape(n, 3)
+        masse = np.ascontiguousarray(np.broadcast_to(np.asarray(masse, dtype=np.float64), (n,)))
+        sorte = np.zeros(n, np.int32) if sorte is None else np.ascontiguousarray(sorte, dtype=np.int32)
+        nummer = np.arange(n, dtype=np.int32) if nummer is None else np.ascontiguousarray(nummer, dtype=np.int32)
+        return n, ort, impuls, masse, sorte, nummer
+
+    def upload_cells(self, cell_n, ort, impuls=None, masse=1.0, sorte=None, nummer=None):
+        """Take the host's cell arrangement as is (cell ordered arrays)."""
+        n, ort, impuls, masse, sorte, nummer = self._atoms(ort, impuls, masse, sorte, nummer)
+        cn = np.ascontiguousarray(cell_n, dtype=np.int32)
+        if len(cn) != self.nallcells:
+            raise ImdGpuError("cell_n must have nallcells=%d entries" % self.nallcells)
+        self._ck(self.L.imdgpu_upload_cells(self.h, _ip(cn), n, _dp(ort), _dp(impuls), _dp(masse), _ip(sorte),
+                                            _ip(nummer)))
+
+    def upload_atoms(self, ort, impuls=None, masse=1.0, sorte=None, nummer=None):
+        n, ort, impuls, masse, sorte, nummer = self._atoms(ort, impuls, masse, sorte, nummer)
+        self._ck(self.L.imdgpu_upload_atoms(self.h, n, _dp(ort), _dp(impuls), _dp(masse), _ip(sorte), _ip(nummer)))
+
+    def num_atoms(self):
+        a, b = C.c_int(), C.c_int()
+        self._ck(self.L.imdgpu_num_atoms(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def download(self, fields=("ort", "impuls", "kraft", "pot_eng", "eam_rho", "eam_dF", "numneighs", "nummer",
+                               "sorte", "nbl_pos", "cell_n")):
+        n, _ = self.num_atoms()
+        out = {}
+        spec = [("cell_n", np.int32, (self.nallcells,)), ("ort", np.float64, (n, 3)), ("impuls", np.float64, (n, 3)),
+                ("kraft", np.float64, (n, 3)), ("pot_eng", np.float64, (n,)), ("eam_rho", np.float64, (n,)),
+                ("eam_dF", np.float64, (n,)), ("numneighs", np.int32, (n,)), ("nummer", np.int32, (n,)),
+                ("sorte", np.int32, (n,)), ("nbl_pos", np.float64, (n, 3))]
+        args = []
+        for name, dt, shp in spec:
+            if name in fields:
+                out[name] = np.zeros(shp, dtype=dt)
+                args.append(_ip(out[name]) if dt == np.int32 else _dp(out[name]))
+            else:
+                args.append(None)
+        self._ck(self.L.imdgpu_download_atoms(self.h, *args))
+        return out
+
+    # -- the reference's entry points ------------------------------------------
+    def fix_cells(self):
+        self._ck(self.L.imdgpu_fix_cells(self.h))
+
+    def send_cells(self):
+        self._ck(self.L.imdgpu_fill_ghosts(self.h))
+
+    def make_nblist(self):
+        self._ck(self.L.imdgpu_make_nblist(self.h))
+
+    def check_nblist(self):
+        v = C.c_int()
+        self._ck(self.L.imdgpu_check_nblist(self.h, C.byref(v)))
+        return bool(v.value)
+
+    def calc_forces(self, steps=0):
+        """Returns dict(tot_pot_energy, virial, is_short)."""
+        s = np.zeros(8)
+        sh = C.c_int()
+        self._ck(self.L.imdgpu_calc_forces(self.h, int(steps), _dp(s), C.byref(sh)))
+        return dict(tot_pot_energy=float(s[0]), virial=float(s[1]), is_short=int(sh.value))
+
+    def move_atoms_nve(self):
+        e = C.c_double()
+        self._ck(self.L.imdgpu_move_atoms_nve(self.h, C.byref(e)))
+        return e.value
+
+    def md_step(self, steps=0):
+        self._ck(self.L.imdgpu_md_step(self.h, int(steps)))
+
+    def get_sums(self):
+        s = np.zeros(8)
+        e = C.c_double()
+        c = C.c_int()
+        self._ck(self.L.imdgpu_get_sums(self.h, _dp(s), C.byref(e), C.byref(c)))
+        return dict(tot_pot_energy=float(s[0]), virial=float(s[1]), tot_kin_energy=e.value, nbl_count=c.value)
+
+    def export_nblist(self):
+        """(tl, tb, cl_off) in the reference's half-list format and numbering."""
+        n, _ = self.num_atoms()
+        ntb = C.c_int()
+        self._ck(self.L.imdgpu_export_nblist(self.h, None, None, None, C.byref(ntb)))
+        tl = np.zeros(n + 1, np.int32)
+        tb = np.zeros(max(ntb.value, 1), np.int32)
+        cl_off = np.zeros(self.nallcells, np.int32)
+        self._ck(self.L.imdgpu_export_nblist(self.h, _ip(tl), _ip(tb), _ip(cl_off), C.byref(ntb)))
+        return tl, tb[: ntb.value], cl_off
+
+    def nblist_stats(self):
+        e = C.c_longlong()
+        m = C.c_int()
+        self._ck(self.L.imdgpu_nblist_stats(self.h, C.byref(e), C.byref(m)))
+        return e.value, m.value
+
+    # -- profiling -----------------------------------------------------------------
+    def profile(self, on=True):
+        self._ck(self.L.imdgpu_profile_enable(self.h, 1 if on else 0))
+
+    def profile_reset(self):
+        self._ck(self.L.imdgpu_profile_reset(self.h))
+
+    def profile_get(self, name):
+        n = C.c_longlong()
+        ms = C.c_double()
+        self._ck(self.L.imdgpu_profile_get(self.h, name.encode(), C.byref(n), C.byref(ms)))
+        return n.value, ms.value

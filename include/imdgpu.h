@@ -1,0 +1,133 @@
+/*
+ * imdgpu.h -- C ABI of libimdgpu.so: MI355X (gfx950) implementation of the
+ * force + TTM inner loop of IMD/lasMD (fmqeisfeld/IMD).
+ *
+ * The reference has no plugin interface: its hot path is entered through
+ * link-time C symbols that work on global state.  Every
+ * entry point below names the reference function it replaces; the shim in
+ * imd_amd/host/imd_shim.c gives them the reference's own names and signatures
+ * (calc_forces(int), make_nblist(void), ...) so that the library can be linked
+ * in place of imd_forces_nbl.o / imd_ttm_3D.o.
+ *
+ * Conventions
+ *   - plain C types only; every call returns 0 on success, non-zero on error,
+ *     and imdgpu_last_error() returns the message (the reference calls error()
+ *     -> exit; a library must not).
+ *   - host arrays handed in/out are "cell ordered": atoms of the inner cells
+ *     concatenated in the order of the reference's `cells` list (x outer, z
+ *     inner; imd_geom_3d.c:898-900), which is also the numbering of the
+ *     reference's `tl` (imd_forces_nbl.c:36-41).  Coordinates are xyz
+ *     interleaved like cell.ort (types.h:189, makros.h:143).
+ *   - all floating point data is fp64 (reference `real` = double, types.h:31).
+ */
+#ifndef IMDGPU_H
+#define IMDGPU_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct imdgpu_ctx imdgpu_ctx;
+
+/* Same members, same order as the reference's pot_table_t (types.h:537-549,
+ * non-SPLINE build): a reference pot_table_t* may be passed as is. */
+typedef struct {
+  double *begin;      /* first argument value per column               */
+  double *end;        /* last argument value per column                */
+  double *step;
+  double *invstep;
+  int    *len;
+  int     ncols;
+  int     maxsteps;
+  double *table;      /* table[k*ncols+col], (maxsteps+2)*ncols values */
+} imdgpu_pot_table;
+
+/* ---- life cycle ---------------------------------------------------------- */
+int  imdgpu_create(imdgpu_ctx **ctx, int device);
+void imdgpu_destroy(imdgpu_ctx *ctx);
+const char *imdgpu_last_error(const imdgpu_ctx *ctx);
+/* run on a caller-owned HIP stream (hipStream_t) instead of the context's own */
+int  imdgpu_set_stream(imdgpu_ctx *ctx, void *hip_stream);
+int  imdgpu_synchronize(imdgpu_ctx *ctx);
+
+/* ---- set-up -------------------------------------------------------------- */
+/* Geometry of one rank: box_x/y/z rows (globals.h:613), pbc_dirs
+ * (globals.h:221), local cell array incl. ghost layer `cell_dim`
+ * (imd_geom_3d.c:253-255), global_cell_dim, cpu_dim, my_coord
+ * (imd_geom_mpi_3d.c:32-90). */
+int imdgpu_set_geometry(imdgpu_ctx *ctx, const double box[9], const int pbc_dirs[3],
+                        const int cell_dim[3], const int global_cell_dim[3],
+                        const int cpu_dim[3], const int my_coord[3]);
+/* cellsz = (r_cut+nbl_margin)^2 as after init_cells (imd_geom_3d.c:127-131) */
+int imdgpu_set_params(imdgpu_ctx *ctx, int ntypes, double cellsz, double nbl_margin,
+                      double timestep, int count_ttm_neighbours);
+/* pair_pot / rho_h_tab / embed_pot (globals.h:701,1414-1415).  pair==NULL:
+ * build without PAIR; rho==embed==NULL: build without EAM2. */
+int imdgpu_upload_tables(imdgpu_ctx *ctx, const imdgpu_pot_table *pair,
+                         const imdgpu_pot_table *rho_h, const imdgpu_pot_table *embed);
+/* per-type force restrictions (globals.h `restrictions`, imd_integrate.c:209-213) */
+int imdgpu_set_restrictions(imdgpu_ctx *ctx, const double *restr /* ntypes*3 */);
+
+/* ---- atoms --------------------------------------------------------------- */
+/* Take over the host's cell arrangement as it stands (no re-binning):
+ * cell_n[nallcells] in linear cell order (ghost entries ignored), per-atom
+ * arrays cell ordered.  Invalidates the neighbour list.  Replaces the
+ * AoS-of-arrays walk over cell_array (types.h:188-349). */
+int imdgpu_upload_cells(imdgpu_ctx *ctx, const int *cell_n, int natoms,
+                        const double *ort, const double *impuls, const double *masse,
+                        const int *sorte, const int *nummer);
+/* Unsorted atoms (e.g. a generator): binned on the device by imdgpu_fix_cells. */
+int imdgpu_upload_atoms(imdgpu_ctx *ctx, int natoms, const double *ort,
+                        const double *impuls, const double *masse,
+                        const int *sorte, const int *nummer);
+int imdgpu_num_atoms(imdgpu_ctx *ctx, int *nlocal, int *nghost);
+/* Any output pointer may be NULL.  cell_n: nallcells ints (inner cells only
+ * are non-zero).  Arrays are cell ordered in the CURRENT device arrangement. */
+int imdgpu_download_atoms(imdgpu_ctx *ctx, int *cell_n, double *ort, double *impuls,
+                          double *kraft, double *pot_eng, double *eam_rho, double *eam_dF,
+                          int *numneighs, int *nummer, int *sorte, double *nbl_pos);
+
+/* ---- hot path (reference names in brackets) ----------------------------- */
+/* [fix_cells, imd_fix_cells_3d.c:43-306 + do_boundaries, imd_main_3d.c:2018]
+ * wrap into the box, re-bin (stable counting order), invalidate the list */
+int imdgpu_fix_cells(imdgpu_ctx *ctx);
+/* [send_cells(copy_cell,...), imd_comm_force_3d.c:222-396] refresh the ghost
+ * layer from the periodic images (all 26 directions, i.e. the non-AR shell) */
+int imdgpu_fill_ghosts(imdgpu_ctx *ctx);
+/* [make_nblist, imd_forces_nbl.c:136-287] */
+int imdgpu_make_nblist(imdgpu_ctx *ctx);
+/* [check_nblist, imd_forces_nbl.c:1062-1092] *have_valid_nbl as the global */
+int imdgpu_check_nblist(imdgpu_ctx *ctx, int *have_valid_nbl);
+/* [calc_forces, imd_forces_nbl.c:295-1054].  sums[8] = tot_pot_energy, virial,
+ * vir_xx, vir_yy, vir_zz, vir_xy, vir_yz, vir_zx (order of tmpvec1, :999-1006;
+ * the vir_?? entries are 0 as in the non-P_AXIAL build).  is_short as :673. */
+int imdgpu_calc_forces(imdgpu_ctx *ctx, int steps, double sums[8], int *is_short);
+/* [move_atoms_nve, imd_integrate.c:35-561] */
+int imdgpu_move_atoms_nve(imdgpu_ctx *ctx, double *tot_kin_energy);
+/* one full MD step kept on the device: calc_forces, [calc_ttm], move_atoms,
+ * check_nblist (main_loop body, imd_main_3d.c:406-812).  Results of the
+ * reductions stay on the device until imdgpu_get_sums. */
+int imdgpu_md_step(imdgpu_ctx *ctx, int steps);
+int imdgpu_get_sums(imdgpu_ctx *ctx, double sums[8], double *tot_kin_energy,
+                    int *nbl_count);
+
+/* The Verlet list in the REFERENCE's own format and numbering (half list,
+ * tl/tb/cl_off, imd_forces_nbl.c:24-42), rebuilt from the current arrangement.
+ * Pass tb==NULL to query sizes: *ntb receives the entry count.  tl has
+ * nlocal+1 entries, cl_off nallcells entries. */
+int imdgpu_export_nblist(imdgpu_ctx *ctx, int *tl, int *tb, int *cl_off, int *ntb);
+/* full (symmetric) device list statistics: total entries and max per atom */
+int imdgpu_nblist_stats(imdgpu_ctx *ctx, long long *entries, int *max_per_atom);
+
+/* ---- profiling ------------------------------------------------------------ */
+/* Accumulate HIP-event timings per kernel class on the context's stream. */
+int imdgpu_profile_enable(imdgpu_ctx *ctx, int on);
+int imdgpu_profile_reset(imdgpu_ctx *ctx);
+/* names: "pass1","pass2","pass3","ghosts","nblist","fix_cells","integrate",
+ * "check","reduce","ttm_update_fd","ttm_diff","ttm_fillmesh" */
+int imdgpu_profile_get(imdgpu_ctx *ctx, const char *name, long long *launches, double *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

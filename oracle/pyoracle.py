@@ -174,6 +174,28 @@ class OracleSystem:
         arr = getattr(self, name)
         return np.concatenate([arr[c, : self.n[c]] for c in self.inner], axis=0)
 
+    def fill_from_positions(self, pos, mom, mass, sorte=None, nummer=None):
+        """Bin atoms like the generator does (cell_coord, then append in input order)."""
+        pos = np.asarray(pos, dtype=np.float64); n = len(pos)
+        t = np.array(self.s.tbox[:]).reshape(3, 3)
+        gd = np.array(self.s.gdim[:])
+        c = (gd * (pos @ t.T)).astype(np.int64)
+        c = np.clip(c, 0, gd - 1) + 1
+        lin = (c[:, 0] * self.dim[1] + c[:, 1]) * self.dim[2] + c[:, 2]
+        order = np.argsort(lin, kind="stable")
+        cnt = np.bincount(lin, minlength=self.s.nall)
+        assert cnt.max() <= self.cap, "cell capacity %d < %d" % (self.cap, cnt.max())
+        start = np.concatenate([[0], np.cumsum(cnt)])
+        slot = np.arange(n) - start[lin[order]]
+        cl = lin[order]
+        self.n[:] = cnt
+        self.ort[cl, slot] = pos[order]
+        self.impuls[cl, slot] = np.asarray(mom, dtype=np.float64)[order]
+        self.masse[cl, slot] = np.broadcast_to(np.asarray(mass, dtype=np.float64), (n,))[order]
+        self.sorte[cl, slot] = 0 if sorte is None else np.asarray(sorte)[order]
+        self.nummer[cl, slot] = (np.arange(n) if nummer is None else np.asarray(nummer))[order]
+        self.s.have_valid_nbl = 0
+
     def load_cells(self, cell_n, per_cell_fields):
         """Fill cells from per-cell lists: per_cell_fields[name][c] -> array(n_c[,3])."""
         self.n[:] = cell_n
