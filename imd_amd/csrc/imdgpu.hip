@@ -965,6 +965,7 @@ extern "C" int imdgpu_fix_cells(imdgpu_ctx *ctx)
     std::swap(ctx->p, ctx->p2); std::swap(ctx->mass, ctx->mass2);
   }
   if (build_cells_from_counts(ctx)) return 1;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipMemcpy(ctx->h_counters, ctx->d_counters, CNT_N * sizeof(int), hipMemcpyDeviceToHost));
   if (ctx->h_counters[CNT_OUTSIDE] > 0 && (ctx->cpu_dim[0] * ctx->cpu_dim[1] * ctx->cpu_dim[2] > 1))
     return imdgpu_fail(ctx, "%d atoms left this rank's domain: migrate them with the halo layer before fix_cells",
@@ -1023,6 +1024,7 @@ extern "C" int imdgpu_make_nblist(imdgpu_ctx *ctx)
 
 extern "C" int imdgpu_nblist_stats(imdgpu_ctx *ctx, long long *entries, int *maxn)
 {
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   std::vector<int> c(ctx->nlocal);
   HIPCHK(hipMemcpy(c.data(), ctx->nbr_cnt, ctx->nlocal * sizeof(int), hipMemcpyDeviceToHost));
   long long s = 0; int m = 0;
@@ -1170,6 +1172,7 @@ extern "C" int imdgpu_md_step(imdgpu_ctx *ctx, int steps)
 
 extern "C" int imdgpu_get_sums(imdgpu_ctx *ctx, double sums[8], double *ekin, int *nbl_count)
 {
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipMemcpy(ctx->h_sums, ctx->d_sums, SUM_N * sizeof(double), hipMemcpyDeviceToHost));
   if (sums) for (int q = 0; q < 8; q++) sums[q] = ctx->h_sums[q];
   if (ekin) *ekin = ctx->h_sums[SUM_EKIN];
@@ -1263,6 +1266,7 @@ extern "C" int imdgpu_export_nblist(imdgpu_ctx *ctx, int *tl, int *tb, int *cl_o
     HIPCHK(hipMalloc((void **) &d_tb, (size_t) (total + 1) * sizeof(int)));
     hipLaunchKernelGGL((k_export_half<true>), dim3(nblk(n, 128)), dim3(128), 0, ctx->stream, n, ctx->pos, ctx->acell,
                        ctx->cell_start, ctx->cell_cnt, g, ctx->cellsz, d_off, d_tl, d_tb);
+    HIPCHK(hipStreamSynchronize(ctx->stream));       // ctx->stream is non-blocking w.r.t. the null stream
     HIPCHK(hipMemcpy(tb, d_tb, (size_t) total * sizeof(int), hipMemcpyDeviceToHost));
     (void) hipFree(d_tb);
   }

@@ -29,8 +29,8 @@ def _gpu_from_golden(G, step, nbl=True, ttm=False):
     return s
 
 
-def _relmax(a, b):
-    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+def _relmax(a, b, floor=1e-300):
+    return np.abs(a - b).max() / max(np.abs(b).max(), floor)
 
 
 @pytest.mark.parametrize("case,step,eam", [("eam_nbl_2048", 0, True), ("eam_nbl_2048", 40, True),
@@ -38,15 +38,11 @@ def _relmax(a, b):
 def test_forces_vs_reference_golden(case, step, eam):
     G = gu.load(case)
     s = _gpu_from_golden(G, step)
-    if step != 0:
-        # the reference's list at `step` is older than its positions; rebuild it from
-        # the same reference positions so the pair set is identical
-        pass
     r = s.calc_forces(step)
     d = s.download()
     pre = "s%d_" % step
     assert np.array_equal(d["nummer"], G[pre + "nummer"])
-    assert _relmax(d["kraft"], G[pre + "kraft"]) < FTOL
+    assert _relmax(d["kraft"], G[pre + "kraft"], floor=1e-3) < FTOL     # step 0: perfect lattice, |F|~1e-14
     assert _relmax(d["pot_eng"], G[pre + "pot_eng"]) < 1e-11
     if eam:
         assert _relmax(d["eam_rho"], G[pre + "eam_rho"]) < 1e-11
