@@ -9,7 +9,7 @@
 # oracle/ref_probe.c, a read-only observation probe attached with ld --wrap.
 #
 # usage: oracle/build_ref.sh [target ...]
-#   targets: eam_nve_nbl  nve_nbl  eam_nve  nve  mpi_eam_nve_nbl
+#   targets: eam_nve_nbl  nve_nbl  eam_nve  nve  mpi_eam_nve_nbl  mpi_eam_ttm3d_nbl
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 REF="${IMD_REFERENCE:-/root/reference}"
@@ -44,7 +44,13 @@ build() {
   done
   wait
   $cc $BASEFLAGS $defs -c "$HERE/ref_probe.c" -o "$obj/ref_probe.o"
-  $cc -o "$OUT/imd_$name" $objs "$obj/ref_probe.o" -Wl,--wrap=calc_forces \
+  local wrap="-Wl,--wrap=calc_forces" extra=""
+  if [[ "$defs" == *-DTTM* ]]; then
+    $cc $BASEFLAGS $defs -c "$HERE/ref_probe_ttm.c" -o "$obj/ref_probe_ttm.o"
+    extra="$obj/ref_probe_ttm.o"
+    wrap="$wrap -Wl,--wrap=calc_ttm -Wl,--wrap=tmm_init -Wl,--wrap=do_tmm"
+  fi
+  $cc -o "$OUT/imd_$name" $objs "$obj/ref_probe.o" $extra $wrap \
       "$REF/nn_interpol/libnn.a" -lm $libs
   echo "built $OUT/imd_$name"
 }
@@ -60,6 +66,14 @@ for t in $TARGETS; do
       MPIINC="${MPI_HOME:-/opt/conda}"
       if [ ! -f "$MPIINC/include/mpi.h" ]; then echo "no MPI at $MPIINC, skipping $t" >&2; continue; fi
       build "$t" "-DMPI -DNBL -DEAM2 -DNVE" "$COMMON $NBLSRC imd_mpi_util.c" \
+            "$CC -I$MPIINC/include" "-L$MPIINC/lib -Wl,-rpath,$MPIINC/lib -lmpi" ;;
+    mpi_eam_ttm3d_nbl)
+      # 3D TTM (imd_ttm_3D.c swapped in for imd_ttm.c as the reference's manual says);
+      # needs MPI, -DTMM (see ref_probe_ttm.c) and -DEOSMODE=1 (only imd_ttm.c defines it).
+      MPIINC="${MPI_HOME:-/opt/conda}"
+      if [ ! -f "$MPIINC/include/mpi.h" ]; then echo "no MPI at $MPIINC, skipping $t" >&2; continue; fi
+      build "$t" "-DMPI -DNBL -DEAM2 -DTTM -DTMM -DEOSMODE=1" \
+            "$COMMON $NBLSRC imd_mpi_util.c imd_ttm_3D.c imd_interpol.c fminbnd3.c" \
             "$CC -I$MPIINC/include" "-L$MPIINC/lib -Wl,-rpath,$MPIINC/lib -lmpi" ;;
     *) echo "unknown target $t" >&2; exit 1 ;;
   esac

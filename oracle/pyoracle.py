@@ -300,3 +300,136 @@ def system_from_probe(P, cap=None, load_outputs=False):
             s.set_table(which, P[key])
     s.s.count_ttm_neigh = 1 if (P["flags"] & 4) else 0
     return s
+
+
+# ---------------------------------------------------------------------------
+# TTM oracle (oracle/ttm_oracle.c)
+# ---------------------------------------------------------------------------
+
+class _Eos(C.Structure):
+    _fields_ = [("nx", C.c_int), ("ny", C.c_int), ("xmin", C.c_double), ("xmax", C.c_double),
+                ("ymin", C.c_double), ("ymax", C.c_double), ("z", C.POINTER(C.c_double))]
+
+
+class _Ttm(C.Structure):
+    _fields_ = [("dim", C.c_int * 3), ("ext", C.c_int * 3), ("pbc", C.c_int * 3), ("ncell", C.c_size_t),
+                ("fd_min_atoms", C.c_int), ("cur", C.c_int),
+                ("h", C.c_double * 3), ("vol", C.c_double), ("neighvol", C.c_double),
+                ("atomic_weight", C.c_double), ("atomic_charge", C.c_double), ("omega_laser", C.c_double),
+                ("Temin", C.c_double), ("max_dt_ttm", C.c_double),
+                ("natoms", C.POINTER(C.c_int)), ("natoms_old", C.POINTER(C.c_int)),
+                ("temp", C.POINTER(C.c_double) * 2), ("U", C.POINTER(C.c_double) * 2),
+                ("xi", C.POINTER(C.c_double)), ("md_temp", C.POINTER(C.c_double)), ("source", C.POINTER(C.c_double)),
+                ("vcom", C.POINTER(C.c_double)), ("dens", C.POINTER(C.c_double)), ("fd_k", C.POINTER(C.c_double)),
+                ("fd_g", C.POINTER(C.c_double)), ("Z", C.POINTER(C.c_double)), ("Ce", C.POINTER(C.c_double)),
+                ("ne", C.POINTER(C.c_double)), ("cve", _Eos), ("ee", _Eos)]
+
+
+_TTM_READY = False
+
+
+def _ttm_lib():
+    global _TTM_READY
+    L = lib()
+    if not _TTM_READY:
+        tp, sp = C.POINTER(_Ttm), C.POINTER(_Sys)
+        L.orc_ttm_new.restype = tp
+        L.orc_ttm_new.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int),
+                                  C.c_int, C.c_double, C.c_double, C.c_double]
+        L.orc_ttm_free.argtypes = [tp]
+        L.orc_ttm_set_eos.argtypes = [tp, C.c_int, C.c_int, C.c_int] + [C.c_double] * 4 + [C.POINTER(C.c_double)]
+        L.orc_ttm_update_fd.argtypes = [tp, sp, C.c_int]
+        L.orc_ttm_cell_activation.argtypes = [tp]
+        L.orc_ttm_fillmesh.argtypes = [tp, C.c_int]
+        L.orc_ttm_fill_ghosts.argtypes = [tp]
+        L.orc_ttm_diff.argtypes = [tp, C.c_double, C.c_int]
+        L.orc_ttm_cfl.argtypes = [tp, C.c_int, C.c_double, C.c_int]
+        L.orc_ttm_calc.argtypes = [tp, sp, C.c_int, C.c_int]
+        L.orc_move_atoms_ttm.argtypes = [sp, tp]
+        for f in ("orc_mean_charge", "orc_get_gamma", "orc_get_kappa"):
+            getattr(L, f).restype = C.c_double
+        L.orc_mean_charge.argtypes = [C.c_double] * 4
+        L.orc_get_gamma.argtypes = [C.c_double] * 5
+        L.orc_get_kappa.argtypes = [C.c_double] * 5
+        L.orc_eos_cve.restype = C.c_double
+        L.orc_eos_cve.argtypes = [tp, C.c_double, C.c_double]
+        L.orc_eos_ee.restype = C.c_double
+        L.orc_eos_ee.argtypes = [tp, C.c_double, C.c_double]
+        _TTM_READY = True
+    return L
+
+
+class OracleTTM:
+    """FD lattice bound to an OracleSystem; numpy views of shape dim (ghosts incl.)."""
+
+    def __init__(self, system, fd_ext, fd_min_atoms, atomic_weight, atomic_charge, r2_cut_pair, fd_h=None):
+        L = _ttm_lib()
+        self.sys = system
+        md = np.asarray(system.dim, dtype=np.int32)
+        ext = np.asarray(fd_ext, dtype=np.int32)
+        box = np.array(system.s.box[:]).reshape(3, 3)
+        if fd_h is None:      # fd_h = fd_ext * box/global_cell_dim (imd_geom_3d.c:243-246)
+            fd_h = np.array([ext[d] * box[d, d] * (1.0 / (md[d] - 2)) for d in range(3)])
+        h = np.ascontiguousarray(fd_h, dtype=np.float64)
+        pbc = np.array(system.s.pbc[:], dtype=np.int32)
+        self._p = L.orc_ttm_new(_ip(md), _ip(ext), _dp(h), _ip(pbc), int(fd_min_atoms), float(atomic_weight),
+                                float(atomic_charge), float(r2_cut_pair))
+        self.t = self._p.contents
+        self.dim = tuple(int(v) for v in self.t.dim)
+        n = int(self.t.ncell)
+        aa = np.ctypeslib.as_array
+        for name in ("natoms", "natoms_old", "xi", "md_temp", "source", "dens", "fd_k", "fd_g", "Z", "Ce", "ne"):
+            setattr(self, name, aa(getattr(self.t, name), (n,)).reshape(self.dim))
+        self.vcom = aa(self.t.vcom, (3 * n,)).reshape(self.dim + (3,))
+        self._temp = [aa(self.t.temp[q], (n,)).reshape(self.dim) for q in (0, 1)]
+        self._U = [aa(self.t.U[q], (n,)).reshape(self.dim) for q in (0, 1)]
+
+    temp = property(lambda self: self._temp[self.t.cur])     # l1
+    temp2 = property(lambda self: self._temp[self.t.cur ^ 1])
+    U = property(lambda self: self._U[self.t.cur])
+    U2 = property(lambda self: self._U[self.t.cur ^ 1])
+
+    def close(self):
+        if self._p is not None:
+            _ttm_lib().orc_ttm_free(self._p)
+            self._p = None
+
+    def set_eos(self, which, nx, ny, xmin, xmax, ymin, ymax, z):
+        z = np.ascontiguousarray(z, dtype=np.float64).reshape(-1)
+        _ttm_lib().orc_ttm_set_eos(self._p, which, nx, ny, xmin, xmax, ymin, ymax, _dp(z))
+
+    def update_fd(self, steps): _ttm_lib().orc_ttm_update_fd(self._p, self.sys._p, steps)
+    def cell_activation(self): _ttm_lib().orc_ttm_cell_activation(self._p)
+    def fillmesh(self, steps): _ttm_lib().orc_ttm_fillmesh(self._p, steps)
+    def fill_ghosts(self): _ttm_lib().orc_ttm_fill_ghosts(self._p)
+    def diff(self, tau, diff_substeps): _ttm_lib().orc_ttm_diff(self._p, tau, diff_substeps)
+    def cfl(self, steps, timestep, n): _ttm_lib().orc_ttm_cfl(self._p, steps, timestep, n)
+    def calc_ttm(self, steps, diff_substeps): _ttm_lib().orc_ttm_calc(self._p, self.sys._p, steps, diff_substeps)
+    def move_atoms_ttm(self): _ttm_lib().orc_move_atoms_ttm(self.sys._p, self._p)
+
+
+TTM_REC = np.dtype([("natoms", "<i4"), ("natoms_old", "<i4"), ("temp", "<f8"), ("xi", "<f8"), ("md_temp", "<f8"),
+                    ("source", "<f8"), ("vcom", "<f8", 3), ("dens", "<f8"), ("fd_k", "<f8"), ("fd_g", "<f8"),
+                    ("Z", "<f8"), ("Ce", "<f8"), ("ne", "<f8"), ("U", "<f8"), ("temp2", "<f8"), ("U2", "<f8")])
+
+
+def read_ttm_probe(path):
+    """Dumps of oracle/ref_probe_ttm.c: header + named lattice snapshots."""
+    buf = open(path, "rb").read()
+    assert buf[:8] == b"IMDTTMPR" and buf[-8:] == b"ENDTTMPR"
+    off = 8
+    hi = np.frombuffer(buf, "<i4", 11, off); off += 44
+    hd = np.frombuffer(buf, "<f8", 10, off); off += 80
+    H = dict(version=int(hi[0]), step=int(hi[1]), fd_dim=hi[2:5].copy(), fd_ext=hi[5:8].copy(),
+             fd_min_atoms=int(hi[8]), diff_substeps=int(hi[9]), fd_n_timesteps=int(hi[10]),
+             fd_h=hd[0:3].copy(), fd_vol=float(hd[3]), neighvol=float(hd[4]), atomic_weight=float(hd[5]),
+             atomic_charge=float(hd[6]), timestep=float(hd[7]), tau=float(hd[8]), omega_laser=float(hd[9]))
+    n = int(np.prod(H["fd_dim"]))
+    stages = {}
+    while off < len(buf) - 8:
+        tag = buf[off:off + 16].split(b"\0")[0].decode(); off += 16
+        mdt = float(np.frombuffer(buf, "<f8", 1, off)[0]); off += 8
+        rec = np.frombuffer(buf, TTM_REC, n, off).reshape(tuple(H["fd_dim"])).copy(); off += TTM_REC.itemsize * n
+        stages[tag] = dict(max_dt_ttm=mdt, lat=rec)
+    H["stages"] = stages
+    return H

@@ -1,0 +1,106 @@
+/*
+ * ref_probe_ttm.c -- TEST INFRASTRUCTURE (oracle side), not product code.
+ *
+ * Probe for the reference's 3D two-temperature model (imd_ttm_3D.c), attached
+ * with ld --wrap by oracle/build_ref.sh (target mpi_eam_ttm3d_nbl).
+ *
+ * Why a probe and not the plain program: the shipped 3D TTM cannot be built as
+ * a whole program -- imd_ttm_3D.c only compiles with -DTMM (it uses tmm_time,
+ * laser_active, ... unconditionally, :73,:82,:161) but the TMM solver the
+ * reference ships (imd_tmm.c) is written for the 1D lattice and does not
+ * compile against the 3D one.  The probe therefore
+ *   - answers the two TMM entry points (tmm_init, do_tmm) with "no laser"
+ *     (return 0, nothing deposited; all fixtures run with the laser off), and
+ *   - drives, from __wrap_calc_ttm, the reference's OWN compiled functions in
+ *     the order of the first block of calc_ttm (imd_ttm_3D.c:50-77):
+ *       update_fd -> do_cell_activation -> do_FILLMESH -> ttm_fill_ghost_layers
+ *       -> diff_substeps x { do_DIFF(tau); do_FILLMESH; ttm_fill_ghost_layers }
+ *       -> CFL_maxdt
+ *     leaving out do_tmm (laser) and do_ADV (advection; out of scope this round),
+ *     dumping the lattice in raw fp64 between the stages.
+ * Every number in the TTM fixtures is thus computed by the reference's code.
+ */
+#include "imd.h"
+
+void __real_calc_forces(int steps);
+
+int __wrap_tmm_init(void) { return 0; }
+int __wrap_do_tmm(real dt) { (void) dt; return 0; }
+
+static int want(int s)
+{
+  const char *e = getenv("IMD_PROBE_STEPS");
+  if (e == NULL) return s == 0;
+  while (*e) {
+    char *end; long v = strtol(e, &end, 10);
+    if (end == e) break;
+    if (v == s) return 1;
+    e = end; while (*e == ',' || *e == ' ') e++;
+  }
+  return 0;
+}
+
+static FILE *tf = NULL;
+static void wi(int v)    { fwrite(&v, sizeof(int), 1, tf); }
+static void wd(double v) { fwrite(&v, sizeof(double), 1, tf); }
+
+static void dump_lattice(const char *tag)
+{
+  int i, j, k;
+  char t[16];
+  memset(t, 0, sizeof(t)); strncpy(t, tag, 15);
+  fwrite(t, 1, 16, tf);
+  wd(max_dt_ttm);
+  for (i = 0; i < local_fd_dim.x; i++)
+    for (j = 0; j < local_fd_dim.y; j++)
+      for (k = 0; k < local_fd_dim.z; k++) {
+        ttm_Element *e = &l1[i][j][k], *e2 = &l2[i][j][k];
+        wi(e->natoms); wi(e->natoms_old);
+        wd(e->temp); wd(e->xi); wd(e->md_temp); wd(e->source);
+        wd(e->vcomx); wd(e->vcomy); wd(e->vcomz);
+        wd(e->dens); wd(e->fd_k); wd(e->fd_g); wd(e->Z); wd(e->Ce); wd(e->ne); wd(e->U);
+        wd(e2->temp); wd(e2->U);
+      }
+}
+
+void __wrap_calc_ttm(void)
+{
+  int i, dumping = want(steps);
+  double tau;
+  diff_substeps = fd_n_timesteps;
+  tau = timestep / ((double) diff_substeps);
+  if (dumping) {
+    char fn[1024];
+    const char *dir = getenv("IMD_PROBE_DIR");
+    sprintf(fn, "%s/ttm.%d.%d.bin", dir ? dir : ".", myid, steps);
+    tf = fopen(fn, "wb");
+    fwrite("IMDTTMPR", 1, 8, tf);
+    wi(1); wi(steps);
+    wi(local_fd_dim.x); wi(local_fd_dim.y); wi(local_fd_dim.z);
+    wi(fd_ext.x); wi(fd_ext.y); wi(fd_ext.z);
+    wi(fd_min_atoms); wi(diff_substeps); wi(fd_n_timesteps);
+    wd(fd_h.x); wd(fd_h.y); wd(fd_h.z); wd(fd_vol); wd(neighvol);
+    wd(atomic_weight); wd(atomic_charge); wd(timestep); wd(tau); wd(omega_laser);
+    dump_lattice("entry");
+  }
+  update_fd();
+  if (dumping) dump_lattice("update_fd");
+  do_cell_activation();
+  do_FILLMESH();
+  ttm_fill_ghost_layers();
+  if (dumping) dump_lattice("fillmesh0");
+  for (i = 0; i < diff_substeps; i++) {
+    do_DIFF(tau);
+    if (dumping && i == 0) dump_lattice("diff_only1");
+    do_FILLMESH();
+    ttm_fill_ghost_layers();
+    if (dumping && (i == 0 || i == 1)) dump_lattice(i == 0 ? "substep1" : "substep2");
+  }
+  if (dumping) dump_lattice("substeps_done");
+  CFL_maxdt();
+  if (dumping) {
+    dump_lattice("cfl");
+    fwrite("ENDTTMPR", 1, 8, tf);
+    fclose(tf); tf = NULL;
+  }
+}

@@ -1,0 +1,47 @@
+/* ttm_oracle.h -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.  See ttm_oracle.c. */
+#ifndef TTM_ORACLE_H
+#define TTM_ORACLE_H
+#include <stddef.h>
+#include "imd_oracle.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { int nx, ny; double xmin, xmax, ymin, ymax; double *z; } orc_eos;
+
+/* SoA restatement of the ttm_Element lattices l1/l2 (types.h:441-492): fields
+ * that do_DIFF double-buffers (temp, U) are ping-pong pairs, `cur` = l1. */
+typedef struct {
+  int dim[3], ext[3], pbc[3];
+  size_t ncell;
+  int fd_min_atoms, cur;
+  double h[3], vol, neighvol, atomic_weight, atomic_charge, omega_laser, Temin, max_dt_ttm;
+  int *natoms, *natoms_old;
+  double *temp[2], *U[2];
+  double *xi, *md_temp, *source, *vcom, *dens, *fd_k, *fd_g, *Z, *Ce, *ne;
+  orc_eos cve, ee;
+} orc_ttm;
+
+orc_ttm *orc_ttm_new(const int md_dim[3], const int fd_ext[3], const double fd_h[3], const int pbc[3],
+                     int fd_min_atoms, double atomic_weight, double atomic_charge, double r2_cut_pair);
+void orc_ttm_free(orc_ttm *t);
+void orc_ttm_set_eos(orc_ttm *t, int which /*0 cve(r,T), 1 ee(r,sqrt T)*/, int nx, int ny, double xmin, double xmax,
+                     double ymin, double ymax, const double *z);
+double orc_eos_lookup(const orc_eos *e, double x, double y);
+double orc_eos_cve(const orc_ttm *t, double r, double tK);
+double orc_eos_ee(const orc_ttm *t, double r, double tK);
+double orc_mean_charge(double temp, double rho, double z0, double am);
+double orc_get_gamma(double Te, double Ti, double Ne, double Z, double omega_laser);
+double orc_get_kappa(double Te, double Ti, double Ne, double Z, double omega_laser);
+void orc_ttm_update_fd(orc_ttm *t, const orc_sys *s, int steps);
+void orc_ttm_cell_activation(orc_ttm *t);
+void orc_ttm_fillmesh(orc_ttm *t, int steps);
+void orc_ttm_fill_ghosts(orc_ttm *t);
+void orc_ttm_diff(orc_ttm *t, double tau, int diff_substeps);
+void orc_ttm_cfl(orc_ttm *t, int steps, double timestep, int fd_n_timesteps);
+void orc_ttm_calc(orc_ttm *t, const orc_sys *s, int steps, int diff_substeps);
+void orc_move_atoms_ttm(orc_sys *s, const orc_ttm *t);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -54,9 +54,34 @@ CASES = {
     "lj_nbl_2048": dict(binary="imd_nve_nbl", box="8 8 8", temp=0.0258, steps=20, dump=[0, 20], full=[0],
                         pot="lj", nbl=True),
     # EAM through do_forces/do_forces_eam2 (cell-pair path, no Verlet list)
+    # EAM + 3D TTM (imd_ttm_3D.c functions driven by oracle/ref_probe_ttm.c), laser off
+    "ttm_2048": dict(binary="imd_mpi_eam_ttm3d_nbl", box="8 8 8", temp=0.03, steps=3, dump=[0, 1, 2, 3], full=[],
+                     pot="eam", nbl=True, ttm=dict(fd_ext="1 1 1", n=100, min_atoms=5)),
+    "ttm_6912_ext2": dict(binary="imd_mpi_eam_ttm3d_nbl", box="12 12 12", temp=0.0258, steps=1, dump=[0, 1], full=[],
+                          pot="eam", nbl=True, ttm=dict(fd_ext="2 2 2", n=25, min_atoms=5)),
+    # slab with vacuum in x: inactive FD cells, mirrored faces, open boundary
+    "ttm_slab": dict(binary="imd_mpi_eam_ttm3d_nbl", box="8 6 6", temp=0.03, steps=2, dump=[0, 1, 2], full=[],
+                     pot="eam", nbl=True, pbc="0 1 1", extra="shiftx_front 8.0\nshiftx_rear 8.0\n",
+                     ttm=dict(fd_ext="1 1 1", n=100, min_atoms=12)),
     "eam_cellpair_2048": dict(binary="imd_eam_nve", box="8 8 8", temp=0.0258, steps=10, dump=[0, 10], full=[0, 10],
                               pot="eam", nbl=False),
 }
+
+
+def write_planar_eos(d):
+    """Synthetic EOS tables, planar in the table's y argument so that linear
+    interpolation on ANY triangulation (the reference's nn-c lpi) reproduces them:
+    cve(r,T) = 0.05*T J/(kg K); ee(r,sqrt T) = 4000*sqrt(T) J/kg."""
+    nr, nt = 24, 40
+    r = np.linspace(500.0, 4500.0, nr); t = np.linspace(1.0, 60000.0, nt); ts = np.linspace(1.0, 245.0, nt)
+    zc = np.outer(np.ones(nr), 0.05 * t); ze = np.outer(np.ones(nr), 4000.0 * ts)
+    for fn, y, z in (("EOS_cve_from_r_te.txt", t, zc), ("EOS_ee_from_r_tesqrt.txt", ts, ze)):
+        with open(os.path.join(d, fn), "w") as f:
+            f.write("%d %d\n%.16e %.16e %.16e %.16e\n" % (nr, nt, r[0], r[-1], y[0], y[-1]))
+            for i in range(nr):
+                for j in range(nt):
+                    f.write("%.16e %.16e %.16e\n" % (r[i], y[j], z[i, j]))
+    return dict(nr=nr, nt=nt, r=r, t=t, ts=ts, cve=zc, ee=ze)
 
 
 def run_case(name, c):
@@ -71,6 +96,12 @@ def run_case(name, c):
         if c["nbl"]:
             par += "nbl_margin 0.5\nnbl_size 1.5\n"
         par += c.get("extra", "")
+        if "ttm" in c:
+            par = par.replace("ensemble nve", "ensemble ttm")
+            par += ("fd_ext %s\nfd_n_timesteps %d\nfd_min_atoms %d\natomic_weight 26.9815\natomic_charge 13\n"
+                    "ttm_int 100000\nI0 1.0\nlambda 800e-9\nlaser_sigma_t 100e-15\nlaser_t_0 1.0\n"
+                    % (c["ttm"]["fd_ext"], c["ttm"]["n"], c["ttm"]["min_atoms"]))
+            eos = write_planar_eos(d)
         open(os.path.join(d, "t.param"), "w").write(par)
         env = dict(os.environ, IMD_PROBE_DIR=d, IMD_PROBE_STEPS=",".join(map(str, c["dump"])))
         r = subprocess.run([os.path.join(REFBIN, c["binary"]), "-p", "t.param"], cwd=d, env=env,
@@ -79,6 +110,7 @@ def run_case(name, c):
             print(r.stdout[-3000:])
             raise SystemExit("reference run failed for %s" % name)
         probes = {s: po.read_probe(os.path.join(d, "probe.0.%d.bin" % s)) for s in c["dump"]}
+        tprobes = {s: po.read_ttm_probe(os.path.join(d, "ttm.0.%d.bin" % s)) for s in c["dump"]} if "ttm" in c else {}
     P0 = probes[c["dump"][0]]
     out = dict(case=name, param_file=par, steps=np.array(c["dump"]), full_steps=np.array(c["full"]))
     for k in ("ntypes", "cell_dim", "global_cell_dim", "pbc_dirs", "box", "cellsz", "nbl_margin", "timestep",
@@ -113,6 +145,19 @@ def run_case(name, c):
             if k == "nbl_pos" and not c["nbl"]:
                 continue
             out[pre + k] = P[k]
+    for s, T in tprobes.items():
+        if s == c["dump"][0]:
+            for k in ("fd_dim", "fd_ext", "fd_min_atoms", "diff_substeps", "fd_n_timesteps", "fd_h", "fd_vol", "neighvol",
+                      "atomic_weight", "atomic_charge", "tau", "omega_laser"):
+                out["ttm_" + k] = T[k]
+            for k, v in eos.items():
+                out["eos_" + k] = v
+        for tag, st in T["stages"].items():
+            out["t%d_%s_max_dt_ttm" % (s, tag)] = st["max_dt_ttm"]
+            for f in po.TTM_REC.names:
+                if tag in ("entry", "substep2") and f not in ("temp", "xi", "natoms", "fd_k", "U", "temp2"):
+                    continue
+                out["t%d_%s_%s" % (s, tag, f)] = st["lat"][f]
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **out)
     print("%-20s %8.1f KB  steps=%s nbl_count(last)=%d maxF=%.3g" %

@@ -57,3 +57,19 @@ def oracle_from_golden(G, step, nbl=True):
         if t is not None:
             s.set_table(which, t)
     return s
+
+
+def oracle_ttm_from_golden(G, s):
+    """TTM oracle bound to oracle system `s`, EOS tables from the fixture."""
+    t = po.OracleTTM(s, G["ttm_fd_ext"], int(G["ttm_fd_min_atoms"]), float(G["ttm_atomic_weight"]),
+                     float(G["ttm_atomic_charge"]), float(G["pair_pot_end"][0]))
+    nr, nt = int(G["eos_nr"]), int(G["eos_nt"])
+    t.set_eos(0, nr, nt, G["eos_r"][0], G["eos_r"][-1], G["eos_t"][0], G["eos_t"][-1], G["eos_cve"])
+    t.set_eos(1, nr, nt, G["eos_r"][0], G["eos_r"][-1], G["eos_ts"][0], G["eos_ts"][-1], G["eos_ee"])
+    t.t.omega_laser = float(G["ttm_omega_laser"])
+    return t
+
+
+def ttm_stage(G, step, tag):
+    pre = "t%d_%s_" % (step, tag)
+    return {k[len(pre):]: G[k] for k in G.files if k.startswith(pre)}
