@@ -83,10 +83,6 @@ static Geo make_geo(const imdgpu_ctx *c)
   return g;
 }
 
-// device counters (ints) ------------------------------------------------------
-enum { CNT_MAXNBR = 0, CNT_IS_SHORT = 1, CNT_OUTSIDE = 2, CNT_NGHOST = 3, CNT_INVALID = 4, CNT_N = 16 };
-// d_sums slots -------------------------------------------------------------------
-enum { SUM_EPOT = 0, SUM_VIRIAL = 1, SUM_EKIN = 8, SUM_MAXDISP = 9, SUM_N = 16 };
 
 // ---------------------------------------------------------------------------
 // table interpolation (device).  Same expression tree as PAIR_INT2 /
@@ -584,27 +580,6 @@ __global__ void k_check_only(int n, int cap, const double4 *pos, const double *r
     for (int q = 0; q < nw; q++) mx = fmax(mx, scratch[q]);
     partials[(size_t) blockIdx.x * 2 + 1] = mx;
     partials[(size_t) blockIdx.x * 2] = 0.0;
-  }
-}
-
-// sum of kinetic partials, max of displacement partials; decides list validity
-// (max > (0.5*margin)^2  =>  invalid; imd_forces_nbl.c:1091)
-__global__ void k_reduce_move(int nb, const double *partials, double *sums, double limit2, int *counters,
-                              int write_ekin)
-{
-  __shared__ double scratch[2 * 16];
-  double e = 0, mx = 0;
-  for (int b = threadIdx.x; b < nb; b += blockDim.x) { e += partials[(size_t) b * 2]; mx = fmax(mx, partials[(size_t) b * 2 + 1]); }
-  e = wave_sum(e); mx = wave_max(mx);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  if (lane == 0) { scratch[w] = e; scratch[16 + w] = mx; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double E = 0, M = 0;
-    for (int q = 0; q < nw; q++) { E += scratch[q]; M = fmax(M, scratch[16 + q]); }
-    if (write_ekin) sums[SUM_EKIN] = E;
-    sums[SUM_MAXDISP] = M;
-    counters[CNT_INVALID] = (M > limit2) ? 1 : 0;
   }
 }
 

@@ -19,6 +19,9 @@ SYMBOLS = [
     "imdgpu_calc_forces", "imdgpu_move_atoms_nve", "imdgpu_md_step", "imdgpu_get_sums",
     "imdgpu_export_nblist", "imdgpu_nblist_stats",
     "imdgpu_profile_enable", "imdgpu_profile_reset", "imdgpu_profile_get",
+    "imdgpu_ttm_init", "imdgpu_ttm_dims", "imdgpu_ttm_download", "imdgpu_ttm_upload", "imdgpu_ttm_update_fd",
+    "imdgpu_ttm_cell_activation", "imdgpu_ttm_fillmesh", "imdgpu_ttm_fill_ghost_layers", "imdgpu_ttm_diff",
+    "imdgpu_ttm_cfl_maxdt", "imdgpu_calc_ttm", "imdgpu_move_atoms_ttm",
 ]
 
 
@@ -32,6 +35,25 @@ class PotTableC(C.Structure):
                 ("step", C.POINTER(C.c_double)), ("invstep", C.POINTER(C.c_double)),
                 ("len", C.POINTER(C.c_int)), ("ncols", C.c_int), ("maxsteps", C.c_int),
                 ("table", C.POINTER(C.c_double))]
+
+
+class TtmParamsC(C.Structure):
+    """imdgpu_ttm_params"""
+    _fields_ = [("fd_ext", C.c_int * 3), ("fd_min_atoms", C.c_int), ("fd_n_timesteps", C.c_int),
+                ("atomic_weight", C.c_double), ("atomic_charge", C.c_double), ("omega_laser", C.c_double),
+                ("cve_nx", C.c_int), ("cve_ny", C.c_int), ("cve_xmin", C.c_double), ("cve_xmax", C.c_double),
+                ("cve_ymin", C.c_double), ("cve_ymax", C.c_double), ("cve_z", C.POINTER(C.c_double)),
+                ("ee_nx", C.c_int), ("ee_ny", C.c_int), ("ee_xmin", C.c_double), ("ee_xmax", C.c_double),
+                ("ee_ymin", C.c_double), ("ee_ymax", C.c_double), ("ee_z", C.POINTER(C.c_double))]
+
+
+TTM_FIELDS = ("natoms", "natoms_old", "temp", "temp2", "xi", "md_temp", "source", "vcom", "dens", "fd_k", "fd_g",
+              "Z", "Ce", "ne", "U", "U2")
+
+
+class TtmFieldsC(C.Structure):
+    """imdgpu_ttm_fields"""
+    _fields_ = [(n, C.POINTER(C.c_int) if n.startswith("natoms") else C.POINTER(C.c_double)) for n in TTM_FIELDS]
 
 
 def build(force=False):
@@ -81,6 +103,18 @@ def load():
     L.imdgpu_profile_enable.argtypes = [vp, C.c_int]
     L.imdgpu_profile_reset.argtypes = [vp]
     L.imdgpu_profile_get.argtypes = [vp, C.c_char_p, C.POINTER(C.c_longlong), dp]
+    L.imdgpu_ttm_init.argtypes = [vp, C.POINTER(TtmParamsC)]
+    L.imdgpu_ttm_dims.argtypes = [vp, ip, dp]
+    L.imdgpu_ttm_download.argtypes = [vp, C.POINTER(TtmFieldsC)]
+    L.imdgpu_ttm_upload.argtypes = [vp, C.POINTER(TtmFieldsC)]
+    L.imdgpu_ttm_update_fd.argtypes = [vp, C.c_int]
+    L.imdgpu_ttm_cell_activation.argtypes = [vp]
+    L.imdgpu_ttm_fillmesh.argtypes = [vp, C.c_int]
+    L.imdgpu_ttm_fill_ghost_layers.argtypes = [vp]
+    L.imdgpu_ttm_diff.argtypes = [vp, C.c_double]
+    L.imdgpu_ttm_cfl_maxdt.argtypes = [vp, C.c_int, dp]
+    L.imdgpu_calc_ttm.argtypes = [vp, C.c_int]
+    L.imdgpu_move_atoms_ttm.argtypes = [vp, dp]
     for s in SYMBOLS:
         if s not in ("imdgpu_destroy", "imdgpu_last_error"):
             getattr(L, s).restype = C.c_int

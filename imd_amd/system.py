@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import lib as _lib
-from .lib import ImdGpuError, PotTableC
+from .lib import TTM_FIELDS, ImdGpuError, PotTableC, TtmFieldsC, TtmParamsC
 
 
 def _dp(a):
@@ -196,6 +196,79 @@ class GpuSystem:
         m = C.c_int()
         self._ck(self.L.imdgpu_nblist_stats(self.h, C.byref(e), C.byref(m)))
         return e.value, m.value
+
+    # -- two-temperature model: the reference's entry points (imd_ttm_3D.c) -------
+    def init_ttm(self, fd_ext, fd_min_atoms, fd_n_timesteps, atomic_weight, atomic_charge, eos_cve, eos_ee,
+                 omega_laser=0.0):
+        """eos_cve / eos_ee: dict(x=rho grid, y=T or sqrt(T) grid, z=(nx,ny) values) on a regular grid."""
+        P = TtmParamsC()
+        P.fd_ext[:] = [int(v) for v in fd_ext]
+        P.fd_min_atoms, P.fd_n_timesteps = int(fd_min_atoms), int(fd_n_timesteps)
+        P.atomic_weight, P.atomic_charge, P.omega_laser = float(atomic_weight), float(atomic_charge), float(omega_laser)
+        zc = np.ascontiguousarray(eos_cve["z"], dtype=np.float64)
+        ze = np.ascontiguousarray(eos_ee["z"], dtype=np.float64)
+        self._keep.append((zc, ze))
+        P.cve_nx, P.cve_ny = zc.shape
+        P.cve_xmin, P.cve_xmax = float(eos_cve["x"][0]), float(eos_cve["x"][-1])
+        P.cve_ymin, P.cve_ymax = float(eos_cve["y"][0]), float(eos_cve["y"][-1])
+        P.cve_z = _dp(zc)
+        P.ee_nx, P.ee_ny = ze.shape
+        P.ee_xmin, P.ee_xmax = float(eos_ee["x"][0]), float(eos_ee["x"][-1])
+        P.ee_ymin, P.ee_ymax = float(eos_ee["y"][0]), float(eos_ee["y"][-1])
+        P.ee_z = _dp(ze)
+        self._ck(self.L.imdgpu_ttm_init(self.h, C.byref(P)))
+        d = np.zeros(3, np.int32)
+        h = np.zeros(3)
+        self._ck(self.L.imdgpu_ttm_dims(self.h, _ip(d), _dp(h)))
+        self.fd_dim, self.fd_h = tuple(int(v) for v in d), h
+        self.diff_substeps = int(fd_n_timesteps)
+
+    def ttm_download(self, fields=TTM_FIELDS):
+        F = TtmFieldsC()
+        out = {}
+        for n in fields:
+            shp = self.fd_dim + ((3,) if n == "vcom" else ())
+            out[n] = np.zeros(shp, dtype=np.int32 if n.startswith("natoms") else np.float64)
+            setattr(F, n, _ip(out[n]) if n.startswith("natoms") else _dp(out[n]))
+        self._ck(self.L.imdgpu_ttm_download(self.h, C.byref(F)))
+        return out
+
+    def ttm_upload(self, **fields):
+        F = TtmFieldsC()
+        keep = []
+        for n, v in fields.items():
+            a = np.ascontiguousarray(v, dtype=np.int32 if n.startswith("natoms") else np.float64)
+            keep.append(a)
+            setattr(F, n, _ip(a) if n.startswith("natoms") else _dp(a))
+        self._ck(self.L.imdgpu_ttm_upload(self.h, C.byref(F)))
+
+    def update_fd(self, steps=0):
+        self._ck(self.L.imdgpu_ttm_update_fd(self.h, int(steps)))
+
+    def do_cell_activation(self):
+        self._ck(self.L.imdgpu_ttm_cell_activation(self.h))
+
+    def do_FILLMESH(self, steps=0):
+        self._ck(self.L.imdgpu_ttm_fillmesh(self.h, int(steps)))
+
+    def ttm_fill_ghost_layers(self):
+        self._ck(self.L.imdgpu_ttm_fill_ghost_layers(self.h))
+
+    def do_DIFF(self, tau):
+        self._ck(self.L.imdgpu_ttm_diff(self.h, float(tau)))
+
+    def CFL_maxdt(self, steps=0):
+        v = C.c_double()
+        self._ck(self.L.imdgpu_ttm_cfl_maxdt(self.h, int(steps), C.byref(v)))
+        return v.value
+
+    def calc_ttm(self, steps=0):
+        self._ck(self.L.imdgpu_calc_ttm(self.h, int(steps)))
+
+    def move_atoms_ttm(self):
+        e = C.c_double()
+        self._ck(self.L.imdgpu_move_atoms_ttm(self.h, C.byref(e)))
+        return e.value
 
     # -- profiling -----------------------------------------------------------------
     def profile(self, on=True):

@@ -119,6 +119,61 @@ int imdgpu_export_nblist(imdgpu_ctx *ctx, int *tl, int *tb, int *cl_off, int *nt
 /* full (symmetric) device list statistics: total entries and max per atom */
 int imdgpu_nblist_stats(imdgpu_ctx *ctx, long long *entries, int *max_per_atom);
 
+/* ---- two-temperature model (3D FD lattice, imd_ttm_3D.c) ------------------- */
+/* Parameters the reference reads from the param file / derives in init_ttm
+ * (imd_ttm_3D.c:1001-1314): fd_ext, fd_min_atoms, fd_n_timesteps (used as
+ * diff_substeps, :51-52), atomic_weight, atomic_charge, omega_laser; and the two
+ * EOS tables of nn_read_table (imd_interpol.c:1174-1232) given on their regular
+ * grid z[ix*ny+iy]: cve(rho [kg/m^3], T [K]) in J/(K kg) and
+ * ee(rho, sqrt(T [K])) in J/kg.  Interpolation is bilinear on that grid. */
+typedef struct {
+  int    fd_ext[3];
+  int    fd_min_atoms;
+  int    fd_n_timesteps;
+  double atomic_weight, atomic_charge, omega_laser;
+  int    cve_nx, cve_ny;
+  double cve_xmin, cve_xmax, cve_ymin, cve_ymax;
+  const double *cve_z;
+  int    ee_nx, ee_ny;
+  double ee_xmin, ee_xmax, ee_ymin, ee_ymax;
+  const double *ee_z;
+} imdgpu_ttm_params;
+
+/* All lattice arrays are SoA over the local FD lattice INCLUDING its ghost shell,
+ * C order [i][j][k] like l1[i][j][k] (imd_ttm_3D.c:1071-1083). */
+typedef struct {
+  int    *natoms, *natoms_old;
+  double *temp, *temp2;          /* l1.temp, l2.temp (do_DIFF ping-pong, :1819-1821) */
+  double *xi, *md_temp, *source;
+  double *vcom;                  /* 3 per cell: vcomx, vcomy, vcomz */
+  double *dens, *fd_k, *fd_g, *Z, *Ce, *ne;
+  double *U, *U2;
+} imdgpu_ttm_fields;
+
+/* [init_ttm] needs geometry, params, pair_pot (neighvol from pair_pot.end[0], :1019) */
+int imdgpu_ttm_init(imdgpu_ctx *ctx, const imdgpu_ttm_params *par);
+int imdgpu_ttm_dims(imdgpu_ctx *ctx, int local_fd_dim[3], double fd_h[3]);
+/* any member of `f` may be NULL */
+int imdgpu_ttm_download(imdgpu_ctx *ctx, const imdgpu_ttm_fields *f);
+int imdgpu_ttm_upload(imdgpu_ctx *ctx, const imdgpu_ttm_fields *f);
+/* [update_fd, :233-488] uses numneighs/impuls/masse of the last calc_forces */
+int imdgpu_ttm_update_fd(imdgpu_ctx *ctx, int steps);
+/* [do_cell_activation, :1468-1596] */
+int imdgpu_ttm_cell_activation(imdgpu_ctx *ctx);
+/* [do_FILLMESH, :492-661] */
+int imdgpu_ttm_fillmesh(imdgpu_ctx *ctx, int steps);
+/* [ttm_fill_ghost_layers, :3314-3504] */
+int imdgpu_ttm_fill_ghost_layers(imdgpu_ctx *ctx);
+/* [do_DIFF(tau), :1603-1829] */
+int imdgpu_ttm_diff(imdgpu_ctx *ctx, double tau);
+/* [CFL_maxdt, :2637-2691] */
+int imdgpu_ttm_cfl_maxdt(imdgpu_ctx *ctx, int steps, double *max_dt_ttm);
+/* [calc_ttm, first block :50-77 without do_tmm/do_ADV]: update_fd, cell
+ * activation, FILLMESH, ghosts, diff_substeps x (DIFF, FILLMESH, ghosts), CFL */
+int imdgpu_calc_ttm(imdgpu_ctx *ctx, int steps);
+/* [move_atoms_ttm, imd_integrate.c:581-811] */
+int imdgpu_move_atoms_ttm(imdgpu_ctx *ctx, double *tot_kin_energy);
+
 /* ---- profiling ------------------------------------------------------------ */
 /* Accumulate HIP-event timings per kernel class on the context's stream. */
 int imdgpu_profile_enable(imdgpu_ctx *ctx, int on);

@@ -1,0 +1,124 @@
+"""GPU parity tests for the two-temperature model (run with -m gpu): HIP kernels
+through the C ABI against golden vectors computed by the reference's own
+imd_ttm_3D.c functions, and against the CPU oracle.
+
+Tolerance: 1e-10 relative on lattice fields (fp64; device libm pow/exp/log differ
+from glibc in the last bits and per-cell sums are tree- instead of sequentially
+ordered); integer fields exact."""
+import numpy as np
+import pytest
+
+from imd_amd.system import GpuSystem
+from tests import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def _eos(G):
+    return (dict(x=G["eos_r"], y=G["eos_t"], z=G["eos_cve"]), dict(x=G["eos_r"], y=G["eos_ts"], z=G["eos_ee"]))
+
+
+def _gpu(G, step=0):
+    pre = "s%d_" % step
+    s = GpuSystem(G["box"], G["pbc_dirs"], G["cell_dim"], 1, float(G["cellsz"]), float(G["nbl_margin"]),
+                  float(G["timestep"]))
+    s.upload_tables(gu.table(G, "pair_pot"), gu.table(G, "rho_h_tab"), gu.table(G, "embed_pot"))
+    cell_n = np.zeros(int(np.prod(G["cell_dim"])), np.int32)
+    cell_n[G["cells"]] = G[pre + "cell_n"][G["cells"]]
+    s.upload_cells(cell_n, G[pre + "ort"], G[pre + "impuls"], G[pre + "masse"], G[pre + "sorte"].astype(np.int32),
+                   G[pre + "nummer"])
+    cve, ee = _eos(G)
+    s.init_ttm(G["ttm_fd_ext"], int(G["ttm_fd_min_atoms"]), int(G["ttm_diff_substeps"]), float(G["ttm_atomic_weight"]),
+               float(G["ttm_atomic_charge"]), cve, ee, float(G["ttm_omega_laser"]))
+    return s
+
+
+def _cmp(d, st, tag, fields=None):
+    inner = (slice(1, -1),) * 3
+    for f, ref in st.items():
+        if f == "max_dt_ttm" or (fields and f not in fields) or f not in d:
+            continue
+        if f == "Z" and tag in ("diff_only1", "entry", "update_fd"):
+            continue
+        a = d[f]
+        if f not in ("natoms", "temp", "fd_k") or tag == "diff_only1":
+            a, ref = a[inner], ref[inner]
+        if a.dtype.kind == "i":
+            assert np.array_equal(a, ref), "%s %s" % (tag, f)
+        else:
+            err = np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-300)
+            assert err < TOL, "%s: %s rel err %.3e" % (tag, f, err)
+
+
+@pytest.mark.parametrize("case", ["ttm_2048", "ttm_6912_ext2", "ttm_slab"])
+def test_ttm_stages_vs_reference(case):
+    """update_fd / do_FILLMESH / ghosts / do_DIFF / CFL_maxdt one by one at step 0."""
+    G = gu.load(case)
+    s = _gpu(G)
+    assert tuple(s.fd_dim) == tuple(int(v) for v in G["ttm_fd_dim"])
+    assert np.allclose(s.fd_h, G["ttm_fd_h"], rtol=1e-15)
+    s.calc_forces(0)
+    d = s.download(fields=("numneighs", "kraft"))
+    assert np.array_equal(d["numneighs"], G["s0_numneighs"])           # integer: exact
+    s.update_fd(0);                                         _cmp(s.ttm_download(), gu.ttm_stage(G, 0, "update_fd"), "update_fd")
+    s.do_cell_activation(); s.do_FILLMESH(0); s.ttm_fill_ghost_layers()
+    _cmp(s.ttm_download(), gu.ttm_stage(G, 0, "fillmesh0"), "fillmesh0")
+    n, tau = int(G["ttm_diff_substeps"]), float(G["ttm_tau"])
+    for i in range(n):
+        s.do_DIFF(tau)
+        if i == 0:
+            _cmp(s.ttm_download(), gu.ttm_stage(G, 0, "diff_only1"), "diff_only1")
+        s.do_FILLMESH(0); s.ttm_fill_ghost_layers()
+        if i == 0:
+            _cmp(s.ttm_download(), gu.ttm_stage(G, 0, "substep1"), "substep1")
+    _cmp(s.ttm_download(), gu.ttm_stage(G, 0, "substeps_done"), "substeps_done")
+    mdt = s.CFL_maxdt(0)
+    assert abs(mdt - float(G["t0_cfl_max_dt_ttm"])) < 1e-12 * mdt
+    s.close()
+
+
+@pytest.mark.parametrize("case", ["ttm_2048", "ttm_slab"])
+def test_ttm_md_trajectory_vs_reference(case):
+    """Full device-resident loop (forces -> calc_ttm [fused sub-steps, hipGraph] ->
+    move_atoms_ttm) against the reference's lattice and atoms at later steps."""
+    G = gu.load(case)
+    s = _gpu(G)
+    last = int(G["steps"][-1])
+    for st in range(last):
+        s.md_step(st)
+        # lattice after calc_ttm of step `st` == reference's 'substeps_done' snapshot of that step
+        _cmp(s.ttm_download(), gu.ttm_stage(G, st, "substeps_done"), "substeps_done@%d" % st,
+             fields=("natoms", "temp", "xi", "md_temp", "dens", "fd_k", "fd_g", "Ce", "U", "vcom"))
+    s.calc_forces(last)
+    d = s.download()
+    pre = "s%d_" % last
+    order, gorder = np.argsort(d["nummer"]), np.argsort(G[pre + "nummer"])
+    assert np.abs(d["ort"][order] - G[pre + "ort"][gorder]).max() < 1e-9
+    assert np.abs(d["impuls"][order] - G[pre + "impuls"][gorder]).max() < 1e-9 * np.abs(G[pre + "impuls"]).max()
+    assert np.array_equal(d["numneighs"][order], G[pre + "numneighs"][gorder])
+    s.close()
+
+
+def test_ttm_cfl_after_step():
+    G = gu.load("ttm_2048")
+    s = _gpu(G)
+    s.md_step(0); s.calc_forces(1); s.calc_ttm(1)
+    mdt = s.CFL_maxdt(1)
+    assert abs(mdt - float(G["t1_cfl_max_dt_ttm"])) < 1e-9 * mdt
+    s.close()
+
+
+def test_ttm_vs_oracle_same_inputs():
+    G = gu.load("ttm_6912_ext2")
+    o = gu.oracle_from_golden(G, 0); o.s.count_ttm_neigh = 1
+    t = gu.oracle_ttm_from_golden(G, o)
+    o.calc_forces(0); t.calc_ttm(0, int(G["ttm_diff_substeps"]))
+    s = _gpu(G)
+    s.calc_forces(0); s.calc_ttm(0)
+    d = s.ttm_download()
+    inner = (slice(1, -1),) * 3
+    for f in ("temp", "xi", "fd_k", "fd_g", "Ce", "md_temp", "dens", "U"):
+        ref = getattr(t, f)
+        assert np.abs(d[f][inner] - ref[inner]).max() <= TOL * np.abs(ref[inner]).max(), f
+    s.close()
