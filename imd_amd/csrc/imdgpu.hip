@@ -65,24 +65,18 @@ static const char *prof_names[PROF_COUNT] = {
   "pass1", "pass2", "pass3", "ghosts", "nblist", "fix_cells", "integrate", "check", "reduce",
   "ttm_update_fd", "ttm_diff", "ttm_fillmesh"};
 
-// ---------------------------------------------------------------------------
-// geometry passed to kernels by value
-// ---------------------------------------------------------------------------
-struct Geo {
-  double box[9], tbox[9];
-  int pbc[3], gdim[3], dim[3], my_coord[3];
-  int nx, ny, nz;                   // inner cells per direction (dim-2)
-};
-
-static Geo make_geo(const imdgpu_ctx *c)
+Geo imdgpu_make_geo(const imdgpu_ctx *c)
 {
   Geo g;
   memcpy(g.box, c->box, sizeof(g.box)); memcpy(g.tbox, c->tbox, sizeof(g.tbox));
   for (int d = 0; d < 3; d++) { g.pbc[d] = c->pbc[d]; g.gdim[d] = c->gdim[d]; g.dim[d] = c->dim[d]; g.my_coord[d] = c->my_coord[d]; }
   g.nx = c->dim[0] - 2; g.ny = c->dim[1] - 2; g.nz = c->dim[2] - 2;
+  g.bx = c->tile[0]; g.by = c->tile[1]; g.bz = c->tile[2];
+  g.ntx = c->ntile[0]; g.nty = c->ntile[1]; g.ntz = c->ntile[2];
+  g.CPT = c->CPT; g.nkeys = c->nkeys;
   return g;
 }
-
+#define make_geo imdgpu_make_geo
 
 // ---------------------------------------------------------------------------
 // table interpolation (device).  Same expression tree as PAIR_INT2 /
@@ -177,7 +171,7 @@ __global__ void k_wrap_key(int n, double4 *pos, Geo g, int *keys, int *perm, int
     }
     c[d] = q;
   }
-  keys[i] = (c[0] * g.ny + c[1]) * g.nz + c[2];
+  keys[i] = xyz_to_key(c[0], c[1], c[2], g);
   perm[i] = i;
 }
 
@@ -195,18 +189,14 @@ __global__ void k_gather_sorted(int n, int cap, const int *perm, const int *keys
   atomicAdd(&icnt[k], 1);
 }
 
-// inner rank -> linear index in the ghost-including cell array
-__device__ __forceinline__ int inner_to_lin(int r, const Geo &g)
-{
-  int iz = r % g.nz, t = r / g.nz, iy = t % g.ny, ix = t / g.ny;
-  return ((ix + 1) * g.dim[1] + (iy + 1)) * g.dim[2] + (iz + 1);
-}
-
-__global__ void k_cells_inner(int ninner, Geo g, const int *icnt, const int *istart, int *cell_start, int *cell_cnt)
+// cell key -> linear index in the ghost-including cell array
+__global__ void k_cells_inner(int nkeys, Geo g, const int *icnt, const int *istart, int *cell_start, int *cell_cnt)
 {
   int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= ninner) return;
-  int lin = inner_to_lin(r, g);
+  if (r >= nkeys) return;
+  int ix, iy, iz;
+  if (!key_to_xyz(r, g, ix, iy, iz)) return;
+  int lin = ((ix + 1) * g.dim[1] + (iy + 1)) * g.dim[2] + (iz + 1);
   cell_start[lin] = istart[r];
   cell_cnt[lin] = icnt[r];
 }
@@ -268,8 +258,8 @@ __global__ void k_nbl_build(int nlocal, const double4 *pos, const int *acell, co
   if (i < nlocal) {
   double4 pi = pos[i];
   ref[i] = pi.x; ref[cap + i] = pi.y; ref[2 * (size_t) cap + i] = pi.z;
-  int r = acell[i];
-  int iz = r % g.nz, t = r / g.nz, iy = t % g.ny, ix = t / g.ny;
+  int ix, iy, iz;
+  key_to_xyz(acell[i], g, ix, iy, iz);
   for (int dx = -1; dx <= 1; dx++)
     for (int dy = -1; dy <= 1; dy++)
       for (int dz = -1; dz <= 1; dz++) {
@@ -316,15 +306,17 @@ __device__ __forceinline__ bool stencil_cell(int m, int ix, int iy, int iz, cons
 
 template <bool FILL>
 __global__ void k_export_half(int nlocal, const double4 *pos, const int *acell, const int *cell_start,
-                              const int *cell_cnt, Geo g, double cellsz, const int *ref_cl_off, int *tl_or_cnt,
-                              int *tb)
+                              const int *cell_cnt, Geo g, double cellsz, const int *ref_cl_off,
+                              const int *refstart, const int *istart, int *tl_or_cnt, int *tb)
 {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nlocal) return;
   double4 pi = pos[i];
-  int r = acell[i];
-  int iz = r % g.nz, t = r / g.nz, iy = t % g.ny, ix = t / g.ny;
-  int m = 0, out = FILL ? tl_or_cnt[i] : 0;
+  int ix, iy, iz;
+  const int key = acell[i];
+  key_to_xyz(key, g, ix, iy, iz);
+  const int ri = refstart[key] + (i - istart[key]);      // index of this atom in the reference's `cells` order
+  int m = 0, out = FILL ? tl_or_cnt[ri] : 0;
   for (int q = 0; q < 14; q++) {
     int c;
     if (!stencil_cell(q, ix, iy, iz, g, c)) continue;
@@ -340,7 +332,7 @@ __global__ void k_export_half(int nlocal, const double4 *pos, const int *acell, 
       }
     }
   }
-  if (!FILL) tl_or_cnt[i] = m;
+  if (!FILL) tl_or_cnt[ri] = m;
 }
 
 // ---------------------------------------------------------------------------
@@ -669,9 +661,33 @@ extern "C" int imdgpu_set_geometry(imdgpu_ctx *ctx, const double box[9], const i
   ctx->nall_cells = D[0] * D[1] * D[2];
   ctx->ninner_cells = (D[0] - 2) * (D[1] - 2) * (D[2] - 2);
   ctx->nghost_cells = ctx->nall_cells - ctx->ninner_cells;
+  // tiling of the inner cells (one force-kernel workgroup per tile): prefer 3 cells per direction,
+  // pick 2..4 where that leaves no (or a larger) partial tile.  IMDGPU_TILE="bx,by,bz" overrides.
+  for (int d = 0; d < 3; d++) {
+    int n = D[d] - 2, best = 3, bestrem = -1;
+    for (int b : {3, 4, 2}) {
+      if (b > n) continue;
+      int rem = n % b == 0 ? b : n % b;           // size of the last tile
+      if (rem > bestrem) { best = b; bestrem = rem; }
+    }
+    if (n < 2) best = 1;
+    ctx->tile[d] = best;
+  }
+  if (const char *e = getenv("IMDGPU_TILE")) {
+    int a, b, c;
+    if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a > 0 && b > 0 && c > 0) { ctx->tile[0] = a; ctx->tile[1] = b; ctx->tile[2] = c; }
+  }
+  for (int d = 0; d < 3; d++) {
+    if (ctx->tile[d] > D[d] - 2) ctx->tile[d] = D[d] - 2;
+    ctx->ntile[d] = (D[d] - 2 + ctx->tile[d] - 1) / ctx->tile[d];
+  }
+  ctx->CPT = ctx->tile[0] * ctx->tile[1] * ctx->tile[2];
+  ctx->ntiles = ctx->ntile[0] * ctx->ntile[1] * ctx->ntile[2];
+  ctx->nkeys = ctx->ntiles * ctx->CPT;
+  if (const char *e = getenv("IMDGPU_MODE")) ctx->mode = atoi(e);
+  const Geo g0 = make_geo(ctx);
   // static ghost-cell tables: source inner cell (periodic wrap on this rank) and shift code
   std::vector<int> lin, src, sh;
-  const int ny = D[1] - 2, nz = D[2] - 2;
   for (int i = 0; i < D[0]; i++)
     for (int j = 0; j < D[1]; j++)
       for (int k = 0; k < D[2]; k++) {
@@ -688,14 +704,14 @@ extern "C" int imdgpu_set_geometry(imdgpu_ctx *ctx, const double box[9], const i
         }
         if (!ghost) continue;
         lin.push_back((i * D[1] + j) * D[2] + k);
-        src.push_back(active ? ((s[0] - 1) * ny + (s[1] - 1)) * nz + (s[2] - 1) : -1);
+        src.push_back(active ? xyz_to_key(s[0] - 1, s[1] - 1, s[2] - 1, g0) : -1);
         sh.push_back((sc[0] + 1) + 3 * (sc[1] + 1) + 9 * (sc[2] + 1));
       }
   int ng = ctx->nghost_cells;
   if (dev_alloc(ctx, &ctx->gcell_lin, ng) || dev_alloc(ctx, &ctx->gcell_src, ng) || dev_alloc(ctx, &ctx->gcell_shift, ng) ||
       dev_alloc(ctx, &ctx->gcnt, ng + 1) || dev_alloc(ctx, &ctx->gstart, ng + 1) ||
       dev_alloc(ctx, &ctx->cell_start, ctx->nall_cells) || dev_alloc(ctx, &ctx->cell_cnt, ctx->nall_cells) ||
-      dev_alloc(ctx, &ctx->icnt, ctx->ninner_cells + 1) || dev_alloc(ctx, &ctx->istart, ctx->ninner_cells + 1))
+      dev_alloc(ctx, &ctx->icnt, ctx->nkeys + 1) || dev_alloc(ctx, &ctx->istart, ctx->nkeys + 1))
     return 1;
   HIPCHK(hipMemcpy(ctx->gcell_lin, lin.data(), ng * sizeof(int), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(ctx->gcell_src, src.data(), ng * sizeof(int), hipMemcpyHostToDevice));
@@ -803,7 +819,7 @@ static int ensure_atom_capacity(imdgpu_ctx *ctx, int nlocal, int ntot)
 static int build_cells_from_counts(imdgpu_ctx *ctx)
 {
   Geo g = make_geo(ctx);
-  const int ni = ctx->ninner_cells, ng = ctx->nghost_cells;
+  const int ni = ctx->nkeys, ng = ctx->nghost_cells;
   size_t need = 0;
   HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, ctx->icnt, ctx->istart, ni + 1, ctx->stream));
   size_t need2 = 0;
@@ -873,26 +889,31 @@ static int upload_common(imdgpu_ctx *ctx, int n, const double *ort, const double
   return 0;
 }
 
+static int sort_and_build(imdgpu_ctx *ctx);
+
 extern "C" int imdgpu_upload_cells(imdgpu_ctx *ctx, const int *cell_n, int natoms, const double *ort,
                                    const double *impuls, const double *masse, const int *sorte, const int *nummer)
 {
   if (upload_common(ctx, natoms, ort, impuls, masse, sorte, nummer)) return 1;
+  // keys from the host's cell assignment (NOT from positions: atoms may have drifted out of the cell
+  // they are stored in since the host's last fix_cells); the stable device sort keeps the slot order
   const int *D = ctx->dim;
-  std::vector<int> icnt(ctx->ninner_cells + 1, 0), acell(natoms);
-  int r = 0, at = 0;
+  const Geo g = make_geo(ctx);
+  std::vector<int> keys(natoms), perm(natoms);
+  int at = 0;
   for (int i = 1; i < D[0] - 1; i++)
     for (int j = 1; j < D[1] - 1; j++)
       for (int k = 1; k < D[2] - 1; k++) {
         int n = cell_n[(i * D[1] + j) * D[2] + k];
         if (n < 0 || at + n > natoms) return imdgpu_fail(ctx, "cell_n does not add up to natoms=%d", natoms);
-        icnt[r] = n;
-        for (int t = 0; t < n; t++) acell[at + t] = r;
-        at += n; r++;
+        int key = xyz_to_key(i - 1, j - 1, k - 1, g);
+        for (int t = 0; t < n; t++) { keys[at + t] = key; perm[at + t] = at + t; }
+        at += n;
       }
   if (at != natoms) return imdgpu_fail(ctx, "cell_n sums to %d, natoms=%d", at, natoms);
-  HIPCHK(hipMemcpy(ctx->icnt, icnt.data(), icnt.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(ctx->acell, acell.data(), natoms * sizeof(int), hipMemcpyHostToDevice));
-  return build_cells_from_counts(ctx);
+  HIPCHK(hipMemcpy(ctx->keys, keys.data(), natoms * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ctx->perm, perm.data(), natoms * sizeof(int), hipMemcpyHostToDevice));
+  return sort_and_build(ctx);
 }
 
 extern "C" int imdgpu_upload_atoms(imdgpu_ctx *ctx, int natoms, const double *ort, const double *impuls,
@@ -909,19 +930,14 @@ extern "C" int imdgpu_num_atoms(imdgpu_ctx *ctx, int *nlocal, int *nghost)
   return 0;
 }
 
-extern "C" int imdgpu_fix_cells(imdgpu_ctx *ctx)
+// stable sort of the local atoms by cell key (ctx->keys / ctx->perm filled), gather, cell tables
+static int sort_and_build(imdgpu_ctx *ctx)
 {
-  HIPCHK(hipSetDevice(ctx->device));
   const int n = ctx->nlocal, cap = ctx->cap_local;
-  if (n == 0) return imdgpu_fail(ctx, "no atoms uploaded");
-  Geo g = make_geo(ctx);
   {
     ProfScope ps(ctx, PROF_FIXCELLS);
-    HIPCHK(hipMemsetAsync(ctx->d_counters + CNT_OUTSIDE, 0, sizeof(int), ctx->stream));
-    hipLaunchKernelGGL(k_wrap_key, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, n, ctx->pos, g, ctx->keys, ctx->perm,
-                       ctx->d_counters);
     int bits = 1;
-    while ((1 << bits) < ctx->ninner_cells) bits++;
+    while ((1 << bits) < ctx->nkeys) bits++;
     size_t need = 0;
     HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, need, ctx->keys, ctx->keys2, ctx->perm, ctx->perm2, n, 0, bits, ctx->stream));
     if (need > ctx->cub_tmp_bytes) {
@@ -932,14 +948,26 @@ extern "C" int imdgpu_fix_cells(imdgpu_ctx *ctx)
     }
     size_t tb = ctx->cub_tmp_bytes;
     HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cub_tmp, tb, ctx->keys, ctx->keys2, ctx->perm, ctx->perm2, n, 0, bits, ctx->stream));
-    HIPCHK(hipMemsetAsync(ctx->icnt, 0, (ctx->ninner_cells + 1) * sizeof(int), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->icnt, 0, (ctx->nkeys + 1) * sizeof(int), ctx->stream));
     hipLaunchKernelGGL(k_gather_sorted, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, n, cap, ctx->perm2, ctx->keys2,
                        ctx->pos, ctx->pos2, ctx->type, ctx->type2, ctx->id, ctx->id2, ctx->p, ctx->p2, ctx->mass,
                        ctx->mass2, ctx->acell, ctx->icnt);
     std::swap(ctx->pos, ctx->pos2); std::swap(ctx->type, ctx->type2); std::swap(ctx->id, ctx->id2);
     std::swap(ctx->p, ctx->p2); std::swap(ctx->mass, ctx->mass2);
   }
-  if (build_cells_from_counts(ctx)) return 1;
+  return build_cells_from_counts(ctx);
+}
+
+extern "C" int imdgpu_fix_cells(imdgpu_ctx *ctx)
+{
+  HIPCHK(hipSetDevice(ctx->device));
+  const int n = ctx->nlocal;
+  if (n == 0) return imdgpu_fail(ctx, "no atoms uploaded");
+  Geo g = make_geo(ctx);
+  HIPCHK(hipMemsetAsync(ctx->d_counters + CNT_OUTSIDE, 0, sizeof(int), ctx->stream));
+  hipLaunchKernelGGL(k_wrap_key, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, n, ctx->pos, g, ctx->keys, ctx->perm,
+                     ctx->d_counters);
+  if (sort_and_build(ctx)) return 1;
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipMemcpy(ctx->h_counters, ctx->d_counters, CNT_N * sizeof(int), hipMemcpyDeviceToHost));
   if (ctx->h_counters[CNT_OUTSIDE] > 0 && (ctx->cpu_dim[0] * ctx->cpu_dim[1] * ctx->cpu_dim[2] > 1))
@@ -1155,6 +1183,26 @@ extern "C" int imdgpu_get_sums(imdgpu_ctx *ctx, double sums[8], double *ekin, in
   return 0;
 }
 
+// perm[r] = device index of the atom that is r-th in the reference's cell order (`cells` list: x outer,
+// z inner; slots inside a cell as on the device); refstart[key] = first r of that cell
+static int build_ref_perm(imdgpu_ctx *ctx, std::vector<int> *perm, std::vector<int> *refstart)
+{
+  const Geo g = make_geo(ctx);
+  std::vector<int> ic(ctx->nkeys + 1), is(ctx->nkeys + 1);
+  HIPCHK(hipMemcpy(ic.data(), ctx->icnt, ic.size() * sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(is.data(), ctx->istart, is.size() * sizeof(int), hipMemcpyDeviceToHost));
+  if (perm) perm->resize(ctx->nlocal);
+  if (refstart) refstart->assign(ctx->nkeys + 1, 0);
+  int r = 0;
+  for (int ix = 0; ix < g.nx; ix++) for (int iy = 0; iy < g.ny; iy++) for (int iz = 0; iz < g.nz; iz++) {
+    int key = xyz_to_key(ix, iy, iz, g);
+    if (refstart) (*refstart)[key] = r;
+    for (int t = 0; t < ic[key]; t++, r++) if (perm) (*perm)[r] = is[key] + t;
+  }
+  if (r != ctx->nlocal) return imdgpu_fail(ctx, "internal: cell tables hold %d atoms, nlocal=%d", r, ctx->nlocal);
+  return 0;
+}
+
 extern "C" int imdgpu_download_atoms(imdgpu_ctx *ctx, int *cell_n, double *ort, double *impuls, double *kraft,
                                      double *pot_eng, double *eam_rho, double *eam_dF, int *numneighs, int *nummer,
                                      int *sorte, double *nbl_pos)
@@ -1162,6 +1210,8 @@ extern "C" int imdgpu_download_atoms(imdgpu_ctx *ctx, int *cell_n, double *ort, 
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   const int n = ctx->nlocal, cap = ctx->cap_local;
+  std::vector<int> perm;
+  if (build_ref_perm(ctx, &perm, nullptr)) return 1;
   if (cell_n) {
     std::vector<int> cc(ctx->nall_cells);
     HIPCHK(hipMemcpy(cc.data(), ctx->cell_cnt, cc.size() * sizeof(int), hipMemcpyDeviceToHost));
@@ -1174,26 +1224,39 @@ extern "C" int imdgpu_download_atoms(imdgpu_ctx *ctx, int *cell_n, double *ort, 
   if (ort || eam_dF) {
     std::vector<double4> hp(n);
     HIPCHK(hipMemcpy(hp.data(), ctx->pos, n * sizeof(double4), hipMemcpyDeviceToHost));
-    for (int i = 0; i < n; i++) {
-      if (ort) { ort[3 * i] = hp[i].x; ort[3 * i + 1] = hp[i].y; ort[3 * i + 2] = hp[i].z; }
-      if (eam_dF) eam_dF[i] = hp[i].w;
+    for (int r = 0; r < n; r++) {
+      const double4 &q = hp[perm[r]];
+      if (ort) { ort[3 * r] = q.x; ort[3 * r + 1] = q.y; ort[3 * r + 2] = q.z; }
+      if (eam_dF) eam_dF[r] = q.w;
     }
   }
   auto planes = [&](const double *dev, double *out) -> int {
     std::vector<double> h(3 * (size_t) n);
     for (int d = 0; d < 3; d++)
       HIPCHK(hipMemcpy(h.data() + (size_t) d * n, dev + (size_t) d * cap, n * sizeof(double), hipMemcpyDeviceToHost));
-    for (int i = 0; i < n; i++) for (int d = 0; d < 3; d++) out[3 * i + d] = h[(size_t) d * n + i];
+    for (int r = 0; r < n; r++) for (int d = 0; d < 3; d++) out[3 * r + d] = h[(size_t) d * n + perm[r]];
+    return 0;
+  };
+  auto scal_d = [&](const double *dev, double *out) -> int {
+    std::vector<double> h(n);
+    HIPCHK(hipMemcpy(h.data(), dev, n * sizeof(double), hipMemcpyDeviceToHost));
+    for (int r = 0; r < n; r++) out[r] = h[perm[r]];
+    return 0;
+  };
+  auto scal_i = [&](const int *dev, int *out) -> int {
+    std::vector<int> h(n);
+    HIPCHK(hipMemcpy(h.data(), dev, n * sizeof(int), hipMemcpyDeviceToHost));
+    for (int r = 0; r < n; r++) out[r] = h[perm[r]];
     return 0;
   };
   if (impuls && planes(ctx->p, impuls)) return 1;
   if (kraft && planes(ctx->f, kraft)) return 1;
   if (nbl_pos && planes(ctx->ref, nbl_pos)) return 1;
-  if (pot_eng) HIPCHK(hipMemcpy(pot_eng, ctx->epot, n * sizeof(double), hipMemcpyDeviceToHost));
-  if (eam_rho) HIPCHK(hipMemcpy(eam_rho, ctx->rhoh, n * sizeof(double), hipMemcpyDeviceToHost));
-  if (numneighs) HIPCHK(hipMemcpy(numneighs, ctx->numneighs, n * sizeof(int), hipMemcpyDeviceToHost));
-  if (nummer) HIPCHK(hipMemcpy(nummer, ctx->id, n * sizeof(int), hipMemcpyDeviceToHost));
-  if (sorte) HIPCHK(hipMemcpy(sorte, ctx->type, n * sizeof(int), hipMemcpyDeviceToHost));
+  if (pot_eng && scal_d(ctx->epot, pot_eng)) return 1;
+  if (eam_rho && scal_d(ctx->rhoh, eam_rho)) return 1;
+  if (numneighs && scal_i(ctx->numneighs, numneighs)) return 1;
+  if (nummer && scal_i(ctx->id, nummer)) return 1;
+  if (sorte && scal_i(ctx->type, sorte)) return 1;
   return 0;
 }
 
@@ -1219,14 +1282,18 @@ extern "C" int imdgpu_export_nblist(imdgpu_ctx *ctx, int *tl, int *tb, int *cl_o
     off[c] = at; at += cnt;
   }
   if (cl_off) memcpy(cl_off, off.data(), nall * sizeof(int));
-  int *d_off = nullptr, *d_tl = nullptr, *d_tb = nullptr;
+  int *d_off = nullptr, *d_tl = nullptr, *d_tb = nullptr, *d_rs = nullptr;
   Geo g = make_geo(ctx);
+  std::vector<int> refstart;
+  if (build_ref_perm(ctx, nullptr, &refstart)) return 1;
+  HIPCHK(hipMalloc((void **) &d_rs, refstart.size() * sizeof(int)));
+  HIPCHK(hipMemcpy(d_rs, refstart.data(), refstart.size() * sizeof(int), hipMemcpyHostToDevice));
   HIPCHK(hipMalloc((void **) &d_off, nall * sizeof(int)));
   HIPCHK(hipMalloc((void **) &d_tl, (n + 1) * sizeof(int)));
   HIPCHK(hipMemcpy(d_off, off.data(), nall * sizeof(int), hipMemcpyHostToDevice));
   HIPCHK(hipMemset(d_tl, 0, (n + 1) * sizeof(int)));
   hipLaunchKernelGGL((k_export_half<false>), dim3(nblk(n, 128)), dim3(128), 0, ctx->stream, n, ctx->pos, ctx->acell,
-                     ctx->cell_start, ctx->cell_cnt, g, ctx->cellsz, d_off, d_tl, (int *) nullptr);
+                     ctx->cell_start, ctx->cell_cnt, g, ctx->cellsz, d_off, d_rs, ctx->istart, d_tl, (int *) nullptr);
   size_t need = 0;
   HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, d_tl, d_tl, n + 1, ctx->stream));
   void *tmp = nullptr;
@@ -1240,12 +1307,12 @@ extern "C" int imdgpu_export_nblist(imdgpu_ctx *ctx, int *tl, int *tb, int *cl_o
   if (tb) {
     HIPCHK(hipMalloc((void **) &d_tb, (size_t) (total + 1) * sizeof(int)));
     hipLaunchKernelGGL((k_export_half<true>), dim3(nblk(n, 128)), dim3(128), 0, ctx->stream, n, ctx->pos, ctx->acell,
-                       ctx->cell_start, ctx->cell_cnt, g, ctx->cellsz, d_off, d_tl, d_tb);
+                       ctx->cell_start, ctx->cell_cnt, g, ctx->cellsz, d_off, d_rs, ctx->istart, d_tl, d_tb);
     HIPCHK(hipStreamSynchronize(ctx->stream));       // ctx->stream is non-blocking w.r.t. the null stream
     HIPCHK(hipMemcpy(tb, d_tb, (size_t) total * sizeof(int), hipMemcpyDeviceToHost));
     (void) hipFree(d_tb);
   }
-  (void) hipFree(tmp); (void) hipFree(d_off); (void) hipFree(d_tl);
+  (void) hipFree(tmp); (void) hipFree(d_off); (void) hipFree(d_tl); (void) hipFree(d_rs);
   return 0;
 }
 

@@ -42,6 +42,7 @@ struct imdgpu_ctx {
   double box[9]{}, tbox[9]{};
   int pbc[3]{1, 1, 1}, dim[3]{}, gdim[3]{}, cpu_dim[3]{1, 1, 1}, my_coord[3]{};
   int nall_cells = 0, ninner_cells = 0, nghost_cells = 0;
+  int tile[3]{3, 3, 3}, ntile[3]{}, ntiles = 0, CPT = 0, nkeys = 0;   // tiling of the inner cells
   bool have_geometry = false;
 
   // parameters -------------------------------------------------------------
@@ -78,9 +79,13 @@ struct imdgpu_ctx {
   int *d_counters = nullptr;                        // misc device ints (see kernels)
   int *h_counters = nullptr;                        // pinned mirror
 
-  // neighbour list (full, ELL transposed: nbr[k*stride+i]) -------------------
+  // neighbour list, full (symmetric).  mode 0: ELL transposed int32 global indices
+  // nbr[k*stride+i]; mode 1: per tile, uint16 LDS-slot indices tl16[(tile*W+k)*tile_cap+a]
+  int mode = 1;
   int *nbr = nullptr, *nbr_cnt = nullptr;
+  unsigned short *nbr16 = nullptr; size_t nbr16_cap = 0;
   int W = 0; size_t stride = 0; size_t nbr_cap = 0;
+  int tile_cap = 0, max_halo = 0, slot_cap = 0, tile_threads = 0;
   int have_valid_nbl = 0, nbl_count = 0, need_fix_cells = 0;
 
   // reductions -----------------------------------------------------------------
@@ -123,8 +128,39 @@ static inline int dev_alloc(imdgpu_ctx *ctx, T **p, size_t n)
   return 0;
 }
 
+// ---------------------------------------------------------------------------
+// geometry passed to kernels by value.  Local atoms are kept sorted by a
+// TILE-MAJOR cell key: the inner cells are grouped into tiles of bx*by*bz cells
+// (one workgroup of the force kernels per tile); key = tile*CPT + cell-in-tile,
+// both z fastest.  Partial tiles at the upper faces leave some keys unused.
+// ---------------------------------------------------------------------------
+struct Geo {
+  double box[9], tbox[9];
+  int pbc[3], gdim[3], dim[3], my_coord[3];
+  int nx, ny, nz;                   // inner cells per direction (dim-2)
+  int bx, by, bz, ntx, nty, ntz, CPT, nkeys;
+};
+
+__host__ __device__ __forceinline__ int xyz_to_key(int ix, int iy, int iz, const Geo &g)
+{
+  int tx = ix / g.bx, ty = iy / g.by, tz = iz / g.bz;
+  int lx = ix - tx * g.bx, ly = iy - ty * g.by, lz = iz - tz * g.bz;
+  return ((tx * g.nty + ty) * g.ntz + tz) * g.CPT + (lx * g.by + ly) * g.bz + lz;
+}
+// returns false for keys of cells that do not exist (partial tiles)
+__host__ __device__ __forceinline__ bool key_to_xyz(int key, const Geo &g, int &ix, int &iy, int &iz)
+{
+  int tile = key / g.CPT, cit = key - tile * g.CPT;
+  int lz = cit % g.bz, q = cit / g.bz, ly = q % g.by, lx = q / g.by;
+  int tz = tile % g.ntz, r = tile / g.ntz, ty = r % g.nty, tx = r / g.nty;
+  ix = tx * g.bx + lx; iy = ty * g.by + ly; iz = tz * g.bz + lz;
+  return ix < g.nx && iy < g.ny && iz < g.nz;
+}
+Geo imdgpu_make_geo(const imdgpu_ctx *c);
+
 // device counters (ints) and d_sums slots shared by the translation units
-enum { CNT_MAXNBR = 0, CNT_IS_SHORT = 1, CNT_OUTSIDE = 2, CNT_NGHOST = 3, CNT_INVALID = 4, CNT_N = 16 };
+enum { CNT_MAXNBR = 0, CNT_IS_SHORT = 1, CNT_OUTSIDE = 2, CNT_NGHOST = 3, CNT_INVALID = 4, CNT_MAXOWN = 5,
+       CNT_MAXHALO = 6, CNT_N = 16 };
 enum { SUM_EPOT = 0, SUM_VIRIAL = 1, SUM_EKIN = 8, SUM_MAXDISP = 9, SUM_N = 16 };
 
 // sum of kinetic partials, max of displacement partials; decides list validity

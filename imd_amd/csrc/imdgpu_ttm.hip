@@ -384,7 +384,7 @@ __global__ void k_ttm_cfl(Lat L, const int *natoms, const double *fd_k, const do
 
 // move_atoms_ttm (imd_integrate.c:581-811, 3D branch) + check_nblist fused:
 // xi of the atom's FD cell if that cell is active, p += dt (F + xi m (p/m - vcom))
-__global__ void k_move_ttm(int n, int cap, Lat L, int ny, int nz, double4 *pos, const int *type, const int *acell,
+__global__ void k_move_ttm(int n, int cap, Lat L, Geo g, double4 *pos, const int *type, const int *acell,
                            double *p, double *f, const double *mass, const double *restr, int ntypes, double dt,
                            const double *ref, const int *natoms, const double *xi, const double *vcom, int ncell,
                            double *partials)
@@ -394,8 +394,8 @@ __global__ void k_move_ttm(int n, int cap, Lat L, int ny, int nz, double4 *pos, 
   double s0 = 0, s1 = 0;
   if (i < n) {
     const size_t c1 = cap, c2 = 2 * (size_t) cap;
-    int r = acell[i];
-    int iz = r % nz, tq = r / nz, iy = tq % ny, ix = tq / ny;
+    int ix, iy, iz;
+    key_to_xyz(acell[i], g, ix, iy, iz);
     int fc = fidx(L, ix / L.ext[0] + 1, iy / L.ext[1] + 1, iz / L.ext[2] + 1);
     double fxi = natoms[fc] >= L.fd_min_atoms ? xi[fc] : 0.0;
     double vx = vcom[fc], vy = vcom[ncell + fc], vz = vcom[2 * ncell + fc];
@@ -673,7 +673,7 @@ static int launch_move_ttm(imdgpu_ctx *ctx, double limit2)
   NEED_TTM();
   const int n = ctx->nlocal, nb = nblk(n, 256);
   ProfScope ps(ctx, PROF_INTEGRATE);
-  hipLaunchKernelGGL(k_move_ttm, dim3(nb), dim3(256), 0, ctx->stream, n, ctx->cap_local, L, ctx->dim[1] - 2, ctx->dim[2] - 2,
+  hipLaunchKernelGGL(k_move_ttm, dim3(nb), dim3(256), 0, ctx->stream, n, ctx->cap_local, L, imdgpu_make_geo(ctx),
                      ctx->pos, ctx->type, ctx->acell, ctx->p, ctx->f, ctx->mass, ctx->d_restr, ctx->ntypes, ctx->timestep,
                      ctx->ref, t->natoms, t->xi, t->vcom, t->ncell, ctx->partials);
   hipLaunchKernelGGL(k_reduce_move, dim3(1), dim3(1024), 0, ctx->stream, nb, ctx->partials, ctx->d_sums, limit2,
