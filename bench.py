@@ -174,6 +174,10 @@ def main():
                                     "NVE, no TTM" if args.no_ttm else "3D TTM fd_ext 2 2 2, diff_substeps 100"),
                        "atoms_per_gpu": natoms, "cells": list(gdim), "half_list_entries_per_atom": M,
                        "max_neighbours": maxn, "list_rebuilds_in_timed_region": rebuilds,
+                       "kernel_family": "lds_tiles" if sysm.get_info("list_mode") == 1 else "global_gather",
+                       "tile": [sysm.get_info("tile_x"), sysm.get_info("tile_y"), sysm.get_info("tile_z")],
+                       "tile_info": {k: sysm.get_info(k) for k in ("ntiles", "tile_cap", "slot_cap", "max_halo",
+                                                                   "tile_threads", "lds_pass1", "lds_pass3", "W")},
                        "parallelism": "1 rank/GPU spatial decomposition" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "k_pass1 (pair+rho)", "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,

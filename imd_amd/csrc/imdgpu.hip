@@ -353,8 +353,17 @@ struct ForceArgs {
 
 __device__ __forceinline__ void lds_load_table(double *dst, const TabPar &t)
 {
-  int n = t.nrows * t.ncols;
-  for (int k = threadIdx.x; k < n; k += blockDim.x) dst[k] = t.tab[k];
+  const int n = t.nrows * t.ncols, n2 = n >> 1;
+  const double2 *src2 = (const double2 *) t.tab;          // hipMalloc'ed: 16-byte aligned
+  double2 *dst2 = (double2 *) dst;
+  for (int k = threadIdx.x; k < n2; k += 4 * blockDim.x) {
+    double2 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { int q = k + u * blockDim.x; if (q < n2) v[u] = src2[q]; }
+#pragma unroll
+    for (int u = 0; u < 4; u++) { int q = k + u * blockDim.x; if (q < n2) dst2[q] = v[u]; }
+  }
+  if ((n & 1) && threadIdx.x == 0) dst[n - 1] = t.tab[n - 1];
 }
 
 // Pass 1: pair energy/force, host electron density, TTM neighbour count
@@ -490,6 +499,485 @@ __global__ __launch_bounds__(512) void k_pass3(ForceArgs a)
   if (is_short) a.counters[CNT_IS_SHORT] = 1;
 }
 
+// ===========================================================================
+// LDS-tiled force path (mode 1).  One workgroup per tile of bx*by*bz inner cells:
+// the positions (pass 3: + dF) of the tile and its one-cell halo are staged once
+// into LDS with coalesced loads, the potential tables sit next to them, and the
+// neighbour list holds 16-bit LDS slot numbers (4 per 8-byte load, ELL-transposed
+// per tile).  HBM sees: list (2 B/entry), own-atom outputs, one staging pass.
+// ===========================================================================
+#define NH_MAX 512                                   // halo cells per tile (<= 6*6*6 = 216 for tiles up to 4^3)
+
+struct TileArgs {
+  int nlocal, ntypes, cap, W4, tile_cap, slot_cap, ntiles;
+  Geo g;
+  const double4 *pos;
+  const int *type, *acell, *cell_start, *cell_cnt, *istart;
+  ushort4 *nbr16;
+  int *nbr_cnt;
+  TabPar pair, rho;
+  double *f, *epot, *rhoh, *ref;
+  int *numneighs;
+  double *partials;
+  int *counters;
+  double cellsz;
+};
+
+struct TileCtx { int tile, hx, hy, hz, nh, own_start, nown; };
+
+// Persistent workgroups: block b works on a contiguous range of tiles [t0,t1) (consecutive tiles are
+// neighbours along z, so their halos overlap in L2), and the blocks that share an XCD (b % 8 under the
+// observed round-robin placement; speed only) get adjacent ranges.
+__device__ __forceinline__ void block_tile_range(int ntiles, int &t0, int &t1)
+{
+  const int nwg = gridDim.x, per = nwg >> 3, b = blockIdx.x;
+  const int p = (nwg & 7) == 0 ? (b & 7) * per + (b >> 3) : b;
+  const int chunk = (ntiles + nwg - 1) / nwg;
+  t0 = p * chunk; t1 = t0 + chunk;
+  if (t0 > ntiles) t0 = ntiles;
+  if (t1 > ntiles) t1 = ntiles;
+}
+
+// halo-cell table + prefix (hstart/hsrc) and staging of positions into LDS as AoS records of NC doubles
+// (NC = 3: x,y,z; NC = 4: x,y,z,dF).  The last slot (slot_cap-1) is a far-away dummy that pads the
+// neighbour list, so the inner loops need no "valid entry" test.  All threads of the block call it.
+template <int NC, bool WITH_T>
+__device__ __forceinline__ void tile_stage(const TileArgs &a, TileCtx &T, double *sp, int *ts, int *hstart, int *hsrc)
+{
+  const Geo &g = a.g;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int tz = T.tile % g.ntz, q = T.tile / g.ntz, ty = q % g.nty, tx = q / g.nty;
+  T.hx = g.bx + 2; T.hy = g.by + 2; T.hz = g.bz + 2; T.nh = T.hx * T.hy * T.hz;
+  for (int h = tid; h < T.nh; h += nthr) {
+    int c = h % T.hz, r = h / T.hz, b = r % T.hy, aa = r / T.hy;
+    int fx = tx * g.bx + aa, fy = ty * g.by + b, fz = tz * g.bz + c;
+    int cnt = 0, src = 0;
+    if (fx < g.dim[0] && fy < g.dim[1] && fz < g.dim[2]) {
+      int lin = (fx * g.dim[1] + fy) * g.dim[2] + fz;
+      cnt = a.cell_cnt[lin]; src = a.cell_start[lin];
+    }
+    hstart[h + 1] = cnt; hsrc[h] = src;
+  }
+  if (tid == 0) {
+    double *d = sp + (size_t) (a.slot_cap - 1) * NC;
+    d[0] = 1e150; d[1] = 1e150; d[2] = 1e150;
+    if (NC == 4) d[3] = 0.0;
+    if (WITH_T) ts[a.slot_cap - 1] = 0;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    int carry = 0;
+    for (int base = 0; base < T.nh; base += 64) {
+      int idx = base + tid, v = idx < T.nh ? hstart[idx + 1] : 0;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(v, o, 64); if (tid >= o) v += t; }
+      if (idx < T.nh) hstart[idx + 1] = v + carry;
+      carry += __shfl(v, 63, 64);
+    }
+    if (tid == 0) hstart[0] = 0;
+  }
+  __syncthreads();
+  // one half-wave per halo cell, four cells in flight per half-wave
+  const int hw = tid >> 5, l = tid & 31, nhw = nthr >> 5;
+  for (int h0 = hw; h0 < T.nh; h0 += 4 * nhw) {
+    double4 p[4]; int sl[4], tt[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      int h = h0 + u * nhw;
+      sl[u] = -1;
+      if (h < T.nh) {
+        int s = hstart[h], n = hstart[h + 1] - s;
+        if (l < n && s + l < a.slot_cap - 1) { sl[u] = s + l; p[u] = a.pos[hsrc[h] + l]; if (WITH_T) tt[u] = a.type[hsrc[h] + l]; }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (sl[u] >= 0) {
+        double *d = sp + (size_t) sl[u] * NC;
+        d[0] = p[u].x; d[1] = p[u].y; d[2] = p[u].z;
+        if (NC == 4) d[3] = p[u].w;
+        if (WITH_T) ts[sl[u]] = tt[u];
+      }
+  }
+  for (int h = hw; h < T.nh; h += nhw) {                    // rare: cells with more than 32 atoms
+    int s = hstart[h], n = hstart[h + 1] - s, src = hsrc[h];
+    for (int e = l + 32; e < n; e += 32)
+      if (s + e < a.slot_cap - 1) {
+        double4 q = a.pos[src + e];
+        double *d = sp + (size_t) (s + e) * NC;
+        d[0] = q.x; d[1] = q.y; d[2] = q.z;
+        if (NC == 4) d[3] = q.w;
+        if (WITH_T) ts[s + e] = a.type[src + e];
+      }
+  }
+  T.own_start = a.istart[T.tile * g.CPT];
+  T.nown = a.istart[(T.tile + 1) * g.CPT] - T.own_start;
+  __syncthreads();
+}
+
+// LDS slot of own atom i (global index) and the halo coordinates of its cell
+__device__ __forceinline__ int own_slot(const TileArgs &a, const TileCtx &T, int i, const int *hstart, const int *hsrc,
+                                        int &lx, int &ly, int &lz)
+{
+  const Geo &g = a.g;
+  int cit = a.acell[i] - T.tile * g.CPT;
+  lz = cit % g.bz; int q = cit / g.bz; ly = q % g.by; lx = q / g.by;
+  int h = ((lx + 1) * T.hy + (ly + 1)) * T.hz + (lz + 1);
+  return hstart[h] + (i - hsrc[h]);
+}
+
+// per tile: own atoms and staged atoms, for sizing tile_cap / slot_cap
+__global__ void k_tile_stats(int ntiles, Geo g, const int *cell_cnt, const int *istart, int *counters)
+{
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  int own = 0, halo = 0;
+  if (t < ntiles) {
+    own = istart[(t + 1) * g.CPT] - istart[t * g.CPT];
+    int tz = t % g.ntz, q = t / g.ntz, ty = q % g.nty, tx = q / g.nty;
+    for (int aa = 0; aa < g.bx + 2; aa++) for (int b = 0; b < g.by + 2; b++) for (int c = 0; c < g.bz + 2; c++) {
+      int fx = tx * g.bx + aa, fy = ty * g.by + b, fz = tz * g.bz + c;
+      if (fx < g.dim[0] && fy < g.dim[1] && fz < g.dim[2]) halo += cell_cnt[(fx * g.dim[1] + fy) * g.dim[2] + fz];
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    int v = __shfl_down(own, o, 64); own = v > own ? v : own;
+    v = __shfl_down(halo, o, 64); halo = v > halo ? v : halo;
+  }
+  if ((threadIdx.x & 63) == 0) { atomicMax(&counters[CNT_MAXOWN], own); atomicMax(&counters[CNT_MAXHALO], halo); }
+}
+
+// Verlet list build, tile form.  Same predicate / same candidate order as k_nbl_build.
+__global__ __launch_bounds__(1024) void k_nbl_build_tile(TileArgs a)
+{
+  extern __shared__ double lds[];
+  double *sp = lds;
+  int *hstart = (int *) (sp + 3 * (size_t) a.slot_cap), *hsrc = hstart + NH_MAX + 1;
+  TileCtx T;
+  int t0, t1;
+  block_tile_range(a.ntiles, t0, t1);
+  const unsigned short dummy = (unsigned short) (a.slot_cap - 1);
+  int mmax = 0;
+  for (T.tile = t0; T.tile < t1; T.tile++) {
+  __syncthreads();
+  tile_stage<3, false>(a, T, sp, nullptr, hstart, hsrc);
+  for (int o = threadIdx.x; o < T.nown; o += blockDim.x) {
+    const int i = T.own_start + o;
+    int lx, ly, lz;
+    const int slot = own_slot(a, T, i, hstart, hsrc, lx, ly, lz);
+    const double xi = sp[3 * slot], yi = sp[3 * slot + 1], zi = sp[3 * slot + 2];
+    a.ref[i] = xi; a.ref[a.cap + i] = yi; a.ref[2 * (size_t) a.cap + i] = zi;
+    ushort4 *lp = a.nbr16 + (size_t) T.tile * a.W4 * a.tile_cap + o;
+    unsigned short buf[4] = {dummy, dummy, dummy, dummy};
+    int m = 0;
+    for (int dx = 0; dx <= 2; dx++)
+      for (int dy = 0; dy <= 2; dy++)
+        for (int dz = 0; dz <= 2; dz++) {
+          int h = ((lx + dx) * T.hy + (ly + dy)) * T.hz + (lz + dz);
+          int s = hstart[h], e = hstart[h + 1];
+          for (int j = s; j < e; j++) {
+            if (j == slot) continue;
+            double ex = sp[3 * j] - xi, ey = sp[3 * j + 1] - yi, ez = sp[3 * j + 2] - zi;
+            double r2 = ex * ex + ey * ey + ez * ez;
+            if (r2 < a.cellsz) {
+              buf[m & 3] = (unsigned short) j;
+              m++;
+              if ((m & 3) == 0) {
+                if ((m >> 2) <= a.W4) lp[(size_t) ((m >> 2) - 1) * a.tile_cap] = make_ushort4(buf[0], buf[1], buf[2], buf[3]);
+                buf[0] = buf[1] = buf[2] = buf[3] = dummy;
+              }
+            }
+          }
+        }
+    if ((m & 3) != 0 && (m >> 2) < a.W4) lp[(size_t) (m >> 2) * a.tile_cap] = make_ushort4(buf[0], buf[1], buf[2], buf[3]);
+    a.nbr_cnt[i] = m < 4 * a.W4 ? m : 4 * a.W4;
+    mmax = m > mmax ? m : mmax;
+  }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { int v = __shfl_down(mmax, o, 64); mmax = v > mmax ? v : mmax; }
+  if ((threadIdx.x & 63) == 0 && mmax > 0) atomicMax(&a.counters[CNT_MAXNBR], mmax);
+}
+
+// ---- inner loops of the tiled kernels ------------------------------------------------------------
+// Branch-free and written in phases over UNR neighbours (all LDS reads of a phase are issued
+// back-to-back, then the arithmetic), because with one ~140 KB workgroup per CU only ~3 waves per
+// SIMD are resident and instruction-level parallelism has to hide the LDS latency.
+// Table interpolation = PAIR_INT2 / VAL_FUNC2 / DERIV_FUNC2 (potaccess.h:323-354,465-495,591-621) with
+// the argument clamped into the table (2 pad rows, imd_potential.c:1272) and the result masked by the
+// cut-off test.  Products may fuse into FMAs here (relative change ~1e-16); the squared distance and
+// every cut-off comparison use the reference's unfused expression.
+#define TILE_MAXTHREADS 768
+#define UNR 4
+
+struct TabK { double begin, end, istep, istep2; };      // one column of a table (NT1 fast path)
+
+__device__ __forceinline__ void tab_index(const TabK &c, double arg, int &k, double &chi)
+{
+  double a = fmax(fmin(arg, c.end) - c.begin, 0.0) * c.istep;
+  k = (int) a;
+  chi = a - (double) k;
+}
+
+// list word prefetch: the asm pins the use of the loaded value (and so the s_waitcnt) behind the
+// work on the current group of neighbours
+__device__ __forceinline__ uint2 pin_u2(uint2 v) { asm volatile("" : "+v"(v.x), "+v"(v.y)); return v; }
+
+template <bool PAIR, bool EAM, bool TTMN, bool NT1>
+__global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile(TileArgs a)
+{
+  extern __shared__ double lds[];
+  double *tp = lds;
+  double *tr = tp + (PAIR ? a.pair.nrows * a.pair.ncols : 0);
+  double *sp = tr + (EAM ? a.rho.nrows * a.rho.ncols : 0);
+  double *scratch = sp + 3 * (size_t) a.slot_cap;
+  int *hstart = (int *) (scratch + 64), *hsrc = hstart + NH_MAX + 1, *ts = hsrc + NH_MAX;
+  TileCtx T;
+  int t0, t1;
+  block_tile_range(a.ntiles, t0, t1);
+  double sums[2] = {0.0, 0.0};
+  int is_short = 0;
+  if (t0 < t1) {                                 // tables are loaded once per (persistent) workgroup
+    if (PAIR) lds_load_table(tp, a.pair);
+    if (EAM) lds_load_table(tr, a.rho);
+  }
+  for (T.tile = t0; T.tile < t1; T.tile++) {     // uniform per block
+    __syncthreads();
+    tile_stage<3, !NT1>(a, T, sp, ts, hstart, hsrc);
+    const int nt = a.ntypes, inc = NT1 ? 1 : nt * nt;
+    const double pend0 = PAIR ? a.pair.end[0] : 0.0;
+    const TabK cp = {a.pair.begin[0], a.pair.end[0], a.pair.invstep[0], 2 * a.pair.invstep[0]};
+    const TabK cr = {a.rho.begin[0], a.rho.end[0], a.rho.invstep[0], 2 * a.rho.invstep[0]};
+    for (int o = threadIdx.x; o < T.nown; o += blockDim.x) {
+      const int i = T.own_start + o;
+      int lx, ly, lz;
+      const int slot = own_slot(a, T, i, hstart, hsrc, lx, ly, lz);
+      const double xi = sp[3 * slot], yi = sp[3 * slot + 1], zi = sp[3 * slot + 2];
+      const int it = NT1 ? 0 : ts[slot];
+      const int n4 = (a.nbr_cnt[i] + 3) >> 2;
+      const uint2 *lp = (const uint2 *) (a.nbr16 + (size_t) T.tile * a.W4 * a.tile_cap + o);
+      double fx = 0, fy = 0, fz = 0, ee = 0, rr = 0, vir = 0, r2min = 1e300;
+      int nb = 0;
+      // list words: PFD groups of four slots in flight (only ~3 waves/SIMD are resident, so the HBM stream
+      // of the list needs memory-level parallelism from each wave)
+      // two list words (8 slots) are consumed per trip while the next two are in flight; lanes past their
+      // own count get the dummy word
+      const unsigned dw = (unsigned) (a.slot_cap - 1) * 0x10001u;
+      const uint2 dummyw = make_uint2(dw, dw);
+      uint2 c0 = n4 > 0 ? lp[0] : dummyw, c1 = n4 > 1 ? lp[(size_t) a.tile_cap] : dummyw, m0 = dummyw, m1 = dummyw;
+      for (int k4 = 0; k4 < n4; k4++) {
+        if ((k4 & 1) == 0) {                                               // even trip: issue the next pair of loads
+          m0 = k4 + 2 < n4 ? lp[(size_t) (k4 + 2) * a.tile_cap] : dummyw;
+          m1 = k4 + 3 < n4 ? lp[(size_t) (k4 + 3) * a.tile_cap] : dummyw;
+        }
+        const uint2 cur = (k4 & 1) ? c1 : c0;
+        if (k4 & 1) { c0 = m0; c1 = m1; }                                  // odd trip: hand over (loads are ~8 neighbours old)
+        const int j[UNR] = {(int) (cur.x & 0xffffu), (int) (cur.x >> 16), (int) (cur.y & 0xffffu), (int) (cur.y >> 16)};
+        double dx[UNR], dy[UNR], dz[UNR], r2[UNR];
+#pragma unroll
+        for (int e = 0; e < UNR; e++) {                                   // phase 1: positions from LDS, all reads first
+          const double *pj = sp + 3 * j[e];
+          dx[e] = pj[0]; dy[e] = pj[1]; dz[e] = pj[2];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < UNR; e++) {
+          dx[e] -= xi; dy[e] -= yi; dz[e] -= zi;
+          r2[e] = dx[e] * dx[e] + dy[e] * dy[e] + dz[e] * dz[e];          // unfused: the reference's r2
+        }
+        if (NT1) {
+          int kp[UNR], kr[UNR];
+          double cp_[UNR], cr_[UNR], P0[UNR], P1[UNR], P2[UNR], R0[UNR], R1[UNR], R2[UNR];
+#pragma unroll
+          for (int e = 0; e < UNR; e++) {                                 // phase 2: table indices, then all row reads
+            r2min = fmin(r2min, r2[e]);
+            if (PAIR) tab_index(cp, r2[e], kp[e], cp_[e]);
+            if (EAM) tab_index(cr, r2[e], kr[e], cr_[e]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int e = 0; e < UNR; e++) {
+            if (PAIR) { P0[e] = tp[kp[e]]; P1[e] = tp[kp[e] + 1]; P2[e] = tp[kp[e] + 2]; }
+            if (EAM) { R0[e] = tr[kr[e]]; R1[e] = tr[kr[e] + 1]; R2[e] = tr[kr[e] + 2]; }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int e = 0; e < UNR; e++) {                                 // phase 3: arithmetic
+#pragma clang fp contract(fast)
+            if (TTMN) nb += (r2[e] <= pend0) ? 1 : 0;
+            if (PAIR) {
+              const double chi = cp_[e], dv = P1[e] - P0[e], d2v = (P2[e] - 2 * P1[e]) + P0[e];
+              const double pot = P0[e] + chi * dv + (0.5 * chi) * (chi - 1) * d2v;     // = 0 at/after the cut-off (shifted table)
+              double grad = cp.istep2 * (dv + (chi - 0.5) * d2v);
+              grad = (r2[e] <= cp.end) ? grad : 0.0;
+              fx += dx[e] * grad; fy += dy[e] * grad; fz += dz[e] * grad;
+              ee += (r2[e] <= cp.end) ? 0.5 * pot : 0.0;
+              vir -= 0.5 * (r2[e] * grad);
+            }
+            if (EAM) {
+              const double chi = cr_[e], dv = R1[e] - R0[e], d2v = (R2[e] - 2 * R1[e]) + R0[e];
+              const double val = R0[e] + chi * dv + (0.5 * chi) * (chi - 1) * d2v;
+              rr += (r2[e] < cr.end) ? val : 0.0;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < UNR; e++) {
+#pragma clang fp contract(fast)
+            const int jt = ts[j[e]], col = it * nt + jt;
+            if (TTMN) nb += (r2[e] <= pend0 && it == 0 && jt == 0) ? 1 : 0;
+            if (PAIR) {
+              const TabK c = {a.pair.begin[col], a.pair.end[col], a.pair.invstep[col], 2 * a.pair.invstep[col]};
+              int k; double chi;
+              tab_index(c, r2[e], k, chi);
+              is_short |= (r2[e] < c.begin);
+              const double *q = tp + k * inc + col;
+              const double p0 = q[0], p1 = q[inc], p2 = q[2 * inc], dv = p1 - p0, d2v = (p2 - 2 * p1) + p0;
+              const double pot = p0 + chi * dv + (0.5 * chi) * (chi - 1) * d2v;
+              double grad = c.istep2 * (dv + (chi - 0.5) * d2v);
+              grad = (r2[e] <= c.end) ? grad : 0.0;
+              fx += dx[e] * grad; fy += dy[e] * grad; fz += dz[e] * grad;
+              ee += (r2[e] <= c.end) ? 0.5 * pot : 0.0;
+              vir -= 0.5 * (r2[e] * grad);
+            }
+            if (EAM) {
+              const TabK c = {a.rho.begin[col], a.rho.end[col], a.rho.invstep[col], 2 * a.rho.invstep[col]};
+              int k; double chi;
+              tab_index(c, r2[e], k, chi);
+              is_short |= (r2[e] < c.begin);
+              const double *q = tr + k * inc + col;
+              const double p0 = q[0], p1 = q[inc], p2 = q[2 * inc], dv = p1 - p0, d2v = (p2 - 2 * p1) + p0;
+              const double val = p0 + chi * dv + (0.5 * chi) * (chi - 1) * d2v;
+              rr += (r2[e] < c.end) ? val : 0.0;
+            }
+          }
+        }
+      }
+      if (NT1) is_short |= ((PAIR && r2min < cp.begin) || (EAM && r2min < cr.begin)) ? 1 : 0;
+      a.f[i] = fx; a.f[a.cap + i] = fy; a.f[2 * (size_t) a.cap + i] = fz;
+      a.epot[i] = ee;
+      if (EAM) a.rhoh[i] = rr;
+      if (TTMN) a.numneighs[i] = nb;
+      sums[0] += ee; sums[1] += vir;
+    }
+  }
+  block_sum<2>(sums, scratch);
+  if (threadIdx.x == 0) {
+    a.partials[(size_t) blockIdx.x * IMDGPU_NPART + 0] = sums[0];
+    a.partials[(size_t) blockIdx.x * IMDGPU_NPART + 1] = sums[1];
+  }
+  if (is_short) a.counters[CNT_IS_SHORT] = 1;
+}
+
+template <bool NT1>
+__global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass3_tile(TileArgs a)
+{
+  extern __shared__ double lds[];
+  double *tr = lds;
+  double *sp = tr + a.rho.nrows * a.rho.ncols;
+  double *scratch = sp + 4 * (size_t) a.slot_cap;
+  int *hstart = (int *) (scratch + 64), *hsrc = hstart + NH_MAX + 1, *ts = hsrc + NH_MAX;
+  TileCtx T;
+  int t0, t1;
+  block_tile_range(a.ntiles, t0, t1);
+  double sums[1] = {0.0};
+  int is_short = 0;
+  if (t0 < t1) lds_load_table(tr, a.rho);
+  for (T.tile = t0; T.tile < t1; T.tile++) {
+    __syncthreads();
+    tile_stage<4, !NT1>(a, T, sp, ts, hstart, hsrc);
+    const int nt = a.ntypes, inc = NT1 ? 1 : nt * nt;
+    const TabK cr = {a.rho.begin[0], a.rho.end[0], a.rho.invstep[0], 2 * a.rho.invstep[0]};
+    for (int o = threadIdx.x; o < T.nown; o += blockDim.x) {
+      const int i = T.own_start + o;
+      int lx, ly, lz;
+      const int slot = own_slot(a, T, i, hstart, hsrc, lx, ly, lz);
+      const double xi = sp[4 * slot], yi = sp[4 * slot + 1], zi = sp[4 * slot + 2], wi = sp[4 * slot + 3];
+      const int it = NT1 ? 0 : ts[slot];
+      const int n4 = (a.nbr_cnt[i] + 3) >> 2;
+      const uint2 *lp = (const uint2 *) (a.nbr16 + (size_t) T.tile * a.W4 * a.tile_cap + o);
+      double fx = 0, fy = 0, fz = 0, vir = 0, r2min = 1e300;
+      // list words: PFD groups of four slots in flight (only ~3 waves/SIMD are resident, so the HBM stream
+      // of the list needs memory-level parallelism from each wave)
+      // two list words (8 slots) are consumed per trip while the next two are in flight; lanes past their
+      // own count get the dummy word
+      const unsigned dw = (unsigned) (a.slot_cap - 1) * 0x10001u;
+      const uint2 dummyw = make_uint2(dw, dw);
+      uint2 c0 = n4 > 0 ? lp[0] : dummyw, c1 = n4 > 1 ? lp[(size_t) a.tile_cap] : dummyw, m0 = dummyw, m1 = dummyw;
+      for (int k4 = 0; k4 < n4; k4++) {
+        if ((k4 & 1) == 0) {                                               // even trip: issue the next pair of loads
+          m0 = k4 + 2 < n4 ? lp[(size_t) (k4 + 2) * a.tile_cap] : dummyw;
+          m1 = k4 + 3 < n4 ? lp[(size_t) (k4 + 3) * a.tile_cap] : dummyw;
+        }
+        const uint2 cur = (k4 & 1) ? c1 : c0;
+        if (k4 & 1) { c0 = m0; c1 = m1; }                                  // odd trip: hand over (loads are ~8 neighbours old)
+        const int j[UNR] = {(int) (cur.x & 0xffffu), (int) (cur.x >> 16), (int) (cur.y & 0xffffu), (int) (cur.y >> 16)};
+        double dx[UNR], dy[UNR], dz[UNR], wj[UNR], r2[UNR];
+#pragma unroll
+        for (int e = 0; e < UNR; e++) {
+          const double *pj = sp + 4 * j[e];
+          dx[e] = pj[0]; dy[e] = pj[1]; dz[e] = pj[2]; wj[e] = pj[3];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < UNR; e++) {
+          dx[e] -= xi; dy[e] -= yi; dz[e] -= zi;
+          r2[e] = dx[e] * dx[e] + dy[e] * dy[e] + dz[e] * dz[e];
+        }
+        if (NT1) {
+          int kr[UNR];
+          double ch[UNR], R0[UNR], R1[UNR], R2[UNR];
+#pragma unroll
+          for (int e = 0; e < UNR; e++) { r2min = fmin(r2min, r2[e]); tab_index(cr, r2[e], kr[e], ch[e]); }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int e = 0; e < UNR; e++) { R0[e] = tr[kr[e]]; R1[e] = tr[kr[e] + 1]; R2[e] = tr[kr[e] + 2]; }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int e = 0; e < UNR; e++) {
+#pragma clang fp contract(fast)
+            const double dv = R1[e] - R0[e], d2v = (R2[e] - 2 * R1[e]) + R0[e];
+            const double rp = cr.istep2 * (dv + (ch[e] - 0.5) * d2v);                 // rho'_i = rho'_j (one type)
+            const double grad = (r2[e] < cr.end) ? (0.5 * (wi + wj[e])) * rp : 0.0;
+            const double gx = dx[e] * grad, gy = dy[e] * grad, gz = dz[e] * grad;
+            fx += gx; fy += gy; fz += gz;
+            vir -= 0.5 * (dx[e] * gx + dy[e] * gy + dz[e] * gz);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < UNR; e++) {
+#pragma clang fp contract(fast)
+            const int jt = ts[j[e]], col1 = jt * nt + it, col2 = it * nt + jt;
+            const TabK c1 = {a.rho.begin[col1], a.rho.end[col1], a.rho.invstep[col1], 2 * a.rho.invstep[col1]};
+            const TabK c2 = {a.rho.begin[col2], a.rho.end[col2], a.rho.invstep[col2], 2 * a.rho.invstep[col2]};
+            int k; double chi;
+            tab_index(c1, r2[e], k, chi);
+            const double *q = tr + k * inc + col1;
+            double p0 = q[0], p1 = q[inc], p2 = q[2 * inc], dv = p1 - p0, d2v = (p2 - 2 * p1) + p0;
+            const double ri = c1.istep2 * (dv + (chi - 0.5) * d2v);
+            tab_index(c2, r2[e], k, chi);
+            q = tr + k * inc + col2;
+            p0 = q[0]; p1 = q[inc]; p2 = q[2 * inc]; dv = p1 - p0; d2v = (p2 - 2 * p1) + p0;
+            const double rj = c2.istep2 * (dv + (chi - 0.5) * d2v);
+            const bool in = (r2[e] < c1.end) || (r2[e] < c2.end);
+            is_short |= (in && (r2[e] < c1.begin || r2[e] < c2.begin));
+            const double grad = in ? 0.5 * (wi * rj + wj[e] * ri) : 0.0;
+            const double gx = dx[e] * grad, gy = dy[e] * grad, gz = dz[e] * grad;
+            fx += gx; fy += gy; fz += gz;
+            vir -= 0.5 * (dx[e] * gx + dy[e] * gy + dz[e] * gz);
+          }
+        }
+      }
+      if (NT1) is_short |= (r2min < cr.begin) ? 1 : 0;
+      a.f[i] += fx; a.f[a.cap + i] += fy; a.f[2 * (size_t) a.cap + i] += fz;
+      sums[0] += vir;
+    }
+  }
+  block_sum<1>(sums, scratch);
+  if (threadIdx.x == 0) a.partials[(size_t) blockIdx.x * IMDGPU_NPART + 3] = sums[0];
+  if (is_short) a.counters[CNT_IS_SHORT] = 1;
+}
+
 // Deterministic final reduction of the per-block partial sums
 // (tot_pot_energy, virial: imd_forces_nbl.c:319-328,:496,:521,:760,:943).
 __global__ void k_reduce_force_sums(int nb1, int nb2, const double *partials, double *sums)
@@ -596,6 +1084,7 @@ extern "C" int imdgpu_create(imdgpu_ctx **out, int device)
   ctx->device = device;
   HIPCHK(hipSetDevice(device));
   HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess) ctx->num_cus = pr.multiProcessorCount; }
   ctx->own_stream = true;
   HIPCHK(hipMalloc((void **) &ctx->d_counters, CNT_N * sizeof(int)));
   HIPCHK(hipMemset(ctx->d_counters, 0, CNT_N * sizeof(int)));
@@ -618,7 +1107,7 @@ extern "C" void imdgpu_destroy(imdgpu_ctx *c)
                   c->pos2, c->type2, c->id2, c->p2, c->mass2, c->nn2, c->keys, c->keys2, c->perm, c->perm2,
                   c->cub_tmp, c->cell_start, c->cell_cnt, c->icnt, c->istart, c->gcell_lin, c->gcell_src,
                   c->gcell_shift, c->gcnt, c->gstart, c->ghost_src, c->ghost_code, c->d_counters, c->nbr,
-                  c->nbr_cnt, c->partials, c->d_sums, c->pair.d_tab, c->rho.d_tab, c->emb.d_tab, c->d_restr};
+                  c->nbr_cnt, c->nbr16, c->partials, c->d_sums, c->pair.d_tab, c->rho.d_tab, c->emb.d_tab, c->d_restr};
   for (void *p : ptrs) if (p) (void) hipFree(p);
   if (c->h_counters) (void) hipHostFree(c->h_counters);
   if (c->h_sums) (void) hipHostFree(c->h_sums);
@@ -627,6 +1116,27 @@ extern "C" void imdgpu_destroy(imdgpu_ctx *c)
 }
 
 extern "C" const char *imdgpu_last_error(const imdgpu_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+extern "C" int imdgpu_set_option(imdgpu_ctx *ctx, const char *name, int value)
+{
+  if (!strcmp(name, "mode")) {
+    if (value != 0 && value != 1) return imdgpu_fail(ctx, "mode must be 0 (global gather) or 1 (LDS tiles)");
+    ctx->mode = value; ctx->have_valid_nbl = 0;
+    return 0;
+  }
+  return imdgpu_fail(ctx, "unknown option %s", name);
+}
+
+extern "C" int imdgpu_get_info(imdgpu_ctx *ctx, const char *name, long long *value)
+{
+  struct { const char *n; long long v; } tab[] = {
+    {"list_mode", ctx->list_mode}, {"mode", ctx->mode}, {"tile_cap", ctx->tile_cap}, {"slot_cap", ctx->slot_cap},
+    {"max_halo", ctx->max_halo}, {"W", ctx->W}, {"tile_x", ctx->tile[0]}, {"tile_y", ctx->tile[1]}, {"tile_z", ctx->tile[2]},
+    {"ntiles", ctx->ntiles}, {"tile_threads", ctx->tile_threads}, {"nlocal", ctx->nlocal}, {"nghost", ctx->nghost},
+    {"lds_pass1", (long long) ctx->lds_need[1]}, {"lds_pass3", (long long) ctx->lds_need[3]}, {"nbl_count", ctx->nbl_count}};
+  for (auto &e : tab) if (!strcmp(name, e.n)) { *value = e.v; return 0; }
+  return imdgpu_fail(ctx, "unknown info %s", name);
+}
 
 extern "C" int imdgpu_set_stream(imdgpu_ctx *ctx, void *s)
 {
@@ -640,6 +1150,67 @@ extern "C" int imdgpu_synchronize(imdgpu_ctx *ctx)
 {
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return 0;
+}
+
+// (re)derive everything that depends on the tile shape: key space, per-key tables, ghost-source keys
+static int setup_tiles(imdgpu_ctx *ctx)
+{
+  const int *D = ctx->dim;
+  for (int d = 0; d < 3; d++) {
+    if (ctx->tile[d] > D[d] - 2) ctx->tile[d] = D[d] - 2;
+    if (ctx->tile[d] < 1) ctx->tile[d] = 1;
+    ctx->ntile[d] = (D[d] - 2 + ctx->tile[d] - 1) / ctx->tile[d];
+  }
+  ctx->CPT = ctx->tile[0] * ctx->tile[1] * ctx->tile[2];
+  ctx->ntiles = ctx->ntile[0] * ctx->ntile[1] * ctx->ntile[2];
+  ctx->nkeys = ctx->ntiles * ctx->CPT;
+  if (dev_alloc(ctx, &ctx->icnt, ctx->nkeys + 1) || dev_alloc(ctx, &ctx->istart, ctx->nkeys + 1)) return 1;
+  const Geo g = make_geo(ctx);
+  const int ng = ctx->nghost_cells;
+  std::vector<int> src(ng);
+  for (int q = 0; q < ng; q++) {
+    const int *x = &ctx->h_gsrc_xyz[3 * q];
+    src[q] = x[0] >= 0 ? xyz_to_key(x[0], x[1], x[2], g) : -1;
+  }
+  HIPCHK(hipMemcpy(ctx->gcell_src, src.data(), ng * sizeof(int), hipMemcpyHostToDevice));
+  int nb = std::max(nblk(ctx->cap_local, 256) + 8, ((ctx->ntiles + 7) / 8) * 8 + 8);
+  if (nb > ctx->npart_blocks) {
+    if (dev_alloc(ctx, &ctx->partials, (size_t) nb * IMDGPU_NPART)) return 1;
+    ctx->npart_blocks = nb;
+  }
+  ctx->nbr16_cap = 0; ctx->tile_cap = 0;
+  ctx->have_valid_nbl = 0;
+  return 0;
+}
+
+// old cell key -> new cell key after a change of the tile shape (cells themselves are unchanged)
+__global__ void k_rekey(int n, const int *acell, Geo gold, Geo gnew, int *keys, int *perm)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int ix, iy, iz;
+  key_to_xyz(acell[i], gold, ix, iy, iz);
+  keys[i] = xyz_to_key(ix, iy, iz, gnew);
+  perm[i] = i;
+}
+
+static int sort_and_build(imdgpu_ctx *ctx);
+
+// shrink the largest tile dimension by one cell and re-sort the atoms into the new key order
+static int shrink_tiles(imdgpu_ctx *ctx)
+{
+  int d = 0;
+  for (int q = 1; q < 3; q++) if (ctx->tile[q] > ctx->tile[d]) d = q;
+  if (ctx->tile[d] <= 1) return imdgpu_fail(ctx, "tiles cannot shrink further");
+  const Geo gold = make_geo(ctx);
+  ctx->tile[d]--;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  // keys of the old arrangement are needed by k_rekey: keep acell, rebuild the rest
+  if (setup_tiles(ctx)) return 1;
+  const Geo gnew = make_geo(ctx);
+  hipLaunchKernelGGL(k_rekey, dim3(nblk(ctx->nlocal, 256)), dim3(256), 0, ctx->stream, ctx->nlocal, ctx->acell, gold, gnew,
+                     ctx->keys, ctx->perm);
+  return sort_and_build(ctx);
 }
 
 extern "C" int imdgpu_set_geometry(imdgpu_ctx *ctx, const double box[9], const int pbc[3], const int cell_dim[3],
@@ -661,33 +1232,20 @@ extern "C" int imdgpu_set_geometry(imdgpu_ctx *ctx, const double box[9], const i
   ctx->nall_cells = D[0] * D[1] * D[2];
   ctx->ninner_cells = (D[0] - 2) * (D[1] - 2) * (D[2] - 2);
   ctx->nghost_cells = ctx->nall_cells - ctx->ninner_cells;
-  // tiling of the inner cells (one force-kernel workgroup per tile): prefer 3 cells per direction,
-  // pick 2..4 where that leaves no (or a larger) partial tile.  IMDGPU_TILE="bx,by,bz" overrides.
+  // tiling of the inner cells (one force-kernel workgroup per tile): 3 cells per direction (2 where that
+  // avoids a one-cell remainder); make_nblist shrinks tiles that do not fit the LDS.  IMDGPU_TILE="bx,by,bz".
   for (int d = 0; d < 3; d++) {
-    int n = D[d] - 2, best = 3, bestrem = -1;
-    for (int b : {3, 4, 2}) {
-      if (b > n) continue;
-      int rem = n % b == 0 ? b : n % b;           // size of the last tile
-      if (rem > bestrem) { best = b; bestrem = rem; }
-    }
-    if (n < 2) best = 1;
-    ctx->tile[d] = best;
+    int n = D[d] - 2;
+    ctx->tile[d] = n >= 3 ? ((n % 3 == 1 && n % 2 == 0) ? 2 : 3) : n;
   }
   if (const char *e = getenv("IMDGPU_TILE")) {
     int a, b, c;
     if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a > 0 && b > 0 && c > 0) { ctx->tile[0] = a; ctx->tile[1] = b; ctx->tile[2] = c; }
   }
-  for (int d = 0; d < 3; d++) {
-    if (ctx->tile[d] > D[d] - 2) ctx->tile[d] = D[d] - 2;
-    ctx->ntile[d] = (D[d] - 2 + ctx->tile[d] - 1) / ctx->tile[d];
-  }
-  ctx->CPT = ctx->tile[0] * ctx->tile[1] * ctx->tile[2];
-  ctx->ntiles = ctx->ntile[0] * ctx->ntile[1] * ctx->ntile[2];
-  ctx->nkeys = ctx->ntiles * ctx->CPT;
   if (const char *e = getenv("IMDGPU_MODE")) ctx->mode = atoi(e);
-  const Geo g0 = make_geo(ctx);
   // static ghost-cell tables: source inner cell (periodic wrap on this rank) and shift code
-  std::vector<int> lin, src, sh;
+  std::vector<int> lin, sh;
+  ctx->h_gsrc_xyz.clear();
   for (int i = 0; i < D[0]; i++)
     for (int j = 0; j < D[1]; j++)
       for (int k = 0; k < D[2]; k++) {
@@ -704,18 +1262,17 @@ extern "C" int imdgpu_set_geometry(imdgpu_ctx *ctx, const double box[9], const i
         }
         if (!ghost) continue;
         lin.push_back((i * D[1] + j) * D[2] + k);
-        src.push_back(active ? xyz_to_key(s[0] - 1, s[1] - 1, s[2] - 1, g0) : -1);
+        for (int d = 0; d < 3; d++) ctx->h_gsrc_xyz.push_back(active ? s[d] - 1 : -1);
         sh.push_back((sc[0] + 1) + 3 * (sc[1] + 1) + 9 * (sc[2] + 1));
       }
   int ng = ctx->nghost_cells;
   if (dev_alloc(ctx, &ctx->gcell_lin, ng) || dev_alloc(ctx, &ctx->gcell_src, ng) || dev_alloc(ctx, &ctx->gcell_shift, ng) ||
       dev_alloc(ctx, &ctx->gcnt, ng + 1) || dev_alloc(ctx, &ctx->gstart, ng + 1) ||
-      dev_alloc(ctx, &ctx->cell_start, ctx->nall_cells) || dev_alloc(ctx, &ctx->cell_cnt, ctx->nall_cells) ||
-      dev_alloc(ctx, &ctx->icnt, ctx->nkeys + 1) || dev_alloc(ctx, &ctx->istart, ctx->nkeys + 1))
+      dev_alloc(ctx, &ctx->cell_start, ctx->nall_cells) || dev_alloc(ctx, &ctx->cell_cnt, ctx->nall_cells))
     return 1;
   HIPCHK(hipMemcpy(ctx->gcell_lin, lin.data(), ng * sizeof(int), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(ctx->gcell_src, src.data(), ng * sizeof(int), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(ctx->gcell_shift, sh.data(), ng * sizeof(int), hipMemcpyHostToDevice));
+  if (setup_tiles(ctx)) return 1;
   HIPCHK(hipMemset(ctx->cell_start, 0, ctx->nall_cells * sizeof(int)));
   HIPCHK(hipMemset(ctx->cell_cnt, 0, ctx->nall_cells * sizeof(int)));
   ctx->have_geometry = true;
@@ -792,7 +1349,7 @@ static int ensure_atom_capacity(imdgpu_ctx *ctx, int nlocal, int ntot)
     HIPCHK(hipMemset(ctx->numneighs, 0, cap * sizeof(int)));
     HIPCHK(hipMemset(ctx->ref, 0, 3 * (size_t) cap * sizeof(double)));
     ctx->cap_local = cap;
-    int nb = nblk(cap, 256) + 8;
+    int nb = std::max(nblk(cap, 256) + 8, ((ctx->ntiles + 7) / 8) * 8 + 8);
     if (dev_alloc(ctx, &ctx->partials, (size_t) nb * IMDGPU_NPART)) return 1;
     ctx->npart_blocks = nb;
     ctx->nbr_cap = 0;                        // list must be re-allocated for the new stride
@@ -888,8 +1445,6 @@ static int upload_common(imdgpu_ctx *ctx, int n, const double *ort, const double
   ctx->nlocal = n;
   return 0;
 }
-
-static int sort_and_build(imdgpu_ctx *ctx);
 
 extern "C" int imdgpu_upload_cells(imdgpu_ctx *ctx, const int *cell_n, int natoms, const double *ort,
                                    const double *impuls, const double *masse, const int *sorte, const int *nummer)
@@ -987,6 +1542,35 @@ extern "C" int imdgpu_fill_ghosts(imdgpu_ctx *ctx)
   return 0;
 }
 
+static size_t align8(size_t b) { return (b + 7) & ~(size_t) 7; }
+// persistent tile kernels: one workgroup per CU (their ~140 KB of LDS admit no second one)
+static int tile_grid(const imdgpu_ctx *ctx) { return std::min(ctx->ntiles, ctx->num_cus > 0 ? ctx->num_cus : 256); }
+#define LDS_LIMIT (160 * 1024)
+
+static TileArgs make_tile_args(imdgpu_ctx *ctx)
+{
+  TileArgs a;
+  a.nlocal = ctx->nlocal; a.ntypes = ctx->ntypes; a.cap = ctx->cap_local; a.W4 = ctx->W / 4;
+  a.tile_cap = ctx->tile_cap; a.slot_cap = ctx->slot_cap; a.ntiles = ctx->ntiles;
+  a.g = make_geo(ctx);
+  a.pos = ctx->pos; a.type = ctx->type; a.acell = ctx->acell; a.cell_start = ctx->cell_start; a.cell_cnt = ctx->cell_cnt;
+  a.istart = ctx->istart; a.nbr16 = (ushort4 *) ctx->nbr16; a.nbr_cnt = ctx->nbr_cnt;
+  a.pair = ctx->pair.par; a.rho = ctx->rho.par;
+  a.f = ctx->f; a.epot = ctx->epot; a.rhoh = ctx->rhoh; a.ref = ctx->ref; a.numneighs = ctx->numneighs;
+  a.partials = ctx->partials; a.counters = ctx->d_counters; a.cellsz = ctx->cellsz;
+  return a;
+}
+
+static size_t tile_lds_bytes(const imdgpu_ctx *ctx, int which /*0 build, 1 pass1, 3 pass3*/)
+{
+  size_t ints = (size_t) (2 * NH_MAX + 1) * sizeof(int) + (ctx->ntypes == 1 ? 0 : (size_t) ctx->slot_cap * sizeof(int));
+  size_t tp = ctx->pair.present ? (size_t) ctx->pair.par.nrows * ctx->pair.par.ncols : 0;
+  size_t tr = ctx->rho.present ? (size_t) ctx->rho.par.nrows * ctx->rho.par.ncols : 0;
+  if (which == 0) return align8((size_t) 3 * ctx->slot_cap * 8 + (size_t) (2 * NH_MAX + 1) * sizeof(int));
+  if (which == 1) return align8((tp + tr + 3 * (size_t) ctx->slot_cap + 64) * 8 + ints);
+  return align8((tr + 4 * (size_t) ctx->slot_cap + 64) * 8 + ints);
+}
+
 extern "C" int imdgpu_make_nblist(imdgpu_ctx *ctx)
 {
   HIPCHK(hipSetDevice(ctx->device));
@@ -995,21 +1579,55 @@ extern "C" int imdgpu_make_nblist(imdgpu_ctx *ctx)
   if (ctx->cellsz <= 0) return imdgpu_fail(ctx, "cellsz not set");
   Geo g = make_geo(ctx);
   if (imdgpu_fill_ghosts(ctx)) return 1;
+  ctx->list_mode = ctx->mode;
+  for (int retile = 0; ctx->list_mode == 1 && retile < 8; retile++) {
+    // size the tiles: largest own-atom count (thread count, list row length) and largest staged count (LDS)
+    HIPCHK(hipMemsetAsync(ctx->d_counters + CNT_MAXOWN, 0, 2 * sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_tile_stats, dim3(nblk(ctx->ntiles, 64)), dim3(64), 0, ctx->stream, ctx->ntiles, g, ctx->cell_cnt,
+                       ctx->istart, ctx->d_counters);
+    HIPCHK(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, CNT_N * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    int tile_cap = (std::max(ctx->h_counters[CNT_MAXOWN], 1) + 63) / 64 * 64;
+    ctx->slot_cap = (ctx->h_counters[CNT_MAXHALO] + 1 + 63) / 64 * 64;      // + far-away dummy slot
+    ctx->max_halo = ctx->h_counters[CNT_MAXHALO];
+    if (tile_cap != ctx->tile_cap) { ctx->tile_cap = tile_cap; ctx->nbr16_cap = 0; }
+    ctx->tile_threads = std::min(TILE_MAXTHREADS, ctx->tile_cap);
+    ctx->lds_need[1] = tile_lds_bytes(ctx, 1); ctx->lds_need[3] = tile_lds_bytes(ctx, 3);
+    size_t need = std::max(ctx->lds_need[1], ctx->lds_need[3]);
+    if (need <= LDS_LIMIT && ctx->slot_cap <= 65535 && (g.bx + 2) * (g.by + 2) * (g.bz + 2) <= NH_MAX) break;
+    if (ctx->tile[0] * ctx->tile[1] * ctx->tile[2] > 1) {      // tile + halo does not fit the 160 KB LDS: smaller tiles
+      if (shrink_tiles(ctx)) return 1;
+      g = make_geo(ctx);
+      if (imdgpu_fill_ghosts(ctx)) return 1;
+    } else ctx->list_mode = 0;                                 // even one cell + halo too big: global-gather kernels
+  }
   size_t stride = (size_t) ctx->cap_local;
   if (ctx->W == 0) ctx->W = 96;
   for (int attempt = 0; attempt < 3; attempt++) {
-    if (ctx->nbr_cap < (size_t) ctx->W * stride) {
-      if (dev_alloc(ctx, &ctx->nbr, (size_t) ctx->W * stride)) return 1;
-      ctx->nbr_cap = (size_t) ctx->W * stride;
-    }
-    ctx->stride = stride;
-    {
+    HIPCHK(hipMemsetAsync(ctx->d_counters + CNT_MAXNBR, 0, sizeof(int), ctx->stream));
+    if (ctx->list_mode == 1) {
+      size_t need = (size_t) ctx->ntiles * (ctx->W / 4) * ctx->tile_cap * 4;           // in ushorts
+      if (ctx->nbr16_cap < need) {
+        if (dev_alloc(ctx, &ctx->nbr16, need)) return 1;
+        ctx->nbr16_cap = need;
+      }
+      TileArgs a = make_tile_args(ctx);
+      size_t lds = tile_lds_bytes(ctx, 0);
+      HIPCHK(hipFuncSetAttribute((const void *) k_nbl_build_tile, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
       ProfScope ps(ctx, PROF_NBLIST);
-      HIPCHK(hipMemsetAsync(ctx->d_counters + CNT_MAXNBR, 0, sizeof(int), ctx->stream));
+      hipLaunchKernelGGL(k_nbl_build_tile, dim3(tile_grid(ctx)), dim3(ctx->tile_threads), lds, ctx->stream, a);
+    } else {
+      if (ctx->nbr_cap < (size_t) ctx->W * stride) {
+        if (dev_alloc(ctx, &ctx->nbr, (size_t) ctx->W * stride)) return 1;
+        ctx->nbr_cap = (size_t) ctx->W * stride;
+      }
+      ctx->stride = stride;
+      ProfScope ps(ctx, PROF_NBLIST);
       hipLaunchKernelGGL(k_nbl_build, dim3(nblk(n, 128)), dim3(128), 0, ctx->stream, n, ctx->pos, ctx->acell,
                          ctx->cell_start, ctx->cell_cnt, g, ctx->cellsz, ctx->nbr, stride, ctx->W, ctx->nbr_cnt, ctx->ref,
                          ctx->cap_local, ctx->d_counters);
     }
+    HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, CNT_N * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     int mx = ctx->h_counters[CNT_MAXNBR];
@@ -1019,8 +1637,8 @@ extern "C" int imdgpu_make_nblist(imdgpu_ctx *ctx)
       HIPCHK(hipMemsetAsync(ctx->d_counters + CNT_INVALID, 0, sizeof(int), ctx->stream));
       return 0;
     }
-    ctx->W = (int) (mx * 1.15) + 8;             // "neighbor table full": grow and rebuild
-    ctx->nbr_cap = 0;
+    ctx->W = ((int) (mx * 1.15) + 8 + 3) / 4 * 4;     // "neighbor table full": grow and rebuild
+    ctx->nbr_cap = 0; ctx->nbr16_cap = 0;
   }
   return imdgpu_fail(ctx, "neighbor table full");
 }
@@ -1068,13 +1686,23 @@ static int launch_forces(imdgpu_ctx *ctx)
   a.pair = ctx->pair.par; a.rho = ctx->rho.par;
   a.f = ctx->f; a.epot = ctx->epot; a.rhoh = ctx->rhoh; a.numneighs = ctx->numneighs;
   a.partials = ctx->partials; a.counters = ctx->d_counters;
-  const int B = 512, nb = nblk(n, B);
+  const bool TILE = ctx->list_mode == 1;
+  const int B = TILE ? ctx->tile_threads : 512, nb = TILE ? tile_grid(ctx) : nblk(n, B);
   if (nb > ctx->npart_blocks) return imdgpu_fail(ctx, "internal: partials too small");
+  TileArgs ta;
+  if (TILE) ta = make_tile_args(ctx);
   size_t lds1 = ((PAIR ? a.pair.nrows * a.pair.ncols : 0) + (EAM ? a.rho.nrows * a.rho.ncols : 0) + 64) * sizeof(double);
   HIPCHK(hipMemsetAsync(ctx->d_counters + CNT_IS_SHORT, 0, sizeof(int), ctx->stream));
   {
     ProfScope ps(ctx, PROF_PASS1);
-#define L1(P, E, T, N) hipLaunchKernelGGL((k_pass1<P, E, T, N>), dim3(nb), dim3(B), lds1, ctx->stream, a)
+#define L1(P, E, T, N)                                                                                          \
+  do {                                                                                                          \
+    if (TILE) {                                                                                                 \
+      size_t l = tile_lds_bytes(ctx, 1);                                                                        \
+      HIPCHK(hipFuncSetAttribute((const void *) k_pass1_tile<P, E, T, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) l)); \
+      hipLaunchKernelGGL((k_pass1_tile<P, E, T, N>), dim3(nb), dim3(B), l, ctx->stream, ta);                     \
+    } else hipLaunchKernelGGL((k_pass1<P, E, T, N>), dim3(nb), dim3(B), lds1, ctx->stream, a);                  \
+  } while (0)
 #define L1T(P, E, T) do { if (NT1) L1(P, E, T, true); else L1(P, E, T, false); } while (0)
 #define L1E(P, E) do { if (TT) L1T(P, E, true); else L1T(P, E, false); } while (0)
     if (PAIR && EAM) L1E(true, true); else if (PAIR) L1E(true, false); else L1E(false, true);
@@ -1093,7 +1721,16 @@ static int launch_forces(imdgpu_ctx *ctx)
     if (imdgpu_fill_ghosts(ctx)) return 1;            // dF of the images  [send_cells(copy_dF), :786]
     size_t lds3 = ((size_t) a.rho.nrows * a.rho.ncols + 64) * sizeof(double);
     ProfScope ps(ctx, PROF_PASS3);
-    if (NT1) hipLaunchKernelGGL((k_pass3<true>), dim3(nb), dim3(B), lds3, ctx->stream, a);
+    if (TILE) {
+      size_t l = tile_lds_bytes(ctx, 3);
+      if (NT1) {
+        HIPCHK(hipFuncSetAttribute((const void *) k_pass3_tile<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) l));
+        hipLaunchKernelGGL((k_pass3_tile<true>), dim3(nb), dim3(B), l, ctx->stream, ta);
+      } else {
+        HIPCHK(hipFuncSetAttribute((const void *) k_pass3_tile<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) l));
+        hipLaunchKernelGGL((k_pass3_tile<false>), dim3(nb), dim3(B), l, ctx->stream, ta);
+      }
+    } else if (NT1) hipLaunchKernelGGL((k_pass3<true>), dim3(nb), dim3(B), lds3, ctx->stream, a);
     else hipLaunchKernelGGL((k_pass3<false>), dim3(nb), dim3(B), lds3, ctx->stream, a);
   }
   {

@@ -33,7 +33,7 @@ enum ProfId {
 struct ProfPending { hipEvent_t a, b; int id; };
 
 struct imdgpu_ctx {
-  int device = 0;
+  int device = 0, num_cus = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
   std::string err;
@@ -44,6 +44,7 @@ struct imdgpu_ctx {
   int nall_cells = 0, ninner_cells = 0, nghost_cells = 0;
   int tile[3]{3, 3, 3}, ntile[3]{}, ntiles = 0, CPT = 0, nkeys = 0;   // tiling of the inner cells
   bool have_geometry = false;
+  std::vector<int> h_gsrc_xyz;      // per ghost cell: inner coords of its periodic source (or -1)
 
   // parameters -------------------------------------------------------------
   int ntypes = 1, count_ttm = 0;
@@ -81,11 +82,12 @@ struct imdgpu_ctx {
 
   // neighbour list, full (symmetric).  mode 0: ELL transposed int32 global indices
   // nbr[k*stride+i]; mode 1: per tile, uint16 LDS-slot indices tl16[(tile*W+k)*tile_cap+a]
-  int mode = 1;
+  int mode = 1, list_mode = 0;
   int *nbr = nullptr, *nbr_cnt = nullptr;
   unsigned short *nbr16 = nullptr; size_t nbr16_cap = 0;
   int W = 0; size_t stride = 0; size_t nbr_cap = 0;
   int tile_cap = 0, max_halo = 0, slot_cap = 0, tile_threads = 0;
+  size_t lds_need[4]{};
   int have_valid_nbl = 0, nbl_count = 0, need_fix_cells = 0;
 
   // reductions -----------------------------------------------------------------

@@ -12,7 +12,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_CSRC, "libimdgpu.so")
 
 SYMBOLS = [
-    "imdgpu_create", "imdgpu_destroy", "imdgpu_last_error", "imdgpu_set_stream", "imdgpu_synchronize",
+    "imdgpu_create", "imdgpu_destroy", "imdgpu_last_error", "imdgpu_set_stream", "imdgpu_synchronize", "imdgpu_set_option", "imdgpu_get_info",
     "imdgpu_set_geometry", "imdgpu_set_params", "imdgpu_upload_tables", "imdgpu_set_restrictions",
     "imdgpu_upload_cells", "imdgpu_upload_atoms", "imdgpu_num_atoms", "imdgpu_download_atoms",
     "imdgpu_fix_cells", "imdgpu_fill_ghosts", "imdgpu_make_nblist", "imdgpu_check_nblist",
@@ -83,6 +83,8 @@ def load():
     L.imdgpu_last_error.restype = C.c_char_p
     L.imdgpu_set_stream.argtypes = [vp, vp]
     L.imdgpu_synchronize.argtypes = [vp]
+    L.imdgpu_set_option.argtypes = [vp, C.c_char_p, C.c_int]
+    L.imdgpu_get_info.argtypes = [vp, C.c_char_p, C.POINTER(C.c_longlong)]
     L.imdgpu_set_geometry.argtypes = [vp, dp, ip, ip, ip, ip, ip]
     L.imdgpu_set_params.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int]
     L.imdgpu_upload_tables.argtypes = [vp, C.POINTER(PotTableC), C.POINTER(PotTableC), C.POINTER(PotTableC)]

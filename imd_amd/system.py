@@ -93,6 +93,14 @@ class GpuSystem:
     def set_stream(self, hip_stream):
         self._ck(self.L.imdgpu_set_stream(self.h, C.c_void_p(int(hip_stream))))
 
+    def set_option(self, name, value):
+        self._ck(self.L.imdgpu_set_option(self.h, name.encode(), int(value)))
+
+    def get_info(self, name):
+        v = C.c_longlong()
+        self._ck(self.L.imdgpu_get_info(self.h, name.encode(), C.byref(v)))
+        return v.value
+
     def synchronize(self):
         self._ck(self.L.imdgpu_synchronize(self.h))
 

@@ -49,6 +49,10 @@ const char *imdgpu_last_error(const imdgpu_ctx *ctx);
 /* run on a caller-owned HIP stream (hipStream_t) instead of the context's own */
 int  imdgpu_set_stream(imdgpu_ctx *ctx, void *hip_stream);
 int  imdgpu_synchronize(imdgpu_ctx *ctx);
+/* tuning knobs: "mode" = 1 LDS-tiled force kernels (default), 0 global-gather kernels */
+int  imdgpu_set_option(imdgpu_ctx *ctx, const char *name, int value);
+/* introspection: "list_mode" (kernel family of the current list), "tile_cap", "slot_cap", "W", "ntiles", ... */
+int  imdgpu_get_info(imdgpu_ctx *ctx, const char *name, long long *value);
 
 /* ---- set-up -------------------------------------------------------------- */
 /* Geometry of one rank: box_x/y/z rows (globals.h:613), pbc_dirs

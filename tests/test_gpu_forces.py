@@ -143,3 +143,61 @@ def test_check_nblist_threshold():
         s.md_step(st)
     assert s.get_sums()["nbl_count"] >= 2
     s.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_both_kernel_modes_match_reference(mode):
+    G = gu.load("eam_nbl_2048")
+    s = _gpu_from_golden(G, 20)
+    s.set_option("mode", mode)
+    r = s.calc_forces(20)
+    assert s.get_info("list_mode") == mode          # no silent fall-back to the other kernel family
+    d = s.download()
+    assert _relmax(d["kraft"], G["s20_kraft"]) < FTOL
+    assert _relmax(d["eam_rho"], G["s20_eam_rho"]) < 1e-11
+    assert abs(r["tot_pot_energy"] - float(G["s20_tot_pot_energy"])) < 1e-11 * abs(float(G["s20_tot_pot_energy"]))
+    s.close()
+
+
+def test_large_system_properties():
+    """Config-2 size (1M atoms, EAM): size-independent properties instead of an oracle run --
+    the two independent kernel families agree, total force vanishes (Newton 3), the
+    symmetric list has an even number of entries, energy is conserved over a short run."""
+    from imd_amd import lattice, potential
+    from imd_amd.system import global_cell_dim
+    nb = (64, 64, 64)
+    box = lattice.fcc_box(nb)
+    pos = lattice.fcc_positions(nb)
+    rng = np.random.default_rng(3)
+    pos = pos + rng.normal(scale=0.05, size=pos.shape)
+    mom = lattice.maxwell_momenta(len(pos), 26.9815, 0.02)
+    pair, rho, emb, r2cut = potential.synthetic_eam_tables()
+    cellsz = (np.sqrt(r2cut) + 0.5) ** 2
+    dim = [g + 2 for g in global_cell_dim(box, cellsz)]
+    res = {}
+    for mode in (0, 1):
+        s = GpuSystem(box, (1, 1, 1), dim, 1, cellsz, 0.5, 0.1)
+        s.set_option("mode", mode)
+        s.upload_tables(pair, rho, emb)
+        s.upload_atoms(pos, mom, 26.9815)
+        r = s.calc_forces(0)
+        assert s.get_info("list_mode") == mode
+        d = s.download(fields=("kraft", "nummer", "pot_eng", "eam_rho"))
+        o = np.argsort(d["nummer"])
+        res[mode] = (d["kraft"][o], d["pot_eng"][o], r)
+        ent, mx = s.nblist_stats()
+        assert ent % 2 == 0 and mx < 120
+        if mode == 1:
+            etot = []
+            for st in range(30):
+                s.md_step(st)
+                if st in (5, 29):
+                    g = s.get_sums()       # Epot of this step's forces + leap-frog mean kinetic energy
+                    etot.append((g["tot_pot_energy"] + g["tot_kin_energy"], g["tot_kin_energy"]))
+            assert abs(etot[1][0] - etot[0][0]) < 2e-3 * etot[0][1]      # NVE: drift << kinetic energy
+        s.close()
+    f0, e0, r0 = res[0]; f1, e1, r1 = res[1]
+    assert np.abs(f0 - f1).max() < 1e-11 * np.abs(f0).max()
+    assert np.abs(e0 - e1).max() < 1e-12 * np.abs(e0).max()
+    assert abs(r0["tot_pot_energy"] - r1["tot_pot_energy"]) < 1e-12 * abs(r0["tot_pot_energy"])
+    assert np.abs(f1.sum(axis=0)).max() < 1e-7            # sum of all forces ~ 0 (1M atoms, |F|~0.5)
