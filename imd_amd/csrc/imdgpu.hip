@@ -516,6 +516,7 @@ struct TileArgs {
   ushort4 *nbr16;
   int *nbr_cnt;
   TabPar pair, rho;
+  const double *merged;           // interleaved (phi,rho) table + 3 zero rows, or nullptr
   double *f, *epot, *rhoh, *ref;
   int *numneighs;
   double *partials;
@@ -708,6 +709,11 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile(TileArgs a)
 // cut-off test.  Products may fuse into FMAs here (relative change ~1e-16); the squared distance and
 // every cut-off comparison use the reference's unfused expression.
 #define TILE_MAXTHREADS 768
+#ifdef IMDGPU_NOSCHED
+#define SCHED_BARRIER
+#else
+#define SCHED_BARRIER __builtin_amdgcn_sched_barrier(0)
+#endif
 #define UNR 4
 
 struct TabK { double begin, end, istep, istep2; };      // one column of a table (NT1 fast path)
@@ -779,7 +785,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile(TileArgs a)
           const double *pj = sp + 3 * j[e];
           dx[e] = pj[0]; dy[e] = pj[1]; dz[e] = pj[2];
         }
-        __builtin_amdgcn_sched_barrier(0);
+        SCHED_BARRIER;
 #pragma unroll
         for (int e = 0; e < UNR; e++) {
           dx[e] -= xi; dy[e] -= yi; dz[e] -= zi;
@@ -794,13 +800,13 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile(TileArgs a)
             if (PAIR) tab_index(cp, r2[e], kp[e], cp_[e]);
             if (EAM) tab_index(cr, r2[e], kr[e], cr_[e]);
           }
-          __builtin_amdgcn_sched_barrier(0);
+          SCHED_BARRIER;
 #pragma unroll
           for (int e = 0; e < UNR; e++) {
             if (PAIR) { P0[e] = tp[kp[e]]; P1[e] = tp[kp[e] + 1]; P2[e] = tp[kp[e] + 2]; }
             if (EAM) { R0[e] = tr[kr[e]]; R1[e] = tr[kr[e] + 1]; R2[e] = tr[kr[e] + 2]; }
           }
-          __builtin_amdgcn_sched_barrier(0);
+          SCHED_BARRIER;
 #pragma unroll
           for (int e = 0; e < UNR; e++) {                                 // phase 3: arithmetic
 #pragma clang fp contract(fast)
@@ -869,6 +875,108 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile(TileArgs a)
   if (is_short) a.counters[CNT_IS_SHORT] = 1;
 }
 
+// Pass 1, one atom type, pair_pot and rho_h_tab tabulated on the SAME r^2 grid (the usual case for EAM
+// files written by one tool): the two tables are interleaved in LDS as (phi[k], rho[k]) so that one index
+// computation and three aligned 16-byte reads serve both; three all-zero rows follow the table and
+// neighbours beyond the cut-off (list skin, padding) are sent there, which replaces every mask.
+template <bool TTMN>
+__global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs a)
+{
+  extern __shared__ double lds[];
+  double2 *tm = (double2 *) lds;                                // (nrows + 3) rows
+  const int nrows = a.pair.nrows, kz = nrows;
+  double *sp = lds + 2 * (size_t) (nrows + 3);
+  double *scratch = sp + 3 * (size_t) a.slot_cap;
+  int *hstart = (int *) (scratch + 64), *hsrc = hstart + NH_MAX + 1;
+  TileCtx T;
+  int t0, t1;
+  block_tile_range(a.ntiles, t0, t1);
+  double sums[2] = {0.0, 0.0};
+  int is_short = 0;
+  if (t0 < t1) {
+    const double2 *src = (const double2 *) a.merged;
+    for (int k = threadIdx.x; k < nrows + 3; k += 4 * blockDim.x) {
+      double2 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { int q = k + u * blockDim.x; if (q < nrows + 3) v[u] = src[q]; }
+#pragma unroll
+      for (int u = 0; u < 4; u++) { int q = k + u * blockDim.x; if (q < nrows + 3) tm[q] = v[u]; }
+    }
+  }
+  const TabK c = {a.pair.begin[0], a.pair.end[0], a.pair.invstep[0], 2 * a.pair.invstep[0]};
+  for (T.tile = t0; T.tile < t1; T.tile++) {
+    __syncthreads();
+    tile_stage<3, false>(a, T, sp, nullptr, hstart, hsrc);
+    for (int o = threadIdx.x; o < T.nown; o += blockDim.x) {
+      const int i = T.own_start + o;
+      int lx, ly, lz;
+      const int slot = own_slot(a, T, i, hstart, hsrc, lx, ly, lz);
+      const double xi = sp[3 * slot], yi = sp[3 * slot + 1], zi = sp[3 * slot + 2];
+      const int n4 = (a.nbr_cnt[i] + 3) >> 2;
+      const uint2 *lp = (const uint2 *) (a.nbr16 + (size_t) T.tile * a.W4 * a.tile_cap + o);
+      double fx = 0, fy = 0, fz = 0, ee = 0, rr = 0, vir = 0, r2min = 1e300;
+      int nb = 0;
+      const unsigned dw = (unsigned) (a.slot_cap - 1) * 0x10001u;
+      const uint2 dummyw = make_uint2(dw, dw);
+      uint2 c0 = n4 > 0 ? lp[0] : dummyw, c1 = n4 > 1 ? lp[(size_t) a.tile_cap] : dummyw, m0 = dummyw, m1 = dummyw;
+      for (int k4 = 0; k4 < n4; k4++) {
+        if ((k4 & 1) == 0) {
+          m0 = k4 + 2 < n4 ? lp[(size_t) (k4 + 2) * a.tile_cap] : dummyw;
+          m1 = k4 + 3 < n4 ? lp[(size_t) (k4 + 3) * a.tile_cap] : dummyw;
+        }
+        const uint2 cur = (k4 & 1) ? c1 : c0;
+        if (k4 & 1) { c0 = m0; c1 = m1; }
+        const int j[UNR] = {(int) (cur.x & 0xffffu), (int) (cur.x >> 16), (int) (cur.y & 0xffffu), (int) (cur.y >> 16)};
+        double dx[UNR], dy[UNR], dz[UNR], r2[UNR], chi[UNR];
+        int k[UNR];
+        double2 A[UNR], B[UNR], C[UNR];
+#pragma unroll
+        for (int e = 0; e < UNR; e++) { const double *pj = sp + 3 * j[e]; dx[e] = pj[0]; dy[e] = pj[1]; dz[e] = pj[2]; }
+        SCHED_BARRIER;
+#pragma unroll
+        for (int e = 0; e < UNR; e++) {
+          dx[e] -= xi; dy[e] -= yi; dz[e] -= zi;
+          r2[e] = dx[e] * dx[e] + dy[e] * dy[e] + dz[e] * dz[e];          // unfused: the reference's r2
+          r2min = fmin(r2min, r2[e]);
+          tab_index(c, r2[e], k[e], chi[e]);
+          const bool in = r2[e] <= c.end;                                 // pair: <= end (imd_forces_nbl.c:489); rho(end) = 0 exactly
+          if (TTMN) nb += in ? 1 : 0;
+          k[e] = in ? k[e] : kz;
+        }
+        SCHED_BARRIER;
+#pragma unroll
+        for (int e = 0; e < UNR; e++) { A[e] = tm[k[e]]; B[e] = tm[k[e] + 1]; C[e] = tm[k[e] + 2]; }
+        SCHED_BARRIER;
+#pragma unroll
+        for (int e = 0; e < UNR; e++) {
+#pragma clang fp contract(fast)
+          const double x = chi[e], h = (0.5 * x) * (x - 1), g = x - 0.5;
+          const double dvp = B[e].x - A[e].x, d2p = (C[e].x - 2 * B[e].x) + A[e].x;
+          const double dvr = B[e].y - A[e].y, d2r = (C[e].y - 2 * B[e].y) + A[e].y;
+          const double pot = A[e].x + x * dvp + h * d2p;
+          const double grad = c.istep2 * (dvp + g * d2p);
+          rr += A[e].y + x * dvr + h * d2r;
+          fx += dx[e] * grad; fy += dy[e] * grad; fz += dz[e] * grad;
+          ee += 0.5 * pot;
+          vir -= 0.5 * (r2[e] * grad);
+        }
+      }
+      is_short |= (r2min < c.begin) ? 1 : 0;
+      a.f[i] = fx; a.f[a.cap + i] = fy; a.f[2 * (size_t) a.cap + i] = fz;
+      a.epot[i] = ee;
+      a.rhoh[i] = rr;
+      if (TTMN) a.numneighs[i] = nb;
+      sums[0] += ee; sums[1] += vir;
+    }
+  }
+  block_sum<2>(sums, scratch);
+  if (threadIdx.x == 0) {
+    a.partials[(size_t) blockIdx.x * IMDGPU_NPART + 0] = sums[0];
+    a.partials[(size_t) blockIdx.x * IMDGPU_NPART + 1] = sums[1];
+  }
+  if (is_short) a.counters[CNT_IS_SHORT] = 1;
+}
+
 template <bool NT1>
 __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass3_tile(TileArgs a)
 {
@@ -918,7 +1026,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass3_tile(TileArgs a)
           const double *pj = sp + 4 * j[e];
           dx[e] = pj[0]; dy[e] = pj[1]; dz[e] = pj[2]; wj[e] = pj[3];
         }
-        __builtin_amdgcn_sched_barrier(0);
+        SCHED_BARRIER;
 #pragma unroll
         for (int e = 0; e < UNR; e++) {
           dx[e] -= xi; dy[e] -= yi; dz[e] -= zi;
@@ -929,10 +1037,10 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass3_tile(TileArgs a)
           double ch[UNR], R0[UNR], R1[UNR], R2[UNR];
 #pragma unroll
           for (int e = 0; e < UNR; e++) { r2min = fmin(r2min, r2[e]); tab_index(cr, r2[e], kr[e], ch[e]); }
-          __builtin_amdgcn_sched_barrier(0);
+          SCHED_BARRIER;
 #pragma unroll
           for (int e = 0; e < UNR; e++) { R0[e] = tr[kr[e]]; R1[e] = tr[kr[e] + 1]; R2[e] = tr[kr[e] + 2]; }
-          __builtin_amdgcn_sched_barrier(0);
+          SCHED_BARRIER;
 #pragma unroll
           for (int e = 0; e < UNR; e++) {
 #pragma clang fp contract(fast)
@@ -1085,6 +1193,9 @@ extern "C" int imdgpu_create(imdgpu_ctx **out, int device)
   HIPCHK(hipSetDevice(device));
   HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess) ctx->num_cus = pr.multiProcessorCount; }
+  HIPCHK(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
   ctx->own_stream = true;
   HIPCHK(hipMalloc((void **) &ctx->d_counters, CNT_N * sizeof(int)));
   HIPCHK(hipMemset(ctx->d_counters, 0, CNT_N * sizeof(int)));
@@ -1107,11 +1218,14 @@ extern "C" void imdgpu_destroy(imdgpu_ctx *c)
                   c->pos2, c->type2, c->id2, c->p2, c->mass2, c->nn2, c->keys, c->keys2, c->perm, c->perm2,
                   c->cub_tmp, c->cell_start, c->cell_cnt, c->icnt, c->istart, c->gcell_lin, c->gcell_src,
                   c->gcell_shift, c->gcnt, c->gstart, c->ghost_src, c->ghost_code, c->d_counters, c->nbr,
-                  c->nbr_cnt, c->nbr16, c->partials, c->d_sums, c->pair.d_tab, c->rho.d_tab, c->emb.d_tab, c->d_restr};
+                  c->nbr_cnt, c->nbr16, c->d_merged, c->partials, c->d_sums, c->pair.d_tab, c->rho.d_tab, c->emb.d_tab, c->d_restr};
   for (void *p : ptrs) if (p) (void) hipFree(p);
   if (c->h_counters) (void) hipHostFree(c->h_counters);
   if (c->h_sums) (void) hipHostFree(c->h_sums);
   if (c->own_stream && c->stream) (void) hipStreamDestroy(c->stream);
+  if (c->stream2) (void) hipStreamDestroy(c->stream2);
+  if (c->ev_fork) (void) hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void) hipEventDestroy(c->ev_join);
   delete c;
 }
 
@@ -1326,6 +1440,15 @@ extern "C" int imdgpu_upload_tables(imdgpu_ctx *ctx, const imdgpu_pot_table *pai
   if (pair && pair->ncols != nn) return imdgpu_fail(ctx, "pair_pot has %d columns, expected ntypes^2=%d", pair->ncols, nn);
   if (rho && rho->ncols != nn) return imdgpu_fail(ctx, "rho_h_tab has %d columns, expected %d", rho->ncols, nn);
   if (emb && emb->ncols != ctx->ntypes) return imdgpu_fail(ctx, "embed_pot has %d columns, expected %d", emb->ncols, ctx->ntypes);
+  if (ctx->d_merged) { (void) hipFree(ctx->d_merged); ctx->d_merged = nullptr; }
+  if (pair && rho && ctx->ntypes == 1 && pair->maxsteps == rho->maxsteps && pair->begin[0] == rho->begin[0] &&
+      pair->end[0] == rho->end[0] && pair->invstep[0] == rho->invstep[0]) {
+    const int R = pair->maxsteps + 2;
+    std::vector<double> m(2 * (size_t) (R + 3), 0.0);
+    for (int k = 0; k < R; k++) { m[2 * k] = pair->table[k]; m[2 * k + 1] = rho->table[k]; }
+    HIPCHK(hipMalloc((void **) &ctx->d_merged, m.size() * sizeof(double)));
+    HIPCHK(hipMemcpy(ctx->d_merged, m.data(), m.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
   size_t lds = ((pair ? ctx->pair.par.nrows * pair->ncols : 0) + (rho ? ctx->rho.par.nrows * rho->ncols : 0) + 64) * sizeof(double);
   if (lds > 150 * 1024) return imdgpu_fail(ctx, "potential tables need %zu B of LDS (limit 150 KB)", lds);
   return 0;
@@ -1555,7 +1678,7 @@ static TileArgs make_tile_args(imdgpu_ctx *ctx)
   a.g = make_geo(ctx);
   a.pos = ctx->pos; a.type = ctx->type; a.acell = ctx->acell; a.cell_start = ctx->cell_start; a.cell_cnt = ctx->cell_cnt;
   a.istart = ctx->istart; a.nbr16 = (ushort4 *) ctx->nbr16; a.nbr_cnt = ctx->nbr_cnt;
-  a.pair = ctx->pair.par; a.rho = ctx->rho.par;
+  a.pair = ctx->pair.par; a.rho = ctx->rho.par; a.merged = ctx->d_merged;
   a.f = ctx->f; a.epot = ctx->epot; a.rhoh = ctx->rhoh; a.ref = ctx->ref; a.numneighs = ctx->numneighs;
   a.partials = ctx->partials; a.counters = ctx->d_counters; a.cellsz = ctx->cellsz;
   return a;
@@ -1567,7 +1690,7 @@ static size_t tile_lds_bytes(const imdgpu_ctx *ctx, int which /*0 build, 1 pass1
   size_t tp = ctx->pair.present ? (size_t) ctx->pair.par.nrows * ctx->pair.par.ncols : 0;
   size_t tr = ctx->rho.present ? (size_t) ctx->rho.par.nrows * ctx->rho.par.ncols : 0;
   if (which == 0) return align8((size_t) 3 * ctx->slot_cap * 8 + (size_t) (2 * NH_MAX + 1) * sizeof(int));
-  if (which == 1) return align8((tp + tr + 3 * (size_t) ctx->slot_cap + 64) * 8 + ints);
+  if (which == 1) return align8((tp + tr + 6 + 3 * (size_t) ctx->slot_cap + 64) * 8 + ints);
   return align8((tr + 4 * (size_t) ctx->slot_cap + 64) * 8 + ints);
 }
 
@@ -1705,11 +1828,21 @@ static int launch_forces(imdgpu_ctx *ctx)
   } while (0)
 #define L1T(P, E, T) do { if (NT1) L1(P, E, T, true); else L1(P, E, T, false); } while (0)
 #define L1E(P, E) do { if (TT) L1T(P, E, true); else L1T(P, E, false); } while (0)
-    if (PAIR && EAM) L1E(true, true); else if (PAIR) L1E(true, false); else L1E(false, true);
+    if (TILE && PAIR && EAM && NT1 && ctx->d_merged) {
+      size_t l = tile_lds_bytes(ctx, 1);
+      if (TT) {
+        HIPCHK(hipFuncSetAttribute((const void *) k_pass1_tile_merged<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) l));
+        hipLaunchKernelGGL((k_pass1_tile_merged<true>), dim3(nb), dim3(B), l, ctx->stream, ta);
+      } else {
+        HIPCHK(hipFuncSetAttribute((const void *) k_pass1_tile_merged<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) l));
+        hipLaunchKernelGGL((k_pass1_tile_merged<false>), dim3(nb), dim3(B), l, ctx->stream, ta);
+      }
+    } else if (PAIR && EAM) L1E(true, true); else if (PAIR) L1E(true, false); else L1E(false, true);
 #undef L1E
 #undef L1T
 #undef L1
   }
+  if (ctx->after_pass1) { if (ctx->after_pass1(ctx, ctx->after_pass1_arg)) return 1; }
   int nb2 = 0;
   if (EAM) {
     nb2 = nblk(n, 256);
@@ -1784,6 +1917,19 @@ extern "C" int imdgpu_move_atoms_nve(imdgpu_ctx *ctx, double *ekin)
   return 0;
 }
 
+static int fork_ttm(imdgpu_ctx *ctx, void *)
+{
+  HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
+  HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+  hipStream_t main = ctx->stream;
+  ctx->stream = ctx->stream2;
+  int rc = imdgpu_calc_ttm(ctx, ctx->ttm_steps);
+  ctx->stream = main;
+  if (rc) return 1;
+  HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
+  return 0;
+}
+
 extern "C" int imdgpu_md_step(imdgpu_ctx *ctx, int steps)
 {
   HIPCHK(hipSetDevice(ctx->device));
@@ -1792,9 +1938,18 @@ extern "C" int imdgpu_md_step(imdgpu_ctx *ctx, int steps)
     if (imdgpu_make_nblist(ctx)) return 1;
   } else if (imdgpu_fill_ghosts(ctx)) return 1;
   if (!ctx->rho.present && zero_eam_partials(ctx)) return 1;
-  if (launch_forces(ctx)) return 1;
-  if (ctx->ttm) { if (imdgpu_ttm_step_internal(ctx, steps)) return 1; }
-  else {
+  if (ctx->ttm) {
+    // calc_ttm needs only pass 1's neighbour counts and the momenta: it runs on the second stream,
+    // concurrently with the embedding pass and the EAM force pass; move_atoms_ttm joins the two
+    ctx->ttm_steps = steps;
+    ctx->after_pass1 = fork_ttm; ctx->after_pass1_arg = nullptr;
+    int rc = launch_forces(ctx);
+    ctx->after_pass1 = nullptr;
+    if (rc) return 1;
+    HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    if (imdgpu_ttm_move_internal(ctx)) return 1;
+  } else {
+    if (launch_forces(ctx)) return 1;
     const int n = ctx->nlocal, nb = nblk(n, 256);
     double h = 0.5 * ctx->nbl_margin;
     ProfScope ps(ctx, PROF_INTEGRATE);

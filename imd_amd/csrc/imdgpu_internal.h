@@ -34,7 +34,10 @@ struct ProfPending { hipEvent_t a, b; int id; };
 
 struct imdgpu_ctx {
   int device = 0, num_cus = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: TTM lattice work overlapped with passes 2-3
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int (*after_pass1)(imdgpu_ctx *, void *) = nullptr; void *after_pass1_arg = nullptr;
+  int ttm_steps = 0;
   bool own_stream = false;
   std::string err;
 
@@ -50,6 +53,7 @@ struct imdgpu_ctx {
   int ntypes = 1, count_ttm = 0;
   double cellsz = 0, nbl_margin = 0, timestep = 0;
   DevTable pair, rho, emb;
+  double *d_merged = nullptr;     // (phi,rho) interleaved + 3 zero rows when both share one r^2 grid
   double *d_restr = nullptr;      // ntypes*3
 
   // atoms (device).  local atoms [0,nlocal) sorted by inner-cell rank, ghost
@@ -188,4 +192,5 @@ static __global__ void k_reduce_move(int nb, const double *partials, double *sum
 
 // TTM entry points called from imdgpu_md_step
 int imdgpu_ttm_step_internal(imdgpu_ctx *ctx, int steps);
+int imdgpu_ttm_move_internal(imdgpu_ctx *ctx);
 void imdgpu_ttm_free(imdgpu_ctx *ctx);

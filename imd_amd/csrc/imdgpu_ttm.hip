@@ -193,7 +193,8 @@ __device__ double d_get_gamma(double Te, double Ti, double Ne, double Z, double 
   double Ni = Ne / Z, EF = d_fermi_E(Ne);
   double TF = 4.828648689433765e+22 * EF, VF = 1.481734876966785e+15 * sqrt(EF);
   double coulomb = d_coulomb_log(omega_laser, Z, Ni, Te);
-  double nupl = 1.863839656495274e-40 * Z * Ne * coulomb / pow(C_BOLTZMAN * Te, 1.5);
+  const double kT = C_BOLTZMAN * Te;
+  double nupl = 1.863839656495274e-40 * Z * Ne * coulomb / (kT * sqrt(kT));          // pow(kT, 1.5)
   double nu_eff = fmin(d_numet(A1g, A2g, Te, Ti, TF), fmin(d_numax(A3g, VF, Te, Ni), nupl));
   return 2.783313120645740e-74 / (m_atom * C_AMU) * Ne * nu_eff;
 }
@@ -206,7 +207,8 @@ __device__ double d_get_kappa(double Te, double Ti, double Ne, double Z, double 
   double nu_eff = fmin(d_numet(A1t, A2t, Te, Ti, TF), d_numax(A3t, VF, Te, Ni));
   double coulomb = d_coulomb_log(omega_laser, Z, Ni, Te);
   double kappa_met = 6.884236239621913e-16 * Ne * Te / nu_eff;
-  double kappa_pl = 4.428788911416808e+43 * pow(C_BOLTZMAN * Te, 2.5) / Z / coulomb;
+  const double kT = C_BOLTZMAN * Te;
+  double kappa_pl = 4.428788911416808e+43 * (kT * kT * sqrt(kT)) / Z / coulomb;      // pow(kT, 2.5)
   double kappa_wr = kappa_pl + (kappa_met - kappa_pl) * exp(-A4t * Te / TF);
   return kappa_wr * 0.073768115942029;
 }
@@ -298,7 +300,10 @@ __global__ void k_ttm_ghosts(Lat L, int *natoms, double *temp, double *fd_k)
 #define DT_X 4
 #define DT_Y 4
 #define DT_Z 16
-template <bool FUSE_MESH>
+// WRAP: ghost-shell cells are not read from memory but resolved on the fly (periodic direction: the
+// opposite inner cell; open direction: empty), i.e. ttm_fill_ghost_layers is folded into the load --
+// valid when the lattice is not split over ranks.
+template <bool FUSE_MESH, bool WRAP>
 __global__ __launch_bounds__(DT_X *DT_Y *DT_Z) void k_ttm_diff(
     Lat L, double tau, int nsub, int steps, const int *natoms, const double *T1, double *T2, double *U1, double *U2,
     const double *fd_k, double *fd_k_out, double *Ce, double *fd_g, const double *md_temp, const double *source,
@@ -315,7 +320,19 @@ __global__ __launch_bounds__(DT_X *DT_Y *DT_Z) void k_ttm_diff(
     int lz = s % (DT_Z + 2), ly = (s / (DT_Z + 2)) % (DT_Y + 2), lx = s / ((DT_Z + 2) * (DT_Y + 2));
     int gi = i0 + lx, gj = j0 + ly, gk = k0 + lz;
     double t = 0, kk = 0; int n = 0;
-    if (gi < L.dim[0] && gj < L.dim[1] && gk < L.dim[2]) { int c = fidx(L, gi, gj, gk); t = T1[c]; kk = fd_k[c]; n = natoms[c]; }
+    if (gi < L.dim[0] && gj < L.dim[1] && gk < L.dim[2]) {
+      bool empty = false;
+      if (WRAP) {
+        int g[3] = {gi, gj, gk};
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+          if (g[d] == 0) { if (L.pbc[d] == 1) g[d] = L.dim[d] - 2; else empty = true; }
+          else if (g[d] == L.dim[d] - 1) { if (L.pbc[d] == 1) g[d] = 1; else empty = true; }
+        }
+        gi = g[0]; gj = g[1]; gk = g[2];
+      }
+      if (!empty) { int c = fidx(L, gi, gj, gk); t = T1[c]; kk = fd_k[c]; n = natoms[c]; }
+    }
     sT[lx][ly][lz] = t; sK[lx][ly][lz] = kk; sN[lx][ly][lz] = n;
   }
   __syncthreads();
@@ -599,7 +616,7 @@ extern "C" int imdgpu_ttm_diff(imdgpu_ctx *ctx, double tau)
 {
   NEED_TTM();
   ProfScope ps(ctx, PROF_TTM_DIFF);
-  hipLaunchKernelGGL((k_ttm_diff<false>), dim3(diff_grid(t)), dim3(DT_X * DT_Y * DT_Z), 0, ctx->stream, L, tau, t->nsub, 1,
+  hipLaunchKernelGGL((k_ttm_diff<false, false>), dim3(diff_grid(t)), dim3(DT_X * DT_Y * DT_Z), 0, ctx->stream, L, tau, t->nsub, 1,
                      t->natoms, t->temp[t->cur], t->temp[t->cur ^ 1], t->U[t->cur], t->U[t->cur ^ 1], t->fd_k[t->kcur],
                      t->fd_k[t->kcur], t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve, t->ee);
   HIPCHK(hipGetLastError());
@@ -624,13 +641,10 @@ extern "C" int imdgpu_ttm_cfl_maxdt(imdgpu_ctx *ctx, int steps, double *out)
 // the same launch still needs the neighbours' old kappa.
 static int launch_substep_fused(imdgpu_ctx *ctx, TtmState *t, const Lat &L, double tau, int steps)
 {
-  hipLaunchKernelGGL((k_ttm_diff<true>), dim3(diff_grid(t)), dim3(DT_X * DT_Y * DT_Z), 0, ctx->stream, L, tau, t->nsub, steps,
+  hipLaunchKernelGGL((k_ttm_diff<true, true>), dim3(diff_grid(t)), dim3(DT_X * DT_Y * DT_Z), 0, ctx->stream, L, tau, t->nsub, steps,
                      t->natoms, t->temp[t->cur], t->temp[t->cur ^ 1], t->U[t->cur], t->U[t->cur ^ 1], t->fd_k[t->kcur],
                      t->fd_k[t->kcur ^ 1], t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve, t->ee);
   t->cur ^= 1; t->kcur ^= 1;
-  int nf = (t->dim[1] - 2) * (t->dim[2] - 2) + (t->dim[2] - 2) * (t->dim[0] - 2) + (t->dim[0] - 2) * (t->dim[1] - 2);
-  hipLaunchKernelGGL(k_ttm_ghosts, dim3(nblk(nf, 256)), dim3(256), 0, ctx->stream, L, t->natoms, t->temp[t->cur],
-                     t->fd_k[t->kcur]);
   return 0;
 }
 
@@ -662,6 +676,7 @@ extern "C" int imdgpu_calc_ttm(imdgpu_ctx *ctx, int steps)
       for (int i = 0; i < t->nsub; i++) launch_substep_fused(ctx, t, L, tau, steps);
     }
   }
+  if (imdgpu_ttm_fill_ghost_layers(ctx)) return 1;     // sub-steps resolve ghosts on the fly; leave the shell consistent
   HIPCHK(hipGetLastError());
   // CFL_maxdt: value is informational for the host (diff_substeps is fixed by fd_n_timesteps in the
   // sequence implemented here); computed on demand by imdgpu_ttm_cfl_maxdt to keep the step sync-free
@@ -689,6 +704,12 @@ extern "C" int imdgpu_move_atoms_ttm(imdgpu_ctx *ctx, double *ekin)
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (ekin) *ekin = ctx->h_sums[8];
   return 0;
+}
+
+int imdgpu_ttm_move_internal(imdgpu_ctx *ctx)
+{
+  double h = 0.5 * ctx->nbl_margin;
+  return launch_move_ttm(ctx, h * h);
 }
 
 int imdgpu_ttm_step_internal(imdgpu_ctx *ctx, int steps)
