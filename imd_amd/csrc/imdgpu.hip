@@ -543,7 +543,8 @@ __device__ __forceinline__ void block_tile_range(int ntiles, int &t0, int &t1)
 // (NC = 3: x,y,z; NC = 4: x,y,z,dF).  The last slot (slot_cap-1) is a far-away dummy that pads the
 // neighbour list, so the inner loops need no "valid entry" test.  All threads of the block call it.
 template <int NC, bool WITH_T>
-__device__ __forceinline__ void tile_stage(const TileArgs &a, TileCtx &T, double *sp, int *ts, int *hstart, int *hsrc)
+__device__ __forceinline__ void tile_stage(const TileArgs &a, TileCtx &T, double *sp, int *ts, int *hstart, int *hsrc,
+                                           double *sw = nullptr)
 {
   const Geo &g = a.g;
   const int tid = threadIdx.x, nthr = blockDim.x;
@@ -560,9 +561,9 @@ __device__ __forceinline__ void tile_stage(const TileArgs &a, TileCtx &T, double
     hstart[h + 1] = cnt; hsrc[h] = src;
   }
   if (tid == 0) {
-    double *d = sp + (size_t) (a.slot_cap - 1) * NC;
+    double *d = sp + (size_t) (a.slot_cap - 1) * 3;
     d[0] = 1e150; d[1] = 1e150; d[2] = 1e150;
-    if (NC == 4) d[3] = 0.0;
+    if (NC == 4) sw[a.slot_cap - 1] = 0.0;
     if (WITH_T) ts[a.slot_cap - 1] = 0;
   }
   __syncthreads();
@@ -594,9 +595,9 @@ __device__ __forceinline__ void tile_stage(const TileArgs &a, TileCtx &T, double
 #pragma unroll
     for (int u = 0; u < 4; u++)
       if (sl[u] >= 0) {
-        double *d = sp + (size_t) sl[u] * NC;
+        double *d = sp + (size_t) sl[u] * 3;
         d[0] = p[u].x; d[1] = p[u].y; d[2] = p[u].z;
-        if (NC == 4) d[3] = p[u].w;
+        if (NC == 4) sw[sl[u]] = p[u].w;
         if (WITH_T) ts[sl[u]] = tt[u];
       }
   }
@@ -605,9 +606,9 @@ __device__ __forceinline__ void tile_stage(const TileArgs &a, TileCtx &T, double
     for (int e = l + 32; e < n; e += 32)
       if (s + e < a.slot_cap - 1) {
         double4 q = a.pos[src + e];
-        double *d = sp + (size_t) (s + e) * NC;
+        double *d = sp + (size_t) (s + e) * 3;
         d[0] = q.x; d[1] = q.y; d[2] = q.z;
-        if (NC == 4) d[3] = q.w;
+        if (NC == 4) sw[s + e] = q.w;
         if (WITH_T) ts[s + e] = a.type[src + e];
       }
   }
@@ -982,8 +983,9 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass3_tile(TileArgs a)
 {
   extern __shared__ double lds[];
   double *tr = lds;
-  double *sp = tr + a.rho.nrows * a.rho.ncols;
-  double *scratch = sp + 4 * (size_t) a.slot_cap;
+  double *sp = tr + a.rho.nrows * a.rho.ncols;          // xyz records (24 B) ...
+  double *sw = sp + 3 * (size_t) a.slot_cap;             // ... and dF in its own array (fewer bank conflicts than 32 B records)
+  double *scratch = sw + a.slot_cap;
   int *hstart = (int *) (scratch + 64), *hsrc = hstart + NH_MAX + 1, *ts = hsrc + NH_MAX;
   TileCtx T;
   int t0, t1;
@@ -993,14 +995,14 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass3_tile(TileArgs a)
   if (t0 < t1) lds_load_table(tr, a.rho);
   for (T.tile = t0; T.tile < t1; T.tile++) {
     __syncthreads();
-    tile_stage<4, !NT1>(a, T, sp, ts, hstart, hsrc);
+    tile_stage<4, !NT1>(a, T, sp, ts, hstart, hsrc, sw);
     const int nt = a.ntypes, inc = NT1 ? 1 : nt * nt;
     const TabK cr = {a.rho.begin[0], a.rho.end[0], a.rho.invstep[0], 2 * a.rho.invstep[0]};
     for (int o = threadIdx.x; o < T.nown; o += blockDim.x) {
       const int i = T.own_start + o;
       int lx, ly, lz;
       const int slot = own_slot(a, T, i, hstart, hsrc, lx, ly, lz);
-      const double xi = sp[4 * slot], yi = sp[4 * slot + 1], zi = sp[4 * slot + 2], wi = sp[4 * slot + 3];
+      const double xi = sp[3 * slot], yi = sp[3 * slot + 1], zi = sp[3 * slot + 2], wi = sw[slot];
       const int it = NT1 ? 0 : ts[slot];
       const int n4 = (a.nbr_cnt[i] + 3) >> 2;
       const uint2 *lp = (const uint2 *) (a.nbr16 + (size_t) T.tile * a.W4 * a.tile_cap + o);
@@ -1023,8 +1025,8 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass3_tile(TileArgs a)
         double dx[UNR], dy[UNR], dz[UNR], wj[UNR], r2[UNR];
 #pragma unroll
         for (int e = 0; e < UNR; e++) {
-          const double *pj = sp + 4 * j[e];
-          dx[e] = pj[0]; dy[e] = pj[1]; dz[e] = pj[2]; wj[e] = pj[3];
+          const double *pj = sp + 3 * j[e];
+          dx[e] = pj[0]; dy[e] = pj[1]; dz[e] = pj[2]; wj[e] = sw[j[e]];
         }
         SCHED_BARRIER;
 #pragma unroll
