@@ -506,6 +506,7 @@ __global__ __launch_bounds__(512) void k_pass3(ForceArgs a)
 // neighbour list holds 16-bit LDS slot numbers (4 per 8-byte load, ELL-transposed
 // per tile).  HBM sees: list (2 B/entry), own-atom outputs, one staging pass.
 // ===========================================================================
+#define LDS_LIMIT (160 * 1024)
 #define NH_MAX 512                                   // halo cells per tile (<= 6*6*6 = 216 for tiles up to 4^3)
 
 struct TileArgs {
@@ -1312,14 +1313,11 @@ __global__ void k_rekey(int n, const int *acell, Geo gold, Geo gnew, int *keys, 
 
 static int sort_and_build(imdgpu_ctx *ctx);
 
-// shrink the largest tile dimension by one cell and re-sort the atoms into the new key order
-static int shrink_tiles(imdgpu_ctx *ctx)
+// change the tile shape and re-sort the atoms into the new key order
+static int retile(imdgpu_ctx *ctx, const int nt[3])
 {
-  int d = 0;
-  for (int q = 1; q < 3; q++) if (ctx->tile[q] > ctx->tile[d]) d = q;
-  if (ctx->tile[d] <= 1) return imdgpu_fail(ctx, "tiles cannot shrink further");
   const Geo gold = make_geo(ctx);
-  ctx->tile[d]--;
+  for (int d = 0; d < 3; d++) ctx->tile[d] = nt[d];
   HIPCHK(hipStreamSynchronize(ctx->stream));
   // keys of the old arrangement are needed by k_rekey: keep acell, rebuild the rest
   if (setup_tiles(ctx)) return 1;
@@ -1327,6 +1325,67 @@ static int shrink_tiles(imdgpu_ctx *ctx)
   hipLaunchKernelGGL(k_rekey, dim3(nblk(ctx->nlocal, 256)), dim3(256), 0, ctx->stream, ctx->nlocal, ctx->acell, gold, gnew,
                      ctx->keys, ctx->perm);
   return sort_and_build(ctx);
+}
+
+// shrink the largest tile dimension by one cell
+static int shrink_tiles(imdgpu_ctx *ctx)
+{
+  int d = 0, nt[3] = {ctx->tile[0], ctx->tile[1], ctx->tile[2]};
+  for (int q = 1; q < 3; q++) if (nt[q] > nt[d]) d = q;
+  if (nt[d] <= 1) return imdgpu_fail(ctx, "tiles cannot shrink further");
+  nt[d]--;
+  return retile(ctx, nt);
+}
+
+static size_t tile_lds_bytes_for(const imdgpu_ctx *ctx, int slot_cap, int which);
+
+// Pick the tile shape from the actual cell occupancies: the largest tile (fewest halo atoms staged per own
+// atom, fewest workgroup rounds) whose fullest tile still fits one TILE_MAXTHREADS workgroup and whose
+// fullest halo fits the LDS next to the tables.  Runs once per arrangement, on the host.
+static int autotile(imdgpu_ctx *ctx)
+{
+  const int *D = ctx->dim;
+  const int nx = D[0] - 2, ny = D[1] - 2, nz = D[2] - 2;
+  std::vector<int> cc(ctx->nall_cells);
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpy(cc.data(), ctx->cell_cnt, cc.size() * sizeof(int), hipMemcpyDeviceToHost));
+  // 3D inclusive prefix sums over the full (ghost-including) cell array, 1-based
+  const int X = D[0] + 1, Y = D[1] + 1, Z = D[2] + 1;
+  std::vector<long long> P((size_t) X * Y * Z, 0);
+  auto at = [&](int i, int j, int k) -> long long & { return P[((size_t) i * Y + j) * Z + k]; };
+  for (int i = 1; i < X; i++) for (int j = 1; j < Y; j++) for (int k = 1; k < Z; k++)
+    at(i, j, k) = cc[((i - 1) * D[1] + (j - 1)) * D[2] + (k - 1)] + at(i - 1, j, k) + at(i, j - 1, k) + at(i, j, k - 1)
+                  - at(i - 1, j - 1, k) - at(i - 1, j, k - 1) - at(i, j - 1, k - 1) + at(i - 1, j - 1, k - 1);
+  auto boxsum = [&](int i0, int i1, int j0, int j1, int k0, int k1) {   // full-grid cell ranges [i0,i1) etc., clipped
+    i0 = std::max(i0, 0); j0 = std::max(j0, 0); k0 = std::max(k0, 0);
+    i1 = std::min(i1, D[0]); j1 = std::min(j1, D[1]); k1 = std::min(k1, D[2]);
+    return at(i1, j1, k1) - at(i0, j1, k1) - at(i1, j0, k1) - at(i1, j1, k0) + at(i0, j0, k1) + at(i0, j1, k0) + at(i1, j0, k0) - at(i0, j0, k0);
+  };
+  int best[3] = {ctx->tile[0], ctx->tile[1], ctx->tile[2]};
+  double bestscore = -1;
+  for (int bx = 1; bx <= 4; bx++) for (int by = 1; by <= 4; by++) for (int bz = 1; bz <= 4; bz++) {
+    if (bx > nx || by > ny || bz > nz) continue;
+    if ((bx + 2) * (by + 2) * (bz + 2) > NH_MAX) continue;
+    long long maxown = 0, maxhalo = 0, ntl = 0, sumhalo = 0;
+    for (int tx = 0; tx * bx < nx; tx++) for (int ty = 0; ty * by < ny; ty++) for (int tz = 0; tz * bz < nz; tz++) {
+      int i0 = tx * bx + 1, j0 = ty * by + 1, k0 = tz * bz + 1;
+      long long own = boxsum(i0, std::min(i0 + bx, nx + 1), j0, std::min(j0 + by, ny + 1), k0, std::min(k0 + bz, nz + 1));
+      long long halo = boxsum(i0 - 1, i0 + bx + 1, j0 - 1, j0 + by + 1, k0 - 1, k0 + bz + 1);
+      maxown = std::max(maxown, own); maxhalo = std::max(maxhalo, halo); ntl++; sumhalo += halo;
+    }
+    if (maxown > TILE_MAXTHREADS) continue;
+    int slot_cap = (int) ((maxhalo + 1 + 63) / 64 * 64);
+    if (std::max(tile_lds_bytes_for(ctx, slot_cap, 1), tile_lds_bytes_for(ctx, slot_cap, 3)) > LDS_LIMIT) continue;
+    // score: atoms per workgroup round, discounted by the wave imbalance over the 4 SIMDs and by the
+    // per-tile staging cost (grows with staged/own atoms; weight fitted on MI355X timings)
+    int threads = (int) std::min<long long>(TILE_MAXTHREADS, (maxown + 63) / 64 * 64), waves = threads / 64;
+    double score = (double) ctx->nlocal / ntl / ((waves + 3) / 4) / (1.0 + 0.3 * (double) sumhalo / std::max(1, ctx->nlocal))
+                   + 1e-3 * bz;
+    if (score > bestscore) { bestscore = score; best[0] = bx; best[1] = by; best[2] = bz; }
+  }
+  ctx->autotiled = 1;
+  if (bestscore < 0 || (best[0] == ctx->tile[0] && best[1] == ctx->tile[1] && best[2] == ctx->tile[2])) return 0;
+  return retile(ctx, best);
 }
 
 extern "C" int imdgpu_set_geometry(imdgpu_ctx *ctx, const double box[9], const int pbc[3], const int cell_dim[3],
@@ -1670,7 +1729,6 @@ extern "C" int imdgpu_fill_ghosts(imdgpu_ctx *ctx)
 static size_t align8(size_t b) { return (b + 7) & ~(size_t) 7; }
 // persistent tile kernels: one workgroup per CU (their ~140 KB of LDS admit no second one)
 static int tile_grid(const imdgpu_ctx *ctx) { return std::min(ctx->ntiles, ctx->num_cus > 0 ? ctx->num_cus : 256); }
-#define LDS_LIMIT (160 * 1024)
 
 static TileArgs make_tile_args(imdgpu_ctx *ctx)
 {
@@ -1686,6 +1744,15 @@ static TileArgs make_tile_args(imdgpu_ctx *ctx)
   return a;
 }
 
+static size_t tile_lds_bytes(const imdgpu_ctx *ctx, int which /*0 build, 1 pass1, 3 pass3*/);
+static size_t tile_lds_bytes_for(const imdgpu_ctx *ctx, int slot_cap, int which)
+{
+  imdgpu_ctx tmp;                       // only the sizing fields are read
+  tmp.ntypes = ctx->ntypes; tmp.slot_cap = slot_cap;
+  tmp.pair.present = ctx->pair.present; tmp.pair.par = ctx->pair.par;
+  tmp.rho.present = ctx->rho.present; tmp.rho.par = ctx->rho.par;
+  return tile_lds_bytes(&tmp, which);
+}
 static size_t tile_lds_bytes(const imdgpu_ctx *ctx, int which /*0 build, 1 pass1, 3 pass3*/)
 {
   size_t ints = (size_t) (2 * NH_MAX + 1) * sizeof(int) + (ctx->ntypes == 1 ? 0 : (size_t) ctx->slot_cap * sizeof(int));
@@ -1705,6 +1772,11 @@ extern "C" int imdgpu_make_nblist(imdgpu_ctx *ctx)
   Geo g = make_geo(ctx);
   if (imdgpu_fill_ghosts(ctx)) return 1;
   ctx->list_mode = ctx->mode;
+  if (ctx->list_mode == 1 && !ctx->autotiled && !getenv("IMDGPU_TILE")) {
+    if (autotile(ctx)) return 1;
+    g = make_geo(ctx);
+    if (imdgpu_fill_ghosts(ctx)) return 1;
+  }
   for (int retile = 0; ctx->list_mode == 1 && retile < 8; retile++) {
     // size the tiles: largest own-atom count (thread count, list row length) and largest staged count (LDS)
     HIPCHK(hipMemsetAsync(ctx->d_counters + CNT_MAXOWN, 0, 2 * sizeof(int), ctx->stream));

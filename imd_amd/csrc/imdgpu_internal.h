@@ -86,7 +86,7 @@ struct imdgpu_ctx {
 
   // neighbour list, full (symmetric).  mode 0: ELL transposed int32 global indices
   // nbr[k*stride+i]; mode 1: per tile, uint16 LDS-slot indices tl16[(tile*W+k)*tile_cap+a]
-  int mode = 1, list_mode = 0;
+  int mode = 1, list_mode = 0, autotiled = 0;
   int *nbr = nullptr, *nbr_cnt = nullptr;
   unsigned short *nbr16 = nullptr; size_t nbr16_cap = 0;
   int W = 0; size_t stride = 0; size_t nbr_cap = 0;
