@@ -1179,6 +1179,8 @@ __global__ void k_check_only(int n, int cap, const double4 *pos, const double *r
 // ---------------------------------------------------------------------------
 static inline int nblk(long long n, int b) { return (int) ((n + b - 1) / b); }
 
+static int setup_tiles(imdgpu_ctx *ctx);
+
 static void invert_box(const double b[9], double t[9])
 {
   double cx[3] = {b[4] * b[8] - b[5] * b[7], b[5] * b[6] - b[3] * b[8], b[3] * b[7] - b[4] * b[6]};
@@ -1240,6 +1242,11 @@ extern "C" int imdgpu_set_option(imdgpu_ctx *ctx, const char *name, int value)
     if (value != 0 && value != 1) return imdgpu_fail(ctx, "mode must be 0 (global gather) or 1 (LDS tiles)");
     ctx->mode = value; ctx->have_valid_nbl = 0;
     return 0;
+  }
+  if (!strcmp(name, "tile_x") || !strcmp(name, "tile_y") || !strcmp(name, "tile_z")) {
+    if (ctx->nlocal > 0) return imdgpu_fail(ctx, "tile shape must be set before atoms are uploaded");
+    ctx->tile[name[5] - 'x'] = value; ctx->autotiled = 1;
+    return ctx->have_geometry ? setup_tiles(ctx) : 0;
   }
   return imdgpu_fail(ctx, "unknown option %s", name);
 }
@@ -1404,6 +1411,7 @@ extern "C" int imdgpu_set_geometry(imdgpu_ctx *ctx, const double box[9], const i
       return imdgpu_fail(ctx, "periodic direction %d needs >= 3 cells (has %d)", d, gdim[d]);
   }
   const int *D = ctx->dim;
+  ctx->external_halo = (cpu_dim[0] * cpu_dim[1] * cpu_dim[2] > 1) ? 1 : 0;
   ctx->nall_cells = D[0] * D[1] * D[2];
   ctx->ninner_cells = (D[0] - 2) * (D[1] - 2) * (D[2] - 2);
   ctx->nghost_cells = ctx->nall_cells - ctx->ninner_cells;
@@ -1436,6 +1444,7 @@ extern "C" int imdgpu_set_geometry(imdgpu_ctx *ctx, const double box[9], const i
           }
         }
         if (!ghost) continue;
+        if (ctx->external_halo) active = false;       // multi-rank: every ghost cell is filled through imdgpu_halo_scatter
         lin.push_back((i * D[1] + j) * D[2] + k);
         for (int d = 0; d < 3; d++) ctx->h_gsrc_xyz.push_back(active ? s[d] - 1 : -1);
         sh.push_back((sc[0] + 1) + 3 * (sc[1] + 1) + 9 * (sc[2] + 1));
@@ -1717,6 +1726,7 @@ extern "C" int imdgpu_fix_cells(imdgpu_ctx *ctx)
 
 extern "C" int imdgpu_fill_ghosts(imdgpu_ctx *ctx)
 {
+  if (ctx->external_halo) return 0;            // ghost atoms are written by imdgpu_halo_scatter (multi-rank)
   if (ctx->nghost <= 0) return 0;
   ProfScope ps(ctx, PROF_GHOSTS);
   Geo g = make_geo(ctx);
@@ -1772,7 +1782,7 @@ extern "C" int imdgpu_make_nblist(imdgpu_ctx *ctx)
   Geo g = make_geo(ctx);
   if (imdgpu_fill_ghosts(ctx)) return 1;
   ctx->list_mode = ctx->mode;
-  if (ctx->list_mode == 1 && !ctx->autotiled && !getenv("IMDGPU_TILE")) {
+  if (ctx->list_mode == 1 && !ctx->autotiled && !getenv("IMDGPU_TILE") && !ctx->external_halo) {
     if (autotile(ctx)) return 1;
     g = make_geo(ctx);
     if (imdgpu_fill_ghosts(ctx)) return 1;
@@ -1792,7 +1802,7 @@ extern "C" int imdgpu_make_nblist(imdgpu_ctx *ctx)
     ctx->lds_need[1] = tile_lds_bytes(ctx, 1); ctx->lds_need[3] = tile_lds_bytes(ctx, 3);
     size_t need = std::max(ctx->lds_need[1], ctx->lds_need[3]);
     if (need <= LDS_LIMIT && ctx->slot_cap <= 65535 && (g.bx + 2) * (g.by + 2) * (g.bz + 2) <= NH_MAX) break;
-    if (ctx->tile[0] * ctx->tile[1] * ctx->tile[2] > 1) {      // tile + halo does not fit the 160 KB LDS: smaller tiles
+    if (ctx->tile[0] * ctx->tile[1] * ctx->tile[2] > 1 && !ctx->external_halo) {   // tile + halo does not fit the 160 KB LDS: smaller tiles
       if (shrink_tiles(ctx)) return 1;
       g = make_geo(ctx);
       if (imdgpu_fill_ghosts(ctx)) return 1;
@@ -1871,7 +1881,9 @@ extern "C" int imdgpu_check_nblist(imdgpu_ctx *ctx, int *valid)
 }
 
 // launches the three passes; assumes ghosts/list are current
-static int launch_forces(imdgpu_ctx *ctx)
+// phase 0: all three passes; 1 / 2 / 3: only that pass (3 includes the final reduction) -- the split form is
+// used when an external halo exchange (multi-rank) has to run between the passes
+static int launch_forces(imdgpu_ctx *ctx, int phase = 0)
 {
   const int n = ctx->nlocal;
   const bool PAIR = ctx->pair.present, EAM = ctx->rho.present, NT1 = ctx->ntypes == 1, TT = ctx->count_ttm != 0;
@@ -1889,8 +1901,8 @@ static int launch_forces(imdgpu_ctx *ctx)
   TileArgs ta;
   if (TILE) ta = make_tile_args(ctx);
   size_t lds1 = ((PAIR ? a.pair.nrows * a.pair.ncols : 0) + (EAM ? a.rho.nrows * a.rho.ncols : 0) + 64) * sizeof(double);
-  HIPCHK(hipMemsetAsync(ctx->d_counters + CNT_IS_SHORT, 0, sizeof(int), ctx->stream));
-  {
+  if (phase == 0 || phase == 1) {
+    HIPCHK(hipMemsetAsync(ctx->d_counters + CNT_IS_SHORT, 0, sizeof(int), ctx->stream));
     ProfScope ps(ctx, PROF_PASS1);
 #define L1(P, E, T, N)                                                                                          \
   do {                                                                                                          \
@@ -1916,16 +1928,17 @@ static int launch_forces(imdgpu_ctx *ctx)
 #undef L1T
 #undef L1
   }
-  if (ctx->after_pass1) { if (ctx->after_pass1(ctx, ctx->after_pass1_arg)) return 1; }
-  int nb2 = 0;
-  if (EAM) {
-    nb2 = nblk(n, 256);
+  if ((phase == 0 || phase == 1) && ctx->after_pass1) { if (ctx->after_pass1(ctx, ctx->after_pass1_arg)) return 1; }
+  const int nb2 = EAM ? nblk(n, 256) : 0;
+  if (EAM && (phase == 0 || phase == 2)) {
     {
       ProfScope ps(ctx, PROF_PASS2);
       hipLaunchKernelGGL(k_pass2, dim3(nb2), dim3(256), 0, ctx->stream, n, ctx->ntypes, ctx->pos, ctx->type, ctx->rhoh,
                          ctx->epot, ctx->emb.par, ctx->partials);
     }
     if (imdgpu_fill_ghosts(ctx)) return 1;            // dF of the images  [send_cells(copy_dF), :786]
+  }
+  if (EAM && (phase == 0 || phase == 3)) {
     size_t lds3 = ((size_t) a.rho.nrows * a.rho.ncols + 64) * sizeof(double);
     ProfScope ps(ctx, PROF_PASS3);
     if (TILE) {
@@ -1940,7 +1953,7 @@ static int launch_forces(imdgpu_ctx *ctx)
     } else if (NT1) hipLaunchKernelGGL((k_pass3<true>), dim3(nb), dim3(B), lds3, ctx->stream, a);
     else hipLaunchKernelGGL((k_pass3<false>), dim3(nb), dim3(B), lds3, ctx->stream, a);
   }
-  {
+  if (phase == 0 || phase == 3) {
     ProfScope ps(ctx, PROF_REDUCE);
     hipLaunchKernelGGL(k_reduce_force_sums, dim3(1), dim3(1024), 0, ctx->stream, nb, EAM ? nb2 : 0, ctx->partials, ctx->d_sums);
   }
@@ -2001,6 +2014,26 @@ static int fork_ttm(imdgpu_ctx *ctx, void *)
   ctx->stream = main;
   if (rc) return 1;
   HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
+  return 0;
+}
+
+int imdgpu_ensure_capacity(imdgpu_ctx *ctx, int nlocal, int ntot) { return ensure_atom_capacity(ctx, nlocal, ntot); }
+int imdgpu_launch_forces_phase(imdgpu_ctx *ctx, int phase)
+{
+  if (phase == 1 && !ctx->rho.present && zero_eam_partials(ctx)) return 1;
+  return launch_forces(ctx, phase);
+}
+int imdgpu_launch_integrate(imdgpu_ctx *ctx)
+{
+  if (ctx->ttm) return imdgpu_ttm_move_internal(ctx);
+  const int n = ctx->nlocal, nb = nblk(n, 256);
+  double h = 0.5 * ctx->nbl_margin;
+  ProfScope ps(ctx, PROF_INTEGRATE);
+  hipLaunchKernelGGL((k_move_nve<true>), dim3(nb), dim3(256), 0, ctx->stream, n, ctx->cap_local, ctx->pos, ctx->type,
+                     ctx->p, ctx->f, ctx->mass, ctx->d_restr, ctx->ntypes, ctx->timestep, ctx->ref, ctx->partials);
+  hipLaunchKernelGGL(k_reduce_move, dim3(1), dim3(1024), 0, ctx->stream, nb, ctx->partials, ctx->d_sums, h * h,
+                     ctx->d_counters, 1);
+  HIPCHK(hipGetLastError());
   return 0;
 }
 

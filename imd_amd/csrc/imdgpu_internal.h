@@ -87,6 +87,8 @@ struct imdgpu_ctx {
   // neighbour list, full (symmetric).  mode 0: ELL transposed int32 global indices
   // nbr[k*stride+i]; mode 1: per tile, uint16 LDS-slot indices tl16[(tile*W+k)*tile_cap+a]
   int mode = 1, list_mode = 0, autotiled = 0;
+  int external_halo = 0;          // ghost atoms are supplied through imdgpu_halo_scatter (multi-rank decomposition)
+  int *mig_idx[2]{nullptr, nullptr}; int mig_n[2]{0, 0}, mig_cap = 0; int *mig_flag = nullptr;
   int *nbr = nullptr, *nbr_cnt = nullptr;
   unsigned short *nbr16 = nullptr; size_t nbr16_cap = 0;
   int W = 0; size_t stride = 0; size_t nbr_cap = 0;
@@ -189,6 +191,10 @@ static __global__ void k_reduce_move(int nb, const double *partials, double *sum
     counters[CNT_INVALID] = (M > limit2) ? 1 : 0;
   }
 }
+
+int imdgpu_ensure_capacity(imdgpu_ctx *ctx, int nlocal, int ntot);
+int imdgpu_launch_forces_phase(imdgpu_ctx *ctx, int phase);
+int imdgpu_launch_integrate(imdgpu_ctx *ctx);
 
 // TTM entry points called from imdgpu_md_step
 int imdgpu_ttm_step_internal(imdgpu_ctx *ctx, int steps);

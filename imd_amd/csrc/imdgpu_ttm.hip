@@ -19,6 +19,7 @@ struct EosDev { int nx, ny; double xmin, xmax, ymin, ymax; const double *z; };
 struct TtmState {
   int dim[3]{}, ext[3]{}, md_dim[3]{}, pbc[3]{};
   int ncell = 0, ninner = 0;
+  int off[3]{}, ldim[3]{};          // this rank's block of the (replicated, global) lattice: offset and inner extent
   int fd_min_atoms = 0, nsub = 0, cur = 0, kcur = 0;
   double h[3]{}, vol = 0, neighvol = 0, atomic_weight = 0, atomic_charge = 0, omega_laser = 0, Temin = 1e-3;
   double max_dt_ttm = 0;
@@ -43,7 +44,7 @@ struct TtmState {
 #define C_PI 3.14159265358979323846
 
 struct Lat {                      // lattice geometry + parameters by value
-  int dim[3], ext[3], md_dim[3], pbc[3];
+  int dim[3], ext[3], md_dim[3], pbc[3], off[3], ldim[3];
   int fd_min_atoms;
   double h[3], vol, neighvol, atomic_weight, atomic_charge, omega_laser, Temin;
 };
@@ -68,17 +69,20 @@ __device__ __forceinline__ int wsumi(int v)
 // (imd_ttm_3D.c:233-488).  First sweep: natoms, sum numneighs, sum p, sum m;
 // second sweep: sum m*(p/m - vcom)^2.  __shfl reductions, no atomics.
 // ---------------------------------------------------------------------------
+// One rank: results go straight into the lattice.  Several ranks (lattice replicated on every rank, each
+// rank owns the block of FD cells over its MD cells): `blockbuf` != nullptr receives 6 doubles per local
+// FD cell {natoms, md_temp, dens, vcomx, vcomy, vcomz}; k_ttm_apply_blocks folds all ranks' blocks in.
 __global__ void k_ttm_update_fd(Lat L, int steps, int cap, const int *cell_start, const int *cell_cnt,
                                 const int *numneighs, const double *p, const double *mass, int *natoms,
                                 int *natoms_old, double *temp0, double *temp1, double *xi, double *md_temp,
-                                double *source, double *vcom, double *dens, int ncell)
+                                double *source, double *vcom, double *dens, int ncell, double *blockbuf)
 {
   const int lane = threadIdx.x & 63;
   const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int ni = L.dim[0] - 2, nj = L.dim[1] - 2, nk = L.dim[2] - 2;
+  const int ni = L.ldim[0], nj = L.ldim[1], nk = L.ldim[2];
   if (w >= ni * nj * nk) return;
-  const int k = w % nk + 1, j = (w / nk) % nj + 1, i = w / (nk * nj) + 1;
-  const int c = fidx(L, i, j, k);
+  const int k = w % nk + 1, j = (w / nk) % nj + 1, i = w / (nk * nj) + 1;     // local FD coordinates (1-based)
+  const int c = fidx(L, i + L.off[0], j + L.off[1], k + L.off[2]);
   int nat = 0, neigh = 0;
   double sx = 0, sy = 0, sz = 0, sm = 0;
   for (int xc = (i - 1) * L.ext[0] + 1; xc < i * L.ext[0] + 1; xc++)
@@ -115,7 +119,11 @@ __global__ void k_ttm_update_fd(Lat L, int steps, int cap, const int *cell_start
         }
       }
   mt = wsum(mt);
-  if (lane == 0) {
+  if (lane == 0 && blockbuf) {
+    if (nat >= L.fd_min_atoms) mt /= 3.0 * nat; else mt = 0.0;
+    double *o = blockbuf + (size_t) w * 6;
+    o[0] = (double) nat; o[1] = mt; o[2] = d; o[3] = vx; o[4] = vy; o[5] = vz;
+  } else if (lane == 0) {
     if (nat >= L.fd_min_atoms) mt /= 3.0 * nat; else mt = 0.0;
     int old = natoms[c];
     natoms_old[c] = (steps < 1) ? nat : old;
@@ -125,6 +133,25 @@ __global__ void k_ttm_update_fd(Lat L, int steps, int cap, const int *cell_start
     vcom[c] = vx; vcom[ncell + c] = vy; vcom[2 * ncell + c] = vz;
     if (steps < 1 && nat >= L.fd_min_atoms) { temp0[c] = mt; temp1[c] = mt; }
   }
+}
+
+__global__ void k_ttm_apply_blocks(Lat L, int steps, int nblocks, const int *offs /* 3 per block */, int bi, int bj, int bk,
+                                   const double *in, int *natoms, int *natoms_old, double *temp0, double *temp1,
+                                   double *xi, double *md_temp, double *source, double *vcom, double *dens, int ncell)
+{
+  const int per = bi * bj * bk, t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nblocks * per) return;
+  const int b = t / per, w = t - b * per;
+  const int k = w % bk + 1, j = (w / bk) % bj + 1, i = w / (bk * bj) + 1;
+  const int c = fidx(L, i + offs[3 * b], j + offs[3 * b + 1], k + offs[3 * b + 2]);
+  const double *o = in + (size_t) t * 6;
+  const int nat = (int) o[0], old = natoms[c];
+  natoms_old[c] = (steps < 1) ? nat : old;
+  natoms[c] = nat;
+  xi[c] = 0.0; source[c] = 0.0;
+  md_temp[c] = o[1]; dens[c] = o[2];
+  vcom[c] = o[3]; vcom[ncell + c] = o[4]; vcom[2 * ncell + c] = o[5];
+  if (steps < 1 && nat >= L.fd_min_atoms) { temp0[c] = o[1]; temp1[c] = o[1]; }
 }
 
 // ---------------------------------------------------------------------------
@@ -413,7 +440,7 @@ __global__ void k_move_ttm(int n, int cap, Lat L, Geo g, double4 *pos, const int
     const size_t c1 = cap, c2 = 2 * (size_t) cap;
     int ix, iy, iz;
     key_to_xyz(acell[i], g, ix, iy, iz);
-    int fc = fidx(L, ix / L.ext[0] + 1, iy / L.ext[1] + 1, iz / L.ext[2] + 1);
+    int fc = fidx(L, ix / L.ext[0] + 1 + L.off[0], iy / L.ext[1] + 1 + L.off[1], iz / L.ext[2] + 1 + L.off[2]);
     double fxi = natoms[fc] >= L.fd_min_atoms ? xi[fc] : 0.0;
     double vx = vcom[fc], vy = vcom[ncell + fc], vz = vcom[2 * ncell + fc];
     int t = ntypes == 1 ? 0 : type[i];
@@ -455,7 +482,8 @@ static inline int nblk(long long n, int b) { return (int) ((n + b - 1) / b); }
 static Lat make_lat(const TtmState *t)
 {
   Lat L;
-  for (int d = 0; d < 3; d++) { L.dim[d] = t->dim[d]; L.ext[d] = t->ext[d]; L.md_dim[d] = t->md_dim[d]; L.pbc[d] = t->pbc[d]; L.h[d] = t->h[d]; }
+  for (int d = 0; d < 3; d++) { L.dim[d] = t->dim[d]; L.ext[d] = t->ext[d]; L.md_dim[d] = t->md_dim[d]; L.pbc[d] = t->pbc[d]; L.h[d] = t->h[d];
+                                L.off[d] = t->off[d]; L.ldim[d] = t->ldim[d]; }
   L.fd_min_atoms = t->fd_min_atoms; L.vol = t->vol; L.neighvol = t->neighvol; L.atomic_weight = t->atomic_weight;
   L.atomic_charge = t->atomic_charge; L.omega_laser = t->omega_laser; L.Temin = t->Temin;
   return L;
@@ -486,10 +514,14 @@ extern "C" int imdgpu_ttm_init(imdgpu_ctx *ctx, const imdgpu_ttm_params *par)
     if (par->fd_ext[d] < 1 || (ctx->dim[d] - 2) % par->fd_ext[d] != 0)
       return imdgpu_fail(ctx, "cell_dim and fd_ext are not commensurate: cell_dim[%d]=%d fd_ext=%d", d, ctx->dim[d], par->fd_ext[d]);
     t->ext[d] = par->fd_ext[d]; t->md_dim[d] = ctx->dim[d]; t->pbc[d] = ctx->pbc[d];
-    t->dim[d] = (ctx->dim[d] - 2) / par->fd_ext[d] + 2;
+    // The lattice is GLOBAL and replicated on every rank (each rank fills the block over its own MD cells,
+    // blocks are all-gathered once per MD step, the cheap diffusion sub-steps run redundantly everywhere:
+    // no per-sub-step ghost exchange).  One rank: global == local.
+    t->ldim[d] = (ctx->dim[d] - 2) / par->fd_ext[d];
+    t->off[d] = ctx->my_coord[d] * t->ldim[d];
+    t->dim[d] = t->ldim[d] * ctx->cpu_dim[d] + 2;
     // fd_h = fd_ext * (box/global_cell_dim), imd_geom_3d.c:243-246 (orthorhombic diagonal like the reference)
     t->h[d] = par->fd_ext[d] * ctx->box[4 * d] * (1.0 / ctx->gdim[d]);
-    if (ctx->cpu_dim[d] > 1) return imdgpu_fail(ctx, "TTM: multi-rank lattice exchange not implemented in this build");
   }
   t->ncell = t->dim[0] * t->dim[1] * t->dim[2];
   t->ninner = (t->dim[0] - 2) * (t->dim[1] - 2) * (t->dim[2] - 2);
@@ -569,9 +601,38 @@ extern "C" int imdgpu_ttm_update_fd(imdgpu_ctx *ctx, int steps)
 {
   NEED_TTM();
   ProfScope ps(ctx, PROF_TTM_UPDATE);
-  hipLaunchKernelGGL(k_ttm_update_fd, dim3(nblk((long long) t->ninner * 64, 256)), dim3(256), 0, ctx->stream, L, steps,
+  hipLaunchKernelGGL(k_ttm_update_fd, dim3(nblk((long long) t->ldim[0] * t->ldim[1] * t->ldim[2] * 64, 256)), dim3(256), 0, ctx->stream, L, steps,
                      ctx->cap_local, ctx->cell_start, ctx->cell_cnt, ctx->numneighs, ctx->p, ctx->mass, t->natoms,
-                     t->natoms_old, t->temp[0], t->temp[1], t->xi, t->md_temp, t->source, t->vcom, t->dens, t->ncell);
+                     t->natoms_old, t->temp[0], t->temp[1], t->xi, t->md_temp, t->source, t->vcom, t->dens, t->ncell,
+                     (double *) nullptr);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// multi-rank: this rank's block of update_fd results -> dev_out (6 doubles per local FD cell)
+extern "C" int imdgpu_ttm_local_block(imdgpu_ctx *ctx, int steps, double *dev_out, int *ncells_block)
+{
+  NEED_TTM();
+  const int nb = t->ldim[0] * t->ldim[1] * t->ldim[2];
+  if (ncells_block) *ncells_block = nb;
+  if (!dev_out) return 0;
+  ProfScope ps(ctx, PROF_TTM_UPDATE);
+  hipLaunchKernelGGL(k_ttm_update_fd, dim3(nblk((long long) nb * 64, 256)), dim3(256), 0, ctx->stream, L, steps,
+                     ctx->cap_local, ctx->cell_start, ctx->cell_cnt, ctx->numneighs, ctx->p, ctx->mass, t->natoms,
+                     t->natoms_old, t->temp[0], t->temp[1], t->xi, t->md_temp, t->source, t->vcom, t->dens, t->ncell, dev_out);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// multi-rank: fold the all-gathered blocks of all ranks into the replicated lattice.
+// dev_in: nblocks * ncells_block * 6 doubles in rank order; dev_offs: 3 ints per block (FD-cell offset of that rank)
+extern "C" int imdgpu_ttm_apply_blocks(imdgpu_ctx *ctx, int steps, const double *dev_in, int nblocks, const int *dev_offs)
+{
+  NEED_TTM();
+  const int per = t->ldim[0] * t->ldim[1] * t->ldim[2];
+  hipLaunchKernelGGL(k_ttm_apply_blocks, dim3(nblk((long long) nblocks * per, 256)), dim3(256), 0, ctx->stream, L, steps, nblocks,
+                     dev_offs, t->ldim[0], t->ldim[1], t->ldim[2], dev_in, t->natoms, t->natoms_old, t->temp[0], t->temp[1],
+                     t->xi, t->md_temp, t->source, t->vcom, t->dens, t->ncell);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -650,10 +711,17 @@ static int launch_substep_fused(imdgpu_ctx *ctx, TtmState *t, const Lat &L, doub
 
 extern "C" int imdgpu_calc_ttm(imdgpu_ctx *ctx, int steps)
 {
+  if (ctx->external_halo) return imdgpu_fail(ctx, "calc_ttm: with several ranks use ttm_local_block / apply_blocks / ttm_lattice_step");
+  if (imdgpu_ttm_update_fd(ctx, steps)) return 1;
+  return imdgpu_ttm_lattice_step(ctx, steps);
+}
+
+// everything of calc_ttm after update_fd: activation, FILLMESH, ghosts, the diffusion sub-steps
+extern "C" int imdgpu_ttm_lattice_step(imdgpu_ctx *ctx, int steps)
+{
   NEED_TTM();
   const double tau = ctx->timestep / ((double) t->nsub);
-  if (imdgpu_ttm_update_fd(ctx, steps) || imdgpu_ttm_cell_activation(ctx) || imdgpu_ttm_fillmesh(ctx, steps) ||
-      imdgpu_ttm_fill_ghost_layers(ctx)) return 1;
+  if (imdgpu_ttm_cell_activation(ctx) || imdgpu_ttm_fillmesh(ctx, steps) || imdgpu_ttm_fill_ghost_layers(ctx)) return 1;
   {
     ProfScope ps(ctx, PROF_TTM_DIFF);
     // the sub-step loop never returns to the host: nsub even => the ping-pong state after the loop equals

@@ -1,0 +1,372 @@
+"""Spatial decomposition over several GPUs: one rank per GPU, ghost-cell halo
+exchange and atom migration over torch.distributed (backend "nccl" = RCCL over
+xGMI on the GPU box, "gloo" in the CPU tests).
+
+This is the host-side restatement of the reference's MPI layer:
+  - rank grid and neighbours: setup_mpi_topology (imd_geom_mpi_3d.c:32-90),
+  - forward halo in Plimpton's three stages z, y, x with the periodic shift added
+    by the sending boundary rank: send_cells (imd_comm_force_3d.c:222-396),
+  - atom migration when the neighbour list is rebuilt: fix_cells -> send_atoms
+    (imd_fix_cells_3d.c:43-306,436-542),
+  - list validity as a global MAX: check_nblist (imd_forces_nbl.c:1087).
+Because the device kernels gather over full neighbour lists, only positions and
+dF travel (forward); the reference's two reverse exchanges (rho, forces) do not
+exist here.  Every ghost direction is filled (the non-AR shell).
+
+`ops` is the per-rank device: GpuOps (libimdgpu through the C ABI) in production;
+the CPU tests plug in a numpy stand-in with the same methods, which is how the
+N>1 logic is exercised without a GPU.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def rank_to_coord(rank, cpu_dim):
+    pz = cpu_dim[2]
+    py = cpu_dim[1]
+    return (rank // (py * pz), (rank // pz) % py, rank % pz)
+
+
+def coord_to_rank(c, cpu_dim):
+    return (c[0] * cpu_dim[1] + c[1]) * cpu_dim[2] + c[2]
+
+
+def choose_cpu_dim(world):
+    """Most cubic factorisation: 8 -> 2x2x2 so that the 6 faces use 6 different xGMI links
+    (calc_cpu_dim, imd_geom_mpi_3d.c:201, picks the same for powers of two)."""
+    best = (world, 1, 1)
+    for a in range(1, world + 1):
+        if world % a:
+            continue
+        for b in range(1, world // a + 1):
+            if (world // a) % b:
+                continue
+            c = world // a // b
+            cand = tuple(sorted((a, b, c), reverse=True))
+            if max(cand) - min(cand) < max(best) - min(best):
+                best = cand
+    return best
+
+
+class Decomposition:
+    """Geometry of one rank: local cell array (with ghost layer), neighbours, stage cell lists."""
+
+    def __init__(self, rank, cpu_dim, global_cell_dim, box, pbc):
+        self.rank, self.cpu_dim = rank, tuple(int(v) for v in cpu_dim)
+        self.coord = rank_to_coord(rank, self.cpu_dim)
+        self.gdim = tuple(int(v) for v in global_cell_dim)
+        for d in range(3):
+            if self.gdim[d] % self.cpu_dim[d]:
+                raise ValueError("global_cell_dim must be a multiple of cpu_dim")
+        self.dim = tuple(self.gdim[d] // self.cpu_dim[d] + 2 for d in range(3))       # cell_dim incl. ghosts
+        self.box = np.asarray(box, dtype=np.float64).reshape(3, 3)
+        self.pbc = tuple(int(v) for v in pbc)
+        self.nall = int(np.prod(self.dim))
+        self.lo, self.hi, self.shift_lo, self.shift_hi = [], [], [], []
+        for d in range(3):
+            P, c = self.cpu_dim[d], self.coord[d]
+            lo = hi = None
+            if c > 0 or self.pbc[d]:
+                n = list(self.coord); n[d] = (c - 1) % P; lo = coord_to_rank(n, self.cpu_dim)
+            if c < P - 1 or self.pbc[d]:
+                n = list(self.coord); n[d] = (c + 1) % P; hi = coord_to_rank(n, self.cpu_dim)
+            self.lo.append(lo); self.hi.append(hi)
+            # periodic image shift added by the SENDING boundary rank (imd_comm_force_3d.c:247-266)
+            self.shift_lo.append(self.box[d] * (1.0 if (c == 0 and self.pbc[d]) else 0.0))
+            self.shift_hi.append(self.box[d] * (-1.0 if (c == P - 1 and self.pbc[d]) else 0.0))
+
+    def lin(self, i, j, k):
+        return (i * self.dim[1] + j) * self.dim[2] + k
+
+    def stage_cells(self, d):
+        """Cell lists of stage d: (send_lo, send_hi, recv_lo, recv_hi) as linear indices.
+        Stage z covers inner x,y; stage y inner x and ALL z; stage x ALL y,z (edges travel twice,
+        corners three times: imd_comm_force_3d.c:213-217)."""
+        D = self.dim
+        rng = {0: None, 1: None, 2: None}
+        if d == 2:
+            rng[0], rng[1] = range(1, D[0] - 1), range(1, D[1] - 1)
+        elif d == 1:
+            rng[0], rng[2] = range(1, D[0] - 1), range(0, D[2])
+        else:
+            rng[1], rng[2] = range(0, D[1]), range(0, D[2])
+        others = [q for q in range(3) if q != d]
+        a, b = np.meshgrid(np.array(rng[others[0]]), np.array(rng[others[1]]), indexing="ij")
+        a, b = a.ravel(), b.ravel()
+
+        def layer(v):
+            idx = [None, None, None]
+            idx[d] = np.full_like(a, v)
+            idx[others[0]], idx[others[1]] = a, b
+            return ((idx[0] * D[1] + idx[1]) * D[2] + idx[2]).astype(np.int64)
+        return layer(1), layer(D[d] - 2), layer(0), layer(D[d] - 1)
+
+
+def _exchange(dec, d, buf_lo, buf_hi, like_lo, like_hi, group=None):
+    """Send buf_lo to the low neighbour and buf_hi to the high one; returns (from_lo, from_hi) where
+    from_lo is the low neighbour's HIGH layer and from_hi the high neighbour's LOW layer.
+    like_*: (numel, dtype) of what arrives.  Self-neighbours (cpu_dim[d]==1) short-circuit."""
+    lo, hi = dec.lo[d], dec.hi[d]
+    if dec.cpu_dim[d] == 1:
+        return (buf_hi if lo is not None else None), (buf_lo if hi is not None else None)
+    ops, from_lo, from_hi = [], None, None
+    dev = buf_lo.device if buf_lo is not None else buf_hi.device
+    if lo is not None:
+        ops.append(dist.P2POp(dist.isend, buf_lo, lo, group))
+    if hi is not None:
+        ops.append(dist.P2POp(dist.isend, buf_hi, hi, group))
+    if hi is not None:
+        from_hi = torch.empty(like_hi[0], dtype=like_hi[1], device=dev)
+        ops.append(dist.P2POp(dist.irecv, from_hi, hi, group))
+    if lo is not None:
+        from_lo = torch.empty(like_lo[0], dtype=like_lo[1], device=dev)
+        ops.append(dist.P2POp(dist.irecv, from_lo, lo, group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return from_lo, from_hi
+
+
+WHAT_WIDTH = {0: (4, torch.float64), 1: (1, torch.float64), 2: (1, torch.int32)}
+
+
+class HaloPlan:
+    """Index lists of one rebuild: per stage what to gather for each neighbour and where arrivals go."""
+
+    def __init__(self, dec, ops):
+        self.dec, self.stages = dec, []
+        cs, cc = ops.cell_tables()
+        cs, cc = cs.astype(np.int64), cc.astype(np.int64)
+        nlocal = ops.nlocal()
+        ghost_mask = np.ones(dec.nall, bool)
+        D = dec.dim
+        ii, jj, kk = np.meshgrid(range(1, D[0] - 1), range(1, D[1] - 1), range(1, D[2] - 1), indexing="ij")
+        ghost_mask[((ii * D[1] + jj) * D[2] + kk).ravel()] = False
+        cc[ghost_mask] = 0
+        nghost = 0
+        dev = ops.device
+        for d in (2, 1, 0):
+            s_lo, s_hi, r_lo, r_hi = dec.stage_cells(d)
+            c_lo, c_hi = torch.from_numpy(cc[s_lo].astype(np.int32)).to(dev), torch.from_numpy(cc[s_hi].astype(np.int32)).to(dev)
+            f_lo, f_hi = _exchange(dec, d, c_lo, c_hi, (len(r_lo), torch.int32), (len(r_hi), torch.int32))
+            st = dict(d=d)
+            for name, cells, cnts in (("lo", r_lo, f_lo), ("hi", r_hi, f_hi)):
+                if cnts is None:
+                    st["recv_" + name] = None
+                    continue
+                cn = cnts.cpu().numpy().astype(np.int64)
+                start = nlocal + nghost + np.concatenate([[0], np.cumsum(cn)[:-1]])
+                cc[cells], cs[cells] = cn, start
+                tot = int(cn.sum())
+                st["recv_" + name] = (nlocal + nghost, tot)
+                nghost += tot
+            for name, cells, nb in (("lo", s_lo, dec.lo[d]), ("hi", s_hi, dec.hi[d])):
+                if nb is None:
+                    st["send_" + name] = None
+                    continue
+                n = cc[cells]
+                # atoms of the listed cells, cell after cell (the same order the receiver laid its ghosts out in)
+                idx = np.repeat(cs[cells] - np.concatenate([[0], np.cumsum(n)[:-1]]), n) + np.arange(int(n.sum()))
+                st["send_" + name] = torch.from_numpy(idx.astype(np.int32)).to(dev)
+            self.stages.append(st)
+        self.nghost = nghost
+        ops.set_ghost_layout(cs.astype(np.int32), cc.astype(np.int32), nghost)
+        for st in self.stages:       # arrivals land in one contiguous range per neighbour
+            for name in ("lo", "hi"):
+                if st["recv_" + name] is not None:
+                    a, n = st["recv_" + name]
+                    st["ridx_" + name] = torch.arange(a, a + n, dtype=torch.int32, device=dev)
+
+    def exchange(self, ops, what):
+        """Forward halo of `what` (0 positions+dF, 1 dF, 2 types) in the stages z, y, x."""
+        w, dt = WHAT_WIDTH[what]
+        dec = self.dec
+        for st in self.stages:
+            d = st["d"]
+            b_lo = ops.gather(what, st["send_lo"], dec.shift_lo[d]) if st["send_lo"] is not None else None
+            b_hi = ops.gather(what, st["send_hi"], dec.shift_hi[d]) if st["send_hi"] is not None else None
+            n_lo = st["recv_lo"][1] * w if st["recv_lo"] is not None else 0
+            n_hi = st["recv_hi"][1] * w if st["recv_hi"] is not None else 0
+            f_lo, f_hi = _exchange(dec, d, b_lo, b_hi, (n_lo, dt), (n_hi, dt))
+            if st["recv_lo"] is not None and f_lo is not None:
+                ops.scatter(what, st["ridx_lo"], f_lo)
+            if st["recv_hi"] is not None and f_hi is not None:
+                ops.scatter(what, st["ridx_hi"], f_hi)
+
+
+class DistributedMD:
+    """The MD step of one rank among several: same sequence as imdgpu_md_step, with the halo
+    exchanges placed between the force passes (main_loop body, imd_main_3d.c:406-812)."""
+
+    def __init__(self, dec, ops, ttm=False):
+        self.dec, self.ops, self.ttm = dec, ops, ttm
+        self.plan = None
+        self.valid = False
+        self.nrebuild = 0
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        if ttm:
+            offs = []
+            for r in range(self.world):
+                c = rank_to_coord(r, dec.cpu_dim)
+                offs += [c[d] * ops.ttm_block_dims()[d] for d in range(3)]
+            self._ttm_offs = torch.tensor(offs, dtype=torch.int32, device=ops.device)
+
+    # -- rebuild: migration, re-binning, ghost layout, neighbour list ------------------------
+    def _migrate(self):
+        dec, ops = self.dec, self.ops
+        for d in range(3):
+            if dec.cpu_dim[d] == 1:
+                continue
+            n_lo, n_hi = ops.migrate_scan(d)
+            cnt = torch.tensor([n_lo, n_hi], dtype=torch.int32, device=ops.device)
+            f_lo, f_hi = _exchange(dec, d, cnt[0:1].clone() if dec.lo[d] is not None else None,
+                                   cnt[1:2].clone() if dec.hi[d] is not None else None, (1, torch.int32), (1, torch.int32))
+            in_lo = int(f_lo.item()) if f_lo is not None else 0       # what the low neighbour sends up to me
+            in_hi = int(f_hi.item()) if f_hi is not None else 0
+            b_lo = ops.migrate_gather(0) if dec.lo[d] is not None else None
+            b_hi = ops.migrate_gather(1) if dec.hi[d] is not None else None
+            if (dec.lo[d] is None and n_lo) or (dec.hi[d] is None and n_hi):
+                raise RuntimeError("atoms left the simulation box through an open boundary")
+            r_lo, r_hi = _exchange(dec, d, b_lo, b_hi, (in_lo * 10, torch.float64), (in_hi * 10, torch.float64))
+            ops.migrate_apply(r_lo, in_lo, r_hi, in_hi)
+
+    def rebuild(self):
+        ops = self.ops
+        if self.nrebuild > 0:
+            self._migrate()
+        ops.fix_cells()
+        self.plan = HaloPlan(self.dec, ops)
+        self.plan.exchange(ops, 0)
+        if ops.ntypes > 1:
+            self.plan.exchange(ops, 2)
+        ops.make_nblist()
+        self.valid = True
+        self.nrebuild += 1
+
+    # -- one MD step ------------------------------------------------------------------------------
+    def md_step(self, step):
+        ops = self.ops
+        if not self.valid:
+            self.rebuild()
+        else:
+            self.plan.exchange(ops, 0)
+        ops.forces_phase(1)
+        if self.ttm:
+            blk = ops.ttm_local_block(step)
+            if self.world > 1:
+                allb = torch.empty(self.world * blk.numel(), dtype=blk.dtype, device=blk.device)
+                dist.all_gather_into_tensor(allb, blk)
+            else:
+                allb = blk
+            ops.ttm_apply_blocks(step, allb, self.world, self._ttm_offs)
+            ops.ttm_lattice_step(step)
+        ops.forces_phase(2)
+        self.plan.exchange(ops, 1)                       # dF of the ghost atoms  [send_cells(copy_dF)]
+        ops.forces_phase(3)
+        ops.integrate()
+        flag = torch.tensor([ops.get_invalid()], dtype=torch.int32, device=ops.device)
+        if self.world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)  # MPI_Allreduce MAX of check_nblist
+        if int(flag.item()):
+            self.valid = False
+            ops.invalidate()
+
+    def global_sums(self):
+        s = self.ops.get_sums()
+        t = torch.tensor([s["tot_pot_energy"], s["virial"], s["tot_kin_energy"], float(self.ops.nlocal())],
+                         dtype=torch.float64, device=self.ops.device)
+        if self.world > 1:
+            dist.all_reduce(t)
+        return dict(tot_pot_energy=float(t[0]), virial=float(t[1]), tot_kin_energy=float(t[2]), natoms=int(t[3]))
+
+
+class GpuOps:
+    """libimdgpu behind the interface DistributedMD / HaloPlan need; buffers are torch CUDA tensors."""
+
+    def __init__(self, sysm, device):
+        import ctypes as C
+        self.C, self.s, self.L, self.h = C, sysm, sysm.L, sysm.h
+        self.device = torch.device("cuda", device)
+        self.ntypes = sysm.ntypes
+        sysm.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _ck(self, rc):
+        self.s._ck(rc)
+
+    def nlocal(self):
+        return self.s.num_atoms()[0]
+
+    def cell_tables(self):
+        cs = np.zeros(self.s.nallcells, np.int32); cc = np.zeros(self.s.nallcells, np.int32)
+        C = self.C
+        self._ck(self.L.imdgpu_get_cell_tables(self.h, cs.ctypes.data_as(C.POINTER(C.c_int)), cc.ctypes.data_as(C.POINTER(C.c_int))))
+        return cs, cc
+
+    def set_ghost_layout(self, cs, cc, nghost):
+        C = self.C
+        cs, cc = np.ascontiguousarray(cs, np.int32), np.ascontiguousarray(cc, np.int32)
+        self._ck(self.L.imdgpu_set_ghost_layout(self.h, cs.ctypes.data_as(C.POINTER(C.c_int)),
+                                                cc.ctypes.data_as(C.POINTER(C.c_int)), int(nghost)))
+
+    def gather(self, what, idx, shift):
+        C = self.C
+        w, dt = WHAT_WIDTH[what]
+        out = torch.empty(idx.numel() * w, dtype=dt, device=self.device)
+        sh = np.ascontiguousarray(shift, np.float64)
+        self._ck(self.L.imdgpu_halo_gather(self.h, what, C.c_void_p(idx.data_ptr()), idx.numel(),
+                                           sh.ctypes.data_as(C.POINTER(C.c_double)), C.c_void_p(out.data_ptr())))
+        return out
+
+    def scatter(self, what, idx, buf):
+        C = self.C
+        self._ck(self.L.imdgpu_halo_scatter(self.h, what, C.c_void_p(idx.data_ptr()), idx.numel(), C.c_void_p(buf.data_ptr())))
+
+    def migrate_scan(self, d):
+        C = self.C
+        a, b = C.c_int(), C.c_int()
+        self._ck(self.L.imdgpu_migrate_scan(self.h, d, C.byref(a), C.byref(b)))
+        self._mig = (a.value, b.value)
+        return a.value, b.value
+
+    def migrate_gather(self, direction):
+        C = self.C
+        out = torch.empty(self._mig[direction] * 10, dtype=torch.float64, device=self.device)
+        self._ck(self.L.imdgpu_migrate_gather(self.h, direction, C.c_void_p(out.data_ptr())))
+        return out
+
+    def migrate_apply(self, r_lo, n_lo, r_hi, n_hi):
+        C = self.C
+        self._ck(self.L.imdgpu_migrate_apply(self.h, C.c_void_p(r_lo.data_ptr() if n_lo else 0), n_lo,
+                                             C.c_void_p(r_hi.data_ptr() if n_hi else 0), n_hi))
+
+    def fix_cells(self): self.s.fix_cells()
+    def make_nblist(self): self.s.make_nblist()
+    def forces_phase(self, k): self._ck(self.L.imdgpu_forces_phase(self.h, k))
+    def integrate(self): self._ck(self.L.imdgpu_integrate(self.h))
+    def invalidate(self): self._ck(self.L.imdgpu_invalidate(self.h))
+    def get_sums(self): return self.s.get_sums()
+
+    def get_invalid(self):
+        v = self.C.c_int()
+        self._ck(self.L.imdgpu_get_invalid(self.h, self.C.byref(v)))
+        return v.value
+
+    # TTM (replicated lattice)
+    def ttm_block_dims(self):
+        return tuple((self.s.cell_dim[d] - 2) // self.s.fd_ext[d] for d in range(3))
+
+    def ttm_local_block(self, step):
+        C = self.C
+        n = C.c_int()
+        self._ck(self.L.imdgpu_ttm_local_block(self.h, step, None, C.byref(n)))
+        out = torch.empty(n.value * 6, dtype=torch.float64, device=self.device)
+        self._ck(self.L.imdgpu_ttm_local_block(self.h, step, C.c_void_p(out.data_ptr()), C.byref(n)))
+        return out
+
+    def ttm_apply_blocks(self, step, allb, nblocks, offs):
+        C = self.C
+        self._ck(self.L.imdgpu_ttm_apply_blocks(self.h, step, C.c_void_p(allb.data_ptr()), nblocks, C.c_void_p(offs.data_ptr())))
+
+    def ttm_lattice_step(self, step):
+        self._ck(self.L.imdgpu_ttm_lattice_step(self.h, step))

@@ -229,6 +229,7 @@ class GpuSystem:
         h = np.zeros(3)
         self._ck(self.L.imdgpu_ttm_dims(self.h, _ip(d), _dp(h)))
         self.fd_dim, self.fd_h = tuple(int(v) for v in d), h
+        self.fd_ext = tuple(int(v) for v in fd_ext)
         self.diff_substeps = int(fd_n_timesteps)
 
     def ttm_download(self, fields=TTM_FIELDS):

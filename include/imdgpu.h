@@ -178,6 +178,36 @@ int imdgpu_calc_ttm(imdgpu_ctx *ctx, int steps);
 /* [move_atoms_ttm, imd_integrate.c:581-811] */
 int imdgpu_move_atoms_ttm(imdgpu_ctx *ctx, double *tot_kin_energy);
 
+/* ---- multi-GPU spatial decomposition (one rank per GPU) --------------------- */
+/* The reference's Plimpton exchange (send_cells / send_forces, imd_comm_force_3d.c:
+ * 222-396,569-715) and atom migration (fix_cells -> send_atoms, imd_fix_cells_3d.c:
+ * 43-306,436-542) become: decomposition logic on the host (imd_amd/parallel.py or an
+ * MPI host), transport over RCCL/xGMI, and these generic device operations.  With
+ * cpu_dim > 1 in imdgpu_set_geometry every ghost cell is owned by the host layer.
+ * All dev_* pointers are device memory of the same GPU. */
+int imdgpu_get_cell_tables(imdgpu_ctx *ctx, int *cell_start /*nallcells*/, int *cell_cnt /*nallcells*/);
+int imdgpu_set_ghost_layout(imdgpu_ctx *ctx, const int *cell_start, const int *cell_cnt, int nghost);
+/* what: 0 = (x,y,z,dF) record of 4 doubles, positions shifted by `shift` (periodic image,
+ *       imd_comm_force_3d.c:247-266); 1 = dF only (1 double) [copy_dF]; 2 = type (int) */
+int imdgpu_halo_gather(imdgpu_ctx *ctx, int what, const int *dev_idx, int n, const double shift[3], void *dev_out);
+int imdgpu_halo_scatter(imdgpu_ctx *ctx, int what, const int *dev_idx, int n, const void *dev_in);
+/* migration along one direction: mark + count atoms whose cell belongs to the lower / higher neighbour rank,
+ * pack them (10 doubles each: x y z px py pz mass type id pad), drop them and append the arrivals */
+int imdgpu_migrate_scan(imdgpu_ctx *ctx, int dim, int *n_lo, int *n_hi);
+int imdgpu_migrate_gather(imdgpu_ctx *ctx, int dir /*0 low, 1 high*/, void *dev_out);
+int imdgpu_migrate_apply(imdgpu_ctx *ctx, const void *dev_in_lo, int n_in_lo, const void *dev_in_hi, int n_in_hi);
+/* the MD step in pieces, all asynchronous on the context's stream: exchanges go between them.
+ * phase 1 = pair + rho pass, 2 = embedding pass, 3 = EAM force pass + sums (calc_forces, imd_forces_nbl.c) */
+int imdgpu_forces_phase(imdgpu_ctx *ctx, int phase);
+int imdgpu_integrate(imdgpu_ctx *ctx);                 /* move_atoms_{nve|ttm} + displacement check */
+int imdgpu_get_invalid(imdgpu_ctx *ctx, int *flag);    /* check_nblist result of this rank (synchronises) */
+int imdgpu_invalidate(imdgpu_ctx *ctx);                /* some rank asked for a rebuild (MPI_Allreduce MAX, :1087) */
+/* TTM with several ranks: the FD lattice is replicated; each rank computes update_fd for the block over
+ * its own MD cells (6 doubles per FD cell), blocks are all-gathered and folded in, the sub-steps run everywhere */
+int imdgpu_ttm_local_block(imdgpu_ctx *ctx, int steps, double *dev_out, int *ncells_block);
+int imdgpu_ttm_apply_blocks(imdgpu_ctx *ctx, int steps, const double *dev_in, int nblocks, const int *dev_offs);
+int imdgpu_ttm_lattice_step(imdgpu_ctx *ctx, int steps);
+
 /* ---- profiling ------------------------------------------------------------ */
 /* Accumulate HIP-event timings per kernel class on the context's stream. */
 int imdgpu_profile_enable(imdgpu_ctx *ctx, int on);

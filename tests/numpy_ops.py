@@ -1,0 +1,177 @@
+"""TEST INFRASTRUCTURE: a numpy stand-in for the per-rank device (imd_amd.parallel.GpuOps) so that the
+multi-rank host logic (decomposition, staged halo, migration, step sequence) runs under gloo on CPUs.
+Forces are brute force over local + ghost atoms with the same 3-point table rule."""
+import numpy as np
+import torch
+
+
+def tab_eval(t, r2):
+    """value and 2*derivative of a one-column pot_table dict (PAIR_INT2, potaccess.h:323-354)."""
+    a = np.minimum(r2, t["end"][0]) - t["begin"][0]
+    a = np.maximum(a, 0.0) * t["invstep"][0]
+    k = a.astype(np.int64)
+    chi = a - k
+    tb = t["table"]
+    p0, p1, p2 = tb[k], tb[k + 1], tb[k + 2]
+    dv, d2v = p1 - p0, p2 - 2 * p1 + p0
+    return p0 + chi * dv + 0.5 * chi * (chi - 1) * d2v, 2 * t["invstep"][0] * (dv + (chi - 0.5) * d2v)
+
+
+class NumpyOps:
+    def __init__(self, dec, pair, rho, emb, cellsz, nbl_margin, timestep):
+        self.dec, self.pair, self.rho, self.emb = dec, pair, rho, emb
+        self.cellsz, self.margin, self.dt = cellsz, nbl_margin, timestep
+        self.device = torch.device("cpu")
+        self.ntypes = 1
+        self.n = 0
+        self.invalid = 0
+        self.sums = dict(tot_pot_energy=0.0, virial=0.0, tot_kin_energy=0.0)
+
+    # -- atoms ---------------------------------------------------------------------
+    def upload(self, pos, mom, mass, ident):
+        self.n = len(pos)
+        self.pos = np.zeros((self.n, 4)); self.pos[:, :3] = pos
+        self.p, self.mass, self.id = mom.copy(), np.broadcast_to(mass, (self.n,)).copy(), ident.copy()
+        self.type = np.zeros(self.n, np.int32)
+
+    def nlocal(self):
+        return self.n
+
+    def _local_lin(self, pos):
+        dec = self.dec
+        t = np.linalg.inv(dec.box).T
+        s = pos[:, :3] @ t.T
+        c = np.clip((np.array(dec.gdim) * s).astype(np.int64), 0, np.array(dec.gdim) - 1)
+        loc = c - np.array(dec.coord) * (np.array(dec.dim) - 2) + 1
+        return loc
+
+    def fix_cells(self):
+        dec = self.dec
+        t = np.linalg.inv(dec.box).T
+        for d in range(3):
+            if dec.pbc[d]:
+                s = -np.floor(self.pos[:self.n, :3] @ t[d])
+                self.pos[:self.n, :3] += s[:, None] * dec.box[d]
+        loc = self._local_lin(self.pos[:self.n])
+        assert ((loc >= 1) & (loc <= np.array(dec.dim) - 2)).all(), "atom outside this rank's domain after migration"
+        lin = (loc[:, 0] * dec.dim[1] + loc[:, 1]) * dec.dim[2] + loc[:, 2]
+        o = np.argsort(lin, kind="stable")
+        for name in ("pos", "p", "mass", "id", "type"):
+            a = getattr(self, name); a[:self.n] = a[:self.n][o]
+        self.cc = np.bincount(lin, minlength=dec.nall).astype(np.int32)
+        self.cs = np.concatenate([[0], np.cumsum(self.cc)[:-1]]).astype(np.int32)
+        self.invalid = 0
+
+    def cell_tables(self):
+        return self.cs.copy(), self.cc.copy()
+
+    def set_ghost_layout(self, cs, cc, nghost):
+        self.cs, self.cc, self.nghost = cs.copy(), cc.copy(), nghost
+        allp = np.zeros((self.n + nghost, 4)); allp[:self.n] = self.pos[:self.n]
+        self.pos = allp
+
+    def gather(self, what, idx, shift):
+        i = idx.numpy().astype(np.int64)
+        if what == 0:
+            out = self.pos[i].copy(); out[:, :3] += np.asarray(shift)
+            return torch.from_numpy(out.reshape(-1))
+        if what == 1:
+            return torch.from_numpy(self.pos[i, 3].copy())
+        return torch.zeros(len(i), dtype=torch.int32)
+
+    def scatter(self, what, idx, buf):
+        i = idx.numpy().astype(np.int64)
+        if what == 0:
+            self.pos[i] = buf.numpy().reshape(-1, 4)
+        elif what == 1:
+            self.pos[i, 3] = buf.numpy()
+
+    # -- migration -------------------------------------------------------------------
+    def migrate_scan(self, d):
+        dec = self.dec
+        t = np.linalg.inv(dec.box).T
+        s = self.pos[:self.n, :3] @ t[d]
+        if dec.pbc[d]:
+            s = s - np.floor(s)
+        c = np.clip((dec.gdim[d] * s).astype(np.int64), 0, dec.gdim[d] - 1)
+        dr = c // (dec.dim[d] - 2) - dec.coord[d]
+        P = dec.cpu_dim[d]
+        if dec.pbc[d]:
+            dr = np.where(2 * dr > P, dr - P, dr); dr = np.where(2 * dr < -P, dr + P, dr)
+        self._flag = np.where(dr < 0, 1, np.where(dr > 0, 2, 0))
+        return int((self._flag == 1).sum()), int((self._flag == 2).sum())
+
+    def migrate_gather(self, direction):
+        m = self._flag == direction + 1
+        rec = np.zeros((int(m.sum()), 10))
+        rec[:, :3], rec[:, 3:6], rec[:, 6], rec[:, 8] = self.pos[:self.n][m, :3], self.p[m], self.mass[m], self.id[m]
+        return torch.from_numpy(rec.reshape(-1))
+
+    def migrate_apply(self, r_lo, n_lo, r_hi, n_hi):
+        stay = self._flag == 0
+        recs = [r.numpy().reshape(-1, 10) for r, n in ((r_lo, n_lo), (r_hi, n_hi)) if n]
+        inc = np.concatenate(recs) if recs else np.zeros((0, 10))
+        pos = np.zeros((stay.sum() + len(inc), 4)); pos[:stay.sum(), :3] = self.pos[:self.n][stay, :3]; pos[stay.sum():, :3] = inc[:, :3]
+        self.p = np.concatenate([self.p[stay], inc[:, 3:6]])
+        self.mass = np.concatenate([self.mass[stay], inc[:, 6]])
+        self.id = np.concatenate([self.id[stay], inc[:, 8].astype(self.id.dtype)])
+        self.type = np.zeros(len(pos), np.int32)
+        self.pos, self.n = pos, len(pos)
+
+    # -- forces --------------------------------------------------------------------------
+    def make_nblist(self):
+        self.ref = self.pos[:self.n, :3].copy()
+
+    def _pairs(self):
+        X = self.pos[:, :3]
+        d = X[None, :, :] - X[:self.n, None, :]
+        r2 = (d * d).sum(-1)
+        np.fill_diagonal(r2[:, :self.n], 1e30)
+        return d, r2
+
+    def forces_phase(self, k):
+        n = self.n
+        if k == 1:
+            self._d, self._r2 = self._pairs()
+            r2 = self._r2
+            pot, grad = tab_eval(self.pair, r2)
+            inp = r2 <= self.pair["end"][0]
+            grad = np.where(inp, grad, 0.0); pot = np.where(inp, pot, 0.0)
+            self.f = (self._d * grad[..., None]).sum(1)
+            self.epot = 0.5 * pot.sum(1)
+            val, _ = tab_eval(self.rho, r2)
+            self.rhoh = np.where(r2 < self.rho["end"][0], val, 0.0).sum(1)
+            self.vir = -0.5 * (r2 * grad).sum()
+        elif k == 2:
+            a = np.minimum(self.rhoh, self.emb["end"][0]) - self.emb["begin"][0]
+            pot, dF = tab_eval(self.emb, self.rhoh)
+            self.epot += pot
+            self.pos[:n, 3] = dF
+        else:
+            r2 = self._r2
+            _, rp = tab_eval(self.rho, r2)
+            w = self.pos[:, 3]
+            grad = np.where(r2 < self.rho["end"][0], 0.5 * (w[:n, None] + w[None, :]) * rp, 0.0)
+            g = self._d * grad[..., None]
+            self.f += g.sum(1)
+            self.vir += -0.5 * (self._d * g).sum()
+            self.sums["tot_pot_energy"], self.sums["virial"] = float(self.epot.sum()), float(self.vir)
+
+    def integrate(self):
+        n = self.n
+        e1 = (self.p ** 2).sum(1)
+        self.p += self.dt * self.f
+        e2 = (self.p ** 2).sum(1)
+        self.sums["tot_kin_energy"] = float(((e1 + e2) / (4 * self.mass)).sum())
+        self.pos[:n, :3] += (self.dt / self.mass)[:, None] * self.p
+        dis = ((self.pos[:n, :3] - self.ref) ** 2).sum(1).max()
+        self.invalid = int(dis > (0.5 * self.margin) ** 2)
+
+    def get_invalid(self):
+        return self.invalid
+
+    def invalidate(self):
+        pass
+
+    def get_sums(self):
+        return dict(self.sums)

@@ -1,0 +1,73 @@
+"""N>1 path on CPUs: the product's host-side decomposition / halo / migration logic
+(imd_amd.parallel) driven over torch.distributed gloo by 2 and 4 processes, each with a numpy
+stand-in device; the distributed trajectory must reproduce the single-domain reference
+trajectory (golden fixture from the real reference binary)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from tests import golden_util as gu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, cpu_dim, nsteps, q):
+    import torch.distributed as dist
+    from imd_amd.parallel import Decomposition, DistributedMD
+    from tests.numpy_ops import NumpyOps
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    G = gu.load("eam_nbl_2048")
+    dec = Decomposition(rank, cpu_dim, G["global_cell_dim"], G["box"], G["pbc_dirs"])
+    pos, mom, mass, ident = G["s0_ort"], G["s0_impuls"], G["s0_masse"], G["s0_nummer"]
+    t = np.linalg.inv(G["box"]).T
+    c = np.clip((np.array(dec.gdim) * (pos @ t.T)).astype(int), 0, np.array(dec.gdim) - 1)
+    mine = np.all(c // (np.array(dec.dim) - 2) == np.array(dec.coord), axis=1)
+    ops = NumpyOps(dec, gu.table(G, "pair_pot"), gu.table(G, "rho_h_tab"), gu.table(G, "embed_pot"), float(G["cellsz"]),
+                   float(G["nbl_margin"]), float(G["timestep"]))
+    ops.upload(pos[mine], mom[mine], mass[mine], ident[mine])
+    md = DistributedMD(dec, ops)
+    for st in range(nsteps):
+        md.md_step(st)
+    md.rebuild() if not md.valid else md.plan.exchange(ops, 0)
+    ops.forces_phase(1); ops.forces_phase(2); md.plan.exchange(ops, 1); ops.forces_phase(3)
+    sums = md.global_sums()
+    q.put((rank, ops.id.copy(), ops.pos[:ops.n, :3].copy(), ops.p.copy(), ops.f.copy(), sums, md.nrebuild))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cpu_dim", [(2, 1, 1), (2, 2, 1)])
+def test_distributed_trajectory_matches_reference(cpu_dim):
+    world = int(np.prod(cpu_dim))
+    nsteps = 20
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, cpu_dim, nsteps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    G = gu.load("eam_nbl_2048")
+    ids = np.concatenate([r[1] for r in res]); pos = np.concatenate([r[2] for r in res])
+    mom = np.concatenate([r[3] for r in res]); frc = np.concatenate([r[4] for r in res])
+    assert len(ids) == len(G["s20_nummer"]) and len(np.unique(ids)) == len(ids)        # no atom lost or duplicated
+    o, go = np.argsort(ids), np.argsort(G["s20_nummer"])
+    box = np.diag(G["box"])
+    dx = pos[o] - G["s20_ort"][go]; dx -= np.round(dx / box) * box
+    assert np.abs(dx).max() < 1e-9
+    assert np.abs(mom[o] - G["s20_impuls"][go]).max() < 1e-9
+    assert np.abs(frc[o] - G["s20_kraft"][go]).max() < 1e-9 * np.abs(G["s20_kraft"]).max() + 1e-10
+    sums = res[0][5]
+    assert abs(sums["tot_pot_energy"] - float(G["s20_tot_pot_energy"])) < 1e-9 * abs(float(G["s20_tot_pot_energy"]))
+    assert sums["natoms"] == len(ids)
+    assert all(r[6] >= 2 for r in res)          # at least one rebuild with migration took place
