@@ -36,31 +36,49 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-box", type=int, default=24, help="unit cells per direction of the CPU sample")
     ap.add_argument("--cpu-steps", type=int, default=40)
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal: host-staged halos)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks on cuda:0")
     return ap.parse_args()
 
 
 def build_system(args, rank, world, device):
+    """One rank's share: its own block of args.box FCC unit cells (weak scaling); the ranks form the most
+    cubic grid (8 -> 2x2x2: six faces on six different xGMI links)."""
     from imd_amd import lattice, potential
     from imd_amd.system import GpuSystem, global_cell_dim
     a = 4.05
-    box = lattice.fcc_box(args.box, a)
     pair, rho, emb, r2cut = potential.synthetic_eam_tables()
     nbl_margin = 0.5
     cellsz = (np.sqrt(r2cut) + nbl_margin) ** 2
     ttm = not args.no_ttm
     fd_ext = (2, 2, 2)
-    gdim = global_cell_dim(box, cellsz, fd_ext if ttm else (1, 1, 1))
-    cell_dim = tuple(g + 2 for g in gdim)
-    sysm = GpuSystem(box, (1, 1, 1), cell_dim, 1, cellsz, nbl_margin, 0.1, device=device,
-                     count_ttm_neighbours=ttm)
+    if world == 1:
+        cpu_dim, coord = (1, 1, 1), (0, 0, 0)
+    else:
+        from imd_amd.parallel import choose_cpu_dim, rank_to_coord
+        cpu_dim = choose_cpu_dim(world)
+        coord = rank_to_coord(rank, cpu_dim)
+    gbox_param = [args.box[d] * cpu_dim[d] for d in range(3)]
+    box = lattice.fcc_box(gbox_param, a)
+    cd = tuple(cpu_dim[d] * (fd_ext[d] if ttm else 1) for d in range(3))
+    gdim = global_cell_dim(box, cellsz, cd)
+    cell_dim = tuple(gdim[d] // cpu_dim[d] + 2 for d in range(3))
+    sysm = GpuSystem(box, (1, 1, 1), cell_dim, 1, cellsz, nbl_margin, 0.1, device=device, global_cell_dim=gdim,
+                     cpu_dim=cpu_dim, my_coord=coord, count_ttm_neighbours=ttm)
     sysm.upload_tables(pair, rho, emb)
-    pos = lattice.fcc_positions(args.box, a)
-    mom = lattice.maxwell_momenta(len(pos), 26.9815, args.temp, seed=12345 + rank)
-    sysm.upload_atoms(pos, mom, 26.9815)
     if ttm:
         from imd_amd import ttm as ttm_mod
         ttm_mod.attach_default(sysm, fd_ext=fd_ext, diff_substeps=100, fd_min_atoms=5)
-    return sysm, len(pos), gdim
+    pos = lattice.fcc_positions(args.box, a) + np.array([coord[d] * args.box[d] * a for d in range(3)])
+    mom = lattice.maxwell_momenta(len(pos), 26.9815, args.temp, seed=12345 + rank)
+    ident = np.arange(len(pos), dtype=np.int64) + rank * len(pos)
+    sysm.upload_atoms(pos, mom, 26.9815, None, (ident % (2 ** 31 - 1)).astype(np.int32))
+    md = None
+    if world > 1:
+        from imd_amd.parallel import Decomposition, DistributedMD, GpuOps
+        dec = Decomposition(rank, cpu_dim, gdim, box, (1, 1, 1))
+        md = DistributedMD(dec, GpuOps(sysm, device), ttm=ttm)
+    return sysm, md, len(pos), gdim, cpu_dim
 
 
 def cpu_baseline(args):
@@ -121,13 +139,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.share_gpu:
+        local = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    sysm, natoms, gdim = build_system(args, rank, world, local)
+    sysm, md, natoms, gdim, cpu_dim = build_system(args, rank, world, local)
+    do_step = md.md_step if md is not None else sysm.md_step
 
     def barrier():
         sysm.synchronize()
@@ -137,21 +161,24 @@ def main():
 
     step = 0
     for _ in range(args.warmup):
-        sysm.md_step(step); step += 1
+        do_step(step); step += 1
     barrier()
     sysm.profile(True); sysm.profile_reset()
     nbl0 = sysm.get_sums()["nbl_count"]
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        sysm.md_step(step); step += 1
+        do_step(step); step += 1
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     sums = sysm.get_sums()
     rebuilds = sums["nbl_count"] - nbl0
+    if md is not None:
+        g = md.global_sums()
+        sums["tot_pot_energy"], sums["tot_kin_energy"] = g["tot_pot_energy"] / world, g["tot_kin_energy"] / world
     entries, maxn = sysm.nblist_stats()
     M = entries / (2.0 * natoms)                       # half-list entries per atom
     prof = {k: sysm.profile_get(k) for k in ("pass1", "pass2", "pass3", "ghosts", "nblist", "fix_cells", "integrate",
@@ -167,7 +194,7 @@ def main():
             "value": args.steps / dt, "unit": "MD-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "atom_steps_per_s": natoms * world * args.steps / dt,
+            "atom_steps_per_s": natoms * world * args.steps / dt, "atoms_total": natoms * world,
             "config": {"workload": "FCC Al %dx%dx%d unit cells per GPU (%d atoms/GPU), synthetic tabulated EAM "
                                    "(r_c 6.5 A), nbl_margin 0.5, dt 0.1, T0 %.4f eV, %s" %
                                    (args.box[0], args.box[1], args.box[2], natoms, args.temp,
@@ -178,7 +205,8 @@ def main():
                        "tile": [sysm.get_info("tile_x"), sysm.get_info("tile_y"), sysm.get_info("tile_z")],
                        "tile_info": {k: sysm.get_info(k) for k in ("ntiles", "tile_cap", "slot_cap", "max_halo",
                                                                    "tile_threads", "lds_pass1", "lds_pass3", "W")},
-                       "parallelism": "1 rank/GPU spatial decomposition" if world > 1 else "single GPU"},
+                       "parallelism": ("%dx%dx%d ranks, 1 rank/GPU, ghost-cell halo over RCCL" % tuple(cpu_dim))
+                       if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "k_pass1 (pair+rho)", "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": bytes_p1, "avg_launch_ms": ms1 / max(n1, 1)},

@@ -1773,6 +1773,19 @@ static size_t tile_lds_bytes(const imdgpu_ctx *ctx, int which /*0 build, 1 pass1
   return align8((tr + 4 * (size_t) ctx->slot_cap + 64) * 8 + ints);
 }
 
+// Multi-rank set-ups call this between the ghost layout and make_nblist: it may re-sort the local atoms
+// (new tile shape), after which the caller has to rebuild its halo index lists.  *changed tells.
+extern "C" int imdgpu_autotile(imdgpu_ctx *ctx, int *changed)
+{
+  HIPCHK(hipSetDevice(ctx->device));
+  if (changed) *changed = 0;
+  if (ctx->mode != 1 || ctx->autotiled || getenv("IMDGPU_TILE")) { ctx->autotiled = 1; return 0; }
+  const int before[3] = {ctx->tile[0], ctx->tile[1], ctx->tile[2]};
+  if (autotile(ctx)) return 1;
+  if (changed) *changed = before[0] != ctx->tile[0] || before[1] != ctx->tile[1] || before[2] != ctx->tile[2];
+  return 0;
+}
+
 extern "C" int imdgpu_make_nblist(imdgpu_ctx *ctx)
 {
   HIPCHK(hipSetDevice(ctx->device));

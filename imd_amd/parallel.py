@@ -103,6 +103,36 @@ class Decomposition:
         return layer(1), layer(D[d] - 2), layer(0), layer(D[d] - 1)
 
 
+def _staged():
+    """gloo moves host memory only: CUDA buffers are staged through the host (used when several ranks
+    share one GPU in tests); with nccl (= RCCL) device buffers travel directly over xGMI."""
+    return dist.is_initialized() and dist.get_backend() == "gloo"
+
+
+def all_gather_flat(t, world):
+    if world == 1:
+        return t
+    if _staged() and t.is_cuda:
+        h = t.cpu()
+        out = [torch.empty_like(h) for _ in range(world)]
+        dist.all_gather(out, h)
+        return torch.cat(out).to(t.device)
+    out = torch.empty(world * t.numel(), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t)
+    return out
+
+
+def all_reduce_(t, op=None):
+    op = op or dist.ReduceOp.SUM
+    if _staged() and t.is_cuda:
+        h = t.cpu()
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op)
+    return t
+
+
 def _exchange(dec, d, buf_lo, buf_hi, like_lo, like_hi, group=None):
     """Send buf_lo to the low neighbour and buf_hi to the high one; returns (from_lo, from_hi) where
     from_lo is the low neighbour's HIGH layer and from_hi the high neighbour's LOW layer.
@@ -112,19 +142,27 @@ def _exchange(dec, d, buf_lo, buf_hi, like_lo, like_hi, group=None):
         return (buf_hi if lo is not None else None), (buf_lo if hi is not None else None)
     ops, from_lo, from_hi = [], None, None
     dev = buf_lo.device if buf_lo is not None else buf_hi.device
+    stage = _staged() and dev.type == "cuda"
+    tdev = torch.device("cpu") if stage else dev
+    if stage:
+        buf_lo = buf_lo.cpu() if buf_lo is not None else None
+        buf_hi = buf_hi.cpu() if buf_hi is not None else None
     if lo is not None:
         ops.append(dist.P2POp(dist.isend, buf_lo, lo, group))
     if hi is not None:
         ops.append(dist.P2POp(dist.isend, buf_hi, hi, group))
     if hi is not None:
-        from_hi = torch.empty(like_hi[0], dtype=like_hi[1], device=dev)
+        from_hi = torch.empty(like_hi[0], dtype=like_hi[1], device=tdev)
         ops.append(dist.P2POp(dist.irecv, from_hi, hi, group))
     if lo is not None:
-        from_lo = torch.empty(like_lo[0], dtype=like_lo[1], device=dev)
+        from_lo = torch.empty(like_lo[0], dtype=like_lo[1], device=tdev)
         ops.append(dist.P2POp(dist.irecv, from_lo, lo, group))
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
+    if stage:
+        from_lo = from_lo.to(dev) if from_lo is not None else None
+        from_hi = from_hi.to(dev) if from_hi is not None else None
     return from_lo, from_hi
 
 
@@ -237,6 +275,8 @@ class DistributedMD:
             self._migrate()
         ops.fix_cells()
         self.plan = HaloPlan(self.dec, ops)
+        if ops.autotile():                               # first rebuild: tile shape chosen from the real occupancies,
+            self.plan = HaloPlan(self.dec, ops)          # local atoms were re-sorted -> new index lists
         self.plan.exchange(ops, 0)
         if ops.ntypes > 1:
             self.plan.exchange(ops, 2)
@@ -254,11 +294,7 @@ class DistributedMD:
         ops.forces_phase(1)
         if self.ttm:
             blk = ops.ttm_local_block(step)
-            if self.world > 1:
-                allb = torch.empty(self.world * blk.numel(), dtype=blk.dtype, device=blk.device)
-                dist.all_gather_into_tensor(allb, blk)
-            else:
-                allb = blk
+            allb = all_gather_flat(blk, self.world)
             ops.ttm_apply_blocks(step, allb, self.world, self._ttm_offs)
             ops.ttm_lattice_step(step)
         ops.forces_phase(2)
@@ -267,7 +303,7 @@ class DistributedMD:
         ops.integrate()
         flag = torch.tensor([ops.get_invalid()], dtype=torch.int32, device=ops.device)
         if self.world > 1:
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)  # MPI_Allreduce MAX of check_nblist
+            all_reduce_(flag, dist.ReduceOp.MAX)         # MPI_Allreduce MAX of check_nblist
         if int(flag.item()):
             self.valid = False
             ops.invalidate()
@@ -277,7 +313,7 @@ class DistributedMD:
         t = torch.tensor([s["tot_pot_energy"], s["virial"], s["tot_kin_energy"], float(self.ops.nlocal())],
                          dtype=torch.float64, device=self.ops.device)
         if self.world > 1:
-            dist.all_reduce(t)
+            all_reduce_(t)
         return dict(tot_pot_energy=float(t[0]), virial=float(t[1]), tot_kin_energy=float(t[2]), natoms=int(t[3]))
 
 
@@ -289,7 +325,11 @@ class GpuOps:
         self.C, self.s, self.L, self.h = C, sysm, sysm.L, sysm.h
         self.device = torch.device("cuda", device)
         self.ntypes = sysm.ntypes
-        sysm.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        # one side stream shared by torch (halo buffers, RCCL ordering) and the library (kernels, hipGraph
+        # capture of the TTM sub-steps is not allowed on the legacy default stream)
+        self.stream = torch.cuda.Stream(self.device)
+        torch.cuda.set_stream(self.stream)
+        sysm.set_stream(self.stream.cuda_stream)
 
     def _ck(self, rc):
         self.s._ck(rc)
@@ -341,6 +381,11 @@ class GpuOps:
                                              C.c_void_p(r_hi.data_ptr() if n_hi else 0), n_hi))
 
     def fix_cells(self): self.s.fix_cells()
+
+    def autotile(self):
+        v = self.C.c_int()
+        self._ck(self.L.imdgpu_autotile(self.h, self.C.byref(v)))
+        return bool(v.value)
     def make_nblist(self): self.s.make_nblist()
     def forces_phase(self, k): self._ck(self.L.imdgpu_forces_phase(self.h, k))
     def integrate(self): self._ck(self.L.imdgpu_integrate(self.h))

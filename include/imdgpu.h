@@ -186,6 +186,9 @@ int imdgpu_move_atoms_ttm(imdgpu_ctx *ctx, double *tot_kin_energy);
  * cpu_dim > 1 in imdgpu_set_geometry every ghost cell is owned by the host layer.
  * All dev_* pointers are device memory of the same GPU. */
 int imdgpu_get_cell_tables(imdgpu_ctx *ctx, int *cell_start /*nallcells*/, int *cell_cnt /*nallcells*/);
+/* pick the LDS tile shape from the current cell occupancies (ghost cells included); *changed != 0 means the
+ * local atoms were re-sorted and the halo index lists must be rebuilt */
+int imdgpu_autotile(imdgpu_ctx *ctx, int *changed);
 int imdgpu_set_ghost_layout(imdgpu_ctx *ctx, const int *cell_start, const int *cell_cnt, int nghost);
 /* what: 0 = (x,y,z,dF) record of 4 doubles, positions shifted by `shift` (periodic image,
  *       imd_comm_force_3d.c:247-266); 1 = dF only (1 double) [copy_dF]; 2 = type (int) */

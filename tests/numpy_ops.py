@@ -62,6 +62,9 @@ class NumpyOps:
         self.cs = np.concatenate([[0], np.cumsum(self.cc)[:-1]]).astype(np.int32)
         self.invalid = 0
 
+    def autotile(self):
+        return False
+
     def cell_tables(self):
         return self.cs.copy(), self.cc.copy()
 

@@ -1,0 +1,117 @@
+"""GPU multi-rank path on ONE GPU (run with -m gpu): two processes, each with its own libimdgpu context on
+cuda:0, exchange halos over gloo (host-staged; on the 8-GPU node the same code runs over nccl = RCCL).
+The distributed trajectory must reproduce the reference's single-domain trajectory."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from tests import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, case, cpu_dim, nsteps, ttm, q):
+    try:
+        _worker_body(rank, world, port, case, cpu_dim, nsteps, ttm, q)
+    except BaseException:
+        import traceback
+        q.put((rank, "ERROR", traceback.format_exc(), 0, None))
+
+
+def _worker_body(rank, world, port, case, cpu_dim, nsteps, ttm, q):
+    import torch
+    import torch.distributed as dist
+    from imd_amd.parallel import Decomposition, DistributedMD, GpuOps
+    from imd_amd.system import GpuSystem
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    G = gu.load(case)
+    dec = Decomposition(rank, cpu_dim, G["global_cell_dim"], G["box"], G["pbc_dirs"])
+    pos, mom, mass, ident = G["s0_ort"], G["s0_impuls"], G["s0_masse"], G["s0_nummer"]
+    t = np.linalg.inv(G["box"]).T
+    c = np.clip((np.array(dec.gdim) * (pos @ t.T)).astype(int), 0, np.array(dec.gdim) - 1)
+    mine = np.all(c // (np.array(dec.dim) - 2) == np.array(dec.coord), axis=1)
+    s = GpuSystem(G["box"], G["pbc_dirs"], dec.dim, 1, float(G["cellsz"]), float(G["nbl_margin"]), float(G["timestep"]),
+                  device=0, global_cell_dim=dec.gdim, cpu_dim=cpu_dim, my_coord=dec.coord)
+    s.upload_tables(gu.table(G, "pair_pot"), gu.table(G, "rho_h_tab"), gu.table(G, "embed_pot"))
+    if ttm:
+        s.init_ttm(G["ttm_fd_ext"], int(G["ttm_fd_min_atoms"]), int(G["ttm_diff_substeps"]), float(G["ttm_atomic_weight"]),
+                   float(G["ttm_atomic_charge"]), dict(x=G["eos_r"], y=G["eos_t"], z=G["eos_cve"]),
+                   dict(x=G["eos_r"], y=G["eos_ts"], z=G["eos_ee"]), float(G["ttm_omega_laser"]))
+    s.upload_atoms(pos[mine], mom[mine], mass[mine], None, ident[mine])
+    ops = GpuOps(s, 0)
+    md = DistributedMD(dec, ops, ttm=ttm)
+    for st in range(nsteps):
+        md.md_step(st)
+    if not md.valid:
+        md.rebuild()
+    else:
+        md.plan.exchange(ops, 0)
+    ops.forces_phase(1); ops.forces_phase(2); md.plan.exchange(ops, 1); ops.forces_phase(3)
+    sums = md.global_sums()
+    d = s.download(fields=("ort", "impuls", "kraft", "nummer", "numneighs"))
+    lat = s.ttm_download(fields=("temp", "xi", "natoms")) if ttm else None
+    q.put((rank, d, sums, md.nrebuild, lat))
+    s.close()
+    dist.destroy_process_group()
+
+
+def _run(case, cpu_dim, nsteps, ttm):
+    world = int(np.prod(cpu_dim))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, cpu_dim, nsteps, ttm, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = []
+    try:
+        for _ in range(world):
+            r = q.get(timeout=150)
+            assert r[1] != "ERROR", "rank %d failed:\n%s" % (r[0], r[2])
+            res.append(r)
+    finally:
+        for p in procs:
+            p.join(timeout=20)
+            if p.is_alive():
+                p.kill()
+    return sorted(res, key=lambda r: r[0])
+
+
+@pytest.mark.parametrize("cpu_dim", [(2, 1, 1), (1, 2, 1)])
+def test_two_ranks_nve(cpu_dim):
+    res = _run("eam_nbl_2048", cpu_dim, 20, False)
+    G = gu.load("eam_nbl_2048")
+    ids = np.concatenate([r[1]["nummer"] for r in res]); pos = np.concatenate([r[1]["ort"] for r in res])
+    frc = np.concatenate([r[1]["kraft"] for r in res])
+    assert len(np.unique(ids)) == len(G["s20_nummer"]) == len(ids)
+    o, go = np.argsort(ids), np.argsort(G["s20_nummer"])
+    box = np.diag(G["box"])
+    dx = pos[o] - G["s20_ort"][go]; dx -= np.round(dx / box) * box
+    assert np.abs(dx).max() < 1e-9
+    assert np.abs(frc[o] - G["s20_kraft"][go]).max() < 1e-9 * np.abs(G["s20_kraft"]).max()
+    assert abs(res[0][2]["tot_pot_energy"] - float(G["s20_tot_pot_energy"])) < 1e-9 * abs(float(G["s20_tot_pot_energy"]))
+    assert all(r[3] >= 2 for r in res)
+
+
+def test_two_ranks_ttm():
+    res = _run("ttm_2048", (2, 1, 1), 3, True)
+    G = gu.load("ttm_2048")
+    ids = np.concatenate([r[1]["nummer"] for r in res]); pos = np.concatenate([r[1]["ort"] for r in res])
+    nn = np.concatenate([r[1]["numneighs"] for r in res])
+    o, go = np.argsort(ids), np.argsort(G["s3_nummer"])
+    assert np.abs(pos[o] - G["s3_ort"][go]).max() < 1e-9
+    assert np.array_equal(nn[o], G["s3_numneighs"][go])
+    # replicated lattice: every rank holds the reference's lattice after the sub-steps of step 2
+    ref = G["t2_substeps_done_temp"][1:-1, 1:-1, 1:-1]
+    for r in res:
+        assert np.abs(r[4]["temp"][1:-1, 1:-1, 1:-1] - ref).max() < 1e-10 * np.abs(ref).max()
