@@ -1180,6 +1180,7 @@ __global__ void k_check_only(int n, int cap, const double4 *pos, const double *r
 static inline int nblk(long long n, int b) { return (int) ((n + b - 1) / b); }
 
 static int setup_tiles(imdgpu_ctx *ctx);
+static int build_ref_perm(imdgpu_ctx *ctx, std::vector<int> *perm, std::vector<int> *refstart);
 
 static void invert_box(const double b[9], double t[9])
 {
@@ -1662,6 +1663,22 @@ extern "C" int imdgpu_upload_cells(imdgpu_ctx *ctx, const int *cell_n, int natom
   HIPCHK(hipMemcpy(ctx->keys, keys.data(), natoms * sizeof(int), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(ctx->perm, perm.data(), natoms * sizeof(int), hipMemcpyHostToDevice));
   return sort_and_build(ctx);
+}
+
+// new positions for the CURRENT arrangement (cell ordered like imdgpu_download_atoms returns them); the
+// neighbour list stays valid -- what a host integrator calls between two list rebuilds
+extern "C" int imdgpu_update_positions(imdgpu_ctx *ctx, int natoms, const double *ort)
+{
+  HIPCHK(hipSetDevice(ctx->device));
+  if (natoms != ctx->nlocal) return imdgpu_fail(ctx, "update_positions: %d atoms given, %d on the device", natoms, ctx->nlocal);
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  std::vector<int> perm;
+  if (build_ref_perm(ctx, &perm, nullptr)) return 1;
+  std::vector<double4> hp(natoms);
+  HIPCHK(hipMemcpy(hp.data(), ctx->pos, natoms * sizeof(double4), hipMemcpyDeviceToHost));
+  for (int r = 0; r < natoms; r++) { double4 &q = hp[perm[r]]; q.x = ort[3 * r]; q.y = ort[3 * r + 1]; q.z = ort[3 * r + 2]; }
+  HIPCHK(hipMemcpy(ctx->pos, hp.data(), natoms * sizeof(double4), hipMemcpyHostToDevice));
+  return 0;
 }
 
 extern "C" int imdgpu_upload_atoms(imdgpu_ctx *ctx, int natoms, const double *ort, const double *impuls,

@@ -1,0 +1,203 @@
+/*
+ * imd_shim.c -- drop-in replacement for imd_forces_nbl.o of IMD/lasMD.
+ *
+ * Compile this file INSIDE the IMD source tree (it includes imd.h, so it sees the
+ * build's own `cell`, `pot_table_t` and globals) with the flags of your target
+ * (e.g. -DNBL -DEAM2 -DNVE) and link it, together with libimdgpu.so, in place of
+ * imd_forces_nbl.o.  It defines the reference's own entry points
+ *
+ *     void calc_forces(int steps);          (prototypes.h:399, imd_forces_nbl.c:295)
+ *     void make_nblist(void);               (prototypes.h:421, imd_forces_nbl.c:136)
+ *     void check_nblist(void);              (prototypes.h:422, imd_forces_nbl.c:1062)
+ *     void deallocate_nblist(void);         (prototypes.h:423)
+ *     int  estimate_nblist_size(void);      (prototypes.h:424)
+ *
+ * with the reference's semantics: calc_forces overwrites kraft, pot_eng, eam_rho,
+ * eam_dF (and numneighs with TTM) of the inner cells and sets tot_pot_energy and
+ * virial; list validity follows have_valid_nbl; errors go through error().
+ * The host keeps integrating (move_atoms) and re-binning (fix_cells) as before;
+ * this is integration level 1 (forces only).  Level 2, the device-resident loop
+ * imdgpu_md_step, needs no IMD code at all.
+ *
+ * Single rank (cpu_dim 1 1 1); an MPI build calls the imdgpu_halo_* operations
+ * from its own send_cells/send_forces replacements.
+ */
+#include "imd.h"
+#include "imdgpu.h"
+
+static imdgpu_ctx *G = NULL;
+static int   g_cap = 0, g_have_cells = 0;
+static double *g_ort, *g_imp, *g_mas, *g_kraft, *g_epot, *g_rho, *g_dF;
+static int    *g_sorte, *g_num, *g_nn, *g_cn;
+
+static void gpu_check(int rc)
+{
+  if (rc) { char msg[1200]; sprintf(msg, "imdgpu: %s", imdgpu_last_error(G)); error(msg); }
+}
+
+static void gpu_init(void)
+{
+  double box[9];
+  int pbc[3], cd[3], gd[3], cpu[3] = {1, 1, 1}, me[3] = {0, 0, 0};
+  if (G) return;
+  if (cpu_dim.x * cpu_dim.y * cpu_dim.z != 1) error("imd_shim: single-rank builds only (see INTEGRATION.md)");
+  gpu_check(imdgpu_create(&G, 0));
+  box[0] = box_x.x; box[1] = box_x.y; box[2] = box_x.z;
+  box[3] = box_y.x; box[4] = box_y.y; box[5] = box_y.z;
+  box[6] = box_z.x; box[7] = box_z.y; box[8] = box_z.z;
+  pbc[0] = pbc_dirs.x; pbc[1] = pbc_dirs.y; pbc[2] = pbc_dirs.z;
+  cd[0] = cell_dim.x; cd[1] = cell_dim.y; cd[2] = cell_dim.z;
+  gd[0] = global_cell_dim.x; gd[1] = global_cell_dim.y; gd[2] = global_cell_dim.z;
+  gpu_check(imdgpu_set_geometry(G, box, pbc, cd, gd, cpu, me));
+#ifdef TTM
+  gpu_check(imdgpu_set_params(G, ntypes, cellsz, nbl_margin, timestep, 1));
+#else
+  gpu_check(imdgpu_set_params(G, ntypes, cellsz, nbl_margin, timestep, 0));
+#endif
+  {
+    /* pot_table_t and imdgpu_pot_table have the same members in the same order (types.h:537-549) */
+    const imdgpu_pot_table *pp = NULL, *pr = NULL, *pe = NULL;
+#ifdef PAIR
+    pp = (const imdgpu_pot_table *) &pair_pot;
+#endif
+#ifdef EAM2
+    pr = (const imdgpu_pot_table *) &rho_h_tab;
+    pe = (const imdgpu_pot_table *) &embed_pot;
+#endif
+    gpu_check(imdgpu_upload_tables(G, pp, pr, pe));
+  }
+}
+
+static int count_atoms(void)
+{
+  int k, n = 0;
+  for (k = 0; k < NCELLS; k++) n += CELLPTR(k)->n;
+  return n;
+}
+
+static void ensure_host(int n)
+{
+  if (n <= g_cap) return;
+  g_cap = n + n / 8 + 1024;
+  g_ort = (double *) realloc(g_ort, 3 * g_cap * sizeof(double)); g_imp = (double *) realloc(g_imp, 3 * g_cap * sizeof(double));
+  g_kraft = (double *) realloc(g_kraft, 3 * g_cap * sizeof(double));
+  g_mas = (double *) realloc(g_mas, g_cap * sizeof(double)); g_epot = (double *) realloc(g_epot, g_cap * sizeof(double));
+  g_rho = (double *) realloc(g_rho, g_cap * sizeof(double)); g_dF = (double *) realloc(g_dF, g_cap * sizeof(double));
+  g_sorte = (int *) realloc(g_sorte, g_cap * sizeof(int)); g_num = (int *) realloc(g_num, g_cap * sizeof(int));
+  g_nn = (int *) realloc(g_nn, g_cap * sizeof(int));
+  g_cn = (int *) realloc(g_cn, nallcells * sizeof(int));
+  if (!g_ort || !g_imp || !g_kraft || !g_mas || !g_epot || !g_rho || !g_dF || !g_sorte || !g_num || !g_nn || !g_cn)
+    error("imd_shim: cannot allocate staging arrays");
+}
+
+/* walk the inner cells in the order of the `cells` list: that IS the ABI's cell order */
+static int gather_cells(int with_all)
+{
+  int k, i, n = 0;
+  for (k = 0; k < nallcells; k++) g_cn[k] = 0;
+  for (k = 0; k < NCELLS; k++) {
+    cell *p = CELLPTR(k);
+    g_cn[p - cell_array] = p->n;
+    for (i = 0; i < p->n; i++, n++) {
+      g_ort[3 * n] = ORT(p, i, X); g_ort[3 * n + 1] = ORT(p, i, Y); g_ort[3 * n + 2] = ORT(p, i, Z);
+      if (with_all) {
+        g_imp[3 * n] = IMPULS(p, i, X); g_imp[3 * n + 1] = IMPULS(p, i, Y); g_imp[3 * n + 2] = IMPULS(p, i, Z);
+        g_mas[n] = MASSE(p, i); g_sorte[n] = SORTE(p, i); g_num[n] = NUMMER(p, i);
+      }
+    }
+  }
+  return n;
+}
+
+void make_nblist(void)
+{
+  int n = count_atoms(), k, i;
+  gpu_init();
+  ensure_host(n);
+  gather_cells(1);
+  gpu_check(imdgpu_upload_cells(G, g_cn, n, g_ort, g_imp, g_mas, g_sorte, g_num));
+  gpu_check(imdgpu_make_nblist(G));
+  g_have_cells = 1;
+  /* this fork keeps tl/tb/cl_off in globals.h:184-188 for other modules (imd_nrb.c): publish the list in the
+   * reference's own half-list format unless IMD_SHIM_NO_NBL_EXPORT is set */
+  if (getenv("IMD_SHIM_NO_NBL_EXPORT") == NULL) {
+    int ntb = 0;
+    gpu_check(imdgpu_export_nblist(G, NULL, NULL, NULL, &ntb));
+    tl = (int *) realloc(tl, (n + 1) * sizeof(int));
+    tb = (int *) realloc(tb, (ntb + 1) * sizeof(int));
+    cl_off = (int *) realloc(cl_off, nallcells * sizeof(int));
+    if (!tl || !tb || !cl_off) error("imd_shim: cannot allocate neighbor table");
+    gpu_check(imdgpu_export_nblist(G, tl, tb, cl_off, &ntb));
+    nb_max = ntb;
+  }
+  for (k = 0; k < ncells; k++) {                 /* reference positions, imd_forces_nbl.c:143-155 */
+    cell *p = cell_array + cnbrs[k].np;
+    for (i = 0; i < p->n; i++) {
+      NBL_POS(p, i, X) = ORT(p, i, X); NBL_POS(p, i, Y) = ORT(p, i, Y); NBL_POS(p, i, Z) = ORT(p, i, Z);
+    }
+  }
+  have_valid_nbl = 1;
+  nbl_count++;
+}
+
+void deallocate_nblist(void) { have_valid_nbl = 0; }
+
+int estimate_nblist_size(void)
+{
+  long long e = 0; int m = 0;
+  if (!G || !g_have_cells) return 100000;
+  gpu_check(imdgpu_nblist_stats(G, &e, &m));
+  return (int) (e / 2) + 1;
+}
+
+void check_nblist(void)
+{
+  /* same rule on the host copies the integrator just advanced (imd_forces_nbl.c:1062-1092) */
+  real max1 = 0.0;
+  int k, i;
+  for (k = 0; k < NCELLS; k++) {
+    cell *p = CELLPTR(k);
+    for (i = 0; i < p->n; i++) {
+      real dx = ORT(p, i, X) - NBL_POS(p, i, X), dy = ORT(p, i, Y) - NBL_POS(p, i, Y), dz = ORT(p, i, Z) - NBL_POS(p, i, Z);
+      real r2 = dx * dx + dy * dy + dz * dz;
+      if (r2 > max1) max1 = r2;
+    }
+  }
+  if (max1 > SQR(0.5 * nbl_margin)) have_valid_nbl = 0;
+}
+
+void calc_forces(int steps)
+{
+  double sums[8];
+  int n, k, i, m = 0, is_short = 0;
+  gpu_init();
+  if (0 == have_valid_nbl) {
+    fix_cells();                                  /* the host's own re-binning, imd_forces_nbl.c:300-308 */
+    make_nblist();
+  } else {
+    n = count_atoms();
+    ensure_host(n);
+    gather_cells(0);
+    gpu_check(imdgpu_update_positions(G, n, g_ort));
+  }
+  n = count_atoms();
+  gpu_check(imdgpu_calc_forces(G, steps, sums, &is_short));
+  gpu_check(imdgpu_download_atoms(G, NULL, NULL, NULL, g_kraft, g_epot, g_rho, g_dF, g_nn, NULL, NULL, NULL));
+  for (k = 0; k < NCELLS; k++) {
+    cell *p = CELLPTR(k);
+    for (i = 0; i < p->n; i++, m++) {
+      KRAFT(p, i, X) = g_kraft[3 * m]; KRAFT(p, i, Y) = g_kraft[3 * m + 1]; KRAFT(p, i, Z) = g_kraft[3 * m + 2];
+      POTENG(p, i) = g_epot[m];
+#ifdef EAM2
+      EAM_RHO(p, i) = g_rho[m]; EAM_DF(p, i) = g_dF[m];
+#endif
+#ifdef TTM
+      NUMNEIGHS(p, i) = g_nn[m];
+#endif
+    }
+  }
+  tot_pot_energy = sums[0]; virial = sums[1];
+  vir_xx = vir_yy = vir_zz = vir_xy = vir_yz = vir_zx = 0.0;
+  nfc++;
+  if (is_short) fprintf(stderr, "Short distance, step %d!\n", steps);
+}

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_CSRC, "libimdgpu.so")
 SYMBOLS = [
     "imdgpu_create", "imdgpu_destroy", "imdgpu_last_error", "imdgpu_set_stream", "imdgpu_synchronize", "imdgpu_set_option", "imdgpu_get_info",
     "imdgpu_set_geometry", "imdgpu_set_params", "imdgpu_upload_tables", "imdgpu_set_restrictions",
-    "imdgpu_upload_cells", "imdgpu_upload_atoms", "imdgpu_num_atoms", "imdgpu_download_atoms",
+    "imdgpu_upload_cells", "imdgpu_upload_atoms", "imdgpu_update_positions", "imdgpu_num_atoms", "imdgpu_download_atoms",
     "imdgpu_fix_cells", "imdgpu_fill_ghosts", "imdgpu_make_nblist", "imdgpu_check_nblist",
     "imdgpu_calc_forces", "imdgpu_move_atoms_nve", "imdgpu_md_step", "imdgpu_get_sums",
     "imdgpu_export_nblist", "imdgpu_nblist_stats",
@@ -96,6 +96,7 @@ def load():
     L.imdgpu_upload_cells.argtypes = [vp, ip, C.c_int, dp, dp, dp, ip, ip]
     L.imdgpu_upload_atoms.argtypes = [vp, C.c_int, dp, dp, dp, ip, ip]
     L.imdgpu_num_atoms.argtypes = [vp, ip, ip]
+    L.imdgpu_update_positions.argtypes = [vp, C.c_int, dp]
     L.imdgpu_download_atoms.argtypes = [vp, ip, dp, dp, dp, dp, dp, dp, ip, ip, ip, dp]
     for f in ("imdgpu_fix_cells", "imdgpu_fill_ghosts", "imdgpu_make_nblist"):
         getattr(L, f).argtypes = [vp]

@@ -84,6 +84,8 @@ int imdgpu_upload_cells(imdgpu_ctx *ctx, const int *cell_n, int natoms,
 int imdgpu_upload_atoms(imdgpu_ctx *ctx, int natoms, const double *ort,
                         const double *impuls, const double *masse,
                         const int *sorte, const int *nummer);
+/* new positions in the current arrangement (cell ordered), list stays valid: a host integrator between rebuilds */
+int imdgpu_update_positions(imdgpu_ctx *ctx, int natoms, const double *ort);
 int imdgpu_num_atoms(imdgpu_ctx *ctx, int *nlocal, int *nghost);
 /* Any output pointer may be NULL.  cell_n: nallcells ints (inner cells only
  * are non-zero).  Arrays are cell ordered in the CURRENT device arrangement. */

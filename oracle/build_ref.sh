@@ -55,7 +55,7 @@ build() {
   echo "built $OUT/imd_$name"
 }
 
-TARGETS="${*:-eam_nve_nbl nve_nbl eam_nve}"
+TARGETS="${*:-eam_nve_nbl nve_nbl eam_nve mpi_eam_ttm3d_nbl dropin}"
 for t in $TARGETS; do
   case "$t" in
     eam_nve_nbl) build "$t" "-DNBL -DEAM2 -DNVE" "$COMMON $NBLSRC" "$CC" "" ;;
@@ -75,6 +75,34 @@ for t in $TARGETS; do
       build "$t" "-DMPI -DNBL -DEAM2 -DTTM -DTMM -DEOSMODE=1" \
             "$COMMON $NBLSRC imd_mpi_util.c imd_ttm_3D.c imd_interpol.c fminbnd3.c" \
             "$CC -I$MPIINC/include" "-L$MPIINC/lib -Wl,-rpath,$MPIINC/lib -lmpi" ;;
+    dropin) ;;    # built below
     *) echo "unknown target $t" >&2; exit 1 ;;
   esac
 done
+
+# ---------------------------------------------------------------------------------------------
+# Drop-in integration build (TEST INFRASTRUCTURE): the real reference program with its
+# imd_forces_nbl.o REPLACED by imd_amd/host/imd_shim.c + libimdgpu.so.  Proves that the library
+# links in place of the reference's force object and that the unmodified IMD main loop
+# (integrator, fix_cells, I/O) runs on top of the GPU forces.  Output: oracle/_ref/imd_eam_nve_nbl_gpu
+# (needs the GPU box to run; tests/test_gpu_dropin.py compares it with oracle/_ref/imd_eam_nve_nbl).
+# ---------------------------------------------------------------------------------------------
+build_dropin() {
+  local name="eam_nve_nbl_gpu" defs="-DNBL -DEAM2 -DNVE"
+  local obj="$OUT/obj_$name" repo="$(cd "$HERE/.." && pwd)"
+  [ -f "$repo/imd_amd/csrc/libimdgpu.so" ] || { echo "libimdgpu.so not built, skipping drop-in" >&2; return 0; }
+  mkdir -p "$obj"
+  local objs=""
+  for s in $COMMON imd_geom_mpi_3d.c imd_comm_force_3d.c imd_fix_cells_3d.c imd_mpiio.c; do
+    local o="$obj/${s%.c}.o"
+    if [ ! -f "$o" ] || [ "$REF/$s" -nt "$o" ]; then $CC $BASEFLAGS $defs -c "$REF/$s" -o "$o" & fi
+    objs="$objs $o"
+  done
+  wait
+  $CC $BASEFLAGS $defs -I"$repo/include" -c "$repo/imd_amd/host/imd_shim.c" -o "$obj/imd_shim.o"
+  $CC $BASEFLAGS $defs -c "$HERE/ref_probe.c" -o "$obj/ref_probe.o"
+  $CC -o "$OUT/imd_$name" $objs "$obj/imd_shim.o" "$obj/ref_probe.o" -Wl,--wrap=calc_forces \
+      "$REF/nn_interpol/libnn.a" -L"$repo/imd_amd/csrc" -limdgpu -Wl,-rpath,/root/repo/imd_amd/csrc -lm
+  echo "built $OUT/imd_$name"
+}
+case " $TARGETS " in *" dropin "*) build_dropin ;; esac
