@@ -9,6 +9,7 @@ Appendix B, state resident in HBM.  N>1: one rank per GPU, each rank owns an
 equal block of atoms (weak scaling), launched by torch.distributed.run.
 """
 import argparse
+import glob
 import json
 import os
 import subprocess
@@ -34,8 +35,8 @@ def parse():
     ap.add_argument("--temp", type=float, default=0.0258)
     ap.add_argument("--no-ttm", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-box", type=int, default=24, help="unit cells per direction of the CPU sample")
-    ap.add_argument("--cpu-steps", type=int, default=40)
+    ap.add_argument("--cpu-box", type=int, default=48, help="unit cells per direction of the CPU sample")
+    ap.add_argument("--cpu-steps", type=int, default=30)
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal: host-staged halos)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks on cuda:0")
     return ap.parse_args()
@@ -132,6 +133,23 @@ def cpu_baseline(args):
             "sample": "oracle C restatement, %d atoms x %d steps, EAM NVE" % (natoms, steps)}
 
 
+def measured_traffic(kernel, natoms):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/profile_bench.sh:
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same workload).  Counters cannot be read
+    from inside the process, so the figure is looked up by (kernel, workload size); null when not measured."""
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic*.json")), reverse=True):
+        try:
+            t = json.load(open(f))
+        except Exception:
+            continue
+        if t.get("_atoms_per_gpu") != natoms:
+            continue
+        for k, v in t.items():
+            if isinstance(v, dict) and kernel in k and v.get("hbm_bytes"):
+                return v["hbm_bytes"], os.path.relpath(f, ROOT)
+    return None, None
+
+
 def main():
     args = parse()
     import torch
@@ -189,6 +207,8 @@ def main():
         n1, ms1 = prof["pass1"]
         bytes_p1 = natoms * (72.0 + 4.0 * M)
         ach = bytes_p1 / (ms1 / max(n1, 1) * 1e-3) / 1e9 if n1 else 0.0
+        kname = "k_pass1_tile_merged" if sysm.get_info("list_mode") == 1 else "k_pass1"
+        traffic, traffic_src = measured_traffic(kname, natoms)
         out = {
             "metric": "MD-steps/sec (and atom-steps/sec) for 10M-atom EAM-Al+TTM at 1/2/4/8 GPU",
             "value": args.steps / dt, "unit": "MD-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -207,8 +227,8 @@ def main():
                                                                    "tile_threads", "lds_pass1", "lds_pass3", "W")},
                        "parallelism": ("%dx%dx%d ranks, 1 rank/GPU, ghost-cell halo over RCCL" % tuple(cpu_dim))
                        if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": "k_pass1 (pair+rho)", "achieved": ach, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": kname + " (pass 1: pair + rho)", "achieved": ach, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": bytes_p1, "avg_launch_ms": ms1 / max(n1, 1)},
             "kernel_ms_per_step": {k: v[1] / args.steps for k, v in prof.items() if v[0]},
             "energy": {"epot_per_atom": sums["tot_pot_energy"] / natoms, "ekin_per_atom": sums["tot_kin_energy"] / natoms},
