@@ -61,6 +61,29 @@ void imdgpu_prof_resolve(imdgpu_ctx *c)
   c->ev_pending.clear();
 }
 
+void imdgpu_tl_mark(imdgpu_ctx *c, const char *name)
+{
+  if (!c->tl_on) return;
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return;
+  (void) hipEventRecord(e, c->stream);
+  c->tl.push_back({name, e});
+}
+static void tl_flush(imdgpu_ctx *c, int steps)
+{
+  if (!c->tl_on || c->tl.empty()) return;
+  (void) hipDeviceSynchronize();
+  fprintf(stderr, "[imdgpu timeline] step %d:", steps);
+  for (auto &m : c->tl) {
+    float ms = 0.f;
+    (void) hipEventElapsedTime(&ms, c->tl[0].second, m.second);
+    fprintf(stderr, " %s=%.3f", m.first, ms);
+  }
+  fprintf(stderr, "\n");
+  for (auto &m : c->tl) (void) hipEventDestroy(m.second);
+  c->tl.clear();
+}
+
 static const char *prof_names[PROF_COUNT] = {
   "pass1", "pass2", "pass3", "ghosts", "nblist", "fix_cells", "integrate", "check", "reduce",
   "ttm_update_fd", "ttm_diff", "ttm_fillmesh"};
@@ -1199,7 +1222,13 @@ extern "C" int imdgpu_create(imdgpu_ctx **out, int device)
   HIPCHK(hipSetDevice(device));
   HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess) ctx->num_cus = pr.multiProcessorCount; }
-  HIPCHK(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+  ctx->tl_on = getenv("IMDGPU_TIMELINE") != nullptr;
+  {
+    // the TTM lattice chain (100 tiny dependent launches) runs beside the force passes: give it the queue priority
+    int least = 0, greatest = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIPCHK(hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, greatest));
+  }
   HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
   ctx->own_stream = true;
@@ -1755,7 +1784,12 @@ extern "C" int imdgpu_fill_ghosts(imdgpu_ctx *ctx)
 
 static size_t align8(size_t b) { return (b + 7) & ~(size_t) 7; }
 // persistent tile kernels: one workgroup per CU (their ~140 KB of LDS admit no second one)
-static int tile_grid(const imdgpu_ctx *ctx) { return std::min(ctx->ntiles, ctx->num_cus > 0 ? ctx->num_cus : 256); }
+static int tile_grid(const imdgpu_ctx *ctx)
+{
+  static const int forced = getenv("IMDGPU_TILE_GRID") ? atoi(getenv("IMDGPU_TILE_GRID")) : 0;   // experiments only
+  if (forced > 0) return std::min(ctx->ntiles, forced);
+  return std::min(ctx->ntiles, ctx->num_cus > 0 ? ctx->num_cus : 256);
+}
 
 static TileArgs make_tile_args(imdgpu_ctx *ctx)
 {
@@ -1958,6 +1992,7 @@ static int launch_forces(imdgpu_ctx *ctx, int phase = 0)
 #undef L1T
 #undef L1
   }
+  imdgpu_tl_mark(ctx, "pass1");
   if ((phase == 0 || phase == 1) && ctx->after_pass1) { if (ctx->after_pass1(ctx, ctx->after_pass1_arg)) return 1; }
   const int nb2 = EAM ? nblk(n, 256) : 0;
   if (EAM && (phase == 0 || phase == 2)) {
@@ -1967,6 +2002,7 @@ static int launch_forces(imdgpu_ctx *ctx, int phase = 0)
                          ctx->epot, ctx->emb.par, ctx->partials);
     }
     if (imdgpu_fill_ghosts(ctx)) return 1;            // dF of the images  [send_cells(copy_dF), :786]
+    imdgpu_tl_mark(ctx, "pass2");
   }
   if (EAM && (phase == 0 || phase == 3)) {
     size_t lds3 = ((size_t) a.rho.nrows * a.rho.ncols + 64) * sizeof(double);
@@ -1987,6 +2023,7 @@ static int launch_forces(imdgpu_ctx *ctx, int phase = 0)
     ProfScope ps(ctx, PROF_REDUCE);
     hipLaunchKernelGGL(k_reduce_force_sums, dim3(1), dim3(1024), 0, ctx->stream, nb, EAM ? nb2 : 0, ctx->partials, ctx->d_sums);
   }
+  imdgpu_tl_mark(ctx, "pass3");
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -2070,10 +2107,12 @@ int imdgpu_launch_integrate(imdgpu_ctx *ctx)
 extern "C" int imdgpu_md_step(imdgpu_ctx *ctx, int steps)
 {
   HIPCHK(hipSetDevice(ctx->device));
+  imdgpu_tl_mark(ctx, "begin");
   if (!ctx->have_valid_nbl) {
     if (ctx->need_fix_cells && imdgpu_fix_cells(ctx)) return 1;
     if (imdgpu_make_nblist(ctx)) return 1;
   } else if (imdgpu_fill_ghosts(ctx)) return 1;
+  imdgpu_tl_mark(ctx, "list");
   if (!ctx->rho.present && zero_eam_partials(ctx)) return 1;
   if (ctx->ttm) {
     // calc_ttm needs only pass 1's neighbour counts and the momenta: it runs on the second stream,
@@ -2097,7 +2136,9 @@ extern "C" int imdgpu_md_step(imdgpu_ctx *ctx, int steps)
   }
   // the only per-step host round trip: one int that says whether the list survived
   HIPCHK(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, CNT_N * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  imdgpu_tl_mark(ctx, "move");
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  tl_flush(ctx, steps);
   if (ctx->h_counters[CNT_INVALID]) { ctx->have_valid_nbl = 0; ctx->need_fix_cells = 1; }
   return 0;
 }

@@ -108,6 +108,9 @@ struct imdgpu_ctx {
   long long prof_n[PROF_COUNT]{};
   double prof_ms[PROF_COUNT]{};
 
+  // debugging aid: IMDGPU_TIMELINE=1 prints where each stage of a step ended on the device clock
+  bool tl_on = false; std::vector<std::pair<const char *, hipEvent_t>> tl;
+
   // TTM state lives in imdgpu_ttm.hip
   struct TtmState *ttm = nullptr;
 };
@@ -127,6 +130,7 @@ struct ProfScope {
   ~ProfScope();
 };
 void imdgpu_prof_resolve(imdgpu_ctx *c);
+void imdgpu_tl_mark(imdgpu_ctx *c, const char *name);     // no-op unless IMDGPU_TIMELINE is set
 
 template <typename T>
 static inline int dev_alloc(imdgpu_ctx *ctx, T **p, size_t n)

@@ -47,6 +47,12 @@ struct Lat {                      // lattice geometry + parameters by value
   int dim[3], ext[3], md_dim[3], pbc[3], off[3], ldim[3];
   int fd_min_atoms;
   double h[3], vol, neighvol, atomic_weight, atomic_charge, omega_laser, Temin;
+  // uniform reciprocals, evaluated once on the host (an fp64 division is ~20 VALU instructions on the device)
+  double inv_z0_43;               // 1e-3 / atomic_charge^(4/3)        (MeanCharge t0)
+  double inv_z0am;                // 1e-3 / (atomic_charge*atomic_weight) (MeanCharge r0)
+  double inv_awamu;               // 1 / (atomic_weight * AMU)          (ne)
+  double invhsq[3];               // 1 / fd_h^2
+  double xi_fac;                  // 26.9815*AMU/3*1e30 / diff_substeps  (do_DIFF :1614)
 };
 
 __device__ __forceinline__ int fidx(const Lat &L, int i, int j, int k) { return (i * L.dim[1] + j) * L.dim[2] + k; }
@@ -174,81 +180,69 @@ __device__ double eos_lookup(const EosDev &e, double x, double y)
   double z10 = e.z[(size_t) (ix + 1) * e.ny + iy], z11 = e.z[(size_t) (ix + 1) * e.ny + iy + 1];
   return (1 - tx) * ((1 - ty) * z00 + ty * z01) + tx * ((1 - ty) * z10 + ty * z11);
 }
-__device__ double eos_cve(const EosDev &e, double r, double tK)
-{
-  double z = eos_lookup(e, r, tK);
-  z *= r; z *= 11604.5; z *= 1e-30; z *= C_J2EV;
-  return z;
-}
 __device__ double eos_ee(const EosDev &e, double r, double tK) { return eos_lookup(e, r, sqrt(tK)); }
 
-__device__ double d_fermi_E(double ne) { return C_HBAR * C_HBAR * pow(3.0 * C_PI * C_PI * ne, 2.0 / 3.0) / 2.0 / C_EMASS; }
-__device__ double d_fermi_T(double ne) { return 2.0 * d_fermi_E(ne) / (3.0 * C_BOLTZMAN); }
-__device__ double d_omega_pl(double ne) { return sqrt(ne * C_ECHARGE * C_ECHARGE / C_EMASS / C_ECONST); }
-__device__ double d_r0(double ni) { return pow(3.0 / (4 * C_PI * ni), 1.0 / 3.0); }
-__device__ double d_coulomb_log(double omega_las, double Z, double ni, double Te)
-{
-  double bmin = fmax(Z * C_ECHARGE * C_ECHARGE / (C_BOLTZMAN * Te), C_HBAR / sqrt(2 * C_EMASS * C_BOLTZMAN * Te));
-  double ft = d_fermi_T(ni * Z);
-  double teff = sqrt(Te * Te + ft * ft);
-  double bmax = fmax(d_r0(ni), sqrt(C_BOLTZMAN * teff / (C_EMASS)) / fmax(omega_las, d_omega_pl(ni * Z)));
-  return fmax(2.0, log(bmax / bmin));
-}
-__device__ double d_numet(double A1, double A2, double Te, double Ti, double TF) { return 1.309202957843054e+11 * (A1 * Ti + A2 * Te * Te / TF); }
-__device__ double d_numax(double A3, double vf, double Te, double ni) { return A3 / d_r0(ni) * sqrt(vf * vf + C_BOLTZMAN * Te / C_EMASS); }
-
-__device__ double d_mean_charge(double temp, double rho, double z0, double am)
-{
-  const double YA1 = 0.003323, YA2 = 0.971832, YA3 = 0.926148e-5, YA4 = 3.10165, YB0 = -1.7630, YB1 = 1.43175,
-               YB2 = 0.315463, YC1 = 0.036666667, YC2 = 0.983333333, YAL = 0.143139e2, YBE = 0.6624e0;
-  temp *= 1e-3; rho *= 1e-3;
-  double t0 = temp / pow(z0, 4. / 3.);
-  double r0 = rho / (z0 * am);
-  double ytf = t0 / (1.0 + t0);
-  double ya = YA1 * pow(t0, YA2) + YA3 * pow(t0, YA4);
-  double yb = -exp(YB0 + YB1 * ytf + YB2 * ytf * ytf);
-  double yc = YC1 * ytf + YC2;
-  double yq1 = ya * pow(r0, yb);
-  double yq = pow(pow(r0, yc) + pow(yq1, yc), 1.0 / yc);
-  double yx = YAL * pow(yq, YBE);
-  return z0 * yx / (1.0 + yx + sqrt(1.0 + 2.0 * yx));
-}
-__device__ double d_get_gamma(double Te, double Ti, double Ne, double Z, double omega_laser)
-{
-  const double A1g = 50, A2g = 20, A3g = 0.25, m_atom = 26.9815;
-  Te *= 11604.5; Ti *= 11604.5;
-  double Ni = Ne / Z, EF = d_fermi_E(Ne);
-  double TF = 4.828648689433765e+22 * EF, VF = 1.481734876966785e+15 * sqrt(EF);
-  double coulomb = d_coulomb_log(omega_laser, Z, Ni, Te);
-  const double kT = C_BOLTZMAN * Te;
-  double nupl = 1.863839656495274e-40 * Z * Ne * coulomb / (kT * sqrt(kT));          // pow(kT, 1.5)
-  double nu_eff = fmin(d_numet(A1g, A2g, Te, Ti, TF), fmin(d_numax(A3g, VF, Te, Ni), nupl));
-  return 2.783313120645740e-74 / (m_atom * C_AMU) * Ne * nu_eff;
-}
-__device__ double d_get_kappa(double Te, double Ti, double Ne, double Z, double omega_laser)
-{
-  const double A1t = 2.95, A2t = 0.5, A3t = 0.16, A4t = 1.2;
-  Te *= 11604.5; Ti *= 11604.5;
-  double Ni = Ne / Z, EF = d_fermi_E(Ne);
-  double TF = 4.828648689433765e+22 * EF, VF = 1.481734876966785e+15 * sqrt(EF);
-  double nu_eff = fmin(d_numet(A1t, A2t, Te, Ti, TF), d_numax(A3t, VF, Te, Ni));
-  double coulomb = d_coulomb_log(omega_laser, Z, Ni, Te);
-  double kappa_met = 6.884236239621913e-16 * Ne * Te / nu_eff;
-  const double kT = C_BOLTZMAN * Te;
-  double kappa_pl = 4.428788911416808e+43 * (kT * kT * sqrt(kT)) / Z / coulomb;      // pow(kT, 2.5)
-  double kappa_wr = kappa_pl + (kappa_met - kappa_pl) * exp(-A4t * Te / TF);
-  return kappa_wr * 0.073768115942029;
-}
-
+// do_FILLMESH per cell: MeanCharge (More's Thomas-Fermi fit, imd_ttm_3D.c:2399-2473), getKappa (:2549-2592),
+// getGamma (:2503-2528) and their helpers fermi_E, fermi_T, omega_pl, r0, coulomb_log, numet, numax, nupl
+// (:2352-2498), written as ONE function so that everything the reference recomputes per helper call is shared:
+// the Fermi energy, the Wigner-Seitz radius, the Coulomb logarithm and the thermal speed are evaluated once
+// for kappa and gamma; pow(a,b) with run-time exponents is exp(b*log(a)) with the logarithms shared (7 pow ->
+// 4 log + 6 exp), x^(2/3) and x^(1/3) use cbrt.  Differences to the reference are rounding-level (<=1e-13).
 struct MeshOut { double Z, ne, Ce, k, g; };
 __device__ __forceinline__ MeshOut mesh_props(const Lat &L, const EosDev &cve, double Te, double Tl, double dens)
 {
   MeshOut o;
-  o.Z = d_mean_charge(Te * 11604.5, dens, L.atomic_charge, L.atomic_weight);
-  o.ne = o.Z * dens / (L.atomic_weight * C_AMU);
-  o.Ce = eos_cve(cve, dens, Te * 11604.5);
-  o.k = d_get_kappa(Te, Tl, o.ne, o.Z, L.omega_laser);
-  o.g = d_get_gamma(Te, Tl, o.ne, o.Z, L.omega_laser);
+  const double TeK = Te * 11604.5, TiK = Tl * 11604.5;
+  {
+    const double YA1 = 0.003323, YA2 = 0.971832, YA3 = 0.926148e-5, YA4 = 3.10165, YB0 = -1.7630, YB1 = 1.43175,
+                 YB2 = 0.315463, YC1 = 0.036666667, YC2 = 0.983333333, YAL = 0.143139e2, YBE = 0.6624e0;
+    const double t0 = TeK * L.inv_z0_43;
+    const double r0 = dens * L.inv_z0am;
+    const double lt = log(t0), lr = log(r0);
+    const double ytf = t0 / (1.0 + t0);
+    const double ya = YA1 * exp(YA2 * lt) + YA3 * exp(YA4 * lt);
+    const double yb = -exp(YB0 + YB1 * ytf + YB2 * ytf * ytf);
+    const double yc = YC1 * ytf + YC2;
+    const double lq1 = log(ya) + yb * lr;                      // log(ya * r0^yb)
+    const double sum = exp(yc * lr) + exp(yc * lq1);           // r0^yc + yq1^yc
+    const double yx = YAL * exp(YBE / yc * log(sum));          // YAL * (sum^(1/yc))^YBE
+    o.Z = L.atomic_charge * yx / (1.0 + yx + sqrt(1.0 + 2.0 * yx));
+  }
+  o.ne = o.Z * dens * L.inv_awamu;
+  {
+    double z = eos_lookup(cve, dens, TeK);                     // EOS_cve_from_r_te (:2736-2783)
+    z *= dens; z *= 11604.5; z *= 1e-30; z *= C_J2EV;
+    o.Ce = z;
+  }
+  constexpr double INV_EMASS = 1.0 / C_EMASS;
+  const double Ne = o.ne, Z = o.Z;
+  const double cb = cbrt(3.0 * C_PI * C_PI * Ne);
+  const double EF = (C_HBAR * C_HBAR * 0.5 * INV_EMASS) * (cb * cb);            // fermi_E
+  const double TF = 4.828648689433765e+22 * EF, VF = 1.481734876966785e+15 * sqrt(EF);
+  const double inv_TF = 1.0 / TF;
+  const double rws = cbrt((3.0 / (4 * C_PI)) * Z / Ne);                         // r0(ni), ni = Ne/Z
+  const double kT = C_BOLTZMAN * TeK, sqkT = sqrt(kT), inv_kT = 1.0 / kT;
+  const double bmin = fmax(Z * (C_ECHARGE * C_ECHARGE) * inv_kT, (C_HBAR / __builtin_sqrt(2 * C_EMASS)) * sqkT * inv_kT);
+  const double ft = (2.0 / (3.0 * C_BOLTZMAN)) * EF;                            // fermi_T
+  const double teff = sqrt(TeK * TeK + ft * ft);
+  const double wpl = sqrt(Ne * (C_ECHARGE * C_ECHARGE * INV_EMASS / C_ECONST)); // omega_pl
+  const double bmax = fmax(rws, sqrt((C_BOLTZMAN * INV_EMASS) * teff) / fmax(L.omega_laser, wpl));
+  const double coulomb = fmax(2.0, log(bmax / bmin));
+  const double vth_over_r = sqrt(VF * VF + kT * INV_EMASS) / rws;               // numax / A3
+  const double te2_tf = TeK * TeK * inv_TF;
+  {
+    const double A1t = 2.95, A2t = 0.5, A3t = 0.16, A4t = 1.2;
+    const double nu_eff = fmin(1.309202957843054e+11 * (A1t * TiK + A2t * te2_tf), A3t * vth_over_r);
+    const double kappa_met = 6.884236239621913e-16 * Ne * TeK / nu_eff;
+    const double kappa_pl = 4.428788911416808e+43 * (kT * kT * sqkT) / (Z * coulomb);
+    o.k = (kappa_pl + (kappa_met - kappa_pl) * exp(-A4t * TeK * inv_TF)) * 0.073768115942029;
+  }
+  {
+    const double A1g = 50, A2g = 20, A3g = 0.25, m_atom = 26.9815;
+    const double nupl = 1.863839656495274e-40 * Z * Ne * coulomb * (inv_kT * inv_kT * sqkT);
+    const double nu_eff = fmin(1.309202957843054e+11 * (A1g * TiK + A2g * te2_tf), fmin(A3g * vth_over_r, nupl));
+    o.g = 2.783313120645740e-74 / (m_atom * C_AMU) * Ne * nu_eff;
+  }
   return o;
 }
 
@@ -324,9 +318,10 @@ __global__ void k_ttm_ghosts(Lat L, int *natoms, double *temp, double *fd_k)
 // do_DIFF: explicit 7-point variable-kappa step with mirror at inactive
 // neighbours (imd_ttm_3D.c:1603-1829), LDS-blocked: a workgroup stages its
 // (TX+2)x(TY+2)x(TZ+2) tile of {temp, fd_k, natoms} once.
-#define DT_X 4
+// one wavefront per workgroup: a 39^3 lattice gives 1000 workgroups = one per SIMD of the chip, a single round
+#define DT_X 2
 #define DT_Y 4
-#define DT_Z 16
+#define DT_Z 8
 // WRAP: ghost-shell cells are not read from memory but resolved on the fly (periodic direction: the
 // opposite inner cell; open direction: empty), i.e. ttm_fill_ghost_layers is folded into the load --
 // valid when the lattice is not split over ranks.
@@ -339,6 +334,7 @@ __global__ __launch_bounds__(DT_X *DT_Y *DT_Z) void k_ttm_diff(
   __shared__ double sT[DT_X + 2][DT_Y + 2][DT_Z + 2];
   __shared__ double sK[DT_X + 2][DT_Y + 2][DT_Z + 2];
   __shared__ int sN[DT_X + 2][DT_Y + 2][DT_Z + 2];
+  __builtin_amdgcn_s_setprio(3);      // latency-critical chain of tiny launches sharing the CUs with the force passes
   const int tz = threadIdx.x % DT_Z, ty = (threadIdx.x / DT_Z) % DT_Y, tx = threadIdx.x / (DT_Z * DT_Y);
   const int nbz = (L.dim[2] - 2 + DT_Z - 1) / DT_Z, nby = (L.dim[1] - 2 + DT_Y - 1) / DT_Y;
   const int bz = blockIdx.x % nbz, by = (blockIdx.x / nbz) % nby, bx = blockIdx.x / (nbz * nby);
@@ -373,7 +369,7 @@ __global__ __launch_bounds__(DT_X *DT_Y *DT_Z) void k_ttm_diff(
     return;
   }
   const double Te = sT[lx][ly][lz], kk = sK[lx][ly][lz];
-  const double invxsq = 1.0 / (L.h[0] * L.h[0]), invysq = 1.0 / (L.h[1] * L.h[1]), invzsq = 1.0 / (L.h[2] * L.h[2]);
+  const double invxsq = L.invhsq[0], invysq = L.invhsq[1], invzsq = L.invhsq[2];
 #define NB(dx, dy, dz, TT, KK) \
   double TT, KK; if (sN[lx + dx][ly + dy][lz + dz] < m) { TT = Te; KK = kk; } else { TT = sT[lx + dx][ly + dy][lz + dz]; KK = sK[lx + dx][ly + dy][lz + dz]; }
   NB(1, 0, 0, xaT, xaK) NB(-1, 0, 0, xbT, xbK) NB(0, 1, 0, yaT, yaK) NB(0, -1, 0, ybT, ybK) NB(0, 0, 1, zaT, zaK) NB(0, 0, -1, zbT, zbK)
@@ -391,8 +387,7 @@ __global__ __launch_bounds__(DT_X *DT_Y *DT_Z) void k_ttm_diff(
       ) + Te;
   T2[c] = Tn;
   U2[c] = U1[c] + (Tn - Te) * ce * L.vol / ((double) nat);
-  const double xi_fac = 26.9815 * C_AMU / 3.0 * 1e30 / ((double) nsub);
-  xi[c] += (Tn - Tl) * xi_fac * g / Tl / dens[c];
+  xi[c] += (Tn - Tl) * L.xi_fac * g / (Tl * dens[c]);
   if (FUSE_MESH) {                 // do_FILLMESH of the same cell with the new temperature
     MeshOut o = mesh_props(L, cve, Tn, Tl, dens[c]);
     Zo[c] = o.Z; neo[c] = o.ne; Ce[c] = o.Ce; fd_k_out[c] = o.k; fd_g[c] = o.g;
@@ -478,6 +473,11 @@ __global__ void k_move_ttm(int n, int cap, Lat L, Geo g, double4 *pos, const int
 // host side
 // ---------------------------------------------------------------------------
 static inline int nblk(long long n, int b) { return (int) ((n + b - 1) / b); }
+// Every kernel of the lattice chain uses ONE-WAVE workgroups.  The chain runs on the second stream beside the
+// force passes, whose persistent 11-wave workgroups leave no CU with room for a multi-wave workgroup (three
+// waves of 150-170 VGPRs fill three of the four SIMDs): measured with tools/coresidency_probe.hip, a 256-thread
+// workgroup waits for the force pass to END, a 64-thread one is placed at once on the fourth SIMD.
+#define TTM_WG 64
 
 static Lat make_lat(const TtmState *t)
 {
@@ -486,6 +486,11 @@ static Lat make_lat(const TtmState *t)
                                 L.off[d] = t->off[d]; L.ldim[d] = t->ldim[d]; }
   L.fd_min_atoms = t->fd_min_atoms; L.vol = t->vol; L.neighvol = t->neighvol; L.atomic_weight = t->atomic_weight;
   L.atomic_charge = t->atomic_charge; L.omega_laser = t->omega_laser; L.Temin = t->Temin;
+  L.inv_z0_43 = 1e-3 / pow(t->atomic_charge, 4.0 / 3.0);
+  L.inv_z0am = 1e-3 / (t->atomic_charge * t->atomic_weight);
+  L.inv_awamu = 1.0 / (t->atomic_weight * C_AMU);
+  for (int d = 0; d < 3; d++) L.invhsq[d] = 1.0 / (t->h[d] * t->h[d]);
+  L.xi_fac = 26.9815 * C_AMU / 3.0 * 1e30 / ((double) t->nsub);
   return L;
 }
 
@@ -601,7 +606,7 @@ extern "C" int imdgpu_ttm_update_fd(imdgpu_ctx *ctx, int steps)
 {
   NEED_TTM();
   ProfScope ps(ctx, PROF_TTM_UPDATE);
-  hipLaunchKernelGGL(k_ttm_update_fd, dim3(nblk((long long) t->ldim[0] * t->ldim[1] * t->ldim[2] * 64, 256)), dim3(256), 0, ctx->stream, L, steps,
+  hipLaunchKernelGGL(k_ttm_update_fd, dim3(nblk((long long) t->ldim[0] * t->ldim[1] * t->ldim[2] * 64, TTM_WG)), dim3(TTM_WG), 0, ctx->stream, L, steps,
                      ctx->cap_local, ctx->cell_start, ctx->cell_cnt, ctx->numneighs, ctx->p, ctx->mass, t->natoms,
                      t->natoms_old, t->temp[0], t->temp[1], t->xi, t->md_temp, t->source, t->vcom, t->dens, t->ncell,
                      (double *) nullptr);
@@ -617,7 +622,7 @@ extern "C" int imdgpu_ttm_local_block(imdgpu_ctx *ctx, int steps, double *dev_ou
   if (ncells_block) *ncells_block = nb;
   if (!dev_out) return 0;
   ProfScope ps(ctx, PROF_TTM_UPDATE);
-  hipLaunchKernelGGL(k_ttm_update_fd, dim3(nblk((long long) nb * 64, 256)), dim3(256), 0, ctx->stream, L, steps,
+  hipLaunchKernelGGL(k_ttm_update_fd, dim3(nblk((long long) nb * 64, TTM_WG)), dim3(TTM_WG), 0, ctx->stream, L, steps,
                      ctx->cap_local, ctx->cell_start, ctx->cell_cnt, ctx->numneighs, ctx->p, ctx->mass, t->natoms,
                      t->natoms_old, t->temp[0], t->temp[1], t->xi, t->md_temp, t->source, t->vcom, t->dens, t->ncell, dev_out);
   HIPCHK(hipGetLastError());
@@ -640,7 +645,7 @@ extern "C" int imdgpu_ttm_apply_blocks(imdgpu_ctx *ctx, int steps, const double 
 extern "C" int imdgpu_ttm_cell_activation(imdgpu_ctx *ctx)
 {
   NEED_TTM();
-  hipLaunchKernelGGL(k_ttm_activation, dim3(nblk(t->ninner, 256)), dim3(256), 0, ctx->stream, L, t->ee, t->natoms,
+  hipLaunchKernelGGL(k_ttm_activation, dim3(nblk(t->ninner, TTM_WG)), dim3(TTM_WG), 0, ctx->stream, L, t->ee, t->natoms,
                      t->natoms_old, t->temp[t->cur], t->temp[t->cur ^ 1], t->U[t->cur], t->U[t->cur ^ 1], t->xi,
                      t->md_temp, t->dens);
   HIPCHK(hipGetLastError());
@@ -651,7 +656,7 @@ extern "C" int imdgpu_ttm_fillmesh(imdgpu_ctx *ctx, int steps)
 {
   NEED_TTM();
   ProfScope ps(ctx, PROF_TTM_FILL);
-  hipLaunchKernelGGL(k_ttm_fillmesh, dim3(nblk(t->ninner, 128)), dim3(128), 0, ctx->stream, L, steps, t->cve, t->ee,
+  hipLaunchKernelGGL(k_ttm_fillmesh, dim3(nblk(t->ninner, TTM_WG)), dim3(TTM_WG), 0, ctx->stream, L, steps, t->cve, t->ee,
                      t->natoms, t->temp[t->cur], t->md_temp, t->dens, t->Z, t->ne, t->Ce, t->fd_k[t->kcur], t->fd_g,
                      t->U[t->cur], t->U[t->cur ^ 1]);
   HIPCHK(hipGetLastError());
@@ -662,7 +667,7 @@ extern "C" int imdgpu_ttm_fill_ghost_layers(imdgpu_ctx *ctx)
 {
   NEED_TTM();
   int nf = (t->dim[1] - 2) * (t->dim[2] - 2) + (t->dim[2] - 2) * (t->dim[0] - 2) + (t->dim[0] - 2) * (t->dim[1] - 2);
-  hipLaunchKernelGGL(k_ttm_ghosts, dim3(nblk(nf, 256)), dim3(256), 0, ctx->stream, L, t->natoms, t->temp[t->cur],
+  hipLaunchKernelGGL(k_ttm_ghosts, dim3(nblk(nf, TTM_WG)), dim3(TTM_WG), 0, ctx->stream, L, t->natoms, t->temp[t->cur],
                      t->fd_k[t->kcur]);
   HIPCHK(hipGetLastError());
   return 0;
@@ -721,7 +726,9 @@ extern "C" int imdgpu_ttm_lattice_step(imdgpu_ctx *ctx, int steps)
 {
   NEED_TTM();
   const double tau = ctx->timestep / ((double) t->nsub);
+  imdgpu_tl_mark(ctx, "ttm_update_fd");
   if (imdgpu_ttm_cell_activation(ctx) || imdgpu_ttm_fillmesh(ctx, steps) || imdgpu_ttm_fill_ghost_layers(ctx)) return 1;
+  imdgpu_tl_mark(ctx, "ttm_fillmesh");
   {
     ProfScope ps(ctx, PROF_TTM_DIFF);
     // the sub-step loop never returns to the host: nsub even => the ping-pong state after the loop equals
@@ -744,6 +751,7 @@ extern "C" int imdgpu_ttm_lattice_step(imdgpu_ctx *ctx, int steps)
       for (int i = 0; i < t->nsub; i++) launch_substep_fused(ctx, t, L, tau, steps);
     }
   }
+  imdgpu_tl_mark(ctx, "ttm_substeps");
   if (imdgpu_ttm_fill_ghost_layers(ctx)) return 1;     // sub-steps resolve ghosts on the fly; leave the shell consistent
   HIPCHK(hipGetLastError());
   // CFL_maxdt: value is informational for the host (diff_substeps is fixed by fd_n_timesteps in the
