@@ -539,6 +539,10 @@ struct TileArgs {
   const int *type, *acell, *cell_start, *cell_cnt, *istart;
   ushort4 *nbr16;
   int *nbr_cnt;
+  // staging plan written by k_nbl_build_tile, valid until the next re-binning: per tile the global index of the atom
+  // in every LDS slot, per own atom (slot | neighbour count << 16), per tile {slots, first own atom, own atoms, 0}
+  int *tsrc; unsigned *ownw; int4 *tinfo;
+  int dbg;                        // experiments (IMDGPU_DBG): 1 = skip the neighbour loops, 2 = skip the staging
   TabPar pair, rho;
   const double *merged;           // interleaved (phi,rho) table + 3 zero rows, or nullptr
   double *f, *epot, *rhoh, *ref;
@@ -652,6 +656,53 @@ __device__ __forceinline__ int own_slot(const TileArgs &a, const TileCtx &T, int
   return hstart[h] + (i - hsrc[h]);
 }
 
+// ---- staging from the plan (force passes) ------------------------------------------------------------
+// stage_issue: the slot -> atom index loads (STG ints per thread), called BEFORE the barrier that ends the previous
+// tile so that this round trip overlaps the wait for the slower waves.  stage_commit: position gathers and LDS
+// writes, between two barriers (holding the records themselves in registers across the barrier spills: the
+// force loops use every VGPR three waves per SIMD allow).  STG entries per thread cover STG*blockDim slots;
+// anything beyond (never at the tile shapes autotile picks) is staged by a plain loop.
+#define STG 5
+__device__ __forceinline__ void stage_issue(const TileArgs &a, int tile, int nsl, int (&IDX)[STG])
+{
+  const int *src = a.tsrc + (size_t) tile * a.slot_cap;
+#pragma unroll
+  for (int u = 0; u < STG; u++) { const int s = threadIdx.x + u * blockDim.x; IDX[u] = s < nsl ? src[s] : -1; }
+}
+template <bool WITH_W, bool WITH_T>
+__device__ __forceinline__ void stage_commit(const TileArgs &a, int tile, int nsl, const int (&IDX)[STG],
+                                             double *sp, double *sw, int *ts, double wscale = 1.0)
+{
+  double4 P[STG]; int TT[STG];
+#pragma unroll
+  for (int u = 0; u < STG; u++) if (IDX[u] >= 0) { P[u] = a.pos[IDX[u]]; if (WITH_T) TT[u] = a.type[IDX[u]]; }
+#pragma unroll
+  for (int u = 0; u < STG; u++) {
+    const int s = threadIdx.x + u * blockDim.x;
+    if (IDX[u] >= 0) {
+      double *d = sp + 3 * (size_t) s;
+      d[0] = P[u].x; d[1] = P[u].y; d[2] = P[u].z;
+      if (WITH_W) sw[s] = P[u].w * wscale;
+      if (WITH_T) ts[s] = TT[u];
+    }
+  }
+  const int *src = a.tsrc + (size_t) tile * a.slot_cap;
+  for (int s = threadIdx.x + STG * blockDim.x; s < nsl; s += blockDim.x) {
+    const int gi = src[s];
+    const double4 q = a.pos[gi];
+    double *d = sp + 3 * (size_t) s;
+    d[0] = q.x; d[1] = q.y; d[2] = q.z;
+    if (WITH_W) sw[s] = q.w * wscale;
+    if (WITH_T) ts[s] = a.type[gi];
+  }
+  if (threadIdx.x == 0) {                          // the far-away dummy that pads the neighbour rows
+    double *d = sp + (size_t) (a.slot_cap - 1) * 3;
+    d[0] = 1e150; d[1] = 1e150; d[2] = 1e150;
+    if (WITH_W) sw[a.slot_cap - 1] = 0.0;
+    if (WITH_T) ts[a.slot_cap - 1] = 0;
+  }
+}
+
 // per tile: own atoms and staged atoms, for sizing tile_cap / slot_cap
 __global__ void k_tile_stats(int ntiles, Geo g, const int *cell_cnt, const int *istart, int *counters)
 {
@@ -687,6 +738,18 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile(TileArgs a)
   for (T.tile = t0; T.tile < t1; T.tile++) {
   __syncthreads();
   tile_stage<3, false>(a, T, sp, nullptr, hstart, hsrc);
+  {                                                  // the staging plan of this tile for the force passes
+    int *src = a.tsrc + (size_t) T.tile * a.slot_cap;
+    const int hw = threadIdx.x >> 5, l = threadIdx.x & 31, nhw = blockDim.x >> 5;
+    for (int h = hw; h < T.nh; h += nhw) {
+      const int s0 = hstart[h], n = hstart[h + 1] - s0, g0 = hsrc[h];
+      for (int e = l; e < n; e += 32) if (s0 + e < a.slot_cap - 1) src[s0 + e] = g0 + e;
+    }
+    if (threadIdx.x == 0) {
+      const int tot = hstart[T.nh];
+      a.tinfo[T.tile] = make_int4(tot < a.slot_cap - 1 ? tot : a.slot_cap - 1, T.own_start, T.nown, 0);
+    }
+  }
   for (int o = threadIdx.x; o < T.nown; o += blockDim.x) {
     const int i = T.own_start + o;
     int lx, ly, lz;
@@ -717,6 +780,7 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile(TileArgs a)
         }
     if ((m & 3) != 0 && (m >> 2) < a.W4) lp[(size_t) (m >> 2) * a.tile_cap] = make_ushort4(buf[0], buf[1], buf[2], buf[3]);
     a.nbr_cnt[i] = m < 4 * a.W4 ? m : 4 * a.W4;
+    a.ownw[(size_t) T.tile * a.tile_cap + o] = (unsigned) slot | ((unsigned) (m < 4 * a.W4 ? m : 4 * a.W4) << 16);
     mmax = m > mmax ? m : mmax;
   }
   }
@@ -741,6 +805,52 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile(TileArgs a)
 #endif
 #define UNR 4
 
+// Tile loop plumbing shared by the force kernels (see stage_issue / stage_commit).  The first list words and the
+// (slot, count) word of the thread's own atom do not depend on the staged positions: they are requested before
+// the barriers, so their latency is hidden as well.
+#define TILE_PROLOGUE(WITH_W, WITH_T, SW, TS, WSCALE)                                                                 \
+    T.own_start = info.y; T.nown = info.z;                                                                       \
+    const unsigned dw = (unsigned) (a.slot_cap - 1) * 0x10001u;                                                  \
+    const uint2 dummyw = make_uint2(dw, dw);                                                                     \
+    const size_t lbase = (size_t) T.tile * a.W4 * a.tile_cap;                                                    \
+    unsigned ow0 = 0; uint2 w0 = dummyw, w1 = dummyw;                                                            \
+    if ((int) threadIdx.x < T.nown) {                                                                            \
+      const uint2 *lq = (const uint2 *) (a.nbr16 + lbase + threadIdx.x);                                         \
+      ow0 = a.ownw[(size_t) T.tile * a.tile_cap + threadIdx.x]; w0 = lq[0]; w1 = lq[(size_t) a.tile_cap];       \
+    }                                                                                                            \
+    __syncthreads();                              /* every wave is done with the previous tile's LDS */          \
+    if (!(a.dbg & 2)) stage_commit<WITH_W, WITH_T>(a, T.tile, info.x, IDX, sp, SW, TS, WSCALE);                                          \
+    __syncthreads();                                                                                             \
+    int4 info_next = info;                                                                                       \
+    if (T.tile + 1 < t1) info_next = a.tinfo[T.tile + 1];
+#define OWN_PROLOGUE                                                                                             \
+      const uint2 *lp = (const uint2 *) (a.nbr16 + lbase + o);                                                   \
+      unsigned ow = ow0, c0x = w0.x, c0y = w0.y, c1x = w1.x, c1y = w1.y;   /* scalars: uint2 selects end up in scratch */ \
+      if (o != (int) threadIdx.x) {                                                                              \
+        ow = a.ownw[(size_t) T.tile * a.tile_cap + o];                                                           \
+        const uint2 q0 = lp[0], q1 = lp[(size_t) a.tile_cap];                                                    \
+        c0x = q0.x; c0y = q0.y; c1x = q1.x; c1y = q1.y;                                                          \
+      }                                                                                                          \
+      const int slot = (int) (ow & 0xffffu), n4 = (a.dbg & 1) ? 0 : ((int) (ow >> 16) + 3) >> 2;                \
+      if (n4 < 1) { c0x = dw; c0y = dw; }                                                                        \
+      if (n4 < 2) { c1x = dw; c1y = dw; }
+// the list walk: two words (8 slots) are consumed per pair of trips while the next two are in flight; lanes past
+// their own count get the dummy word.  Opens the k4 loop and defines j[UNR].
+#define LIST_WORDS_BEGIN                                                                                         \
+      unsigned m0x = dw, m0y = dw, m1x = dw, m1y = dw;                                                           \
+      for (int k4 = 0; k4 < n4; k4++) {                                                                          \
+        if ((k4 & 1) == 0) {                      /* even trip: issue the next pair of loads */                  \
+          m0x = dw; m0y = dw; m1x = dw; m1y = dw;                                                                \
+          if (k4 + 2 < n4) { const uint2 q = lp[(size_t) (k4 + 2) * a.tile_cap]; m0x = q.x; m0y = q.y; }        \
+          if (k4 + 3 < n4) { const uint2 q = lp[(size_t) (k4 + 3) * a.tile_cap]; m1x = q.x; m1y = q.y; }        \
+        }                                                                                                        \
+        const unsigned curx = (k4 & 1) ? c1x : c0x, cury = (k4 & 1) ? c1y : c0y;                                 \
+        if (k4 & 1) { c0x = m0x; c0y = m0y; c1x = m1x; c1y = m1y; }   /* odd trip: hand over (loads are ~8 neighbours old) */ \
+        const int j[UNR] = {(int) (curx & 0xffffu), (int) (curx >> 16), (int) (cury & 0xffffu), (int) (cury >> 16)};
+#define TILE_EPILOGUE                                                                                            \
+    if (T.tile + 1 < t1) stage_issue(a, T.tile + 1, info_next.x, IDX);                                           \
+    info = info_next;
+
 struct TabK { double begin, end, istep, istep2; };      // one column of a table (NT1 fast path)
 
 __device__ __forceinline__ void tab_index(const TabK &c, double arg, int &k, double &chi)
@@ -762,7 +872,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile(TileArgs a)
   double *tr = tp + (PAIR ? a.pair.nrows * a.pair.ncols : 0);
   double *sp = tr + (EAM ? a.rho.nrows * a.rho.ncols : 0);
   double *scratch = sp + 3 * (size_t) a.slot_cap;
-  int *hstart = (int *) (scratch + 64), *hsrc = hstart + NH_MAX + 1, *ts = hsrc + NH_MAX;
+  int *ts = (int *) (scratch + 64);
   TileCtx T;
   int t0, t1;
   block_tile_range(a.ntiles, t0, t1);
@@ -772,38 +882,27 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile(TileArgs a)
     if (PAIR) lds_load_table(tp, a.pair);
     if (EAM) lds_load_table(tr, a.rho);
   }
+  int4 info = make_int4(0, 0, 0, 0);
+  int IDX[STG];
+  if (t0 < t1) { info = a.tinfo[t0]; stage_issue(a, t0, info.x, IDX); }
   for (T.tile = t0; T.tile < t1; T.tile++) {     // uniform per block
-    __syncthreads();
-    tile_stage<3, !NT1>(a, T, sp, ts, hstart, hsrc);
+    TILE_PROLOGUE(false, !NT1, nullptr, ts, 1.0)
     const int nt = a.ntypes, inc = NT1 ? 1 : nt * nt;
     const double pend0 = PAIR ? a.pair.end[0] : 0.0;
     const TabK cp = {a.pair.begin[0], a.pair.end[0], a.pair.invstep[0], 2 * a.pair.invstep[0]};
     const TabK cr = {a.rho.begin[0], a.rho.end[0], a.rho.invstep[0], 2 * a.rho.invstep[0]};
     for (int o = threadIdx.x; o < T.nown; o += blockDim.x) {
       const int i = T.own_start + o;
-      int lx, ly, lz;
-      const int slot = own_slot(a, T, i, hstart, hsrc, lx, ly, lz);
+      OWN_PROLOGUE
       const double xi = sp[3 * slot], yi = sp[3 * slot + 1], zi = sp[3 * slot + 2];
       const int it = NT1 ? 0 : ts[slot];
-      const int n4 = (a.nbr_cnt[i] + 3) >> 2;
-      const uint2 *lp = (const uint2 *) (a.nbr16 + (size_t) T.tile * a.W4 * a.tile_cap + o);
       double fx = 0, fy = 0, fz = 0, ee = 0, rr = 0, vir = 0, r2min = 1e300;
       int nb = 0;
       // list words: PFD groups of four slots in flight (only ~3 waves/SIMD are resident, so the HBM stream
       // of the list needs memory-level parallelism from each wave)
       // two list words (8 slots) are consumed per trip while the next two are in flight; lanes past their
       // own count get the dummy word
-      const unsigned dw = (unsigned) (a.slot_cap - 1) * 0x10001u;
-      const uint2 dummyw = make_uint2(dw, dw);
-      uint2 c0 = n4 > 0 ? lp[0] : dummyw, c1 = n4 > 1 ? lp[(size_t) a.tile_cap] : dummyw, m0 = dummyw, m1 = dummyw;
-      for (int k4 = 0; k4 < n4; k4++) {
-        if ((k4 & 1) == 0) {                                               // even trip: issue the next pair of loads
-          m0 = k4 + 2 < n4 ? lp[(size_t) (k4 + 2) * a.tile_cap] : dummyw;
-          m1 = k4 + 3 < n4 ? lp[(size_t) (k4 + 3) * a.tile_cap] : dummyw;
-        }
-        const uint2 cur = (k4 & 1) ? c1 : c0;
-        if (k4 & 1) { c0 = m0; c1 = m1; }                                  // odd trip: hand over (loads are ~8 neighbours old)
-        const int j[UNR] = {(int) (cur.x & 0xffffu), (int) (cur.x >> 16), (int) (cur.y & 0xffffu), (int) (cur.y >> 16)};
+      LIST_WORDS_BEGIN
         double dx[UNR], dy[UNR], dz[UNR], r2[UNR];
 #pragma unroll
         for (int e = 0; e < UNR; e++) {                                   // phase 1: positions from LDS, all reads first
@@ -891,6 +990,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile(TileArgs a)
       if (TTMN) a.numneighs[i] = nb;
       sums[0] += ee; sums[1] += vir;
     }
+    TILE_EPILOGUE
   }
   block_sum<2>(sums, scratch);
   if (threadIdx.x == 0) {
@@ -912,7 +1012,6 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
   const int nrows = a.pair.nrows, kz = nrows;
   double *sp = lds + 2 * (size_t) (nrows + 3);
   double *scratch = sp + 3 * (size_t) a.slot_cap;
-  int *hstart = (int *) (scratch + 64), *hsrc = hstart + NH_MAX + 1;
   TileCtx T;
   int t0, t1;
   block_tile_range(a.ntiles, t0, t1);
@@ -929,29 +1028,18 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
     }
   }
   const TabK c = {a.pair.begin[0], a.pair.end[0], a.pair.invstep[0], 2 * a.pair.invstep[0]};
+  int4 info = make_int4(0, 0, 0, 0);
+  int IDX[STG];
+  if (t0 < t1) { info = a.tinfo[t0]; stage_issue(a, t0, info.x, IDX); }
   for (T.tile = t0; T.tile < t1; T.tile++) {
-    __syncthreads();
-    tile_stage<3, false>(a, T, sp, nullptr, hstart, hsrc);
+    TILE_PROLOGUE(false, false, nullptr, nullptr, 1.0)
     for (int o = threadIdx.x; o < T.nown; o += blockDim.x) {
       const int i = T.own_start + o;
-      int lx, ly, lz;
-      const int slot = own_slot(a, T, i, hstart, hsrc, lx, ly, lz);
+      OWN_PROLOGUE
       const double xi = sp[3 * slot], yi = sp[3 * slot + 1], zi = sp[3 * slot + 2];
-      const int n4 = (a.nbr_cnt[i] + 3) >> 2;
-      const uint2 *lp = (const uint2 *) (a.nbr16 + (size_t) T.tile * a.W4 * a.tile_cap + o);
       double fx = 0, fy = 0, fz = 0, ee = 0, rr = 0, vir = 0, r2min = 1e300;
       int nb = 0;
-      const unsigned dw = (unsigned) (a.slot_cap - 1) * 0x10001u;
-      const uint2 dummyw = make_uint2(dw, dw);
-      uint2 c0 = n4 > 0 ? lp[0] : dummyw, c1 = n4 > 1 ? lp[(size_t) a.tile_cap] : dummyw, m0 = dummyw, m1 = dummyw;
-      for (int k4 = 0; k4 < n4; k4++) {
-        if ((k4 & 1) == 0) {
-          m0 = k4 + 2 < n4 ? lp[(size_t) (k4 + 2) * a.tile_cap] : dummyw;
-          m1 = k4 + 3 < n4 ? lp[(size_t) (k4 + 3) * a.tile_cap] : dummyw;
-        }
-        const uint2 cur = (k4 & 1) ? c1 : c0;
-        if (k4 & 1) { c0 = m0; c1 = m1; }
-        const int j[UNR] = {(int) (cur.x & 0xffffu), (int) (cur.x >> 16), (int) (cur.y & 0xffffu), (int) (cur.y >> 16)};
+      LIST_WORDS_BEGIN
         double dx[UNR], dy[UNR], dz[UNR], r2[UNR], chi[UNR];
         int k[UNR];
         double2 A[UNR], B[UNR], C[UNR];
@@ -975,17 +1063,17 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
 #pragma unroll
         for (int e = 0; e < UNR; e++) {
 #pragma clang fp contract(fast)
-          const double x = chi[e], h = (0.5 * x) * (x - 1), g = x - 0.5;
+          const double g = chi[e] - 0.5, h = fma(0.5 * g, g, -0.125);      // h = chi (chi - 1) / 2
           const double dvp = B[e].x - A[e].x, d2p = (C[e].x - 2 * B[e].x) + A[e].x;
           const double dvr = B[e].y - A[e].y, d2r = (C[e].y - 2 * B[e].y) + A[e].y;
-          const double pot = A[e].x + x * dvp + h * d2p;
-          const double grad = c.istep2 * (dvp + g * d2p);
-          rr += A[e].y + x * dvr + h * d2r;
-          fx += dx[e] * grad; fy += dy[e] * grad; fz += dz[e] * grad;
-          ee += 0.5 * pot;
-          vir -= 0.5 * (r2[e] * grad);
+          const double gr = dvp + g * d2p;                                  // grad / (2 invstep): scaled once per atom
+          rr += A[e].y + chi[e] * dvr + h * d2r;
+          fx += dx[e] * gr; fy += dy[e] * gr; fz += dz[e] * gr;
+          ee += A[e].x + chi[e] * dvp + h * d2p;                            // halved once per atom
+          vir += r2[e] * gr;
         }
       }
+      fx *= c.istep2; fy *= c.istep2; fz *= c.istep2; ee *= 0.5; vir *= -0.5 * c.istep2;
       is_short |= (r2min < c.begin) ? 1 : 0;
       a.f[i] = fx; a.f[a.cap + i] = fy; a.f[2 * (size_t) a.cap + i] = fz;
       a.epot[i] = ee;
@@ -993,6 +1081,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
       if (TTMN) a.numneighs[i] = nb;
       sums[0] += ee; sums[1] += vir;
     }
+    TILE_EPILOGUE
   }
   block_sum<2>(sums, scratch);
   if (threadIdx.x == 0) {
@@ -1006,46 +1095,41 @@ template <bool NT1>
 __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass3_tile(TileArgs a)
 {
   extern __shared__ double lds[];
-  double *tr = lds;
-  double *sp = tr + a.rho.nrows * a.rho.ncols;          // xyz records (24 B) ...
+  double *tr = lds;                                      // rho_h_tab, one type: + zero rows for r2 >= end (no mask)
+  double *sp = tr + a.rho.nrows * a.rho.ncols + 4;      // xyz records (24 B) ...
   double *sw = sp + 3 * (size_t) a.slot_cap;             // ... and dF in its own array (fewer bank conflicts than 32 B records)
   double *scratch = sw + a.slot_cap;
-  int *hstart = (int *) (scratch + 64), *hsrc = hstart + NH_MAX + 1, *ts = hsrc + NH_MAX;
+  int *ts = (int *) (scratch + 64);
   TileCtx T;
   int t0, t1;
   block_tile_range(a.ntiles, t0, t1);
   double sums[1] = {0.0};
   int is_short = 0;
-  if (t0 < t1) lds_load_table(tr, a.rho);
+  if (t0 < t1) {
+    lds_load_table(tr, a.rho);
+    if (threadIdx.x < 4) tr[a.rho.nrows * a.rho.ncols + threadIdx.x] = 0.0;
+  }
+  // one type: dF is staged as dF * invstep (= 0.5 * 2 invstep), so grad = (w_i + w_j) * (dv + (chi - 1/2) d2v)
+  const double wscale = NT1 ? a.rho.invstep[0] : 1.0;
+  const int kz = a.rho.nrows * a.rho.ncols;
+  int4 info = make_int4(0, 0, 0, 0);
+  int IDX[STG];
+  if (t0 < t1) { info = a.tinfo[t0]; stage_issue(a, t0, info.x, IDX); }
   for (T.tile = t0; T.tile < t1; T.tile++) {
-    __syncthreads();
-    tile_stage<4, !NT1>(a, T, sp, ts, hstart, hsrc, sw);
+    TILE_PROLOGUE(true, !NT1, sw, ts, wscale)
     const int nt = a.ntypes, inc = NT1 ? 1 : nt * nt;
     const TabK cr = {a.rho.begin[0], a.rho.end[0], a.rho.invstep[0], 2 * a.rho.invstep[0]};
     for (int o = threadIdx.x; o < T.nown; o += blockDim.x) {
       const int i = T.own_start + o;
-      int lx, ly, lz;
-      const int slot = own_slot(a, T, i, hstart, hsrc, lx, ly, lz);
+      OWN_PROLOGUE
       const double xi = sp[3 * slot], yi = sp[3 * slot + 1], zi = sp[3 * slot + 2], wi = sw[slot];
       const int it = NT1 ? 0 : ts[slot];
-      const int n4 = (a.nbr_cnt[i] + 3) >> 2;
-      const uint2 *lp = (const uint2 *) (a.nbr16 + (size_t) T.tile * a.W4 * a.tile_cap + o);
       double fx = 0, fy = 0, fz = 0, vir = 0, r2min = 1e300;
       // list words: PFD groups of four slots in flight (only ~3 waves/SIMD are resident, so the HBM stream
       // of the list needs memory-level parallelism from each wave)
       // two list words (8 slots) are consumed per trip while the next two are in flight; lanes past their
       // own count get the dummy word
-      const unsigned dw = (unsigned) (a.slot_cap - 1) * 0x10001u;
-      const uint2 dummyw = make_uint2(dw, dw);
-      uint2 c0 = n4 > 0 ? lp[0] : dummyw, c1 = n4 > 1 ? lp[(size_t) a.tile_cap] : dummyw, m0 = dummyw, m1 = dummyw;
-      for (int k4 = 0; k4 < n4; k4++) {
-        if ((k4 & 1) == 0) {                                               // even trip: issue the next pair of loads
-          m0 = k4 + 2 < n4 ? lp[(size_t) (k4 + 2) * a.tile_cap] : dummyw;
-          m1 = k4 + 3 < n4 ? lp[(size_t) (k4 + 3) * a.tile_cap] : dummyw;
-        }
-        const uint2 cur = (k4 & 1) ? c1 : c0;
-        if (k4 & 1) { c0 = m0; c1 = m1; }                                  // odd trip: hand over (loads are ~8 neighbours old)
-        const int j[UNR] = {(int) (cur.x & 0xffffu), (int) (cur.x >> 16), (int) (cur.y & 0xffffu), (int) (cur.y >> 16)};
+      LIST_WORDS_BEGIN
         double dx[UNR], dy[UNR], dz[UNR], wj[UNR], r2[UNR];
 #pragma unroll
         for (int e = 0; e < UNR; e++) {
@@ -1062,7 +1146,10 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass3_tile(TileArgs a)
           int kr[UNR];
           double ch[UNR], R0[UNR], R1[UNR], R2[UNR];
 #pragma unroll
-          for (int e = 0; e < UNR; e++) { r2min = fmin(r2min, r2[e]); tab_index(cr, r2[e], kr[e], ch[e]); }
+          for (int e = 0; e < UNR; e++) {
+            r2min = fmin(r2min, r2[e]); tab_index(cr, r2[e], kr[e], ch[e]);
+            kr[e] = (r2[e] < cr.end) ? kr[e] : kz;                        // rho': r2 < end (imd_forces_nbl.c:868)
+          }
           SCHED_BARRIER;
 #pragma unroll
           for (int e = 0; e < UNR; e++) { R0[e] = tr[kr[e]]; R1[e] = tr[kr[e] + 1]; R2[e] = tr[kr[e] + 2]; }
@@ -1071,11 +1158,9 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass3_tile(TileArgs a)
           for (int e = 0; e < UNR; e++) {
 #pragma clang fp contract(fast)
             const double dv = R1[e] - R0[e], d2v = (R2[e] - 2 * R1[e]) + R0[e];
-            const double rp = cr.istep2 * (dv + (ch[e] - 0.5) * d2v);                 // rho'_i = rho'_j (one type)
-            const double grad = (r2[e] < cr.end) ? (0.5 * (wi + wj[e])) * rp : 0.0;
-            const double gx = dx[e] * grad, gy = dy[e] * grad, gz = dz[e] * grad;
-            fx += gx; fy += gy; fz += gz;
-            vir -= 0.5 * (dx[e] * gx + dy[e] * gy + dz[e] * gz);
+            const double grad = (wi + wj[e]) * (dv + (ch[e] - 0.5) * d2v);           // rho'_i = rho'_j (one type)
+            fx += dx[e] * grad; fy += dy[e] * grad; fz += dz[e] * grad;
+            vir += r2[e] * grad;                                                      // d.f = grad r2
           }
         } else {
 #pragma unroll
@@ -1102,10 +1187,11 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass3_tile(TileArgs a)
           }
         }
       }
-      if (NT1) is_short |= (r2min < cr.begin) ? 1 : 0;
+      if (NT1) { is_short |= (r2min < cr.begin) ? 1 : 0; vir *= -0.5; }
       a.f[i] += fx; a.f[a.cap + i] += fy; a.f[2 * (size_t) a.cap + i] += fz;
       sums[0] += vir;
     }
+    TILE_EPILOGUE
   }
   block_sum<1>(sums, scratch);
   if (threadIdx.x == 0) a.partials[(size_t) blockIdx.x * IMDGPU_NPART + 3] = sums[0];
@@ -1253,7 +1339,7 @@ extern "C" void imdgpu_destroy(imdgpu_ctx *c)
                   c->pos2, c->type2, c->id2, c->p2, c->mass2, c->nn2, c->keys, c->keys2, c->perm, c->perm2,
                   c->cub_tmp, c->cell_start, c->cell_cnt, c->icnt, c->istart, c->gcell_lin, c->gcell_src,
                   c->gcell_shift, c->gcnt, c->gstart, c->ghost_src, c->ghost_code, c->d_counters, c->nbr,
-                  c->nbr_cnt, c->nbr16, c->d_merged, c->partials, c->d_sums, c->pair.d_tab, c->rho.d_tab, c->emb.d_tab, c->d_restr};
+                  c->nbr_cnt, c->nbr16, c->tsrc, c->ownw, c->tinfo, c->d_merged, c->partials, c->d_sums, c->pair.d_tab, c->rho.d_tab, c->emb.d_tab, c->d_restr};
   for (void *p : ptrs) if (p) (void) hipFree(p);
   if (c->h_counters) (void) hipHostFree(c->h_counters);
   if (c->h_sums) (void) hipHostFree(c->h_sums);
@@ -1799,6 +1885,8 @@ static TileArgs make_tile_args(imdgpu_ctx *ctx)
   a.g = make_geo(ctx);
   a.pos = ctx->pos; a.type = ctx->type; a.acell = ctx->acell; a.cell_start = ctx->cell_start; a.cell_cnt = ctx->cell_cnt;
   a.istart = ctx->istart; a.nbr16 = (ushort4 *) ctx->nbr16; a.nbr_cnt = ctx->nbr_cnt;
+  a.tsrc = ctx->tsrc; a.ownw = ctx->ownw; a.tinfo = (int4 *) ctx->tinfo;
+  { static const int dbg = getenv("IMDGPU_DBG") ? atoi(getenv("IMDGPU_DBG")) : 0; a.dbg = dbg; }
   a.pair = ctx->pair.par; a.rho = ctx->rho.par; a.merged = ctx->d_merged;
   a.f = ctx->f; a.epot = ctx->epot; a.rhoh = ctx->rhoh; a.ref = ctx->ref; a.numneighs = ctx->numneighs;
   a.partials = ctx->partials; a.counters = ctx->d_counters; a.cellsz = ctx->cellsz;
@@ -1816,12 +1904,12 @@ static size_t tile_lds_bytes_for(const imdgpu_ctx *ctx, int slot_cap, int which)
 }
 static size_t tile_lds_bytes(const imdgpu_ctx *ctx, int which /*0 build, 1 pass1, 3 pass3*/)
 {
-  size_t ints = (size_t) (2 * NH_MAX + 1) * sizeof(int) + (ctx->ntypes == 1 ? 0 : (size_t) ctx->slot_cap * sizeof(int));
+  size_t ints = (ctx->ntypes == 1 ? 0 : (size_t) ctx->slot_cap * sizeof(int));      // per-slot types (several types only)
   size_t tp = ctx->pair.present ? (size_t) ctx->pair.par.nrows * ctx->pair.par.ncols : 0;
   size_t tr = ctx->rho.present ? (size_t) ctx->rho.par.nrows * ctx->rho.par.ncols : 0;
   if (which == 0) return align8((size_t) 3 * ctx->slot_cap * 8 + (size_t) (2 * NH_MAX + 1) * sizeof(int));
   if (which == 1) return align8((tp + tr + 6 + 3 * (size_t) ctx->slot_cap + 64) * 8 + ints);
-  return align8((tr + 4 * (size_t) ctx->slot_cap + 64) * 8 + ints);
+  return align8((tr + 4 + 4 * (size_t) ctx->slot_cap + 64) * 8 + ints);
 }
 
 // Multi-rank set-ups call this between the ghost layout and make_nblist: it may re-sort the local atoms
@@ -1882,6 +1970,10 @@ extern "C" int imdgpu_make_nblist(imdgpu_ctx *ctx)
         if (dev_alloc(ctx, &ctx->nbr16, need)) return 1;
         ctx->nbr16_cap = need;
       }
+      const size_t need_src = (size_t) ctx->ntiles * ctx->slot_cap, need_own = (size_t) ctx->ntiles * ctx->tile_cap;
+      if (ctx->tsrc_cap < need_src) { if (dev_alloc(ctx, &ctx->tsrc, need_src)) return 1; ctx->tsrc_cap = need_src; }
+      if (ctx->ownw_cap < need_own) { if (dev_alloc(ctx, &ctx->ownw, need_own)) return 1; ctx->ownw_cap = need_own; }
+      if (ctx->tinfo_cap < (size_t) ctx->ntiles * 4) { if (dev_alloc(ctx, &ctx->tinfo, (size_t) ctx->ntiles * 4)) return 1; ctx->tinfo_cap = (size_t) ctx->ntiles * 4; }
       TileArgs a = make_tile_args(ctx);
       size_t lds = tile_lds_bytes(ctx, 0);
       HIPCHK(hipFuncSetAttribute((const void *) k_nbl_build_tile, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));

@@ -91,6 +91,8 @@ struct imdgpu_ctx {
   int *mig_idx[2]{nullptr, nullptr}; int mig_n[2]{0, 0}, mig_cap = 0; int *mig_flag = nullptr;
   int *nbr = nullptr, *nbr_cnt = nullptr;
   unsigned short *nbr16 = nullptr; size_t nbr16_cap = 0;
+  int *tsrc = nullptr; unsigned *ownw = nullptr; int *tinfo = nullptr;   // staging plan of the tiles (k_nbl_build_tile)
+  size_t tsrc_cap = 0, ownw_cap = 0, tinfo_cap = 0;
   int W = 0; size_t stride = 0; size_t nbr_cap = 0;
   int tile_cap = 0, max_halo = 0, slot_cap = 0, tile_threads = 0;
   size_t lds_need[4]{};
