@@ -659,7 +659,7 @@ __device__ __forceinline__ int own_slot(const TileArgs &a, const TileCtx &T, int
 // ---- staging from the plan (force passes) ------------------------------------------------------------
 // stage_issue: the slot -> atom index loads (STG ints per thread), called BEFORE the barrier that ends the previous
 // tile so that this round trip overlaps the wait for the slower waves.  stage_commit: position gathers and LDS
-// writes, between two barriers (holding the records themselves in registers across the barrier spills: the
+// writes (x, y, z planes: conflict-free ds_read_b64 gathers), between two barriers (holding the records themselves in registers across the barrier spills: the
 // force loops use every VGPR three waves per SIMD allow).  STG entries per thread cover STG*blockDim slots;
 // anything beyond (never at the tile shapes autotile picks) is staged by a plain loop.
 #define STG 5
@@ -680,8 +680,7 @@ __device__ __forceinline__ void stage_commit(const TileArgs &a, int tile, int ns
   for (int u = 0; u < STG; u++) {
     const int s = threadIdx.x + u * blockDim.x;
     if (IDX[u] >= 0) {
-      double *d = sp + 3 * (size_t) s;
-      d[0] = P[u].x; d[1] = P[u].y; d[2] = P[u].z;
+      sp[s] = P[u].x; sp[a.slot_cap + s] = P[u].y; sp[2 * a.slot_cap + s] = P[u].z;
       if (WITH_W) sw[s] = P[u].w * wscale;
       if (WITH_T) ts[s] = TT[u];
     }
@@ -690,14 +689,12 @@ __device__ __forceinline__ void stage_commit(const TileArgs &a, int tile, int ns
   for (int s = threadIdx.x + STG * blockDim.x; s < nsl; s += blockDim.x) {
     const int gi = src[s];
     const double4 q = a.pos[gi];
-    double *d = sp + 3 * (size_t) s;
-    d[0] = q.x; d[1] = q.y; d[2] = q.z;
+    sp[s] = q.x; sp[a.slot_cap + s] = q.y; sp[2 * a.slot_cap + s] = q.z;
     if (WITH_W) sw[s] = q.w * wscale;
     if (WITH_T) ts[s] = a.type[gi];
   }
   if (threadIdx.x == 0) {                          // the far-away dummy that pads the neighbour rows
-    double *d = sp + (size_t) (a.slot_cap - 1) * 3;
-    d[0] = 1e150; d[1] = 1e150; d[2] = 1e150;
+    sp[a.slot_cap - 1] = 1e150; sp[2 * a.slot_cap - 1] = 1e150; sp[3 * a.slot_cap - 1] = 1e150;
     if (WITH_W) sw[a.slot_cap - 1] = 0.0;
     if (WITH_T) ts[a.slot_cap - 1] = 0;
   }
@@ -797,7 +794,9 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile(TileArgs a)
 // the argument clamped into the table (2 pad rows, imd_potential.c:1272) and the result masked by the
 // cut-off test.  Products may fuse into FMAs here (relative change ~1e-16); the squared distance and
 // every cut-off comparison use the reference's unfused expression.
+#ifndef TILE_MAXTHREADS
 #define TILE_MAXTHREADS 768
+#endif
 #ifdef IMDGPU_NOSCHED
 #define SCHED_BARRIER
 #else
@@ -894,7 +893,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile(TileArgs a)
     for (int o = threadIdx.x; o < T.nown; o += blockDim.x) {
       const int i = T.own_start + o;
       OWN_PROLOGUE
-      const double xi = sp[3 * slot], yi = sp[3 * slot + 1], zi = sp[3 * slot + 2];
+      const double xi = sp[slot], yi = sp[a.slot_cap + slot], zi = sp[2 * a.slot_cap + slot];
       const int it = NT1 ? 0 : ts[slot];
       double fx = 0, fy = 0, fz = 0, ee = 0, rr = 0, vir = 0, r2min = 1e300;
       int nb = 0;
@@ -906,8 +905,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile(TileArgs a)
         double dx[UNR], dy[UNR], dz[UNR], r2[UNR];
 #pragma unroll
         for (int e = 0; e < UNR; e++) {                                   // phase 1: positions from LDS, all reads first
-          const double *pj = sp + 3 * j[e];
-          dx[e] = pj[0]; dy[e] = pj[1]; dz[e] = pj[2];
+          dx[e] = sp[j[e]]; dy[e] = sp[a.slot_cap + j[e]]; dz[e] = sp[2 * a.slot_cap + j[e]];
         }
         SCHED_BARRIER;
 #pragma unroll
@@ -1036,7 +1034,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
     for (int o = threadIdx.x; o < T.nown; o += blockDim.x) {
       const int i = T.own_start + o;
       OWN_PROLOGUE
-      const double xi = sp[3 * slot], yi = sp[3 * slot + 1], zi = sp[3 * slot + 2];
+      const double xi = sp[slot], yi = sp[a.slot_cap + slot], zi = sp[2 * a.slot_cap + slot];
       double fx = 0, fy = 0, fz = 0, ee = 0, rr = 0, vir = 0, r2min = 1e300;
       int nb = 0;
       LIST_WORDS_BEGIN
@@ -1044,7 +1042,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
         int k[UNR];
         double2 A[UNR], B[UNR], C[UNR];
 #pragma unroll
-        for (int e = 0; e < UNR; e++) { const double *pj = sp + 3 * j[e]; dx[e] = pj[0]; dy[e] = pj[1]; dz[e] = pj[2]; }
+        for (int e = 0; e < UNR; e++) { dx[e] = sp[j[e]]; dy[e] = sp[a.slot_cap + j[e]]; dz[e] = sp[2 * a.slot_cap + j[e]]; }
         SCHED_BARRIER;
 #pragma unroll
         for (int e = 0; e < UNR; e++) {
@@ -1122,7 +1120,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass3_tile(TileArgs a)
     for (int o = threadIdx.x; o < T.nown; o += blockDim.x) {
       const int i = T.own_start + o;
       OWN_PROLOGUE
-      const double xi = sp[3 * slot], yi = sp[3 * slot + 1], zi = sp[3 * slot + 2], wi = sw[slot];
+      const double xi = sp[slot], yi = sp[a.slot_cap + slot], zi = sp[2 * a.slot_cap + slot], wi = sw[slot];
       const int it = NT1 ? 0 : ts[slot];
       double fx = 0, fy = 0, fz = 0, vir = 0, r2min = 1e300;
       // list words: PFD groups of four slots in flight (only ~3 waves/SIMD are resident, so the HBM stream
@@ -1133,8 +1131,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass3_tile(TileArgs a)
         double dx[UNR], dy[UNR], dz[UNR], wj[UNR], r2[UNR];
 #pragma unroll
         for (int e = 0; e < UNR; e++) {
-          const double *pj = sp + 3 * j[e];
-          dx[e] = pj[0]; dy[e] = pj[1]; dz[e] = pj[2]; wj[e] = sw[j[e]];
+          dx[e] = sp[j[e]]; dy[e] = sp[a.slot_cap + j[e]]; dz[e] = sp[2 * a.slot_cap + j[e]]; wj[e] = sw[j[e]];
         }
         SCHED_BARRIER;
 #pragma unroll
