@@ -19,6 +19,14 @@
  * this is integration level 1 (forces only).  Level 2, the device-resident loop
  * imdgpu_md_step, needs no IMD code at all.
  *
+ * Builds WITHOUT -DNBL (cell-pair force loop: calc_forces of imd_main_risc_3d.c:31 calling do_forces,
+ * imd_forces.c:33, do_embedding_energy and do_forces_eam2, imd_forces_eam2.c:202,239) are served by the
+ * second half of this file: the same device kernels with a zero list margin, i.e. every call re-bins and
+ * finds all pairs with r2 < cellsz exactly like the loop over cell pairs does.  There the host's cell array
+ * has no buffer layer (periodic images come from the pair list's shift vectors), so the shim presents the
+ * cells to the library with one added.  Compile imd_main_risc_3d.c with -Dcalc_forces=calc_forces_host
+ * (or guard that definition) so that this calc_forces is the one that links.
+ *
  * Single rank (cpu_dim 1 1 1); an MPI build calls the imdgpu_halo_* operations
  * from its own send_cells/send_forces replacements.
  */
@@ -46,14 +54,25 @@ static void gpu_init(void)
   box[3] = box_y.x; box[4] = box_y.y; box[5] = box_y.z;
   box[6] = box_z.x; box[7] = box_z.y; box[8] = box_z.z;
   pbc[0] = pbc_dirs.x; pbc[1] = pbc_dirs.y; pbc[2] = pbc_dirs.z;
+#ifdef NBL
   cd[0] = cell_dim.x; cd[1] = cell_dim.y; cd[2] = cell_dim.z;
+#else
+  cd[0] = cell_dim.x + 2; cd[1] = cell_dim.y + 2; cd[2] = cell_dim.z + 2;      /* library cells carry a ghost layer */
+#endif
   gd[0] = global_cell_dim.x; gd[1] = global_cell_dim.y; gd[2] = global_cell_dim.z;
   gpu_check(imdgpu_set_geometry(G, box, pbc, cd, gd, cpu, me));
-#ifdef TTM
-  gpu_check(imdgpu_set_params(G, ntypes, cellsz, nbl_margin, timestep, 1));
+  {
+#ifdef NBL
+    double margin = nbl_margin;
 #else
-  gpu_check(imdgpu_set_params(G, ntypes, cellsz, nbl_margin, timestep, 0));
+    double margin = 0.0;
 #endif
+#ifdef TTM
+    gpu_check(imdgpu_set_params(G, ntypes, cellsz, margin, timestep, 1));
+#else
+    gpu_check(imdgpu_set_params(G, ntypes, cellsz, margin, timestep, 0));
+#endif
+  }
   {
     /* pot_table_t and imdgpu_pot_table have the same members in the same order (types.h:537-549) */
     const imdgpu_pot_table *pp = NULL, *pr = NULL, *pe = NULL;
@@ -67,6 +86,19 @@ static void gpu_init(void)
     gpu_check(imdgpu_upload_tables(G, pp, pr, pe));
   }
 }
+
+#ifdef NBL
+#define SHIM_NALL nallcells
+#define SHIM_CELLIDX(p) ((int) ((p) - cell_array))
+#else
+#define SHIM_NALL ((cell_dim.x + 2) * (cell_dim.y + 2) * (cell_dim.z + 2))
+static int shim_padded_index(int k)       /* host cell k = (i*dim.y + j)*dim.z + l  ->  (i+1, j+1, l+1) in the padded array */
+{
+  int l = k % cell_dim.z, r = k / cell_dim.z, j = r % cell_dim.y, i = r / cell_dim.y;
+  return ((i + 1) * (cell_dim.y + 2) + (j + 1)) * (cell_dim.z + 2) + (l + 1);
+}
+#define SHIM_CELLIDX(p) shim_padded_index((int) ((p) - cell_array))
+#endif
 
 static int count_atoms(void)
 {
@@ -85,7 +117,7 @@ static void ensure_host(int n)
   g_rho = (double *) realloc(g_rho, g_cap * sizeof(double)); g_dF = (double *) realloc(g_dF, g_cap * sizeof(double));
   g_sorte = (int *) realloc(g_sorte, g_cap * sizeof(int)); g_num = (int *) realloc(g_num, g_cap * sizeof(int));
   g_nn = (int *) realloc(g_nn, g_cap * sizeof(int));
-  g_cn = (int *) realloc(g_cn, nallcells * sizeof(int));
+  g_cn = (int *) realloc(g_cn, SHIM_NALL * sizeof(int));
   if (!g_ort || !g_imp || !g_kraft || !g_mas || !g_epot || !g_rho || !g_dF || !g_sorte || !g_num || !g_nn || !g_cn)
     error("imd_shim: cannot allocate staging arrays");
 }
@@ -94,10 +126,10 @@ static void ensure_host(int n)
 static int gather_cells(int with_all)
 {
   int k, i, n = 0;
-  for (k = 0; k < nallcells; k++) g_cn[k] = 0;
+  for (k = 0; k < SHIM_NALL; k++) g_cn[k] = 0;
   for (k = 0; k < NCELLS; k++) {
     cell *p = CELLPTR(k);
-    g_cn[p - cell_array] = p->n;
+    g_cn[SHIM_CELLIDX(p)] = p->n;
     for (i = 0; i < p->n; i++, n++) {
       g_ort[3 * n] = ORT(p, i, X); g_ort[3 * n + 1] = ORT(p, i, Y); g_ort[3 * n + 2] = ORT(p, i, Z);
       if (with_all) {
@@ -109,6 +141,7 @@ static int gather_cells(int with_all)
   return n;
 }
 
+#ifdef NBL
 void make_nblist(void)
 {
   int n = count_atoms(), k, i;
@@ -166,11 +199,14 @@ void check_nblist(void)
   if (max1 > SQR(0.5 * nbl_margin)) have_valid_nbl = 0;
 }
 
+#endif /* NBL */
+
 void calc_forces(int steps)
 {
   double sums[8];
   int n, k, i, m = 0, is_short = 0;
   gpu_init();
+#ifdef NBL
   if (0 == have_valid_nbl) {
     fix_cells();                                  /* the host's own re-binning, imd_forces_nbl.c:300-308 */
     make_nblist();
@@ -180,6 +216,15 @@ void calc_forces(int steps)
     gather_cells(0);
     gpu_check(imdgpu_update_positions(G, n, g_ort));
   }
+#else
+  /* cell-pair variant: the main loop has re-binned (fix_cells, imd_main_3d.c:815); all pairs of this arrangement */
+  n = count_atoms();
+  ensure_host(n);
+  gather_cells(1);
+  gpu_check(imdgpu_upload_cells(G, g_cn, n, g_ort, g_imp, g_mas, g_sorte, g_num));
+  gpu_check(imdgpu_make_nblist(G));
+  g_have_cells = 1;
+#endif
   n = count_atoms();
   gpu_check(imdgpu_calc_forces(G, steps, sums, &is_short));
   gpu_check(imdgpu_download_atoms(G, NULL, NULL, NULL, g_kraft, g_epot, g_rho, g_dF, g_nn, NULL, NULL, NULL));

@@ -106,3 +106,28 @@ build_dropin() {
   echo "built $OUT/imd_$name"
 }
 case " $TARGETS " in *" dropin "*) build_dropin ;; esac
+
+# The same for the cell-pair force loop (no -DNBL): calc_forces of imd_main_risc_3d.c is renamed at compile time
+# (-Dcalc_forces=calc_forces_host, no source change) so that the shim's calc_forces links; do_forces,
+# do_forces_eam2 and do_embedding_energy (imd_forces.c, imd_forces_eam2.c) stay linked only because the renamed,
+# never-called host loop references them.
+build_dropin_cellpair() {
+  local name="eam_nve_gpu" defs="-DEAM2 -DNVE"
+  local obj="$OUT/obj_$name" repo="$(cd "$HERE/.." && pwd)"
+  [ -f "$repo/imd_amd/csrc/libimdgpu.so" ] || { echo "libimdgpu.so not built, skipping drop-in" >&2; return 0; }
+  mkdir -p "$obj"
+  local objs=""
+  for s in $COMMON imd_forces.c imd_forces_eam2.c; do
+    local o="$obj/${s%.c}.o"
+    if [ ! -f "$o" ] || [ "$REF/$s" -nt "$o" ]; then $CC $BASEFLAGS $defs -c "$REF/$s" -o "$o" & fi
+    objs="$objs $o"
+  done
+  $CC $BASEFLAGS $defs -Dcalc_forces=calc_forces_host -c "$REF/imd_main_risc_3d.c" -o "$obj/imd_main_risc_3d.o" &
+  wait
+  $CC $BASEFLAGS $defs -I"$repo/include" -c "$repo/imd_amd/host/imd_shim.c" -o "$obj/imd_shim.o"
+  $CC $BASEFLAGS $defs -c "$HERE/ref_probe.c" -o "$obj/ref_probe.o"
+  $CC -o "$OUT/imd_$name" $objs "$obj/imd_main_risc_3d.o" "$obj/imd_shim.o" "$obj/ref_probe.o" -Wl,--wrap=calc_forces \
+      "$REF/nn_interpol/libnn.a" -L"$repo/imd_amd/csrc" -limdgpu -Wl,-rpath,/root/repo/imd_amd/csrc -lm
+  echo "built $OUT/imd_$name"
+}
+case " $TARGETS " in *" dropin "*) build_dropin_cellpair ;; esac

@@ -16,6 +16,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CPU = os.path.join(ROOT, "oracle", "_ref", "imd_eam_nve_nbl")
 GPU = os.path.join(ROOT, "oracle", "_ref", "imd_eam_nve_nbl_gpu")
+CPU_CP = os.path.join(ROOT, "oracle", "_ref", "imd_eam_nve")           # cell-pair force loop (no -DNBL)
+GPU_CP = os.path.join(ROOT, "oracle", "_ref", "imd_eam_nve_gpu")
 
 PARAM = """coordname _fcc
 outfiles out
@@ -81,3 +83,32 @@ def _inner_ids(P):
 def _inner_pos(P):
     start = np.concatenate([[0], np.cumsum(P["cell_n"])])
     return np.concatenate([P["all_ort"][start[c]:start[c + 1]] for c in P["cells"]])
+
+
+@pytest.mark.skipif(not (os.path.exists(CPU_CP) and os.path.exists(GPU_CP)), reason="oracle/_ref binaries not built")
+def test_reference_cellpair_main_loop_on_gpu_forces():
+    """builds without -DNBL enter through calc_forces -> do_forces / do_forces_eam2
+    (imd_main_risc_3d.c:31, imd_forces.c:33, imd_forces_eam2.c:239).  Same program, shim instead of that loop."""
+    param = "\n".join(l for l in PARAM.splitlines() if not l.startswith("nbl_")) + "\n"
+    out = {}
+    for tag, exe in (("cpu", CPU_CP), ("gpu", GPU_CP)):
+        with tempfile.TemporaryDirectory() as d:
+            potential.write_synthetic_eam_files(d)
+            open(os.path.join(d, "t.param"), "w").write(param)
+            env = dict(os.environ, IMD_PROBE_DIR=d, IMD_PROBE_STEPS="0,1,30")
+            r = subprocess.run([exe, "-p", "t.param"], cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                               text=True, timeout=300)
+            assert r.returncode == 0, r.stdout[-2000:]
+            out[tag] = {s: po.read_probe(os.path.join(d, "probe.0.%d.bin" % s)) for s in (0, 1, 30)}
+            out[tag]["eng"] = np.loadtxt(os.path.join(d, "out.eng"))
+    for s in (0, 1, 30):
+        a, b = out["gpu"][s], out["cpu"][s]
+        oa, ob = np.argsort(_inner_ids(a)), np.argsort(_inner_ids(b))
+        fa, fb = a["kraft"][oa], b["kraft"][ob]
+        assert np.abs(fa - fb).max() < 1e-9 * max(np.abs(fb).max(), 1e-3), "forces differ at step %d" % s
+        assert np.abs(a["pot_eng"][oa] - b["pot_eng"][ob]).max() < 1e-10
+        assert np.abs(a["eam_rho"][oa] - b["eam_rho"][ob]).max() < 1e-10
+        assert abs(a["tot_pot_energy"] - b["tot_pot_energy"]) < 1e-9 * abs(b["tot_pot_energy"])
+        assert abs(a["virial"] - b["virial"]) < 1e-9 * abs(b["virial"])
+        assert np.abs(_inner_pos(a)[oa] - _inner_pos(b)[ob]).max() < 1e-9
+    assert np.allclose(out["gpu"]["eng"], out["cpu"]["eng"], rtol=1e-6, atol=1e-9)

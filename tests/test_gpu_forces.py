@@ -18,12 +18,17 @@ FTOL = 1e-9
 def _gpu_from_golden(G, step, nbl=True, ttm=False):
     pre = "s%d_" % step
     dim = G["cell_dim"] if nbl else G["cell_dim"] + 2
-    s = GpuSystem(G["box"], G["pbc_dirs"], dim, int(G["ntypes"]), float(G["cellsz"]) if nbl else
-                  float(G["cellsz"]), float(G["nbl_margin"]), float(G["timestep"]), count_ttm_neighbours=ttm)
+    s = GpuSystem(G["box"], G["pbc_dirs"], dim, int(G["ntypes"]), float(G["cellsz"]),
+                  float(G["nbl_margin"]) if nbl else 0.0, float(G["timestep"]), count_ttm_neighbours=ttm)
     s.upload_tables(gu.table(G, "pair_pot"), gu.table(G, "rho_h_tab"), gu.table(G, "embed_pot"))
     cell_n = np.zeros(int(np.prod(dim)), np.int32)
     if nbl:
         cell_n[G["cells"]] = G[pre + "cell_n"][G["cells"]]
+    else:                            # cell-pair build: no ghost layer in the reference's cell array, embed it
+        d0 = G["cell_dim"]
+        i, j, k = np.meshgrid(np.arange(d0[0]), np.arange(d0[1]), np.arange(d0[2]), indexing="ij")
+        padded = ((i + 1) * dim[1] + (j + 1)) * dim[2] + (k + 1)
+        cell_n[padded.ravel()] = G[pre + "cell_n"][: padded.size]
     s.upload_cells(cell_n, G[pre + "ort"], G[pre + "impuls"], G[pre + "masse"], G[pre + "sorte"].astype(np.int32),
                    G[pre + "nummer"])
     return s
@@ -50,6 +55,25 @@ def test_forces_vs_reference_golden(case, step, eam):
     assert abs(r["tot_pot_energy"] - float(G[pre + "tot_pot_energy"])) < 1e-11 * abs(float(G[pre + "tot_pot_energy"]))
     assert abs(r["virial"] - float(G[pre + "virial"])) < 1e-10 * abs(float(G[pre + "virial"]))
     assert r["is_short"] == 0
+    s.close()
+
+
+@pytest.mark.parametrize("step", [0, 10])
+def test_cellpair_entry_vs_reference_golden(step):
+    """the reference built WITHOUT -DNBL (calc_forces -> do_forces / do_embedding_energy /
+    do_forces_eam2 over the cell-pair list, imd_main_risc_3d.c:31-182, imd_forces.c:33, imd_forces_eam2.c:202,239).
+    Device equivalent: zero list margin, i.e. all pairs with r2 < cellsz of the current arrangement."""
+    G = gu.load("eam_cellpair_2048")
+    s = _gpu_from_golden(G, step, nbl=False)
+    r = s.calc_forces(step)
+    d = s.download()
+    pre = "s%d_" % step
+    assert np.array_equal(d["nummer"], G[pre + "nummer"])
+    assert _relmax(d["kraft"], G[pre + "kraft"], floor=1e-3) < FTOL
+    assert _relmax(d["pot_eng"], G[pre + "pot_eng"]) < 1e-11
+    assert _relmax(d["eam_rho"], G[pre + "eam_rho"]) < 1e-11
+    assert abs(r["tot_pot_energy"] - float(G[pre + "tot_pot_energy"])) < 1e-11 * abs(float(G[pre + "tot_pot_energy"]))
+    assert abs(r["virial"] - float(G[pre + "virial"])) < 1e-10 * abs(float(G[pre + "virial"]))
     s.close()
 
 
