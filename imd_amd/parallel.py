@@ -293,13 +293,21 @@ class DistributedMD:
             self.plan.exchange(ops, 0)
         ops.forces_phase(1)
         if self.ttm:
+            # calc_ttm needs pass 1's neighbour counts and feeds only the integrator: it runs on a side stream
+            # (block of update_fd -> all-gather -> fold in -> diffusion sub-steps) beside the embedding pass, the
+            # dF halo and the EAM force pass, exactly like the single-rank fork in imdgpu_md_step
+            ops.ttm_fork()
             blk = ops.ttm_local_block(step)
             allb = all_gather_flat(blk, self.world)
             ops.ttm_apply_blocks(step, allb, self.world, self._ttm_offs)
             ops.ttm_lattice_step(step)
+            self._ttm_keep = (blk, allb)                 # buffers stay referenced until the join
+            ops.ttm_unfork()
         ops.forces_phase(2)
         self.plan.exchange(ops, 1)                       # dF of the ghost atoms  [send_cells(copy_dF)]
         ops.forces_phase(3)
+        if self.ttm:
+            ops.ttm_join()
         ops.integrate()
         flag = torch.tensor([ops.get_invalid()], dtype=torch.int32, device=ops.device)
         if self.world > 1:
@@ -400,6 +408,22 @@ class GpuOps:
     # TTM (replicated lattice)
     def ttm_block_dims(self):
         return tuple((self.s.cell_dim[d] - 2) // self.s.fd_ext[d] for d in range(3))
+
+    # the TTM lattice chain on its own (high priority) stream: library kernels and the all-gather follow torch's
+    # current stream, so fork = side waits for main and becomes current; unfork = back to main; join = main waits
+    def ttm_fork(self):
+        if not hasattr(self, "side"):
+            self.side = torch.cuda.Stream(self.device, priority=-1)
+        self.side.wait_stream(self.stream)
+        torch.cuda.set_stream(self.side)
+        self.s.set_stream(self.side.cuda_stream)
+
+    def ttm_unfork(self):
+        torch.cuda.set_stream(self.stream)
+        self.s.set_stream(self.stream.cuda_stream)
+
+    def ttm_join(self):
+        self.stream.wait_stream(self.side)
 
     def ttm_local_block(self, step):
         C = self.C
