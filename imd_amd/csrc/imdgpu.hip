@@ -567,8 +567,8 @@ __device__ __forceinline__ void block_tile_range(int ntiles, int &t0, int &t1)
   if (t1 > ntiles) t1 = ntiles;
 }
 
-// halo-cell table + prefix (hstart/hsrc) and staging of positions into LDS as AoS records of NC doubles
-// (NC = 3: x,y,z; NC = 4: x,y,z,dF).  The last slot (slot_cap-1) is a far-away dummy that pads the
+// halo-cell table + prefix (hstart/hsrc) and staging of positions into LDS as x, y, z planes of slot_cap
+// doubles (NC = 4: + dF plane sw).  Used by the list build; the force passes stage from the plan it writes.  The last slot (slot_cap-1) is a far-away dummy that pads the
 // neighbour list, so the inner loops need no "valid entry" test.  All threads of the block call it.
 template <int NC, bool WITH_T>
 __device__ __forceinline__ void tile_stage(const TileArgs &a, TileCtx &T, double *sp, int *ts, int *hstart, int *hsrc,
@@ -589,8 +589,7 @@ __device__ __forceinline__ void tile_stage(const TileArgs &a, TileCtx &T, double
     hstart[h + 1] = cnt; hsrc[h] = src;
   }
   if (tid == 0) {
-    double *d = sp + (size_t) (a.slot_cap - 1) * 3;
-    d[0] = 1e150; d[1] = 1e150; d[2] = 1e150;
+    sp[a.slot_cap - 1] = 1e150; sp[2 * a.slot_cap - 1] = 1e150; sp[3 * a.slot_cap - 1] = 1e150;
     if (NC == 4) sw[a.slot_cap - 1] = 0.0;
     if (WITH_T) ts[a.slot_cap - 1] = 0;
   }
@@ -623,8 +622,7 @@ __device__ __forceinline__ void tile_stage(const TileArgs &a, TileCtx &T, double
 #pragma unroll
     for (int u = 0; u < 4; u++)
       if (sl[u] >= 0) {
-        double *d = sp + (size_t) sl[u] * 3;
-        d[0] = p[u].x; d[1] = p[u].y; d[2] = p[u].z;
+        sp[sl[u]] = p[u].x; sp[a.slot_cap + sl[u]] = p[u].y; sp[2 * a.slot_cap + sl[u]] = p[u].z;
         if (NC == 4) sw[sl[u]] = p[u].w;
         if (WITH_T) ts[sl[u]] = tt[u];
       }
@@ -634,8 +632,7 @@ __device__ __forceinline__ void tile_stage(const TileArgs &a, TileCtx &T, double
     for (int e = l + 32; e < n; e += 32)
       if (s + e < a.slot_cap - 1) {
         double4 q = a.pos[src + e];
-        double *d = sp + (size_t) (s + e) * 3;
-        d[0] = q.x; d[1] = q.y; d[2] = q.z;
+        sp[s + e] = q.x; sp[a.slot_cap + s + e] = q.y; sp[2 * a.slot_cap + s + e] = q.z;
         if (NC == 4) sw[s + e] = q.w;
         if (WITH_T) ts[s + e] = a.type[src + e];
       }
@@ -751,31 +748,46 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile(TileArgs a)
     const int i = T.own_start + o;
     int lx, ly, lz;
     const int slot = own_slot(a, T, i, hstart, hsrc, lx, ly, lz);
-    const double xi = sp[3 * slot], yi = sp[3 * slot + 1], zi = sp[3 * slot + 2];
+    const double *sx = sp, *sy = sp + a.slot_cap, *sz = sp + 2 * a.slot_cap;
+    const double xi = sx[slot], yi = sy[slot], zi = sz[slot];
     a.ref[i] = xi; a.ref[a.cap + i] = yi; a.ref[2 * (size_t) a.cap + i] = zi;
-    ushort4 *lp = a.nbr16 + (size_t) T.tile * a.W4 * a.tile_cap + o;
-    unsigned short buf[4] = {dummy, dummy, dummy, dummy};
+    unsigned long long *lp = (unsigned long long *) (a.nbr16 + (size_t) T.tile * a.W4 * a.tile_cap + o);
+    // four 16-bit slots per list word, filled through a shift register (first entry ends up in the low bits;
+    // a partial last word keeps dummies in its low slots)
+    const unsigned long long dummy64 = (unsigned long long) dummy * 0x0001000100010001ull;
+    unsigned long long w = dummy64;
     int m = 0;
     for (int dx = 0; dx <= 2; dx++)
       for (int dy = 0; dy <= 2; dy++)
         for (int dz = 0; dz <= 2; dz++) {
-          int h = ((lx + dx) * T.hy + (ly + dy)) * T.hz + (lz + dz);
-          int s = hstart[h], e = hstart[h + 1];
-          for (int j = s; j < e; j++) {
-            if (j == slot) continue;
-            double ex = sp[3 * j] - xi, ey = sp[3 * j + 1] - yi, ez = sp[3 * j + 2] - zi;
-            double r2 = ex * ex + ey * ey + ez * ez;
-            if (r2 < a.cellsz) {
-              buf[m & 3] = (unsigned short) j;
-              m++;
-              if ((m & 3) == 0) {
-                if ((m >> 2) <= a.W4) lp[(size_t) ((m >> 2) - 1) * a.tile_cap] = make_ushort4(buf[0], buf[1], buf[2], buf[3]);
-                buf[0] = buf[1] = buf[2] = buf[3] = dummy;
+          const int h = ((lx + dx) * T.hy + (ly + dy)) * T.hz + (lz + dz);
+          const int s = hstart[h], e = hstart[h + 1];
+          for (int j0 = s; j0 < e; j0 += 4) {                 // four candidates in flight
+            double r2[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const int j = j0 + u < e ? j0 + u : e - 1;
+              const double ex = sx[j] - xi, ey = sy[j] - yi, ez = sz[j] - zi;
+              r2[u] = ex * ex + ey * ey + ez * ez;            // unfused, as the reference (imd_forces_nbl.c:218-222)
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const int j = j0 + u;
+              if (j < e && j != slot && r2[u] < a.cellsz) {
+                w = (w >> 16) | ((unsigned long long) j << 48);
+                m++;
+                if ((m & 3) == 0) {
+                  if ((m >> 2) <= a.W4) lp[(size_t) ((m >> 2) - 1) * a.tile_cap] = w;
+                  w = dummy64;
+                }
               }
             }
           }
         }
-    if ((m & 3) != 0 && (m >> 2) < a.W4) lp[(size_t) (m >> 2) * a.tile_cap] = make_ushort4(buf[0], buf[1], buf[2], buf[3]);
+    if ((m & 3) != 0 && (m >> 2) < a.W4) {
+      for (int q = m & 3; q < 4; q++) w = (w >> 16) | ((unsigned long long) dummy << 48);   // entries to the low slots
+      lp[(size_t) (m >> 2) * a.tile_cap] = w;
+    }
     a.nbr_cnt[i] = m < 4 * a.W4 ? m : 4 * a.W4;
     a.ownw[(size_t) T.tile * a.tile_cap + o] = (unsigned) slot | ((unsigned) (m < 4 * a.W4 ? m : 4 * a.W4) << 16);
     mmax = m > mmax ? m : mmax;
@@ -1975,7 +1987,9 @@ extern "C" int imdgpu_make_nblist(imdgpu_ctx *ctx)
       size_t lds = tile_lds_bytes(ctx, 0);
       HIPCHK(hipFuncSetAttribute((const void *) k_nbl_build_tile, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
       ProfScope ps(ctx, PROF_NBLIST);
-      hipLaunchKernelGGL(k_nbl_build_tile, dim3(tile_grid(ctx)), dim3(ctx->tile_threads), lds, ctx->stream, a);
+      // the build needs only the position planes (about half the LDS of a force pass): two workgroups per CU
+      const int bgrid = 2 * lds <= LDS_LIMIT ? std::min(ctx->ntiles, 2 * tile_grid(ctx)) : tile_grid(ctx);
+      hipLaunchKernelGGL(k_nbl_build_tile, dim3(bgrid), dim3(ctx->tile_threads), lds, ctx->stream, a);
     } else {
       if (ctx->nbr_cap < (size_t) ctx->W * stride) {
         if (dev_alloc(ctx, &ctx->nbr, (size_t) ctx->W * stride)) return 1;
