@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=30)
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal: host-staged halos)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks on cuda:0")
+    ap.add_argument("--force-distributed", action="store_true",
+                    help="rehearsal: run the multi-rank host layer (halo plan, gather/scatter, fork/join) on one rank")
     return ap.parse_args()
 
 
@@ -65,7 +67,8 @@ def build_system(args, rank, world, device):
     gdim = global_cell_dim(box, cellsz, cd)
     cell_dim = tuple(gdim[d] // cpu_dim[d] + 2 for d in range(3))
     sysm = GpuSystem(box, (1, 1, 1), cell_dim, 1, cellsz, nbl_margin, 0.1, device=device, global_cell_dim=gdim,
-                     cpu_dim=cpu_dim, my_coord=coord, count_ttm_neighbours=ttm)
+                     cpu_dim=cpu_dim, my_coord=coord, count_ttm_neighbours=ttm,
+                     external_halo=args.force_distributed)
     sysm.upload_tables(pair, rho, emb)
     if ttm:
         from imd_amd import ttm as ttm_mod
@@ -75,7 +78,7 @@ def build_system(args, rank, world, device):
     ident = np.arange(len(pos), dtype=np.int64) + rank * len(pos)
     sysm.upload_atoms(pos, mom, 26.9815, None, (ident % (2 ** 31 - 1)).astype(np.int32))
     md = None
-    if world > 1:
+    if world > 1 or args.force_distributed:
         from imd_amd.parallel import Decomposition, DistributedMD, GpuOps
         dec = Decomposition(rank, cpu_dim, gdim, box, (1, 1, 1))
         md = DistributedMD(dec, GpuOps(sysm, device), ttm=ttm)

@@ -1373,6 +1373,11 @@ extern "C" int imdgpu_set_option(imdgpu_ctx *ctx, const char *name, int value)
     ctx->tile[name[5] - 'x'] = value; ctx->autotiled = 1;
     return ctx->have_geometry ? setup_tiles(ctx) : 0;
   }
+  if (!strcmp(name, "external_halo")) {          // before set_geometry: the host layer owns the ghost cells even on one rank
+    if (ctx->have_geometry) return imdgpu_fail(ctx, "external_halo must be set before set_geometry");
+    ctx->force_external_halo = value ? 1 : 0;
+    return 0;
+  }
   return imdgpu_fail(ctx, "unknown option %s", name);
 }
 
@@ -1536,7 +1541,7 @@ extern "C" int imdgpu_set_geometry(imdgpu_ctx *ctx, const double box[9], const i
       return imdgpu_fail(ctx, "periodic direction %d needs >= 3 cells (has %d)", d, gdim[d]);
   }
   const int *D = ctx->dim;
-  ctx->external_halo = (cpu_dim[0] * cpu_dim[1] * cpu_dim[2] > 1) ? 1 : 0;
+  ctx->external_halo = (cpu_dim[0] * cpu_dim[1] * cpu_dim[2] > 1 || ctx->force_external_halo) ? 1 : 0;
   ctx->nall_cells = D[0] * D[1] * D[2];
   ctx->ninner_cells = (D[0] - 2) * (D[1] - 2) * (D[2] - 2);
   ctx->nghost_cells = ctx->nall_cells - ctx->ninner_cells;
@@ -2096,6 +2101,9 @@ static int launch_forces(imdgpu_ctx *ctx, int phase = 0)
 #undef L1
   }
   imdgpu_tl_mark(ctx, "pass1");
+  // fork point of the TTM lattice chain.  Forking later (after the embedding pass) was tried: update_fd then starts
+  // under the EAM force pass, whose waves leave it one SIMD per CU, takes 1.5 ms instead of 0.4 and the chain
+  // outlasts the pass; beside the short, register-light embedding pass it runs at streaming speed.
   if ((phase == 0 || phase == 1) && ctx->after_pass1) { if (ctx->after_pass1(ctx, ctx->after_pass1_arg)) return 1; }
   const int nb2 = EAM ? nblk(n, 256) : 0;
   if (EAM && (phase == 0 || phase == 2)) {

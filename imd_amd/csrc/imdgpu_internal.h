@@ -87,6 +87,7 @@ struct imdgpu_ctx {
   // neighbour list, full (symmetric).  mode 0: ELL transposed int32 global indices
   // nbr[k*stride+i]; mode 1: per tile, uint16 LDS-slot indices tl16[(tile*W+k)*tile_cap+a]
   int mode = 1, list_mode = 0, autotiled = 0;
+  int force_external_halo = 0;
   int external_halo = 0;          // ghost atoms are supplied through imdgpu_halo_scatter (multi-rank decomposition)
   int *mig_idx[2]{nullptr, nullptr}; int mig_n[2]{0, 0}, mig_cap = 0; int *mig_flag = nullptr;
   int *nbr = nullptr, *nbr_cnt = nullptr;
