@@ -182,6 +182,60 @@ __device__ double eos_lookup(const EosDev &e, double x, double y)
 }
 __device__ double eos_ee(const EosDev &e, double r, double tK) { return eos_lookup(e, r, sqrt(tK)); }
 
+// EOS_te_from_r_ee (imd_ttm_3D.c:2786-2811): T_e [K] from density and internal energy: minimise |ee(r,T) - e| over
+// the temperature range of the ee(r, sqrt T) table with Brent's bracketing minimiser as the reference configures
+// it (fminbnd3.c:6-107: x tolerance 1e-5 whatever is passed, eps weight, 500 iterations, golden first probe, and
+// the sign its unparenthesised SIGNUM macro gives the parabolic numerator: +sign(q), makros.h:338).
+__device__ __forceinline__ double d_sgn(double v) { return (double) ((v > 0) - (v < 0)); }
+__device__ double d_te_from_r_ee(const EosDev &ee, double r, double e)
+{
+  const double tolx = 1e-5, eps = 2.220446049250313e-16, gold = 0.5 * (3.0 - sqrt(5.0));
+  double lo = ee.ymin * ee.ymin, hi = ee.ymax * ee.ymax;
+  double x = lo + gold * (hi - lo), w = x, v = x;
+  double fx = fabs(eos_ee(ee, r, x) - e), fw = fx, fv = fx;
+  double step = 0.0, prev = 0.0;
+  for (int it = 0; it <= 500; it++) {
+    const double mid = 0.5 * (lo + hi), tol = 2.0 * eps * fabs(x) + tolx / 3.0;
+    if (fabs(x - mid) <= 2.0 * tol - 0.5 * (hi - lo) || it == 500) return x;
+    bool golden = true;
+    double u;
+    if (fabs(prev) > tol) {
+      double rr = (x - w) * (fx - fv), q = (x - v) * (fx - fw), p = (x - v) * q - (x - w) * rr;
+      q = 2.0 * (q - rr);
+      p *= d_sgn(q);
+      q = fabs(q);
+      rr = prev;
+      prev = step;
+      if (fabs(p) < fabs(0.5 * q * rr) && p > q * (lo - x) && p < q * (hi - x)) {
+        step = p / q;
+        u = x + step;
+        if (fmin(u - lo, hi - u) < 2.0 * tol) step = tol * (d_sgn(mid - x) + (mid == x ? 1.0 : 0.0));
+        golden = false;
+      }
+    }
+    if (golden) {
+      prev = (x >= mid) ? lo - x : hi - x;
+      step = gold * prev;
+    }
+    u = x + fmax(fabs(step), tol) * (d_sgn(step) + (step == 0 ? 1.0 : 0.0));
+    const double fu = fabs(eos_ee(ee, r, u) - e);
+    if (fu < fx) {
+      if (u < x) hi = x; else lo = x;
+      v = w; fv = fw; w = x; fw = fx; x = u; fx = fu;
+    } else {
+      if (u < x) lo = u; else hi = u;
+      if (fu <= fw || w == x) { v = w; fv = fw; w = u; fw = fu; }
+      else if (fu <= fv || v == x || v == w) { v = u; fv = fu; }
+    }
+  }
+  return -1.0;
+}
+__global__ void k_ttm_te_from_r_ee(int n, EosDev ee, const double *r, const double *e, double *out)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = d_te_from_r_ee(ee, r[i], e[i]);
+}
+
 // do_FILLMESH per cell: MeanCharge (More's Thomas-Fermi fit, imd_ttm_3D.c:2399-2473), getKappa (:2549-2592),
 // getGamma (:2503-2528) and their helpers fermi_E, fermi_T, omega_pl, r0, coulomb_log, numet, numax, nupl
 // (:2352-2498), written as ONE function so that everything the reference recomputes per helper call is shared:
@@ -639,6 +693,22 @@ extern "C" int imdgpu_ttm_apply_blocks(imdgpu_ctx *ctx, int steps, const double 
                      dev_offs, t->ldim[0], t->ldim[1], t->ldim[2], dev_in, t->natoms, t->natoms_old, t->temp[0], t->temp[1],
                      t->xi, t->md_temp, t->source, t->vcom, t->dens, t->ncell);
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// EOS entry points on host arrays (EOS_ee_from_r_te is part of FILLMESH/activation; the inverse is used by do_ADV)
+extern "C" int imdgpu_ttm_eos_te_from_r_ee(imdgpu_ctx *ctx, int n, const double *r, const double *e, double *te_out)
+{
+  NEED_TTM();
+  if (n <= 0) return 0;
+  double *d = nullptr;
+  HIPCHK(hipMalloc((void **) &d, (size_t) 3 * n * sizeof(double)));
+  HIPCHK(hipMemcpy(d, r, n * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d + n, e, n * sizeof(double), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_ttm_te_from_r_ee, dim3(nblk(n, TTM_WG)), dim3(TTM_WG), 0, ctx->stream, n, t->ee, d, d + n, d + 2 * (size_t) n);
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpy(te_out, d + 2 * (size_t) n, n * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipFree(d));
   return 0;
 }
 

@@ -254,6 +254,13 @@ class GpuSystem:
             setattr(F, n, _ip(a) if n.startswith("natoms") else _dp(a))
         self._ck(self.L.imdgpu_ttm_upload(self.h, C.byref(F)))
 
+    def EOS_te_from_r_ee(self, r, e):
+        """imd_ttm_3D.c:2786: vectorised over host arrays, K."""
+        r = np.ascontiguousarray(r, dtype=np.float64); e = np.ascontiguousarray(e, dtype=np.float64)
+        out = np.zeros_like(r)
+        self._ck(self.L.imdgpu_ttm_eos_te_from_r_ee(self.h, int(r.size), _dp(r), _dp(e), _dp(out)))
+        return out
+
     def update_fd(self, steps=0):
         self._ck(self.L.imdgpu_ttm_update_fd(self.h, int(steps)))
 

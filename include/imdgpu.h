@@ -172,6 +172,9 @@ int imdgpu_ttm_fillmesh(imdgpu_ctx *ctx, int steps);
 int imdgpu_ttm_fill_ghost_layers(imdgpu_ctx *ctx);
 /* [do_DIFF(tau), :1603-1829] */
 int imdgpu_ttm_diff(imdgpu_ctx *ctx, double tau);
+/* [EOS_te_from_r_ee, :2786-2811 + fminbnd3.c:6-107] electron temperature in K from density (kg/m^3) and internal
+ * energy (table units) for n points on host arrays: the reference's Brent minimisation over the ee(r, sqrt T) table */
+int imdgpu_ttm_eos_te_from_r_ee(imdgpu_ctx *ctx, int n, const double *r, const double *e, double *te_out);
 /* [CFL_maxdt, :2637-2691] */
 int imdgpu_ttm_cfl_maxdt(imdgpu_ctx *ctx, int steps, double *max_dt_ttm);
 /* [calc_ttm, first block :50-77 without do_tmm/do_ADV]: update_fd, cell

@@ -63,9 +63,34 @@ static void dump_lattice(const char *tag)
       }
 }
 
+/* IMD_PROBE_EOSINV=1: at step 0 evaluate the reference's own EOS_ee_from_r_te and EOS_te_from_r_ee (Brent minimiser,
+ * imd_ttm_3D.c:2694-2811, fminbnd3.c) on a fixed set of (density, temperature) points and dump inputs and results */
+static void dump_eos_inverse(void)
+{
+  static const double rs[] = {1200.0, 1900.0, 2350.0, 2699.0, 2950.0, 3300.0};
+  static const double ts[] = {310.0, 555.5, 1000.0, 2345.0, 7000.0, 15000.0, 42000.0};
+  static const double fe[] = {1.0, 0.97, 1.0004};         /* on the curve and slightly off it */
+  char fn[1024];
+  const char *dir = getenv("IMD_PROBE_DIR");
+  FILE *f;
+  int a, b, c, n = 0;
+  sprintf(fn, "%s/eosinv.%d.bin", dir ? dir : ".", myid);
+  f = fopen(fn, "wb");
+  fwrite("IMDEOSIN", 1, 8, f);
+  n = 6 * 7 * 3;
+  fwrite(&n, sizeof(int), 1, f);
+  for (a = 0; a < 6; a++) for (b = 0; b < 7; b++) for (c = 0; c < 3; c++) {
+    double r = rs[a], t = ts[b], e = EOS_ee_from_r_te(r, t) * fe[c], tout = EOS_te_from_r_ee(r, e);
+    fwrite(&r, sizeof(double), 1, f); fwrite(&t, sizeof(double), 1, f);
+    fwrite(&e, sizeof(double), 1, f); fwrite(&tout, sizeof(double), 1, f);
+  }
+  fclose(f);
+}
+
 void __wrap_calc_ttm(void)
 {
   int i, dumping = want(steps);
+  if (steps == 0 && getenv("IMD_PROBE_EOSINV")) dump_eos_inverse();
   double tau;
   diff_substeps = fd_n_timesteps;
   tau = timestep / ((double) diff_substeps);

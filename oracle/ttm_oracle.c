@@ -115,6 +115,61 @@ double orc_eos_ee(const orc_ttm *t, double r, double tK)
   return orc_eos_lookup(&t->ee, r, sqrt(tK));
 }
 
+/* EOS_te_from_r_ee (:2786-2806): electron temperature [K] from density and internal energy by minimising
+ * |ee(r, T) - e| over T in [ymin^2, ymax^2] of the ee(r, sqrt T) table with Brent's bracketing minimiser
+ * (golden section + successive parabolic interpolation; the reference uses octave's fminbnd, fminbnd3.c:6-107).
+ * Restated with the reference's constants: x tolerance fixed at 1e-5 (the argument passed, 1e-4, is overwritten,
+ * fminbnd3.c:8), machine-eps weight 2*2.22e-16*|x|, at most 500 iterations, first probe at the golden point,
+ * and one sign quirk of the reference's macro expansion (below). */
+static double sgn(double v) { return (v > 0) - (v < 0); }
+double orc_eos_te_from_r_ee(const orc_ttm *t, double r, double e)
+{
+  const double tolx = 1e-5, eps = 2.220446049250313e-16, gold = 0.5 * (3.0 - sqrt(5.0));
+  double lo = t->ee.ymin * t->ee.ymin, hi = t->ee.ymax * t->ee.ymax;
+  double x = lo + gold * (hi - lo), w = x, v = x;
+  double fx = fabs(orc_eos_ee(t, r, x) - e), fw = fx, fv = fx;
+  double step = 0.0, prev = 0.0;          /* last step and the one before (reference: d, e) */
+  int it;
+  for (it = 0; it <= 500; it++) {
+    const double mid = 0.5 * (lo + hi), tol = 2.0 * eps * fabs(x) + tolx / 3.0;
+    double u, fu;
+    int golden = 1;
+    if (fabs(x - mid) <= 2.0 * tol - 0.5 * (hi - lo) || it == 500) return x;
+    if (fabs(prev) > tol) {                /* try the parabola through (v,fv), (w,fw), (x,fx) */
+      double rr = (x - w) * (fx - fv), q = (x - v) * (fx - fw), p = (x - v) * q - (x - w) * rr;
+      q = 2.0 * (q - rr);
+      /* the reference writes `p*=-SIGNUM(q)` with the unparenthesised macro `(a > 0) ? 1 : ((a < 0) ? -1 : 0)`
+       * (makros.h:338): the unary minus lands on the condition, so the factor is +sign(q), not -sign(q) as in
+       * Brent's algorithm.  The bracket updates keep the method convergent; the iterates are the reference's. */
+      p *= sgn(q);
+      q = fabs(q);
+      rr = prev;
+      prev = step;
+      if (fabs(p) < fabs(0.5 * q * rr) && p > q * (lo - x) && p < q * (hi - x)) {
+        step = p / q;
+        u = x + step;
+        if (fmin(u - lo, hi - u) < 2.0 * tol) step = tol * (sgn(mid - x) + (mid == x));
+        golden = 0;
+      }
+    }
+    if (golden) {
+      prev = (x >= mid) ? lo - x : hi - x;
+      step = gold * prev;
+    }
+    u = x + fmax(fabs(step), tol) * (sgn(step) + (step == 0));
+    fu = fabs(orc_eos_ee(t, r, u) - e);
+    if (fu < fx) {
+      if (u < x) hi = x; else lo = x;
+      v = w; fv = fw; w = x; fw = fx; x = u; fx = fu;
+    } else {
+      if (u < x) lo = u; else hi = u;
+      if (fu <= fw || w == x) { v = w; fv = fw; w = u; fw = fu; }
+      else if (fu <= fv || v == x || v == w) { v = u; fv = fu; }
+    }
+  }
+  return -1.0;
+}
+
 /* ---- wide-range transport model (Povarnitsyn), imd_ttm_3D.c:2352-2592 ------ */
 static double fermi_E(double ne) { return HBAR * HBAR * pow(3.0 * M_PI * M_PI * ne, 2.0 / 3.0) / 2.0 / EMASS; }
 static double fermi_T(double ne) { return 2.0 * fermi_E(ne) / (3.0 * BOLTZMAN); }

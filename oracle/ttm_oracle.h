@@ -30,6 +30,7 @@ void orc_ttm_set_eos(orc_ttm *t, int which /*0 cve(r,T), 1 ee(r,sqrt T)*/, int n
 double orc_eos_lookup(const orc_eos *e, double x, double y);
 double orc_eos_cve(const orc_ttm *t, double r, double tK);
 double orc_eos_ee(const orc_ttm *t, double r, double tK);
+double orc_eos_te_from_r_ee(const orc_ttm *t, double r, double e);
 double orc_mean_charge(double temp, double rho, double z0, double am);
 double orc_get_gamma(double Te, double Ti, double Ne, double Z, double omega_laser);
 double orc_get_kappa(double Te, double Ti, double Ne, double Z, double omega_laser);

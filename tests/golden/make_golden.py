@@ -165,7 +165,44 @@ def run_case(name, c):
            np.abs(probes[c["dump"][-1]]["kraft"]).max()))
 
 
+def run_eos_inverse():
+    """EOS_te_from_r_ee / EOS_ee_from_r_te of the reference (Brent minimiser over the ee(r, sqrt T) table) on the
+    sample points of oracle/ref_probe_ttm.c:dump_eos_inverse -> tests/golden/eos_inverse.npz"""
+    c = CASES["ttm_2048"]
+    with tempfile.TemporaryDirectory() as d:
+        par = COMMON.format(pbc="1 1 1", seed=12345, cpu="1 1 1")
+        par += "box_param %s\nstarttemp %g\nmaxsteps 0\n" % (c["box"], c["temp"])
+        potential.write_synthetic_eam_files(d)
+        par += "core_potential_file phi.pt\nembedding_energy_file F.pt\natomic_e-density_file rho.pt\n"
+        par += "nbl_margin 0.5\nnbl_size 1.5\n"
+        par = par.replace("ensemble nve", "ensemble ttm")
+        par += ("fd_ext 1 1 1\nfd_n_timesteps 100\nfd_min_atoms 5\natomic_weight 26.9815\natomic_charge 13\n"
+                "ttm_int 100000\nI0 1.0\nlambda 800e-9\nlaser_sigma_t 100e-15\nlaser_t_0 1.0\n")
+        eos = write_planar_eos(d)
+        open(os.path.join(d, "t.param"), "w").write(par)
+        env = dict(os.environ, IMD_PROBE_DIR=d, IMD_PROBE_STEPS="0", IMD_PROBE_EOSINV="1")
+        r = subprocess.run([os.path.join(REFBIN, c["binary"]), "-p", "t.param"], cwd=d, env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            print(r.stdout[-3000:])
+            raise SystemExit("reference run failed for eos_inverse")
+        raw = open(os.path.join(d, "eosinv.0.bin"), "rb").read()
+    assert raw[:8] == b"IMDEOSIN"
+    n = int(np.frombuffer(raw[8:12], np.int32)[0])
+    a = np.frombuffer(raw[12:12 + 32 * n], np.float64).reshape(n, 4)
+    out = dict(r=a[:, 0], t_in=a[:, 1], e=a[:, 2], t_out=a[:, 3])
+    for k, v in eos.items():
+        out["eos_" + k] = v
+    path = os.path.join(OUT, "eos_inverse.npz")
+    np.savez_compressed(path, **out)
+    print("%-20s %8.1f KB  %d points, max |t_out/t_in - 1| on the curve = %.3g" %
+          ("eos_inverse", os.path.getsize(path) / 1024, n, np.abs(a[::3, 3] / a[::3, 1] - 1).max()))
+
+
 if __name__ == "__main__":
-    names = sys.argv[1:] or list(CASES)
+    names = sys.argv[1:] or (list(CASES) + ["eos_inverse"])
     for n in names:
-        run_case(n, CASES[n])
+        if n == "eos_inverse":
+            run_eos_inverse()
+        else:
+            run_case(n, CASES[n])

@@ -122,3 +122,19 @@ def test_ttm_vs_oracle_same_inputs():
         ref = getattr(t, f)
         assert np.abs(d[f][inner] - ref[inner]).max() <= TOL * np.abs(ref[inner]).max(), f
     s.close()
+
+
+def test_inverse_eos_vs_reference_and_oracle():
+    """EOS_te_from_r_ee (Brent minimiser, imd_ttm_3D.c:2786-2811, fminbnd3.c).  GPU vs the values the
+    reference's own function produced (tests/golden/eos_inverse.npz; bar = the minimiser's x tolerance 1e-5 K, see
+    test_oracle_ttm_vs_reference.py) and vs the oracle on the same look-up rule (same iterates: 1e-9 relative)."""
+    G = gu.load("eos_inverse")
+    G0 = gu.load("ttm_2048")
+    s = _gpu(G0, 0)
+    te = s.EOS_te_from_r_ee(G["r"], G["e"])
+    assert np.abs(te - G["t_out"]).max() < 1e-5
+    o = gu.oracle_from_golden(G0, 0)
+    t = gu.oracle_ttm_from_golden(G0, o)
+    to = np.array([t.eos_te_from_r_ee(r, e) for r, e in zip(G["r"], G["e"])])
+    assert np.abs(te / to - 1).max() < 1e-9
+    t.close(); s.close()

@@ -77,3 +77,24 @@ def test_calc_ttm_sequence_equals_stages():
     s.calc_forces(0)
     t.calc_ttm(0, int(G["ttm_diff_substeps"]))
     _cmp(t, gu.ttm_stage(G, 0, "cfl"), "cfl")
+
+
+def test_inverse_eos_vs_reference():
+    """EOS_te_from_r_ee (Brent minimiser, imd_ttm_3D.c:2786-2811 + fminbnd3.c) and EOS_ee_from_r_te: the oracle's
+    restatement against values computed by the reference's own functions (tests/golden/eos_inverse.npz, 126 points
+    on and off the ee(T) curve).  The iteration is deterministic, but the table look-up rules differ in the last
+    ulp (triangle-linear vs bilinear), which can flip one late comparison: 90 of the 126 points agree to 1e-9 K, the
+    rest to 1.6e-6 K.  The bar is the minimiser's own x tolerance, 1e-5 K (fminbnd3.c:8)."""
+    G = gu.load("eos_inverse")
+    G0 = gu.load("ttm_2048")
+    s = gu.oracle_from_golden(G0, 0)
+    t = gu.oracle_ttm_from_golden(G0, s)
+    nr, nt = int(G["eos_nr"]), int(G["eos_nt"])
+    t.set_eos(1, nr, nt, G["eos_r"][0], G["eos_r"][-1], G["eos_ts"][0], G["eos_ts"][-1], G["eos_ee"])
+    on_curve = np.arange(len(G["r"])) % 3 == 0
+    ee = np.array([t.eos_ee(r, tk) for r, tk in zip(G["r"][on_curve], G["t_in"][on_curve])])
+    assert np.abs(ee / G["e"][on_curve] - 1).max() < 1e-13
+    te = np.array([t.eos_te_from_r_ee(r, e) for r, e in zip(G["r"], G["e"])])
+    assert np.abs(te - G["t_out"]).max() < 1e-5
+    assert (np.abs(te - G["t_out"]) < 1e-9).sum() >= 80
+    t.close()
