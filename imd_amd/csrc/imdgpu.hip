@@ -393,16 +393,8 @@ __device__ __forceinline__ void lds_load_table(double *dst, const TabPar &t)
 // (imd_forces_nbl.c:418-672), gather form: every local atom sums over its full
 // list, nothing is scattered, ghost atoms are read-only.
 template <bool PAIR, bool EAM, bool TTMN, bool NT1>
-__global__ __launch_bounds__(512) void k_pass1(ForceArgs a)
+__device__ __forceinline__ void pass1_body(const ForceArgs &a, const double *tp, const double *tr, double *scratch)
 {
-  extern __shared__ double lds[];
-  double *tp = lds;
-  double *tr = lds + (PAIR ? a.pair.nrows * a.pair.ncols : 0);
-  double *scratch = tr + (EAM ? a.rho.nrows * a.rho.ncols : 0);
-  if (PAIR) lds_load_table(tp, a.pair);
-  if (EAM) lds_load_table(tr, a.rho);
-  __syncthreads();
-
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int inc = a.ntypes * a.ntypes;
   double sums[2] = {0.0, 0.0};             // pair energy, virial
@@ -451,6 +443,26 @@ __global__ __launch_bounds__(512) void k_pass1(ForceArgs a)
   }
   if (is_short) a.counters[CNT_IS_SHORT] = 1;
 }
+// tables copied into LDS (they fit: one atom type always does) ...
+template <bool PAIR, bool EAM, bool TTMN, bool NT1>
+__global__ __launch_bounds__(512) void k_pass1(ForceArgs a)
+{
+  extern __shared__ double lds[];
+  double *tp = lds;
+  double *tr = lds + (PAIR ? a.pair.nrows * a.pair.ncols : 0);
+  double *scratch = tr + (EAM ? a.rho.nrows * a.rho.ncols : 0);
+  if (PAIR) lds_load_table(tp, a.pair);
+  if (EAM) lds_load_table(tr, a.rho);
+  __syncthreads();
+  pass1_body<PAIR, EAM, TTMN, NT1>(a, tp, tr, scratch);
+}
+// ... or read where they are (ntypes^2 columns of a few thousand rows exceed the LDS): the rows come through L2
+template <bool PAIR, bool EAM, bool TTMN>
+__global__ __launch_bounds__(512) void k_pass1_gt(ForceArgs a)
+{
+  __shared__ double scratch[64];
+  pass1_body<PAIR, EAM, TTMN, false>(a, a.pair.tab, a.rho.tab, scratch);
+}
 
 // Pass 2: embedding energy F(rho_i) and its derivative (stored as twice the
 // derivative exactly like EAM_DF, imd_forces_nbl.c:748-783; the factor is taken
@@ -477,13 +489,8 @@ __global__ void k_pass2(int nlocal, int ntypes, double4 *pos, const int *type, c
 // Pass 3: EAM force, grad = 0.5*(dF_i*rho'_j + dF_j*rho'_i)
 // (imd_forces_nbl.c:789-985), gather form.
 template <bool NT1>
-__global__ __launch_bounds__(512) void k_pass3(ForceArgs a)
+__device__ __forceinline__ void pass3_body(const ForceArgs &a, const double *tr, double *scratch)
 {
-  extern __shared__ double lds[];
-  double *tr = lds;
-  double *scratch = tr + a.rho.nrows * a.rho.ncols;
-  lds_load_table(tr, a.rho);
-  __syncthreads();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int inc = a.ntypes * a.ntypes;
   double sums[1] = {0.0};
@@ -521,6 +528,21 @@ __global__ __launch_bounds__(512) void k_pass3(ForceArgs a)
   if (threadIdx.x == 0) a.partials[(size_t) blockIdx.x * IMDGPU_NPART + 3] = sums[0];
   if (is_short) a.counters[CNT_IS_SHORT] = 1;
 }
+template <bool NT1>
+__global__ __launch_bounds__(512) void k_pass3(ForceArgs a)
+{
+  extern __shared__ double lds[];
+  double *tr = lds;
+  double *scratch = tr + a.rho.nrows * a.rho.ncols;
+  lds_load_table(tr, a.rho);
+  __syncthreads();
+  pass3_body<NT1>(a, tr, scratch);
+}
+__global__ __launch_bounds__(512) void k_pass3_gt(ForceArgs a)
+{
+  __shared__ double scratch[64];
+  pass3_body<false>(a, a.rho.tab, scratch);
+}
 
 // ===========================================================================
 // LDS-tiled force path (mode 1).  One workgroup per tile of bx*by*bz inner cells:
@@ -530,6 +552,7 @@ __global__ __launch_bounds__(512) void k_pass3(ForceArgs a)
 // per tile).  HBM sees: list (2 B/entry), own-atom outputs, one staging pass.
 // ===========================================================================
 #define LDS_LIMIT (160 * 1024)
+#define TABLE_LDS_LIMIT (150 * 1024)                 // global-gather kernels: tables beyond this stay in global memory
 #define NH_MAX 512                                   // halo cells per tile (<= 6*6*6 = 216 for tiles up to 4^3)
 
 struct TileArgs {
@@ -1649,8 +1672,8 @@ extern "C" int imdgpu_upload_tables(imdgpu_ctx *ctx, const imdgpu_pot_table *pai
     HIPCHK(hipMalloc((void **) &ctx->d_merged, m.size() * sizeof(double)));
     HIPCHK(hipMemcpy(ctx->d_merged, m.data(), m.size() * sizeof(double), hipMemcpyHostToDevice));
   }
-  size_t lds = ((pair ? ctx->pair.par.nrows * pair->ncols : 0) + (rho ? ctx->rho.par.nrows * rho->ncols : 0) + 64) * sizeof(double);
-  if (lds > 150 * 1024) return imdgpu_fail(ctx, "potential tables need %zu B of LDS (limit 150 KB)", lds);
+  // tables larger than the LDS (several atom types: ntypes^2 columns) are read in place by the global-gather
+  // kernels (k_pass1_gt / k_pass3_gt); the tile kernels need them in LDS, make_nblist then picks list_mode 0
   return 0;
 }
 
@@ -1948,6 +1971,10 @@ extern "C" int imdgpu_make_nblist(imdgpu_ctx *ctx)
   Geo g = make_geo(ctx);
   if (imdgpu_fill_ghosts(ctx)) return 1;
   ctx->list_mode = ctx->mode;
+  // the tile kernels keep the potential tables in LDS next to the staged positions: tables that leave no room for
+  // even a one-cell tile (several atom types) select the global-gather kernels (reported by get_info("list_mode"))
+  if (ctx->list_mode == 1 && std::max(tile_lds_bytes_for(ctx, 1024, 1), tile_lds_bytes_for(ctx, 1024, 3)) > LDS_LIMIT)
+    ctx->list_mode = 0;
   if (ctx->list_mode == 1 && !ctx->autotiled && !getenv("IMDGPU_TILE") && !ctx->external_halo) {
     if (autotile(ctx)) return 1;
     g = make_geo(ctx);
@@ -2082,7 +2109,8 @@ static int launch_forces(imdgpu_ctx *ctx, int phase = 0)
       size_t l = tile_lds_bytes(ctx, 1);                                                                        \
       HIPCHK(hipFuncSetAttribute((const void *) k_pass1_tile<P, E, T, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) l)); \
       hipLaunchKernelGGL((k_pass1_tile<P, E, T, N>), dim3(nb), dim3(B), l, ctx->stream, ta);                     \
-    } else hipLaunchKernelGGL((k_pass1<P, E, T, N>), dim3(nb), dim3(B), lds1, ctx->stream, a);                  \
+    } else if (lds1 > TABLE_LDS_LIMIT) hipLaunchKernelGGL((k_pass1_gt<P, E, T>), dim3(nb), dim3(B), 0, ctx->stream, a); \
+    else hipLaunchKernelGGL((k_pass1<P, E, T, N>), dim3(nb), dim3(B), lds1, ctx->stream, a);                    \
   } while (0)
 #define L1T(P, E, T) do { if (NT1) L1(P, E, T, true); else L1(P, E, T, false); } while (0)
 #define L1E(P, E) do { if (TT) L1T(P, E, true); else L1T(P, E, false); } while (0)
@@ -2127,7 +2155,8 @@ static int launch_forces(imdgpu_ctx *ctx, int phase = 0)
         HIPCHK(hipFuncSetAttribute((const void *) k_pass3_tile<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) l));
         hipLaunchKernelGGL((k_pass3_tile<false>), dim3(nb), dim3(B), l, ctx->stream, ta);
       }
-    } else if (NT1) hipLaunchKernelGGL((k_pass3<true>), dim3(nb), dim3(B), lds3, ctx->stream, a);
+    } else if (lds3 > TABLE_LDS_LIMIT) hipLaunchKernelGGL(k_pass3_gt, dim3(nb), dim3(B), 0, ctx->stream, a);
+    else if (NT1) hipLaunchKernelGGL((k_pass3<true>), dim3(nb), dim3(B), lds3, ctx->stream, a);
     else hipLaunchKernelGGL((k_pass3<false>), dim3(nb), dim3(B), lds3, ctx->stream, a);
   }
   if (phase == 0 || phase == 3) {

@@ -229,3 +229,39 @@ def write_synthetic_eam_files(dirname, n=4000, r_begin=1.5, r_cut=6.5, rho_max=4
     write_pot_table2(os.path.join(dirname, "rho.pt"), [b2], [e2], [step], [rho(r)])
     ps = rho_max / (n - 1)
     write_pot_table2(os.path.join(dirname, "F.pt"), [0.0], [rho_max], [ps], [emb(ps * np.arange(n))])
+
+
+def write_synthetic_eam_files_2types(dirname, rows=1.0):
+    """Two atom types (A = Al-like, B heavier): pair and density tables with ntypes^2 = 4 columns
+    (col = type_i * ntypes + type_j, types.h:537-549), each with ITS OWN begin / end / step / length, the
+    embedding table with 2 columns.  Exercises the per-column indexing of PAIR_INT2 / VAL_FUNC2 / DERIV_FUNC2.
+    rows < 1 shrinks every column (coarse tables that fit the LDS next to a tile)."""
+    import os
+    phi, rho, emb = synthetic_eam_functions()
+    spec = {0: (1.5, 6.5, 4000, 1.00, 1.00), 1: (1.6, 6.2, 3500, 0.85, 1.03), 2: (1.6, 6.2, 3500, 0.85, 1.03),
+            3: (1.7, 6.4, 3000, 1.25, 0.97)}             # r_begin, r_cut, n, amplitude, radial stretch
+    rspec = {0: (1.5, 6.5, 4000, 1.00), 1: (1.5, 6.3, 3800, 0.80), 2: (1.6, 6.1, 3600, 1.30), 3: (1.5, 6.4, 3900, 1.10)}
+    def cut_at(fn, rc):
+        return lambda r: fn(r * 6.5 / rc)                # the analytic cut-off of fn sits at 6.5: squeeze it to rc
+    b, e, st, cols = [], [], [], []
+    for c in range(4):
+        rb, rc, n, amp, stretch = spec[c]
+        n = int(n * rows)
+        b2, e2 = rb * rb, rc * rc
+        step = (e2 - b2) / (n - 1)
+        r = np.sqrt(b2 + step * np.arange(n))
+        b.append(b2); e.append(e2); st.append(step); cols.append(amp * cut_at(phi, rc)(r * stretch / stretch))
+    write_pot_table2(os.path.join(dirname, "phi.pt"), b, e, st, cols)
+    b, e, st, cols = [], [], [], []
+    for c in range(4):
+        rb, rc, n, amp = rspec[c]
+        n = int(n * rows)
+        b2, e2 = rb * rb, rc * rc
+        step = (e2 - b2) / (n - 1)
+        r = np.sqrt(b2 + step * np.arange(n))
+        b.append(b2); e.append(e2); st.append(step); cols.append(amp * cut_at(rho, rc)(r))
+    write_pot_table2(os.path.join(dirname, "rho.pt"), b, e, st, cols)
+    ne = [int(4000 * rows), int(3500 * rows)]
+    ps = [40.0 / (ne[0] - 1), 55.0 / (ne[1] - 1)]
+    write_pot_table2(os.path.join(dirname, "F.pt"), [0.0, 0.0], [40.0, 55.0], ps,
+                     [emb(ps[0] * np.arange(ne[0])), 1.15 * emb(0.9 * ps[1] * np.arange(ne[1]))])

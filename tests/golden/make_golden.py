@@ -63,6 +63,14 @@ CASES = {
     "ttm_slab": dict(binary="imd_mpi_eam_ttm3d_nbl", box="8 6 6", temp=0.03, steps=2, dump=[0, 1, 2], full=[],
                      pot="eam", nbl=True, pbc="0 1 1", extra="shiftx_front 8.0\nshiftx_rear 8.0\n",
                      ttm=dict(fd_ext="1 1 1", n=100, min_atoms=12)),
+    # two atom types on the Cu3Au (L1_2) lattice: 4-column pair / density tables with per-column ranges
+    "eam2_l12_nbl": dict(binary="imd_eam_nve_nbl", box="8 8 8", temp=0.05, steps=20, dump=[0, 1, 20], full=[0],
+                         pot="eam2types", nbl=True, coord="_l12",
+                         types="ntypes 2\ntotal_types 2\nmasses 26.9815 63.546\ntypes 0 1"),
+    # the same with coarse tables (600 rows): they fit the LDS, so the TILE kernels' several-type branch runs
+    "eam2_l12_coarse": dict(binary="imd_eam_nve_nbl", box="8 8 8", temp=0.05, steps=20, dump=[0, 20], full=[0],
+                            pot="eam2types_coarse", nbl=True, coord="_l12",
+                            types="ntypes 2\ntotal_types 2\nmasses 26.9815 63.546\ntypes 0 1"),
     "eam_cellpair_2048": dict(binary="imd_eam_nve", box="8 8 8", temp=0.0258, steps=10, dump=[0, 10], full=[0, 10],
                               pot="eam", nbl=False),
 }
@@ -88,7 +96,14 @@ def run_case(name, c):
     with tempfile.TemporaryDirectory() as d:
         par = COMMON.format(pbc=c.get("pbc", "1 1 1"), seed=c.get("seed", 12345), cpu=c.get("cpu", "1 1 1"))
         par += "box_param %s\nstarttemp %g\nmaxsteps %d\n" % (c["box"], c["temp"], c["steps"])
-        if c["pot"] == "eam":
+        if "coord" in c:
+            par = par.replace("coordname _fcc", "coordname " + c["coord"])
+        if "types" in c:
+            par = par.replace("ntypes 1\ntotal_types 1\nmasses 26.9815\ntypes 0", c["types"])
+        if c["pot"].startswith("eam2types"):
+            potential.write_synthetic_eam_files_2types(d, rows=0.15 if c["pot"].endswith("coarse") else 1.0)
+            par += "core_potential_file phi.pt\nembedding_energy_file F.pt\natomic_e-density_file rho.pt\n"
+        elif c["pot"] == "eam":
             potential.write_synthetic_eam_files(d)
             par += "core_potential_file phi.pt\nembedding_energy_file F.pt\natomic_e-density_file rho.pt\n"
         else:
@@ -140,7 +155,7 @@ def run_case(name, c):
         out[pre + "sorte"] = P["all_sorte"][inner_idx].astype(np.int8)
         out[pre + "ort"] = P["all_ort"][inner_idx]
         for k in ("masse", "impuls", "kraft", "pot_eng", "eam_rho", "eam_dF", "nbl_pos", "numneighs"):
-            if k in ("eam_rho", "eam_dF") and c["pot"] != "eam":
+            if k in ("eam_rho", "eam_dF") and not c["pot"].startswith("eam"):
                 continue
             if k == "nbl_pos" and not c["nbl"]:
                 continue
