@@ -433,6 +433,10 @@ def read_ttm_probe(path):
     while off < len(buf) - 8:
         tag = buf[off:off + 16].split(b"\0")[0].decode(); off += 16
         mdt = float(np.frombuffer(buf, "<f8", 1, off)[0]); off += 8
+        if mdt == -1.0:               # int record: the 8 atom-flux counters per cell (dump_flux)
+            fl = np.frombuffer(buf, "<i4", 8 * n, off).reshape(tuple(H["fd_dim"]) + (8,)).copy(); off += 32 * n
+            stages[tag] = dict(max_dt_ttm=mdt, flux=fl)
+            continue
         rec = np.frombuffer(buf, TTM_REC, n, off).reshape(tuple(H["fd_dim"])).copy(); off += TTM_REC.itemsize * n
         stages[tag] = dict(max_dt_ttm=mdt, lat=rec)
     H["stages"] = stages

@@ -16,8 +16,9 @@
  *       update_fd -> do_cell_activation -> do_FILLMESH -> ttm_fill_ghost_layers
  *       -> diff_substeps x { do_DIFF(tau); do_FILLMESH; ttm_fill_ghost_layers }
  *       -> CFL_maxdt
- *     leaving out do_tmm (laser) and do_ADV (advection; out of scope this round),
- *     dumping the lattice in raw fp64 between the stages.
+ *     leaving out do_tmm (laser) and, unless IMD_PROBE_ADV is set, do_ADV (advection: see DESIGN.md 9 for
+ *     what the reference does there), dumping the lattice in raw fp64 between the stages.
+ *     IMD_PROBE_EOSINV=1 additionally evaluates the reference's EOS_ee_from_r_te / EOS_te_from_r_ee on sample points.
  * Every number in the TTM fixtures is thus computed by the reference's code.
  */
 #include "imd.h"
@@ -87,6 +88,20 @@ static void dump_eos_inverse(void)
   fclose(f);
 }
 
+/* advection bookkeeping of update_fd: the eight atom-flux counters per FD cell (imd_ttm_3D.c:335-370) */
+static void dump_flux(const char *tag)
+{
+  int i, j, k, q;
+  char t[16];
+  memset(t, 0, sizeof(t)); strncpy(t, tag, 15);
+  fwrite(t, 1, 16, tf);
+  wd(-1.0);                                  /* marks an int record: 8 ints per cell follow */
+  for (i = 0; i < local_fd_dim.x; i++)
+    for (j = 0; j < local_fd_dim.y; j++)
+      for (k = 0; k < local_fd_dim.z; k++)
+        for (q = 0; q < 8; q++) wi(l1[i][j][k].flux[q]);
+}
+
 void __wrap_calc_ttm(void)
 {
   int i, dumping = want(steps);
@@ -110,6 +125,11 @@ void __wrap_calc_ttm(void)
   }
   update_fd();
   if (dumping) dump_lattice("update_fd");
+  if (getenv("IMD_PROBE_ADV")) {           /* advection step of calc_ttm (imd_ttm_3D.c:58-60); returns at once for steps < 1 */
+    if (dumping) dump_flux("flux");
+    do_ADV(1.0);
+    if (dumping) dump_lattice("adv");
+  }
   do_cell_activation();
   do_FILLMESH();
   ttm_fill_ghost_layers();
