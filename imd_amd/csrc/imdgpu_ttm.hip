@@ -53,6 +53,7 @@ struct Lat {                      // lattice geometry + parameters by value
   double inv_awamu;               // 1 / (atomic_weight * AMU)          (ne)
   double invhsq[3];               // 1 / fd_h^2
   double xi_fac;                  // 26.9815*AMU/3*1e30 / diff_substeps  (do_DIFF :1614)
+  int wave_prio;                  // wave priority of the sub-step kernel (IMDGPU_TTM_PRIO, default 0)
 };
 
 __device__ __forceinline__ int fidx(const Lat &L, int i, int j, int k) { return (i * L.dim[1] + j) * L.dim[2] + k; }
@@ -388,7 +389,12 @@ __global__ __launch_bounds__(DT_X *DT_Y *DT_Z) void k_ttm_diff(
   __shared__ double sT[DT_X + 2][DT_Y + 2][DT_Z + 2];
   __shared__ double sK[DT_X + 2][DT_Y + 2][DT_Z + 2];
   __shared__ int sN[DT_X + 2][DT_Y + 2][DT_Z + 2];
-  __builtin_amdgcn_s_setprio(3);      // latency-critical chain of tiny launches sharing the CUs with the force passes
+  // chain of tiny launches sharing the CUs with the force passes.  Raising the wave priority (1..3, all the same)
+  // finishes the chain in 1.4 ms instead of 2.2 but costs the EAM force pass 0.22 ms: measured best is NOT to raise it
+  // (180 vs 177 steps/s); IMDGPU_TTM_PRIO keeps the experiment available.
+  if (L.wave_prio == 3) __builtin_amdgcn_s_setprio(3);
+  else if (L.wave_prio == 2) __builtin_amdgcn_s_setprio(2);
+  else if (L.wave_prio == 1) __builtin_amdgcn_s_setprio(1);
   const int tz = threadIdx.x % DT_Z, ty = (threadIdx.x / DT_Z) % DT_Y, tx = threadIdx.x / (DT_Z * DT_Y);
   const int nbz = (L.dim[2] - 2 + DT_Z - 1) / DT_Z, nby = (L.dim[1] - 2 + DT_Y - 1) / DT_Y;
   const int bz = blockIdx.x % nbz, by = (blockIdx.x / nbz) % nby, bx = blockIdx.x / (nbz * nby);
@@ -545,6 +551,7 @@ static Lat make_lat(const TtmState *t)
   L.inv_awamu = 1.0 / (t->atomic_weight * C_AMU);
   for (int d = 0; d < 3; d++) L.invhsq[d] = 1.0 / (t->h[d] * t->h[d]);
   L.xi_fac = 26.9815 * C_AMU / 3.0 * 1e30 / ((double) t->nsub);
+  { static const int prio = getenv("IMDGPU_TTM_PRIO") ? atoi(getenv("IMDGPU_TTM_PRIO")) : 0; L.wave_prio = prio; }
   return L;
 }
 
