@@ -77,6 +77,28 @@ extern "C" int imdgpu_halo_gather(imdgpu_ctx *ctx, int what, const int *dev_idx,
   HIPCHK(hipGetLastError());
   return 0;
 }
+// both faces of one exchange stage in one launch: entries [0, n_lo) take shift_lo, [n_lo, n) shift_hi
+__global__ void k_halo_gather2(int what, int n_lo, int n, const int *idx, const double4 *pos, const int *type, double lx,
+                               double ly, double lz, double hx, double hy, double hz, void *out)
+{
+  int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= n) return;
+  int i = idx[m];
+  const bool lo = m < n_lo;
+  if (what == 0) { double4 r = pos[i]; r.x += lo ? lx : hx; r.y += lo ? ly : hy; r.z += lo ? lz : hz; ((double4 *) out)[m] = r; }
+  else if (what == 1) ((double *) out)[m] = pos[i].w;
+  else ((int *) out)[m] = type[i];
+}
+extern "C" int imdgpu_halo_gather2(imdgpu_ctx *ctx, int what, const int *dev_idx, int n_lo, int n, const double shift_lo[3],
+                                   const double shift_hi[3], void *dev_out)
+{
+  if (n <= 0) return 0;
+  ProfScope ps(ctx, PROF_GHOSTS);
+  hipLaunchKernelGGL(k_halo_gather2, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, what, n_lo, n, dev_idx, ctx->pos, ctx->type,
+                     shift_lo[0], shift_lo[1], shift_lo[2], shift_hi[0], shift_hi[1], shift_hi[2], dev_out);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
 extern "C" int imdgpu_halo_scatter(imdgpu_ctx *ctx, int what, const int *dev_idx, int n, const void *dev_in)
 {
   if (n <= 0) return 0;

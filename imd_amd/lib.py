@@ -22,7 +22,7 @@ SYMBOLS = [
     "imdgpu_ttm_init", "imdgpu_ttm_dims", "imdgpu_ttm_download", "imdgpu_ttm_upload", "imdgpu_ttm_update_fd",
     "imdgpu_ttm_cell_activation", "imdgpu_ttm_fillmesh", "imdgpu_ttm_fill_ghost_layers", "imdgpu_ttm_diff",
     "imdgpu_ttm_cfl_maxdt", "imdgpu_calc_ttm", "imdgpu_move_atoms_ttm", "imdgpu_ttm_eos_te_from_r_ee",
-    "imdgpu_get_cell_tables", "imdgpu_autotile", "imdgpu_set_ghost_layout", "imdgpu_halo_gather", "imdgpu_halo_scatter",
+    "imdgpu_get_cell_tables", "imdgpu_autotile", "imdgpu_set_ghost_layout", "imdgpu_halo_gather", "imdgpu_halo_gather2", "imdgpu_halo_scatter",
     "imdgpu_migrate_scan", "imdgpu_migrate_gather", "imdgpu_migrate_apply", "imdgpu_forces_phase", "imdgpu_integrate",
     "imdgpu_get_invalid", "imdgpu_invalidate", "imdgpu_ttm_local_block", "imdgpu_ttm_apply_blocks",
     "imdgpu_ttm_lattice_step",
@@ -127,6 +127,7 @@ def load():
     L.imdgpu_autotile.argtypes = [vp, ip]
     L.imdgpu_set_ghost_layout.argtypes = [vp, ip, ip, C.c_int]
     L.imdgpu_halo_gather.argtypes = [vp, C.c_int, vp, C.c_int, dp, vp]
+    L.imdgpu_halo_gather2.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, dp, dp, vp]
     L.imdgpu_halo_scatter.argtypes = [vp, C.c_int, vp, C.c_int, vp]
     L.imdgpu_migrate_scan.argtypes = [vp, C.c_int, ip, ip]
     L.imdgpu_migrate_gather.argtypes = [vp, C.c_int, vp]

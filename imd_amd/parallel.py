@@ -17,6 +17,9 @@ exist here.  Every ghost direction is filled (the non-AR shell).
 the CPU tests plug in a numpy stand-in with the same methods, which is how the
 N>1 logic is exercised without a GPU.
 """
+import os
+import sys
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -133,10 +136,11 @@ def all_reduce_(t, op=None):
     return t
 
 
-def _exchange(dec, d, buf_lo, buf_hi, like_lo, like_hi, group=None):
+def _exchange(dec, d, buf_lo, buf_hi, like_lo, like_hi, group=None, out_lo=None, out_hi=None):
     """Send buf_lo to the low neighbour and buf_hi to the high one; returns (from_lo, from_hi) where
     from_lo is the low neighbour's HIGH layer and from_hi the high neighbour's LOW layer.
-    like_*: (numel, dtype) of what arrives.  Self-neighbours (cpu_dim[d]==1) short-circuit."""
+    like_*: (numel, dtype) of what arrives; out_*: optional tensors to receive into (views of one buffer).
+    Self-neighbours (cpu_dim[d]==1) short-circuit."""
     lo, hi = dec.lo[d], dec.hi[d]
     if dec.cpu_dim[d] == 1:
         return (buf_hi if lo is not None else None), (buf_lo if hi is not None else None)
@@ -152,17 +156,19 @@ def _exchange(dec, d, buf_lo, buf_hi, like_lo, like_hi, group=None):
     if hi is not None:
         ops.append(dist.P2POp(dist.isend, buf_hi, hi, group))
     if hi is not None:
-        from_hi = torch.empty(like_hi[0], dtype=like_hi[1], device=tdev)
+        from_hi = out_hi if (out_hi is not None and not stage) else torch.empty(like_hi[0], dtype=like_hi[1], device=tdev)
         ops.append(dist.P2POp(dist.irecv, from_hi, hi, group))
     if lo is not None:
-        from_lo = torch.empty(like_lo[0], dtype=like_lo[1], device=tdev)
+        from_lo = out_lo if (out_lo is not None and not stage) else torch.empty(like_lo[0], dtype=like_lo[1], device=tdev)
         ops.append(dist.P2POp(dist.irecv, from_lo, lo, group))
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
     if stage:
-        from_lo = from_lo.to(dev) if from_lo is not None else None
-        from_hi = from_hi.to(dev) if from_hi is not None else None
+        if from_lo is not None:
+            from_lo = out_lo.copy_(from_lo) if out_lo is not None else from_lo.to(dev)
+        if from_hi is not None:
+            from_hi = out_hi.copy_(from_hi) if out_hi is not None else from_hi.to(dev)
     return from_lo, from_hi
 
 
@@ -177,15 +183,18 @@ class HaloPlan:
         cs, cc = ops.cell_tables()
         cs, cc = cs.astype(np.int64), cc.astype(np.int64)
         nlocal = ops.nlocal()
-        ghost_mask = np.ones(dec.nall, bool)
-        D = dec.dim
-        ii, jj, kk = np.meshgrid(range(1, D[0] - 1), range(1, D[1] - 1), range(1, D[2] - 1), indexing="ij")
-        ghost_mask[((ii * D[1] + jj) * D[2] + kk).ravel()] = False
-        cc[ghost_mask] = 0
+        if getattr(dec, "_static", None) is None:     # geometry only: ghost-cell mask and the stage cell lists
+            ghost_mask = np.ones(dec.nall, bool)
+            D = dec.dim
+            ii, jj, kk = np.meshgrid(range(1, D[0] - 1), range(1, D[1] - 1), range(1, D[2] - 1), indexing="ij")
+            ghost_mask[((ii * D[1] + jj) * D[2] + kk).ravel()] = False
+            dec._static = (np.flatnonzero(ghost_mask), {d: dec.stage_cells(d) for d in (0, 1, 2)})
+        ghost_cells, stage_cells = dec._static
+        cc[ghost_cells] = 0
         nghost = 0
         dev = ops.device
         for d in (2, 1, 0):
-            s_lo, s_hi, r_lo, r_hi = dec.stage_cells(d)
+            s_lo, s_hi, r_lo, r_hi = stage_cells[d]
             c_lo, c_hi = torch.from_numpy(cc[s_lo].astype(np.int32)).to(dev), torch.from_numpy(cc[s_hi].astype(np.int32)).to(dev)
             f_lo, f_hi = _exchange(dec, d, c_lo, c_hi, (len(r_lo), torch.int32), (len(r_hi), torch.int32))
             st = dict(d=d)
@@ -215,6 +224,15 @@ class HaloPlan:
                 if st["recv_" + name] is not None:
                     a, n = st["recv_" + name]
                     st["ridx_" + name] = torch.arange(a, a + n, dtype=torch.int32, device=dev)
+            # one gather and one scatter launch per stage: send list = [low face; high face]; arrivals are laid out
+            # as [from the high neighbour; from the low neighbour], which for a self-neighbour IS the send buffer
+            e = torch.empty(0, dtype=torch.int32, device=dev)
+            s_lo = st["send_lo"] if st["send_lo"] is not None else e
+            s_hi = st["send_hi"] if st["send_hi"] is not None else e
+            st["send_cat"], st["n_send"] = torch.cat([s_lo, s_hi]), (int(s_lo.numel()), int(s_hi.numel()))
+            r_hi = st["ridx_hi"] if st["recv_hi"] is not None else e
+            r_lo = st["ridx_lo"] if st["recv_lo"] is not None else e
+            st["ridx_cat"], st["n_recv"] = torch.cat([r_hi, r_lo]), (int(r_hi.numel()), int(r_lo.numel()))
 
     def exchange(self, ops, what):
         """Forward halo of `what` (0 positions+dF, 1 dF, 2 types) in the stages z, y, x."""
@@ -222,15 +240,20 @@ class HaloPlan:
         dec = self.dec
         for st in self.stages:
             d = st["d"]
-            b_lo = ops.gather(what, st["send_lo"], dec.shift_lo[d]) if st["send_lo"] is not None else None
-            b_hi = ops.gather(what, st["send_hi"], dec.shift_hi[d]) if st["send_hi"] is not None else None
-            n_lo = st["recv_lo"][1] * w if st["recv_lo"] is not None else 0
-            n_hi = st["recv_hi"][1] * w if st["recv_hi"] is not None else 0
-            f_lo, f_hi = _exchange(dec, d, b_lo, b_hi, (n_lo, dt), (n_hi, dt))
-            if st["recv_lo"] is not None and f_lo is not None:
-                ops.scatter(what, st["ridx_lo"], f_lo)
-            if st["recv_hi"] is not None and f_hi is not None:
-                ops.scatter(what, st["ridx_hi"], f_hi)
+            n_lo, n_hi = st["n_send"]
+            m_hi, m_lo = st["n_recv"]
+            if n_lo + n_hi == 0 and m_hi + m_lo == 0:
+                continue
+            buf = ops.gather2(what, st["send_cat"], n_lo, dec.shift_lo[d], dec.shift_hi[d])
+            b_lo = buf[:n_lo * w] if st["send_lo"] is not None else None
+            b_hi = buf[n_lo * w:] if st["send_hi"] is not None else None
+            if dec.cpu_dim[d] == 1:
+                if dec.lo[d] is not None and dec.hi[d] is not None:       # periodic self-neighbour: [from_hi; from_lo] = [b_lo; b_hi]
+                    ops.scatter(what, st["ridx_cat"], buf)
+                continue
+            recv = torch.empty((m_hi + m_lo) * w, dtype=dt, device=buf.device)
+            _exchange(dec, d, b_lo, b_hi, (m_lo * w, dt), (m_hi * w, dt), out_lo=recv[m_hi * w:], out_hi=recv[:m_hi * w])
+            ops.scatter(what, st["ridx_cat"], recv)
 
 
 class DistributedMD:
@@ -241,6 +264,7 @@ class DistributedMD:
         self.dec, self.ops, self.ttm = dec, ops, ttm
         self.plan = None
         self.valid = False
+        self._halo_ready = False
         self.nrebuild = 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         if ttm:
@@ -287,10 +311,13 @@ class DistributedMD:
     # -- one MD step ------------------------------------------------------------------------------
     def md_step(self, step):
         ops = self.ops
+        if os.environ.get("IMDGPU_PY_TIMING"):
+            return self._md_step_timed(step)
         if not self.valid:
             self.rebuild()
-        else:
+        elif not self._halo_ready:
             self.plan.exchange(ops, 0)
+        self._halo_ready = False
         ops.forces_phase(1)
         if self.ttm:
             # calc_ttm needs pass 1's neighbour counts and feeds only the integrator: it runs on a side stream
@@ -309,12 +336,52 @@ class DistributedMD:
         if self.ttm:
             ops.ttm_join()
         ops.integrate()
+        # the position halo of the NEXT step is enqueued now, before the host blocks on the validity flag: its launch
+        # overhead hides behind that round trip (wasted only on the ~1 step in 17 that ends with a rebuild)
+        self.plan.exchange(ops, 0)
+        self._halo_ready = True
         flag = torch.tensor([ops.get_invalid()], dtype=torch.int32, device=ops.device)
         if self.world > 1:
             all_reduce_(flag, dist.ReduceOp.MAX)         # MPI_Allreduce MAX of check_nblist
         if int(flag.item()):
             self.valid = False
+            self._halo_ready = False
             ops.invalidate()
+
+    def _md_step_timed(self, step):
+        """Debugging aid (IMDGPU_PY_TIMING=1): the same step with a device synchronisation after every phase;
+        prints wall-clock milliseconds per phase (serialised, so the sum is larger than a normal step)."""
+        import time
+        ops, t = self.ops, {}
+
+        def lap(name, t0):
+            torch.cuda.synchronize()
+            t[name] = t.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
+            return time.perf_counter()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if not self.valid:
+            self.rebuild(); t0 = lap("rebuild", t0)
+        else:
+            self.plan.exchange(ops, 0); t0 = lap("halo_pos", t0)
+        ops.forces_phase(1); t0 = lap("pass1", t0)
+        if self.ttm:
+            blk = ops.ttm_local_block(step); allb = all_gather_flat(blk, self.world)
+            ops.ttm_apply_blocks(step, allb, self.world, self._ttm_offs); ops.ttm_lattice_step(step)
+            t0 = lap("ttm", t0)
+        ops.forces_phase(2); t0 = lap("pass2", t0)
+        self.plan.exchange(ops, 1); t0 = lap("halo_dF", t0)
+        ops.forces_phase(3); t0 = lap("pass3", t0)
+        ops.integrate(); t0 = lap("integrate", t0)
+        flag = torch.tensor([ops.get_invalid()], dtype=torch.int32, device=ops.device)
+        if self.world > 1:
+            all_reduce_(flag, dist.ReduceOp.MAX)
+        if int(flag.item()):
+            self.valid = False
+            ops.invalidate()
+        t0 = lap("flag", t0)
+        if dist.is_initialized() is False or dist.get_rank() == 0:
+            print("[py timing] step %d: " % step + " ".join("%s=%.3f" % kv for kv in t.items()), file=sys.stderr)
 
     def global_sums(self):
         s = self.ops.get_sums()
@@ -364,6 +431,16 @@ class GpuOps:
         sh = np.ascontiguousarray(shift, np.float64)
         self._ck(self.L.imdgpu_halo_gather(self.h, what, C.c_void_p(idx.data_ptr()), idx.numel(),
                                            sh.ctypes.data_as(C.POINTER(C.c_double)), C.c_void_p(out.data_ptr())))
+        return out
+
+    def gather2(self, what, idx, n_lo, shift_lo, shift_hi):
+        C = self.C
+        w, dt = WHAT_WIDTH[what]
+        out = torch.empty(idx.numel() * w, dtype=dt, device=self.device)
+        lo, hi = np.ascontiguousarray(shift_lo, np.float64), np.ascontiguousarray(shift_hi, np.float64)
+        dp = C.POINTER(C.c_double)
+        self._ck(self.L.imdgpu_halo_gather2(self.h, what, C.c_void_p(idx.data_ptr()), int(n_lo), idx.numel(),
+                                            lo.ctypes.data_as(dp), hi.ctypes.data_as(dp), C.c_void_p(out.data_ptr())))
         return out
 
     def scatter(self, what, idx, buf):

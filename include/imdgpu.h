@@ -198,6 +198,9 @@ int imdgpu_set_ghost_layout(imdgpu_ctx *ctx, const int *cell_start, const int *c
 /* what: 0 = (x,y,z,dF) record of 4 doubles, positions shifted by `shift` (periodic image,
  *       imd_comm_force_3d.c:247-266); 1 = dF only (1 double) [copy_dF]; 2 = type (int) */
 int imdgpu_halo_gather(imdgpu_ctx *ctx, int what, const int *dev_idx, int n, const double shift[3], void *dev_out);
+/* both faces of a stage in one launch: entries [0, n_lo) of dev_idx are the low face (shift_lo), the rest the high face */
+int imdgpu_halo_gather2(imdgpu_ctx *ctx, int what, const int *dev_idx, int n_lo, int n, const double shift_lo[3],
+                        const double shift_hi[3], void *dev_out);
 int imdgpu_halo_scatter(imdgpu_ctx *ctx, int what, const int *dev_idx, int n, const void *dev_in);
 /* migration along one direction: mark + count atoms whose cell belongs to the lower / higher neighbour rank,
  * pack them (10 doubles each: x y z px py pz mass type id pad), drop them and append the arrivals */

@@ -82,6 +82,11 @@ class NumpyOps:
             return torch.from_numpy(self.pos[i, 3].copy())
         return torch.zeros(len(i), dtype=torch.int32)
 
+    def gather2(self, what, idx, n_lo, shift_lo, shift_hi):
+        lo = self.gather(what, idx[:n_lo], shift_lo)
+        hi = self.gather(what, idx[n_lo:], shift_hi)
+        return torch.cat([lo, hi])
+
     def scatter(self, what, idx, buf):
         i = idx.numpy().astype(np.int64)
         if what == 0:
