@@ -780,29 +780,42 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile(TileArgs a)
     const unsigned long long dummy64 = (unsigned long long) dummy * 0x0001000100010001ull;
     unsigned long long w = dummy64;
     int m = 0;
-    for (int dx = 0; dx <= 2; dx++)
+    for (int dx = 0; dx <= ((a.dbg & 4) ? -1 : 2); dx++)
       for (int dy = 0; dy <= 2; dy++)
         for (int dz = 0; dz <= 2; dz++) {
           const int h = ((lx + dx) * T.hy + (ly + dy)) * T.hz + (lz + dz);
           const int s = hstart[h], e = hstart[h + 1];
-          for (int j0 = s; j0 < e; j0 += 4) {                 // four candidates in flight
-            double r2[4];
+          // two steps per neighbour cell: (1) branch-free distance tests, four candidates in flight, accepted ones
+          // recorded as bits; (2) the append loop runs over the set bits only (~10 % of the candidates pass)
+          for (int j0 = s; j0 < e; j0 += 32) {
+            const int cnt = e - j0 < 32 ? e - j0 : 32;
+            unsigned mask = 0;
+            // reads may run up to 3 slots past the cell (the next cell's atoms or the planes' padding): their bits are
+            // cleared below, so the loop needs no per-candidate bounds or self tests
+            for (int u0 = 0; u0 < cnt; u0 += 4) {
+              const double *px = sx + j0 + u0, *py = sy + j0 + u0, *pz = sz + j0 + u0;
+              double r2[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-              const int j = j0 + u < e ? j0 + u : e - 1;
-              const double ex = sx[j] - xi, ey = sy[j] - yi, ez = sz[j] - zi;
-              r2[u] = ex * ex + ey * ey + ez * ez;            // unfused, as the reference (imd_forces_nbl.c:218-222)
+              for (int u = 0; u < 4; u++) {
+                const double ex = px[u] - xi, ey = py[u] - yi, ez = pz[u] - zi;
+                r2[u] = ex * ex + ey * ey + ez * ez;          // unfused, as the reference (imd_forces_nbl.c:218-222)
+              }
+              unsigned four = 0;
+#pragma unroll
+              for (int u = 0; u < 4; u++) four |= (r2[u] < a.cellsz) ? (1u << u) : 0u;
+              mask |= four << u0;
             }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-              const int j = j0 + u;
-              if (j < e && j != slot && r2[u] < a.cellsz) {
-                w = (w >> 16) | ((unsigned long long) j << 48);
-                m++;
-                if ((m & 3) == 0) {
-                  if ((m >> 2) <= a.W4) lp[(size_t) ((m >> 2) - 1) * a.tile_cap] = w;
-                  w = dummy64;
-                }
+            mask &= cnt == 32 ? 0xffffffffu : ((1u << cnt) - 1u);
+            if (slot >= j0 && slot < j0 + 32) mask &= ~(1u << (slot - j0));   // not its own neighbour
+            if (a.dbg & 8) mask = 0;
+            while (mask) {                                   // ascending j: the reference's order inside a cell
+              const int j = j0 + __builtin_ctz(mask);
+              mask &= mask - 1;
+              w = (w >> 16) | ((unsigned long long) j << 48);
+              m++;
+              if ((m & 3) == 0) {
+                if ((m >> 2) <= a.W4) lp[(size_t) ((m >> 2) - 1) * a.tile_cap] = w;
+                w = dummy64;
               }
             }
           }
