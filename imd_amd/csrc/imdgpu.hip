@@ -1137,8 +1137,10 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
   if (is_short) a.counters[CNT_IS_SHORT] = 1;
 }
 
+// 144 VGPRs: three waves per SIMD then leave 80 registers free on EVERY SIMD, which is what one wave of the TTM
+// sub-step kernel needs -- the lattice chain that runs beside this pass gets four SIMDs per CU instead of one
 template <bool NT1>
-__global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass3_tile(TileArgs a)
+__global__ __launch_bounds__(TILE_MAXTHREADS) __attribute__((amdgpu_num_vgpr(144))) void k_pass3_tile(TileArgs a)
 {
   extern __shared__ double lds[];
   double *tr = lds;                                      // rho_h_tab, one type: + zero rows for r2 >= end (no mask)
