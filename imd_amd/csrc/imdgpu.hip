@@ -907,10 +907,6 @@ __device__ __forceinline__ void tab_index(const TabK &c, double arg, int &k, dou
   chi = a - (double) k;
 }
 
-// list word prefetch: the asm pins the use of the loaded value (and so the s_waitcnt) behind the
-// work on the current group of neighbours
-__device__ __forceinline__ uint2 pin_u2(uint2 v) { asm volatile("" : "+v"(v.x), "+v"(v.y)); return v; }
-
 template <bool PAIR, bool EAM, bool TTMN, bool NT1>
 __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile(TileArgs a)
 {
