@@ -1,0 +1,87 @@
+"""GPU edge cases (run with -m gpu): arrangements that take the less travelled branches of the tile kernels --
+crowded cells (more than 32 atoms: second staging sweep, tile_cap above the 768-thread workgroup), neighbour rows that
+outgrow the default width (list regrown), boxes whose cell counts are not multiples of the tile, a slab with empty
+cells, a box of a single tile.  Every case: both kernel families against the CPU oracle on the same input."""
+import numpy as np
+import pytest
+
+from imd_amd import lattice, potential
+from imd_amd.system import GpuSystem, global_cell_dim
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(nb, a, pbc=(1, 1, 1), jitter=0.05, vacuum=0.0, seed=1):
+    pair, rho, emb, r2cut = potential.synthetic_eam_tables()
+    cellsz = (np.sqrt(r2cut) + 0.5) ** 2
+    box = lattice.fcc_box(nb, a)
+    pos = lattice.fcc_positions(nb, a)
+    if vacuum > 0:                                     # open x: slab in the middle of a longer box
+        box = box.copy(); box[0, 0] += 2 * vacuum; pos = pos + np.array([vacuum, 0, 0])
+    rng = np.random.default_rng(seed)
+    pos = pos + rng.normal(scale=jitter, size=pos.shape)
+    mom = lattice.maxwell_momenta(len(pos), 26.9815, 0.03, seed=seed)
+    gd = global_cell_dim(box, cellsz)
+    dim = [g + 2 for g in gd]
+    return dict(box=box, pos=pos, mom=mom, dim=dim, cellsz=cellsz, tabs=(pair, rho, emb), pbc=pbc)
+
+
+def _oracle(c, cap):
+    o = po.OracleSystem(c["dim"], cap, 1, c["box"], c["pbc"], c["cellsz"], 0.5, 0.1)
+    for w, t in enumerate(c["tabs"]):
+        o.set_table(w, t.as_dict())
+    L = np.diag(c["box"])
+    p = c["pos"].copy()
+    for d in range(3):
+        if c["pbc"][d]:
+            p[:, d] %= L[d]
+    o.fill_from_positions(p, c["mom"], 26.9815)
+    o.calc_forces(0)
+    idn = o.gather_inner("nummer")
+    return o.gather_inner("kraft")[np.argsort(idn)], o.gather_inner("rho")[np.argsort(idn)], o.s.tot_pot_energy
+
+
+def _gpu(c, mode):
+    s = GpuSystem(c["box"], c["pbc"], c["dim"], 1, c["cellsz"], 0.5, 0.1)
+    s.set_option("mode", mode)
+    s.upload_tables(*c["tabs"])
+    s.upload_atoms(c["pos"], c["mom"], 26.9815)
+    r = s.calc_forces(0)
+    d = s.download(fields=("kraft", "nummer", "eam_rho"))
+    o = np.argsort(d["nummer"])
+    info = {k: s.get_info(k) for k in ("list_mode", "tile_cap", "tile_threads", "W", "tile_x", "tile_y", "tile_z")}
+    for st in range(3):                                # and the device loop keeps running on it
+        s.md_step(st)
+    assert np.isfinite(s.download(fields=("ort",))["ort"]).all()
+    s.close()
+    return d["kraft"][o], d["eam_rho"][o], r["tot_pot_energy"], info
+
+
+CASES = {
+    # a = 3.3 A: 1.85x the density -> ~40 atoms per cell, ~150 neighbours: rows regrow past W = 96, cells > 32 atoms
+    "crowded": dict(nb=(14, 14, 14), a=3.3, cap=96),
+    # 11 x 9 x 7 cells: no tile shape divides all three
+    "ragged_box": dict(nb=(20, 16, 13), a=4.05, cap=64),
+    # open x with vacuum: empty cells inside the tile halos
+    "slab": dict(nb=(10, 12, 12), a=4.05, cap=64, pbc=(0, 1, 1), vacuum=9.0),
+    # 3 x 3 x 3 cells: one tile, every halo cell is a periodic image
+    "single_tile": dict(nb=(6, 6, 6), a=4.05, cap=64),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_edge_case_both_families_vs_oracle(name):
+    k = dict(CASES[name])
+    cap = k.pop("cap")
+    c = _case(**k)
+    fo, ro, eo = _oracle(c, cap)
+    scale = np.abs(fo).max()
+    for mode in (0, 1):
+        f, r, e, info = _gpu(c, mode)
+        assert info["list_mode"] == mode, info
+        assert np.abs(f - fo).max() < 1e-9 * scale, (name, mode, info)
+        assert np.abs(r - ro).max() < 1e-11 * np.abs(ro).max()
+        assert abs(e - eo) < 1e-11 * abs(eo)
+        if name == "crowded" and mode == 1:
+            assert info["W"] > 96 and info["tile_cap"] >= 64
