@@ -47,7 +47,8 @@ extern "C" int imdgpu_set_ghost_layout(imdgpu_ctx *ctx, const int *cell_start, c
   return 0;
 }
 
-// what: 0 = position record (x,y,z,dF) as 4 doubles, shifted; 1 = dF only (1 double); 2 = type (int)
+// what: 0 = position record (x,y,z,dF) as 4 doubles, shifted; 1 = dF only (1 double); 2 = type (int);
+//       3 = shifted position only (3 doubles: the per-step halo, 24 instead of 32 bytes per atom on the wire)
 __global__ void k_halo_gather(int what, int n, const int *idx, const double4 *pos, const int *type, double sx,
                               double sy, double sz, void *out)
 {
@@ -56,6 +57,7 @@ __global__ void k_halo_gather(int what, int n, const int *idx, const double4 *po
   int i = idx[m];
   if (what == 0) { double4 r = pos[i]; r.x += sx; r.y += sy; r.z += sz; ((double4 *) out)[m] = r; }
   else if (what == 1) ((double *) out)[m] = pos[i].w;
+  else if (what == 3) { double4 r = pos[i]; double *o = (double *) out + 3 * (size_t) m; o[0] = r.x + sx; o[1] = r.y + sy; o[2] = r.z + sz; }
   else ((int *) out)[m] = type[i];
 }
 __global__ void k_halo_scatter(int what, int n, const int *idx, double4 *pos, int *type, const void *in)
@@ -65,6 +67,7 @@ __global__ void k_halo_scatter(int what, int n, const int *idx, double4 *pos, in
   int i = idx[m];
   if (what == 0) pos[i] = ((const double4 *) in)[m];
   else if (what == 1) pos[i].w = ((const double *) in)[m];
+  else if (what == 3) { const double *q = (const double *) in + 3 * (size_t) m; pos[i].x = q[0]; pos[i].y = q[1]; pos[i].z = q[2]; }
   else type[i] = ((const int *) in)[m];
 }
 
@@ -87,6 +90,10 @@ __global__ void k_halo_gather2(int what, int n_lo, int n, const int *idx, const 
   const bool lo = m < n_lo;
   if (what == 0) { double4 r = pos[i]; r.x += lo ? lx : hx; r.y += lo ? ly : hy; r.z += lo ? lz : hz; ((double4 *) out)[m] = r; }
   else if (what == 1) ((double *) out)[m] = pos[i].w;
+  else if (what == 3) {
+    double4 r = pos[i]; double *o = (double *) out + 3 * (size_t) m;
+    o[0] = r.x + (lo ? lx : hx); o[1] = r.y + (lo ? ly : hy); o[2] = r.z + (lo ? lz : hz);
+  }
   else ((int *) out)[m] = type[i];
 }
 extern "C" int imdgpu_halo_gather2(imdgpu_ctx *ctx, int what, const int *dev_idx, int n_lo, int n, const double shift_lo[3],

@@ -172,7 +172,7 @@ def _exchange(dec, d, buf_lo, buf_hi, like_lo, like_hi, group=None, out_lo=None,
     return from_lo, from_hi
 
 
-WHAT_WIDTH = {0: (4, torch.float64), 1: (1, torch.float64), 2: (1, torch.int32)}
+WHAT_WIDTH = {0: (4, torch.float64), 1: (1, torch.float64), 2: (1, torch.int32), 3: (3, torch.float64)}
 
 
 class HaloPlan:
@@ -316,7 +316,7 @@ class DistributedMD:
         if not self.valid:
             self.rebuild()
         elif not self._halo_ready:
-            self.plan.exchange(ops, 0)
+            self.plan.exchange(ops, 3)
         self._halo_ready = False
         ops.forces_phase(1)
         if self.ttm:
@@ -338,7 +338,7 @@ class DistributedMD:
         ops.integrate()
         # the position halo of the NEXT step is enqueued now, before the host blocks on the validity flag: its launch
         # overhead hides behind that round trip (wasted only on the ~1 step in 17 that ends with a rebuild)
-        self.plan.exchange(ops, 0)
+        self.plan.exchange(ops, 3)                       # xyz only: dF travels separately after the embedding pass
         self._halo_ready = True
         flag = torch.tensor([ops.get_invalid()], dtype=torch.int32, device=ops.device)
         if self.world > 1:
@@ -363,7 +363,7 @@ class DistributedMD:
         if not self.valid:
             self.rebuild(); t0 = lap("rebuild", t0)
         else:
-            self.plan.exchange(ops, 0); t0 = lap("halo_pos", t0)
+            self.plan.exchange(ops, 3); t0 = lap("halo_pos", t0)
         ops.forces_phase(1); t0 = lap("pass1", t0)
         if self.ttm:
             blk = ops.ttm_local_block(step); allb = all_gather_flat(blk, self.world)

@@ -196,7 +196,8 @@ int imdgpu_get_cell_tables(imdgpu_ctx *ctx, int *cell_start /*nallcells*/, int *
 int imdgpu_autotile(imdgpu_ctx *ctx, int *changed);
 int imdgpu_set_ghost_layout(imdgpu_ctx *ctx, const int *cell_start, const int *cell_cnt, int nghost);
 /* what: 0 = (x,y,z,dF) record of 4 doubles, positions shifted by `shift` (periodic image,
- *       imd_comm_force_3d.c:247-266); 1 = dF only (1 double) [copy_dF]; 2 = type (int) */
+ *       imd_comm_force_3d.c:247-266); 1 = dF only (1 double) [copy_dF]; 2 = type (int);
+ *       3 = shifted position only (3 doubles): the per-step position halo */
 int imdgpu_halo_gather(imdgpu_ctx *ctx, int what, const int *dev_idx, int n, const double shift[3], void *dev_out);
 /* both faces of a stage in one launch: entries [0, n_lo) of dev_idx are the low face (shift_lo), the rest the high face */
 int imdgpu_halo_gather2(imdgpu_ctx *ctx, int what, const int *dev_idx, int n_lo, int n, const double shift_lo[3],

@@ -80,6 +80,8 @@ class NumpyOps:
             return torch.from_numpy(out.reshape(-1))
         if what == 1:
             return torch.from_numpy(self.pos[i, 3].copy())
+        if what == 3:
+            return torch.from_numpy((self.pos[i, :3] + np.asarray(shift)).reshape(-1))
         return torch.zeros(len(i), dtype=torch.int32)
 
     def gather2(self, what, idx, n_lo, shift_lo, shift_hi):
@@ -93,6 +95,8 @@ class NumpyOps:
             self.pos[i] = buf.numpy().reshape(-1, 4)
         elif what == 1:
             self.pos[i, 3] = buf.numpy()
+        elif what == 3:
+            self.pos[i, :3] = buf.numpy().reshape(-1, 3)
 
     # -- migration -------------------------------------------------------------------
     def migrate_scan(self, d):
