@@ -46,6 +46,9 @@ def _worker(rank, world, port, cpu_dim, nsteps, q):
 def test_distributed_trajectory_matches_reference(cpu_dim):
     world = int(np.prod(cpu_dim))
     nsteps = 20
+    # the workers are spawned: two threads each keeps 2-4 dense-numpy ranks from oversubscribing the CI cores
+    for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ.setdefault(v, "2")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
