@@ -28,8 +28,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--box", type=int, nargs=3, default=[136, 136, 136],
                     help="FCC unit cells per direction PER GPU (136^3*4 = 10 061 824 atoms)")
     ap.add_argument("--temp", type=float, default=0.0258)
