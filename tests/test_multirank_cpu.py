@@ -42,7 +42,7 @@ def _worker(rank, world, port, cpu_dim, nsteps, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("cpu_dim", [(2, 1, 1), (2, 2, 1)])
+@pytest.mark.parametrize("cpu_dim", [(2, 1, 1), (2, 2, 1), (2, 2, 2)])      # 2x2x2 is the 8-GPU layout of bench.py
 def test_distributed_trajectory_matches_reference(cpu_dim):
     world = int(np.prod(cpu_dim))
     nsteps = 20
