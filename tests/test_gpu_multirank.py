@@ -103,8 +103,11 @@ def test_two_ranks_nve(cpu_dim):
     assert all(r[3] >= 2 for r in res)
 
 
-def test_two_ranks_ttm():
-    res = _run("ttm_2048", (2, 1, 1), 3, True)
+@pytest.mark.parametrize("cpu_dim", [(2, 1, 1), (2, 2, 1)])
+def test_ranks_ttm(cpu_dim):
+    """2 and 4 ranks (the 2x2x1 layout of bench.py --gpus 4) sharing the one GPU: the replicated lattice, fed by
+    all-gathered update_fd blocks, must equal the reference's after the sub-steps."""
+    res = _run("ttm_2048", cpu_dim, 3, True)
     G = gu.load("ttm_2048")
     ids = np.concatenate([r[1]["nummer"] for r in res]); pos = np.concatenate([r[1]["ort"] for r in res])
     nn = np.concatenate([r[1]["numneighs"] for r in res])
