@@ -34,6 +34,8 @@ def parse():
                     help="FCC unit cells per direction PER GPU (136^3*4 = 10 061 824 atoms)")
     ap.add_argument("--temp", type=float, default=0.0258)
     ap.add_argument("--no-ttm", action="store_true")
+    ap.add_argument("--fd-ext", type=int, nargs=3, default=[2, 2, 2],
+                    help="MD cells per FD cell (BASELINE config 3: 2 2 2); 1 1 1 gives the 8x lattice an 8-GPU run replicates")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-box", type=int, default=48, help="unit cells per direction of the CPU sample")
     ap.add_argument("--cpu-steps", type=int, default=30)
@@ -54,7 +56,7 @@ def build_system(args, rank, world, device):
     nbl_margin = 0.5
     cellsz = (np.sqrt(r2cut) + nbl_margin) ** 2
     ttm = not args.no_ttm
-    fd_ext = (2, 2, 2)
+    fd_ext = tuple(args.fd_ext)
     if world == 1:
         cpu_dim, coord = (1, 1, 1), (0, 0, 0)
     else:
@@ -221,7 +223,7 @@ def main():
             "config": {"workload": "FCC Al %dx%dx%d unit cells per GPU (%d atoms/GPU), synthetic tabulated EAM "
                                    "(r_c 6.5 A), nbl_margin 0.5, dt 0.1, T0 %.4f eV, %s" %
                                    (args.box[0], args.box[1], args.box[2], natoms, args.temp,
-                                    "NVE, no TTM" if args.no_ttm else "3D TTM fd_ext 2 2 2, diff_substeps 100"),
+                                    "NVE, no TTM" if args.no_ttm else "3D TTM fd_ext %d %d %d, diff_substeps 100" % tuple(args.fd_ext)),
                        "atoms_per_gpu": natoms, "cells": list(gdim), "half_list_entries_per_atom": M,
                        "max_neighbours": maxn, "list_rebuilds_in_timed_region": rebuilds,
                        "kernel_family": "lds_tiles" if sysm.get_info("list_mode") == 1 else "global_gather",

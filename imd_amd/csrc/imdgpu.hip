@@ -1407,6 +1407,11 @@ extern "C" int imdgpu_set_option(imdgpu_ctx *ctx, const char *name, int value)
     ctx->tile[name[5] - 'x'] = value; ctx->autotiled = 1;
     return ctx->have_geometry ? setup_tiles(ctx) : 0;
   }
+  if (!strcmp(name, "ttm_decomposed")) {         // before ttm_init
+    if (ctx->ttm) return imdgpu_fail(ctx, "ttm_decomposed must be set before ttm_init");
+    ctx->ttm_decomposed = value ? 1 : 0;
+    return 0;
+  }
   if (!strcmp(name, "external_halo")) {          // before set_geometry: the host layer owns the ghost cells even on one rank
     if (ctx->have_geometry) return imdgpu_fail(ctx, "external_halo must be set before set_geometry");
     ctx->force_external_halo = value ? 1 : 0;

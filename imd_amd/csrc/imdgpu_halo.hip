@@ -281,6 +281,8 @@ extern "C" int imdgpu_get_invalid(imdgpu_ctx *ctx, int *flag)
   HIPCHK(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, CNT_N * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (flag) *flag = ctx->h_counters[CNT_INVALID];
+  if (ctx->h_counters[CNT_TTM_TIMEOUT])
+    return imdgpu_fail(ctx, "TTM mailbox: a neighbour rank did not publish its lattice faces in time (rank gone or stalled)");
   return 0;
 }
 

@@ -88,6 +88,7 @@ struct imdgpu_ctx {
   // nbr[k*stride+i]; mode 1: per tile, uint16 LDS-slot indices tl16[(tile*W+k)*tile_cap+a]
   int mode = 1, list_mode = 0, autotiled = 0;
   int force_external_halo = 0;
+  int ttm_decomposed = 0;         // several ranks: one TTM lattice block per rank, faces through the shared-memory mailbox
   int external_halo = 0;          // ghost atoms are supplied through imdgpu_halo_scatter (multi-rank decomposition)
   int *mig_idx[2]{nullptr, nullptr}; int mig_n[2]{0, 0}, mig_cap = 0; int *mig_flag = nullptr;
   int *nbr = nullptr, *nbr_cnt = nullptr;
@@ -175,7 +176,7 @@ Geo imdgpu_make_geo(const imdgpu_ctx *c);
 
 // device counters (ints) and d_sums slots shared by the translation units
 enum { CNT_MAXNBR = 0, CNT_IS_SHORT = 1, CNT_OUTSIDE = 2, CNT_NGHOST = 3, CNT_INVALID = 4, CNT_MAXOWN = 5,
-       CNT_MAXHALO = 6, CNT_N = 16 };
+       CNT_MAXHALO = 6, CNT_TTM_TIMEOUT = 7, CNT_N = 16 };
 enum { SUM_EPOT = 0, SUM_VIRIAL = 1, SUM_EKIN = 8, SUM_MAXDISP = 9, SUM_N = 16 };
 
 // sum of kinetic partials, max of displacement partials; decides list validity

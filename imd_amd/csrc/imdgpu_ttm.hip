@@ -16,6 +16,19 @@
 
 struct EosDev { int nx, ny; double xmin, xmax, ymin, ymax; const double *z; };
 
+// descriptor of the shared-memory mailbox of a decomposed lattice (explained above the kernels that use it)
+struct MailboxDev {
+  char *base;                    // device-visible address of the shared region (all ranks)
+  size_t stride;                 // bytes per rank
+  size_t o_nat, o_dat;           // offsets inside a rank's part: natoms faces, data faces [2][6][maxface][2]
+  int rank, nranks, maxface;
+  int nbr[6];                    // neighbour rank per direction 2*d+side (side 0 = low), -1 = open boundary
+  int nwg_sub[6], nwg_push[6];   // workgroups that publish on face b in the sub-step / push kernel
+  unsigned long long *gbase;     // device: index of the first publication of the current MD step
+  int *facecnt;                  // device [12]: finished publishers per face (monotone), sub-step then push kernel
+  int *counters;                 // ctx->d_counters
+};
+
 struct TtmState {
   int dim[3]{}, ext[3]{}, md_dim[3]{}, pbc[3]{};
   int ncell = 0, ninner = 0;
@@ -31,6 +44,11 @@ struct TtmState {
   EosDev cve{}, ee{};
   double *d_red = nullptr;       // reduction scratch
   hipGraphExec_t graph = nullptr; int graph_cur = -1, graph_kcur = -1; double graph_tau = 0;
+  // decomposed lattice (several ranks): faces travel through a host shared-memory mailbox (see Mailbox below)
+  void *mb_host = nullptr; size_t mb_bytes = 0; int mb_rank = -1, mb_nranks = 0;
+  MailboxDev mbd{};
+  unsigned long long *d_gbase = nullptr; // index of the next face publication (monotone over the whole run)
+  int *d_facecnt = nullptr;              // per face: workgroups that finished publishing (monotone)
 };
 
 // physical constants of the reference, globals.h:324-331,1190
@@ -70,6 +88,102 @@ __device__ __forceinline__ int wsumi(int v)
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
   return __shfl(v, 0, 64);
 }
+
+// ---------------------------------------------------------------------------
+// Decomposed lattice (one block per rank): the ghost faces of {natoms, temp, fd_k} that the reference exchanges with
+// MPI_Sendrecv after every diffusion sub-step (ttm_fill_ghost_layers, imd_ttm_3D.c:3314-3504) travel through a
+// MAILBOX in host shared memory that the GPUs of all ranks of the node read and write directly: the sub-step kernel
+// of rank A stores its boundary layer into the slot of its neighbour B and raises B's flag; B's next sub-step kernel
+// polls that flag before it reads the slot.  No collective, no extra launch, no CU held by a communication kernel
+// (RCCL's workgroups cannot be co-resident with the persistent force kernels); the data is a few
+// hundred KB per sub-step, so PCIe-attached host memory is plenty.  Publications are numbered by one monotone index;
+// two slot parities make a writer that is one sub-step ahead harmless.  Every spin is bounded.
+// ---------------------------------------------------------------------------
+#define MB_SPIN_MAX 2000000L
+__device__ __forceinline__ unsigned long long mb_ld(const unsigned long long *p)
+{ return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void mb_st(unsigned long long *p, unsigned long long v)
+{ __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ unsigned long long *mb_flag(const MailboxDev &M, int rank, int dir)
+{ return (unsigned long long *) (M.base + (size_t) rank * M.stride) + dir; }
+__device__ __forceinline__ unsigned long long *mb_abort(const MailboxDev &M) { return (unsigned long long *) (M.base + 64); }
+__device__ __forceinline__ double *mb_dat(const MailboxDev &M, int rank, int parity, int dir, int idx)
+{ return (double *) (M.base + (size_t) rank * M.stride + M.o_dat) + (((size_t) parity * 6 + dir) * M.maxface + idx) * 2; }
+__device__ __forceinline__ double mb_ldd(const double *p)      // data written by another GPU: never from a cache
+{ return __longlong_as_double((long long) __hip_atomic_load((const unsigned long long *) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)); }
+__device__ __forceinline__ int mb_ldi(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ int *mb_nat(const MailboxDev &M, int rank, int dir, int idx)
+{ return (int *) (M.base + (size_t) rank * M.stride + M.o_nat) + (size_t) dir * M.maxface + idx; }
+// wait until my flag for direction dir shows `need` publications; false on abort/time-out (results are then invalid,
+// CNT_TTM_TIMEOUT is set and reported by the host)
+__device__ bool mb_wait(const MailboxDev &M, int dir, unsigned long long need)
+{
+  const unsigned long long *f = mb_flag(M, M.rank, dir);
+  for (long it = 0; it < MB_SPIN_MAX; it++) {
+    if (mb_ld(f) >= need) return true;
+    if (mb_ld(mb_abort(M))) return false;
+    __builtin_amdgcn_s_sleep(16);
+  }
+  mb_st(mb_abort(M), 1ull);
+  M.counters[CNT_TTM_TIMEOUT] = 1;
+  return false;
+}
+// face index of an inner cell (i,j,k) on a face with normal d
+__device__ __forceinline__ int mb_fidx(const Lat &L, int d, int i, int j, int k)
+{
+  const int c[3] = {i, j, k};
+  const int d1 = (d + 1) % 3, d2 = (d + 2) % 3;
+  return (c[d1] - 1) * (L.dim[d2] - 2) + (c[d2] - 1);
+}
+// one publisher (workgroup) is done with face b: the last one of this round raises the neighbour's flag
+__device__ __forceinline__ void mb_done(const MailboxDev &M, int b, int cnt_slot, int nwg, unsigned long long newflag)
+{
+  const int old = atomicAdd(&M.facecnt[cnt_slot], 1);
+  if ((old + 1) % nwg == 0) mb_st(mb_flag(M, M.nbr[b], b ^ 1), newflag);
+}
+
+// first publication of an MD step (index *gbase): natoms, temp and fd_k of my six boundary layers after FILLMESH
+__global__ void k_ttm_push_faces(Lat L, MailboxDev M, const int *natoms, const double *temp, const double *fd_k)
+{
+  const int b = blockIdx.y, d = b >> 1, side = b & 1;
+  const int d1 = (d + 1) % 3, d2 = (d + 2) % 3, n1 = L.dim[d1] - 2, n2 = L.dim[d2] - 2;
+  if (M.nbr[b] < 0) return;
+  const unsigned long long g = *M.gbase;
+  // the neighbour must have finished the previous MD step's last sub-step before its slot is overwritten
+  if (g > 0 && !mb_wait(M, b, g)) return;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < n1 * n2) {
+    int c[3];
+    c[d] = side ? L.dim[d] - 2 : 1; c[d1] = idx / n2 + 1; c[d2] = idx % n2 + 1;
+    const int cell = fidx(L, c[0], c[1], c[2]);
+    double *o = mb_dat(M, M.nbr[b], (int) (g & 1), b ^ 1, idx);
+    o[0] = temp[cell]; o[1] = fd_k[cell];
+    *mb_nat(M, M.nbr[b], b ^ 1, idx) = natoms[cell];
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) mb_done(M, b, 6 + b, M.nwg_push[b], g + 1);
+}
+// after the sub-steps: the neighbours' final layers into the ghost cells of the arrays (cell activation of the next
+// step and downloads read them), then the publication index moves on
+__global__ void k_ttm_pull_ghosts(Lat L, MailboxDev M, int nsub, int *natoms, double *temp, double *fd_k)
+{
+  const int b = blockIdx.y, d = b >> 1, side = b & 1;
+  const int d1 = (d + 1) % 3, d2 = (d + 2) % 3, n1 = L.dim[d1] - 2, n2 = L.dim[d2] - 2;
+  const unsigned long long g = *M.gbase + (unsigned long long) nsub;       // index of the last publication of this step
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  int c[3];
+  c[d] = side ? L.dim[d] - 1 : 0; c[d1] = idx / n2 + 1; c[d2] = idx % n2 + 1;
+  if (M.nbr[b] < 0) { if (idx < n1 * n2) natoms[fidx(L, c[0], c[1], c[2])] = 0; return; }
+  if (!mb_wait(M, b, g + 1)) return;
+  if (idx < n1 * n2) {
+    const int cell = fidx(L, c[0], c[1], c[2]);
+    const double *q = mb_dat(M, M.rank, (int) (g & 1), b, idx);
+    temp[cell] = mb_ldd(q); fd_k[cell] = mb_ldd(q + 1);
+    natoms[cell] = mb_ldi(mb_nat(M, M.rank, b, idx));
+  }
+}
+__global__ void k_ttm_advance_base(unsigned long long *gbase, int nsub) { *gbase += (unsigned long long) nsub + 1ull; }
 
 // ---------------------------------------------------------------------------
 // update_fd: one wavefront per FD cell gathers its fd_ext^3 MD cells
@@ -380,11 +494,14 @@ __global__ void k_ttm_ghosts(Lat L, int *natoms, double *temp, double *fd_k)
 // WRAP: ghost-shell cells are not read from memory but resolved on the fly (periodic direction: the
 // opposite inner cell; open direction: empty), i.e. ttm_fill_ghost_layers is folded into the load --
 // valid when the lattice is not split over ranks.
-template <bool FUSE_MESH, bool WRAP>
+// MB: decomposed lattice, ghost FACES come from / go to the shared-memory mailbox (sub = sub-step number of this
+// launch: reads publication *gbase + sub, publishes *gbase + sub + 1); edges and corners of the ghost shell are never
+// read by the 7-point stencil.
+template <bool FUSE_MESH, bool WRAP, bool MB>
 __global__ __launch_bounds__(DT_X *DT_Y *DT_Z) void k_ttm_diff(
     Lat L, double tau, int nsub, int steps, const int *natoms, const double *T1, double *T2, double *U1, double *U2,
     const double *fd_k, double *fd_k_out, double *Ce, double *fd_g, const double *md_temp, const double *source,
-    const double *dens, double *xi, double *Zo, double *neo, EosDev cve, EosDev ee)
+    const double *dens, double *xi, double *Zo, double *neo, EosDev cve, EosDev ee, MailboxDev M, int sub)
 {
   __shared__ double sT[DT_X + 2][DT_Y + 2][DT_Z + 2];
   __shared__ double sK[DT_X + 2][DT_Y + 2][DT_Z + 2];
@@ -399,20 +516,48 @@ __global__ __launch_bounds__(DT_X *DT_Y *DT_Z) void k_ttm_diff(
   const int nbz = (L.dim[2] - 2 + DT_Z - 1) / DT_Z, nby = (L.dim[1] - 2 + DT_Y - 1) / DT_Y;
   const int bz = blockIdx.x % nbz, by = (blockIdx.x / nbz) % nby, bx = blockIdx.x / (nbz * nby);
   const int i0 = bx * DT_X, j0 = by * DT_Y, k0 = bz * DT_Z;     // tile origin in ghost-including coordinates
+  const int o0[3] = {i0, j0, k0}, dt[3] = {DT_X, DT_Y, DT_Z};
+  unsigned long long g = 0;
+  bool mb_ok = true;
+  if (MB) {
+    g = *M.gbase + (unsigned long long) sub;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {                               // faces this tile's halo reaches
+      if (o0[d] == 0 && M.nbr[2 * d] >= 0) mb_ok &= mb_wait(M, 2 * d, g + 1);
+      if (o0[d] + dt[d] + 1 >= L.dim[d] - 1 && M.nbr[2 * d + 1] >= 0) mb_ok &= mb_wait(M, 2 * d + 1, g + 1);
+    }
+  }
   for (int s = threadIdx.x; s < (DT_X + 2) * (DT_Y + 2) * (DT_Z + 2); s += blockDim.x) {
     int lz = s % (DT_Z + 2), ly = (s / (DT_Z + 2)) % (DT_Y + 2), lx = s / ((DT_Z + 2) * (DT_Y + 2));
     int gi = i0 + lx, gj = j0 + ly, gk = k0 + lz;
     double t = 0, kk = 0; int n = 0;
     if (gi < L.dim[0] && gj < L.dim[1] && gk < L.dim[2]) {
       bool empty = false;
-      if (WRAP) {
-        int g[3] = {gi, gj, gk};
+      if (MB) {
+        const int gc[3] = {gi, gj, gk};
+        int ng = 0, dir = -1;
 #pragma unroll
         for (int d = 0; d < 3; d++) {
-          if (g[d] == 0) { if (L.pbc[d] == 1) g[d] = L.dim[d] - 2; else empty = true; }
-          else if (g[d] == L.dim[d] - 1) { if (L.pbc[d] == 1) g[d] = 1; else empty = true; }
+          if (gc[d] == 0) { ng++; dir = 2 * d; }
+          else if (gc[d] == L.dim[d] - 1) { ng++; dir = 2 * d + 1; }
         }
-        gi = g[0]; gj = g[1]; gk = g[2];
+        if (ng == 1) {
+          empty = true;                                        // not from the arrays: from the neighbour's publication
+          if (M.nbr[dir] >= 0 && mb_ok) {
+            const int fi = mb_fidx(L, dir >> 1, gi, gj, gk);
+            const double *q = mb_dat(M, M.rank, (int) (g & 1), dir, fi);
+            t = mb_ldd(q); kk = mb_ldd(q + 1); n = mb_ldi(mb_nat(M, M.rank, dir, fi));
+          }
+        } else if (ng >= 2) empty = true;
+      }
+      if (WRAP) {
+        int g3[3] = {gi, gj, gk};
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+          if (g3[d] == 0) { if (L.pbc[d] == 1) g3[d] = L.dim[d] - 2; else empty = true; }
+          else if (g3[d] == L.dim[d] - 1) { if (L.pbc[d] == 1) g3[d] = 1; else empty = true; }
+        }
+        gi = g3[0]; gj = g3[1]; gk = g3[2];
       }
       if (!empty) { int c = fidx(L, gi, gj, gk); t = T1[c]; kk = fd_k[c]; n = natoms[c]; }
     }
@@ -420,40 +565,72 @@ __global__ __launch_bounds__(DT_X *DT_Y *DT_Z) void k_ttm_diff(
   }
   __syncthreads();
   const int i = i0 + tx + 1, j = j0 + ty + 1, k = k0 + tz + 1;
-  if (i > L.dim[0] - 2 || j > L.dim[1] - 2 || k > L.dim[2] - 2) return;
-  const int c = fidx(L, i, j, k), m = L.fd_min_atoms;
+  const bool inside = !(i > L.dim[0] - 2 || j > L.dim[1] - 2 || k > L.dim[2] - 2);
+  if (!MB && !inside) return;
+  const int c = inside ? fidx(L, i, j, k) : 0, m = L.fd_min_atoms;
   const int lx = tx + 1, ly = ty + 1, lz = tz + 1;
-  const int nat = sN[lx][ly][lz];
-  if (nat < m) {
+  const int nat = inside ? sN[lx][ly][lz] : 0;
+  double Tn = 0.0, knew = 0.0;
+  if (inside && nat < m) {
     if (FUSE_MESH) { fd_k_out[c] = 0.0; fd_g[c] = 0.0; Zo[c] = 0.0; neo[c] = 0.0; Ce[c] = 0.0; }
-    return;
+    if (!MB) return;
   }
+  if (inside && nat >= m) {
   const double Te = sT[lx][ly][lz], kk = sK[lx][ly][lz];
   const double invxsq = L.invhsq[0], invysq = L.invhsq[1], invzsq = L.invhsq[2];
 #define NB(dx, dy, dz, TT, KK) \
   double TT, KK; if (sN[lx + dx][ly + dy][lz + dz] < m) { TT = Te; KK = kk; } else { TT = sT[lx + dx][ly + dy][lz + dz]; KK = sK[lx + dx][ly + dy][lz + dz]; }
   NB(1, 0, 0, xaT, xaK) NB(-1, 0, 0, xbT, xbK) NB(0, 1, 0, yaT, yaK) NB(0, -1, 0, ybT, ybK) NB(0, 0, 1, zaT, zaK) NB(0, 0, -1, zbT, zbK)
 #undef NB
-  const double ce = Ce[c], g = fd_g[c], Tl = md_temp[c];
-  const double Tn = tau / ce *
+  const double ce = Ce[c], gg = fd_g[c], Tl = md_temp[c];
+  Tn = tau / ce *
       ( ( ((kk + xaK) / 2 * (xaT - Te) * invxsq)
          - ((kk + xbK) / 2 * (Te - xbT) * invxsq)
          + ((kk + yaK) / 2 * (yaT - Te) * invysq)
          - ((kk + ybK) / 2 * (Te - ybT) * invysq)
          + ((kk + zaK) / 2 * (zaT - Te) * invzsq)
          - ((kk + zbK) / 2 * (Te - zbT) * invzsq) )
-        - g * (Te - Tl)
+        - gg * (Te - Tl)
         + source[c]
       ) + Te;
   T2[c] = Tn;
   U2[c] = U1[c] + (Tn - Te) * ce * L.vol / ((double) nat);
-  xi[c] += (Tn - Tl) * L.xi_fac * g / (Tl * dens[c]);
+  xi[c] += (Tn - Tl) * L.xi_fac * gg / (Tl * dens[c]);
   if (FUSE_MESH) {                 // do_FILLMESH of the same cell with the new temperature
     MeshOut o = mesh_props(L, cve, Tn, Tl, dens[c]);
     Zo[c] = o.Z; neo[c] = o.ne; Ce[c] = o.Ce; fd_k_out[c] = o.k; fd_g[c] = o.g;
+    knew = o.k;
     if (steps < 1) {               // do_FILLMESH re-initialises U from the EOS on every call of step 0 (:614-623)
       double u = eos_ee(ee, dens[c], Tn * 11604.5) * 26.9815 * C_AMU * C_J2EV;
       U1[c] = u; U2[c] = u;
+    }
+  }
+  }
+  if (MB) {
+    // publish my boundary layers (new temp, new fd_k) into the neighbours' slots, then count this workgroup in
+    if (inside) {
+      const int cc[3] = {i, j, k};
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        if (cc[d] == 1 && M.nbr[2 * d] >= 0) {
+          double *q = mb_dat(M, M.nbr[2 * d], (int) ((g + 1) & 1), 2 * d + 1, mb_fidx(L, d, i, j, k));
+          q[0] = Tn; q[1] = knew;
+        }
+        if (cc[d] == L.dim[d] - 2 && M.nbr[2 * d + 1] >= 0) {
+          double *q = mb_dat(M, M.nbr[2 * d + 1], (int) ((g + 1) & 1), 2 * d, mb_fidx(L, d, i, j, k));
+          q[0] = Tn; q[1] = knew;
+        }
+      }
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        if (o0[d] == 0 && M.nbr[2 * d] >= 0) mb_done(M, 2 * d, 2 * d, M.nwg_sub[2 * d], g + 2);
+        if (o0[d] + 1 <= L.dim[d] - 2 && L.dim[d] - 2 <= o0[d] + dt[d] && M.nbr[2 * d + 1] >= 0)
+          mb_done(M, 2 * d + 1, 2 * d + 1, M.nwg_sub[2 * d + 1], g + 2);
+      }
     }
   }
 }
@@ -563,6 +740,9 @@ void imdgpu_ttm_free(imdgpu_ctx *ctx)
                   t->md_temp, t->source, t->vcom, t->dens, t->fd_g, t->Z, t->Ce, t->ne, t->cve_z, t->ee_z, t->d_red};
   for (void *p : ptrs) if (p) (void) hipFree(p);
   if (t->graph) (void) hipGraphExecDestroy(t->graph);
+  if (t->mb_host) (void) hipHostUnregister(t->mb_host);
+  if (t->d_gbase) (void) hipFree(t->d_gbase);
+  if (t->d_facecnt) (void) hipFree(t->d_facecnt);
   delete t;
   ctx->ttm = nullptr;
 }
@@ -584,8 +764,8 @@ extern "C" int imdgpu_ttm_init(imdgpu_ctx *ctx, const imdgpu_ttm_params *par)
     // blocks are all-gathered once per MD step, the cheap diffusion sub-steps run redundantly everywhere:
     // no per-sub-step ghost exchange).  One rank: global == local.
     t->ldim[d] = (ctx->dim[d] - 2) / par->fd_ext[d];
-    t->off[d] = ctx->my_coord[d] * t->ldim[d];
-    t->dim[d] = t->ldim[d] * ctx->cpu_dim[d] + 2;
+    t->off[d] = ctx->ttm_decomposed ? 0 : ctx->my_coord[d] * t->ldim[d];
+    t->dim[d] = ctx->ttm_decomposed ? t->ldim[d] + 2 : t->ldim[d] * ctx->cpu_dim[d] + 2;
     // fd_h = fd_ext * (box/global_cell_dim), imd_geom_3d.c:243-246 (orthorhombic diagonal like the reference)
     t->h[d] = par->fd_ext[d] * ctx->box[4 * d] * (1.0 / ctx->gdim[d]);
   }
@@ -759,9 +939,9 @@ extern "C" int imdgpu_ttm_diff(imdgpu_ctx *ctx, double tau)
 {
   NEED_TTM();
   ProfScope ps(ctx, PROF_TTM_DIFF);
-  hipLaunchKernelGGL((k_ttm_diff<false, false>), dim3(diff_grid(t)), dim3(DT_X * DT_Y * DT_Z), 0, ctx->stream, L, tau, t->nsub, 1,
+  hipLaunchKernelGGL((k_ttm_diff<false, false, false>), dim3(diff_grid(t)), dim3(DT_X * DT_Y * DT_Z), 0, ctx->stream, L, tau, t->nsub, 1,
                      t->natoms, t->temp[t->cur], t->temp[t->cur ^ 1], t->U[t->cur], t->U[t->cur ^ 1], t->fd_k[t->kcur],
-                     t->fd_k[t->kcur], t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve, t->ee);
+                     t->fd_k[t->kcur], t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve, t->ee, MailboxDev{}, 0);
   HIPCHK(hipGetLastError());
   t->cur ^= 1;                                        // l1 <-> l2
   return 0;
@@ -782,18 +962,24 @@ extern "C" int imdgpu_ttm_cfl_maxdt(imdgpu_ctx *ctx, int steps, double *out)
 // One fused sub-step: do_DIFF + do_FILLMESH (own cell, new temperature) in one
 // launch, then the ghost faces.  fd_k is double buffered because the stencil of
 // the same launch still needs the neighbours' old kappa.
-static int launch_substep_fused(imdgpu_ctx *ctx, TtmState *t, const Lat &L, double tau, int steps)
+static int launch_substep_fused(imdgpu_ctx *ctx, TtmState *t, const Lat &L, double tau, int steps, int sub = 0)
 {
-  hipLaunchKernelGGL((k_ttm_diff<true, true>), dim3(diff_grid(t)), dim3(DT_X * DT_Y * DT_Z), 0, ctx->stream, L, tau, t->nsub, steps,
+  if (t->mb_host) {                // decomposed lattice: ghost faces through the mailbox
+    MailboxDev M = t->mbd;
+    hipLaunchKernelGGL((k_ttm_diff<true, false, true>), dim3(diff_grid(t)), dim3(DT_X * DT_Y * DT_Z), 0, ctx->stream, L, tau, t->nsub, steps,
+                       t->natoms, t->temp[t->cur], t->temp[t->cur ^ 1], t->U[t->cur], t->U[t->cur ^ 1], t->fd_k[t->kcur],
+                       t->fd_k[t->kcur ^ 1], t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve, t->ee, M, sub);
+  } else
+  hipLaunchKernelGGL((k_ttm_diff<true, true, false>), dim3(diff_grid(t)), dim3(DT_X * DT_Y * DT_Z), 0, ctx->stream, L, tau, t->nsub, steps,
                      t->natoms, t->temp[t->cur], t->temp[t->cur ^ 1], t->U[t->cur], t->U[t->cur ^ 1], t->fd_k[t->kcur],
-                     t->fd_k[t->kcur ^ 1], t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve, t->ee);
+                     t->fd_k[t->kcur ^ 1], t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve, t->ee, MailboxDev{}, 0);
   t->cur ^= 1; t->kcur ^= 1;
   return 0;
 }
 
 extern "C" int imdgpu_calc_ttm(imdgpu_ctx *ctx, int steps)
 {
-  if (ctx->external_halo) return imdgpu_fail(ctx, "calc_ttm: with several ranks use ttm_local_block / apply_blocks / ttm_lattice_step");
+  if (ctx->external_halo && !ctx->ttm_decomposed) return imdgpu_fail(ctx, "calc_ttm: with several ranks use ttm_local_block / apply_blocks / ttm_lattice_step");
   if (imdgpu_ttm_update_fd(ctx, steps)) return 1;
   return imdgpu_ttm_lattice_step(ctx, steps);
 }
@@ -803,8 +989,15 @@ extern "C" int imdgpu_ttm_lattice_step(imdgpu_ctx *ctx, int steps)
 {
   NEED_TTM();
   const double tau = ctx->timestep / ((double) t->nsub);
+  const bool MBX = t->mb_host != nullptr;
+  if (ctx->ttm_decomposed && !MBX) return imdgpu_fail(ctx, "decomposed TTM lattice: imdgpu_ttm_mailbox_attach first");
   imdgpu_tl_mark(ctx, "ttm_update_fd");
-  if (imdgpu_ttm_cell_activation(ctx) || imdgpu_ttm_fillmesh(ctx, steps) || imdgpu_ttm_fill_ghost_layers(ctx)) return 1;
+  if (imdgpu_ttm_cell_activation(ctx) || imdgpu_ttm_fillmesh(ctx, steps)) return 1;
+  const int maxface = MBX ? t->mbd.maxface : 0;
+  if (MBX) {                       // first publication of this MD step: natoms, temp, fd_k of my boundary layers
+    hipLaunchKernelGGL(k_ttm_push_faces, dim3(nblk(maxface, 256), 6), dim3(256), 0, ctx->stream, L, t->mbd, t->natoms,
+                       t->temp[t->cur], t->fd_k[t->kcur]);
+  } else if (imdgpu_ttm_fill_ghost_layers(ctx)) return 1;
   imdgpu_tl_mark(ctx, "ttm_fillmesh");
   {
     ProfScope ps(ctx, PROF_TTM_DIFF);
@@ -825,7 +1018,7 @@ extern "C" int imdgpu_ttm_lattice_step(imdgpu_ctx *ctx, int steps)
       for (int i = 0; i < t->nsub; i++) {
         Lat Li = L;
         if (i < nhigh) Li.wave_prio = 3;
-        launch_substep_fused(ctx, t, Li, tau, 1);
+        launch_substep_fused(ctx, t, Li, tau, 1, i);
       }
       HIPCHK(hipStreamEndCapture(ctx->stream, &g));
       HIPCHK(hipGraphInstantiate(&t->graph, g, nullptr, nullptr, 0));
@@ -833,15 +1026,78 @@ extern "C" int imdgpu_ttm_lattice_step(imdgpu_ctx *ctx, int steps)
       t->graph_cur = c0; t->graph_kcur = k0; t->graph_tau = tau;
       HIPCHK(hipGraphLaunch(t->graph, ctx->stream));
     } else {
-      for (int i = 0; i < t->nsub; i++) launch_substep_fused(ctx, t, L, tau, steps);
+      for (int i = 0; i < t->nsub; i++) launch_substep_fused(ctx, t, L, tau, steps, i);
     }
   }
   imdgpu_tl_mark(ctx, "ttm_substeps");
-  if (imdgpu_ttm_fill_ghost_layers(ctx)) return 1;     // sub-steps resolve ghosts on the fly; leave the shell consistent
+  if (MBX) {                       // neighbours' final layers into the ghost cells; next MD step = next block of indices
+    hipLaunchKernelGGL(k_ttm_pull_ghosts, dim3(nblk(maxface, 256), 6), dim3(256), 0, ctx->stream, L, t->mbd, t->nsub, t->natoms,
+                       t->temp[t->cur], t->fd_k[t->kcur]);
+    hipLaunchKernelGGL(k_ttm_advance_base, dim3(1), dim3(1), 0, ctx->stream, t->d_gbase, t->nsub);
+  } else if (imdgpu_ttm_fill_ghost_layers(ctx)) return 1;     // sub-steps resolve ghosts on the fly; leave the shell consistent
   HIPCHK(hipGetLastError());
   // CFL_maxdt: value is informational for the host (diff_substeps is fixed by fd_n_timesteps in the
   // sequence implemented here); computed on demand by imdgpu_ttm_cfl_maxdt to keep the step sync-free
   return 0;
+}
+
+// ---- decomposed lattice: the shared-memory mailbox -----------------------------------------------------------
+static void mailbox_layout(const TtmState *t, int *maxface, size_t *o_nat, size_t *o_dat, size_t *bytes)
+{
+  int mf = 0;
+  for (int d = 0; d < 3; d++) mf = std::max(mf, (t->dim[(d + 1) % 3] - 2) * (t->dim[(d + 2) % 3] - 2));
+  *maxface = mf;
+  *o_nat = 128;
+  *o_dat = 128 + (((size_t) 6 * mf * sizeof(int) + 63) / 64) * 64;
+  *bytes = ((*o_dat + (size_t) 2 * 6 * mf * 2 * sizeof(double) + 4095) / 4096) * 4096;
+}
+extern "C" int imdgpu_ttm_mailbox_bytes(imdgpu_ctx *ctx, size_t *bytes_per_rank)
+{
+  NEED_TTM();
+  if (!ctx->ttm_decomposed) return imdgpu_fail(ctx, "mailbox: set option ttm_decomposed before ttm_init");
+  int mf; size_t a, b;
+  mailbox_layout(t, &mf, &a, &b, bytes_per_rank);
+  return 0;
+}
+// host_base: a region of nranks * bytes_per_rank bytes shared by all ranks of the node (e.g. a mmap'ed /dev/shm file),
+// zero-filled before any rank attaches.  nbr[2*d+side]: rank of the neighbour block (may be this rank), -1 = open.
+extern "C" int imdgpu_ttm_mailbox_attach(imdgpu_ctx *ctx, void *host_base, size_t bytes_per_rank, int rank, int nranks,
+                                         const int nbr[6])
+{
+  NEED_TTM();
+  if (!ctx->ttm_decomposed) return imdgpu_fail(ctx, "mailbox: set option ttm_decomposed before ttm_init");
+  int mf; size_t o_nat, o_dat, need;
+  mailbox_layout(t, &mf, &o_nat, &o_dat, &need);
+  if (bytes_per_rank < need) return imdgpu_fail(ctx, "mailbox: %zu bytes per rank given, %zu needed", bytes_per_rank, need);
+  HIPCHK(hipHostRegister(host_base, bytes_per_rank * (size_t) nranks, hipHostRegisterMapped | hipHostRegisterPortable));
+  void *dev = nullptr;
+  HIPCHK(hipHostGetDevicePointer(&dev, host_base, 0));
+  t->mb_host = host_base; t->mb_bytes = bytes_per_rank; t->mb_rank = rank; t->mb_nranks = nranks;
+  if (dev_alloc(ctx, &t->d_gbase, 1) || dev_alloc(ctx, &t->d_facecnt, 12)) return 1;
+  HIPCHK(hipMemset(t->d_gbase, 0, sizeof(unsigned long long)));
+  HIPCHK(hipMemset(t->d_facecnt, 0, 12 * sizeof(int)));
+  MailboxDev &M = t->mbd;
+  M.base = (char *) dev; M.stride = bytes_per_rank; M.o_nat = o_nat; M.o_dat = o_dat;
+  M.rank = rank; M.nranks = nranks; M.maxface = mf;
+  M.gbase = t->d_gbase; M.facecnt = t->d_facecnt; M.counters = ctx->d_counters;
+  const int nb[3] = {(t->dim[0] - 2 + DT_X - 1) / DT_X, (t->dim[1] - 2 + DT_Y - 1) / DT_Y, (t->dim[2] - 2 + DT_Z - 1) / DT_Z};
+  for (int d = 0; d < 3; d++)
+    for (int side = 0; side < 2; side++) {
+      const int b = 2 * d + side;
+      if (nbr[b] >= nranks) return imdgpu_fail(ctx, "mailbox: neighbour rank %d out of range", nbr[b]);
+      M.nbr[b] = nbr[b];
+      M.nwg_sub[b] = nb[(d + 1) % 3] * nb[(d + 2) % 3];
+      M.nwg_push[b] = nblk(mf, 256);
+    }
+  if (t->graph) { (void) hipGraphExecDestroy(t->graph); t->graph = nullptr; }
+  return 0;
+}
+// calc_ttm of one rank's block: update_fd, activation, FILLMESH, face publication, the sub-steps
+extern "C" int imdgpu_ttm_local_step(imdgpu_ctx *ctx, int steps)
+{
+  if (!ctx->ttm_decomposed) return imdgpu_fail(ctx, "ttm_local_step: decomposed lattice only");
+  if (imdgpu_ttm_update_fd(ctx, steps)) return 1;
+  return imdgpu_ttm_lattice_step(ctx, steps);
 }
 
 static int launch_move_ttm(imdgpu_ctx *ctx, double limit2)

@@ -25,7 +25,7 @@ SYMBOLS = [
     "imdgpu_get_cell_tables", "imdgpu_autotile", "imdgpu_set_ghost_layout", "imdgpu_halo_gather", "imdgpu_halo_gather2", "imdgpu_halo_scatter",
     "imdgpu_migrate_scan", "imdgpu_migrate_gather", "imdgpu_migrate_apply", "imdgpu_forces_phase", "imdgpu_integrate",
     "imdgpu_get_invalid", "imdgpu_invalidate", "imdgpu_ttm_local_block", "imdgpu_ttm_apply_blocks",
-    "imdgpu_ttm_lattice_step",
+    "imdgpu_ttm_lattice_step", "imdgpu_ttm_mailbox_bytes", "imdgpu_ttm_mailbox_attach", "imdgpu_ttm_local_step",
 ]
 
 
@@ -139,6 +139,9 @@ def load():
     L.imdgpu_ttm_local_block.argtypes = [vp, C.c_int, vp, ip]
     L.imdgpu_ttm_apply_blocks.argtypes = [vp, C.c_int, vp, C.c_int, vp]
     L.imdgpu_ttm_lattice_step.argtypes = [vp, C.c_int]
+    L.imdgpu_ttm_mailbox_bytes.argtypes = [vp, C.POINTER(C.c_size_t)]
+    L.imdgpu_ttm_mailbox_attach.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, ip]
+    L.imdgpu_ttm_local_step.argtypes = [vp, C.c_int]
     for s in SYMBOLS:
         if s not in ("imdgpu_destroy", "imdgpu_last_error"):
             getattr(L, s).restype = C.c_int

@@ -256,6 +256,28 @@ class HaloPlan:
             ops.scatter(what, st["ridx_cat"], recv)
 
 
+def attach_ttm_mailbox(ops, rank, world, nbr):
+    """Create (rank 0) / open the shared-memory file of the TTM face mailbox, map it and hand it to the library.
+    Returns the objects that must stay alive.  One node only (the ranks share /dev/shm), like bench.py's contract."""
+    import mmap
+    per = ops.ttm_mailbox_bytes()
+    name = [None]
+    if rank == 0:
+        name[0] = "/dev/shm/imdgpu_ttm_%d_%d" % (os.getpid(), int.from_bytes(os.urandom(4), "little"))
+        with open(name[0], "wb") as f:
+            f.truncate(per * world)                         # zero-filled
+    if world > 1:
+        dist.broadcast_object_list(name, src=0)
+    f = open(name[0], "r+b")
+    mm = mmap.mmap(f.fileno(), per * world)
+    ops.ttm_mailbox_attach(mm, per, rank, world, nbr)
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        os.unlink(name[0])                                  # the mappings keep it alive
+    return f, mm
+
+
 class DistributedMD:
     """The MD step of one rank among several: same sequence as imdgpu_md_step, with the halo
     exchanges placed between the force passes (main_loop body, imd_main_3d.c:406-812)."""
@@ -267,7 +289,14 @@ class DistributedMD:
         self._halo_ready = False
         self.nrebuild = 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
-        if ttm:
+        self.ttm_decomposed = bool(ttm and getattr(ops, "ttm_is_decomposed", lambda: False)())
+        if ttm and self.ttm_decomposed:
+            # every rank diffuses its own block; ghost faces go GPU -> host shared memory -> GPU (imdgpu_ttm_mailbox_*)
+            nbr = []
+            for d in range(3):
+                nbr += [dec.lo[d] if dec.lo[d] is not None else -1, dec.hi[d] if dec.hi[d] is not None else -1]
+            self._mailbox = attach_ttm_mailbox(ops, dec.rank, self.world, nbr)
+        elif ttm:
             offs = []
             for r in range(self.world):
                 c = rank_to_coord(r, dec.cpu_dim)
@@ -324,11 +353,14 @@ class DistributedMD:
             # (block of update_fd -> all-gather -> fold in -> diffusion sub-steps) beside the embedding pass, the
             # dF halo and the EAM force pass, exactly like the single-rank fork in imdgpu_md_step
             ops.ttm_fork()
-            blk = ops.ttm_local_block(step)
-            allb = all_gather_flat(blk, self.world)
-            ops.ttm_apply_blocks(step, allb, self.world, self._ttm_offs)
-            ops.ttm_lattice_step(step)
-            self._ttm_keep = (blk, allb)                 # buffers stay referenced until the join
+            if self.ttm_decomposed:
+                ops.ttm_local_step(step)
+            else:
+                blk = ops.ttm_local_block(step)
+                allb = all_gather_flat(blk, self.world)
+                ops.ttm_apply_blocks(step, allb, self.world, self._ttm_offs)
+                ops.ttm_lattice_step(step)
+                self._ttm_keep = (blk, allb)             # buffers stay referenced until the join
             ops.ttm_unfork()
         ops.forces_phase(2)
         self.plan.exchange(ops, 1)                       # dF of the ghost atoms  [send_cells(copy_dF)]
@@ -366,8 +398,11 @@ class DistributedMD:
             self.plan.exchange(ops, 3); t0 = lap("halo_pos", t0)
         ops.forces_phase(1); t0 = lap("pass1", t0)
         if self.ttm:
-            blk = ops.ttm_local_block(step); allb = all_gather_flat(blk, self.world)
-            ops.ttm_apply_blocks(step, allb, self.world, self._ttm_offs); ops.ttm_lattice_step(step)
+            if self.ttm_decomposed:
+                ops.ttm_local_step(step)
+            else:
+                blk = ops.ttm_local_block(step); allb = all_gather_flat(blk, self.world)
+                ops.ttm_apply_blocks(step, allb, self.world, self._ttm_offs); ops.ttm_lattice_step(step)
             t0 = lap("ttm", t0)
         ops.forces_phase(2); t0 = lap("pass2", t0)
         self.plan.exchange(ops, 1); t0 = lap("halo_dF", t0)
@@ -501,6 +536,24 @@ class GpuOps:
 
     def ttm_join(self):
         self.stream.wait_stream(self.side)
+
+    def ttm_is_decomposed(self):
+        return bool(getattr(self.s, "ttm_decomposed", False))
+
+    def ttm_mailbox_bytes(self):
+        C = self.C
+        n = C.c_size_t()
+        self._ck(self.L.imdgpu_ttm_mailbox_bytes(self.h, C.byref(n)))
+        return int(n.value)
+
+    def ttm_mailbox_attach(self, mm, per, rank, world, nbr):
+        C = self.C
+        base = C.addressof(C.c_char.from_buffer(mm))
+        arr = (C.c_int * 6)(*[int(v) for v in nbr])
+        self._ck(self.L.imdgpu_ttm_mailbox_attach(self.h, C.c_void_p(base), per, int(rank), int(world), arr))
+
+    def ttm_local_step(self, step):
+        self._ck(self.L.imdgpu_ttm_local_step(self.h, int(step)))
 
     def ttm_local_block(self, step):
         C = self.C

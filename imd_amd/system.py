@@ -39,7 +39,7 @@ def global_cell_dim(box, cellsz, cd=(1, 1, 1)):
 class GpuSystem:
     def __init__(self, box, pbc_dirs, cell_dim, ntypes, cellsz, nbl_margin, timestep, device=0,
                  global_cell_dim=None, cpu_dim=(1, 1, 1), my_coord=(0, 0, 0), count_ttm_neighbours=False,
-                 external_halo=False):
+                 external_halo=False, ttm_decomposed=False):
         self.L = _lib.load()
         h = C.c_void_p()
         if self.L.imdgpu_create(C.byref(h), int(device)):
@@ -54,6 +54,9 @@ class GpuSystem:
         self.nallcells = int(np.prod(self.cell_dim))
         self.ntypes = int(ntypes)
         self._keep = []
+        self.ttm_decomposed = bool(ttm_decomposed)
+        if ttm_decomposed:           # several ranks: one TTM lattice block per rank (faces through the mailbox)
+            self._ck(self.L.imdgpu_set_option(self.h, b"ttm_decomposed", 1))
         if external_halo:            # a host layer (imd_amd.parallel) fills the ghost cells even on one rank
             self._ck(self.L.imdgpu_set_option(self.h, b"external_halo", 1))
         self._ck(self.L.imdgpu_set_geometry(self.h, _dp(self.box), _ip(self.pbc), _ip(self.cell_dim), _ip(gd),

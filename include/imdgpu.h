@@ -23,6 +23,8 @@
 #ifndef IMDGPU_H
 #define IMDGPU_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -219,6 +221,17 @@ int imdgpu_invalidate(imdgpu_ctx *ctx);                /* some rank asked for a 
 int imdgpu_ttm_local_block(imdgpu_ctx *ctx, int steps, double *dev_out, int *ncells_block);
 int imdgpu_ttm_apply_blocks(imdgpu_ctx *ctx, int steps, const double *dev_in, int nblocks, const int *dev_offs);
 int imdgpu_ttm_lattice_step(imdgpu_ctx *ctx, int steps);
+/* Alternative that keeps the per-rank TTM cost constant as ranks are added: imdgpu_set_option("ttm_decomposed", 1)
+ * before imdgpu_ttm_init gives every rank only ITS block of the lattice (as in the reference); the ghost faces of
+ * {natoms, temp, fd_k} that the reference moves with MPI_Sendrecv after every sub-step (ttm_fill_ghost_layers,
+ * imd_ttm_3D.c:3314-3504) go through a mailbox in host shared memory which the GPUs of all ranks of the node read
+ * and write from inside the sub-step kernels (no collective, no launch).  host_base: nranks * bytes_per_rank bytes
+ * mapped by every rank, zero-filled before the first attach; nbr[2*d+side] = rank of the neighbouring block
+ * (this rank itself for a periodic direction with one rank), -1 = open boundary. */
+int imdgpu_ttm_mailbox_bytes(imdgpu_ctx *ctx, size_t *bytes_per_rank);
+int imdgpu_ttm_mailbox_attach(imdgpu_ctx *ctx, void *host_base, size_t bytes_per_rank, int rank, int nranks, const int nbr[6]);
+/* [calc_ttm] for this rank's block: update_fd, activation, FILLMESH, face publication, the sub-steps */
+int imdgpu_ttm_local_step(imdgpu_ctx *ctx, int steps);
 
 /* ---- profiling ------------------------------------------------------------ */
 /* Accumulate HIP-event timings per kernel class on the context's stream. */

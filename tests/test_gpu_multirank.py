@@ -18,15 +18,15 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, case, cpu_dim, nsteps, ttm, q):
+def _worker(rank, world, port, case, cpu_dim, nsteps, ttm, q, decomposed=False):
     try:
-        _worker_body(rank, world, port, case, cpu_dim, nsteps, ttm, q)
+        _worker_body(rank, world, port, case, cpu_dim, nsteps, ttm, q, decomposed)
     except BaseException:
         import traceback
         q.put((rank, "ERROR", traceback.format_exc(), 0, None))
 
 
-def _worker_body(rank, world, port, case, cpu_dim, nsteps, ttm, q):
+def _worker_body(rank, world, port, case, cpu_dim, nsteps, ttm, q, decomposed=False):
     import torch
     import torch.distributed as dist
     from imd_amd.parallel import Decomposition, DistributedMD, GpuOps
@@ -41,7 +41,7 @@ def _worker_body(rank, world, port, case, cpu_dim, nsteps, ttm, q):
     c = np.clip((np.array(dec.gdim) * (pos @ t.T)).astype(int), 0, np.array(dec.gdim) - 1)
     mine = np.all(c // (np.array(dec.dim) - 2) == np.array(dec.coord), axis=1)
     s = GpuSystem(G["box"], G["pbc_dirs"], dec.dim, 1, float(G["cellsz"]), float(G["nbl_margin"]), float(G["timestep"]),
-                  device=0, global_cell_dim=dec.gdim, cpu_dim=cpu_dim, my_coord=dec.coord)
+                  device=0, global_cell_dim=dec.gdim, cpu_dim=cpu_dim, my_coord=dec.coord, ttm_decomposed=decomposed)
     s.upload_tables(gu.table(G, "pair_pot"), gu.table(G, "rho_h_tab"), gu.table(G, "embed_pot"))
     if ttm:
         s.init_ttm(G["ttm_fd_ext"], int(G["ttm_fd_min_atoms"]), int(G["ttm_diff_substeps"]), float(G["ttm_atomic_weight"]),
@@ -60,17 +60,17 @@ def _worker_body(rank, world, port, case, cpu_dim, nsteps, ttm, q):
     sums = md.global_sums()
     d = s.download(fields=("ort", "impuls", "kraft", "nummer", "numneighs"))
     lat = s.ttm_download(fields=("temp", "xi", "natoms")) if ttm else None
-    q.put((rank, d, sums, md.nrebuild, lat))
+    q.put((rank, d, sums, md.nrebuild, lat, tuple(dec.coord)))
     s.close()
     dist.destroy_process_group()
 
 
-def _run(case, cpu_dim, nsteps, ttm):
+def _run(case, cpu_dim, nsteps, ttm, decomposed=False):
     world = int(np.prod(cpu_dim))
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, case, cpu_dim, nsteps, ttm, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, cpu_dim, nsteps, ttm, q, decomposed)) for r in range(world)]
     for p in procs:
         p.start()
     res = []
@@ -118,3 +118,22 @@ def test_ranks_ttm(cpu_dim):
     ref = G["t2_substeps_done_temp"][1:-1, 1:-1, 1:-1]
     for r in res:
         assert np.abs(r[4]["temp"][1:-1, 1:-1, 1:-1] - ref).max() < 1e-10 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("cpu_dim", [(2, 1, 1), (2, 2, 1)])
+def test_ranks_ttm_decomposed_lattice(cpu_dim):
+    """The scalable TTM mode: every rank diffuses only its block of the electron lattice; the ghost faces go through
+    the host shared-memory mailbox, written and polled by the sub-step kernels themselves (imdgpu_ttm_mailbox_*).
+    The blocks, put together, must equal the reference's lattice after the sub-steps of step 2."""
+    res = _run("ttm_2048", cpu_dim, 3, True, decomposed=True)
+    G = gu.load("ttm_2048")
+    ids = np.concatenate([r[1]["nummer"] for r in res]); pos = np.concatenate([r[1]["ort"] for r in res])
+    o, go = np.argsort(ids), np.argsort(G["s3_nummer"])
+    assert np.abs(pos[o] - G["s3_ort"][go]).max() < 1e-9
+    ref = G["t2_substeps_done_temp"][1:-1, 1:-1, 1:-1]
+    full = np.zeros_like(ref)
+    for r in res:
+        blk = r[4]["temp"][1:-1, 1:-1, 1:-1]
+        c, n = r[5], blk.shape
+        full[c[0] * n[0]:(c[0] + 1) * n[0], c[1] * n[1]:(c[1] + 1) * n[1], c[2] * n[2]:(c[2] + 1) * n[2]] = blk
+    assert np.abs(full - ref).max() < 1e-10 * np.abs(ref).max()
