@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=30)
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal: host-staged halos)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks on cuda:0")
+    ap.add_argument("--ttm-decomposed", action="store_true",
+                    help="several ranks: one TTM lattice block per rank, faces through the shared-memory mailbox (default: the\n"
+                         "lattice is replicated, one all-gather per step; see DESIGN.md 5)")
     ap.add_argument("--force-distributed", action="store_true",
                     help="rehearsal: run the multi-rank host layer (halo plan, gather/scatter, fork/join) on one rank")
     return ap.parse_args()
@@ -70,7 +73,8 @@ def build_system(args, rank, world, device):
     cell_dim = tuple(gdim[d] // cpu_dim[d] + 2 for d in range(3))
     sysm = GpuSystem(box, (1, 1, 1), cell_dim, 1, cellsz, nbl_margin, 0.1, device=device, global_cell_dim=gdim,
                      cpu_dim=cpu_dim, my_coord=coord, count_ttm_neighbours=ttm,
-                     external_halo=args.force_distributed)
+                     external_halo=args.force_distributed,
+                     ttm_decomposed=ttm and (world > 1 or args.force_distributed) and args.ttm_decomposed)
     sysm.upload_tables(pair, rho, emb)
     if ttm:
         from imd_amd import ttm as ttm_mod

@@ -23,9 +23,7 @@ struct MailboxDev {
   size_t o_nat, o_dat;           // offsets inside a rank's part: natoms faces, data faces [2][6][maxface][2]
   int rank, nranks, maxface;
   int nbr[6];                    // neighbour rank per direction 2*d+side (side 0 = low), -1 = open boundary
-  int nwg_sub[6], nwg_push[6];   // workgroups that publish on face b in the sub-step / push kernel
   unsigned long long *gbase;     // device: index of the first publication of the current MD step
-  int *facecnt;                  // device [12]: finished publishers per face (monotone), sub-step then push kernel
   int *counters;                 // ctx->d_counters
 };
 
@@ -92,18 +90,25 @@ __device__ __forceinline__ int wsumi(int v)
 // ---------------------------------------------------------------------------
 // Decomposed lattice (one block per rank): the ghost faces of {natoms, temp, fd_k} that the reference exchanges with
 // MPI_Sendrecv after every diffusion sub-step (ttm_fill_ghost_layers, imd_ttm_3D.c:3314-3504) travel through a
-// MAILBOX in host shared memory that the GPUs of all ranks of the node read and write directly: the sub-step kernel
-// of rank A stores its boundary layer into the slot of its neighbour B and raises B's flag; B's next sub-step kernel
-// polls that flag before it reads the slot.  No collective, no extra launch, no CU held by a communication kernel
-// (RCCL's workgroups cannot be co-resident with the persistent force kernels); the data is a few
-// hundred KB per sub-step, so PCIe-attached host memory is plenty.  Publications are numbered by one monotone index;
-// two slot parities make a writer that is one sub-step ahead harmless.  Every spin is bounded.
+// MAILBOX in host shared memory that the GPUs of all ranks of the node read and write directly: after every sub-step
+// a six-wave kernel of rank A stores A's boundary layers into the slots of its neighbours and raises their flags;
+// before the next sub-step a six-wave kernel of rank B polls B's flags and copies the slots into B's ghost cells.
+// No collective and no CU held by a communication kernel (RCCL's workgroups cannot be co-resident with the persistent
+// force kernels); the data is ~150 KB per sub-step, so PCIe-attached host memory is plenty.
+// Publications are numbered by one monotone index; two slot parities make a writer that is one sub-step ahead
+// harmless.  Every spin is bounded.
 // ---------------------------------------------------------------------------
 #define MB_SPIN_MAX 2000000L
+// All mailbox traffic uses RELAXED system-scope accesses (cache-bypassing loads/stores of fine-grained host memory)
+// and, on the writer, an AGENT-scope release (wait for the stores' acknowledgements) before the flag goes out.  A
+// system-scope fence or acquire would write back / invalidate the whole L2 every time -- measured: 158 us per
+// sub-step and the concurrent force pass 2.5x slower.  The reader needs no fence: it branches on the flag value
+// before it issues the data loads, and those bypass the caches.
 __device__ __forceinline__ unsigned long long mb_ld(const unsigned long long *p)
-{ return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
+{ return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void mb_st(unsigned long long *p, unsigned long long v)
-{ __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+{ __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void mb_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
 __device__ __forceinline__ unsigned long long *mb_flag(const MailboxDev &M, int rank, int dir)
 { return (unsigned long long *) (M.base + (size_t) rank * M.stride) + dir; }
 __device__ __forceinline__ unsigned long long *mb_abort(const MailboxDev &M) { return (unsigned long long *) (M.base + 64); }
@@ -128,59 +133,87 @@ __device__ bool mb_wait(const MailboxDev &M, int dir, unsigned long long need)
   M.counters[CNT_TTM_TIMEOUT] = 1;
   return false;
 }
-// face index of an inner cell (i,j,k) on a face with normal d
-__device__ __forceinline__ int mb_fidx(const Lat &L, int d, int i, int j, int k)
+// publish my six boundary layers as publication `*gbase + off` (off = 0: after FILLMESH, with natoms; off = s + 1: after
+// sub-step s).  ONE wave per face (six pollers / six flag writers in total: a flood of PCIe polls from many
+// workgroups was measured to cost more than the exchange itself); the face is walked with eight independent
+// accesses in flight per lane.
+#define MB_UNR 8
+__global__ __launch_bounds__(64) void k_ttm_push_faces(Lat L, MailboxDev M, int off, int with_nat, const int *natoms,
+                                                        const double *temp, const double *fd_k)
 {
-  const int c[3] = {i, j, k};
-  const int d1 = (d + 1) % 3, d2 = (d + 2) % 3;
-  return (c[d1] - 1) * (L.dim[d2] - 2) + (c[d2] - 1);
-}
-// one publisher (workgroup) is done with face b: the last one of this round raises the neighbour's flag
-__device__ __forceinline__ void mb_done(const MailboxDev &M, int b, int cnt_slot, int nwg, unsigned long long newflag)
-{
-  const int old = atomicAdd(&M.facecnt[cnt_slot], 1);
-  if ((old + 1) % nwg == 0) mb_st(mb_flag(M, M.nbr[b], b ^ 1), newflag);
-}
-
-// first publication of an MD step (index *gbase): natoms, temp and fd_k of my six boundary layers after FILLMESH
-__global__ void k_ttm_push_faces(Lat L, MailboxDev M, const int *natoms, const double *temp, const double *fd_k)
-{
-  const int b = blockIdx.y, d = b >> 1, side = b & 1;
-  const int d1 = (d + 1) % 3, d2 = (d + 2) % 3, n1 = L.dim[d1] - 2, n2 = L.dim[d2] - 2;
+  const int b = blockIdx.x, d = b >> 1, side = b & 1, lane = threadIdx.x;
+  const int d1 = (d + 1) % 3, d2 = (d + 2) % 3, n1 = L.dim[d1] - 2, n2 = L.dim[d2] - 2, nf = n1 * n2;
   if (M.nbr[b] < 0) return;
-  const unsigned long long g = *M.gbase;
-  // the neighbour must have finished the previous MD step's last sub-step before its slot is overwritten
-  if (g > 0 && !mb_wait(M, b, g)) return;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < n1 * n2) {
-    int c[3];
-    c[d] = side ? L.dim[d] - 2 : 1; c[d1] = idx / n2 + 1; c[d2] = idx % n2 + 1;
-    const int cell = fidx(L, c[0], c[1], c[2]);
-    double *o = mb_dat(M, M.nbr[b], (int) (g & 1), b ^ 1, idx);
-    o[0] = temp[cell]; o[1] = fd_k[cell];
-    *mb_nat(M, M.nbr[b], b ^ 1, idx) = natoms[cell];
+  const unsigned long long g = *M.gbase + (unsigned long long) off;
+  // first publication of an MD step: the neighbour must have taken my previous step's last publication (it says so
+  // with its own last publication) before its slot is overwritten; later ones are ordered by the pull before them
+  int ok = 1;
+  if (off == 0 && g > 0) { if (lane == 0) ok = mb_wait(M, b, g) ? 1 : 0; ok = __shfl(ok, 0, 64); }
+  if (!ok) return;
+  double2 *o = (double2 *) mb_dat(M, M.nbr[b], (int) (g & 1), b ^ 1, 0);
+  int *on = mb_nat(M, M.nbr[b], b ^ 1, 0);
+  for (int base = 0; base < nf; base += 64 * MB_UNR) {
+    double2 v[MB_UNR]; int nn[MB_UNR];
+#pragma unroll
+    for (int u = 0; u < MB_UNR; u++) {
+      const int idx = base + u * 64 + lane;
+      if (idx < nf) {
+        int c[3];
+        c[d] = side ? L.dim[d] - 2 : 1; c[d1] = idx / n2 + 1; c[d2] = idx % n2 + 1;
+        const int cell = fidx(L, c[0], c[1], c[2]);
+        v[u] = make_double2(temp[cell], fd_k[cell]);
+        if (with_nat) nn[u] = natoms[cell];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < MB_UNR; u++) {
+      const int idx = base + u * 64 + lane;
+      if (idx < nf) { o[idx] = v[u]; if (with_nat) on[idx] = nn[u]; }
+    }
   }
-  __threadfence_system();
-  __syncthreads();
-  if (threadIdx.x == 0) mb_done(M, b, 6 + b, M.nwg_push[b], g + 1);
+  mb_release();                                      // the stores above are acknowledged before the flag goes out
+  if (lane == 0) mb_st(mb_flag(M, M.nbr[b], b ^ 1), g + 1);
 }
-// after the sub-steps: the neighbours' final layers into the ghost cells of the arrays (cell activation of the next
-// step and downloads read them), then the publication index moves on
-__global__ void k_ttm_pull_ghosts(Lat L, MailboxDev M, int nsub, int *natoms, double *temp, double *fd_k)
+// take the neighbours' publication `*gbase + off` into the ghost cells of the arrays (natoms only with the first of a step)
+__global__ __launch_bounds__(64) void k_ttm_pull_ghosts(Lat L, MailboxDev M, int off, int with_nat, int *natoms, double *temp,
+                                                         double *fd_k)
 {
-  const int b = blockIdx.y, d = b >> 1, side = b & 1;
-  const int d1 = (d + 1) % 3, d2 = (d + 2) % 3, n1 = L.dim[d1] - 2, n2 = L.dim[d2] - 2;
-  const unsigned long long g = *M.gbase + (unsigned long long) nsub;       // index of the last publication of this step
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  int c[3];
-  c[d] = side ? L.dim[d] - 1 : 0; c[d1] = idx / n2 + 1; c[d2] = idx % n2 + 1;
-  if (M.nbr[b] < 0) { if (idx < n1 * n2) natoms[fidx(L, c[0], c[1], c[2])] = 0; return; }
-  if (!mb_wait(M, b, g + 1)) return;
-  if (idx < n1 * n2) {
-    const int cell = fidx(L, c[0], c[1], c[2]);
-    const double *q = mb_dat(M, M.rank, (int) (g & 1), b, idx);
-    temp[cell] = mb_ldd(q); fd_k[cell] = mb_ldd(q + 1);
-    natoms[cell] = mb_ldi(mb_nat(M, M.rank, b, idx));
+  const int b = blockIdx.x, d = b >> 1, side = b & 1, lane = threadIdx.x;
+  const int d1 = (d + 1) % 3, d2 = (d + 2) % 3, n1 = L.dim[d1] - 2, n2 = L.dim[d2] - 2, nf = n1 * n2;
+  const unsigned long long g = *M.gbase + (unsigned long long) off;
+  if (M.nbr[b] < 0) {                                // open boundary: the ghost layer is empty (reflecting)
+    if (with_nat)
+      for (int idx = lane; idx < nf; idx += 64) {
+        int c[3];
+        c[d] = side ? L.dim[d] - 1 : 0; c[d1] = idx / n2 + 1; c[d2] = idx % n2 + 1;
+        natoms[fidx(L, c[0], c[1], c[2])] = 0;
+      }
+    return;
+  }
+  int ok = 0;
+  if (lane == 0) ok = mb_wait(M, b, g + 1) ? 1 : 0;
+  ok = __shfl(ok, 0, 64);
+  if (!ok) return;
+  const double *q = mb_dat(M, M.rank, (int) (g & 1), b, 0);
+  const int *qn = mb_nat(M, M.rank, b, 0);
+  for (int base = 0; base < nf; base += 64 * MB_UNR) {
+    double v0[MB_UNR], v1[MB_UNR]; int nn[MB_UNR];
+#pragma unroll
+    for (int u = 0; u < MB_UNR; u++) {
+      const int idx = base + u * 64 + lane;
+      if (idx < nf) { v0[u] = mb_ldd(q + 2 * idx); v1[u] = mb_ldd(q + 2 * idx + 1); if (with_nat) nn[u] = mb_ldi(qn + idx); }
+    }
+#pragma unroll
+    for (int u = 0; u < MB_UNR; u++) {
+      const int idx = base + u * 64 + lane;
+      if (idx < nf) {
+        int c[3];
+        c[d] = side ? L.dim[d] - 1 : 0; c[d1] = idx / n2 + 1; c[d2] = idx % n2 + 1;
+        const int cell = fidx(L, c[0], c[1], c[2]);
+        temp[cell] = v0[u]; fd_k[cell] = v1[u];
+        if (with_nat) natoms[cell] = nn[u];
+      }
+    }
   }
 }
 __global__ void k_ttm_advance_base(unsigned long long *gbase, int nsub) { *gbase += (unsigned long long) nsub + 1ull; }
@@ -494,14 +527,11 @@ __global__ void k_ttm_ghosts(Lat L, int *natoms, double *temp, double *fd_k)
 // WRAP: ghost-shell cells are not read from memory but resolved on the fly (periodic direction: the
 // opposite inner cell; open direction: empty), i.e. ttm_fill_ghost_layers is folded into the load --
 // valid when the lattice is not split over ranks.
-// MB: decomposed lattice, ghost FACES come from / go to the shared-memory mailbox (sub = sub-step number of this
-// launch: reads publication *gbase + sub, publishes *gbase + sub + 1); edges and corners of the ghost shell are never
-// read by the 7-point stencil.
-template <bool FUSE_MESH, bool WRAP, bool MB>
+template <bool FUSE_MESH, bool WRAP>
 __global__ __launch_bounds__(DT_X *DT_Y *DT_Z) void k_ttm_diff(
     Lat L, double tau, int nsub, int steps, const int *natoms, const double *T1, double *T2, double *U1, double *U2,
     const double *fd_k, double *fd_k_out, double *Ce, double *fd_g, const double *md_temp, const double *source,
-    const double *dens, double *xi, double *Zo, double *neo, EosDev cve, EosDev ee, MailboxDev M, int sub)
+    const double *dens, double *xi, double *Zo, double *neo, EosDev cve, EosDev ee)
 {
   __shared__ double sT[DT_X + 2][DT_Y + 2][DT_Z + 2];
   __shared__ double sK[DT_X + 2][DT_Y + 2][DT_Z + 2];
@@ -516,48 +546,20 @@ __global__ __launch_bounds__(DT_X *DT_Y *DT_Z) void k_ttm_diff(
   const int nbz = (L.dim[2] - 2 + DT_Z - 1) / DT_Z, nby = (L.dim[1] - 2 + DT_Y - 1) / DT_Y;
   const int bz = blockIdx.x % nbz, by = (blockIdx.x / nbz) % nby, bx = blockIdx.x / (nbz * nby);
   const int i0 = bx * DT_X, j0 = by * DT_Y, k0 = bz * DT_Z;     // tile origin in ghost-including coordinates
-  const int o0[3] = {i0, j0, k0}, dt[3] = {DT_X, DT_Y, DT_Z};
-  unsigned long long g = 0;
-  bool mb_ok = true;
-  if (MB) {
-    g = *M.gbase + (unsigned long long) sub;
-#pragma unroll
-    for (int d = 0; d < 3; d++) {                               // faces this tile's halo reaches
-      if (o0[d] == 0 && M.nbr[2 * d] >= 0) mb_ok &= mb_wait(M, 2 * d, g + 1);
-      if (o0[d] + dt[d] + 1 >= L.dim[d] - 1 && M.nbr[2 * d + 1] >= 0) mb_ok &= mb_wait(M, 2 * d + 1, g + 1);
-    }
-  }
   for (int s = threadIdx.x; s < (DT_X + 2) * (DT_Y + 2) * (DT_Z + 2); s += blockDim.x) {
     int lz = s % (DT_Z + 2), ly = (s / (DT_Z + 2)) % (DT_Y + 2), lx = s / ((DT_Z + 2) * (DT_Y + 2));
     int gi = i0 + lx, gj = j0 + ly, gk = k0 + lz;
     double t = 0, kk = 0; int n = 0;
     if (gi < L.dim[0] && gj < L.dim[1] && gk < L.dim[2]) {
       bool empty = false;
-      if (MB) {
-        const int gc[3] = {gi, gj, gk};
-        int ng = 0, dir = -1;
-#pragma unroll
-        for (int d = 0; d < 3; d++) {
-          if (gc[d] == 0) { ng++; dir = 2 * d; }
-          else if (gc[d] == L.dim[d] - 1) { ng++; dir = 2 * d + 1; }
-        }
-        if (ng == 1) {
-          empty = true;                                        // not from the arrays: from the neighbour's publication
-          if (M.nbr[dir] >= 0 && mb_ok) {
-            const int fi = mb_fidx(L, dir >> 1, gi, gj, gk);
-            const double *q = mb_dat(M, M.rank, (int) (g & 1), dir, fi);
-            t = mb_ldd(q); kk = mb_ldd(q + 1); n = mb_ldi(mb_nat(M, M.rank, dir, fi));
-          }
-        } else if (ng >= 2) empty = true;
-      }
       if (WRAP) {
-        int g3[3] = {gi, gj, gk};
+        int g[3] = {gi, gj, gk};
 #pragma unroll
         for (int d = 0; d < 3; d++) {
-          if (g3[d] == 0) { if (L.pbc[d] == 1) g3[d] = L.dim[d] - 2; else empty = true; }
-          else if (g3[d] == L.dim[d] - 1) { if (L.pbc[d] == 1) g3[d] = 1; else empty = true; }
+          if (g[d] == 0) { if (L.pbc[d] == 1) g[d] = L.dim[d] - 2; else empty = true; }
+          else if (g[d] == L.dim[d] - 1) { if (L.pbc[d] == 1) g[d] = 1; else empty = true; }
         }
-        gi = g3[0]; gj = g3[1]; gk = g3[2];
+        gi = g[0]; gj = g[1]; gk = g[2];
       }
       if (!empty) { int c = fidx(L, gi, gj, gk); t = T1[c]; kk = fd_k[c]; n = natoms[c]; }
     }
@@ -565,72 +567,40 @@ __global__ __launch_bounds__(DT_X *DT_Y *DT_Z) void k_ttm_diff(
   }
   __syncthreads();
   const int i = i0 + tx + 1, j = j0 + ty + 1, k = k0 + tz + 1;
-  const bool inside = !(i > L.dim[0] - 2 || j > L.dim[1] - 2 || k > L.dim[2] - 2);
-  if (!MB && !inside) return;
-  const int c = inside ? fidx(L, i, j, k) : 0, m = L.fd_min_atoms;
+  if (i > L.dim[0] - 2 || j > L.dim[1] - 2 || k > L.dim[2] - 2) return;
+  const int c = fidx(L, i, j, k), m = L.fd_min_atoms;
   const int lx = tx + 1, ly = ty + 1, lz = tz + 1;
-  const int nat = inside ? sN[lx][ly][lz] : 0;
-  double Tn = 0.0, knew = 0.0;
-  if (inside && nat < m) {
+  const int nat = sN[lx][ly][lz];
+  if (nat < m) {
     if (FUSE_MESH) { fd_k_out[c] = 0.0; fd_g[c] = 0.0; Zo[c] = 0.0; neo[c] = 0.0; Ce[c] = 0.0; }
-    if (!MB) return;
+    return;
   }
-  if (inside && nat >= m) {
   const double Te = sT[lx][ly][lz], kk = sK[lx][ly][lz];
   const double invxsq = L.invhsq[0], invysq = L.invhsq[1], invzsq = L.invhsq[2];
 #define NB(dx, dy, dz, TT, KK) \
   double TT, KK; if (sN[lx + dx][ly + dy][lz + dz] < m) { TT = Te; KK = kk; } else { TT = sT[lx + dx][ly + dy][lz + dz]; KK = sK[lx + dx][ly + dy][lz + dz]; }
   NB(1, 0, 0, xaT, xaK) NB(-1, 0, 0, xbT, xbK) NB(0, 1, 0, yaT, yaK) NB(0, -1, 0, ybT, ybK) NB(0, 0, 1, zaT, zaK) NB(0, 0, -1, zbT, zbK)
 #undef NB
-  const double ce = Ce[c], gg = fd_g[c], Tl = md_temp[c];
-  Tn = tau / ce *
+  const double ce = Ce[c], g = fd_g[c], Tl = md_temp[c];
+  const double Tn = tau / ce *
       ( ( ((kk + xaK) / 2 * (xaT - Te) * invxsq)
          - ((kk + xbK) / 2 * (Te - xbT) * invxsq)
          + ((kk + yaK) / 2 * (yaT - Te) * invysq)
          - ((kk + ybK) / 2 * (Te - ybT) * invysq)
          + ((kk + zaK) / 2 * (zaT - Te) * invzsq)
          - ((kk + zbK) / 2 * (Te - zbT) * invzsq) )
-        - gg * (Te - Tl)
+        - g * (Te - Tl)
         + source[c]
       ) + Te;
   T2[c] = Tn;
   U2[c] = U1[c] + (Tn - Te) * ce * L.vol / ((double) nat);
-  xi[c] += (Tn - Tl) * L.xi_fac * gg / (Tl * dens[c]);
+  xi[c] += (Tn - Tl) * L.xi_fac * g / (Tl * dens[c]);
   if (FUSE_MESH) {                 // do_FILLMESH of the same cell with the new temperature
     MeshOut o = mesh_props(L, cve, Tn, Tl, dens[c]);
     Zo[c] = o.Z; neo[c] = o.ne; Ce[c] = o.Ce; fd_k_out[c] = o.k; fd_g[c] = o.g;
-    knew = o.k;
     if (steps < 1) {               // do_FILLMESH re-initialises U from the EOS on every call of step 0 (:614-623)
       double u = eos_ee(ee, dens[c], Tn * 11604.5) * 26.9815 * C_AMU * C_J2EV;
       U1[c] = u; U2[c] = u;
-    }
-  }
-  }
-  if (MB) {
-    // publish my boundary layers (new temp, new fd_k) into the neighbours' slots, then count this workgroup in
-    if (inside) {
-      const int cc[3] = {i, j, k};
-#pragma unroll
-      for (int d = 0; d < 3; d++) {
-        if (cc[d] == 1 && M.nbr[2 * d] >= 0) {
-          double *q = mb_dat(M, M.nbr[2 * d], (int) ((g + 1) & 1), 2 * d + 1, mb_fidx(L, d, i, j, k));
-          q[0] = Tn; q[1] = knew;
-        }
-        if (cc[d] == L.dim[d] - 2 && M.nbr[2 * d + 1] >= 0) {
-          double *q = mb_dat(M, M.nbr[2 * d + 1], (int) ((g + 1) & 1), 2 * d, mb_fidx(L, d, i, j, k));
-          q[0] = Tn; q[1] = knew;
-        }
-      }
-    }
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-#pragma unroll
-      for (int d = 0; d < 3; d++) {
-        if (o0[d] == 0 && M.nbr[2 * d] >= 0) mb_done(M, 2 * d, 2 * d, M.nwg_sub[2 * d], g + 2);
-        if (o0[d] + 1 <= L.dim[d] - 2 && L.dim[d] - 2 <= o0[d] + dt[d] && M.nbr[2 * d + 1] >= 0)
-          mb_done(M, 2 * d + 1, 2 * d + 1, M.nwg_sub[2 * d + 1], g + 2);
-      }
     }
   }
 }
@@ -939,9 +909,9 @@ extern "C" int imdgpu_ttm_diff(imdgpu_ctx *ctx, double tau)
 {
   NEED_TTM();
   ProfScope ps(ctx, PROF_TTM_DIFF);
-  hipLaunchKernelGGL((k_ttm_diff<false, false, false>), dim3(diff_grid(t)), dim3(DT_X * DT_Y * DT_Z), 0, ctx->stream, L, tau, t->nsub, 1,
+  hipLaunchKernelGGL((k_ttm_diff<false, false>), dim3(diff_grid(t)), dim3(DT_X * DT_Y * DT_Z), 0, ctx->stream, L, tau, t->nsub, 1,
                      t->natoms, t->temp[t->cur], t->temp[t->cur ^ 1], t->U[t->cur], t->U[t->cur ^ 1], t->fd_k[t->kcur],
-                     t->fd_k[t->kcur], t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve, t->ee, MailboxDev{}, 0);
+                     t->fd_k[t->kcur], t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve, t->ee);
   HIPCHK(hipGetLastError());
   t->cur ^= 1;                                        // l1 <-> l2
   return 0;
@@ -964,15 +934,20 @@ extern "C" int imdgpu_ttm_cfl_maxdt(imdgpu_ctx *ctx, int steps, double *out)
 // the same launch still needs the neighbours' old kappa.
 static int launch_substep_fused(imdgpu_ctx *ctx, TtmState *t, const Lat &L, double tau, int steps, int sub = 0)
 {
-  if (t->mb_host) {                // decomposed lattice: ghost faces through the mailbox
-    MailboxDev M = t->mbd;
-    hipLaunchKernelGGL((k_ttm_diff<true, false, true>), dim3(diff_grid(t)), dim3(DT_X * DT_Y * DT_Z), 0, ctx->stream, L, tau, t->nsub, steps,
+  if (t->mb_host) {
+    // decomposed lattice: pull the neighbours' publication `*gbase + sub` into the ghost cells, one sub-step on the
+    // arrays (ghost cells read like any other), publish my new boundary layers as `*gbase + sub + 1`
+    hipLaunchKernelGGL(k_ttm_pull_ghosts, dim3(6), dim3(64), 0, ctx->stream, L, t->mbd, sub, sub == 0 ? 1 : 0, t->natoms,
+                       t->temp[t->cur], t->fd_k[t->kcur]);
+    hipLaunchKernelGGL((k_ttm_diff<true, false>), dim3(diff_grid(t)), dim3(DT_X * DT_Y * DT_Z), 0, ctx->stream, L, tau, t->nsub, steps,
                        t->natoms, t->temp[t->cur], t->temp[t->cur ^ 1], t->U[t->cur], t->U[t->cur ^ 1], t->fd_k[t->kcur],
-                       t->fd_k[t->kcur ^ 1], t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve, t->ee, M, sub);
+                       t->fd_k[t->kcur ^ 1], t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve, t->ee);
+    hipLaunchKernelGGL(k_ttm_push_faces, dim3(6), dim3(64), 0, ctx->stream, L, t->mbd, sub + 1, 0, t->natoms,
+                       t->temp[t->cur ^ 1], t->fd_k[t->kcur ^ 1]);
   } else
-  hipLaunchKernelGGL((k_ttm_diff<true, true, false>), dim3(diff_grid(t)), dim3(DT_X * DT_Y * DT_Z), 0, ctx->stream, L, tau, t->nsub, steps,
+  hipLaunchKernelGGL((k_ttm_diff<true, true>), dim3(diff_grid(t)), dim3(DT_X * DT_Y * DT_Z), 0, ctx->stream, L, tau, t->nsub, steps,
                      t->natoms, t->temp[t->cur], t->temp[t->cur ^ 1], t->U[t->cur], t->U[t->cur ^ 1], t->fd_k[t->kcur],
-                     t->fd_k[t->kcur ^ 1], t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve, t->ee, MailboxDev{}, 0);
+                     t->fd_k[t->kcur ^ 1], t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve, t->ee);
   t->cur ^= 1; t->kcur ^= 1;
   return 0;
 }
@@ -993,9 +968,8 @@ extern "C" int imdgpu_ttm_lattice_step(imdgpu_ctx *ctx, int steps)
   if (ctx->ttm_decomposed && !MBX) return imdgpu_fail(ctx, "decomposed TTM lattice: imdgpu_ttm_mailbox_attach first");
   imdgpu_tl_mark(ctx, "ttm_update_fd");
   if (imdgpu_ttm_cell_activation(ctx) || imdgpu_ttm_fillmesh(ctx, steps)) return 1;
-  const int maxface = MBX ? t->mbd.maxface : 0;
   if (MBX) {                       // first publication of this MD step: natoms, temp, fd_k of my boundary layers
-    hipLaunchKernelGGL(k_ttm_push_faces, dim3(nblk(maxface, 256), 6), dim3(256), 0, ctx->stream, L, t->mbd, t->natoms,
+    hipLaunchKernelGGL(k_ttm_push_faces, dim3(6), dim3(64), 0, ctx->stream, L, t->mbd, 0, 1, t->natoms,
                        t->temp[t->cur], t->fd_k[t->kcur]);
   } else if (imdgpu_ttm_fill_ghost_layers(ctx)) return 1;
   imdgpu_tl_mark(ctx, "ttm_fillmesh");
@@ -1031,7 +1005,7 @@ extern "C" int imdgpu_ttm_lattice_step(imdgpu_ctx *ctx, int steps)
   }
   imdgpu_tl_mark(ctx, "ttm_substeps");
   if (MBX) {                       // neighbours' final layers into the ghost cells; next MD step = next block of indices
-    hipLaunchKernelGGL(k_ttm_pull_ghosts, dim3(nblk(maxface, 256), 6), dim3(256), 0, ctx->stream, L, t->mbd, t->nsub, t->natoms,
+    hipLaunchKernelGGL(k_ttm_pull_ghosts, dim3(6), dim3(64), 0, ctx->stream, L, t->mbd, t->nsub, 0, t->natoms,
                        t->temp[t->cur], t->fd_k[t->kcur]);
     hipLaunchKernelGGL(k_ttm_advance_base, dim3(1), dim3(1), 0, ctx->stream, t->d_gbase, t->nsub);
   } else if (imdgpu_ttm_fill_ghost_layers(ctx)) return 1;     // sub-steps resolve ghosts on the fly; leave the shell consistent
@@ -1079,15 +1053,12 @@ extern "C" int imdgpu_ttm_mailbox_attach(imdgpu_ctx *ctx, void *host_base, size_
   MailboxDev &M = t->mbd;
   M.base = (char *) dev; M.stride = bytes_per_rank; M.o_nat = o_nat; M.o_dat = o_dat;
   M.rank = rank; M.nranks = nranks; M.maxface = mf;
-  M.gbase = t->d_gbase; M.facecnt = t->d_facecnt; M.counters = ctx->d_counters;
-  const int nb[3] = {(t->dim[0] - 2 + DT_X - 1) / DT_X, (t->dim[1] - 2 + DT_Y - 1) / DT_Y, (t->dim[2] - 2 + DT_Z - 1) / DT_Z};
+  M.gbase = t->d_gbase; M.counters = ctx->d_counters;
   for (int d = 0; d < 3; d++)
     for (int side = 0; side < 2; side++) {
       const int b = 2 * d + side;
       if (nbr[b] >= nranks) return imdgpu_fail(ctx, "mailbox: neighbour rank %d out of range", nbr[b]);
       M.nbr[b] = nbr[b];
-      M.nwg_sub[b] = nb[(d + 1) % 3] * nb[(d + 2) % 3];
-      M.nwg_push[b] = nblk(mf, 256);
     }
   if (t->graph) { (void) hipGraphExecDestroy(t->graph); t->graph = nullptr; }
   return 0;
