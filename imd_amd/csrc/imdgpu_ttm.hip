@@ -34,6 +34,7 @@ struct TtmState {
   int fd_min_atoms = 0, nsub = 0, cur = 0, kcur = 0;
   double h[3]{}, vol = 0, neighvol = 0, atomic_weight = 0, atomic_charge = 0, omega_laser = 0, Temin = 1e-3;
   double max_dt_ttm = 0;
+  int have_source = 0;              // a source term was uploaded (imdgpu_ttm_upload with `source`): the sub-steps read it
   int *natoms = nullptr, *natoms_old = nullptr;
   double *temp[2]{}, *U[2]{}, *fd_k[2]{};
   double *xi = nullptr, *md_temp = nullptr, *source = nullptr, *vcom = nullptr /* 3 planes */, *dens = nullptr,
@@ -531,8 +532,10 @@ template <bool FUSE_MESH, bool WRAP>
 __global__ __launch_bounds__(DT_X *DT_Y *DT_Z) void k_ttm_diff(
     Lat L, double tau, int nsub, int steps, const int *natoms, const double *T1, double *T2, double *U1, double *U2,
     const double *fd_k, double *fd_k_out, double *Ce, double *fd_g, const double *md_temp, const double *source,
-    const double *dens, double *xi, double *Zo, double *neo, EosDev cve, EosDev ee)
+    const double *dens, double *xi, double *Zo, double *neo, EosDev cve, EosDev ee, int flags)
 {
+  // flags: 1 = store Z and ne (diagnostic fields nothing in the sub-step loop reads: only the last sub-step of an MD
+  // step has to), 2 = there is a source term to read.  A large (replicated) lattice is bound by its bytes per cell.
   __shared__ double sT[DT_X + 2][DT_Y + 2][DT_Z + 2];
   __shared__ double sK[DT_X + 2][DT_Y + 2][DT_Z + 2];
   __shared__ int sN[DT_X + 2][DT_Y + 2][DT_Z + 2];
@@ -572,7 +575,7 @@ __global__ __launch_bounds__(DT_X *DT_Y *DT_Z) void k_ttm_diff(
   const int lx = tx + 1, ly = ty + 1, lz = tz + 1;
   const int nat = sN[lx][ly][lz];
   if (nat < m) {
-    if (FUSE_MESH) { fd_k_out[c] = 0.0; fd_g[c] = 0.0; Zo[c] = 0.0; neo[c] = 0.0; Ce[c] = 0.0; }
+    if (FUSE_MESH) { fd_k_out[c] = 0.0; fd_g[c] = 0.0; Ce[c] = 0.0; if (flags & 1) { Zo[c] = 0.0; neo[c] = 0.0; } }
     return;
   }
   const double Te = sT[lx][ly][lz], kk = sK[lx][ly][lz];
@@ -590,14 +593,15 @@ __global__ __launch_bounds__(DT_X *DT_Y *DT_Z) void k_ttm_diff(
          + ((kk + zaK) / 2 * (zaT - Te) * invzsq)
          - ((kk + zbK) / 2 * (Te - zbT) * invzsq) )
         - g * (Te - Tl)
-        + source[c]
+        + ((flags & 2) ? source[c] : 0.0)
       ) + Te;
   T2[c] = Tn;
   U2[c] = U1[c] + (Tn - Te) * ce * L.vol / ((double) nat);
   xi[c] += (Tn - Tl) * L.xi_fac * g / (Tl * dens[c]);
   if (FUSE_MESH) {                 // do_FILLMESH of the same cell with the new temperature
     MeshOut o = mesh_props(L, cve, Tn, Tl, dens[c]);
-    Zo[c] = o.Z; neo[c] = o.ne; Ce[c] = o.Ce; fd_k_out[c] = o.k; fd_g[c] = o.g;
+    if (flags & 1) { Zo[c] = o.Z; neo[c] = o.ne; }
+    Ce[c] = o.Ce; fd_k_out[c] = o.k; fd_g[c] = o.g;
     if (steps < 1) {               // do_FILLMESH re-initialises U from the EOS on every call of step 0 (:614-623)
       double u = eos_ee(ee, dens[c], Tn * 11604.5) * 26.9815 * C_AMU * C_J2EV;
       U1[c] = u; U2[c] = u;
@@ -811,7 +815,11 @@ static int ttm_xfer(imdgpu_ctx *ctx, const imdgpu_ttm_fields *f, bool down)
   return 0;
 }
 extern "C" int imdgpu_ttm_download(imdgpu_ctx *ctx, const imdgpu_ttm_fields *f) { return ttm_xfer(ctx, f, true); }
-extern "C" int imdgpu_ttm_upload(imdgpu_ctx *ctx, const imdgpu_ttm_fields *f) { return ttm_xfer(ctx, f, false); }
+extern "C" int imdgpu_ttm_upload(imdgpu_ctx *ctx, const imdgpu_ttm_fields *f)
+{
+  if (f->source && ctx->ttm) ctx->ttm->have_source = 1;
+  return ttm_xfer(ctx, f, false);
+}
 
 extern "C" int imdgpu_ttm_update_fd(imdgpu_ctx *ctx, int steps)
 {
@@ -911,7 +919,7 @@ extern "C" int imdgpu_ttm_diff(imdgpu_ctx *ctx, double tau)
   ProfScope ps(ctx, PROF_TTM_DIFF);
   hipLaunchKernelGGL((k_ttm_diff<false, false>), dim3(diff_grid(t)), dim3(DT_X * DT_Y * DT_Z), 0, ctx->stream, L, tau, t->nsub, 1,
                      t->natoms, t->temp[t->cur], t->temp[t->cur ^ 1], t->U[t->cur], t->U[t->cur ^ 1], t->fd_k[t->kcur],
-                     t->fd_k[t->kcur], t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve, t->ee);
+                     t->fd_k[t->kcur], t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve, t->ee, 3);
   HIPCHK(hipGetLastError());
   t->cur ^= 1;                                        // l1 <-> l2
   return 0;
@@ -934,6 +942,7 @@ extern "C" int imdgpu_ttm_cfl_maxdt(imdgpu_ctx *ctx, int steps, double *out)
 // the same launch still needs the neighbours' old kappa.
 static int launch_substep_fused(imdgpu_ctx *ctx, TtmState *t, const Lat &L, double tau, int steps, int sub = 0)
 {
+  const int flags = (sub == t->nsub - 1 ? 1 : 0) | (t->have_source ? 2 : 0);
   if (t->mb_host) {
     // decomposed lattice: pull the neighbours' publication `*gbase + sub` into the ghost cells, one sub-step on the
     // arrays (ghost cells read like any other), publish my new boundary layers as `*gbase + sub + 1`
@@ -941,13 +950,13 @@ static int launch_substep_fused(imdgpu_ctx *ctx, TtmState *t, const Lat &L, doub
                        t->temp[t->cur], t->fd_k[t->kcur]);
     hipLaunchKernelGGL((k_ttm_diff<true, false>), dim3(diff_grid(t)), dim3(DT_X * DT_Y * DT_Z), 0, ctx->stream, L, tau, t->nsub, steps,
                        t->natoms, t->temp[t->cur], t->temp[t->cur ^ 1], t->U[t->cur], t->U[t->cur ^ 1], t->fd_k[t->kcur],
-                       t->fd_k[t->kcur ^ 1], t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve, t->ee);
+                       t->fd_k[t->kcur ^ 1], t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve, t->ee, flags);
     hipLaunchKernelGGL(k_ttm_push_faces, dim3(6), dim3(64), 0, ctx->stream, L, t->mbd, sub + 1, 0, t->natoms,
                        t->temp[t->cur ^ 1], t->fd_k[t->kcur ^ 1]);
   } else
   hipLaunchKernelGGL((k_ttm_diff<true, true>), dim3(diff_grid(t)), dim3(DT_X * DT_Y * DT_Z), 0, ctx->stream, L, tau, t->nsub, steps,
                      t->natoms, t->temp[t->cur], t->temp[t->cur ^ 1], t->U[t->cur], t->U[t->cur ^ 1], t->fd_k[t->kcur],
-                     t->fd_k[t->kcur ^ 1], t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve, t->ee);
+                     t->fd_k[t->kcur ^ 1], t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve, t->ee, flags);
   t->cur ^= 1; t->kcur ^= 1;
   return 0;
 }
