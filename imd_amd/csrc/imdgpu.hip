@@ -200,12 +200,12 @@ __global__ void k_wrap_key(int n, double4 *pos, Geo g, int *keys, int *perm, int
 
 __global__ void k_gather_sorted(int n, int cap, const int *perm, const int *keys, const double4 *pos, double4 *pos2,
                                 const int *type, int *type2, const int *id, int *id2, const double *p, double *p2,
-                                const double *mass, double *mass2, int *acell, int *icnt)
+                                const double *mass, double *mass2, int *acell, int *icnt, const int *fdc, int *fdc2)
 {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int s = perm[i];
-  pos2[i] = pos[s]; type2[i] = type[s]; id2[i] = id[s]; mass2[i] = mass[s];
+  pos2[i] = pos[s]; type2[i] = type[s]; id2[i] = id[s]; mass2[i] = mass[s]; fdc2[i] = fdc[s];
   p2[i] = p[s]; p2[cap + i] = p[cap + s]; p2[2 * (size_t) cap + i] = p[2 * (size_t) cap + s];
   int k = keys[i];
   acell[i] = k;
@@ -1379,7 +1379,7 @@ extern "C" void imdgpu_destroy(imdgpu_ctx *c)
   for (auto e : c->ev_pool) (void) hipEventDestroy(e);
   imdgpu_ttm_free(c);
   void *ptrs[] = {c->pos, c->type, c->id, c->acell, c->p, c->f, c->ref, c->mass, c->epot, c->rhoh, c->numneighs,
-                  c->pos2, c->type2, c->id2, c->p2, c->mass2, c->nn2, c->keys, c->keys2, c->perm, c->perm2,
+                  c->pos2, c->type2, c->id2, c->p2, c->mass2, c->nn2, c->fdc, c->fdc2, c->keys, c->keys2, c->perm, c->perm2,
                   c->cub_tmp, c->cell_start, c->cell_cnt, c->icnt, c->istart, c->gcell_lin, c->gcell_src,
                   c->gcell_shift, c->gcnt, c->gstart, c->ghost_src, c->ghost_code, c->d_counters, c->nbr,
                   c->nbr_cnt, c->nbr16, c->tsrc, c->ownw, c->tinfo, c->d_merged, c->partials, c->d_sums, c->pair.d_tab, c->rho.d_tab, c->emb.d_tab, c->d_restr};
@@ -1407,6 +1407,7 @@ extern "C" int imdgpu_set_option(imdgpu_ctx *ctx, const char *name, int value)
     ctx->tile[name[5] - 'x'] = value; ctx->autotiled = 1;
     return ctx->have_geometry ? setup_tiles(ctx) : 0;
   }
+  if (!strcmp(name, "ttm_flux")) { ctx->ttm_flux = value ? 1 : 0; return 0; }
   if (!strcmp(name, "ttm_decomposed")) {         // before ttm_init
     if (ctx->ttm) return imdgpu_fail(ctx, "ttm_decomposed must be set before ttm_init");
     ctx->ttm_decomposed = value ? 1 : 0;
@@ -1703,8 +1704,10 @@ static int ensure_atom_capacity(imdgpu_ctx *ctx, int nlocal, int ntot)
         dev_alloc(ctx, &ctx->mass, cap) || dev_alloc(ctx, &ctx->epot, cap) || dev_alloc(ctx, &ctx->rhoh, cap) ||
         dev_alloc(ctx, &ctx->numneighs, cap) || dev_alloc(ctx, &ctx->id2, cap) || dev_alloc(ctx, &ctx->p2, 3 * (size_t) cap) ||
         dev_alloc(ctx, &ctx->mass2, cap) || dev_alloc(ctx, &ctx->keys, cap) || dev_alloc(ctx, &ctx->keys2, cap) ||
-        dev_alloc(ctx, &ctx->perm, cap) || dev_alloc(ctx, &ctx->perm2, cap) || dev_alloc(ctx, &ctx->nbr_cnt, cap))
+        dev_alloc(ctx, &ctx->perm, cap) || dev_alloc(ctx, &ctx->perm2, cap) || dev_alloc(ctx, &ctx->nbr_cnt, cap) ||
+        dev_alloc(ctx, &ctx->fdc, cap) || dev_alloc(ctx, &ctx->fdc2, cap))
       return 1;
+    HIPCHK(hipMemset(ctx->fdc, 0xff, cap * sizeof(int)));
     HIPCHK(hipMemset(ctx->f, 0, 3 * (size_t) cap * sizeof(double)));
     HIPCHK(hipMemset(ctx->epot, 0, cap * sizeof(double)));
     HIPCHK(hipMemset(ctx->rhoh, 0, cap * sizeof(double)));
@@ -1785,6 +1788,7 @@ static int upload_common(imdgpu_ctx *ctx, int n, const double *ort, const double
   HIPCHK(hipSetDevice(ctx->device));
   ctx->nlocal = 0;
   if (ensure_atom_capacity(ctx, n, n)) return 1;
+  HIPCHK(hipMemset(ctx->fdc, 0xff, (size_t) ctx->cap_local * sizeof(int)));      // no FD cell known yet for any atom
   const int cap = ctx->cap_local;
   std::vector<double4> hp(n);
   std::vector<double> hm(3 * (size_t) n);
@@ -1884,9 +1888,9 @@ static int sort_and_build(imdgpu_ctx *ctx)
     HIPCHK(hipMemsetAsync(ctx->icnt, 0, (ctx->nkeys + 1) * sizeof(int), ctx->stream));
     hipLaunchKernelGGL(k_gather_sorted, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, n, cap, ctx->perm2, ctx->keys2,
                        ctx->pos, ctx->pos2, ctx->type, ctx->type2, ctx->id, ctx->id2, ctx->p, ctx->p2, ctx->mass,
-                       ctx->mass2, ctx->acell, ctx->icnt);
+                       ctx->mass2, ctx->acell, ctx->icnt, ctx->fdc, ctx->fdc2);
     std::swap(ctx->pos, ctx->pos2); std::swap(ctx->type, ctx->type2); std::swap(ctx->id, ctx->id2);
-    std::swap(ctx->p, ctx->p2); std::swap(ctx->mass, ctx->mass2);
+    std::swap(ctx->p, ctx->p2); std::swap(ctx->mass, ctx->mass2); std::swap(ctx->fdc, ctx->fdc2);
   }
   return build_cells_from_counts(ctx);
 }

@@ -141,7 +141,7 @@ __global__ void k_migrate_mark(int n, int d, const double4 *pos, Geo g, int ncpu
 }
 
 __global__ void k_migrate_gather(int n, const int *idx, int cap, const double4 *pos, const double *p, const double *mass,
-                                 const int *type, const int *id, double *out)
+                                 const int *type, const int *id, const int *fdc, double *out)
 {
   int m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= n) return;
@@ -150,22 +150,22 @@ __global__ void k_migrate_gather(int n, const int *idx, int cap, const double4 *
   double *o = out + (size_t) m * MIG_REC;
   o[0] = r.x; o[1] = r.y; o[2] = r.z;
   o[3] = p[i]; o[4] = p[cap + i]; o[5] = p[2 * (size_t) cap + i];
-  o[6] = mass[i]; o[7] = (double) type[i]; o[8] = (double) id[i]; o[9] = 0.0;
+  o[6] = mass[i]; o[7] = (double) type[i]; o[8] = (double) id[i]; o[9] = (double) fdc[i];   // fdi/fdj/fdk travel too (imd_mpi_util.c:399)
 }
 
 __global__ void k_migrate_compact(int n, int cap, const int *perm, const double4 *pos, double4 *pos2, const int *type,
                                   int *type2, const int *id, int *id2, const double *p, double *p2, const double *mass,
-                                  double *mass2)
+                                  double *mass2, const int *fdc, int *fdc2)
 {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int s = perm[i];
-  pos2[i] = pos[s]; type2[i] = type[s]; id2[i] = id[s]; mass2[i] = mass[s];
+  pos2[i] = pos[s]; type2[i] = type[s]; id2[i] = id[s]; mass2[i] = mass[s]; fdc2[i] = fdc[s];
   p2[i] = p[s]; p2[cap + i] = p[cap + s]; p2[2 * (size_t) cap + i] = p[2 * (size_t) cap + s];
 }
 
 __global__ void k_migrate_append(int n, int at, int cap, const double *in, double4 *pos, int *type, int *id, double *p,
-                                 double *mass)
+                                 double *mass, int *fdc)
 {
   int m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= n) return;
@@ -173,7 +173,7 @@ __global__ void k_migrate_append(int n, int at, int cap, const double *in, doubl
   int i = at + m;
   pos[i] = make_double4(o[0], o[1], o[2], 0.0);
   p[i] = o[3]; p[cap + i] = o[4]; p[2 * (size_t) cap + i] = o[5];
-  mass[i] = o[6]; type[i] = (int) o[7]; id[i] = (int) o[8];
+  mass[i] = o[6]; type[i] = (int) o[7]; id[i] = (int) o[8]; fdc[i] = (int) o[9];
 }
 
 __global__ void k_iota_stay(int n, const int *flag, int *iota, char *stay)
@@ -211,7 +211,7 @@ extern "C" int imdgpu_migrate_gather(imdgpu_ctx *ctx, int dir, void *dev_out)
   const int n = ctx->mig_n[dir];
   if (n <= 0) return 0;
   hipLaunchKernelGGL(k_migrate_gather, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, n, ctx->mig_idx[dir], ctx->cap_local,
-                     ctx->pos, ctx->p, ctx->mass, ctx->type, ctx->id, (double *) dev_out);
+                     ctx->pos, ctx->p, ctx->mass, ctx->type, ctx->id, ctx->fdc, (double *) dev_out);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -238,9 +238,10 @@ extern "C" int imdgpu_migrate_apply(imdgpu_ctx *ctx, const void *in_lo, int n_in
     size_t tb = ctx->cub_tmp_bytes;
     HIPCHK(hipcub::DeviceSelect::Flagged(ctx->cub_tmp, tb, iota, stay, sel, dnum, n, ctx->stream));
     hipLaunchKernelGGL(k_migrate_compact, dim3(nblk(nstay, 256)), dim3(256), 0, ctx->stream, nstay, ctx->cap_local, sel,
-                       ctx->pos, ctx->pos2, ctx->type, ctx->type2, ctx->id, ctx->id2, ctx->p, ctx->p2, ctx->mass, ctx->mass2);
+                       ctx->pos, ctx->pos2, ctx->type, ctx->type2, ctx->id, ctx->id2, ctx->p, ctx->p2, ctx->mass, ctx->mass2,
+                       ctx->fdc, ctx->fdc2);
     std::swap(ctx->pos, ctx->pos2); std::swap(ctx->type, ctx->type2); std::swap(ctx->id, ctx->id2);
-    std::swap(ctx->p, ctx->p2); std::swap(ctx->mass, ctx->mass2);
+    std::swap(ctx->p, ctx->p2); std::swap(ctx->mass, ctx->mass2); std::swap(ctx->fdc, ctx->fdc2);
   }
   ctx->nlocal = nstay;
   if (nnew > ctx->cap_local) {
@@ -250,10 +251,10 @@ extern "C" int imdgpu_migrate_apply(imdgpu_ctx *ctx, const void *in_lo, int n_in
   if (nnew > ctx->cap_tot && imdgpu_ensure_capacity(ctx, nstay, nnew)) return 1;
   if (n_in_lo > 0)
     hipLaunchKernelGGL(k_migrate_append, dim3(nblk(n_in_lo, 256)), dim3(256), 0, ctx->stream, n_in_lo, nstay, ctx->cap_local,
-                       (const double *) in_lo, ctx->pos, ctx->type, ctx->id, ctx->p, ctx->mass);
+                       (const double *) in_lo, ctx->pos, ctx->type, ctx->id, ctx->p, ctx->mass, ctx->fdc);
   if (n_in_hi > 0)
     hipLaunchKernelGGL(k_migrate_append, dim3(nblk(n_in_hi, 256)), dim3(256), 0, ctx->stream, n_in_hi, nstay + n_in_lo,
-                       ctx->cap_local, (const double *) in_hi, ctx->pos, ctx->type, ctx->id, ctx->p, ctx->mass);
+                       ctx->cap_local, (const double *) in_hi, ctx->pos, ctx->type, ctx->id, ctx->p, ctx->mass, ctx->fdc);
   HIPCHK(hipGetLastError());
   ctx->nlocal = nnew;
   ctx->mig_n[0] = ctx->mig_n[1] = 0;

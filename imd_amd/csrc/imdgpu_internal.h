@@ -68,6 +68,8 @@ struct imdgpu_ctx {
   double *ref = nullptr;          // nbl_pos 3 planes
   double *mass = nullptr, *epot = nullptr, *rhoh = nullptr;
   int *numneighs = nullptr;
+  int *fdc = nullptr, *fdc2 = nullptr;   // FD cell of the atom at the last update_fd, packed i | j<<10 | k<<20 (-1: none yet);
+                                         // travels with the atom like the reference's cell.fdi/fdj/fdk (imd_alloc.c:210,645)
   // double buffers for re-binning
   double4 *pos2 = nullptr; int *type2 = nullptr, *id2 = nullptr; double *p2 = nullptr, *mass2 = nullptr;
   int *nn2 = nullptr;
@@ -88,6 +90,7 @@ struct imdgpu_ctx {
   // nbr[k*stride+i]; mode 1: per tile, uint16 LDS-slot indices tl16[(tile*W+k)*tile_cap+a]
   int mode = 1, list_mode = 0, autotiled = 0;
   int force_external_halo = 0;
+  int ttm_flux = 0;               // update_fd also counts the atoms that changed FD cells (imd_ttm_3D.c:335-370)
   int ttm_decomposed = 0;         // several ranks: one TTM lattice block per rank, faces through the shared-memory mailbox
   int external_halo = 0;          // ghost atoms are supplied through imdgpu_halo_scatter (multi-rank decomposition)
   int *mig_idx[2]{nullptr, nullptr}; int mig_n[2]{0, 0}, mig_cap = 0; int *mig_flag = nullptr;

@@ -36,6 +36,7 @@ struct TtmState {
   double max_dt_ttm = 0;
   int have_source = 0;              // a source term was uploaded (imdgpu_ttm_upload with `source`): the sub-steps read it
   int *natoms = nullptr, *natoms_old = nullptr;
+  int *flux = nullptr;              // 8 planes: atoms that entered the FD cell since the last update_fd (option ttm_flux)
   double *temp[2]{}, *U[2]{}, *fd_k[2]{};
   double *xi = nullptr, *md_temp = nullptr, *source = nullptr, *vcom = nullptr /* 3 planes */, *dens = nullptr,
          *fd_g = nullptr, *Z = nullptr, *Ce = nullptr, *ne = nullptr;
@@ -230,8 +231,11 @@ __global__ void k_ttm_advance_base(unsigned long long *gbase, int nsub) { *gbase
 __global__ void k_ttm_update_fd(Lat L, int steps, int cap, const int *cell_start, const int *cell_cnt,
                                 const int *numneighs, const double *p, const double *mass, int *natoms,
                                 int *natoms_old, double *temp0, double *temp1, double *xi, double *md_temp,
-                                double *source, double *vcom, double *dens, int ncell, double *blockbuf)
+                                double *source, double *vcom, double *dens, int ncell, double *blockbuf, int *fdc, int *flux)
 {
+  // fdc/flux != nullptr: also the atom-flux bookkeeping of the advection step (imd_ttm_3D.c:335-370): every atom
+  // remembers the global FD cell it was counted in; an atom found in another (i, j) column than last time is counted
+  // by the direction it came from (0: +x, 1: -x, 2: +y, 3: +x-y, 4: +x+y, 5: -y, 6: -x+y, 7: -x-y).
   const int lane = threadIdx.x & 63;
   const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int ni = L.ldim[0], nj = L.ldim[1], nk = L.ldim[2];
@@ -239,6 +243,7 @@ __global__ void k_ttm_update_fd(Lat L, int steps, int cap, const int *cell_start
   const int k = w % nk + 1, j = (w / nk) % nj + 1, i = w / (nk * nj) + 1;     // local FD coordinates (1-based)
   const int c = fidx(L, i + L.off[0], j + L.off[1], k + L.off[2]);
   int nat = 0, neigh = 0;
+  int fl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   double sx = 0, sy = 0, sz = 0, sm = 0;
   for (int xc = (i - 1) * L.ext[0] + 1; xc < i * L.ext[0] + 1; xc++)
     for (int yc = (j - 1) * L.ext[1] + 1; yc < j * L.ext[1] + 1; yc++)
@@ -250,9 +255,24 @@ __global__ void k_ttm_update_fd(Lat L, int steps, int cap, const int *cell_start
           neigh += numneighs[a];
           sx += p[a]; sy += p[cap + a]; sz += p[2 * (size_t) cap + a];
           sm += mass[a];
+          if (fdc) {
+            const int ig = i + L.off[0] - 1, jg = j + L.off[1] - 1, kg = k + L.off[2] - 1, old = fdc[a];
+            if (steps > 0 && old >= 0) {
+              const int di = old & 1023, dj = (old >> 10) & 1023;
+              if (di != ig || dj != jg) {
+                const int q = di > ig ? (dj > jg ? 4 : (dj < jg ? 3 : 0)) : (di < ig ? (dj < jg ? 7 : (dj > jg ? 6 : 1)) : (dj > jg ? 2 : 5));
+                fl[q]++;
+              }
+            }
+            fdc[a] = ig | (jg << 10) | (kg << 20);
+          }
         }
       }
   neigh = wsumi(neigh);
+  if (flux) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) { const int v = wsumi(fl[q]); if (lane == 0) flux[(size_t) q * ncell + c] = v; }
+  }
   sx = wsum(sx); sy = wsum(sy); sz = wsum(sz); sm = wsum(sm);
   double vx = 0, vy = 0, vz = 0, d = 0;
   if (nat > 0) {
@@ -711,7 +731,7 @@ void imdgpu_ttm_free(imdgpu_ctx *ctx)
   TtmState *t = ctx->ttm;
   if (!t) return;
   void *ptrs[] = {t->natoms, t->natoms_old, t->temp[0], t->temp[1], t->U[0], t->U[1], t->fd_k[0], t->fd_k[1], t->xi,
-                  t->md_temp, t->source, t->vcom, t->dens, t->fd_g, t->Z, t->Ce, t->ne, t->cve_z, t->ee_z, t->d_red};
+                  t->md_temp, t->source, t->vcom, t->dens, t->fd_g, t->Z, t->Ce, t->ne, t->cve_z, t->ee_z, t->d_red, t->flux};
   for (void *p : ptrs) if (p) (void) hipFree(p);
   if (t->graph) (void) hipGraphExecDestroy(t->graph);
   if (t->mb_host) (void) hipHostUnregister(t->mb_host);
@@ -757,7 +777,7 @@ extern "C" int imdgpu_ttm_init(imdgpu_ctx *ctx, const imdgpu_ttm_params *par)
       dev_alloc(ctx, &t->fd_k[0], n) || dev_alloc(ctx, &t->fd_k[1], n) || dev_alloc(ctx, &t->xi, n) ||
       dev_alloc(ctx, &t->md_temp, n) || dev_alloc(ctx, &t->source, n) || dev_alloc(ctx, &t->vcom, 3 * n) ||
       dev_alloc(ctx, &t->dens, n) || dev_alloc(ctx, &t->fd_g, n) || dev_alloc(ctx, &t->Z, n) ||
-      dev_alloc(ctx, &t->Ce, n) || dev_alloc(ctx, &t->ne, n) || dev_alloc(ctx, &t->d_red, 16))
+      dev_alloc(ctx, &t->Ce, n) || dev_alloc(ctx, &t->ne, n) || dev_alloc(ctx, &t->d_red, 16) || dev_alloc(ctx, &t->flux, 8 * n))
     return 1;
   int *ip[] = {t->natoms, t->natoms_old};
   for (int *p : ip) HIPCHK(hipMemset(p, 0, n * sizeof(int)));
@@ -765,6 +785,9 @@ extern "C" int imdgpu_ttm_init(imdgpu_ctx *ctx, const imdgpu_ttm_params *par)
                   t->dens, t->fd_g, t->Z, t->Ce, t->ne};
   for (double *p : dp) HIPCHK(hipMemset(p, 0, n * sizeof(double)));
   HIPCHK(hipMemset(t->vcom, 0, 3 * n * sizeof(double)));
+  HIPCHK(hipMemset(t->flux, 0, 8 * n * sizeof(int)));
+  if (ctx->ttm_flux && (t->dim[0] > 1024 || t->dim[1] > 1024 || t->dim[2] > 1024))
+    return imdgpu_fail(ctx, "ttm_flux: the packed FD cell index holds 10 bits per direction");
   size_t nc = (size_t) par->cve_nx * par->cve_ny, ne = (size_t) par->ee_nx * par->ee_ny;
   if (dev_alloc(ctx, &t->cve_z, nc) || dev_alloc(ctx, &t->ee_z, ne)) return 1;
   HIPCHK(hipMemcpy(t->cve_z, par->cve_z, nc * sizeof(double), hipMemcpyHostToDevice));
@@ -802,6 +825,16 @@ static int ttm_xfer(imdgpu_ctx *ctx, const imdgpu_ttm_fields *f, bool down)
       X(f->fd_g, t->fd_g, n * 8) || X(f->Z, t->Z, n * 8) || X(f->Ce, t->Ce, n * 8) || X(f->ne, t->ne, n * 8) ||
       X(f->U, t->U[t->cur], n * 8) || X(f->U2, t->U[t->cur ^ 1], n * 8))
     return 1;
+  if (f->flux) {                       // 8 planes <-> [cell][8] like ttm_Element.flux
+    std::vector<int> h(8 * n);
+    if (down) {
+      HIPCHK(hipMemcpy(h.data(), t->flux, 8 * n * 4, hipMemcpyDeviceToHost));
+      for (size_t c = 0; c < n; c++) for (int q = 0; q < 8; q++) f->flux[8 * c + q] = h[q * n + c];
+    } else {
+      for (size_t c = 0; c < n; c++) for (int q = 0; q < 8; q++) h[q * n + c] = f->flux[8 * c + q];
+      HIPCHK(hipMemcpy(t->flux, h.data(), 8 * n * 4, hipMemcpyHostToDevice));
+    }
+  }
   if (f->vcom) {                       // planes <-> interleaved
     std::vector<double> h(3 * n);
     if (down) {
@@ -828,7 +861,7 @@ extern "C" int imdgpu_ttm_update_fd(imdgpu_ctx *ctx, int steps)
   hipLaunchKernelGGL(k_ttm_update_fd, dim3(nblk((long long) t->ldim[0] * t->ldim[1] * t->ldim[2] * 64, TTM_WG)), dim3(TTM_WG), 0, ctx->stream, L, steps,
                      ctx->cap_local, ctx->cell_start, ctx->cell_cnt, ctx->numneighs, ctx->p, ctx->mass, t->natoms,
                      t->natoms_old, t->temp[0], t->temp[1], t->xi, t->md_temp, t->source, t->vcom, t->dens, t->ncell,
-                     (double *) nullptr);
+                     (double *) nullptr, ctx->ttm_flux ? ctx->fdc : (int *) nullptr, ctx->ttm_flux ? t->flux : (int *) nullptr);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -843,7 +876,8 @@ extern "C" int imdgpu_ttm_local_block(imdgpu_ctx *ctx, int steps, double *dev_ou
   ProfScope ps(ctx, PROF_TTM_UPDATE);
   hipLaunchKernelGGL(k_ttm_update_fd, dim3(nblk((long long) nb * 64, TTM_WG)), dim3(TTM_WG), 0, ctx->stream, L, steps,
                      ctx->cap_local, ctx->cell_start, ctx->cell_cnt, ctx->numneighs, ctx->p, ctx->mass, t->natoms,
-                     t->natoms_old, t->temp[0], t->temp[1], t->xi, t->md_temp, t->source, t->vcom, t->dens, t->ncell, dev_out);
+                     t->natoms_old, t->temp[0], t->temp[1], t->xi, t->md_temp, t->source, t->vcom, t->dens, t->ncell, dev_out,
+                     (int *) nullptr, (int *) nullptr);
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -52,12 +52,13 @@ class TtmParamsC(C.Structure):
 
 
 TTM_FIELDS = ("natoms", "natoms_old", "temp", "temp2", "xi", "md_temp", "source", "vcom", "dens", "fd_k", "fd_g",
-              "Z", "Ce", "ne", "U", "U2")
+              "Z", "Ce", "ne", "U", "U2", "flux")
+TTM_INT_FIELDS = ("natoms", "natoms_old", "flux")
 
 
 class TtmFieldsC(C.Structure):
     """imdgpu_ttm_fields"""
-    _fields_ = [(n, C.POINTER(C.c_int) if n.startswith("natoms") else C.POINTER(C.c_double)) for n in TTM_FIELDS]
+    _fields_ = [(n, C.POINTER(C.c_int) if n in TTM_INT_FIELDS else C.POINTER(C.c_double)) for n in TTM_FIELDS]
 
 
 def build(force=False):

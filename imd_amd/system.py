@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import lib as _lib
-from .lib import TTM_FIELDS, ImdGpuError, PotTableC, TtmFieldsC, TtmParamsC
+from .lib import TTM_FIELDS, TTM_INT_FIELDS, ImdGpuError, PotTableC, TtmFieldsC, TtmParamsC
 
 
 def _dp(a):
@@ -242,9 +242,9 @@ class GpuSystem:
         F = TtmFieldsC()
         out = {}
         for n in fields:
-            shp = self.fd_dim + ((3,) if n == "vcom" else ())
-            out[n] = np.zeros(shp, dtype=np.int32 if n.startswith("natoms") else np.float64)
-            setattr(F, n, _ip(out[n]) if n.startswith("natoms") else _dp(out[n]))
+            shp = self.fd_dim + ((3,) if n == "vcom" else (8,) if n == "flux" else ())
+            out[n] = np.zeros(shp, dtype=np.int32 if n in TTM_INT_FIELDS else np.float64)
+            setattr(F, n, _ip(out[n]) if n in TTM_INT_FIELDS else _dp(out[n]))
         self._ck(self.L.imdgpu_ttm_download(self.h, C.byref(F)))
         return out
 
@@ -252,9 +252,9 @@ class GpuSystem:
         F = TtmFieldsC()
         keep = []
         for n, v in fields.items():
-            a = np.ascontiguousarray(v, dtype=np.int32 if n.startswith("natoms") else np.float64)
+            a = np.ascontiguousarray(v, dtype=np.int32 if n in TTM_INT_FIELDS else np.float64)
             keep.append(a)
-            setattr(F, n, _ip(a) if n.startswith("natoms") else _dp(a))
+            setattr(F, n, _ip(a) if n in TTM_INT_FIELDS else _dp(a))
         self._ck(self.L.imdgpu_ttm_upload(self.h, C.byref(F)))
 
     def EOS_te_from_r_ee(self, r, e):

@@ -156,6 +156,8 @@ typedef struct {
   double *vcom;                  /* 3 per cell: vcomx, vcomy, vcomz */
   double *dens, *fd_k, *fd_g, *Z, *Ce, *ne;
   double *U, *U2;
+  int    *flux;                  /* 8 per cell: atoms that entered the cell since the last update_fd, by direction
+                                    (ttm_Element.flux, imd_ttm_3D.c:335-370); counted with option "ttm_flux" */
 } imdgpu_ttm_fields;
 
 /* [init_ttm] needs geometry, params, pair_pot (neighvol from pair_pot.end[0], :1019) */

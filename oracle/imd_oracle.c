@@ -67,6 +67,7 @@ orc_sys *orc_new(const int dim[3], int cap, int ntypes, const double box[9],
   s->sorte  = (int *) xcalloc(slots, sizeof(int));
   s->nummer = (int *) xcalloc(slots, sizeof(int));
   s->numneighs = (int *) xcalloc(slots, sizeof(int));
+  s->fdi = (int *) xcalloc(slots, sizeof(int)); s->fdj = (int *) xcalloc(slots, sizeof(int)); s->fdk = (int *) xcalloc(slots, sizeof(int));
   s->cl_off = (int *) xcalloc(s->nall+1, sizeof(int));
   s->restrictions[0] = s->restrictions[1] = s->restrictions[2] = 1.0;
   orc_make_cell_lists(s);
@@ -86,7 +87,7 @@ void orc_free(orc_sys *s)
   free(s->n); free(s->inner); free(s->nq);
   free(s->ort); free(s->impuls); free(s->kraft); free(s->nbl_pos);
   free(s->masse); free(s->pot_eng); free(s->rho); free(s->dF);
-  free(s->sorte); free(s->nummer); free(s->numneighs);
+  free(s->sorte); free(s->nummer); free(s->numneighs); free(s->fdi); free(s->fdj); free(s->fdk);
   free(s->cl_off); free(s->tl); free(s->tb);
   free_table(&s->pair); free_table(&s->rhotab); free_table(&s->embed);
   free(s);
@@ -274,6 +275,7 @@ static void copy_slot(orc_sys *s, size_t to, size_t from)
   s->rho[to] = s->rho[from];     s->dF[to] = s->dF[from];
   s->sorte[to] = s->sorte[from]; s->nummer[to] = s->nummer[from];
   s->numneighs[to] = s->numneighs[from];
+  s->fdi[to] = s->fdi[from]; s->fdj[to] = s->fdj[from]; s->fdk[to] = s->fdk[from];   /* imd_alloc.c:210-212 */
 }
 
 /* Wrap atoms of inner cells back into the box, direction by direction.

@@ -58,6 +58,7 @@ typedef struct {
   double  tot_pot_energy, virial, tot_kin_energy;
   int     is_short;
   double  restrictions[3];   /* single vsorte: (1,1,1)                 */
+  int    *fdi, *fdj, *fdk;   /* [nall*cap] global FD cell of the atom at the last update_fd (cell.fdi.., imd_alloc.c:645) */
 } orc_sys;
 
 orc_sys *orc_new(const int dim[3], int cap, int ntypes, const double box[9],

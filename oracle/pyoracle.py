@@ -47,7 +47,8 @@ class _Sys(C.Structure):
                 ("pair", _Table), ("rhotab", _Table), ("embed", _Table),
                 ("have_pair", C.c_int), ("have_eam", C.c_int), ("count_ttm_neigh", C.c_int),
                 ("tot_pot_energy", C.c_double), ("virial", C.c_double), ("tot_kin_energy", C.c_double),
-                ("is_short", C.c_int), ("restrictions", C.c_double * 3)]
+                ("is_short", C.c_int), ("restrictions", C.c_double * 3),
+                ("fdi", C.POINTER(C.c_int)), ("fdj", C.POINTER(C.c_int)), ("fdk", C.POINTER(C.c_int))]
 
 
 def lib():
@@ -322,7 +323,7 @@ class _Ttm(C.Structure):
                 ("xi", C.POINTER(C.c_double)), ("md_temp", C.POINTER(C.c_double)), ("source", C.POINTER(C.c_double)),
                 ("vcom", C.POINTER(C.c_double)), ("dens", C.POINTER(C.c_double)), ("fd_k", C.POINTER(C.c_double)),
                 ("fd_g", C.POINTER(C.c_double)), ("Z", C.POINTER(C.c_double)), ("Ce", C.POINTER(C.c_double)),
-                ("ne", C.POINTER(C.c_double)), ("cve", _Eos), ("ee", _Eos)]
+                ("ne", C.POINTER(C.c_double)), ("cve", _Eos), ("ee", _Eos), ("flux", C.POINTER(C.c_int))]
 
 
 _TTM_READY = False
@@ -383,6 +384,7 @@ class OracleTTM:
         for name in ("natoms", "natoms_old", "xi", "md_temp", "source", "dens", "fd_k", "fd_g", "Z", "Ce", "ne"):
             setattr(self, name, aa(getattr(self.t, name), (n,)).reshape(self.dim))
         self.vcom = aa(self.t.vcom, (3 * n,)).reshape(self.dim + (3,))
+        self.flux = aa(self.t.flux, (8 * n,)).reshape(self.dim + (8,))
         self._temp = [aa(self.t.temp[q], (n,)).reshape(self.dim) for q in (0, 1)]
         self._U = [aa(self.t.U[q], (n,)).reshape(self.dim) for q in (0, 1)]
 

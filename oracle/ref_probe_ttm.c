@@ -125,8 +125,9 @@ void __wrap_calc_ttm(void)
   }
   update_fd();
   if (dumping) dump_lattice("update_fd");
+  if (dumping && getenv("IMD_PROBE_FLUX")) dump_flux("flux");   /* update_fd's atom-flux counters (:335-370) */
   if (getenv("IMD_PROBE_ADV")) {           /* advection step of calc_ttm (imd_ttm_3D.c:58-60); returns at once for steps < 1 */
-    if (dumping) dump_flux("flux");
+    if (dumping && !getenv("IMD_PROBE_FLUX")) dump_flux("flux");
     do_ADV(1.0);
     if (dumping) dump_lattice("adv");
   }

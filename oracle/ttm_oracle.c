@@ -55,6 +55,7 @@ orc_ttm *orc_ttm_new(const int md_dim[3], const int fd_ext[3], const double fd_h
   t->vol = fd_h[0] * fd_h[1] * fd_h[2];                                   /* :1012 */
   t->neighvol = pow(sqrt(r2_cut_pair), 3.0) * 4.0 / 3.0 * M_PI;           /* :1019 */
   t->natoms = (int *) zalloc(n, sizeof(int)); t->natoms_old = (int *) zalloc(n, sizeof(int));
+  t->flux = (int *) zalloc(8 * n, sizeof(int));
   t->temp[0] = (double *) zalloc(n, 8); t->temp[1] = (double *) zalloc(n, 8);
   t->U[0] = (double *) zalloc(n, 8); t->U[1] = (double *) zalloc(n, 8);
   t->xi = (double *) zalloc(n, 8); t->md_temp = (double *) zalloc(n, 8); t->source = (double *) zalloc(n, 8);
@@ -68,7 +69,7 @@ orc_ttm *orc_ttm_new(const int md_dim[3], const int fd_ext[3], const double fd_h
 void orc_ttm_free(orc_ttm *t)
 {
   if (!t) return;
-  free(t->natoms); free(t->natoms_old); free(t->temp[0]); free(t->temp[1]); free(t->U[0]); free(t->U[1]);
+  free(t->flux); free(t->natoms); free(t->natoms_old); free(t->temp[0]); free(t->temp[1]); free(t->U[0]); free(t->U[1]);
   free(t->xi); free(t->md_temp); free(t->source); free(t->vcom); free(t->dens); free(t->fd_k); free(t->fd_g);
   free(t->Z); free(t->Ce); free(t->ne); free(t->cve.z); free(t->ee.z); free(t);
 }
@@ -246,7 +247,7 @@ double orc_get_kappa(double Te, double Ti, double Ne, double Z, double omega_las
 }
 
 /* ---- update_fd, imd_ttm_3D.c:233-488 ------------------------------------------ */
-void orc_ttm_update_fd(orc_ttm *t, const orc_sys *s, int steps)
+void orc_ttm_update_fd(orc_ttm *t, orc_sys *s, int steps)
 {
   int i, j, k;
   double *T1 = t->temp[t->cur], *T2 = t->temp[t->cur ^ 1];
@@ -256,9 +257,12 @@ void orc_ttm_update_fd(orc_ttm *t, const orc_sys *s, int steps)
         size_t c = FIDX(t, i, j, k);
         int xc, yc, zc, l, tot_neighs = 0, nat = 0;
         double vx = 0.0, vy = 0.0, vz = 0.0, tot_mass = 0.0, mdt = 0.0;
+        int *fl = t->flux + 8 * c, q;
+        const int ig = i - 1, jg = j - 1, kg = k - 1;            /* global FD indices of one rank, :281,:293,:296 */
         t->source[c] = 0.0;
         t->natoms_old[c] = t->natoms[c];
         t->xi[c] = 0.0;
+        for (q = 0; q < 8; q++) fl[q] = 0;
         for (xc = (i - 1) * t->ext[0] + 1; xc < i * t->ext[0] + 1; xc++)          /* md_cellptrs order, :1094-1120 */
           for (yc = (j - 1) * t->ext[1] + 1; yc < j * t->ext[1] + 1; yc++)
             for (zc = (k - 1) * t->ext[2] + 1; zc < k * t->ext[2] + 1; zc++) {
@@ -269,6 +273,20 @@ void orc_ttm_update_fd(orc_ttm *t, const orc_sys *s, int steps)
                 tot_neighs += s->numneighs[a];
                 vx += s->impuls[3 * a]; vy += s->impuls[3 * a + 1]; vz += s->impuls[3 * a + 2];
                 tot_mass += s->masse[a];
+                /* atom-flux counters for the advection step (:335-370): where was the atom at the last update_fd?
+                 * flux 0: from +x, 1: from -x, 2: from +y, 3: from +x-y, 4: from +x+y, 5: from -y, 6: from -x+y, 7: from -x-y */
+                if (steps > 0 && (s->fdi[a] != ig || s->fdj[a] != jg)) {
+                  const int di = s->fdi[a], dj = s->fdj[a];
+                  if (di > ig && dj > jg) fl[4]++;
+                  else if (di > ig && dj < jg) fl[3]++;
+                  else if (di > ig && dj == jg) fl[0]++;
+                  else if (di < ig && dj < jg) fl[7]++;
+                  else if (di < ig && dj > jg) fl[6]++;
+                  else if (di < ig && dj == jg) fl[1]++;
+                  else if (di == ig && dj > jg) fl[2]++;
+                  else if (di == ig && dj < jg) fl[5]++;
+                }
+                s->fdi[a] = ig; s->fdj[a] = jg; s->fdk[a] = kg;
               }
             }
         t->natoms[c] = nat;
@@ -439,7 +457,7 @@ void orc_ttm_cfl(orc_ttm *t, int steps, double timestep, int fd_n_timesteps)
 
 /* first block of calc_ttm (:50-77) without do_tmm / do_ADV -- the sequence the
  * product implements and the probe (oracle/ref_probe_ttm.c) drives */
-void orc_ttm_calc(orc_ttm *t, const orc_sys *s, int steps, int diff_substeps)
+void orc_ttm_calc(orc_ttm *t, orc_sys *s, int steps, int diff_substeps)
 {
   int i;
   double tau = s->timestep / ((double) diff_substeps);

@@ -20,6 +20,7 @@ typedef struct {
   double *temp[2], *U[2];
   double *xi, *md_temp, *source, *vcom, *dens, *fd_k, *fd_g, *Z, *Ce, *ne;
   orc_eos cve, ee;
+  int *flux;                 /* [8*ncell]: atoms that entered the FD cell since the last update_fd, by direction (:335-370) */
 } orc_ttm;
 
 orc_ttm *orc_ttm_new(const int md_dim[3], const int fd_ext[3], const double fd_h[3], const int pbc[3],
@@ -34,13 +35,13 @@ double orc_eos_te_from_r_ee(const orc_ttm *t, double r, double e);
 double orc_mean_charge(double temp, double rho, double z0, double am);
 double orc_get_gamma(double Te, double Ti, double Ne, double Z, double omega_laser);
 double orc_get_kappa(double Te, double Ti, double Ne, double Z, double omega_laser);
-void orc_ttm_update_fd(orc_ttm *t, const orc_sys *s, int steps);
+void orc_ttm_update_fd(orc_ttm *t, orc_sys *s, int steps);
 void orc_ttm_cell_activation(orc_ttm *t);
 void orc_ttm_fillmesh(orc_ttm *t, int steps);
 void orc_ttm_fill_ghosts(orc_ttm *t);
 void orc_ttm_diff(orc_ttm *t, double tau, int diff_substeps);
 void orc_ttm_cfl(orc_ttm *t, int steps, double timestep, int fd_n_timesteps);
-void orc_ttm_calc(orc_ttm *t, const orc_sys *s, int steps, int diff_substeps);
+void orc_ttm_calc(orc_ttm *t, orc_sys *s, int steps, int diff_substeps);
 void orc_move_atoms_ttm(orc_sys *s, const orc_ttm *t);
 #ifdef __cplusplus
 }

@@ -71,6 +71,10 @@ CASES = {
     "eam2_l12_coarse": dict(binary="imd_eam_nve_nbl", box="8 8 8", temp=0.05, steps=20, dump=[0, 20], full=[0],
                             pot="eam2types_coarse", nbl=True, coord="_l12",
                             types="ntypes 2\ntotal_types 2\nmasses 26.9815 63.546\ntypes 0 1"),
+    # atom-flux counters of update_fd (imd_ttm_3D.c:335-370): 19 x 8 x 6 unit cells put lattice planes 0.2 A from
+    # cell boundaries, so atoms change FD cells at the list rebuilds of steps 17, 30 and 43; one FD cell thick in z
+    "ttm_flux": dict(binary="imd_mpi_eam_ttm3d_nbl", box="19 8 6", temp=0.12, steps=44, dump=[0, 1, 17, 30, 43], full=[],
+                     pot="eam", nbl=True, ttm=dict(fd_ext="1 1 3", n=100, min_atoms=5), env=dict(IMD_PROBE_FLUX="1")),
     "eam_cellpair_2048": dict(binary="imd_eam_nve", box="8 8 8", temp=0.0258, steps=10, dump=[0, 10], full=[0, 10],
                               pot="eam", nbl=False),
 }
@@ -119,6 +123,7 @@ def run_case(name, c):
             eos = write_planar_eos(d)
         open(os.path.join(d, "t.param"), "w").write(par)
         env = dict(os.environ, IMD_PROBE_DIR=d, IMD_PROBE_STEPS=",".join(map(str, c["dump"])))
+        env.update(c.get("env", {}))
         r = subprocess.run([os.path.join(REFBIN, c["binary"]), "-p", "t.param"], cwd=d, env=env,
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
@@ -168,6 +173,11 @@ def run_case(name, c):
             for k, v in eos.items():
                 out["eos_" + k] = v
         for tag, st in T["stages"].items():
+            if "flux" in st:
+                out["t%d_flux" % s] = st["flux"].astype(np.int16)
+                continue
+            if "env" in c and tag not in ("update_fd", "substeps_done"):
+                continue                                  # the flux fixture keeps two stages per step only
             out["t%d_%s_max_dt_ttm" % (s, tag)] = st["max_dt_ttm"]
             for f in po.TTM_REC.names:
                 if tag in ("entry", "substep2") and f not in ("temp", "xi", "natoms", "fd_k", "U", "temp2"):

@@ -138,3 +138,34 @@ def test_inverse_eos_vs_reference_and_oracle():
     to = np.array([t.eos_te_from_r_ee(r, e) for r, e in zip(G["r"], G["e"])])
     assert np.abs(te / to - 1).max() < 1e-9
     t.close(); s.close()
+
+
+def test_flux_counters_of_update_fd_over_a_trajectory():
+    """update_fd's atom-flux counters (imd_ttm_3D.c:335-370, option "ttm_flux"): the device-resident MD + TTM loop from
+    the reference's step-0 arrangement; at the list rebuilds where atoms changed FD cells (steps 17, 30, 43) the eight
+    counters of every cell equal the reference's exactly.  The per-atom FD cell travels through every re-binning."""
+    G = gu.load("ttm_flux")
+    pre = "s0_"
+    s = GpuSystem(G["box"], G["pbc_dirs"], G["cell_dim"], 1, float(G["cellsz"]), float(G["nbl_margin"]),
+                  float(G["timestep"]), count_ttm_neighbours=True)
+    s.set_option("ttm_flux", 1)
+    s.upload_tables(gu.table(G, "pair_pot"), gu.table(G, "rho_h_tab"), gu.table(G, "embed_pot"))
+    cell_n = np.zeros(int(np.prod(G["cell_dim"])), np.int32)
+    cell_n[G["cells"]] = G[pre + "cell_n"][G["cells"]]
+    s.upload_cells(cell_n, G[pre + "ort"], G[pre + "impuls"], G[pre + "masse"], G[pre + "sorte"].astype(np.int32),
+                   G[pre + "nummer"])
+    cve, ee = _eos(G)
+    s.init_ttm(G["ttm_fd_ext"], int(G["ttm_fd_min_atoms"]), int(G["ttm_diff_substeps"]), float(G["ttm_atomic_weight"]),
+               float(G["ttm_atomic_charge"]), cve, ee, float(G["ttm_omega_laser"]))
+    inner = (slice(1, -1),) * 3
+    seen = 0
+    for st in range(44):
+        s.md_step(st)
+        if st in (1, 17, 30, 43):
+            d = s.ttm_download(fields=("flux", "natoms"))
+            assert np.array_equal(d["flux"][inner], G["t%d_flux" % st][inner]), st
+            assert np.array_equal(d["natoms"][inner], G["t%d_update_fd_natoms" % st][inner])
+            seen += int(d["flux"].sum())
+    assert seen == int(G["t17_flux"].sum() + G["t30_flux"].sum() + G["t43_flux"].sum()) > 0
+    assert s.get_sums()["nbl_count"] == int(G["s43_nbl_count"])
+    s.close()

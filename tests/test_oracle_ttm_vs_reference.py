@@ -98,3 +98,33 @@ def test_inverse_eos_vs_reference():
     assert np.abs(te - G["t_out"]).max() < 1e-5
     assert (np.abs(te - G["t_out"]) < 1e-9).sum() >= 80
     t.close()
+
+
+def test_flux_counters_of_update_fd_over_a_trajectory():
+    """update_fd's atom-flux counters (imd_ttm_3D.c:335-370; the input of do_ADV): MD + TTM from the reference's
+    step-0 arrangement for 43 steps; at the three list rebuilds where atoms changed FD cells (steps 17, 30, 43) the
+    eight counters of every cell must equal the reference's exactly, and the arrangement must still be the reference's."""
+    G = gu.load("ttm_flux")
+    s = gu.oracle_from_golden(G, 0)
+    s.s.count_ttm_neigh = 1
+    t = gu.oracle_ttm_from_golden(G, s)
+    nsub = int(G["ttm_diff_substeps"])
+    inner = (slice(1, -1),) * 3
+    for st in range(44):
+        s.calc_forces(st)
+        if st in (0, 1, 17, 30, 43):
+            t.update_fd(st)
+            assert np.array_equal(t.flux[inner], G["t%d_flux" % st][inner]), st
+            assert np.array_equal(t.natoms[inner], G["t%d_update_fd_natoms" % st][inner])
+            # run the rest of calc_ttm from here (update_fd again is idempotent for everything but the counters)
+            t.cell_activation(); t.fillmesh(st); t.fill_ghosts()
+            for _ in range(nsub):
+                t.diff(float(G["ttm_tau"]), nsub); t.fillmesh(st); t.fill_ghosts()
+        else:
+            t.calc_ttm(st, nsub)
+        if st in (17, 30, 43):
+            assert np.array_equal(s.gather_inner("nummer"), G["s%d_nummer" % st])
+        t.move_atoms_ttm()
+        s.check_nblist()
+    assert int(G["t17_flux"].sum()) > 0 and int(G["t30_flux"].sum()) > 0
+    t.close()
