@@ -323,7 +323,7 @@ class _Ttm(C.Structure):
                 ("xi", C.POINTER(C.c_double)), ("md_temp", C.POINTER(C.c_double)), ("source", C.POINTER(C.c_double)),
                 ("vcom", C.POINTER(C.c_double)), ("dens", C.POINTER(C.c_double)), ("fd_k", C.POINTER(C.c_double)),
                 ("fd_g", C.POINTER(C.c_double)), ("Z", C.POINTER(C.c_double)), ("Ce", C.POINTER(C.c_double)),
-                ("ne", C.POINTER(C.c_double)), ("cve", _Eos), ("ee", _Eos), ("flux", C.POINTER(C.c_int))]
+                ("ne", C.POINTER(C.c_double)), ("cve", _Eos), ("ee", _Eos), ("flux", C.POINTER(C.c_int)), ("adv", C.c_int)]
 
 
 _TTM_READY = False
@@ -341,6 +341,7 @@ def _ttm_lib():
         L.orc_ttm_set_eos.argtypes = [tp, C.c_int, C.c_int, C.c_int] + [C.c_double] * 4 + [C.POINTER(C.c_double)]
         L.orc_ttm_update_fd.argtypes = [tp, sp, C.c_int]
         L.orc_ttm_cell_activation.argtypes = [tp]
+        L.orc_ttm_adv.argtypes = [tp, C.c_double, C.c_int]
         L.orc_ttm_fillmesh.argtypes = [tp, C.c_int]
         L.orc_ttm_fill_ghosts.argtypes = [tp]
         L.orc_ttm_diff.argtypes = [tp, C.c_double, C.c_int]
@@ -403,6 +404,7 @@ class OracleTTM:
         _ttm_lib().orc_ttm_set_eos(self._p, which, nx, ny, xmin, xmax, ymin, ymax, _dp(z))
 
     def update_fd(self, steps): _ttm_lib().orc_ttm_update_fd(self._p, self.sys._p, steps)
+    def adv(self, tau, steps): _ttm_lib().orc_ttm_adv(self._p, float(tau), int(steps))
     def cell_activation(self): _ttm_lib().orc_ttm_cell_activation(self._p)
     def fillmesh(self, steps): _ttm_lib().orc_ttm_fillmesh(self._p, steps)
     def fill_ghosts(self): _ttm_lib().orc_ttm_fill_ghosts(self._p)

@@ -17,7 +17,7 @@
  * table's regular (rho, T) grid; on the planar synthetic tables of the fixtures
  * both rules reproduce the plane, which is what pins the unit chain.
  *
- * Left out (not restated this round): do_ADV / do_COMMFLUX (advection),
+ * do_ADV / do_COMMFLUX (advection) are restated in orc_ttm_adv.  Left out:
  * do_tmm / FDTD / laser sources, COLRAD.
  */
 #include "ttm_oracle.h"
@@ -455,13 +455,56 @@ void orc_ttm_cfl(orc_ttm *t, int steps, double timestep, int fd_n_timesteps)
   t->max_dt_ttm *= 0.9;
 }
 
-/* first block of calc_ttm (:50-77) without do_tmm / do_ADV -- the sequence the
+/* do_ADV, :1321-1458, with do_COMMFLUX (:667-995) for a lattice that is not decomposed.
+ *
+ * What the reference compiles (ADVMODE 1, ADV2D undefined -- the file defines ADVMODE2d, which nothing tests): an
+ * upwind update of the electron energy per atom U along x only, and only in the lattice plane k = 1 (:1327), from the
+ * atom-flux counters of update_fd; the new U goes into l2, for an active cell the temperature is recovered with the
+ * inverse EOS, then l1 and l2 are swapped as a whole (:1454-1456).  Cells outside the plane k = 1 are not written, so
+ * after the swap they hold l2's values: temp and U from before the last diffusion sub-step of the previous MD step
+ * (do_DIFF copies every other field it changes into both lattices, update_fd writes both, do_FILLMESH's outputs are
+ * recomputed before they are read).  That is exactly what flipping `cur` does to the ping-pong pairs here.
+ *
+ * do_COMMFLUX only moves flux[8] and U of the boundary columns i = 1 / lx-2 into the neighbour rank's ghost columns
+ * (non-periodically: ranks at the ends of the x range exchange with their one inner neighbour only).  On a lattice
+ * held as a whole those ghost columns are the neighbouring inner columns themselves, and the ghost columns at the two
+ * global x faces are never written by anyone: flux 0 and U 0 as init_ttm (:1136-1157) set them in every cell, ghosts included -- also with periodic x.
+ * Note: with cpu_dim.x == 1 the reference cannot run this step at all (its Sendrecv to itself uses send tag 7302 and
+ * receive tag 7402); the fixture tests/golden/ttm_adv.npz therefore comes from a run on two ranks. */
+void orc_ttm_adv(orc_ttm *t, double tau, int steps)
+{
+  int i, j;
+  const int k = 1;
+  double *T2 = t->temp[t->cur ^ 1], *U1 = t->U[t->cur], *U2 = t->U[t->cur ^ 1];
+  if (steps < 1) return;
+  for (i = 1; i < t->dim[0] - 1; i++)
+    for (j = 1; j < t->dim[1] - 1; j++) {
+      size_t c = FIDX(t, i, j, k), xp = FIDX(t, i + 1, j, k), xm = FIDX(t, i - 1, j, k);
+      double Nold = (double) t->natoms_old[c], Nnew = (double) t->natoms[c];
+      if (Nnew > 0) {
+        U2[c] = U1[c] * Nold / Nnew + tau * (
+                  + (double) t->flux[8 * c + 0] * U1[xp]        /* received from +x */
+                  - (double) t->flux[8 * xp + 1] * U1[c]        /* left to +x */
+                  + (double) t->flux[8 * c + 1] * U1[xm]        /* received from -x */
+                  - (double) t->flux[8 * xm + 0] * U1[c]        /* left to -x */
+                ) / Nnew;
+        if (t->natoms[c] >= t->fd_min_atoms)
+          T2[c] = orc_eos_te_from_r_ee(t, t->dens[c], U2[c] / (26.9815 * AMU * J2EV)) / 11604.5;
+      } else if (Nnew < 1) {
+        U2[c] = 0.0; T2[c] = 0.0;
+      }
+    }
+  t->cur ^= 1;                                                        /* l1 <-> l2, :1454-1456 */
+}
+
+/* first block of calc_ttm (:50-77) without do_tmm; do_ADV only with t->adv -- the sequence the
  * product implements and the probe (oracle/ref_probe_ttm.c) drives */
 void orc_ttm_calc(orc_ttm *t, orc_sys *s, int steps, int diff_substeps)
 {
   int i;
   double tau = s->timestep / ((double) diff_substeps);
   orc_ttm_update_fd(t, s, steps);
+  if (t->adv) orc_ttm_adv(t, 1.0, steps);
   orc_ttm_cell_activation(t);
   orc_ttm_fillmesh(t, steps);
   orc_ttm_fill_ghosts(t);

@@ -21,6 +21,7 @@ typedef struct {
   double *xi, *md_temp, *source, *vcom, *dens, *fd_k, *fd_g, *Z, *Ce, *ne;
   orc_eos cve, ee;
   int *flux;                 /* [8*ncell]: atoms that entered the FD cell since the last update_fd, by direction (:335-370) */
+  int adv;                   /* 1: orc_ttm_calc runs do_ADV after update_fd as calc_ttm does (:57-60) */
 } orc_ttm;
 
 orc_ttm *orc_ttm_new(const int md_dim[3], const int fd_ext[3], const double fd_h[3], const int pbc[3],
@@ -36,6 +37,7 @@ double orc_mean_charge(double temp, double rho, double z0, double am);
 double orc_get_gamma(double Te, double Ti, double Ne, double Z, double omega_laser);
 double orc_get_kappa(double Te, double Ti, double Ne, double Z, double omega_laser);
 void orc_ttm_update_fd(orc_ttm *t, orc_sys *s, int steps);
+void orc_ttm_adv(orc_ttm *t, double tau, int steps);
 void orc_ttm_cell_activation(orc_ttm *t);
 void orc_ttm_fillmesh(orc_ttm *t, int steps);
 void orc_ttm_fill_ghosts(orc_ttm *t);

@@ -75,6 +75,12 @@ CASES = {
     # cell boundaries, so atoms change FD cells at the list rebuilds of steps 17, 30 and 43; one FD cell thick in z
     "ttm_flux": dict(binary="imd_mpi_eam_ttm3d_nbl", box="19 8 6", temp=0.12, steps=44, dump=[0, 1, 17, 30, 43], full=[],
                      pot="eam", nbl=True, ttm=dict(fd_ext="1 1 3", n=100, min_atoms=5), env=dict(IMD_PROBE_FLUX="1")),
+    # do_ADV / do_COMMFLUX (imd_ttm_3D.c:1321-1458, :667-995): the same system on TWO ranks along x -- the reference's
+    # advection step only runs with cpu_dim.x >= 2 (on one rank do_COMMFLUX posts a self-Sendrecv whose tags never
+    # match) -- assembled into the global lattice; lattice stages only (see run_adv_case)
+    "ttm_adv": dict(binary="imd_mpi_eam_ttm3d_nbl", box="19 8 6", temp=0.12, steps=60, dump=None, full=[],
+                    pot="eam", nbl=True, cpu="2 1 1", ttm=dict(fd_ext="1 1 3", n=100, min_atoms=5),
+                    env=dict(IMD_PROBE_ADV="1")),
     "eam_cellpair_2048": dict(binary="imd_eam_nve", box="8 8 8", temp=0.0258, steps=10, dump=[0, 10], full=[0, 10],
                               pot="eam", nbl=False),
 }
@@ -96,32 +102,39 @@ def write_planar_eos(d):
     return dict(nr=nr, nt=nt, r=r, t=t, ts=ts, cve=zc, ee=ze)
 
 
+def write_inputs(c, d):
+    """parameter file, potential files and EOS tables of case `c` in directory `d`"""
+    eos = None
+    par = COMMON.format(pbc=c.get("pbc", "1 1 1"), seed=c.get("seed", 12345), cpu=c.get("cpu", "1 1 1"))
+    par += "box_param %s\nstarttemp %g\nmaxsteps %d\n" % (c["box"], c["temp"], c["steps"])
+    if "coord" in c:
+        par = par.replace("coordname _fcc", "coordname " + c["coord"])
+    if "types" in c:
+        par = par.replace("ntypes 1\ntotal_types 1\nmasses 26.9815\ntypes 0", c["types"])
+    if c["pot"].startswith("eam2types"):
+        potential.write_synthetic_eam_files_2types(d, rows=0.15 if c["pot"].endswith("coarse") else 1.0)
+        par += "core_potential_file phi.pt\nembedding_energy_file F.pt\natomic_e-density_file rho.pt\n"
+    elif c["pot"] == "eam":
+        potential.write_synthetic_eam_files(d)
+        par += "core_potential_file phi.pt\nembedding_energy_file F.pt\natomic_e-density_file rho.pt\n"
+    else:
+        par += "lj_epsilon 0.392\nlj_sigma 2.62\nr_cut 6.0\nr_begin 1.5\npot_res 2000\n"
+    if c["nbl"]:
+        par += "nbl_margin 0.5\nnbl_size 1.5\n"
+    par += c.get("extra", "")
+    if "ttm" in c:
+        par = par.replace("ensemble nve", "ensemble ttm")
+        par += ("fd_ext %s\nfd_n_timesteps %d\nfd_min_atoms %d\natomic_weight 26.9815\natomic_charge 13\n"
+                "ttm_int 100000\nI0 1.0\nlambda 800e-9\nlaser_sigma_t 100e-15\nlaser_t_0 1.0\n"
+                % (c["ttm"]["fd_ext"], c["ttm"]["n"], c["ttm"]["min_atoms"]))
+        eos = write_planar_eos(d)
+    open(os.path.join(d, "t.param"), "w").write(par)
+    return par, eos
+
+
 def run_case(name, c):
     with tempfile.TemporaryDirectory() as d:
-        par = COMMON.format(pbc=c.get("pbc", "1 1 1"), seed=c.get("seed", 12345), cpu=c.get("cpu", "1 1 1"))
-        par += "box_param %s\nstarttemp %g\nmaxsteps %d\n" % (c["box"], c["temp"], c["steps"])
-        if "coord" in c:
-            par = par.replace("coordname _fcc", "coordname " + c["coord"])
-        if "types" in c:
-            par = par.replace("ntypes 1\ntotal_types 1\nmasses 26.9815\ntypes 0", c["types"])
-        if c["pot"].startswith("eam2types"):
-            potential.write_synthetic_eam_files_2types(d, rows=0.15 if c["pot"].endswith("coarse") else 1.0)
-            par += "core_potential_file phi.pt\nembedding_energy_file F.pt\natomic_e-density_file rho.pt\n"
-        elif c["pot"] == "eam":
-            potential.write_synthetic_eam_files(d)
-            par += "core_potential_file phi.pt\nembedding_energy_file F.pt\natomic_e-density_file rho.pt\n"
-        else:
-            par += "lj_epsilon 0.392\nlj_sigma 2.62\nr_cut 6.0\nr_begin 1.5\npot_res 2000\n"
-        if c["nbl"]:
-            par += "nbl_margin 0.5\nnbl_size 1.5\n"
-        par += c.get("extra", "")
-        if "ttm" in c:
-            par = par.replace("ensemble nve", "ensemble ttm")
-            par += ("fd_ext %s\nfd_n_timesteps %d\nfd_min_atoms %d\natomic_weight 26.9815\natomic_charge 13\n"
-                    "ttm_int 100000\nI0 1.0\nlambda 800e-9\nlaser_sigma_t 100e-15\nlaser_t_0 1.0\n"
-                    % (c["ttm"]["fd_ext"], c["ttm"]["n"], c["ttm"]["min_atoms"]))
-            eos = write_planar_eos(d)
-        open(os.path.join(d, "t.param"), "w").write(par)
+        par, eos = write_inputs(c, d)
         env = dict(os.environ, IMD_PROBE_DIR=d, IMD_PROBE_STEPS=",".join(map(str, c["dump"])))
         env.update(c.get("env", {}))
         r = subprocess.run([os.path.join(REFBIN, c["binary"]), "-p", "t.param"], cwd=d, env=env,
@@ -224,10 +237,95 @@ def run_eos_inverse():
           ("eos_inverse", os.path.getsize(path) / 1024, n, np.abs(a[::3, 3] / a[::3, 1] - 1).max()))
 
 
+def run_adv_case(name, c):
+    """do_ADV fixture: the reference on TWO ranks along x (mpiexec -n 2), every rank's lattice dumped by
+    oracle/ref_probe_ttm.c around update_fd / do_ADV / the sub-steps and assembled here into the GLOBAL lattice
+    (rank r's inner columns 1..lx-2 become global columns r*(lx-2)+1.., the outer ghost columns are kept), plus the
+    global step-0 atom arrangement in the single-rank layout the other fixtures use."""
+    nsteps = c["steps"]
+    with tempfile.TemporaryDirectory() as d:
+        par, eos = write_inputs(c, d)
+        env = dict(os.environ, IMD_PROBE_DIR=d, IMD_PROBE_STEPS=",".join(map(str, range(nsteps + 1))))
+        env.update(c["env"])
+        r = subprocess.run(["mpiexec", "-n", "2", os.path.join(REFBIN, c["binary"]), "-p", "t.param"], cwd=d, env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            print(r.stdout[-3000:])
+            raise SystemExit("reference run failed for %s" % name)
+        T = [[po.read_ttm_probe(os.path.join(d, "ttm.%d.%d.bin" % (rk, s))) for rk in (0, 1)] for s in range(nsteps + 1)]
+        P = [po.read_probe(os.path.join(d, "probe.%d.0.bin" % rk)) for rk in (0, 1)]
+
+    def glob(a0, a1):                   # two local arrays [lx, ...] -> global [2(lx-2)+2, ...]
+        return np.concatenate([a0[:-1], a1[1:]], axis=0)
+
+    fluxsum = [int(T[s][0]["stages"]["flux"]["flux"][1:-1].sum() + T[s][1]["stages"]["flux"]["flux"][1:-1].sum())
+               for s in range(nsteps + 1)]
+    moved = [s for s in range(nsteps + 1) if fluxsum[s] > 0]
+    assert len(moved) >= 2, "no atom changed its FD cell: nothing to advect"
+    keep = sorted(set([0, 1, 2, moved[0] - 1, moved[0], moved[0] + 1, moved[1], moved[1] + 1]))
+    P0 = P[0]
+    out = dict(case=name, param_file=par, steps=np.array(keep), flux_steps=np.array(moved), full_steps=np.array([], int))
+    for k in ("ntypes", "pbc_dirs", "box", "cellsz", "nbl_margin", "timestep", "global_cell_dim", "flags"):
+        out[k] = P0[k]
+    for tk in ("pair_pot", "rho_h_tab", "embed_pot"):
+        for f, v in P0[tk].items():
+            out["%s_%s" % (tk, f)] = v
+    # global step-0 arrangement: inner cells in x-outer order, each cell's atoms in its owner's slot order
+    ld = P0["cell_dim"]; nx = ld[0] - 2
+    gd = np.array([2 * nx + 2, ld[1], ld[2]])
+    out["cell_dim"] = gd
+    out["natoms"] = P[0]["ninner_atoms"] + P[1]["ninner_atoms"]
+    cell_n = np.zeros(int(np.prod(gd)), np.int64)
+    cells, cols = [], {k: [] for k in ("nummer", "sorte", "ort", "masse", "impuls")}
+    for gi in range(1, gd[0] - 1):
+        rk, li = (gi - 1) // nx, (gi - 1) % nx + 1
+        Pr = P[rk]
+        start = np.concatenate([[0], np.cumsum(Pr["cell_n"])])
+        istart = np.concatenate([[0], np.cumsum(Pr["cell_n"][Pr["cells"]])])
+        pos_in_cells = {int(cc): q for q, cc in enumerate(Pr["cells"])}
+        for j in range(1, gd[1] - 1):
+            for k in range(1, gd[2] - 1):
+                lc = (li * ld[1] + j) * ld[2] + k
+                gc = (gi * gd[1] + j) * gd[2] + k
+                m = int(Pr["cell_n"][lc]); cell_n[gc] = m; cells.append(gc)
+                q = pos_in_cells[lc]
+                cols["nummer"].append(Pr["all_nummer"][start[lc]:start[lc] + m])
+                cols["sorte"].append(Pr["all_sorte"][start[lc]:start[lc] + m])
+                cols["ort"].append(Pr["all_ort"][start[lc]:start[lc] + m])
+                cols["masse"].append(Pr["masse"][istart[q]:istart[q] + m])
+                cols["impuls"].append(Pr["impuls"][istart[q]:istart[q] + m])
+    out["cells"] = np.array(cells, np.int32)
+    out["s0_cell_n"] = cell_n.astype(np.int16)
+    out["s0_nummer"] = np.concatenate(cols["nummer"]).astype(np.int32)
+    out["s0_sorte"] = np.concatenate(cols["sorte"]).astype(np.int8)
+    out["s0_ort"] = np.concatenate(cols["ort"]); out["s0_masse"] = np.concatenate(cols["masse"])
+    out["s0_impuls"] = np.concatenate(cols["impuls"])
+    T0 = T[0][0]
+    for k in ("fd_ext", "fd_min_atoms", "diff_substeps", "fd_n_timesteps", "fd_h", "fd_vol", "neighvol",
+              "atomic_weight", "atomic_charge", "tau", "omega_laser"):
+        out["ttm_" + k] = T0[k]
+    out["ttm_fd_dim"] = np.array([2 * (T0["fd_dim"][0] - 2) + 2, T0["fd_dim"][1], T0["fd_dim"][2]])
+    for k, v in eos.items():
+        out["eos_" + k] = v
+    for s in keep:
+        st0, st1 = T[s][0]["stages"], T[s][1]["stages"]
+        out["t%d_flux" % s] = glob(st0["flux"]["flux"], st1["flux"]["flux"]).astype(np.int16)
+        for tag in ("update_fd", "adv", "fillmesh0", "substeps_done"):
+            for f in po.TTM_REC.names:
+                if tag == "fillmesh0" and f not in ("temp", "U", "temp2", "U2", "natoms"):
+                    continue
+                out["t%d_%s_%s" % (s, tag, f)] = glob(st0[tag]["lat"][f], st1[tag]["lat"][f])
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("%-20s %8.1f KB  kept steps=%s  steps with flux=%s" % (name, os.path.getsize(path) / 1024, keep, moved))
+
+
 if __name__ == "__main__":
     names = sys.argv[1:] or (list(CASES) + ["eos_inverse"])
     for n in names:
         if n == "eos_inverse":
             run_eos_inverse()
+        elif n == "ttm_adv":
+            run_adv_case(n, CASES[n])
         else:
             run_case(n, CASES[n])

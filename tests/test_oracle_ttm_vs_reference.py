@@ -128,3 +128,82 @@ def test_flux_counters_of_update_fd_over_a_trajectory():
         s.check_nblist()
     assert int(G["t17_flux"].sum()) > 0 and int(G["t30_flux"].sum()) > 0
     t.close()
+
+
+def _load_lattice(t, G, pre, flux):
+    t.t.cur = 0
+    for f in ("natoms", "natoms_old", "xi", "md_temp", "source", "dens", "fd_k", "fd_g", "Z", "Ce", "ne"):
+        getattr(t, f)[...] = G[pre + f]
+    t.vcom[...] = G[pre + "vcom"]
+    t._temp[0][...] = G[pre + "temp"]; t._temp[1][...] = G[pre + "temp2"]
+    t._U[0][...] = G[pre + "U"]; t._U[1][...] = G[pre + "U2"]
+    t.flux[...] = flux
+
+
+def test_do_adv_single_stage_against_the_two_rank_reference():
+    """do_ADV + do_COMMFLUX (imd_ttm_3D.c:1321-1458, :667-995).  The fixture is the reference run on two ranks along x
+    (the step cannot run on one), assembled into the global lattice.  The oracle's lattice is loaded with the
+    reference's state after update_fd (both lattices + flux counters), orc_ttm_adv runs once, and the result is
+    compared with the reference's state after do_ADV: U (both lattices = the swap) and the untouched temp2 bit-exact,
+    the new temp -- it comes out of the Brent minimiser of EOS_te_from_r_ee -- within that minimiser's own x
+    tolerance, 1e-5 K (see test_inverse_eos...).  Steps 41 and 48 are list rebuilds where atoms changed FD cells."""
+    G = gu.load("ttm_adv")
+    s = gu.oracle_from_golden(G, 0)
+    t = gu.oracle_ttm_from_golden(G, s)
+    inner = (slice(1, -1),) * 3
+    assert {41, 48} <= set(int(v) for v in G["flux_steps"])
+    for st in (int(v) for v in G["steps"]):
+        _load_lattice(t, G, "t%d_update_fd_" % st, G["t%d_flux" % st])
+        t.adv(1.0, st)
+        for f in ("U", "U2", "temp2"):
+            assert np.array_equal(getattr(t, f)[inner], G["t%d_adv_%s" % (st, f)][inner]), (st, f)
+        assert np.abs(t.temp[inner] - G["t%d_adv_temp" % st][inner]).max() * 11604.5 < 1e-5, st
+    # the advected energy really moved at the rebuild steps
+    assert np.abs(G["t41_adv_U"][inner] - G["t41_update_fd_U"][inner]).max() > 1e-4
+    t.close()
+
+
+def test_diffusion_after_the_adv_swap():
+    """From the reference's lattice right after do_ADV: cell activation, FILLMESH, ghost fill and the 100 sub-steps
+    must land on the reference's lattice (1e-12): pins which lattice is current after the extra swap."""
+    G = gu.load("ttm_adv")
+    s = gu.oracle_from_golden(G, 0)
+    t = gu.oracle_ttm_from_golden(G, s)
+    nsub = int(G["ttm_diff_substeps"])
+    inner = (slice(1, -1),) * 3
+    for st in (2, 41):
+        _load_lattice(t, G, "t%d_adv_" % st, G["t%d_flux" % st])
+        t.cell_activation(); t.fillmesh(st); t.fill_ghosts()
+        for f in ("temp", "U", "temp2", "U2"):
+            assert np.array_equal(getattr(t, f)[inner], G["t%d_fillmesh0_%s" % (st, f)][inner]), (st, f)
+        for _ in range(nsub):
+            t.diff(float(G["ttm_tau"]), nsub); t.fillmesh(st); t.fill_ghosts()
+        for f in ("temp", "U", "temp2", "U2", "xi", "fd_k", "fd_g", "Ce"):
+            a, b = getattr(t, f)[inner], G["t%d_substeps_done_%s" % (st, f)][inner]
+            assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max(), (st, f)
+    t.close()
+
+
+def test_md_ttm_trajectory_with_advection_against_the_two_rank_reference():
+    """MD + TTM with do_ADV every step from the reference's (global) step-0 arrangement for 50 steps: flux counters
+    exact at every kept step (41 and 48 are rebuilds with atoms changing FD cells), lattice fields within 2e-8
+    relative (each step's new temperatures carry the inverse-EOS minimiser's 1e-5 K tolerance, ~4e-9 relative)."""
+    G = gu.load("ttm_adv")
+    s = gu.oracle_from_golden(G, 0)
+    s.s.count_ttm_neigh = 1
+    t = gu.oracle_ttm_from_golden(G, s)
+    t.t.adv = 1
+    nsub = int(G["ttm_diff_substeps"])
+    inner = (slice(1, -1),) * 3
+    for st in range(50):
+        s.calc_forces(st)
+        t.calc_ttm(st, nsub)
+        if st in G["steps"]:
+            assert np.array_equal(t.flux[inner], G["t%d_flux" % st][inner]), st
+            assert np.array_equal(t.natoms[inner], G["t%d_substeps_done_natoms" % st][inner])
+            for f in ("temp", "U", "temp2", "U2", "xi", "md_temp", "dens", "vcom"):
+                a, b = getattr(t, f)[inner], G["t%d_substeps_done_%s" % (st, f)][inner]
+                assert np.abs(a - b).max() <= 2e-8 * np.abs(b).max(), (st, f)
+        t.move_atoms_ttm()
+        s.check_nblist()
+    t.close()
