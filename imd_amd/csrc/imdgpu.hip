@@ -1407,7 +1407,8 @@ extern "C" int imdgpu_set_option(imdgpu_ctx *ctx, const char *name, int value)
     ctx->tile[name[5] - 'x'] = value; ctx->autotiled = 1;
     return ctx->have_geometry ? setup_tiles(ctx) : 0;
   }
-  if (!strcmp(name, "ttm_flux")) { ctx->ttm_flux = value ? 1 : 0; return 0; }
+  if (!strcmp(name, "ttm_flux")) { ctx->ttm_flux = value ? 1 : 0; if (!value) ctx->ttm_adv = 0; return 0; }
+  if (!strcmp(name, "ttm_adv")) { ctx->ttm_adv = value ? 1 : 0; if (value) ctx->ttm_flux = 1; return 0; }
   if (!strcmp(name, "ttm_decomposed")) {         // before ttm_init
     if (ctx->ttm) return imdgpu_fail(ctx, "ttm_decomposed must be set before ttm_init");
     ctx->ttm_decomposed = value ? 1 : 0;

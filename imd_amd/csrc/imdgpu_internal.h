@@ -91,6 +91,7 @@ struct imdgpu_ctx {
   int mode = 1, list_mode = 0, autotiled = 0;
   int force_external_halo = 0;
   int ttm_flux = 0;               // update_fd also counts the atoms that changed FD cells (imd_ttm_3D.c:335-370)
+  int ttm_adv = 0;                // calc_ttm runs do_ADV after update_fd (imd_ttm_3D.c:57-60); implies ttm_flux
   int ttm_decomposed = 0;         // several ranks: one TTM lattice block per rank, faces through the shared-memory mailbox
   int external_halo = 0;          // ghost atoms are supplied through imdgpu_halo_scatter (multi-rank decomposition)
   int *mig_idx[2]{nullptr, nullptr}; int mig_n[2]{0, 0}, mig_cap = 0; int *mig_flag = nullptr;

@@ -43,7 +43,8 @@ struct TtmState {
   double *cve_z = nullptr, *ee_z = nullptr;
   EosDev cve{}, ee{};
   double *d_red = nullptr;       // reduction scratch
-  hipGraphExec_t graph = nullptr; int graph_cur = -1, graph_kcur = -1; double graph_tau = 0;
+  // one captured sub-step chain per value of `cur` at its start (do_ADV's extra swap alternates it from step to step)
+  hipGraphExec_t graph[2] = {nullptr, nullptr}; int graph_kcur[2] = {-1, -1}; double graph_tau[2] = {0, 0};
   // decomposed lattice (several ranks): faces travel through a host shared-memory mailbox (see Mailbox below)
   void *mb_host = nullptr; size_t mb_bytes = 0; int mb_rank = -1, mb_nranks = 0;
   MailboxDev mbd{};
@@ -405,6 +406,34 @@ __global__ void k_ttm_te_from_r_ee(int n, EosDev ee, const double *r, const doub
   if (i < n) out[i] = d_te_from_r_ee(ee, r[i], e[i]);
 }
 
+// do_ADV (imd_ttm_3D.c:1321-1458) on a lattice that is not split over ranks -- there do_COMMFLUX (:667-995) has
+// nothing to move: the ghost columns it fills on a rank boundary are the neighbouring inner columns themselves, and
+// the ghost columns at the two global x faces keep flux 0 / U 0 from init_ttm (:1136-1157), periodic or not.
+// As compiled in the reference (ADVMODE 1, ADV2D undefined): upwind in x only, lattice plane k = 1 only (:1327); the
+// new energy per atom goes to l2, an active cell gets its temperature from the inverse EOS, and the host swaps
+// l1 <-> l2 afterwards.  One thread per cell of the plane; the Brent minimiser dominates (about 40 EOS look-ups).
+__global__ __launch_bounds__(64) void k_ttm_adv(Lat L, EosDev ee, double tau, const int *natoms, const int *natoms_old,
+                                                const int *flux, int ncell, const double *dens, const double *U1,
+                                                double *U2, double *T2)
+{
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, nj = L.dim[1] - 2;
+  if (t >= (L.dim[0] - 2) * nj) return;
+  const int i = t / nj + 1, j = t % nj + 1, k = 1;
+  const int c = fidx(L, i, j, k), xp = fidx(L, i + 1, j, k), xm = fidx(L, i - 1, j, k);
+  const double Nold = (double) natoms_old[c], Nnew = (double) natoms[c];
+  if (Nnew > 0) {
+    const double u = U1[c];
+    const double u2 = u * Nold / Nnew + tau * (
+                        + (double) flux[c] * U1[xp]                       // flux[0]: received from +x
+                        - (double) flux[(size_t) ncell + xp] * u          // +x neighbour's flux[1]: left to +x
+                        + (double) flux[(size_t) ncell + c] * U1[xm]      // flux[1]: received from -x
+                        - (double) flux[xm] * u                           // -x neighbour's flux[0]: left to -x
+                      ) / Nnew;
+    U2[c] = u2;
+    if (natoms[c] >= L.fd_min_atoms) T2[c] = d_te_from_r_ee(ee, dens[c], u2 / (26.9815 * C_AMU * C_J2EV)) / 11604.5;
+  } else if (Nnew < 1) { U2[c] = 0.0; T2[c] = 0.0; }
+}
+
 // do_FILLMESH per cell: MeanCharge (More's Thomas-Fermi fit, imd_ttm_3D.c:2399-2473), getKappa (:2549-2592),
 // getGamma (:2503-2528) and their helpers fermi_E, fermi_T, omega_pl, r0, coulomb_log, numet, numax, nupl
 // (:2352-2498), written as ONE function so that everything the reference recomputes per helper call is shared:
@@ -733,7 +762,7 @@ void imdgpu_ttm_free(imdgpu_ctx *ctx)
   void *ptrs[] = {t->natoms, t->natoms_old, t->temp[0], t->temp[1], t->U[0], t->U[1], t->fd_k[0], t->fd_k[1], t->xi,
                   t->md_temp, t->source, t->vcom, t->dens, t->fd_g, t->Z, t->Ce, t->ne, t->cve_z, t->ee_z, t->d_red, t->flux};
   for (void *p : ptrs) if (p) (void) hipFree(p);
-  if (t->graph) (void) hipGraphExecDestroy(t->graph);
+  for (int q = 0; q < 2; q++) if (t->graph[q]) (void) hipGraphExecDestroy(t->graph[q]);
   if (t->mb_host) (void) hipHostUnregister(t->mb_host);
   if (t->d_gbase) (void) hipFree(t->d_gbase);
   if (t->d_facecnt) (void) hipFree(t->d_facecnt);
@@ -911,6 +940,22 @@ extern "C" int imdgpu_ttm_eos_te_from_r_ee(imdgpu_ctx *ctx, int n, const double 
   return 0;
 }
 
+// [do_ADV(tau), imd_ttm_3D.c:1321-1458; calc_ttm calls it with tau = 1.0 right after update_fd (:57-60)]
+extern "C" int imdgpu_ttm_adv(imdgpu_ctx *ctx, double tau, int steps)
+{
+  NEED_TTM();
+  if (ctx->external_halo) return imdgpu_fail(ctx, "ttm_adv: only for a lattice held by one rank (the reference's do_COMMFLUX exchange is not built)");
+  if (!ctx->ttm_flux) return imdgpu_fail(ctx, "ttm_adv: needs the atom-flux counters of update_fd (option ttm_flux or ttm_adv)");
+  if (t->dim[2] < 3) return imdgpu_fail(ctx, "ttm_adv: lattice has no plane k = 1");
+  if (steps < 1) return 0;                               // :1323
+  const int n = (t->dim[0] - 2) * (t->dim[1] - 2);
+  hipLaunchKernelGGL(k_ttm_adv, dim3(nblk(n, 64)), dim3(64), 0, ctx->stream, L, t->ee, tau, t->natoms, t->natoms_old,
+                     t->flux, t->ncell, t->dens, t->U[t->cur], t->U[t->cur ^ 1], t->temp[t->cur ^ 1]);
+  HIPCHK(hipGetLastError());
+  t->cur ^= 1;                                           // l1 <-> l2 as a whole, :1454-1456
+  return 0;
+}
+
 extern "C" int imdgpu_ttm_cell_activation(imdgpu_ctx *ctx)
 {
   NEED_TTM();
@@ -999,6 +1044,7 @@ extern "C" int imdgpu_calc_ttm(imdgpu_ctx *ctx, int steps)
 {
   if (ctx->external_halo && !ctx->ttm_decomposed) return imdgpu_fail(ctx, "calc_ttm: with several ranks use ttm_local_block / apply_blocks / ttm_lattice_step");
   if (imdgpu_ttm_update_fd(ctx, steps)) return 1;
+  if (ctx->ttm_adv && imdgpu_ttm_adv(ctx, 1.0, steps)) return 1;
   return imdgpu_ttm_lattice_step(ctx, steps);
 }
 
@@ -1021,12 +1067,13 @@ extern "C" int imdgpu_ttm_lattice_step(imdgpu_ctx *ctx, int steps)
     // the sub-step loop never returns to the host: nsub even => the ping-pong state after the loop equals
     // the state before it, so one captured hipGraph replays every MD step
     const bool can_graph = (t->nsub % 2 == 0) && steps >= 1;      // step 0 re-initialises U: run it un-captured
-    if (can_graph && t->graph && t->graph_cur == t->cur && t->graph_kcur == t->kcur && t->graph_tau == tau) {
-      HIPCHK(hipGraphLaunch(t->graph, ctx->stream));
+    const int gi = t->cur;
+    if (can_graph && t->graph[gi] && t->graph_kcur[gi] == t->kcur && t->graph_tau[gi] == tau) {
+      HIPCHK(hipGraphLaunch(t->graph[gi], ctx->stream));
     } else if (can_graph) {
-      if (t->graph) { (void) hipGraphExecDestroy(t->graph); t->graph = nullptr; }
+      if (t->graph[gi]) { (void) hipGraphExecDestroy(t->graph[gi]); t->graph[gi] = nullptr; }
       hipGraph_t g;
-      int c0 = t->cur, k0 = t->kcur;
+      const int k0 = t->kcur;
       HIPCHK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
       // the first few sub-steps run at raised wave priority: beside the EAM force pass a sub-step takes 22 us at normal
       // priority and 14 us raised (at 0.22 ms cost to the pass if all 100 were); a fifth of them raised lets the chain
@@ -1038,10 +1085,10 @@ extern "C" int imdgpu_ttm_lattice_step(imdgpu_ctx *ctx, int steps)
         launch_substep_fused(ctx, t, Li, tau, 1, i);
       }
       HIPCHK(hipStreamEndCapture(ctx->stream, &g));
-      HIPCHK(hipGraphInstantiate(&t->graph, g, nullptr, nullptr, 0));
+      HIPCHK(hipGraphInstantiate(&t->graph[gi], g, nullptr, nullptr, 0));
       (void) hipGraphDestroy(g);
-      t->graph_cur = c0; t->graph_kcur = k0; t->graph_tau = tau;
-      HIPCHK(hipGraphLaunch(t->graph, ctx->stream));
+      t->graph_kcur[gi] = k0; t->graph_tau[gi] = tau;
+      HIPCHK(hipGraphLaunch(t->graph[gi], ctx->stream));
     } else {
       for (int i = 0; i < t->nsub; i++) launch_substep_fused(ctx, t, L, tau, steps, i);
     }
@@ -1103,7 +1150,7 @@ extern "C" int imdgpu_ttm_mailbox_attach(imdgpu_ctx *ctx, void *host_base, size_
       if (nbr[b] >= nranks) return imdgpu_fail(ctx, "mailbox: neighbour rank %d out of range", nbr[b]);
       M.nbr[b] = nbr[b];
     }
-  if (t->graph) { (void) hipGraphExecDestroy(t->graph); t->graph = nullptr; }
+  for (int q = 0; q < 2; q++) if (t->graph[q]) { (void) hipGraphExecDestroy(t->graph[q]); t->graph[q] = nullptr; }
   return 0;
 }
 // calc_ttm of one rank's block: update_fd, activation, FILLMESH, face publication, the sub-steps

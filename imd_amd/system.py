@@ -273,6 +273,10 @@ class GpuSystem:
     def do_FILLMESH(self, steps=0):
         self._ck(self.L.imdgpu_ttm_fillmesh(self.h, int(steps)))
 
+    def do_ADV(self, tau=1.0, steps=1):
+        """do_ADV(tau) (imd_ttm_3D.c:1321-1458)"""
+        self._ck(self.L.imdgpu_ttm_adv(self.h, float(tau), int(steps)))
+
     def ttm_fill_ghost_layers(self):
         self._ck(self.L.imdgpu_ttm_fill_ghost_layers(self.h))
 

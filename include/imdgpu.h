@@ -168,6 +168,11 @@ int imdgpu_ttm_download(imdgpu_ctx *ctx, const imdgpu_ttm_fields *f);
 int imdgpu_ttm_upload(imdgpu_ctx *ctx, const imdgpu_ttm_fields *f);
 /* [update_fd, :233-488] uses numneighs/impuls/masse of the last calc_forces */
 int imdgpu_ttm_update_fd(imdgpu_ctx *ctx, int steps);
+/* [do_ADV(tau), :1321-1458, with do_COMMFLUX, :667-995] advection of the electron energy with the atoms that changed
+ * FD cells, as the reference compiles it (ADVMODE 1 without ADV2D): x direction, lattice plane k = 1, then l1 <-> l2.
+ * Needs update_fd's flux counters (option "ttm_flux"; option "ttm_adv" sets it and makes imdgpu_calc_ttm call
+ * imdgpu_ttm_adv(1.0) after update_fd like calc_ttm :57-60).  Only for a lattice held by one rank. */
+int imdgpu_ttm_adv(imdgpu_ctx *ctx, double tau, int steps);
 /* [do_cell_activation, :1468-1596] */
 int imdgpu_ttm_cell_activation(imdgpu_ctx *ctx);
 /* [do_FILLMESH, :492-661] */

@@ -169,3 +169,59 @@ def test_flux_counters_of_update_fd_over_a_trajectory():
     assert seen == int(G["t17_flux"].sum() + G["t30_flux"].sum() + G["t43_flux"].sum()) > 0
     assert s.get_sums()["nbl_count"] == int(G["s43_nbl_count"])
     s.close()
+
+
+def _gpu_adv(G):
+    s = GpuSystem(G["box"], G["pbc_dirs"], G["cell_dim"], 1, float(G["cellsz"]), float(G["nbl_margin"]),
+                  float(G["timestep"]), count_ttm_neighbours=True)
+    s.set_option("ttm_adv", 1)
+    s.upload_tables(gu.table(G, "pair_pot"), gu.table(G, "rho_h_tab"), gu.table(G, "embed_pot"))
+    cell_n = np.zeros(int(np.prod(G["cell_dim"])), np.int32)
+    cell_n[G["cells"]] = G["s0_cell_n"][G["cells"]]
+    s.upload_cells(cell_n, G["s0_ort"], G["s0_impuls"], G["s0_masse"], G["s0_sorte"].astype(np.int32), G["s0_nummer"])
+    cve, ee = _eos(G)
+    s.init_ttm(G["ttm_fd_ext"], int(G["ttm_fd_min_atoms"]), int(G["ttm_diff_substeps"]), float(G["ttm_atomic_weight"]),
+               float(G["ttm_atomic_charge"]), cve, ee, float(G["ttm_omega_laser"]))
+    return s
+
+
+def test_do_adv_single_stage_against_the_two_rank_reference():
+    """do_ADV + do_COMMFLUX (imd_ttm_3D.c:1321-1458, :667-995; fixture: the reference on two ranks along x, assembled
+    into the global lattice).  The device lattice is loaded with the reference's state after update_fd (both lattices
+    and the flux counters), imdgpu_ttm_adv runs once: U of both lattices (= the update and the swap) and the untouched
+    temp2 bit-exact, the new temp within the inverse-EOS minimiser's own tolerance of 1e-5 K."""
+    G = gu.load("ttm_adv")
+    s = _gpu_adv(G)
+    assert tuple(s.fd_dim) == tuple(int(v) for v in G["ttm_fd_dim"])
+    inner = (slice(1, -1),) * 3
+    for st in (int(v) for v in G["steps"]):
+        pre = "t%d_update_fd_" % st
+        s.ttm_upload(flux=G["t%d_flux" % st].astype(np.int32),
+                     **{f: G[pre + f] for f in ("natoms", "natoms_old", "temp", "temp2", "U", "U2", "dens")})
+        s.do_ADV(1.0, st)
+        d = s.ttm_download(fields=("temp", "temp2", "U", "U2"))
+        for f in ("U", "U2", "temp2"):
+            assert np.array_equal(d[f][inner], G["t%d_adv_%s" % (st, f)][inner]), (st, f)
+        assert np.abs(d["temp"][inner] - G["t%d_adv_temp" % st][inner]).max() * 11604.5 < 1e-5, st
+    s.close()
+
+
+def test_md_ttm_trajectory_with_advection_against_the_two_rank_reference():
+    """The device-resident MD + TTM loop with option "ttm_adv" (calc_ttm = update_fd, do_ADV(1.0), activation, ...,
+    imd_ttm_3D.c:50-77) for 50 steps from the reference's global step-0 arrangement: flux counters exact at every kept
+    step (41 and 48: atoms changed FD cells), lattice fields within 2e-8 relative (the inverse EOS carries 1e-5 K =
+    4e-9 relative into every step; the CPU oracle shows the same distance to the reference)."""
+    G = gu.load("ttm_adv")
+    s = _gpu_adv(G)
+    inner = (slice(1, -1),) * 3
+    for st in range(50):
+        s.md_step(st)
+        if st in G["steps"]:
+            d = s.ttm_download()
+            assert np.array_equal(d["flux"][inner], G["t%d_flux" % st][inner]), st
+            assert np.array_equal(d["natoms"][inner], G["t%d_substeps_done_natoms" % st][inner])
+            for f in ("temp", "U", "temp2", "U2", "xi", "md_temp", "dens", "vcom"):
+                a, b = d[f][inner], G["t%d_substeps_done_%s" % (st, f)][inner]
+                assert np.abs(a - b).max() <= 2e-8 * np.abs(b).max(), (st, f)
+    assert int(G["t41_flux"].sum()) > 0 and int(G["t48_flux"].sum()) > 0
+    s.close()
