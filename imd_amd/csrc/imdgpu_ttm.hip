@@ -270,9 +270,12 @@ __global__ void k_ttm_update_fd(Lat L, int steps, int cap, const int *cell_start
         }
       }
   neigh = wsumi(neigh);
-  if (flux) {
+  if (fdc) {
 #pragma unroll
-    for (int q = 0; q < 8; q++) { const int v = wsumi(fl[q]); if (lane == 0) flux[(size_t) q * ncell + c] = v; }
+    for (int q = 0; q < 8; q++) {
+      fl[q] = wsumi(fl[q]);
+      if (lane == 0 && flux) flux[(size_t) q * ncell + c] = fl[q];
+    }
   }
   sx = wsum(sx); sy = wsum(sy); sz = wsum(sz); sm = wsum(sm);
   double vx = 0, vy = 0, vz = 0, d = 0;
@@ -297,8 +300,13 @@ __global__ void k_ttm_update_fd(Lat L, int steps, int cap, const int *cell_start
   mt = wsum(mt);
   if (lane == 0 && blockbuf) {
     if (nat >= L.fd_min_atoms) mt /= 3.0 * nat; else mt = 0.0;
-    double *o = blockbuf + (size_t) w * 6;
+    double *o = blockbuf + (size_t) w * (fdc ? 10 : 6);
     o[0] = (double) nat; o[1] = mt; o[2] = d; o[3] = vx; o[4] = vy; o[5] = vz;
+    if (fdc) {                                  // the eight flux counters, two per double
+      int *oi = (int *) (o + 6);
+#pragma unroll
+      for (int q = 0; q < 8; q++) oi[q] = fl[q];
+    }
   } else if (lane == 0) {
     if (nat >= L.fd_min_atoms) mt /= 3.0 * nat; else mt = 0.0;
     int old = natoms[c];
@@ -313,14 +321,20 @@ __global__ void k_ttm_update_fd(Lat L, int steps, int cap, const int *cell_start
 
 __global__ void k_ttm_apply_blocks(Lat L, int steps, int nblocks, const int *offs /* 3 per block */, int bi, int bj, int bk,
                                    const double *in, int *natoms, int *natoms_old, double *temp0, double *temp1,
-                                   double *xi, double *md_temp, double *source, double *vcom, double *dens, int ncell)
+                                   double *xi, double *md_temp, double *source, double *vcom, double *dens, int ncell,
+                                   int *flux /* nullptr: 6 doubles per cell, else 10 */)
 {
   const int per = bi * bj * bk, t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nblocks * per) return;
   const int b = t / per, w = t - b * per;
   const int k = w % bk + 1, j = (w / bk) % bj + 1, i = w / (bk * bj) + 1;
   const int c = fidx(L, i + offs[3 * b], j + offs[3 * b + 1], k + offs[3 * b + 2]);
-  const double *o = in + (size_t) t * 6;
+  const double *o = in + (size_t) t * (flux ? 10 : 6);
+  if (flux) {
+    const int *oi = (const int *) (o + 6);
+#pragma unroll
+    for (int q = 0; q < 8; q++) flux[(size_t) q * ncell + c] = oi[q];
+  }
   const int nat = (int) o[0], old = natoms[c];
   natoms_old[c] = (steps < 1) ? nat : old;
   natoms[c] = nat;
@@ -895,7 +909,8 @@ extern "C" int imdgpu_ttm_update_fd(imdgpu_ctx *ctx, int steps)
   return 0;
 }
 
-// multi-rank: this rank's block of update_fd results -> dev_out (6 doubles per local FD cell)
+// multi-rank: this rank's block of update_fd results -> dev_out (6 doubles per local FD cell; 10 with option ttm_flux:
+// the eight flux counters follow as ints; imdgpu_get_info "ttm_block_width")
 extern "C" int imdgpu_ttm_local_block(imdgpu_ctx *ctx, int steps, double *dev_out, int *ncells_block)
 {
   NEED_TTM();
@@ -906,20 +921,20 @@ extern "C" int imdgpu_ttm_local_block(imdgpu_ctx *ctx, int steps, double *dev_ou
   hipLaunchKernelGGL(k_ttm_update_fd, dim3(nblk((long long) nb * 64, TTM_WG)), dim3(TTM_WG), 0, ctx->stream, L, steps,
                      ctx->cap_local, ctx->cell_start, ctx->cell_cnt, ctx->numneighs, ctx->p, ctx->mass, t->natoms,
                      t->natoms_old, t->temp[0], t->temp[1], t->xi, t->md_temp, t->source, t->vcom, t->dens, t->ncell, dev_out,
-                     (int *) nullptr, (int *) nullptr);
+                     ctx->ttm_flux ? ctx->fdc : (int *) nullptr, (int *) nullptr);
   HIPCHK(hipGetLastError());
   return 0;
 }
 
 // multi-rank: fold the all-gathered blocks of all ranks into the replicated lattice.
-// dev_in: nblocks * ncells_block * 6 doubles in rank order; dev_offs: 3 ints per block (FD-cell offset of that rank)
+// dev_in: nblocks * ncells_block * 6 (10 with ttm_flux) doubles in rank order; dev_offs: 3 ints per block (FD-cell offset of that rank)
 extern "C" int imdgpu_ttm_apply_blocks(imdgpu_ctx *ctx, int steps, const double *dev_in, int nblocks, const int *dev_offs)
 {
   NEED_TTM();
   const int per = t->ldim[0] * t->ldim[1] * t->ldim[2];
   hipLaunchKernelGGL(k_ttm_apply_blocks, dim3(nblk((long long) nblocks * per, 256)), dim3(256), 0, ctx->stream, L, steps, nblocks,
                      dev_offs, t->ldim[0], t->ldim[1], t->ldim[2], dev_in, t->natoms, t->natoms_old, t->temp[0], t->temp[1],
-                     t->xi, t->md_temp, t->source, t->vcom, t->dens, t->ncell);
+                     t->xi, t->md_temp, t->source, t->vcom, t->dens, t->ncell, ctx->ttm_flux ? t->flux : (int *) nullptr);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -944,7 +959,7 @@ extern "C" int imdgpu_ttm_eos_te_from_r_ee(imdgpu_ctx *ctx, int n, const double 
 extern "C" int imdgpu_ttm_adv(imdgpu_ctx *ctx, double tau, int steps)
 {
   NEED_TTM();
-  if (ctx->external_halo) return imdgpu_fail(ctx, "ttm_adv: only for a lattice held by one rank (the reference's do_COMMFLUX exchange is not built)");
+  if (ctx->ttm_decomposed) return imdgpu_fail(ctx, "ttm_adv: only for a lattice held as a whole (one rank, or replicated); the do_COMMFLUX exchange of a decomposed lattice is not built");
   if (!ctx->ttm_flux) return imdgpu_fail(ctx, "ttm_adv: needs the atom-flux counters of update_fd (option ttm_flux or ttm_adv)");
   if (t->dim[2] < 3) return imdgpu_fail(ctx, "ttm_adv: lattice has no plane k = 1");
   if (steps < 1) return 0;                               // :1323
@@ -1157,6 +1172,7 @@ extern "C" int imdgpu_ttm_mailbox_attach(imdgpu_ctx *ctx, void *host_base, size_
 extern "C" int imdgpu_ttm_local_step(imdgpu_ctx *ctx, int steps)
 {
   if (!ctx->ttm_decomposed) return imdgpu_fail(ctx, "ttm_local_step: decomposed lattice only");
+  if (ctx->ttm_adv) return imdgpu_fail(ctx, "ttm_adv is not available on a decomposed lattice");
   if (imdgpu_ttm_update_fd(ctx, steps)) return 1;
   return imdgpu_ttm_lattice_step(ctx, steps);
 }

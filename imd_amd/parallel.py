@@ -290,6 +290,7 @@ class DistributedMD:
         self.nrebuild = 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.ttm_decomposed = bool(ttm and getattr(ops, "ttm_is_decomposed", lambda: False)())
+        self.ttm_adv = bool(ttm and getattr(ops, "ttm_has_adv", lambda: False)())
         if ttm and self.ttm_decomposed:
             # every rank diffuses its own block; ghost faces go GPU -> host shared memory -> GPU (imdgpu_ttm_mailbox_*)
             nbr = []
@@ -359,6 +360,8 @@ class DistributedMD:
                 blk = ops.ttm_local_block(step)
                 allb = all_gather_flat(blk, self.world)
                 ops.ttm_apply_blocks(step, allb, self.world, self._ttm_offs)
+                if self.ttm_adv:                         # calc_ttm's order: update_fd, do_ADV(1.0), the rest
+                    ops.ttm_adv(1.0, step)
                 ops.ttm_lattice_step(step)
                 self._ttm_keep = (blk, allb)             # buffers stay referenced until the join
             ops.ttm_unfork()
@@ -402,7 +405,10 @@ class DistributedMD:
                 ops.ttm_local_step(step)
             else:
                 blk = ops.ttm_local_block(step); allb = all_gather_flat(blk, self.world)
-                ops.ttm_apply_blocks(step, allb, self.world, self._ttm_offs); ops.ttm_lattice_step(step)
+                ops.ttm_apply_blocks(step, allb, self.world, self._ttm_offs)
+                if self.ttm_adv:
+                    ops.ttm_adv(1.0, step)
+                ops.ttm_lattice_step(step)
             t0 = lap("ttm", t0)
         ops.forces_phase(2); t0 = lap("pass2", t0)
         self.plan.exchange(ops, 1); t0 = lap("halo_dF", t0)
@@ -555,11 +561,17 @@ class GpuOps:
     def ttm_local_step(self, step):
         self._ck(self.L.imdgpu_ttm_local_step(self.h, int(step)))
 
+    def ttm_has_adv(self):
+        return bool(self.s.get_info("ttm_adv"))
+
+    def ttm_adv(self, tau, step):
+        self._ck(self.L.imdgpu_ttm_adv(self.h, float(tau), int(step)))
+
     def ttm_local_block(self, step):
         C = self.C
         n = C.c_int()
         self._ck(self.L.imdgpu_ttm_local_block(self.h, step, None, C.byref(n)))
-        out = torch.empty(n.value * 6, dtype=torch.float64, device=self.device)
+        out = torch.empty(n.value * self.s.get_info("ttm_block_width"), dtype=torch.float64, device=self.device)
         self._ck(self.L.imdgpu_ttm_local_block(self.h, step, C.c_void_p(out.data_ptr()), C.byref(n)))
         return out
 

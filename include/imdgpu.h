@@ -53,7 +53,8 @@ int  imdgpu_set_stream(imdgpu_ctx *ctx, void *hip_stream);
 int  imdgpu_synchronize(imdgpu_ctx *ctx);
 /* tuning knobs: "mode" = 1 LDS-tiled force kernels (default), 0 global-gather kernels */
 int  imdgpu_set_option(imdgpu_ctx *ctx, const char *name, int value);
-/* introspection: "list_mode" (kernel family of the current list), "tile_cap", "slot_cap", "W", "ntiles", ... */
+/* introspection: "list_mode" (kernel family of the current list), "tile_cap", "slot_cap", "W", "ntiles", ...,
+ * "ttm_flux", "ttm_adv", "ttm_block_width" (doubles per FD cell in imdgpu_ttm_local_block's records) */
 int  imdgpu_get_info(imdgpu_ctx *ctx, const char *name, long long *value);
 
 /* ---- set-up -------------------------------------------------------------- */
@@ -171,7 +172,8 @@ int imdgpu_ttm_update_fd(imdgpu_ctx *ctx, int steps);
 /* [do_ADV(tau), :1321-1458, with do_COMMFLUX, :667-995] advection of the electron energy with the atoms that changed
  * FD cells, as the reference compiles it (ADVMODE 1 without ADV2D): x direction, lattice plane k = 1, then l1 <-> l2.
  * Needs update_fd's flux counters (option "ttm_flux"; option "ttm_adv" sets it and makes imdgpu_calc_ttm call
- * imdgpu_ttm_adv(1.0) after update_fd like calc_ttm :57-60).  Only for a lattice held by one rank. */
+ * imdgpu_ttm_adv(1.0) after update_fd like calc_ttm :57-60).  For a lattice held as a whole (one rank, or the
+ * replicated lattice of several ranks); not for option "ttm_decomposed". */
 int imdgpu_ttm_adv(imdgpu_ctx *ctx, double tau, int steps);
 /* [do_cell_activation, :1468-1596] */
 int imdgpu_ttm_cell_activation(imdgpu_ctx *ctx);
@@ -224,7 +226,9 @@ int imdgpu_integrate(imdgpu_ctx *ctx);                 /* move_atoms_{nve|ttm} +
 int imdgpu_get_invalid(imdgpu_ctx *ctx, int *flag);    /* check_nblist result of this rank (synchronises) */
 int imdgpu_invalidate(imdgpu_ctx *ctx);                /* some rank asked for a rebuild (MPI_Allreduce MAX, :1087) */
 /* TTM with several ranks: the FD lattice is replicated; each rank computes update_fd for the block over
- * its own MD cells (6 doubles per FD cell), blocks are all-gathered and folded in, the sub-steps run everywhere */
+ * its own MD cells (6 doubles per FD cell: natoms, md_temp, dens, vcom; with option "ttm_flux" 10: the eight flux
+ * counters follow as ints), blocks are all-gathered and folded in, the sub-steps run everywhere.  With option
+ * "ttm_adv" the host calls imdgpu_ttm_adv(1.0) between apply_blocks and lattice_step (calc_ttm's order, :57-60). */
 int imdgpu_ttm_local_block(imdgpu_ctx *ctx, int steps, double *dev_out, int *ncells_block);
 int imdgpu_ttm_apply_blocks(imdgpu_ctx *ctx, int steps, const double *dev_in, int nblocks, const int *dev_offs);
 int imdgpu_ttm_lattice_step(imdgpu_ctx *ctx, int steps);

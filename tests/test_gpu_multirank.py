@@ -18,15 +18,15 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, case, cpu_dim, nsteps, ttm, q, decomposed=False):
+def _worker(rank, world, port, case, cpu_dim, nsteps, ttm, q, decomposed=False, adv=False):
     try:
-        _worker_body(rank, world, port, case, cpu_dim, nsteps, ttm, q, decomposed)
+        _worker_body(rank, world, port, case, cpu_dim, nsteps, ttm, q, decomposed, adv)
     except BaseException:
         import traceback
         q.put((rank, "ERROR", traceback.format_exc(), 0, None))
 
 
-def _worker_body(rank, world, port, case, cpu_dim, nsteps, ttm, q, decomposed=False):
+def _worker_body(rank, world, port, case, cpu_dim, nsteps, ttm, q, decomposed=False, adv=False):
     import torch
     import torch.distributed as dist
     from imd_amd.parallel import Decomposition, DistributedMD, GpuOps
@@ -43,6 +43,8 @@ def _worker_body(rank, world, port, case, cpu_dim, nsteps, ttm, q, decomposed=Fa
     s = GpuSystem(G["box"], G["pbc_dirs"], dec.dim, 1, float(G["cellsz"]), float(G["nbl_margin"]), float(G["timestep"]),
                   device=0, global_cell_dim=dec.gdim, cpu_dim=cpu_dim, my_coord=dec.coord, ttm_decomposed=decomposed)
     s.upload_tables(gu.table(G, "pair_pot"), gu.table(G, "rho_h_tab"), gu.table(G, "embed_pot"))
+    if adv:
+        s.set_option("ttm_adv", 1)
     if ttm:
         s.init_ttm(G["ttm_fd_ext"], int(G["ttm_fd_min_atoms"]), int(G["ttm_diff_substeps"]), float(G["ttm_atomic_weight"]),
                    float(G["ttm_atomic_charge"]), dict(x=G["eos_r"], y=G["eos_t"], z=G["eos_cve"]),
@@ -59,18 +61,18 @@ def _worker_body(rank, world, port, case, cpu_dim, nsteps, ttm, q, decomposed=Fa
     ops.forces_phase(1); ops.forces_phase(2); md.plan.exchange(ops, 1); ops.forces_phase(3)
     sums = md.global_sums()
     d = s.download(fields=("ort", "impuls", "kraft", "nummer", "numneighs"))
-    lat = s.ttm_download(fields=("temp", "xi", "natoms")) if ttm else None
+    lat = s.ttm_download(fields=("temp", "xi", "natoms", "U", "temp2", "U2", "flux")) if ttm else None
     q.put((rank, d, sums, md.nrebuild, lat, tuple(dec.coord)))
     s.close()
     dist.destroy_process_group()
 
 
-def _run(case, cpu_dim, nsteps, ttm, decomposed=False):
+def _run(case, cpu_dim, nsteps, ttm, decomposed=False, adv=False):
     world = int(np.prod(cpu_dim))
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, case, cpu_dim, nsteps, ttm, q, decomposed)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, cpu_dim, nsteps, ttm, q, decomposed, adv)) for r in range(world)]
     for p in procs:
         p.start()
     res = []
@@ -137,3 +139,20 @@ def test_ranks_ttm_decomposed_lattice(cpu_dim):
         c, n = r[5], blk.shape
         full[c[0] * n[0]:(c[0] + 1) * n[0], c[1] * n[1]:(c[1] + 1) * n[1], c[2] * n[2]:(c[2] + 1) * n[2]] = blk
     assert np.abs(full - ref).max() < 1e-10 * np.abs(ref).max()
+
+
+def test_two_ranks_ttm_with_advection():
+    """do_ADV with two ranks along x, like the reference run behind tests/golden/ttm_adv.npz: the flux counters travel
+    in the all-gathered update_fd blocks, every rank advects its replica of the lattice.  After 49 MD steps (list
+    rebuilds with atoms changing FD cells -- and ranks -- at steps 41 and 48) every rank holds the reference's lattice
+    of step 48: flux counters exact, temp/U of both lattices within 2e-8 (inverse-EOS tolerance, see test_gpu_ttm)."""
+    res = _run("ttm_adv", (2, 1, 1), 49, True, adv=True)
+    G = gu.load("ttm_adv")
+    inner = (slice(1, -1),) * 3
+    assert int(G["t48_flux"].sum()) > 0
+    for r in res:
+        assert np.array_equal(r[4]["flux"][inner], G["t48_flux"][inner])
+        assert np.array_equal(r[4]["natoms"][inner], G["t48_substeps_done_natoms"][inner])
+        for f in ("temp", "U", "temp2", "U2", "xi"):
+            a, b = r[4][f][inner], G["t48_substeps_done_" + f][inner]
+            assert np.abs(a - b).max() <= 2e-8 * np.abs(b).max(), f
