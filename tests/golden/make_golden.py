@@ -320,11 +320,67 @@ def run_adv_case(name, c):
     print("%-20s %8.1f KB  kept steps=%s  steps with flux=%s" % (name, os.path.getsize(path) / 1024, keep, moved))
 
 
+def run_chkpt_case():
+    """Configuration-file fixture (imd_amd/config_io.py) -> tests/golden/chkpt.npz:
+    run A writes an ASCII checkpoint after step 10, run B the same state as a binary one (binary_output 1); then
+    imd_amd.config_io.write_config writes B's state back as a binary file and the reference READS it (run C,
+    coordname mine.chkpt, box from the header): its memory at step 0 is stored as reread_*."""
+    from imd_amd import config_io
+    c = dict(binary="imd_eam_nve_nbl", box="4 4 4", temp=0.06, steps=11, dump=[10, 11], pot="eam", nbl=True,
+             extra="checkpt_int 10\n")
+    files, probes = {}, {}
+    for tag, extra in (("A", ""), ("L", "binary_output 1\n")):
+        with tempfile.TemporaryDirectory() as d:
+            par, _ = write_inputs(dict(c, extra=c["extra"] + extra), d)
+            env = dict(os.environ, IMD_PROBE_DIR=d, IMD_PROBE_STEPS="10,11")
+            r = subprocess.run([os.path.join(REFBIN, c["binary"]), "-p", "t.param"], cwd=d, env=env,
+                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            if r.returncode != 0:
+                print(r.stdout[-3000:]); raise SystemExit("reference run failed")
+            files[tag] = open(os.path.join(d, "out.00001.chkpt"), "rb").read()
+            probes[tag] = {s: po.read_probe(os.path.join(d, "probe.0.%d.bin" % s)) for s in (10, 11)}
+    out = dict(chkpt_A=np.frombuffer(files["A"], np.uint8), chkpt_L=np.frombuffer(files["L"], np.uint8))
+    P10, P11 = probes["L"][10], probes["L"][11]
+    for s, P in ((10, P10), (11, P11)):
+        start = np.concatenate([[0], np.cumsum(P["cell_n"])])
+        idx = np.concatenate([np.arange(start[cc], start[cc + 1]) for cc in P["cells"]])
+        out["s%d_nummer" % s] = P["all_nummer"][idx]; out["s%d_ort" % s] = P["all_ort"][idx]
+        for k in ("masse", "impuls", "pot_eng", "eam_rho"):
+            out["s%d_%s" % (s, k)] = P[k]
+    out["box"] = P10["box"]; out["pbc_dirs"] = P10["pbc_dirs"]
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "L.chkpt"), "wb").write(files["L"])
+        st = config_io.read_config(os.path.join(d, "L.chkpt"), ntypes=1)
+        config_io.write_config(os.path.join(d, "mine.chkpt"), st["number"], st["vtype"], st["mass"], st["pos"], st["impuls"],
+                               st["data"]["Epot"], st["header"]["box"], st["header"]["pbc"], eam_rho=st["data"]["eam_rho"],
+                               binary=True, stamp="(fixture)")
+        out["mine_L"] = np.frombuffer(open(os.path.join(d, "mine.chkpt"), "rb").read(), np.uint8)
+        par, _ = write_inputs(dict(c, steps=0, extra=""), d)
+        par = par.replace("coordname _fcc", "coordname mine.chkpt").replace("box_param 4 4 4\n", "box_from_header 1\n")
+        open(os.path.join(d, "t.param"), "w").write(par)
+        env = dict(os.environ, IMD_PROBE_DIR=d, IMD_PROBE_STEPS="0")
+        r = subprocess.run([os.path.join(REFBIN, c["binary"]), "-p", "t.param"], cwd=d, env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            print(r.stdout[-3000:]); raise SystemExit("reference re-read run failed")
+        P = po.read_probe(os.path.join(d, "probe.0.0.bin"))
+        start = np.concatenate([[0], np.cumsum(P["cell_n"])])
+        idx = np.concatenate([np.arange(start[cc], start[cc + 1]) for cc in P["cells"]])
+        out["reread_nummer"] = P["all_nummer"][idx]; out["reread_ort"] = P["all_ort"][idx]
+        out["reread_impuls"] = P["impuls"]; out["reread_masse"] = P["masse"]; out["reread_box"] = P["box"]
+        out["reread_param_file"] = par
+    path = os.path.join(OUT, "chkpt.npz")
+    np.savez_compressed(path, **out)
+    print("%-20s %8.1f KB  %d atoms" % ("chkpt", os.path.getsize(path) / 1024, len(out["s11_nummer"])))
+
+
 if __name__ == "__main__":
-    names = sys.argv[1:] or (list(CASES) + ["eos_inverse"])
+    names = sys.argv[1:] or (list(CASES) + ["eos_inverse", "chkpt"])
     for n in names:
         if n == "eos_inverse":
             run_eos_inverse()
+        elif n == "chkpt":
+            run_chkpt_case()
         elif n == "ttm_adv":
             run_adv_case(n, CASES[n])
         else:
