@@ -50,6 +50,9 @@ def init_threepoint(table, ncols, lens):
         t[n + 1, col] = 6 * a - 8 * b + 3 * c
 
 
+PSTEP = 50          # config.h:260
+
+
 def _tokens(path):
     header, body = [], []
     with open(path) as f:
@@ -107,7 +110,7 @@ def read_pot_table(path, ncols, radial):
         npot = rows.shape[0]
         r2_start, r2 = rows[0, 0], rows[-1, 0]
         r2_step = (r2 - r2_start) / (npot - 1)
-        maxsteps = npot
+        maxsteps = max(PSTEP, -(-npot // PSTEP) * PSTEP)       # allocated in blocks of PSTEP rows (:307-323)
         table = np.zeros((maxsteps + 2, ncols))
         table[:npot] = rows[:, 1:]
         begin = np.full(ncols, r2_start); step = np.full(ncols, r2_step)
@@ -139,6 +142,15 @@ def write_pot_table2(path, begin, end, step, columns):
             for v in col:
                 f.write("%.16e\n" % v)
             f.write("\n")
+
+
+def write_pot_table1(path, r2, columns):
+    """Write format 1 (``#F 1 ncols`` / ``#E`` / one line `r2 v_0 v_1 ...` per sample, r2 equidistant)."""
+    cols = np.asarray(columns, dtype=np.float64)
+    with open(path, "w") as f:
+        f.write("#F 1 %d\n#E\n" % cols.shape[0])
+        for k, x in enumerate(r2):
+            f.write(" ".join("%.16e" % v for v in [x] + list(cols[:, k])) + "\n")
 
 
 def pair_int_lj(eps, sigma, r2):

@@ -53,6 +53,8 @@ CASES = {
     # LJ, Verlet list, serial: config-1 physics at fixture size
     "lj_nbl_2048": dict(binary="imd_nve_nbl", box="8 8 8", temp=0.0258, steps=20, dump=[0, 20], full=[0],
                         pot="lj", nbl=True),
+    # pair potential from a FORMAT 1 file (read_pot_table1, imd_potential.c:297-375)
+    "pair_fmt1": dict(binary="imd_nve_nbl", box="4 4 4", temp=0.0258, steps=0, dump=[0], full=[], pot="pair1", nbl=True),
     # EAM through do_forces/do_forces_eam2 (cell-pair path, no Verlet list)
     # EAM + 3D TTM (imd_ttm_3D.c functions driven by oracle/ref_probe_ttm.c), laser off
     "ttm_2048": dict(binary="imd_mpi_eam_ttm3d_nbl", box="8 8 8", temp=0.03, steps=3, dump=[0, 1, 2, 3], full=[],
@@ -117,6 +119,11 @@ def write_inputs(c, d):
     elif c["pot"] == "eam":
         potential.write_synthetic_eam_files(d)
         par += "core_potential_file phi.pt\nembedding_energy_file F.pt\natomic_e-density_file rho.pt\n"
+    elif c["pot"] == "pair1":       # the LJ table of config 1, handed over as a format-1 potential file
+        pt, _ = potential.create_lj_table(0.392, 2.62, 6.0, 1.5, 731)
+        r2 = pt.begin[0] + pt.step[0] * np.arange(731)
+        potential.write_pot_table1(os.path.join(d, "pair1.pt"), r2, [pt.table[:731]])
+        par += "potfile pair1.pt\n"
     else:
         par += "lj_epsilon 0.392\nlj_sigma 2.62\nr_cut 6.0\nr_begin 1.5\npot_res 2000\n"
     if c["nbl"]:
@@ -374,11 +381,36 @@ def run_chkpt_case():
     print("%-20s %8.1f KB  %d atoms" % ("chkpt", os.path.getsize(path) / 1024, len(out["s11_nummer"])))
 
 
+def run_ttm_file_case():
+    """`.ttm` lattice file (imd_amd/ttm_io.py) -> tests/golden/ttm_file.npz: the file ttm_writeout wrote after step 2
+    (ttm_int 1) and the lattice the reference held at the end of calc_ttm of that step (probe stage `cfl`)."""
+    c = dict(CASES["ttm_2048"], steps=2, dump=[2])
+    with tempfile.TemporaryDirectory() as d:
+        par, _ = write_inputs(c, d)
+        par = par.replace("ttm_int 100000", "ttm_int 1")
+        open(os.path.join(d, "t.param"), "w").write(par)
+        env = dict(os.environ, IMD_PROBE_DIR=d, IMD_PROBE_STEPS="2")
+        r = subprocess.run([os.path.join(REFBIN, c["binary"]), "-p", "t.param"], cwd=d, env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            print(r.stdout[-3000:]); raise SystemExit("reference run failed")
+        text = open(os.path.join(d, "out.2.ttm"), "rb").read()
+        T = po.read_ttm_probe(os.path.join(d, "ttm.0.2.bin"))
+    out = dict(ttm_file=np.frombuffer(text, np.uint8), param_file=par)
+    for f in po.TTM_REC.names:
+        out["lat_" + f] = T["stages"]["cfl"]["lat"][f]
+    path = os.path.join(OUT, "ttm_file.npz")
+    np.savez_compressed(path, **out)
+    print("%-20s %8.1f KB" % ("ttm_file", os.path.getsize(path) / 1024))
+
+
 if __name__ == "__main__":
-    names = sys.argv[1:] or (list(CASES) + ["eos_inverse", "chkpt"])
+    names = sys.argv[1:] or (list(CASES) + ["eos_inverse", "chkpt", "ttm_file"])
     for n in names:
         if n == "eos_inverse":
             run_eos_inverse()
+        elif n == "ttm_file":
+            run_ttm_file_case()
         elif n == "chkpt":
             run_chkpt_case()
         elif n == "ttm_adv":

@@ -107,3 +107,21 @@ def test_headerless_and_velocity_free_files(tmp_path):
         assert False
     except ValueError as e:
         assert "incorrect line" in str(e)
+
+
+def test_ttm_file_writer_and_reader(tmp_path):
+    """ttm_writeout / ttm_read (imd_ttm_3D.c:1836-2118, :2127-2330): from the lattice the reference held after calc_ttm
+    of step 2, write_ttm gives the file the reference wrote byte for byte; read_ttm returns those values at printf's
+    %e / %f precision."""
+    from imd_amd import ttm_io
+    G = gu.load("ttm_file")
+    lat = {k[4:]: G[k] for k in G.files if k.startswith("lat_")}
+    p = str(tmp_path / "out.2.ttm")
+    ttm_io.write_ttm(p, lat, proc=0)
+    assert open(p, "rb").read() == bytes(G["ttm_file"])
+    r = ttm_io.read_ttm(p)
+    inner = (slice(1, -1),) * 3
+    assert np.array_equal(r["natoms"], lat["natoms"][inner])
+    for f in ("temp", "md_temp", "U", "xi", "dens", "fd_k", "fd_g", "Z", "vcom"):
+        assert np.allclose(r[f], lat[f][inner], rtol=1e-6, atol=0), f
+    assert np.abs(r["Ce"] - lat["Ce"][inner]).max() <= 0.5e-6

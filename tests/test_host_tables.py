@@ -34,3 +34,22 @@ def test_eam_files_read_back_like_the_reference():
             for f in ("begin", "end", "step", "invstep"):
                 assert np.array_equal(getattr(pt, f), t[f]), (key, f)
             assert np.array_equal(pt.table, t["table"]), key
+
+
+def test_format1_pair_file_reads_back_like_the_reference():
+    """read_pot_table1 (imd_potential.c:297-375): `r2 value` lines, end/len from the last non-zero value, cut-off shift,
+    allocation in PSTEP blocks, then init_threepoint's two extrapolated rows.  The golden holds pair_pot as the
+    reference built it from the same file (731 samples of the LJ table, written by write_pot_table1)."""
+    G = gu.load("pair_fmt1")
+    t = gu.table(G, "pair_pot")
+    with tempfile.TemporaryDirectory() as d:
+        lj, _ = potential.create_lj_table(0.392, 2.62, 6.0, 1.5, 731)
+        r2 = lj.begin[0] + lj.step[0] * np.arange(731)
+        potential.write_pot_table1(os.path.join(d, "pair1.pt"), r2, [lj.table[:731]])
+        pt, cellsz = potential.read_pot_table(os.path.join(d, "pair1.pt"), 1, True)
+    for f in ("begin", "end", "step", "invstep", "len"):
+        assert np.array_equal(getattr(pt, f), t[f]), f
+    assert pt.maxsteps == int(t["maxsteps"]) == 750 and pt.ncols == 1
+    n = int(t["len"][0]) + 2                       # rows beyond len+2 are uninitialised heap in the reference
+    assert np.array_equal(pt.table[:n], t["table"][:n])
+    assert cellsz == float(t["end"][0])
