@@ -1855,6 +1855,22 @@ extern "C" int imdgpu_update_positions(imdgpu_ctx *ctx, int natoms, const double
   return 0;
 }
 
+// new momenta for the current arrangement (cell ordered): a host integrator that keeps calc_ttm on the device
+extern "C" int imdgpu_update_momenta(imdgpu_ctx *ctx, int natoms, const double *impuls)
+{
+  HIPCHK(hipSetDevice(ctx->device));
+  if (natoms != ctx->nlocal) return imdgpu_fail(ctx, "update_momenta: %d atoms given, %d on the device", natoms, ctx->nlocal);
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  std::vector<int> perm;
+  if (build_ref_perm(ctx, &perm, nullptr)) return 1;
+  std::vector<double> hp((size_t) 3 * natoms);
+  for (int r = 0; r < natoms; r++)
+    for (int d = 0; d < 3; d++) hp[(size_t) d * natoms + perm[r]] = impuls[3 * r + d];
+  for (int d = 0; d < 3; d++)
+    HIPCHK(hipMemcpy(ctx->p + (size_t) d * ctx->cap_local, hp.data() + (size_t) d * natoms, natoms * sizeof(double), hipMemcpyHostToDevice));
+  return 0;
+}
+
 extern "C" int imdgpu_upload_atoms(imdgpu_ctx *ctx, int natoms, const double *ort, const double *impuls,
                                    const double *masse, const int *sorte, const int *nummer)
 {

@@ -27,6 +27,18 @@
  * cells to the library with one added.  Compile imd_main_risc_3d.c with -Dcalc_forces=calc_forces_host
  * (or guard that definition) so that this calc_forces is the one that links.
  *
+ * Builds with -DTTM (3D lattice, imd_ttm_3D.c) additionally get
+ *
+ *     void calc_ttm(void);                  (prototypes.h:1020, imd_ttm_3D.c:35)
+ *
+ * the first block of the reference's calc_ttm (:50-77: update_fd, [do_ADV,] do_cell_activation, do_FILLMESH,
+ * ttm_fill_ghost_layers, diff_substeps x {do_DIFF, do_FILLMESH, ttm_fill_ghost_layers}) plus CFL_maxdt on the
+ * device; the lattice comes back into l1/l2 so that move_atoms_ttm, ttm_writeout and everything else of the host
+ * program read it as before.  init_ttm stays the reference's (it allocates l1/l2 and reads the EOS tables, which
+ * the shim takes over from intp_cve_from_r_te / intp_ee_from_r_tesqrt -- they must be regular grids).  Compile
+ * imd_ttm_3D.c with -Dcalc_ttm=calc_ttm_host so that this calc_ttm is the one that links.  do_ADV: the reference
+ * cannot run it on one rank (do_COMMFLUX's self-Sendrecv never matches); IMD_SHIM_TTM_ADV=1 turns it on here.
+ *
  * Single rank (cpu_dim 1 1 1); an MPI build calls the imdgpu_halo_* operations
  * from its own send_cells/send_forces replacements.
  */
@@ -246,3 +258,93 @@ void calc_forces(int steps)
   nfc++;
   if (is_short) fprintf(stderr, "Short distance, step %d!\n", steps);
 }
+
+#ifdef TTM
+/* ---- calc_ttm on the device ------------------------------------------------------------------------------- */
+static int     g_ttm_ready = 0, g_fdn = 0;
+static int    *g_fi[2];                               /* natoms, natoms_old */
+static double *g_fd[15];                              /* temp temp2 xi md_temp source vcom(3n) dens fd_k fd_g Z Ce ne U U2 */
+
+/* the reference keeps an EOS table as the point list nn_read_table read (imd_interpol.c:1174-1232: x outer, y inner);
+ * the library takes the same values on their regular grid */
+static void eos_grid(const nn_interp *nn, const char *what, int *nx, int *ny, double **z)
+{
+  int n = nn->npoints, js = 1, q;
+  while (js < n && nn->points[js].x == nn->points[0].x) js++;
+  if (n <= 0 || n % js != 0) error_str("imd_shim: EOS table %s is not a regular grid", (char *) what);
+  *ny = js; *nx = n / js;
+  *z = (double *) malloc(n * sizeof(double));
+  if (NULL == *z) error("imd_shim: cannot allocate EOS grid");
+  for (q = 0; q < n; q++) {
+    if (nn->points[q].x != nn->points[(q / js) * js].x || nn->points[q].y != nn->points[q % js].y)
+      error_str("imd_shim: EOS table %s is not a regular grid", (char *) what);
+    (*z)[q] = nn->points[q].z;
+  }
+}
+
+static void ttm_gpu_init(void)
+{
+  imdgpu_ttm_params par;
+  double *zc, *ze;
+  int dim[3], k;
+  double h[3];
+  memset(&par, 0, sizeof(par));
+  par.fd_ext[0] = fd_ext.x; par.fd_ext[1] = fd_ext.y; par.fd_ext[2] = fd_ext.z;
+  par.fd_min_atoms = fd_min_atoms;
+  par.fd_n_timesteps = 100;                            /* calc_ttm hard-codes it, imd_ttm_3D.c:51-52 */
+  par.atomic_weight = atomic_weight; par.atomic_charge = atomic_charge; par.omega_laser = omega_laser;
+  eos_grid(&intp_cve_from_r_te, "EOS_cve_from_r_te", &par.cve_nx, &par.cve_ny, &zc);
+  eos_grid(&intp_ee_from_r_tesqrt, "EOS_ee_from_r_tesqrt", &par.ee_nx, &par.ee_ny, &ze);
+  par.cve_xmin = intp_cve_from_r_te.xmin; par.cve_xmax = intp_cve_from_r_te.xmax;
+  par.cve_ymin = intp_cve_from_r_te.ymin; par.cve_ymax = intp_cve_from_r_te.ymax; par.cve_z = zc;
+  par.ee_xmin = intp_ee_from_r_tesqrt.xmin; par.ee_xmax = intp_ee_from_r_tesqrt.xmax;
+  par.ee_ymin = intp_ee_from_r_tesqrt.ymin; par.ee_ymax = intp_ee_from_r_tesqrt.ymax; par.ee_z = ze;
+  if (getenv("IMD_SHIM_TTM_ADV")) gpu_check(imdgpu_set_option(G, "ttm_adv", 1));
+  gpu_check(imdgpu_ttm_init(G, &par));
+  free(zc); free(ze);
+  gpu_check(imdgpu_ttm_dims(G, dim, h));
+  if (dim[0] != local_fd_dim.x || dim[1] != local_fd_dim.y || dim[2] != local_fd_dim.z)
+    error("imd_shim: FD lattice of the library differs from local_fd_dim");
+  g_fdn = dim[0] * dim[1] * dim[2];
+  for (k = 0; k < 2; k++) g_fi[k] = (int *) malloc(g_fdn * sizeof(int));
+  for (k = 0; k < 15; k++) g_fd[k] = (double *) malloc((k == 5 ? 3 : 1) * (size_t) g_fdn * sizeof(double));
+  g_ttm_ready = 1;
+}
+
+void calc_ttm(void)
+{
+  imdgpu_ttm_fields F;
+  int n, i, j, k, c = 0;
+  double mdt = 0.0;
+  gpu_init();
+  if (!g_have_cells) error("imd_shim: calc_ttm before calc_forces");
+  if (!g_ttm_ready) ttm_gpu_init();
+  fd_n_timesteps = 100; diff_substeps = fd_n_timesteps;              /* imd_ttm_3D.c:51-52 */
+  /* same arrangement as the calc_forces of this step; the momenta are the host integrator's */
+  n = count_atoms();
+  ensure_host(n);
+  gather_cells(1);
+  gpu_check(imdgpu_update_momenta(G, n, g_imp));
+  gpu_check(imdgpu_calc_ttm(G, steps));
+  gpu_check(imdgpu_ttm_cfl_maxdt(G, steps, &mdt));
+  max_dt_ttm = mdt;
+  memset(&F, 0, sizeof(F));
+  F.natoms = g_fi[0]; F.natoms_old = g_fi[1];
+  F.temp = g_fd[0]; F.temp2 = g_fd[1]; F.xi = g_fd[2]; F.md_temp = g_fd[3]; F.source = g_fd[4]; F.vcom = g_fd[5];
+  F.dens = g_fd[6]; F.fd_k = g_fd[7]; F.fd_g = g_fd[8]; F.Z = g_fd[9]; F.Ce = g_fd[10]; F.ne = g_fd[11];
+  F.U = g_fd[12]; F.U2 = g_fd[13];
+  gpu_check(imdgpu_ttm_download(G, &F));
+  for (i = 0; i < local_fd_dim.x; i++)
+    for (j = 0; j < local_fd_dim.y; j++)
+      for (k = 0; k < local_fd_dim.z; k++, c++) {
+        ttm_Element *e = &l1[i][j][k], *e2 = &l2[i][j][k];
+        e->natoms = e2->natoms = F.natoms[c]; e->natoms_old = e2->natoms_old = F.natoms_old[c];
+        e->temp = F.temp[c]; e2->temp = F.temp2[c];
+        e->U = F.U[c]; e2->U = F.U2[c];
+        e->xi = e2->xi = F.xi[c]; e->md_temp = e2->md_temp = F.md_temp[c]; e->source = e2->source = F.source[c];
+        e->vcomx = e2->vcomx = F.vcom[3 * c]; e->vcomy = e2->vcomy = F.vcom[3 * c + 1]; e->vcomz = e2->vcomz = F.vcom[3 * c + 2];
+        e->dens = e2->dens = F.dens[c];
+        e->fd_k = F.fd_k[c]; e->fd_g = F.fd_g[c]; e->Z = F.Z[c]; e->Ce = F.Ce[c]; e->ne = F.ne[c];
+      }
+}
+#endif /* TTM */

@@ -17,7 +17,7 @@ SYMBOLS = [
     "imdgpu_upload_cells", "imdgpu_upload_atoms", "imdgpu_update_positions", "imdgpu_num_atoms", "imdgpu_download_atoms",
     "imdgpu_fix_cells", "imdgpu_fill_ghosts", "imdgpu_make_nblist", "imdgpu_check_nblist",
     "imdgpu_calc_forces", "imdgpu_move_atoms_nve", "imdgpu_md_step", "imdgpu_get_sums",
-    "imdgpu_export_nblist", "imdgpu_nblist_stats",
+    "imdgpu_export_nblist", "imdgpu_update_momenta", "imdgpu_nblist_stats",
     "imdgpu_profile_enable", "imdgpu_profile_reset", "imdgpu_profile_get",
     "imdgpu_ttm_init", "imdgpu_ttm_dims", "imdgpu_ttm_download", "imdgpu_ttm_upload", "imdgpu_ttm_update_fd", "imdgpu_ttm_adv",
     "imdgpu_ttm_cell_activation", "imdgpu_ttm_fillmesh", "imdgpu_ttm_fill_ghost_layers", "imdgpu_ttm_diff",
@@ -98,6 +98,7 @@ def load():
     L.imdgpu_upload_atoms.argtypes = [vp, C.c_int, dp, dp, dp, ip, ip]
     L.imdgpu_num_atoms.argtypes = [vp, ip, ip]
     L.imdgpu_update_positions.argtypes = [vp, C.c_int, dp]
+    L.imdgpu_update_momenta.argtypes = [vp, C.c_int, dp]
     L.imdgpu_download_atoms.argtypes = [vp, ip, dp, dp, dp, dp, dp, dp, ip, ip, ip, dp]
     for f in ("imdgpu_fix_cells", "imdgpu_fill_ghosts", "imdgpu_make_nblist"):
         getattr(L, f).argtypes = [vp]

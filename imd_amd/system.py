@@ -134,6 +134,15 @@ class GpuSystem:
         n, ort, impuls, masse, sorte, nummer = self._atoms(ort, impuls, masse, sorte, nummer)
         self._ck(self.L.imdgpu_upload_atoms(self.h, n, _dp(ort), _dp(impuls), _dp(masse), _ip(sorte), _ip(nummer)))
 
+    def update_positions(self, ort):
+        """new positions, cell ordered like download() returns them; the list stays valid"""
+        a = np.ascontiguousarray(ort, dtype=np.float64)
+        self._ck(self.L.imdgpu_update_positions(self.h, len(a), _dp(a)))
+
+    def update_momenta(self, impuls):
+        a = np.ascontiguousarray(impuls, dtype=np.float64)
+        self._ck(self.L.imdgpu_update_momenta(self.h, len(a), _dp(a)))
+
     def num_atoms(self):
         a, b = C.c_int(), C.c_int()
         self._ck(self.L.imdgpu_num_atoms(self.h, C.byref(a), C.byref(b)))

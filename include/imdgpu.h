@@ -89,6 +89,9 @@ int imdgpu_upload_atoms(imdgpu_ctx *ctx, int natoms, const double *ort,
                         const int *sorte, const int *nummer);
 /* new positions in the current arrangement (cell ordered), list stays valid: a host integrator between rebuilds */
 int imdgpu_update_positions(imdgpu_ctx *ctx, int natoms, const double *ort);
+/* new momenta in the current arrangement (cell ordered): what a host integrator hands over before imdgpu_calc_ttm
+ * (update_fd reads IMPULS, imd_ttm_3D.c:323-325,431-436) */
+int imdgpu_update_momenta(imdgpu_ctx *ctx, int natoms, const double *impuls);
 int imdgpu_num_atoms(imdgpu_ctx *ctx, int *nlocal, int *nghost);
 /* Any output pointer may be NULL.  cell_n: nallcells ints (inner cells only
  * are non-zero).  Arrays are cell ordered in the CURRENT device arrangement. */

@@ -131,3 +131,36 @@ build_dropin_cellpair() {
   echo "built $OUT/imd_$name"
 }
 case " $TARGETS " in *" dropin "*) build_dropin_cellpair ;; esac
+
+# The 3D TTM program on the device: forces through the shim as above AND calc_ttm of the shim (imd_ttm_3D.c compiled
+# with -Dcalc_ttm=calc_ttm_host, no source change; its init_ttm, ttm_writeout, ... stay).  The probe only adds the
+# lattice dump (-DPROBE_TTM_DROPIN) and the two TMM entry points the 3D file needs (see ref_probe_ttm.c).
+# tests/test_gpu_dropin.py compares it with oracle/_ref/imd_mpi_eam_ttm3d_nbl.
+build_dropin_ttm() {
+  local name="mpi_eam_ttm3d_nbl_gpu" defs="-DMPI -DNBL -DEAM2 -DTTM -DTMM -DEOSMODE=1"
+  local obj="$OUT/obj_$name" repo="$(cd "$HERE/.." && pwd)"
+  local MPIINC="${MPI_HOME:-/opt/conda}"
+  [ -f "$repo/imd_amd/csrc/libimdgpu.so" ] || { echo "libimdgpu.so not built, skipping drop-in" >&2; return 0; }
+  [ -f "$MPIINC/include/mpi.h" ] || { echo "no MPI at $MPIINC, skipping $name" >&2; return 0; }
+  local cc="$CC -I$MPIINC/include"
+  mkdir -p "$obj"
+  local objs=""
+  for s in $COMMON imd_geom_mpi_3d.c imd_comm_force_3d.c imd_fix_cells_3d.c imd_mpiio.c imd_mpi_util.c imd_interpol.c fminbnd3.c; do
+    local o="$obj/${s%.c}.o"
+    if [ ! -f "$o" ] || [ "$REF/$s" -nt "$o" ]; then $cc $BASEFLAGS $defs -c "$REF/$s" -o "$o" & fi
+    objs="$objs $o"
+  done
+  $cc $BASEFLAGS $defs -Dcalc_ttm=calc_ttm_host -c "$REF/imd_ttm_3D.c" -o "$obj/imd_ttm_3D.o" &
+  wait
+  $cc $BASEFLAGS $defs -I"$repo/include" -c "$repo/imd_amd/host/imd_shim.c" -o "$obj/imd_shim.o"
+  $cc $BASEFLAGS $defs -c "$HERE/ref_probe.c" -o "$obj/ref_probe.o"
+  $cc $BASEFLAGS $defs -DPROBE_TTM_DROPIN -c "$HERE/ref_probe_ttm.c" -o "$obj/ref_probe_ttm.o"
+  $cc -o "$OUT/imd_$name" $objs "$obj/imd_ttm_3D.o" "$obj/imd_shim.o" "$obj/ref_probe.o" "$obj/ref_probe_ttm.o" \
+      -Wl,--wrap=calc_forces -Wl,--wrap=calc_ttm -Wl,--wrap=tmm_init -Wl,--wrap=do_tmm \
+      "$REF/nn_interpol/libnn.a" -L"$repo/imd_amd/csrc" -limdgpu -Wl,-rpath,/root/repo/imd_amd/csrc \
+      -Wl,-rpath-link,/usr/lib/x86_64-linux-gnu "$MPIINC/lib/libmpi.so" -Wl,-rpath,"$MPIINC/lib" -lm
+  # (libmpi by path and the system directory first for indirect dependencies: the MPI prefix carries an older
+  #  libstdc++ than the HIP runtime needs; at run time libimdgpu.so is listed, hence loaded, before libmpi)
+  echo "built $OUT/imd_$name"
+}
+case " $TARGETS " in *" dropin "*) build_dropin_ttm ;; esac

@@ -102,6 +102,37 @@ static void dump_flux(const char *tag)
         for (q = 0; q < 8; q++) wi(l1[i][j][k].flux[q]);
 }
 
+static void open_dump(double tau)
+{
+  char fn[1024];
+  const char *dir = getenv("IMD_PROBE_DIR");
+  sprintf(fn, "%s/ttm.%d.%d.bin", dir ? dir : ".", myid, steps);
+  tf = fopen(fn, "wb");
+  fwrite("IMDTTMPR", 1, 8, tf);
+  wi(1); wi(steps);
+  wi(local_fd_dim.x); wi(local_fd_dim.y); wi(local_fd_dim.z);
+  wi(fd_ext.x); wi(fd_ext.y); wi(fd_ext.z);
+  wi(fd_min_atoms); wi(diff_substeps); wi(fd_n_timesteps);
+  wd(fd_h.x); wd(fd_h.y); wd(fd_h.z); wd(fd_vol); wd(neighvol);
+  wd(atomic_weight); wd(atomic_charge); wd(timestep); wd(tau); wd(omega_laser);
+}
+
+#ifdef PROBE_TTM_DROPIN
+/* Drop-in build (oracle/build_ref.sh dropin: imd_mpi_eam_ttm3d_nbl_gpu): calc_ttm is the one of
+ * imd_amd/host/imd_shim.c (device); only the dump of the lattice it left in l1/l2 is added here. */
+void __real_calc_ttm(void);
+void __wrap_calc_ttm(void)
+{
+  int dumping = want(steps);
+  __real_calc_ttm();
+  if (dumping) {
+    open_dump(timestep / ((double) diff_substeps));
+    dump_lattice("cfl");
+    fwrite("ENDTTMPR", 1, 8, tf);
+    fclose(tf); tf = NULL;
+  }
+}
+#else
 void __wrap_calc_ttm(void)
 {
   int i, dumping = want(steps);
@@ -110,17 +141,7 @@ void __wrap_calc_ttm(void)
   diff_substeps = fd_n_timesteps;
   tau = timestep / ((double) diff_substeps);
   if (dumping) {
-    char fn[1024];
-    const char *dir = getenv("IMD_PROBE_DIR");
-    sprintf(fn, "%s/ttm.%d.%d.bin", dir ? dir : ".", myid, steps);
-    tf = fopen(fn, "wb");
-    fwrite("IMDTTMPR", 1, 8, tf);
-    wi(1); wi(steps);
-    wi(local_fd_dim.x); wi(local_fd_dim.y); wi(local_fd_dim.z);
-    wi(fd_ext.x); wi(fd_ext.y); wi(fd_ext.z);
-    wi(fd_min_atoms); wi(diff_substeps); wi(fd_n_timesteps);
-    wd(fd_h.x); wd(fd_h.y); wd(fd_h.z); wd(fd_vol); wd(neighvol);
-    wd(atomic_weight); wd(atomic_charge); wd(timestep); wd(tau); wd(omega_laser);
+    open_dump(tau);
     dump_lattice("entry");
   }
   update_fd();
@@ -150,3 +171,4 @@ void __wrap_calc_ttm(void)
     fclose(tf); tf = NULL;
   }
 }
+#endif /* PROBE_TTM_DROPIN */

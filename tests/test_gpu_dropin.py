@@ -112,3 +112,72 @@ def test_reference_cellpair_main_loop_on_gpu_forces():
         assert abs(a["virial"] - b["virial"]) < 1e-9 * abs(b["virial"])
         assert np.abs(_inner_pos(a)[oa] - _inner_pos(b)[ob]).max() < 1e-9
     assert np.allclose(out["gpu"]["eng"], out["cpu"]["eng"], rtol=1e-6, atol=1e-9)
+
+
+CPU_TTM = os.path.join(ROOT, "oracle", "_ref", "imd_mpi_eam_ttm3d_nbl")
+GPU_TTM = os.path.join(ROOT, "oracle", "_ref", "imd_mpi_eam_ttm3d_nbl_gpu")
+
+PARAM_TTM = PARAM.replace("ensemble nve", "ensemble ttm").replace("box_param 10 10 10", "box_param 8 8 8") \
+    .replace("starttemp 0.06", "starttemp 0.03").replace("maxsteps 30", "maxsteps 12") + """fd_ext 1 1 1
+fd_n_timesteps 100
+fd_min_atoms 5
+atomic_weight 26.9815
+atomic_charge 13
+ttm_int 6
+I0 1.0
+lambda 800e-9
+laser_sigma_t 100e-15
+laser_t_0 1.0
+"""
+
+
+def _write_planar_eos(d):
+    """the synthetic EOS tables of the fixtures (tests/golden/make_golden.py:write_planar_eos)"""
+    nr, nt = 24, 40
+    r = np.linspace(500.0, 4500.0, nr); t = np.linspace(1.0, 60000.0, nt); ts = np.linspace(1.0, 245.0, nt)
+    zc = np.outer(np.ones(nr), 0.05 * t); ze = np.outer(np.ones(nr), 4000.0 * ts)
+    for fn, y, z in (("EOS_cve_from_r_te.txt", t, zc), ("EOS_ee_from_r_tesqrt.txt", ts, ze)):
+        with open(os.path.join(d, fn), "w") as f:
+            f.write("%d %d\n%.16e %.16e %.16e %.16e\n" % (nr, nt, r[0], r[-1], y[0], y[-1]))
+            for i in range(nr):
+                for j in range(nt):
+                    f.write("%.16e %.16e %.16e\n" % (r[i], y[j], z[i, j]))
+
+
+@pytest.mark.skipif(not (os.path.exists(CPU_TTM) and os.path.exists(GPU_TTM)), reason="oracle/_ref binaries not built")
+def test_reference_ttm_main_loop_on_gpu_forces_and_gpu_calc_ttm():
+    """The reference's 3D TTM program (MPI build, one rank) with BOTH hot-path entry points replaced by the shim:
+    calc_forces and calc_ttm run on the device, the host keeps init_ttm (EOS tables, l1/l2), move_atoms_ttm,
+    fix_cells, ttm_writeout.  Against the CPU build of the same program (its calc_ttm = the reference's own functions
+    in the order of the first block, see oracle/ref_probe_ttm.c) over 12 steps: lattice (what move_atoms_ttm
+    reads: xi, vcom, natoms; and temp, U, md_temp, dens, fd_k, fd_g, Ce) within 1e-9, atoms within 1e-9, and
+    the .ttm file the host wrote from l1 equal line by line at its printed precision."""
+    out = {}
+    steps = (0, 1, 6, 12)
+    for tag, exe in (("cpu", CPU_TTM), ("gpu", GPU_TTM)):
+        with tempfile.TemporaryDirectory() as d:
+            potential.write_synthetic_eam_files(d)
+            _write_planar_eos(d)
+            open(os.path.join(d, "t.param"), "w").write(PARAM_TTM)
+            env = dict(os.environ, IMD_PROBE_DIR=d, IMD_PROBE_STEPS=",".join(map(str, steps)))
+            r = subprocess.run([exe, "-p", "t.param"], cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                               text=True, timeout=600)
+            assert r.returncode == 0, r.stdout[-3000:]
+            out[tag] = {s: po.read_probe(os.path.join(d, "probe.0.%d.bin" % s)) for s in steps}
+            out[tag]["lat"] = {s: po.read_ttm_probe(os.path.join(d, "ttm.0.%d.bin" % s))["stages"]["cfl"] for s in steps}
+            out[tag]["ttm_file"] = np.loadtxt(os.path.join(d, "out.2.ttm"))
+    inner = (slice(1, -1),) * 3
+    for s in steps:
+        a, b = out["gpu"]["lat"][s], out["cpu"]["lat"][s]
+        assert np.array_equal(a["lat"]["natoms"][inner], b["lat"]["natoms"][inner])
+        assert np.array_equal(a["lat"]["natoms_old"][inner], b["lat"]["natoms_old"][inner])
+        for f in ("temp", "temp2", "U", "U2", "xi", "md_temp", "dens", "vcom", "fd_k", "fd_g", "Ce", "Z", "ne"):
+            x, y = a["lat"][f][inner], b["lat"][f][inner]
+            assert np.abs(x - y).max() <= 1e-9 * np.abs(y).max(), (s, f)
+        assert abs(a["max_dt_ttm"] - b["max_dt_ttm"]) <= 1e-9 * abs(b["max_dt_ttm"])
+        A, B = out["gpu"][s], out["cpu"][s]
+        oa, ob = np.argsort(_inner_ids(A)), np.argsort(_inner_ids(B))
+        assert np.abs(_inner_pos(A)[oa] - _inner_pos(B)[ob]).max() < 1e-9, s
+        assert np.abs(A["impuls"][oa] - B["impuls"][ob]).max() < 1e-9 * np.abs(B["impuls"]).max(), s
+        assert np.array_equal(A["numneighs"][oa], B["numneighs"][ob])
+    assert np.allclose(out["gpu"]["ttm_file"], out["cpu"]["ttm_file"], rtol=2e-6, atol=1e-12)

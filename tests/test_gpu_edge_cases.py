@@ -85,3 +85,22 @@ def test_edge_case_both_families_vs_oracle(name):
         assert abs(e - eo) < 1e-11 * abs(eo)
         if name == "crowded" and mode == 1:
             assert info["W"] > 96 and info["tile_cap"] >= 64
+
+
+def test_host_integrator_hand_over_of_positions_and_momenta():
+    """imdgpu_update_positions / imdgpu_update_momenta: a host that integrates itself (shim, level 1) hands over the
+    arrays in the cell order download() reports; the device holds exactly those values at the same atoms."""
+    c = _case((8, 8, 8), 4.05)
+    s = GpuSystem(c["box"], c["pbc"], c["dim"], 1, c["cellsz"], 0.5, 0.1)
+    s.upload_tables(*c["tabs"])
+    s.upload_atoms(c["pos"], c["mom"], 26.9815)
+    s.calc_forces(0)
+    d = s.download(fields=("ort", "impuls", "nummer"))
+    rng = np.random.default_rng(5)
+    new_x = d["ort"] + 1e-3 * rng.standard_normal(d["ort"].shape)
+    new_p = rng.standard_normal(d["impuls"].shape)
+    s.update_positions(new_x); s.update_momenta(new_p)
+    e = s.download(fields=("ort", "impuls", "nummer"))
+    assert np.array_equal(e["nummer"], d["nummer"])
+    assert np.array_equal(e["ort"], new_x) and np.array_equal(e["impuls"], new_p)
+    s.close()
