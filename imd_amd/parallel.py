@@ -359,6 +359,7 @@ class DistributedMD:
             else:
                 blk = ops.ttm_local_block(step)
                 allb = all_gather_flat(blk, self.world)
+                ops.ttm_mark_gathered()
                 ops.ttm_apply_blocks(step, allb, self.world, self._ttm_offs)
                 if self.ttm_adv:                         # calc_ttm's order: update_fd, do_ADV(1.0), the rest
                     ops.ttm_adv(1.0, step)
@@ -367,6 +368,11 @@ class DistributedMD:
             ops.ttm_unfork()
         ops.forces_phase(2)
         self.plan.exchange(ops, 1)                       # dF of the ghost atoms  [send_cells(copy_dF)]
+        if self.ttm and not self.ttm_decomposed:
+            # the EAM force pass is a persistent kernel that fills every CU: a collective's multi-wave workgroups that
+            # are not resident by then wait for its end and the whole lattice chain with them.  The
+            # all-gather normally finishes under the embedding pass; if not, the force pass waits for it (not for the chain)
+            ops.ttm_wait_gathered()
         ops.forces_phase(3)
         if self.ttm:
             ops.ttm_join()
@@ -535,6 +541,13 @@ class GpuOps:
         self.side.wait_stream(self.stream)
         torch.cuda.set_stream(self.side)
         self.s.set_stream(self.side.cuda_stream)
+
+    def ttm_mark_gathered(self):
+        self._ev_gathered = torch.cuda.Event()
+        self._ev_gathered.record(self.side)
+
+    def ttm_wait_gathered(self):
+        self.stream.wait_event(self._ev_gathered)
 
     def ttm_unfork(self):
         torch.cuda.set_stream(self.stream)
