@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-box", type=int, default=48, help="unit cells per direction of the CPU sample")
     ap.add_argument("--cpu-steps", type=int, default=30)
+    ap.add_argument("--cpu-steps-mpi", type=int, default=120, help="steps of the multi-core (MPI + TTM) reference sample")
+    ap.add_argument("--cpu-box-mpi", type=int, default=64, help="unit cells per direction of that sample")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal: host-staged halos)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks on cuda:0")
     ap.add_argument("--ttm-decomposed", action="store_true",
@@ -91,7 +93,82 @@ def build_system(args, rank, world, device):
     return sysm, md, len(pos), gdim, cpu_dim
 
 
+def _host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def _find_mpiexec():
+    import shutil
+    for c in (shutil.which("mpiexec"), "/opt/conda/bin/mpiexec"):
+        if c and os.path.exists(c):
+            return c
+    return None
+
+
+def cpu_baseline_mpi_ttm(args):
+    """The workload of the GPU number on the host cores: the reference's own MPI build with the 3D TTM
+    (oracle/_ref/imd_mpi_eam_ttm3d_nbl: EAM forces through imd_forces_nbl.c, calc_ttm's first block with 100
+    sub-steps, move_atoms_ttm, list maintenance, halo exchange), one rank per core, on a bounded sample."""
+    from imd_amd import potential, ttm as ttm_mod
+    exe = os.path.join(ROOT, "oracle", "_ref", "imd_mpi_eam_ttm3d_nbl")
+    mpiexec = _find_mpiexec()
+    if args.no_ttm or not os.path.exists(exe) or mpiexec is None:
+        return None
+    cores = _host_cores()                       # the GPU box grants 16 cores per GPU whatever the affinity mask shows
+    cpu_dim = (4, 2, 2) if cores >= 16 else (2, 2, 2) if cores >= 8 else (2, 2, 1) if cores >= 4 else (2, 1, 1) if cores >= 2 else (1, 1, 1)
+    nranks = cpu_dim[0] * cpu_dim[1] * cpu_dim[2]
+    nb, steps = args.cpu_box_mpi, args.cpu_steps_mpi
+    natoms = 4 * nb ** 3
+    with tempfile.TemporaryDirectory() as d:
+        potential.write_synthetic_eam_files(d)
+        cve, ee = ttm_mod.synthetic_eos()
+        ttm_mod.write_eos_table(os.path.join(d, "EOS_cve_from_r_te.txt"), cve)
+        ttm_mod.write_eos_table(os.path.join(d, "EOS_ee_from_r_tesqrt.txt"), ee)
+        open(os.path.join(d, "b.param"), "w").write(
+            "coordname _fcc\noutfiles out\nensemble ttm\nmaxsteps %d\ntimestep 0.1\nntypes 1\ntotal_types 1\n"
+            "masses 26.9815\ntypes 0\nbox_param %d %d %d\nbox_unit 4.05\npbc_dirs 1 1 1\nstarttemp %g\nseed 12345\n"
+            "core_potential_file phi.pt\nembedding_energy_file F.pt\natomic_e-density_file rho.pt\n"
+            "eng_int 100000\ncheckpt_int 100000\nnbl_margin 0.5\nnbl_size 1.5\ncpu_dim %d %d %d\n"
+            "fd_ext %d %d %d\nfd_n_timesteps 100\nfd_min_atoms 5\natomic_weight 26.9815\natomic_charge 13\n"
+            "ttm_int 100000\nI0 1.0\nlambda 800e-9\nlaser_sigma_t 100e-15\nlaser_t_0 1.0\n"
+            % ((steps, nb, nb, nb, args.temp) + cpu_dim + tuple(args.fd_ext)))
+        env = dict(os.environ, IMD_PROBE_STEPS="-1")
+        t0 = time.time()
+        try:
+            r = subprocess.run([mpiexec, "-n", str(nranks), exe, "-p", "b.param"], cwd=d, env=env, stdout=subprocess.PIPE,
+                               stderr=subprocess.STDOUT, text=True, timeout=300)
+        except (subprocess.TimeoutExpired, OSError):
+            return None
+        wall = time.time() - t0
+    if r.returncode != 0:
+        return None
+    secs = None
+    for line in r.stdout.splitlines():
+        if "seconds excluding setup time" in line:
+            secs = float(line.split()[0])                 # imd.c prints cputime / num_cpus here = seconds of the main loop
+    if not secs:
+        return None
+    return {"value": natoms * (steps + 1) / secs, "unit": "atom-steps/s", "cores": nranks, "kind": "reference",
+            "sample": "reference binary imd_mpi_eam_ttm3d_nbl (gcc -O2, MPI, cpu_dim %d %d %d = %d ranks on %d host cores), %d atoms "
+                      "x %d steps, EAM + 3D TTM (fd_ext %d %d %d, 100 sub-steps, no laser, calc_ttm's first block), main loop "
+                      "incl. list rebuilds, %.1f s wall" % (cpu_dim + (nranks, cores, natoms, steps + 1) + tuple(args.fd_ext) + (wall,))}
+
+
 def cpu_baseline(args):
+    """Primary: the reference's MPI + TTM build on all host cores (cpu_baseline_mpi_ttm).  Also timed, and the
+    fallback: the serial NVE reference binary on one core (`serial`)."""
+    ser = cpu_baseline_serial(args)
+    par = cpu_baseline_mpi_ttm(args)
+    if par is None:
+        return ser
+    par["serial"] = {k: ser[k] for k in ("value", "unit", "cores", "kind", "sample")}
+    return par
+
+
+def cpu_baseline_serial(args):
     """The REAL reference binary (oracle/_ref, built here from /root/reference and
     shipped to the GPU box as a binary) on a bounded sample, 1 core; falls back to
     the oracle port when the binary is absent."""
