@@ -230,3 +230,54 @@ def test_large_system_properties():
     assert np.abs(e0 - e1).max() < 1e-12 * np.abs(e0).max()
     assert abs(r0["tot_pot_energy"] - r1["tot_pot_energy"]) < 1e-12 * abs(r0["tot_pot_energy"])
     assert np.abs(f1.sum(axis=0)).max() < 1e-7            # sum of all forces ~ 0 (1M atoms, |F|~0.5)
+
+
+def test_bench_size_properties_with_ttm():
+    """BASELINE config 3 at full size (136^3 unit cells = 10 061 824 atoms, EAM + 3D TTM fd_ext 2 2 2, 100 sub-steps):
+    properties that need no oracle run -- the two kernel families agree on every force, the total force vanishes, the
+    symmetric list is even; after device-resident MD+TTM steps every atom sits in exactly one FD cell (sum natoms = N),
+    the lattice temperature of the FD cells averages to 2/3 of the kinetic energy per atom (in the frame of each
+    cell's centre of mass, hence a little below), electron temperatures stay within the initial thermal spread,
+    and the coupling xi is finite everywhere."""
+    from imd_amd import lattice, potential, ttm as ttm_mod
+    from imd_amd.system import global_cell_dim
+    nb = (136, 136, 136)
+    box = lattice.fcc_box(nb)
+    pos = lattice.fcc_positions(nb)
+    n = len(pos)
+    assert n == 10061824
+    mom = lattice.maxwell_momenta(n, 26.9815, 0.0258, seed=12345)
+    pair, rho, emb, r2cut = potential.synthetic_eam_tables()
+    cellsz = (np.sqrt(r2cut) + 0.5) ** 2
+    gd = global_cell_dim(box, cellsz, (2, 2, 2))
+    dim = [g + 2 for g in gd]
+    res = {}
+    for mode in (0, 1):
+        s = GpuSystem(box, (1, 1, 1), dim, 1, cellsz, 0.5, 0.1, count_ttm_neighbours=True)
+        s.set_option("mode", mode)
+        s.upload_tables(pair, rho, emb)
+        s.upload_atoms(pos, mom, 26.9815)
+        s.calc_forces(0)
+        d = s.download(fields=("kraft", "nummer", "numneighs"))
+        o = np.argsort(d["nummer"])
+        res[mode] = (d["kraft"][o], d["numneighs"][o])
+        ent, mx = s.nblist_stats()
+        assert ent % 2 == 0
+        if mode == 1:
+            ttm_mod.attach_default(s, fd_ext=(2, 2, 2), diff_substeps=100, fd_min_atoms=5)
+            for st in range(4):
+                s.md_step(st)
+            lat = s.ttm_download(fields=("natoms", "md_temp", "temp", "xi"))
+            inner = (slice(1, -1),) * 3
+            assert int(lat["natoms"][inner].sum()) == n
+            ekin = s.get_sums()["tot_kin_energy"] / n
+            tl = lat["md_temp"][inner]
+            assert 0.90 * (2.0 / 3.0) * ekin < tl.mean() < 1.02 * (2.0 / 3.0) * ekin
+            te = lat["temp"][inner]
+            assert te.min() > 0.5 * tl.mean() and te.max() < 1.5 * tl.mean()
+            assert np.isfinite(lat["xi"]).all()
+        s.close()
+    f0, f1 = res[0][0], res[1][0]
+    assert np.abs(f0 - f1).max() < 1e-11 * max(np.abs(f0).max(), 1e-3)
+    assert np.array_equal(res[0][1], res[1][1])
+    assert np.abs(f1.sum(axis=0)).max() < 1e-6
