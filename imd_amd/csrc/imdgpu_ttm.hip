@@ -34,7 +34,8 @@ struct TtmState {
   int fd_min_atoms = 0, nsub = 0, cur = 0, kcur = 0;
   double h[3]{}, vol = 0, neighvol = 0, atomic_weight = 0, atomic_charge = 0, omega_laser = 0, Temin = 1e-3;
   double max_dt_ttm = 0;
-  int have_source = 0;              // a source term was uploaded (imdgpu_ttm_upload with `source`): the sub-steps read it
+  int have_source = 0;              // a source term was uploaded (imdgpu_ttm_upload with `source`) or a laser is set: the sub-steps read it
+  int laser_on = 0; imdgpu_laser_params laser{};   // imdgpu_ttm_set_laser: imdgpu_calc_ttm applies laser_rescale_ttm every step
   int *natoms = nullptr, *natoms_old = nullptr;
   int *flux = nullptr;              // 8 planes: atoms that entered the FD cell since the last update_fd (option ttm_flux)
   double *temp[2]{}, *U[2]{}, *fd_k[2]{};
@@ -44,7 +45,7 @@ struct TtmState {
   EosDev cve{}, ee{};
   double *d_red = nullptr;       // reduction scratch
   // one captured sub-step chain per value of `cur` at its start (do_ADV's extra swap alternates it from step to step)
-  hipGraphExec_t graph[2] = {nullptr, nullptr}; int graph_kcur[2] = {-1, -1}; double graph_tau[2] = {0, 0};
+  hipGraphExec_t graph[2] = {nullptr, nullptr}; int graph_kcur[2] = {-1, -1}, graph_src[2] = {-1, -1}; double graph_tau[2] = {0, 0};
   // decomposed lattice (several ranks): faces travel through a host shared-memory mailbox (see Mailbox below)
   void *mb_host = nullptr; size_t mb_bytes = 0; int mb_rank = -1, mb_nranks = 0;
   MailboxDev mbd{};
@@ -446,6 +447,23 @@ __global__ __launch_bounds__(64) void k_ttm_adv(Lat L, EosDev ee, double tau, co
     U2[c] = u2;
     if (natoms[c] >= L.fd_min_atoms) T2[c] = d_te_from_r_ee(ee, dens[c], u2 / (26.9815 * C_AMU * C_J2EV)) / 11604.5;
   } else if (Nnew < 1) { U2[c] = 0.0; T2[c] = 0.0; }
+}
+
+// laser_rescale_ttm (imd_laser.c:715-788, the branch without LASERYZ) with ttm_calc_depth (:699-710): Beer-Lambert
+// source term exp(-mu depth) * [exp(-(t - t_0)^2 / sigma_t^2 / 2) * p_peak] in every ACTIVE cell; depth = distance of
+// the cell's low corner along laser_dir behind laser_offset, clamped at 0.  `e` = the bracket, evaluated on the host.
+__global__ void k_ttm_laser(Lat L, int g0, int g1, int g2, int d0, int d1, int d2, double offset, double mu, double e,
+                            const int *natoms, double *source)
+{
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ni = L.dim[0] - 2, nj = L.dim[1] - 2, nk = L.dim[2] - 2;
+  if (t >= ni * nj * nk) return;
+  const int i = t / (nk * nj) + 1, j = (t / nk) % nj + 1, k = t % nk + 1, c = fidx(L, i, j, k);
+  if (natoms[c] < L.fd_min_atoms) return;
+  double depth = (L.h[0] * ((i - 1) + g0)) * d0 + (L.h[1] * ((j - 1) + g1)) * d1 + (L.h[2] * ((k - 1) + g2)) * d2;
+  depth -= offset;
+  if (depth < 0) depth = 0;
+  source[c] = exp(-mu * depth) * e;
 }
 
 // do_FILLMESH per cell: MeanCharge (More's Thomas-Fermi fit, imd_ttm_3D.c:2399-2473), getKappa (:2549-2592),
@@ -955,6 +973,32 @@ extern "C" int imdgpu_ttm_eos_te_from_r_ee(imdgpu_ctx *ctx, int n, const double 
   return 0;
 }
 
+// [laser_rescale_ttm, imd_laser.c:715-788]: writes the source term of the current MD step (time = timestep * steps)
+extern "C" int imdgpu_ttm_laser_rescale(imdgpu_ctx *ctx, const imdgpu_laser_params *p, int steps)
+{
+  NEED_TTM();
+  if (!p) return imdgpu_fail(ctx, "ttm_laser_rescale: no parameters");
+  double g = ctx->timestep * steps - p->t_0;
+  g *= g;
+  const double e = exp(-g / p->sigma_t_squared / 2.0) * p->p_peak;
+  int go[3];
+  for (int d = 0; d < 3; d++) go[d] = ctx->ttm_decomposed ? ctx->my_coord[d] * t->ldim[d] : 0;
+  hipLaunchKernelGGL(k_ttm_laser, dim3(nblk(t->ninner, TTM_WG)), dim3(TTM_WG), 0, ctx->stream, L, go[0], go[1], go[2],
+                     p->dir[0], p->dir[1], p->dir[2], p->offset, p->mu, e, t->natoms, t->source);
+  HIPCHK(hipGetLastError());
+  t->have_source = 1;
+  return 0;
+}
+
+// imdgpu_calc_ttm / imdgpu_ttm_lattice_step apply the laser after update_fd from now on (p == NULL: off)
+extern "C" int imdgpu_ttm_set_laser(imdgpu_ctx *ctx, const imdgpu_laser_params *p)
+{
+  NEED_TTM();
+  t->laser_on = p != nullptr;
+  if (p) { t->laser = *p; t->have_source = 1; }
+  return 0;
+}
+
 // [do_ADV(tau), imd_ttm_3D.c:1321-1458; calc_ttm calls it with tau = 1.0 right after update_fd (:57-60)]
 extern "C" int imdgpu_ttm_adv(imdgpu_ctx *ctx, double tau, int steps)
 {
@@ -1071,6 +1115,7 @@ extern "C" int imdgpu_ttm_lattice_step(imdgpu_ctx *ctx, int steps)
   const bool MBX = t->mb_host != nullptr;
   if (ctx->ttm_decomposed && !MBX) return imdgpu_fail(ctx, "decomposed TTM lattice: imdgpu_ttm_mailbox_attach first");
   imdgpu_tl_mark(ctx, "ttm_update_fd");
+  if (t->laser_on && imdgpu_ttm_laser_rescale(ctx, &t->laser, steps)) return 1;   // update_fd has just zeroed the source
   if (imdgpu_ttm_cell_activation(ctx) || imdgpu_ttm_fillmesh(ctx, steps)) return 1;
   if (MBX) {                       // first publication of this MD step: natoms, temp, fd_k of my boundary layers
     hipLaunchKernelGGL(k_ttm_push_faces, dim3(6), dim3(64), 0, ctx->stream, L, t->mbd, 0, 1, t->natoms,
@@ -1083,7 +1128,7 @@ extern "C" int imdgpu_ttm_lattice_step(imdgpu_ctx *ctx, int steps)
     // the state before it, so one captured hipGraph replays every MD step
     const bool can_graph = (t->nsub % 2 == 0) && steps >= 1;      // step 0 re-initialises U: run it un-captured
     const int gi = t->cur;
-    if (can_graph && t->graph[gi] && t->graph_kcur[gi] == t->kcur && t->graph_tau[gi] == tau) {
+    if (can_graph && t->graph[gi] && t->graph_kcur[gi] == t->kcur && t->graph_tau[gi] == tau && t->graph_src[gi] == t->have_source) {
       HIPCHK(hipGraphLaunch(t->graph[gi], ctx->stream));
     } else if (can_graph) {
       if (t->graph[gi]) { (void) hipGraphExecDestroy(t->graph[gi]); t->graph[gi] = nullptr; }
@@ -1102,7 +1147,7 @@ extern "C" int imdgpu_ttm_lattice_step(imdgpu_ctx *ctx, int steps)
       HIPCHK(hipStreamEndCapture(ctx->stream, &g));
       HIPCHK(hipGraphInstantiate(&t->graph[gi], g, nullptr, nullptr, 0));
       (void) hipGraphDestroy(g);
-      t->graph_kcur[gi] = k0; t->graph_tau[gi] = tau;
+      t->graph_kcur[gi] = k0; t->graph_tau[gi] = tau; t->graph_src[gi] = t->have_source;
       HIPCHK(hipGraphLaunch(t->graph[gi], ctx->stream));
     } else {
       for (int i = 0; i < t->nsub; i++) launch_substep_fused(ctx, t, L, tau, steps, i);

@@ -36,7 +36,8 @@
  * device; the lattice comes back into l1/l2 so that move_atoms_ttm, ttm_writeout and everything else of the host
  * program read it as before.  init_ttm stays the reference's (it allocates l1/l2 and reads the EOS tables, which
  * the shim takes over from intp_cve_from_r_te / intp_ee_from_r_tesqrt -- they must be regular grids).  Compile
- * imd_ttm_3D.c with -Dcalc_ttm=calc_ttm_host so that this calc_ttm is the one that links.  do_ADV: the reference
+ * imd_ttm_3D.c with -Dcalc_ttm=calc_ttm_host so that this calc_ttm is the one that links.  With -DLASER and
+ * laser_rescale_mode 4 the Beer-Lambert source of laser_rescale_ttm is applied on the device too.  do_ADV: the reference
  * cannot run it on one rank (do_COMMFLUX's self-Sendrecv never matches); IMD_SHIM_TTM_ADV=1 turns it on here.
  *
  * Single rank (cpu_dim 1 1 1); an MPI build calls the imdgpu_halo_* operations
@@ -301,6 +302,15 @@ static void ttm_gpu_init(void)
   par.ee_ymin = intp_ee_from_r_tesqrt.ymin; par.ee_ymax = intp_ee_from_r_tesqrt.ymax; par.ee_z = ze;
   if (getenv("IMD_SHIM_TTM_ADV")) gpu_check(imdgpu_set_option(G, "ttm_adv", 1));
   gpu_check(imdgpu_ttm_init(G, &par));
+#ifdef LASER
+  if (laser_rescale_mode == 4) {                       /* laser_rescale_ttm (imd_laser.c:715-788) inside calc_ttm */
+    imdgpu_laser_params lp;
+    lp.dir[0] = laser_dir.x; lp.dir[1] = laser_dir.y; lp.dir[2] = laser_dir.z;
+    lp.offset = laser_offset; lp.mu = laser_mu; lp.p_peak = laser_p_peak; lp.t_0 = laser_t_0;
+    lp.sigma_t_squared = laser_sigma_t_squared;
+    gpu_check(imdgpu_ttm_set_laser(G, &lp));
+  }
+#endif
   free(zc); free(ze);
   gpu_check(imdgpu_ttm_dims(G, dim, h));
   if (dim[0] != local_fd_dim.x || dim[1] != local_fd_dim.y || dim[2] != local_fd_dim.z)

@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import lib as _lib
-from .lib import TTM_FIELDS, TTM_INT_FIELDS, ImdGpuError, PotTableC, TtmFieldsC, TtmParamsC
+from .lib import TTM_FIELDS, TTM_INT_FIELDS, ImdGpuError, LaserParamsC, PotTableC, TtmFieldsC, TtmParamsC
 
 
 def _dp(a):
@@ -285,6 +285,22 @@ class GpuSystem:
     def do_ADV(self, tau=1.0, steps=1):
         """do_ADV(tau) (imd_ttm_3D.c:1321-1458)"""
         self._ck(self.L.imdgpu_ttm_adv(self.h, float(tau), int(steps)))
+
+    @staticmethod
+    def _laser(direction, offset, mu, p_peak, t_0, sigma_t_squared):
+        p = LaserParamsC()
+        p.dir[:] = [int(v) for v in direction]
+        p.offset, p.mu, p.p_peak, p.t_0, p.sigma_t_squared = float(offset), float(mu), float(p_peak), float(t_0), float(sigma_t_squared)
+        return p
+
+    def laser_rescale_ttm(self, steps, **laser):
+        """laser_rescale_ttm (imd_laser.c:715-788): source term of MD step `steps`; laser = dict(direction, offset, mu,
+        p_peak, t_0, sigma_t_squared) -- the reference's laser_* globals after init_laser"""
+        self._ck(self.L.imdgpu_ttm_laser_rescale(self.h, C.byref(self._laser(**laser)), int(steps)))
+
+    def set_laser(self, **laser):
+        """calc_ttm applies the laser source after update_fd in every step from now on (no arguments: off)"""
+        self._ck(self.L.imdgpu_ttm_set_laser(self.h, C.byref(self._laser(**laser)) if laser else None))
 
     def ttm_fill_ghost_layers(self):
         self._ck(self.L.imdgpu_ttm_fill_ghost_layers(self.h))

@@ -178,6 +178,20 @@ int imdgpu_ttm_update_fd(imdgpu_ctx *ctx, int steps);
  * imdgpu_ttm_adv(1.0) after update_fd like calc_ttm :57-60).  For a lattice held as a whole (one rank, or the
  * replicated lattice of several ranks); not for option "ttm_decomposed". */
 int imdgpu_ttm_adv(imdgpu_ctx *ctx, double tau, int steps);
+/* [laser_rescale_ttm, imd_laser.c:715-788 (-DLASER, laser_rescale_mode 4), with ttm_calc_depth :699-710]
+ * Beer-Lambert source term of the electron heat equation: in every active FD cell
+ *   source = exp(-mu * depth) * exp(-(timestep*steps - t_0)^2 / sigma_t_squared / 2) * p_peak,
+ * depth = position of the cell's low corner along `dir` minus `offset`, clamped at 0.  The members are the reference's
+ * globals laser_dir, laser_offset, laser_mu, laser_p_peak, laser_t_0, laser_sigma_t_squared after init_laser
+ * (imd_laser.c:283-360: p_peak = mu * sigma_e / sigma_t / sqrt(2 pi), offset = get_surface()).
+ * imdgpu_ttm_laser_rescale writes the term once (update_fd zeroes it every step); imdgpu_ttm_set_laser makes
+ * imdgpu_calc_ttm / imdgpu_ttm_lattice_step do that after update_fd in every step (NULL switches it off). */
+typedef struct {
+  int    dir[3];
+  double offset, mu, p_peak, t_0, sigma_t_squared;
+} imdgpu_laser_params;
+int imdgpu_ttm_laser_rescale(imdgpu_ctx *ctx, const imdgpu_laser_params *par, int steps);
+int imdgpu_ttm_set_laser(imdgpu_ctx *ctx, const imdgpu_laser_params *par);
 /* [do_cell_activation, :1468-1596] */
 int imdgpu_ttm_cell_activation(imdgpu_ctx *ctx);
 /* [do_FILLMESH, :492-661] */

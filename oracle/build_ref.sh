@@ -9,7 +9,7 @@
 # oracle/ref_probe.c, a read-only observation probe attached with ld --wrap.
 #
 # usage: oracle/build_ref.sh [target ...]
-#   targets: eam_nve_nbl  nve_nbl  eam_nve  nve  mpi_eam_nve_nbl  mpi_eam_ttm3d_nbl
+#   targets: eam_nve_nbl  nve_nbl  eam_nve  nve  mpi_eam_nve_nbl  mpi_eam_ttm3d_nbl  mpi_eam_ttm3d_laser_nbl  dropin
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 REF="${IMD_REFERENCE:-/root/reference}"
@@ -55,7 +55,7 @@ build() {
   echo "built $OUT/imd_$name"
 }
 
-TARGETS="${*:-eam_nve_nbl nve_nbl eam_nve mpi_eam_ttm3d_nbl dropin}"
+TARGETS="${*:-eam_nve_nbl nve_nbl eam_nve mpi_eam_ttm3d_nbl mpi_eam_ttm3d_laser_nbl dropin}"
 for t in $TARGETS; do
   case "$t" in
     eam_nve_nbl) build "$t" "-DNBL -DEAM2 -DNVE" "$COMMON $NBLSRC" "$CC" "" ;;
@@ -74,6 +74,13 @@ for t in $TARGETS; do
       if [ ! -f "$MPIINC/include/mpi.h" ]; then echo "no MPI at $MPIINC, skipping $t" >&2; continue; fi
       build "$t" "-DMPI -DNBL -DEAM2 -DTTM -DTMM -DEOSMODE=1" \
             "$COMMON $NBLSRC imd_mpi_util.c imd_ttm_3D.c imd_interpol.c fminbnd3.c" \
+            "$CC -I$MPIINC/include" "-L$MPIINC/lib -Wl,-rpath,$MPIINC/lib -lmpi" ;;
+    mpi_eam_ttm3d_laser_nbl)
+      # the same with -DLASER (imd_laser.c: Beer-Lambert source laser_rescale_ttm, init_laser, get_surface)
+      MPIINC="${MPI_HOME:-/opt/conda}"
+      if [ ! -f "$MPIINC/include/mpi.h" ]; then echo "no MPI at $MPIINC, skipping $t" >&2; continue; fi
+      build "$t" "-DMPI -DNBL -DEAM2 -DTTM -DTMM -DEOSMODE=1 -DLASER" \
+            "$COMMON $NBLSRC imd_mpi_util.c imd_ttm_3D.c imd_interpol.c fminbnd3.c imd_laser.c" \
             "$CC -I$MPIINC/include" "-L$MPIINC/lib -Wl,-rpath,$MPIINC/lib -lmpi" ;;
     dropin) ;;    # built below
     *) echo "unknown target $t" >&2; exit 1 ;;

@@ -342,6 +342,7 @@ def _ttm_lib():
         L.orc_ttm_update_fd.argtypes = [tp, sp, C.c_int]
         L.orc_ttm_cell_activation.argtypes = [tp]
         L.orc_ttm_adv.argtypes = [tp, C.c_double, C.c_int]
+        L.orc_ttm_laser_rescale.argtypes = [tp, C.POINTER(C.c_int)] + [C.c_double] * 6
         L.orc_ttm_fillmesh.argtypes = [tp, C.c_int]
         L.orc_ttm_fill_ghosts.argtypes = [tp]
         L.orc_ttm_diff.argtypes = [tp, C.c_double, C.c_int]
@@ -405,6 +406,11 @@ class OracleTTM:
 
     def update_fd(self, steps): _ttm_lib().orc_ttm_update_fd(self._p, self.sys._p, steps)
     def adv(self, tau, steps): _ttm_lib().orc_ttm_adv(self._p, float(tau), int(steps))
+    def laser_rescale(self, direction, offset, mu, p_peak, t_0, sigma_t_squared, time):
+        d = np.ascontiguousarray(direction, dtype=np.int32)
+        _ttm_lib().orc_ttm_laser_rescale(self._p, _ip(d), float(offset), float(mu), float(p_peak), float(t_0),
+                                         float(sigma_t_squared), float(time))
+
     def cell_activation(self): _ttm_lib().orc_ttm_cell_activation(self._p)
     def fillmesh(self, steps): _ttm_lib().orc_ttm_fillmesh(self._p, steps)
     def fill_ghosts(self): _ttm_lib().orc_ttm_fill_ghosts(self._p)
@@ -437,6 +443,12 @@ def read_ttm_probe(path):
     while off < len(buf) - 8:
         tag = buf[off:off + 16].split(b"\0")[0].decode(); off += 16
         mdt = float(np.frombuffer(buf, "<f8", 1, off)[0]); off += 8
+        if mdt == -2.0:               # parameter record (dump_laser_params): 10 doubles
+            v = np.frombuffer(buf, "<f8", 10, off).copy(); off += 80
+            stages[tag] = dict(max_dt_ttm=mdt, params=dict(dir=v[0:3].astype(int), offset=float(v[3]), mu=float(v[4]),
+                               p_peak=float(v[5]), t_0=float(v[6]), sigma_t_squared=float(v[7]), sigma_e=float(v[8]),
+                               sigma_t=float(v[9])))
+            continue
         if mdt == -1.0:               # int record: the 8 atom-flux counters per cell (dump_flux)
             fl = np.frombuffer(buf, "<i4", 8 * n, off).reshape(tuple(H["fd_dim"]) + (8,)).copy(); off += 32 * n
             stages[tag] = dict(max_dt_ttm=mdt, flux=fl)

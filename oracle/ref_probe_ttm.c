@@ -133,6 +133,20 @@ void __wrap_calc_ttm(void)
   }
 }
 #else
+#ifdef LASER
+/* the globals laser_rescale_ttm reads (after init_laser, imd_laser.c:283-360) */
+static void dump_laser_params(const char *tag)
+{
+  char t[16];
+  memset(t, 0, sizeof(t)); strncpy(t, tag, 15);
+  fwrite(t, 1, 16, tf);
+  wd(-2.0);                                  /* marks a parameter record: 10 doubles follow */
+  wd((double) laser_dir.x); wd((double) laser_dir.y); wd((double) laser_dir.z);
+  wd(laser_offset); wd(laser_mu); wd(laser_p_peak); wd(laser_t_0); wd(laser_sigma_t_squared);
+  wd(laser_sigma_e); wd(laser_sigma_t);
+}
+#endif
+
 void __wrap_calc_ttm(void)
 {
   int i, dumping = want(steps);
@@ -147,6 +161,14 @@ void __wrap_calc_ttm(void)
   update_fd();
   if (dumping) dump_lattice("update_fd");
   if (dumping && getenv("IMD_PROBE_FLUX")) dump_flux("flux");   /* update_fd's atom-flux counters (:335-370) */
+#ifdef LASER
+  if (getenv("IMD_PROBE_LASER")) {         /* Beer-Lambert source term (imd_laser.c:715-788; calc_ttm's second block calls it
+                                              before every do_DIFF, :192-197, with the same value within an MD step:
+                                              here once for the dump, then in the sub-step loop below) */
+    laser_rescale_ttm();
+    if (dumping) { dump_laser_params("laserpar"); dump_lattice("laser"); }
+  }
+#endif
   if (getenv("IMD_PROBE_ADV")) {           /* advection step of calc_ttm (imd_ttm_3D.c:58-60); returns at once for steps < 1 */
     if (dumping && !getenv("IMD_PROBE_FLUX")) dump_flux("flux");
     do_ADV(1.0);
@@ -157,6 +179,10 @@ void __wrap_calc_ttm(void)
   ttm_fill_ghost_layers();
   if (dumping) dump_lattice("fillmesh0");
   for (i = 0; i < diff_substeps; i++) {
+#ifdef LASER
+    if (getenv("IMD_PROBE_LASER")) laser_rescale_ttm();   /* before EVERY do_DIFF as in :192-197: it writes l1 only, and
+                                                              do_DIFF has just swapped the lattices */
+#endif
     do_DIFF(tau);
     if (dumping && i == 0) dump_lattice("diff_only1");
     do_FILLMESH();

@@ -497,6 +497,30 @@ void orc_ttm_adv(orc_ttm *t, double tau, int steps)
   t->cur ^= 1;                                                        /* l1 <-> l2, :1454-1456 */
 }
 
+/* laser_rescale_ttm, imd_laser.c:715-788 (with ttm_calc_depth, :699-710), the branch compiled without LASERYZ:
+ * source = exp(-mu * depth) * exp(-(t - t_0)^2 / sigma_t^2 / 2) * p_peak in every ACTIVE cell, depth = distance of the
+ * cell's low corner along laser_dir behind laser_offset, clamped at 0.  `time` = timestep * steps.  The lattice is not
+ * split here (my_coord = 0).  Inactive cells keep what update_fd left (0). */
+void orc_ttm_laser_rescale(orc_ttm *t, const int dir[3], double offset, double mu, double p_peak, double t_0,
+                           double sigma_t_squared, double time)
+{
+  int i, j, k;
+  double g = time - t_0, e;
+  g *= g;
+  e = exp(-g / sigma_t_squared / 2.0) * p_peak;
+  for (i = 1; i < t->dim[0] - 1; i++)
+    for (j = 1; j < t->dim[1] - 1; j++)
+      for (k = 1; k < t->dim[2] - 1; k++) {
+        size_t c = FIDX(t, i, j, k);
+        double depth;
+        if (t->natoms[c] < t->fd_min_atoms) continue;
+        depth = (t->h[0] * (i - 1)) * dir[0] + (t->h[1] * (j - 1)) * dir[1] + (t->h[2] * (k - 1)) * dir[2];
+        depth -= offset;
+        if (depth < 0) depth = 0;
+        t->source[c] = exp(-mu * depth) * e;
+      }
+}
+
 /* first block of calc_ttm (:50-77) without do_tmm; do_ADV only with t->adv -- the sequence the
  * product implements and the probe (oracle/ref_probe_ttm.c) drives */
 void orc_ttm_calc(orc_ttm *t, orc_sys *s, int steps, int diff_substeps)

@@ -38,6 +38,9 @@ double orc_get_gamma(double Te, double Ti, double Ne, double Z, double omega_las
 double orc_get_kappa(double Te, double Ti, double Ne, double Z, double omega_laser);
 void orc_ttm_update_fd(orc_ttm *t, orc_sys *s, int steps);
 void orc_ttm_adv(orc_ttm *t, double tau, int steps);
+/* laser_rescale_ttm (imd_laser.c:715-788), non-LASERYZ branch; the globals it reads are the arguments */
+void orc_ttm_laser_rescale(orc_ttm *t, const int dir[3], double offset, double mu, double p_peak, double t_0,
+                           double sigma_t_squared, double time);
 void orc_ttm_cell_activation(orc_ttm *t);
 void orc_ttm_fillmesh(orc_ttm *t, int steps);
 void orc_ttm_fill_ghosts(orc_ttm *t);

@@ -65,6 +65,14 @@ CASES = {
     "ttm_slab": dict(binary="imd_mpi_eam_ttm3d_nbl", box="8 6 6", temp=0.03, steps=2, dump=[0, 1, 2], full=[],
                      pot="eam", nbl=True, pbc="0 1 1", extra="shiftx_front 8.0\nshiftx_rear 8.0\n",
                      ttm=dict(fd_ext="1 1 1", n=100, min_atoms=12)),
+    # Beer-Lambert laser source (laser_rescale_ttm, imd_laser.c:715-788, -DLASER build) into the slab: pulse centred on
+    # step 3 (t_0 0.3, sigma_t 0.15 in IMD time units), absorption length 20 A; the source term then drives do_DIFF
+    "ttm_laser": dict(binary="imd_mpi_eam_ttm3d_laser_nbl", box="8 6 6", temp=0.03, steps=5, dump=[0, 2, 3, 5], full=[],
+                      pot="eam", nbl=True, pbc="0 1 1",
+                      extra="shiftx_front 8.0\nshiftx_rear 8.0\nlaser_dir 1 0 0\nlaser_mu 0.05\nlaser_sigma_e 40.0\n"
+                            "laser_rescale_mode 4\n",
+                      ttm=dict(fd_ext="1 1 1", n=100, min_atoms=12, laser_sigma_t="0.15", laser_t_0="0.3"),
+                      env=dict(IMD_PROBE_LASER="1"), keep_stages=("update_fd", "laser", "substep1", "substeps_done")),
     # two atom types on the Cu3Au (L1_2) lattice: 4-column pair / density tables with per-column ranges
     "eam2_l12_nbl": dict(binary="imd_eam_nve_nbl", box="8 8 8", temp=0.05, steps=20, dump=[0, 1, 20], full=[0],
                          pot="eam2types", nbl=True, coord="_l12",
@@ -132,8 +140,9 @@ def write_inputs(c, d):
     if "ttm" in c:
         par = par.replace("ensemble nve", "ensemble ttm")
         par += ("fd_ext %s\nfd_n_timesteps %d\nfd_min_atoms %d\natomic_weight 26.9815\natomic_charge 13\n"
-                "ttm_int 100000\nI0 1.0\nlambda 800e-9\nlaser_sigma_t 100e-15\nlaser_t_0 1.0\n"
-                % (c["ttm"]["fd_ext"], c["ttm"]["n"], c["ttm"]["min_atoms"]))
+                "ttm_int 100000\nI0 1.0\nlambda 800e-9\nlaser_sigma_t %s\nlaser_t_0 %s\n"
+                % (c["ttm"]["fd_ext"], c["ttm"]["n"], c["ttm"]["min_atoms"], c["ttm"].get("laser_sigma_t", "100e-15"),
+                   c["ttm"].get("laser_t_0", "1.0")))
         eos = write_planar_eos(d)
     open(os.path.join(d, "t.param"), "w").write(par)
     return par, eos
@@ -196,8 +205,12 @@ def run_case(name, c):
             if "flux" in st:
                 out["t%d_flux" % s] = st["flux"].astype(np.int16)
                 continue
-            if "env" in c and tag not in ("update_fd", "substeps_done"):
-                continue                                  # the flux fixture keeps two stages per step only
+            if "params" in st:
+                for k, v in st["params"].items():
+                    out["laser_" + k] = v
+                continue
+            if "env" in c and tag not in c.get("keep_stages", ("update_fd", "substeps_done")):
+                continue                                  # fixtures of the optional stages keep few stages per step
             out["t%d_%s_max_dt_ttm" % (s, tag)] = st["max_dt_ttm"]
             for f in po.TTM_REC.names:
                 if tag in ("entry", "substep2") and f not in ("temp", "xi", "natoms", "fd_k", "U", "temp2"):

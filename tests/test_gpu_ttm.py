@@ -225,3 +225,53 @@ def test_md_ttm_trajectory_with_advection_against_the_two_rank_reference():
                 assert np.abs(a - b).max() <= 2e-8 * np.abs(b).max(), (st, f)
     assert int(G["t41_flux"].sum()) > 0 and int(G["t48_flux"].sum()) > 0
     s.close()
+
+
+def _laser_kw(G):
+    return dict(direction=G["laser_dir"], offset=float(G["laser_offset"]), mu=float(G["laser_mu"]),
+                p_peak=float(G["laser_p_peak"]), t_0=float(G["laser_t_0"]), sigma_t_squared=float(G["laser_sigma_t_squared"]))
+
+
+def test_laser_source_and_diffusion_with_source_against_reference():
+    """laser_rescale_ttm (imd_laser.c:715-788, -DLASER build of the reference) and the sub-steps with a non-zero source
+    term: from the reference's lattice after update_fd, imdgpu_ttm_laser_rescale gives the reference's source (1e-15:
+    device exp vs glibc); then activation, FILLMESH and the 100 fused sub-steps land on the reference's lattice (TOL).
+    Steps 0..5 straddle the pulse; Te rises from 0.03 to 3 eV."""
+    G = gu.load("ttm_laser")
+    s = _gpu(G)
+    inner = (slice(1, -1),) * 3
+    nsub = int(G["ttm_diff_substeps"])
+    for st in (2, 3, 5):
+        pre = "t%d_update_fd_" % st
+        s.ttm_upload(**{f: G[pre + f] for f in ("natoms", "natoms_old", "temp", "temp2", "U", "U2", "dens", "md_temp", "xi",
+                                                 "source", "fd_k", "fd_g", "Ce", "Z", "ne")})
+        s.laser_rescale_ttm(st, **_laser_kw(G))
+        d = s.ttm_download(fields=("source",))
+        ref = G["t%d_laser_source" % st]
+        assert np.abs(d["source"][inner] - ref[inner]).max() <= 1e-15 * ref.max(), st
+        assert np.array_equal(d["source"][inner] > 0, ref[inner] > 0)
+        s.do_cell_activation(); s.do_FILLMESH(st); s.ttm_fill_ghost_layers()
+        for _ in range(nsub):
+            s.do_DIFF(float(G["ttm_tau"])); s.do_FILLMESH(st); s.ttm_fill_ghost_layers()
+        _cmp(s.ttm_download(), gu.ttm_stage(G, st, "substeps_done"), "laser substeps_done %d" % st,
+             fields=("temp", "U", "xi", "fd_k", "fd_g", "Ce"))
+    s.close()
+
+
+def test_md_ttm_with_laser_trajectory_against_reference():
+    """The device-resident loop with imdgpu_ttm_set_laser (source applied after update_fd in every step, fused
+    sub-step graph reading it) for six steps from the reference's step-0 arrangement: lattice after the sub-steps of
+    steps 2, 3 and 5 against the reference run with the laser (1e-9; the electrons heat the slab by two orders of
+    magnitude, so every coupling term of FILLMESH/DIFF/xi is exercised far from the equilibrium fixtures)."""
+    G = gu.load("ttm_laser")
+    s = _gpu(G)
+    s.set_laser(**_laser_kw(G))
+    inner = (slice(1, -1),) * 3
+    for st in range(6):
+        s.md_step(st)
+        if st in (2, 3, 5):
+            d = s.ttm_download()
+            for f in ("temp", "U", "xi", "md_temp", "source"):
+                a, b = d[f][inner], G["t%d_substeps_done_%s" % (st, f)][inner]
+                assert np.abs(a - b).max() <= 1e-9 * np.abs(b).max(), (st, f)
+    s.close()

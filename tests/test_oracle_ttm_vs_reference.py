@@ -207,3 +207,38 @@ def test_md_ttm_trajectory_with_advection_against_the_two_rank_reference():
         t.move_atoms_ttm()
         s.check_nblist()
     t.close()
+
+
+def _laser(G):
+    return (G["laser_dir"], float(G["laser_offset"]), float(G["laser_mu"]), float(G["laser_p_peak"]), float(G["laser_t_0"]),
+            float(G["laser_sigma_t_squared"]))
+
+
+def test_laser_source_and_diffusion_with_source_against_reference():
+    """laser_rescale_ttm (Beer-Lambert source, imd_laser.c:715-788; -DLASER build of the reference) and do_DIFF with a
+    non-zero source term (imd_ttm_3D.c:1718): slab fixture, pulse centred on step 3.
+    (1) from the reference's lattice after update_fd the source of every cell equals the reference's bit for bit;
+    (2) from the lattice with the source in, activation + FILLMESH + 100 sub-steps land on the reference's lattice
+        (1e-11; temperatures rise from 0.03 to 3 eV within the pulse)."""
+    G = gu.load("ttm_laser")
+    s = gu.oracle_from_golden(G, 0)
+    t = gu.oracle_ttm_from_golden(G, s)
+    nsub = int(G["ttm_diff_substeps"])
+    inner = (slice(1, -1),) * 3
+    dt = float(G["timestep"])
+    for st in (0, 2, 3, 5):
+        _load_lattice(t, G, "t%d_update_fd_" % st, 0)
+        t.laser_rescale(*_laser(G), time=dt * st)
+        assert np.array_equal(t.source[inner], G["t%d_laser_source" % st][inner]), st
+        t.cell_activation(); t.fillmesh(st); t.fill_ghosts()
+        for q in range(nsub):
+            t.diff(float(G["ttm_tau"]), nsub); t.fillmesh(st); t.fill_ghosts()
+            if q == 0:
+                for f in ("temp", "U", "xi"):
+                    a, b = getattr(t, f)[inner], G["t%d_substep1_%s" % (st, f)][inner]
+                    assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max(), (st, f)
+        for f in ("temp", "U", "xi", "fd_k", "fd_g", "Ce", "Z"):
+            a, b = getattr(t, f)[inner], G["t%d_substeps_done_%s" % (st, f)][inner]
+            assert np.abs(a - b).max() <= 1e-11 * np.abs(b).max(), (st, f)
+    assert G["t3_laser_source"].max() > 5.0 and G["t5_substeps_done_temp"].max() > 3.0
+    t.close()
