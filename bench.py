@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--fd-ext", type=int, nargs=3, default=[2, 2, 2],
                     help="MD cells per FD cell (BASELINE config 3: 2 2 2); 1 1 1 gives the 8x lattice an 8-GPU run replicates")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--laser", action="store_true",
+                    help="config 5, Beer-Lambert variant: laser_rescale_ttm source (imd_laser.c:715) applied in every step")
     ap.add_argument("--cpu-box", type=int, default=48, help="unit cells per direction of the CPU sample")
     ap.add_argument("--cpu-steps", type=int, default=30)
     ap.add_argument("--cpu-steps-mpi", type=int, default=120, help="steps of the multi-core (MPI + TTM) reference sample")
@@ -81,6 +83,10 @@ def build_system(args, rank, world, device):
     if ttm:
         from imd_amd import ttm as ttm_mod
         ttm_mod.attach_default(sysm, fd_ext=fd_ext, diff_substeps=100, fd_min_atoms=5)
+        if args.laser:          # a gentle pulse along x peaking at step 150: mu = 1/(20 A), 0.4 eV/A^2 fluence, sigma_t = 5 time units
+            sig_t, mu, sig_e = 5.0, 0.05, 0.4
+            sysm.set_laser(direction=(1, 0, 0), offset=0.0, mu=mu, p_peak=mu * sig_e / sig_t / np.sqrt(2 * np.pi),
+                           t_0=15.0, sigma_t_squared=sig_t * sig_t)
     pos = lattice.fcc_positions(args.box, a) + np.array([coord[d] * args.box[d] * a for d in range(3)])
     mom = lattice.maxwell_momenta(len(pos), 26.9815, args.temp, seed=12345 + rank)
     ident = np.arange(len(pos), dtype=np.int64) + rank * len(pos)
@@ -304,7 +310,8 @@ def main():
             "config": {"workload": "FCC Al %dx%dx%d unit cells per GPU (%d atoms/GPU), synthetic tabulated EAM "
                                    "(r_c 6.5 A), nbl_margin 0.5, dt 0.1, T0 %.4f eV, %s" %
                                    (args.box[0], args.box[1], args.box[2], natoms, args.temp,
-                                    "NVE, no TTM" if args.no_ttm else "3D TTM fd_ext %d %d %d, diff_substeps 100" % tuple(args.fd_ext)),
+                                    "NVE, no TTM" if args.no_ttm else ("3D TTM fd_ext %d %d %d, diff_substeps 100" % tuple(args.fd_ext)) +
+                                    (", Beer-Lambert laser source (laser_rescale_ttm)" if args.laser else "")),
                        "atoms_per_gpu": natoms, "cells": list(gdim), "half_list_entries_per_atom": M,
                        "max_neighbours": maxn, "list_rebuilds_in_timed_region": rebuilds,
                        "kernel_family": "lds_tiles" if sysm.get_info("list_mode") == 1 else "global_gather",
