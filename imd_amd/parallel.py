@@ -543,7 +543,8 @@ class GpuOps:
         self.s.set_stream(self.side.cuda_stream)
 
     def ttm_mark_gathered(self):
-        self._ev_gathered = torch.cuda.Event()
+        if not hasattr(self, "_ev_gathered"):
+            self._ev_gathered = torch.cuda.Event()
         self._ev_gathered.record(self.side)
 
     def ttm_wait_gathered(self):
