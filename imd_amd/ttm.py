@@ -46,3 +46,41 @@ def attach_default(sysm, fd_ext=(2, 2, 2), diff_substeps=100, fd_min_atoms=5):
     """3D TTM as in BASELINE config 3: Al, fd_ext 2 2 2, fixed diff_substeps, no laser."""
     cve, ee = synthetic_eos()
     sysm.init_ttm(fd_ext, fd_min_atoms, diff_substeps, 26.9815, 13.0, cve, ee, omega_laser=0.0)
+
+
+# ---------------------------------------------------------------------------
+# laser set-up on the host (imd_laser.c): the parameters laser_rescale_ttm reads
+# ---------------------------------------------------------------------------
+
+def get_surface(x, box_xx):
+    """laser_offset as get_surface() finds it (imd_laser.c:117-282): histogram of the atoms' x in 2.5 A bins (strict
+    inequalities on both bin edges, :162), the sample's right end = outermost occupied bin, its surface = the bin after
+    the first two adjacent empty bins met when walking left from there, nudged inwards past bins with < 500 atoms;
+    returns (leftside + 0.5) * 2.5."""
+    deltax = 2.5
+    nd = int(box_xx / deltax)
+    x = np.asarray(x, dtype=np.float64)
+    dens = np.zeros(nd, dtype=np.int64)
+    for l in range(nd):
+        dens[l] = int(((x > l * deltax) & (x < (l + 1) * deltax)).sum())
+    rightside, leftside = nd, 0
+    for l in range(nd - 1, 0, -1):
+        if dens[l] == 0 and dens[l - 1] != 0:
+            rightside = l - 1
+            break
+    l = rightside
+    while l > 0:
+        if dens[l] == 0 and dens[l - 1] == 0:
+            break
+        l -= 1
+    leftside = l + 1
+    if dens[leftside] < 500:
+        leftside = l + 3 if dens[leftside + 1] < 500 else l + 2
+    return (leftside + 0.5) * deltax
+
+
+def init_laser(mu, sigma_e, sigma_t, t_0, direction=(1, 0, 0), offset=0.0):
+    """The globals after init_laser (imd_laser.c:283-327, no LASERYZ) as keyword arguments of
+    GpuSystem.set_laser / laser_rescale_ttm: p_peak = mu * sigma_e / sigma_t / sqrt(2 pi), sigma_t_squared."""
+    return dict(direction=tuple(int(v) for v in direction), offset=float(offset), mu=float(mu),
+                p_peak=mu * sigma_e / sigma_t / np.sqrt(2 * np.pi), t_0=float(t_0), sigma_t_squared=sigma_t * sigma_t)

@@ -53,3 +53,15 @@ def test_format1_pair_file_reads_back_like_the_reference():
     n = int(t["len"][0]) + 2                       # rows beyond len+2 are uninitialised heap in the reference
     assert np.array_equal(pt.table[:n], t["table"][:n])
     assert cellsz == float(t["end"][0])
+
+
+def test_laser_setup_like_init_laser():
+    """init_laser / get_surface (imd_laser.c:283-327, :117-282) from the inputs of the laser fixture: the derived
+    globals equal the ones the reference held (probe record `laserpar` of tests/golden/ttm_laser.npz)."""
+    from imd_amd import ttm as ttm_mod
+    G = gu.load("ttm_laser")
+    off = ttm_mod.get_surface(G["s0_ort"][:, 0], float(G["box"][0, 0]))
+    assert off == float(G["laser_offset"])
+    p = ttm_mod.init_laser(mu=0.05, sigma_e=40.0, sigma_t=0.15, t_0=0.3, direction=(1, 0, 0), offset=off)
+    assert p["p_peak"] == float(G["laser_p_peak"]) and p["sigma_t_squared"] == float(G["laser_sigma_t_squared"])
+    assert p["mu"] == float(G["laser_mu"]) and p["t_0"] == float(G["laser_t_0"]) and list(p["direction"]) == list(G["laser_dir"])
