@@ -35,6 +35,8 @@ struct TtmState {
   double h[3]{}, vol = 0, neighvol = 0, atomic_weight = 0, atomic_charge = 0, omega_laser = 0, Temin = 1e-3;
   double max_dt_ttm = 0;
   int have_source = 0;              // a source term was uploaded (imdgpu_ttm_upload with `source`) or a laser is set: the sub-steps read it
+  int laser_active = 0;             // laser_rescale_ttm's flag (source above 1e-3 of its peak): do_DIFF then books the absorbed energy
+  double *d_eabs = nullptr;         // Eabs_local [eV] (imd_ttm_3D.c:1647-1651), device resident
   int laser_on = 0; imdgpu_laser_params laser{};   // imdgpu_ttm_set_laser: imdgpu_calc_ttm applies laser_rescale_ttm every step
   int *natoms = nullptr, *natoms_old = nullptr;
   int *flux = nullptr;              // 8 planes: atoms that entered the FD cell since the last update_fd (option ttm_flux)
@@ -466,6 +468,27 @@ __global__ void k_ttm_laser(Lat L, int g0, int g1, int g2, int d0, int d1, int d
   source[c] = exp(-mu * depth) * e;
 }
 
+// do_DIFF's bookkeeping of the absorbed laser energy (imd_ttm_3D.c:1647-1651): Eabs_local += source * fd_vol * tau for
+// every inner cell in every sub-step.  The source does not change within an MD step, so `rep` sub-steps are booked at once.
+__global__ void k_ttm_eabs(Lat L, const double *source, double vol_tau_rep, double *eabs)
+{
+  __shared__ double sh[16];
+  const int ni = L.dim[0] - 2, nj = L.dim[1] - 2, nk = L.dim[2] - 2, n = ni * nj * nk;
+  double s = 0.0;
+  for (int t = threadIdx.x; t < n; t += blockDim.x) {
+    const int i = t / (nk * nj) + 1, j = (t / nk) % nj + 1, k = t % nk + 1;
+    s += source[fidx(L, i, j, k)];
+  }
+  s = wsum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int w = 0; w < (int) (blockDim.x >> 6); w++) tot += sh[w];
+    *eabs += tot * vol_tau_rep;
+  }
+}
+
 // do_FILLMESH per cell: MeanCharge (More's Thomas-Fermi fit, imd_ttm_3D.c:2399-2473), getKappa (:2549-2592),
 // getGamma (:2503-2528) and their helpers fermi_E, fermi_T, omega_pl, r0, coulomb_log, numet, numax, nupl
 // (:2352-2498), written as ONE function so that everything the reference recomputes per helper call is shared:
@@ -792,7 +815,7 @@ void imdgpu_ttm_free(imdgpu_ctx *ctx)
   TtmState *t = ctx->ttm;
   if (!t) return;
   void *ptrs[] = {t->natoms, t->natoms_old, t->temp[0], t->temp[1], t->U[0], t->U[1], t->fd_k[0], t->fd_k[1], t->xi,
-                  t->md_temp, t->source, t->vcom, t->dens, t->fd_g, t->Z, t->Ce, t->ne, t->cve_z, t->ee_z, t->d_red, t->flux};
+                  t->md_temp, t->source, t->vcom, t->dens, t->fd_g, t->Z, t->Ce, t->ne, t->cve_z, t->ee_z, t->d_red, t->flux, t->d_eabs};
   for (void *p : ptrs) if (p) (void) hipFree(p);
   for (int q = 0; q < 2; q++) if (t->graph[q]) (void) hipGraphExecDestroy(t->graph[q]);
   if (t->mb_host) (void) hipHostUnregister(t->mb_host);
@@ -838,7 +861,7 @@ extern "C" int imdgpu_ttm_init(imdgpu_ctx *ctx, const imdgpu_ttm_params *par)
       dev_alloc(ctx, &t->fd_k[0], n) || dev_alloc(ctx, &t->fd_k[1], n) || dev_alloc(ctx, &t->xi, n) ||
       dev_alloc(ctx, &t->md_temp, n) || dev_alloc(ctx, &t->source, n) || dev_alloc(ctx, &t->vcom, 3 * n) ||
       dev_alloc(ctx, &t->dens, n) || dev_alloc(ctx, &t->fd_g, n) || dev_alloc(ctx, &t->Z, n) ||
-      dev_alloc(ctx, &t->Ce, n) || dev_alloc(ctx, &t->ne, n) || dev_alloc(ctx, &t->d_red, 16) || dev_alloc(ctx, &t->flux, 8 * n))
+      dev_alloc(ctx, &t->Ce, n) || dev_alloc(ctx, &t->ne, n) || dev_alloc(ctx, &t->d_red, 16) || dev_alloc(ctx, &t->flux, 8 * n) || dev_alloc(ctx, &t->d_eabs, 1))
     return 1;
   int *ip[] = {t->natoms, t->natoms_old};
   for (int *p : ip) HIPCHK(hipMemset(p, 0, n * sizeof(int)));
@@ -847,6 +870,7 @@ extern "C" int imdgpu_ttm_init(imdgpu_ctx *ctx, const imdgpu_ttm_params *par)
   for (double *p : dp) HIPCHK(hipMemset(p, 0, n * sizeof(double)));
   HIPCHK(hipMemset(t->vcom, 0, 3 * n * sizeof(double)));
   HIPCHK(hipMemset(t->flux, 0, 8 * n * sizeof(int)));
+  HIPCHK(hipMemset(t->d_eabs, 0, sizeof(double)));
   if (ctx->ttm_flux && (t->dim[0] > 1024 || t->dim[1] > 1024 || t->dim[2] > 1024))
     return imdgpu_fail(ctx, "ttm_flux: the packed FD cell index holds 10 bits per direction");
   size_t nc = (size_t) par->cve_nx * par->cve_ny, ne = (size_t) par->ee_nx * par->ee_ny;
@@ -987,6 +1011,7 @@ extern "C" int imdgpu_ttm_laser_rescale(imdgpu_ctx *ctx, const imdgpu_laser_para
                      p->dir[0], p->dir[1], p->dir[2], p->offset, p->mu, e, t->natoms, t->source);
   HIPCHK(hipGetLastError());
   t->have_source = 1;
+  t->laser_active = !(e < p->p_peak * 0.001);          // imd_laser.c:744-747
   return 0;
 }
 
@@ -1051,9 +1076,27 @@ static int diff_grid(const TtmState *t)
   return ((t->dim[0] - 2 + DT_X - 1) / DT_X) * ((t->dim[1] - 2 + DT_Y - 1) / DT_Y) * ((t->dim[2] - 2 + DT_Z - 1) / DT_Z);
 }
 
+static int book_eabs(imdgpu_ctx *ctx, TtmState *t, const Lat &L, double tau, int rep)
+{
+  if (!t->laser_active) return 0;
+  hipLaunchKernelGGL(k_ttm_eabs, dim3(1), dim3(64), 0, ctx->stream, L, t->source, t->vol * tau * (double) rep, t->d_eabs);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// Eabs_local [eV]: absorbed laser energy booked by the diffusion sub-steps so far (synchronises)
+extern "C" int imdgpu_ttm_get_eabs(imdgpu_ctx *ctx, double *eabs_local)
+{
+  NEED_TTM();
+  HIPCHK(hipMemcpyAsync(eabs_local, t->d_eabs, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
 extern "C" int imdgpu_ttm_diff(imdgpu_ctx *ctx, double tau)
 {
   NEED_TTM();
+  if (book_eabs(ctx, t, L, tau, 1)) return 1;
   ProfScope ps(ctx, PROF_TTM_DIFF);
   hipLaunchKernelGGL((k_ttm_diff<false, false>), dim3(diff_grid(t)), dim3(DT_X * DT_Y * DT_Z), 0, ctx->stream, L, tau, t->nsub, 1,
                      t->natoms, t->temp[t->cur], t->temp[t->cur ^ 1], t->U[t->cur], t->U[t->cur ^ 1], t->fd_k[t->kcur],
@@ -1122,6 +1165,7 @@ extern "C" int imdgpu_ttm_lattice_step(imdgpu_ctx *ctx, int steps)
                        t->temp[t->cur], t->fd_k[t->kcur]);
   } else if (imdgpu_ttm_fill_ghost_layers(ctx)) return 1;
   imdgpu_tl_mark(ctx, "ttm_fillmesh");
+  if (book_eabs(ctx, t, L, tau, t->nsub)) return 1;          // one 64-thread workgroup, once per MD step
   {
     ProfScope ps(ctx, PROF_TTM_DIFF);
     // the sub-step loop never returns to the host: nsub even => the ping-pong state after the loop equals

@@ -302,6 +302,12 @@ class GpuSystem:
         """calc_ttm applies the laser source after update_fd in every step from now on (no arguments: off)"""
         self._ck(self.L.imdgpu_ttm_set_laser(self.h, C.byref(self._laser(**laser)) if laser else None))
 
+    def get_eabs(self):
+        """Eabs_local: absorbed laser energy [eV] booked by do_DIFF so far (imd_ttm_3D.c:1647-1651)"""
+        v = C.c_double()
+        self._ck(self.L.imdgpu_ttm_get_eabs(self.h, C.byref(v)))
+        return v.value
+
     def ttm_fill_ghost_layers(self):
         self._ck(self.L.imdgpu_ttm_fill_ghost_layers(self.h))
 

@@ -192,6 +192,9 @@ typedef struct {
 } imdgpu_laser_params;
 int imdgpu_ttm_laser_rescale(imdgpu_ctx *ctx, const imdgpu_laser_params *par, int steps);
 int imdgpu_ttm_set_laser(imdgpu_ctx *ctx, const imdgpu_laser_params *par);
+/* [Eabs_local, imd_ttm_3D.c:1647-1651] absorbed laser energy in eV booked by the diffusion sub-steps so far
+ * (while the source is above 1e-3 of its peak: laser_active, imd_laser.c:744-747) */
+int imdgpu_ttm_get_eabs(imdgpu_ctx *ctx, double *eabs_local);
 /* [do_cell_activation, :1468-1596] */
 int imdgpu_ttm_cell_activation(imdgpu_ctx *ctx);
 /* [do_FILLMESH, :492-661] */

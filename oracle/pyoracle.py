@@ -323,7 +323,7 @@ class _Ttm(C.Structure):
                 ("xi", C.POINTER(C.c_double)), ("md_temp", C.POINTER(C.c_double)), ("source", C.POINTER(C.c_double)),
                 ("vcom", C.POINTER(C.c_double)), ("dens", C.POINTER(C.c_double)), ("fd_k", C.POINTER(C.c_double)),
                 ("fd_g", C.POINTER(C.c_double)), ("Z", C.POINTER(C.c_double)), ("Ce", C.POINTER(C.c_double)),
-                ("ne", C.POINTER(C.c_double)), ("cve", _Eos), ("ee", _Eos), ("flux", C.POINTER(C.c_int)), ("adv", C.c_int)]
+                ("ne", C.POINTER(C.c_double)), ("cve", _Eos), ("ee", _Eos), ("flux", C.POINTER(C.c_int)), ("adv", C.c_int), ("laser_active", C.c_int), ("eabs", C.c_double)]
 
 
 _TTM_READY = False
@@ -443,6 +443,10 @@ def read_ttm_probe(path):
     while off < len(buf) - 8:
         tag = buf[off:off + 16].split(b"\0")[0].decode(); off += 16
         mdt = float(np.frombuffer(buf, "<f8", 1, off)[0]); off += 8
+        if mdt == -3.0:               # absorbed energy so far and laser_active
+            v = np.frombuffer(buf, "<f8", 2, off).copy(); off += 16
+            stages[tag] = dict(max_dt_ttm=mdt, eabs=float(v[0]), laser_active=int(v[1]))
+            continue
         if mdt == -2.0:               # parameter record (dump_laser_params): 10 doubles
             v = np.frombuffer(buf, "<f8", 10, off).copy(); off += 80
             stages[tag] = dict(max_dt_ttm=mdt, params=dict(dir=v[0:3].astype(int), offset=float(v[3]), mu=float(v[4]),

@@ -190,6 +190,15 @@ void __wrap_calc_ttm(void)
     if (dumping && (i == 0 || i == 1)) dump_lattice(i == 0 ? "substep1" : "substep2");
   }
   if (dumping) dump_lattice("substeps_done");
+#ifdef LASER
+  if (dumping && getenv("IMD_PROBE_LASER")) {              /* do_DIFF's bookkeeping of the absorbed energy, :1647-1651 */
+    char t[16];
+    memset(t, 0, sizeof(t)); strncpy(t, "eabs", 15);
+    fwrite(t, 1, 16, tf);
+    wd(-3.0);                                              /* marks a 2-double record */
+    wd(Eabs_local); wd((double) laser_active);
+  }
+#endif
   CFL_maxdt();
   if (dumping) {
     dump_lattice("cfl");

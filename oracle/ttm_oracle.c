@@ -409,6 +409,7 @@ void orc_ttm_diff(orc_ttm *t, double tau, int diff_substeps)
       for (k = 1; k < t->dim[2] - 1; k++) {
         size_t c = FIDX(t, i, j, k), xa, xb, ya, yb, za, zb;
         double Te, kk, Ce;
+        if (t->laser_active) t->eabs += t->source[c] * t->vol * tau;        /* every inner cell, :1647-1651 */
         if (t->natoms[c] < m) continue;
         xb = t->natoms[FIDX(t, i - 1, j, k)] < m ? c : FIDX(t, i - 1, j, k);
         xa = t->natoms[FIDX(t, i + 1, j, k)] < m ? c : FIDX(t, i + 1, j, k);
@@ -508,6 +509,7 @@ void orc_ttm_laser_rescale(orc_ttm *t, const int dir[3], double offset, double m
   double g = time - t_0, e;
   g *= g;
   e = exp(-g / sigma_t_squared / 2.0) * p_peak;
+  t->laser_active = !(e < p_peak * 0.001);                                   /* :744-747 */
   for (i = 1; i < t->dim[0] - 1; i++)
     for (j = 1; j < t->dim[1] - 1; j++)
       for (k = 1; k < t->dim[2] - 1; k++) {

@@ -22,6 +22,8 @@ typedef struct {
   orc_eos cve, ee;
   int *flux;                 /* [8*ncell]: atoms that entered the FD cell since the last update_fd, by direction (:335-370) */
   int adv;                   /* 1: orc_ttm_calc runs do_ADV after update_fd as calc_ttm does (:57-60) */
+  int laser_active;          /* set by orc_ttm_laser_rescale like the global of that name (imd_laser.c:744-747) */
+  double eabs;               /* Eabs_local: absorbed laser energy [eV] accumulated by do_DIFF (:1647-1651) */
 } orc_ttm;
 
 orc_ttm *orc_ttm_new(const int md_dim[3], const int fd_ext[3], const double fd_h[3], const int pbc[3],

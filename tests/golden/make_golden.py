@@ -205,6 +205,9 @@ def run_case(name, c):
             if "flux" in st:
                 out["t%d_flux" % s] = st["flux"].astype(np.int16)
                 continue
+            if "eabs" in st:
+                out["t%d_eabs" % s] = st["eabs"]; out["t%d_laser_active" % s] = st["laser_active"]
+                continue
             if "params" in st:
                 for k, v in st["params"].items():
                     out["laser_" + k] = v

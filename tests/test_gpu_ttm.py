@@ -274,4 +274,6 @@ def test_md_ttm_with_laser_trajectory_against_reference():
             for f in ("temp", "U", "xi", "md_temp", "source"):
                 a, b = d[f][inner], G["t%d_substeps_done_%s" % (st, f)][inner]
                 assert np.abs(a - b).max() <= 1e-9 * np.abs(b).max(), (st, f)
+            # do_DIFF's running total of the absorbed energy (Eabs_local, imd_ttm_3D.c:1647-1651)
+            assert abs(s.get_eabs() - float(G["t%d_eabs" % st])) <= 1e-12 * float(G["t%d_eabs" % st]), st
     s.close()

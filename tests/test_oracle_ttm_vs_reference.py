@@ -242,3 +242,32 @@ def test_laser_source_and_diffusion_with_source_against_reference():
             assert np.abs(a - b).max() <= 1e-11 * np.abs(b).max(), (st, f)
     assert G["t3_laser_source"].max() > 5.0 and G["t5_substeps_done_temp"].max() > 3.0
     t.close()
+
+
+def test_md_ttm_trajectory_with_laser_against_reference():
+    """MD + TTM with the Beer-Lambert source for six steps from the reference's step-0 arrangement (calc_ttm sequence
+    with laser_rescale_ttm after update_fd): lattice after the sub-steps of steps 2, 3, 5 within 1e-9, and do_DIFF's
+    running total of the absorbed energy Eabs_local (imd_ttm_3D.c:1647-1651) within 1e-12."""
+    G = gu.load("ttm_laser")
+    s = gu.oracle_from_golden(G, 0)
+    s.s.count_ttm_neigh = 1
+    t = gu.oracle_ttm_from_golden(G, s)
+    nsub = int(G["ttm_diff_substeps"])
+    inner = (slice(1, -1),) * 3
+    dt = float(G["timestep"])
+    for st in range(6):
+        s.calc_forces(st)
+        t.update_fd(st)
+        t.laser_rescale(*_laser(G), time=dt * st)
+        t.cell_activation(); t.fillmesh(st); t.fill_ghosts()
+        for _ in range(nsub):
+            t.diff(float(G["ttm_tau"]), nsub); t.fillmesh(st); t.fill_ghosts()
+        if st in (0, 2, 3, 5):
+            assert t.t.laser_active == int(G["t%d_laser_active" % st])
+            assert abs(t.t.eabs - float(G["t%d_eabs" % st])) <= 1e-12 * float(G["t%d_eabs" % st]), st
+            for f in ("temp", "U", "xi", "md_temp"):
+                a, b = getattr(t, f)[inner], G["t%d_substeps_done_%s" % (st, f)][inner]
+                assert np.abs(a - b).max() <= 1e-9 * np.abs(b).max(), (st, f)
+        t.move_atoms_ttm()
+        s.check_nblist()
+    t.close()
