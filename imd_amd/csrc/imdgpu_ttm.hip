@@ -36,6 +36,7 @@ struct TtmState {
   double max_dt_ttm = 0;
   int have_source = 0;              // a source term was uploaded (imdgpu_ttm_upload with `source`) or a laser is set: the sub-steps read it
   int laser_active = 0;             // laser_rescale_ttm's flag (source above 1e-3 of its peak): do_DIFF then books the absorbed energy
+  int *d_cand = nullptr;            // do_cell_activation: [ninner] candidates, [ninner] sorted, [1] count
   double *d_eabs = nullptr;         // Eabs_local [eV] (imd_ttm_3D.c:1647-1651), device resident
   int laser_on = 0; imdgpu_laser_params laser{};   // imdgpu_ttm_set_laser: imdgpu_calc_ttm applies laser_rescale_ttm every step
   int *natoms = nullptr, *natoms_old = nullptr;
@@ -568,9 +569,13 @@ __global__ void k_ttm_fillmesh(Lat L, int steps, EosDev cve, EosDev ee, const in
   } else { fd_k[c] = 0.0; fd_g[c] = 0.0; Z[c] = 0.0; ne[c] = 0.0; Ce[c] = 0.0; }
 }
 
-// do_cell_activation, fallback scheme (imd_ttm_3D.c:1468-1596)
-__global__ void k_ttm_activation(Lat L, EosDev ee, const int *natoms, const int *natoms_old, double *T1, double *T2,
-                                 double *U1, double *U2, double *xi, const double *md_temp, const double *dens)
+// do_cell_activation (imd_ttm_3D.c:1468-1596).  The reference walks the cells in order (i outer, k inner) and writes
+// a freshly activated cell's fallback temperature IN PLACE, so a cell activated in the same step as a neighbour that
+// comes earlier in that order sees the neighbour's NEW temperature.  Two kernels keep that: the first, parallel, does
+// what is order independent (xi = 0 of deactivated cells) and collects the cells that need the fallback (rare:
+// usually none); the second, one wave, puts them into the reference's order and processes them one after the other.
+__global__ void k_ttm_activation(Lat L, const int *natoms, const int *natoms_old, const double *T1, double *xi,
+                                 int *cand, int *ncand)
 {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int ni = L.dim[0] - 2, nj = L.dim[1] - 2, nk = L.dim[2] - 2;
@@ -578,20 +583,46 @@ __global__ void k_ttm_activation(Lat L, EosDev ee, const int *natoms, const int 
   const int i = t / (nk * nj) + 1, j = (t / nk) % nj + 1, k = t % nk + 1, c = fidx(L, i, j, k), m = L.fd_min_atoms;
   if (natoms_old[c] >= m && natoms[c] < m) xi[c] = 0.0;
   else if (natoms_old[c] < m && natoms[c] >= m) {
-    double tc = T1[c];
-    if (isnan(tc) || tc <= L.Temin) {
-      int nb[6] = {fidx(L, i + 1, j, k), fidx(L, i - 1, j, k), fidx(L, i, j + 1, k), fidx(L, i, j - 1, k),
-                   fidx(L, i, j, k + 1), fidx(L, i, j, k - 1)};
-      int nn = 0; double E = 0;
-      for (int q = 0; q < 6; q++) if (natoms[nb[q]] >= m) { E += T1[nb[q]] * T1[nb[q]]; nn++; }
-      if (nn != 0) { tc = sqrt(E / ((double) nn)); if (tc < L.Temin) tc = md_temp[c]; }
-      else tc = md_temp[c];
-      // NOTE: the reference updates cells in place while neighbours may still be read; activation of two
-      // adjacent cells in the same step is order dependent there.  Here neighbours are read as they were.
-      T1[c] = tc; T2[c] = tc;
-      double u = eos_ee(ee, dens[c], tc * 11604.5) * 26.9815 * C_AMU * C_J2EV;
-      U1[c] = u; U2[c] = u;
-    }
+    const double tc = T1[c];
+    if (isnan(tc) || tc <= L.Temin) cand[atomicAdd(ncand, 1)] = t;       // t = position in the reference's loop order
+  }
+}
+
+__device__ void d_activate_cell(const Lat &L, const EosDev &ee, int t, const int *natoms, double *T1, double *T2,
+                                double *U1, double *U2, const double *md_temp, const double *dens)
+{
+  const int nj = L.dim[1] - 2, nk = L.dim[2] - 2;
+  const int i = t / (nk * nj) + 1, j = (t / nk) % nj + 1, k = t % nk + 1, c = fidx(L, i, j, k), m = L.fd_min_atoms;
+  const int nb[6] = {fidx(L, i + 1, j, k), fidx(L, i - 1, j, k), fidx(L, i, j + 1, k), fidx(L, i, j - 1, k),
+                     fidx(L, i, j, k + 1), fidx(L, i, j, k - 1)};
+  int nn = 0; double E = 0, tc;
+  for (int q = 0; q < 6; q++) if (natoms[nb[q]] >= m) { E += T1[nb[q]] * T1[nb[q]]; nn++; }
+  if (nn != 0) { tc = sqrt(E / ((double) nn)); if (tc < L.Temin) tc = md_temp[c]; }
+  else tc = md_temp[c];
+  T1[c] = tc; T2[c] = tc;
+  const double u = eos_ee(ee, dens[c], tc * 11604.5) * 26.9815 * C_AMU * C_J2EV;
+  U1[c] = u; U2[c] = u;
+}
+
+// one wave (a multi-wave workgroup would not be placed beside the persistent force kernels)
+__global__ __launch_bounds__(64) void k_ttm_activation_seq(Lat L, EosDev ee, const int *natoms, double *T1, double *T2,
+                                                           double *U1, double *U2, const double *md_temp,
+                                                           const double *dens, int *cand, int *sorted, int *ncand)
+{
+  const int n = *ncand, lane = threadIdx.x;
+  if (n == 0) return;
+  // rank sort (the positions are distinct): O(n^2 / 64), n is a handful of cells in practice
+  for (int a = lane; a < n; a += 64) {
+    const int v = cand[a];
+    int r = 0;
+    for (int b = 0; b < n; b++) r += cand[b] < v ? 1 : 0;
+    sorted[r] = v;
+  }
+  __threadfence_block();
+  __syncthreads();
+  if (lane == 0) {
+    for (int q = 0; q < n; q++) d_activate_cell(L, ee, sorted[q], natoms, T1, T2, U1, U2, md_temp, dens);
+    *ncand = 0;
   }
 }
 
@@ -815,7 +846,7 @@ void imdgpu_ttm_free(imdgpu_ctx *ctx)
   TtmState *t = ctx->ttm;
   if (!t) return;
   void *ptrs[] = {t->natoms, t->natoms_old, t->temp[0], t->temp[1], t->U[0], t->U[1], t->fd_k[0], t->fd_k[1], t->xi,
-                  t->md_temp, t->source, t->vcom, t->dens, t->fd_g, t->Z, t->Ce, t->ne, t->cve_z, t->ee_z, t->d_red, t->flux, t->d_eabs};
+                  t->md_temp, t->source, t->vcom, t->dens, t->fd_g, t->Z, t->Ce, t->ne, t->cve_z, t->ee_z, t->d_red, t->flux, t->d_eabs, t->d_cand};
   for (void *p : ptrs) if (p) (void) hipFree(p);
   for (int q = 0; q < 2; q++) if (t->graph[q]) (void) hipGraphExecDestroy(t->graph[q]);
   if (t->mb_host) (void) hipHostUnregister(t->mb_host);
@@ -861,7 +892,8 @@ extern "C" int imdgpu_ttm_init(imdgpu_ctx *ctx, const imdgpu_ttm_params *par)
       dev_alloc(ctx, &t->fd_k[0], n) || dev_alloc(ctx, &t->fd_k[1], n) || dev_alloc(ctx, &t->xi, n) ||
       dev_alloc(ctx, &t->md_temp, n) || dev_alloc(ctx, &t->source, n) || dev_alloc(ctx, &t->vcom, 3 * n) ||
       dev_alloc(ctx, &t->dens, n) || dev_alloc(ctx, &t->fd_g, n) || dev_alloc(ctx, &t->Z, n) ||
-      dev_alloc(ctx, &t->Ce, n) || dev_alloc(ctx, &t->ne, n) || dev_alloc(ctx, &t->d_red, 16) || dev_alloc(ctx, &t->flux, 8 * n) || dev_alloc(ctx, &t->d_eabs, 1))
+      dev_alloc(ctx, &t->Ce, n) || dev_alloc(ctx, &t->ne, n) || dev_alloc(ctx, &t->d_red, 16) || dev_alloc(ctx, &t->flux, 8 * n) || dev_alloc(ctx, &t->d_eabs, 1) ||
+      dev_alloc(ctx, &t->d_cand, 2 * (size_t) t->ninner + 1))
     return 1;
   int *ip[] = {t->natoms, t->natoms_old};
   for (int *p : ip) HIPCHK(hipMemset(p, 0, n * sizeof(int)));
@@ -871,6 +903,7 @@ extern "C" int imdgpu_ttm_init(imdgpu_ctx *ctx, const imdgpu_ttm_params *par)
   HIPCHK(hipMemset(t->vcom, 0, 3 * n * sizeof(double)));
   HIPCHK(hipMemset(t->flux, 0, 8 * n * sizeof(int)));
   HIPCHK(hipMemset(t->d_eabs, 0, sizeof(double)));
+  HIPCHK(hipMemset(t->d_cand, 0, (2 * (size_t) t->ninner + 1) * sizeof(int)));
   if (ctx->ttm_flux && (t->dim[0] > 1024 || t->dim[1] > 1024 || t->dim[2] > 1024))
     return imdgpu_fail(ctx, "ttm_flux: the packed FD cell index holds 10 bits per direction");
   size_t nc = (size_t) par->cve_nx * par->cve_ny, ne = (size_t) par->ee_nx * par->ee_ny;
@@ -1043,9 +1076,11 @@ extern "C" int imdgpu_ttm_adv(imdgpu_ctx *ctx, double tau, int steps)
 extern "C" int imdgpu_ttm_cell_activation(imdgpu_ctx *ctx)
 {
   NEED_TTM();
-  hipLaunchKernelGGL(k_ttm_activation, dim3(nblk(t->ninner, TTM_WG)), dim3(TTM_WG), 0, ctx->stream, L, t->ee, t->natoms,
-                     t->natoms_old, t->temp[t->cur], t->temp[t->cur ^ 1], t->U[t->cur], t->U[t->cur ^ 1], t->xi,
-                     t->md_temp, t->dens);
+  hipLaunchKernelGGL(k_ttm_activation, dim3(nblk(t->ninner, TTM_WG)), dim3(TTM_WG), 0, ctx->stream, L, t->natoms,
+                     t->natoms_old, t->temp[t->cur], t->xi, t->d_cand, t->d_cand + 2 * (size_t) t->ninner);
+  hipLaunchKernelGGL(k_ttm_activation_seq, dim3(1), dim3(64), 0, ctx->stream, L, t->ee, t->natoms, t->temp[t->cur],
+                     t->temp[t->cur ^ 1], t->U[t->cur], t->U[t->cur ^ 1], t->md_temp, t->dens, t->d_cand,
+                     t->d_cand + t->ninner, t->d_cand + 2 * (size_t) t->ninner);
   HIPCHK(hipGetLastError());
   return 0;
 }

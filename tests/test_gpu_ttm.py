@@ -277,3 +277,46 @@ def test_md_ttm_with_laser_trajectory_against_reference():
             # do_DIFF's running total of the absorbed energy (Eabs_local, imd_ttm_3D.c:1647-1651)
             assert abs(s.get_eabs() - float(G["t%d_eabs" % st])) <= 1e-12 * float(G["t%d_eabs" % st]), st
     s.close()
+
+
+def test_adjacent_cells_activated_in_the_same_step_follow_the_reference_order():
+    """do_cell_activation (imd_ttm_3D.c:1468-1596) writes the fallback temperature of a freshly activated cell in place
+    while it walks the lattice (i outer, k inner): a neighbour activated in the same step sees the new value if it
+    comes later in that order.  Slab lattice of the fixture with a block of 2 x 2 x 2 adjacent cells (and one isolated
+    cell) marked as just activated with Te = 0: the device result equals the sequential oracle (1e-14), and differs
+    from what reading all neighbours 'as they were' would give."""
+    G = gu.load("ttm_slab")
+    s = _gpu(G)
+    so = gu.oracle_from_golden(G, 0)
+    o = gu.oracle_ttm_from_golden(G, so)
+    pre = "t1_update_fd_"
+    lat = {f: G[pre + f].copy() for f in ("natoms", "natoms_old", "temp", "temp2", "U", "U2", "dens", "md_temp", "xi")}
+    act = np.argwhere(lat["natoms"][1:-1, 1:-1, 1:-1] >= int(G["ttm_fd_min_atoms"])) + 1
+    i0, j0, k0 = act[len(act) // 2]
+    block = [(i0 + a, j0 + b, k0 + c) for a in (0, 1) for b in (0, 1) for c in (0, 1)]
+    block = [q for q in block if lat["natoms"][q] >= int(G["ttm_fd_min_atoms"])]
+    assert len(block) >= 4
+    lone = tuple(act[0])
+    rng = np.random.default_rng(11)
+    lat["temp"] = lat["temp"] * (1.0 + 0.3 * rng.random(lat["temp"].shape))      # distinct neighbour temperatures
+    for q in block + [lone]:
+        lat["natoms_old"][q] = 0; lat["temp"][q] = 0.0; lat["temp2"][q] = 0.0
+    s.ttm_upload(**lat)
+    s.do_cell_activation()
+    d = s.ttm_download(fields=("temp", "temp2", "U", "U2", "xi"))
+    o.t.cur = 0
+    for f in ("natoms", "natoms_old", "xi", "md_temp", "dens"):
+        getattr(o, f)[...] = lat[f]
+    o._temp[0][...] = lat["temp"]; o._temp[1][...] = lat["temp2"]; o._U[0][...] = lat["U"]; o._U[1][...] = lat["U2"]
+    o.cell_activation()
+    for f, ref in (("temp", o.temp), ("temp2", o.temp2), ("U", o.U), ("U2", o.U2)):
+        assert np.abs(d[f] - ref).max() <= 1e-14 * np.abs(ref).max(), f
+    assert all(d["temp"][q] > 0 for q in block + [lone])
+    # order dependence is real in this set-up: the last cell of the block averaged over already updated neighbours
+    q = block[-1]
+    nb = [(q[0] + 1, q[1], q[2]), (q[0] - 1, q[1], q[2]), (q[0], q[1] + 1, q[2]), (q[0], q[1] - 1, q[2]),
+          (q[0], q[1], q[2] + 1), (q[0], q[1], q[2] - 1)]
+    m = int(G["ttm_fd_min_atoms"])
+    as_they_were = np.sqrt(np.mean([lat["temp"][n] ** 2 for n in nb if lat["natoms"][n] >= m]))
+    assert abs(d["temp"][q] - as_they_were) > 1e-3 * d["temp"][q]
+    s.close(); o.close()
