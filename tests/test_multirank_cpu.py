@@ -74,3 +74,89 @@ def test_distributed_trajectory_matches_reference(cpu_dim):
     assert abs(sums["tot_pot_energy"] - float(G["s20_tot_pot_energy"])) < 1e-9 * abs(float(G["s20_tot_pot_energy"]))
     assert sums["natoms"] == len(ids)
     assert all(r[6] >= 2 for r in res)          # at least one rebuild with migration took place
+
+
+class _FakeTtmOps:
+    """TTM stand-ins for the numpy device: every rank's update_fd block is a known function of the GLOBAL FD cell index,
+    so the host logic under test (block offsets per rank, rank order of the all-gather, fork/join bookkeeping) is right
+    exactly when the replicated lattice of every rank equals that function everywhere."""
+
+    def _ttm_setup(self):
+        self.calls = []
+        self.bdim = tuple(int(v) - 2 for v in self.dec.dim)                      # fd_ext 1 1 1
+        self.gfd = tuple(self.bdim[d] * self.dec.cpu_dim[d] for d in range(3))
+        self.lat = np.full(self.gfd + (6,), np.nan)
+
+    @staticmethod
+    def expected(gfd, step):
+        lin = np.arange(int(np.prod(gfd))).reshape(gfd)
+        return 1000.0 * step + lin[..., None] + 0.1 * np.arange(6)
+
+    def ttm_block_dims(self): return self.bdim
+    def ttm_fork(self): self.calls.append("fork")
+    def ttm_unfork(self): self.calls.append("unfork")
+    def ttm_join(self): self.calls.append("join")
+    def ttm_mark_gathered(self): self.calls.append("mark")
+    def ttm_wait_gathered(self): self.calls.append("wait")
+
+    def ttm_local_block(self, step):
+        import torch
+        o = [self.dec.coord[d] * self.bdim[d] for d in range(3)]
+        blk = self.expected(self.gfd, step)[o[0]:o[0] + self.bdim[0], o[1]:o[1] + self.bdim[1], o[2]:o[2] + self.bdim[2]]
+        return torch.from_numpy(np.ascontiguousarray(blk).reshape(-1))
+
+    def ttm_apply_blocks(self, step, allb, nblocks, offs):
+        a = allb.numpy().reshape((nblocks,) + self.bdim + (6,))
+        offs = offs.numpy().reshape(nblocks, 3)
+        for b in range(nblocks):
+            o = offs[b]
+            self.lat[o[0]:o[0] + self.bdim[0], o[1]:o[1] + self.bdim[1], o[2]:o[2] + self.bdim[2]] = a[b]
+
+    def ttm_lattice_step(self, step): self.calls.append("lattice_step")
+
+
+def _worker_ttm(rank, world, port, cpu_dim, q):
+    import torch.distributed as dist
+    from imd_amd.parallel import Decomposition, DistributedMD
+    from tests.numpy_ops import NumpyOps
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    G = gu.load("eam_nbl_2048")
+    dec = Decomposition(rank, cpu_dim, G["global_cell_dim"], G["box"], G["pbc_dirs"])
+    pos, mom, mass, ident = G["s0_ort"], G["s0_impuls"], G["s0_masse"], G["s0_nummer"]
+    t = np.linalg.inv(G["box"]).T
+    c = np.clip((np.array(dec.gdim) * (pos @ t.T)).astype(int), 0, np.array(dec.gdim) - 1)
+    mine = np.all(c // (np.array(dec.dim) - 2) == np.array(dec.coord), axis=1)
+    Ops = type("Ops", (_FakeTtmOps, NumpyOps), {})
+    ops = Ops(dec, gu.table(G, "pair_pot"), gu.table(G, "rho_h_tab"), gu.table(G, "embed_pot"), float(G["cellsz"]),
+              float(G["nbl_margin"]), float(G["timestep"]))
+    ops._ttm_setup()
+    ops.upload(pos[mine], mom[mine], mass[mine], ident[mine])
+    md = DistributedMD(dec, ops, ttm=True)
+    for st in range(3):
+        md.md_step(st)
+    q.put((rank, ops.lat.copy(), list(ops.calls), ops.gfd))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cpu_dim", [(2, 1, 1), (2, 2, 1)])
+def test_ttm_blocks_are_gathered_into_the_replicated_lattice(cpu_dim):
+    """The TTM part of the multi-rank step on CPUs (gloo): update_fd block of every rank -> all-gather -> fold into the
+    replicated lattice at the rank's FD-cell offset -> lattice step, on the side stream between pass 1 and the
+    integrator, the EAM force pass waiting for the gather."""
+    world = int(np.prod(cpu_dim))
+    for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ.setdefault(v, "2")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ttm, args=(r, world, port, cpu_dim, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, lat, calls, gfd in res:
+        assert np.array_equal(lat, _FakeTtmOps.expected(gfd, 2)), rank            # the lattice of the last step, complete
+        per_step = ["fork", "mark", "lattice_step", "unfork", "wait", "join"]
+        assert calls == per_step * 3, calls
