@@ -81,6 +81,11 @@ CASES = {
     "eam2_l12_coarse": dict(binary="imd_eam_nve_nbl", box="8 8 8", temp=0.05, steps=20, dump=[0, 20], full=[0],
                             pot="eam2types_coarse", nbl=True, coord="_l12",
                             types="ntypes 2\ntotal_types 2\nmasses 26.9815 63.546\ntypes 0 1"),
+    # two atom types WITH the TTM: update_fd's density counts only pairs of type 0 (imd_forces_nbl.c:473-476)
+    "ttm_2types": dict(binary="imd_mpi_eam_ttm3d_nbl", box="8 8 8", temp=0.04, steps=2, dump=[0, 1, 2], full=[],
+                       pot="eam2types_coarse", nbl=True, coord="_l12",
+                       types="ntypes 2\ntotal_types 2\nmasses 26.9815 63.546\ntypes 0 1",
+                       ttm=dict(fd_ext="1 1 1", n=100, min_atoms=5)),
     # atom-flux counters of update_fd (imd_ttm_3D.c:335-370): 19 x 8 x 6 unit cells put lattice planes 0.2 A from
     # cell boundaries, so atoms change FD cells at the list rebuilds of steps 17, 30 and 43; one FD cell thick in z
     "ttm_flux": dict(binary="imd_mpi_eam_ttm3d_nbl", box="19 8 6", temp=0.12, steps=44, dump=[0, 1, 17, 30, 43], full=[],

@@ -21,7 +21,7 @@ def _eos(G):
 
 def _gpu(G, step=0):
     pre = "s%d_" % step
-    s = GpuSystem(G["box"], G["pbc_dirs"], G["cell_dim"], 1, float(G["cellsz"]), float(G["nbl_margin"]),
+    s = GpuSystem(G["box"], G["pbc_dirs"], G["cell_dim"], int(G["ntypes"]), float(G["cellsz"]), float(G["nbl_margin"]),
                   float(G["timestep"]))
     s.upload_tables(gu.table(G, "pair_pot"), gu.table(G, "rho_h_tab"), gu.table(G, "embed_pot"))
     cell_n = np.zeros(int(np.prod(G["cell_dim"])), np.int32)
@@ -51,7 +51,7 @@ def _cmp(d, st, tag, fields=None):
             assert err < TOL, "%s: %s rel err %.3e" % (tag, f, err)
 
 
-@pytest.mark.parametrize("case", ["ttm_2048", "ttm_6912_ext2", "ttm_slab"])
+@pytest.mark.parametrize("case", ["ttm_2048", "ttm_6912_ext2", "ttm_slab", "ttm_2types"])
 def test_ttm_stages_vs_reference(case):
     """update_fd / do_FILLMESH / ghosts / do_DIFF / CFL_maxdt one by one at step 0."""
     G = gu.load(case)
@@ -78,7 +78,7 @@ def test_ttm_stages_vs_reference(case):
     s.close()
 
 
-@pytest.mark.parametrize("case", ["ttm_2048", "ttm_slab"])
+@pytest.mark.parametrize("case", ["ttm_2048", "ttm_slab", "ttm_2types"])
 def test_ttm_md_trajectory_vs_reference(case):
     """Full device-resident loop (forces -> calc_ttm [fused sub-steps, hipGraph] ->
     move_atoms_ttm) against the reference's lattice and atoms at later steps."""
