@@ -104,3 +104,40 @@ def test_host_integrator_hand_over_of_positions_and_momenta():
     assert np.array_equal(e["nummer"], d["nummer"])
     assert np.array_equal(e["ort"], new_x) and np.array_equal(e["impuls"], new_p)
     s.close()
+
+
+def test_tiny_and_empty_systems():
+    """The smallest inputs: no atoms is refused loudly (the reference has no defined behaviour there); one atom feels
+    nothing; two atoms feel equal and opposite forces that match the oracle; the device loop runs on them."""
+    from imd_amd.lib import ImdGpuError
+    pair, rho, emb, r2cut = potential.synthetic_eam_tables()
+    cellsz = (np.sqrt(r2cut) + 0.5) ** 2
+    box = lattice.fcc_box((8, 8, 8), 4.05)
+    dim = [g + 2 for g in global_cell_dim(box, cellsz)]
+    both = np.array([[1.0, 1.0, 1.0], [3.2, 1.4, 0.9]])
+    for n in (0, 1, 2):
+        s = GpuSystem(box, (1, 1, 1), dim, 1, cellsz, 0.5, 0.1)
+        s.upload_tables(pair, rho, emb)
+        if n == 0:
+            with pytest.raises(ImdGpuError):
+                s.upload_atoms(both[:0], np.zeros((0, 3)), 26.9815)
+                s.calc_forces(0)
+            s.close()
+            continue
+        s.upload_atoms(both[:n], np.zeros((n, 3)), 26.9815)
+        r = s.calc_forces(0)
+        d = s.download(fields=("kraft", "nummer"))
+        f = d["kraft"][np.argsort(d["nummer"])]
+        o = po.OracleSystem(dim, 16, 1, box, (1, 1, 1), cellsz, 0.5, 0.1)
+        for w, t in enumerate((pair, rho, emb)):
+            o.set_table(w, t.as_dict())
+        o.fill_from_positions(both[:n], np.zeros((n, 3)), 26.9815)
+        o.calc_forces(0)
+        fo = o.gather_inner("kraft")[np.argsort(o.gather_inner("nummer"))]
+        assert np.abs(f - fo).max() <= 1e-12 * max(np.abs(fo).max(), 1.0)
+        assert abs(r["tot_pot_energy"] - o.s.tot_pot_energy) <= 1e-12 * max(abs(o.s.tot_pot_energy), 1.0)
+        if n == 2:
+            assert np.abs(f[0] + f[1]).max() < 1e-14 and np.abs(f[0]).max() > 0.1
+        for st in range(3):
+            s.md_step(st)
+        s.close()
