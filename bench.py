@@ -99,6 +99,15 @@ def build_system(args, rank, world, device):
     return sysm, md, len(pos), gdim, cpu_dim
 
 
+def _cpu_env():
+    """environment of the CPU reference runs: no profiler preloads (under rocprofv3 every child would otherwise load the
+    tool library and touch the GPU), probe dumps off"""
+    env = {k: v for k, v in os.environ.items()
+           if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS", "ROCTRACER", "ROCTX"))}
+    env["IMD_PROBE_STEPS"] = "-1"
+    return env
+
+
 def _host_cores():
     try:
         return len(os.sched_getaffinity(0))
@@ -141,7 +150,7 @@ def cpu_baseline_mpi_ttm(args):
             "fd_ext %d %d %d\nfd_n_timesteps 100\nfd_min_atoms 5\natomic_weight 26.9815\natomic_charge 13\n"
             "ttm_int 100000\nI0 1.0\nlambda 800e-9\nlaser_sigma_t 100e-15\nlaser_t_0 1.0\n"
             % ((steps, nb, nb, nb, args.temp) + cpu_dim + tuple(args.fd_ext)))
-        env = dict(os.environ, IMD_PROBE_STEPS="-1")
+        env = _cpu_env()
         t0 = time.time()
         try:
             r = subprocess.run([mpiexec, "-n", str(nranks), exe, "-p", "b.param"], cwd=d, env=env, stdout=subprocess.PIPE,
@@ -191,7 +200,7 @@ def cpu_baseline_serial(args):
                 "core_potential_file phi.pt\nembedding_energy_file F.pt\natomic_e-density_file rho.pt\n"
                 "eng_int 100000\ncheckpt_int 100000\nnbl_margin 0.5\nnbl_size 1.5\ncpu_dim 1 1 1\n"
                 % (steps, nb, nb, nb, args.temp))
-            env = dict(os.environ, IMD_PROBE_STEPS="-1")
+            env = _cpu_env()
             t0 = time.time()
             r = subprocess.run([exe, "-p", "b.param"], cwd=d, env=env, stdout=subprocess.PIPE,
                                stderr=subprocess.STDOUT, text=True)
