@@ -31,6 +31,7 @@ struct TtmState {
   int dim[3]{}, ext[3]{}, md_dim[3]{}, pbc[3]{};
   int ncell = 0, ninner = 0;
   int off[3]{}, ldim[3]{};          // this rank's block of the (replicated, global) lattice: offset and inner extent
+  int goff[3]{};                    // GLOBAL FD index of this rank's first inner cell (= off, except on the decomposed lattice where off = 0)
   int fd_min_atoms = 0, nsub = 0, cur = 0, kcur = 0;
   double h[3]{}, vol = 0, neighvol = 0, atomic_weight = 0, atomic_charge = 0, omega_laser = 0, Temin = 1e-3;
   double max_dt_ttm = 0;
@@ -67,7 +68,7 @@ struct TtmState {
 #define C_PI 3.14159265358979323846
 
 struct Lat {                      // lattice geometry + parameters by value
-  int dim[3], ext[3], md_dim[3], pbc[3], off[3], ldim[3];
+  int dim[3], ext[3], md_dim[3], pbc[3], off[3], ldim[3], goff[3];
   int fd_min_atoms;
   double h[3], vol, neighvol, atomic_weight, atomic_charge, omega_laser, Temin;
   // uniform reciprocals, evaluated once on the host (an fp64 division is ~20 VALU instructions on the device)
@@ -261,7 +262,7 @@ __global__ void k_ttm_update_fd(Lat L, int steps, int cap, const int *cell_start
           sx += p[a]; sy += p[cap + a]; sz += p[2 * (size_t) cap + a];
           sm += mass[a];
           if (fdc) {
-            const int ig = i + L.off[0] - 1, jg = j + L.off[1] - 1, kg = k + L.off[2] - 1, old = fdc[a];
+            const int ig = i + L.goff[0] - 1, jg = j + L.goff[1] - 1, kg = k + L.goff[2] - 1, old = fdc[a];
             if (steps > 0 && old >= 0) {
               const int di = old & 1023, dj = (old >> 10) & 1023;
               if (di != ig || dj != jg) {
@@ -487,6 +488,29 @@ __global__ void k_ttm_eabs(Lat L, const double *source, double vol_tau_rep, doub
     double tot = 0.0;
     for (int w = 0; w < (int) (blockDim.x >> 6); w++) tot += sh[w];
     *eabs += tot * vol_tau_rep;
+  }
+}
+
+// do_COMMFLUX (imd_ttm_3D.c:667-995, the part compiled without ADV2D) for a lattice split over ranks: the columns
+// i = 1 and i = lx-2 of {flux[8], U} for every inner (j, k) go to the x neighbours' ghost columns
+// i = lx-1 / i = 0.  pack: side 0 = my column i = 1, side 1 = my column lx-2; 5 doubles per (j, k): the eight counters
+// as ints, then U.  unpack: side 0 = into my ghost column i = 0, side 1 = into i = lx-1.
+__global__ void k_ttm_commflux(Lat L, int side, int unpack, int *flux, int ncell, double *U, double *buf)
+{
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, nj = L.dim[1] - 2, nk = L.dim[2] - 2;
+  if (t >= nj * nk) return;
+  const int j = t / nk + 1, k = t % nk + 1;
+  const int i = unpack ? (side ? L.dim[0] - 1 : 0) : (side ? L.dim[0] - 2 : 1), c = fidx(L, i, j, k);
+  double *o = buf + (size_t) t * 5;
+  int *oi = (int *) o;
+  if (unpack) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) flux[(size_t) q * ncell + c] = oi[q];
+    U[c] = o[4];
+  } else {
+#pragma unroll
+    for (int q = 0; q < 8; q++) oi[q] = flux[(size_t) q * ncell + c];
+    o[4] = U[c];
   }
 }
 
@@ -829,7 +853,7 @@ static Lat make_lat(const TtmState *t)
 {
   Lat L;
   for (int d = 0; d < 3; d++) { L.dim[d] = t->dim[d]; L.ext[d] = t->ext[d]; L.md_dim[d] = t->md_dim[d]; L.pbc[d] = t->pbc[d]; L.h[d] = t->h[d];
-                                L.off[d] = t->off[d]; L.ldim[d] = t->ldim[d]; }
+                                L.off[d] = t->off[d]; L.ldim[d] = t->ldim[d]; L.goff[d] = t->goff[d]; }
   L.fd_min_atoms = t->fd_min_atoms; L.vol = t->vol; L.neighvol = t->neighvol; L.atomic_weight = t->atomic_weight;
   L.atomic_charge = t->atomic_charge; L.omega_laser = t->omega_laser; L.Temin = t->Temin;
   L.inv_z0_43 = 1e-3 / pow(t->atomic_charge, 4.0 / 3.0);
@@ -874,6 +898,7 @@ extern "C" int imdgpu_ttm_init(imdgpu_ctx *ctx, const imdgpu_ttm_params *par)
     // no per-sub-step ghost exchange).  One rank: global == local.
     t->ldim[d] = (ctx->dim[d] - 2) / par->fd_ext[d];
     t->off[d] = ctx->ttm_decomposed ? 0 : ctx->my_coord[d] * t->ldim[d];
+    t->goff[d] = ctx->my_coord[d] * t->ldim[d];
     t->dim[d] = ctx->ttm_decomposed ? t->ldim[d] + 2 : t->ldim[d] * ctx->cpu_dim[d] + 2;
     // fd_h = fd_ext * (box/global_cell_dim), imd_geom_3d.c:243-246 (orthorhombic diagonal like the reference)
     t->h[d] = par->fd_ext[d] * ctx->box[4 * d] * (1.0 / ctx->gdim[d]);
@@ -1039,7 +1064,7 @@ extern "C" int imdgpu_ttm_laser_rescale(imdgpu_ctx *ctx, const imdgpu_laser_para
   g *= g;
   const double e = exp(-g / p->sigma_t_squared / 2.0) * p->p_peak;
   int go[3];
-  for (int d = 0; d < 3; d++) go[d] = ctx->ttm_decomposed ? ctx->my_coord[d] * t->ldim[d] : 0;
+  for (int d = 0; d < 3; d++) go[d] = ctx->ttm_decomposed ? t->goff[d] : 0;
   hipLaunchKernelGGL(k_ttm_laser, dim3(nblk(t->ninner, TTM_WG)), dim3(TTM_WG), 0, ctx->stream, L, go[0], go[1], go[2],
                      p->dir[0], p->dir[1], p->dir[2], p->offset, p->mu, e, t->natoms, t->source);
   HIPCHK(hipGetLastError());
@@ -1057,11 +1082,26 @@ extern "C" int imdgpu_ttm_set_laser(imdgpu_ctx *ctx, const imdgpu_laser_params *
   return 0;
 }
 
+// [do_COMMFLUX, imd_ttm_3D.c:667-995] one x face of {flux[8], U} of the current lattice: dev_buf holds 5 doubles per
+// inner (j, k).  unpack == 0: side 0 packs my column i = 1, side 1 my column lx-2; unpack == 1: side 0 fills my ghost
+// column i = 0, side 1 the ghost column lx-1.  *ncells receives the number of (j, k) pairs.
+extern "C" int imdgpu_ttm_commflux(imdgpu_ctx *ctx, int side, int unpack, double *dev_buf, int *ncells)
+{
+  NEED_TTM();
+  const int n = (t->dim[1] - 2) * (t->dim[2] - 2);
+  if (ncells) *ncells = n;
+  if (!dev_buf) return 0;
+  if (!ctx->ttm_flux) return imdgpu_fail(ctx, "ttm_commflux: option ttm_flux / ttm_adv is off");
+  hipLaunchKernelGGL(k_ttm_commflux, dim3(nblk(n, TTM_WG)), dim3(TTM_WG), 0, ctx->stream, L, side, unpack, t->flux, t->ncell,
+                     t->U[t->cur], dev_buf);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 // [do_ADV(tau), imd_ttm_3D.c:1321-1458; calc_ttm calls it with tau = 1.0 right after update_fd (:57-60)]
 extern "C" int imdgpu_ttm_adv(imdgpu_ctx *ctx, double tau, int steps)
 {
   NEED_TTM();
-  if (ctx->ttm_decomposed) return imdgpu_fail(ctx, "ttm_adv: only for a lattice held as a whole (one rank, or replicated); the do_COMMFLUX exchange of a decomposed lattice is not built");
   if (!ctx->ttm_flux) return imdgpu_fail(ctx, "ttm_adv: needs the atom-flux counters of update_fd (option ttm_flux or ttm_adv)");
   if (t->dim[2] < 3) return imdgpu_fail(ctx, "ttm_adv: lattice has no plane k = 1");
   if (steps < 1) return 0;                               // :1323
@@ -1296,7 +1336,7 @@ extern "C" int imdgpu_ttm_mailbox_attach(imdgpu_ctx *ctx, void *host_base, size_
 extern "C" int imdgpu_ttm_local_step(imdgpu_ctx *ctx, int steps)
 {
   if (!ctx->ttm_decomposed) return imdgpu_fail(ctx, "ttm_local_step: decomposed lattice only");
-  if (ctx->ttm_adv) return imdgpu_fail(ctx, "ttm_adv is not available on a decomposed lattice");
+  if (ctx->ttm_adv) return imdgpu_fail(ctx, "ttm_local_step with ttm_adv: call update_fd, the do_COMMFLUX exchange (imdgpu_ttm_commflux), ttm_adv and ttm_lattice_step separately");
   if (imdgpu_ttm_update_fd(ctx, steps)) return 1;
   return imdgpu_ttm_lattice_step(ctx, steps);
 }

@@ -19,7 +19,7 @@ SYMBOLS = [
     "imdgpu_calc_forces", "imdgpu_move_atoms_nve", "imdgpu_md_step", "imdgpu_get_sums",
     "imdgpu_export_nblist", "imdgpu_update_momenta", "imdgpu_nblist_stats",
     "imdgpu_profile_enable", "imdgpu_profile_reset", "imdgpu_profile_get",
-    "imdgpu_ttm_init", "imdgpu_ttm_dims", "imdgpu_ttm_download", "imdgpu_ttm_upload", "imdgpu_ttm_update_fd", "imdgpu_ttm_adv", "imdgpu_ttm_laser_rescale", "imdgpu_ttm_set_laser", "imdgpu_ttm_get_eabs",
+    "imdgpu_ttm_init", "imdgpu_ttm_dims", "imdgpu_ttm_download", "imdgpu_ttm_upload", "imdgpu_ttm_update_fd", "imdgpu_ttm_adv", "imdgpu_ttm_commflux", "imdgpu_ttm_laser_rescale", "imdgpu_ttm_set_laser", "imdgpu_ttm_get_eabs",
     "imdgpu_ttm_cell_activation", "imdgpu_ttm_fillmesh", "imdgpu_ttm_fill_ghost_layers", "imdgpu_ttm_diff",
     "imdgpu_ttm_cfl_maxdt", "imdgpu_calc_ttm", "imdgpu_move_atoms_ttm", "imdgpu_ttm_eos_te_from_r_ee",
     "imdgpu_get_cell_tables", "imdgpu_autotile", "imdgpu_set_ghost_layout", "imdgpu_halo_gather", "imdgpu_halo_gather2", "imdgpu_halo_scatter",
@@ -123,6 +123,7 @@ def load():
     L.imdgpu_ttm_upload.argtypes = [vp, C.POINTER(TtmFieldsC)]
     L.imdgpu_ttm_update_fd.argtypes = [vp, C.c_int]
     L.imdgpu_ttm_adv.argtypes = [vp, C.c_double, C.c_int]
+    L.imdgpu_ttm_commflux.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(C.c_int)]
     L.imdgpu_ttm_laser_rescale.argtypes = [vp, C.POINTER(LaserParamsC), C.c_int]
     L.imdgpu_ttm_set_laser.argtypes = [vp, C.POINTER(LaserParamsC)]
     L.imdgpu_ttm_get_eabs.argtypes = [vp, C.POINTER(C.c_double)]

@@ -172,6 +172,15 @@ def _exchange(dec, d, buf_lo, buf_hi, like_lo, like_hi, group=None, out_lo=None,
     return from_lo, from_hi
 
 
+class _Neighbours:
+    """view of a Decomposition with other neighbours along one direction (do_COMMFLUX: no periodic wrap)"""
+
+    def __init__(self, dec, d, lo, hi):
+        self.cpu_dim = dec.cpu_dim
+        self.lo = list(dec.lo); self.hi = list(dec.hi)
+        self.lo[d], self.hi[d] = lo, hi
+
+
 WHAT_WIDTH = {0: (4, torch.float64), 1: (1, torch.float64), 2: (1, torch.int32), 3: (3, torch.float64)}
 
 
@@ -338,6 +347,26 @@ class DistributedMD:
         self.valid = True
         self.nrebuild += 1
 
+    def _commflux(self):
+        """do_COMMFLUX (imd_ttm_3D.c:667-995, without ADV2D) on the decomposed lattice: my boundary columns of {flux[8], U}
+        go into the x neighbours' ghost columns.  Like the reference, the ranks at the two ends of the x range exchange
+        with their inner neighbour only -- no wrap-around even with periodic x (:724-760)."""
+        dec, ops = self.dec, self.ops
+        P, cx = dec.cpu_dim[0], dec.coord[0]
+        if P == 1:
+            return
+        lo = dec.lo[0] if cx > 0 else None
+        hi = dec.hi[0] if cx < P - 1 else None
+        n = ops.ttm_commflux_cells() * 5
+        send_lo = ops.ttm_commflux(0, 0) if lo is not None else None
+        send_hi = ops.ttm_commflux(1, 0) if hi is not None else None
+        sub = _Neighbours(dec, 0, lo, hi)
+        from_lo, from_hi = _exchange(sub, 0, send_lo, send_hi, (n, torch.float64), (n, torch.float64))
+        if from_lo is not None:
+            ops.ttm_commflux(0, 1, from_lo)
+        if from_hi is not None:
+            ops.ttm_commflux(1, 1, from_hi)
+
     # -- one MD step ------------------------------------------------------------------------------
     def md_step(self, step):
         ops = self.ops
@@ -354,7 +383,12 @@ class DistributedMD:
             # (block of update_fd -> all-gather -> fold in -> diffusion sub-steps) beside the embedding pass, the
             # dF halo and the EAM force pass, exactly like the single-rank fork in imdgpu_md_step
             ops.ttm_fork()
-            if self.ttm_decomposed:
+            if self.ttm_decomposed and self.ttm_adv:
+                ops.ttm_update_fd(step)
+                self._commflux()
+                ops.ttm_adv(1.0, step)
+                ops.ttm_lattice_step(step)
+            elif self.ttm_decomposed:
                 ops.ttm_local_step(step)
             else:
                 blk = ops.ttm_local_block(step)
@@ -407,7 +441,9 @@ class DistributedMD:
             self.plan.exchange(ops, 3); t0 = lap("halo_pos", t0)
         ops.forces_phase(1); t0 = lap("pass1", t0)
         if self.ttm:
-            if self.ttm_decomposed:
+            if self.ttm_decomposed and self.ttm_adv:
+                ops.ttm_update_fd(step); self._commflux(); ops.ttm_adv(1.0, step); ops.ttm_lattice_step(step)
+            elif self.ttm_decomposed:
                 ops.ttm_local_step(step)
             else:
                 blk = ops.ttm_local_block(step); allb = all_gather_flat(blk, self.world)
@@ -574,6 +610,20 @@ class GpuOps:
 
     def ttm_local_step(self, step):
         self._ck(self.L.imdgpu_ttm_local_step(self.h, int(step)))
+
+    def ttm_update_fd(self, step):
+        self._ck(self.L.imdgpu_ttm_update_fd(self.h, int(step)))
+
+    def ttm_commflux_cells(self):
+        n = self.C.c_int()
+        self._ck(self.L.imdgpu_ttm_commflux(self.h, 0, 0, None, self.C.byref(n)))
+        return n.value
+
+    def ttm_commflux(self, side, unpack, buf=None):
+        if buf is None:
+            buf = torch.empty(self.ttm_commflux_cells() * 5, dtype=torch.float64, device=self.device)
+        self._ck(self.L.imdgpu_ttm_commflux(self.h, int(side), int(unpack), self.C.c_void_p(buf.data_ptr()), None))
+        return buf
 
     def ttm_has_adv(self):
         return bool(self.s.get_info("ttm_adv"))

@@ -175,9 +175,14 @@ int imdgpu_ttm_update_fd(imdgpu_ctx *ctx, int steps);
 /* [do_ADV(tau), :1321-1458, with do_COMMFLUX, :667-995] advection of the electron energy with the atoms that changed
  * FD cells, as the reference compiles it (ADVMODE 1 without ADV2D): x direction, lattice plane k = 1, then l1 <-> l2.
  * Needs update_fd's flux counters (option "ttm_flux"; option "ttm_adv" sets it and makes imdgpu_calc_ttm call
- * imdgpu_ttm_adv(1.0) after update_fd like calc_ttm :57-60).  For a lattice held as a whole (one rank, or the
- * replicated lattice of several ranks); not for option "ttm_decomposed". */
+ * imdgpu_ttm_adv(1.0) after update_fd like calc_ttm :57-60).  On a lattice held as a whole (one rank, or the
+ * replicated lattice of several ranks) do_COMMFLUX has nothing to move; on the decomposed lattice the host exchanges
+ * the x faces of {flux[8], U} with imdgpu_ttm_commflux between update_fd and imdgpu_ttm_adv (ranks at the ends of the
+ * x range do not wrap around, :724-760). */
 int imdgpu_ttm_adv(imdgpu_ctx *ctx, double tau, int steps);
+/* [do_COMMFLUX :667-995] dev_buf: 5 doubles per inner (j,k) = the eight counters as ints, then U.  unpack 0: side 0 packs
+ * my column i = 1, side 1 my column lx-2; unpack 1: side 0 fills my ghost column i = 0, side 1 the ghost column lx-1 */
+int imdgpu_ttm_commflux(imdgpu_ctx *ctx, int side, int unpack, double *dev_buf, int *ncells);
 /* [laser_rescale_ttm, imd_laser.c:715-788 (-DLASER, laser_rescale_mode 4), with ttm_calc_depth :699-710]
  * Beer-Lambert source term of the electron heat equation: in every active FD cell
  *   source = exp(-mu * depth) * exp(-(timestep*steps - t_0)^2 / sigma_t_squared / 2) * p_peak,

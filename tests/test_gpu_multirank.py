@@ -156,3 +156,23 @@ def test_two_ranks_ttm_with_advection():
         for f in ("temp", "U", "temp2", "U2", "xi"):
             a, b = r[4][f][inner], G["t48_substeps_done_" + f][inner]
             assert np.abs(a - b).max() <= 2e-8 * np.abs(b).max(), f
+
+
+def test_two_ranks_ttm_with_advection_on_the_decomposed_lattice():
+    """The same run with one lattice block per rank (option ttm_decomposed): do_COMMFLUX's exchange of the boundary
+    columns of {flux[8], U} (imd_ttm_3D.c:667-995; imdgpu_ttm_commflux + the host layer's P2P exchange, no wrap-around at
+    the ends of the x range) feeds do_ADV; the per-atom FD cell index is global, so atoms that change ranks are counted
+    like in the reference.  Every rank's block equals its part of the reference lattice of step 48."""
+    res = _run("ttm_adv", (2, 1, 1), 49, True, decomposed=True, adv=True)
+    G = gu.load("ttm_adv")
+    nx = (int(G["ttm_fd_dim"][0]) - 2) // 2
+    for r in res:
+        cx = r[5][0]
+        sl = (slice(1 + cx * nx, 1 + (cx + 1) * nx), slice(1, -1), slice(1, -1))
+        inner = (slice(1, -1),) * 3
+        assert r[4]["temp"].shape[0] == nx + 2
+        assert np.array_equal(r[4]["flux"][inner], G["t48_flux"][sl])
+        assert np.array_equal(r[4]["natoms"][inner], G["t48_substeps_done_natoms"][sl])
+        for f in ("temp", "U", "temp2", "U2", "xi"):
+            a, b = r[4][f][inner], G["t48_substeps_done_" + f][sl]
+            assert np.abs(a - b).max() <= 2e-8 * np.abs(b).max(), f
