@@ -317,7 +317,8 @@ void orc_ttm_update_fd(orc_ttm *t, orc_sys *s, int steps)
       }
 }
 
-/* do_cell_activation, :1468-1596 (fallback scheme only; advection is not restated) */
+/* do_cell_activation, :1468-1596: in place, in loop order (a cell activated in the same step as an earlier neighbour sees
+ * the neighbour's new temperature) */
 void orc_ttm_cell_activation(orc_ttm *t)
 {
   int i, j, k;
