@@ -88,6 +88,30 @@ static void dump_eos_inverse(void)
   fclose(f);
 }
 
+/* IMD_PROBE_EOSGRID=1: at step 0 read points "x y" from eos_samples.txt (working directory) and evaluate the reference's
+ * interpolators on both EOS tables at them: raw lpi_interpolate_point results, no unit factors */
+static void dump_eos_grid(void)
+{
+  char fn[1024];
+  const char *dir = getenv("IMD_PROBE_DIR");
+  FILE *in = fopen("eos_samples.txt", "r"), *f;
+  double x, y;
+  int n = 0;
+  if (in == NULL) return;
+  sprintf(fn, "%s/eosgrid.%d.bin", dir ? dir : ".", myid);
+  f = fopen(fn, "wb");
+  while (2 == fscanf(in, "%lf %lf", &x, &y)) {
+    point a, b;
+    a.x = x; a.y = y; a.z = 0; b = a;
+    lpi_interpolate_point(intp_cve_from_r_te.interpolator, &a);
+    lpi_interpolate_point(intp_ee_from_r_tesqrt.interpolator, &b);
+    fwrite(&x, sizeof(double), 1, f); fwrite(&y, sizeof(double), 1, f);
+    fwrite(&a.z, sizeof(double), 1, f); fwrite(&b.z, sizeof(double), 1, f);
+    n++;
+  }
+  fclose(in); fclose(f);
+}
+
 /* advection bookkeeping of update_fd: the eight atom-flux counters per FD cell (imd_ttm_3D.c:335-370) */
 static void dump_flux(const char *tag)
 {
@@ -151,6 +175,7 @@ void __wrap_calc_ttm(void)
 {
   int i, dumping = want(steps);
   if (steps == 0 && getenv("IMD_PROBE_EOSINV")) dump_eos_inverse();
+  if (steps == 0 && getenv("IMD_PROBE_EOSGRID")) dump_eos_grid();
   double tau;
   diff_substeps = fd_n_timesteps;
   tau = timestep / ((double) diff_substeps);
