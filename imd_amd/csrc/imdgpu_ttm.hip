@@ -251,29 +251,97 @@ __global__ void k_ttm_update_fd(Lat L, int steps, int cap, const int *cell_start
   int nat = 0, neigh = 0;
   int fl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   double sx = 0, sy = 0, sz = 0, sm = 0;
-  for (int xc = (i - 1) * L.ext[0] + 1; xc < i * L.ext[0] + 1; xc++)
-    for (int yc = (j - 1) * L.ext[1] + 1; yc < j * L.ext[1] + 1; yc++)
-      for (int zc = (k - 1) * L.ext[2] + 1; zc < k * L.ext[2] + 1; zc++) {
-        int mc = (xc * L.md_dim[1] + yc) * L.md_dim[2] + zc;
-        int s = cell_start[mc], n = cell_cnt[mc];
-        nat += n;
-        for (int a = s + lane; a < s + n; a += 64) {
-          neigh += numneighs[a];
-          sx += p[a]; sy += p[cap + a]; sz += p[2 * (size_t) cap + a];
-          sm += mass[a];
-          if (fdc) {
-            const int ig = i + L.goff[0] - 1, jg = j + L.goff[1] - 1, kg = k + L.goff[2] - 1, old = fdc[a];
-            if (steps > 0 && old >= 0) {
-              const int di = old & 1023, dj = (old >> 10) & 1023;
-              if (di != ig || dj != jg) {
-                const int q = di > ig ? (dj > jg ? 4 : (dj < jg ? 3 : 0)) : (di < ig ? (dj < jg ? 7 : (dj > jg ? 6 : 1)) : (dj > jg ? 2 : 5));
-                fl[q]++;
-              }
-            }
-            fdc[a] = ig | (jg << 10) | (kg << 20);
+  // Up to eight MD cells of at most 64 atoms per FD cell (fd_ext 2 2 2 and smaller: the usual case): every lane meets
+  // at most one atom per MD cell and keeps its momentum and mass in registers for the second sweep, which then reads
+  // nothing -- the kernel is bound by exactly those loads.  Same operations in the same order either way.
+  const int e0 = L.ext[0], e1 = L.ext[1], e2 = L.ext[2], ne = e0 * e1 * e2;
+  const bool small = ne <= 8;
+  bool cached = small;
+  double cx[8], cy[8], cz[8], cm[8];
+  // one MD cell: first-sweep sums (+ the flux bookkeeping); returns this lane's first atom through (px, py, pz, pm)
+  auto sweep1 = [&](int xc, int yc, int zc, double &px, double &py, double &pz, double &pm) {
+    const int mc = (xc * L.md_dim[1] + yc) * L.md_dim[2] + zc;
+    const int s = cell_start[mc], n = cell_cnt[mc];
+    nat += n;
+    if (n > 64) cached = false;
+    for (int a = s + lane; a < s + n; a += 64) {
+      neigh += numneighs[a];
+      const double ax = p[a], ay = p[cap + a], az = p[2 * (size_t) cap + a], am = mass[a];
+      sx += ax; sy += ay; sz += az;
+      sm += am;
+      if (a == s + lane) { px = ax; py = ay; pz = az; pm = am; }
+      if (fdc) {
+        const int ig = i + L.goff[0] - 1, jg = j + L.goff[1] - 1, kg = k + L.goff[2] - 1, old = fdc[a];
+        if (steps > 0 && old >= 0) {
+          const int di = old & 1023, dj = (old >> 10) & 1023;
+          if (di != ig || dj != jg) {
+            const int q = di > ig ? (dj > jg ? 4 : (dj < jg ? 3 : 0)) : (di < ig ? (dj < jg ? 7 : (dj > jg ? 6 : 1)) : (dj > jg ? 2 : 5));
+            fl[q]++;
           }
         }
+        fdc[a] = ig | (jg << 10) | (kg << 20);
       }
+    }
+  };
+  int cs[8], cn[8];
+  if (small) {                                   // the cells' (start, count) first: eight independent loads
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      cs[q] = 0; cn[q] = 0; cx[q] = 0.0; cy[q] = 0.0; cz[q] = 0.0; cm[q] = 0.0;
+      if (q < ne) {
+        const int xc = (i - 1) * e0 + 1 + q / (e2 * e1), yc = (j - 1) * e1 + 1 + (q / e2) % e1, zc = (k - 1) * e2 + 1 + q % e2;
+        const int mc = (xc * L.md_dim[1] + yc) * L.md_dim[2] + zc;
+        cs[q] = cell_start[mc]; cn[q] = cell_cnt[mc];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++) if (cn[q] > 64) cached = false;
+  }
+  if (cached) {
+    // straight-line: all loads of the (at most eight) atoms this lane meets are issued before the first use
+    int nn[8], old[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      nn[q] = 0; old[q] = -1;
+      if (lane < cn[q]) {
+        const int a = cs[q] + lane;
+        nn[q] = numneighs[a];
+        cx[q] = p[a]; cy[q] = p[cap + a]; cz[q] = p[2 * (size_t) cap + a]; cm[q] = mass[a];
+        if (fdc) old[q] = fdc[a];
+      }
+    }
+    const int ig = i + L.goff[0] - 1, jg = j + L.goff[1] - 1, kg = k + L.goff[2] - 1;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      nat += cn[q];
+      if (lane < cn[q]) {
+        neigh += nn[q];
+        sx += cx[q]; sy += cy[q]; sz += cz[q];
+        sm += cm[q];
+        if (fdc) {
+          if (steps > 0 && old[q] >= 0) {
+            const int di = old[q] & 1023, dj = (old[q] >> 10) & 1023;
+            if (di != ig || dj != jg) {
+              const int w8 = di > ig ? (dj > jg ? 4 : (dj < jg ? 3 : 0)) : (di < ig ? (dj < jg ? 7 : (dj > jg ? 6 : 1)) : (dj > jg ? 2 : 5));
+#pragma unroll
+              for (int u = 0; u < 8; u++) fl[u] += (u == w8) ? 1 : 0;
+            }
+          }
+          fdc[cs[q] + lane] = ig | (jg << 10) | (kg << 20);
+        }
+      }
+    }
+  } else if (small) {
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+      if (q < ne) sweep1((i - 1) * e0 + 1 + q / (e2 * e1), (j - 1) * e1 + 1 + (q / e2) % e1, (k - 1) * e2 + 1 + q % e2,
+                         cx[q], cy[q], cz[q], cm[q]);
+  } else {
+    double d0, d1, d2, d3;
+    for (int xc = (i - 1) * e0 + 1; xc < i * e0 + 1; xc++)
+      for (int yc = (j - 1) * e1 + 1; yc < j * e1 + 1; yc++)
+        for (int zc = (k - 1) * e2 + 1; zc < k * e2 + 1; zc++) sweep1(xc, yc, zc, d0, d1, d2, d3);
+  }
   neigh = wsumi(neigh);
   if (fdc) {
 #pragma unroll
@@ -290,6 +358,17 @@ __global__ void k_ttm_update_fd(Lat L, int steps, int cap, const int *cell_start
     vx = sx / sm; vy = sy / sm; vz = sz / sm;
   }
   double mt = 0;
+  if (cached) {
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+      if (cm[q] != 0.0) {                        // this lane met an atom in MD cell q (masses are positive)
+        const double m = cm[q];
+        double u;
+        u = cx[q] / m - vx; mt += m * (u * u);
+        u = cy[q] / m - vy; mt += m * (u * u);
+        u = cz[q] / m - vz; mt += m * (u * u);
+      }
+  } else
   for (int xc = (i - 1) * L.ext[0] + 1; xc < i * L.ext[0] + 1; xc++)
     for (int yc = (j - 1) * L.ext[1] + 1; yc < j * L.ext[1] + 1; yc++)
       for (int zc = (k - 1) * L.ext[2] + 1; zc < k * L.ext[2] + 1; zc++) {
