@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--fd-ext", type=int, nargs=3, default=[2, 2, 2],
                     help="MD cells per FD cell (BASELINE config 3: 2 2 2); 1 1 1 gives the 8x lattice an 8-GPU run replicates")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="experiment: no HIP events around the kernel classes in the timed region (roofline then reports 0)")
     ap.add_argument("--laser", action="store_true",
                     help="config 5, Beer-Lambert variant: laser_rescale_ttm source (imd_laser.c:715) applied in every step")
     ap.add_argument("--cpu-box", type=int, default=48, help="unit cells per direction of the CPU sample")
@@ -282,7 +284,7 @@ def main():
     for _ in range(args.warmup):
         do_step(step); step += 1
     barrier()
-    sysm.profile(True); sysm.profile_reset()
+    sysm.profile(not args.no_kernel_timing); sysm.profile_reset()
     nbl0 = sysm.get_sums()["nbl_count"]
     t0 = time.perf_counter()
     for _ in range(args.steps):
