@@ -710,23 +710,44 @@ __device__ void d_activate_cell(const Lat &L, const EosDev &ee, int t, const int
 // one wave (a multi-wave workgroup would not be placed beside the persistent force kernels)
 __global__ __launch_bounds__(64) void k_ttm_activation_seq(Lat L, EosDev ee, const int *natoms, double *T1, double *T2,
                                                            double *U1, double *U2, const double *md_temp,
-                                                           const double *dens, int *cand, int *sorted, int *ncand)
+                                                           const double *dens, int *cand, int *sorted, int *ncand,
+                                                           int rank_max)
 {
   const int n = *ncand, lane = threadIdx.x;
   if (n == 0) return;
-  // rank sort (the positions are distinct): O(n^2 / 64), n is a handful of cells in practice
-  for (int a = lane; a < n; a += 64) {
-    const int v = cand[a];
-    int r = 0;
-    for (int b = 0; b < n; b++) r += cand[b] < v ? 1 : 0;
-    sorted[r] = v;
+  if (n <= rank_max) {
+    // rank sort (the positions are distinct): O(n^2 / 64), n is a handful of cells in practice
+    for (int a = lane; a < n; a += 64) {
+      const int v = cand[a];
+      int r = 0;
+      for (int b = 0; b < n; b++) r += cand[b] < v ? 1 : 0;
+      sorted[r] = v;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (lane == 0)
+      for (int q = 0; q < n; q++) d_activate_cell(L, ee, sorted[q], natoms, T1, T2, U1, U2, md_temp, dens);
+  } else {
+    // many at once (e.g. a lattice uploaded cold): mark them and walk all cells in order, 64 per trip
+    const int ninner = (L.dim[0] - 2) * (L.dim[1] - 2) * (L.dim[2] - 2);
+    for (int a = lane; a < ninner; a += 64) sorted[a] = 0;
+    __threadfence_block();
+    __syncthreads();
+    for (int a = lane; a < n; a += 64) sorted[cand[a]] = 1;
+    __threadfence_block();
+    __syncthreads();
+    for (int base = 0; base < ninner; base += 64) {
+      const int m = base + lane < ninner ? sorted[base + lane] : 0;
+      unsigned long long mask = __ballot(m != 0);
+      if (lane == 0)
+        while (mask) {
+          const int b = __ffsll((long long) mask) - 1;
+          mask &= mask - 1;
+          d_activate_cell(L, ee, base + b, natoms, T1, T2, U1, U2, md_temp, dens);
+        }
+    }
   }
-  __threadfence_block();
-  __syncthreads();
-  if (lane == 0) {
-    for (int q = 0; q < n; q++) d_activate_cell(L, ee, sorted[q], natoms, T1, T2, U1, U2, md_temp, dens);
-    *ncand = 0;
-  }
+  if (lane == 0) *ncand = 0;
 }
 
 // ttm_fill_ghost_layers, one rank: FACE cells only (plane datatypes of
@@ -1199,7 +1220,8 @@ extern "C" int imdgpu_ttm_cell_activation(imdgpu_ctx *ctx)
                      t->natoms_old, t->temp[t->cur], t->xi, t->d_cand, t->d_cand + 2 * (size_t) t->ninner);
   hipLaunchKernelGGL(k_ttm_activation_seq, dim3(1), dim3(64), 0, ctx->stream, L, t->ee, t->natoms, t->temp[t->cur],
                      t->temp[t->cur ^ 1], t->U[t->cur], t->U[t->cur ^ 1], t->md_temp, t->dens, t->d_cand,
-                     t->d_cand + t->ninner, t->d_cand + 2 * (size_t) t->ninner);
+                     t->d_cand + t->ninner, t->d_cand + 2 * (size_t) t->ninner,
+                     getenv("IMDGPU_ACT_RANKSORT_MAX") ? atoi(getenv("IMDGPU_ACT_RANKSORT_MAX")) : 1024);
   HIPCHK(hipGetLastError());
   return 0;
 }

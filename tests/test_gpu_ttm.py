@@ -320,3 +320,30 @@ def test_adjacent_cells_activated_in_the_same_step_follow_the_reference_order():
     as_they_were = np.sqrt(np.mean([lat["temp"][n] ** 2 for n in nb if lat["natoms"][n] >= m]))
     assert abs(d["temp"][q] - as_they_were) > 1e-3 * d["temp"][q]
     s.close(); o.close()
+
+
+def test_cold_lattice_activates_every_cell_in_order(monkeypatch):
+    """All cells activated in the same step (a lattice handed over with natoms_old = 0 and Te = 0) with the rank-sort
+    limit lowered to 8 candidates (IMDGPU_ACT_RANKSORT_MAX), so the ordered walk over all cells runs -- the path for
+    more than 1024 simultaneous activations; still the sequential oracle (1e-14)."""
+    monkeypatch.setenv("IMDGPU_ACT_RANKSORT_MAX", "8")
+    G = gu.load("ttm_2048")
+    s = _gpu(G)
+    so = gu.oracle_from_golden(G, 0)
+    o = gu.oracle_ttm_from_golden(G, so)
+    pre = "t1_update_fd_"
+    lat = {f: G[pre + f].copy() for f in ("natoms", "natoms_old", "temp", "temp2", "U", "U2", "dens", "md_temp", "xi")}
+    lat["natoms_old"][...] = 0; lat["temp"][...] = 0.0; lat["temp2"][...] = 0.0
+    s.ttm_upload(**lat)
+    s.do_cell_activation()
+    d = s.ttm_download(fields=("temp", "temp2", "U", "U2"))
+    o.t.cur = 0
+    for f in ("natoms", "natoms_old", "xi", "md_temp", "dens"):
+        getattr(o, f)[...] = lat[f]
+    o._temp[0][...] = lat["temp"]; o._temp[1][...] = lat["temp2"]; o._U[0][...] = lat["U"]; o._U[1][...] = lat["U2"]
+    o.cell_activation()
+    inner = (slice(1, -1),) * 3
+    assert (o.temp[inner] > 0).all()
+    for f, ref in (("temp", o.temp), ("temp2", o.temp2), ("U", o.U), ("U2", o.U2)):
+        assert np.abs(d[f] - ref).max() <= 1e-14 * np.abs(ref).max(), f
+    s.close(); o.close()
