@@ -566,7 +566,8 @@ struct TileArgs {
   // in every LDS slot, per own atom (slot | neighbour count << 16), per tile {slots, first own atom, own atoms, 0}
   int *tsrc; unsigned *ownw; int4 *tinfo;
   int dbg;                        // experiments (IMDGPU_DBG): 1 = skip the neighbour loops, 2 = skip the staging
-  TabPar pair, rho;
+  TabPar pair, rho, emb;
+  double4 *posw;                  // pos again, writable: the fused embedding pass stores F'(rho) in .w
   const double *merged;           // interleaved (phi,rho) table + 3 zero rows, or nullptr
   double *f, *epot, *rhoh, *ref;
   int *numneighs;
@@ -1046,7 +1047,10 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile(TileArgs a)
 // files written by one tool): the two tables are interleaved in LDS as (phi[k], rho[k]) so that one index
 // computation and three aligned 16-byte reads serve both; three all-zero rows follow the table and
 // neighbours beyond the cut-off (list skin, padding) are sent there, which replaces every mask.
-template <bool TTMN>
+// FEMB: the embedding pass (pass 2, imd_forces_nbl.c:748-783) is folded into the epilogue -- with the full list rho of an
+// own atom is complete when its neighbour loop ends, so F(rho) and F'(rho) can be taken right there: no k_pass2 launch,
+// rho is not re-read, epot is written once.
+template <bool TTMN, bool FEMB>
 __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs a)
 {
   extern __shared__ double lds[];
@@ -1057,7 +1061,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
   TileCtx T;
   int t0, t1;
   block_tile_range(a.ntiles, t0, t1);
-  double sums[2] = {0.0, 0.0};
+  double sums[3] = {0.0, 0.0, 0.0};        // pair energy, virial, embedding energy
   int is_short = 0;
   if (t0 < t1) {
     const double2 *src = (const double2 *) a.merged;
@@ -1118,17 +1122,25 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
       fx *= c.istep2; fy *= c.istep2; fz *= c.istep2; ee *= 0.5; vir *= -0.5 * c.istep2;
       is_short |= (r2min < c.begin) ? 1 : 0;
       a.f[i] = fx; a.f[a.cap + i] = fy; a.f[2 * (size_t) a.cap + i] = fz;
-      a.epot[i] = ee;
       a.rhoh[i] = rr;
+      if (FEMB) {                                           // PAIR_INT on embed_pot, :757-760; EAM_DF into pos.w
+        int dummy = 0;
+        const Tab3 q = tab3(a.emb.tab, 1, 0, a.emb.begin[0], a.emb.end[0], a.emb.invstep[0], rr, dummy);
+        const double pe = tab_val(q);
+        a.posw[i].w = tab_grad(q);
+        a.epot[i] = ee + pe;
+        sums[2] += pe;
+      } else a.epot[i] = ee;
       if (TTMN) a.numneighs[i] = nb;
       sums[0] += ee; sums[1] += vir;
     }
     TILE_EPILOGUE
   }
-  block_sum<2>(sums, scratch);
+  block_sum<3>(sums, scratch);
   if (threadIdx.x == 0) {
     a.partials[(size_t) blockIdx.x * IMDGPU_NPART + 0] = sums[0];
     a.partials[(size_t) blockIdx.x * IMDGPU_NPART + 1] = sums[1];
+    if (FEMB) a.partials[(size_t) blockIdx.x * IMDGPU_NPART + 2] = sums[2];
   }
   if (is_short) a.counters[CNT_IS_SHORT] = 1;
 }
@@ -1360,6 +1372,7 @@ extern "C" int imdgpu_create(imdgpu_ctx **out, int device)
   }
   HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&ctx->ev_ufd, hipEventDisableTiming));
   ctx->own_stream = true;
   HIPCHK(hipMalloc((void **) &ctx->d_counters, CNT_N * sizeof(int)));
   HIPCHK(hipMemset(ctx->d_counters, 0, CNT_N * sizeof(int)));
@@ -1390,6 +1403,7 @@ extern "C" void imdgpu_destroy(imdgpu_ctx *c)
   if (c->stream2) (void) hipStreamDestroy(c->stream2);
   if (c->ev_fork) (void) hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void) hipEventDestroy(c->ev_join);
+  if (c->ev_ufd) (void) hipEventDestroy(c->ev_ufd);
   delete c;
 }
 
@@ -1962,7 +1976,7 @@ static TileArgs make_tile_args(imdgpu_ctx *ctx)
   a.istart = ctx->istart; a.nbr16 = (ushort4 *) ctx->nbr16; a.nbr_cnt = ctx->nbr_cnt;
   a.tsrc = ctx->tsrc; a.ownw = ctx->ownw; a.tinfo = (int4 *) ctx->tinfo;
   { static const int dbg = getenv("IMDGPU_DBG") ? atoi(getenv("IMDGPU_DBG")) : 0; a.dbg = dbg; }
-  a.pair = ctx->pair.par; a.rho = ctx->rho.par; a.merged = ctx->d_merged;
+  a.pair = ctx->pair.par; a.rho = ctx->rho.par; a.emb = ctx->emb.par; a.posw = ctx->pos; a.merged = ctx->d_merged;
   a.f = ctx->f; a.epot = ctx->epot; a.rhoh = ctx->rhoh; a.ref = ctx->ref; a.numneighs = ctx->numneighs;
   a.partials = ctx->partials; a.counters = ctx->d_counters; a.cellsz = ctx->cellsz;
   return a;
@@ -2120,6 +2134,14 @@ extern "C" int imdgpu_check_nblist(imdgpu_ctx *ctx, int *valid)
 // launches the three passes; assumes ghosts/list are current
 // phase 0: all three passes; 1 / 2 / 3: only that pass (3 includes the final reduction) -- the split form is
 // used when an external halo exchange (multi-rank) has to run between the passes
+// the embedding pass is folded into pass 1 whenever the merged-table tile kernel runs (one atom type, pair and rho on the
+// same grid); IMDGPU_FUSE_EMB=0 keeps the separate k_pass2 (experiments)
+static bool fuse_emb(const imdgpu_ctx *ctx)
+{
+  static const int on = getenv("IMDGPU_FUSE_EMB") ? atoi(getenv("IMDGPU_FUSE_EMB")) : 1;
+  return on && ctx->list_mode == 1 && ctx->pair.present && ctx->rho.present && ctx->ntypes == 1 && ctx->d_merged != nullptr;
+}
+
 static int launch_forces(imdgpu_ctx *ctx, int phase = 0)
 {
   const int n = ctx->nlocal;
@@ -2154,13 +2176,14 @@ static int launch_forces(imdgpu_ctx *ctx, int phase = 0)
 #define L1E(P, E) do { if (TT) L1T(P, E, true); else L1T(P, E, false); } while (0)
     if (TILE && PAIR && EAM && NT1 && ctx->d_merged) {
       size_t l = tile_lds_bytes(ctx, 1);
-      if (TT) {
-        HIPCHK(hipFuncSetAttribute((const void *) k_pass1_tile_merged<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) l));
-        hipLaunchKernelGGL((k_pass1_tile_merged<true>), dim3(nb), dim3(B), l, ctx->stream, ta);
-      } else {
-        HIPCHK(hipFuncSetAttribute((const void *) k_pass1_tile_merged<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) l));
-        hipLaunchKernelGGL((k_pass1_tile_merged<false>), dim3(nb), dim3(B), l, ctx->stream, ta);
-      }
+#define LM(T, F)                                                                                                     \
+  do {                                                                                                               \
+    HIPCHK(hipFuncSetAttribute((const void *) k_pass1_tile_merged<T, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) l)); \
+    hipLaunchKernelGGL((k_pass1_tile_merged<T, F>), dim3(nb), dim3(B), l, ctx->stream, ta);                          \
+  } while (0)
+      if (TT) { if (fuse_emb(ctx)) LM(true, true); else LM(true, false); }
+      else { if (fuse_emb(ctx)) LM(false, true); else LM(false, false); }
+#undef LM
     } else if (PAIR && EAM) L1E(true, true); else if (PAIR) L1E(true, false); else L1E(false, true);
 #undef L1E
 #undef L1T
@@ -2171,9 +2194,10 @@ static int launch_forces(imdgpu_ctx *ctx, int phase = 0)
   // under the EAM force pass, whose waves leave it one SIMD per CU, takes 1.5 ms instead of 0.4 and the chain
   // outlasts the pass; beside the short, register-light embedding pass it runs at streaming speed.
   if ((phase == 0 || phase == 1) && ctx->after_pass1) { if (ctx->after_pass1(ctx, ctx->after_pass1_arg)) return 1; }
-  const int nb2 = EAM ? nblk(n, 256) : 0;
+  const bool FUSED = fuse_emb(ctx);                    // the embedding pass ran inside pass 1: its partials sit in pass 1's blocks
+  const int nb2 = EAM ? (FUSED ? nb : nblk(n, 256)) : 0;
   if (EAM && (phase == 0 || phase == 2)) {
-    {
+    if (!FUSED) {
       ProfScope ps(ctx, PROF_PASS2);
       hipLaunchKernelGGL(k_pass2, dim3(nb2), dim3(256), 0, ctx->stream, n, ctx->ntypes, ctx->pos, ctx->type, ctx->rhoh,
                          ctx->epot, ctx->emb.par, ctx->partials);
@@ -2182,6 +2206,9 @@ static int launch_forces(imdgpu_ctx *ctx, int phase = 0)
     imdgpu_tl_mark(ctx, "pass2");
   }
   if (EAM && (phase == 0 || phase == 3)) {
+    // without the embedding pass between them, update_fd of the forked TTM chain would start beside the persistent EAM
+    // force kernel and crawl (see above): the force pass waits for it (0.15 ms alone), the rest of the chain overlaps
+    if (ctx->ufd_pending) { HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_ufd, 0)); ctx->ufd_pending = 0; }
     size_t lds3 = ((size_t) a.rho.nrows * a.rho.ncols + 64) * sizeof(double);
     ProfScope ps(ctx, PROF_PASS3);
     if (TILE) {

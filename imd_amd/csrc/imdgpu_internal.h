@@ -35,7 +35,8 @@ struct ProfPending { hipEvent_t a, b; int id; };
 struct imdgpu_ctx {
   int device = 0, num_cus = 0;
   hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: TTM lattice work overlapped with passes 2-3
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_ufd = nullptr;
+  int ufd_pending = 0;            // the forked TTM chain recorded ev_ufd after update_fd: the EAM force pass waits for it
   int (*after_pass1)(imdgpu_ctx *, void *) = nullptr; void *after_pass1_arg = nullptr;
   int ttm_steps = 0;
   bool own_stream = false;

@@ -1322,6 +1322,10 @@ extern "C" int imdgpu_calc_ttm(imdgpu_ctx *ctx, int steps)
 {
   if (ctx->external_halo && !ctx->ttm_decomposed) return imdgpu_fail(ctx, "calc_ttm: with several ranks use ttm_local_block / apply_blocks / ttm_lattice_step");
   if (imdgpu_ttm_update_fd(ctx, steps)) return 1;
+  if (ctx->stream == ctx->stream2) {                  // forked by imdgpu_md_step: tell the main stream that update_fd is through
+    HIPCHK(hipEventRecord(ctx->ev_ufd, ctx->stream));
+    ctx->ufd_pending = 1;
+  }
   if (ctx->ttm_adv && imdgpu_ttm_adv(ctx, 1.0, steps)) return 1;
   return imdgpu_ttm_lattice_step(ctx, steps);
 }
