@@ -306,9 +306,11 @@ def main():
                                              "reduce", "ttm_update_fd", "ttm_diff", "ttm_fillmesh")}
     sysm.profile(False)
     if rank == 0:
-        # dominant kernel: pass 1 (pair + rho).  Algorithmic bytes per atom = 72 + 4M
+        # dominant kernel: pass 1 (pair + rho).  Algorithmic bytes per atom = 72 + 4M; when the embedding
+        # pass is folded into the same launch its 32 B/atom (rho 8 + dF 8 + pot_eng RMW 16) belong to that launch too
         n1, ms1 = prof["pass1"]
-        bytes_p1 = natoms * (72.0 + 4.0 * M)
+        fused = bool(sysm.get_info("fused_embedding"))
+        bytes_p1 = natoms * (72.0 + 4.0 * M + (32.0 if fused else 0.0))
         ach = bytes_p1 / (ms1 / max(n1, 1) * 1e-3) / 1e9 if n1 else 0.0
         kname = "k_pass1_tile_merged" if sysm.get_info("list_mode") == 1 else "k_pass1"
         traffic, traffic_src = measured_traffic(kname, natoms)
@@ -331,7 +333,7 @@ def main():
                                                                    "tile_threads", "lds_pass1", "lds_pass3", "W")},
                        "parallelism": ("%dx%dx%d ranks, 1 rank/GPU, ghost-cell halo over RCCL" % tuple(cpu_dim))
                        if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": kname + " (pass 1: pair + rho)", "achieved": ach, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": kname + (" (pass 1: pair + rho, embedding pass folded in)" if fused else " (pass 1: pair + rho)"), "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": bytes_p1, "avg_launch_ms": ms1 / max(n1, 1)},
             "kernel_ms_per_step": {k: v[1] / args.steps for k, v in prof.items() if v[0]},

@@ -1436,6 +1436,7 @@ extern "C" int imdgpu_set_option(imdgpu_ctx *ctx, const char *name, int value)
   return imdgpu_fail(ctx, "unknown option %s", name);
 }
 
+static bool fuse_emb(const imdgpu_ctx *ctx);
 extern "C" int imdgpu_get_info(imdgpu_ctx *ctx, const char *name, long long *value)
 {
   struct { const char *n; long long v; } tab[] = {
@@ -1443,7 +1444,7 @@ extern "C" int imdgpu_get_info(imdgpu_ctx *ctx, const char *name, long long *val
     {"max_halo", ctx->max_halo}, {"W", ctx->W}, {"tile_x", ctx->tile[0]}, {"tile_y", ctx->tile[1]}, {"tile_z", ctx->tile[2]},
     {"ntiles", ctx->ntiles}, {"tile_threads", ctx->tile_threads}, {"nlocal", ctx->nlocal}, {"nghost", ctx->nghost},
     {"lds_pass1", (long long) ctx->lds_need[1]}, {"lds_pass3", (long long) ctx->lds_need[3]}, {"nbl_count", ctx->nbl_count},
-    {"ttm_flux", ctx->ttm_flux}, {"ttm_adv", ctx->ttm_adv}, {"ttm_block_width", ctx->ttm_flux ? 10 : 6}};
+    {"fused_embedding", fuse_emb(ctx) ? 1 : 0}, {"ttm_flux", ctx->ttm_flux}, {"ttm_adv", ctx->ttm_adv}, {"ttm_block_width", ctx->ttm_flux ? 10 : 6}};
   for (auto &e : tab) if (!strcmp(name, e.n)) { *value = e.v; return 0; }
   return imdgpu_fail(ctx, "unknown info %s", name);
 }

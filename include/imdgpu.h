@@ -54,6 +54,7 @@ int  imdgpu_synchronize(imdgpu_ctx *ctx);
 /* tuning knobs: "mode" = 1 LDS-tiled force kernels (default), 0 global-gather kernels */
 int  imdgpu_set_option(imdgpu_ctx *ctx, const char *name, int value);
 /* introspection: "list_mode" (kernel family of the current list), "tile_cap", "slot_cap", "W", "ntiles", ...,
+ * "fused_embedding" (1: the embedding pass runs inside the pass-1 kernel of the current list),
  * "ttm_flux", "ttm_adv", "ttm_block_width" (doubles per FD cell in imdgpu_ttm_local_block's records) */
 int  imdgpu_get_info(imdgpu_ctx *ctx, const char *name, long long *value);
 
