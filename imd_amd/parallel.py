@@ -405,7 +405,7 @@ class DistributedMD:
         if self.ttm and not self.ttm_decomposed:
             # the EAM force pass is a persistent kernel that fills every CU: a collective's multi-wave workgroups that
             # are not resident by then wait for its end and the whole lattice chain with them.  The
-            # all-gather normally finishes under the embedding pass; if not, the force pass waits for it (not for the chain)
+            # all-gather normally finishes under the dF halo exchange; if not, the force pass waits for it (not for the chain)
             ops.ttm_wait_gathered()
         ops.forces_phase(3)
         if self.ttm:
