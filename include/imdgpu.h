@@ -246,7 +246,9 @@ int imdgpu_migrate_scan(imdgpu_ctx *ctx, int dim, int *n_lo, int *n_hi);
 int imdgpu_migrate_gather(imdgpu_ctx *ctx, int dir /*0 low, 1 high*/, void *dev_out);
 int imdgpu_migrate_apply(imdgpu_ctx *ctx, const void *dev_in_lo, int n_in_lo, const void *dev_in_hi, int n_in_hi);
 /* the MD step in pieces, all asynchronous on the context's stream: exchanges go between them.
- * phase 1 = pair + rho pass, 2 = embedding pass, 3 = EAM force pass + sums (calc_forces, imd_forces_nbl.c) */
+ * phase 1 = pair + rho pass, 2 = embedding pass, 3 = EAM force pass + sums (calc_forces, imd_forces_nbl.c).
+ * With one atom type and pair/rho tables on one grid the embedding pass runs inside phase 1 (get_info
+ * "fused_embedding"): F'(rho) of the local atoms is complete after phase 1, phase 2 then only refreshes periodic images. */
 int imdgpu_forces_phase(imdgpu_ctx *ctx, int phase);
 int imdgpu_integrate(imdgpu_ctx *ctx);                 /* move_atoms_{nve|ttm} + displacement check */
 int imdgpu_get_invalid(imdgpu_ctx *ctx, int *flag);    /* check_nblist result of this rank (synchronises) */
