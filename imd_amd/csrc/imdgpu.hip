@@ -852,6 +852,14 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile(TileArgs a)
 #define SCHED_BARRIER __builtin_amdgcn_sched_barrier(0)
 #endif
 #define UNR 4
+// experiment (make EXTRA=-DIMDGPU_LDSPRIO): raised wave priority while a wave issues its LDS gathers
+#ifdef IMDGPU_LDSPRIO
+#define PRIO_HI __builtin_amdgcn_s_setprio(2)
+#define PRIO_LO __builtin_amdgcn_s_setprio(0)
+#else
+#define PRIO_HI
+#define PRIO_LO
+#endif
 
 // Tile loop plumbing shared by the force kernels (see stage_issue / stage_commit).  The first list words and the
 // (slot, count) word of the thread's own atom do not depend on the staged positions: they are requested before
@@ -1089,8 +1097,10 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
         double dx[UNR], dy[UNR], dz[UNR], r2[UNR], chi[UNR];
         int k[UNR];
         double2 A[UNR], B[UNR], C[UNR];
+        PRIO_HI;
 #pragma unroll
         for (int e = 0; e < UNR; e++) { dx[e] = sp[j[e]]; dy[e] = sp[a.slot_cap + j[e]]; dz[e] = sp[2 * a.slot_cap + j[e]]; }
+        PRIO_LO;
         SCHED_BARRIER;
 #pragma unroll
         for (int e = 0; e < UNR; e++) {
@@ -1103,8 +1113,10 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
           k[e] = in ? k[e] : kz;
         }
         SCHED_BARRIER;
+        PRIO_HI;
 #pragma unroll
         for (int e = 0; e < UNR; e++) { A[e] = tm[k[e]]; B[e] = tm[k[e] + 1]; C[e] = tm[k[e] + 2]; }
+        PRIO_LO;
         SCHED_BARRIER;
 #pragma unroll
         for (int e = 0; e < UNR; e++) {
@@ -1187,10 +1199,12 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) __attribute__((amdgpu_num_vgpr(144
       // own count get the dummy word
       LIST_WORDS_BEGIN
         double dx[UNR], dy[UNR], dz[UNR], wj[UNR], r2[UNR];
+        PRIO_HI;
 #pragma unroll
         for (int e = 0; e < UNR; e++) {
           dx[e] = sp[j[e]]; dy[e] = sp[a.slot_cap + j[e]]; dz[e] = sp[2 * a.slot_cap + j[e]]; wj[e] = sw[j[e]];
         }
+        PRIO_LO;
         SCHED_BARRIER;
 #pragma unroll
         for (int e = 0; e < UNR; e++) {
@@ -1206,8 +1220,10 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) __attribute__((amdgpu_num_vgpr(144
             kr[e] = (r2[e] < cr.end) ? kr[e] : kz;                        // rho': r2 < end (imd_forces_nbl.c:868)
           }
           SCHED_BARRIER;
+          PRIO_HI;
 #pragma unroll
           for (int e = 0; e < UNR; e++) { R0[e] = tr[kr[e]]; R1[e] = tr[kr[e] + 1]; R2[e] = tr[kr[e] + 2]; }
+          PRIO_LO;
           SCHED_BARRIER;
 #pragma unroll
           for (int e = 0; e < UNR; e++) {
