@@ -151,16 +151,20 @@ def _exchange(dec, d, buf_lo, buf_hi, like_lo, like_hi, group=None, out_lo=None,
     if stage:
         buf_lo = buf_lo.cpu() if buf_lo is not None else None
         buf_hi = buf_hi.cpu() if buf_hi is not None else None
-    if lo is not None:
+    # empty messages are not posted at all: both sides know the sizes (counts travel first), and a zero-byte
+    # point-to-point operation is the one thing collectives libraries disagree about
+    if lo is not None and buf_lo.numel() > 0:
         ops.append(dist.P2POp(dist.isend, buf_lo, lo, group))
-    if hi is not None:
+    if hi is not None and buf_hi.numel() > 0:
         ops.append(dist.P2POp(dist.isend, buf_hi, hi, group))
     if hi is not None:
         from_hi = out_hi if (out_hi is not None and not stage) else torch.empty(like_hi[0], dtype=like_hi[1], device=tdev)
-        ops.append(dist.P2POp(dist.irecv, from_hi, hi, group))
+        if like_hi[0] > 0:
+            ops.append(dist.P2POp(dist.irecv, from_hi, hi, group))
     if lo is not None:
         from_lo = out_lo if (out_lo is not None and not stage) else torch.empty(like_lo[0], dtype=like_lo[1], device=tdev)
-        ops.append(dist.P2POp(dist.irecv, from_lo, lo, group))
+        if like_lo[0] > 0:
+            ops.append(dist.P2POp(dist.irecv, from_lo, lo, group))
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
