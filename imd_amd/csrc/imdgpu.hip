@@ -1465,6 +1465,14 @@ extern "C" int imdgpu_get_info(imdgpu_ctx *ctx, const char *name, long long *val
   return imdgpu_fail(ctx, "unknown info %s", name);
 }
 
+extern "C" int imdgpu_device_count(int *n)
+{
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) c = 0;
+  if (n) *n = c;
+  return c > 0 ? 0 : 1;
+}
+
 extern "C" int imdgpu_set_stream(imdgpu_ctx *ctx, void *s)
 {
   if (ctx->own_stream && ctx->stream) { HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipStreamDestroy(ctx->stream)); }

@@ -47,6 +47,50 @@ extern "C" int imdgpu_set_ghost_layout(imdgpu_ctx *ctx, const int *cell_start, c
   return 0;
 }
 
+// ---- host-buffer variants for a C host that runs its OWN halo exchange (level-1 MPI builds of the reference: after its
+// send_cells the buffer cells of the host hold the ghost atoms).  ghost_cell_n: atoms per cell for all nallcells cells,
+// 0 for the inner ones; ort / sorte / dF: the ghost atoms in cell order (cell index ascending, slots as on the host).
+extern "C" int imdgpu_upload_ghosts(imdgpu_ctx *ctx, const int *ghost_cell_n, int nghost, const double *ort, const int *sorte)
+{
+  HIPCHK(hipSetDevice(ctx->device));
+  if (!ctx->external_halo) return imdgpu_fail(ctx, "upload_ghosts: only with a multi-rank geometry (cpu_dim > 1)");
+  const int nall = ctx->nall_cells;
+  std::vector<int> cs(nall), cc(nall);
+  if (imdgpu_get_cell_tables(ctx, cs.data(), cc.data())) return 1;
+  long long off = 0;
+  for (int c = 0; c < nall; c++)
+    if (ghost_cell_n[c] > 0) {
+      if (cc[c] != 0 && cs[c] < ctx->nlocal) return imdgpu_fail(ctx, "upload_ghosts: cell %d holds local atoms", c);
+      cs[c] = ctx->nlocal + (int) off; cc[c] = ghost_cell_n[c]; off += ghost_cell_n[c];
+    } else if (cs[c] >= ctx->nlocal) { cs[c] = ctx->nlocal; cc[c] = 0; }       // a ghost cell that is empty now
+  if (off != nghost) return imdgpu_fail(ctx, "upload_ghosts: ghost_cell_n sums to %lld, nghost = %d", off, nghost);
+  if (imdgpu_set_ghost_layout(ctx, cs.data(), cc.data(), nghost)) return 1;
+  if (nghost == 0) return 0;
+  std::vector<double4> hp(nghost);
+  for (int g = 0; g < nghost; g++) hp[g] = make_double4(ort[3 * g], ort[3 * g + 1], ort[3 * g + 2], 0.0);
+  HIPCHK(hipMemcpy(ctx->pos + ctx->nlocal, hp.data(), (size_t) nghost * sizeof(double4), hipMemcpyHostToDevice));
+  if (sorte) HIPCHK(hipMemcpy(ctx->type + ctx->nlocal, sorte, (size_t) nghost * sizeof(int), hipMemcpyHostToDevice));
+  else HIPCHK(hipMemset(ctx->type + ctx->nlocal, 0, (size_t) nghost * sizeof(int)));
+  return 0;
+}
+
+// new positions (ort != NULL) and/or F'(rho) (dF != NULL) of the ghost atoms, same order as in imdgpu_upload_ghosts
+extern "C" int imdgpu_update_ghosts(imdgpu_ctx *ctx, int nghost, const double *ort, const double *dF)
+{
+  HIPCHK(hipSetDevice(ctx->device));
+  if (nghost != ctx->nghost) return imdgpu_fail(ctx, "update_ghosts: %d ghost atoms given, %d on the device", nghost, ctx->nghost);
+  if (nghost == 0 || (!ort && !dF)) return 0;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  std::vector<double4> hp(nghost);
+  HIPCHK(hipMemcpy(hp.data(), ctx->pos + ctx->nlocal, (size_t) nghost * sizeof(double4), hipMemcpyDeviceToHost));
+  for (int g = 0; g < nghost; g++) {
+    if (ort) { hp[g].x = ort[3 * g]; hp[g].y = ort[3 * g + 1]; hp[g].z = ort[3 * g + 2]; }
+    if (dF) hp[g].w = dF[g];
+  }
+  HIPCHK(hipMemcpy(ctx->pos + ctx->nlocal, hp.data(), (size_t) nghost * sizeof(double4), hipMemcpyHostToDevice));
+  return 0;
+}
+
 // what: 0 = position record (x,y,z,dF) as 4 doubles, shifted; 1 = dF only (1 double); 2 = type (int);
 //       3 = shifted position only (3 doubles: the per-step halo, 24 instead of 32 bytes per atom on the wire)
 __global__ void k_halo_gather(int what, int n, const int *idx, const double4 *pos, const int *type, double sx,

@@ -40,8 +40,14 @@
  * laser_rescale_mode 4 the Beer-Lambert source of laser_rescale_ttm is applied on the device too.  do_ADV: the reference
  * cannot run it on one rank (do_COMMFLUX's self-Sendrecv never matches); IMD_SHIM_TTM_ADV=1 turns it on here.
  *
- * Single rank (cpu_dim 1 1 1); an MPI build calls the imdgpu_halo_* operations
- * from its own send_cells/send_forces replacements.
+ * MPI builds with several ranks (one GPU per rank, or ranks sharing GPUs): the host keeps its own halo exchange --
+ * send_cells(copy_cell, ...) before the forces and send_cells(copy_dF, ...) between the embedding and the EAM force
+ * pass exactly where imd_forces_nbl.c has them (:311, :786), plus the transfer into the x = 0 buffer layer that AR
+ * builds leave out (send_cells_west below) -- and hands the buffer cells to the library
+ * (imdgpu_upload_ghosts / imdgpu_update_ghosts).  The two reverse exchanges of the reference (send_forces for rho
+ * and for the forces, :745, :1052) are not needed: the device list is symmetric, every rank computes complete
+ * forces and densities for its own atoms.  Sums are reduced with MPI_Allreduce like :1007.  (calc_ttm of the shim is
+ * single-rank for now.)
  */
 #include "imd.h"
 #include "imdgpu.h"
@@ -50,6 +56,10 @@ static imdgpu_ctx *G = NULL;
 static int   g_cap = 0, g_have_cells = 0;
 static double *g_ort, *g_imp, *g_mas, *g_kraft, *g_epot, *g_rho, *g_dF;
 static int    *g_sorte, *g_num, *g_nn, *g_cn;
+static int    g_multi = 0;                    /* several ranks: ghosts come from the host's send_cells */
+static int    g_gcap = 0, g_nghost = 0, *g_gcn = NULL, *g_gsorte = NULL;
+static char   *g_inner = NULL;
+static double *g_gort = NULL, *g_gdF = NULL;
 
 static void gpu_check(int rc)
 {
@@ -59,10 +69,24 @@ static void gpu_check(int rc)
 static void gpu_init(void)
 {
   double box[9];
-  int pbc[3], cd[3], gd[3], cpu[3] = {1, 1, 1}, me[3] = {0, 0, 0};
+  int pbc[3], cd[3], gd[3], cpu[3] = {1, 1, 1}, me[3] = {0, 0, 0}, dev = 0;
   if (G) return;
-  if (cpu_dim.x * cpu_dim.y * cpu_dim.z != 1) error("imd_shim: single-rank builds only (see INTEGRATION.md)");
-  gpu_check(imdgpu_create(&G, 0));
+#ifdef MPI
+  g_multi = cpu_dim.x * cpu_dim.y * cpu_dim.z != 1;
+#ifndef NBL
+  if (g_multi) error("imd_shim: several ranks need the neighbour-list build (-DNBL)");
+#endif
+  if (g_multi) {
+    int ndev = 1;
+    cpu[0] = cpu_dim.x; cpu[1] = cpu_dim.y; cpu[2] = cpu_dim.z;
+    me[0] = my_coord.x; me[1] = my_coord.y; me[2] = my_coord.z;
+    if (imdgpu_device_count(&ndev) || ndev < 1) error("imd_shim: no GPU");
+    dev = getenv("IMD_SHIM_DEVICE") ? atoi(getenv("IMD_SHIM_DEVICE")) : myid % ndev;
+  }
+#else
+  if (cpu_dim.x * cpu_dim.y * cpu_dim.z != 1) error("imd_shim: several ranks need an MPI build");
+#endif
+  gpu_check(imdgpu_create(&G, dev));
   box[0] = box_x.x; box[1] = box_x.y; box[2] = box_x.z;
   box[3] = box_y.x; box[4] = box_y.y; box[5] = box_y.z;
   box[6] = box_z.x; box[7] = box_z.y; box[8] = box_z.z;
@@ -154,6 +178,68 @@ static int gather_cells(int with_all)
   return n;
 }
 
+#if defined(NBL) && defined(MPI)
+/* With AR (actio = reactio; forced for NBL builds, config.h:150-153) the reference's send_cells only fills the buffer
+ * layer at cell_dim.x-1: its half list lets every rank compute the pairs across the other face and send the forces
+ * back.  The device list is symmetric and needs the layer at x = 0 as well: this is the transfer send_cells itself
+ * makes without AR (imd_comm_force_3d.c:356-392), with the reference's own pack/unpack functions and buffers, after
+ * the y and z stages like there. */
+static void send_cells_west(void (*copy_func)(int, int, int, int, int, int, vektor),
+                            void (*pack_func)(msgbuf *, int, int, int, vektor), void (*unpack_func)(msgbuf *, int, int, int))
+{
+  int i, j;
+  vektor wvec = {0, 0, 0};
+  if (pbc_dirs.x == 1 && my_coord.x == cpu_dim.x - 1) { wvec.x = -box_x.x; wvec.y = -box_x.y; wvec.z = -box_x.z; }
+  if (cpu_dim.x == 1) {
+    for (i = 0; i < cell_dim.y; ++i)
+      for (j = 0; j < cell_dim.z; ++j) (*copy_func)(cell_dim.x - 2, i, j, 0, i, j, wvec);
+  } else {
+    MPI_Request req[2];
+    MPI_Status  st[2];
+    send_buf_west.n = 0; recv_buf_east.n = 0;
+    for (i = 0; i < cell_dim.y; ++i)
+      for (j = 0; j < cell_dim.z; ++j) (*pack_func)(&send_buf_west, cell_dim.x - 2, i, j, wvec);
+    irecv_buf(&recv_buf_east, nbeast, &req[1]);
+    isend_buf(&send_buf_west, nbwest, &req[0]);
+    MPI_Waitall(2, req, st);
+    recv_buf_east.n = 0;
+    for (i = 0; i < cell_dim.y; ++i)
+      for (j = 0; j < cell_dim.z; ++j) (*unpack_func)(&recv_buf_east, 0, i, j);
+  }
+}
+
+/* the buffer cells as send_cells left them: counts per cell (inner cells 0), atoms in cell order */
+static void gather_ghosts(int with_dF)
+{
+  int c, i, n = 0;
+  if (NULL == g_inner) {
+    g_inner = (char *) calloc(nallcells, 1); g_gcn = (int *) calloc(nallcells, sizeof(int));
+    if (!g_inner || !g_gcn) error("imd_shim: cannot allocate ghost tables");
+  }
+  memset(g_inner, 0, nallcells);
+  for (c = 0; c < NCELLS; c++) g_inner[SHIM_CELLIDX(CELLPTR(c))] = 1;
+  for (c = 0; c < nallcells; c++) { g_gcn[c] = g_inner[c] ? 0 : cell_array[c].n; n += g_gcn[c]; }
+  if (n > g_gcap) {
+    g_gcap = n + n / 8 + 1024;
+    g_gort = (double *) realloc(g_gort, 3 * g_gcap * sizeof(double)); g_gdF = (double *) realloc(g_gdF, g_gcap * sizeof(double));
+    g_gsorte = (int *) realloc(g_gsorte, g_gcap * sizeof(int));
+    if (!g_gort || !g_gdF || !g_gsorte) error("imd_shim: cannot allocate ghost staging arrays");
+  }
+  g_nghost = n;
+  for (c = 0, n = 0; c < nallcells; c++) {
+    cell *p = cell_array + c;
+    if (g_inner[c]) continue;
+    for (i = 0; i < p->n; i++, n++) {
+      g_gort[3 * n] = ORT(p, i, X); g_gort[3 * n + 1] = ORT(p, i, Y); g_gort[3 * n + 2] = ORT(p, i, Z);
+      g_gsorte[n] = SORTE(p, i);
+#ifdef EAM2
+      if (with_dF) g_gdF[n] = EAM_DF(p, i);
+#endif
+    }
+  }
+}
+#endif
+
 #ifdef NBL
 void make_nblist(void)
 {
@@ -162,11 +248,20 @@ void make_nblist(void)
   ensure_host(n);
   gather_cells(1);
   gpu_check(imdgpu_upload_cells(G, g_cn, n, g_ort, g_imp, g_mas, g_sorte, g_num));
+#ifdef MPI
+  if (g_multi) {                                  /* the caller has just run send_cells(copy_cell, ...) */
+    int changed = 0;
+    gather_ghosts(0);
+    gpu_check(imdgpu_upload_ghosts(G, g_gcn, g_nghost, g_gort, g_gsorte));
+    gpu_check(imdgpu_autotile(G, &changed));      /* first list: tile shape from the real occupancies */
+    if (changed) gpu_check(imdgpu_upload_ghosts(G, g_gcn, g_nghost, g_gort, g_gsorte));
+  }
+#endif
   gpu_check(imdgpu_make_nblist(G));
   g_have_cells = 1;
   /* this fork keeps tl/tb/cl_off in globals.h:184-188 for other modules (imd_nrb.c): publish the list in the
    * reference's own half-list format unless IMD_SHIM_NO_NBL_EXPORT is set */
-  if (getenv("IMD_SHIM_NO_NBL_EXPORT") == NULL) {
+  if (getenv("IMD_SHIM_NO_NBL_EXPORT") == NULL && !g_multi) {
     int ntb = 0;
     gpu_check(imdgpu_export_nblist(G, NULL, NULL, NULL, &ntb));
     tl = (int *) realloc(tl, (n + 1) * sizeof(int));
@@ -175,6 +270,12 @@ void make_nblist(void)
     if (!tl || !tb || !cl_off) error("imd_shim: cannot allocate neighbor table");
     gpu_check(imdgpu_export_nblist(G, tl, tb, cl_off, &ntb));
     nb_max = ntb;
+  }
+  if (g_multi) {                                 /* several ranks: the globals exist but hold an empty list */
+    tl = (int *) realloc(tl, (n + 1) * sizeof(int)); tb = (int *) realloc(tb, sizeof(int));
+    cl_off = (int *) realloc(cl_off, nallcells * sizeof(int));
+    if (!tl || !tb || !cl_off) error("imd_shim: cannot allocate neighbor table");
+    memset(tl, 0, (n + 1) * sizeof(int)); tb[0] = 0; memset(cl_off, 0, nallcells * sizeof(int));
   }
   for (k = 0; k < ncells; k++) {                 /* reference positions, imd_forces_nbl.c:143-155 */
     cell *p = cell_array + cnbrs[k].np;
@@ -209,6 +310,9 @@ void check_nblist(void)
       if (r2 > max1) max1 = r2;
     }
   }
+#ifdef MPI
+  { real max2; MPI_Allreduce(&max1, &max2, 1, REAL, MPI_MAX, cpugrid); max1 = max2; }      /* :1087 */
+#endif
   if (max1 > SQR(0.5 * nbl_margin)) have_valid_nbl = 0;
 }
 
@@ -222,12 +326,25 @@ void calc_forces(int steps)
 #ifdef NBL
   if (0 == have_valid_nbl) {
     fix_cells();                                  /* the host's own re-binning, imd_forces_nbl.c:300-308 */
+#ifdef MPI
+    if (g_multi) {
+      if (0 == nbl_count % BUFSTEP) setup_buffers();                       /* :304 */
+      send_cells(copy_cell, pack_cell, unpack_cell);                        /* :311 */
+      send_cells_west(copy_cell, pack_cell, unpack_cell);
+    }
+#endif
     make_nblist();
   } else {
+#ifdef MPI
+    if (g_multi) { send_cells(copy_cell, pack_cell, unpack_cell); send_cells_west(copy_cell, pack_cell, unpack_cell); }   /* :311 */
+#endif
     n = count_atoms();
     ensure_host(n);
     gather_cells(0);
     gpu_check(imdgpu_update_positions(G, n, g_ort));
+#ifdef MPI
+    if (g_multi) { gather_ghosts(0); gpu_check(imdgpu_update_ghosts(G, g_nghost, g_gort, NULL)); }
+#endif
   }
 #else
   /* cell-pair variant: the main loop has re-binned (fix_cells, imd_main_3d.c:815); all pairs of this arrangement */
@@ -239,6 +356,26 @@ void calc_forces(int steps)
   g_have_cells = 1;
 #endif
   n = count_atoms();
+#if defined(NBL) && defined(MPI)
+  if (g_multi) {
+    double ek = 0; int nc = 0;
+    gpu_check(imdgpu_forces_phase(G, 1));                                   /* pair + rho */
+    gpu_check(imdgpu_forces_phase(G, 2));                                   /* embedding */
+#ifdef EAM2
+    gpu_check(imdgpu_download_atoms(G, NULL, NULL, NULL, NULL, NULL, NULL, g_dF, NULL, NULL, NULL, NULL));
+    for (k = 0, m = 0; k < NCELLS; k++) { cell *p = CELLPTR(k); for (i = 0; i < p->n; i++, m++) EAM_DF(p, i) = g_dF[m]; }
+    m = 0;
+    send_cells(copy_dF, pack_dF, unpack_dF);                                /* :786 */
+    send_cells_west(copy_dF, pack_dF, unpack_dF);
+    gather_ghosts(1);
+    gpu_check(imdgpu_update_ghosts(G, g_nghost, NULL, g_gdF));
+#endif
+    gpu_check(imdgpu_forces_phase(G, 3));                                   /* EAM forces + sums */
+    gpu_check(imdgpu_get_sums(G, sums, &ek, &nc));
+    { double loc[2], glob[2]; loc[0] = sums[0]; loc[1] = sums[1];
+      MPI_Allreduce(loc, glob, 2, MPI_DOUBLE, MPI_SUM, cpugrid); sums[0] = glob[0]; sums[1] = glob[1]; }      /* :1007 */
+  } else
+#endif
   gpu_check(imdgpu_calc_forces(G, steps, sums, &is_short));
   gpu_check(imdgpu_download_atoms(G, NULL, NULL, NULL, g_kraft, g_epot, g_rho, g_dF, g_nn, NULL, NULL, NULL));
   for (k = 0; k < NCELLS; k++) {
@@ -327,6 +464,7 @@ void calc_ttm(void)
   int n, i, j, k, c = 0;
   double mdt = 0.0;
   gpu_init();
+  if (g_multi) error("imd_shim: calc_ttm on several ranks is not wired into the shim yet (the library has it: INTEGRATION.md)");
   if (!g_have_cells) error("imd_shim: calc_ttm before calc_forces");
   if (!g_ttm_ready) ttm_gpu_init();
   fd_n_timesteps = 100; diff_substeps = fd_n_timesteps;              /* imd_ttm_3D.c:51-52 */

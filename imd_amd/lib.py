@@ -22,7 +22,7 @@ SYMBOLS = [
     "imdgpu_ttm_init", "imdgpu_ttm_dims", "imdgpu_ttm_download", "imdgpu_ttm_upload", "imdgpu_ttm_update_fd", "imdgpu_ttm_adv", "imdgpu_ttm_commflux", "imdgpu_ttm_laser_rescale", "imdgpu_ttm_set_laser", "imdgpu_ttm_get_eabs",
     "imdgpu_ttm_cell_activation", "imdgpu_ttm_fillmesh", "imdgpu_ttm_fill_ghost_layers", "imdgpu_ttm_diff",
     "imdgpu_ttm_cfl_maxdt", "imdgpu_calc_ttm", "imdgpu_move_atoms_ttm", "imdgpu_ttm_eos_te_from_r_ee",
-    "imdgpu_get_cell_tables", "imdgpu_autotile", "imdgpu_set_ghost_layout", "imdgpu_halo_gather", "imdgpu_halo_gather2", "imdgpu_halo_scatter",
+    "imdgpu_get_cell_tables", "imdgpu_upload_ghosts", "imdgpu_update_ghosts", "imdgpu_device_count", "imdgpu_autotile", "imdgpu_set_ghost_layout", "imdgpu_halo_gather", "imdgpu_halo_gather2", "imdgpu_halo_scatter",
     "imdgpu_migrate_scan", "imdgpu_migrate_gather", "imdgpu_migrate_apply", "imdgpu_forces_phase", "imdgpu_integrate",
     "imdgpu_get_invalid", "imdgpu_invalidate", "imdgpu_ttm_local_block", "imdgpu_ttm_apply_blocks",
     "imdgpu_ttm_lattice_step", "imdgpu_ttm_mailbox_bytes", "imdgpu_ttm_mailbox_attach", "imdgpu_ttm_local_step",
@@ -104,6 +104,9 @@ def load():
     L.imdgpu_num_atoms.argtypes = [vp, ip, ip]
     L.imdgpu_update_positions.argtypes = [vp, C.c_int, dp]
     L.imdgpu_update_momenta.argtypes = [vp, C.c_int, dp]
+    L.imdgpu_upload_ghosts.argtypes = [vp, ip, C.c_int, dp, ip]
+    L.imdgpu_update_ghosts.argtypes = [vp, C.c_int, dp, dp]
+    L.imdgpu_device_count.argtypes = [ip]
     L.imdgpu_download_atoms.argtypes = [vp, ip, dp, dp, dp, dp, dp, dp, ip, ip, ip, dp]
     for f in ("imdgpu_fix_cells", "imdgpu_fill_ghosts", "imdgpu_make_nblist"):
         getattr(L, f).argtypes = [vp]

@@ -232,6 +232,14 @@ int imdgpu_get_cell_tables(imdgpu_ctx *ctx, int *cell_start /*nallcells*/, int *
  * local atoms were re-sorted and the halo index lists must be rebuilt */
 int imdgpu_autotile(imdgpu_ctx *ctx, int *changed);
 int imdgpu_set_ghost_layout(imdgpu_ctx *ctx, const int *cell_start, const int *cell_cnt, int nghost);
+/* Host-buffer variants for a C host that keeps the reference's OWN halo exchange (level-1 shim in an MPI build: after
+ * send_cells(copy_cell, ...), imd_forces_nbl.c:311, the host's buffer cells hold the ghost atoms; after
+ * send_cells(copy_dF, ...), :786, their EAM_DF).  ghost_cell_n: atoms per cell for all nallcells cells, 0 for inner
+ * cells; ort / sorte / dF: the ghost atoms in cell order (cell index ascending, slots as on the host). */
+int imdgpu_upload_ghosts(imdgpu_ctx *ctx, const int *ghost_cell_n, int nghost, const double *ort, const int *sorte);
+int imdgpu_update_ghosts(imdgpu_ctx *ctx, int nghost, const double *ort /*or NULL*/, const double *dF /*or NULL*/);
+/* number of visible GPUs (to spread the ranks of a node) */
+int imdgpu_device_count(int *n);
 /* what: 0 = (x,y,z,dF) record of 4 doubles, positions shifted by `shift` (periodic image,
  *       imd_comm_force_3d.c:247-266); 1 = dF only (1 double) [copy_dF]; 2 = type (int);
  *       3 = shifted position only (3 doubles): the per-step position halo */

@@ -55,7 +55,7 @@ build() {
   echo "built $OUT/imd_$name"
 }
 
-TARGETS="${*:-eam_nve_nbl nve_nbl eam_nve mpi_eam_ttm3d_nbl mpi_eam_ttm3d_laser_nbl dropin}"
+TARGETS="${*:-eam_nve_nbl nve_nbl eam_nve mpi_eam_nve_nbl mpi_eam_ttm3d_nbl mpi_eam_ttm3d_laser_nbl dropin}"
 for t in $TARGETS; do
   case "$t" in
     eam_nve_nbl) build "$t" "-DNBL -DEAM2 -DNVE" "$COMMON $NBLSRC" "$CC" "" ;;
@@ -171,3 +171,30 @@ build_dropin_ttm() {
   echo "built $OUT/imd_$name"
 }
 case " $TARGETS " in *" dropin "*) build_dropin_ttm ;; esac
+
+# The MPI force program on several ranks with the shim: the reference keeps its own decomposition, migration and halo
+# exchange (send_cells inside the shim's calc_forces where imd_forces_nbl.c has them); every rank drives a GPU.
+# tests/test_gpu_dropin.py runs it with mpiexec -n 2 beside oracle/_ref/imd_mpi_eam_nve_nbl.
+build_dropin_mpi() {
+  local name="mpi_eam_nve_nbl_gpu" defs="-DMPI -DNBL -DEAM2 -DNVE"
+  local obj="$OUT/obj_$name" repo="$(cd "$HERE/.." && pwd)"
+  local MPIINC="${MPI_HOME:-/opt/conda}"
+  [ -f "$repo/imd_amd/csrc/libimdgpu.so" ] || { echo "libimdgpu.so not built, skipping drop-in" >&2; return 0; }
+  [ -f "$MPIINC/include/mpi.h" ] || { echo "no MPI at $MPIINC, skipping $name" >&2; return 0; }
+  local cc="$CC -I$MPIINC/include"
+  mkdir -p "$obj"
+  local objs=""
+  for s in $COMMON imd_geom_mpi_3d.c imd_comm_force_3d.c imd_fix_cells_3d.c imd_mpiio.c imd_mpi_util.c; do
+    local o="$obj/${s%.c}.o"
+    if [ ! -f "$o" ] || [ "$REF/$s" -nt "$o" ]; then $cc $BASEFLAGS $defs -c "$REF/$s" -o "$o" & fi
+    objs="$objs $o"
+  done
+  wait
+  $cc $BASEFLAGS $defs -I"$repo/include" -c "$repo/imd_amd/host/imd_shim.c" -o "$obj/imd_shim.o"
+  $cc $BASEFLAGS $defs -c "$HERE/ref_probe.c" -o "$obj/ref_probe.o"
+  $cc -o "$OUT/imd_$name" $objs "$obj/imd_shim.o" "$obj/ref_probe.o" -Wl,--wrap=calc_forces \
+      "$REF/nn_interpol/libnn.a" -L"$repo/imd_amd/csrc" -limdgpu -Wl,-rpath,/root/repo/imd_amd/csrc \
+      -Wl,-rpath-link,/usr/lib/x86_64-linux-gnu "$MPIINC/lib/libmpi.so" -Wl,-rpath,"$MPIINC/lib" -lm
+  echo "built $OUT/imd_$name"
+}
+case " $TARGETS " in *" dropin "*) build_dropin_mpi ;; esac

@@ -181,3 +181,52 @@ def test_reference_ttm_main_loop_on_gpu_forces_and_gpu_calc_ttm():
         assert np.abs(A["impuls"][oa] - B["impuls"][ob]).max() < 1e-9 * np.abs(B["impuls"]).max(), s
         assert np.array_equal(A["numneighs"][oa], B["numneighs"][ob])
     assert np.allclose(out["gpu"]["ttm_file"], out["cpu"]["ttm_file"], rtol=2e-6, atol=1e-12)
+
+
+CPU_MPI = os.path.join(ROOT, "oracle", "_ref", "imd_mpi_eam_nve_nbl")
+GPU_MPI = os.path.join(ROOT, "oracle", "_ref", "imd_mpi_eam_nve_nbl_gpu")
+
+
+def _mpiexec():
+    import shutil
+    for c in (shutil.which("mpiexec"), "/opt/conda/bin/mpiexec"):
+        if c and os.path.exists(c):
+            return c
+    return None
+
+
+@pytest.mark.skipif(not (os.path.exists(CPU_MPI) and os.path.exists(GPU_MPI) and _mpiexec()), reason="MPI binaries / mpiexec not there")
+@pytest.mark.parametrize("cpu_dim", ["2 1 1", "2 2 1"])
+def test_reference_mpi_program_on_gpu_forces(cpu_dim):
+    """The reference's MPI build on 2 and 4 ranks (mpiexec; the ranks share cuda:0) with the shim in place of
+    imd_forces_nbl.o: the host keeps its decomposition, migration (fix_cells) and halo exchange (send_cells for the
+    buffer cells and for EAM_DF), every rank's forces come from the device.  Per rank the same atoms with the same
+    forces / energies / positions as the CPU build on the same decomposition over 30 steps."""
+    nranks = int(np.prod([int(v) for v in cpu_dim.split()]))
+    # msgbuf_size: the reference's own estimate of its MPI buffers is too small for this box (pack_cell aborts), CPU build too
+    param = PARAM.replace("cpu_dim 1 1 1", "cpu_dim " + cpu_dim) + "msgbuf_size 4000000\n"
+    out = {}
+    for tag, exe in (("cpu", CPU_MPI), ("gpu", GPU_MPI)):
+        with tempfile.TemporaryDirectory() as d:
+            potential.write_synthetic_eam_files(d)
+            open(os.path.join(d, "t.param"), "w").write(param)
+            env = dict(os.environ, IMD_PROBE_DIR=d, IMD_PROBE_STEPS="0,1,30", IMD_SHIM_DEVICE="0")
+            r = subprocess.run([_mpiexec(), "-n", str(nranks), exe, "-p", "t.param"], cwd=d, env=env, stdout=subprocess.PIPE,
+                               stderr=subprocess.STDOUT, text=True, timeout=600)
+            assert r.returncode == 0, r.stdout[-3000:]
+            out[tag] = {(rk, s): po.read_probe(os.path.join(d, "probe.%d.%d.bin" % (rk, s))) for rk in range(nranks) for s in (0, 1, 30)}
+            out[tag]["eng"] = np.loadtxt(os.path.join(d, "out.eng"))
+    fmax = max(np.abs(out["cpu"][(rk, 30)]["kraft"]).max() for rk in range(nranks))
+    for rk in range(nranks):
+        for s in (0, 1, 30):
+            a, b = out["gpu"][(rk, s)], out["cpu"][(rk, s)]
+            ia, ib = _inner_ids(a), _inner_ids(b)
+            oa, ob = np.argsort(ia), np.argsort(ib)
+            assert np.array_equal(ia[oa], ib[ob]), "rank %d step %d: different atoms" % (rk, s)
+            assert np.abs(a["kraft"][oa] - b["kraft"][ob]).max() < 1e-9 * fmax, (rk, s)
+            assert np.abs(a["pot_eng"][oa] - b["pot_eng"][ob]).max() < 1e-10
+            assert np.abs(a["eam_rho"][oa] - b["eam_rho"][ob]).max() < 1e-10
+            assert abs(a["tot_pot_energy"] - b["tot_pot_energy"]) < 1e-9 * abs(b["tot_pot_energy"])
+            assert np.abs(_inner_pos(a)[oa] - _inner_pos(b)[ob]).max() < 1e-9
+        assert out["gpu"][(rk, 30)]["nbl_count"] == out["cpu"][(rk, 30)]["nbl_count"] >= 2
+    assert np.allclose(out["gpu"]["eng"], out["cpu"]["eng"], rtol=1e-6, atol=1e-9)
