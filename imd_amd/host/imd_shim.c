@@ -46,11 +46,17 @@
  * builds leave out (send_cells_west below) -- and hands the buffer cells to the library
  * (imdgpu_upload_ghosts / imdgpu_update_ghosts).  The two reverse exchanges of the reference (send_forces for rho
  * and for the forces, :745, :1052) are not needed: the device list is symmetric, every rank computes complete
- * forces and densities for its own atoms.  Sums are reduced with MPI_Allreduce like :1007.  (calc_ttm of the shim is
- * single-rank for now.)
+ * forces and densities for its own atoms.  Sums are reduced with MPI_Allreduce like :1007.  calc_ttm on several ranks:
+ * one lattice block per rank (option ttm_decomposed), the per-sub-step ghost faces through the library's mailbox in
+ * host shared memory (the ranks of one node).
  */
 #include "imd.h"
 #include "imdgpu.h"
+#if defined(TTM) && defined(MPI)
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
+#endif
 
 static imdgpu_ctx *G = NULL;
 static int   g_cap = 0, g_have_cells = 0;
@@ -437,8 +443,47 @@ static void ttm_gpu_init(void)
   par.cve_ymin = intp_cve_from_r_te.ymin; par.cve_ymax = intp_cve_from_r_te.ymax; par.cve_z = zc;
   par.ee_xmin = intp_ee_from_r_tesqrt.xmin; par.ee_xmax = intp_ee_from_r_tesqrt.xmax;
   par.ee_ymin = intp_ee_from_r_tesqrt.ymin; par.ee_ymax = intp_ee_from_r_tesqrt.ymax; par.ee_z = ze;
-  if (getenv("IMD_SHIM_TTM_ADV")) gpu_check(imdgpu_set_option(G, "ttm_adv", 1));
+  if (getenv("IMD_SHIM_TTM_ADV")) {
+    if (g_multi) error("imd_shim: IMD_SHIM_TTM_ADV on several ranks is not wired into the shim");
+    gpu_check(imdgpu_set_option(G, "ttm_adv", 1));
+  }
+#ifdef MPI
+  if (g_multi) gpu_check(imdgpu_set_option(G, "ttm_decomposed", 1));    /* one lattice block per rank, like l1/l2 */
+#endif
   gpu_check(imdgpu_ttm_init(G, &par));
+#ifdef MPI
+  if (g_multi) {
+    /* the ghost faces of {natoms, temp, fd_k} that ttm_fill_ghost_layers moves with MPI_Sendrecv after every sub-step
+     * (imd_ttm_3D.c:3314-3504) go through the library's mailbox in host shared memory, written and read by the GPUs
+     * themselves (one node): rank 0 creates the file, everybody maps it */
+    size_t per = 0;
+    char name[256];
+    int fd, nbr[6], nranks = cpu_dim.x * cpu_dim.y * cpu_dim.z;
+    void *base;
+    gpu_check(imdgpu_ttm_mailbox_bytes(G, &per));
+    memset(name, 0, sizeof(name));
+    if (0 == myid) {
+      sprintf(name, "/dev/shm/imdgpu_ttm_%d", (int) getpid());
+      fd = open(name, O_CREAT | O_RDWR | O_TRUNC, 0600);
+      if (fd < 0 || ftruncate(fd, (off_t) (per * nranks)) != 0) error("imd_shim: cannot create the TTM mailbox in /dev/shm");
+      close(fd);
+    }
+    MPI_Bcast(name, sizeof(name), MPI_CHAR, 0, cpugrid);
+    fd = open(name, O_RDWR);
+    if (fd < 0) error("imd_shim: cannot open the TTM mailbox");
+    base = mmap(NULL, per * nranks, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (MAP_FAILED == base) error("imd_shim: cannot map the TTM mailbox");
+    /* east = -x, west = +x, north = -y, south = +y, up = -z, down = +z (imd_ttm_3D.c:680-687); -1 = open boundary */
+    nbr[0] = nbeast; nbr[1] = nbwest; nbr[2] = nbnorth; nbr[3] = nbsouth; nbr[4] = nbup; nbr[5] = nbdown;
+    if (pbc_dirs.x != 1) { if (my_coord.x == 0) nbr[0] = -1; if (my_coord.x == cpu_dim.x - 1) nbr[1] = -1; }
+    if (pbc_dirs.y != 1) { if (my_coord.y == 0) nbr[2] = -1; if (my_coord.y == cpu_dim.y - 1) nbr[3] = -1; }
+    if (pbc_dirs.z != 1) { if (my_coord.z == 0) nbr[4] = -1; if (my_coord.z == cpu_dim.z - 1) nbr[5] = -1; }
+    gpu_check(imdgpu_ttm_mailbox_attach(G, base, per, myid, nranks, nbr));
+    MPI_Barrier(cpugrid);
+    if (0 == myid) unlink(name);
+  }
+#endif
 #ifdef LASER
   if (laser_rescale_mode == 4) {                       /* laser_rescale_ttm (imd_laser.c:715-788) inside calc_ttm */
     imdgpu_laser_params lp;
@@ -464,7 +509,6 @@ void calc_ttm(void)
   int n, i, j, k, c = 0;
   double mdt = 0.0;
   gpu_init();
-  if (g_multi) error("imd_shim: calc_ttm on several ranks is not wired into the shim yet (the library has it: INTEGRATION.md)");
   if (!g_have_cells) error("imd_shim: calc_ttm before calc_forces");
   if (!g_ttm_ready) ttm_gpu_init();
   fd_n_timesteps = 100; diff_substeps = fd_n_timesteps;              /* imd_ttm_3D.c:51-52 */
@@ -473,8 +517,12 @@ void calc_ttm(void)
   ensure_host(n);
   gather_cells(1);
   gpu_check(imdgpu_update_momenta(G, n, g_imp));
-  gpu_check(imdgpu_calc_ttm(G, steps));
+  if (g_multi) gpu_check(imdgpu_ttm_local_step(G, steps));      /* this rank's block; faces through the mailbox */
+  else gpu_check(imdgpu_calc_ttm(G, steps));
   gpu_check(imdgpu_ttm_cfl_maxdt(G, steps, &mdt));
+#ifdef MPI
+  if (g_multi) { double m2; MPI_Allreduce(&mdt, &m2, 1, MPI_DOUBLE, MPI_MIN, cpugrid); mdt = m2; }   /* :2683-2687 */
+#endif
   max_dt_ttm = mdt;
   memset(&F, 0, sizeof(F));
   F.natoms = g_fi[0]; F.natoms_old = g_fi[1];

@@ -230,3 +230,43 @@ def test_reference_mpi_program_on_gpu_forces(cpu_dim):
             assert np.abs(_inner_pos(a)[oa] - _inner_pos(b)[ob]).max() < 1e-9
         assert out["gpu"][(rk, 30)]["nbl_count"] == out["cpu"][(rk, 30)]["nbl_count"] >= 2
     assert np.allclose(out["gpu"]["eng"], out["cpu"]["eng"], rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.skipif(not (os.path.exists(CPU_TTM) and os.path.exists(GPU_TTM) and _mpiexec()), reason="MPI binaries / mpiexec not there")
+@pytest.mark.parametrize("cpu_dim", ["2 1 1", "2 2 1"])
+def test_reference_mpi_ttm_program_on_gpu(cpu_dim):
+    """The 3D-TTM program on 2 and 4 ranks with calc_forces AND calc_ttm from the shim: forces with the host's own halo
+    exchange, the electron lattice as one block per rank (like l1/l2) with the per-sub-step ghost faces going through the
+    library's shared-memory mailbox instead of ttm_fill_ghost_layers' MPI_Sendrecv.  Per rank: lattice block (what
+    move_atoms_ttm reads, and temp, U, fd_k, ...) within 1e-9 of the CPU build on the same decomposition, atoms within 1e-9."""
+    nranks = int(np.prod([int(v) for v in cpu_dim.split()]))
+    param = PARAM_TTM.replace("cpu_dim 1 1 1", "cpu_dim " + cpu_dim)
+    out = {}
+    steps = (0, 1, 6, 12)
+    for tag, exe in (("cpu", CPU_TTM), ("gpu", GPU_TTM)):
+        with tempfile.TemporaryDirectory() as d:
+            potential.write_synthetic_eam_files(d)
+            _write_planar_eos(d)
+            open(os.path.join(d, "t.param"), "w").write(param)
+            env = dict(os.environ, IMD_PROBE_DIR=d, IMD_PROBE_STEPS=",".join(map(str, steps)), IMD_SHIM_DEVICE="0")
+            r = subprocess.run([_mpiexec(), "-n", str(nranks), exe, "-p", "t.param"], cwd=d, env=env, stdout=subprocess.PIPE,
+                               stderr=subprocess.STDOUT, text=True, timeout=600)
+            assert r.returncode == 0, r.stdout[-3000:]
+            out[tag] = {(rk, s): po.read_probe(os.path.join(d, "probe.%d.%d.bin" % (rk, s))) for rk in range(nranks) for s in steps}
+            out[tag]["lat"] = {(rk, s): po.read_ttm_probe(os.path.join(d, "ttm.%d.%d.bin" % (rk, s)))["stages"]["cfl"]
+                               for rk in range(nranks) for s in steps}
+    inner = (slice(1, -1),) * 3
+    for rk in range(nranks):
+        for s in steps:
+            a, b = out["gpu"]["lat"][(rk, s)], out["cpu"]["lat"][(rk, s)]
+            assert np.array_equal(a["lat"]["natoms"][inner], b["lat"]["natoms"][inner]), (rk, s)
+            for f in ("temp", "temp2", "U", "U2", "xi", "md_temp", "dens", "vcom", "fd_k", "fd_g", "Ce"):
+                x, y = a["lat"][f][inner], b["lat"][f][inner]
+                assert np.abs(x - y).max() <= 1e-9 * np.abs(y).max(), (rk, s, f)
+            assert abs(a["max_dt_ttm"] - b["max_dt_ttm"]) <= 1e-9 * abs(b["max_dt_ttm"])
+            A, B = out["gpu"][(rk, s)], out["cpu"][(rk, s)]
+            ia, ib = _inner_ids(A), _inner_ids(B)
+            oa, ob = np.argsort(ia), np.argsort(ib)
+            assert np.array_equal(ia[oa], ib[ob])
+            assert np.abs(_inner_pos(A)[oa] - _inner_pos(B)[ob]).max() < 1e-9, (rk, s)
+            assert np.array_equal(A["numneighs"][oa], B["numneighs"][ob])
