@@ -31,3 +31,28 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".c", ".cpp", "Makefile")):
                 txt = open(os.path.join(dp, f)).read()
                 assert not pat.search(txt), "%s references the oracle" % os.path.join(dp, f)
+
+
+def test_shim_compiles_in_every_build_variant_of_the_reference():
+    """imd_amd/host/imd_shim.c is compiled inside the reference tree with the target's own flags: the serial
+    neighbour-list build, the cell-pair build, the MPI build, the 3D-TTM build and the TTM + LASER build must all
+    compile (dev container only: needs the reference's headers)."""
+    import subprocess
+    ref = os.environ.get("IMD_REFERENCE", "/root/reference")
+    if not os.path.isdir(ref):
+        import pytest
+        pytest.skip("reference tree not present")
+    mpi = "/opt/conda/include"
+    variants = {
+        "serial NBL": ["-DNBL", "-DEAM2", "-DNVE"],
+        "cell pair": ["-DEAM2", "-DNVE"],
+        "pair only": ["-DNBL", "-DNVE"],
+    }
+    if os.path.exists(os.path.join(mpi, "mpi.h")):
+        variants["MPI NBL"] = ["-DMPI", "-DNBL", "-DEAM2", "-DNVE", "-I" + mpi]
+        variants["MPI TTM"] = ["-DMPI", "-DNBL", "-DEAM2", "-DTTM", "-DTMM", "-DEOSMODE=1", "-I" + mpi]
+        variants["MPI TTM LASER"] = ["-DMPI", "-DNBL", "-DEAM2", "-DTTM", "-DTMM", "-DEOSMODE=1", "-DLASER", "-I" + mpi]
+    for name, flags in variants.items():
+        r = subprocess.run(["gcc", "-fsyntax-only", "-fcommon", "-w", "-I" + ref, "-I" + os.path.join(ROOT, "include")] + flags +
+                           [os.path.join(ROOT, "imd_amd", "host", "imd_shim.c")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, "%s: %s" % (name, r.stdout[-1500:])
