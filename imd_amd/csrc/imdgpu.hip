@@ -851,7 +851,9 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile(TileArgs a)
 #else
 #define SCHED_BARRIER __builtin_amdgcn_sched_barrier(0)
 #endif
-#define UNR 4
+#ifndef UNR
+#define UNR 4                     // neighbours in flight per wave and phase (4 = one list word; 2 = half a word: fewer registers)
+#endif
 // experiment (make EXTRA=-DIMDGPU_LDSPRIO): raised wave priority while a wave issues its LDS gathers
 #ifdef IMDGPU_LDSPRIO
 #define PRIO_HI __builtin_amdgcn_s_setprio(2)
@@ -902,7 +904,15 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile(TileArgs a)
         }                                                                                                        \
         const unsigned curx = (k4 & 1) ? c1x : c0x, cury = (k4 & 1) ? c1y : c0y;                                 \
         if (k4 & 1) { c0x = m0x; c0y = m0y; c1x = m1x; c1y = m1y; }   /* odd trip: hand over (loads are ~8 neighbours old) */ \
-        const int j[UNR] = {(int) (curx & 0xffffu), (int) (curx >> 16), (int) (cury & 0xffffu), (int) (cury >> 16)};
+        const int j4[4] = {(int) (curx & 0xffffu), (int) (curx >> 16), (int) (cury & 0xffffu), (int) (cury >> 16)};     \
+        HALF_BEGIN
+#if UNR == 4
+#define HALF_BEGIN { const int *j = j4;
+#define HALF_END }
+#else
+#define HALF_BEGIN _Pragma("unroll") for (int hh = 0; hh < 4 / UNR; hh++) { const int j[2] = {j4[2 * hh], j4[2 * hh + 1]};
+#define HALF_END SCHED_BARRIER; }
+#endif
 #define TILE_EPILOGUE                                                                                            \
     if (T.tile + 1 < t1) stage_issue(a, T.tile + 1, info_next.x, IDX);                                           \
     info = info_next;
@@ -1033,6 +1043,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile(TileArgs a)
             }
           }
         }
+        HALF_END
       }
       if (NT1) is_short |= ((PAIR && r2min < cp.begin) || (EAM && r2min < cr.begin)) ? 1 : 0;
       a.f[i] = fx; a.f[a.cap + i] = fy; a.f[2 * (size_t) a.cap + i] = fz;
@@ -1130,6 +1141,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
           ee += A[e].x + chi[e] * dvp + h * d2p;                            // halved once per atom
           vir += r2[e] * gr;
         }
+        HALF_END
       }
       fx *= c.istep2; fy *= c.istep2; fz *= c.istep2; ee *= 0.5; vir *= -0.5 * c.istep2;
       is_short |= (r2min < c.begin) ? 1 : 0;
@@ -1257,6 +1269,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) __attribute__((amdgpu_num_vgpr(144
             vir -= 0.5 * (dx[e] * gx + dy[e] * gy + dz[e] * gz);
           }
         }
+        HALF_END
       }
       if (NT1) { is_short |= (r2min < cr.begin) ? 1 : 0; vir *= -0.5; }
       a.f[i] += fx; a.f[a.cap + i] += fy; a.f[2 * (size_t) a.cap + i] += fz;
