@@ -504,6 +504,12 @@ __global__ void k_ttm_te_from_r_ee(int n, EosDev ee, const double *r, const doub
   if (i < n) out[i] = d_te_from_r_ee(ee, r[i], e[i]);
 }
 
+__global__ void k_ttm_eos_lookup(int n, EosDev tab, const double *x, const double *y, double *out)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = eos_lookup(tab, x[i], y[i]);
+}
+
 // do_ADV (imd_ttm_3D.c:1321-1458) on a lattice that is not split over ranks -- there do_COMMFLUX (:667-995) has
 // nothing to move: the ghost columns it fills on a rank boundary are the neighbouring inner columns themselves, and
 // the ghost columns at the two global x faces keep flux 0 / U 0 from init_ttm (:1136-1157), periodic or not.
@@ -1151,6 +1157,25 @@ extern "C" int imdgpu_ttm_eos_te_from_r_ee(imdgpu_ctx *ctx, int n, const double 
   hipLaunchKernelGGL(k_ttm_te_from_r_ee, dim3(nblk(n, TTM_WG)), dim3(TTM_WG), 0, ctx->stream, n, t->ee, d, d + n, d + 2 * (size_t) n);
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipMemcpy(te_out, d + 2 * (size_t) n, n * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipFree(d));
+  return 0;
+}
+
+// the raw table look-up both EOS functions are built on (the reference: lpi_interpolate_point, imd_ttm_3D.c:2722,2759),
+// without unit factors; which = 0: cve(r, T) table, 1: ee(r, sqrt T) table; (x, y) in the table's own coordinates
+extern "C" int imdgpu_ttm_eos_lookup(imdgpu_ctx *ctx, int which, int n, const double *x, const double *y, double *z_out)
+{
+  NEED_TTM();
+  if (which != 0 && which != 1) return imdgpu_fail(ctx, "ttm_eos_lookup: which must be 0 (cve) or 1 (ee)");
+  if (n <= 0) return 0;
+  double *d = nullptr;
+  HIPCHK(hipMalloc((void **) &d, (size_t) 3 * n * sizeof(double)));
+  HIPCHK(hipMemcpy(d, x, n * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d + n, y, n * sizeof(double), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_ttm_eos_lookup, dim3(nblk(n, TTM_WG)), dim3(TTM_WG), 0, ctx->stream, n, which ? t->ee : t->cve, d, d + n,
+                     d + 2 * (size_t) n);
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpy(z_out, d + 2 * (size_t) n, n * sizeof(double), hipMemcpyDeviceToHost));
   HIPCHK(hipFree(d));
   return 0;
 }

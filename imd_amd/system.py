@@ -273,6 +273,14 @@ class GpuSystem:
         self._ck(self.L.imdgpu_ttm_eos_te_from_r_ee(self.h, int(r.size), _dp(r), _dp(e), _dp(out)))
         return out
 
+    def eos_lookup(self, which, x, y):
+        """the raw table look-up behind EOS_cve_from_r_te (which=0) / EOS_ee_from_r_te (which=1): the reference's
+        lpi_interpolate_point (imd_ttm_3D.c:2722,2759), vectorised over host arrays, table coordinates"""
+        x = np.ascontiguousarray(x, dtype=np.float64); y = np.ascontiguousarray(y, dtype=np.float64)
+        out = np.zeros_like(x)
+        self._ck(self.L.imdgpu_ttm_eos_lookup(self.h, int(which), int(x.size), _dp(x), _dp(y), _dp(out)))
+        return out
+
     def update_fd(self, steps=0):
         self._ck(self.L.imdgpu_ttm_update_fd(self.h, int(steps)))
 

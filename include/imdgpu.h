@@ -212,6 +212,11 @@ int imdgpu_ttm_diff(imdgpu_ctx *ctx, double tau);
 /* [EOS_te_from_r_ee, :2786-2811 + fminbnd3.c:6-107] electron temperature in K from density (kg/m^3) and internal
  * energy (table units) for n points on host arrays: the reference's Brent minimisation over the ee(r, sqrt T) table */
 int imdgpu_ttm_eos_te_from_r_ee(imdgpu_ctx *ctx, int n, const double *r, const double *e, double *te_out);
+/* [lpi_interpolate_point as called at :2722 (which = 1: ee(r, sqrt T) table) and :2759 (which = 0: cve(r, T) table)]
+ * the raw table look-up for n points (x, y) in the table's own coordinates on host arrays, no unit factors.  Rule:
+ * bilinear inside the grid cell; the reference's rule is linear on a Delaunay triangulation of the same nodes, which
+ * agrees at nodes and on cell edges and differs inside a cell by at most |z00 + z11 - z10 - z01| / 4 */
+int imdgpu_ttm_eos_lookup(imdgpu_ctx *ctx, int which, int n, const double *x, const double *y, double *z_out);
 /* [CFL_maxdt, :2637-2691] */
 int imdgpu_ttm_cfl_maxdt(imdgpu_ctx *ctx, int steps, double *max_dt_ttm);
 /* [calc_ttm, first block :50-77 without do_tmm/do_ADV]: update_fd, cell

@@ -358,6 +358,8 @@ def _ttm_lib():
         L.orc_eos_cve.argtypes = [tp, C.c_double, C.c_double]
         L.orc_eos_ee.restype = C.c_double
         L.orc_eos_ee.argtypes = [tp, C.c_double, C.c_double]
+        L.orc_eos_lookup.restype = C.c_double
+        L.orc_eos_lookup.argtypes = [C.POINTER(_Eos), C.c_double, C.c_double]
         L.orc_eos_te_from_r_ee.restype = C.c_double
         L.orc_eos_te_from_r_ee.argtypes = [tp, C.c_double, C.c_double]
         _TTM_READY = True
@@ -418,6 +420,10 @@ class OracleTTM:
     def cfl(self, steps, timestep, n): _ttm_lib().orc_ttm_cfl(self._p, steps, timestep, n)
     def calc_ttm(self, steps, diff_substeps): _ttm_lib().orc_ttm_calc(self._p, self.sys._p, steps, diff_substeps)
     def move_atoms_ttm(self): _ttm_lib().orc_move_atoms_ttm(self.sys._p, self._p)
+    def eos_lookup(self, which, x, y):
+        tab = self.t.ee if which else self.t.cve
+        return _ttm_lib().orc_eos_lookup(C.byref(tab), float(x), float(y))
+
     def eos_ee(self, r, tK): return _ttm_lib().orc_eos_ee(self._p, float(r), float(tK))
     def eos_te_from_r_ee(self, r, e): return _ttm_lib().orc_eos_te_from_r_ee(self._p, float(r), float(e))
 

@@ -265,6 +265,80 @@ def run_eos_inverse():
           ("eos_inverse", os.path.getsize(path) / 1024, n, np.abs(a[::3, 3] / a[::3, 1] - 1).max()))
 
 
+def _curved_tables(nr, nt):
+    """Curved, NON-separable synthetic tables on a regular (r, y) grid; both tables share the grid so that one sample
+    file serves both interpolators of the probe.  Shapes loosely follow the physics (C_e/rho rising then saturating in
+    T with a density-dependent knee; e growing like T^2 -> T) -- only the curvature matters here."""
+    r = np.linspace(500.0, 4500.0, nr)
+    y = np.linspace(1.0, 245.0, nt)
+    R, Y = np.meshgrid(r, y, indexing="ij")
+    zc = 40.0 * Y * (1.0 + 0.3 * np.sin(R / 700.0)) / (1.0 + (Y / (60.0 + R / 50.0)) ** 2) + 1e-3 * R
+    ze = 900.0 * Y * Y / (1.0 + Y / (30.0 + 0.02 * R)) * (1.0 + 0.2 * np.cos(R / 900.0 + Y / 80.0)) + 5.0 * R
+    return r, y, zc, ze
+
+
+def run_eos_grid():
+    """SURVEY 8(c) / VERDICT r1 item 2: the reference's own table interpolators (nn-c lpi_interpolate_point behind
+    EOS_cve_from_r_te / EOS_ee_from_r_te, imd_ttm_3D.c:2722,2759) evaluated on CURVED tables at every grid node, every
+    cell-edge midpoint, every cell centre and two random interior points per cell (probe option IMD_PROBE_EOSGRID,
+    oracle/ref_probe_ttm.c:dump_eos_grid) -> tests/golden/eos_grid.npz.  The MD run itself is a throw-away 2048-atom
+    step 0; only the interpolator dump is kept."""
+    c = CASES["ttm_2048"]
+    out = {}
+    for tag, (nr, nt) in (("a", (9, 11)), ("b", (24, 40))):
+        r, y, zc, ze = _curved_tables(nr, nt)
+        rng = np.random.default_rng(100 + nr)
+        pts, kind = [], []
+        for i in range(nr):
+            for j in range(nt):
+                pts.append((r[i], y[j])); kind.append(0)                                   # node
+                if i + 1 < nr:
+                    pts.append((0.5 * (r[i] + r[i + 1]), y[j])); kind.append(1)            # edge along r
+                if j + 1 < nt:
+                    pts.append((r[i], 0.5 * (y[j] + y[j + 1]))); kind.append(1)            # edge along y
+                if i + 1 < nr and j + 1 < nt:
+                    pts.append((0.5 * (r[i] + r[i + 1]), 0.5 * (y[j] + y[j + 1]))); kind.append(2)   # cell centre
+                    for _ in range(2):
+                        u, v = rng.uniform(0.02, 0.98, 2)
+                        pts.append((r[i] + u * (r[i + 1] - r[i]), y[j] + v * (y[j + 1] - y[j]))); kind.append(3)
+        pts = np.array(pts); kind = np.array(kind, np.int8)
+        with tempfile.TemporaryDirectory() as d:
+            par = COMMON.format(pbc="1 1 1", seed=12345, cpu="1 1 1")
+            par += "box_param %s\nstarttemp %g\nmaxsteps 0\n" % (c["box"], c["temp"])
+            potential.write_synthetic_eam_files(d)
+            par += "core_potential_file phi.pt\nembedding_energy_file F.pt\natomic_e-density_file rho.pt\n"
+            par += "nbl_margin 0.5\nnbl_size 1.5\n"
+            par = par.replace("ensemble nve", "ensemble ttm")
+            par += ("fd_ext 1 1 1\nfd_n_timesteps 1\nfd_min_atoms 5\natomic_weight 26.9815\natomic_charge 13\n"
+                    "ttm_int 100000\nI0 1.0\nlambda 800e-9\nlaser_sigma_t 100e-15\nlaser_t_0 1.0\n")
+            for fn, z in (("EOS_cve_from_r_te.txt", zc), ("EOS_ee_from_r_tesqrt.txt", ze)):
+                with open(os.path.join(d, fn), "w") as f:
+                    f.write("%d %d\n%.16e %.16e %.16e %.16e\n" % (nr, nt, r[0], r[-1], y[0], y[-1]))
+                    for i in range(nr):
+                        for j in range(nt):
+                            f.write("%.16e %.16e %.16e\n" % (r[i], y[j], z[i, j]))
+            with open(os.path.join(d, "eos_samples.txt"), "w") as f:
+                for x, yy in pts:
+                    f.write("%.17g %.17g\n" % (x, yy))
+            open(os.path.join(d, "t.param"), "w").write(par)
+            env = dict(os.environ, IMD_PROBE_DIR=d, IMD_PROBE_STEPS="0", IMD_PROBE_EOSGRID="1")
+            rr = subprocess.run([os.path.join(REFBIN, c["binary"]), "-p", "t.param"], cwd=d, env=env,
+                                stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            fn = os.path.join(d, "eosgrid.0.bin")
+            if not os.path.exists(fn):
+                print(rr.stdout[-3000:])
+                raise SystemExit("reference run failed for eos_grid")
+            a = np.fromfile(fn, np.float64).reshape(-1, 4)
+        assert len(a) == len(pts) and np.array_equal(a[:, :2], pts)
+        out.update({tag + "_r": r, tag + "_y": y, tag + "_cve": zc, tag + "_ee": ze, tag + "_x": a[:, 0],
+                    tag + "_yq": a[:, 1], tag + "_kind": kind, tag + "_ref_cve": a[:, 2], tag + "_ref_ee": a[:, 3]})
+        print("eos_grid %s: %dx%d table, %d samples, %d NaN from the reference" %
+              (tag, nr, nt, len(a), int(np.isnan(a[:, 2:]).any(axis=1).sum())))
+    path = os.path.join(OUT, "eos_grid.npz")
+    np.savez_compressed(path, **out)
+    print("%-20s %8.1f KB" % ("eos_grid", os.path.getsize(path) / 1024))
+
+
 def run_adv_case(name, c):
     """do_ADV fixture: the reference on TWO ranks along x (mpiexec -n 2), every rank's lattice dumped by
     oracle/ref_probe_ttm.c around update_fd / do_ADV / the sub-steps and assembled here into the GLOBAL lattice
@@ -426,10 +500,12 @@ def run_ttm_file_case():
 
 
 if __name__ == "__main__":
-    names = sys.argv[1:] or (list(CASES) + ["eos_inverse", "chkpt", "ttm_file"])
+    names = sys.argv[1:] or (list(CASES) + ["eos_inverse", "eos_grid", "chkpt", "ttm_file"])
     for n in names:
         if n == "eos_inverse":
             run_eos_inverse()
+        elif n == "eos_grid":
+            run_eos_grid()
         elif n == "ttm_file":
             run_ttm_file_case()
         elif n == "chkpt":
