@@ -1370,7 +1370,7 @@ __global__ void k_check_only(int n, int cap, const double4 *pos, const double *r
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-static inline int nblk(long long n, int b) { return (int) ((n + b - 1) / b); }
+static inline int nblk(long long n, int b) { return n <= 0 ? 1 : (int) ((n + b - 1) / b); }   // never an empty grid: a rank may own no atoms (vacuum)
 
 static int setup_tiles(imdgpu_ctx *ctx);
 static int build_ref_perm(imdgpu_ctx *ctx, std::vector<int> *perm, std::vector<int> *refstart);
@@ -1750,7 +1750,7 @@ extern "C" int imdgpu_upload_tables(imdgpu_ctx *ctx, const imdgpu_pot_table *pai
 
 static int ensure_atom_capacity(imdgpu_ctx *ctx, int nlocal, int ntot)
 {
-  if (nlocal > ctx->cap_local) {
+  if (nlocal > ctx->cap_local || ctx->cap_local == 0) {
     int cap = (int) (nlocal * 1.1) + 1024;
     cap = (cap + 63) / 64 * 64;
     if (dev_alloc(ctx, &ctx->id, cap) || dev_alloc(ctx, &ctx->acell, cap) || dev_alloc(ctx, &ctx->p, 3 * (size_t) cap) ||
@@ -1773,7 +1773,7 @@ static int ensure_atom_capacity(imdgpu_ctx *ctx, int nlocal, int ntot)
     ctx->npart_blocks = nb;
     ctx->nbr_cap = 0;                        // list must be re-allocated for the new stride
   }
-  if (ntot > ctx->cap_tot) {
+  if (ntot > ctx->cap_tot || ctx->cap_tot == 0) {
     int cap = (int) (ntot * 1.1) + 4096;
     double4 *np = nullptr, *np2 = nullptr; int *nt = nullptr, *nt2 = nullptr;
     HIPCHK(hipMalloc((void **) &np, (size_t) cap * sizeof(double4)));
@@ -1863,6 +1863,7 @@ static int upload_common(imdgpu_ctx *ctx, int n, const double *ort, const double
   HIPCHK(hipMemcpy(ctx->type, ht.data(), n * sizeof(int), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(ctx->id, hid.data(), n * sizeof(int), hipMemcpyHostToDevice));
   ctx->nlocal = n;
+  ctx->have_atoms = 1;
   return 0;
 }
 
@@ -1968,8 +1969,8 @@ static int sort_and_build(imdgpu_ctx *ctx)
 extern "C" int imdgpu_fix_cells(imdgpu_ctx *ctx)
 {
   HIPCHK(hipSetDevice(ctx->device));
-  const int n = ctx->nlocal;
-  if (n == 0) return imdgpu_fail(ctx, "no atoms uploaded");
+  const int n = ctx->nlocal;                     // 0 is legal (a rank in vacuum)
+  if (!ctx->have_atoms) return imdgpu_fail(ctx, "no atoms uploaded");
   Geo g = make_geo(ctx);
   HIPCHK(hipMemsetAsync(ctx->d_counters + CNT_OUTSIDE, 0, sizeof(int), ctx->stream));
   hipLaunchKernelGGL(k_wrap_key, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, n, ctx->pos, g, ctx->keys, ctx->perm,
@@ -2055,8 +2056,8 @@ extern "C" int imdgpu_autotile(imdgpu_ctx *ctx, int *changed)
 extern "C" int imdgpu_make_nblist(imdgpu_ctx *ctx)
 {
   HIPCHK(hipSetDevice(ctx->device));
-  const int n = ctx->nlocal;
-  if (n == 0) return imdgpu_fail(ctx, "no atoms uploaded");
+  const int n = ctx->nlocal;                     // 0 is legal: a rank whose domain is vacuum (laser-ablation slabs split along x)
+  if (!ctx->have_atoms) return imdgpu_fail(ctx, "no atoms uploaded");
   if (ctx->cellsz <= 0) return imdgpu_fail(ctx, "cellsz not set");
   Geo g = make_geo(ctx);
   if (imdgpu_fill_ghosts(ctx)) return 1;

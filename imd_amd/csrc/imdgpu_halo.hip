@@ -21,7 +21,7 @@
 
 #include <vector>
 
-static inline int nblk(long long n, int b) { return (int) ((n + b - 1) / b); }
+static inline int nblk(long long n, int b) { return n <= 0 ? 1 : (int) ((n + b - 1) / b); }   // never an empty grid: a rank may own no atoms (vacuum)
 
 extern "C" int imdgpu_get_cell_tables(imdgpu_ctx *ctx, int *cell_start, int *cell_cnt)
 {

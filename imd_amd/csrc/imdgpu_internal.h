@@ -84,6 +84,7 @@ struct imdgpu_ctx {
   int *gcnt = nullptr, *gstart = nullptr;           // [nghost_cells+1]
   int *ghost_src = nullptr, *ghost_code = nullptr;  // [cap ghost]
   int cap_ghost = 0;
+  int have_atoms = 0;                               // an upload has happened (nlocal may be 0: a rank in vacuum)
   int *d_counters = nullptr;                        // misc device ints (see kernels)
   int *h_counters = nullptr;                        // pinned mirror
 

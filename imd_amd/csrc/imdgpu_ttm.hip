@@ -176,10 +176,17 @@ __global__ __launch_bounds__(64) void k_ttm_push_faces(Lat L, MailboxDev M, int 
 #pragma unroll
     for (int u = 0; u < MB_UNR; u++) {
       const int idx = base + u * 64 + lane;
-      if (idx < nf) { o[idx] = v[u]; if (with_nat) on[idx] = nn[u]; }
+      if (idx < nf) {           // payload: system-scope (cache-bypassing) atomic stores, like every other mailbox access
+        mb_st((unsigned long long *) &o[idx].x, (unsigned long long) __double_as_longlong(v[u].x));
+        mb_st((unsigned long long *) &o[idx].y, (unsigned long long) __double_as_longlong(v[u].y));
+        if (with_nat) __hip_atomic_store(on + idx, nn[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
   }
-  mb_release();                                      // the stores above are acknowledged before the flag goes out
+  // every lane's stores are acknowledged (vmcnt 0: inline asm, the compiler may not drop it -- MI355X_MICROARCH.md,
+  // "Compiler hazard") before the one wave of this face lets the flag go out
+  mb_release();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (lane == 0) mb_st(mb_flag(M, M.nbr[b], b ^ 1), g + 1);
 }
 // take the neighbours' publication `*gbase + off` into the ghost cells of the arrays (natoms only with the first of a step)
@@ -948,7 +955,7 @@ __global__ void k_move_ttm(int n, int cap, Lat L, Geo g, double4 *pos, const int
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-static inline int nblk(long long n, int b) { return (int) ((n + b - 1) / b); }
+static inline int nblk(long long n, int b) { return n <= 0 ? 1 : (int) ((n + b - 1) / b); }   // never an empty grid: a rank may own no atoms (vacuum)
 // Every kernel of the lattice chain uses ONE-WAVE workgroups.  The chain runs on the second stream beside the
 // force passes, whose persistent 11-wave workgroups leave no CU with room for a multi-wave workgroup (three
 // waves of 150-170 VGPRs fill three of the four SIMDs): measured with tools/coresidency_probe.hip, a 256-thread
@@ -1057,10 +1064,26 @@ extern "C" int imdgpu_ttm_dims(imdgpu_ctx *ctx, int dim[3], double h[3])
   return 0;
 }
 
+// decomposed lattice: a face that a neighbour rank never published leaves the sticky time-out flag behind and every later
+// pull/push returns early -- so every call that hands lattice results to the host (download, CFL_maxdt) reports it
+static int ttm_check_mailbox(imdgpu_ctx *ctx)
+{
+  TtmState *t = ctx->ttm;
+  if (!t || !t->mb_host) return 0;
+  int flag = 0;
+  HIPCHK(hipMemcpyAsync(&flag, ctx->d_counters + CNT_TTM_TIMEOUT, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (flag)
+    return imdgpu_fail(ctx, "TTM mailbox: a neighbour rank did not publish its lattice faces in time (rank gone or stalled); "
+                            "the lattice of this step is not valid");
+  return 0;
+}
+
 static int ttm_xfer(imdgpu_ctx *ctx, const imdgpu_ttm_fields *f, bool down)
 {
   NEED_TTM();
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (down && ttm_check_mailbox(ctx)) return 1;
   const size_t n = t->ncell;
   auto X = [&](void *host, void *dev, size_t bytes) -> int {
     if (!host) return 0;
@@ -1314,6 +1337,7 @@ extern "C" int imdgpu_ttm_cfl_maxdt(imdgpu_ctx *ctx, int steps, double *out)
   double mx = 0;
   HIPCHK(hipMemcpyAsync(&mx, t->d_red, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (ttm_check_mailbox(ctx)) return 1;
   t->max_dt_ttm = (steps > 0 ? mx : ctx->timestep / ((double) t->nsub)) * 0.9;
   if (out) *out = t->max_dt_ttm;
   return 0;

@@ -152,7 +152,7 @@ static int count_atoms(void)
 
 static void ensure_host(int n)
 {
-  if (n <= g_cap) return;
+  if (n <= g_cap && g_cn != NULL) return;        /* g_cn == NULL: first call, also for a rank without atoms (vacuum) */
   g_cap = n + n / 8 + 1024;
   g_ort = (double *) realloc(g_ort, 3 * g_cap * sizeof(double)); g_imp = (double *) realloc(g_imp, 3 * g_cap * sizeof(double));
   g_kraft = (double *) realloc(g_kraft, 3 * g_cap * sizeof(double));
@@ -500,6 +500,30 @@ static void ttm_gpu_init(void)
   g_fdn = dim[0] * dim[1] * dim[2];
   for (k = 0; k < 2; k++) g_fi[k] = (int *) malloc(g_fdn * sizeof(int));
   for (k = 0; k < 15; k++) g_fd[k] = (double *) malloc((k == 5 ? 3 : 1) * (size_t) g_fdn * sizeof(double));
+  /* the device lattice starts from the HOST lattice as init_ttm left it: on a restart (imdrestart > 0) ttm_read has
+   * filled l1/l2 with the checkpointed electron state (imd_ttm_3D.c:1284-1290, :2128-2330: natoms, temp, md_temp, U, xi,
+   * source, dens, vcom, fd_k, fd_g, Z, Ce); on a fresh start the same upload carries init_ttm's zeros.  Later host-side
+   * edits of l1/l2 between steps are NOT seen by the device (level 1). */
+  {
+    imdgpu_ttm_fields F;
+    int i, j, kk, c = 0;
+    for (i = 0; i < local_fd_dim.x; i++)
+      for (j = 0; j < local_fd_dim.y; j++)
+        for (kk = 0; kk < local_fd_dim.z; kk++, c++) {
+          const ttm_Element *e = &l1[i][j][kk], *e2 = &l2[i][j][kk];
+          g_fi[0][c] = e->natoms; g_fi[1][c] = e->natoms_old;
+          g_fd[0][c] = e->temp; g_fd[1][c] = e2->temp; g_fd[2][c] = e->xi; g_fd[3][c] = e->md_temp; g_fd[4][c] = e->source;
+          g_fd[5][3 * c] = e->vcomx; g_fd[5][3 * c + 1] = e->vcomy; g_fd[5][3 * c + 2] = e->vcomz;
+          g_fd[6][c] = e->dens; g_fd[7][c] = e->fd_k; g_fd[8][c] = e->fd_g; g_fd[9][c] = e->Z; g_fd[10][c] = e->Ce;
+          g_fd[11][c] = e->ne; g_fd[12][c] = e->U; g_fd[13][c] = e2->U;
+        }
+    memset(&F, 0, sizeof(F));
+    F.natoms = g_fi[0]; F.natoms_old = g_fi[1];
+    F.temp = g_fd[0]; F.temp2 = g_fd[1]; F.xi = g_fd[2]; F.md_temp = g_fd[3]; F.vcom = g_fd[5];
+    F.dens = g_fd[6]; F.fd_k = g_fd[7]; F.fd_g = g_fd[8]; F.Z = g_fd[9]; F.Ce = g_fd[10]; F.ne = g_fd[11];
+    F.U = g_fd[12]; F.U2 = g_fd[13];
+    gpu_check(imdgpu_ttm_upload(G, &F));
+  }
   g_ttm_ready = 1;
 }
 
@@ -519,6 +543,8 @@ void calc_ttm(void)
   gpu_check(imdgpu_update_momenta(G, n, g_imp));
   if (g_multi) gpu_check(imdgpu_ttm_local_step(G, steps));      /* this rank's block; faces through the mailbox */
   else gpu_check(imdgpu_calc_ttm(G, steps));
+  /* CFL_maxdt and the download below fail (-> error() on this rank, MPI_Abort for all) when a neighbour's lattice
+   * faces never arrived in the mailbox: a stale-ghost lattice is never copied into l1/l2 */
   gpu_check(imdgpu_ttm_cfl_maxdt(G, steps, &mdt));
 #ifdef MPI
   if (g_multi) { double m2; MPI_Allreduce(&mdt, &m2, 1, MPI_DOUBLE, MPI_MIN, cpugrid); mdt = m2; }   /* :2683-2687 */

@@ -342,7 +342,12 @@ class DistributedMD:
             self._migrate()
         ops.fix_cells()
         self.plan = HaloPlan(self.dec, ops)
-        if ops.autotile():                               # first rebuild: tile shape chosen from the real occupancies,
+        changed = 1 if ops.autotile() else 0             # first rebuild: tile shape chosen from the real occupancies
+        if self.world > 1 and self.nrebuild == 0:        # building a plan is collective (counts travel): every rank must
+            t = torch.tensor([changed], dtype=torch.int32, device=ops.device)    # agree -- a rank in vacuum never re-tiles
+            all_reduce_(t, dist.ReduceOp.MAX)
+            changed = int(t.item())
+        if changed:
             self.plan = HaloPlan(self.dec, ops)          # local atoms were re-sorted -> new index lists
         self.plan.exchange(ops, 0)
         if ops.ntypes > 1:

@@ -132,30 +132,39 @@ class NumpyOps:
 
     # -- forces --------------------------------------------------------------------------
     def make_nblist(self):
+        """pair candidates (i local, j local or ghost, i != j) inside the list radius, found once per rebuild by a
+        chunked all-pairs search; the force phases then work on these sparse pair arrays only"""
         self.ref = self.pos[:self.n, :3].copy()
-
-    def _pairs(self):
         X = self.pos[:, :3]
-        d = X[None, :, :] - X[:self.n, None, :]
-        r2 = (d * d).sum(-1)
-        np.fill_diagonal(r2[:, :self.n], 1e30)
-        return d, r2
+        ii, jj = [], []
+        for a in range(0, self.n, 256):
+            b = min(a + 256, self.n)
+            d = X[None, :, :] - X[a:b, None, :]
+            r2 = (d * d).sum(-1)
+            r2[np.arange(b - a), np.arange(a, b)] = 1e30
+            i, j = np.nonzero(r2 < self.cellsz)
+            ii.append(i + a); jj.append(j)
+        self._ii, self._jj = np.concatenate(ii), np.concatenate(jj)
+
+    def _acc(self, w):
+        return np.bincount(self._ii, weights=w, minlength=self.n)
 
     def forces_phase(self, k):
         n = self.n
+        ii, jj = self._ii, self._jj
         if k == 1:
-            self._d, self._r2 = self._pairs()
-            r2 = self._r2
+            X = self.pos[:, :3]
+            self._d = X[jj] - X[ii]
+            self._r2 = r2 = (self._d * self._d).sum(-1)
             pot, grad = tab_eval(self.pair, r2)
             inp = r2 <= self.pair["end"][0]
             grad = np.where(inp, grad, 0.0); pot = np.where(inp, pot, 0.0)
-            self.f = (self._d * grad[..., None]).sum(1)
-            self.epot = 0.5 * pot.sum(1)
+            self.f = np.stack([self._acc(self._d[:, c] * grad) for c in range(3)], axis=1)
+            self.epot = 0.5 * self._acc(pot)
             val, _ = tab_eval(self.rho, r2)
-            self.rhoh = np.where(r2 < self.rho["end"][0], val, 0.0).sum(1)
+            self.rhoh = self._acc(np.where(r2 < self.rho["end"][0], val, 0.0))
             self.vir = -0.5 * (r2 * grad).sum()
         elif k == 2:
-            a = np.minimum(self.rhoh, self.emb["end"][0]) - self.emb["begin"][0]
             pot, dF = tab_eval(self.emb, self.rhoh)
             self.epot += pot
             self.pos[:n, 3] = dF
@@ -163,9 +172,9 @@ class NumpyOps:
             r2 = self._r2
             _, rp = tab_eval(self.rho, r2)
             w = self.pos[:, 3]
-            grad = np.where(r2 < self.rho["end"][0], 0.5 * (w[:n, None] + w[None, :]) * rp, 0.0)
-            g = self._d * grad[..., None]
-            self.f += g.sum(1)
+            grad = np.where(r2 < self.rho["end"][0], 0.5 * (w[ii] + w[jj]) * rp, 0.0)
+            g = self._d * grad[:, None]
+            self.f += np.stack([self._acc(g[:, c]) for c in range(3)], axis=1)
             self.vir += -0.5 * (self._d * g).sum()
             self.sums["tot_pot_energy"], self.sums["virial"] = float(self.epot.sum()), float(self.vir)
 

@@ -183,6 +183,48 @@ def test_reference_ttm_main_loop_on_gpu_forces_and_gpu_calc_ttm():
     assert np.allclose(out["gpu"]["ttm_file"], out["cpu"]["ttm_file"], rtol=2e-6, atol=1e-12)
 
 
+@pytest.mark.skipif(not (os.path.exists(CPU_TTM) and os.path.exists(GPU_TTM)), reason="oracle/_ref binaries not built")
+def test_reference_ttm_restart_keeps_the_electron_state_on_gpu():
+    """a restarted run (`-r 1`: init_ttm -> ttm_read fills l1/l2 from out.1.ttm, imd_ttm_3D.c:1284-1290) must
+    continue from the checkpointed electron lattice on the device too.  The CPU build writes checkpoint + .ttm file at
+    step 6; both builds are restarted from those files and run steps 7..12; lattices and atoms must agree (the
+    shim uploads the host lattice once, at the first calc_ttm -- without that the device would start from zeros)."""
+    import shutil
+    steps = (7, 12)
+    with tempfile.TemporaryDirectory() as d0:
+        potential.write_synthetic_eam_files(d0)
+        _write_planar_eos(d0)
+        par = PARAM_TTM.replace("checkpt_int 100000", "checkpt_int 6")
+        open(os.path.join(d0, "t.param"), "w").write(par.replace("maxsteps 12", "maxsteps 6"))
+        r = subprocess.run([CPU_TTM, "-p", "t.param"], cwd=d0, env=dict(os.environ, IMD_PROBE_STEPS="-1"),
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert r.returncode == 0 and os.path.exists(os.path.join(d0, "out.1.ttm")), r.stdout[-2000:]
+        open(os.path.join(d0, "t.param"), "w").write(par)
+        out = {}
+        for tag, exe in (("cpu", CPU_TTM), ("gpu", GPU_TTM)):
+            d = os.path.join(d0, tag)
+            shutil.copytree(d0, d, ignore=shutil.ignore_patterns("cpu", "gpu"))
+            env = dict(os.environ, IMD_PROBE_DIR=d, IMD_PROBE_STEPS=",".join(map(str, steps)))
+            r = subprocess.run([exe, "-r", "1", "-p", "t.param"], cwd=d, env=env, stdout=subprocess.PIPE,
+                               stderr=subprocess.STDOUT, text=True, timeout=600)
+            assert r.returncode == 0 and "Reading 64 lines from ttm-file" in r.stdout, r.stdout[-3000:]
+            out[tag] = {s: po.read_probe(os.path.join(d, "probe.0.%d.bin" % s)) for s in steps}
+            out[tag]["lat"] = {s: po.read_ttm_probe(os.path.join(d, "ttm.0.%d.bin" % s))["stages"]["cfl"] for s in steps}
+    inner = (slice(1, -1),) * 3
+    for s in steps:
+        a, b = out["gpu"]["lat"][s], out["cpu"]["lat"][s]
+        assert np.array_equal(a["lat"]["natoms"][inner], b["lat"]["natoms"][inner])
+        # the electrons are NOT in equilibrium with the lattice in this state: temp carries the checkpointed history
+        assert np.abs(b["lat"]["temp"][inner] - b["lat"]["md_temp"][inner]).max() > 1e-6
+        for f in ("temp", "U", "xi", "md_temp", "dens", "vcom", "fd_k", "fd_g", "Ce"):
+            x, y = a["lat"][f][inner], b["lat"][f][inner]
+            assert np.abs(x - y).max() <= 1e-9 * np.abs(y).max(), (s, f)
+        A, B = out["gpu"][s], out["cpu"][s]
+        oa, ob = np.argsort(_inner_ids(A)), np.argsort(_inner_ids(B))
+        assert np.abs(_inner_pos(A)[oa] - _inner_pos(B)[ob]).max() < 1e-9, s
+        assert np.abs(A["impuls"][oa] - B["impuls"][ob]).max() < 1e-9 * np.abs(B["impuls"]).max(), s
+
+
 CPU_MPI = os.path.join(ROOT, "oracle", "_ref", "imd_mpi_eam_nve_nbl")
 GPU_MPI = os.path.join(ROOT, "oracle", "_ref", "imd_mpi_eam_nve_nbl_gpu")
 

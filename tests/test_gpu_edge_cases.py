@@ -107,8 +107,8 @@ def test_host_integrator_hand_over_of_positions_and_momenta():
 
 
 def test_tiny_and_empty_systems():
-    """The smallest inputs: no atoms is refused loudly (the reference has no defined behaviour there); one atom feels
-    nothing; two atoms feel equal and opposite forces that match the oracle; the device loop runs on them."""
+    """The smallest inputs: forces before any upload are refused loudly, an upload of zero atoms is a legal empty rank
+    (test_rank_without_atoms); one atom feels nothing; two atoms feel equal and opposite forces that match the oracle; the device loop runs on them."""
     from imd_amd.lib import ImdGpuError
     pair, rho, emb, r2cut = potential.synthetic_eam_tables()
     cellsz = (np.sqrt(r2cut) + 0.5) ** 2
@@ -120,8 +120,9 @@ def test_tiny_and_empty_systems():
         s.upload_tables(pair, rho, emb)
         if n == 0:
             with pytest.raises(ImdGpuError):
-                s.upload_atoms(both[:0], np.zeros((0, 3)), 26.9815)
-                s.calc_forces(0)
+                s.calc_forces(0)                       # nothing uploaded yet
+            s.upload_atoms(both[:0], np.zeros((0, 3)), 26.9815)
+            assert s.calc_forces(0)["tot_pot_energy"] == 0.0
             s.close()
             continue
         s.upload_atoms(both[:n], np.zeros((n, 3)), 26.9815)
@@ -141,3 +142,26 @@ def test_tiny_and_empty_systems():
         for st in range(3):
             s.md_step(st)
         s.close()
+
+
+def test_rank_without_atoms():
+    """a rank whose domain is vacuum (laser-ablation slab split along x) owns no atoms -- the reference runs
+    such ranks.  Every entry point must accept nlocal = 0: no launches fault, sums are zero, the TTM lattice of that rank is
+    all inactive."""
+    from imd_amd import ttm as ttm_mod
+    c = _case((8, 8, 8), 4.05)
+    s = GpuSystem(c["box"], c["pbc"], c["dim"], 1, c["cellsz"], 0.5, 0.1, count_ttm_neighbours=True)
+    s.upload_tables(*c["tabs"])
+    s.upload_atoms(np.zeros((0, 3)), np.zeros((0, 3)), 26.9815)
+    assert s.num_atoms()[0] == 0
+    r = s.calc_forces(0)
+    assert r["tot_pot_energy"] == 0.0 and r["virial"] == 0.0 and r["is_short"] == 0
+    ttm_mod.attach_default(s, fd_ext=(1, 1, 1), diff_substeps=10, fd_min_atoms=5)
+    for st in range(3):
+        s.md_step(st)
+    lat = s.ttm_download(fields=("natoms", "temp", "xi"))
+    assert int(lat["natoms"].sum()) == 0 and np.all(lat["xi"] == 0.0)
+    d = s.download()
+    assert d["ort"].shape == (0, 3) and int(d["cell_n"].sum()) == 0
+    assert s.get_sums()["tot_kin_energy"] == 0.0
+    s.close()

@@ -176,3 +176,92 @@ def test_two_ranks_ttm_with_advection_on_the_decomposed_lattice():
         for f in ("temp", "U", "temp2", "U2", "xi"):
             a, b = r[4][f][inner], G["t48_substeps_done_" + f][sl]
             assert np.abs(a - b).max() <= 2e-8 * np.abs(b).max(), f
+
+
+def _worker_vacuum(rank, world, port, q):
+    try:
+        import torch
+        import torch.distributed as dist
+        from imd_amd import lattice, potential
+        from imd_amd.parallel import Decomposition, DistributedMD, GpuOps
+        from imd_amd.system import GpuSystem
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        C = _vacuum_case()
+        dec = Decomposition(rank, (2, 1, 1), C["gdim"], C["box"], (0, 1, 1))
+        mine = (C["pos"][:, 0] >= np.diag(C["box"])[0] / 2) == (rank == 1)
+        s = GpuSystem(C["box"], (0, 1, 1), dec.dim, 1, C["cellsz"], 0.5, 0.1, device=0, global_cell_dim=dec.gdim,
+                      cpu_dim=(2, 1, 1), my_coord=dec.coord)
+        s.upload_tables(*C["tabs"])
+        s.upload_atoms(C["pos"][mine], C["mom"][mine], 26.9815, None, np.arange(len(C["pos"]), dtype=np.int32)[mine])
+        ops = GpuOps(s, 0)
+        md = DistributedMD(dec, ops)
+        for st in range(C["nsteps"]):
+            md.md_step(st)
+        sums = md.global_sums()
+        d = s.download(fields=("ort", "impuls", "nummer"))
+        q.put((rank, d, sums, int(mine.sum())))
+        s.close()
+        dist.destroy_process_group()
+    except BaseException:
+        import traceback
+        q.put((rank, "ERROR", traceback.format_exc(), 0))
+
+
+def _vacuum_case():
+    """a slab in the low half of a box twice as long in x (open x): rank 1 of a 2x1x1 grid owns only vacuum"""
+    from imd_amd import lattice, potential
+    from imd_amd.system import global_cell_dim
+    nb = (5, 6, 6)
+    pair, rho, emb, r2cut = potential.synthetic_eam_tables()
+    cellsz = (np.sqrt(r2cut) + 0.5) ** 2
+    box = lattice.fcc_box(nb, 4.05).copy()
+    box[0, 0] = 2 * 32.4                                        # slab 2.0 .. 22.3 A, rank boundary at 32.4 A
+    pos = lattice.fcc_positions(nb, 4.05) + np.array([2.0, 0.0, 0.0])
+    rng = np.random.default_rng(5)
+    pos = pos + rng.normal(scale=0.04, size=pos.shape)
+    pos[:, 1:] %= np.diag(box)[1:]
+    mom = lattice.maxwell_momenta(len(pos), 26.9815, 0.05, seed=5)
+    gdim = global_cell_dim(box, cellsz, (2, 1, 1))
+    return dict(box=box, pos=pos, mom=mom, gdim=gdim, cellsz=cellsz, tabs=(pair, rho, emb), nsteps=12)
+
+
+def test_two_ranks_one_in_vacuum():
+    """the normal case of an ablation slab decomposed along x -- one rank holds every atom, the other none.
+    12 steps of the two-rank run against the CPU oracle's single-domain loop on the same atoms."""
+    from oracle import pyoracle as po
+    C = _vacuum_case()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_vacuum, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = []
+    try:
+        for _ in range(2):
+            r = q.get(timeout=150)
+            assert r[1] != "ERROR", "rank %d failed:\n%s" % (r[0], r[2])
+            res.append(r)
+    finally:
+        for p in procs:
+            p.join(timeout=20)
+            if p.is_alive():
+                p.kill()
+    res = sorted(res, key=lambda r: r[0])
+    assert res[1][3] == 0 and res[0][3] == len(C["pos"])          # rank 1 really had nothing
+    o = po.OracleSystem([g + 2 for g in C["gdim"]], 64, 1, C["box"], (0, 1, 1), C["cellsz"], 0.5, 0.1)
+    for w, t in enumerate(C["tabs"]):
+        o.set_table(w, t.as_dict())
+    o.fill_from_positions(C["pos"], C["mom"], 26.9815)
+    for st in range(C["nsteps"]):
+        o.calc_forces(st); o.move_atoms_nve(); o.check_nblist()
+    ids = np.concatenate([r[1]["nummer"] for r in res]); pos = np.concatenate([r[1]["ort"] for r in res])
+    mom = np.concatenate([r[1]["impuls"] for r in res])
+    a, b = np.argsort(ids), np.argsort(o.gather_inner("nummer"))
+    assert len(ids) == len(C["pos"])
+    dx = pos[a] - o.gather_inner("ort")[b]
+    L = np.diag(C["box"]); dx[:, 1:] -= np.round(dx[:, 1:] / L[1:]) * L[1:]
+    assert np.abs(dx).max() < 1e-9
+    assert np.abs(mom[a] - o.gather_inner("impuls")[b]).max() < 1e-9 * np.abs(mom).max()

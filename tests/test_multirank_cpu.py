@@ -12,13 +12,60 @@ import torch.multiprocessing as mp
 from tests import golden_util as gu
 
 
+def _run_ranks(target, world, args, timeout=None):
+    """Spawn `world` workers, collect one result each; on a time-out (scaled with the cores available) or a dead
+    worker the remaining ones are killed, the queue is drained and the test FAILS instead of hanging in the exit handler."""
+    import queue as _q
+    import time
+    # one thread per rank: dense numpy / torch thread pools spin in sched_yield when ranks outnumber cores
+    for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+        os.environ[v] = "1"
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    if timeout is None:
+        timeout = 240.0 * max(1.0, world / max(ncpu, 1)) + 120.0
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port) + tuple(args) + (q,)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res, deadline, err = [], time.time() + timeout, None
+    while len(res) < world:
+        try:
+            res.append(q.get(timeout=2.0))
+        except _q.Empty:
+            dead = [p for p in procs if not p.is_alive() and p.exitcode not in (0, None)]
+            if dead:
+                err = "worker died with exit code %s" % dead[0].exitcode
+                break
+            if time.time() > deadline:
+                err = "no result after %.0f s" % timeout
+                break
+    for p in procs:
+        p.join(timeout=30 if err is None else 0.1)
+        if p.is_alive():
+            p.kill()
+            p.join(timeout=10)
+    try:                                   # drain: a worker blocked in q.put must not keep the feeder thread alive
+        while True:
+            q.get_nowait()
+    except Exception:
+        pass
+    q.close(); q.join_thread()
+    if err:
+        pytest.fail("multi-rank CPU run (%d ranks): %s" % (world, err))
+    return res
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
     return p
 
 
 def _worker(rank, world, port, cpu_dim, nsteps, q):
+    import torch
     import torch.distributed as dist
+    torch.set_num_threads(1)
     from imd_amd.parallel import Decomposition, DistributedMD
     from tests.numpy_ops import NumpyOps
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
@@ -46,20 +93,7 @@ def _worker(rank, world, port, cpu_dim, nsteps, q):
 def test_distributed_trajectory_matches_reference(cpu_dim):
     world = int(np.prod(cpu_dim))
     nsteps = 20
-    # the workers are spawned: two threads each keeps 2-4 dense-numpy ranks from oversubscribing the CI cores
-    for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
-        os.environ.setdefault(v, "2")
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, cpu_dim, nsteps, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=300) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=60)
-        if p.is_alive():
-            p.kill()
+    res = _run_ranks(_worker, world, (cpu_dim, nsteps))
     G = gu.load("eam_nbl_2048")
     ids = np.concatenate([r[1] for r in res]); pos = np.concatenate([r[2] for r in res])
     mom = np.concatenate([r[3] for r in res]); frc = np.concatenate([r[4] for r in res])
@@ -116,7 +150,9 @@ class _FakeTtmOps:
 
 
 def _worker_ttm(rank, world, port, cpu_dim, q):
+    import torch
     import torch.distributed as dist
+    torch.set_num_threads(1)
     from imd_amd.parallel import Decomposition, DistributedMD
     from tests.numpy_ops import NumpyOps
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
@@ -145,17 +181,7 @@ def test_ttm_blocks_are_gathered_into_the_replicated_lattice(cpu_dim):
     replicated lattice at the rank's FD-cell offset -> lattice step, on the side stream between pass 1 and the
     integrator, the EAM force pass waiting for the gather."""
     world = int(np.prod(cpu_dim))
-    for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
-        os.environ.setdefault(v, "2")
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker_ttm, args=(r, world, port, cpu_dim, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=300) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=60)
+    res = _run_ranks(_worker_ttm, world, (cpu_dim,))
     for rank, lat, calls, gfd in res:
         assert np.array_equal(lat, _FakeTtmOps.expected(gfd, 2)), rank            # the lattice of the last step, complete
         per_step = ["fork", "mark", "lattice_step", "unfork", "wait", "join"]
