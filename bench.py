@@ -43,8 +43,10 @@ def parse():
                     help="config 5, Beer-Lambert variant: laser_rescale_ttm source (imd_laser.c:715) applied in every step")
     ap.add_argument("--cpu-box", type=int, default=48, help="unit cells per direction of the CPU sample")
     ap.add_argument("--cpu-steps", type=int, default=30)
-    ap.add_argument("--cpu-steps-mpi", type=int, default=120, help="steps of the multi-core (MPI + TTM) reference sample")
-    ap.add_argument("--cpu-box-mpi", type=int, default=64, help="unit cells per direction of that sample")
+    ap.add_argument("--cpu-steps-mpi", type=int, default=40, help="steps of the multi-core (MPI + TTM) reference sample")
+    ap.add_argument("--cpu-box-mpi", type=int, default=100, help="unit cells per direction of that sample (100: 4 000 000 atoms,\n"
+                    "250 000 per rank at 16 ranks -- sub-boxes of 25 x 50 x 50 unit cells, comparable with config 3's)")
+    ap.add_argument("--cpu-ranks", type=int, default=16, help="MPI ranks of the CPU sample = host cores used (a one-GPU box grants 16)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal: host-staged halos)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks on cuda:0")
     ap.add_argument("--ttm-decomposed", action="store_true",
@@ -134,9 +136,12 @@ def cpu_baseline_mpi_ttm(args):
     mpiexec = _find_mpiexec()
     if args.no_ttm or not os.path.exists(exe) or mpiexec is None:
         return None
-    cores = _host_cores()                       # the GPU box grants 16 cores per GPU whatever the affinity mask shows
-    cpu_dim = (4, 2, 2) if cores >= 16 else (2, 2, 2) if cores >= 8 else (2, 2, 1) if cores >= 4 else (2, 1, 1) if cores >= 2 else (1, 1, 1)
+    avail = _host_cores()                       # what the affinity mask shows (the whole host on the GPU box)
+    # ranks actually started: the share of host cores a one-GPU job gets (16), never more than the mask shows
+    want = max(1, min(args.cpu_ranks, avail))
+    cpu_dim = (4, 2, 2) if want >= 16 else (2, 2, 2) if want >= 8 else (2, 2, 1) if want >= 4 else (2, 1, 1) if want >= 2 else (1, 1, 1)
     nranks = cpu_dim[0] * cpu_dim[1] * cpu_dim[2]
+    cores = avail
     nb, steps = args.cpu_box_mpi, args.cpu_steps_mpi
     natoms = 4 * nb ** 3
     with tempfile.TemporaryDirectory() as d:
@@ -156,7 +161,7 @@ def cpu_baseline_mpi_ttm(args):
         t0 = time.time()
         try:
             r = subprocess.run([mpiexec, "-n", str(nranks), exe, "-p", "b.param"], cwd=d, env=env, stdout=subprocess.PIPE,
-                               stderr=subprocess.STDOUT, text=True, timeout=300)
+                               stderr=subprocess.STDOUT, text=True, timeout=400)
         except (subprocess.TimeoutExpired, OSError):
             return None
         wall = time.time() - t0
@@ -168,7 +173,8 @@ def cpu_baseline_mpi_ttm(args):
             secs = float(line.split()[0])                 # imd.c prints cputime / num_cpus here = seconds of the main loop
     if not secs:
         return None
-    return {"value": natoms * (steps + 1) / secs, "unit": "atom-steps/s", "cores": nranks, "kind": "reference",
+    return {"value": natoms * (steps + 1) / secs, "unit": "atom-steps/s", "cores": nranks, "cores_used": nranks,
+            "cores_available": cores, "kind": "reference",
             "sample": "reference binary imd_mpi_eam_ttm3d_nbl (gcc -O2, MPI, cpu_dim %d %d %d = %d ranks on %d host cores), %d atoms "
                       "x %d steps, EAM + 3D TTM (fd_ext %d %d %d, 100 sub-steps, no laser, calc_ttm's first block), main loop "
                       "incl. list rebuilds, %.1f s wall" % (cpu_dim + (nranks, cores, natoms, steps + 1) + tuple(args.fd_ext) + (wall,))}
@@ -182,6 +188,8 @@ def cpu_baseline(args):
     if par is None:
         return ser
     par["serial"] = {k: ser[k] for k in ("value", "unit", "cores", "kind", "sample")}
+    par["note"] = ("cores = cores_used = MPI ranks started (the host-core share of a one-GPU job); cores_available = what the "
+                   "affinity mask of the box shows; the GPU/CPU ratio is against cores_used cores, not against the whole host")
     return par
 
 
@@ -212,7 +220,8 @@ def cpu_baseline_serial(args):
                 if "cpuseconds per step and atom" in line:
                     per = float(line.split()[0])
             if r.returncode == 0 and per:
-                return {"value": 1.0 / per, "unit": "atom-steps/s", "cores": 1, "kind": "reference",
+                return {"value": 1.0 / per, "unit": "atom-steps/s", "cores": 1, "cores_used": 1, "cores_available": _host_cores(),
+                        "kind": "reference",
                         "sample": "reference binary imd_eam_nve_nbl (gcc -O2), %d atoms x %d steps, EAM NVE, "
                                   "main loop incl. list rebuilds, %.1f s wall" % (natoms, steps + 1, wall)}
     # port: the oracle restatement
@@ -236,30 +245,53 @@ def cpu_baseline_serial(args):
             "sample": "oracle C restatement, %d atoms x %d steps, EAM NVE" % (natoms, steps)}
 
 
-def measured_traffic(kernel, natoms):
+def measured_traffic(kernel, natoms, kernel_rev):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/profile_bench.sh:
     separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same workload).  Counters cannot be read
-    from inside the process, so the figure is looked up by (kernel, workload size); null when not measured."""
+    from inside the process, so the figure is looked up by (full kernel name incl. template arguments, workload size,
+    kernel revision of the library); an entry measured on another build of the force kernels (`_kernel_rev` differs
+    from imdgpu_get_info("kernel_rev")) is REFUSED -> traffic null."""
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic*.json")), reverse=True):
         try:
             t = json.load(open(f))
         except Exception:
             continue
-        if t.get("_atoms_per_gpu") != natoms:
+        if t.get("_atoms_per_gpu") != natoms or t.get("_kernel_rev") != kernel_rev:
             continue
         for k, v in t.items():
-            if isinstance(v, dict) and kernel in k and v.get("hbm_bytes"):
+            if isinstance(v, dict) and k.replace("void ", "").startswith(kernel) and v.get("hbm_bytes"):
                 return v["hbm_bytes"], os.path.relpath(f, ROOT)
     return None, None
 
 
+def _spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (this process has not
+    touched the GPU yet) through torch.distributed.run and relay rank 0's JSON line."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    line = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    if line:
+        print(line[-1])
+    else:
+        sys.stdout.write(r.stdout)
+    raise SystemExit(r.returncode if r.returncode else (0 if line else 1))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _spawn_ranks(args)
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d, "
+                         "or without a launcher)" % (args.gpus, world, args.gpus))
     if args.share_gpu:
         local = 0
     if world > 1:
@@ -312,8 +344,9 @@ def main():
         fused = bool(sysm.get_info("fused_embedding"))
         bytes_p1 = natoms * (72.0 + 4.0 * M + (32.0 if fused else 0.0))
         ach = bytes_p1 / (ms1 / max(n1, 1) * 1e-3) / 1e9 if n1 else 0.0
-        kname = "k_pass1_tile_merged" if sysm.get_info("list_mode") == 1 else "k_pass1"
-        traffic, traffic_src = measured_traffic(kname, natoms)
+        ttmn = "true" if not args.no_ttm else "false"
+        kname = ("k_pass1_tile_merged<%s, %s>" % (ttmn, "true" if fused else "false")) if sysm.get_info("list_mode") == 1 else "k_pass1"
+        traffic, traffic_src = measured_traffic(kname, natoms, sysm.get_info("kernel_rev"))
         out = {
             "metric": "MD-steps/sec (and atom-steps/sec) for 10M-atom EAM-Al+TTM at 1/2/4/8 GPU",
             "value": args.steps / dt, "unit": "MD-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -331,11 +364,12 @@ def main():
                        "tile": [sysm.get_info("tile_x"), sysm.get_info("tile_y"), sysm.get_info("tile_z")],
                        "tile_info": {k: sysm.get_info(k) for k in ("ntiles", "tile_cap", "slot_cap", "max_halo",
                                                                    "tile_threads", "lds_pass1", "lds_pass3", "W")},
-                       "parallelism": ("%dx%dx%d ranks, 1 rank/GPU, ghost-cell halo over RCCL" % tuple(cpu_dim))
-                       if world > 1 else "single GPU"},
+                       "parallelism": ("%dx%dx%d ranks, 1 rank/GPU, direct 26-neighbour ghost-cell halo, native step (%s)"
+                                       % (tuple(cpu_dim) + (md.ops.transport,))) if md is not None else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": kname + (" (pass 1: pair + rho, embedding pass folded in)" if fused else " (pass 1: pair + rho)"), "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": bytes_p1, "avg_launch_ms": ms1 / max(n1, 1)},
+                         "algorithmic_bytes_per_launch": bytes_p1, "avg_launch_ms": ms1 / max(n1, 1),
+                         "kernel_rev": sysm.get_info("kernel_rev")},
             "kernel_ms_per_step": {k: v[1] / args.steps for k, v in prof.items() if v[0]},
             "energy": {"epot_per_atom": sums["tot_pot_energy"] / natoms, "ekin_per_atom": sums["tot_kin_energy"] / natoms},
         }

@@ -372,6 +372,7 @@ struct ForceArgs {
   int *numneighs;
   double *partials;
   int *counters;
+  const int *guard;               // see TileArgs.guard
 };
 
 __device__ __forceinline__ void lds_load_table(double *dst, const TabPar &t)
@@ -447,6 +448,7 @@ __device__ __forceinline__ void pass1_body(const ForceArgs &a, const double *tp,
 template <bool PAIR, bool EAM, bool TTMN, bool NT1>
 __global__ __launch_bounds__(512) void k_pass1(ForceArgs a)
 {
+  if (a.guard && *a.guard) return;
   extern __shared__ double lds[];
   double *tp = lds;
   double *tr = lds + (PAIR ? a.pair.nrows * a.pair.ncols : 0);
@@ -460,6 +462,7 @@ __global__ __launch_bounds__(512) void k_pass1(ForceArgs a)
 template <bool PAIR, bool EAM, bool TTMN>
 __global__ __launch_bounds__(512) void k_pass1_gt(ForceArgs a)
 {
+  if (a.guard && *a.guard) return;
   __shared__ double scratch[64];
   pass1_body<PAIR, EAM, TTMN, false>(a, a.pair.tab, a.rho.tab, scratch);
 }
@@ -551,6 +554,7 @@ __global__ __launch_bounds__(512) void k_pass3_gt(ForceArgs a)
 // neighbour list holds 16-bit LDS slot numbers (4 per 8-byte load, ELL-transposed
 // per tile).  HBM sees: list (2 B/entry), own-atom outputs, one staging pass.
 // ===========================================================================
+#define IMDGPU_KERNEL_REV 2
 #define LDS_LIMIT (160 * 1024)
 #define TABLE_LDS_LIMIT (150 * 1024)                 // global-gather kernels: tables beyond this stay in global memory
 #define NH_MAX 512                                   // halo cells per tile (<= 6*6*6 = 216 for tiles up to 4^3)
@@ -574,6 +578,7 @@ struct TileArgs {
   double *partials;
   int *counters;
   double cellsz;
+  const int *guard;               // pass 1 launched ahead of the host's look at the list-validity flag: *guard != 0 -> return at once
 };
 
 struct TileCtx { int tile, hx, hy, hz, nh, own_start, nown; };
@@ -930,6 +935,7 @@ template <bool PAIR, bool EAM, bool TTMN, bool NT1>
 __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile(TileArgs a)
 {
   extern __shared__ double lds[];
+  if (a.guard && *a.guard) return;
   double *tp = lds;
   double *tr = tp + (PAIR ? a.pair.nrows * a.pair.ncols : 0);
   double *sp = tr + (EAM ? a.rho.nrows * a.rho.ncols : 0);
@@ -1073,6 +1079,7 @@ template <bool TTMN, bool FEMB>
 __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs a)
 {
   extern __shared__ double lds[];
+  if (a.guard && *a.guard) return;
   double2 *tm = (double2 *) lds;                                // (nrows + 3) rows
   const int nrows = a.pair.nrows, kz = nrows;
   double *sp = lds + 2 * (size_t) (nrows + 3);
@@ -1420,6 +1427,7 @@ extern "C" void imdgpu_destroy(imdgpu_ctx *c)
   imdgpu_prof_resolve(c);
   for (auto e : c->ev_pool) (void) hipEventDestroy(e);
   imdgpu_ttm_free(c);
+  imdgpu_dist_free(c);
   void *ptrs[] = {c->pos, c->type, c->id, c->acell, c->p, c->f, c->ref, c->mass, c->epot, c->rhoh, c->numneighs,
                   c->pos2, c->type2, c->id2, c->p2, c->mass2, c->nn2, c->fdc, c->fdc2, c->keys, c->keys2, c->perm, c->perm2,
                   c->cub_tmp, c->cell_start, c->cell_cnt, c->icnt, c->istart, c->gcell_lin, c->gcell_src,
@@ -1440,6 +1448,7 @@ extern "C" const char *imdgpu_last_error(const imdgpu_ctx *c) { return c ? c->er
 
 extern "C" int imdgpu_set_option(imdgpu_ctx *ctx, const char *name, int value)
 {
+  imdgpu_dist_cancel_ahead(ctx);
   if (!strcmp(name, "mode")) {
     if (value != 0 && value != 1) return imdgpu_fail(ctx, "mode must be 0 (global gather) or 1 (LDS tiles)");
     ctx->mode = value; ctx->have_valid_nbl = 0;
@@ -1473,7 +1482,10 @@ extern "C" int imdgpu_get_info(imdgpu_ctx *ctx, const char *name, long long *val
     {"max_halo", ctx->max_halo}, {"W", ctx->W}, {"tile_x", ctx->tile[0]}, {"tile_y", ctx->tile[1]}, {"tile_z", ctx->tile[2]},
     {"ntiles", ctx->ntiles}, {"tile_threads", ctx->tile_threads}, {"nlocal", ctx->nlocal}, {"nghost", ctx->nghost},
     {"lds_pass1", (long long) ctx->lds_need[1]}, {"lds_pass3", (long long) ctx->lds_need[3]}, {"nbl_count", ctx->nbl_count},
-    {"fused_embedding", fuse_emb(ctx) ? 1 : 0}, {"ttm_flux", ctx->ttm_flux}, {"ttm_adv", ctx->ttm_adv}, {"ttm_block_width", ctx->ttm_flux ? 10 : 6}};
+    {"fused_embedding", fuse_emb(ctx) ? 1 : 0}, {"ttm_flux", ctx->ttm_flux}, {"ttm_adv", ctx->ttm_adv}, {"ttm_block_width", ctx->ttm_flux ? 10 : 6},
+    // bumped whenever a force / list kernel or its data layout changes: committed PMC traffic figures carry the revision
+    // they were measured on (profiles/*hbm_traffic*.json "_kernel_rev"), bench.py refuses figures of another revision
+    {"kernel_rev", IMDGPU_KERNEL_REV}};
   for (auto &e : tab) if (!strcmp(name, e.n)) { *value = e.v; return 0; }
   return imdgpu_fail(ctx, "unknown info %s", name);
 }
@@ -1838,6 +1850,7 @@ static int build_cells_from_counts(imdgpu_ctx *ctx)
 static int upload_common(imdgpu_ctx *ctx, int n, const double *ort, const double *impuls, const double *masse,
                          const int *sorte, const int *nummer)
 {
+  imdgpu_dist_cancel_ahead(ctx);
   if (!ctx->have_geometry) return imdgpu_fail(ctx, "imdgpu_set_geometry must be called first");
   HIPCHK(hipSetDevice(ctx->device));
   ctx->nlocal = 0;
@@ -1896,6 +1909,7 @@ extern "C" int imdgpu_upload_cells(imdgpu_ctx *ctx, const int *cell_n, int natom
 // neighbour list stays valid -- what a host integrator calls between two list rebuilds
 extern "C" int imdgpu_update_positions(imdgpu_ctx *ctx, int natoms, const double *ort)
 {
+  imdgpu_dist_cancel_ahead(ctx);
   HIPCHK(hipSetDevice(ctx->device));
   if (natoms != ctx->nlocal) return imdgpu_fail(ctx, "update_positions: %d atoms given, %d on the device", natoms, ctx->nlocal);
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1968,6 +1982,7 @@ static int sort_and_build(imdgpu_ctx *ctx)
 
 extern "C" int imdgpu_fix_cells(imdgpu_ctx *ctx)
 {
+  imdgpu_dist_cancel_ahead(ctx);
   HIPCHK(hipSetDevice(ctx->device));
   const int n = ctx->nlocal;                     // 0 is legal (a rank in vacuum)
   if (!ctx->have_atoms) return imdgpu_fail(ctx, "no atoms uploaded");
@@ -2017,7 +2032,7 @@ static TileArgs make_tile_args(imdgpu_ctx *ctx)
   { static const int dbg = getenv("IMDGPU_DBG") ? atoi(getenv("IMDGPU_DBG")) : 0; a.dbg = dbg; }
   a.pair = ctx->pair.par; a.rho = ctx->rho.par; a.emb = ctx->emb.par; a.posw = ctx->pos; a.merged = ctx->d_merged;
   a.f = ctx->f; a.epot = ctx->epot; a.rhoh = ctx->rhoh; a.ref = ctx->ref; a.numneighs = ctx->numneighs;
-  a.partials = ctx->partials; a.counters = ctx->d_counters; a.cellsz = ctx->cellsz;
+  a.partials = ctx->partials; a.counters = ctx->d_counters; a.cellsz = ctx->cellsz; a.guard = nullptr;
   return a;
 }
 
@@ -2055,6 +2070,7 @@ extern "C" int imdgpu_autotile(imdgpu_ctx *ctx, int *changed)
 
 extern "C" int imdgpu_make_nblist(imdgpu_ctx *ctx)
 {
+  imdgpu_dist_cancel_ahead(ctx);
   HIPCHK(hipSetDevice(ctx->device));
   const int n = ctx->nlocal;                     // 0 is legal: a rank whose domain is vacuum (laser-ablation slabs split along x)
   if (!ctx->have_atoms) return imdgpu_fail(ctx, "no atoms uploaded");
@@ -2192,12 +2208,12 @@ static int launch_forces(imdgpu_ctx *ctx, int phase = 0)
   a.pos = ctx->pos; a.type = ctx->type; a.nbr = ctx->nbr; a.nbr_cnt = ctx->nbr_cnt; a.stride = ctx->stride;
   a.pair = ctx->pair.par; a.rho = ctx->rho.par;
   a.f = ctx->f; a.epot = ctx->epot; a.rhoh = ctx->rhoh; a.numneighs = ctx->numneighs;
-  a.partials = ctx->partials; a.counters = ctx->d_counters;
+  a.partials = ctx->partials; a.counters = ctx->d_counters; a.guard = ctx->pass1_guard;
   const bool TILE = ctx->list_mode == 1;
   const int B = TILE ? ctx->tile_threads : 512, nb = TILE ? tile_grid(ctx) : nblk(n, B);
   if (nb > ctx->npart_blocks) return imdgpu_fail(ctx, "internal: partials too small");
   TileArgs ta;
-  if (TILE) ta = make_tile_args(ctx);
+  if (TILE) { ta = make_tile_args(ctx); ta.guard = ctx->pass1_guard; }
   size_t lds1 = ((PAIR ? a.pair.nrows * a.pair.ncols : 0) + (EAM ? a.rho.nrows * a.rho.ncols : 0) + 64) * sizeof(double);
   if (phase == 0 || phase == 1) {
     HIPCHK(hipMemsetAsync(ctx->d_counters + CNT_IS_SHORT, 0, sizeof(int), ctx->stream));

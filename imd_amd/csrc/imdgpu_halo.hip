@@ -36,6 +36,7 @@ extern "C" int imdgpu_get_cell_tables(imdgpu_ctx *ctx, int *cell_start, int *cel
 // entries of the two arrays must be the ones returned by imdgpu_get_cell_tables.
 extern "C" int imdgpu_set_ghost_layout(imdgpu_ctx *ctx, const int *cell_start, const int *cell_cnt, int nghost)
 {
+  imdgpu_dist_cancel_ahead(ctx);
   HIPCHK(hipSetDevice(ctx->device));
   if (!ctx->external_halo) return imdgpu_fail(ctx, "set_ghost_layout: only with a multi-rank geometry (cpu_dim > 1)");
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -264,6 +265,7 @@ extern "C" int imdgpu_migrate_gather(imdgpu_ctx *ctx, int dir, void *dev_out)
 // imdgpu_migrate_gather on the neighbour ranks)
 extern "C" int imdgpu_migrate_apply(imdgpu_ctx *ctx, const void *in_lo, int n_in_lo, const void *in_hi, int n_in_hi)
 {
+  imdgpu_dist_cancel_ahead(ctx);
   HIPCHK(hipSetDevice(ctx->device));
   const int n = ctx->nlocal, nout = ctx->mig_n[0] + ctx->mig_n[1], nstay = n - nout, nnew = nstay + n_in_lo + n_in_hi;
   if (nout > 0) {
@@ -333,6 +335,7 @@ extern "C" int imdgpu_get_invalid(imdgpu_ctx *ctx, int *flag)
 
 extern "C" int imdgpu_invalidate(imdgpu_ctx *ctx)
 {
+  imdgpu_dist_cancel_ahead(ctx);
   ctx->have_valid_nbl = 0; ctx->need_fix_cells = 1;
   return 0;
 }

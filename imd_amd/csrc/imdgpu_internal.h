@@ -123,6 +123,9 @@ struct imdgpu_ctx {
 
   // TTM state lives in imdgpu_ttm.hip
   struct TtmState *ttm = nullptr;
+  // native multi-GPU step (imdgpu_dist.hip)
+  void *dist = nullptr;
+  const int *pass1_guard = nullptr;   // device int: a pass-1 kernel launched AHEAD of the host's look at the list-validity flag returns at once when it is set
 };
 
 int imdgpu_fail(imdgpu_ctx *c, const char *fmt, ...);
@@ -214,3 +217,5 @@ int imdgpu_launch_integrate(imdgpu_ctx *ctx);
 int imdgpu_ttm_step_internal(imdgpu_ctx *ctx, int steps);
 int imdgpu_ttm_move_internal(imdgpu_ctx *ctx);
 void imdgpu_ttm_free(imdgpu_ctx *ctx);
+void imdgpu_dist_free(imdgpu_ctx *ctx);
+void imdgpu_dist_cancel_ahead(imdgpu_ctx *ctx);

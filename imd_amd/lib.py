@@ -9,7 +9,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(_CSRC, "libimdgpu.so")
+# IMDGPU_LIB: experiments only (tools/variant_bench.sh builds kernel variants outside the tree)
+LIB_PATH = os.environ.get("IMDGPU_LIB") or os.path.join(_CSRC, "libimdgpu.so")
 
 SYMBOLS = [
     "imdgpu_create", "imdgpu_destroy", "imdgpu_last_error", "imdgpu_set_stream", "imdgpu_synchronize", "imdgpu_set_option", "imdgpu_get_info",
@@ -26,6 +27,8 @@ SYMBOLS = [
     "imdgpu_migrate_scan", "imdgpu_migrate_gather", "imdgpu_migrate_apply", "imdgpu_forces_phase", "imdgpu_integrate",
     "imdgpu_get_invalid", "imdgpu_invalidate", "imdgpu_ttm_local_block", "imdgpu_ttm_apply_blocks",
     "imdgpu_ttm_lattice_step", "imdgpu_ttm_mailbox_bytes", "imdgpu_ttm_mailbox_attach", "imdgpu_ttm_local_step",
+    "imdgpu_dist_unique_id", "imdgpu_dist_init_rccl", "imdgpu_dist_init_callback", "imdgpu_dist_set_plan",
+    "imdgpu_dist_halo", "imdgpu_dist_set_ttm_blocks", "imdgpu_dist_md_step", "imdgpu_dist_allreduce_sum",
 ]
 
 
@@ -139,6 +142,14 @@ def load():
     L.imdgpu_ttm_eos_te_from_r_ee.argtypes = [vp, C.c_int, dp, dp, dp]
     L.imdgpu_ttm_eos_lookup.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp]
     L.imdgpu_move_atoms_ttm.argtypes = [vp, dp]
+    L.imdgpu_dist_unique_id.argtypes = [C.c_char_p, C.c_int]
+    L.imdgpu_dist_init_rccl.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.c_int]
+    L.imdgpu_dist_init_callback.argtypes = [vp, C.c_int, C.c_int, vp, vp]
+    L.imdgpu_dist_set_plan.argtypes = [vp, C.c_int, ip, ip, dp, vp, C.c_int, ip, ip]
+    L.imdgpu_dist_halo.argtypes = [vp, C.c_int]
+    L.imdgpu_dist_set_ttm_blocks.argtypes = [vp, ip]
+    L.imdgpu_dist_md_step.argtypes = [vp, C.c_int, ip]
+    L.imdgpu_dist_allreduce_sum.argtypes = [vp, dp, C.c_int]
     L.imdgpu_get_cell_tables.argtypes = [vp, ip, ip]
     L.imdgpu_autotile.argtypes = [vp, ip]
     L.imdgpu_set_ghost_layout.argtypes = [vp, ip, ip, C.c_int]

@@ -4,14 +4,22 @@ xGMI on the GPU box, "gloo" in the CPU tests).
 
 This is the host-side restatement of the reference's MPI layer:
   - rank grid and neighbours: setup_mpi_topology (imd_geom_mpi_3d.c:32-90),
-  - forward halo in Plimpton's three stages z, y, x with the periodic shift added
-    by the sending boundary rank: send_cells (imd_comm_force_3d.c:222-396),
+  - forward halo with the periodic shift added by the sending boundary rank: send_cells
+    (imd_comm_force_3d.c:222-396).  The reference fills the ghost shell in Plimpton's three stages
+    (z, y, x; 6 messages, edges travel twice, corners three times); here every one of the 26 ghost
+    regions comes DIRECTLY from the rank that owns it (DirectHaloPlan): the 8 GPUs of a node are
+    fully connected by xGMI, so one group of point-to-point messages replaces three dependent stages,
   - atom migration when the neighbour list is rebuilt: fix_cells -> send_atoms
     (imd_fix_cells_3d.c:43-306,436-542),
   - list validity as a global MAX: check_nblist (imd_forces_nbl.c:1087).
 Because the device kernels gather over full neighbour lists, only positions and
 dF travel (forward); the reference's two reverse exchanges (rho, forces) do not
 exist here.  Every ghost direction is filled (the non-AR shell).
+
+Division of labour: the REBUILD (migration, ghost layout, index lists; every ~17 steps) is driven from
+here over torch.distributed; the STEP itself is native -- imdgpu_dist_md_step (imd_amd/csrc/imdgpu_dist.hip)
+posts the halos as RCCL groups from C, keeps the validity flag on the device and returns only the
+"rebuild needed" bit.
 
 `ops` is the per-rank device: GpuOps (libimdgpu through the C ABI) in production;
 the CPU tests plug in a numpy stand-in with the same methods, which is how the
@@ -269,6 +277,121 @@ class HaloPlan:
             ops.scatter(what, st["ridx_cat"], recv)
 
 
+DIRECTIONS = [(a, b, c) for a in (-1, 0, 1) for b in (-1, 0, 1) for c in (-1, 0, 1) if (a, b, c) != (0, 0, 0)]
+
+
+class DirectHaloPlan:
+    """The 26-message halo of one neighbour list.  For a direction d in {-1,0,1}^3 this rank SENDS the atoms of its
+    boundary cell layer S(d) (cell index 1 where d_k = -1, dim_k - 2 where d_k = +1, all inner cells where d_k = 0) to
+    the rank at coord + d, with the periodic image shift added when that step crosses the box boundary, and RECEIVES
+    from the rank at coord - d the atoms of ITS S(d), which fill this rank's ghost region R(-d) (cell index dim_k - 1
+    where d_k = -1, 0 where d_k = +1).  Directions are walked in one fixed order on every rank, so the messages between
+    one pair of ranks pair up by position (both transports match point-to-point messages in posting order).
+    Ghost atoms are laid out region after region in that order: the receive buffer of a halo IS the ghost range."""
+
+    def __init__(self, dec, ops):
+        self.dec = dec
+        cs, cc = ops.cell_tables()
+        cs, cc = cs.astype(np.int64), cc.astype(np.int64)
+        nlocal = ops.nlocal()
+        D = dec.dim
+        if getattr(dec, "_direct", None) is None:          # geometry only
+            ghost_mask = np.ones(dec.nall, bool)
+            ii, jj, kk = np.meshgrid(range(1, D[0] - 1), range(1, D[1] - 1), range(1, D[2] - 1), indexing="ij")
+            ghost_mask[((ii * D[1] + jj) * D[2] + kk).ravel()] = False
+            segs = []
+            for d in DIRECTIONS:
+                peer_to, peer_from, shift, ok_to, ok_from = [], [], np.zeros(3), True, True
+                for k in range(3):
+                    P, c = dec.cpu_dim[k], dec.coord[k]
+                    t, f = c + d[k], c - d[k]
+                    if t < 0 or t >= P:
+                        if not dec.pbc[k]:
+                            ok_to = False
+                        elif d[k]:
+                            shift = shift + dec.box[k] * (1.0 if t < 0 else -1.0)      # added by the SENDER (:247-266)
+                    if f < 0 or f >= P:
+                        if not dec.pbc[k]:
+                            ok_from = False
+                    peer_to.append(t % P); peer_from.append(f % P)
+
+                def layer(sel):
+                    r = [range(1, D[k] - 1) if sel[k] is None else [sel[k]] for k in range(3)]
+                    a, b, c = np.meshgrid(np.array(list(r[0])), np.array(list(r[1])), np.array(list(r[2])), indexing="ij")
+                    return ((a * D[1] + b) * D[2] + c).ravel().astype(np.int64)
+                send_cells = layer([None if d[k] == 0 else (1 if d[k] < 0 else D[k] - 2) for k in range(3)])
+                # arrivals of direction d come from coord - d and fill my ghost region on the side they come from
+                recv_cells = layer([None if d[k] == 0 else (D[k] - 1 if d[k] < 0 else 0) for k in range(3)])
+                segs.append(dict(d=d, to=coord_to_rank(peer_to, dec.cpu_dim) if ok_to else -1,
+                                 frm=coord_to_rank(peer_from, dec.cpu_dim) if ok_from else -1, shift=shift,
+                                 send_cells=send_cells, recv_cells=recv_cells))
+            dec._direct = (np.flatnonzero(ghost_mask), segs)
+        ghost_cells, segs = dec._direct
+        cc[ghost_cells] = 0
+        self.segs = segs
+        dev = ops.device
+        # per-cell counts travel first: one batch of point-to-point messages in direction order
+        sends = [torch.from_numpy(cc[g["send_cells"]].astype(np.int32)).to(dev) if g["to"] >= 0 else None for g in segs]
+        recvs = _exchange_direct(dec, segs, sends, [len(g["recv_cells"]) for g in segs], torch.int32, dev)
+        nghost = 0
+        send_peer, send_cnt, send_shift, send_idx, recv_peer, recv_cnt = [], [], [], [], [], []
+        for g, cnts in zip(segs, recvs):
+            if g["frm"] < 0:
+                continue
+            cn = cnts.cpu().numpy().astype(np.int64)
+            cells = g["recv_cells"]
+            cc[cells] = cn
+            cs[cells] = nlocal + nghost + np.concatenate([[0], np.cumsum(cn)[:-1]])
+            recv_peer.append(g["frm"]); recv_cnt.append(int(cn.sum()))
+            nghost += int(cn.sum())
+        for g in segs:
+            if g["to"] < 0:
+                continue
+            cells = g["send_cells"]
+            n = cc[cells]
+            idx = np.repeat(cs[cells] - np.concatenate([[0], np.cumsum(n)[:-1]]), n) + np.arange(int(n.sum()))
+            send_peer.append(g["to"]); send_cnt.append(int(n.sum())); send_shift.append(g["shift"]); send_idx.append(idx)
+        self.nghost = nghost
+        ops.set_ghost_layout(cs.astype(np.int32), cc.astype(np.int32), nghost)
+        idx = np.concatenate(send_idx).astype(np.int32) if send_idx else np.zeros(0, np.int32)
+        ops.dist_set_plan(send_peer, send_cnt, np.array(send_shift).reshape(-1, 3), torch.from_numpy(idx).to(dev),
+                          recv_peer, recv_cnt)
+
+    def exchange(self, ops, what):
+        ops.dist_halo(what)
+
+
+def _exchange_direct(dec, segs, sends, recv_len, dtype, dev):
+    """one batch of point-to-point messages in direction order (rebuild time: counts); self-peers short-circuit:
+    my k-th self-send is my k-th self-receive"""
+    me = dec.rank
+    out = [None] * len(segs)
+    stage = _staged() and dev.type == "cuda"
+    tdev = torch.device("cpu") if stage else dev
+    ops, self_sends = [], []
+    for g, b in zip(segs, sends):
+        if g["to"] < 0:
+            continue
+        if g["to"] == me:
+            self_sends.append(b)
+        elif b.numel() > 0:
+            ops.append(dist.P2POp(dist.isend, b.cpu() if stage else b, g["to"]))
+    k = 0
+    for q, g in enumerate(segs):
+        if g["frm"] < 0:
+            continue
+        if g["frm"] == me:
+            out[q] = self_sends[k]; k += 1
+            continue
+        out[q] = torch.empty(recv_len[q], dtype=dtype, device=tdev)
+        if recv_len[q] > 0:
+            ops.append(dist.P2POp(dist.irecv, out[q], g["frm"]))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return [o.to(dev) if (o is not None and stage) else o for o in out]
+
+
 def attach_ttm_mailbox(ops, rank, world, nbr):
     """Create (rank 0) / open the shared-memory file of the TTM face mailbox, map it and hand it to the library.
     Returns the objects that must stay alive.  One node only (the ranks share /dev/shm), like bench.py's contract."""
@@ -292,18 +415,19 @@ def attach_ttm_mailbox(ops, rank, world, nbr):
 
 
 class DistributedMD:
-    """The MD step of one rank among several: same sequence as imdgpu_md_step, with the halo
-    exchanges placed between the force passes (main_loop body, imd_main_3d.c:406-812)."""
+    """The MD loop of one rank among several.  Rebuilds (migration, re-binning, ghost layout, halo plan, list) are
+    driven from here; the step itself is ops.dist_md_step = imdgpu_dist_md_step (C + RCCL, imdgpu_dist.hip), which
+    returns whether some rank's list became invalid (main_loop body, imd_main_3d.c:406-812)."""
 
     def __init__(self, dec, ops, ttm=False):
         self.dec, self.ops, self.ttm = dec, ops, ttm
         self.plan = None
         self.valid = False
-        self._halo_ready = False
         self.nrebuild = 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.ttm_decomposed = bool(ttm and getattr(ops, "ttm_is_decomposed", lambda: False)())
         self.ttm_adv = bool(ttm and getattr(ops, "ttm_has_adv", lambda: False)())
+        ops.dist_init(dec.rank, self.world)
         if ttm and self.ttm_decomposed:
             # every rank diffuses its own block; ghost faces go GPU -> host shared memory -> GPU (imdgpu_ttm_mailbox_*)
             nbr = []
@@ -315,7 +439,7 @@ class DistributedMD:
             for r in range(self.world):
                 c = rank_to_coord(r, dec.cpu_dim)
                 offs += [c[d] * ops.ttm_block_dims()[d] for d in range(3)]
-            self._ttm_offs = torch.tensor(offs, dtype=torch.int32, device=ops.device)
+            ops.dist_set_ttm_blocks(offs)
 
     # -- rebuild: migration, re-binning, ghost layout, neighbour list ------------------------
     def _migrate(self):
@@ -341,14 +465,14 @@ class DistributedMD:
         if self.nrebuild > 0:
             self._migrate()
         ops.fix_cells()
-        self.plan = HaloPlan(self.dec, ops)
+        self.plan = DirectHaloPlan(self.dec, ops)
         changed = 1 if ops.autotile() else 0             # first rebuild: tile shape chosen from the real occupancies
         if self.world > 1 and self.nrebuild == 0:        # building a plan is collective (counts travel): every rank must
             t = torch.tensor([changed], dtype=torch.int32, device=ops.device)    # agree -- a rank in vacuum never re-tiles
             all_reduce_(t, dist.ReduceOp.MAX)
             changed = int(t.item())
         if changed:
-            self.plan = HaloPlan(self.dec, ops)          # local atoms were re-sorted -> new index lists
+            self.plan = DirectHaloPlan(self.dec, ops)    # local atoms were re-sorted -> new index lists
         self.plan.exchange(ops, 0)
         if ops.ntypes > 1:
             self.plan.exchange(ops, 2)
@@ -379,101 +503,47 @@ class DistributedMD:
     # -- one MD step ------------------------------------------------------------------------------
     def md_step(self, step):
         ops = self.ops
-        if os.environ.get("IMDGPU_PY_TIMING"):
-            return self._md_step_timed(step)
         if not self.valid:
             self.rebuild()
-        elif not self._halo_ready:
-            self.plan.exchange(ops, 3)
-        self._halo_ready = False
-        ops.forces_phase(1)
-        if self.ttm:
-            # calc_ttm needs pass 1's neighbour counts and feeds only the integrator: it runs on a side stream
-            # (block of update_fd -> all-gather -> fold in -> diffusion sub-steps) beside the embedding pass, the
-            # dF halo and the EAM force pass, exactly like the single-rank fork in imdgpu_md_step
-            ops.ttm_fork()
-            if self.ttm_decomposed and self.ttm_adv:
-                ops.ttm_update_fd(step)
-                self._commflux()
-                ops.ttm_adv(1.0, step)
-                ops.ttm_lattice_step(step)
-            elif self.ttm_decomposed:
-                ops.ttm_local_step(step)
-            else:
-                blk = ops.ttm_local_block(step)
-                allb = all_gather_flat(blk, self.world)
-                ops.ttm_mark_gathered()
-                ops.ttm_apply_blocks(step, allb, self.world, self._ttm_offs)
-                if self.ttm_adv:                         # calc_ttm's order: update_fd, do_ADV(1.0), the rest
-                    ops.ttm_adv(1.0, step)
-                ops.ttm_lattice_step(step)
-                self._ttm_keep = (blk, allb)             # buffers stay referenced until the join
-            ops.ttm_unfork()
-        ops.forces_phase(2)
-        self.plan.exchange(ops, 1)                       # dF of the ghost atoms  [send_cells(copy_dF)]
-        if self.ttm and not self.ttm_decomposed:
-            # the EAM force pass is a persistent kernel that fills every CU: a collective's multi-wave workgroups that
-            # are not resident by then wait for its end and the whole lattice chain with them.  The
-            # all-gather normally finishes under the dF halo exchange; if not, the force pass waits for it (not for the chain)
-            ops.ttm_wait_gathered()
-        ops.forces_phase(3)
-        if self.ttm:
-            ops.ttm_join()
-        ops.integrate()
-        # the position halo of the NEXT step is enqueued now, before the host blocks on the validity flag: its launch
-        # overhead hides behind that round trip (wasted only on the ~1 step in 17 that ends with a rebuild)
-        self.plan.exchange(ops, 3)                       # xyz only: dF travels separately after the embedding pass
-        self._halo_ready = True
-        flag = torch.tensor([ops.get_invalid()], dtype=torch.int32, device=ops.device)
-        if self.world > 1:
-            all_reduce_(flag, dist.ReduceOp.MAX)         # MPI_Allreduce MAX of check_nblist
-        if int(flag.item()):
+        if self.ttm and self.ttm_decomposed and self.ttm_adv:
+            return self._md_step_host(step)          # do_COMMFLUX sits between update_fd and do_ADV: host-driven variant
+        if ops.dist_md_step(step):                   # some rank's list became invalid during this step
             self.valid = False
-            self._halo_ready = False
-            ops.invalidate()
 
-    def _md_step_timed(self, step):
-        """Debugging aid (IMDGPU_PY_TIMING=1): the same step with a device synchronisation after every phase;
-        prints wall-clock milliseconds per phase (serialised, so the sum is larger than a normal step)."""
-        import time
-        ops, t = self.ops, {}
-
-        def lap(name, t0):
-            torch.cuda.synchronize()
-            t[name] = t.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
-            return time.perf_counter()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
+    def calc_forces(self):
+        """forces of the CURRENT positions, complete (all three passes with their halos), e.g. before a download"""
+        ops = self.ops
         if not self.valid:
-            self.rebuild(); t0 = lap("rebuild", t0)
+            self.rebuild()
         else:
-            self.plan.exchange(ops, 3); t0 = lap("halo_pos", t0)
-        ops.forces_phase(1); t0 = lap("pass1", t0)
-        if self.ttm:
-            if self.ttm_decomposed and self.ttm_adv:
-                ops.ttm_update_fd(step); self._commflux(); ops.ttm_adv(1.0, step); ops.ttm_lattice_step(step)
-            elif self.ttm_decomposed:
-                ops.ttm_local_step(step)
-            else:
-                blk = ops.ttm_local_block(step); allb = all_gather_flat(blk, self.world)
-                ops.ttm_apply_blocks(step, allb, self.world, self._ttm_offs)
-                if self.ttm_adv:
-                    ops.ttm_adv(1.0, step)
-                ops.ttm_lattice_step(step)
-            t0 = lap("ttm", t0)
-        ops.forces_phase(2); t0 = lap("pass2", t0)
-        self.plan.exchange(ops, 1); t0 = lap("halo_dF", t0)
-        ops.forces_phase(3); t0 = lap("pass3", t0)
-        ops.integrate(); t0 = lap("integrate", t0)
+            self.plan.exchange(ops, 3)
+        ops.forces_phase(1); ops.forces_phase(2)
+        self.plan.exchange(ops, 1)
+        ops.forces_phase(3)
+
+    def _md_step_host(self, step):
+        """The same step with the phases called one by one from the host (needed only where an exchange of the host layer
+        sits inside the lattice chain: decomposed lattice WITH advection); one flag round trip per step."""
+        ops = self.ops
+        self.plan.exchange(ops, 3)
+        ops.forces_phase(1)
+        ops.ttm_fork()
+        ops.ttm_update_fd(step)
+        self._commflux()
+        ops.ttm_adv(1.0, step)
+        ops.ttm_lattice_step(step)
+        ops.ttm_unfork()
+        ops.forces_phase(2)
+        self.plan.exchange(ops, 1)                   # dF of the ghost atoms  [send_cells(copy_dF)]
+        ops.forces_phase(3)
+        ops.ttm_join()
+        ops.integrate()
         flag = torch.tensor([ops.get_invalid()], dtype=torch.int32, device=ops.device)
         if self.world > 1:
-            all_reduce_(flag, dist.ReduceOp.MAX)
+            all_reduce_(flag, dist.ReduceOp.MAX)     # MPI_Allreduce MAX of check_nblist
         if int(flag.item()):
             self.valid = False
             ops.invalidate()
-        t0 = lap("flag", t0)
-        if dist.is_initialized() is False or dist.get_rank() == 0:
-            print("[py timing] step %d: " % step + " ".join("%s=%.3f" % kv for kv in t.items()), file=sys.stderr)
 
     def global_sums(self):
         s = self.ops.get_sums()
@@ -482,6 +552,68 @@ class DistributedMD:
         if self.world > 1:
             all_reduce_(t)
         return dict(tot_pot_energy=float(t[0]), virial=float(t[1]), tot_kin_energy=float(t[2]), natoms=int(t[3]))
+
+
+def make_host_transport(ops, rank, world):
+    """imdgpu_exchange_fn for rehearsals without RCCL: device buffers are staged through the host and travel over
+    torch.distributed (gloo).  Messages between one pair of ranks match in posting order, like RCCL's."""
+    import ctypes as C
+    L = ops.L
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    LL = C.POINTER(C.c_longlong)
+    FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), LL, LL, C.c_int,
+                     C.POINTER(C.c_int), LL, LL, C.c_int)
+
+    def d2h(ptr, nbytes):
+        a = np.empty(nbytes, np.uint8)
+        if nbytes and hip.hipMemcpy(a.ctypes.data, ptr, nbytes, 2):
+            raise RuntimeError("hipMemcpy D2H failed")
+        return a
+
+    def h2d(ptr, a):
+        a = np.ascontiguousarray(a)
+        if a.nbytes and hip.hipMemcpy(ptr, a.ctypes.data, a.nbytes, 1):
+            raise RuntimeError("hipMemcpy H2D failed")
+
+    def fn(user, op, dsend, drecv, nsend, sp, so, sc, nrecv, rp, ro, rc, eb):
+        try:
+            if op == 0:
+                reqs, outs = [], []
+                for k in range(nsend):
+                    buf = torch.from_numpy(d2h(dsend + so[k] * eb, sc[k] * eb))
+                    reqs.append(dist.P2POp(dist.isend, buf, int(sp[k])))
+                for k in range(nrecv):
+                    buf = torch.empty(rc[k] * eb, dtype=torch.uint8)
+                    outs.append((ro[k], buf))
+                    reqs.append(dist.P2POp(dist.irecv, buf, int(rp[k])))
+                if reqs:
+                    for w in dist.batch_isend_irecv(reqs):
+                        w.wait()
+                for off, buf in outs:
+                    h2d(drecv + off * eb, buf.numpy())
+            elif op in (1, 3):
+                dt = np.int32 if op == 1 else np.float64
+                t = torch.from_numpy(d2h(dsend, nsend * eb).view(dt).copy())
+                if world > 1:
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM)
+                h2d(drecv, t.numpy())
+            elif op == 2:
+                t = torch.from_numpy(d2h(dsend, nsend * eb).view(np.float64).copy())
+                out = [torch.empty_like(t) for _ in range(world)]
+                if world > 1:
+                    dist.all_gather(out, t)
+                else:
+                    out = [t]
+                h2d(drecv, torch.cat(out).numpy())
+            else:
+                return 1
+            return 0
+        except BaseException:
+            import traceback
+            traceback.print_exc()
+            return 1
+    return FN(fn)
 
 
 class GpuOps:
@@ -556,6 +688,51 @@ class GpuOps:
         C = self.C
         self._ck(self.L.imdgpu_migrate_apply(self.h, C.c_void_p(r_lo.data_ptr() if n_lo else 0), n_lo,
                                              C.c_void_p(r_hi.data_ptr() if n_hi else 0), n_hi))
+
+    # -- native step (imdgpu_dist.hip) -------------------------------------------------------------------
+    def dist_init(self, rank, world):
+        """RCCL communicators created by the library itself when torch.distributed runs on nccl (or alone on one rank);
+        under gloo (several ranks sharing one GPU in the tests) the same C step logic gets a host-staged transport."""
+        C = self.C
+        use_rccl = (not dist.is_initialized() and world == 1) or (dist.is_initialized() and dist.get_backend() == "nccl")
+        if os.environ.get("IMDGPU_DIST_TRANSPORT") == "callback":
+            use_rccl = False
+        if use_rccl:
+            uid = [None]
+            if rank == 0:
+                buf = C.create_string_buffer(256)
+                self._ck(self.L.imdgpu_dist_unique_id(buf, 256))
+                uid[0] = bytes(buf.raw)
+            if world > 1:
+                dist.broadcast_object_list(uid, src=0)
+            self._ck(self.L.imdgpu_dist_init_rccl(self.h, world, rank, uid[0], 256))
+            self.transport = "rccl"
+        else:
+            self._cb = make_host_transport(self, rank, world)
+            self._ck(self.L.imdgpu_dist_init_callback(self.h, world, rank, C.cast(self._cb, C.c_void_p), None))
+            self.transport = "host callback (%s)" % (dist.get_backend() if dist.is_initialized() else "single rank")
+
+    def dist_set_plan(self, send_peer, send_cnt, send_shift, send_idx, recv_peer, recv_cnt):
+        C = self.C
+        ip = C.POINTER(C.c_int)
+        sp, sc = np.ascontiguousarray(send_peer, np.int32), np.ascontiguousarray(send_cnt, np.int32)
+        rp, rc = np.ascontiguousarray(recv_peer, np.int32), np.ascontiguousarray(recv_cnt, np.int32)
+        sh = np.ascontiguousarray(send_shift, np.float64).reshape(-1)
+        self._ck(self.L.imdgpu_dist_set_plan(self.h, len(sp), sp.ctypes.data_as(ip), sc.ctypes.data_as(ip),
+                                             sh.ctypes.data_as(C.POINTER(C.c_double)), C.c_void_p(send_idx.data_ptr()),
+                                             len(rp), rp.ctypes.data_as(ip), rc.ctypes.data_as(ip)))
+
+    def dist_halo(self, what):
+        self._ck(self.L.imdgpu_dist_halo(self.h, int(what)))
+
+    def dist_set_ttm_blocks(self, offs):
+        a = np.ascontiguousarray(offs, np.int32)
+        self._ck(self.L.imdgpu_dist_set_ttm_blocks(self.h, a.ctypes.data_as(self.C.POINTER(self.C.c_int))))
+
+    def dist_md_step(self, step):
+        v = self.C.c_int()
+        self._ck(self.L.imdgpu_dist_md_step(self.h, int(step), self.C.byref(v)))
+        return bool(v.value)
 
     def fix_cells(self): self.s.fix_cells()
 

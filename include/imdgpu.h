@@ -285,6 +285,40 @@ int imdgpu_ttm_mailbox_attach(imdgpu_ctx *ctx, void *host_base, size_t bytes_per
 /* [calc_ttm] for this rank's block: update_fd, activation, FILLMESH, face publication, the sub-steps */
 int imdgpu_ttm_local_step(imdgpu_ctx *ctx, int steps);
 
+/* ---- native multi-GPU step: C host + RCCL over xGMI (imd_amd/csrc/imdgpu_dist.hip) ------------------------------
+ * Replaces, per step, what the reference does with MPI: send_cells(copy_cell) before pass 1 and send_cells(copy_dF)
+ * before the EAM force pass (imd_forces_nbl.c:311,786; imd_comm_force_3d.c:222-396) and the MPI_Allreduce of the list
+ * validity (imd_forces_nbl.c:1087).  The 26 ghost regions of a rank are filled by 26 DIRECT messages in one RCCL group
+ * (every GPU of the node has its own xGMI link to every other one); the validity flag is all-reduced on the device and
+ * guards the next step's pass 1, which is enqueued before the host reads the flag.  Rebuilds (migration, ghost layout,
+ * plan, list) stay with the host layer between two calls.  All of it runs on the context's stream. */
+/* host transport for rehearsals without RCCL (several ranks on ONE GPU): op 0 = point-to-point segments (element
+ * offsets / counts into dev_send / dev_recv, elem_bytes each; messages between one pair of ranks match in the order
+ * they are listed), 1 = all-reduce MAX of nsend int32 in place, 2 = all-gather of nsend doubles per rank into dev_recv,
+ * 3 = all-reduce SUM of nsend doubles in place.  Called with the stream drained; returns 0 on success. */
+typedef int (*imdgpu_exchange_fn)(void *user, int op, void *dev_send, void *dev_recv, int nsend, const int *send_peer,
+                                  const long long *send_off, const long long *send_cnt, int nrecv, const int *recv_peer,
+                                  const long long *recv_off, const long long *recv_cnt, int elem_bytes);
+/* rank 0 makes the communicator ids (nbytes >= 256: two ncclUniqueId), the launcher hands them to every rank */
+int imdgpu_dist_unique_id(void *out, int nbytes);
+int imdgpu_dist_init_rccl(imdgpu_ctx *ctx, int nranks, int rank, const void *unique_id, int nbytes);
+int imdgpu_dist_init_callback(imdgpu_ctx *ctx, int nranks, int rank, imdgpu_exchange_fn fn, void *user);
+/* after imdgpu_set_ghost_layout: the send segments (peer rank, atoms, periodic shift added by the sender
+ * [imd_comm_force_3d.c:247-266], atom indices on the device, segment after segment) and the receive segments; the
+ * ghost atoms [nlocal, nlocal + nghost) lie in the order of the receive segments */
+int imdgpu_dist_set_plan(imdgpu_ctx *ctx, int nsend, const int *send_peer, const int *send_count, const double *send_shift,
+                         const int *dev_send_idx, int nrecv, const int *recv_peer, const int *recv_count);
+/* one halo exchange: what = 0 (x,y,z,dF), 1 dF [copy_dF], 2 type, 3 (x,y,z) [copy_cell per step] */
+int imdgpu_dist_halo(imdgpu_ctx *ctx, int what);
+/* replicated TTM lattice: FD-cell offset of every rank's update_fd block, 3 ints per rank */
+int imdgpu_dist_set_ttm_blocks(imdgpu_ctx *ctx, const int *offs);
+/* one MD step (forces, calc_ttm, integrator, list check); *rebuild_needed != 0: some rank's list became invalid in this
+ * step -- migrate / re-bin / re-plan / make_nblist before the next call.  After the call the force arrays already
+ * belong to the NEXT step's pass 1 (enqueued ahead); positions, momenta and sums are those of this step. */
+int imdgpu_dist_md_step(imdgpu_ctx *ctx, int steps, int *rebuild_needed);
+/* sum of n <= 16 host doubles over the ranks (energies) */
+int imdgpu_dist_allreduce_sum(imdgpu_ctx *ctx, double *vals, int n);
+
 /* ---- profiling ------------------------------------------------------------ */
 /* Accumulate HIP-event timings per kernel class on the context's stream. */
 int imdgpu_profile_enable(imdgpu_ctx *ctx, int on);

@@ -98,6 +98,93 @@ class NumpyOps:
         elif what == 3:
             self.pos[i, :3] = buf.numpy().reshape(-1, 3)
 
+    # -- the native step's interface (imdgpu_dist_*), restated for the stand-in: same plan, same sequence ------------
+    def dist_init(self, rank, world):
+        self.rank, self.world = rank, world
+        self._halo_ready = False
+        self._ttm_offs = None
+
+    def dist_set_plan(self, send_peer, send_cnt, send_shift, send_idx, recv_peer, recv_cnt):
+        self._plan = dict(sp=list(send_peer), sc=list(send_cnt), sh=np.asarray(send_shift, float).reshape(-1, 3),
+                          idx=send_idx.numpy().astype(np.int64), rp=list(recv_peer), rc=list(recv_cnt))
+        assert sum(recv_cnt) == self.nghost
+        self._halo_ready = False
+
+    def dist_halo(self, what):
+        import torch.distributed as dist
+        P = self._plan
+        w = {0: 4, 1: 1, 2: 1, 3: 3}[what]
+        off, bufs = 0, []
+        for k, n in enumerate(P["sc"]):
+            i = P["idx"][off:off + n]; off += n
+            if what == 0:
+                b = self.pos[i].copy(); b[:, :3] += P["sh"][k]
+            elif what == 1:
+                b = self.pos[i, 3].copy()
+            elif what == 2:
+                b = self.type[i].astype(np.float64) if len(self.type) > i.max(initial=-1) else np.zeros(n)
+            else:
+                b = self.pos[i, :3] + P["sh"][k]
+            bufs.append(np.ascontiguousarray(b, dtype=np.float64).reshape(-1))
+        reqs, selfq, outs = [], [], []
+        for k, n in enumerate(P["sc"]):
+            if n == 0:
+                continue
+            if P["sp"][k] == self.rank:
+                selfq.append(bufs[k])
+            else:
+                reqs.append(dist.P2POp(dist.isend, torch.from_numpy(bufs[k]), P["sp"][k]))
+        at, q = self.n, 0
+        for k, n in enumerate(P["rc"]):
+            if n == 0:
+                continue
+            if P["rp"][k] == self.rank:
+                outs.append((at, n, torch.from_numpy(selfq[q]))); q += 1
+            else:
+                t = torch.empty(n * w, dtype=torch.float64)
+                reqs.append(dist.P2POp(dist.irecv, t, P["rp"][k]))
+                outs.append((at, n, t))
+            at += n
+        if reqs:
+            for r in dist.batch_isend_irecv(reqs):
+                r.wait()
+        for at, n, t in outs:
+            a = t.numpy()
+            if what == 0:
+                self.pos[at:at + n] = a.reshape(-1, 4)
+            elif what == 1:
+                self.pos[at:at + n, 3] = a
+            elif what == 3:
+                self.pos[at:at + n, :3] = a.reshape(-1, 3)
+
+    def dist_set_ttm_blocks(self, offs):
+        self._ttm_offs = torch.tensor(list(offs), dtype=torch.int32)
+
+    def dist_md_step(self, step):
+        import torch.distributed as dist
+        if not self._halo_ready:
+            self.dist_halo(3)
+        self._halo_ready = False
+        self.forces_phase(1)
+        if self._ttm_offs is not None:               # replicated lattice: block -> all-gather -> fold in -> lattice step
+            blk = self.ttm_local_block(step)
+            out = [torch.empty_like(blk) for _ in range(self.world)]
+            dist.all_gather(out, blk)
+            self.ttm_apply_blocks(step, torch.cat(out), self.world, self._ttm_offs)
+            self.ttm_lattice_step(step)
+        self.forces_phase(2)
+        self.dist_halo(1)
+        self.forces_phase(3)
+        self.integrate()
+        self.dist_halo(3)
+        flag = torch.tensor([self.invalid], dtype=torch.int32)
+        if self.world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()):
+            return True
+        self._halo_ready = True
+        return False
+
     # -- migration -------------------------------------------------------------------
     def migrate_scan(self, d):
         dec = self.dec

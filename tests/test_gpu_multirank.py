@@ -54,11 +54,7 @@ def _worker_body(rank, world, port, case, cpu_dim, nsteps, ttm, q, decomposed=Fa
     md = DistributedMD(dec, ops, ttm=ttm)
     for st in range(nsteps):
         md.md_step(st)
-    if not md.valid:
-        md.rebuild()
-    else:
-        md.plan.exchange(ops, 0)
-    ops.forces_phase(1); ops.forces_phase(2); md.plan.exchange(ops, 1); ops.forces_phase(3)
+    md.calc_forces()
     sums = md.global_sums()
     d = s.download(fields=("ort", "impuls", "kraft", "nummer", "numneighs"))
     lat = s.ttm_download(fields=("temp", "xi", "natoms", "U", "temp2", "U2", "flux")) if ttm else None

@@ -27,15 +27,24 @@ def _system(external):
     return s, gdim, box
 
 
-def test_distributed_layer_on_one_rank_equals_native_step():
+@pytest.mark.parametrize("self_comm", [False, True])
+def test_distributed_layer_on_one_rank_equals_native_step(self_comm, monkeypatch):
+    """self_comm: the 26 self-neighbour messages, the flag all-reduce and the TTM all-gather really go through RCCL
+    (ncclSend/ncclRecv to the own rank in one group, collectives on a one-rank communicator) instead of the local
+    short cuts -- the only way to execute the RCCL calls of imdgpu_dist.hip on a one-GPU box."""
     import torch
     from imd_amd.parallel import Decomposition, DistributedMD, GpuOps
+    if self_comm:
+        monkeypatch.setenv("IMDGPU_DIST_SELF_COMM", "1")
     ref, gdim, box = _system(False)
     s, _, _ = _system(True)
-    md = DistributedMD(Decomposition(0, (1, 1, 1), gdim, box, (1, 1, 1)), GpuOps(s, 0), ttm=True)
+    ops = GpuOps(s, 0)
+    md = DistributedMD(Decomposition(0, (1, 1, 1), gdim, box, (1, 1, 1)), ops, ttm=True)
+    assert ops.transport == "rccl"
     for step in range(25):                       # two list rebuilds at this temperature
         ref.md_step(step)
         md.md_step(step)
+    ref.calc_forces(25); md.calc_forces()        # (the native step leaves the NEXT step's pass 1 in the force arrays)
     s.synchronize(); torch.cuda.synchronize()
     a, b = ref.download(), s.download()
     oa, ob = np.argsort(a["nummer"]), np.argsort(b["nummer"])

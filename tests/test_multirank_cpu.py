@@ -82,8 +82,7 @@ def _worker(rank, world, port, cpu_dim, nsteps, q):
     md = DistributedMD(dec, ops)
     for st in range(nsteps):
         md.md_step(st)
-    md.rebuild() if not md.valid else md.plan.exchange(ops, 0)
-    ops.forces_phase(1); ops.forces_phase(2); md.plan.exchange(ops, 1); ops.forces_phase(3)
+    md.calc_forces()
     sums = md.global_sums()
     q.put((rank, ops.id.copy(), ops.pos[:ops.n, :3].copy(), ops.p.copy(), ops.f.copy(), sums, md.nrebuild))
     dist.destroy_process_group()
@@ -127,11 +126,6 @@ class _FakeTtmOps:
         return 1000.0 * step + lin[..., None] + 0.1 * np.arange(6)
 
     def ttm_block_dims(self): return self.bdim
-    def ttm_fork(self): self.calls.append("fork")
-    def ttm_unfork(self): self.calls.append("unfork")
-    def ttm_join(self): self.calls.append("join")
-    def ttm_mark_gathered(self): self.calls.append("mark")
-    def ttm_wait_gathered(self): self.calls.append("wait")
 
     def ttm_local_block(self, step):
         import torch
@@ -178,11 +172,10 @@ def _worker_ttm(rank, world, port, cpu_dim, q):
 @pytest.mark.parametrize("cpu_dim", [(2, 1, 1), (2, 2, 1)])
 def test_ttm_blocks_are_gathered_into_the_replicated_lattice(cpu_dim):
     """The TTM part of the multi-rank step on CPUs (gloo): update_fd block of every rank -> all-gather -> fold into the
-    replicated lattice at the rank's FD-cell offset -> lattice step, on the side stream between pass 1 and the
-    integrator, the EAM force pass waiting for the gather."""
+    replicated lattice at the rank's FD-cell offset (the offsets DistributedMD hands to imdgpu_dist_set_ttm_blocks) ->
+    lattice step."""
     world = int(np.prod(cpu_dim))
     res = _run_ranks(_worker_ttm, world, (cpu_dim,))
     for rank, lat, calls, gfd in res:
         assert np.array_equal(lat, _FakeTtmOps.expected(gfd, 2)), rank            # the lattice of the last step, complete
-        per_step = ["fork", "mark", "lattice_step", "unfork", "wait", "join"]
-        assert calls == per_step * 3, calls
+        assert calls == ["lattice_step"] * 3, calls
