@@ -284,6 +284,11 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         _spawn_ranks(args)
+    # stdout carries exactly ONE JSON line: everything native libraries print while they start up (RCCL's version banner
+    # goes to stdout) is diverted to stderr; the real stdout comes back just before rank 0 prints the result
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -376,7 +381,10 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
             out["cpu_baseline"]["gpu_over_cpu_atom_steps"] = out["atom_steps_per_s"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if world > 1:
         dist.destroy_process_group()
     sysm.close()

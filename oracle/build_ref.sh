@@ -9,7 +9,7 @@
 # oracle/ref_probe.c, a read-only observation probe attached with ld --wrap.
 #
 # usage: oracle/build_ref.sh [target ...]
-#   targets: eam_nve_nbl  nve_nbl  eam_nve  nve  mpi_eam_nve_nbl  mpi_eam_ttm3d_nbl  mpi_eam_ttm3d_laser_nbl  dropin
+#   targets: eam_nve_nbl  nve_nbl  eam_nve  nve  mpi_eam_nve_nbl  mpi_eam_ttm3d_nbl  mpi_eam_ttm3d_laser_nbl  fdtd_probe  dropin
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 REF="${IMD_REFERENCE:-/root/reference}"
@@ -55,7 +55,7 @@ build() {
   echo "built $OUT/imd_$name"
 }
 
-TARGETS="${*:-eam_nve_nbl nve_nbl eam_nve mpi_eam_nve_nbl mpi_eam_ttm3d_nbl mpi_eam_ttm3d_laser_nbl dropin}"
+TARGETS="${*:-eam_nve_nbl nve_nbl eam_nve mpi_eam_nve_nbl mpi_eam_ttm3d_nbl mpi_eam_ttm3d_laser_nbl fdtd_probe dropin}"
 for t in $TARGETS; do
   case "$t" in
     eam_nve_nbl) build "$t" "-DNBL -DEAM2 -DNVE" "$COMMON $NBLSRC" "$CC" "" ;;
@@ -82,6 +82,19 @@ for t in $TARGETS; do
       build "$t" "-DMPI -DNBL -DEAM2 -DTTM -DTMM -DEOSMODE=1 -DLASER" \
             "$COMMON $NBLSRC imd_mpi_util.c imd_ttm_3D.c imd_interpol.c fminbnd3.c imd_laser.c" \
             "$CC -I$MPIINC/include" "-L$MPIINC/lib -Wl,-rpath,$MPIINC/lib -lmpi" ;;
+    fdtd_probe)
+      # the reference's 1D Maxwell solver at function level (see oracle/ref_probe_fdtd.c): imd_fdtd.c + imd_misc.c
+      # (error()) from the reference, the harness as MAIN; imd_ttm_3D.c does not compile with -DFDTD as shipped
+      MPIINC="${MPI_HOME:-/opt/conda}"
+      if [ ! -f "$MPIINC/include/mpi.h" ]; then echo "no MPI at $MPIINC, skipping $t" >&2; continue; fi
+      obj="$OUT/obj_fdtd_probe"; mkdir -p "$obj"
+      FD="-DMPI -DNBL -DEAM2 -DTTM -DTMM -DEOSMODE=1 -DFDTD"
+      $CC -I$MPIINC/include $BASEFLAGS $FD -c "$REF/imd_fdtd.c" -o "$obj/imd_fdtd.o"
+      $CC -I$MPIINC/include $BASEFLAGS $FD -c "$REF/imd_misc.c" -o "$obj/imd_misc.o"
+      $CC -I$MPIINC/include $BASEFLAGS $FD -c "$HERE/ref_probe_fdtd.c" -o "$obj/ref_probe_fdtd.o"
+      $CC -o "$OUT/ref_probe_fdtd" "$obj/ref_probe_fdtd.o" "$obj/imd_fdtd.o" "$obj/imd_misc.o" \
+          -L$MPIINC/lib -Wl,-rpath,$MPIINC/lib -lmpi -lm
+      echo "built $OUT/ref_probe_fdtd" ;;
     dropin) ;;    # built below
     *) echo "unknown target $t" >&2; exit 1 ;;
   esac

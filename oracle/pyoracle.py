@@ -467,3 +467,79 @@ def read_ttm_probe(path):
         stages[tag] = dict(max_dt_ttm=mdt, lat=rec)
     H["stages"] = stages
     return H
+
+
+# ---------------------------------------------------------------------------
+# 1D Maxwell solver (oracle/fdtd_oracle.c) and the dumps of oracle/ref_probe_fdtd.c
+# ---------------------------------------------------------------------------
+
+class _Fdtd(C.Structure):
+    _fields_ = [("nx", C.c_int), ("fd_min_atoms", C.c_int), ("bw", C.c_int), ("srcx_int", C.c_int), ("containssrc", C.c_int),
+                ("laser_active", C.c_int)] + \
+               [(n, C.c_double) for n in ("Imp0", "fd_dx", "Sc_FDTD", "dt", "omega_laser", "Nlambdax", "E0", "E0_init", "t0",
+                                          "sigma_t_squared", "laser_timefun")] + \
+               [(n, C.POINTER(C.c_double)) for n in ("Ezx", "Hy", "Jzx", "Jlzx", "Pzx", "source", "sigmay", "Jzx_old", "Jlzx_old",
+                                                     "DL")] + [("natoms", C.POINTER(C.c_int))]
+
+
+FDTD_FIELDS = ("Ezx", "Hy", "Jzx", "Jlzx", "Pzx", "source", "sigmay", "Jzx_old", "Jlzx_old")
+
+
+class OracleFDTD:
+    def __init__(self, nx, fd_h_x, I0, lam, sigma_t, t0, srcx, bw, Sc, fd_min_atoms=5):
+        L = lib()
+        L.orc_fdtd_new.restype = C.POINTER(_Fdtd)
+        L.orc_fdtd_new.argtypes = [C.c_int] + [C.c_double] * 6 + [C.c_int, C.c_double, C.c_int]
+        L.orc_fdtd_free.argtypes = [C.POINTER(_Fdtd)]
+        L.orc_fdtd_begin_md_step.argtypes = [C.POINTER(_Fdtd), C.c_double, C.c_double, C.POINTER(C.c_double)]
+        L.orc_fdtd_step.argtypes = [C.POINTER(_Fdtd), C.c_double]
+        self._p = L.orc_fdtd_new(int(nx), float(fd_h_x), float(I0), float(lam), float(sigma_t), float(t0), float(srcx),
+                                 int(bw), float(Sc), int(fd_min_atoms))
+        self.f = self._p.contents
+        aa = np.ctypeslib.as_array
+        for n in FDTD_FIELDS:
+            setattr(self, n, aa(getattr(self.f, n), (nx,)))
+        self.DL = aa(self.f.DL, (6 * nx,)).reshape(nx, 6)
+        self.natoms = aa(self.f.natoms, (nx,))
+
+    def begin_md_step(self, t_SI, timestep):
+        tau = C.c_double()
+        n = lib().orc_fdtd_begin_md_step(self._p, float(t_SI), float(timestep), C.byref(tau))
+        return n, tau.value
+
+    def step(self, t): lib().orc_fdtd_step(self._p, float(t))
+
+    def close(self):
+        if self._p is not None:
+            lib().orc_fdtd_free(self._p)
+            self._p = None
+
+
+def read_fdtd_probe(path):
+    b = open(path, "rb").read()
+    assert b[:8] == b"IMDFDTD1" and b[-8:] == b"ENDFDTD1"
+    off = 8
+    hi = np.frombuffer(b, "<i4", 4, off); off += 16
+    hd = np.frombuffer(b, "<f8", 8, off); off += 64
+    nx = int(hi[0])
+    H = dict(nx=nx, bw=int(hi[1]), srcx_int=int(hi[2]), containssrc=int(hi[3]), dt_FDTD=float(hd[0]), fd_dx=float(hd[1]),
+             E0=float(hd[2]), E0_init=float(hd[3]), Nlambdax=float(hd[4]), Imp0=float(hd[5]), sigma_t_squared=float(hd[6]),
+             omega_laser=float(hd[7]))
+    rec = np.dtype([("natoms", "<i4"), ("dens", "<f8"), ("temp", "<f8"), ("ne", "<f8"), ("DL", "<f8", 6)])
+    H["cells"] = np.frombuffer(b, rec, nx, off).copy(); off += rec.itemsize * nx
+    H["dumps"], H["md"] = {}, []
+
+    def rd():
+        nonlocal off
+        tag = b[off:off + 16].split(b"\0")[0].decode(); off += 16
+        t, ltf = np.frombuffer(b, "<f8", 2, off); off += 16
+        a = np.frombuffer(b, "<f8", 9 * nx, off).reshape(nx, 9).copy(); off += 72 * nx
+        H["dumps"][tag] = dict(t_SI=float(t), laser_timefun=float(ltf), **{n: a[:, q] for q, n in enumerate(FDTD_FIELDS)})
+        return tag
+    rd()
+    while off < len(b) - 8:
+        nsub, act = np.frombuffer(b, "<i4", 2, off); off += 8
+        H["md"].append((int(nsub), int(act)))
+        while not rd().startswith("md"):
+            pass
+    return H

@@ -339,6 +339,40 @@ def run_eos_grid():
     print("%-20s %8.1f KB" % ("eos_grid", os.path.getsize(path) / 1024))
 
 
+FDTD_ARGS = dict(nx=160, hx=7.0, lo=60, hi=140, I0=1e16, lam=800e-9, sigma_t=1e-15, t0=3e-15, srcx=2.1e-8, bw=10, Sc=1.0,
+                 nmd=6, timestep=0.1)
+
+
+def run_fdtd_case():
+    """SURVEY 8(f)2 / BASELINE config 5: the reference's own 1D Maxwell solver (do_fdtd, fdtd_softsource, init_fdtd,
+    init_pml; imd_fdtd.c) driven at function level by oracle/ref_probe_fdtd.c (its caller imd_ttm_3D.c does not compile
+    with -DFDTD as shipped) -> tests/golden/fdtd_1d.npz: a 158-cell row, 7 A cells, an 80-cell Al slab behind 60 cells
+    of vacuum, a 1 fs pulse of 1e12 W/cm^2 at 800 nm, six MD steps of 437 FDTD sub-steps each."""
+    a = FDTD_ARGS
+    exe = os.path.join(REFBIN, "ref_probe_fdtd")
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "fdtd.bin")
+        r = subprocess.run([exe, out] + [repr(a[k]) for k in ("nx", "hx", "lo", "hi", "I0", "lam", "sigma_t", "t0", "srcx", "bw",
+                                                               "Sc", "nmd", "timestep")],
+                           cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            print(r.stdout[-3000:]); raise SystemExit("ref_probe_fdtd failed")
+        H = po.read_fdtd_probe(out)
+    o = {"arg_" + k: v for k, v in a.items()}
+    for k in ("nx", "bw", "srcx_int", "containssrc", "dt_FDTD", "fd_dx", "E0", "E0_init", "Nlambdax", "Imp0", "sigma_t_squared",
+              "omega_laser"):
+        o[k] = H[k]
+    for k in ("natoms", "dens", "temp", "ne", "DL"):
+        o["cell_" + k] = H["cells"][k]
+    o["md_nsub"] = np.array([m[0] for m in H["md"]]); o["md_active"] = np.array([m[1] for m in H["md"]])
+    for tag, dmp in H["dumps"].items():
+        for k, v in dmp.items():
+            o["%s_%s" % (tag, k)] = v
+    path = os.path.join(OUT, "fdtd_1d.npz")
+    np.savez_compressed(path, **o)
+    print("%-20s %8.1f KB  dumps: %s" % ("fdtd_1d", os.path.getsize(path) / 1024, " ".join(H["dumps"])))
+
+
 def run_adv_case(name, c):
     """do_ADV fixture: the reference on TWO ranks along x (mpiexec -n 2), every rank's lattice dumped by
     oracle/ref_probe_ttm.c around update_fd / do_ADV / the sub-steps and assembled here into the GLOBAL lattice
@@ -500,12 +534,14 @@ def run_ttm_file_case():
 
 
 if __name__ == "__main__":
-    names = sys.argv[1:] or (list(CASES) + ["eos_inverse", "eos_grid", "chkpt", "ttm_file"])
+    names = sys.argv[1:] or (list(CASES) + ["eos_inverse", "eos_grid", "fdtd_1d", "chkpt", "ttm_file"])
     for n in names:
         if n == "eos_inverse":
             run_eos_inverse()
         elif n == "eos_grid":
             run_eos_grid()
+        elif n == "fdtd_1d":
+            run_fdtd_case()
         elif n == "ttm_file":
             run_ttm_file_case()
         elif n == "chkpt":
