@@ -55,6 +55,8 @@ struct TtmState {
   MailboxDev mbd{};
   unsigned long long *d_gbase = nullptr; // index of the next face publication (monotone over the whole run)
   int *d_facecnt = nullptr;              // per face: workgroups that finished publishing (monotone)
+  struct FdtdState *fdtd = nullptr;      // 1D Maxwell solver on a one-row lattice (imdgpu_ttm_fdtd_*, end of this file)
+  int fdtd_on = 0;
 };
 
 // physical constants of the reference, globals.h:324-331,1190
@@ -978,6 +980,8 @@ static Lat make_lat(const TtmState *t)
   return L;
 }
 
+static void imdgpu_fdtd_free(TtmState *t);
+static int fdtd_lattice_loop(imdgpu_ctx *ctx, TtmState *t, const Lat &L, int steps);
 void imdgpu_ttm_free(imdgpu_ctx *ctx)
 {
   TtmState *t = ctx->ttm;
@@ -989,6 +993,7 @@ void imdgpu_ttm_free(imdgpu_ctx *ctx)
   if (t->mb_host) (void) hipHostUnregister(t->mb_host);
   if (t->d_gbase) (void) hipFree(t->d_gbase);
   if (t->d_facecnt) (void) hipFree(t->d_facecnt);
+  imdgpu_fdtd_free(t);
   delete t;
   ctx->ttm = nullptr;
 }
@@ -1394,6 +1399,11 @@ extern "C" int imdgpu_ttm_lattice_step(imdgpu_ctx *ctx, int steps)
                        t->temp[t->cur], t->fd_k[t->kcur]);
   } else if (imdgpu_ttm_fill_ghost_layers(ctx)) return 1;
   imdgpu_tl_mark(ctx, "ttm_fillmesh");
+  if (t->fdtd && t->fdtd_on) {                               // config 5: the Maxwell solver drives the source inside the loop
+    if (fdtd_lattice_loop(ctx, t, L, steps)) return 1;
+    imdgpu_tl_mark(ctx, "ttm_diff");
+    return 0;
+  }
   if (book_eabs(ctx, t, L, tau, t->nsub)) return 1;          // one 64-thread workgroup, once per MD step
   {
     ProfScope ps(ctx, PROF_TTM_DIFF);
@@ -1529,4 +1539,355 @@ int imdgpu_ttm_step_internal(imdgpu_ctx *ctx, int steps)
   if (imdgpu_calc_ttm(ctx, steps)) return 1;
   double h = 0.5 * ctx->nbl_margin;
   return launch_move_ttm(ctx, h * h);
+}
+
+
+// ===========================================================================================================
+// 1D Maxwell solver as laser source (BASELINE config 5): the reference's do_fdtd -- Yee scheme along x,
+// z-polarised, Drude + Lorentz poles by auxiliary differential equations, split-field PML at both ends, soft source
+// with total-field/scattered-field correction (imd_fdtd.c:63-126 fdtd_softsource, :128-306 do_fdtd, :594-763 init_fdtd,
+// :765-859 init_pml; 1D branches) -- on a lattice of ONE row of FD cells (global_fd_dim.y = z = 1, which init_fdtd
+// demands, :602-614).  calc_ttm's loop (imd_ttm_3D.c:96-122,163-179) runs per MD step
+//     fdtd_substeps x [ do_fdtd(t_SI);  diff_substeps x (do_DIFF, ghosts, do_FILLMESH);  t_SI += tau_FDTD ]
+// with fdtd_substeps ~ 440 for 7 A cells: far too many launches for a chain.  The row has at most ~1000 cells, so the
+// whole loop of an MD step is ONE launch of ONE workgroup, a thread per cell: the fields and the cell's electron state
+// stay in registers, neighbours are read through LDS, two barriers per FDTD update and one per diffusion sub-step.
+// The Drude-Lorentz parameters DL[0..4] come from fitDL's tricubic tables in the reference (DL1..5.txt, not shipped):
+// here they are constants from the host (fitDL's own commented alternative, imd_ttm_3D.c:2921-2937) or a per-cell array;
+// DL[5], the plasma frequency, follows the cell's electron density like :2960.
+// ===========================================================================================================
+#define F_EPS0 8.841941282883075e-12      // globals.h:497-499: the reference's values
+#define F_MU0 1.256637061435917e-06
+#define F_C0 3.0e8
+
+struct FdtdDev {
+  int nx, fd_min_atoms, srcx_int, containssrc, dl_mode;     // dl_mode 0: constants + plasma frequency from ne; 1: per-cell array as is
+  double dt, dx, Nlambdax, Imp0, E0, t0, sigma_t_squared, DLc[5];
+  double *E, *H, *J, *Jl, *P, *sig, *Jo, *Jlo, *DL;
+};
+struct FdtdState {
+  FdtdDev d{};
+  double E0_init = 0, omega_laser = 0, t_SI = 0;
+  int bw = 0, on = 0;
+};
+
+static void imdgpu_fdtd_free(TtmState *t)
+{
+  if (!t->fdtd) return;
+  void *ptrs[] = {t->fdtd->d.E, t->fdtd->d.H, t->fdtd->d.J, t->fdtd->d.Jl, t->fdtd->d.P, t->fdtd->d.sig, t->fdtd->d.Jo, t->fdtd->d.Jlo, t->fdtd->d.DL};
+  for (void *p : ptrs) if (p) (void) hipFree(p);
+  delete t->fdtd;
+  t->fdtd = nullptr; t->fdtd_on = 0;
+}
+
+// one do_fdtd(t) for the cell of this thread; all threads of the block call it (two barriers inside).  sH / sE: LDS rows.
+struct FdtdCell { double E, H, J, Jl, P, Jo, Jlo, src, sig, DL[6]; int active; };
+__device__ __forceinline__ void fdtd_step(const FdtdDev &F, FdtdCell &c, int i, bool have, bool inner, double t, double laser_timefun,
+                                          double *sH, double *sE)
+{
+  const double dt = F.dt, dx = F.dx;
+  const double wt = 2.0 * C_PI * (F_C0 / (dx * F.Nlambdax));
+  const int ilocal = F.srcx_int + 1;
+  if (F.containssrc == 1 && i == ilocal) {                                   // fdtd_softsource, :78-83,114-122 (ilocal < nx)
+    const double ezy2 = (dt / dx) / (F_EPS0);
+    const double Hinc = laser_timefun * sin(wt * (t + dt)) / F.Imp0;
+    c.E += ezy2 * Hinc;
+  }
+  if (have) sH[i] = c.H;                     // every thread of the block passes the two barriers (threads past the row idle)
+  __syncthreads();
+  if (inner) {                                                               // E: n -> n+1, :178-231
+    const double Hm = sH[i - 1];
+    if (c.active) {
+      const double Cb = dt / F_EPS0 / c.DL[0];
+      c.Jo = c.J; c.Jlo = c.Jl;
+      c.E = c.E + Cb * (c.H - Hm) / dx - Cb * c.J - Cb * c.Jl;
+      c.P = c.P + dt * c.Jl;
+    } else {
+      const double ezx1 = (F_EPS0 - 0.5 * dt * c.sig) / (F_EPS0 + 0.5 * dt * c.sig);
+      const double ezx2 = (dt / dx) / (F_EPS0 + 0.5 * dt * c.sig);
+      c.E = ezx1 * c.E + ezx2 * (c.H - Hm);
+    }
+  }
+  if (have) sE[i] = c.E;
+  __syncthreads();
+  if (inner) {                                                               // H: -> n+3/2, currents, power, :236-286
+    const double sigmastary = c.sig * F_MU0 / F_EPS0;
+    const double hy1 = (F_MU0 - 0.5 * dt * sigmastary) / (F_MU0 + 0.5 * dt * sigmastary);
+    const double hy2 = (dt / dx) / (F_MU0 + 0.5 * dt * sigmastary);
+    c.H = hy1 * c.H + hy2 * (sE[i + 1] - c.E);
+    if (c.active) {
+      const double gamma_p = c.DL[1], omegapl_L = c.DL[2], Omega0_L = c.DL[3], Gamma_L = c.DL[4], omega_plasma = c.DL[5];
+      const double CD1 = (2 - dt * gamma_p) / (2 + dt * gamma_p), CL1 = (2 - dt * Gamma_L) / (2 + dt * Gamma_L);
+      const double CD2 = 2 * dt / (2 + dt * gamma_p), CL2 = 2 * dt / (2 + dt * Gamma_L);
+      const double wD2 = omega_plasma * omega_plasma, wL2 = omegapl_L * omegapl_L, w02 = Omega0_L * Omega0_L;
+      c.J = CD1 * c.J + CD2 * (wD2 * F_EPS0 * c.E);
+      c.Jl = CL1 * c.Jl + CL2 * (wL2 * F_EPS0 * c.E - w02 * c.P);
+      const double Jz = (c.J + c.Jo) * 0.5, Jlz = 0.5 * (c.Jl + c.Jlo);
+      const double qe = gamma_p * (Jz * Jz) / F_EPS0 / wD2 + Gamma_L / F_EPS0 / wL2 * (Jlz * Jlz);
+      c.src = 6.3538562638e-26 * qe;                                          // W/m^3 -> IMD units
+    }
+  }
+  if (F.containssrc && i == ilocal - 1) {                                    // TF/SF: no wave towards -x, :293-303
+    const double d = t - F.t0;
+    const double Einc = sin(wt * t) * exp(-0.5 * (d * d) / F.sigma_t_squared) * F.E0;
+    c.H -= (dt / dx) / (F_MU0) * Einc;
+  }
+}
+
+// nsub x [do_fdtd; ndiff x (do_DIFF, do_FILLMESH)] for the whole row, one workgroup.  WITH_TTM = false: the solver alone.
+template <bool WITH_TTM>
+__global__ __launch_bounds__(1024) void k_ttm_fdtd_chain(Lat L, FdtdDev F, int nsub, int ndiff, double t_SI, double tau_fdtd,
+    double tau_diff, int laser_active, double laser_timefun, int steps, const int *natoms, double *T1, double *T2, double *U1,
+    double *U2, double *fd_k, double *Ce, double *fd_g, const double *md_temp, double *source, const double *dens, double *xi,
+    double *Zo, double *neo, EosDev cve, EosDev ee, double *eabs)
+{
+  extern __shared__ double fl[];
+  const int nx = F.nx, i = threadIdx.x;
+  double *sH = fl, *sE = fl + nx, *sT = fl + 2 * nx, *sK = fl + 3 * nx;
+  int *sN = (int *) (fl + 4 * nx);
+  const bool have = i < nx, inner = i >= 1 && i < nx - 1;
+  const int cell = have ? fidx(L, i, 1, 1) : 0, m = L.fd_min_atoms;
+  FdtdCell c{};
+  int nat = 0;
+  double Te = 0, Tprev = 0, U = 0, Uprev = 0, xiv = 0, ce = 0, kk = 0, g = 0, Tl = 0, rho = 0, Zv = 0, nev = 0, eacc = 0;
+  if (have) {
+    c.E = F.E[i]; c.H = F.H[i]; c.J = F.J[i]; c.Jl = F.Jl[i]; c.P = F.P[i]; c.Jo = F.Jo[i]; c.Jlo = F.Jlo[i]; c.sig = F.sig[i];
+    nat = inner ? natoms[cell] : 0;
+    c.active = nat >= m;
+    c.src = WITH_TTM ? source[cell] : 0.0;
+    if (F.dl_mode == 1) for (int q = 0; q < 6; q++) c.DL[q] = F.DL[6 * i + q];
+    else { for (int q = 0; q < 5; q++) c.DL[q] = F.DLc[q]; c.DL[5] = 0.0; }
+    if (WITH_TTM && inner) {
+      Te = T1[cell]; Tprev = T2[cell]; U = U1[cell]; Uprev = U2[cell]; xiv = xi[cell]; ce = Ce[cell]; kk = fd_k[cell]; g = fd_g[cell];
+      Tl = md_temp[cell]; rho = dens[cell]; Zv = Zo[cell]; nev = neo[cell];
+      if (F.dl_mode == 0 && c.active) c.DL[5] = sqrt(nev * C_ECHARGE * C_ECHARGE / C_ECONST / C_EMASS);      // fitDL, :2960
+    }
+    sN[i] = nat;
+  }
+  __syncthreads();
+  // diffusion neighbours along x: ghost cells of a periodic row are the opposite inner cells, of an open row empty
+  const int ilo = i == 1 ? (L.pbc[0] == 1 ? nx - 2 : -1) : i - 1, ihi = i == nx - 2 ? (L.pbc[0] == 1 ? 1 : -1) : i + 1;
+  const bool lo_ok = inner && ilo >= 0 && sN[ilo] >= m, hi_ok = inner && ihi >= 0 && sN[ihi] >= m;
+  double t = t_SI;
+  for (int s = 0; s < nsub; s++) {
+    if (laser_active) fdtd_step(F, c, i, have, inner, t, laser_timefun, sH, sE);       // uniform: laser_active is a kernel argument
+    if (WITH_TTM) {
+      for (int q = 0; q < ndiff; q++) {
+        if (have) { sT[i] = Te; sK[i] = kk; }
+        __syncthreads();
+        if (inner) {
+          if (laser_active) eacc += c.src * L.vol * tau_diff;                          // do_DIFF, :1647-1651
+          if (c.active) {
+            const double xaT = hi_ok ? sT[ihi] : Te, xaK = hi_ok ? sK[ihi] : kk, xbT = lo_ok ? sT[ilo] : Te, xbK = lo_ok ? sK[ilo] : kk;
+            // the y and z faces of a one-row lattice see the cell itself (periodic) or nothing (open): zero flux either way
+            const double Tn = tau_diff / ce * ((((kk + xaK) / 2 * (xaT - Te) * L.invhsq[0]) - ((kk + xbK) / 2 * (Te - xbT) * L.invhsq[0]))
+                                               - g * (Te - Tl) + c.src) + Te;
+            Tprev = Te; Uprev = U;
+            U = U + (Tn - Te) * ce * L.vol / ((double) nat);
+            xiv += (Tn - Tl) * L.xi_fac * g / (Tl * rho);
+            Te = Tn;
+            MeshOut o = mesh_props(L, cve, Te, Tl, rho);
+            Zv = o.Z; nev = o.ne; ce = o.Ce; kk = o.k; g = o.g;
+            if (steps < 1) { U = eos_ee(ee, rho, Te * 11604.5) * 26.9815 * C_AMU * C_J2EV; Uprev = U; }
+            if (F.dl_mode == 0) c.DL[5] = sqrt(nev * C_ECHARGE * C_ECHARGE / C_ECONST / C_EMASS);
+          }
+        }
+        __syncthreads();
+      }
+    }
+    t += tau_fdtd;
+  }
+  if (have) {
+    F.E[i] = c.E; F.H[i] = c.H; F.J[i] = c.J; F.Jl[i] = c.Jl; F.P[i] = c.P; F.Jo[i] = c.Jo; F.Jlo[i] = c.Jlo;
+    if (F.dl_mode == 0 && F.DL) for (int q = 0; q < 6; q++) F.DL[6 * i + q] = c.DL[q];
+    if (WITH_TTM && inner) {
+      source[cell] = c.src;
+      if (c.active) { T1[cell] = Te; T2[cell] = Tprev; U1[cell] = U; U2[cell] = Uprev; xi[cell] = xiv; Ce[cell] = ce; fd_k[cell] = kk;
+                      fd_g[cell] = g; Zo[cell] = Zv; neo[cell] = nev; }
+    } else if (!WITH_TTM && inner) source[i] = c.src;
+  }
+  if (WITH_TTM && eabs) {                       // Eabs_local of this MD step, summed in cell order by one thread (deterministic)
+    __syncthreads();
+    sT[have ? i : 0] = have ? eacc : 0.0;
+    __syncthreads();
+    if (i == 0) { double e = 0; for (int q = 1; q < nx - 1; q++) e += sT[q]; eabs[0] += e; }
+  }
+}
+
+extern "C" int imdgpu_ttm_fdtd_init(imdgpu_ctx *ctx, const imdgpu_fdtd_params *p)
+{
+  NEED_TTM();
+  if (!p) return imdgpu_fail(ctx, "ttm_fdtd_init: no parameters");
+  if (t->dim[1] != 3 || t->dim[2] != 3) return imdgpu_fail(ctx, "ttm_fdtd_init: the 1D Maxwell solver needs a lattice of one row of FD cells (fd_ext covering all MD cells in y and z), like init_fdtd (imd_fdtd.c:602-614)");
+  if (t->pbc[0] == 1) return imdgpu_fail(ctx, "ttm_fdtd_init: x must be open (PML at both ends)");
+  if (ctx->external_halo) return imdgpu_fail(ctx, "ttm_fdtd_init: one rank only");
+  if (t->dim[0] > 1024) return imdgpu_fail(ctx, "ttm_fdtd_init: at most 1022 cells along x");
+  imdgpu_fdtd_free(t);
+  FdtdState *S = new FdtdState();
+  t->fdtd = S;
+  FdtdDev &F = S->d;
+  const int nx = t->dim[0];
+  F.nx = nx; F.fd_min_atoms = t->fd_min_atoms; F.dl_mode = 0;
+  // init_fdtd, :594-652
+  F.Imp0 = sqrt(F_MU0 / F_EPS0);
+  F.dx = t->h[0] / 1e10;
+  F.dt = std::min(1.0, p->Sc) * F.dx / F_C0;
+  const double freq = F_C0 / p->lambda;
+  S->omega_laser = 2.0 * M_PI * freq;
+  F.Nlambdax = F_C0 / (freq * F.dx);
+  F.E0 = sqrt(2.0 * p->I0 * F.Imp0);
+  S->E0_init = F.E0;
+  F.t0 = p->t_0; F.sigma_t_squared = p->sigma_t * p->sigma_t;
+  F.srcx_int = (int) round(p->srcx / F.dx);
+  if (F.srcx_int < p->bw + 10) F.srcx_int = p->bw + 10;
+  F.containssrc = (F.srcx_int <= nx - 2 && F.srcx_int >= 0) ? 1 : 0;
+  S->bw = std::max(p->bw, 5);
+  for (int q = 0; q < 5; q++) F.DLc[q] = p->DL[q];
+  double **arr[] = {&F.E, &F.H, &F.J, &F.Jl, &F.P, &F.sig, &F.Jo, &F.Jlo};
+  for (double **a : arr) { HIPCHK(hipMalloc((void **) a, nx * sizeof(double))); HIPCHK(hipMemset(*a, 0, nx * sizeof(double))); }
+  HIPCHK(hipMalloc((void **) &F.DL, 6 * (size_t) nx * sizeof(double)));
+  HIPCHK(hipMemset(F.DL, 0, 6 * (size_t) nx * sizeof(double)));
+  // init_pml, 1D branch :765-858 (evaluated on the host with the reference's expressions)
+  {
+    const double refl_coeff = 1.0e-12, go = 8.0, bw = (double) S->bw;
+    const double sigma_max = (-log10(refl_coeff) * (go + 1.0) * F_EPS0 * F_C0) / (2.0 * bw * F.dx);
+    const double bf3 = (1.0 * sigma_max) / (pow(bw, go) * (go + 1.0));
+    std::vector<double> sig(nx, 0.0);
+    const int gx = nx - 2;
+    for (int i = 1; i < nx - 1; i++) {
+      const int ig = i - 1;
+      if (ig >= gx - S->bw) {
+        const double idist = (double) (S->bw - ((gx - 1) - ig));
+        sig[i] = bf3 * (pow(idist + 0.5, go + 1.0) - pow(idist - 0.5 * (ig > gx - 1 - S->bw), go + 1.0));
+      } else if (ig <= S->bw) {
+        const double idist = (double) (S->bw - ig);
+        sig[i] = bf3 * (pow(idist + 0.5, go + 1.0) - pow(idist - 0.5 * (ig < S->bw), go + 1.0));
+      }
+    }
+    HIPCHK(hipMemcpy(F.sig, sig.data(), nx * sizeof(double), hipMemcpyHostToDevice));
+  }
+  S->t_SI = 0.0; S->on = 1; t->fdtd_on = 1;
+  t->have_source = 1;
+  t->omega_laser = S->omega_laser;                 // init_fdtd sets the global the wide-range model reads (:633)
+  return 0;
+}
+
+// per-cell Drude-Lorentz parameters (6 per cell of the row, ghost cells included) instead of the constants
+extern "C" int imdgpu_ttm_fdtd_set_dl(imdgpu_ctx *ctx, const double *DL)
+{
+  NEED_TTM();
+  if (!t->fdtd) return imdgpu_fail(ctx, "ttm_fdtd_set_dl: imdgpu_ttm_fdtd_init first");
+  t->fdtd->d.dl_mode = DL ? 1 : 0;
+  if (DL) HIPCHK(hipMemcpy(t->fdtd->d.DL, DL, 6 * (size_t) t->fdtd->d.nx * sizeof(double), hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int imdgpu_ttm_fdtd_get(imdgpu_ctx *ctx, double *dt_FDTD, double *E0, int *srcx_int, double *t_SI)
+{
+  NEED_TTM();
+  if (!t->fdtd) return imdgpu_fail(ctx, "ttm_fdtd_get: imdgpu_ttm_fdtd_init first");
+  if (dt_FDTD) *dt_FDTD = t->fdtd->d.dt;
+  if (E0) *E0 = t->fdtd->d.E0;
+  if (srcx_int) *srcx_int = t->fdtd->d.srcx_int;
+  if (t_SI) *t_SI = t->fdtd->t_SI;
+  return 0;
+}
+extern "C" int imdgpu_ttm_fdtd_set_time(imdgpu_ctx *ctx, double t_SI)
+{
+  NEED_TTM();
+  if (!t->fdtd) return imdgpu_fail(ctx, "ttm_fdtd_set_time: imdgpu_ttm_fdtd_init first");
+  t->fdtd->t_SI = t_SI;
+  return 0;
+}
+
+// the fields of the row (nx values each, ghost cells included; NULL = skip).  which: 0 Ezx, 1 Hy, 2 Jzx, 3 Jlzx, 4 Pzx,
+// 5 sigmay, 6 Jzx of the step before, 7 Jlzx of the step before
+extern "C" int imdgpu_ttm_fdtd_fields(imdgpu_ctx *ctx, int which, double *out)
+{
+  NEED_TTM();
+  if (!t->fdtd) return imdgpu_fail(ctx, "ttm_fdtd_fields: imdgpu_ttm_fdtd_init first");
+  const FdtdDev &F = t->fdtd->d;
+  double *src[] = {F.E, F.H, F.J, F.Jl, F.P, F.sig, F.Jo, F.Jlo};
+  if (which < 0 || which > 7) return imdgpu_fail(ctx, "ttm_fdtd_fields: which = 0..7");
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpy(out, src[which], F.nx * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// what calc_ttm settles once per MD step (imd_ttm_3D.c:96-122): envelope at the start of the step, solver on/off,
+// the number of FDTD sub-steps, the diffusion sub-steps inside each, and their lengths
+static void fdtd_plan_step(const imdgpu_ctx *ctx, const TtmState *t, const FdtdState *S, int *nsub, int *ndiff, double *tau_f,
+                           double *tau_d, int *active, double *timefun)
+{
+  const FdtdDev &F = S->d;
+  const double d = S->t_SI + F.dt - F.t0;
+  *timefun = F.E0 * exp(-0.5 * (d * d) / F.sigma_t_squared);
+  *active = !(*timefun < S->E0_init * 1e-4);
+  const double dt_md = ctx->timestep * 10.18 * 1.0e-15;
+  if (*active) {
+    *nsub = (int) (dt_md / F.dt + 1.0);
+    int nd = std::max(*nsub, t->max_dt_ttm > 0 ? (int) (ctx->timestep / t->max_dt_ttm) : 0);
+    nd = std::max(nd, t->nsub);
+    nd = (int) (((double) nd) / ((double) *nsub));
+    *ndiff = std::max(nd, 1);
+    *tau_f = dt_md / ((double) *nsub);
+    *tau_d = *tau_f / ((double) *ndiff) / (10.18 * 1.0e-15);
+  } else {
+    *nsub = std::max(t->nsub, t->max_dt_ttm > 0 ? (int) (ctx->timestep / t->max_dt_ttm) : 0);
+    *ndiff = 1;
+    *tau_f = dt_md / ((double) *nsub);
+    *tau_d = *tau_f / (10.18 * 1.0e-15);
+  }
+}
+
+// the solver alone: nsub x do_fdtd from time t_SI on with a fixed envelope value (function-level parity with do_fdtd);
+// the dissipated power lands in the lattice's source array (row cells i, 1, 1)
+extern "C" int imdgpu_ttm_fdtd_substeps(imdgpu_ctx *ctx, double t_SI, int nsub, double tau_FDTD, double laser_timefun)
+{
+  NEED_TTM();
+  if (!t->fdtd) return imdgpu_fail(ctx, "ttm_fdtd_substeps: imdgpu_ttm_fdtd_init first");
+  FdtdDev F = t->fdtd->d;
+  const int thr = (F.nx + 63) / 64 * 64;
+  // the bare solver works on a contiguous row: use a scratch row for the source and copy it into the lattice afterwards
+  double *row = nullptr;
+  HIPCHK(hipMalloc((void **) &row, F.nx * sizeof(double)));
+  HIPCHK(hipMemsetAsync(row, 0, F.nx * sizeof(double), ctx->stream));
+  hipLaunchKernelGGL((k_ttm_fdtd_chain<false>), dim3(1), dim3(thr), (4 * F.nx + F.nx / 2 + 2) * sizeof(double), ctx->stream, L, F, nsub, 0,
+                     t_SI, tau_FDTD, 0.0, 1, laser_timefun, 1, t->natoms, (double *) nullptr, (double *) nullptr, (double *) nullptr,
+                     (double *) nullptr, (double *) nullptr, (double *) nullptr, (double *) nullptr, (const double *) nullptr, row,
+                     (const double *) nullptr, (double *) nullptr, (double *) nullptr, (double *) nullptr, t->cve, t->ee, (double *) nullptr);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  std::vector<double> h(F.nx), lat(t->ncell);
+  HIPCHK(hipMemcpy(h.data(), row, F.nx * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(lat.data(), t->source, t->ncell * sizeof(double), hipMemcpyDeviceToHost));
+  for (int i = 1; i < F.nx - 1; i++) lat[(i * t->dim[1] + 1) * t->dim[2] + 1] = h[i];
+  HIPCHK(hipMemcpy(t->source, lat.data(), t->ncell * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipFree(row));
+  t->fdtd->t_SI = t_SI + nsub * tau_FDTD;
+  return 0;
+}
+
+// the lattice loop of one MD step with the Maxwell solver inside (called by imdgpu_ttm_lattice_step when the solver is on)
+static int fdtd_lattice_loop(imdgpu_ctx *ctx, TtmState *t, const Lat &L, int steps)
+{
+  FdtdState *S = t->fdtd;
+  int nsub, ndiff, active; double tau_f, tau_d, timefun;
+  fdtd_plan_step(ctx, t, S, &nsub, &ndiff, &tau_f, &tau_d, &active, &timefun);
+  Lat L2 = L;
+  // do_DIFF's xi_fac divides by the GLOBAL diff_substeps (imd_ttm_3D.c:1614), which inside the solver loop is the number of
+  // diffusion sub-steps per FDTD sub-step (:116-118), not their total per MD step: xi therefore accumulates
+  // fdtd_substeps times the weight it has without the solver.  Reproduced as the source has it.
+  L2.xi_fac = 26.9815 * C_AMU / 3.0 * 1e30 / ((double) ndiff);
+  FdtdDev F = S->d;
+  const int thr = (F.nx + 63) / 64 * 64;
+  t->laser_active = active;
+  ProfScope ps(ctx, PROF_TTM_DIFF);
+  hipLaunchKernelGGL((k_ttm_fdtd_chain<true>), dim3(1), dim3(thr), (4 * F.nx + F.nx / 2 + 2) * sizeof(double), ctx->stream, L2, F, nsub, ndiff,
+                     S->t_SI, tau_f, tau_d, active, timefun, steps, t->natoms, t->temp[t->cur], t->temp[t->cur ^ 1], t->U[t->cur],
+                     t->U[t->cur ^ 1], t->fd_k[t->kcur], t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve,
+                     t->ee, t->d_eabs);
+  HIPCHK(hipGetLastError());
+  S->t_SI += nsub * tau_f;
+  return 0;
 }

@@ -27,6 +27,8 @@ SYMBOLS = [
     "imdgpu_migrate_scan", "imdgpu_migrate_gather", "imdgpu_migrate_apply", "imdgpu_forces_phase", "imdgpu_integrate",
     "imdgpu_get_invalid", "imdgpu_invalidate", "imdgpu_ttm_local_block", "imdgpu_ttm_apply_blocks",
     "imdgpu_ttm_lattice_step", "imdgpu_ttm_mailbox_bytes", "imdgpu_ttm_mailbox_attach", "imdgpu_ttm_local_step",
+    "imdgpu_ttm_fdtd_init", "imdgpu_ttm_fdtd_set_dl", "imdgpu_ttm_fdtd_substeps", "imdgpu_ttm_fdtd_fields",
+    "imdgpu_ttm_fdtd_get", "imdgpu_ttm_fdtd_set_time",
     "imdgpu_dist_unique_id", "imdgpu_dist_init_rccl", "imdgpu_dist_init_callback", "imdgpu_dist_set_plan",
     "imdgpu_dist_halo", "imdgpu_dist_set_ttm_blocks", "imdgpu_dist_md_step", "imdgpu_dist_allreduce_sum",
 ]
@@ -62,6 +64,12 @@ TTM_INT_FIELDS = ("natoms", "natoms_old", "flux")
 class LaserParamsC(C.Structure):
     _fields_ = [("dir", C.c_int * 3), ("offset", C.c_double), ("mu", C.c_double), ("p_peak", C.c_double),
                 ("t_0", C.c_double), ("sigma_t_squared", C.c_double)]
+
+
+class FdtdParamsC(C.Structure):
+    """imdgpu_fdtd_params"""
+    _fields_ = [("I0", C.c_double), ("lam", C.c_double), ("sigma_t", C.c_double), ("t_0", C.c_double), ("srcx", C.c_double),
+                ("bw", C.c_int), ("Sc", C.c_double), ("DL", C.c_double * 5)]
 
 
 class TtmFieldsC(C.Structure):
@@ -142,6 +150,12 @@ def load():
     L.imdgpu_ttm_eos_te_from_r_ee.argtypes = [vp, C.c_int, dp, dp, dp]
     L.imdgpu_ttm_eos_lookup.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp]
     L.imdgpu_move_atoms_ttm.argtypes = [vp, dp]
+    L.imdgpu_ttm_fdtd_init.argtypes = [vp, C.POINTER(FdtdParamsC)]
+    L.imdgpu_ttm_fdtd_set_dl.argtypes = [vp, dp]
+    L.imdgpu_ttm_fdtd_substeps.argtypes = [vp, C.c_double, C.c_int, C.c_double, C.c_double]
+    L.imdgpu_ttm_fdtd_fields.argtypes = [vp, C.c_int, dp]
+    L.imdgpu_ttm_fdtd_get.argtypes = [vp, dp, dp, ip, dp]
+    L.imdgpu_ttm_fdtd_set_time.argtypes = [vp, C.c_double]
     L.imdgpu_dist_unique_id.argtypes = [C.c_char_p, C.c_int]
     L.imdgpu_dist_init_rccl.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.c_int]
     L.imdgpu_dist_init_callback.argtypes = [vp, C.c_int, C.c_int, vp, vp]

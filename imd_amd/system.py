@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import lib as _lib
-from .lib import TTM_FIELDS, TTM_INT_FIELDS, ImdGpuError, LaserParamsC, PotTableC, TtmFieldsC, TtmParamsC
+from .lib import TTM_FIELDS, TTM_INT_FIELDS, FdtdParamsC, ImdGpuError, LaserParamsC, PotTableC, TtmFieldsC, TtmParamsC
 
 
 def _dp(a):
@@ -309,6 +309,37 @@ class GpuSystem:
     def set_laser(self, **laser):
         """calc_ttm applies the laser source after update_fd in every step from now on (no arguments: off)"""
         self._ck(self.L.imdgpu_ttm_set_laser(self.h, C.byref(self._laser(**laser)) if laser else None))
+
+    # -- 1D Maxwell solver (imd_fdtd.c) on a one-row lattice -------------------------------------------------------------
+    AL_DRUDE_LORENTZ = (2.73, 1.1174e+15, 7.6595e+15, 2.4024e+15, 4.5199e+14)     # fitDL's constants for Al, imd_ttm_3D.c:2921-2928
+
+    def init_fdtd(self, I0, lam, sigma_t, t_0, srcx, bw=15, Sc=1.0, DL=AL_DRUDE_LORENTZ):
+        """init_fdtd / init_pml (imd_fdtd.c:594-859); SI units as in the reference's parameter file"""
+        p = FdtdParamsC()
+        p.I0, p.lam, p.sigma_t, p.t_0, p.srcx, p.bw, p.Sc = float(I0), float(lam), float(sigma_t), float(t_0), float(srcx), int(bw), float(Sc)
+        p.DL[:] = [float(v) for v in DL]
+        self._ck(self.L.imdgpu_ttm_fdtd_init(self.h, C.byref(p)))
+
+    def fdtd_set_dl(self, DL):
+        a = None if DL is None else np.ascontiguousarray(DL, dtype=np.float64)
+        self._ck(self.L.imdgpu_ttm_fdtd_set_dl(self.h, None if a is None else _dp(a)))
+
+    def do_fdtd(self, t_SI, nsub, tau_FDTD, laser_timefun):
+        """nsub x do_fdtd(t) (imd_fdtd.c:128-306), t advancing by tau_FDTD"""
+        self._ck(self.L.imdgpu_ttm_fdtd_substeps(self.h, float(t_SI), int(nsub), float(tau_FDTD), float(laser_timefun)))
+
+    def fdtd_fields(self):
+        out = {}
+        for q, n in enumerate(("Ezx", "Hy", "Jzx", "Jlzx", "Pzx", "sigmay", "Jzx_old", "Jlzx_old")):
+            out[n] = np.zeros(self.fd_dim[0])
+            self._ck(self.L.imdgpu_ttm_fdtd_fields(self.h, q, _dp(out[n])))
+        return out
+
+    def fdtd_info(self):
+        dt, e0, t = C.c_double(), C.c_double(), C.c_double()
+        sx = C.c_int()
+        self._ck(self.L.imdgpu_ttm_fdtd_get(self.h, C.byref(dt), C.byref(e0), C.byref(sx), C.byref(t)))
+        return dict(dt_FDTD=dt.value, E0=e0.value, srcx_int=sx.value, t_SI=t.value)
 
     def get_eabs(self):
         """Eabs_local: absorbed laser energy [eV] booked by do_DIFF so far (imd_ttm_3D.c:1647-1651)"""

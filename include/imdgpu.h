@@ -217,6 +217,25 @@ int imdgpu_ttm_eos_te_from_r_ee(imdgpu_ctx *ctx, int n, const double *r, const d
  * bilinear inside the grid cell; the reference's rule is linear on a Delaunay triangulation of the same nodes, which
  * agrees at nodes and on cell edges and differs inside a cell by at most |z00 + z11 - z10 - z01| / 4 */
 int imdgpu_ttm_eos_lookup(imdgpu_ctx *ctx, int which, int n, const double *x, const double *y, double *z_out);
+/* ---- 1D Maxwell solver as laser source (BASELINE config 5; imd_fdtd.c) ---------------------------------------------
+ * [init_fdtd :594-763, init_pml :765-859] on a lattice of ONE row of FD cells (fd_ext spans all MD cells in y and z),
+ * open in x.  SI units like the reference's parameters: I0 [W/m^2], lambda [m], sigma_t and t_0 [s], srcx [m] position
+ * of the soft source, bw PML cells, Sc Courant number (<= 1).  DL: Drude-Lorentz constants eps_inf, gamma_p [1/s],
+ * omegapl_L, Omega0_L, Gamma_L [rad/s] (fitDL's constant alternative, imd_ttm_3D.c:2921-2937; its tricubic tables
+ * DL1..5.txt are not part of the reference tree); the Drude plasma frequency follows the cells' electron density.
+ * After this call imdgpu_calc_ttm / imdgpu_ttm_lattice_step run calc_ttm's solver loop (imd_ttm_3D.c:96-122,163-179):
+ * fdtd_substeps x [do_fdtd(t_SI); diff_substeps x (do_DIFF, do_FILLMESH); t_SI += tau_FDTD] in one launch. */
+typedef struct imdgpu_fdtd_params { double I0, lambda, sigma_t, t_0, srcx; int bw; double Sc; double DL[5]; } imdgpu_fdtd_params;
+int imdgpu_ttm_fdtd_init(imdgpu_ctx *ctx, const imdgpu_fdtd_params *p);
+/* per-cell parameters DL[6] for every cell of the row (ghost cells included) instead of the constants; NULL: back */
+int imdgpu_ttm_fdtd_set_dl(imdgpu_ctx *ctx, const double *DL);
+/* [do_fdtd(t), imd_fdtd.c:128-306] nsub times from t_SI on (t += tau_FDTD after each) with the envelope value
+ * laser_timefun held fixed as calc_ttm does within an MD step (:98); the dissipated power goes to the lattice's source */
+int imdgpu_ttm_fdtd_substeps(imdgpu_ctx *ctx, double t_SI, int nsub, double tau_FDTD, double laser_timefun);
+/* which: 0 Ezx, 1 Hy, 2 Jzx, 3 Jlzx, 4 Pzx, 5 sigmay, 6/7 Jzx/Jlzx of the sub-step before; nx values */
+int imdgpu_ttm_fdtd_fields(imdgpu_ctx *ctx, int which, double *out);
+int imdgpu_ttm_fdtd_get(imdgpu_ctx *ctx, double *dt_FDTD, double *E0, int *srcx_int, double *t_SI);
+int imdgpu_ttm_fdtd_set_time(imdgpu_ctx *ctx, double t_SI);
 /* [CFL_maxdt, :2637-2691] */
 int imdgpu_ttm_cfl_maxdt(imdgpu_ctx *ctx, int steps, double *max_dt_ttm);
 /* [calc_ttm, first block :50-77 without do_tmm/do_ADV]: update_fd, cell
