@@ -39,8 +39,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="experiment: no HIP events around the kernel classes in the timed region (roofline then reports 0)")
-    ap.add_argument("--laser", action="store_true",
-                    help="config 5, Beer-Lambert variant: laser_rescale_ttm source (imd_laser.c:715) applied in every step")
+    ap.add_argument("--laser", nargs="?", const="beer", default=None, choices=["beer", "fdtd"],
+                    help="config 5: `--laser` / `--laser beer` = Beer-Lambert source laser_rescale_ttm (imd_laser.c:715) in every\n"
+                         "step; `--laser fdtd` = the 1D Maxwell solver (imd_fdtd.c) on a slab: open x with vacuum in front of and\n"
+                         "behind the atoms, ONE row of FD cells along x (fd_ext 1 ny nz), pulse centred on the timed region")
     ap.add_argument("--cpu-box", type=int, default=48, help="unit cells per direction of the CPU sample")
     ap.add_argument("--cpu-steps", type=int, default=30)
     ap.add_argument("--cpu-steps-mpi", type=int, default=40, help="steps of the multi-core (MPI + TTM) reference sample")
@@ -76,10 +78,23 @@ def build_system(args, rank, world, device):
         coord = rank_to_coord(rank, cpu_dim)
     gbox_param = [args.box[d] * cpu_dim[d] for d in range(3)]
     box = lattice.fcc_box(gbox_param, a)
-    cd = tuple(cpu_dim[d] * (fd_ext[d] if ttm else 1) for d in range(3))
-    gdim = global_cell_dim(box, cellsz, cd)
+    pbc, shift_x = (1, 1, 1), 0.0
+    if args.laser == "fdtd":
+        if world > 1:
+            raise SystemExit("bench.py --laser fdtd: one GPU (the reference's 1D solver row is not decomposed either)")
+        # slab: 45 MD cells of vacuum in front (PML 15 + source + run-up), 25 behind; the lattice is one row of FD cells
+        gd0 = global_cell_dim(box, cellsz)
+        hx = box[0, 0] / gd0[0]
+        shift_x = 45 * hx
+        box = box.copy(); box[0, 0] += 70 * hx
+        pbc = (0, 1, 1)
+        gdim = (gd0[0] + 70, gd0[1], gd0[2])
+        fd_ext = (1, gd0[1], gd0[2])
+    else:
+        cd = tuple(cpu_dim[d] * (fd_ext[d] if ttm else 1) for d in range(3))
+        gdim = global_cell_dim(box, cellsz, cd)
     cell_dim = tuple(gdim[d] // cpu_dim[d] + 2 for d in range(3))
-    sysm = GpuSystem(box, (1, 1, 1), cell_dim, 1, cellsz, nbl_margin, 0.1, device=device, global_cell_dim=gdim,
+    sysm = GpuSystem(box, pbc, cell_dim, 1, cellsz, nbl_margin, 0.1, device=device, global_cell_dim=gdim,
                      cpu_dim=cpu_dim, my_coord=coord, count_ttm_neighbours=ttm,
                      external_halo=args.force_distributed,
                      ttm_decomposed=ttm and (world > 1 or args.force_distributed) and args.ttm_decomposed)
@@ -87,11 +102,16 @@ def build_system(args, rank, world, device):
     if ttm:
         from imd_amd import ttm as ttm_mod
         ttm_mod.attach_default(sysm, fd_ext=fd_ext, diff_substeps=100, fd_min_atoms=5)
-        if args.laser:          # a gentle pulse along x peaking at step 150: mu = 1/(20 A), 0.4 eV/A^2 fluence, sigma_t = 5 time units
+        if args.laser == "fdtd":
+            # 800 nm, 2e11 W/cm^2, sigma_t 60 fs centred 150 MD steps in (the timed region follows 50 warm-up steps): the
+            # solver is active during the whole timed region; source 30 cells in front of the surface
+            sysm.init_fdtd(I0=2e15, lam=800e-9, sigma_t=60e-15, t_0=150 * 0.1 * 10.18e-15, srcx=25 * (box[0, 0] / gdim[0]) * 1e-10,
+                           bw=15, Sc=1.0)
+        elif args.laser:          # a gentle pulse along x peaking at step 150: mu = 1/(20 A), 0.4 eV/A^2 fluence, sigma_t = 5 time units
             sig_t, mu, sig_e = 5.0, 0.05, 0.4
             sysm.set_laser(direction=(1, 0, 0), offset=0.0, mu=mu, p_peak=mu * sig_e / sig_t / np.sqrt(2 * np.pi),
                            t_0=15.0, sigma_t_squared=sig_t * sig_t)
-    pos = lattice.fcc_positions(args.box, a) + np.array([coord[d] * args.box[d] * a for d in range(3)])
+    pos = lattice.fcc_positions(args.box, a) + np.array([coord[d] * args.box[d] * a for d in range(3)]) + np.array([shift_x, 0.0, 0.0])
     mom = lattice.maxwell_momenta(len(pos), 26.9815, args.temp, seed=12345 + rank)
     ident = np.arange(len(pos), dtype=np.int64) + rank * len(pos)
     sysm.upload_atoms(pos, mom, 26.9815, None, (ident % (2 ** 31 - 1)).astype(np.int32))
@@ -361,8 +381,9 @@ def main():
             "config": {"workload": "FCC Al %dx%dx%d unit cells per GPU (%d atoms/GPU), synthetic tabulated EAM "
                                    "(r_c 6.5 A), nbl_margin 0.5, dt 0.1, T0 %.4f eV, %s" %
                                    (args.box[0], args.box[1], args.box[2], natoms, args.temp,
-                                    "NVE, no TTM" if args.no_ttm else ("3D TTM fd_ext %d %d %d, diff_substeps 100" % tuple(args.fd_ext)) +
-                                    (", Beer-Lambert laser source (laser_rescale_ttm)" if args.laser else "")),
+                                    "NVE, no TTM" if args.no_ttm else ("3D TTM fd_ext %s, diff_substeps 100" % (" ".join(str(v) for v in sysm.fd_ext))) +
+                                    (", Beer-Lambert laser source (laser_rescale_ttm)" if args.laser == "beer" else
+                                     ", 1D Maxwell solver as laser source (do_fdtd; slab, open x, one row of FD cells)" if args.laser == "fdtd" else "")),
                        "atoms_per_gpu": natoms, "cells": list(gdim), "half_list_entries_per_atom": M,
                        "max_neighbours": maxn, "list_rebuilds_in_timed_region": rebuilds,
                        "kernel_family": "lds_tiles" if sysm.get_info("list_mode") == 1 else "global_gather",

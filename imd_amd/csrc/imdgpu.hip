@@ -579,21 +579,39 @@ struct TileArgs {
   int *counters;
   double cellsz;
   const int *guard;               // pass 1 launched ahead of the host's look at the list-validity flag: *guard != 0 -> return at once
+  int balance;                    // block ranges cut by atoms (boxes with vacuum) instead of by tiles
 };
 
 struct TileCtx { int tile, hx, hy, hz, nh, own_start, nown; };
 
 // Persistent workgroups: block b works on a contiguous range of tiles [t0,t1) (consecutive tiles are
 // neighbours along z, so their halos overlap in L2), and the blocks that share an XCD (b % 8 under the
-// observed round-robin placement; speed only) get adjacent ranges.
-__device__ __forceinline__ void block_tile_range(int ntiles, int &t0, int &t1)
+// observed round-robin placement; speed only) get adjacent ranges.  The ranges are cut by ATOMS, not by
+// tiles: block p gets the tiles whose first own atom lies in [p N/G, (p+1) N/G) -- in a slab with vacuum
+// (config 4, the Maxwell-solver slab) half of the tiles are empty and equal tile counts would idle half the chip.
+// istart[t * CPT] = first own atom of tile t (monotone in t): two binary searches per block.
+__device__ __forceinline__ int tile_of_atom(const int *istart, int CPT, int ntiles, long long atom)
+{
+  int lo = 0, hi = ntiles;                      // the tile that holds `atom`: smallest t with istart[(t + 1) * CPT] > atom
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (istart[(size_t) (mid + 1) * CPT] > atom) hi = mid; else lo = mid + 1; }
+  return lo;
+}
+__device__ __forceinline__ void block_tile_range(int ntiles, const int *istart, int CPT, int nlocal, int balance, int &t0, int &t1)
 {
   const int nwg = gridDim.x, per = nwg >> 3, b = blockIdx.x;
   const int p = (nwg & 7) == 0 ? (b & 7) * per + (b >> 3) : b;
-  const int chunk = (ntiles + nwg - 1) / nwg;
-  t0 = p * chunk; t1 = t0 + chunk;
-  if (t0 > ntiles) t0 = ntiles;
-  if (t1 > ntiles) t1 = ntiles;
+  if (!balance || nlocal <= 0) {                // equal tile counts (dense periodic boxes: identical result, no search)
+    const int chunk = (ntiles + nwg - 1) / nwg;
+    t0 = p * chunk; t1 = t0 + chunk;
+    if (t0 > ntiles) t0 = ntiles;
+    if (t1 > ntiles) t1 = ntiles;
+    return;
+  }
+  // block p: from the tile holding atom ceil(N p / G) up to (not including) the tile holding atom ceil(N (p+1) / G); the last
+  // block ends behind the tile of the last atom.  Empty tiles in front of the first and behind the last atom belong to nobody.
+  const long long a0 = ((long long) nlocal * p + nwg - 1) / nwg, a1 = ((long long) nlocal * (p + 1) + nwg - 1) / nwg;
+  t0 = a0 >= nlocal ? ntiles : tile_of_atom(istart, CPT, ntiles, a0);
+  t1 = a1 >= nlocal ? (a0 >= nlocal ? ntiles : tile_of_atom(istart, CPT, ntiles, (long long) nlocal - 1) + 1) : tile_of_atom(istart, CPT, ntiles, a1);
 }
 
 // halo-cell table + prefix (hstart/hsrc) and staging of positions into LDS as x, y, z planes of slot_cap
@@ -755,7 +773,7 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile(TileArgs a)
   int *hstart = (int *) (sp + 3 * (size_t) a.slot_cap), *hsrc = hstart + NH_MAX + 1;
   TileCtx T;
   int t0, t1;
-  block_tile_range(a.ntiles, t0, t1);
+  block_tile_range(a.ntiles, a.istart, a.g.CPT, a.nlocal, a.balance, t0, t1);
   const unsigned short dummy = (unsigned short) (a.slot_cap - 1);
   int mmax = 0;
   for (T.tile = t0; T.tile < t1; T.tile++) {
@@ -943,7 +961,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile(TileArgs a)
   int *ts = (int *) (scratch + 64);
   TileCtx T;
   int t0, t1;
-  block_tile_range(a.ntiles, t0, t1);
+  block_tile_range(a.ntiles, a.istart, a.g.CPT, a.nlocal, a.balance, t0, t1);
   double sums[2] = {0.0, 0.0};
   int is_short = 0;
   if (t0 < t1) {                                 // tables are loaded once per (persistent) workgroup
@@ -1086,7 +1104,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
   double *scratch = sp + 3 * (size_t) a.slot_cap;
   TileCtx T;
   int t0, t1;
-  block_tile_range(a.ntiles, t0, t1);
+  block_tile_range(a.ntiles, a.istart, a.g.CPT, a.nlocal, a.balance, t0, t1);
   double sums[3] = {0.0, 0.0, 0.0};        // pair energy, virial, embedding energy
   int is_short = 0;
   if (t0 < t1) {
@@ -1189,7 +1207,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) __attribute__((amdgpu_num_vgpr(144
   int *ts = (int *) (scratch + 64);
   TileCtx T;
   int t0, t1;
-  block_tile_range(a.ntiles, t0, t1);
+  block_tile_range(a.ntiles, a.istart, a.g.CPT, a.nlocal, a.balance, t0, t1);
   double sums[1] = {0.0};
   int is_short = 0;
   if (t0 < t1) {
@@ -2017,7 +2035,9 @@ static int tile_grid(const imdgpu_ctx *ctx)
 {
   static const int forced = getenv("IMDGPU_TILE_GRID") ? atoi(getenv("IMDGPU_TILE_GRID")) : 0;   // experiments only
   if (forced > 0) return std::min(ctx->ntiles, forced);
-  return std::min(ctx->ntiles, ctx->num_cus > 0 ? ctx->num_cus : 256);
+  // reserve_cus: CUs left free by the persistent force kernels for a multi-wave workgroup of the lattice stream that cannot
+  // sit beside them on one CU (the single-workgroup Maxwell-solver loop, imdgpu_ttm_fdtd_init)
+  return std::min(ctx->ntiles, (ctx->num_cus > 0 ? ctx->num_cus : 256) - ctx->reserve_cus);
 }
 
 static TileArgs make_tile_args(imdgpu_ctx *ctx)
@@ -2033,6 +2053,7 @@ static TileArgs make_tile_args(imdgpu_ctx *ctx)
   a.pair = ctx->pair.par; a.rho = ctx->rho.par; a.emb = ctx->emb.par; a.posw = ctx->pos; a.merged = ctx->d_merged;
   a.f = ctx->f; a.epot = ctx->epot; a.rhoh = ctx->rhoh; a.ref = ctx->ref; a.numneighs = ctx->numneighs;
   a.partials = ctx->partials; a.counters = ctx->d_counters; a.cellsz = ctx->cellsz; a.guard = nullptr;
+  a.balance = ctx->tile_balance;
   return a;
 }
 
@@ -2095,6 +2116,10 @@ extern "C" int imdgpu_make_nblist(imdgpu_ctx *ctx)
     HIPCHK(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, CNT_N * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     int tile_cap = (std::max(ctx->h_counters[CNT_MAXOWN], 1) + 63) / 64 * 64;
+    {   // uneven occupancy (vacuum, slabs): cut the persistent blocks' tile ranges by atoms, not by tiles
+      static const char *fb = getenv("IMDGPU_TILE_BALANCE");
+      ctx->tile_balance = fb ? atoi(fb) : ((double) ctx->h_counters[CNT_MAXOWN] * ctx->ntiles > 1.25 * (double) std::max(n, 1));
+    }
     ctx->slot_cap = (ctx->h_counters[CNT_MAXHALO] + 1 + 63) / 64 * 64;      // + far-away dummy slot
     ctx->max_halo = ctx->h_counters[CNT_MAXHALO];
     if (tile_cap != ctx->tile_cap) { ctx->tile_cap = tile_cap; ctx->nbr16_cap = 0; }

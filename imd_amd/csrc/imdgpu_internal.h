@@ -124,6 +124,8 @@ struct imdgpu_ctx {
   // TTM state lives in imdgpu_ttm.hip
   struct TtmState *ttm = nullptr;
   // native multi-GPU step (imdgpu_dist.hip)
+  int reserve_cus = 0;
+  int tile_balance = 0;             // set by make_nblist when some tiles are (nearly) empty: see block_tile_range
   void *dist = nullptr;
   const int *pass1_guard = nullptr;   // device int: a pass-1 kernel launched AHEAD of the host's look at the list-validity flag returns at once when it is set
 };

@@ -412,6 +412,95 @@ __global__ void k_ttm_update_fd(Lat L, int steps, int cap, const int *cell_start
   }
 }
 
+// update_fd for FD cells spanning MANY MD cells (fd_ext product > 64, e.g. the one-row lattice of the Maxwell solver:
+// 1 x 78 x 78 MD cells = 130 000 atoms per FD cell): one 1024-thread workgroup per FD cell, a WAVE per MD cell (strided over
+// the cells, lanes over the cell's atoms: coalesced), block-wide sums through LDS in a fixed order (deterministic; the order
+// differs from the reference's sequential loop at rounding level, integers are exact).  No flux bookkeeping here.
+__global__ __launch_bounds__(1024) void k_ttm_update_fd_wide(Lat L, int steps, int cap, const int *cell_start, const int *cell_cnt,
+                                const int *numneighs, const double *p, const double *mass, int *natoms,
+                                int *natoms_old, double *temp0, double *temp1, double *xi, double *md_temp,
+                                double *source, double *vcom, double *dens, int ncell)
+{
+  __shared__ double sd[5][16];
+  __shared__ int si[2][16];
+  __shared__ double bc[4];
+  const int w = blockIdx.x, ni = L.ldim[0], nj = L.ldim[1], nk = L.ldim[2];
+  if (w >= ni * nj * nk) return;
+  const int k = w % nk + 1, j = (w / nk) % nj + 1, i = w / (nk * nj) + 1;
+  const int c = fidx(L, i + L.off[0], j + L.off[1], k + L.off[2]);
+  const int e0 = L.ext[0], e1 = L.ext[1], e2 = L.ext[2], ne = e0 * e1 * e2;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  auto md_cell = [&](int q) {
+    const int xc = (i - 1) * e0 + 1 + q / (e2 * e1), yc = (j - 1) * e1 + 1 + (q / e2) % e1, zc = (k - 1) * e2 + 1 + q % e2;
+    return (xc * L.md_dim[1] + yc) * L.md_dim[2] + zc;
+  };
+  int nat = 0, neigh = 0;
+  double sx = 0, sy = 0, sz = 0, sm = 0;
+  for (int q0 = wv; q0 < ne; q0 += 2 * nw) {                     // two MD cells in flight per wave
+    const int q1 = q0 + nw;
+    const int m0 = md_cell(q0), s0 = cell_start[m0], n0 = cell_cnt[m0];
+    int s1 = 0, n1 = 0;
+    if (q1 < ne) { const int m1 = md_cell(q1); s1 = cell_start[m1]; n1 = cell_cnt[m1]; }
+    if (lane == 0) nat += n0 + n1;
+    for (int a = lane; a < n0 || a < n1; a += 64) {
+      if (a < n0) { const int g = s0 + a; neigh += numneighs[g]; sx += p[g]; sy += p[cap + g]; sz += p[2 * (size_t) cap + g]; sm += mass[g]; }
+      if (a < n1) { const int g = s1 + a; neigh += numneighs[g]; sx += p[g]; sy += p[cap + g]; sz += p[2 * (size_t) cap + g]; sm += mass[g]; }
+    }
+  }
+  nat = wsumi(nat); neigh = wsumi(neigh); sx = wsum(sx); sy = wsum(sy); sz = wsum(sz); sm = wsum(sm);
+  if (lane == 0) { si[0][wv] = nat; si[1][wv] = neigh; sd[0][wv] = sx; sd[1][wv] = sy; sd[2][wv] = sz; sd[3][wv] = sm; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int N = 0, NN = 0; double X = 0, Y = 0, Z = 0, M = 0;
+    for (int q = 0; q < nw; q++) { N += si[0][q]; NN += si[1][q]; X += sd[0][q]; Y += sd[1][q]; Z += sd[2][q]; M += sd[3][q]; }
+    double d = 0, vx = 0, vy = 0, vz = 0;
+    if (N > 0) {
+      d = (double) NN / ((double) N) * L.atomic_weight / L.neighvol * 1660.53907;
+      if (d == 0) d = (double) N * L.atomic_weight / L.vol * 1660.53907;
+      vx = X / M; vy = Y / M; vz = Z / M;
+    }
+    si[0][0] = N; bc[0] = d; bc[1] = vx; bc[2] = vy; bc[3] = vz;
+  }
+  __syncthreads();
+  nat = si[0][0];
+  const double d = bc[0], vx = bc[1], vy = bc[2], vz = bc[3];
+  double mt = 0;
+  for (int q0 = wv; q0 < ne; q0 += 2 * nw) {
+    const int q1 = q0 + nw;
+    const int m0 = md_cell(q0), s0 = cell_start[m0], n0 = cell_cnt[m0];
+    int s1 = 0, n1 = 0;
+    if (q1 < ne) { const int m1 = md_cell(q1); s1 = cell_start[m1]; n1 = cell_cnt[m1]; }
+    for (int a = lane; a < n0 || a < n1; a += 64) {
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int n = h ? n1 : n0, g = (h ? s1 : s0) + a;
+        if (a < n) {
+          const double m = mass[g];
+          double u;
+          u = p[g] / m - vx; mt += m * (u * u);
+          u = p[cap + g] / m - vy; mt += m * (u * u);
+          u = p[2 * (size_t) cap + g] / m - vz; mt += m * (u * u);
+        }
+      }
+    }
+  }
+  mt = wsum(mt);
+  if (lane == 0) sd[4][wv] = mt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double T = 0;
+    for (int q = 0; q < nw; q++) T += sd[4][q];
+    if (nat >= L.fd_min_atoms) T /= 3.0 * nat; else T = 0.0;
+    const int old = natoms[c];
+    natoms_old[c] = (steps < 1) ? nat : old;
+    natoms[c] = nat;
+    xi[c] = 0.0; source[c] = 0.0;
+    dens[c] = d; md_temp[c] = T;
+    vcom[c] = vx; vcom[ncell + c] = vy; vcom[2 * ncell + c] = vz;
+    if (steps < 1 && nat >= L.fd_min_atoms) { temp0[c] = T; temp1[c] = T; }
+  }
+}
+
 __global__ void k_ttm_apply_blocks(Lat L, int steps, int nblocks, const int *offs /* 3 per block */, int bi, int bj, int bk,
                                    const double *in, int *natoms, int *natoms_old, double *temp0, double *temp1,
                                    double *xi, double *md_temp, double *source, double *vcom, double *dens, int ncell,
@@ -1135,6 +1224,14 @@ extern "C" int imdgpu_ttm_update_fd(imdgpu_ctx *ctx, int steps)
 {
   NEED_TTM();
   ProfScope ps(ctx, PROF_TTM_UPDATE);
+  if (t->ext[0] * t->ext[1] * t->ext[2] > 64) {             // FD cells over many MD cells: a workgroup per FD cell
+    if (ctx->ttm_flux) return imdgpu_fail(ctx, "update_fd: the flux bookkeeping (ttm_flux / ttm_adv) is not available for FD cells of more than 64 MD cells");
+    hipLaunchKernelGGL(k_ttm_update_fd_wide, dim3(t->ldim[0] * t->ldim[1] * t->ldim[2]), dim3(1024), 0, ctx->stream, L, steps,
+                       ctx->cap_local, ctx->cell_start, ctx->cell_cnt, ctx->numneighs, ctx->p, ctx->mass, t->natoms,
+                       t->natoms_old, t->temp[0], t->temp[1], t->xi, t->md_temp, t->source, t->vcom, t->dens, t->ncell);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(k_ttm_update_fd, dim3(nblk((long long) t->ldim[0] * t->ldim[1] * t->ldim[2] * 64, TTM_WG)), dim3(TTM_WG), 0, ctx->stream, L, steps,
                      ctx->cap_local, ctx->cell_start, ctx->cell_cnt, ctx->numneighs, ctx->p, ctx->mass, t->natoms,
                      t->natoms_old, t->temp[0], t->temp[1], t->xi, t->md_temp, t->source, t->vcom, t->dens, t->ncell,
@@ -1767,6 +1864,7 @@ extern "C" int imdgpu_ttm_fdtd_init(imdgpu_ctx *ctx, const imdgpu_fdtd_params *p
     HIPCHK(hipMemcpy(F.sig, sig.data(), nx * sizeof(double), hipMemcpyHostToDevice));
   }
   S->t_SI = 0.0; S->on = 1; t->fdtd_on = 1;
+  ctx->reserve_cus = 1;                            // the solver loop is one multi-wave workgroup: it gets a CU of its own beside the force passes
   t->have_source = 1;
   t->omega_laser = S->omega_laser;                 // init_fdtd sets the global the wide-range model reads (:633)
   return 0;

@@ -147,3 +147,45 @@ def test_solver_loop_with_diffusion_vs_oracle():
             # the electrons did heat up where the field got in, and only there
             assert lat["temp"][row].max() > 1.05 * ot.md_temp[row].max()
     of.close(); ot.close(); o.close(); s.close()
+
+
+def test_update_fd_for_fd_cells_of_many_md_cells():
+    """the one-row lattice of a wide slab puts thousands of MD cells under one FD cell (fd_ext 1 ny nz): update_fd then runs a
+    workgroup per FD cell (k_ttm_update_fd_wide) -- same numbers as the oracle's sequential loop (integers exact, sums to
+    rounding)"""
+    hx, nxc, nyz = 7.0, 12, 9
+    pair, rho, emb, r2cut = potential.synthetic_eam_tables()
+    margin = 0.4
+    cellsz = (np.sqrt(r2cut) + margin) ** 2
+    box = np.diag([nxc * hx, nyz * 7.0, nyz * 7.0])
+    nb = (int(round(8 * hx / 4.05)), 15, 15)
+    pos = lattice.fcc_positions(nb, 4.05) * np.array([8 * hx / (nb[0] * 4.05), box[1, 1] / (15 * 4.05), box[2, 2] / (15 * 4.05)])
+    pos = pos + np.array([2 * hx + 0.3, 0.0, 0.0])
+    rng = np.random.default_rng(4)
+    pos = pos + rng.normal(scale=0.03, size=pos.shape)
+    pos[:, 1:] %= box[1, 1]
+    mom = lattice.maxwell_momenta(len(pos), 26.9815, 0.05, seed=4)
+    dim = (nxc + 2, nyz + 2, nyz + 2)
+    s = GpuSystem(box, (0, 1, 1), dim, 1, cellsz, margin, 0.1, count_ttm_neighbours=True)
+    s.upload_tables(pair, rho, emb)
+    s.upload_atoms(pos, mom, 26.9815)
+    cve, ee = ttm_mod.synthetic_eos()
+    s.init_ttm((1, nyz, nyz), 5, 100, 26.9815, 13.0, cve, ee)
+    assert s.fd_dim == (nxc + 2, 3, 3)
+    s.calc_forces(0)
+    s.update_fd(0)
+    lat = s.ttm_download()
+    o = po.OracleSystem(dim, 96, 1, box, (0, 1, 1), cellsz, margin, 0.1)
+    for w, t_ in enumerate((pair, rho, emb)):
+        o.set_table(w, t_.as_dict())
+    o.fill_from_positions(pos, mom, 26.9815)
+    o.s.count_ttm_neigh = 1
+    o.calc_forces(0)
+    ot = po.OracleTTM(o, (1, nyz, nyz), 5, 26.9815, 13.0, float(pair.end[0]))
+    ot.update_fd(0)
+    row = (slice(1, -1), 1, 1)
+    assert np.array_equal(lat["natoms"][row], ot.natoms[row]) and int(ot.natoms[row].sum()) == len(pos)
+    for k in ("md_temp", "dens", "temp"):
+        assert _rel(lat[k][row], getattr(ot, k)[row]) < 1e-12, k
+    assert np.abs(lat["vcom"][row] - ot.vcom[row]).max() < 1e-12 * np.abs(ot.vcom[row]).max() + 1e-18
+    ot.close(); o.close(); s.close()
