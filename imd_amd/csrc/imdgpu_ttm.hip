@@ -14,7 +14,7 @@
 #include <cstring>
 #include <vector>
 
-struct EosDev { int nx, ny; double xmin, xmax, ymin, ymax; const double *z; };
+struct EosDev { int nx, ny; double xmin, xmax, ymin, ymax; const double *z; const unsigned char *diag; };   // diag: see eos_lookup
 
 // descriptor of the shared-memory mailbox of a decomposed lattice (explained above the kernels that use it)
 struct MailboxDev {
@@ -46,6 +46,7 @@ struct TtmState {
   double *xi = nullptr, *md_temp = nullptr, *source = nullptr, *vcom = nullptr /* 3 planes */, *dens = nullptr,
          *fd_g = nullptr, *Z = nullptr, *Ce = nullptr, *ne = nullptr;
   double *cve_z = nullptr, *ee_z = nullptr;
+  unsigned char *eos_diag[2] = {nullptr, nullptr};   // triangulation maps of the two EOS tables (imdgpu_ttm_set_eos_triangulation)
   EosDev cve{}, ee{};
   double *d_red = nullptr;       // reduction scratch
   // one captured sub-step chain per value of `cur` at its start (do_ADV's extra swap alternates it from step to step)
@@ -530,6 +531,12 @@ __global__ void k_ttm_apply_blocks(Lat L, int steps, int nblocks, const int *off
 // wide-range model + EOS (do_FILLMESH and helpers, imd_ttm_3D.c:492-661,
 // :2352-2592, :2694-2783)
 // ---------------------------------------------------------------------------
+// Table look-up.  The reference interpolates LINEARLY ON A TRIANGULATION of the table's nodes (nn-c lpi_interpolate_point,
+// imd_ttm_3D.c:2722,2759); which diagonal splits a grid cell is a property of its triangulator.  With a
+// triangulation map (e.diag, one byte per grid cell: 1 = diagonal (i+1,j)-(i,j+1), 2 = diagonal (i,j)-(i+1,j+1); the
+// level-1 shim reads it off the reference's own interpolator, imdgpu_ttm_set_eos_triangulation) the look-up is that
+// triangle's plane; without one (0) it is bilinear, which agrees at nodes and on cell edges and differs inside a cell
+// by at most a quarter of the cell's twist.
 __device__ double eos_lookup(const EosDev &e, double x, double y)
 {
   double fx = (x - e.xmin) / (e.xmax - e.xmin) * (e.nx - 1);
@@ -544,6 +551,9 @@ __device__ double eos_lookup(const EosDev &e, double x, double y)
   double tx = fx - ix, ty = fy - iy;
   double z00 = e.z[(size_t) ix * e.ny + iy], z01 = e.z[(size_t) ix * e.ny + iy + 1];
   double z10 = e.z[(size_t) (ix + 1) * e.ny + iy], z11 = e.z[(size_t) (ix + 1) * e.ny + iy + 1];
+  const int dg = e.diag ? e.diag[(size_t) ix * (e.ny - 1) + iy] : 0;
+  if (dg == 1) return tx + ty <= 1.0 ? z00 + tx * (z10 - z00) + ty * (z01 - z00) : z11 + (1.0 - tx) * (z01 - z11) + (1.0 - ty) * (z10 - z11);
+  if (dg == 2) return tx >= ty ? z00 + tx * (z10 - z00) + ty * (z11 - z10) : z00 + tx * (z11 - z01) + ty * (z01 - z00);
   return (1 - tx) * ((1 - ty) * z00 + ty * z01) + tx * ((1 - ty) * z10 + ty * z11);
 }
 __device__ double eos_ee(const EosDev &e, double r, double tK) { return eos_lookup(e, r, sqrt(tK)); }
@@ -1083,6 +1093,7 @@ void imdgpu_ttm_free(imdgpu_ctx *ctx)
   if (t->d_gbase) (void) hipFree(t->d_gbase);
   if (t->d_facecnt) (void) hipFree(t->d_facecnt);
   imdgpu_fdtd_free(t);
+  for (int q = 0; q < 2; q++) if (t->eos_diag[q]) (void) hipFree(t->eos_diag[q]);
   delete t;
   ctx->ttm = nullptr;
 }
@@ -1142,8 +1153,8 @@ extern "C" int imdgpu_ttm_init(imdgpu_ctx *ctx, const imdgpu_ttm_params *par)
   if (dev_alloc(ctx, &t->cve_z, nc) || dev_alloc(ctx, &t->ee_z, ne)) return 1;
   HIPCHK(hipMemcpy(t->cve_z, par->cve_z, nc * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(t->ee_z, par->ee_z, ne * sizeof(double), hipMemcpyHostToDevice));
-  t->cve = {par->cve_nx, par->cve_ny, par->cve_xmin, par->cve_xmax, par->cve_ymin, par->cve_ymax, t->cve_z};
-  t->ee = {par->ee_nx, par->ee_ny, par->ee_xmin, par->ee_xmax, par->ee_ymin, par->ee_ymax, t->ee_z};
+  t->cve = {par->cve_nx, par->cve_ny, par->cve_xmin, par->cve_xmax, par->cve_ymin, par->cve_ymax, t->cve_z, nullptr};
+  t->ee = {par->ee_nx, par->ee_ny, par->ee_xmin, par->ee_xmax, par->ee_ymin, par->ee_ymax, t->ee_z, nullptr};
   ctx->count_ttm = 1;
   return 0;
 }
@@ -1283,6 +1294,27 @@ extern "C" int imdgpu_ttm_eos_te_from_r_ee(imdgpu_ctx *ctx, int n, const double 
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipMemcpy(te_out, d + 2 * (size_t) n, n * sizeof(double), hipMemcpyDeviceToHost));
   HIPCHK(hipFree(d));
+  return 0;
+}
+
+// which = 0: cve table, 1: ee table; diag: (nx-1)*(ny-1) bytes, cell (ix, iy) at ix*(ny-1)+iy: 1 = the reference's triangulation
+// splits the cell along (ix+1,iy)-(ix,iy+1), 2 = along (ix,iy)-(ix+1,iy+1), 0 = unknown (bilinear); NULL: back to bilinear
+extern "C" int imdgpu_ttm_set_eos_triangulation(imdgpu_ctx *ctx, int which, const unsigned char *diag)
+{
+  NEED_TTM();
+  if (which != 0 && which != 1) return imdgpu_fail(ctx, "ttm_set_eos_triangulation: which must be 0 (cve) or 1 (ee)");
+  EosDev &e = which ? t->ee : t->cve;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (t->eos_diag[which]) { (void) hipFree(t->eos_diag[which]); t->eos_diag[which] = nullptr; }
+  e.diag = nullptr;
+  if (diag) {
+    const size_t n = (size_t) (e.nx - 1) * (e.ny - 1);
+    for (size_t q = 0; q < n; q++) if (diag[q] > 2) return imdgpu_fail(ctx, "ttm_set_eos_triangulation: entries must be 0, 1 or 2");
+    HIPCHK(hipMalloc((void **) &t->eos_diag[which], n));
+    HIPCHK(hipMemcpy(t->eos_diag[which], diag, n, hipMemcpyHostToDevice));
+    e.diag = t->eos_diag[which];
+  }
+  for (int q = 0; q < 2; q++) if (t->graph[q]) { (void) hipGraphExecDestroy(t->graph[q]); t->graph[q] = nullptr; }   // captured kernel arguments
   return 0;
 }
 

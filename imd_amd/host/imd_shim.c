@@ -426,6 +426,28 @@ static void eos_grid(const nn_interp *nn, const char *what, int *nx, int *ny, do
   }
 }
 
+/* Which diagonal did nn-c's triangulation put into every cell of the table grid?  The reference's own interpolator tells:
+ * at a cell centre lpi_interpolate_point (the call of EOS_cve_from_r_te / EOS_ee_from_r_te, imd_ttm_3D.c:2722,2759) returns
+ * the mean over the two nodes of the diagonal that splits the cell.  The library then interpolates on the same triangles
+ * (imdgpu_ttm_set_eos_triangulation) -- the EOS look-up of the device IS the reference's, not a bilinear approximation. */
+static unsigned char *eos_triangulation(nn_interp *nn, int nx, int ny, const double *z)
+{
+  unsigned char *d = (unsigned char *) malloc((size_t) (nx - 1) * (ny - 1));
+  int i, j;
+  if (NULL == d) error("imd_shim: cannot allocate the EOS triangulation map");
+  for (i = 0; i < nx - 1; i++)
+    for (j = 0; j < ny - 1; j++) {
+      const point *p00 = &nn->points[i * ny + j], *p11 = &nn->points[(i + 1) * ny + j + 1];
+      const double z00 = z[i * ny + j], z01 = z[i * ny + j + 1], z10 = z[(i + 1) * ny + j], z11 = z[(i + 1) * ny + j + 1];
+      const double da = 0.5 * (z10 + z01), db = 0.5 * (z00 + z11);
+      point c;
+      c.x = 0.5 * (p00->x + p11->x); c.y = 0.5 * (p00->y + p11->y); c.z = 0.0;
+      lpi_interpolate_point(nn->interpolator, &c);
+      d[i * (ny - 1) + j] = (c.z != c.z) ? 0 : (fabs(c.z - da) <= fabs(c.z - db) ? 1 : 2);     /* NaN (outside the hull): bilinear */
+    }
+  return d;
+}
+
 static void ttm_gpu_init(void)
 {
   imdgpu_ttm_params par;
@@ -451,6 +473,13 @@ static void ttm_gpu_init(void)
   if (g_multi) gpu_check(imdgpu_set_option(G, "ttm_decomposed", 1));    /* one lattice block per rank, like l1/l2 */
 #endif
   gpu_check(imdgpu_ttm_init(G, &par));
+  if (getenv("IMD_SHIM_EOS_BILINEAR") == NULL) {       /* default: the reference's own triangulation of the two tables */
+    unsigned char *dc = eos_triangulation(&intp_cve_from_r_te, par.cve_nx, par.cve_ny, zc);
+    unsigned char *de = eos_triangulation(&intp_ee_from_r_tesqrt, par.ee_nx, par.ee_ny, ze);
+    gpu_check(imdgpu_ttm_set_eos_triangulation(G, 0, dc));
+    gpu_check(imdgpu_ttm_set_eos_triangulation(G, 1, de));
+    free(dc); free(de);
+  }
 #ifdef MPI
   if (g_multi) {
     /* the ghost faces of {natoms, temp, fd_k} that ttm_fill_ghost_layers moves with MPI_Sendrecv after every sub-step

@@ -273,6 +273,15 @@ class GpuSystem:
         self._ck(self.L.imdgpu_ttm_eos_te_from_r_ee(self.h, int(r.size), _dp(r), _dp(e), _dp(out)))
         return out
 
+    def set_eos_triangulation(self, which, diag):
+        """which diagonal the reference's triangulation puts into every grid cell of EOS table `which` (0 cve, 1 ee):
+        array (nx-1, ny-1) of 0 (unknown: bilinear) / 1 ((i+1,j)-(i,j+1)) / 2 ((i,j)-(i+1,j+1)); None: bilinear everywhere"""
+        if diag is None:
+            self._ck(self.L.imdgpu_ttm_set_eos_triangulation(self.h, int(which), None))
+            return
+        a = np.ascontiguousarray(diag, dtype=np.uint8)
+        self._ck(self.L.imdgpu_ttm_set_eos_triangulation(self.h, int(which), a.tobytes()))
+
     def eos_lookup(self, which, x, y):
         """the raw table look-up behind EOS_cve_from_r_te (which=0) / EOS_ee_from_r_te (which=1): the reference's
         lpi_interpolate_point (imd_ttm_3D.c:2722,2759), vectorised over host arrays, table coordinates"""

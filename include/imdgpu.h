@@ -212,6 +212,13 @@ int imdgpu_ttm_diff(imdgpu_ctx *ctx, double tau);
 /* [EOS_te_from_r_ee, :2786-2811 + fminbnd3.c:6-107] electron temperature in K from density (kg/m^3) and internal
  * energy (table units) for n points on host arrays: the reference's Brent minimisation over the ee(r, sqrt T) table */
 int imdgpu_ttm_eos_te_from_r_ee(imdgpu_ctx *ctx, int n, const double *r, const double *e, double *te_out);
+/* The reference interpolates its EOS tables linearly on a Delaunay TRIANGULATION of the table nodes (nn-c, binary
+ * nn_interpol/libnn.a); on a regular grid which diagonal splits a cell is a property of that triangulator.  A host that
+ * has the reference's interpolators (the level-1 shim does) reads the choice off them -- lpi_interpolate_point at every
+ * cell centre equals the mean over one of the two diagonals -- and hands it over here; the look-up is then the same
+ * triangle's plane as the reference's.  diag: (nx-1)*(ny-1) bytes, cell (ix, iy) at ix*(ny-1)+iy: 1 = diagonal
+ * (ix+1,iy)-(ix,iy+1), 2 = diagonal (ix,iy)-(ix+1,iy+1), 0 = unknown (bilinear in that cell); NULL = bilinear everywhere. */
+int imdgpu_ttm_set_eos_triangulation(imdgpu_ctx *ctx, int which /*0 cve, 1 ee*/, const unsigned char *diag);
 /* [lpi_interpolate_point as called at :2722 (which = 1: ee(r, sqrt T) table) and :2759 (which = 0: cve(r, T) table)]
  * the raw table look-up for n points (x, y) in the table's own coordinates on host arrays, no unit factors.  Rule:
  * bilinear inside the grid cell; the reference's rule is linear on a Delaunay triangulation of the same nodes, which

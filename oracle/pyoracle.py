@@ -309,7 +309,7 @@ def system_from_probe(P, cap=None, load_outputs=False):
 
 class _Eos(C.Structure):
     _fields_ = [("nx", C.c_int), ("ny", C.c_int), ("xmin", C.c_double), ("xmax", C.c_double),
-                ("ymin", C.c_double), ("ymax", C.c_double), ("z", C.POINTER(C.c_double))]
+                ("ymin", C.c_double), ("ymax", C.c_double), ("z", C.POINTER(C.c_double)), ("diag", C.c_void_p)]
 
 
 class _Ttm(C.Structure):
@@ -420,6 +420,11 @@ class OracleTTM:
     def cfl(self, steps, timestep, n): _ttm_lib().orc_ttm_cfl(self._p, steps, timestep, n)
     def calc_ttm(self, steps, diff_substeps): _ttm_lib().orc_ttm_calc(self._p, self.sys._p, steps, diff_substeps)
     def move_atoms_ttm(self): _ttm_lib().orc_move_atoms_ttm(self.sys._p, self._p)
+    def set_eos_diag(self, which, diag):
+        L = _ttm_lib()
+        L.orc_ttm_set_eos_diag.argtypes = [C.POINTER(_Ttm), C.c_int, C.c_char_p]
+        L.orc_ttm_set_eos_diag(self._p, int(which), None if diag is None else np.ascontiguousarray(diag, np.uint8).tobytes())
+
     def eos_lookup(self, which, x, y):
         tab = self.t.ee if which else self.t.cve
         return _ttm_lib().orc_eos_lookup(C.byref(tab), float(x), float(y))

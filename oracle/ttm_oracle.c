@@ -71,7 +71,7 @@ void orc_ttm_free(orc_ttm *t)
   if (!t) return;
   free(t->flux); free(t->natoms); free(t->natoms_old); free(t->temp[0]); free(t->temp[1]); free(t->U[0]); free(t->U[1]);
   free(t->xi); free(t->md_temp); free(t->source); free(t->vcom); free(t->dens); free(t->fd_k); free(t->fd_g);
-  free(t->Z); free(t->Ce); free(t->ne); free(t->cve.z); free(t->ee.z); free(t);
+  free(t->Z); free(t->Ce); free(t->ne); free(t->cve.z); free(t->ee.z); free(t->cve.diag); free(t->ee.diag); free(t);
 }
 
 void orc_ttm_set_eos(orc_ttm *t, int which, int nx, int ny, double xmin, double xmax, double ymin, double ymax,
@@ -82,6 +82,17 @@ void orc_ttm_set_eos(orc_ttm *t, int which, int nx, int ny, double xmin, double 
   e->nx = nx; e->ny = ny; e->xmin = xmin; e->xmax = xmax; e->ymin = ymin; e->ymax = ymax;
   e->z = (double *) zalloc((size_t) nx * ny, 8);
   memcpy(e->z, z, (size_t) nx * ny * 8);
+  free(e->diag); e->diag = NULL;
+}
+
+/* which diagonal the reference's triangulation puts into every grid cell (1: (i+1,j)-(i,j+1), 2: (i,j)-(i+1,j+1), 0: unknown);
+ * read off the reference's own interpolator at the cell centres (tests/golden/eos_grid.npz) */
+void orc_ttm_set_eos_diag(orc_ttm *t, int which, const unsigned char *diag)
+{
+  orc_eos *e = which == 0 ? &t->cve : &t->ee;
+  size_t n = (size_t) (e->nx - 1) * (e->ny - 1);
+  free(e->diag); e->diag = NULL;
+  if (diag) { e->diag = (unsigned char *) zalloc(n, 1); memcpy(e->diag, diag, n); }
 }
 
 /* bilinear interpolation on the regular table grid z[ix*ny+iy] (file order of
@@ -100,6 +111,11 @@ double orc_eos_lookup(const orc_eos *e, double x, double y)
   tx = fx - ix; ty = fy - iy;
   z00 = e->z[(size_t) ix * e->ny + iy];       z01 = e->z[(size_t) ix * e->ny + iy + 1];
   z10 = e->z[(size_t) (ix + 1) * e->ny + iy]; z11 = e->z[(size_t) (ix + 1) * e->ny + iy + 1];
+  if (e->diag) {                       /* linear on the reference's triangle of this cell (lpi_interpolate_point) */
+    int dg = e->diag[(size_t) ix * (e->ny - 1) + iy];
+    if (dg == 1) return tx + ty <= 1.0 ? z00 + tx * (z10 - z00) + ty * (z01 - z00) : z11 + (1.0 - tx) * (z01 - z11) + (1.0 - ty) * (z10 - z11);
+    if (dg == 2) return tx >= ty ? z00 + tx * (z10 - z00) + ty * (z11 - z10) : z00 + tx * (z11 - z01) + ty * (z01 - z00);
+  }
   return (1 - tx) * ((1 - ty) * z00 + ty * z01) + tx * ((1 - ty) * z10 + ty * z11);
 }
 

@@ -7,7 +7,7 @@
 extern "C" {
 #endif
 
-typedef struct { int nx, ny; double xmin, xmax, ymin, ymax; double *z; } orc_eos;
+typedef struct { int nx, ny; double xmin, xmax, ymin, ymax; double *z; unsigned char *diag; } orc_eos;   /* diag: triangulation map or NULL */
 
 /* SoA restatement of the ttm_Element lattices l1/l2 (types.h:441-492): fields
  * that do_DIFF double-buffers (temp, U) are ping-pong pairs, `cur` = l1. */
@@ -32,6 +32,7 @@ void orc_ttm_free(orc_ttm *t);
 void orc_ttm_set_eos(orc_ttm *t, int which /*0 cve(r,T), 1 ee(r,sqrt T)*/, int nx, int ny, double xmin, double xmax,
                      double ymin, double ymax, const double *z);
 double orc_eos_lookup(const orc_eos *e, double x, double y);
+void orc_ttm_set_eos_diag(orc_ttm *t, int which, const unsigned char *diag);
 double orc_eos_cve(const orc_ttm *t, double r, double tK);
 double orc_eos_ee(const orc_ttm *t, double r, double tK);
 double orc_eos_te_from_r_ee(const orc_ttm *t, double r, double e);

@@ -144,20 +144,40 @@ def _write_planar_eos(d):
                     f.write("%.16e %.16e %.16e\n" % (r[i], y[j], z[i, j]))
 
 
+def _write_curved_eos(d):
+    """curved, non-separable tables: here the reference's triangle-linear interpolation (nn-c) and a bilinear rule differ
+    inside every grid cell -- the shim hands the library the reference's own triangulation (imd_shim.c:eos_triangulation)"""
+    nr, nt = 24, 40
+    r = np.linspace(500.0, 4500.0, nr); t = np.linspace(1.0, 60000.0, nt); ts = np.linspace(1.0, 245.0, nt)
+    R, T = np.meshgrid(r, t, indexing="ij")
+    zc = 0.05 * T * (1.0 + 0.25 * np.sin(R / 700.0)) * (1.0 + 0.5 * T / 60000.0) + 2.0
+    R, S = np.meshgrid(r, ts, indexing="ij")
+    ze = 4000.0 * S * (1.0 + 0.15 * np.cos(R / 900.0)) + 6.0 * S * S
+    for fn, y, z in (("EOS_cve_from_r_te.txt", t, zc), ("EOS_ee_from_r_tesqrt.txt", ts, ze)):
+        with open(os.path.join(d, fn), "w") as f:
+            f.write("%d %d\n%.16e %.16e %.16e %.16e\n" % (nr, nt, r[0], r[-1], y[0], y[-1]))
+            for i in range(nr):
+                for j in range(nt):
+                    f.write("%.16e %.16e %.16e\n" % (r[i], y[j], z[i, j]))
+
+
 @pytest.mark.skipif(not (os.path.exists(CPU_TTM) and os.path.exists(GPU_TTM)), reason="oracle/_ref binaries not built")
-def test_reference_ttm_main_loop_on_gpu_forces_and_gpu_calc_ttm():
+@pytest.mark.parametrize("eos", ["planar", "curved"])
+def test_reference_ttm_main_loop_on_gpu_forces_and_gpu_calc_ttm(eos):
     """The reference's 3D TTM program (MPI build, one rank) with BOTH hot-path entry points replaced by the shim:
     calc_forces and calc_ttm run on the device, the host keeps init_ttm (EOS tables, l1/l2), move_atoms_ttm,
     fix_cells, ttm_writeout.  Against the CPU build of the same program (its calc_ttm = the reference's own functions
     in the order of the first block, see oracle/ref_probe_ttm.c) over 12 steps: lattice (what move_atoms_ttm
     reads: xi, vcom, natoms; and temp, U, md_temp, dens, fd_k, fd_g, Ce) within 1e-9, atoms within 1e-9, and
-    the .ttm file the host wrote from l1 equal line by line at its printed precision."""
+    the .ttm file the host wrote from l1 equal line by line at its printed precision.
+    eos = "curved": non-separable EOS tables, where the result depends on which triangles nn-c interpolates on -- the
+    shim passes the reference's own triangulation to the library, so row a14 holds on real (curved) tables too."""
     out = {}
     steps = (0, 1, 6, 12)
     for tag, exe in (("cpu", CPU_TTM), ("gpu", GPU_TTM)):
         with tempfile.TemporaryDirectory() as d:
             potential.write_synthetic_eam_files(d)
-            _write_planar_eos(d)
+            (_write_planar_eos if eos == "planar" else _write_curved_eos)(d)
             open(os.path.join(d, "t.param"), "w").write(PARAM_TTM)
             env = dict(os.environ, IMD_PROBE_DIR=d, IMD_PROBE_STEPS=",".join(map(str, steps)))
             r = subprocess.run([exe, "-p", "t.param"], cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
@@ -181,6 +201,19 @@ def test_reference_ttm_main_loop_on_gpu_forces_and_gpu_calc_ttm():
         assert np.abs(A["impuls"][oa] - B["impuls"][ob]).max() < 1e-9 * np.abs(B["impuls"]).max(), s
         assert np.array_equal(A["numneighs"][oa], B["numneighs"][ob])
     assert np.allclose(out["gpu"]["ttm_file"], out["cpu"]["ttm_file"], rtol=2e-6, atol=1e-12)
+    if eos == "curved":
+        # not vacuous: the same run with the library's stand-alone bilinear rule (no triangulation map) is visibly different
+        with tempfile.TemporaryDirectory() as d:
+            potential.write_synthetic_eam_files(d)
+            _write_curved_eos(d)
+            open(os.path.join(d, "t.param"), "w").write(PARAM_TTM)
+            env = dict(os.environ, IMD_PROBE_DIR=d, IMD_PROBE_STEPS="12", IMD_SHIM_EOS_BILINEAR="1")
+            r = subprocess.run([GPU_TTM, "-p", "t.param"], cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                               text=True, timeout=600)
+            assert r.returncode == 0, r.stdout[-3000:]
+            bl = po.read_ttm_probe(os.path.join(d, "ttm.0.12.bin"))["stages"]["cfl"]
+        x, y = bl["lat"]["temp"][inner], out["cpu"]["lat"][12]["lat"]["temp"][inner]
+        assert np.abs(x - y).max() > 1e-7 * np.abs(y).max()
 
 
 @pytest.mark.skipif(not (os.path.exists(CPU_TTM) and os.path.exists(GPU_TTM)), reason="oracle/_ref binaries not built")

@@ -72,6 +72,7 @@ def main():
         cfg = json.loads(line)["config"]
         out["_workload"] = cfg["workload"]
         out["_atoms_per_gpu"] = cfg["atoms_per_gpu"]
+        out["_kernel_rev"] = json.loads(line)["roofline"].get("kernel_rev")      # bench.py refuses figures of another revision
     except Exception as e:                                  # keep the counters even if the bench line is missing
         out["_workload_error"] = str(e)
     json.dump(out, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
