@@ -1446,6 +1446,8 @@ extern "C" void imdgpu_destroy(imdgpu_ctx *c)
   for (auto e : c->ev_pool) (void) hipEventDestroy(e);
   imdgpu_ttm_free(c);
   imdgpu_dist_free(c);
+  if (c->d_refperm) (void) hipFree(c->d_refperm);
+  if (c->d_stage) (void) hipFree(c->d_stage);
   void *ptrs[] = {c->pos, c->type, c->id, c->acell, c->p, c->f, c->ref, c->mass, c->epot, c->rhoh, c->numneighs,
                   c->pos2, c->type2, c->id2, c->p2, c->mass2, c->nn2, c->fdc, c->fdc2, c->keys, c->keys2, c->perm, c->perm2,
                   c->cub_tmp, c->cell_start, c->cell_cnt, c->icnt, c->istart, c->gcell_lin, c->gcell_src,
@@ -1824,6 +1826,7 @@ static int ensure_atom_capacity(imdgpu_ctx *ctx, int nlocal, int ntot)
 // scan + ghost bookkeeping from per-inner-cell counts already in ctx->icnt
 static int build_cells_from_counts(imdgpu_ctx *ctx)
 {
+  ctx->cells_epoch++;                              // the host-order permutation of the level-1 boundary is stale now
   Geo g = make_geo(ctx);
   const int ni = ctx->nkeys, ng = ctx->nghost_cells;
   size_t need = 0;
@@ -1923,6 +1926,76 @@ extern "C" int imdgpu_upload_cells(imdgpu_ctx *ctx, const int *cell_n, int natom
   return sort_and_build(ctx);
 }
 
+
+// ---- host-buffer boundary: reorder on the device, move whole arrays over PCIe --------------------------------------------
+// perm[r] = device index of the atom that is r-th in the reference's cell order (build_ref_perm), kept on the device
+static int ensure_refperm(imdgpu_ctx *ctx)
+{
+  if (ctx->refperm_epoch == ctx->cells_epoch && ctx->d_refperm) return 0;
+  std::vector<int> perm;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (build_ref_perm(ctx, &perm, nullptr)) return 1;
+  if ((size_t) ctx->nlocal > ctx->refperm_cap) {
+    if (dev_alloc(ctx, &ctx->d_refperm, (size_t) ctx->cap_local)) return 1;
+    ctx->refperm_cap = (size_t) ctx->cap_local;
+  }
+  if (ctx->nlocal > 0) HIPCHK(hipMemcpy(ctx->d_refperm, perm.data(), (size_t) ctx->nlocal * sizeof(int), hipMemcpyHostToDevice));
+  ctx->refperm_epoch = ctx->cells_epoch;
+  return 0;
+}
+static int ensure_stage(imdgpu_ctx *ctx, size_t bytes)
+{
+  if (bytes <= ctx->stage_bytes) return 0;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (ctx->d_stage) (void) hipFree(ctx->d_stage);
+  ctx->stage_bytes = bytes + bytes / 8 + 4096;
+  HIPCHK(hipMalloc(&ctx->d_stage, ctx->stage_bytes));
+  return 0;
+}
+__global__ void k_l1_put_pos(int n, const int *perm, const double *in, double4 *pos)
+{
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const int i = perm[r];
+  pos[i].x = in[3 * (size_t) r]; pos[i].y = in[3 * (size_t) r + 1]; pos[i].z = in[3 * (size_t) r + 2];
+}
+__global__ void k_l1_put_planes(int n, int cap, const int *perm, const double *in, double *planes)
+{
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const int i = perm[r];
+  planes[i] = in[3 * (size_t) r]; planes[cap + i] = in[3 * (size_t) r + 1]; planes[2 * (size_t) cap + i] = in[3 * (size_t) r + 2];
+}
+__global__ void k_l1_get_planes(int n, int cap, const int *perm, const double *planes, double *out)
+{
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const int i = perm[r];
+  out[3 * (size_t) r] = planes[i]; out[3 * (size_t) r + 1] = planes[cap + i]; out[3 * (size_t) r + 2] = planes[2 * (size_t) cap + i];
+}
+__global__ void k_l1_get_pos(int n, const int *perm, const double4 *pos, double *ort, double *dF)
+{
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const double4 q = pos[perm[r]];
+  if (ort) { ort[3 * (size_t) r] = q.x; ort[3 * (size_t) r + 1] = q.y; ort[3 * (size_t) r + 2] = q.z; }
+  if (dF) dF[r] = q.w;
+}
+template <typename T>
+__global__ void k_l1_get_scalar(int n, const int *perm, const T *in, T *out)
+{
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) out[r] = in[perm[r]];
+}
+
+// page-locked host memory for the arrays a host hands to imdgpu_update_* / imdgpu_download_atoms every step: transfers
+// from / to such memory run at PCIe speed and asynchronously (pageable memory is staged by the runtime at a fraction of it)
+extern "C" int imdgpu_host_alloc(void **p, size_t bytes)
+{
+  return hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? 0 : 1;
+}
+extern "C" int imdgpu_host_free(void *p) { return p == nullptr || hipHostFree(p) == hipSuccess ? 0 : 1; }
+
 // new positions for the CURRENT arrangement (cell ordered like imdgpu_download_atoms returns them); the
 // neighbour list stays valid -- what a host integrator calls between two list rebuilds
 extern "C" int imdgpu_update_positions(imdgpu_ctx *ctx, int natoms, const double *ort)
@@ -1930,13 +2003,12 @@ extern "C" int imdgpu_update_positions(imdgpu_ctx *ctx, int natoms, const double
   imdgpu_dist_cancel_ahead(ctx);
   HIPCHK(hipSetDevice(ctx->device));
   if (natoms != ctx->nlocal) return imdgpu_fail(ctx, "update_positions: %d atoms given, %d on the device", natoms, ctx->nlocal);
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  std::vector<int> perm;
-  if (build_ref_perm(ctx, &perm, nullptr)) return 1;
-  std::vector<double4> hp(natoms);
-  HIPCHK(hipMemcpy(hp.data(), ctx->pos, natoms * sizeof(double4), hipMemcpyDeviceToHost));
-  for (int r = 0; r < natoms; r++) { double4 &q = hp[perm[r]]; q.x = ort[3 * r]; q.y = ort[3 * r + 1]; q.z = ort[3 * r + 2]; }
-  HIPCHK(hipMemcpy(ctx->pos, hp.data(), natoms * sizeof(double4), hipMemcpyHostToDevice));
+  if (natoms == 0) return 0;
+  if (ensure_refperm(ctx) || ensure_stage(ctx, (size_t) natoms * 24)) return 1;
+  HIPCHK(hipMemcpyAsync(ctx->d_stage, ort, (size_t) natoms * 24, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_l1_put_pos, dim3(nblk(natoms, 256)), dim3(256), 0, ctx->stream, natoms, ctx->d_refperm, (const double *) ctx->d_stage, ctx->pos);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));            // the caller may reuse `ort` at once
   return 0;
 }
 
@@ -1945,14 +2017,13 @@ extern "C" int imdgpu_update_momenta(imdgpu_ctx *ctx, int natoms, const double *
 {
   HIPCHK(hipSetDevice(ctx->device));
   if (natoms != ctx->nlocal) return imdgpu_fail(ctx, "update_momenta: %d atoms given, %d on the device", natoms, ctx->nlocal);
+  if (natoms == 0) return 0;
+  if (ensure_refperm(ctx) || ensure_stage(ctx, (size_t) natoms * 24)) return 1;
+  HIPCHK(hipMemcpyAsync(ctx->d_stage, impuls, (size_t) natoms * 24, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_l1_put_planes, dim3(nblk(natoms, 256)), dim3(256), 0, ctx->stream, natoms, ctx->cap_local, ctx->d_refperm,
+                     (const double *) ctx->d_stage, ctx->p);
+  HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  std::vector<int> perm;
-  if (build_ref_perm(ctx, &perm, nullptr)) return 1;
-  std::vector<double> hp((size_t) 3 * natoms);
-  for (int r = 0; r < natoms; r++)
-    for (int d = 0; d < 3; d++) hp[(size_t) d * natoms + perm[r]] = impuls[3 * r + d];
-  for (int d = 0; d < 3; d++)
-    HIPCHK(hipMemcpy(ctx->p + (size_t) d * ctx->cap_local, hp.data() + (size_t) d * natoms, natoms * sizeof(double), hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -2463,11 +2534,9 @@ extern "C" int imdgpu_download_atoms(imdgpu_ctx *ctx, int *cell_n, double *ort, 
                                      int *sorte, double *nbl_pos)
 {
   HIPCHK(hipSetDevice(ctx->device));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
   const int n = ctx->nlocal, cap = ctx->cap_local;
-  std::vector<int> perm;
-  if (build_ref_perm(ctx, &perm, nullptr)) return 1;
   if (cell_n) {
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     std::vector<int> cc(ctx->nall_cells);
     HIPCHK(hipMemcpy(cc.data(), ctx->cell_cnt, cc.size() * sizeof(int), hipMemcpyDeviceToHost));
     const int *D = ctx->dim;
@@ -2476,32 +2545,39 @@ extern "C" int imdgpu_download_atoms(imdgpu_ctx *ctx, int *cell_n, double *ort, 
       int c = (i * D[1] + j) * D[2] + k; cell_n[c] = cc[c];
     }
   }
+  if (n == 0) return 0;
+  // the fields are put into the host's cell order ON THE DEVICE (one staging buffer, field after field) and leave in
+  // whole-array transfers on the stream; one synchronisation at the end
+  size_t need = 0;
+  need += (ort ? 24 : 0) + (eam_dF ? 8 : 0) + (impuls ? 24 : 0) + (kraft ? 24 : 0) + (nbl_pos ? 24 : 0) + (pot_eng ? 8 : 0) +
+          (eam_rho ? 8 : 0) + (numneighs ? 8 : 0) + (nummer ? 8 : 0) + (sorte ? 8 : 0);
+  if (need == 0) return 0;
+  if (ensure_refperm(ctx) || ensure_stage(ctx, need * (size_t) n)) return 1;
+  char *st = (char *) ctx->d_stage;
+  const dim3 G(nblk(n, 256)), B(256);
+  auto take = [&](size_t bytes_per_atom) { char *p = st; st += bytes_per_atom * (size_t) n; return p; };
   if (ort || eam_dF) {
-    std::vector<double4> hp(n);
-    HIPCHK(hipMemcpy(hp.data(), ctx->pos, n * sizeof(double4), hipMemcpyDeviceToHost));
-    for (int r = 0; r < n; r++) {
-      const double4 &q = hp[perm[r]];
-      if (ort) { ort[3 * r] = q.x; ort[3 * r + 1] = q.y; ort[3 * r + 2] = q.z; }
-      if (eam_dF) eam_dF[r] = q.w;
-    }
+    double *so = ort ? (double *) take(24) : nullptr, *sd = eam_dF ? (double *) take(8) : nullptr;
+    hipLaunchKernelGGL(k_l1_get_pos, G, B, 0, ctx->stream, n, ctx->d_refperm, ctx->pos, so, sd);
+    if (ort) HIPCHK(hipMemcpyAsync(ort, so, (size_t) n * 24, hipMemcpyDeviceToHost, ctx->stream));
+    if (eam_dF) HIPCHK(hipMemcpyAsync(eam_dF, sd, (size_t) n * 8, hipMemcpyDeviceToHost, ctx->stream));
   }
   auto planes = [&](const double *dev, double *out) -> int {
-    std::vector<double> h(3 * (size_t) n);
-    for (int d = 0; d < 3; d++)
-      HIPCHK(hipMemcpy(h.data() + (size_t) d * n, dev + (size_t) d * cap, n * sizeof(double), hipMemcpyDeviceToHost));
-    for (int r = 0; r < n; r++) for (int d = 0; d < 3; d++) out[3 * r + d] = h[(size_t) d * n + perm[r]];
+    double *so = (double *) take(24);
+    hipLaunchKernelGGL(k_l1_get_planes, G, B, 0, ctx->stream, n, cap, ctx->d_refperm, dev, so);
+    HIPCHK(hipMemcpyAsync(out, so, (size_t) n * 24, hipMemcpyDeviceToHost, ctx->stream));
     return 0;
   };
   auto scal_d = [&](const double *dev, double *out) -> int {
-    std::vector<double> h(n);
-    HIPCHK(hipMemcpy(h.data(), dev, n * sizeof(double), hipMemcpyDeviceToHost));
-    for (int r = 0; r < n; r++) out[r] = h[perm[r]];
+    double *so = (double *) take(8);
+    hipLaunchKernelGGL((k_l1_get_scalar<double>), G, B, 0, ctx->stream, n, ctx->d_refperm, dev, so);
+    HIPCHK(hipMemcpyAsync(out, so, (size_t) n * 8, hipMemcpyDeviceToHost, ctx->stream));
     return 0;
   };
   auto scal_i = [&](const int *dev, int *out) -> int {
-    std::vector<int> h(n);
-    HIPCHK(hipMemcpy(h.data(), dev, n * sizeof(int), hipMemcpyDeviceToHost));
-    for (int r = 0; r < n; r++) out[r] = h[perm[r]];
+    int *so = (int *) take(8);
+    hipLaunchKernelGGL((k_l1_get_scalar<int>), G, B, 0, ctx->stream, n, ctx->d_refperm, dev, so);
+    HIPCHK(hipMemcpyAsync(out, so, (size_t) n * 4, hipMemcpyDeviceToHost, ctx->stream));
     return 0;
   };
   if (impuls && planes(ctx->p, impuls)) return 1;
@@ -2512,6 +2588,8 @@ extern "C" int imdgpu_download_atoms(imdgpu_ctx *ctx, int *cell_n, double *ort, 
   if (numneighs && scal_i(ctx->numneighs, numneighs)) return 1;
   if (nummer && scal_i(ctx->id, nummer)) return 1;
   if (sorte && scal_i(ctx->type, sorte)) return 1;
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   return 0;
 }
 

@@ -303,6 +303,7 @@ extern "C" int imdgpu_migrate_apply(imdgpu_ctx *ctx, const void *in_lo, int n_in
                        ctx->cap_local, (const double *) in_hi, ctx->pos, ctx->type, ctx->id, ctx->p, ctx->mass, ctx->fdc);
   HIPCHK(hipGetLastError());
   ctx->nlocal = nnew;
+  ctx->cells_epoch++;
   ctx->mig_n[0] = ctx->mig_n[1] = 0;
   ctx->have_valid_nbl = 0; ctx->need_fix_cells = 1;
   return 0;

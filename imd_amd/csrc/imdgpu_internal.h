@@ -124,6 +124,10 @@ struct imdgpu_ctx {
   // TTM state lives in imdgpu_ttm.hip
   struct TtmState *ttm = nullptr;
   // native multi-GPU step (imdgpu_dist.hip)
+  // host-buffer boundary (level-1 integration): device-side reordering between the device's tile-major atom order and the
+  // host's cell order, staged through one device buffer; the permutation is rebuilt when the cell tables change
+  int *d_refperm = nullptr; size_t refperm_cap = 0; long long refperm_epoch = -1, cells_epoch = 0;
+  void *d_stage = nullptr; size_t stage_bytes = 0;
   int reserve_cus = 0;
   int tile_balance = 0;             // set by make_nblist when some tiles are (nearly) empty: see block_tile_range
   void *dist = nullptr;

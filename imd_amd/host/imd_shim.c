@@ -52,6 +52,9 @@
  */
 #include "imd.h"
 #include "imdgpu.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #if defined(TTM) && defined(MPI)
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -93,6 +96,13 @@ static void gpu_init(void)
   if (cpu_dim.x * cpu_dim.y * cpu_dim.z != 1) error("imd_shim: several ranks need an MPI build");
 #endif
   gpu_check(imdgpu_create(&G, dev));
+#ifdef _OPENMP
+  /* copy loops: the cores of this rank's share (a one-GPU job: 16), not the whole host; IMD_SHIM_THREADS overrides */
+  {
+    int nranks = cpu_dim.x * cpu_dim.y * cpu_dim.z, nt = getenv("IMD_SHIM_THREADS") ? atoi(getenv("IMD_SHIM_THREADS")) : 16 / (nranks > 16 ? 16 : nranks);
+    omp_set_num_threads(nt < 1 ? 1 : nt);
+  }
+#endif
   box[0] = box_x.x; box[1] = box_x.y; box[2] = box_x.z;
   box[3] = box_y.x; box[4] = box_y.y; box[5] = box_y.z;
   box[6] = box_z.x; box[7] = box_z.y; box[8] = box_z.z;
@@ -150,34 +160,64 @@ static int count_atoms(void)
   return n;
 }
 
+/* the per-step staging arrays are page-locked (imdgpu_host_alloc): they cross PCIe whole, at link speed, and the library
+ * reorders between its atom order and this cell order on the device */
+static void *pin_realloc(void *old, size_t bytes)
+{
+  void *p = NULL;
+  if (old) imdgpu_host_free(old);                 /* contents are rewritten before every use */
+  if (imdgpu_host_alloc(&p, bytes)) error("imd_shim: cannot allocate page-locked staging arrays");
+  return p;
+}
 static void ensure_host(int n)
 {
   if (n <= g_cap && g_cn != NULL) return;        /* g_cn == NULL: first call, also for a rank without atoms (vacuum) */
   g_cap = n + n / 8 + 1024;
-  g_ort = (double *) realloc(g_ort, 3 * g_cap * sizeof(double)); g_imp = (double *) realloc(g_imp, 3 * g_cap * sizeof(double));
-  g_kraft = (double *) realloc(g_kraft, 3 * g_cap * sizeof(double));
-  g_mas = (double *) realloc(g_mas, g_cap * sizeof(double)); g_epot = (double *) realloc(g_epot, g_cap * sizeof(double));
-  g_rho = (double *) realloc(g_rho, g_cap * sizeof(double)); g_dF = (double *) realloc(g_dF, g_cap * sizeof(double));
-  g_sorte = (int *) realloc(g_sorte, g_cap * sizeof(int)); g_num = (int *) realloc(g_num, g_cap * sizeof(int));
-  g_nn = (int *) realloc(g_nn, g_cap * sizeof(int));
+  g_ort = (double *) pin_realloc(g_ort, 3 * (size_t) g_cap * sizeof(double)); g_imp = (double *) pin_realloc(g_imp, 3 * (size_t) g_cap * sizeof(double));
+  g_kraft = (double *) pin_realloc(g_kraft, 3 * (size_t) g_cap * sizeof(double));
+  g_mas = (double *) pin_realloc(g_mas, g_cap * sizeof(double)); g_epot = (double *) pin_realloc(g_epot, g_cap * sizeof(double));
+  g_rho = (double *) pin_realloc(g_rho, g_cap * sizeof(double)); g_dF = (double *) pin_realloc(g_dF, g_cap * sizeof(double));
+  g_sorte = (int *) pin_realloc(g_sorte, g_cap * sizeof(int)); g_num = (int *) pin_realloc(g_num, g_cap * sizeof(int));
+  g_nn = (int *) pin_realloc(g_nn, g_cap * sizeof(int));
   g_cn = (int *) realloc(g_cn, SHIM_NALL * sizeof(int));
-  if (!g_ort || !g_imp || !g_kraft || !g_mas || !g_epot || !g_rho || !g_dF || !g_sorte || !g_num || !g_nn || !g_cn)
-    error("imd_shim: cannot allocate staging arrays");
+  if (!g_cn) error("imd_shim: cannot allocate staging arrays");
 }
 
 /* walk the inner cells in the order of the `cells` list: that IS the ABI's cell order */
+static int *g_off = NULL; static int g_off_cap = 0;
+/* first flat index of every inner cell (cells list order); returns the number of atoms */
+static int cell_offsets(void)
+{
+  int k, n = 0;
+  if (NCELLS + 1 > g_off_cap) {
+    g_off_cap = NCELLS + 1;
+    g_off = (int *) realloc(g_off, g_off_cap * sizeof(int));
+    if (!g_off) error("imd_shim: cannot allocate cell offsets");
+  }
+  for (k = 0; k < NCELLS; k++) { g_off[k] = n; n += CELLPTR(k)->n; }
+  g_off[NCELLS] = n;
+  return n;
+}
+/* The copy loops between the reference's per-cell arrays and the flat staging arrays run on all the cores of the rank's
+ * share (OpenMP, when the shim is compiled with -fopenmp: the drop-in builds of oracle/build_ref.sh are); cells are
+ * independent, every atom has its fixed flat index g_off[k] + i. */
 static int gather_cells(int with_all)
 {
-  int k, i, n = 0;
+  int k, n;
   for (k = 0; k < SHIM_NALL; k++) g_cn[k] = 0;
+  n = cell_offsets();
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
   for (k = 0; k < NCELLS; k++) {
     cell *p = CELLPTR(k);
+    int i, m = g_off[k];
     g_cn[SHIM_CELLIDX(p)] = p->n;
-    for (i = 0; i < p->n; i++, n++) {
-      g_ort[3 * n] = ORT(p, i, X); g_ort[3 * n + 1] = ORT(p, i, Y); g_ort[3 * n + 2] = ORT(p, i, Z);
+    for (i = 0; i < p->n; i++, m++) {
+      g_ort[3 * m] = ORT(p, i, X); g_ort[3 * m + 1] = ORT(p, i, Y); g_ort[3 * m + 2] = ORT(p, i, Z);
       if (with_all) {
-        g_imp[3 * n] = IMPULS(p, i, X); g_imp[3 * n + 1] = IMPULS(p, i, Y); g_imp[3 * n + 2] = IMPULS(p, i, Z);
-        g_mas[n] = MASSE(p, i); g_sorte[n] = SORTE(p, i); g_num[n] = NUMMER(p, i);
+        g_imp[3 * m] = IMPULS(p, i, X); g_imp[3 * m + 1] = IMPULS(p, i, Y); g_imp[3 * m + 2] = IMPULS(p, i, Z);
+        g_mas[m] = MASSE(p, i); g_sorte[m] = SORTE(p, i); g_num[m] = NUMMER(p, i);
       }
     }
   }
@@ -384,9 +424,13 @@ void calc_forces(int steps)
 #endif
   gpu_check(imdgpu_calc_forces(G, steps, sums, &is_short));
   gpu_check(imdgpu_download_atoms(G, NULL, NULL, NULL, g_kraft, g_epot, g_rho, g_dF, g_nn, NULL, NULL, NULL));
+  (void) cell_offsets();
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) private(i, m)
+#endif
   for (k = 0; k < NCELLS; k++) {
     cell *p = CELLPTR(k);
-    for (i = 0; i < p->n; i++, m++) {
+    for (i = 0, m = g_off[k]; i < p->n; i++, m++) {
       KRAFT(p, i, X) = g_kraft[3 * m]; KRAFT(p, i, Y) = g_kraft[3 * m + 1]; KRAFT(p, i, Z) = g_kraft[3 * m + 2];
       POTENG(p, i) = g_epot[m];
 #ifdef EAM2

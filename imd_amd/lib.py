@@ -27,6 +27,7 @@ SYMBOLS = [
     "imdgpu_migrate_scan", "imdgpu_migrate_gather", "imdgpu_migrate_apply", "imdgpu_forces_phase", "imdgpu_integrate",
     "imdgpu_get_invalid", "imdgpu_invalidate", "imdgpu_ttm_local_block", "imdgpu_ttm_apply_blocks",
     "imdgpu_ttm_lattice_step", "imdgpu_ttm_mailbox_bytes", "imdgpu_ttm_mailbox_attach", "imdgpu_ttm_local_step",
+    "imdgpu_host_alloc", "imdgpu_host_free",
     "imdgpu_ttm_fdtd_init", "imdgpu_ttm_fdtd_set_dl", "imdgpu_ttm_fdtd_substeps", "imdgpu_ttm_fdtd_fields",
     "imdgpu_ttm_fdtd_get", "imdgpu_ttm_fdtd_set_time",
     "imdgpu_dist_unique_id", "imdgpu_dist_init_rccl", "imdgpu_dist_init_callback", "imdgpu_dist_set_plan",

@@ -132,6 +132,12 @@ int imdgpu_export_nblist(imdgpu_ctx *ctx, int *tl, int *tb, int *cl_off, int *nt
 /* full (symmetric) device list statistics: total entries and max per atom */
 int imdgpu_nblist_stats(imdgpu_ctx *ctx, long long *entries, int *max_per_atom);
 
+/* Page-locked host memory for the arrays a level-1 host passes to imdgpu_update_positions / _update_momenta /
+ * _download_atoms every step: the reordering between the device's atom order and the host's cell order
+ * happens on the device, the arrays cross PCIe whole; from pinned memory that runs at link speed. */
+int imdgpu_host_alloc(void **p, size_t bytes);
+int imdgpu_host_free(void *p);
+
 /* ---- two-temperature model (3D FD lattice, imd_ttm_3D.c) ------------------- */
 /* Parameters the reference reads from the param file / derives in init_ttm
  * (imd_ttm_3D.c:1001-1314): fd_ext, fd_min_atoms, fd_n_timesteps (used as

@@ -119,10 +119,10 @@ build_dropin() {
     objs="$objs $o"
   done
   wait
-  $CC $BASEFLAGS $defs -I"$repo/include" -c "$repo/imd_amd/host/imd_shim.c" -o "$obj/imd_shim.o"
+  $CC $BASEFLAGS $defs -fopenmp -I"$repo/include" -c "$repo/imd_amd/host/imd_shim.c" -o "$obj/imd_shim.o"
   $CC $BASEFLAGS $defs -c "$HERE/ref_probe.c" -o "$obj/ref_probe.o"
   $CC -o "$OUT/imd_$name" $objs "$obj/imd_shim.o" "$obj/ref_probe.o" -Wl,--wrap=calc_forces \
-      "$REF/nn_interpol/libnn.a" -L"$repo/imd_amd/csrc" -limdgpu -Wl,-rpath,/root/repo/imd_amd/csrc -lm
+      "$REF/nn_interpol/libnn.a" -L"$repo/imd_amd/csrc" -limdgpu -Wl,-rpath,/root/repo/imd_amd/csrc -fopenmp -lm
   echo "built $OUT/imd_$name"
 }
 case " $TARGETS " in *" dropin "*) build_dropin ;; esac
@@ -144,10 +144,10 @@ build_dropin_cellpair() {
   done
   $CC $BASEFLAGS $defs -Dcalc_forces=calc_forces_host -c "$REF/imd_main_risc_3d.c" -o "$obj/imd_main_risc_3d.o" &
   wait
-  $CC $BASEFLAGS $defs -I"$repo/include" -c "$repo/imd_amd/host/imd_shim.c" -o "$obj/imd_shim.o"
+  $CC $BASEFLAGS $defs -fopenmp -I"$repo/include" -c "$repo/imd_amd/host/imd_shim.c" -o "$obj/imd_shim.o"
   $CC $BASEFLAGS $defs -c "$HERE/ref_probe.c" -o "$obj/ref_probe.o"
   $CC -o "$OUT/imd_$name" $objs "$obj/imd_main_risc_3d.o" "$obj/imd_shim.o" "$obj/ref_probe.o" -Wl,--wrap=calc_forces \
-      "$REF/nn_interpol/libnn.a" -L"$repo/imd_amd/csrc" -limdgpu -Wl,-rpath,/root/repo/imd_amd/csrc -lm
+      "$REF/nn_interpol/libnn.a" -L"$repo/imd_amd/csrc" -limdgpu -Wl,-rpath,/root/repo/imd_amd/csrc -fopenmp -lm
   echo "built $OUT/imd_$name"
 }
 case " $TARGETS " in *" dropin "*) build_dropin_cellpair ;; esac
@@ -172,12 +172,12 @@ build_dropin_ttm() {
   done
   $cc $BASEFLAGS $defs -Dcalc_ttm=calc_ttm_host -c "$REF/imd_ttm_3D.c" -o "$obj/imd_ttm_3D.o" &
   wait
-  $cc $BASEFLAGS $defs -I"$repo/include" -c "$repo/imd_amd/host/imd_shim.c" -o "$obj/imd_shim.o"
+  $cc $BASEFLAGS $defs -fopenmp -I"$repo/include" -c "$repo/imd_amd/host/imd_shim.c" -o "$obj/imd_shim.o"
   $cc $BASEFLAGS $defs -c "$HERE/ref_probe.c" -o "$obj/ref_probe.o"
   $cc $BASEFLAGS $defs -DPROBE_TTM_DROPIN -c "$HERE/ref_probe_ttm.c" -o "$obj/ref_probe_ttm.o"
   $cc -o "$OUT/imd_$name" $objs "$obj/imd_ttm_3D.o" "$obj/imd_shim.o" "$obj/ref_probe.o" "$obj/ref_probe_ttm.o" \
       -Wl,--wrap=calc_forces -Wl,--wrap=calc_ttm -Wl,--wrap=tmm_init -Wl,--wrap=do_tmm \
-      "$REF/nn_interpol/libnn.a" -L"$repo/imd_amd/csrc" -limdgpu -Wl,-rpath,/root/repo/imd_amd/csrc \
+      "$REF/nn_interpol/libnn.a" -L"$repo/imd_amd/csrc" -limdgpu -Wl,-rpath,/root/repo/imd_amd/csrc -fopenmp \
       -Wl,-rpath-link,/usr/lib/x86_64-linux-gnu "$MPIINC/lib/libmpi.so" -Wl,-rpath,"$MPIINC/lib" -lm
   # (libmpi by path and the system directory first for indirect dependencies: the MPI prefix carries an older
   #  libstdc++ than the HIP runtime needs; at run time libimdgpu.so is listed, hence loaded, before libmpi)
@@ -203,10 +203,10 @@ build_dropin_mpi() {
     objs="$objs $o"
   done
   wait
-  $cc $BASEFLAGS $defs -I"$repo/include" -c "$repo/imd_amd/host/imd_shim.c" -o "$obj/imd_shim.o"
+  $cc $BASEFLAGS $defs -fopenmp -I"$repo/include" -c "$repo/imd_amd/host/imd_shim.c" -o "$obj/imd_shim.o"
   $cc $BASEFLAGS $defs -c "$HERE/ref_probe.c" -o "$obj/ref_probe.o"
   $cc -o "$OUT/imd_$name" $objs "$obj/imd_shim.o" "$obj/ref_probe.o" -Wl,--wrap=calc_forces \
-      "$REF/nn_interpol/libnn.a" -L"$repo/imd_amd/csrc" -limdgpu -Wl,-rpath,/root/repo/imd_amd/csrc \
+      "$REF/nn_interpol/libnn.a" -L"$repo/imd_amd/csrc" -limdgpu -Wl,-rpath,/root/repo/imd_amd/csrc -fopenmp \
       -Wl,-rpath-link,/usr/lib/x86_64-linux-gnu "$MPIINC/lib/libmpi.so" -Wl,-rpath,"$MPIINC/lib" -lm
   echo "built $OUT/imd_$name"
 }
