@@ -225,7 +225,10 @@ def _vacuum_case():
 
 def test_two_ranks_one_in_vacuum():
     """the normal case of an ablation slab decomposed along x -- one rank holds every atom, the other none.
-    12 steps of the two-rank run against the CPU oracle's single-domain loop on the same atoms."""
+    12 steps of the two-rank run against the CPU oracle's single-domain loop on the same atoms.
+    (No mpiexec drop-in twin of this case: the reference's own MPI + NBL build, oracle/_ref/imd_mpi_eam_nve_nbl, dies with
+    a segmentation fault on such an input -- pbc 0 1 1, cpu_dim 2 1 1, the second rank all vacuum -- so there is no CPU
+    binary to compare a shim run with.)"""
     from oracle import pyoracle as po
     C = _vacuum_case()
     ctx = mp.get_context("spawn")
