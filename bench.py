@@ -43,6 +43,8 @@ def parse():
                     help="config 5: `--laser` / `--laser beer` = Beer-Lambert source laser_rescale_ttm (imd_laser.c:715) in every\n"
                          "step; `--laser fdtd` = the 1D Maxwell solver (imd_fdtd.c) on a slab: open x with vacuum in front of and\n"
                          "behind the atoms, ONE row of FD cells along x (fd_ext 1 ny nz), pulse centred on the timed region")
+    ap.add_argument("--slab", action="store_true",
+                    help="config 4's geometry: open x with 12 MD cells of vacuum in front of and behind the atoms (pbc 0 1 1)")
     ap.add_argument("--cpu-box", type=int, default=48, help="unit cells per direction of the CPU sample")
     ap.add_argument("--cpu-steps", type=int, default=30)
     ap.add_argument("--cpu-steps-mpi", type=int, default=40, help="steps of the multi-core (MPI + TTM) reference sample")
@@ -92,7 +94,16 @@ def build_system(args, rank, world, device):
         fd_ext = (1, gd0[1], gd0[2])
     else:
         cd = tuple(cpu_dim[d] * (fd_ext[d] if ttm else 1) for d in range(3))
-        gdim = global_cell_dim(box, cellsz, cd)
+        if args.slab:                 # vacuum on both x sides (shiftx_front / shiftx_rear of the reference's generator)
+            pbc = (0, 1, 1)
+            gd0 = global_cell_dim(box, cellsz, cd)
+            hx = box[0, 0] / gd0[0]
+            nvac = ((12 + cd[0] - 1) // cd[0]) * cd[0]            # a multiple of cpu_dim.x * fd_ext.x cells per side
+            shift_x = nvac * hx
+            box = box.copy(); box[0, 0] += 2 * nvac * hx
+            gdim = (gd0[0] + 2 * nvac, gd0[1], gd0[2])
+        else:
+            gdim = global_cell_dim(box, cellsz, cd)
     cell_dim = tuple(gdim[d] // cpu_dim[d] + 2 for d in range(3))
     sysm = GpuSystem(box, pbc, cell_dim, 1, cellsz, nbl_margin, 0.1, device=device, global_cell_dim=gdim,
                      cpu_dim=cpu_dim, my_coord=coord, count_ttm_neighbours=ttm,
@@ -118,7 +129,7 @@ def build_system(args, rank, world, device):
     md = None
     if world > 1 or args.force_distributed:
         from imd_amd.parallel import Decomposition, DistributedMD, GpuOps
-        dec = Decomposition(rank, cpu_dim, gdim, box, (1, 1, 1))
+        dec = Decomposition(rank, cpu_dim, gdim, box, pbc)
         md = DistributedMD(dec, GpuOps(sysm, device), ttm=ttm)
     return sysm, md, len(pos), gdim, cpu_dim
 
@@ -382,6 +393,7 @@ def main():
                                    "(r_c 6.5 A), nbl_margin 0.5, dt 0.1, T0 %.4f eV, %s" %
                                    (args.box[0], args.box[1], args.box[2], natoms, args.temp,
                                     "NVE, no TTM" if args.no_ttm else ("3D TTM fd_ext %s, diff_substeps 100" % (" ".join(str(v) for v in sysm.fd_ext))) +
+                                    (", slab: open x with vacuum on both sides" if args.slab else "") +
                                     (", Beer-Lambert laser source (laser_rescale_ttm)" if args.laser == "beer" else
                                      ", 1D Maxwell solver as laser source (do_fdtd; slab, open x, one row of FD cells)" if args.laser == "fdtd" else "")),
                        "atoms_per_gpu": natoms, "cells": list(gdim), "half_list_entries_per_atom": M,

@@ -1626,6 +1626,8 @@ static int autotile(imdgpu_ctx *ctx)
   };
   int best[3] = {ctx->tile[0], ctx->tile[1], ctx->tile[2]};
   double bestscore = -1;
+  struct Cand { double score; int b[3]; };
+  std::vector<Cand> cands;
   for (int bx = 1; bx <= 4; bx++) for (int by = 1; by <= 4; by++) for (int bz = 1; bz <= 4; bz++) {
     if (bx > nx || by > ny || bz > nz) continue;
     if ((bx + 2) * (by + 2) * (bz + 2) > NH_MAX) continue;
@@ -1634,7 +1636,8 @@ static int autotile(imdgpu_ctx *ctx)
       int i0 = tx * bx + 1, j0 = ty * by + 1, k0 = tz * bz + 1;
       long long own = boxsum(i0, std::min(i0 + bx, nx + 1), j0, std::min(j0 + by, ny + 1), k0, std::min(k0 + bz, nz + 1));
       long long halo = boxsum(i0 - 1, i0 + bx + 1, j0 - 1, j0 + by + 1, k0 - 1, k0 + bz + 1);
-      maxown = std::max(maxown, own); maxhalo = std::max(maxhalo, halo); ntl++; sumhalo += halo;
+      maxown = std::max(maxown, own); maxhalo = std::max(maxhalo, halo);
+      if (own > 0) { ntl++; sumhalo += halo; }            // tiles in vacuum cost nothing (block ranges are cut by atoms)
     }
     if (maxown > TILE_MAXTHREADS) continue;
     int slot_cap = (int) ((maxhalo + 1 + 63) / 64 * 64);
@@ -1642,10 +1645,20 @@ static int autotile(imdgpu_ctx *ctx)
     // score: atoms per workgroup round, discounted by the wave imbalance over the 4 SIMDs and by the
     // per-tile staging cost (grows with staged/own atoms; weight fitted on MI355X timings)
     int threads = (int) std::min<long long>(TILE_MAXTHREADS, (maxown + 63) / 64 * 64), waves = threads / 64;
+    if (ntl == 0) ntl = 1;
+    // ties: long in z (contiguous cell keys), then thin in x (measured on a slab: 2x4x4 25 % faster than 4x2x4)
     double score = (double) ctx->nlocal / ntl / ((waves + 3) / 4) / (1.0 + 0.3 * (double) sumhalo / std::max(1, ctx->nlocal))
-                   + 1e-3 * bz;
+                   + 1e-3 * bz + 1e-4 * by - 1e-4 * bx;
     if (score > bestscore) { bestscore = score; best[0] = bx; best[1] = by; best[2] = bz; }
+    cands.push_back({score, {bx, by, bz}});
   }
+  // shapes within 3 % of the best score are equivalent by this model: among them thin in x (the slowest index), then long in
+  // z, then in y -- measured on a 10 M-atom slab: 2x4x4 6.87 ms per step, 4x2x4 (same score) 8.59
+  for (const Cand &c : cands)
+    if (c.score >= 0.97 * bestscore) {
+      const bool better = c.b[0] != best[0] ? c.b[0] < best[0] : (c.b[2] != best[2] ? c.b[2] > best[2] : c.b[1] > best[1]);
+      if (better) { best[0] = c.b[0]; best[1] = c.b[1]; best[2] = c.b[2]; }
+    }
   ctx->autotiled = 1;
   if (bestscore < 0 || (best[0] == ctx->tile[0] && best[1] == ctx->tile[1] && best[2] == ctx->tile[2])) return 0;
   return retile(ctx, best);

@@ -40,7 +40,8 @@ def _worker_body(rank, world, port, case, cpu_dim, nsteps, ttm, q, decomposed=Fa
     t = np.linalg.inv(G["box"]).T
     c = np.clip((np.array(dec.gdim) * (pos @ t.T)).astype(int), 0, np.array(dec.gdim) - 1)
     mine = np.all(c // (np.array(dec.dim) - 2) == np.array(dec.coord), axis=1)
-    s = GpuSystem(G["box"], G["pbc_dirs"], dec.dim, 1, float(G["cellsz"]), float(G["nbl_margin"]), float(G["timestep"]),
+    ntypes = int(G["ntypes"])
+    s = GpuSystem(G["box"], G["pbc_dirs"], dec.dim, ntypes, float(G["cellsz"]), float(G["nbl_margin"]), float(G["timestep"]),
                   device=0, global_cell_dim=dec.gdim, cpu_dim=cpu_dim, my_coord=dec.coord, ttm_decomposed=decomposed)
     s.upload_tables(gu.table(G, "pair_pot"), gu.table(G, "rho_h_tab"), gu.table(G, "embed_pot"))
     if adv:
@@ -49,7 +50,7 @@ def _worker_body(rank, world, port, case, cpu_dim, nsteps, ttm, q, decomposed=Fa
         s.init_ttm(G["ttm_fd_ext"], int(G["ttm_fd_min_atoms"]), int(G["ttm_diff_substeps"]), float(G["ttm_atomic_weight"]),
                    float(G["ttm_atomic_charge"]), dict(x=G["eos_r"], y=G["eos_t"], z=G["eos_cve"]),
                    dict(x=G["eos_r"], y=G["eos_ts"], z=G["eos_ee"]), float(G["ttm_omega_laser"]))
-    s.upload_atoms(pos[mine], mom[mine], mass[mine], None, ident[mine])
+    s.upload_atoms(pos[mine], mom[mine], mass[mine], G["s0_sorte"][mine].astype(np.int32) if ntypes > 1 else None, ident[mine])
     ops = GpuOps(s, 0)
     md = DistributedMD(dec, ops, ttm=ttm)
     for st in range(nsteps):
@@ -99,6 +100,21 @@ def test_two_ranks_nve(cpu_dim):
     assert np.abs(frc[o] - G["s20_kraft"][go]).max() < 1e-9 * np.abs(G["s20_kraft"]).max()
     assert abs(res[0][2]["tot_pot_energy"] - float(G["s20_tot_pot_energy"])) < 1e-9 * abs(float(G["s20_tot_pot_energy"]))
     assert all(r[3] >= 2 for r in res)
+
+
+def test_two_ranks_two_atom_types():
+    """Cu3Au lattice, two atom types (4-column tables with per-column ranges): the halo also carries the types of the ghost
+    atoms (what = 2) at every rebuild; 20 steps on 2 ranks against the reference's single-domain trajectory"""
+    res = _run("eam2_l12_coarse", (2, 1, 1), 20, False)
+    G = gu.load("eam2_l12_coarse")
+    ids = np.concatenate([r[1]["nummer"] for r in res]); pos = np.concatenate([r[1]["ort"] for r in res])
+    frc = np.concatenate([r[1]["kraft"] for r in res])
+    o, go = np.argsort(ids), np.argsort(G["s20_nummer"])
+    box = np.diag(G["box"])
+    dx = pos[o] - G["s20_ort"][go]; dx -= np.round(dx / box) * box
+    assert len(ids) == len(G["s20_nummer"]) and np.abs(dx).max() < 1e-9
+    assert np.abs(frc[o] - G["s20_kraft"][go]).max() < 1e-9 * np.abs(G["s20_kraft"]).max()
+    assert abs(res[0][2]["tot_pot_energy"] - float(G["s20_tot_pot_energy"])) < 1e-9 * abs(float(G["s20_tot_pot_energy"]))
 
 
 @pytest.mark.parametrize("cpu_dim", [(2, 1, 1), (2, 2, 1)])
