@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--ttm-decomposed", action="store_true",
                     help="several ranks: one TTM lattice block per rank, faces through the shared-memory mailbox (default: the\n"
                          "lattice is replicated, one all-gather per step; see DESIGN.md 5)")
+    ap.add_argument("--init-dist", action="store_true",
+                    help="rehearsal with --force-distributed: a ONE-rank torch.distributed process group on --backend, so that the\n"
+                         "host layer's nccl code path (object broadcast of the RCCL ids, all-reduces on device tensors) executes")
     ap.add_argument("--force-distributed", action="store_true",
                     help="rehearsal: run the multi-rank host layer (halo plan, gather/scatter, fork/join) on one rank")
     return ap.parse_args()
@@ -330,8 +333,9 @@ def main():
                          "or without a launcher)" % (args.gpus, world, args.gpus))
     if args.share_gpu:
         local = 0
-    if world > 1:
+    if world > 1 or (args.force_distributed and args.init_dist):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         torch.cuda.set_device(local)
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
@@ -345,7 +349,7 @@ def main():
     def barrier():
         sysm.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
 
     step = 0
@@ -359,7 +363,7 @@ def main():
         do_step(step); step += 1
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -418,9 +422,9 @@ def main():
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
-    if world > 1:
-        dist.destroy_process_group()
     sysm.close()
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -467,7 +467,7 @@ class DistributedMD:
         ops.fix_cells()
         self.plan = DirectHaloPlan(self.dec, ops)
         changed = 1 if ops.autotile() else 0             # first rebuild: tile shape chosen from the real occupancies
-        if self.world > 1 and self.nrebuild == 0:        # building a plan is collective (counts travel): every rank must
+        if dist.is_initialized() and self.nrebuild == 0:   # building a plan is collective (counts travel): every rank must
             t = torch.tensor([changed], dtype=torch.int32, device=ops.device)    # agree -- a rank in vacuum never re-tiles
             all_reduce_(t, dist.ReduceOp.MAX)
             changed = int(t.item())
@@ -549,7 +549,7 @@ class DistributedMD:
         s = self.ops.get_sums()
         t = torch.tensor([s["tot_pot_energy"], s["virial"], s["tot_kin_energy"], float(self.ops.nlocal())],
                          dtype=torch.float64, device=self.ops.device)
-        if self.world > 1:
+        if dist.is_initialized():
             all_reduce_(t)
         return dict(tot_pot_energy=float(t[0]), virial=float(t[1]), tot_kin_energy=float(t[2]), natoms=int(t[3]))
 
@@ -703,7 +703,7 @@ class GpuOps:
                 buf = C.create_string_buffer(256)
                 self._ck(self.L.imdgpu_dist_unique_id(buf, 256))
                 uid[0] = bytes(buf.raw)
-            if world > 1:
+            if dist.is_initialized():
                 dist.broadcast_object_list(uid, src=0)
             self._ck(self.L.imdgpu_dist_init_rccl(self.h, world, rank, uid[0], 256))
             self.transport = "rccl"

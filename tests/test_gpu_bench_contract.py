@@ -37,3 +37,37 @@ def test_bench_line_has_the_contract_fields():
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0
     if cb["cores"] > 1:          # the reference's MPI + TTM build on the host cores; the one-core NVE figure rides along
         assert "imd_mpi_eam_ttm3d_nbl" in cb["sample"] and cb["serial"]["cores"] == 1 and cb["serial"]["value"] > 0
+
+
+def _one_json_line(r):
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout          # RCCL's start-up banner and the launcher's chatter must not reach stdout
+    return json.loads(lines[0])
+
+
+def test_bench_spawns_its_ranks_and_refuses_a_mismatch():
+    """`python bench.py --gpus N` without a launcher starts the N ranks itself (here 2 ranks sharing the one GPU
+    over gloo, the native C step with the host transport) and prints rank 0's line; --gpus that contradicts WORLD_SIZE is
+    refused."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--backend", "gloo", "--box", "24", "24", "24",
+           "--steps", "8", "--warmup", "2", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    d = _one_json_line(subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600))
+    assert d["n_gpus"] == 2 and d["atoms_total"] == 2 * d["config"]["atoms_per_gpu"] and "cpu_baseline" not in d
+    assert "2x1x1 ranks" in d["config"]["parallelism"] and "native step" in d["config"]["parallelism"]
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"], cwd=ROOT,
+                         env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=300)
+    assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr
+
+
+def test_bench_nccl_code_path_on_one_rank():
+    """the nccl (= RCCL) code path on the one-GPU box -- a one-rank torch.distributed process group
+    on the nccl backend (device-tensor all-reduces, barrier, the broadcast of the RCCL ids), the library's own RCCL
+    communicators, and with IMDGPU_DIST_SELF_COMM the 26 halo messages / flag all-reduce / lattice all-gather as real RCCL calls"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-distributed", "--init-dist", "--backend", "nccl", "--box", "24", "24", "24",
+           "--steps", "8", "--warmup", "2", "--no-cpu-baseline"]
+    env = dict({k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}, IMDGPU_DIST_SELF_COMM="1")
+    d = _one_json_line(subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600))
+    assert d["n_gpus"] == 1 and "(rccl)" in d["config"]["parallelism"] and d["value"] > 0
