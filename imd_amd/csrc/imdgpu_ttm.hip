@@ -1764,8 +1764,9 @@ __device__ __forceinline__ void fdtd_step(const FdtdDev &F, FdtdCell &c, int i, 
 }
 
 // nsub x [do_fdtd; ndiff x (do_DIFF, do_FILLMESH)] for the whole row, one workgroup.  WITH_TTM = false: the solver alone.
-template <bool WITH_TTM>
-__global__ __launch_bounds__(1024) void k_ttm_fdtd_chain(Lat L, FdtdDev F, int nsub, int ndiff, double t_SI, double tau_fdtd,
+// MAXT: 256 for rows of up to 254 cells (the register file then holds the cell's whole state: no spills), 1024 beyond
+template <bool WITH_TTM, int MAXT>
+__global__ __launch_bounds__(MAXT) void k_ttm_fdtd_chain(Lat L, FdtdDev F, int nsub, int ndiff, double t_SI, double tau_fdtd,
     double tau_diff, int laser_active, double laser_timefun, int steps, const int *natoms, double *T1, double *T2, double *U1,
     double *U2, double *fd_k, double *Ce, double *fd_g, const double *md_temp, double *source, const double *dens, double *xi,
     double *Zo, double *neo, EosDev cve, EosDev ee, double *eabs)
@@ -1982,10 +1983,12 @@ extern "C" int imdgpu_ttm_fdtd_substeps(imdgpu_ctx *ctx, double t_SI, int nsub, 
   double *row = nullptr;
   HIPCHK(hipMalloc((void **) &row, F.nx * sizeof(double)));
   HIPCHK(hipMemsetAsync(row, 0, F.nx * sizeof(double), ctx->stream));
-  hipLaunchKernelGGL((k_ttm_fdtd_chain<false>), dim3(1), dim3(thr), (4 * F.nx + F.nx / 2 + 2) * sizeof(double), ctx->stream, L, F, nsub, 0,
-                     t_SI, tau_FDTD, 0.0, 1, laser_timefun, 1, t->natoms, (double *) nullptr, (double *) nullptr, (double *) nullptr,
-                     (double *) nullptr, (double *) nullptr, (double *) nullptr, (double *) nullptr, (const double *) nullptr, row,
-                     (const double *) nullptr, (double *) nullptr, (double *) nullptr, (double *) nullptr, t->cve, t->ee, (double *) nullptr);
+#define FD_BARE(MT) hipLaunchKernelGGL((k_ttm_fdtd_chain<false, MT>), dim3(1), dim3(thr), (4 * F.nx + F.nx / 2 + 2) * sizeof(double), ctx->stream, L, F, nsub, 0, \
+                     t_SI, tau_FDTD, 0.0, 1, laser_timefun, 1, t->natoms, (double *) nullptr, (double *) nullptr, (double *) nullptr, \
+                     (double *) nullptr, (double *) nullptr, (double *) nullptr, (double *) nullptr, (const double *) nullptr, row, \
+                     (const double *) nullptr, (double *) nullptr, (double *) nullptr, (double *) nullptr, t->cve, t->ee, (double *) nullptr)
+  if (thr <= 256) FD_BARE(256); else FD_BARE(1024);
+#undef FD_BARE
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(ctx->stream));
   std::vector<double> h(F.nx), lat(t->ncell);
@@ -2013,10 +2016,12 @@ static int fdtd_lattice_loop(imdgpu_ctx *ctx, TtmState *t, const Lat &L, int ste
   const int thr = (F.nx + 63) / 64 * 64;
   t->laser_active = active;
   ProfScope ps(ctx, PROF_TTM_DIFF);
-  hipLaunchKernelGGL((k_ttm_fdtd_chain<true>), dim3(1), dim3(thr), (4 * F.nx + F.nx / 2 + 2) * sizeof(double), ctx->stream, L2, F, nsub, ndiff,
-                     S->t_SI, tau_f, tau_d, active, timefun, steps, t->natoms, t->temp[t->cur], t->temp[t->cur ^ 1], t->U[t->cur],
-                     t->U[t->cur ^ 1], t->fd_k[t->kcur], t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve,
-                     t->ee, t->d_eabs);
+#define FD_LOOP(MT) hipLaunchKernelGGL((k_ttm_fdtd_chain<true, MT>), dim3(1), dim3(thr), (4 * F.nx + F.nx / 2 + 2) * sizeof(double), ctx->stream, L2, F, nsub, ndiff, \
+                     S->t_SI, tau_f, tau_d, active, timefun, steps, t->natoms, t->temp[t->cur], t->temp[t->cur ^ 1], t->U[t->cur], \
+                     t->U[t->cur ^ 1], t->fd_k[t->kcur], t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve, \
+                     t->ee, t->d_eabs)
+  if (thr <= 256) FD_LOOP(256); else FD_LOOP(1024);
+#undef FD_LOOP
   HIPCHK(hipGetLastError());
   S->t_SI += nsub * tau_f;
   return 0;
