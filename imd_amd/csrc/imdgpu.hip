@@ -554,7 +554,7 @@ __global__ __launch_bounds__(512) void k_pass3_gt(ForceArgs a)
 // neighbour list holds 16-bit LDS slot numbers (4 per 8-byte load, ELL-transposed
 // per tile).  HBM sees: list (2 B/entry), own-atom outputs, one staging pass.
 // ===========================================================================
-#define IMDGPU_KERNEL_REV 2
+#define IMDGPU_KERNEL_REV 3
 #define LDS_LIMIT (160 * 1024)
 #define TABLE_LDS_LIMIT (150 * 1024)                 // global-gather kernels: tables beyond this stay in global memory
 #define NH_MAX 512                                   // halo cells per tile (<= 6*6*6 = 216 for tiles up to 4^3)
@@ -915,20 +915,43 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile(TileArgs a)
       const int slot = (int) (ow & 0xffffu), n4 = (a.dbg & 1) ? 0 : ((int) (ow >> 16) + 3) >> 2;                \
       if (n4 < 1) { c0x = dw; c0y = dw; }                                                                        \
       if (n4 < 2) { c1x = dw; c1y = dw; }
-// the list walk: two words (8 slots) are consumed per pair of trips while the next two are in flight; lanes past
-// their own count get the dummy word.  Opens the k4 loop and defines j[UNR].
+// The list walk.  LIST_WORDS_BEGIN opens the per-word body (a lambda over one list word = four slots, defines j[UNR]);
+// LIST_WORDS_END(RING) closes it and drives it over the words of the lane's row in one of two ways:
+//  RING = 0  two words (8 slots) are consumed per pair of trips while the next two are in flight and handed over every
+//            second trip; per-lane trip counts.  Fewest registers: pass 3 beside the TTM chain (<= 144 VGPRs, see there).
+//  RING = 4  the words live in a ring of four registers with static names: word w is consumed from ring[w % 4] and that
+//            register is re-loaded at once with word w + 4, so three loads of 8 B per lane are in flight per wave and no
+//            hand-over waits for the newest one.  The loop runs to the wave's longest list (uniform branches; lanes past
+//            their own count walk dummy words, which costs the SIMD nothing).  Measured -8 % (pass 1) / -4 % (pass 3):
+//            the list is a 2 GB stream per pass and its latency, not only the LDS gathers, is what the waves wait for.
+// Lanes past their own count get the dummy word either way.
 #define LIST_WORDS_BEGIN                                                                                         \
-      unsigned m0x = dw, m0y = dw, m1x = dw, m1y = dw;                                                           \
-      for (int k4 = 0; k4 < n4; k4++) {                                                                          \
-        if ((k4 & 1) == 0) {                      /* even trip: issue the next pair of loads */                  \
-          m0x = dw; m0y = dw; m1x = dw; m1y = dw;                                                                \
-          if (k4 + 2 < n4) { const uint2 q = lp[(size_t) (k4 + 2) * a.tile_cap]; m0x = q.x; m0y = q.y; }        \
-          if (k4 + 3 < n4) { const uint2 q = lp[(size_t) (k4 + 3) * a.tile_cap]; m1x = q.x; m1y = q.y; }        \
-        }                                                                                                        \
-        const unsigned curx = (k4 & 1) ? c1x : c0x, cury = (k4 & 1) ? c1y : c0y;                                 \
-        if (k4 & 1) { c0x = m0x; c0y = m0y; c1x = m1x; c1y = m1y; }   /* odd trip: hand over (loads are ~8 neighbours old) */ \
+      auto body = [&](const unsigned curx, const unsigned cury) __attribute__((always_inline)) {                 \
         const int j4[4] = {(int) (curx & 0xffffu), (int) (curx >> 16), (int) (cury & 0xffffu), (int) (cury >> 16)};     \
         HALF_BEGIN
+#define RING_LOAD(DX, DY, W) { DX = dw; DY = dw; if ((W) < n4) { const uint2 q = lp[(size_t) (W) * a.tile_cap]; DX = q.x; DY = q.y; } }
+#define RING_STEP(RX, RY) if (w >= nwu) break; body(RX, RY); RING_LOAD(RX, RY, w + 4) w++;
+#define LIST_WORDS_END(RING)                                                                                     \
+      };                                                                                                         \
+      if constexpr ((RING) == 0) {                                                                               \
+        unsigned m0x = dw, m0y = dw, m1x = dw, m1y = dw;                                                         \
+        for (int k4 = 0; k4 < n4; k4++) {                                                                        \
+          if ((k4 & 1) == 0) {                    /* even trip: issue the next pair of loads */                  \
+            RING_LOAD(m0x, m0y, k4 + 2) RING_LOAD(m1x, m1y, k4 + 3)                                              \
+          }                                                                                                      \
+          const unsigned curx = (k4 & 1) ? c1x : c0x, cury = (k4 & 1) ? c1y : c0y;                               \
+          if (k4 & 1) { c0x = m0x; c0y = m0y; c1x = m1x; c1y = m1y; }   /* odd trip: hand over (loads are ~8 neighbours old) */ \
+          body(curx, cury);                                                                                      \
+        }                                                                                                        \
+      } else {                                                                                                   \
+        int nwu = n4;                                                                                            \
+        _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(nwu, o, 64); nwu = t > nwu ? t : nwu; }  \
+        nwu = __builtin_amdgcn_readfirstlane(nwu);                                                               \
+        unsigned r2x, r2y, r3x, r3y;                                                                             \
+        RING_LOAD(r2x, r2y, 2) RING_LOAD(r3x, r3y, 3)                                                            \
+        int w = 0;                                                                                               \
+        for (;;) { RING_STEP(c0x, c0y) RING_STEP(c1x, c1y) RING_STEP(r2x, r2y) RING_STEP(r3x, r3y) }             \
+      }
 #if UNR == 4
 #define HALF_BEGIN { const int *j = j4;
 #define HALF_END }
@@ -947,6 +970,15 @@ __device__ __forceinline__ void tab_index(const TabK &c, double arg, int &k, dou
   double a = fmax(fmin(arg, c.end) - c.begin, 0.0) * c.istep;
   k = (int) a;
   chi = a - (double) k;
+}
+
+// the same index for callers that send every argument beyond `end` to the zero rows themselves (no upper clamp needed);
+// chi = a - trunc(a) is exact, and so is v_fract_f64 for a >= 0: the same bits with one instruction less
+__device__ __forceinline__ void tab_index_open(const TabK &c, double arg, int &k, double &chi)
+{
+  const double a = fmax(arg - c.begin, 0.0) * c.istep;
+  k = (int) a;
+  chi = __builtin_amdgcn_fract(a);
 }
 
 template <bool PAIR, bool EAM, bool TTMN, bool NT1>
@@ -1068,7 +1100,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile(TileArgs a)
           }
         }
         HALF_END
-      }
+      LIST_WORDS_END(0)
       if (NT1) is_short |= ((PAIR && r2min < cp.begin) || (EAM && r2min < cr.begin)) ? 1 : 0;
       a.f[i] = fx; a.f[a.cap + i] = fy; a.f[2 * (size_t) a.cap + i] = fz;
       a.epot[i] = ee;
@@ -1143,7 +1175,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
           dx[e] -= xi; dy[e] -= yi; dz[e] -= zi;
           r2[e] = dx[e] * dx[e] + dy[e] * dy[e] + dz[e] * dz[e];          // unfused: the reference's r2
           r2min = fmin(r2min, r2[e]);
-          tab_index(c, r2[e], k[e], chi[e]);
+          tab_index_open(c, r2[e], k[e], chi[e]);
           const bool in = r2[e] <= c.end;                                 // pair: <= end (imd_forces_nbl.c:489); rho(end) = 0 exactly
           if (TTMN) nb += in ? 1 : 0;
           k[e] = in ? k[e] : kz;
@@ -1167,7 +1199,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
           vir += r2[e] * gr;
         }
         HALF_END
-      }
+      LIST_WORDS_END(4)
       fx *= c.istep2; fy *= c.istep2; fz *= c.istep2; ee *= 0.5; vir *= -0.5 * c.istep2;
       is_short |= (r2min < c.begin) ? 1 : 0;
       a.f[i] = fx; a.f[a.cap + i] = fy; a.f[2 * (size_t) a.cap + i] = fz;
@@ -1196,8 +1228,9 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
 
 // 144 VGPRs: three waves per SIMD then leave 80 registers free on EVERY SIMD, which is what one wave of the TTM
 // sub-step kernel needs -- the lattice chain that runs beside this pass gets four SIMDs per CU instead of one
-template <bool NT1>
-__global__ __launch_bounds__(TILE_MAXTHREADS) __attribute__((amdgpu_num_vgpr(144))) void k_pass3_tile(TileArgs a)
+// RING = 0 beside the TTM chain (142 VGPRs), 4 otherwise (148): see LIST_WORDS_END
+template <bool NT1, int RING>
+__global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass3_tile(TileArgs a)
 {
   extern __shared__ double lds[];
   double *tr = lds;                                      // rho_h_tab, one type: + zero rows for r2 >= end (no mask)
@@ -1253,7 +1286,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) __attribute__((amdgpu_num_vgpr(144
           double ch[UNR], R0[UNR], R1[UNR], R2[UNR];
 #pragma unroll
           for (int e = 0; e < UNR; e++) {
-            r2min = fmin(r2min, r2[e]); tab_index(cr, r2[e], kr[e], ch[e]);
+            r2min = fmin(r2min, r2[e]); tab_index_open(cr, r2[e], kr[e], ch[e]);
             kr[e] = (r2[e] < cr.end) ? kr[e] : kz;                        // rho': r2 < end (imd_forces_nbl.c:868)
           }
           SCHED_BARRIER;
@@ -1295,7 +1328,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) __attribute__((amdgpu_num_vgpr(144
           }
         }
         HALF_END
-      }
+      LIST_WORDS_END(RING)
       if (NT1) { is_short |= (r2min < cr.begin) ? 1 : 0; vir *= -0.5; }
       a.f[i] += fx; a.f[a.cap + i] += fy; a.f[2 * (size_t) a.cap + i] += fz;
       sums[0] += vir;
@@ -2377,13 +2410,16 @@ static int launch_forces(imdgpu_ctx *ctx, int phase = 0)
     ProfScope ps(ctx, PROF_PASS3);
     if (TILE) {
       size_t l = tile_lds_bytes(ctx, 3);
-      if (NT1) {
-        HIPCHK(hipFuncSetAttribute((const void *) k_pass3_tile<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) l));
-        hipLaunchKernelGGL((k_pass3_tile<true>), dim3(nb), dim3(B), l, ctx->stream, ta);
-      } else {
-        HIPCHK(hipFuncSetAttribute((const void *) k_pass3_tile<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) l));
-        hipLaunchKernelGGL((k_pass3_tile<false>), dim3(nb), dim3(B), l, ctx->stream, ta);
-      }
+      // with a lattice attached its sub-step chain runs beside this pass and needs 80 registers on every SIMD: the
+      // leaner list walk (142 VGPRs) then; the register ring (148) otherwise
+#define L3(N, R)                                                                                                     \
+  do {                                                                                                               \
+    HIPCHK(hipFuncSetAttribute((const void *) k_pass3_tile<N, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) l)); \
+    hipLaunchKernelGGL((k_pass3_tile<N, R>), dim3(nb), dim3(B), l, ctx->stream, ta);                                 \
+  } while (0)
+      if (ctx->ttm) { if (NT1) L3(true, 0); else L3(false, 0); }
+      else { if (NT1) L3(true, 4); else L3(false, 4); }
+#undef L3
     } else if (lds3 > TABLE_LDS_LIMIT) hipLaunchKernelGGL(k_pass3_gt, dim3(nb), dim3(B), 0, ctx->stream, a);
     else if (NT1) hipLaunchKernelGGL((k_pass3<true>), dim3(nb), dim3(B), lds3, ctx->stream, a);
     else hipLaunchKernelGGL((k_pass3<false>), dim3(nb), dim3(B), lds3, ctx->stream, a);
