@@ -889,11 +889,16 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile(TileArgs a)
 // Tile loop plumbing shared by the force kernels (see stage_issue / stage_commit).  The first list words and the
 // (slot, count) word of the thread's own atom do not depend on the staged positions: they are requested before
 // the barriers, so their latency is hidden as well.
+#ifdef EXP_LIST0
+#define EXP_LBASE ((size_t) (T.tile & 7) * a.W4 * a.tile_cap)
+#else
+#define EXP_LBASE (size_t) T.tile * a.W4 * a.tile_cap
+#endif
 #define TILE_PROLOGUE(WITH_W, WITH_T, SW, TS, WSCALE)                                                                 \
     T.own_start = info.y; T.nown = info.z;                                                                       \
     const unsigned dw = (unsigned) (a.slot_cap - 1) * 0x10001u;                                                  \
     const uint2 dummyw = make_uint2(dw, dw);                                                                     \
-    const size_t lbase = (size_t) T.tile * a.W4 * a.tile_cap;                                                    \
+    const size_t lbase = EXP_LBASE;                                                                              \
     unsigned ow0 = 0; uint2 w0 = dummyw, w1 = dummyw;                                                            \
     if ((int) threadIdx.x < T.nown) {                                                                            \
       const uint2 *lq = (const uint2 *) (a.nbr16 + lbase + threadIdx.x);                                         \
@@ -1514,6 +1519,7 @@ extern "C" int imdgpu_set_option(imdgpu_ctx *ctx, const char *name, int value)
   }
   if (!strcmp(name, "ttm_flux")) { ctx->ttm_flux = value ? 1 : 0; if (!value) ctx->ttm_adv = 0; return 0; }
   if (!strcmp(name, "ttm_adv")) { ctx->ttm_adv = value ? 1 : 0; if (value) ctx->ttm_flux = 1; return 0; }
+  if (!strcmp(name, "ttm_persist")) { imdgpu_ttm_set_persist(ctx, value < 0 ? -1 : (value ? 1 : 0)); return 0; }
   if (!strcmp(name, "ttm_decomposed")) {         // before ttm_init
     if (ctx->ttm) return imdgpu_fail(ctx, "ttm_decomposed must be set before ttm_init");
     ctx->ttm_decomposed = value ? 1 : 0;
@@ -1538,7 +1544,8 @@ extern "C" int imdgpu_get_info(imdgpu_ctx *ctx, const char *name, long long *val
     {"fused_embedding", fuse_emb(ctx) ? 1 : 0}, {"ttm_flux", ctx->ttm_flux}, {"ttm_adv", ctx->ttm_adv}, {"ttm_block_width", ctx->ttm_flux ? 10 : 6},
     // bumped whenever a force / list kernel or its data layout changes: committed PMC traffic figures carry the revision
     // they were measured on (profiles/*hbm_traffic*.json "_kernel_rev"), bench.py refuses figures of another revision
-    {"kernel_rev", IMDGPU_KERNEL_REV}};
+    {"kernel_rev", IMDGPU_KERNEL_REV},
+    {"ttm_persist_mode", imdgpu_ttm_persist_info(ctx, 0)}, {"ttm_persist_runs", imdgpu_ttm_persist_info(ctx, 1)}};
   for (auto &e : tab) if (!strcmp(name, e.n)) { *value = e.v; return 0; }
   return imdgpu_fail(ctx, "unknown info %s", name);
 }
@@ -2478,6 +2485,12 @@ extern "C" int imdgpu_move_atoms_nve(imdgpu_ctx *ctx, double *ekin)
 
 static int fork_ttm(imdgpu_ctx *ctx, void *)
 {
+  static const int serial = getenv("IMDGPU_TTM_SERIAL") ? atoi(getenv("IMDGPU_TTM_SERIAL")) : 0;   // experiment: calc_ttm alone on the chip
+  if (serial) {
+    if (imdgpu_calc_ttm(ctx, ctx->ttm_steps)) return 1;
+    HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream));
+    return 0;
+  }
   HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
   HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
   hipStream_t main = ctx->stream;
@@ -2545,6 +2558,7 @@ extern "C" int imdgpu_md_step(imdgpu_ctx *ctx, int steps)
   HIPCHK(hipStreamSynchronize(ctx->stream));
   tl_flush(ctx, steps);
   if (ctx->h_counters[CNT_INVALID]) { ctx->have_valid_nbl = 0; ctx->need_fix_cells = 1; }
+  if (ctx->h_counters[CNT_TTM_TIMEOUT]) return imdgpu_fail(ctx, "TTM lattice: a sub-step hand-off timed out; the lattice of this step is not valid (IMDGPU_TTM_PERSIST=0 disables the persistent sub-step kernel)");
   return 0;
 }
 

@@ -94,6 +94,7 @@ struct imdgpu_ctx {
   int force_external_halo = 0;
   int ttm_flux = 0;               // update_fd also counts the atoms that changed FD cells (imd_ttm_3D.c:335-370)
   int ttm_adv = 0;                // calc_ttm runs do_ADV after update_fd (imd_ttm_3D.c:57-60); implies ttm_flux
+  int ttm_persist_opt = -1;       // option ttm_persist: the persistent sub-step kernel on (1) / off (0) / default (-1)
   int ttm_decomposed = 0;         // several ranks: one TTM lattice block per rank, faces through the shared-memory mailbox
   int external_halo = 0;          // ghost atoms are supplied through imdgpu_halo_scatter (multi-rank decomposition)
   int *mig_idx[2]{nullptr, nullptr}; int mig_n[2]{0, 0}, mig_cap = 0; int *mig_flag = nullptr;
@@ -223,5 +224,7 @@ int imdgpu_launch_integrate(imdgpu_ctx *ctx);
 int imdgpu_ttm_step_internal(imdgpu_ctx *ctx, int steps);
 int imdgpu_ttm_move_internal(imdgpu_ctx *ctx);
 void imdgpu_ttm_free(imdgpu_ctx *ctx);
+void imdgpu_ttm_set_persist(imdgpu_ctx *ctx, int value);
+long long imdgpu_ttm_persist_info(imdgpu_ctx *ctx, int which);
 void imdgpu_dist_free(imdgpu_ctx *ctx);
 void imdgpu_dist_cancel_ahead(imdgpu_ctx *ctx);

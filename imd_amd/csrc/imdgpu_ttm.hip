@@ -58,6 +58,15 @@ struct TtmState {
   int *d_facecnt = nullptr;              // per face: workgroups that finished publishing (monotone)
   struct FdtdState *fdtd = nullptr;      // 1D Maxwell solver on a one-row lattice (imdgpu_ttm_fdtd_*, end of this file)
   int fdtd_on = 0;
+  // persistent sub-step kernel (k_ttm_chain_persist): 0 = off, 1 = trial (the captured launch chain follows every launch,
+  // guarded by the kernel's status word), 2 = trusted (launch chain dropped)
+  int persist = -1, persist_ok = 0, persist_tiles = 0, pstat_pending = 0;
+  unsigned *d_pflags = nullptr;          // census word, gate word
+  unsigned long long *d_prec = nullptr;  // hand-off records [2][ncell][4]
+  unsigned persist_base = 0;             // tag of state 0 of the next launch
+  int *d_pstat = nullptr, *h_pstat = nullptr;   // status of the last launch (device word / pinned copy)
+  hipEvent_t ev_pstat = nullptr;
+  const int *graph_guard[2] = {nullptr, nullptr};
 };
 
 // physical constants of the reference, globals.h:324-331,1190
@@ -905,8 +914,10 @@ template <bool FUSE_MESH, bool WRAP>
 __global__ __launch_bounds__(DT_X *DT_Y *DT_Z) void k_ttm_diff(
     Lat L, double tau, int nsub, int steps, const int *natoms, const double *T1, double *T2, double *U1, double *U2,
     const double *fd_k, double *fd_k_out, double *Ce, double *fd_g, const double *md_temp, const double *source,
-    const double *dens, double *xi, double *Zo, double *neo, EosDev cve, EosDev ee, int flags)
+    const double *dens, double *xi, double *Zo, double *neo, EosDev cve, EosDev ee, int flags, const int *run_if)
 {
+  // run_if: status word of the persistent sub-step kernel that ran in front of this launch chain -- 0 = it did the work
+  if (run_if && *run_if == 0) return;
   // flags: 1 = store Z and ne (diagnostic fields nothing in the sub-step loop reads: only the last sub-step of an MD
   // step has to), 2 = there is a source term to read.  A large (replicated) lattice is bound by its bytes per cell.
   __shared__ double sT[DT_X + 2][DT_Y + 2][DT_Z + 2];
@@ -980,6 +991,197 @@ __global__ __launch_bounds__(DT_X *DT_Y *DT_Z) void k_ttm_diff(
       U1[c] = u; U2[c] = u;
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// All diffusion sub-steps of one MD step in ONE launch (the loop of calc_ttm, imd_ttm_3D.c:62-77, without a return to
+// the host or to the command processor between sub-steps).  One wave per 4x4x4 block of inner FD cells, every block
+// resident at once (a 39^3 lattice: 1000 one-wave workgroups, one per SIMD beside the EAM force pass).  A lane keeps its
+// cell's state (Te, kappa, Ce, gamma, U, xi) in registers for the whole loop.  What the stencil needs from other cells:
+//   * neighbours inside the block: (Te, kappa) by lane shuffle;
+//   * neighbours in another block: through RECORDS in device memory, four 8-byte granules per cell and parity
+//     {tag | hi(Te)}, {tag | lo(Te)}, {tag | hi(kappa)}, {tag | lo(kappa)}, each written by ONE agent-scope relaxed atomic
+//     store (`sc1`, write-through) and read by agent-scope relaxed atomic loads until its tag shows the wanted sub-step:
+//     the data is the flag (cdna_hip_programming.md, Guideline 16, form R2) -- no drain, no flag store, no fence, one
+//     memory round trip per hand-off.  tag = base + s for state s (after s sub-steps), base advancing by nsub + 1 per
+//     launch, so records never have to be cleared; state s lives in parity s & 1.
+//   * overwriting parity (s+1) & 1 (state s-1) is safe once every neighbour record this block reads carries tag s: the
+//     neighbour block computed its state s from this block's state s-1 before it stored that tag.
+// State 0 is read from temp[] / fd_k[] (written by the kernels in front), the final state goes back there.
+// The arithmetic is k_ttm_diff<true, true>'s, statement by statement: results are bit-identical to the launch chain.
+// Liveness: a census word counts the workgroups that have started; the LAST arriver opens the gate, a workgroup that
+// waits longer than PERSIST_CENSUS_TICKS closes it for good (one CAS decides) and every workgroup then leaves WITHOUT having
+// touched the lattice (status 1: the guarded launch chain behind this kernel does the step instead).  Spins inside the
+// loop are bounded as well (status 2 + CNT_TTM_TIMEOUT: the lattice of this step is not valid, reported by the host).
+#define PT 4
+#define PERSIST_MAX_TILES 1024
+#define PERSIST_CENSUS_TICKS 20000000ull       // 0.2 s of the 100 MHz s_memrealtime counter
+#define PERSIST_SPIN_TICKS 200000000ull        // 2 s
+struct PersistDev {
+  unsigned *census, *gate;              // zeroed before every launch
+  unsigned long long *rec;              // [2][ncell][4] granules
+  int *status, *counters;
+  int nt[3], ntiles, trusted, ncell;
+  unsigned base;                        // tag of state 0 of this launch
+};
+__device__ __forceinline__ unsigned ld_flag(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void rec_store(unsigned long long *r, unsigned tag, double v)
+{
+  const unsigned long long b = (unsigned long long) __double_as_longlong(v), t = (unsigned long long) tag << 32;
+  __hip_atomic_store(r, t | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(r + 1, t | (b & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <bool SRC>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_ttm_chain_persist(
+    Lat L, double tau, int nsub, const int *natoms, double *T0, double *T1, double *U0, double *U1, double *K0, double *K1,
+    double *Ce, double *fd_g, const double *md_temp, const double *source, const double *dens, double *xi, double *Zo,
+    double *neo, EosDev cve, PersistDev P)
+{
+  const int lane = threadIdx.x, tile = blockIdx.x;
+  const int tz = tile % P.nt[2], ty = (tile / P.nt[2]) % P.nt[1], tx = tile / (P.nt[2] * P.nt[1]);
+  const int l3[3] = {lane >> 4, (lane >> 2) & 3, lane & 3};
+  const int i = tx * PT + l3[0] + 1, j = ty * PT + l3[1] + 1, k = tz * PT + l3[2] + 1;
+  const bool inside = i <= L.dim[0] - 2 && j <= L.dim[1] - 2 && k <= L.dim[2] - 2;
+  const int m = L.fd_min_atoms, c = inside ? fidx(L, i, j, k) : 0;
+  const int nat = inside ? natoms[c] : 0;
+  const bool active = inside && nat >= m;
+  // ---- census and gate -------------------------------------------------------------------------------------------
+  int go = 0;
+  if (lane == 0) {
+    const unsigned long long t0 = wall_clock64();
+    const unsigned n = __hip_atomic_fetch_add(P.census, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    if (n == (unsigned) P.ntiles) {
+      unsigned expect = 0;
+      __hip_atomic_compare_exchange_strong(P.gate, &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (;;) {
+      const unsigned g = ld_flag(P.gate);
+      if (g == 1u) { go = 1; break; }
+      if (g >= 2u) break;
+      if (wall_clock64() - t0 > PERSIST_CENSUS_TICKS) {
+        unsigned expect = 0;
+        if (__hip_atomic_compare_exchange_strong(P.gate, &expect, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+          __hip_atomic_store(P.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (P.trusted) __hip_atomic_store(P.counters + CNT_TTM_TIMEOUT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        if (expect == 1u) go = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  go = __shfl(go, 0, 64);
+  if (!go) return;                                     // nothing of the lattice has been touched
+  // ---- neighbours ------------------------------------------------------------------------------------------------
+  // per direction: nc = cell index of the neighbour, or -1 = mirror (outside an open boundary or an inactive cell; the
+  // ghost shell is resolved on the fly as in k_ttm_diff<.., WRAP = true>); intile bit = the neighbour is a lane of this wave
+  int nc[6];
+  unsigned intile = 0;
+#pragma unroll
+  for (int q = 0; q < 6; q++) {
+    int g[3] = {i, j, k};
+    const int d = q >> 1, dir = (q & 1) ? -1 : 1;
+    g[d] += dir;
+    bool empty = !inside;
+    if (g[d] == 0) { if (L.pbc[d] == 1) g[d] = L.dim[d] - 2; else empty = true; }
+    else if (g[d] == L.dim[d] - 1) { if (L.pbc[d] == 1) g[d] = 1; else empty = true; }
+    int cell = -1;
+    if (!empty) { cell = fidx(L, g[0], g[1], g[2]); if (natoms[cell] < m) cell = -1; }
+    nc[q] = cell;
+    const int ln = l3[d] + dir;
+    if (ln >= 0 && ln < PT && g[d] == (d == 0 ? i : d == 1 ? j : k) + dir) intile |= 1u << q;    // same block and not wrapped
+  }
+  if (inside && !active) { K0[c] = 0.0; K1[c] = 0.0; fd_g[c] = 0.0; Ce[c] = 0.0; Zo[c] = 0.0; neo[c] = 0.0; }   // what the chain's launches write (nobody reads an inactive cell)
+  if (__ballot(active) == 0ull) return;                // a block without an active cell: nothing to compute, never read
+  // at most ONE neighbour per dimension lies in another block (the host does not use this kernel for lattices with a
+  // one-cell-wide last block): xc[d] = its cell or -1 (bit d of xany: there is one)
+  int xc[3]; unsigned xany = 0;
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    const bool cp = nc[2 * d] >= 0 && !(intile >> (2 * d) & 1u), cm = nc[2 * d + 1] >= 0 && !(intile >> (2 * d + 1) & 1u);
+    xc[d] = cp ? nc[2 * d] : (cm ? nc[2 * d + 1] : -1);
+    if (cp || cm) xany |= 1u << d;
+  }
+  // ---- the sub-step loop -------------------------------------------------------------------------------------------
+  double Te = 0, kk = 0, ce = 1, g = 0, Tl = 1, dn = 1, src = 0, u = 0, x = 0;
+  if (active) {
+    Te = T0[c]; kk = K0[c]; ce = Ce[c]; g = fd_g[c]; Tl = md_temp[c]; dn = dens[c]; u = U0[c]; x = xi[c];
+    if (SRC) src = source[c];
+  }
+  const double invsq[3] = {L.invhsq[0], L.invhsq[1], L.invhsq[2]};
+  const unsigned long long tloop = wall_clock64();
+  for (int s = 0; s < nsub; s++) {
+    double xT[3], xK[3];
+    // (1) the neighbours in other blocks: state 0 from the arrays, later states from their records once the tags are there
+    if (s == 0) {
+#pragma unroll
+      for (int d = 0; d < 3; d++) { xT[d] = Te; xK[d] = kk; if (xany >> d & 1u) { xT[d] = T0[xc[d]]; xK[d] = K0[xc[d]]; } }
+    } else {
+      const unsigned long long want = (unsigned long long) (P.base + (unsigned) s);
+      const unsigned long long *R = P.rec + (size_t) (s & 1) * P.ncell * 4;
+      unsigned todo = xany;
+#pragma unroll
+      for (int d = 0; d < 3; d++) { xT[d] = Te; xK[d] = kk; }
+      for (;;) {
+#pragma unroll
+        for (int d = 0; d < 3; d++)
+          if (todo >> d & 1u) {
+            const unsigned long long *r = R + (size_t) xc[d] * 4;
+            const unsigned long long a0 = __hip_atomic_load(r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                     a1 = __hip_atomic_load(r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                     a2 = __hip_atomic_load(r + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                     a3 = __hip_atomic_load(r + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((a0 >> 32) == want && (a1 >> 32) == want && (a2 >> 32) == want && (a3 >> 32) == want) {
+              xT[d] = __longlong_as_double((long long) ((a0 << 32) | (a1 & 0xffffffffull)));
+              xK[d] = __longlong_as_double((long long) ((a2 << 32) | (a3 & 0xffffffffull)));
+              todo &= ~(1u << d);
+            }
+          }
+        if (__all(todo == 0)) break;
+        if (__any(wall_clock64() - tloop > PERSIST_SPIN_TICKS || ld_flag(P.gate) == 3u)) {   // a neighbour never came: give up, loudly
+          if (lane == 0) {
+            __hip_atomic_store(P.gate, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(P.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(P.counters + CNT_TTM_TIMEOUT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          return;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    // (2) the six flux terms in the reference's order; neighbours inside the block by lane shuffle, mirror = own values
+    double flux = 0;
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+      const int d = q >> 1, st = d == 0 ? 16 : d == 1 ? 4 : 1, srcl = lane + ((q & 1) ? -st : st);
+      const double sT = __shfl(Te, srcl & 63, 64), sK = __shfl(kk, srcl & 63, 64);
+      double nT = Te, nK = kk;
+      if (nc[q] >= 0) {
+        if (intile >> q & 1u) { nT = sT; nK = sK; } else { nT = xT[d]; nK = xK[d]; }
+      }
+      const double term = (q & 1) ? ((kk + nK) / 2 * (Te - nT) * invsq[d]) : ((kk + nK) / 2 * (nT - Te) * invsq[d]);
+      flux = q == 0 ? term : ((q & 1) ? flux - term : flux + term);
+    }
+    if (active) {
+      const double Tn = tau / ce * (flux - g * (Te - Tl) + (SRC ? src : 0.0)) + Te;
+      double *Tw = (s & 1) ? T0 : T1, *Kw = (s & 1) ? K0 : K1, *Uw = (s & 1) ? U0 : U1;
+      u = u + (Tn - Te) * ce * L.vol / ((double) nat);
+      x += (Tn - Tl) * L.xi_fac * g / (Tl * dn);
+      const MeshOut o = mesh_props(L, cve, Tn, Tl, dn);
+      ce = o.Ce; kk = o.k; g = o.g; Te = Tn;
+      if (xany != 0 && s + 1 < nsub) {                  // a lane with a neighbour in another block publishes state s + 1
+        unsigned long long *r = P.rec + ((size_t) ((s + 1) & 1) * P.ncell + c) * 4;
+        rec_store(r, P.base + (unsigned) (s + 1), Te);
+        rec_store(r + 2, P.base + (unsigned) (s + 1), kk);
+      }
+      // the arrays follow as in the launch chain (ping-pong): nobody in this launch reads them after state 0
+      Tw[c] = Te; Kw[c] = kk; Uw[c] = u;
+      if (s == nsub - 1) { Zo[c] = o.Z; neo[c] = o.ne; }
+    }
+  }
+  if (active) { xi[c] = x; Ce[c] = ce; fd_g[c] = g; }
 }
 
 // CFL_maxdt (imd_ttm_3D.c:2637-2691): min over cells and +x,+y,+z faces
@@ -1092,6 +1294,11 @@ void imdgpu_ttm_free(imdgpu_ctx *ctx)
   if (t->mb_host) (void) hipHostUnregister(t->mb_host);
   if (t->d_gbase) (void) hipFree(t->d_gbase);
   if (t->d_facecnt) (void) hipFree(t->d_facecnt);
+  if (t->d_pflags) (void) hipFree(t->d_pflags);
+  if (t->d_prec) (void) hipFree(t->d_prec);
+  if (t->d_pstat) (void) hipFree(t->d_pstat);
+  if (t->h_pstat) (void) hipHostFree(t->h_pstat);
+  if (t->ev_pstat) (void) hipEventDestroy(t->ev_pstat);
   imdgpu_fdtd_free(t);
   for (int q = 0; q < 2; q++) if (t->eos_diag[q]) (void) hipFree(t->eos_diag[q]);
   delete t;
@@ -1174,13 +1381,13 @@ extern "C" int imdgpu_ttm_dims(imdgpu_ctx *ctx, int dim[3], double h[3])
 static int ttm_check_mailbox(imdgpu_ctx *ctx)
 {
   TtmState *t = ctx->ttm;
-  if (!t || !t->mb_host) return 0;
+  if (!t || (!t->mb_host && t->persist <= 0)) return 0;
   int flag = 0;
   HIPCHK(hipMemcpyAsync(&flag, ctx->d_counters + CNT_TTM_TIMEOUT, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (flag)
-    return imdgpu_fail(ctx, "TTM mailbox: a neighbour rank did not publish its lattice faces in time (rank gone or stalled); "
-                            "the lattice of this step is not valid");
+    return imdgpu_fail(ctx, "TTM lattice: a sub-step hand-off timed out (mailbox: a neighbour rank did not publish its faces; or the "
+                            "persistent sub-step kernel lost residency, IMDGPU_TTM_PERSIST=0 disables it); the lattice of this step is not valid");
   return 0;
 }
 
@@ -1458,7 +1665,7 @@ extern "C" int imdgpu_ttm_diff(imdgpu_ctx *ctx, double tau)
   ProfScope ps(ctx, PROF_TTM_DIFF);
   hipLaunchKernelGGL((k_ttm_diff<false, false>), dim3(diff_grid(t)), dim3(DT_X * DT_Y * DT_Z), 0, ctx->stream, L, tau, t->nsub, 1,
                      t->natoms, t->temp[t->cur], t->temp[t->cur ^ 1], t->U[t->cur], t->U[t->cur ^ 1], t->fd_k[t->kcur],
-                     t->fd_k[t->kcur], t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve, t->ee, 3);
+                     t->fd_k[t->kcur], t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve, t->ee, 3, nullptr);
   HIPCHK(hipGetLastError());
   t->cur ^= 1;                                        // l1 <-> l2
   return 0;
@@ -1480,7 +1687,7 @@ extern "C" int imdgpu_ttm_cfl_maxdt(imdgpu_ctx *ctx, int steps, double *out)
 // One fused sub-step: do_DIFF + do_FILLMESH (own cell, new temperature) in one
 // launch, then the ghost faces.  fd_k is double buffered because the stencil of
 // the same launch still needs the neighbours' old kappa.
-static int launch_substep_fused(imdgpu_ctx *ctx, TtmState *t, const Lat &L, double tau, int steps, int sub = 0)
+static int launch_substep_fused(imdgpu_ctx *ctx, TtmState *t, const Lat &L, double tau, int steps, int sub = 0, const int *guard = nullptr)
 {
   const int flags = (sub == t->nsub - 1 ? 1 : 0) | (t->have_source ? 2 : 0);
   if (t->mb_host) {
@@ -1490,14 +1697,92 @@ static int launch_substep_fused(imdgpu_ctx *ctx, TtmState *t, const Lat &L, doub
                        t->temp[t->cur], t->fd_k[t->kcur]);
     hipLaunchKernelGGL((k_ttm_diff<true, false>), dim3(diff_grid(t)), dim3(DT_X * DT_Y * DT_Z), 0, ctx->stream, L, tau, t->nsub, steps,
                        t->natoms, t->temp[t->cur], t->temp[t->cur ^ 1], t->U[t->cur], t->U[t->cur ^ 1], t->fd_k[t->kcur],
-                       t->fd_k[t->kcur ^ 1], t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve, t->ee, flags);
+                       t->fd_k[t->kcur ^ 1], t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve, t->ee, flags, guard);
     hipLaunchKernelGGL(k_ttm_push_faces, dim3(6), dim3(64), 0, ctx->stream, L, t->mbd, sub + 1, 0, t->natoms,
                        t->temp[t->cur ^ 1], t->fd_k[t->kcur ^ 1]);
   } else
   hipLaunchKernelGGL((k_ttm_diff<true, true>), dim3(diff_grid(t)), dim3(DT_X * DT_Y * DT_Z), 0, ctx->stream, L, tau, t->nsub, steps,
                      t->natoms, t->temp[t->cur], t->temp[t->cur ^ 1], t->U[t->cur], t->U[t->cur ^ 1], t->fd_k[t->kcur],
-                     t->fd_k[t->kcur ^ 1], t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve, t->ee, flags);
+                     t->fd_k[t->kcur ^ 1], t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve, t->ee, flags, guard);
   t->cur ^= 1; t->kcur ^= 1;
+  return 0;
+}
+
+// The persistent sub-step kernel, when it applies: one rank's whole lattice (no mailbox), no Maxwell solver, an even
+// number of sub-steps, at most PERSIST_MAX_TILES blocks (all of them must be resident at once).  IMDGPU_TTM_PERSIST=0
+// switches it off.  Trial mode: the captured launch chain follows, each of its kernels guarded by the status word (0 = the
+// persistent kernel did the step), until two launches in a row came through; from then on the chain is dropped and a
+// failed census is an error (CNT_TTM_TIMEOUT), as is a time-out inside the loop at any time.
+// option "ttm_persist" (0 / 1; -1 = the default, IMDGPU_TTM_PERSIST or on) and the info words "ttm_persist_mode" (0 off,
+// 1 trial, 2 trusted, -1 not decided yet) / "ttm_persist_runs" (launches that came through)
+void imdgpu_ttm_set_persist(imdgpu_ctx *ctx, int value)
+{
+  ctx->ttm_persist_opt = value;
+  if (ctx->ttm) { ctx->ttm->persist = value == 0 ? 0 : -1; ctx->ttm->persist_ok = 0; }
+}
+long long imdgpu_ttm_persist_info(imdgpu_ctx *ctx, int which)
+{
+  TtmState *t = ctx->ttm;
+  if (!t) return -1;
+  if (t->persist > 0 && t->pstat_pending && hipEventQuery(t->ev_pstat) == hipSuccess) {
+    t->pstat_pending = 0;
+    if (t->h_pstat[0] == 0) { if (++t->persist_ok >= 2 && t->persist == 1) t->persist = 2; } else t->persist = 0;
+  }
+  return which == 0 ? t->persist : t->persist_ok;
+}
+
+static int persist_mode(imdgpu_ctx *ctx, TtmState *t)
+{
+  if (t->persist < 0) {
+    static const int envv = getenv("IMDGPU_TTM_PERSIST") ? atoi(getenv("IMDGPU_TTM_PERSIST")) : 1;
+    const int env = ctx->ttm_persist_opt >= 0 ? ctx->ttm_persist_opt : envv;
+    const int nt[3] = {(t->dim[0] - 2 + PT - 1) / PT, (t->dim[1] - 2 + PT - 1) / PT, (t->dim[2] - 2 + PT - 1) / PT};
+    t->persist_tiles = nt[0] * nt[1] * nt[2];
+    bool shape_ok = true;                                 // a one-cell-wide last block would need two out-of-block neighbours per dimension
+    for (int d = 0; d < 3; d++) if ((t->dim[d] - 2) % PT == 1) shape_ok = false;
+    t->persist = (env && shape_ok && t->persist_tiles <= PERSIST_MAX_TILES) ? 1 : 0;
+    if (t->persist && !t->d_pflags) {
+      if (dev_alloc(ctx, &t->d_pflags, 16) || dev_alloc(ctx, &t->d_pstat, 4) || dev_alloc(ctx, &t->d_prec, (size_t) 2 * t->ncell * 4)) return -1;
+      if (hipMemsetAsync(t->d_prec, 0, (size_t) 2 * t->ncell * 4 * sizeof(unsigned long long), ctx->stream) != hipSuccess) return -1;
+      t->persist_base = 1;
+      if (hipHostMalloc((void **) &t->h_pstat, 4 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+          hipEventCreateWithFlags(&t->ev_pstat, hipEventDisableTiming) != hipSuccess) { imdgpu_fail(ctx, "persistent TTM kernel: host allocations failed"); return -1; }
+      if (hipMemsetAsync(t->d_pstat, 0, 4 * sizeof(int), ctx->stream) != hipSuccess) return -1;
+      t->h_pstat[0] = 0;
+    }
+  }
+  if (t->persist > 0 && t->pstat_pending && hipEventQuery(t->ev_pstat) == hipSuccess) {   // how the previous launch went
+    t->pstat_pending = 0;
+    if (t->h_pstat[0] == 0) { if (++t->persist_ok >= 2 && t->persist == 1) t->persist = 2; }
+    else t->persist = 0;                                // census failed (co-tenants on the GPU): the launch chain from now on
+  }
+  return t->persist;
+}
+
+static int launch_persist(imdgpu_ctx *ctx, TtmState *t, const Lat &L, double tau, int mode)
+{
+  PersistDev P;
+  P.census = t->d_pflags; P.gate = t->d_pflags + 1; P.rec = t->d_prec; P.ncell = t->ncell;
+  P.base = t->persist_base; t->persist_base += (unsigned) t->nsub + 1u;
+  P.status = t->d_pstat; P.counters = ctx->d_counters;
+  for (int d = 0; d < 3; d++) P.nt[d] = (t->dim[d] - 2 + PT - 1) / PT;
+  P.ntiles = t->persist_tiles; P.trusted = mode == 2;
+  HIPCHK(hipMemsetAsync(t->d_pflags, 0, 16 * sizeof(unsigned), ctx->stream));
+  HIPCHK(hipMemsetAsync(t->d_pstat, 0, 4 * sizeof(int), ctx->stream));
+  double *T0 = t->temp[t->cur], *T1 = t->temp[t->cur ^ 1], *U0 = t->U[t->cur], *U1 = t->U[t->cur ^ 1];
+  double *K0 = t->fd_k[t->kcur], *K1 = t->fd_k[t->kcur ^ 1];
+  if (t->have_source)
+    hipLaunchKernelGGL((k_ttm_chain_persist<true>), dim3(t->persist_tiles), dim3(64), 0, ctx->stream, L, tau, t->nsub, t->natoms, T0, T1,
+                       U0, U1, K0, K1, t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve, P);
+  else
+    hipLaunchKernelGGL((k_ttm_chain_persist<false>), dim3(t->persist_tiles), dim3(64), 0, ctx->stream, L, tau, t->nsub, t->natoms, T0, T1,
+                       U0, U1, K0, K1, t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve, P);
+  HIPCHK(hipGetLastError());
+  if (!t->pstat_pending) {                               // feedback for persist_mode; never waited for
+    HIPCHK(hipMemcpyAsync(t->h_pstat, t->d_pstat, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipEventRecord(t->ev_pstat, ctx->stream));
+    t->pstat_pending = 1;
+  }
   return 0;
 }
 
@@ -1540,7 +1825,14 @@ extern "C" int imdgpu_ttm_lattice_step(imdgpu_ctx *ctx, int steps)
     // the state before it, so one captured hipGraph replays every MD step
     const bool can_graph = (t->nsub % 2 == 0) && steps >= 1;      // step 0 re-initialises U: run it un-captured
     const int gi = t->cur;
-    if (can_graph && t->graph[gi] && t->graph_kcur[gi] == t->kcur && t->graph_tau[gi] == tau && t->graph_src[gi] == t->have_source) {
+    int pmode = 0;
+    if (can_graph && !MBX) { pmode = persist_mode(ctx, t); if (pmode < 0) return 1; }
+    if (pmode > 0 && launch_persist(ctx, t, L, tau, pmode)) return 1;
+    const int *guard = pmode == 1 ? t->d_pstat : nullptr;
+    if (pmode == 2) {
+      // trusted: the persistent kernel alone
+    } else if (can_graph && t->graph[gi] && t->graph_kcur[gi] == t->kcur && t->graph_tau[gi] == tau && t->graph_src[gi] == t->have_source &&
+               t->graph_guard[gi] == guard) {
       HIPCHK(hipGraphLaunch(t->graph[gi], ctx->stream));
     } else if (can_graph) {
       if (t->graph[gi]) { (void) hipGraphExecDestroy(t->graph[gi]); t->graph[gi] = nullptr; }
@@ -1554,12 +1846,12 @@ extern "C" int imdgpu_ttm_lattice_step(imdgpu_ctx *ctx, int steps)
       for (int i = 0; i < t->nsub; i++) {
         Lat Li = L;
         if (i < nhigh) Li.wave_prio = 3;
-        launch_substep_fused(ctx, t, Li, tau, 1, i);
+        launch_substep_fused(ctx, t, Li, tau, 1, i, guard);
       }
       HIPCHK(hipStreamEndCapture(ctx->stream, &g));
       HIPCHK(hipGraphInstantiate(&t->graph[gi], g, nullptr, nullptr, 0));
       (void) hipGraphDestroy(g);
-      t->graph_kcur[gi] = k0; t->graph_tau[gi] = tau; t->graph_src[gi] = t->have_source;
+      t->graph_kcur[gi] = k0; t->graph_tau[gi] = tau; t->graph_src[gi] = t->have_source; t->graph_guard[gi] = guard;
       HIPCHK(hipGraphLaunch(t->graph[gi], ctx->stream));
     } else {
       for (int i = 0; i < t->nsub; i++) launch_substep_fused(ctx, t, L, tau, steps, i);

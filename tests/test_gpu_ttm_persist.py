@@ -1,0 +1,104 @@
+"""The persistent sub-step kernel (k_ttm_chain_persist: all diff_substeps of an MD step in one launch, blocks handing
+(Te, kappa) to each other through tagged records) against the launch chain it replaces (run with -m gpu).
+
+Same arithmetic statement by statement, so the lattices must agree BIT FOR BIT; the chain itself is pinned against the
+reference's goldens in test_gpu_ttm.py (whose trajectory tests also run through the persistent kernel from step 1 on)."""
+import numpy as np
+import pytest
+
+from tests import golden_util as gu
+from tests.test_gpu_ttm import _gpu
+
+pytestmark = pytest.mark.gpu
+FIELDS = ("natoms", "temp", "xi", "md_temp", "dens", "fd_k", "fd_g", "Ce", "U", "Z", "ne")
+
+
+def _run(case, persist, nsteps):
+    G = gu.load(case)
+    s = _gpu(G)
+    s.set_option("ttm_persist", persist)
+    out = []
+    for st in range(nsteps):
+        s.md_step(st)
+        out.append(s.ttm_download())
+    info = (s.get_info("ttm_persist_mode"), s.get_info("ttm_persist_runs"))
+    s.close()
+    return out, info, G
+
+
+@pytest.mark.parametrize("case", ["ttm_2048", "ttm_slab", "ttm_6912_ext2", "ttm_2types"])
+def test_persistent_substeps_equal_the_launch_chain_bit_for_bit(case):
+    nsteps = 6
+    a, ia, G = _run(case, 0, nsteps)
+    b, ib, _ = _run(case, 1, nsteps)
+    assert ia[0] <= 0
+    inner = [int(v) - 2 for v in G["ttm_fd_dim"]]
+    if int(G["ttm_diff_substeps"]) % 2:
+        assert ib[0] == -1, "an odd number of sub-steps stays on the un-captured launch loop"
+    elif any(n % 4 == 1 for n in inner):
+        assert ib[0] == 0, "a one-cell-wide last block must fall back to the launch chain"
+    else:
+        # step 0 re-initialises U and runs un-captured; steps 1.. go through the persistent kernel: two launches on trial
+        # (guarded chain behind them), the rest trusted -- the comparison is not vacuous
+        assert ib[0] == 2 and ib[1] >= 3, "persistent kernel did not run: mode %d, %d launches" % ib
+    inn = (slice(1, -1),) * 3
+    for st in range(nsteps):
+        for f in FIELDS:
+            if f in a[st]:
+                assert np.array_equal(a[st][f][inn], b[st][f][inn]), "step %d field %s" % (st, f)
+
+
+def test_option_switches_the_kernel_off_and_on_again():
+    G = gu.load("ttm_2048")
+    s = _gpu(G)
+    s.set_option("ttm_persist", 0)
+    for st in range(3):
+        s.md_step(st)
+    assert s.get_info("ttm_persist_mode") == 0
+    s.set_option("ttm_persist", 1)
+    for st in range(3, 7):
+        s.md_step(st)
+    inner = [int(v) - 2 for v in G["ttm_fd_dim"]]
+    if not any(n % 4 == 1 for n in inner):
+        assert s.get_info("ttm_persist_mode") == 2
+    s.close()
+
+
+def _big(persist, nb=(64, 64, 40), nsteps=6):
+    """1 M-atom-scale box, fd_ext 2 2 2: an 18 x 18 x 11 lattice = 5 x 5 x 3 blocks handing off across workgroups"""
+    from imd_amd import lattice, potential, ttm as ttm_mod
+    from imd_amd.system import GpuSystem, global_cell_dim
+    box = lattice.fcc_box(nb)
+    pos = lattice.fcc_positions(nb)
+    rng = np.random.default_rng(5)
+    pos = (pos + rng.normal(scale=0.05, size=pos.shape)) % np.diag(box)
+    mom = lattice.maxwell_momenta(len(pos), 26.9815, 0.03, seed=5)
+    pair, rho, emb, r2cut = potential.synthetic_eam_tables()
+    cellsz = (np.sqrt(r2cut) + 0.5) ** 2
+    dim = [g + 2 for g in global_cell_dim(box, cellsz, (2, 2, 2))]
+    g = GpuSystem(box, (1, 1, 1), dim, 1, cellsz, 0.5, 0.1, count_ttm_neighbours=True)
+    g.upload_tables(pair, rho, emb)
+    g.upload_atoms(pos, mom, 26.9815)
+    ttm_mod.attach_default(g, fd_ext=(2, 2, 2), diff_substeps=100, fd_min_atoms=5)
+    g.set_option("ttm_persist", persist)
+    for st in range(nsteps):
+        g.md_step(st)
+    lat = g.ttm_download()
+    d = g.download(fields=("ort", "impuls", "nummer"))
+    info = (g.get_info("ttm_persist_mode"), g.get_info("ttm_persist_runs"), tuple(g.fd_dim))
+    g.close()
+    return lat, d, info
+
+
+def test_many_blocks_hand_off_across_workgroups():
+    la, da, ia = _big(0)
+    lb, db, ib = _big(1)
+    assert ia[0] == 0 and ib[0] == 2 and ib[1] >= 3, (ia, ib)
+    assert all((n - 2) > 4 for n in ib[2])                       # several blocks along every axis
+    inn = (slice(1, -1),) * 3
+    for f in FIELDS:
+        if f in la:
+            assert np.isfinite(la[f][inn]).all()
+            assert np.array_equal(la[f][inn], lb[f][inn]), f
+    assert np.array_equal(da["nummer"], db["nummer"])
+    assert np.array_equal(da["ort"], db["ort"]) and np.array_equal(da["impuls"], db["impuls"])
