@@ -889,16 +889,11 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile(TileArgs a)
 // Tile loop plumbing shared by the force kernels (see stage_issue / stage_commit).  The first list words and the
 // (slot, count) word of the thread's own atom do not depend on the staged positions: they are requested before
 // the barriers, so their latency is hidden as well.
-#ifdef EXP_LIST0
-#define EXP_LBASE ((size_t) (T.tile & 7) * a.W4 * a.tile_cap)
-#else
-#define EXP_LBASE (size_t) T.tile * a.W4 * a.tile_cap
-#endif
 #define TILE_PROLOGUE(WITH_W, WITH_T, SW, TS, WSCALE)                                                                 \
     T.own_start = info.y; T.nown = info.z;                                                                       \
     const unsigned dw = (unsigned) (a.slot_cap - 1) * 0x10001u;                                                  \
     const uint2 dummyw = make_uint2(dw, dw);                                                                     \
-    const size_t lbase = EXP_LBASE;                                                                              \
+    const size_t lbase = (size_t) T.tile * a.W4 * a.tile_cap;                                                    \
     unsigned ow0 = 0; uint2 w0 = dummyw, w1 = dummyw;                                                            \
     if ((int) threadIdx.x < T.nown) {                                                                            \
       const uint2 *lq = (const uint2 *) (a.nbr16 + lbase + threadIdx.x);                                         \
