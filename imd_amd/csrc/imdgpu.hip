@@ -554,7 +554,7 @@ __global__ __launch_bounds__(512) void k_pass3_gt(ForceArgs a)
 // neighbour list holds 16-bit LDS slot numbers (4 per 8-byte load, ELL-transposed
 // per tile).  HBM sees: list (2 B/entry), own-atom outputs, one staging pass.
 // ===========================================================================
-#define IMDGPU_KERNEL_REV 3
+#define IMDGPU_KERNEL_REV 4
 #define LDS_LIMIT (160 * 1024)
 #define TABLE_LDS_LIMIT (150 * 1024)                 // global-gather kernels: tables beyond this stay in global memory
 #define NH_MAX 512                                   // halo cells per tile (<= 6*6*6 = 216 for tiles up to 4^3)
@@ -974,9 +974,13 @@ __device__ __forceinline__ void tab_index(const TabK &c, double arg, int &k, dou
 
 // the same index for callers that send every argument beyond `end` to the zero rows themselves (no upper clamp needed);
 // chi = a - trunc(a) is exact, and so is v_fract_f64 for a >= 0: the same bits with one instruction less
-__device__ __forceinline__ void tab_index_open(const TabK &c, double arg, int &k, double &chi)
+// sgn collects the sign bits of (arg - begin): negative once any argument lay below the table (is_short, potaccess.h:331) --
+// one integer OR per neighbour instead of a running fp64 minimum
+__device__ __forceinline__ void tab_index_open(const TabK &c, double arg, int &k, double &chi, int &sgn)
 {
-  const double a = fmax(arg - c.begin, 0.0) * c.istep;
+  const double d = arg - c.begin;
+  sgn |= __double2hiint(d);
+  const double a = fmax(d, 0.0) * c.istep;
   k = (int) a;
   chi = __builtin_amdgcn_fract(a);
 }
@@ -1159,8 +1163,8 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
       const int i = T.own_start + o;
       OWN_PROLOGUE
       const double xi = sp[slot], yi = sp[a.slot_cap + slot], zi = sp[2 * a.slot_cap + slot];
-      double fx = 0, fy = 0, fz = 0, ee = 0, rr = 0, vir = 0, r2min = 1e300;
-      int nb = 0;
+      double fx = 0, fy = 0, fz = 0, ee = 0, rr = 0, vir = 0;
+      int nb = 0, sgn = 0;
       LIST_WORDS_BEGIN
         double dx[UNR], dy[UNR], dz[UNR], r2[UNR], chi[UNR];
         int k[UNR];
@@ -1174,8 +1178,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
         for (int e = 0; e < UNR; e++) {
           dx[e] -= xi; dy[e] -= yi; dz[e] -= zi;
           r2[e] = dx[e] * dx[e] + dy[e] * dy[e] + dz[e] * dz[e];          // unfused: the reference's r2
-          r2min = fmin(r2min, r2[e]);
-          tab_index_open(c, r2[e], k[e], chi[e]);
+          tab_index_open(c, r2[e], k[e], chi[e], sgn);
           const bool in = r2[e] <= c.end;                                 // pair: <= end (imd_forces_nbl.c:489); rho(end) = 0 exactly
           if (TTMN) nb += in ? 1 : 0;
           k[e] = in ? k[e] : kz;
@@ -1201,7 +1204,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
         HALF_END
       LIST_WORDS_END(4)
       fx *= c.istep2; fy *= c.istep2; fz *= c.istep2; ee *= 0.5; vir *= -0.5 * c.istep2;
-      is_short |= (r2min < c.begin) ? 1 : 0;
+      is_short |= sgn < 0 ? 1 : 0;
       a.f[i] = fx; a.f[a.cap + i] = fy; a.f[2 * (size_t) a.cap + i] = fz;
       a.rhoh[i] = rr;
       if (FEMB) {                                           // PAIR_INT on embed_pot, :757-760; EAM_DF into pos.w
@@ -1263,6 +1266,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass3_tile(TileArgs a)
       const double xi = sp[slot], yi = sp[a.slot_cap + slot], zi = sp[2 * a.slot_cap + slot], wi = sw[slot];
       const int it = NT1 ? 0 : ts[slot];
       double fx = 0, fy = 0, fz = 0, vir = 0, r2min = 1e300;
+      int sgn = 0;
       // list words: PFD groups of four slots in flight (only ~3 waves/SIMD are resident, so the HBM stream
       // of the list needs memory-level parallelism from each wave)
       // two list words (8 slots) are consumed per trip while the next two are in flight; lanes past their
@@ -1286,7 +1290,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass3_tile(TileArgs a)
           double ch[UNR], R0[UNR], R1[UNR], R2[UNR];
 #pragma unroll
           for (int e = 0; e < UNR; e++) {
-            r2min = fmin(r2min, r2[e]); tab_index_open(cr, r2[e], kr[e], ch[e]);
+            tab_index_open(cr, r2[e], kr[e], ch[e], sgn);
             kr[e] = (r2[e] < cr.end) ? kr[e] : kz;                        // rho': r2 < end (imd_forces_nbl.c:868)
           }
           SCHED_BARRIER;
@@ -1329,7 +1333,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass3_tile(TileArgs a)
         }
         HALF_END
       LIST_WORDS_END(RING)
-      if (NT1) { is_short |= (r2min < cr.begin) ? 1 : 0; vir *= -0.5; }
+      if (NT1) { is_short |= sgn < 0 ? 1 : 0; vir *= -0.5; }
       a.f[i] += fx; a.f[a.cap + i] += fy; a.f[2 * (size_t) a.cap + i] += fz;
       sums[0] += vir;
     }
