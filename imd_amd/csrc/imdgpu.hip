@@ -579,39 +579,62 @@ struct TileArgs {
   int *counters;
   double cellsz;
   const int *guard;               // pass 1 launched ahead of the host's look at the list-validity flag: *guard != 0 -> return at once
-  int balance;                    // block ranges cut by atoms (boxes with vacuum) instead of by tiles
+  int balance;                    // block ranges cut by cost (boxes with vacuum, moving surfaces) instead of by tiles
+  const long long *wprefix;       // [ntiles + 1] cost prefix (k_tile_wprefix), read when balance is set
 };
 
 struct TileCtx { int tile, hx, hy, hz, nh, own_start, nown; };
 
 // Persistent workgroups: block b works on a contiguous range of tiles [t0,t1) (consecutive tiles are
 // neighbours along z, so their halos overlap in L2), and the blocks that share an XCD (b % 8 under the
-// observed round-robin placement; speed only) get adjacent ranges.  The ranges are cut by ATOMS, not by
-// tiles: block p gets the tiles whose first own atom lies in [p N/G, (p+1) N/G) -- in a slab with vacuum
-// (config 4, the Maxwell-solver slab) half of the tiles are empty and equal tile counts would idle half the chip.
-// istart[t * CPT] = first own atom of tile t (monotone in t): two binary searches per block.
-__device__ __forceinline__ int tile_of_atom(const int *istart, int CPT, int ntiles, long long atom)
+// observed round-robin placement; speed only) get adjacent ranges.  With uneven occupancy the ranges are cut by COST, not
+// by tiles -- in a slab with vacuum (config 4, the Maxwell-solver slab) half of the tiles are empty and equal tile counts
+// would idle half the chip: two binary searches per block over a cost prefix.
+// wprefix[t] = cost of the tiles before t, cost(t) = own atoms + TILE_FIXED_COST if the tile has any (the per-tile staging and
+// barriers of a force pass are worth several hundred atoms' neighbour loops there: 512 measured best, flat up to 1024): a slab whose surface has just moved into the next layer of
+// tiles has hundreds of sparse tiles there, and ranges cut by atoms alone hand all of them to ONE block (measured on the
+// 10 M-atom slab: passes 2.0 -> 4.1 ms once 800 tiles hold 16..127 atoms each)
+#ifndef TILE_FIXED_COST
+#define TILE_FIXED_COST 512
+#endif
+__device__ __forceinline__ int tile_of_cost(const long long *wprefix, int ntiles, long long c)
 {
-  int lo = 0, hi = ntiles;                      // the tile that holds `atom`: smallest t with istart[(t + 1) * CPT] > atom
-  while (lo < hi) { const int mid = (lo + hi) >> 1; if (istart[(size_t) (mid + 1) * CPT] > atom) hi = mid; else lo = mid + 1; }
+  int lo = 0, hi = ntiles;                      // smallest t with wprefix[t + 1] > c
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (wprefix[mid + 1] > c) hi = mid; else lo = mid + 1; }
   return lo;
 }
-__device__ __forceinline__ void block_tile_range(int ntiles, const int *istart, int CPT, int nlocal, int balance, int &t0, int &t1)
+__device__ __forceinline__ void block_tile_range(int ntiles, const long long *wprefix, int balance, int &t0, int &t1)
 {
   const int nwg = gridDim.x, per = nwg >> 3, b = blockIdx.x;
   const int p = (nwg & 7) == 0 ? (b & 7) * per + (b >> 3) : b;
-  if (!balance || nlocal <= 0) {                // equal tile counts (dense periodic boxes: identical result, no search)
+  const long long W = balance ? wprefix[ntiles] : 0;
+  if (!balance || W <= 0) {                     // equal tile counts (dense periodic boxes: identical result, no search)
     const int chunk = (ntiles + nwg - 1) / nwg;
     t0 = p * chunk; t1 = t0 + chunk;
     if (t0 > ntiles) t0 = ntiles;
     if (t1 > ntiles) t1 = ntiles;
     return;
   }
-  // block p: from the tile holding atom ceil(N p / G) up to (not including) the tile holding atom ceil(N (p+1) / G); the last
-  // block ends behind the tile of the last atom.  Empty tiles in front of the first and behind the last atom belong to nobody.
-  const long long a0 = ((long long) nlocal * p + nwg - 1) / nwg, a1 = ((long long) nlocal * (p + 1) + nwg - 1) / nwg;
-  t0 = a0 >= nlocal ? ntiles : tile_of_atom(istart, CPT, ntiles, a0);
-  t1 = a1 >= nlocal ? (a0 >= nlocal ? ntiles : tile_of_atom(istart, CPT, ntiles, (long long) nlocal - 1) + 1) : tile_of_atom(istart, CPT, ntiles, a1);
+  // block p: from the tile holding cost unit ceil(W p / G) up to (not including) the tile holding unit ceil(W (p+1) / G); the
+  // last block ends behind the last tile with atoms.  Empty tiles in front of the first and behind the last atom belong to nobody.
+  const long long a0 = (W * p + nwg - 1) / nwg, a1 = (W * (p + 1) + nwg - 1) / nwg;
+  t0 = a0 >= W ? ntiles : tile_of_cost(wprefix, ntiles, a0);
+  t1 = a1 >= W ? (a0 >= W ? ntiles : tile_of_cost(wprefix, ntiles, W - 1) + 1) : tile_of_cost(wprefix, ntiles, a1);
+}
+
+// one workgroup: cost prefix over the tiles (a chunk per thread, then a scan of the chunk sums)
+__global__ __launch_bounds__(1024) void k_tile_wprefix(int ntiles, int CPT, const int *istart, long long *wprefix)
+{
+  __shared__ long long part[1024];
+  const int chunk = (ntiles + 1023) / 1024, t0 = threadIdx.x * chunk, t1 = min(ntiles, t0 + chunk);
+  long long sum = 0;
+  for (int t = t0; t < t1; t++) { const int o = istart[(size_t) (t + 1) * CPT] - istart[(size_t) t * CPT]; sum += o > 0 ? o + TILE_FIXED_COST : 0; }
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) { long long acc = 0; for (int q = 0; q < 1024; q++) { const long long v = part[q]; part[q] = acc; acc += v; } wprefix[ntiles] = acc; }
+  __syncthreads();
+  long long acc = part[threadIdx.x];
+  for (int t = t0; t < t1; t++) { wprefix[t] = acc; const int o = istart[(size_t) (t + 1) * CPT] - istart[(size_t) t * CPT]; acc += o > 0 ? o + TILE_FIXED_COST : 0; }
 }
 
 // halo-cell table + prefix (hstart/hsrc) and staging of positions into LDS as x, y, z planes of slot_cap
@@ -773,7 +796,7 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile(TileArgs a)
   int *hstart = (int *) (sp + 3 * (size_t) a.slot_cap), *hsrc = hstart + NH_MAX + 1;
   TileCtx T;
   int t0, t1;
-  block_tile_range(a.ntiles, a.istart, a.g.CPT, a.nlocal, a.balance, t0, t1);
+  block_tile_range(a.ntiles, a.wprefix, a.balance, t0, t1);
   const unsigned short dummy = (unsigned short) (a.slot_cap - 1);
   int mmax = 0;
   for (T.tile = t0; T.tile < t1; T.tile++) {
@@ -997,7 +1020,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile(TileArgs a)
   int *ts = (int *) (scratch + 64);
   TileCtx T;
   int t0, t1;
-  block_tile_range(a.ntiles, a.istart, a.g.CPT, a.nlocal, a.balance, t0, t1);
+  block_tile_range(a.ntiles, a.wprefix, a.balance, t0, t1);
   double sums[2] = {0.0, 0.0};
   int is_short = 0;
   if (t0 < t1) {                                 // tables are loaded once per (persistent) workgroup
@@ -1140,7 +1163,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
   double *scratch = sp + 3 * (size_t) a.slot_cap;
   TileCtx T;
   int t0, t1;
-  block_tile_range(a.ntiles, a.istart, a.g.CPT, a.nlocal, a.balance, t0, t1);
+  block_tile_range(a.ntiles, a.wprefix, a.balance, t0, t1);
   double sums[3] = {0.0, 0.0, 0.0};        // pair energy, virial, embedding energy
   int is_short = 0;
   if (t0 < t1) {
@@ -1243,7 +1266,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass3_tile(TileArgs a)
   int *ts = (int *) (scratch + 64);
   TileCtx T;
   int t0, t1;
-  block_tile_range(a.ntiles, a.istart, a.g.CPT, a.nlocal, a.balance, t0, t1);
+  block_tile_range(a.ntiles, a.wprefix, a.balance, t0, t1);
   double sums[1] = {0.0};
   int is_short = 0;
   if (t0 < t1) {
@@ -1485,6 +1508,7 @@ extern "C" void imdgpu_destroy(imdgpu_ctx *c)
   imdgpu_dist_free(c);
   if (c->d_refperm) (void) hipFree(c->d_refperm);
   if (c->d_stage) (void) hipFree(c->d_stage);
+  if (c->d_wprefix) (void) hipFree(c->d_wprefix);
   void *ptrs[] = {c->pos, c->type, c->id, c->acell, c->p, c->f, c->ref, c->mass, c->epot, c->rhoh, c->numneighs,
                   c->pos2, c->type2, c->id2, c->p2, c->mass2, c->nn2, c->fdc, c->fdc2, c->keys, c->keys2, c->perm, c->perm2,
                   c->cub_tmp, c->cell_start, c->cell_cnt, c->icnt, c->istart, c->gcell_lin, c->gcell_src,
@@ -2176,7 +2200,7 @@ static TileArgs make_tile_args(imdgpu_ctx *ctx)
   a.pair = ctx->pair.par; a.rho = ctx->rho.par; a.emb = ctx->emb.par; a.posw = ctx->pos; a.merged = ctx->d_merged;
   a.f = ctx->f; a.epot = ctx->epot; a.rhoh = ctx->rhoh; a.ref = ctx->ref; a.numneighs = ctx->numneighs;
   a.partials = ctx->partials; a.counters = ctx->d_counters; a.cellsz = ctx->cellsz; a.guard = nullptr;
-  a.balance = ctx->tile_balance;
+  a.balance = ctx->tile_balance; a.wprefix = ctx->d_wprefix;
   return a;
 }
 
@@ -2243,6 +2267,10 @@ extern "C" int imdgpu_make_nblist(imdgpu_ctx *ctx)
       static const char *fb = getenv("IMDGPU_TILE_BALANCE");
       ctx->tile_balance = fb ? atoi(fb) : ((double) ctx->h_counters[CNT_MAXOWN] * ctx->ntiles > 1.25 * (double) std::max(n, 1));
     }
+    if (ctx->tile_balance) {
+      if (ctx->wprefix_cap < (size_t) ctx->ntiles + 1) { if (dev_alloc(ctx, &ctx->d_wprefix, (size_t) ctx->ntiles + 1)) return 1; ctx->wprefix_cap = (size_t) ctx->ntiles + 1; }
+      hipLaunchKernelGGL(k_tile_wprefix, dim3(1), dim3(1024), 0, ctx->stream, ctx->ntiles, g.CPT, ctx->istart, ctx->d_wprefix);
+    }
     ctx->slot_cap = (ctx->h_counters[CNT_MAXHALO] + 1 + 63) / 64 * 64;      // + far-away dummy slot
     ctx->max_halo = ctx->h_counters[CNT_MAXHALO];
     if (tile_cap != ctx->tile_cap) { ctx->tile_cap = tile_cap; ctx->nbr16_cap = 0; }
@@ -2293,6 +2321,15 @@ extern "C" int imdgpu_make_nblist(imdgpu_ctx *ctx)
     HIPCHK(hipStreamSynchronize(ctx->stream));
     int mx = ctx->h_counters[CNT_MAXNBR];
     if (mx <= ctx->W) {
+      if (ctx->tl_on && ctx->list_mode == 1) {               // diagnostics: how the own atoms are spread over the tiles
+        std::vector<int> is((size_t) ctx->ntiles * ctx->CPT + 1);
+        (void) hipMemcpy(is.data(), ctx->istart, is.size() * sizeof(int), hipMemcpyDeviceToHost);
+        int h[5] = {0, 0, 0, 0, 0};
+        for (int t = 0; t < ctx->ntiles; t++) { const int o = is[(size_t) (t + 1) * ctx->CPT] - is[(size_t) t * ctx->CPT]; h[o == 0 ? 0 : o < 16 ? 1 : o < 128 ? 2 : o < 512 ? 3 : 4]++; }
+        fprintf(stderr, "[imdgpu timeline] tiles by own atoms: empty %d, 1-15: %d, 16-127: %d, 128-511: %d, >=512: %d\n", h[0], h[1], h[2], h[3], h[4]);
+      }
+      if (ctx->tl_on) fprintf(stderr, "[imdgpu timeline] list build %d: mode %d tile %d %d %d ntiles %d tile_cap %d slot_cap %d W %d max_nbr %d balance %d nlocal %d nghost %d\n",
+                                 ctx->nbl_count + 1, ctx->list_mode, ctx->tile[0], ctx->tile[1], ctx->tile[2], ctx->ntiles, ctx->tile_cap, ctx->slot_cap, ctx->W, mx, ctx->tile_balance, ctx->nlocal, ctx->nghost);
       ctx->have_valid_nbl = 1;
       ctx->nbl_count++;
       HIPCHK(hipMemsetAsync(ctx->d_counters + CNT_INVALID, 0, sizeof(int), ctx->stream));

@@ -131,6 +131,7 @@ struct imdgpu_ctx {
   void *d_stage = nullptr; size_t stage_bytes = 0;
   int reserve_cus = 0;
   int tile_balance = 0;             // set by make_nblist when some tiles are (nearly) empty: see block_tile_range
+  long long *d_wprefix = nullptr; size_t wprefix_cap = 0;   // [ntiles + 1] cost prefix of the tiles (k_tile_wprefix)
   void *dist = nullptr;
   const int *pass1_guard = nullptr;   // device int: a pass-1 kernel launched AHEAD of the host's look at the list-validity flag returns at once when it is set
 };
