@@ -1400,10 +1400,13 @@ __global__ void k_move_nve(int n, int cap, double4 *pos, const int *type, double
   if (i < n) {
     const size_t c1 = cap, c2 = 2 * (size_t) cap;
     int t = ntypes == 1 ? 0 : type[i];
-    double fx = f[i] * restr[3 * t], fy = f[c1 + i] * restr[3 * t + 1], fz = f[c2 + i] * restr[3 * t + 2];
+    double fx = f[i], fy = f[c1 + i], fz = f[c2 + i];
     double px = p[i], py = p[c1 + i], pz = p[c2 + i], m = mass[i];
     double e1 = px * px + py * py + pz * pz;
-    f[i] = fx; f[c1 + i] = fy; f[c2 + i] = fz;
+    if (restr) {                                 // KRAFT *= restrictions (imd_integrate.c); nullptr = every factor is 1: nothing to write back
+      fx *= restr[3 * t]; fy *= restr[3 * t + 1]; fz *= restr[3 * t + 2];
+      f[i] = fx; f[c1 + i] = fy; f[c2 + i] = fz;
+    }
     px += dt * fx; py += dt * fy; pz += dt * fz;
     double e2 = px * px + py * py + pz * pz;
     s[0] = (e1 + e2) / (4 * m);
@@ -1805,6 +1808,7 @@ extern "C" int imdgpu_set_params(imdgpu_ctx *ctx, int ntypes, double cellsz, dou
   std::vector<double> ones(3 * ntypes, 1.0);
   if (dev_alloc(ctx, &ctx->d_restr, 3 * ntypes)) return 1;
   HIPCHK(hipMemcpy(ctx->d_restr, ones.data(), ones.size() * sizeof(double), hipMemcpyHostToDevice));
+  ctx->restr_identity = 1;
   ctx->have_valid_nbl = 0;
   return 0;
 }
@@ -1813,6 +1817,8 @@ extern "C" int imdgpu_set_restrictions(imdgpu_ctx *ctx, const double *r)
 {
   if (!ctx->d_restr) return imdgpu_fail(ctx, "set_params first");
   HIPCHK(hipMemcpy(ctx->d_restr, r, 3 * ctx->ntypes * sizeof(double), hipMemcpyHostToDevice));
+  ctx->restr_identity = 1;
+  for (int q = 0; q < 3 * ctx->ntypes; q++) if (r[q] != 1.0) ctx->restr_identity = 0;
   return 0;
 }
 
@@ -2509,7 +2515,7 @@ extern "C" int imdgpu_move_atoms_nve(imdgpu_ctx *ctx, double *ekin)
   {
     ProfScope ps(ctx, PROF_INTEGRATE);
     hipLaunchKernelGGL((k_move_nve<false>), dim3(nb), dim3(256), 0, ctx->stream, n, ctx->cap_local, ctx->pos, ctx->type,
-                       ctx->p, ctx->f, ctx->mass, ctx->d_restr, ctx->ntypes, ctx->timestep, ctx->ref, ctx->partials);
+                       ctx->p, ctx->f, ctx->mass, ctx->restr_identity ? nullptr : ctx->d_restr, ctx->ntypes, ctx->timestep, ctx->ref, ctx->partials);
     hipLaunchKernelGGL(k_reduce_move, dim3(1), dim3(1024), 0, ctx->stream, nb, ctx->partials, ctx->d_sums, h * h + 1e300,
                        ctx->d_counters, 1);
   }
@@ -2551,7 +2557,7 @@ int imdgpu_launch_integrate(imdgpu_ctx *ctx)
   double h = 0.5 * ctx->nbl_margin;
   ProfScope ps(ctx, PROF_INTEGRATE);
   hipLaunchKernelGGL((k_move_nve<true>), dim3(nb), dim3(256), 0, ctx->stream, n, ctx->cap_local, ctx->pos, ctx->type,
-                     ctx->p, ctx->f, ctx->mass, ctx->d_restr, ctx->ntypes, ctx->timestep, ctx->ref, ctx->partials);
+                     ctx->p, ctx->f, ctx->mass, ctx->restr_identity ? nullptr : ctx->d_restr, ctx->ntypes, ctx->timestep, ctx->ref, ctx->partials);
   hipLaunchKernelGGL(k_reduce_move, dim3(1), dim3(1024), 0, ctx->stream, nb, ctx->partials, ctx->d_sums, h * h,
                      ctx->d_counters, 1);
   HIPCHK(hipGetLastError());
@@ -2584,7 +2590,7 @@ extern "C" int imdgpu_md_step(imdgpu_ctx *ctx, int steps)
     double h = 0.5 * ctx->nbl_margin;
     ProfScope ps(ctx, PROF_INTEGRATE);
     hipLaunchKernelGGL((k_move_nve<true>), dim3(nb), dim3(256), 0, ctx->stream, n, ctx->cap_local, ctx->pos, ctx->type,
-                       ctx->p, ctx->f, ctx->mass, ctx->d_restr, ctx->ntypes, ctx->timestep, ctx->ref, ctx->partials);
+                       ctx->p, ctx->f, ctx->mass, ctx->restr_identity ? nullptr : ctx->d_restr, ctx->ntypes, ctx->timestep, ctx->ref, ctx->partials);
     hipLaunchKernelGGL(k_reduce_move, dim3(1), dim3(1024), 0, ctx->stream, nb, ctx->partials, ctx->d_sums, h * h,
                        ctx->d_counters, 1);
   }

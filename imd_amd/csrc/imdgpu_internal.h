@@ -56,6 +56,7 @@ struct imdgpu_ctx {
   DevTable pair, rho, emb;
   double *d_merged = nullptr;     // (phi,rho) interleaved + 3 zero rows when both share one r^2 grid
   double *d_restr = nullptr;      // ntypes*3
+  int restr_identity = 1;         // every factor is 1: the integrators need not write the (unchanged) forces back
 
   // atoms (device).  local atoms [0,nlocal) sorted by inner-cell rank, ghost
   // atoms [nlocal,ntot) grouped by ghost cell in linear cell order ----------

@@ -1225,10 +1225,13 @@ __global__ void k_move_ttm(int n, int cap, Lat L, Geo g, double4 *pos, const int
     double fxi = natoms[fc] >= L.fd_min_atoms ? xi[fc] : 0.0;
     double vx = vcom[fc], vy = vcom[ncell + fc], vz = vcom[2 * ncell + fc];
     int t = ntypes == 1 ? 0 : type[i];
-    double fx = f[i] * restr[3 * t], fy = f[c1 + i] * restr[3 * t + 1], fz = f[c2 + i] * restr[3 * t + 2];
+    double fx = f[i], fy = f[c1 + i], fz = f[c2 + i];
     double px = p[i], py = p[c1 + i], pz = p[c2 + i], m = mass[i];
     double e1 = px * px + py * py + pz * pz;
-    f[i] = fx; f[c1 + i] = fy; f[c2 + i] = fz;
+    if (restr) {                                 // nullptr = every restriction factor is 1: the forces need no write-back
+      fx *= restr[3 * t]; fy *= restr[3 * t + 1]; fz *= restr[3 * t + 2];
+      f[i] = fx; f[c1 + i] = fy; f[c2 + i] = fz;
+    }
     px += dt * (fx + fxi * m * (px / m - vx));
     py += dt * (fy + fxi * m * (py / m - vy));
     pz += dt * (fz + fxi * m * (pz / m - vz));
@@ -1932,7 +1935,7 @@ static int launch_move_ttm(imdgpu_ctx *ctx, double limit2)
   const int n = ctx->nlocal, nb = nblk(n, 256);
   ProfScope ps(ctx, PROF_INTEGRATE);
   hipLaunchKernelGGL(k_move_ttm, dim3(nb), dim3(256), 0, ctx->stream, n, ctx->cap_local, L, imdgpu_make_geo(ctx),
-                     ctx->pos, ctx->type, ctx->acell, ctx->p, ctx->f, ctx->mass, ctx->d_restr, ctx->ntypes, ctx->timestep,
+                     ctx->pos, ctx->type, ctx->acell, ctx->p, ctx->f, ctx->mass, ctx->restr_identity ? nullptr : ctx->d_restr, ctx->ntypes, ctx->timestep,
                      ctx->ref, t->natoms, t->xi, t->vcom, t->ncell, ctx->partials);
   hipLaunchKernelGGL(k_reduce_move, dim3(1), dim3(1024), 0, ctx->stream, nb, ctx->partials, ctx->d_sums, limit2,
                      ctx->d_counters, 1);

@@ -99,6 +99,11 @@ class GpuSystem:
     def set_stream(self, hip_stream):
         self._ck(self.L.imdgpu_set_stream(self.h, C.c_void_p(int(hip_stream))))
 
+    def set_restrictions(self, r):
+        """`restrictions` of the parameter file (globals.h; KRAFT *= restrictions in move_atoms_*): [ntypes][3] factors"""
+        a = np.ascontiguousarray(r, dtype=np.float64).reshape(-1)
+        self._ck(self.L.imdgpu_set_restrictions(self.h, _dp(a)))
+
     def set_option(self, name, value):
         self._ck(self.L.imdgpu_set_option(self.h, name.encode(), int(value)))
 

@@ -165,3 +165,44 @@ def test_rank_without_atoms():
     assert d["ort"].shape == (0, 3) and int(d["cell_n"].sum()) == 0
     assert s.get_sums()["tot_kin_energy"] == 0.0
     s.close()
+
+
+def test_restrictions_scale_the_forces_in_the_integrator():
+    """move_atoms_nve: KRAFT *= restrictions before the momenta are advanced (imd_integrate.c:98-104 via the oracle's
+    restatement); with every factor 1 the integrator skips the write-back, with others it must not"""
+    from imd_amd import lattice, potential
+    from imd_amd.system import global_cell_dim
+    from oracle import pyoracle as po
+    nb = (8, 8, 8)
+    box = lattice.fcc_box(nb)
+    pos = lattice.fcc_positions(nb)
+    rng = np.random.default_rng(21)
+    pos = (pos + rng.normal(scale=0.05, size=pos.shape)) % np.diag(box)
+    mom = lattice.maxwell_momenta(len(pos), 26.9815, 0.03, seed=21)
+    pair, rho, emb, r2cut = potential.synthetic_eam_tables()
+    cellsz = (np.sqrt(r2cut) + 0.5) ** 2
+    dim = [g + 2 for g in global_cell_dim(box, cellsz, (1, 1, 1))]
+    for restr in ((1.0, 1.0, 1.0), (1.0, 0.0, 0.5)):
+        o = po.OracleSystem(dim, 64, 1, box, (1, 1, 1), cellsz, 0.5, 0.1)
+        for w, t in enumerate((pair, rho, emb)):
+            o.set_table(w, t.as_dict())
+        o.fill_from_positions(pos, mom, 26.9815)
+        for q in range(3):
+            o.s.restrictions[q] = restr[q]
+        g = GpuSystem(box, (1, 1, 1), dim, 1, cellsz, 0.5, 0.1)
+        g.upload_tables(pair, rho, emb)
+        g.upload_cells(o.n.copy(), o.gather_inner("ort"), o.gather_inner("impuls"), o.gather_inner("masse"),
+                       o.gather_inner("sorte").astype(np.int32), o.gather_inner("nummer").astype(np.int32))
+        g.set_restrictions([restr])
+        for st in range(4):
+            o.calc_forces(st); o.move_atoms_nve(); o.check_nblist()
+            g.md_step(st)
+        d = g.download(fields=("ort", "impuls", "kraft", "nummer"))
+        og, oo = np.argsort(d["nummer"]), np.argsort(o.gather_inner("nummer"))
+        fo = o.gather_inner("kraft")[oo]
+        assert np.abs(d["kraft"][og] - fo).max() < 1e-9 * np.abs(fo).max()
+        assert np.abs(d["impuls"][og] - o.gather_inner("impuls")[oo]).max() < 1e-10 * np.abs(mom).max()
+        assert np.abs(d["ort"][og] - o.gather_inner("ort")[oo]).max() < 1e-10
+        if restr[1] == 0.0:
+            assert np.abs(d["kraft"][:, 1]).max() == 0.0          # written back scaled
+        g.close(); o.close()
