@@ -67,6 +67,7 @@ struct TtmState {
   int *d_pstat = nullptr, *h_pstat = nullptr;   // status of the last launch (device word / pinned copy)
   hipEvent_t ev_pstat = nullptr;
   const int *graph_guard[2] = {nullptr, nullptr};
+  double *d_ufd_part = nullptr; size_t ufd_part_cap = 0;   // partial sums of the chunked update_fd
 };
 
 // physical constants of the reference, globals.h:324-331,1190
@@ -1298,6 +1299,7 @@ void imdgpu_ttm_free(imdgpu_ctx *ctx)
   if (t->d_gbase) (void) hipFree(t->d_gbase);
   if (t->d_facecnt) (void) hipFree(t->d_facecnt);
   if (t->d_pflags) (void) hipFree(t->d_pflags);
+  if (t->d_ufd_part) (void) hipFree(t->d_ufd_part);
   if (t->d_prec) (void) hipFree(t->d_prec);
   if (t->d_pstat) (void) hipFree(t->d_pstat);
   if (t->h_pstat) (void) hipHostFree(t->h_pstat);
@@ -1441,12 +1443,116 @@ extern "C" int imdgpu_ttm_upload(imdgpu_ctx *ctx, const imdgpu_ttm_fields *f)
   return ttm_xfer(ctx, f, false);
 }
 
+// update_fd for FD cells over THOUSANDS of MD cells (a one-row lattice spans the whole cross-section of the sample:
+// 78 x 78 MD cells per FD cell at config 5): one workgroup per FD cell (k_ttm_update_fd_wide) leaves most of the chip idle
+// and walks 6000 cells per workgroup, latency bound (1.1 ms at 10 M atoms).  Here every FD cell is cut into UFD_CHUNKS
+// chunks of MD cells, a four-wave workgroup per chunk writes partial sums, and a one-wave kernel per FD cell adds the
+// chunks in a fixed order (deterministic); two sweeps as in the reference (the second needs v_com), so four launches.
+#define UFD_CHUNKS 64
+template <int PHASE>
+__global__ __launch_bounds__(256) void k_ttm_ufd_part(Lat L, int cap, const int *cell_start, const int *cell_cnt, const int *numneighs,
+                                                      const double *p, const double *mass, const double *vcom, int ncell, double *part)
+{
+  __shared__ double sd[6][4];
+  const int w = blockIdx.x / UFD_CHUNKS, ch = blockIdx.x % UFD_CHUNKS, nj = L.ldim[1], nk = L.ldim[2];
+  const int k = w % nk + 1, j = (w / nk) % nj + 1, i = w / (nk * nj) + 1;
+  const int c = fidx(L, i + L.off[0], j + L.off[1], k + L.off[2]);
+  const int e0 = L.ext[0], e1 = L.ext[1], e2 = L.ext[2], ne = e0 * e1 * e2;
+  const int per = (ne + UFD_CHUNKS - 1) / UFD_CHUNKS, qa = ch * per, qb = min(ne, qa + per);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  auto md_cell = [&](int q) {
+    const int xc = (i - 1) * e0 + 1 + q / (e2 * e1), yc = (j - 1) * e1 + 1 + (q / e2) % e1, zc = (k - 1) * e2 + 1 + q % e2;
+    return (xc * L.md_dim[1] + yc) * L.md_dim[2] + zc;
+  };
+  double v[6] = {0, 0, 0, 0, 0, 0};                     // phase 1: natoms, sum numneighs, sum p (3), sum m; phase 2: sum m |v - v_com|^2
+  double vx = 0, vy = 0, vz = 0;
+  if (PHASE == 2) { vx = vcom[c]; vy = vcom[ncell + c]; vz = vcom[2 * ncell + c]; }
+  // a wave walks three cells at a time: lane l takes atom l % 21 of cell l / 21 (cells hold ~21 atoms; lane 63 idles), longer
+  // cells finish in extra trips
+  for (int q0 = qa + wv * 3; q0 < qb; q0 += 4 * 3) {
+    const int sub = lane / 21, a0 = lane % 21, q = q0 + sub;
+    if (sub < 3 && q < qb) {
+      const int m = md_cell(q), s0 = cell_start[m], n0 = cell_cnt[m];
+      if (PHASE == 1 && a0 == 0) v[0] += n0;
+      for (int a = a0; a < n0; a += 21) {
+        const int g = s0 + a;
+        if (PHASE == 1) { v[1] += numneighs[g]; v[2] += p[g]; v[3] += p[cap + g]; v[4] += p[2 * (size_t) cap + g]; v[5] += mass[g]; }
+        else {
+          const double mm = mass[g];
+          double u;
+          u = p[g] / mm - vx; v[0] += mm * (u * u);
+          u = p[cap + g] / mm - vy; v[0] += mm * (u * u);
+          u = p[2 * (size_t) cap + g] / mm - vz; v[0] += mm * (u * u);
+        }
+      }
+    }
+  }
+  const int NV = PHASE == 1 ? 6 : 1;
+#pragma unroll
+  for (int q = 0; q < NV; q++) { v[q] = wsum(v[q]); if (lane == 0) sd[q][wv] = v[q]; }
+  __syncthreads();
+  if (threadIdx.x < NV) part[((size_t) blockIdx.x) * 6 + threadIdx.x] = ((sd[threadIdx.x][0] + sd[threadIdx.x][1]) + sd[threadIdx.x][2]) + sd[threadIdx.x][3];
+}
+
+template <int PHASE>
+__global__ __launch_bounds__(64) void k_ttm_ufd_combine(Lat L, int steps, const double *part, int *natoms, int *natoms_old, double *temp0,
+                                                       double *temp1, double *xi, double *md_temp, double *source, double *vcom,
+                                                       double *dens, int ncell)
+{
+  const int w = blockIdx.x, lane = threadIdx.x, nj = L.ldim[1], nk = L.ldim[2];
+  const int k = w % nk + 1, j = (w / nk) % nj + 1, i = w / (nk * nj) + 1;
+  const int c = fidx(L, i + L.off[0], j + L.off[1], k + L.off[2]);
+  double v[6];
+#pragma unroll
+  for (int q = 0; q < 6; q++) v[q] = (lane < UFD_CHUNKS && (PHASE == 1 || q == 0)) ? part[((size_t) w * UFD_CHUNKS + lane) * 6 + q] : 0.0;
+#pragma unroll
+  for (int q = 0; q < (PHASE == 1 ? 6 : 1); q++) v[q] = wsum(v[q]);
+  if (lane != 0) return;
+  if (PHASE == 1) {
+    const int N = (int) v[0];
+    double d = 0, vx = 0, vy = 0, vz = 0;
+    if (N > 0) {
+      d = v[1] / ((double) N) * L.atomic_weight / L.neighvol * 1660.53907;
+      if (d == 0) d = (double) N * L.atomic_weight / L.vol * 1660.53907;
+      vx = v[2] / v[5]; vy = v[3] / v[5]; vz = v[4] / v[5];
+    }
+    const int old = natoms[c];
+    natoms_old[c] = (steps < 1) ? N : old;
+    natoms[c] = N;
+    xi[c] = 0.0; source[c] = 0.0; dens[c] = d;
+    vcom[c] = vx; vcom[ncell + c] = vy; vcom[2 * ncell + c] = vz;
+  } else {
+    const int nat = natoms[c];
+    double T = v[0];
+    if (nat >= L.fd_min_atoms) T /= 3.0 * nat; else T = 0.0;
+    md_temp[c] = T;
+    if (steps < 1 && nat >= L.fd_min_atoms) { temp0[c] = T; temp1[c] = T; }
+  }
+}
+
 extern "C" int imdgpu_ttm_update_fd(imdgpu_ctx *ctx, int steps)
 {
   NEED_TTM();
   ProfScope ps(ctx, PROF_TTM_UPDATE);
   if (t->ext[0] * t->ext[1] * t->ext[2] > 64) {             // FD cells over many MD cells: a workgroup per FD cell
     if (ctx->ttm_flux) return imdgpu_fail(ctx, "update_fd: the flux bookkeeping (ttm_flux / ttm_adv) is not available for FD cells of more than 64 MD cells");
+    const int nfd = t->ldim[0] * t->ldim[1] * t->ldim[2];
+    if (t->ext[0] * t->ext[1] * t->ext[2] >= 2048) {         // thousands of MD cells per FD cell: chunked, four launches
+      if (t->ufd_part_cap < (size_t) nfd * UFD_CHUNKS * 6) {
+        if (dev_alloc(ctx, &t->d_ufd_part, (size_t) nfd * UFD_CHUNKS * 6)) return 1;
+        t->ufd_part_cap = (size_t) nfd * UFD_CHUNKS * 6;
+      }
+      hipLaunchKernelGGL((k_ttm_ufd_part<1>), dim3(nfd * UFD_CHUNKS), dim3(256), 0, ctx->stream, L, ctx->cap_local, ctx->cell_start,
+                         ctx->cell_cnt, ctx->numneighs, ctx->p, ctx->mass, t->vcom, t->ncell, t->d_ufd_part);
+      hipLaunchKernelGGL((k_ttm_ufd_combine<1>), dim3(nfd), dim3(64), 0, ctx->stream, L, steps, t->d_ufd_part, t->natoms, t->natoms_old,
+                         t->temp[0], t->temp[1], t->xi, t->md_temp, t->source, t->vcom, t->dens, t->ncell);
+      hipLaunchKernelGGL((k_ttm_ufd_part<2>), dim3(nfd * UFD_CHUNKS), dim3(256), 0, ctx->stream, L, ctx->cap_local, ctx->cell_start,
+                         ctx->cell_cnt, ctx->numneighs, ctx->p, ctx->mass, t->vcom, t->ncell, t->d_ufd_part);
+      hipLaunchKernelGGL((k_ttm_ufd_combine<2>), dim3(nfd), dim3(64), 0, ctx->stream, L, steps, t->d_ufd_part, t->natoms, t->natoms_old,
+                         t->temp[0], t->temp[1], t->xi, t->md_temp, t->source, t->vcom, t->dens, t->ncell);
+      HIPCHK(hipGetLastError());
+      return 0;
+    }
     hipLaunchKernelGGL(k_ttm_update_fd_wide, dim3(t->ldim[0] * t->ldim[1] * t->ldim[2]), dim3(1024), 0, ctx->stream, L, steps,
                        ctx->cap_local, ctx->cell_start, ctx->cell_cnt, ctx->numneighs, ctx->p, ctx->mass, t->natoms,
                        t->natoms_old, t->temp[0], t->temp[1], t->xi, t->md_temp, t->source, t->vcom, t->dens, t->ncell);

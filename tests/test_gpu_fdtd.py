@@ -149,17 +149,20 @@ def test_solver_loop_with_diffusion_vs_oracle():
     of.close(); ot.close(); o.close(); s.close()
 
 
-def test_update_fd_for_fd_cells_of_many_md_cells():
+@pytest.mark.parametrize("nyz", [9, 46])
+def test_update_fd_for_fd_cells_of_many_md_cells(nyz):
     """the one-row lattice of a wide slab puts thousands of MD cells under one FD cell (fd_ext 1 ny nz): update_fd then runs a
-    workgroup per FD cell (k_ttm_update_fd_wide) -- same numbers as the oracle's sequential loop (integers exact, sums to
-    rounding)"""
-    hx, nxc, nyz = 7.0, 12, 9
+    workgroup per FD cell (k_ttm_update_fd_wide; 81 MD cells per FD cell) or, from 2048 MD cells per FD cell on, 64 chunk
+    workgroups per FD cell and a fixed-order combine (k_ttm_ufd_part / _combine; 2116 cells) -- same numbers as the oracle's
+    sequential loop (integers exact, sums to rounding)"""
+    hx, nxc = 7.0, 12
     pair, rho, emb, r2cut = potential.synthetic_eam_tables()
     margin = 0.4
     cellsz = (np.sqrt(r2cut) + margin) ** 2
     box = np.diag([nxc * hx, nyz * 7.0, nyz * 7.0])
-    nb = (int(round(8 * hx / 4.05)), 15, 15)
-    pos = lattice.fcc_positions(nb, 4.05) * np.array([8 * hx / (nb[0] * 4.05), box[1, 1] / (15 * 4.05), box[2, 2] / (15 * 4.05)])
+    nuc = int(round(nyz * 7.0 / 4.05))
+    nb = (int(round(8 * hx / 4.05)), nuc, nuc)
+    pos = lattice.fcc_positions(nb, 4.05) * np.array([8 * hx / (nb[0] * 4.05), box[1, 1] / (nuc * 4.05), box[2, 2] / (nuc * 4.05)])
     pos = pos + np.array([2 * hx + 0.3, 0.0, 0.0])
     rng = np.random.default_rng(4)
     pos = pos + rng.normal(scale=0.03, size=pos.shape)
