@@ -61,7 +61,6 @@ static const char *rccl_load()
 }
 
 #define MAXSEG 32
-struct SegTab { int n; long long soff[MAXSEG], doff[MAXSEG], cnt[MAXSEG]; };   // element units
 
 struct DistState {
   int nranks = 1, rank = 0;
@@ -75,6 +74,9 @@ struct DistState {
   long long nsend_atoms = 0, nrecv_atoms = 0;
   int *d_send_idx = nullptr; size_t send_idx_cap = 0;
   int *d_seg_of = nullptr;                     // per send atom: its segment (for the shift)
+  int *d_self_dst = nullptr;                   // per send atom: the ghost atom it becomes on THIS rank (self segments), or -1
+  unsigned char *d_recv_self = nullptr; size_t recv_self_cap = 0;   // per ghost atom: filled directly by the gather (self segment)
+  long long nself_atoms = 0;
   double *d_shift = nullptr;                   // 3 * MAXSEG
   double *sendbuf = nullptr, *recvbuf = nullptr; size_t sendbuf_cap = 0, recvbuf_cap = 0;   // doubles
   int *d_flag = nullptr;                       // [0] global "list invalid" of the step just integrated
@@ -95,7 +97,7 @@ void imdgpu_dist_free(imdgpu_ctx *ctx)
   if (!D) return;
   if (D->comm && g_rccl.CommDestroy) (void) g_rccl.CommDestroy(D->comm);
   if (D->comm2 && g_rccl.CommDestroy) (void) g_rccl.CommDestroy(D->comm2);
-  void *ptrs[] = {D->d_send_idx, D->d_seg_of, D->d_shift, D->sendbuf, D->recvbuf, D->d_flag, D->ttm_blk, D->ttm_all, D->d_ttm_offs};
+  void *ptrs[] = {D->d_send_idx, D->d_seg_of, D->d_self_dst, D->d_recv_self, D->d_shift, D->sendbuf, D->recvbuf, D->d_flag, D->ttm_blk, D->ttm_all, D->d_ttm_offs};
   for (void *p : ptrs) if (p) (void) hipFree(p);
   if (D->h_flag) (void) hipHostFree(D->h_flag);
   if (D->ev_flag) (void) hipEventDestroy(D->ev_flag);
@@ -195,15 +197,41 @@ extern "C" int imdgpu_dist_set_plan(imdgpu_ctx *ctx, int nsend, const int *send_
   if ((size_t) D->nsend_atoms > D->send_idx_cap) {
     if (D->d_send_idx) (void) hipFree(D->d_send_idx);
     if (D->d_seg_of) (void) hipFree(D->d_seg_of);
+    if (D->d_self_dst) (void) hipFree(D->d_self_dst);
     D->send_idx_cap = (size_t) (D->nsend_atoms * 1.2) + 1024;
     HIPCHK(hipMalloc((void **) &D->d_send_idx, D->send_idx_cap * sizeof(int)));
     HIPCHK(hipMalloc((void **) &D->d_seg_of, D->send_idx_cap * sizeof(int)));
+    HIPCHK(hipMalloc((void **) &D->d_self_dst, D->send_idx_cap * sizeof(int)));
+  }
+  if ((size_t) D->nrecv_atoms + 1 > D->recv_self_cap) {
+    if (D->d_recv_self) (void) hipFree(D->d_recv_self);
+    D->recv_self_cap = (size_t) (D->nrecv_atoms * 1.2) + 1024;
+    HIPCHK(hipMalloc((void **) &D->d_recv_self, D->recv_self_cap));
   }
   if (D->nsend_atoms > 0) HIPCHK(hipMemcpy(D->d_send_idx, dev_send_idx, D->nsend_atoms * sizeof(int), hipMemcpyDeviceToDevice));
   {
     std::vector<int> seg((size_t) D->nsend_atoms);
     for (int s = 0; s < nsend; s++) for (long long q = 0; q < D->send_cnt[s]; q++) seg[D->send_off[s] + q] = s;
     if (D->nsend_atoms > 0) HIPCHK(hipMemcpy(D->d_seg_of, seg.data(), seg.size() * sizeof(int), hipMemcpyHostToDevice));
+    // Segments this rank sends to itself (a periodic direction with one rank: all 26 at one rank, the y/z faces of a 2x1x1 grid)
+    // never touch the buffers: the gather kernel writes those atoms, shifted, straight into the ghost range, the k-th self
+    // segment sent being the k-th self segment received; unpack skips them.
+    std::vector<int> dst((size_t) D->nsend_atoms, -1);
+    std::vector<unsigned char> rs((size_t) D->nrecv_atoms + 1, 0);
+    D->nself_atoms = 0;
+    if (!D->self_comm) {
+      std::vector<int> self_recv;
+      for (int r = 0; r < nrecv; r++) if (recv_peer[r] == D->rank) self_recv.push_back(r);
+      size_t k = 0;
+      for (int q = 0; q < nsend; q++) {
+        if (send_peer[q] != D->rank) continue;
+        const int r = self_recv[k++];
+        for (long long a2 = 0; a2 < D->send_cnt[q]; a2++) { dst[D->send_off[q] + a2] = ctx->nlocal + (int) (D->recv_off[r] + a2); rs[D->recv_off[r] + a2] = 1; }
+        D->nself_atoms += D->send_cnt[q];
+      }
+    }
+    if (D->nsend_atoms > 0) HIPCHK(hipMemcpy(D->d_self_dst, dst.data(), dst.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(D->d_recv_self, rs.data(), rs.size(), hipMemcpyHostToDevice));
     double sh[3 * MAXSEG] = {0};
     for (int s = 0; s < 3 * nsend; s++) sh[s] = send_shift[s];
     HIPCHK(hipMemcpy(D->d_shift, sh, sizeof(sh), hipMemcpyHostToDevice));
@@ -218,62 +246,46 @@ extern "C" int imdgpu_dist_set_plan(imdgpu_ctx *ctx, int nsend, const int *send_
 // what: 0 = (x,y,z,dF) 4 doubles; 1 = dF; 2 = type (as double: one element width for every message); 3 = x,y,z
 static __host__ __device__ __forceinline__ int what_width(int what) { return what == 0 ? 4 : what == 3 ? 3 : 1; }
 
-__global__ void k_dist_gather(int what, long long n, const int *idx, const int *seg_of, const double *shift, const double4 *pos,
-                              const int *type, double *out)
+__global__ void k_dist_gather(int what, long long n, const int *idx, const int *seg_of, const int *self_dst, const double *shift,
+                              double4 *pos, int *type, double *out)
 {
   const long long m = (long long) blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= n) return;
-  const int i = idx[m];
-  if (what == 1) { out[m] = pos[i].w; return; }
-  if (what == 2) { out[m] = (double) type[i]; return; }
+  const int i = idx[m], g = self_dst[m];                // g >= 0: this atom is its own rank's ghost atom g (nothing to send)
+  if (what == 1) { if (g >= 0) pos[g].w = pos[i].w; else out[m] = pos[i].w; return; }
+  if (what == 2) { if (g >= 0) type[g] = type[i]; else out[m] = (double) type[i]; return; }
   const double *s = shift + 3 * seg_of[m];
   const double4 r = pos[i];
+  if (g >= 0) {
+    if (what == 0) pos[g] = make_double4(r.x + s[0], r.y + s[1], r.z + s[2], r.w);
+    else { pos[g].x = r.x + s[0]; pos[g].y = r.y + s[1]; pos[g].z = r.z + s[2]; }
+    return;
+  }
   if (what == 0) { double *o = out + 4 * m; o[0] = r.x + s[0]; o[1] = r.y + s[1]; o[2] = r.z + s[2]; o[3] = r.w; }
   else { double *o = out + 3 * m; o[0] = r.x + s[0]; o[1] = r.y + s[1]; o[2] = r.z + s[2]; }
 }
-// the receive buffer IS the ghost atoms in order: atom nlocal + m
-__global__ void k_dist_unpack(int what, long long n, int nlocal, const double *in, double4 *pos, int *type)
+// the receive buffer IS the ghost atoms in order: atom nlocal + m (those of self segments are already in place)
+__global__ void k_dist_unpack(int what, long long n, int nlocal, const unsigned char *recv_self, const double *in, double4 *pos, int *type)
 {
   const long long m = (long long) blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= n) return;
+  if (m >= n || recv_self[m]) return;
   const long long i = nlocal + m;
   if (what == 1) pos[i].w = in[m];
   else if (what == 2) type[i] = (int) in[m];
   else if (what == 0) { const double *q = in + 4 * m; pos[i] = make_double4(q[0], q[1], q[2], q[3]); }
   else { const double *q = in + 3 * m; pos[i].x = q[0]; pos[i].y = q[1]; pos[i].z = q[2]; }
 }
-__global__ void k_dist_segcopy(SegTab T, const double *src, double *dst)
-{
-  const int s = blockIdx.y;
-  if (s >= T.n) return;
-  const double *a = src + T.soff[s]; double *b = dst + T.doff[s];
-  for (long long q = (long long) blockIdx.x * blockDim.x + threadIdx.x; q < T.cnt[s]; q += (long long) gridDim.x * blockDim.x) b[q] = a[q];
-}
-
 // one exchange of `w` doubles per atom following the plan, on the context's stream
 static int dist_exchange(imdgpu_ctx *ctx, DistState *D, int w)
 {
-  SegTab self; self.n = 0;
   std::vector<long long> so, sc, ro, rc; std::vector<int> sp, rp;
-  {
-    std::vector<int> self_send;
-    for (int s = 0; s < D->nsend; s++) {
-      if (D->send_cnt[s] == 0) continue;
-      if (D->send_peer[s] == D->rank && !D->self_comm) self_send.push_back(s);
-      else { sp.push_back(D->send_peer[s]); so.push_back(D->send_off[s] * w); sc.push_back(D->send_cnt[s] * w); }
-    }
-    size_t k = 0;
-    for (int s = 0; s < D->nrecv; s++) {
-      if (D->recv_cnt[s] == 0) continue;
-      if (D->recv_peer[s] == D->rank && !D->self_comm) {
-        const int q = self_send[k++];
-        self.soff[self.n] = D->send_off[q] * w; self.doff[self.n] = D->recv_off[s] * w; self.cnt[self.n] = D->recv_cnt[s] * w; self.n++;
-      } else { rp.push_back(D->recv_peer[s]); ro.push_back(D->recv_off[s] * w); rc.push_back(D->recv_cnt[s] * w); }
-    }
+  for (int s = 0; s < D->nsend; s++) {
+    if (D->send_cnt[s] == 0 || (D->send_peer[s] == D->rank && !D->self_comm)) continue;      // self segments: done by the gather
+    sp.push_back(D->send_peer[s]); so.push_back(D->send_off[s] * w); sc.push_back(D->send_cnt[s] * w);
   }
-  if (self.n > 0) {
-    hipLaunchKernelGGL(k_dist_segcopy, dim3(64, self.n), dim3(256), 0, ctx->stream, self, D->sendbuf, D->recvbuf);
-    HIPCHK(hipGetLastError());
+  for (int s = 0; s < D->nrecv; s++) {
+    if (D->recv_cnt[s] == 0 || (D->recv_peer[s] == D->rank && !D->self_comm)) continue;
+    rp.push_back(D->recv_peer[s]); ro.push_back(D->recv_off[s] * w); rc.push_back(D->recv_cnt[s] * w);
   }
   if (sp.empty() && rp.empty()) return 0;
   if (D->comm) {
@@ -299,11 +311,11 @@ extern "C" int imdgpu_dist_halo(imdgpu_ctx *ctx, int what)
   ProfScope ps(ctx, PROF_GHOSTS);
   if (D->nsend_atoms > 0)
     hipLaunchKernelGGL(k_dist_gather, dim3(nblk(D->nsend_atoms, 256)), dim3(256), 0, ctx->stream, what, D->nsend_atoms, D->d_send_idx,
-                       D->d_seg_of, D->d_shift, ctx->pos, ctx->type, D->sendbuf);
+                       D->d_seg_of, D->d_self_dst, D->d_shift, ctx->pos, ctx->type, D->sendbuf);
   if (dist_exchange(ctx, D, w)) return 1;
-  if (D->nrecv_atoms > 0)
+  if (D->nrecv_atoms > D->nself_atoms)                    // something did arrive through the buffers
     hipLaunchKernelGGL(k_dist_unpack, dim3(nblk(D->nrecv_atoms, 256)), dim3(256), 0, ctx->stream, what, D->nrecv_atoms, ctx->nlocal,
-                       D->recvbuf, ctx->pos, ctx->type);
+                       D->d_recv_self, D->recvbuf, ctx->pos, ctx->type);
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -291,7 +291,13 @@ class DirectHaloPlan:
 
     def __init__(self, dec, ops):
         self.dec = dec
+        timing = os.environ.get("IMD_DIST_TIMING") == "1"
+        if timing:
+            import time
+            tm = [("start", time.perf_counter())]
         cs, cc = ops.cell_tables()
+        if timing:
+            tm.append(("cell_tables", time.perf_counter()))
         cs, cc = cs.astype(np.int64), cc.astype(np.int64)
         nlocal = ops.nlocal()
         D = dec.dim
@@ -330,15 +336,18 @@ class DirectHaloPlan:
         cc[ghost_cells] = 0
         self.segs = segs
         dev = ops.device
-        # per-cell counts travel first: one batch of point-to-point messages in direction order
-        sends = [torch.from_numpy(cc[g["send_cells"]].astype(np.int32)).to(dev) if g["to"] >= 0 else None for g in segs]
-        recvs = _exchange_direct(dec, segs, sends, [len(g["recv_cells"]) for g in segs], torch.int32, dev)
+        # per-cell counts travel first: one batch of point-to-point messages in direction order (host arrays in, host arrays
+        # out: segments to this rank itself never leave the host, the others share one device buffer each way)
+        sends = [cc[g["send_cells"]].astype(np.int32) if g["to"] >= 0 else None for g in segs]
+        recvs = _exchange_direct(dec, segs, sends, [len(g["recv_cells"]) for g in segs], dev)
+        if timing:
+            tm.append(("counts", time.perf_counter()))
         nghost = 0
         send_peer, send_cnt, send_shift, send_idx, recv_peer, recv_cnt = [], [], [], [], [], []
         for g, cnts in zip(segs, recvs):
             if g["frm"] < 0:
                 continue
-            cn = cnts.cpu().numpy().astype(np.int64)
+            cn = cnts.astype(np.int64)
             cells = g["recv_cells"]
             cc[cells] = cn
             cs[cells] = nlocal + nghost + np.concatenate([[0], np.cumsum(cn)[:-1]])
@@ -352,44 +361,64 @@ class DirectHaloPlan:
             idx = np.repeat(cs[cells] - np.concatenate([[0], np.cumsum(n)[:-1]]), n) + np.arange(int(n.sum()))
             send_peer.append(g["to"]); send_cnt.append(int(n.sum())); send_shift.append(g["shift"]); send_idx.append(idx)
         self.nghost = nghost
+        if timing:
+            tm.append(("index lists", time.perf_counter()))
         ops.set_ghost_layout(cs.astype(np.int32), cc.astype(np.int32), nghost)
+        if timing:
+            tm.append(("set_ghost_layout", time.perf_counter()))
         idx = np.concatenate(send_idx).astype(np.int32) if send_idx else np.zeros(0, np.int32)
         ops.dist_set_plan(send_peer, send_cnt, np.array(send_shift).reshape(-1, 3), torch.from_numpy(idx).to(dev),
                           recv_peer, recv_cnt)
+        if timing:
+            tm.append(("dist_set_plan", time.perf_counter()))
+            print("[dist plan] ms: " + ", ".join("%s %.2f" % (tm[q][0], 1e3 * (tm[q][1] - tm[q - 1][1])) for q in range(1, len(tm))), file=sys.stderr)
 
     def exchange(self, ops, what):
         ops.dist_halo(what)
 
 
-def _exchange_direct(dec, segs, sends, recv_len, dtype, dev):
-    """one batch of point-to-point messages in direction order (rebuild time: counts); self-peers short-circuit:
-    my k-th self-send is my k-th self-receive"""
+def _exchange_direct(dec, segs, sends, recv_len, dev):
+    """one batch of point-to-point int32 messages in direction order (rebuild time: the per-cell counts), numpy in and out.
+    Self-peers short-circuit on the host: my k-th self-send is my k-th self-receive.  Everything for other ranks is packed
+    into ONE buffer per direction of travel (one host-to-device copy, the P2P batch on slices of it, one copy back)."""
     me = dec.rank
     out = [None] * len(segs)
-    stage = _staged() and dev.type == "cuda"
-    tdev = torch.device("cpu") if stage else dev
-    ops, self_sends = [], []
+    stage = _staged() or dev.type != "cuda"
+    self_sends, remote_s, remote_r = [], [], []
     for g, b in zip(segs, sends):
         if g["to"] < 0:
             continue
         if g["to"] == me:
             self_sends.append(b)
-        elif b.numel() > 0:
-            ops.append(dist.P2POp(dist.isend, b.cpu() if stage else b, g["to"]))
+        elif b.size > 0:
+            remote_s.append((g["to"], b))
     k = 0
     for q, g in enumerate(segs):
         if g["frm"] < 0:
             continue
         if g["frm"] == me:
             out[q] = self_sends[k]; k += 1
-            continue
-        out[q] = torch.empty(recv_len[q], dtype=dtype, device=tdev)
-        if recv_len[q] > 0:
-            ops.append(dist.P2POp(dist.irecv, out[q], g["frm"]))
-    if ops:
-        for w in dist.batch_isend_irecv(ops):
+        elif recv_len[q] > 0:
+            remote_r.append((g["frm"], q))
+        else:
+            out[q] = np.zeros(0, np.int32)
+    if remote_s or remote_r:
+        tdev = torch.device("cpu") if stage else dev
+        sbuf = torch.from_numpy(np.concatenate([b for _, b in remote_s]) if remote_s else np.zeros(0, np.int32)).to(tdev)
+        rbuf = torch.empty(sum(recv_len[q] for _, q in remote_r), dtype=torch.int32, device=tdev)
+        p2p, o = [], 0
+        for peer, b in remote_s:
+            p2p.append(dist.P2POp(dist.isend, sbuf[o:o + b.size], peer)); o += b.size
+        o = 0
+        for peer, q in remote_r:
+            p2p.append(dist.P2POp(dist.irecv, rbuf[o:o + recv_len[q]], peer)); o += recv_len[q]
+        for w in dist.batch_isend_irecv(p2p):
             w.wait()
-    return [o.to(dev) if (o is not None and stage) else o for o in out]
+        host = rbuf.cpu().numpy()
+        o = 0
+        for peer, q in remote_r:
+            out[q] = host[o:o + recv_len[q]]; o += recv_len[q]
+    return out
 
 
 def attach_ttm_mailbox(ops, rank, world, nbr):
@@ -462,10 +491,24 @@ class DistributedMD:
 
     def rebuild(self):
         ops = self.ops
+        timing = os.environ.get("IMD_DIST_TIMING") == "1"      # experiment: where a rebuild's time goes (stderr)
+        if timing:
+            import sys, time
+            sync = getattr(ops, "synchronize", lambda: None)
+            sync(); t0 = time.perf_counter(); marks = []
+
+            def mark(name):
+                sync(); marks.append((name, time.perf_counter()))
+        else:
+            def mark(name):
+                pass
         if self.nrebuild > 0:
             self._migrate()
+        mark("migrate")
         ops.fix_cells()
+        mark("fix_cells")
         self.plan = DirectHaloPlan(self.dec, ops)
+        mark("plan")
         changed = 1 if ops.autotile() else 0             # first rebuild: tile shape chosen from the real occupancies
         if dist.is_initialized() and self.nrebuild == 0:   # building a plan is collective (counts travel): every rank must
             t = torch.tensor([changed], dtype=torch.int32, device=ops.device)    # agree -- a rank in vacuum never re-tiles
@@ -476,7 +519,15 @@ class DistributedMD:
         self.plan.exchange(ops, 0)
         if ops.ntypes > 1:
             self.plan.exchange(ops, 2)
+        mark("exchange")
         ops.make_nblist()
+        mark("make_nblist")
+        if timing:
+            prev = t0
+            out = []
+            for name, t in marks:
+                out.append("%s %.2f" % (name, 1e3 * (t - prev))); prev = t
+            print("[dist rebuild %d] ms: %s" % (self.nrebuild, ", ".join(out)), file=sys.stderr)
         self.valid = True
         self.nrebuild += 1
 
@@ -629,6 +680,9 @@ class GpuOps:
         self.stream = torch.cuda.Stream(self.device)
         torch.cuda.set_stream(self.stream)
         sysm.set_stream(self.stream.cuda_stream)
+
+    def synchronize(self):
+        self.s.synchronize()
 
     def _ck(self, rc):
         self.s._ck(rc)
