@@ -102,3 +102,18 @@ def test_many_blocks_hand_off_across_workgroups():
             assert np.array_equal(la[f][inn], lb[f][inn]), f
     assert np.array_equal(da["nummer"], db["nummer"])
     assert np.array_equal(da["ort"], db["ort"]) and np.array_equal(da["impuls"], db["impuls"])
+
+
+def test_config3_lattice_1000_blocks_all_resident():
+    """BASELINE config 3's own lattice (10 061 824 atoms, fd_ext 2 2 2: 39^3 FD cells = 1000 one-wave blocks, every one of
+    them resident beside the force pass): four MD + TTM steps with the persistent kernel and with the launch chain end in
+    the same lattice and the same atoms, bit for bit"""
+    la, da, ia = _big(0, nb=(136, 136, 136), nsteps=4)
+    lb, db, ib = _big(1, nb=(136, 136, 136), nsteps=4)
+    assert ia[0] == 0 and ib[0] >= 1 and ib[1] >= 2, (ia, ib)      # three launches: two on trial, the third may still be unread
+    assert ib[2] == (41, 41, 41)
+    inn = (slice(1, -1),) * 3
+    for f in FIELDS:
+        if f in la:
+            assert np.array_equal(la[f][inn], lb[f][inn]), f
+    assert np.array_equal(da["ort"], db["ort"]) and np.array_equal(da["impuls"], db["impuls"])
