@@ -117,3 +117,24 @@ def test_config3_lattice_1000_blocks_all_resident():
         if f in la:
             assert np.array_equal(la[f][inn], lb[f][inn]), f
     assert np.array_equal(da["ort"], db["ort"]) and np.array_equal(da["impuls"], db["impuls"])
+
+
+@pytest.mark.parametrize("case", ["ttm_2048", "ttm_slab"])
+def test_stand_alone_calc_ttm_with_the_same_bits(case):
+    """calc_ttm called by itself (not forked beside the force pass by md_step): the host-driven loop calc_forces / calc_ttm /
+    move_atoms_ttm ends in the same lattice and atoms with the persistent kernel as with the launch chain"""
+    res = []
+    for persist in (0, 1):
+        G = gu.load(case)
+        s = _gpu(G)
+        s.set_option("ttm_persist", persist)
+        for st in range(5):
+            s.calc_forces(st); s.calc_ttm(st); s.move_atoms_ttm()
+        res.append((s.ttm_download(), s.download(fields=("ort", "impuls")), s.get_info("ttm_persist_mode")))
+        s.close()
+    assert res[0][2] <= 0 and res[1][2] == 2
+    inn = (slice(1, -1),) * 3
+    for f in FIELDS:
+        if f in res[0][0]:
+            assert np.array_equal(res[0][0][f][inn], res[1][0][f][inn]), f
+    assert np.array_equal(res[0][1]["ort"], res[1][1]["ort"]) and np.array_equal(res[0][1]["impuls"], res[1][1]["impuls"])
