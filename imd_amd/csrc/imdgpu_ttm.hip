@@ -1033,8 +1033,11 @@ __device__ __forceinline__ void rec_store(unsigned long long *r, unsigned tag, d
   __hip_atomic_store(r + 1, t | (b & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <bool SRC>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_ttm_chain_persist(
+// WPE = waves per SIMD the register budget is cut for: 6 (80 VGPRs, 52 of them spilled to scratch) is what fits beside three
+// 144-register waves of the force pass -- the forked chain of an MD step; 4 (128 VGPRs, no spills: 0.76 instead of 0.83 ms)
+// is what a stand-alone calc_ttm runs, alone on the chip
+template <bool SRC, int WPE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_ttm_chain_persist(
     Lat L, double tau, int nsub, const int *natoms, double *T0, double *T1, double *U0, double *U1, double *K0, double *K1,
     double *Ce, double *fd_g, const double *md_temp, const double *source, const double *dens, double *xi, double *Zo,
     double *neo, EosDev cve, PersistDev P)
@@ -1880,12 +1883,13 @@ static int launch_persist(imdgpu_ctx *ctx, TtmState *t, const Lat &L, double tau
   HIPCHK(hipMemsetAsync(t->d_pstat, 0, 4 * sizeof(int), ctx->stream));
   double *T0 = t->temp[t->cur], *T1 = t->temp[t->cur ^ 1], *U0 = t->U[t->cur], *U1 = t->U[t->cur ^ 1];
   double *K0 = t->fd_k[t->kcur], *K1 = t->fd_k[t->kcur ^ 1];
-  if (t->have_source)
-    hipLaunchKernelGGL((k_ttm_chain_persist<true>), dim3(t->persist_tiles), dim3(64), 0, ctx->stream, L, tau, t->nsub, t->natoms, T0, T1,
-                       U0, U1, K0, K1, t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve, P);
-  else
-    hipLaunchKernelGGL((k_ttm_chain_persist<false>), dim3(t->persist_tiles), dim3(64), 0, ctx->stream, L, tau, t->nsub, t->natoms, T0, T1,
-                       U0, U1, K0, K1, t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve, P);
+  const bool alone = ctx->stream != ctx->stream2;         // not forked beside the force pass: a stand-alone calc_ttm
+#define PERSIST_LAUNCH(S, W)                                                                                                     \
+  hipLaunchKernelGGL((k_ttm_chain_persist<S, W>), dim3(t->persist_tiles), dim3(64), 0, ctx->stream, L, tau, t->nsub, t->natoms, T0, T1, \
+                     U0, U1, K0, K1, t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve, P)
+  if (t->have_source) { if (alone) PERSIST_LAUNCH(true, 4); else PERSIST_LAUNCH(true, 6); }
+  else { if (alone) PERSIST_LAUNCH(false, 4); else PERSIST_LAUNCH(false, 6); }
+#undef PERSIST_LAUNCH
   HIPCHK(hipGetLastError());
   if (!t->pstat_pending) {                               // feedback for persist_mode; never waited for
     HIPCHK(hipMemcpyAsync(t->h_pstat, t->d_pstat, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
