@@ -36,6 +36,9 @@ def parse():
     ap.add_argument("--no-ttm", action="store_true")
     ap.add_argument("--fd-ext", type=int, nargs=3, default=[2, 2, 2],
                     help="MD cells per FD cell (BASELINE config 3: 2 2 2); 1 1 1 gives the 8x lattice an 8-GPU run replicates")
+    ap.add_argument("--no-adv", action="store_true",
+                    help="leave do_ADV out of calc_ttm (the reference compiles ADVMODE 1 and calls do_ADV(1.0) in every step,\n"
+                         "imd_ttm_3D.c:17,58-60: on by default here as well)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="experiment: no HIP events around the kernel classes in the timed region (roofline then reports 0)")
@@ -48,9 +51,12 @@ def parse():
     ap.add_argument("--cpu-box", type=int, default=48, help="unit cells per direction of the CPU sample")
     ap.add_argument("--cpu-steps", type=int, default=30)
     ap.add_argument("--cpu-steps-mpi", type=int, default=40, help="steps of the multi-core (MPI + TTM) reference sample")
-    ap.add_argument("--cpu-box-mpi", type=int, default=100, help="unit cells per direction of that sample (100: 4 000 000 atoms,\n"
-                    "250 000 per rank at 16 ranks -- sub-boxes of 25 x 50 x 50 unit cells, comparable with config 3's)")
-    ap.add_argument("--cpu-ranks", type=int, default=16, help="MPI ranks of the CPU sample = host cores used (a one-GPU box grants 16)")
+    ap.add_argument("--cpu-cells-per-rank", type=int, default=40, help="FCC unit cells per direction PER RANK of the MPI samples\n"
+                    "(40: 256 000 atoms per rank -- sub-boxes comparable with config 3's 250 000 per core at 40 cores)")
+    ap.add_argument("--cpu-ranks", type=int, default=16, help="MPI ranks of the 16-core CPU sample (the host-core share of a one-GPU job)")
+    ap.add_argument("--cpu-ranks-all", type=int, default=0,
+                    help="MPI ranks of the all-core CPU sample (0 = every core the affinity mask and the cgroup quota grant)")
+    ap.add_argument("--cpu-all-timeout", type=float, default=240.0, help="give the all-core CPU sample up after this many seconds")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal: host-staged halos)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks on cuda:0")
     ap.add_argument("--ttm-decomposed", action="store_true",
@@ -113,6 +119,8 @@ def build_system(args, rank, world, device):
                      external_halo=args.force_distributed,
                      ttm_decomposed=ttm and (world > 1 or args.force_distributed) and args.ttm_decomposed)
     sysm.upload_tables(pair, rho, emb)
+    if ttm and adv_on(args):
+        sysm.set_option("ttm_adv", 1)            # calc_ttm's own sequence: update_fd, do_ADV(1.0), activation, ... (:57-60)
     if ttm:
         from imd_amd import ttm as ttm_mod
         ttm_mod.attach_default(sysm, fd_ext=fd_ext, diff_substeps=100, fd_min_atoms=5)
@@ -135,6 +143,12 @@ def build_system(args, rank, world, device):
         dec = Decomposition(rank, cpu_dim, gdim, box, pbc)
         md = DistributedMD(dec, GpuOps(sysm, device), ttm=ttm)
     return sysm, md, len(pos), gdim, cpu_dim
+
+
+def adv_on(args):
+    """do_ADV belongs to the reference's calc_ttm (ADVMODE 1); not with the one-row lattice of the Maxwell-solver slab, whose
+    FD cells span thousands of MD cells (no flux counters there)"""
+    return not args.no_ttm and not args.no_adv and args.laser != "fdtd"
 
 
 def _cpu_env():
@@ -161,23 +175,53 @@ def _find_mpiexec():
     return None
 
 
-def cpu_baseline_mpi_ttm(args):
+def _cpu_quota():
+    """cores a cgroup CPU quota leaves to this job, or None (cgroup v2 cpu.max, v1 cfs_quota_us)"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return max(1, int(float(q) / float(per)))
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return max(1, q // per)
+    except Exception:
+        pass
+    return None
+
+
+def _rank_grid(n):
+    """cpu_dim for n MPI ranks: powers of two split as evenly as possible, x first (x >= 2 so that do_ADV's exchange with the
+    x neighbour exists: with cpu_dim.x = 1 the reference's do_COMMFLUX cannot run)"""
+    n = max(1, int(n))
+    p = 1
+    while p * 2 <= n:
+        p *= 2
+    d = [1, 1, 1]
+    k = 0
+    while p > 1:
+        d[k % 3] *= 2; p //= 2; k += 1
+    return tuple(d)
+
+
+def cpu_baseline_mpi_ttm(args, nranks_want, per_rank_cells, steps, timeout):
     """The workload of the GPU number on the host cores: the reference's own MPI build with the 3D TTM
-    (oracle/_ref/imd_mpi_eam_ttm3d_nbl: EAM forces through imd_forces_nbl.c, calc_ttm's first block with 100
-    sub-steps, move_atoms_ttm, list maintenance, halo exchange), one rank per core, on a bounded sample."""
+    (oracle/_ref/imd_mpi_eam_ttm3d_nbl: EAM forces through imd_forces_nbl.c, calc_ttm's first block -- update_fd, do_ADV,
+    activation, FILLMESH, 100 x (do_DIFF, FILLMESH, ghosts), CFL --, move_atoms_ttm, list maintenance, halo exchange), one
+    rank per core, on a bounded sample of per_rank_cells^3 FCC unit cells per rank (sub-boxes like config 3's)."""
     from imd_amd import potential, ttm as ttm_mod
     exe = os.path.join(ROOT, "oracle", "_ref", "imd_mpi_eam_ttm3d_nbl")
     mpiexec = _find_mpiexec()
     if args.no_ttm or not os.path.exists(exe) or mpiexec is None:
         return None
-    avail = _host_cores()                       # what the affinity mask shows (the whole host on the GPU box)
-    # ranks actually started: the share of host cores a one-GPU job gets (16), never more than the mask shows
-    want = max(1, min(args.cpu_ranks, avail))
-    cpu_dim = (4, 2, 2) if want >= 16 else (2, 2, 2) if want >= 8 else (2, 2, 1) if want >= 4 else (2, 1, 1) if want >= 2 else (1, 1, 1)
+    cpu_dim = _rank_grid(nranks_want)
     nranks = cpu_dim[0] * cpu_dim[1] * cpu_dim[2]
-    cores = avail
-    nb, steps = args.cpu_box_mpi, args.cpu_steps_mpi
-    natoms = 4 * nb ** 3
+    nb = [per_rank_cells * c for c in cpu_dim]
+    natoms = 4 * nb[0] * nb[1] * nb[2]
+    adv = adv_on(args) and cpu_dim[0] >= 2
     with tempfile.TemporaryDirectory() as d:
         potential.write_synthetic_eam_files(d)
         cve, ee = ttm_mod.synthetic_eos()
@@ -190,13 +234,19 @@ def cpu_baseline_mpi_ttm(args):
             "eng_int 100000\ncheckpt_int 100000\nnbl_margin 0.5\nnbl_size 1.5\ncpu_dim %d %d %d\n"
             "fd_ext %d %d %d\nfd_n_timesteps 100\nfd_min_atoms 5\natomic_weight 26.9815\natomic_charge 13\n"
             "ttm_int 100000\nI0 1.0\nlambda 800e-9\nlaser_sigma_t 100e-15\nlaser_t_0 1.0\n"
-            % ((steps, nb, nb, nb, args.temp) + cpu_dim + tuple(args.fd_ext)))
+            % ((steps, nb[0], nb[1], nb[2], args.temp) + cpu_dim + tuple(args.fd_ext)))
         env = _cpu_env()
+        if adv:
+            env["IMD_PROBE_ADV"] = "1"           # the probe-driven calc_ttm then calls the reference's do_ADV(1.0) (ref_probe_ttm.c)
         t0 = time.time()
         try:
             r = subprocess.run([mpiexec, "-n", str(nranks), exe, "-p", "b.param"], cwd=d, env=env, stdout=subprocess.PIPE,
-                               stderr=subprocess.STDOUT, text=True, timeout=400)
-        except (subprocess.TimeoutExpired, OSError):
+                               stderr=subprocess.STDOUT, text=True, timeout=timeout)
+        except subprocess.TimeoutExpired:
+            return {"value": None, "unit": "atom-steps/s", "cores": nranks, "cores_used": nranks, "kind": "reference",
+                    "sample": "reference binary imd_mpi_eam_ttm3d_nbl on %d ranks, %d atoms x %d steps: gave up after %.0f s"
+                              % (nranks, natoms, steps + 1, timeout)}
+        except OSError:
             return None
         wall = time.time() - t0
     if r.returncode != 0:
@@ -208,22 +258,43 @@ def cpu_baseline_mpi_ttm(args):
     if not secs:
         return None
     return {"value": natoms * (steps + 1) / secs, "unit": "atom-steps/s", "cores": nranks, "cores_used": nranks,
-            "cores_available": cores, "kind": "reference",
-            "sample": "reference binary imd_mpi_eam_ttm3d_nbl (gcc -O2, MPI, cpu_dim %d %d %d = %d ranks on %d host cores), %d atoms "
-                      "x %d steps, EAM + 3D TTM (fd_ext %d %d %d, 100 sub-steps, no laser, calc_ttm's first block), main loop "
-                      "incl. list rebuilds, %.1f s wall" % (cpu_dim + (nranks, cores, natoms, steps + 1) + tuple(args.fd_ext) + (wall,))}
+            "kind": "reference",
+            "sample": "reference binary imd_mpi_eam_ttm3d_nbl (gcc -O2, MPI, cpu_dim %d %d %d = %d ranks), %d atoms (%d per rank) "
+                      "x %d steps, EAM + 3D TTM (fd_ext %d %d %d, 100 sub-steps, do_ADV %s, no laser, calc_ttm's first block), main "
+                      "loop incl. list rebuilds, %.1f s main loop, %.1f s wall"
+                      % (cpu_dim + (nranks, natoms, natoms // nranks, steps + 1) + tuple(args.fd_ext) + ("on" if adv else "off", secs, wall))}
 
 
 def cpu_baseline(args):
-    """Primary: the reference's MPI + TTM build on all host cores (cpu_baseline_mpi_ttm).  Also timed, and the
-    fallback: the serial NVE reference binary on one core (`serial`)."""
+    """Primary: the reference's MPI + TTM build on EVERY core this job may use (affinity mask, capped by a cgroup CPU quota
+    if there is one) -- BASELINE.md's "all physical host cores".  Beside it: the same build on 16 ranks (the host-core share
+    of a one-GPU job) and the serial NVE reference binary on one core; they are also the fallbacks, in that order."""
     ser = cpu_baseline_serial(args)
-    par = cpu_baseline_mpi_ttm(args)
+    avail, quota = _host_cores(), _cpu_quota()
+    grant = min(avail, quota) if quota else avail
+    r16 = cpu_baseline_mpi_ttm(args, min(args.cpu_ranks, grant), args.cpu_cells_per_rank, args.cpu_steps_mpi, 400)
+    want_all = args.cpu_ranks_all if args.cpu_ranks_all > 0 else grant
+    rall = None
+    if r16 is not None and r16.get("value") and _rank_grid(want_all) != _rank_grid(min(args.cpu_ranks, grant)):
+        # 40^3 unit cells = 256 000 atoms per rank; steps so that the main loop is ~10-20 s at the 16-rank per-core rate
+        per_core = r16["value"] / r16["cores_used"]
+        n_all = int(np.prod(_rank_grid(want_all)))
+        steps = int(min(40, max(8, 15.0 * per_core / 256000.0)))
+        rall = cpu_baseline_mpi_ttm(args, n_all, args.cpu_cells_per_rank, steps, args.cpu_all_timeout)
+    par = rall if (rall is not None and rall.get("value")) else r16
     if par is None:
         return ser
+    par = dict(par)
+    par["cores_available"] = avail
+    par["cores_cgroup_quota"] = quota
+    if r16 is not None:
+        par["ranks16"] = {k: r16[k] for k in ("value", "unit", "cores", "kind", "sample")}
+    if rall is not None and not rall.get("value"):
+        par["all_cores_attempt"] = rall["sample"]
     par["serial"] = {k: ser[k] for k in ("value", "unit", "cores", "kind", "sample")}
-    par["note"] = ("cores = cores_used = MPI ranks started (the host-core share of a one-GPU job); cores_available = what the "
-                   "affinity mask of the box shows; the GPU/CPU ratio is against cores_used cores, not against the whole host")
+    par["note"] = ("cores = cores_used = MPI ranks started: every core the affinity mask (cores_available) and the cgroup quota "
+                   "(cores_cgroup_quota, null = none) grant, rounded down to a power of two; ranks16 = the same build on the "
+                   "host-core share of a one-GPU job; serial = the NVE binary on one core")
     return par
 
 
@@ -378,15 +449,35 @@ def main():
                                              "reduce", "ttm_update_fd", "ttm_diff", "ttm_fillmesh")}
     sysm.profile(False)
     if rank == 0:
-        # dominant kernel: pass 1 (pair + rho).  Algorithmic bytes per atom = 72 + 4M; when the embedding
-        # pass is folded into the same launch its 32 B/atom (rho 8 + dF 8 + pot_eng RMW 16) belong to that launch too
-        n1, ms1 = prof["pass1"]
+        # The two force passes share the top of the profile; `roofline` prices whichever of them took longer in THIS run
+        # (the dominant kernel) and `roofline_other` the second.  Algorithmic bytes per atom: pass 1 = 72 + 4M,
+        # plus pass 2's 32 (rho 8 + dF 8 + pot_eng RMW 16) when the embedding pass is folded into the same launch;
+        # pass 3 = 84 + 4M.  Durations: HIP events on the library's stream around every launch of the timed region.
         fused = bool(sysm.get_info("fused_embedding"))
-        bytes_p1 = natoms * (72.0 + 4.0 * M + (32.0 if fused else 0.0))
-        ach = bytes_p1 / (ms1 / max(n1, 1) * 1e-3) / 1e9 if n1 else 0.0
         ttmn = "true" if not args.no_ttm else "false"
-        kname = ("k_pass1_tile_merged<%s, %s>" % (ttmn, "true" if fused else "false")) if sysm.get_info("list_mode") == 1 else "k_pass1"
-        traffic, traffic_src = measured_traffic(kname, natoms, sysm.get_info("kernel_rev"))
+        tiles = sysm.get_info("list_mode") == 1
+        krev = sysm.get_info("kernel_rev")
+
+        def price(which):
+            n, ms = prof[which]
+            if which == "pass1":
+                byts = natoms * (72.0 + 4.0 * M + (32.0 if fused else 0.0))
+                kn = ("k_pass1_tile_merged<%s, %s>" % (ttmn, "true" if fused else "false")) if tiles else "k_pass1"
+                label = kn + (" (pass 1: pair + rho, embedding pass folded in)" if fused else " (pass 1: pair + rho)")
+            else:
+                byts = natoms * (84.0 + 4.0 * M)
+                kn = ("k_pass3_tile<true, %d>" % sysm.get_info("pass3_ring")) if tiles else "k_pass3"     # one atom type here
+                label = kn + " (pass 3: EAM force pass)"
+            avg = ms / max(n, 1)
+            a = byts / (avg * 1e-3) / 1e9 if n else 0.0
+            tr, src = measured_traffic(kn, natoms, krev)
+            return {"bound": "hbm", "kernel": label, "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
+                    "traffic": tr, "traffic_source": src, "algorithmic_bytes_per_launch": byts, "avg_launch_ms": avg,
+                    "launches": n, "kernel_rev": krev}
+        r1, r3 = price("pass1"), price("pass3")
+        dom, other = (r3, r1) if prof["pass3"][1] >= prof["pass1"][1] else (r1, r3)
+        n_nbl, ms_nbl = prof["nblist"]
+        n_fix, ms_fix = prof["fix_cells"]
         out = {
             "metric": "MD-steps/sec (and atom-steps/sec) for 10M-atom EAM-Al+TTM at 1/2/4/8 GPU",
             "value": args.steps / dt, "unit": "MD-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -396,7 +487,8 @@ def main():
             "config": {"workload": "FCC Al %dx%dx%d unit cells per GPU (%d atoms/GPU), synthetic tabulated EAM "
                                    "(r_c 6.5 A), nbl_margin 0.5, dt 0.1, T0 %.4f eV, %s" %
                                    (args.box[0], args.box[1], args.box[2], natoms, args.temp,
-                                    "NVE, no TTM" if args.no_ttm else ("3D TTM fd_ext %s, diff_substeps 100" % (" ".join(str(v) for v in sysm.fd_ext))) +
+                                    "NVE, no TTM" if args.no_ttm else ("3D TTM fd_ext %s, diff_substeps 100, calc_ttm = update_fd, do_ADV %s, activation, FILLMESH, "
+                                                                       "100 x (do_DIFF, FILLMESH, ghosts)" % (" ".join(str(v) for v in sysm.fd_ext), "on" if adv_on(args) else "off")) +
                                     (", slab: open x with vacuum on both sides" if args.slab else "") +
                                     (", Beer-Lambert laser source (laser_rescale_ttm)" if args.laser == "beer" else
                                      ", 1D Maxwell solver as laser source (do_fdtd; slab, open x, one row of FD cells)" if args.laser == "fdtd" else "")),
@@ -408,11 +500,10 @@ def main():
                                                                    "tile_threads", "lds_pass1", "lds_pass3", "W")},
                        "parallelism": ("%dx%dx%d ranks, 1 rank/GPU, direct 26-neighbour ghost-cell halo, native step (%s)"
                                        % (tuple(cpu_dim) + (md.ops.transport,))) if md is not None else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": kname + (" (pass 1: pair + rho, embedding pass folded in)" if fused else " (pass 1: pair + rho)"), "achieved": ach, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": bytes_p1, "avg_launch_ms": ms1 / max(n1, 1),
-                         "kernel_rev": sysm.get_info("kernel_rev")},
+            "roofline": dom, "roofline_other": other,
             "kernel_ms_per_step": {k: v[1] / args.steps for k, v in prof.items() if v[0]},
+            "rebuild_ms": {"rebuilds": rebuilds, "make_nblist_ms_each": ms_nbl / max(n_nbl, 1), "fix_cells_ms_each": ms_fix / max(n_fix, 1),
+                           "amortised_ms_per_step": (ms_nbl + ms_fix) / args.steps},
             "energy": {"epot_per_atom": sums["tot_pot_energy"] / natoms, "ekin_per_atom": sums["tot_kin_energy"] / natoms},
         }
         if not args.no_cpu_baseline and world == 1:

@@ -1570,7 +1570,7 @@ extern "C" int imdgpu_get_info(imdgpu_ctx *ctx, const char *name, long long *val
     {"fused_embedding", fuse_emb(ctx) ? 1 : 0}, {"ttm_flux", ctx->ttm_flux}, {"ttm_adv", ctx->ttm_adv}, {"ttm_block_width", ctx->ttm_flux ? 10 : 6},
     // bumped whenever a force / list kernel or its data layout changes: committed PMC traffic figures carry the revision
     // they were measured on (profiles/*hbm_traffic*.json "_kernel_rev"), bench.py refuses figures of another revision
-    {"kernel_rev", IMDGPU_KERNEL_REV},
+    {"kernel_rev", IMDGPU_KERNEL_REV}, {"pass3_ring", ctx->ttm ? 0 : 4},
     {"ttm_persist_mode", imdgpu_ttm_persist_info(ctx, 0)}, {"ttm_persist_runs", imdgpu_ttm_persist_info(ctx, 1)}};
   for (auto &e : tab) if (!strcmp(name, e.n)) { *value = e.v; return 0; }
   return imdgpu_fail(ctx, "unknown info %s", name);

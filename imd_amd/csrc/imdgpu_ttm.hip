@@ -1108,6 +1108,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     xc[d] = cp ? nc[2 * d] : (cm ? nc[2 * d + 1] : -1);
     if (cp || cm) xany |= 1u << d;
   }
+  // an inactive cell of a partly active block computes nothing and is a mirror for its neighbours, which therefore
+  // publish no record on its account: it must not wait for any (rough surfaces, voids, craters across a block face)
+  if (!active) xany = 0;
   // ---- the sub-step loop -------------------------------------------------------------------------------------------
   double Te = 0, kk = 0, ce = 1, g = 0, Tl = 1, dn = 1, src = 0, u = 0, x = 0;
   if (active) {

@@ -64,8 +64,10 @@ def test_option_switches_the_kernel_off_and_on_again():
     s.close()
 
 
-def _big(persist, nb=(64, 64, 40), nsteps=6):
-    """1 M-atom-scale box, fd_ext 2 2 2: an 18 x 18 x 11 lattice = 5 x 5 x 3 blocks handing off across workgroups"""
+def _big(persist, nb=(64, 64, 40), nsteps=6, voids=False):
+    """1 M-atom-scale box, fd_ext 2 2 2: an 18 x 18 x 11 lattice = 5 x 5 x 3 blocks handing off across workgroups.
+    voids: empty a scattered set of FD cells (and a rough surface layer) so that inactive cells sit next to active ones
+    across block faces inside partly active blocks"""
     from imd_amd import lattice, potential, ttm as ttm_mod
     from imd_amd.system import GpuSystem, global_cell_dim
     box = lattice.fcc_box(nb)
@@ -76,6 +78,13 @@ def _big(persist, nb=(64, 64, 40), nsteps=6):
     pair, rho, emb, r2cut = potential.synthetic_eam_tables()
     cellsz = (np.sqrt(r2cut) + 0.5) ** 2
     dim = [g + 2 for g in global_cell_dim(box, cellsz, (2, 2, 2))]
+    if voids:
+        nfd = np.array([(d - 2) // 2 for d in dim])
+        fc = np.minimum((pos / (np.diag(box) / nfd)).astype(int), nfd - 1)
+        h = (fc[:, 0] * 7 + fc[:, 1] * 3 + fc[:, 2] * 5) % 11
+        rough = (fc[:, 0] >= 10 + (fc[:, 1] * 5 + fc[:, 2] * 3) % 4)          # a ragged surface between x cells 10 and 13
+        keep = ~((h == 0) | rough)
+        pos, mom = pos[keep], mom[keep]
     g = GpuSystem(box, (1, 1, 1), dim, 1, cellsz, 0.5, 0.1, count_ttm_neighbours=True)
     g.upload_tables(pair, rho, emb)
     g.upload_atoms(pos, mom, 26.9815)
@@ -101,6 +110,25 @@ def test_many_blocks_hand_off_across_workgroups():
             assert np.isfinite(la[f][inn]).all()
             assert np.array_equal(la[f][inn], lb[f][inn]), f
     assert np.array_equal(da["nummer"], db["nummer"])
+    assert np.array_equal(da["ort"], db["ort"]) and np.array_equal(da["impuls"], db["impuls"])
+
+
+def test_rough_interfaces_inside_partly_active_blocks():
+    """inactive FD cells next to active ones across the faces of 4x4x4 blocks -- scattered voids and a
+    ragged surface.  An inactive lane must not wait for records nobody publishes on its account: the persistent kernel
+    runs (no time-out, mode 'trusted') and equals the launch chain bit for bit."""
+    la, da, ia = _big(0, voids=True)
+    lb, db, ib = _big(1, voids=True)
+    assert ia[0] == 0 and ib[0] == 2 and ib[1] >= 3, (ia, ib)
+    inn = (slice(1, -1),) * 3
+    nat = la["natoms"][inn]
+    act = nat >= 5
+    assert (~act).sum() > 200 and act.sum() > 1000
+    # the pattern really puts inactive cells beside active ones across block faces (x index 3|4 of a block boundary)
+    assert (act[3::4][: act[4::4].shape[0]] != act[4::4]).any()
+    for f in FIELDS:
+        if f in la:
+            assert np.array_equal(la[f][inn], lb[f][inn]), f
     assert np.array_equal(da["ort"], db["ort"]) and np.array_equal(da["impuls"], db["impuls"])
 
 
