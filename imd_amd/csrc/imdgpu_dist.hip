@@ -24,7 +24,12 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <vector>
 
 static inline int nblk(long long n, int b) { return n <= 0 ? 1 : (int) ((n + b - 1) / b); }
@@ -91,9 +96,11 @@ struct DistState {
 
 static DistState *DS(imdgpu_ctx *ctx) { return (DistState *) ctx->dist; }
 
+void imdgpu_dist_plan_free(imdgpu_ctx *ctx);
 void imdgpu_dist_free(imdgpu_ctx *ctx)
 {
   DistState *D = DS(ctx);
+  imdgpu_dist_plan_free(ctx);
   if (!D) return;
   if (D->comm && g_rccl.CommDestroy) (void) g_rccl.CommDestroy(D->comm);
   if (D->comm2 && g_rccl.CommDestroy) (void) g_rccl.CommDestroy(D->comm2);
@@ -321,14 +328,15 @@ extern "C" int imdgpu_dist_halo(imdgpu_ctx *ctx, int what)
 }
 
 // MAX over the ranks of this rank's list-validity flag (check_nblist's MPI_Allreduce, imd_forces_nbl.c:1087) -> d_flag[0]
-__global__ void k_dist_flag_in(const int *counters, int *flag) { flag[0] = counters[CNT_INVALID]; }
+// flag[1]: a time-out of the lattice's hand-offs (persistent sub-step kernel, mailbox) on ANY rank fails the step everywhere
+__global__ void k_dist_flag_in(const int *counters, int *flag) { flag[0] = counters[CNT_INVALID]; flag[1] = counters[CNT_TTM_TIMEOUT]; }
 static int dist_flag_allreduce(imdgpu_ctx *ctx, DistState *D)
 {
   hipLaunchKernelGGL(k_dist_flag_in, dim3(1), dim3(1), 0, ctx->stream, ctx->d_counters, D->d_flag);
   if (D->nranks == 1 && !D->self_comm) return 0;
-  if (D->comm) { NCCLCHK(g_rccl.AllReduce(D->d_flag, D->d_flag, 1, ncclInt, ncclMax, D->comm, ctx->stream)); return 0; }
+  if (D->comm) { NCCLCHK(g_rccl.AllReduce(D->d_flag, D->d_flag, 2, ncclInt, ncclMax, D->comm, ctx->stream)); return 0; }
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  if (D->cb(D->cb_user, 1, D->d_flag, D->d_flag, 1, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 4))
+  if (D->cb(D->cb_user, 1, D->d_flag, D->d_flag, 2, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 4))
     return imdgpu_fail(ctx, "dist: the host transport failed (all-reduce)");
   return 0;
 }
@@ -402,9 +410,13 @@ extern "C" int imdgpu_dist_md_step(imdgpu_ctx *ctx, int steps, int *rebuild_need
     if (imdgpu_launch_forces_phase(ctx, 1)) return 1;
   }
   D->spec_pass1 = false; D->halo_ready = false;
-  if (ctx->ttm && dist_ttm_chain(ctx, D, steps)) return 1;
   if (imdgpu_launch_forces_phase(ctx, 2)) return 1;
   if (ctx->rho.present && imdgpu_dist_halo(ctx, 1)) return 1;          // dF of the ghost atoms  [send_cells(copy_dF), :786]
+  // The lattice chain is forked AFTER the dF halo: its all-gather (second communicator, lattice stream) then follows the
+  // halo group in device order on EVERY rank, so the two communicators can never wait for each other crosswise, whatever
+  // the CUs admit side by side (the embedding pass is folded into pass 1, so nothing of substance sits between pass 1
+  // and this point; the EAM force pass below waits for the gather anyway).
+  if (ctx->ttm && dist_ttm_chain(ctx, D, steps)) return 1;
   if (ctx->ttm && !ctx->ttm_decomposed) HIPCHK(hipStreamWaitEvent(ctx->stream, D->ev_gathered, 0));
   if (imdgpu_launch_forces_phase(ctx, 3)) return 1;
   if (ctx->ttm) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
@@ -413,7 +425,7 @@ extern "C" int imdgpu_dist_md_step(imdgpu_ctx *ctx, int steps, int *rebuild_need
   // device has work while the host reads the flag
   if (imdgpu_dist_halo(ctx, 3)) return 1;
   if (dist_flag_allreduce(ctx, D)) return 1;
-  HIPCHK(hipMemcpyAsync(D->h_flag, D->d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(D->h_flag, D->d_flag, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipEventRecord(D->ev_flag, ctx->stream));
   const bool spec = !getenv("IMDGPU_NO_SPECULATION");
   if (spec) {
@@ -423,6 +435,8 @@ extern "C" int imdgpu_dist_md_step(imdgpu_ctx *ctx, int steps, int *rebuild_need
     if (rc) return 1;
   }
   HIPCHK(hipEventSynchronize(D->ev_flag));
+  if (D->h_flag[1])                 // like imdgpu_md_step: the lattice of this step was not (or only half) advanced on some rank
+    return imdgpu_fail(ctx, "TTM: a hand-off between lattice blocks timed out on some rank (persistent sub-step kernel or mailbox): the lattice of this step is not valid");
   const int invalid = D->h_flag[0];
   if (invalid) {
     ctx->have_valid_nbl = 0; ctx->need_fix_cells = 1; D->have_plan = false;
@@ -460,4 +474,589 @@ extern "C" int imdgpu_dist_allreduce_sum(imdgpu_ctx *ctx, double *vals, int n)
   else if (D->cb(D->cb_user, 3, d, d, n, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 8)) return imdgpu_fail(ctx, "dist: the host transport failed (sum)");
   HIPCHK(hipMemcpy(vals, d, n * sizeof(double), hipMemcpyDeviceToHost));
   return 0;
+}
+
+// =====================================================================================================================
+// The REBUILD, native as well: what fix_cells -> send_atoms (imd_fix_cells_3d.c:43-306,436-542; records of
+// imd_mpi_util.c:349-650) and setup_buffers / the first send_cells of a new list (imd_comm_force_3d.c:222-396,
+// imd_mpi_util.c:850-1059) do in the reference, for the direct 26-neighbour halo of this file.  A C host needs nothing
+// but imdgpu_dist_step(): migration along x, y, z, re-binning, per-cell counts to the 26 peers, ghost layout, send index
+// lists (built on the device), tile choice, first halo, neighbour list -- then steps until some rank's list goes stale.
+// Every exchange goes through the transport of the step (RCCL / host callback / the in-process transport below).
+// =====================================================================================================================
+struct PlanSeg {                 // one of the 26 directions; static for a geometry
+  int d[3];
+  int to = -1, frm = -1;         // rank this direction's boundary layer goes to / rank whose layer fills my ghost region
+  double shift[3] = {0, 0, 0};   // periodic image shift, added by the SENDER (imd_comm_force_3d.c:247-266)
+  int nsc = 0, nrc = 0;          // cells of the send layer S(d) / of the ghost region R(-d)
+  int soff = 0, roff = 0;        // their offsets in the concatenated cell lists (valid when to >= 0 / frm >= 0)
+};
+struct PlanState {
+  bool ready = false;
+  int dim[3] = {0, 0, 0};
+  PlanSeg seg[26];
+  int nsc = 0, nrc = 0;                                  // send cells over all segments with to >= 0; recv cells likewise
+  int *d_send_cells = nullptr, *d_recv_cells = nullptr;  // linear cell indices, segment after segment
+  int *d_cnt_send = nullptr, *d_cnt_recv = nullptr;      // atoms per listed cell
+  int *h_cnt_send = nullptr, *h_cnt_recv = nullptr;      // pinned mirrors
+  int *h_aux = nullptr, *d_aux = nullptr;                // per send cell: off, dst, seg; per recv cell: start   (3 nsc + nrc ints)
+  int lo[3] = {-1, -1, -1}, hi[3] = {-1, -1, -1};        // migration neighbours (imd_geom_mpi_3d.c:32-90)
+  double *mig_send = nullptr, *mig_recv = nullptr; size_t mig_send_cap = 0, mig_recv_cap = 0;
+  int *d_mig_cnt = nullptr;                              // 4 ints: n_lo, n_hi out; from_hi, from_lo in
+  int nrebuild = 0;
+  double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int timing = 0;
+};
+static std::map<imdgpu_ctx *, PlanState *> g_plans;      // one per context; guarded by g_plans_mu (contexts may live on several threads)
+static std::mutex g_plans_mu;
+static PlanState *PS(imdgpu_ctx *ctx)
+{
+  std::lock_guard<std::mutex> lk(g_plans_mu);
+  auto it = g_plans.find(ctx);
+  if (it != g_plans.end()) return it->second;
+  PlanState *p = new PlanState();
+  p->timing = getenv("IMD_DIST_TIMING") != nullptr;
+  g_plans[ctx] = p;
+  return p;
+}
+void imdgpu_dist_plan_free(imdgpu_ctx *ctx)
+{
+  PlanState *p = nullptr;
+  { std::lock_guard<std::mutex> lk(g_plans_mu); auto it = g_plans.find(ctx); if (it == g_plans.end()) return; p = it->second; g_plans.erase(it); }
+  void *ptrs[] = {p->d_send_cells, p->d_recv_cells, p->d_cnt_send, p->d_cnt_recv, p->d_aux, p->mig_send, p->mig_recv, p->d_mig_cnt};
+  for (void *q : ptrs) if (q) (void) hipFree(q);
+  if (p->h_cnt_send) (void) hipHostFree(p->h_cnt_send);
+  if (p->h_cnt_recv) (void) hipHostFree(p->h_cnt_recv);
+  if (p->h_aux) (void) hipHostFree(p->h_aux);
+  delete p;
+}
+
+static inline int rank_of(const int c[3], const int P[3]) { return (c[0] * P[1] + c[1]) * P[2] + c[2]; }
+
+// The geometry of the 26 segments in a fixed order (x slowest, then y, z; (0,0,0) skipped) -- the same order on every rank,
+// so that the messages between one pair of ranks pair up by position.  Pure host code: exported for the CPU tests
+// (imdgpu_dist_plan_geometry) and used by the rebuild.
+static void plan_geometry(const int cpu_dim[3], const int coord[3], const int dim[3], const int pbc[3], const double box[9], PlanSeg seg[26],
+                          std::vector<int> *send_cells, std::vector<int> *recv_cells)
+{
+  int q = 0;
+  for (int a = -1; a <= 1; a++) for (int b = -1; b <= 1; b++) for (int c = -1; c <= 1; c++) {
+    if (!a && !b && !c) continue;
+    PlanSeg &g = seg[q];
+    g = PlanSeg();
+    g.d[0] = a; g.d[1] = b; g.d[2] = c;
+    int pt[3], pf[3]; bool ok_to = true, ok_from = true;
+    for (int k = 0; k < 3; k++) {
+      const int P = cpu_dim[k], t = coord[k] + g.d[k], f = coord[k] - g.d[k];
+      if (t < 0 || t >= P) {
+        if (!pbc[k]) ok_to = false;
+        else if (g.d[k]) for (int x = 0; x < 3; x++) g.shift[x] += box[3 * k + x] * (t < 0 ? 1.0 : -1.0);
+      }
+      if ((f < 0 || f >= P) && !pbc[k]) ok_from = false;
+      pt[k] = ((t % P) + P) % P; pf[k] = ((f % P) + P) % P;
+    }
+    g.to = ok_to ? rank_of(pt, cpu_dim) : -1;
+    g.frm = ok_from ? rank_of(pf, cpu_dim) : -1;
+    // S(d): cell index 1 where d_k = -1, dim_k - 2 where d_k = +1, all inner cells where d_k = 0;
+    // R(-d) (filled by what arrives from coord - d): dim_k - 1 where d_k = -1, 0 where d_k = +1
+    int lo_s[3], hi_s[3], lo_r[3], hi_r[3];
+    for (int k = 0; k < 3; k++) {
+      if (g.d[k] == 0) { lo_s[k] = lo_r[k] = 1; hi_s[k] = hi_r[k] = dim[k] - 2; }
+      else if (g.d[k] < 0) { lo_s[k] = hi_s[k] = 1; lo_r[k] = hi_r[k] = dim[k] - 1; }
+      else { lo_s[k] = hi_s[k] = dim[k] - 2; lo_r[k] = hi_r[k] = 0; }
+    }
+    g.nsc = g.nrc = 0;
+    for (int i = lo_s[0]; i <= hi_s[0]; i++) for (int j = lo_s[1]; j <= hi_s[1]; j++) for (int k = lo_s[2]; k <= hi_s[2]; k++) {
+      if (send_cells && g.to >= 0) send_cells->push_back((i * dim[1] + j) * dim[2] + k);
+      g.nsc++;
+    }
+    for (int i = lo_r[0]; i <= hi_r[0]; i++) for (int j = lo_r[1]; j <= hi_r[1]; j++) for (int k = lo_r[2]; k <= hi_r[2]; k++) {
+      if (recv_cells && g.frm >= 0) recv_cells->push_back((i * dim[1] + j) * dim[2] + k);
+      g.nrc++;
+    }
+    q++;
+  }
+}
+
+// For tests and for hosts that want to inspect the plan: per direction (26 x) {dx, dy, dz, to, from, cells}; shifts 26 x 3.
+extern "C" int imdgpu_dist_plan_geometry(const int cpu_dim[3], const int my_coord[3], const int cell_dim[3], const int pbc[3],
+                                         const double box[9], int *seg_out /*26*6*/, double *shift_out /*26*3*/,
+                                         int *send_cells /*or NULL*/, int *nsend_cells, int *recv_cells /*or NULL*/, int *nrecv_cells)
+{
+  PlanSeg seg[26];
+  std::vector<int> sc, rc;
+  plan_geometry(cpu_dim, my_coord, cell_dim, pbc, box, seg, &sc, &rc);
+  for (int q = 0; q < 26; q++) {
+    int *o = seg_out + 6 * q;
+    o[0] = seg[q].d[0]; o[1] = seg[q].d[1]; o[2] = seg[q].d[2]; o[3] = seg[q].to; o[4] = seg[q].frm; o[5] = seg[q].nsc;
+    for (int x = 0; x < 3; x++) shift_out[3 * q + x] = seg[q].shift[x];
+  }
+  if (send_cells) memcpy(send_cells, sc.data(), sc.size() * sizeof(int));
+  if (recv_cells) memcpy(recv_cells, rc.data(), rc.size() * sizeof(int));
+  if (nsend_cells) *nsend_cells = (int) sc.size();
+  if (nrecv_cells) *nrecv_cells = (int) rc.size();
+  return 0;
+}
+
+static int plan_static(imdgpu_ctx *ctx, DistState *D, PlanState *P)
+{
+  if (P->ready && P->dim[0] == ctx->dim[0] && P->dim[1] == ctx->dim[1] && P->dim[2] == ctx->dim[2]) return 0;
+  if (rank_of(ctx->my_coord, ctx->cpu_dim) != D->rank || ctx->cpu_dim[0] * ctx->cpu_dim[1] * ctx->cpu_dim[2] != D->nranks)
+    return imdgpu_fail(ctx, "dist_rebuild: rank %d of %d does not match the geometry (cpu_dim %d %d %d, my_coord %d %d %d: ranks are "
+                       "numbered x slowest, z fastest)", D->rank, D->nranks, ctx->cpu_dim[0], ctx->cpu_dim[1], ctx->cpu_dim[2],
+                       ctx->my_coord[0], ctx->my_coord[1], ctx->my_coord[2]);
+  std::vector<int> sc, rc;
+  plan_geometry(ctx->cpu_dim, ctx->my_coord, ctx->dim, ctx->pbc, ctx->box, P->seg, &sc, &rc);
+  int so = 0, ro = 0;
+  for (int q = 0; q < 26; q++) {
+    PlanSeg &g = P->seg[q];
+    if (g.to >= 0) { g.soff = so; so += g.nsc; }
+    if (g.frm >= 0) { g.roff = ro; ro += g.nrc; }
+  }
+  P->nsc = so; P->nrc = ro;
+  for (int k = 0; k < 3; k++) {
+    P->dim[k] = ctx->dim[k];
+    const int Pk = ctx->cpu_dim[k], c = ctx->my_coord[k];
+    int n[3] = {ctx->my_coord[0], ctx->my_coord[1], ctx->my_coord[2]};
+    P->lo[k] = P->hi[k] = -1;
+    if (c > 0 || ctx->pbc[k]) { n[k] = (c - 1 + Pk) % Pk; P->lo[k] = rank_of(n, ctx->cpu_dim); }
+    if (c < Pk - 1 || ctx->pbc[k]) { n[k] = (c + 1) % Pk; P->hi[k] = rank_of(n, ctx->cpu_dim); }
+  }
+  void *old[] = {P->d_send_cells, P->d_recv_cells, P->d_cnt_send, P->d_cnt_recv, P->d_aux};
+  for (void *p : old) if (p) (void) hipFree(p);
+  if (P->h_cnt_send) (void) hipHostFree(P->h_cnt_send);
+  if (P->h_cnt_recv) (void) hipHostFree(P->h_cnt_recv);
+  if (P->h_aux) (void) hipHostFree(P->h_aux);
+  const size_t ns = (size_t) std::max(so, 1), nr = (size_t) std::max(ro, 1);
+  HIPCHK(hipMalloc((void **) &P->d_send_cells, ns * sizeof(int)));
+  HIPCHK(hipMalloc((void **) &P->d_recv_cells, nr * sizeof(int)));
+  HIPCHK(hipMalloc((void **) &P->d_cnt_send, ns * sizeof(int)));
+  HIPCHK(hipMalloc((void **) &P->d_cnt_recv, nr * sizeof(int)));
+  HIPCHK(hipMalloc((void **) &P->d_aux, (3 * ns + nr) * sizeof(int)));
+  HIPCHK(hipHostMalloc((void **) &P->h_cnt_send, ns * sizeof(int)));
+  HIPCHK(hipHostMalloc((void **) &P->h_cnt_recv, nr * sizeof(int)));
+  HIPCHK(hipHostMalloc((void **) &P->h_aux, (3 * ns + nr) * sizeof(int)));
+  if (so) HIPCHK(hipMemcpy(P->d_send_cells, sc.data(), (size_t) so * sizeof(int), hipMemcpyHostToDevice));
+  if (ro) HIPCHK(hipMemcpy(P->d_recv_cells, rc.data(), (size_t) ro * sizeof(int), hipMemcpyHostToDevice));
+  if (!P->d_mig_cnt) HIPCHK(hipMalloc((void **) &P->d_mig_cnt, 8 * sizeof(int)));
+  P->ready = true;
+  return 0;
+}
+
+// generic point-to-point batch of the rebuild: byte-addressed segments of two device buffers.  Messages to THIS rank are
+// copied on the device (the k-th self send is the k-th self receive); empty messages are not posted (both sides know).
+struct P2P { std::vector<int> sp, rp; std::vector<long long> so, sc, ro, rc; };
+static int dist_p2p(imdgpu_ctx *ctx, DistState *D, char *sendbuf, char *recvbuf, const P2P &m)
+{
+  std::vector<int> sp, rp; std::vector<long long> so, sc, ro, rc;
+  std::vector<size_t> self_s, self_r;
+  for (size_t k = 0; k < m.sp.size(); k++) {
+    if (m.sp[k] == D->rank) { self_s.push_back(k); continue; }
+    if (m.sc[k] > 0) { sp.push_back(m.sp[k]); so.push_back(m.so[k]); sc.push_back(m.sc[k]); }
+  }
+  for (size_t k = 0; k < m.rp.size(); k++) {
+    if (m.rp[k] == D->rank) { self_r.push_back(k); continue; }
+    if (m.rc[k] > 0) { rp.push_back(m.rp[k]); ro.push_back(m.ro[k]); rc.push_back(m.rc[k]); }
+  }
+  if (self_s.size() != self_r.size()) return imdgpu_fail(ctx, "dist: self messages do not pair up (%zu sent, %zu expected)", self_s.size(), self_r.size());
+  for (size_t k = 0; k < self_s.size(); k++) {
+    const size_t a = self_s[k], b = self_r[k];
+    if (m.sc[a] != m.rc[b]) return imdgpu_fail(ctx, "dist: self message %zu: %lld bytes sent, %lld expected", k, m.sc[a], m.rc[b]);
+    if (m.sc[a] > 0) HIPCHK(hipMemcpyAsync(recvbuf + m.ro[b], sendbuf + m.so[a], (size_t) m.sc[a], hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  if (sp.empty() && rp.empty()) return 0;
+  if (D->comm) {
+    NCCLCHK(g_rccl.GroupStart());
+    for (size_t s = 0; s < sp.size(); s++) NCCLCHK(g_rccl.Send(sendbuf + so[s], (size_t) sc[s], ncclChar, sp[s], D->comm, ctx->stream));
+    for (size_t s = 0; s < rp.size(); s++) NCCLCHK(g_rccl.Recv(recvbuf + ro[s], (size_t) rc[s], ncclChar, rp[s], D->comm, ctx->stream));
+    NCCLCHK(g_rccl.GroupEnd());
+    return 0;
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (D->cb(D->cb_user, 0, sendbuf, recvbuf, (int) sp.size(), sp.data(), so.data(), sc.data(), (int) rp.size(), rp.data(), ro.data(), rc.data(), 1))
+    return imdgpu_fail(ctx, "dist: the host transport failed (rebuild)");
+  return 0;
+}
+// MAX over the ranks of one host int (collective decisions of the rebuild)
+static int dist_max_int(imdgpu_ctx *ctx, DistState *D, int *v)
+{
+  if (D->nranks == 1) return 0;
+  HIPCHK(hipMemcpyAsync(D->d_flag + 2, v, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  if (D->comm) NCCLCHK(g_rccl.AllReduce(D->d_flag + 2, D->d_flag + 2, 1, ncclInt, ncclMax, D->comm, ctx->stream));
+  else {
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (D->cb(D->cb_user, 1, D->d_flag + 2, D->d_flag + 2, 1, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 4))
+      return imdgpu_fail(ctx, "dist: the host transport failed (all-reduce)");
+  }
+  HIPCHK(hipMemcpyAsync(v, D->d_flag + 2, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+__global__ void k_plan_counts(int n, const int *cells, const int *cell_cnt, int *out)
+{
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m < n) out[m] = cell_cnt[cells[m]];
+}
+// every ghost cell empty (start = nlocal), then the received regions get their ranges
+__global__ void k_plan_clear_ghost_cells(int d0, int d1, int d2, int nlocal, int *cell_start, int *cell_cnt)
+{
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= d0 * d1 * d2) return;
+  const int k = c % d2, j = (c / d2) % d1, i = c / (d2 * d1);
+  if (i == 0 || j == 0 || k == 0 || i == d0 - 1 || j == d1 - 1 || k == d2 - 1) { cell_start[c] = nlocal; cell_cnt[c] = 0; }
+}
+__global__ void k_plan_set_ghost_cells(int n, const int *cells, const int *start, const int *cnt, int *cell_start, int *cell_cnt)
+{
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m < n) { cell_start[cells[m]] = start[m]; cell_cnt[cells[m]] = cnt[m]; }
+}
+// the send index lists, cell after cell (the order in which the receiver laid its ghost atoms out): one thread per cell
+__global__ void k_plan_send_idx(int n, const int *cells, const int *cell_start, const int *cnt, const int *off, const int *dst,
+                                const int *segof, int *idx, int *seg_of, int *self_dst)
+{
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= n) return;
+  const int s = cell_start[cells[m]], c = cnt[m], o = off[m], g = dst[m], sg = segof[m];
+  for (int a = 0; a < c; a++) { idx[o + a] = s + a; seg_of[o + a] = sg; self_dst[o + a] = g >= 0 ? g + a : -1; }
+}
+
+static double ms_since(std::chrono::steady_clock::time_point &t)
+{
+  auto n = std::chrono::steady_clock::now();
+  double d = std::chrono::duration<double, std::milli>(n - t).count();
+  t = n;
+  return d;
+}
+
+// counts to the 26 peers, ghost layout, send lists, buffers: the plan of the list about to be built
+static int dist_plan(imdgpu_ctx *ctx, DistState *D, PlanState *P)
+{
+  if (plan_static(ctx, D, P)) return 1;
+  imdgpu_dist_cancel_ahead(ctx);
+  const int nlocal = ctx->nlocal;
+  if (P->nsc > 0)
+    hipLaunchKernelGGL(k_plan_counts, dim3(nblk(P->nsc, 256)), dim3(256), 0, ctx->stream, P->nsc, P->d_send_cells, ctx->cell_cnt, P->d_cnt_send);
+  {
+    P2P m;
+    for (int q = 0; q < 26; q++) {
+      const PlanSeg &g = P->seg[q];
+      if (g.to >= 0) { m.sp.push_back(g.to); m.so.push_back((long long) g.soff * 4); m.sc.push_back((long long) g.nsc * 4); }
+      if (g.frm >= 0) { m.rp.push_back(g.frm); m.ro.push_back((long long) g.roff * 4); m.rc.push_back((long long) g.nrc * 4); }
+    }
+    if (dist_p2p(ctx, D, (char *) P->d_cnt_send, (char *) P->d_cnt_recv, m)) return 1;
+  }
+  if (P->nsc) HIPCHK(hipMemcpyAsync(P->h_cnt_send, P->d_cnt_send, (size_t) P->nsc * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  if (P->nrc) HIPCHK(hipMemcpyAsync(P->h_cnt_recv, P->d_cnt_recv, (size_t) P->nrc * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  // host: prefix sums per segment
+  int *a_off = P->h_aux, *a_dst = P->h_aux + P->nsc, *a_seg = P->h_aux + 2 * (size_t) P->nsc, *a_start = P->h_aux + 3 * (size_t) P->nsc;
+  D->send_peer.clear(); D->recv_peer.clear(); D->send_cnt.clear(); D->send_off.clear(); D->recv_cnt.clear(); D->recv_off.clear(); D->send_shift.clear();
+  long long run = 0;
+  std::vector<int> self_recv;                   // indices (in the receive-segment list) of the segments from this rank
+  std::vector<int> recv_of_seg(26, -1);
+  for (int q = 0; q < 26; q++) {
+    const PlanSeg &g = P->seg[q];
+    if (g.frm < 0) continue;
+    const long long first = run;
+    for (int m = 0; m < g.nrc; m++) { a_start[g.roff + m] = nlocal + (int) run; run += P->h_cnt_recv[g.roff + m]; }
+    if (g.frm == D->rank) self_recv.push_back((int) D->recv_peer.size());
+    D->recv_peer.push_back(g.frm); D->recv_off.push_back(first); D->recv_cnt.push_back(run - first);
+  }
+  const long long nghost = run;
+  if ((long long) nlocal + nghost > 2000000000LL) return imdgpu_fail(ctx, "dist_rebuild: %lld atoms on one rank exceed the 32-bit atom index", (long long) nlocal + nghost);
+  run = 0;
+  size_t kself = 0;
+  for (int q = 0; q < 26; q++) {
+    const PlanSeg &g = P->seg[q];
+    if (g.to < 0) continue;
+    const long long first = run;
+    const int sidx = (int) D->send_peer.size();
+    long long dst0 = -1;
+    const bool self = g.to == D->rank && !D->self_comm;
+    if (g.to == D->rank) {
+      if (kself >= self_recv.size()) return imdgpu_fail(ctx, "dist_rebuild: self segments do not pair up");
+      if (self) dst0 = nlocal + D->recv_off[self_recv[kself]];
+    }
+    for (int m = 0; m < g.nsc; m++) {
+      a_off[g.soff + m] = (int) run; a_seg[g.soff + m] = sidx;
+      a_dst[g.soff + m] = self ? (int) (dst0 + (run - first)) : -1;
+      run += P->h_cnt_send[g.soff + m];
+    }
+    if (g.to == D->rank) {
+      if (D->recv_cnt[self_recv[kself]] != run - first) return imdgpu_fail(ctx, "dist_rebuild: self segment %zu: %lld atoms sent, %lld expected", kself, run - first, D->recv_cnt[self_recv[kself]]);
+      kself++;
+    }
+    D->send_peer.push_back(g.to); D->send_off.push_back(first); D->send_cnt.push_back(run - first);
+    for (int x = 0; x < 3; x++) D->send_shift.push_back(g.shift[x]);
+  }
+  D->nsend = (int) D->send_peer.size(); D->nrecv = (int) D->recv_peer.size();
+  D->nsend_atoms = run; D->nrecv_atoms = nghost;
+  if (D->nsend > MAXSEG || D->nrecv > MAXSEG) return imdgpu_fail(ctx, "dist_rebuild: more than %d segments", MAXSEG);
+  // device side of the layout
+  if (imdgpu_ensure_capacity(ctx, nlocal, nlocal + (int) nghost)) return 1;
+  ctx->nghost = (int) nghost; ctx->have_valid_nbl = 0;
+  if ((size_t) D->nsend_atoms > D->send_idx_cap) {
+    if (D->d_send_idx) (void) hipFree(D->d_send_idx);
+    if (D->d_seg_of) (void) hipFree(D->d_seg_of);
+    if (D->d_self_dst) (void) hipFree(D->d_self_dst);
+    D->send_idx_cap = (size_t) (D->nsend_atoms * 1.2) + 1024;
+    HIPCHK(hipMalloc((void **) &D->d_send_idx, D->send_idx_cap * sizeof(int)));
+    HIPCHK(hipMalloc((void **) &D->d_seg_of, D->send_idx_cap * sizeof(int)));
+    HIPCHK(hipMalloc((void **) &D->d_self_dst, D->send_idx_cap * sizeof(int)));
+  }
+  if ((size_t) D->nrecv_atoms + 1 > D->recv_self_cap) {
+    if (D->d_recv_self) (void) hipFree(D->d_recv_self);
+    D->recv_self_cap = (size_t) (D->nrecv_atoms * 1.2) + 1024;
+    HIPCHK(hipMalloc((void **) &D->d_recv_self, D->recv_self_cap));
+  }
+  const size_t ns = (size_t) D->nsend_atoms * 4 + 8, nr = (size_t) D->nrecv_atoms * 4 + 8;
+  if (ns > D->sendbuf_cap) { if (D->sendbuf) (void) hipFree(D->sendbuf); D->sendbuf_cap = (size_t) (ns * 1.2); HIPCHK(hipMalloc((void **) &D->sendbuf, D->sendbuf_cap * sizeof(double))); }
+  if (nr > D->recvbuf_cap) { if (D->recvbuf) (void) hipFree(D->recvbuf); D->recvbuf_cap = (size_t) (nr * 1.2); HIPCHK(hipMalloc((void **) &D->recvbuf, D->recvbuf_cap * sizeof(double))); }
+  const size_t naux = 3 * (size_t) P->nsc + P->nrc;
+  if (naux) HIPCHK(hipMemcpyAsync(P->d_aux, P->h_aux, naux * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_plan_clear_ghost_cells, dim3(nblk(ctx->nall_cells, 256)), dim3(256), 0, ctx->stream, ctx->dim[0], ctx->dim[1], ctx->dim[2],
+                     nlocal, ctx->cell_start, ctx->cell_cnt);
+  if (P->nrc > 0)
+    hipLaunchKernelGGL(k_plan_set_ghost_cells, dim3(nblk(P->nrc, 256)), dim3(256), 0, ctx->stream, P->nrc, P->d_recv_cells,
+                       P->d_aux + 3 * (size_t) P->nsc, P->d_cnt_recv, ctx->cell_start, ctx->cell_cnt);
+  if (P->nsc > 0)
+    hipLaunchKernelGGL(k_plan_send_idx, dim3(nblk(P->nsc, 128)), dim3(128), 0, ctx->stream, P->nsc, P->d_send_cells, ctx->cell_start, P->d_cnt_send,
+                       P->d_aux, P->d_aux + P->nsc, P->d_aux + 2 * (size_t) P->nsc, D->d_send_idx, D->d_seg_of, D->d_self_dst);
+  HIPCHK(hipMemsetAsync(D->d_recv_self, 0, (size_t) D->nrecv_atoms + 1, ctx->stream));
+  D->nself_atoms = 0;
+  if (!D->self_comm)
+    for (int r : self_recv) {
+      if (D->recv_cnt[r] > 0) HIPCHK(hipMemsetAsync(D->d_recv_self + D->recv_off[r], 1, (size_t) D->recv_cnt[r], ctx->stream));
+      D->nself_atoms += D->recv_cnt[r];
+    }
+  {
+    double sh[3 * MAXSEG] = {0};
+    for (size_t s = 0; s < D->send_shift.size(); s++) sh[s] = D->send_shift[s];
+    HIPCHK(hipMemcpyAsync(D->d_shift, sh, sizeof(sh), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));          // sh and the host vectors are locals
+  }
+  HIPCHK(hipGetLastError());
+  ctx->cells_epoch++;
+  D->have_plan = true; D->halo_ready = false; D->spec_pass1 = false;
+  return 0;
+}
+
+// fix_cells -> send_atoms (imd_fix_cells_3d.c:436-542): along x, y, z in turn, atoms whose cell now belongs to the lower /
+// higher neighbour rank leave (10 doubles each) and the arrivals are appended; counts travel first
+static int dist_migrate(imdgpu_ctx *ctx, DistState *D, PlanState *P)
+{
+  if (plan_static(ctx, D, P)) return 1;
+  for (int d = 0; d < 3; d++) {
+    if (ctx->cpu_dim[d] == 1) continue;
+    int n_lo = 0, n_hi = 0;
+    if (imdgpu_migrate_scan(ctx, d, &n_lo, &n_hi)) return 1;
+    const int lo = P->lo[d], hi = P->hi[d];
+    if ((lo < 0 && n_lo) || (hi < 0 && n_hi)) return imdgpu_fail(ctx, "atoms left the simulation box through an open boundary");
+    int h[4] = {n_lo, n_hi, 0, 0};
+    HIPCHK(hipMemcpyAsync(P->d_mig_cnt, h, 2 * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemsetAsync(P->d_mig_cnt + 2, 0, 2 * sizeof(int), ctx->stream));
+    {                                       // sends in the order (low, high), receives (from high, from low): pairs up on grids of two
+      P2P m;
+      if (lo >= 0) { m.sp.push_back(lo); m.so.push_back(0); m.sc.push_back(4); }
+      if (hi >= 0) { m.sp.push_back(hi); m.so.push_back(4); m.sc.push_back(4); }
+      if (hi >= 0) { m.rp.push_back(hi); m.ro.push_back(0); m.rc.push_back(4); }
+      if (lo >= 0) { m.rp.push_back(lo); m.ro.push_back(4); m.rc.push_back(4); }
+      if (dist_p2p(ctx, D, (char *) P->d_mig_cnt, (char *) (P->d_mig_cnt + 2), m)) return 1;
+    }
+    HIPCHK(hipMemcpyAsync(h + 2, P->d_mig_cnt + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const int in_hi = hi >= 0 ? h[2] : 0, in_lo = lo >= 0 ? h[3] : 0;
+    const size_t need_s = (size_t) (n_lo + n_hi) * 10 + 16, need_r = (size_t) (in_lo + in_hi) * 10 + 16;
+    if (need_s > P->mig_send_cap) { if (P->mig_send) (void) hipFree(P->mig_send); P->mig_send_cap = need_s * 2; HIPCHK(hipMalloc((void **) &P->mig_send, P->mig_send_cap * sizeof(double))); }
+    if (need_r > P->mig_recv_cap) { if (P->mig_recv) (void) hipFree(P->mig_recv); P->mig_recv_cap = need_r * 2; HIPCHK(hipMalloc((void **) &P->mig_recv, P->mig_recv_cap * sizeof(double))); }
+    if (lo >= 0 && imdgpu_migrate_gather(ctx, 0, P->mig_send)) return 1;
+    if (hi >= 0 && imdgpu_migrate_gather(ctx, 1, P->mig_send + (size_t) n_lo * 10)) return 1;
+    {
+      P2P m;
+      if (lo >= 0) { m.sp.push_back(lo); m.so.push_back(0); m.sc.push_back((long long) n_lo * 80); }
+      if (hi >= 0) { m.sp.push_back(hi); m.so.push_back((long long) n_lo * 80); m.sc.push_back((long long) n_hi * 80); }
+      if (hi >= 0) { m.rp.push_back(hi); m.ro.push_back((long long) in_lo * 80); m.rc.push_back((long long) in_hi * 80); }
+      if (lo >= 0) { m.rp.push_back(lo); m.ro.push_back(0); m.rc.push_back((long long) in_lo * 80); }
+      if (dist_p2p(ctx, D, (char *) P->mig_send, (char *) P->mig_recv, m)) return 1;
+    }
+    if (imdgpu_migrate_apply(ctx, in_lo ? P->mig_recv : nullptr, in_lo, in_hi ? P->mig_recv + (size_t) in_lo * 10 : nullptr, in_hi)) return 1;
+  }
+  return 0;
+}
+
+void imdgpu_ttm_block_dims(imdgpu_ctx *ctx, int ldim[3]);
+
+// The whole rebuild of one rank (collective: every rank calls it).  After it the list is valid and imdgpu_dist_md_step runs.
+extern "C" int imdgpu_dist_rebuild(imdgpu_ctx *ctx)
+{
+  NEED_DIST();
+  PlanState *P = PS(ctx);
+  auto t = std::chrono::steady_clock::now();
+  const bool T = P->timing;
+  if (T) HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (P->nrebuild > 0 && dist_migrate(ctx, D, P)) return 1;
+  if (T) { HIPCHK(hipStreamSynchronize(ctx->stream)); P->ms[0] = ms_since(t); }
+  if (imdgpu_fix_cells(ctx)) return 1;
+  if (T) { HIPCHK(hipStreamSynchronize(ctx->stream)); P->ms[1] = ms_since(t); }
+  if (dist_plan(ctx, D, P)) return 1;
+  int changed = 0;
+  if (imdgpu_autotile(ctx, &changed)) return 1;      // first rebuild: tile shape from the real occupancies
+  if (P->nrebuild == 0 && dist_max_int(ctx, D, &changed)) return 1;   // planning is collective: a rank in vacuum never re-tiles by itself
+  if (changed && dist_plan(ctx, D, P)) return 1;     // local atoms were re-sorted: new index lists
+  if (T) { HIPCHK(hipStreamSynchronize(ctx->stream)); P->ms[2] = ms_since(t); }
+  if (imdgpu_dist_halo(ctx, 0)) return 1;
+  if (ctx->ntypes > 1 && imdgpu_dist_halo(ctx, 2)) return 1;
+  if (T) { HIPCHK(hipStreamSynchronize(ctx->stream)); P->ms[3] = ms_since(t); }
+  if (imdgpu_make_nblist(ctx)) return 1;
+  if (T) {
+    HIPCHK(hipStreamSynchronize(ctx->stream)); P->ms[4] = ms_since(t);
+    fprintf(stderr, "[dist rebuild %d, native] ms: migrate %.2f, fix_cells %.2f, plan %.2f, exchange %.2f, make_nblist %.2f\n", P->nrebuild,
+            P->ms[0], P->ms[1], P->ms[2], P->ms[3], P->ms[4]);
+  }
+  if (ctx->ttm && !ctx->ttm_decomposed && !D->d_ttm_offs) {          // replicated lattice: where every rank's update_fd block goes
+    int ld[3];
+    imdgpu_ttm_block_dims(ctx, ld);
+    std::vector<int> offs(3 * (size_t) D->nranks);
+    for (int r = 0; r < D->nranks; r++) {
+      const int c[3] = {r / (ctx->cpu_dim[1] * ctx->cpu_dim[2]), (r / ctx->cpu_dim[2]) % ctx->cpu_dim[1], r % ctx->cpu_dim[2]};
+      for (int x = 0; x < 3; x++) offs[3 * r + x] = c[x] * ld[x];
+    }
+    if (imdgpu_dist_set_ttm_blocks(ctx, offs.data())) return 1;
+  }
+  P->nrebuild++;
+  return 0;
+}
+extern "C" int imdgpu_dist_rebuild_count(imdgpu_ctx *ctx, int *n) { if (n) *n = PS(ctx)->nrebuild; return 0; }
+
+// One call per MD step for a C host: rebuild when the list is stale, then the step.
+extern "C" int imdgpu_dist_step(imdgpu_ctx *ctx, int steps)
+{
+  NEED_DIST();
+  if ((!D->have_plan || !ctx->have_valid_nbl) && imdgpu_dist_rebuild(ctx)) return 1;
+  int stale = 0;
+  return imdgpu_dist_md_step(ctx, steps, &stale);     // a stale list leaves have_plan / have_valid_nbl cleared for the next call
+}
+// complete forces of the CURRENT positions (all passes with their halos), e.g. before a download
+extern "C" int imdgpu_dist_calc_forces(imdgpu_ctx *ctx)
+{
+  NEED_DIST();
+  if (!D->have_plan || !ctx->have_valid_nbl) { if (imdgpu_dist_rebuild(ctx)) return 1; }
+  else if (imdgpu_dist_halo(ctx, 3)) return 1;
+  imdgpu_dist_cancel_ahead(ctx);
+  if (imdgpu_launch_forces_phase(ctx, 1) || imdgpu_launch_forces_phase(ctx, 2)) return 1;
+  if (ctx->rho.present && imdgpu_dist_halo(ctx, 1)) return 1;
+  return imdgpu_launch_forces_phase(ctx, 3);
+}
+
+// ---- in-process transport: the ranks are contexts of ONE process, each driven by its own host thread ----------------------
+// (several ranks rehearsing on one GPU without a process per rank -- a GPU box admits few processes --, or one process driving
+// the GPUs of a node with peer copies).  Same semantics as the host callback: called with the stream drained; messages
+// between a pair of ranks match in posting order; collectives over all ranks of the group.
+struct LocalPost { int op = -1; char *send = nullptr, *recv = nullptr; int nsend = 0; std::vector<int> sp; std::vector<long long> so, sc; int eb = 0; };
+struct LocalGroup {
+  int n = 0;
+  std::mutex mu; std::condition_variable cv;
+  int arrived = 0; unsigned long long gen = 0; bool broken = false;
+  std::vector<LocalPost> post;
+  std::map<std::string, std::pair<void *, size_t>> shared;   // named page-locked regions (the TTM face mailbox)
+};
+struct LocalMember { LocalGroup *g; int rank; int device; hipStream_t s = nullptr; };
+static int local_barrier(LocalGroup *G)
+{
+  std::unique_lock<std::mutex> lk(G->mu);
+  if (G->broken) return 1;
+  const unsigned long long my = G->gen;
+  if (++G->arrived == G->n) { G->arrived = 0; G->gen++; G->cv.notify_all(); return 0; }
+  if (!G->cv.wait_for(lk, std::chrono::seconds(120), [&] { return G->gen != my || G->broken; })) { G->broken = true; G->cv.notify_all(); return 1; }
+  return G->broken ? 1 : 0;
+}
+static int local_exchange(void *user, int op, void *dsend, void *drecv, int nsend, const int *sp, const long long *so, const long long *sc,
+                          int nrecv, const int *rp, const long long *ro, const long long *rc, int eb)
+{
+  LocalMember *M = (LocalMember *) user;
+  LocalGroup *G = M->g;
+  if (hipSetDevice(M->device) != hipSuccess) return 1;
+  LocalPost &me = G->post[M->rank];
+  me.op = op; me.send = (char *) dsend; me.recv = (char *) drecv; me.nsend = nsend; me.eb = eb;
+  me.sp.clear(); me.so.clear(); me.sc.clear();
+  if (op == 0) for (int k = 0; k < nsend; k++) { me.sp.push_back(sp[k]); me.so.push_back(so[k]); me.sc.push_back(sc[k]); }
+  if (local_barrier(G)) return 1;
+  int rc_ = 0;
+  if (op == 0) {
+    std::vector<int> seen(G->n, 0);                      // how many messages from each peer I have matched so far
+    for (int k = 0; k < nrecv && !rc_; k++) {
+      const int p = rp[k];
+      if (p < 0 || p >= G->n) { rc_ = 1; break; }
+      const LocalPost &o = G->post[p];
+      int want = seen[p]++, at = -1;
+      for (size_t j = 0; j < o.sp.size(); j++) if (o.sp[j] == M->rank && want-- == 0) { at = (int) j; break; }
+      if (at < 0 || o.sc[at] != rc[k] || o.eb != eb || o.op != 0) { rc_ = 1; break; }
+      if (rc[k] > 0 && hipMemcpyAsync((char *) drecv + ro[k] * eb, o.send + o.so[at] * eb, (size_t) rc[k] * eb, hipMemcpyDeviceToDevice, M->s) != hipSuccess) rc_ = 1;
+    }
+    if (hipStreamSynchronize(M->s) != hipSuccess) rc_ = 1;
+  } else if (op == 1 || op == 3) {
+    const size_t bytes = (size_t) nsend * eb;
+    std::vector<char> mine(bytes), other(bytes);
+    for (int r = 0; r < G->n && !rc_; r++) {
+      if (G->post[r].op != op || G->post[r].nsend != nsend) { rc_ = 1; break; }
+      if (hipMemcpy(r == 0 ? mine.data() : other.data(), G->post[r].send, bytes, hipMemcpyDeviceToHost) != hipSuccess) { rc_ = 1; break; }
+      if (r == 0) continue;
+      if (op == 1) { int *a = (int *) mine.data(); const int *b = (const int *) other.data(); for (int i = 0; i < nsend; i++) a[i] = b[i] > a[i] ? b[i] : a[i]; }
+      else { double *a = (double *) mine.data(); const double *b = (const double *) other.data(); for (int i = 0; i < nsend; i++) a[i] += b[i]; }   // rank order: the same sum on every rank
+    }
+    if (local_barrier(G)) return 1;                      // everyone has read every send buffer (in-place reductions)
+    if (!rc_ && hipMemcpy(drecv, mine.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) rc_ = 1;
+  } else if (op == 2) {
+    for (int r = 0; r < G->n && !rc_; r++) {
+      if (G->post[r].op != 2 || G->post[r].nsend != nsend) { rc_ = 1; break; }
+      if (hipMemcpyAsync((char *) drecv + (size_t) r * nsend * eb, G->post[r].send, (size_t) nsend * eb, hipMemcpyDeviceToDevice, M->s) != hipSuccess) rc_ = 1;
+    }
+    if (hipStreamSynchronize(M->s) != hipSuccess) rc_ = 1;
+  } else rc_ = 1;
+  if (rc_) { std::lock_guard<std::mutex> lk(G->mu); G->broken = true; G->cv.notify_all(); return 1; }
+  if (local_barrier(G)) return 1;                        // nobody reuses a send buffer before every reader is through
+  return 0;
+}
+extern "C" int imdgpu_local_group_create(int nranks, void **group)
+{
+  if (nranks < 1 || !group) return 1;
+  LocalGroup *G = new LocalGroup();
+  G->n = nranks; G->post.resize(nranks);
+  *group = G;
+  return 0;
+}
+extern "C" void imdgpu_local_group_destroy(void *group)
+{
+  LocalGroup *G = (LocalGroup *) group;
+  if (!G) return;
+  for (auto &e : G->shared) (void) hipHostFree(e.second.first);
+  delete G;
+}
+// a zero-filled page-locked host region all ranks of the group see under one name (first caller allocates, the size must agree)
+extern "C" int imdgpu_local_group_shared(void *group, const char *name, size_t bytes, void **ptr)
+{
+  LocalGroup *G = (LocalGroup *) group;
+  if (!G || !name || !ptr) return 1;
+  std::lock_guard<std::mutex> lk(G->mu);
+  auto it = G->shared.find(name);
+  if (it == G->shared.end()) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) return 1;
+    memset(p, 0, bytes);
+    it = G->shared.emplace(name, std::make_pair(p, bytes)).first;
+  }
+  if (it->second.second != bytes) return 1;
+  *ptr = it->second.first;
+  return 0;
+}
+extern "C" int imdgpu_local_group_barrier(void *group) { return local_barrier((LocalGroup *) group); }
+extern "C" int imdgpu_dist_init_local(imdgpu_ctx *ctx, void *group, int rank)
+{
+  LocalGroup *G = (LocalGroup *) group;
+  if (!G || rank < 0 || rank >= G->n) return imdgpu_fail(ctx, "dist_init_local: bad rank %d", rank);
+  LocalMember *M = new LocalMember();                    // lives as long as the process (a few bytes per rank)
+  M->g = G; M->rank = rank; M->device = ctx->device;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamCreateWithFlags(&M->s, hipStreamNonBlocking));
+  return imdgpu_dist_init_callback(ctx, G->n, rank, local_exchange, M);
 }

@@ -52,7 +52,7 @@ struct TtmState {
   // one captured sub-step chain per value of `cur` at its start (do_ADV's extra swap alternates it from step to step)
   hipGraphExec_t graph[2] = {nullptr, nullptr}; int graph_kcur[2] = {-1, -1}, graph_src[2] = {-1, -1}; double graph_tau[2] = {0, 0};
   // decomposed lattice (several ranks): faces travel through a host shared-memory mailbox (see Mailbox below)
-  void *mb_host = nullptr; size_t mb_bytes = 0; int mb_rank = -1, mb_nranks = 0;
+  void *mb_host = nullptr; size_t mb_bytes = 0; int mb_rank = -1, mb_nranks = 0; bool mb_registered = false;
   MailboxDev mbd{};
   unsigned long long *d_gbase = nullptr; // index of the next face publication (monotone over the whole run)
   int *d_facecnt = nullptr;              // per face: workgroups that finished publishing (monotone)
@@ -1301,7 +1301,7 @@ void imdgpu_ttm_free(imdgpu_ctx *ctx)
                   t->md_temp, t->source, t->vcom, t->dens, t->fd_g, t->Z, t->Ce, t->ne, t->cve_z, t->ee_z, t->d_red, t->flux, t->d_eabs, t->d_cand};
   for (void *p : ptrs) if (p) (void) hipFree(p);
   for (int q = 0; q < 2; q++) if (t->graph[q]) (void) hipGraphExecDestroy(t->graph[q]);
-  if (t->mb_host) (void) hipHostUnregister(t->mb_host);
+  if (t->mb_host && t->mb_registered) (void) hipHostUnregister(t->mb_host);
   if (t->d_gbase) (void) hipFree(t->d_gbase);
   if (t->d_facecnt) (void) hipFree(t->d_facecnt);
   if (t->d_pflags) (void) hipFree(t->d_pflags);
@@ -1902,6 +1902,12 @@ static int launch_persist(imdgpu_ctx *ctx, TtmState *t, const Lat &L, double tau
   return 0;
 }
 
+// FD cells per direction of this rank's block (what imdgpu_ttm_local_block packs)
+void imdgpu_ttm_block_dims(imdgpu_ctx *ctx, int ldim[3])
+{
+  for (int d = 0; d < 3; d++) ldim[d] = ctx->ttm ? ctx->ttm->ldim[d] : 0;
+}
+
 extern "C" int imdgpu_calc_ttm(imdgpu_ctx *ctx, int steps)
 {
   if (ctx->external_halo && !ctx->ttm_decomposed) return imdgpu_fail(ctx, "calc_ttm: with several ranks use ttm_local_block / apply_blocks / ttm_lattice_step");
@@ -2016,9 +2022,15 @@ extern "C" int imdgpu_ttm_mailbox_attach(imdgpu_ctx *ctx, void *host_base, size_
   int mf; size_t o_nat, o_dat, need;
   mailbox_layout(t, &mf, &o_nat, &o_dat, &need);
   if (bytes_per_rank < need) return imdgpu_fail(ctx, "mailbox: %zu bytes per rank given, %zu needed", bytes_per_rank, need);
-  HIPCHK(hipHostRegister(host_base, bytes_per_rank * (size_t) nranks, hipHostRegisterMapped | hipHostRegisterPortable));
+  // memory that is page-locked and mapped already (imdgpu_local_group_shared: ranks as threads of one process) is used as it
+  // is; anything else (a mmap'ed /dev/shm file shared by processes) is registered here
   void *dev = nullptr;
-  HIPCHK(hipHostGetDevicePointer(&dev, host_base, 0));
+  if (hipHostGetDevicePointer(&dev, host_base, 0) != hipSuccess || !dev) {
+    (void) hipGetLastError();
+    HIPCHK(hipHostRegister(host_base, bytes_per_rank * (size_t) nranks, hipHostRegisterMapped | hipHostRegisterPortable));
+    t->mb_registered = true;
+    HIPCHK(hipHostGetDevicePointer(&dev, host_base, 0));
+  }
   t->mb_host = host_base; t->mb_bytes = bytes_per_rank; t->mb_rank = rank; t->mb_nranks = nranks;
   if (dev_alloc(ctx, &t->d_gbase, 1) || dev_alloc(ctx, &t->d_facecnt, 12)) return 1;
   HIPCHK(hipMemset(t->d_gbase, 0, sizeof(unsigned long long)));

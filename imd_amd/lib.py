@@ -32,6 +32,8 @@ SYMBOLS = [
     "imdgpu_ttm_fdtd_get", "imdgpu_ttm_fdtd_set_time",
     "imdgpu_dist_unique_id", "imdgpu_dist_init_rccl", "imdgpu_dist_init_callback", "imdgpu_dist_set_plan",
     "imdgpu_dist_halo", "imdgpu_dist_set_ttm_blocks", "imdgpu_dist_md_step", "imdgpu_dist_allreduce_sum",
+    "imdgpu_dist_rebuild", "imdgpu_dist_rebuild_count", "imdgpu_dist_step", "imdgpu_dist_calc_forces", "imdgpu_dist_plan_geometry",
+    "imdgpu_local_group_create", "imdgpu_local_group_destroy", "imdgpu_local_group_barrier", "imdgpu_local_group_shared", "imdgpu_dist_init_local",
 ]
 
 
@@ -166,6 +168,17 @@ def load():
     L.imdgpu_dist_set_ttm_blocks.argtypes = [vp, ip]
     L.imdgpu_dist_md_step.argtypes = [vp, C.c_int, ip]
     L.imdgpu_dist_allreduce_sum.argtypes = [vp, dp, C.c_int]
+    L.imdgpu_dist_rebuild.argtypes = [vp]
+    L.imdgpu_dist_rebuild_count.argtypes = [vp, ip]
+    L.imdgpu_dist_step.argtypes = [vp, C.c_int]
+    L.imdgpu_dist_calc_forces.argtypes = [vp]
+    L.imdgpu_dist_plan_geometry.argtypes = [ip, ip, ip, ip, dp, ip, dp, ip, ip, ip, ip]
+    L.imdgpu_local_group_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.imdgpu_local_group_destroy.argtypes = [vp]
+    L.imdgpu_local_group_destroy.restype = None
+    L.imdgpu_local_group_barrier.argtypes = [vp]
+    L.imdgpu_local_group_shared.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(vp)]
+    L.imdgpu_dist_init_local.argtypes = [vp, vp, C.c_int]
     L.imdgpu_get_cell_tables.argtypes = [vp, ip, ip]
     L.imdgpu_autotile.argtypes = [vp, ip]
     L.imdgpu_set_ghost_layout.argtypes = [vp, ip, ip, C.c_int]
@@ -186,7 +199,7 @@ def load():
     L.imdgpu_ttm_mailbox_attach.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, ip]
     L.imdgpu_ttm_local_step.argtypes = [vp, C.c_int]
     for s in SYMBOLS:
-        if s not in ("imdgpu_destroy", "imdgpu_last_error"):
+        if s not in ("imdgpu_destroy", "imdgpu_last_error", "imdgpu_local_group_destroy"):
             getattr(L, s).restype = C.c_int
     _lib = L
     return L

@@ -280,6 +280,43 @@ class HaloPlan:
 DIRECTIONS = [(a, b, c) for a in (-1, 0, 1) for b in (-1, 0, 1) for c in (-1, 0, 1) if (a, b, c) != (0, 0, 0)]
 
 
+def direct_segments(dec):
+    """The static part of the direct halo: per direction (in the fixed order of DIRECTIONS) the peers, the periodic shift
+    the sender adds and the cell layers.  The library builds the same in C (imdgpu_dist_plan_geometry, imdgpu_dist.hip);
+    tests/test_dist_plan_geometry.py holds the two against each other."""
+    D = dec.dim
+    ghost_mask = np.ones(dec.nall, bool)
+    ii, jj, kk = np.meshgrid(range(1, D[0] - 1), range(1, D[1] - 1), range(1, D[2] - 1), indexing="ij")
+    ghost_mask[((ii * D[1] + jj) * D[2] + kk).ravel()] = False
+    segs = []
+    for d in DIRECTIONS:
+        peer_to, peer_from, shift, ok_to, ok_from = [], [], np.zeros(3), True, True
+        for k in range(3):
+            P, c = dec.cpu_dim[k], dec.coord[k]
+            t, f = c + d[k], c - d[k]
+            if t < 0 or t >= P:
+                if not dec.pbc[k]:
+                    ok_to = False
+                elif d[k]:
+                    shift = shift + dec.box[k] * (1.0 if t < 0 else -1.0)      # added by the SENDER (:247-266)
+            if f < 0 or f >= P:
+                if not dec.pbc[k]:
+                    ok_from = False
+            peer_to.append(t % P); peer_from.append(f % P)
+
+        def layer(sel):
+            r = [range(1, D[k] - 1) if sel[k] is None else [sel[k]] for k in range(3)]
+            a, b, c = np.meshgrid(np.array(list(r[0])), np.array(list(r[1])), np.array(list(r[2])), indexing="ij")
+            return ((a * D[1] + b) * D[2] + c).ravel().astype(np.int64)
+        send_cells = layer([None if d[k] == 0 else (1 if d[k] < 0 else D[k] - 2) for k in range(3)])
+        # arrivals of direction d come from coord - d and fill my ghost region on the side they come from
+        recv_cells = layer([None if d[k] == 0 else (D[k] - 1 if d[k] < 0 else 0) for k in range(3)])
+        segs.append(dict(d=d, to=coord_to_rank(peer_to, dec.cpu_dim) if ok_to else -1,
+                         frm=coord_to_rank(peer_from, dec.cpu_dim) if ok_from else -1, shift=shift,
+                         send_cells=send_cells, recv_cells=recv_cells))
+    return np.flatnonzero(ghost_mask), segs
+
+
 class DirectHaloPlan:
     """The 26-message halo of one neighbour list.  For a direction d in {-1,0,1}^3 this rank SENDS the atoms of its
     boundary cell layer S(d) (cell index 1 where d_k = -1, dim_k - 2 where d_k = +1, all inner cells where d_k = 0) to
@@ -302,36 +339,7 @@ class DirectHaloPlan:
         nlocal = ops.nlocal()
         D = dec.dim
         if getattr(dec, "_direct", None) is None:          # geometry only
-            ghost_mask = np.ones(dec.nall, bool)
-            ii, jj, kk = np.meshgrid(range(1, D[0] - 1), range(1, D[1] - 1), range(1, D[2] - 1), indexing="ij")
-            ghost_mask[((ii * D[1] + jj) * D[2] + kk).ravel()] = False
-            segs = []
-            for d in DIRECTIONS:
-                peer_to, peer_from, shift, ok_to, ok_from = [], [], np.zeros(3), True, True
-                for k in range(3):
-                    P, c = dec.cpu_dim[k], dec.coord[k]
-                    t, f = c + d[k], c - d[k]
-                    if t < 0 or t >= P:
-                        if not dec.pbc[k]:
-                            ok_to = False
-                        elif d[k]:
-                            shift = shift + dec.box[k] * (1.0 if t < 0 else -1.0)      # added by the SENDER (:247-266)
-                    if f < 0 or f >= P:
-                        if not dec.pbc[k]:
-                            ok_from = False
-                    peer_to.append(t % P); peer_from.append(f % P)
-
-                def layer(sel):
-                    r = [range(1, D[k] - 1) if sel[k] is None else [sel[k]] for k in range(3)]
-                    a, b, c = np.meshgrid(np.array(list(r[0])), np.array(list(r[1])), np.array(list(r[2])), indexing="ij")
-                    return ((a * D[1] + b) * D[2] + c).ravel().astype(np.int64)
-                send_cells = layer([None if d[k] == 0 else (1 if d[k] < 0 else D[k] - 2) for k in range(3)])
-                # arrivals of direction d come from coord - d and fill my ghost region on the side they come from
-                recv_cells = layer([None if d[k] == 0 else (D[k] - 1 if d[k] < 0 else 0) for k in range(3)])
-                segs.append(dict(d=d, to=coord_to_rank(peer_to, dec.cpu_dim) if ok_to else -1,
-                                 frm=coord_to_rank(peer_from, dec.cpu_dim) if ok_from else -1, shift=shift,
-                                 send_cells=send_cells, recv_cells=recv_cells))
-            dec._direct = (np.flatnonzero(ghost_mask), segs)
+            dec._direct = direct_segments(dec)
         ghost_cells, segs = dec._direct
         cc[ghost_cells] = 0
         self.segs = segs
@@ -448,22 +456,37 @@ class DistributedMD:
     driven from here; the step itself is ops.dist_md_step = imdgpu_dist_md_step (C + RCCL, imdgpu_dist.hip), which
     returns whether some rank's list became invalid (main_loop body, imd_main_3d.c:406-812)."""
 
-    def __init__(self, dec, ops, ttm=False):
+    def __init__(self, dec, ops, ttm=False, local_group=None):
+        """local_group: a LocalGroup -- the ranks are threads of THIS process (in-process transport of the library, no
+        torch.distributed); otherwise the transport follows torch.distributed's backend (nccl -> RCCL, gloo -> host callback)."""
         self.dec, self.ops, self.ttm = dec, ops, ttm
         self.plan = None
         self.valid = False
         self.nrebuild = 0
-        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.local_group = local_group
+        if local_group is not None:
+            self.world = local_group.world
+        else:
+            self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.ttm_decomposed = bool(ttm and getattr(ops, "ttm_is_decomposed", lambda: False)())
         self.ttm_adv = bool(ttm and getattr(ops, "ttm_has_adv", lambda: False)())
-        ops.dist_init(dec.rank, self.world)
+        # the rebuild is native (imdgpu_dist_rebuild) wherever the device layer offers it; the host-side plan below remains
+        # for device stand-ins (CPU tests) and as the readable statement of the same plan (IMD_DIST_PY_REBUILD=1 forces it)
+        self.native_rebuild = hasattr(ops, "dist_rebuild") and os.environ.get("IMD_DIST_PY_REBUILD") != "1"
+        if local_group is not None:
+            ops.dist_init_local(local_group, dec.rank)
+        else:
+            ops.dist_init(dec.rank, self.world)
         if ttm and self.ttm_decomposed:
             # every rank diffuses its own block; ghost faces go GPU -> host shared memory -> GPU (imdgpu_ttm_mailbox_*)
             nbr = []
             for d in range(3):
                 nbr += [dec.lo[d] if dec.lo[d] is not None else -1, dec.hi[d] if dec.hi[d] is not None else -1]
-            self._mailbox = attach_ttm_mailbox(ops, dec.rank, self.world, nbr)
-        elif ttm:
+            if local_group is not None:
+                self._mailbox = local_group.attach_ttm_mailbox(ops, dec.rank, nbr)
+            else:
+                self._mailbox = attach_ttm_mailbox(ops, dec.rank, self.world, nbr)
+        elif ttm and not self.native_rebuild:
             offs = []
             for r in range(self.world):
                 c = rank_to_coord(r, dec.cpu_dim)
@@ -491,6 +514,12 @@ class DistributedMD:
 
     def rebuild(self):
         ops = self.ops
+        if self.native_rebuild:
+            ops.dist_rebuild()                   # migration, re-binning, plan, first halo, list: all in C (imdgpu_dist.hip)
+            self.plan = _NativePlan()
+            self.valid = True
+            self.nrebuild += 1
+            return
         timing = os.environ.get("IMD_DIST_TIMING") == "1"      # experiment: where a rebuild's time goes (stderr)
         if timing:
             import sys, time
@@ -557,6 +586,8 @@ class DistributedMD:
         if not self.valid:
             self.rebuild()
         if self.ttm and self.ttm_decomposed and self.ttm_adv:
+            if self.local_group is not None:
+                raise RuntimeError("decomposed lattice with advection: the do_COMMFLUX exchange is driven over torch.distributed")
             return self._md_step_host(step)          # do_COMMFLUX sits between update_fd and do_ADV: host-driven variant
         if ops.dist_md_step(step):                   # some rank's list became invalid during this step
             self.valid = False
@@ -598,11 +629,79 @@ class DistributedMD:
 
     def global_sums(self):
         s = self.ops.get_sums()
+        if self.local_group is not None:
+            v = self.ops.dist_allreduce_sum([s["tot_pot_energy"], s["virial"], s["tot_kin_energy"], float(self.ops.nlocal())])
+            return dict(tot_pot_energy=v[0], virial=v[1], tot_kin_energy=v[2], natoms=int(v[3]))
         t = torch.tensor([s["tot_pot_energy"], s["virial"], s["tot_kin_energy"], float(self.ops.nlocal())],
                          dtype=torch.float64, device=self.ops.device)
         if dist.is_initialized():
             all_reduce_(t)
         return dict(tot_pot_energy=float(t[0]), virial=float(t[1]), tot_kin_energy=float(t[2]), natoms=int(t[3]))
+
+
+class _NativePlan:
+    """after a native rebuild the plan lives in the library: halos go through imdgpu_dist_halo"""
+
+    def exchange(self, ops, what):
+        ops.dist_halo(what)
+
+
+class LocalGroup:
+    """N ranks as N threads of one process (imdgpu_local_group_*): how many ranks rehearse on ONE GPU when the box admits only
+    a few processes, e.g. the 2x2x2 grid of BASELINE config 4 on a one-GPU box.  run(fn) starts fn(rank) on a thread per rank
+    (ctypes releases the GIL inside the library) and returns the results in rank order."""
+
+    def __init__(self, world):
+        import ctypes as C
+        import threading
+        from . import lib
+        self.world, self.L = int(world), lib.load()
+        g = C.c_void_p()
+        if self.L.imdgpu_local_group_create(self.world, C.byref(g)):
+            raise RuntimeError("imdgpu_local_group_create failed")
+        self.handle = g
+        self._lock = threading.Lock()
+        self._shared = {}
+
+    def barrier(self):
+        if self.L.imdgpu_local_group_barrier(self.handle):
+            raise RuntimeError("local group: a rank failed or did not arrive")
+
+    def attach_ttm_mailbox(self, ops, rank, nbr):
+        """the face mailbox of the decomposed lattice: ordinary host memory shared by the threads"""
+        import ctypes as C
+        per = ops.ttm_mailbox_bytes()
+        p = C.c_void_p()
+        if self.L.imdgpu_local_group_shared(self.handle, b"ttm_mailbox", per * self.world, C.byref(p)):
+            raise RuntimeError("imdgpu_local_group_shared failed")
+        ops.ttm_mailbox_attach(p, per, rank, self.world, nbr)
+        self.barrier()
+        return p
+
+    def run(self, fn, timeout=600):
+        import threading
+        out, err = [None] * self.world, [None] * self.world
+
+        def body(r):
+            try:
+                out[r] = fn(r)
+            except BaseException:
+                import traceback
+                err[r] = traceback.format_exc()
+        th = [threading.Thread(target=body, args=(r,), daemon=True) for r in range(self.world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout)
+        bad = [r for r in range(self.world) if err[r] is not None or th[r].is_alive()]
+        if bad:
+            raise RuntimeError("local ranks failed: " + "; ".join("rank %d: %s" % (r, err[r] or "still running") for r in bad))
+        return out
+
+    def close(self):
+        if self.handle:
+            self.L.imdgpu_local_group_destroy(self.handle)
+            self.handle = None
 
 
 def make_host_transport(ops, rank, world):
@@ -766,6 +865,18 @@ class GpuOps:
             self._ck(self.L.imdgpu_dist_init_callback(self.h, world, rank, C.cast(self._cb, C.c_void_p), None))
             self.transport = "host callback (%s)" % (dist.get_backend() if dist.is_initialized() else "single rank")
 
+    def dist_init_local(self, group, rank):
+        self._ck(self.L.imdgpu_dist_init_local(self.h, group.handle, int(rank)))
+        self.transport = "in-process (%d ranks on threads)" % group.world
+
+    def dist_rebuild(self):
+        self._ck(self.L.imdgpu_dist_rebuild(self.h))
+
+    def dist_allreduce_sum(self, vals):
+        a = np.ascontiguousarray(vals, np.float64)
+        self._ck(self.L.imdgpu_dist_allreduce_sum(self.h, a.ctypes.data_as(self.C.POINTER(self.C.c_double)), len(a)))
+        return [float(v) for v in a]
+
     def dist_set_plan(self, send_peer, send_cnt, send_shift, send_idx, recv_peer, recv_cnt):
         C = self.C
         ip = C.POINTER(C.c_int)
@@ -844,7 +955,7 @@ class GpuOps:
 
     def ttm_mailbox_attach(self, mm, per, rank, world, nbr):
         C = self.C
-        base = C.addressof(C.c_char.from_buffer(mm))
+        base = mm.value if isinstance(mm, C.c_void_p) else C.addressof(C.c_char.from_buffer(mm))
         arr = (C.c_int * 6)(*[int(v) for v in nbr])
         self._ck(self.L.imdgpu_ttm_mailbox_attach(self.h, C.c_void_p(base), per, int(rank), int(world), arr))
 

@@ -354,6 +354,37 @@ int imdgpu_dist_set_ttm_blocks(imdgpu_ctx *ctx, const int *offs);
 int imdgpu_dist_md_step(imdgpu_ctx *ctx, int steps, int *rebuild_needed);
 /* sum of n <= 16 host doubles over the ranks (energies) */
 int imdgpu_dist_allreduce_sum(imdgpu_ctx *ctx, double *vals, int n);
+/* The REBUILD, native too (a C host needs no other layer): what fix_cells -> send_atoms (imd_fix_cells_3d.c:43-306,
+ * 436-542; atom records of imd_mpi_util.c:349-650) and the first send_cells of a new list (imd_comm_force_3d.c:222-396,
+ * buffers of imd_mpi_util.c:850-1059) do in the reference: migration along x, y, z (counts, then 10 doubles per atom),
+ * re-binning, per-cell counts to the 26 peers, ghost layout and send index lists (built on the device), tile choice,
+ * first halo, imdgpu_make_nblist.  Collective: every rank calls it; ranks are numbered x slowest, z fastest
+ * (rank = (cx * cpu_dim.y + cy) * cpu_dim.z + cz as in imd_geom_mpi_3d.c:32-90 with MPI_Cart_create's row-major order). */
+int imdgpu_dist_rebuild(imdgpu_ctx *ctx);
+int imdgpu_dist_rebuild_count(imdgpu_ctx *ctx, int *n);
+/* one MD step of a multi-rank run for a C host: imdgpu_dist_rebuild when the list is stale, then imdgpu_dist_md_step
+ * (the main_loop body, imd_main_3d.c:406-812, with calc_forces / calc_ttm / move_atoms / check_nblist on the device) */
+int imdgpu_dist_step(imdgpu_ctx *ctx, int steps);
+/* complete forces of the CURRENT positions (three passes with their halos), e.g. before imdgpu_download_atoms */
+int imdgpu_dist_calc_forces(imdgpu_ctx *ctx);
+/* the static part of the plan, host only (inspection, tests): the 26 directions in the fixed order of the exchange
+ * (dx slowest; (0,0,0) skipped).  seg_out: 6 ints per direction {dx, dy, dz, rank the boundary layer goes to or -1, rank
+ * whose layer fills my ghost region or -1, cells of the layer}; shift_out: 3 doubles per direction (periodic image shift
+ * the SENDER adds, imd_comm_force_3d.c:247-266); send_cells / recv_cells (may be NULL): linear cell indices of the layers
+ * that are really sent / received, direction after direction. */
+int imdgpu_dist_plan_geometry(const int cpu_dim[3], const int my_coord[3], const int cell_dim[3], const int pbc_dirs[3],
+                              const double box[9], int *seg_out, double *shift_out, int *send_cells, int *nsend_cells,
+                              int *recv_cells, int *nrecv_cells);
+/* In-process transport: the ranks are contexts of ONE process, each driven by its own host thread (rehearsals of many
+ * ranks on one GPU -- a GPU box admits only a few processes --, or one process driving all GPUs of a node with peer
+ * copies).  Same contract as the host callback; every collective call must be made by all ranks of the group. */
+int imdgpu_local_group_create(int nranks, void **group);
+void imdgpu_local_group_destroy(void *group);
+int imdgpu_local_group_barrier(void *group);
+/* a zero-filled page-locked host region that all ranks of the group see under one name (e.g. the TTM face mailbox of
+ * imdgpu_ttm_mailbox_attach); the first caller allocates, later callers get the same pointer; freed with the group */
+int imdgpu_local_group_shared(void *group, const char *name, size_t bytes, void **ptr);
+int imdgpu_dist_init_local(imdgpu_ctx *ctx, void *group, int rank);
 
 /* ---- profiling ------------------------------------------------------------ */
 /* Accumulate HIP-event timings per kernel class on the context's stream. */

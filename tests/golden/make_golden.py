@@ -25,6 +25,8 @@ from imd_amd import potential  # noqa: E402
 from oracle import pyoracle as po  # noqa: E402
 
 REFBIN = os.path.join(ROOT, "oracle", "_ref")
+import shutil  # noqa: E402
+MPIEXEC = shutil.which("mpiexec") or "/opt/conda/bin/mpiexec"
 OUT = os.path.dirname(os.path.abspath(__file__))
 
 COMMON = """coordname _fcc
@@ -96,6 +98,13 @@ CASES = {
     "ttm_adv": dict(binary="imd_mpi_eam_ttm3d_nbl", box="19 8 6", temp=0.12, steps=60, dump=None, full=[],
                     pot="eam", nbl=True, cpu="2 1 1", ttm=dict(fd_ext="1 1 3", n=100, min_atoms=5),
                     env=dict(IMD_PROBE_ADV="1")),
+    # BASELINE config 4's layout at fixture size: the reference itself on 2x2x2 ranks (mpiexec -n 8), 16 384 atoms, every
+    # rank's memory dumped and assembled into global arrays (SURVEY 8c golden (1)); see run_mpi_case
+    "eam_nbl_16384_mpi8": dict(binary="imd_mpi_eam_nve_nbl", box="16 16 16", temp=0.06, steps=20, dump=[0, 20], full=[],
+                               pot="eam", nbl=True, cpu="2 2 2", extra="msgbuf_size 3.0\n"),
+    # the same grid with the 3D TTM: eight lattice blocks of 4^3 FD cells with MPI ghost faces, assembled into the 8^3 lattice
+    "ttm_16384_mpi8": dict(binary="imd_mpi_eam_ttm3d_nbl", box="16 16 16", temp=0.03, steps=3, dump=[0, 1, 2, 3], full=[],
+                           pot="eam", nbl=True, cpu="2 2 2", extra="msgbuf_size 3.0\n", ttm=dict(fd_ext="1 1 1", n=100, min_atoms=5)),
     "eam_cellpair_2048": dict(binary="imd_eam_nve", box="8 8 8", temp=0.0258, steps=10, dump=[0, 10], full=[0, 10],
                               pot="eam", nbl=False),
 }
@@ -383,7 +392,7 @@ def run_adv_case(name, c):
         par, eos = write_inputs(c, d)
         env = dict(os.environ, IMD_PROBE_DIR=d, IMD_PROBE_STEPS=",".join(map(str, range(nsteps + 1))))
         env.update(c["env"])
-        r = subprocess.run(["mpiexec", "-n", "2", os.path.join(REFBIN, c["binary"]), "-p", "t.param"], cwd=d, env=env,
+        r = subprocess.run([MPIEXEC, "-n", "2", os.path.join(REFBIN, c["binary"]), "-p", "t.param"], cwd=d, env=env,
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             print(r.stdout[-3000:])
@@ -454,6 +463,85 @@ def run_adv_case(name, c):
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **out)
     print("%-20s %8.1f KB  kept steps=%s  steps with flux=%s" % (name, os.path.getsize(path) / 1024, keep, moved))
+
+
+def run_mpi_case(name, c):
+    """The reference on a rank grid (mpiexec -n P): every rank's probe dump assembled into GLOBAL arrays.
+    Atoms: the inner atoms of all ranks concatenated (rank order, cell order inside a rank) -- positions, momenta, forces,
+    energies by atom number; sums are the reference's all-reduced globals.  TTM: every rank's lattice block put at its place
+    in the global lattice (inner cells; the outer ghost shell stays zero)."""
+    cpu = [int(v) for v in c["cpu"].split()]
+    world = cpu[0] * cpu[1] * cpu[2]
+    with tempfile.TemporaryDirectory() as d:
+        par, eos = write_inputs(c, d)
+        env = dict(os.environ, IMD_PROBE_DIR=d, IMD_PROBE_STEPS=",".join(map(str, c["dump"])))
+        env.update(c.get("env", {}))
+        r = subprocess.run([MPIEXEC, "-n", str(world), os.path.join(REFBIN, c["binary"]), "-p", "t.param"], cwd=d, env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            print(r.stdout[-3000:])
+            raise SystemExit("reference run failed for %s" % name)
+        P = {s: [po.read_probe(os.path.join(d, "probe.%d.%d.bin" % (rk, s))) for rk in range(world)] for s in c["dump"]}
+        T = {s: [po.read_ttm_probe(os.path.join(d, "ttm.%d.%d.bin" % (rk, s))) for rk in range(world)] for s in c["dump"]} if "ttm" in c else {}
+    P0 = P[c["dump"][0]][0]
+    out = dict(case=name, param_file=par, steps=np.array(c["dump"]), full_steps=np.array([], int), cpu_dim=np.array(cpu))
+    for k in ("ntypes", "global_cell_dim", "pbc_dirs", "box", "cellsz", "nbl_margin", "timestep", "natoms", "flags"):
+        out[k] = P0[k]
+    out["cell_dim"] = np.array(P0["global_cell_dim"]) + 2              # the single-domain layout the other fixtures use
+    for tk in ("pair_pot", "rho_h_tab", "embed_pot"):
+        if P0[tk] is not None:
+            for f, v in P0[tk].items():
+                out["%s_%s" % (tk, f)] = v
+    for s in c["dump"]:
+        pre = "s%d_" % s
+        for k in ("tot_pot_energy", "virial", "tot_kin_energy", "nbl_count"):
+            out[pre + k] = P[s][0][k]
+        if s not in (c["dump"][0], c["dump"][-1]):
+            continue                                    # per-atom arrays of the first and the last dumped step only
+        cols = {k: [] for k in ("nummer", "sorte", "ort", "masse", "impuls", "kraft", "pot_eng", "eam_rho", "eam_dF", "numneighs", "rank")}
+        for rk, Pr in enumerate(P[s]):
+            assert tuple(Pr["cpu_dim"]) == tuple(cpu) and Pr["myid"] == rk
+            start = np.concatenate([[0], np.cumsum(Pr["cell_n"])])
+            inner_idx = np.concatenate([np.arange(start[cc], start[cc + 1]) for cc in Pr["cells"]] + [np.zeros(0, int)]).astype(int)
+            cols["nummer"].append(Pr["all_nummer"][inner_idx]); cols["sorte"].append(Pr["all_sorte"][inner_idx])
+            cols["ort"].append(Pr["all_ort"][inner_idx])
+            for k in ("masse", "impuls", "kraft", "pot_eng", "eam_rho", "eam_dF", "numneighs"):
+                cols[k].append(Pr[k])
+            cols["rank"].append(np.full(len(inner_idx), rk))
+        for k, v in cols.items():
+            a = np.concatenate(v)
+            out[pre + k] = a.astype(np.int32) if k in ("nummer", "numneighs") else a.astype(np.int8) if k in ("sorte", "rank") else a
+        assert len(np.unique(out[pre + "nummer"])) == out["natoms"]
+    if T:
+        T0 = T[c["dump"][0]][0]
+        for k in ("fd_ext", "fd_min_atoms", "diff_substeps", "fd_n_timesteps", "fd_h", "fd_vol", "neighvol",
+                  "atomic_weight", "atomic_charge", "tau", "omega_laser"):
+            out["ttm_" + k] = T0[k]
+        ld = np.array(T0["fd_dim"]) - 2
+        gd = ld * np.array(cpu) + 2
+        out["ttm_fd_dim"] = gd
+        for k, v in eos.items():
+            out["eos_" + k] = v
+        for s in c["dump"]:
+            for tag in ("update_fd", "substeps_done"):
+                for f in po.TTM_REC.names:
+                    if tag == "update_fd" and f not in ("natoms", "md_temp", "dens", "temp", "xi"):
+                        continue
+                    if tag == "substeps_done" and f not in ("natoms", "temp", "xi", "fd_k", "fd_g", "Ce", "U", "md_temp", "dens"):
+                        continue
+                    a0 = T[s][0]["stages"][tag]["lat"][f]
+                    g = np.zeros(tuple(gd) + a0.shape[3:], a0.dtype)
+                    for rk in range(world):
+                        co = (rk // (cpu[1] * cpu[2]), (rk // cpu[2]) % cpu[1], rk % cpu[2])
+                        blk = T[s][rk]["stages"][tag]["lat"][f][1:-1, 1:-1, 1:-1]
+                        sl = tuple(slice(1 + co[q] * ld[q], 1 + (co[q] + 1) * ld[q]) for q in range(3))
+                        g[sl] = blk
+                    out["t%d_%s_%s" % (s, tag, f)] = g
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    last = c["dump"][-1]
+    print("%-20s %8.1f KB  ranks=%d steps=%s nbl_count(last)=%d maxF=%.3g" %
+          (name, os.path.getsize(path) / 1024, world, c["dump"], out["s%d_nbl_count" % last], np.abs(out["s%d_kraft" % last]).max()))
 
 
 def run_chkpt_case():
@@ -548,5 +636,7 @@ if __name__ == "__main__":
             run_chkpt_case()
         elif n == "ttm_adv":
             run_adv_case(n, CASES[n])
+        elif n.endswith("_mpi8"):
+            run_mpi_case(n, CASES[n])
         else:
             run_case(n, CASES[n])

@@ -1,0 +1,136 @@
+"""BASELINE config 4's rank grid on the device path (run with -m gpu): 2x2x2 and a z split (1x1x2), NVE and TTM with the
+replicated and the decomposed lattice, every rank with its own libimdgpu context on cuda:0 and REAL device operations
+-- native rebuild (imdgpu_dist_rebuild: migration, counts, ghost layout, send lists, list) and native step
+(imdgpu_dist_md_step) over the library's in-process transport, the ranks being threads of one child process (a GPU box
+admits at most six processes on its card).  Expected values: the reference ITSELF on 2x2x2 MPI ranks
+(tests/golden/eam_nbl_16384_mpi8.npz, ttm_16384_mpi8.npz: mpiexec -n 8, every rank's memory dumped and assembled) and
+the single-domain fixtures for the z split.
+Reference: setup_mpi_topology imd_geom_mpi_3d.c:32-90, send_cells imd_comm_force_3d.c:222-396, send_atoms
+imd_fix_cells_3d.c:436-542, ttm_fill_ghost_layers imd_ttm_3D.c:3314-3504."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+from tests import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(case, cpu_dim, nsteps, ttm=False, decomposed=False):
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "res.npz")
+        env = dict(os.environ, GPU_MAX_HW_QUEUES="32", PYTHONPATH=ROOT)     # 8 ranks x 2 streams: polling lattice kernels of different ranks must not share a queue
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "local_ranks_worker.py"), case] + [str(v) for v in cpu_dim] +
+                           [str(nsteps), str(int(ttm)), str(int(decomposed)), out], env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True, timeout=900)
+        assert r.returncode == 0, "local ranks %s failed:\n%s" % (str(cpu_dim), r.stdout[-4000:])
+        R = dict(np.load(out))
+    world = int(np.prod(cpu_dim))
+    assert "in-process" in str(R["transport"])
+    return R, world
+
+
+def _cat(R, world, k):
+    return np.concatenate([R["r%d_%s" % (r, k)] for r in range(world)])
+
+
+def _check_atoms(R, world, G, step, forces=True):
+    ids, pos = _cat(R, world, "nummer"), _cat(R, world, "ort")
+    pre = "s%d_" % step
+    assert len(ids) == len(G[pre + "nummer"]) == len(np.unique(ids))
+    o, go = np.argsort(ids), np.argsort(G[pre + "nummer"])
+    box = np.diag(G["box"])
+    dx = pos[o] - G[pre + "ort"][go]; dx -= np.round(dx / box) * box
+    assert np.abs(dx).max() < 1e-9
+    if forces:
+        frc = _cat(R, world, "kraft")
+        assert np.abs(frc[o] - G[pre + "kraft"][go]).max() < 1e-9 * np.abs(G[pre + "kraft"]).max()
+        assert abs(R["r0_tot_pot_energy"] - float(G[pre + "tot_pot_energy"])) < 1e-9 * abs(float(G[pre + "tot_pot_energy"]))
+    return o, go
+
+
+def test_2x2x2_nve_against_the_reference_on_8_mpi_ranks():
+    """16 384 atoms on 2x2x2 ranks, 20 steps with a list rebuild and migration on the way: positions, forces, total energy
+    of the reference's own 8-rank run"""
+    G = gu.load("eam_nbl_16384_mpi8")
+    R, world = _run("eam_nbl_16384_mpi8", (2, 2, 2), 20)
+    _check_atoms(R, world, G, 20)
+    assert all(int(R["r%d_nrebuild" % r]) >= 2 for r in range(world))
+    assert all(int(R["r%d_list_mode" % r]) == 1 for r in range(world))          # the LDS-tile kernels, not the fallback
+    assert int(R["r0_natoms"]) == 16384
+
+
+@pytest.mark.parametrize("decomposed", [False, True])
+def test_2x2x2_ttm_against_the_reference_on_8_mpi_ranks(decomposed):
+    """the same grid with the 3D TTM (fd_ext 1 1 1: an 8^3 lattice, 4^3 per rank): atoms after 3 steps and the electron
+    lattice after the sub-steps of step 2 equal the reference's 8-rank run -- replicated lattice (all-gathered update_fd
+    blocks) and decomposed lattice (one block per rank, ghost faces exchanged per sub-step)"""
+    G = gu.load("ttm_16384_mpi8")
+    R, world = _run("ttm_16384_mpi8", (2, 2, 2), 3, ttm=True, decomposed=decomposed)
+    o, go = _check_atoms(R, world, G, 3, forces=False)
+    nn = _cat(R, world, "numneighs")
+    assert np.array_equal(nn[o], G["s3_numneighs"][go])
+    ref = G["t2_substeps_done_temp"][1:-1, 1:-1, 1:-1]
+    refx = G["t2_substeps_done_xi"][1:-1, 1:-1, 1:-1]
+    if not decomposed:
+        for r in range(world):
+            assert np.array_equal(R["r%d_lat_natoms" % r][1:-1, 1:-1, 1:-1], G["t2_substeps_done_natoms"][1:-1, 1:-1, 1:-1])
+            assert np.abs(R["r%d_lat_temp" % r][1:-1, 1:-1, 1:-1] - ref).max() < 1e-10 * np.abs(ref).max()
+            assert np.abs(R["r%d_lat_xi" % r][1:-1, 1:-1, 1:-1] - refx).max() < 1e-9 * np.abs(refx).max()
+    else:
+        full = np.zeros_like(ref)
+        for r in range(world):
+            blk = R["r%d_lat_temp" % r][1:-1, 1:-1, 1:-1]
+            c, n = R["r%d_coord" % r], blk.shape
+            full[c[0] * n[0]:(c[0] + 1) * n[0], c[1] * n[1]:(c[1] + 1) * n[1], c[2] * n[2]:(c[2] + 1) * n[2]] = blk
+        assert np.abs(full - ref).max() < 1e-10 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("cpu_dim", [(1, 1, 2), (2, 2, 2)])
+def test_z_split_and_cube_on_the_single_domain_fixture(cpu_dim):
+    """2 048 atoms (4x4x4 MD cells: two cells per rank and direction on 2x2x2 -- every cell of a rank is a boundary cell and
+    most peers are reached in several directions) against the reference's single-domain trajectory"""
+    G = gu.load("eam_nbl_2048")
+    R, world = _run("eam_nbl_2048", cpu_dim, 20)
+    _check_atoms(R, world, G, 20)
+
+
+@pytest.mark.parametrize("decomposed", [False, True])
+def test_z_split_ttm(decomposed):
+    G = gu.load("ttm_2048")
+    R, world = _run("ttm_2048", (1, 1, 2), 3, ttm=True, decomposed=decomposed)
+    _check_atoms(R, world, G, 3, forces=False)
+    ref = G["t2_substeps_done_temp"][1:-1, 1:-1, 1:-1]
+    full = np.zeros_like(ref)
+    for r in range(world):
+        blk = R["r%d_lat_temp" % r][1:-1, 1:-1, 1:-1]
+        if not decomposed:
+            assert np.abs(blk - ref).max() < 1e-10 * np.abs(ref).max()
+            continue
+        c, n = R["r%d_coord" % r], blk.shape
+        full[c[0] * n[0]:(c[0] + 1) * n[0], c[1] * n[1]:(c[1] + 1) * n[1], c[2] * n[2]:(c[2] + 1) * n[2]] = blk
+    if decomposed:
+        assert np.abs(full - ref).max() < 1e-10 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("args", [("2", "1", "1", "25", "0"), ("2", "2", "2", "25", "0"), ("1", "2", "2", "6", "1")])
+def test_c_host_without_python_drives_the_ranks(args):
+    """imd_amd/host/dist_host.c: a plain C program (threads as ranks, imdgpu_dist_init_local + imdgpu_dist_step) against its
+    own single-rank imdgpu_md_step run of the same atoms: the whole multi-rank loop -- rebuilds included -- needs no host
+    layer but the C ABI"""
+    src = os.path.join(ROOT, "imd_amd", "host", "dist_host.c")
+    lib = os.path.join(ROOT, "imd_amd", "csrc")
+    with tempfile.TemporaryDirectory() as d:
+        exe = os.path.join(d, "dist_host")
+        b = subprocess.run(["gcc", "-O2", "-o", exe, src, "-I" + os.path.join(ROOT, "include"), "-L" + lib, "-limdgpu", "-lpthread",
+                            "-lm", "-Wl,-rpath," + lib], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert b.returncode == 0, b.stdout
+        r = subprocess.run([exe] + list(args), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600,
+                           env=dict(os.environ, GPU_MAX_HW_QUEUES="32"))
+        assert r.returncode == 0, r.stdout[-3000:]
+        assert "max |dx|" in r.stdout
