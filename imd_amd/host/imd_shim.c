@@ -492,6 +492,59 @@ static unsigned char *eos_triangulation(nn_interp *nn, int nx, int ny, const dou
   return d;
 }
 
+/* the host lattice l1/l2 -> the device lattice.  Used once when the device lattice is created: it starts from the HOST
+ * lattice as init_ttm left it -- on a restart (imdrestart > 0) ttm_read has filled l1/l2 with the checkpointed electron
+ * state (imd_ttm_3D.c:1284-1290, :2128-2330: natoms, temp, md_temp, U, xi, source, dens, vcom, fd_k, fd_g, Z, Ce); on a
+ * fresh start the same upload carries init_ttm's zeros.  Later host-side edits of l1/l2 between steps are NOT seen by the
+ * whole-step calc_ttm (level 1); the per-function entry points below (IMD_SHIM_TTM_FUNCTIONS) upload
+ * before every call. */
+static void lattice_to_device(int with_source)
+{
+  imdgpu_ttm_fields F;
+  int i, j, kk, c = 0;
+  for (i = 0; i < local_fd_dim.x; i++)
+    for (j = 0; j < local_fd_dim.y; j++)
+      for (kk = 0; kk < local_fd_dim.z; kk++, c++) {
+        const ttm_Element *e = &l1[i][j][kk], *e2 = &l2[i][j][kk];
+        g_fi[0][c] = e->natoms; g_fi[1][c] = e->natoms_old;
+        g_fd[0][c] = e->temp; g_fd[1][c] = e2->temp; g_fd[2][c] = e->xi; g_fd[3][c] = e->md_temp; g_fd[4][c] = e->source;
+        g_fd[5][3 * c] = e->vcomx; g_fd[5][3 * c + 1] = e->vcomy; g_fd[5][3 * c + 2] = e->vcomz;
+        g_fd[6][c] = e->dens; g_fd[7][c] = e->fd_k; g_fd[8][c] = e->fd_g; g_fd[9][c] = e->Z; g_fd[10][c] = e->Ce;
+        g_fd[11][c] = e->ne; g_fd[12][c] = e->U; g_fd[13][c] = e2->U;
+      }
+  memset(&F, 0, sizeof(F));
+  F.natoms = g_fi[0]; F.natoms_old = g_fi[1];
+  F.temp = g_fd[0]; F.temp2 = g_fd[1]; F.xi = g_fd[2]; F.md_temp = g_fd[3]; F.vcom = g_fd[5];
+  if (with_source) F.source = g_fd[4];          /* a host that calls the pieces may have written l1.source itself */
+  F.dens = g_fd[6]; F.fd_k = g_fd[7]; F.fd_g = g_fd[8]; F.Z = g_fd[9]; F.Ce = g_fd[10]; F.ne = g_fd[11];
+  F.U = g_fd[12]; F.U2 = g_fd[13];
+  gpu_check(imdgpu_ttm_upload(G, &F));
+}
+/* the device lattice -> l1/l2 (l1 = the current lattice, l2 = the other half of the ping-pong pairs) */
+static void lattice_to_host(void)
+{
+  imdgpu_ttm_fields F;
+  int i, j, k, c = 0;
+  memset(&F, 0, sizeof(F));
+  F.natoms = g_fi[0]; F.natoms_old = g_fi[1];
+  F.temp = g_fd[0]; F.temp2 = g_fd[1]; F.xi = g_fd[2]; F.md_temp = g_fd[3]; F.source = g_fd[4]; F.vcom = g_fd[5];
+  F.dens = g_fd[6]; F.fd_k = g_fd[7]; F.fd_g = g_fd[8]; F.Z = g_fd[9]; F.Ce = g_fd[10]; F.ne = g_fd[11];
+  F.U = g_fd[12]; F.U2 = g_fd[13];
+  gpu_check(imdgpu_ttm_download(G, &F));
+  for (i = 0; i < local_fd_dim.x; i++)
+    for (j = 0; j < local_fd_dim.y; j++)
+      for (k = 0; k < local_fd_dim.z; k++, c++) {
+        ttm_Element *e = &l1[i][j][k], *e2 = &l2[i][j][k];
+        e->natoms = e2->natoms = F.natoms[c]; e->natoms_old = e2->natoms_old = F.natoms_old[c];
+        e->temp = F.temp[c]; e2->temp = F.temp2[c];
+        e->U = F.U[c]; e2->U = F.U2[c];
+        e->xi = e2->xi = F.xi[c]; e->md_temp = e2->md_temp = F.md_temp[c]; e->source = e2->source = F.source[c];
+        e->vcomx = e2->vcomx = F.vcom[3 * c]; e->vcomy = e2->vcomy = F.vcom[3 * c + 1]; e->vcomz = e2->vcomz = F.vcom[3 * c + 2];
+        e->dens = e2->dens = F.dens[c];
+        e->fd_k = F.fd_k[c]; e->fd_g = F.fd_g[c]; e->Z = F.Z[c]; e->Ce = F.Ce[c]; e->ne = F.ne[c];
+      }
+}
+
 static void ttm_gpu_init(void)
 {
   imdgpu_ttm_params par;
@@ -573,37 +626,13 @@ static void ttm_gpu_init(void)
   g_fdn = dim[0] * dim[1] * dim[2];
   for (k = 0; k < 2; k++) g_fi[k] = (int *) malloc(g_fdn * sizeof(int));
   for (k = 0; k < 15; k++) g_fd[k] = (double *) malloc((k == 5 ? 3 : 1) * (size_t) g_fdn * sizeof(double));
-  /* the device lattice starts from the HOST lattice as init_ttm left it: on a restart (imdrestart > 0) ttm_read has
-   * filled l1/l2 with the checkpointed electron state (imd_ttm_3D.c:1284-1290, :2128-2330: natoms, temp, md_temp, U, xi,
-   * source, dens, vcom, fd_k, fd_g, Z, Ce); on a fresh start the same upload carries init_ttm's zeros.  Later host-side
-   * edits of l1/l2 between steps are NOT seen by the device (level 1). */
-  {
-    imdgpu_ttm_fields F;
-    int i, j, kk, c = 0;
-    for (i = 0; i < local_fd_dim.x; i++)
-      for (j = 0; j < local_fd_dim.y; j++)
-        for (kk = 0; kk < local_fd_dim.z; kk++, c++) {
-          const ttm_Element *e = &l1[i][j][kk], *e2 = &l2[i][j][kk];
-          g_fi[0][c] = e->natoms; g_fi[1][c] = e->natoms_old;
-          g_fd[0][c] = e->temp; g_fd[1][c] = e2->temp; g_fd[2][c] = e->xi; g_fd[3][c] = e->md_temp; g_fd[4][c] = e->source;
-          g_fd[5][3 * c] = e->vcomx; g_fd[5][3 * c + 1] = e->vcomy; g_fd[5][3 * c + 2] = e->vcomz;
-          g_fd[6][c] = e->dens; g_fd[7][c] = e->fd_k; g_fd[8][c] = e->fd_g; g_fd[9][c] = e->Z; g_fd[10][c] = e->Ce;
-          g_fd[11][c] = e->ne; g_fd[12][c] = e->U; g_fd[13][c] = e2->U;
-        }
-    memset(&F, 0, sizeof(F));
-    F.natoms = g_fi[0]; F.natoms_old = g_fi[1];
-    F.temp = g_fd[0]; F.temp2 = g_fd[1]; F.xi = g_fd[2]; F.md_temp = g_fd[3]; F.vcom = g_fd[5];
-    F.dens = g_fd[6]; F.fd_k = g_fd[7]; F.fd_g = g_fd[8]; F.Z = g_fd[9]; F.Ce = g_fd[10]; F.ne = g_fd[11];
-    F.U = g_fd[12]; F.U2 = g_fd[13];
-    gpu_check(imdgpu_ttm_upload(G, &F));
-  }
+  lattice_to_device(0);
   g_ttm_ready = 1;
 }
 
 void calc_ttm(void)
 {
-  imdgpu_ttm_fields F;
-  int n, i, j, k, c = 0;
+  int n;
   double mdt = 0.0;
   gpu_init();
   if (!g_have_cells) error("imd_shim: calc_ttm before calc_forces");
@@ -623,23 +652,60 @@ void calc_ttm(void)
   if (g_multi) { double m2; MPI_Allreduce(&mdt, &m2, 1, MPI_DOUBLE, MPI_MIN, cpugrid); mdt = m2; }   /* :2683-2687 */
 #endif
   max_dt_ttm = mdt;
-  memset(&F, 0, sizeof(F));
-  F.natoms = g_fi[0]; F.natoms_old = g_fi[1];
-  F.temp = g_fd[0]; F.temp2 = g_fd[1]; F.xi = g_fd[2]; F.md_temp = g_fd[3]; F.source = g_fd[4]; F.vcom = g_fd[5];
-  F.dens = g_fd[6]; F.fd_k = g_fd[7]; F.fd_g = g_fd[8]; F.Z = g_fd[9]; F.Ce = g_fd[10]; F.ne = g_fd[11];
-  F.U = g_fd[12]; F.U2 = g_fd[13];
-  gpu_check(imdgpu_ttm_download(G, &F));
-  for (i = 0; i < local_fd_dim.x; i++)
-    for (j = 0; j < local_fd_dim.y; j++)
-      for (k = 0; k < local_fd_dim.z; k++, c++) {
-        ttm_Element *e = &l1[i][j][k], *e2 = &l2[i][j][k];
-        e->natoms = e2->natoms = F.natoms[c]; e->natoms_old = e2->natoms_old = F.natoms_old[c];
-        e->temp = F.temp[c]; e2->temp = F.temp2[c];
-        e->U = F.U[c]; e2->U = F.U2[c];
-        e->xi = e2->xi = F.xi[c]; e->md_temp = e2->md_temp = F.md_temp[c]; e->source = e2->source = F.source[c];
-        e->vcomx = e2->vcomx = F.vcom[3 * c]; e->vcomy = e2->vcomy = F.vcom[3 * c + 1]; e->vcomz = e2->vcomz = F.vcom[3 * c + 2];
-        e->dens = e2->dens = F.dens[c];
-        e->fd_k = F.fd_k[c]; e->fd_g = F.fd_g[c]; e->Z = F.Z[c]; e->Ce = F.Ce[c]; e->ne = F.ne[c];
-      }
+  lattice_to_host();
 }
+
+#ifdef IMD_SHIM_TTM_FUNCTIONS
+/* ---- the lattice functions one by one, under the reference's own names and signatures -------------------------------
+ *     void update_fd(void);              (prototypes.h:1021, imd_ttm_3D.c:233)
+ *     void do_ADV(double tau);           (prototypes.h:143,  imd_ttm_3D.c:1321)   [option ttm_adv: IMD_SHIM_TTM_ADV=1]
+ *     void do_cell_activation(void);     (prototypes.h:147,  imd_ttm_3D.c:1468)
+ *     void do_FILLMESH(void);            (prototypes.h:141,  imd_ttm_3D.c:492)
+ *     void ttm_fill_ghost_layers(void);  (prototypes.h:1018, imd_ttm_3D.c:3314)
+ *     void do_DIFF(double tau);          (prototypes.h:145,  imd_ttm_3D.c:1603)
+ *     void CFL_maxdt(void);              (prototypes.h:153,  imd_ttm_3D.c:2637)
+ * for hosts that keep their own calc_ttm (or a variant of it) and call the pieces.  Each call is
+ *   l1/l2 -> device, the matching imdgpu_ttm_* call, device -> l1/l2,
+ * i.e. it honours whatever the host did to the lattice in between (level 1: two 10-MB copies per call at config 3's size;
+ * the whole-step calc_ttm above is the fast path).  Compile imd_ttm_3D.c with -Dupdate_fd=update_fd_host ... (one -D per
+ * name, no source change) so that these definitions are the ones that link; one rank only (on several ranks the faces go
+ * through the mailbox inside the whole-step calc_ttm). */
+static void fn_begin(const char *who)
+{
+  gpu_init();
+  if (g_multi) error("imd_shim: the per-function TTM entry points serve one rank; use calc_ttm on several");
+  if (!g_have_cells) error("imd_shim: TTM function called before calc_forces");
+  if (!g_ttm_ready) ttm_gpu_init();
+  lattice_to_device(1);
+  (void) who;
+}
+void update_fd(void)
+{
+  int n;
+  fn_begin("update_fd");
+  n = count_atoms();
+  ensure_host(n);
+  gather_cells(1);
+  gpu_check(imdgpu_update_momenta(G, n, g_imp));          /* update_fd reads IMPULS (:323-325,431-436) and NUMNEIGHS of the last calc_forces */
+  gpu_check(imdgpu_ttm_update_fd(G, steps));
+  lattice_to_host();
+}
+void do_ADV(double tau)
+{
+  fn_begin("do_ADV");
+  gpu_check(imdgpu_ttm_adv(G, tau, steps));
+  lattice_to_host();
+}
+void do_cell_activation(void) { fn_begin("do_cell_activation"); gpu_check(imdgpu_ttm_cell_activation(G)); lattice_to_host(); }
+void do_FILLMESH(void) { fn_begin("do_FILLMESH"); gpu_check(imdgpu_ttm_fillmesh(G, steps)); lattice_to_host(); }
+void ttm_fill_ghost_layers(void) { fn_begin("ttm_fill_ghost_layers"); gpu_check(imdgpu_ttm_fill_ghost_layers(G)); lattice_to_host(); }
+void do_DIFF(double tau) { fn_begin("do_DIFF"); gpu_check(imdgpu_ttm_diff(G, tau)); lattice_to_host(); }
+void CFL_maxdt(void)
+{
+  double mdt = 0.0;
+  fn_begin("CFL_maxdt");
+  gpu_check(imdgpu_ttm_cfl_maxdt(G, steps, &mdt));
+  max_dt_ttm = mdt;
+}
+#endif /* IMD_SHIM_TTM_FUNCTIONS */
 #endif /* TTM */

@@ -185,6 +185,40 @@ build_dropin_ttm() {
 }
 case " $TARGETS " in *" dropin "*) build_dropin_ttm ;; esac
 
+# The 3D TTM program with the lattice functions forwarded ONE BY ONE (imd_shim.c, -DIMD_SHIM_TTM_FUNCTIONS): imd_ttm_3D.c is
+# compiled with its update_fd, do_ADV, do_cell_activation, do_FILLMESH, ttm_fill_ghost_layers, do_DIFF, CFL_maxdt renamed
+# (-Dname=name_host, no source change), so the probe's calc_ttm sequence (ref_probe_ttm.c: the reference's own call order,
+# function by function) calls the shim's versions of exactly these names.  tests/test_gpu_dropin.py compares it with the CPU
+# build, whose probe drives the reference's own functions in the same order.
+build_dropin_ttm_fn() {
+  local name="mpi_eam_ttm3d_nbl_gpufn" defs="-DMPI -DNBL -DEAM2 -DTTM -DTMM -DEOSMODE=1"
+  local obj="$OUT/obj_$name" repo="$(cd "$HERE/.." && pwd)"
+  local MPIINC="${MPI_HOME:-/opt/conda}"
+  [ -f "$repo/imd_amd/csrc/libimdgpu.so" ] || { echo "libimdgpu.so not built, skipping drop-in" >&2; return 0; }
+  [ -f "$MPIINC/include/mpi.h" ] || { echo "no MPI at $MPIINC, skipping $name" >&2; return 0; }
+  local cc="$CC -I$MPIINC/include"
+  mkdir -p "$obj"
+  local objs=""
+  for s in $COMMON imd_geom_mpi_3d.c imd_comm_force_3d.c imd_fix_cells_3d.c imd_mpiio.c imd_mpi_util.c imd_interpol.c fminbnd3.c; do
+    local o="$obj/${s%.c}.o"
+    if [ ! -f "$o" ] || [ "$REF/$s" -nt "$o" ]; then $cc $BASEFLAGS $defs -c "$REF/$s" -o "$o" & fi
+    objs="$objs $o"
+  done
+  local ren="-Dcalc_ttm=calc_ttm_host -Dupdate_fd=update_fd_host -Ddo_ADV=do_ADV_host -Ddo_cell_activation=do_cell_activation_host"
+  ren="$ren -Ddo_FILLMESH=do_FILLMESH_host -Dttm_fill_ghost_layers=ttm_fill_ghost_layers_host -Ddo_DIFF=do_DIFF_host -DCFL_maxdt=CFL_maxdt_host"
+  $cc $BASEFLAGS $defs $ren -c "$REF/imd_ttm_3D.c" -o "$obj/imd_ttm_3D.o" &
+  wait
+  $cc $BASEFLAGS $defs -DIMD_SHIM_TTM_FUNCTIONS -fopenmp -I"$repo/include" -c "$repo/imd_amd/host/imd_shim.c" -o "$obj/imd_shim.o"
+  $cc $BASEFLAGS $defs -c "$HERE/ref_probe.c" -o "$obj/ref_probe.o"
+  $cc $BASEFLAGS $defs -c "$HERE/ref_probe_ttm.c" -o "$obj/ref_probe_ttm.o"
+  $cc -o "$OUT/imd_$name" $objs "$obj/imd_ttm_3D.o" "$obj/imd_shim.o" "$obj/ref_probe.o" "$obj/ref_probe_ttm.o" \
+      -Wl,--wrap=calc_forces -Wl,--wrap=calc_ttm -Wl,--wrap=tmm_init -Wl,--wrap=do_tmm \
+      "$REF/nn_interpol/libnn.a" -L"$repo/imd_amd/csrc" -limdgpu -Wl,-rpath,/root/repo/imd_amd/csrc -fopenmp \
+      -Wl,-rpath-link,/usr/lib/x86_64-linux-gnu "$MPIINC/lib/libmpi.so" -Wl,-rpath,"$MPIINC/lib" -lm
+  echo "built $OUT/imd_$name"
+}
+case " $TARGETS " in *" dropin "*) build_dropin_ttm_fn ;; esac
+
 # The MPI force program on several ranks with the shim: the reference keeps its own decomposition, migration and halo
 # exchange (send_cells inside the shim's calc_forces where imd_forces_nbl.c has them); every rank drives a GPU.
 # tests/test_gpu_dropin.py runs it with mpiexec -n 2 beside oracle/_ref/imd_mpi_eam_nve_nbl.

@@ -216,6 +216,46 @@ def test_reference_ttm_main_loop_on_gpu_forces_and_gpu_calc_ttm(eos):
         assert np.abs(x - y).max() > 1e-7 * np.abs(y).max()
 
 
+GPU_TTM_FN = os.path.join(ROOT, "oracle", "_ref", "imd_mpi_eam_ttm3d_nbl_gpufn")
+
+
+@pytest.mark.skipif(not (os.path.exists(CPU_TTM) and os.path.exists(GPU_TTM_FN)), reason="oracle/_ref binaries not built")
+def test_reference_calls_the_lattice_functions_one_by_one():
+    """The per-function boundary: update_fd, do_cell_activation, do_FILLMESH, ttm_fill_ghost_layers,
+    do_DIFF and CFL_maxdt exist in the shim under the reference's own names and signatures (prototypes.h:141-153,1018-1021).
+    In this build of the reference program imd_ttm_3D.c's definitions of these names are renamed at compile time, so the C
+    host sequence of oracle/ref_probe_ttm.c (calc_ttm's first block, one call per function, l1/l2 read by the host between
+    them) reaches the DEVICE through them: 1 + 1 + 1 + 1 + 100 x (1 + 1 + 1) + 1 calls per MD step, each
+    l1/l2 -> device -> call -> l1/l2.  Stage by stage the host's lattice equals the CPU build's, whose probe drives the
+    reference's own functions in the same order."""
+    out = {}
+    steps = (0, 1, 4)
+    par = PARAM_TTM.replace("maxsteps 12", "maxsteps 4")
+    for tag, exe in (("cpu", CPU_TTM), ("gpu", GPU_TTM_FN)):
+        with tempfile.TemporaryDirectory() as d:
+            potential.write_synthetic_eam_files(d)
+            _write_planar_eos(d)
+            open(os.path.join(d, "t.param"), "w").write(par)
+            env = dict(os.environ, IMD_PROBE_DIR=d, IMD_PROBE_STEPS=",".join(map(str, steps)))
+            r = subprocess.run([exe, "-p", "t.param"], cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                               text=True, timeout=900)
+            assert r.returncode == 0, r.stdout[-3000:]
+            out[tag] = {s: po.read_ttm_probe(os.path.join(d, "ttm.0.%d.bin" % s))["stages"] for s in steps}
+            out[tag]["atoms"] = po.read_probe(os.path.join(d, "probe.0.4.bin"))
+    inner = (slice(1, -1),) * 3
+    for s in steps:
+        for stage in ("update_fd", "fillmesh0", "diff_only1", "substep1", "substep2", "substeps_done", "cfl"):
+            a, b = out["gpu"][s][stage], out["cpu"][s][stage]
+            assert np.array_equal(a["lat"]["natoms"][inner], b["lat"]["natoms"][inner]), (s, stage)
+            for f in ("temp", "temp2", "U", "U2", "xi", "md_temp", "dens", "fd_k", "fd_g", "Ce"):
+                x, y = a["lat"][f][inner], b["lat"][f][inner]
+                assert np.abs(x - y).max() <= 1e-9 * max(np.abs(y).max(), 1e-300), (s, stage, f)
+        assert abs(out["gpu"][s]["cfl"]["max_dt_ttm"] - out["cpu"][s]["cfl"]["max_dt_ttm"]) <= 1e-9 * abs(out["cpu"][s]["cfl"]["max_dt_ttm"])
+    A, B = out["gpu"]["atoms"], out["cpu"]["atoms"]
+    oa, ob = np.argsort(_inner_ids(A)), np.argsort(_inner_ids(B))
+    assert np.abs(_inner_pos(A)[oa] - _inner_pos(B)[ob]).max() < 1e-9
+
+
 @pytest.mark.skipif(not (os.path.exists(CPU_TTM) and os.path.exists(GPU_TTM)), reason="oracle/_ref binaries not built")
 def test_reference_ttm_restart_keeps_the_electron_state_on_gpu():
     """a restarted run (`-r 1`: init_ttm -> ttm_read fills l1/l2 from out.1.ttm, imd_ttm_3D.c:1284-1290) must
