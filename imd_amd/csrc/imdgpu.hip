@@ -730,6 +730,28 @@ __device__ __forceinline__ int own_slot(const TileArgs &a, const TileCtx &T, int
 // force loops use every VGPR three waves per SIMD allow).  STG entries per thread cover STG*blockDim slots;
 // anything beyond (never at the tile shapes autotile picks) is staged by a plain loop.
 #define STG 5
+// LDS layout of the staged positions.  Default: x, y, z (, dF) planes of 8-byte records.  make EXTRA=-DPOSXY: (x, y) pairs in
+// one plane of 16-byte records and z in a plane of its own -- pass 3: (z, dF) pairs in the second plane --, i.e. one
+// ds_read_b128 + one ds_read_b64 per neighbour (pass 3: two ds_read_b128) instead of three (four) ds_read_b64.  Measured in
+// round 3 (profiles/r03_kernel_variants.json, 10 M atoms): without TTM pass 1 -0.9 %, pass 3 -1.7 %; but the 128-bit loads
+// need aligned register quads -- pass 3 grows from 138 to 148 VGPRs, three of its waves then leave no SIMD with the 80
+// registers a wave of the lattice chain needs, and the step WITH TTM gets 33 % slower (6.76 vs 5.07 ms).  Not the default.
+#ifdef POSXY
+#define LPOS_RD(sp, sw, cap, j, X, Y, Z) { const double2 q_ = ((const double2 *) (sp))[j]; X = q_.x; Y = q_.y; Z = (sp)[2 * (size_t) (cap) + (j)]; }
+#ifndef P3_SPLITZW
+#define LPOS_RDW(sp, sw, cap, j, X, Y, Z, W) { const double2 q_ = ((const double2 *) (sp))[j], r_ = ((const double2 *) (sp) + (cap))[j]; X = q_.x; Y = q_.y; Z = r_.x; W = r_.y; }
+#define LPOS_STW(sp, sw, cap, s, X, Y, Z, W) { ((double2 *) (sp))[s] = make_double2(X, Y); ((double2 *) (sp) + (cap))[s] = make_double2(Z, W); }
+#else
+#define LPOS_RDW(sp, sw, cap, j, X, Y, Z, W) { const double2 q_ = ((const double2 *) (sp))[j]; X = q_.x; Y = q_.y; Z = (sp)[2 * (size_t) (cap) + (j)]; W = (sw)[j]; }
+#define LPOS_STW(sp, sw, cap, s, X, Y, Z, W) { ((double2 *) (sp))[s] = make_double2(X, Y); (sp)[2 * (size_t) (cap) + (s)] = (Z); (sw)[s] = (W); }
+#endif
+#define LPOS_ST(sp, sw, cap, s, X, Y, Z) { ((double2 *) (sp))[s] = make_double2(X, Y); (sp)[2 * (size_t) (cap) + (s)] = (Z); }
+#else
+#define LPOS_RD(sp, sw, cap, j, X, Y, Z) { X = (sp)[j]; Y = (sp)[(cap) + (j)]; Z = (sp)[2 * (size_t) (cap) + (j)]; }
+#define LPOS_RDW(sp, sw, cap, j, X, Y, Z, W) { X = (sp)[j]; Y = (sp)[(cap) + (j)]; Z = (sp)[2 * (size_t) (cap) + (j)]; W = (sw)[j]; }
+#define LPOS_ST(sp, sw, cap, s, X, Y, Z) { (sp)[s] = (X); (sp)[(cap) + (s)] = (Y); (sp)[2 * (size_t) (cap) + (s)] = (Z); }
+#define LPOS_STW(sp, sw, cap, s, X, Y, Z, W) { (sp)[s] = (X); (sp)[(cap) + (s)] = (Y); (sp)[2 * (size_t) (cap) + (s)] = (Z); (sw)[s] = (W); }
+#endif
 __device__ __forceinline__ void stage_issue(const TileArgs &a, int tile, int nsl, int (&IDX)[STG])
 {
   const int *src = a.tsrc + (size_t) tile * a.slot_cap;
@@ -747,8 +769,8 @@ __device__ __forceinline__ void stage_commit(const TileArgs &a, int tile, int ns
   for (int u = 0; u < STG; u++) {
     const int s = threadIdx.x + u * blockDim.x;
     if (IDX[u] >= 0) {
-      sp[s] = P[u].x; sp[a.slot_cap + s] = P[u].y; sp[2 * a.slot_cap + s] = P[u].z;
-      if (WITH_W) sw[s] = P[u].w * wscale;
+      if (WITH_W) LPOS_STW(sp, sw, a.slot_cap, s, P[u].x, P[u].y, P[u].z, P[u].w * wscale)
+      else LPOS_ST(sp, sw, a.slot_cap, s, P[u].x, P[u].y, P[u].z)
       if (WITH_T) ts[s] = TT[u];
     }
   }
@@ -756,13 +778,13 @@ __device__ __forceinline__ void stage_commit(const TileArgs &a, int tile, int ns
   for (int s = threadIdx.x + STG * blockDim.x; s < nsl; s += blockDim.x) {
     const int gi = src[s];
     const double4 q = a.pos[gi];
-    sp[s] = q.x; sp[a.slot_cap + s] = q.y; sp[2 * a.slot_cap + s] = q.z;
-    if (WITH_W) sw[s] = q.w * wscale;
+    if (WITH_W) LPOS_STW(sp, sw, a.slot_cap, s, q.x, q.y, q.z, q.w * wscale)
+    else LPOS_ST(sp, sw, a.slot_cap, s, q.x, q.y, q.z)
     if (WITH_T) ts[s] = a.type[gi];
   }
   if (threadIdx.x == 0) {                          // the far-away dummy that pads the neighbour rows
-    sp[a.slot_cap - 1] = 1e150; sp[2 * a.slot_cap - 1] = 1e150; sp[3 * a.slot_cap - 1] = 1e150;
-    if (WITH_W) sw[a.slot_cap - 1] = 0.0;
+    if (WITH_W) LPOS_STW(sp, sw, a.slot_cap, a.slot_cap - 1, 1e150, 1e150, 1e150, 0.0)
+    else LPOS_ST(sp, sw, a.slot_cap, a.slot_cap - 1, 1e150, 1e150, 1e150)
     if (WITH_T) ts[a.slot_cap - 1] = 0;
   }
 }
@@ -1016,6 +1038,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile(TileArgs a)
   double *tp = lds;
   double *tr = tp + (PAIR ? a.pair.nrows * a.pair.ncols : 0);
   double *sp = tr + (EAM ? a.rho.nrows * a.rho.ncols : 0);
+  sp += ((size_t) sp >> 3) & 1;                         // 16-byte records (LPOS_*): tables may hold an odd number of doubles
   double *scratch = sp + 3 * (size_t) a.slot_cap;
   int *ts = (int *) (scratch + 64);
   TileCtx T;
@@ -1039,7 +1062,8 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile(TileArgs a)
     for (int o = threadIdx.x; o < T.nown; o += blockDim.x) {
       const int i = T.own_start + o;
       OWN_PROLOGUE
-      const double xi = sp[slot], yi = sp[a.slot_cap + slot], zi = sp[2 * a.slot_cap + slot];
+      double xi, yi, zi;
+      LPOS_RD(sp, sp, a.slot_cap, slot, xi, yi, zi)
       const int it = NT1 ? 0 : ts[slot];
       double fx = 0, fy = 0, fz = 0, ee = 0, rr = 0, vir = 0, r2min = 1e300;
       int nb = 0;
@@ -1051,7 +1075,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile(TileArgs a)
         double dx[UNR], dy[UNR], dz[UNR], r2[UNR];
 #pragma unroll
         for (int e = 0; e < UNR; e++) {                                   // phase 1: positions from LDS, all reads first
-          dx[e] = sp[j[e]]; dy[e] = sp[a.slot_cap + j[e]]; dz[e] = sp[2 * a.slot_cap + j[e]];
+          LPOS_RD(sp, sp, a.slot_cap, j[e], dx[e], dy[e], dz[e])
         }
         SCHED_BARRIER;
 #pragma unroll
@@ -1185,7 +1209,8 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
     for (int o = threadIdx.x; o < T.nown; o += blockDim.x) {
       const int i = T.own_start + o;
       OWN_PROLOGUE
-      const double xi = sp[slot], yi = sp[a.slot_cap + slot], zi = sp[2 * a.slot_cap + slot];
+      double xi, yi, zi;
+      LPOS_RD(sp, sp, a.slot_cap, slot, xi, yi, zi)
       double fx = 0, fy = 0, fz = 0, ee = 0, rr = 0, vir = 0;
       int nb = 0, sgn = 0;
       LIST_WORDS_BEGIN
@@ -1194,7 +1219,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
         double2 A[UNR], B[UNR], C[UNR];
         PRIO_HI;
 #pragma unroll
-        for (int e = 0; e < UNR; e++) { dx[e] = sp[j[e]]; dy[e] = sp[a.slot_cap + j[e]]; dz[e] = sp[2 * a.slot_cap + j[e]]; }
+        for (int e = 0; e < UNR; e++) LPOS_RD(sp, sp, a.slot_cap, j[e], dx[e], dy[e], dz[e])
         PRIO_LO;
         SCHED_BARRIER;
 #pragma unroll
@@ -1255,12 +1280,18 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
 // 144 VGPRs: three waves per SIMD then leave 80 registers free on EVERY SIMD, which is what one wave of the TTM
 // sub-step kernel needs -- the lattice chain that runs beside this pass gets four SIMDs per CU instead of one
 // RING = 0 beside the TTM chain (142 VGPRs), 4 otherwise (148): see LIST_WORDS_END
+#ifdef P3_VGPRS
+#define P3_ATTR __attribute__((amdgpu_num_vgpr(P3_VGPRS)))
+#else
+#define P3_ATTR
+#endif
 template <bool NT1, int RING>
-__global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass3_tile(TileArgs a)
+__global__ __launch_bounds__(TILE_MAXTHREADS) P3_ATTR void k_pass3_tile(TileArgs a)
 {
   extern __shared__ double lds[];
   double *tr = lds;                                      // rho_h_tab, one type: + zero rows for r2 >= end (no mask)
-  double *sp = tr + a.rho.nrows * a.rho.ncols + 4;      // xyz records (24 B) ...
+  double *sp = tr + a.rho.nrows * a.rho.ncols + 4;      // (x, y) records, then (z, dF) records (LPOS_*) ...
+  sp += ((size_t) sp >> 3) & 1;
   double *sw = sp + 3 * (size_t) a.slot_cap;             // ... and dF in its own array (fewer bank conflicts than 32 B records)
   double *scratch = sw + a.slot_cap;
   int *ts = (int *) (scratch + 64);
@@ -1286,7 +1317,8 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass3_tile(TileArgs a)
     for (int o = threadIdx.x; o < T.nown; o += blockDim.x) {
       const int i = T.own_start + o;
       OWN_PROLOGUE
-      const double xi = sp[slot], yi = sp[a.slot_cap + slot], zi = sp[2 * a.slot_cap + slot], wi = sw[slot];
+      double xi, yi, zi, wi;
+      LPOS_RDW(sp, sw, a.slot_cap, slot, xi, yi, zi, wi)
       const int it = NT1 ? 0 : ts[slot];
       double fx = 0, fy = 0, fz = 0, vir = 0, r2min = 1e300;
       int sgn = 0;
@@ -1298,9 +1330,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass3_tile(TileArgs a)
         double dx[UNR], dy[UNR], dz[UNR], wj[UNR], r2[UNR];
         PRIO_HI;
 #pragma unroll
-        for (int e = 0; e < UNR; e++) {
-          dx[e] = sp[j[e]]; dy[e] = sp[a.slot_cap + j[e]]; dz[e] = sp[2 * a.slot_cap + j[e]]; wj[e] = sw[j[e]];
-        }
+        for (int e = 0; e < UNR; e++) LPOS_RDW(sp, sw, a.slot_cap, j[e], dx[e], dy[e], dz[e], wj[e])
         PRIO_LO;
         SCHED_BARRIER;
 #pragma unroll
@@ -2225,8 +2255,8 @@ static size_t tile_lds_bytes(const imdgpu_ctx *ctx, int which /*0 build, 1 pass1
   size_t tp = ctx->pair.present ? (size_t) ctx->pair.par.nrows * ctx->pair.par.ncols : 0;
   size_t tr = ctx->rho.present ? (size_t) ctx->rho.par.nrows * ctx->rho.par.ncols : 0;
   if (which == 0) return align8((size_t) 3 * ctx->slot_cap * 8 + (size_t) (2 * NH_MAX + 1) * sizeof(int));
-  if (which == 1) return align8((tp + tr + 6 + 3 * (size_t) ctx->slot_cap + 64) * 8 + ints);
-  return align8((tr + 4 + 4 * (size_t) ctx->slot_cap + 64) * 8 + ints);
+  if (which == 1) return align8((tp + tr + 6 + 2 + 3 * (size_t) ctx->slot_cap + 64) * 8 + ints);
+  return align8((tr + 4 + 2 + 4 * (size_t) ctx->slot_cap + 64) * 8 + ints);
 }
 
 // Multi-rank set-ups call this between the ghost layout and make_nblist: it may re-sort the local atoms
