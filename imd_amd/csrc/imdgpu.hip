@@ -1601,7 +1601,9 @@ extern "C" int imdgpu_get_info(imdgpu_ctx *ctx, const char *name, long long *val
     // bumped whenever a force / list kernel or its data layout changes: committed PMC traffic figures carry the revision
     // they were measured on (profiles/*hbm_traffic*.json "_kernel_rev"), bench.py refuses figures of another revision
     {"kernel_rev", IMDGPU_KERNEL_REV}, {"pass3_ring", ctx->ttm ? 0 : 4},
-    {"ttm_persist_mode", imdgpu_ttm_persist_info(ctx, 0)}, {"ttm_persist_runs", imdgpu_ttm_persist_info(ctx, 1)}};
+    {"ttm_persist_mode", imdgpu_ttm_persist_info(ctx, 0)}, {"ttm_persist_runs", imdgpu_ttm_persist_info(ctx, 1)},
+    // decomposed lattice: 0 = faces through the host mailbox, 1 / 2 = ghost records in the neighbours' device memory (coarse- / fine-grained)
+    {"ttm_remote", imdgpu_ttm_persist_info(ctx, 2)}};
   for (auto &e : tab) if (!strcmp(name, e.n)) { *value = e.v; return 0; }
   return imdgpu_fail(ctx, "unknown info %s", name);
 }

@@ -22,6 +22,7 @@
 #include "imdgpu_internal.h"
 
 #include <dlfcn.h>
+#include <unistd.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
@@ -886,6 +887,86 @@ static int dist_migrate(imdgpu_ctx *ctx, DistState *D, PlanState *P)
 
 void imdgpu_ttm_block_dims(imdgpu_ctx *ctx, int ldim[3]);
 
+// all-gather of n doubles per rank through the transport of the step (host arrays in and out; rebuild-time set-up only)
+static int dist_allgather_host(imdgpu_ctx *ctx, DistState *D, const double *mine, int n, double *all)
+{
+  if (D->nranks == 1) { memcpy(all, mine, n * sizeof(double)); return 0; }
+  double *ds = nullptr, *dr = nullptr;
+  HIPCHK(hipMalloc((void **) &ds, n * sizeof(double)));
+  HIPCHK(hipMalloc((void **) &dr, (size_t) n * D->nranks * sizeof(double)));
+  HIPCHK(hipMemcpy(ds, mine, n * sizeof(double), hipMemcpyHostToDevice));
+  int rc = 0;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (D->comm) { if (g_rccl.AllGather(ds, dr, (size_t) n, ncclDouble, D->comm, ctx->stream) != ncclSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) rc = 1; }
+  else if (D->cb(D->cb_user, 2, ds, dr, n, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 8)) rc = 1;
+  if (!rc && hipMemcpy(all, dr, (size_t) n * D->nranks * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = 1;
+  (void) hipFree(ds); (void) hipFree(dr);
+  return rc ? imdgpu_fail(ctx, "dist: all-gather of the set-up data failed") : 0;
+}
+
+// Decomposed TTM lattice: every rank's ghost-record buffer is made known to the ranks beyond its six faces, which from then on
+// write their boundary cells' (Te, kappa) straight into it from inside the persistent sub-step kernel (imdgpu_ttm_remote_*,
+// k_ttm_chain_persist<.., REM>): what ttm_fill_ghost_layers does with six MPI_Sendrecv per sub-step (imd_ttm_3D.c:3314-3504)
+// becomes stores over xGMI without a launch, a collective or the host.  Ranks in other processes are reached through
+// hipIpc handles, ranks of this process (threads) by their pointer.  Collective.
+extern "C" int imdgpu_ttm_remote_init(imdgpu_ctx *ctx, int coarse, void **dev_ptr, size_t *bytes);
+extern "C" int imdgpu_ttm_remote_ipc_handle(imdgpu_ctx *ctx, void *handle64, int *fine);
+extern "C" int imdgpu_ttm_remote_open(imdgpu_ctx *ctx, const void *handle64, void **dev_ptr);
+extern "C" int imdgpu_ttm_remote_attach(imdgpu_ctx *ctx, void *const peer[6]);
+extern "C" int imdgpu_dist_ttm_remote_setup(imdgpu_ctx *ctx)
+{
+  NEED_DIST();
+  PlanState *P = PS(ctx);
+  if (!ctx->ttm || !ctx->ttm_decomposed) return imdgpu_fail(ctx, "dist_ttm_remote_setup: needs a decomposed TTM lattice");
+  if (plan_static(ctx, D, P)) return 1;
+  const int N = D->nranks, W = 14;                       // per rank: pid, pointer, fine flag, need-coarse flag, 2 x bus id, 8 x handle
+  std::vector<double> mine(W, 0.0), all((size_t) W * N, 0.0);
+  char bus[16] = {0};
+  (void) hipDeviceGetPCIBusId(bus, 16, ctx->device);
+  long long pid = (long long) getpid();
+  // round 1: who lives where
+  memcpy(&mine[0], &pid, 8); memcpy(&mine[4], bus, 16);
+  if (dist_allgather_host(ctx, D, mine.data(), W, all.data())) return 1;
+  bool all_same_gpu = true, other_process = false;
+  for (int d = 0; d < 3; d++)
+    for (int side = 0; side < 2; side++) {
+      const int nb = side ? P->lo[d] : P->hi[d];
+      if (nb < 0 || nb == D->rank) continue;
+      long long p2; memcpy(&p2, &all[(size_t) W * nb], 8);
+      if (memcmp(&all[(size_t) W * nb + 4], bus, 16) != 0) all_same_gpu = false;
+      if (p2 != pid) other_process = true;
+    }
+  void *ptr = nullptr; size_t bytes = 0;
+  const bool force_coarse = getenv("IMDGPU_TTM_REMOTE_COARSE") != nullptr;
+  if (imdgpu_ttm_remote_init(ctx, force_coarse ? 1 : 0, &ptr, &bytes)) return 1;
+  unsigned char handle[64] = {0};
+  int fine = 0;
+  if (other_process && imdgpu_ttm_remote_ipc_handle(ctx, handle, &fine)) {
+    // no IPC handle for fine-grained memory on this driver: plain device memory is enough when every neighbour shares my GPU
+    if (!all_same_gpu) return 1;
+    if (imdgpu_ttm_remote_init(ctx, 1, &ptr, &bytes) || imdgpu_ttm_remote_ipc_handle(ctx, handle, &fine)) return 1;
+  }
+  memcpy(&mine[1], &ptr, 8); mine[2] = fine; memcpy(&mine[6], handle, 64);
+  if (dist_allgather_host(ctx, D, mine.data(), W, all.data())) return 1;
+  void *peer[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  std::map<int, void *> opened;
+  for (int d = 0; d < 3; d++)
+    for (int side = 0; side < 2; side++) {                 // face 2d: towards +d (my high neighbour), 2d+1: towards -d
+      const int nb = side ? P->lo[d] : P->hi[d], q = 2 * d + side;
+      if (nb < 0 || nb == D->rank) continue;
+      auto it = opened.find(nb);
+      if (it != opened.end()) { peer[q] = it->second; continue; }
+      long long p2; void *rp; memcpy(&p2, &all[(size_t) W * nb], 8); memcpy(&rp, &all[(size_t) W * nb + 1], 8);
+      void *mapped = rp;
+      if (p2 != pid && imdgpu_ttm_remote_open(ctx, &all[(size_t) W * nb + 6], &mapped)) return 1;
+      opened[nb] = mapped; peer[q] = mapped;
+    }
+  if (imdgpu_ttm_remote_attach(ctx, peer)) return 1;
+  // nobody starts writing before every rank has zeroed and attached its buffer
+  int one = 1;
+  return dist_max_int(ctx, D, &one);
+}
+
 // The whole rebuild of one rank (collective: every rank calls it).  After it the list is valid and imdgpu_dist_md_step runs.
 extern "C" int imdgpu_dist_rebuild(imdgpu_ctx *ctx)
 {
@@ -912,6 +993,9 @@ extern "C" int imdgpu_dist_rebuild(imdgpu_ctx *ctx)
     HIPCHK(hipStreamSynchronize(ctx->stream)); P->ms[4] = ms_since(t);
     fprintf(stderr, "[dist rebuild %d, native] ms: migrate %.2f, fix_cells %.2f, plan %.2f, exchange %.2f, make_nblist %.2f\n", P->nrebuild,
             P->ms[0], P->ms[1], P->ms[2], P->ms[3], P->ms[4]);
+  }
+  if (ctx->ttm && ctx->ttm_decomposed && P->nrebuild == 0 && D->nranks > 1 && !(getenv("IMDGPU_TTM_REMOTE") && atoi(getenv("IMDGPU_TTM_REMOTE")) == 0)) {
+    if (imdgpu_dist_ttm_remote_setup(ctx)) return 1;                  // decomposed lattice: faces through ghost records in the neighbours' memory
   }
   if (ctx->ttm && !ctx->ttm_decomposed && !D->d_ttm_offs) {          // replicated lattice: where every rank's update_fd block goes
     int ld[3];

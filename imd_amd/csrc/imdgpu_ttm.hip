@@ -68,6 +68,9 @@ struct TtmState {
   hipEvent_t ev_pstat = nullptr;
   const int *graph_guard[2] = {nullptr, nullptr};
   double *d_ufd_part = nullptr; size_t ufd_part_cap = 0;   // partial sums of the chunked update_fd
+  // decomposed lattice, faces through ghost RECORDS in the neighbours' device memory (imdgpu_ttm_remote_*)
+  unsigned long long *d_xrec = nullptr; size_t xrec_bytes = 0; int xoff[6]{}, xcells = 0; bool xrec_fine = false;
+  unsigned long long *peer[6]{}; int xremote = 0; bool xrec_ready = false;
 };
 
 // physical constants of the reference, globals.h:324-331,1190
@@ -877,7 +880,9 @@ __global__ __launch_bounds__(64) void k_ttm_activation_seq(Lat L, EosDev ee, con
 // ttm_fill_ghost_layers, one rank: FACE cells only (plane datatypes of
 // ttm_create_mpi_datatypes, imd_ttm_3D.c:2972-3312); periodic: copy from the
 // opposite inner plane; open: ghost face empty (natoms = 0).
-__global__ void k_ttm_ghosts(Lat L, int *natoms, double *temp, double *fd_k)
+// remote: bit q (2d: the + face, 2d+1: the - face) = that ghost face belongs to another rank and is filled by it (decomposed
+// lattice with remote records: the persistent sub-step kernel has written it); such faces are left alone
+__global__ void k_ttm_ghosts(Lat L, int *natoms, double *temp, double *fd_k, int remote = 0)
 {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int *D = L.dim;
@@ -891,10 +896,11 @@ __global__ void k_ttm_ghosts(Lat L, int *natoms, double *temp, double *fd_k)
       idx[d] = D[d] - 1; int hi = fidx(L, idx[0], idx[1], idx[2]);
       idx[d] = 1;        int ilo = fidx(L, idx[0], idx[1], idx[2]);
       idx[d] = D[d] - 2; int ihi = fidx(L, idx[0], idx[1], idx[2]);
+      const bool rhi = remote >> (2 * d) & 1, rlo = remote >> (2 * d + 1) & 1;
       if (L.pbc[d] == 1) {
-        natoms[hi] = natoms[ilo]; temp[hi] = temp[ilo]; fd_k[hi] = fd_k[ilo];
-        natoms[lo] = natoms[ihi]; temp[lo] = temp[ihi]; fd_k[lo] = fd_k[ihi];
-      } else { natoms[lo] = 0; natoms[hi] = 0; }
+        if (!rhi) { natoms[hi] = natoms[ilo]; temp[hi] = temp[ilo]; fd_k[hi] = fd_k[ilo]; }
+        if (!rlo) { natoms[lo] = natoms[ihi]; temp[lo] = temp[ihi]; fd_k[lo] = fd_k[ihi]; }
+      } else { if (!rlo) natoms[lo] = 0; if (!rhi) natoms[hi] = 0; }
       return;
     }
     off += nf;
@@ -1024,6 +1030,13 @@ struct PersistDev {
   int *status, *counters;
   int nt[3], ntiles, trusted, ncell;
   unsigned base;                        // tag of state 0 of this launch
+  // decomposed lattice (REM): the cells beyond a rank boundary live on ANOTHER GPU.  Every rank owns a buffer of ghost
+  // records -- per face cell and parity the same four granules as `rec`, then one granule {tag | natoms} per face cell --
+  // which its neighbours write straight into (system-scope stores over xGMI, or the same memory when ranks share a GPU)
+  // and which it polls locally: the push direction keeps the polling off the link.
+  unsigned long long *xrec;             // mine: [2][xcells][4], then [xcells] natoms granules
+  unsigned long long *peer[6];          // the buffer of the rank beyond face q (2d: +, 2d+1: -), nullptr = no other rank there
+  int xoff[6], xcells;                  // first record of face q in every rank's buffer; records per parity
 };
 __device__ __forceinline__ unsigned ld_flag(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void rec_store(unsigned long long *r, unsigned tag, double v)
@@ -1033,12 +1046,28 @@ __device__ __forceinline__ void rec_store(unsigned long long *r, unsigned tag, d
   __hip_atomic_store(r + 1, t | (b & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// the same granules across GPUs: system scope (fine-grained memory; over xGMI a store is posted, the poll stays local)
+__device__ __forceinline__ void xrec_store(unsigned long long *r, unsigned tag, double v)
+{
+  const unsigned long long b = (unsigned long long) __double_as_longlong(v), t = (unsigned long long) tag << 32;
+  __hip_atomic_store(r, t | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(r + 1, t | (b & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ unsigned long long xrec_load(const unsigned long long *r) { return __hip_atomic_load(r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// index of inner cell (i, j, k) within face q of its rank's block: the two other inner coordinates, larger dimension fastest
+__device__ __forceinline__ int face_index(const Lat &L, int q, int i, int j, int k)
+{
+  const int d = q >> 1;
+  return d == 0 ? (j - 1) * (L.dim[2] - 2) + (k - 1) : d == 1 ? (i - 1) * (L.dim[2] - 2) + (k - 1) : (i - 1) * (L.dim[1] - 2) + (j - 1);
+}
+
 // WPE = waves per SIMD the register budget is cut for: 6 (80 VGPRs, 52 of them spilled to scratch) is what fits beside three
 // 144-register waves of the force pass -- the forked chain of an MD step; 4 (128 VGPRs, no spills: 0.76 instead of 0.83 ms)
 // is what a stand-alone calc_ttm runs, alone on the chip
-template <bool SRC, int WPE>
+// REM: the lattice is this rank's BLOCK of a decomposed lattice; faces towards other ranks go through PersistDev::xrec / peer
+template <bool SRC, int WPE, bool REM>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_ttm_chain_persist(
-    Lat L, double tau, int nsub, const int *natoms, double *T0, double *T1, double *U0, double *U1, double *K0, double *K1,
+    Lat L, double tau, int nsub, int *natoms, double *T0, double *T1, double *U0, double *U1, double *K0, double *K1,
     double *Ce, double *fd_g, const double *md_temp, const double *source, const double *dens, double *xi, double *Zo,
     double *neo, EosDev cve, PersistDev P)
 {
@@ -1082,31 +1111,82 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
   // per direction: nc = cell index of the neighbour, or -1 = mirror (outside an open boundary or an inactive cell; the
   // ghost shell is resolved on the fly as in k_ttm_diff<.., WRAP = true>); intile bit = the neighbour is a lane of this wave
   int nc[6];
-  unsigned intile = 0;
+  unsigned intile = 0, rem = 0;                        // rem bit q: the neighbour in direction q is a cell of another rank
+  const unsigned long long tloop = wall_clock64();
+  if (REM) {
+    // every inner cell on a face towards another rank tells that rank its atom count (activity decides mirror or flux) and,
+    // if active, its state 0; then the ghost cells' counts are awaited -- all of it tagged with this launch's base
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+      const int d = q >> 1, me = d == 0 ? i : d == 1 ? j : k;
+      if (!inside || P.peer[q] == nullptr || me != ((q & 1) ? 1 : L.dim[d] - 2)) continue;
+      rem |= 1u << q;
+      const int f = P.xoff[q ^ 1] + face_index(L, q, i, j, k);                    // my cell in the peer's face q ^ 1
+      if (active) {
+        unsigned long long *r = P.peer[q] + (size_t) f * 4;                       // parity 0
+        xrec_store(r, P.base, T0[c]); xrec_store(r + 2, P.base, K0[c]);
+      }
+      __hip_atomic_store(P.peer[q] + (size_t) 2 * P.xcells * 4 + f, ((unsigned long long) P.base << 32) | (unsigned) nat,
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 #pragma unroll
   for (int q = 0; q < 6; q++) {
     int g[3] = {i, j, k};
     const int d = q >> 1, dir = (q & 1) ? -1 : 1;
     g[d] += dir;
     bool empty = !inside;
+    int cell = -1;
+    if (REM && (rem >> q & 1u)) {                      // ghost cell filled by the rank beyond: wait for its atom count
+      const int gc = fidx(L, g[0], g[1], g[2]);
+      const unsigned long long *r = P.xrec + (size_t) 2 * P.xcells * 4 + P.xoff[q] + face_index(L, q, i, j, k);
+      int gn = -1;
+      for (;;) {
+        const unsigned long long v = xrec_load(r);
+        if ((unsigned) (v >> 32) == P.base) { gn = (int) (unsigned) v; break; }
+        if (wall_clock64() - tloop > PERSIST_SPIN_TICKS || ld_flag(P.gate) == 3u) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+      if (gn < 0) {                                    // the neighbour rank never started its launch: give up, loudly
+        __hip_atomic_store(P.gate, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(P.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(P.counters + CNT_TTM_TIMEOUT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        gn = 0;
+      }
+      natoms[gc] = gn;                                 // the ghost shell of the arrays follows (downloads, CFL_maxdt)
+      if (gn >= m) cell = gc;
+      nc[q] = cell;
+      continue;
+    }
     if (g[d] == 0) { if (L.pbc[d] == 1) g[d] = L.dim[d] - 2; else empty = true; }
     else if (g[d] == L.dim[d] - 1) { if (L.pbc[d] == 1) g[d] = 1; else empty = true; }
-    int cell = -1;
     if (!empty) { cell = fidx(L, g[0], g[1], g[2]); if (natoms[cell] < m) cell = -1; }
     nc[q] = cell;
     const int ln = l3[d] + dir;
     if (ln >= 0 && ln < PT && g[d] == (d == 0 ? i : d == 1 ? j : k) + dir) intile |= 1u << q;    // same block and not wrapped
   }
   if (inside && !active) { K0[c] = 0.0; K1[c] = 0.0; fd_g[c] = 0.0; Ce[c] = 0.0; Zo[c] = 0.0; neo[c] = 0.0; }   // what the chain's launches write (nobody reads an inactive cell)
-  if (__ballot(active) == 0ull) return;                // a block without an active cell: nothing to compute, never read
-  // at most ONE neighbour per dimension lies in another block (the host does not use this kernel for lattices with a
-  // one-cell-wide last block): xc[d] = its cell or -1 (bit d of xany: there is one)
-  int xc[3]; unsigned xany = 0;
+  // which ghost cells beyond a rank boundary are active: their final state is fetched into the arrays' ghost shell at the end
+  unsigned gact = 0;
+  if (REM) {
+#pragma unroll
+    for (int q = 0; q < 6; q++) if ((rem >> q & 1u) && nc[q] >= 0) gact |= 1u << q;
+  }
+  const bool any_active = __ballot(active) != 0ull;
+  if (!any_active && !(REM && __ballot(gact != 0) != 0ull)) return;   // a block without an active cell: nothing to compute, never read
+  // at most ONE neighbour per dimension lies in another block or on another rank (the host does not use this kernel for
+  // lattices with a one-cell-wide last block): xc[d] = its cell -- for a cell of another rank: its record in xrec -- or -1
+  // (bit d of xany: there is one; bit d of xrm: it is a record of xrec)
+  int xc[3]; unsigned xany = 0, xrm = 0;
 #pragma unroll
   for (int d = 0; d < 3; d++) {
     const bool cp = nc[2 * d] >= 0 && !(intile >> (2 * d) & 1u), cm = nc[2 * d + 1] >= 0 && !(intile >> (2 * d + 1) & 1u);
     xc[d] = cp ? nc[2 * d] : (cm ? nc[2 * d + 1] : -1);
     if (cp || cm) xany |= 1u << d;
+    if (REM && (cp || cm)) {
+      const int q = cp ? 2 * d : 2 * d + 1;
+      if (rem >> q & 1u) { xrm |= 1u << d; xc[d] = P.xoff[q] + face_index(L, q, i, j, k); }
+    }
   }
   // an inactive cell of a partly active block computes nothing and is a mirror for its neighbours, which therefore
   // publish no record on its account: it must not wait for any (rough surfaces, voids, craters across a block face)
@@ -1118,28 +1198,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     if (SRC) src = source[c];
   }
   const double invsq[3] = {L.invhsq[0], L.invhsq[1], L.invhsq[2]};
-  const unsigned long long tloop = wall_clock64();
-  for (int s = 0; s < nsub; s++) {
+  if (!REM) { (void) tloop; }
+  for (int s = 0; any_active && s < nsub; s++) {
     double xT[3], xK[3];
     // (1) the neighbours in other blocks: state 0 from the arrays, later states from their records once the tags are there
+    //     (cells of other ranks: every state from their records in xrec)
+    unsigned todo = (s == 0) ? (xany & xrm) : xany;
     if (s == 0) {
 #pragma unroll
-      for (int d = 0; d < 3; d++) { xT[d] = Te; xK[d] = kk; if (xany >> d & 1u) { xT[d] = T0[xc[d]]; xK[d] = K0[xc[d]]; } }
+      for (int d = 0; d < 3; d++) { xT[d] = Te; xK[d] = kk; if ((xany & ~xrm) >> d & 1u) { xT[d] = T0[xc[d]]; xK[d] = K0[xc[d]]; } }
     } else {
-      const unsigned long long want = (unsigned long long) (P.base + (unsigned) s);
-      const unsigned long long *R = P.rec + (size_t) (s & 1) * P.ncell * 4;
-      unsigned todo = xany;
 #pragma unroll
       for (int d = 0; d < 3; d++) { xT[d] = Te; xK[d] = kk; }
+    }
+    if (s > 0 || (REM && todo != 0) || REM) {
+      const unsigned long long want = (unsigned long long) (P.base + (unsigned) s);
+      const unsigned long long *R = P.rec + (size_t) (s & 1) * P.ncell * 4;
+      const unsigned long long *X = REM ? P.xrec + (size_t) (s & 1) * P.xcells * 4 : nullptr;
       for (;;) {
 #pragma unroll
         for (int d = 0; d < 3; d++)
           if (todo >> d & 1u) {
-            const unsigned long long *r = R + (size_t) xc[d] * 4;
-            const unsigned long long a0 = __hip_atomic_load(r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                                     a1 = __hip_atomic_load(r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                                     a2 = __hip_atomic_load(r + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                                     a3 = __hip_atomic_load(r + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long *r = (REM && (xrm >> d & 1u)) ? X + (size_t) xc[d] * 4 : R + (size_t) xc[d] * 4;
+            unsigned long long a0, a1, a2, a3;
+            if (REM && (xrm >> d & 1u)) { a0 = xrec_load(r); a1 = xrec_load(r + 1); a2 = xrec_load(r + 2); a3 = xrec_load(r + 3); }
+            else {
+              a0 = __hip_atomic_load(r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); a1 = __hip_atomic_load(r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              a2 = __hip_atomic_load(r + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); a3 = __hip_atomic_load(r + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             if ((a0 >> 32) == want && (a1 >> 32) == want && (a2 >> 32) == want && (a3 >> 32) == want) {
               xT[d] = __longlong_as_double((long long) ((a0 << 32) | (a1 & 0xffffffffull)));
               xK[d] = __longlong_as_double((long long) ((a2 << 32) | (a3 & 0xffffffffull)));
@@ -1178,10 +1264,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
       x += (Tn - Tl) * L.xi_fac * g / (Tl * dn);
       const MeshOut o = mesh_props(L, cve, Tn, Tl, dn);
       ce = o.Ce; kk = o.k; g = o.g; Te = Tn;
-      if (xany != 0 && s + 1 < nsub) {                  // a lane with a neighbour in another block publishes state s + 1
+      if ((xany & ~xrm) != 0 && s + 1 < nsub) {         // a lane with a neighbour in another block publishes state s + 1
         unsigned long long *r = P.rec + ((size_t) ((s + 1) & 1) * P.ncell + c) * 4;
         rec_store(r, P.base + (unsigned) (s + 1), Te);
         rec_store(r + 2, P.base + (unsigned) (s + 1), kk);
+      }
+      if (REM && rem != 0) {                            // ... and to the ranks beyond its faces, the final state included
+#pragma unroll
+        for (int q = 0; q < 6; q++)
+          if (rem >> q & 1u) {
+            unsigned long long *r = P.peer[q] + ((size_t) ((s + 1) & 1) * P.xcells + P.xoff[q ^ 1] + face_index(L, q, i, j, k)) * 4;
+            xrec_store(r, P.base + (unsigned) (s + 1), Te);
+            xrec_store(r + 2, P.base + (unsigned) (s + 1), kk);
+          }
       }
       // the arrays follow as in the launch chain (ping-pong): nobody in this launch reads them after state 0
       Tw[c] = Te; Kw[c] = kk; Uw[c] = u;
@@ -1189,6 +1284,38 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     }
   }
   if (active) { xi[c] = x; Ce[c] = ce; fd_g[c] = g; }
+  if (REM && gact != 0) {
+    // ttm_fill_ghost_layers after the last sub-step (imd_ttm_3D.c:70,3314-3504): the final state of the active cells beyond
+    // my faces goes into the ghost shell of the arrays that hold the final state (what the next step's cell activation,
+    // CFL_maxdt and downloads read)
+    const unsigned long long want = (unsigned long long) (P.base + (unsigned) nsub);
+    const unsigned long long *X = P.xrec + (size_t) (nsub & 1) * P.xcells * 4;
+    double *Tf = (nsub & 1) ? T1 : T0, *Kf = (nsub & 1) ? K1 : K0;
+    unsigned todo = gact;
+    for (;;) {
+#pragma unroll
+      for (int q = 0; q < 6; q++)
+        if (todo >> q & 1u) {
+          const unsigned long long *r = X + (size_t) (P.xoff[q] + face_index(L, q, i, j, k)) * 4;
+          const unsigned long long a0 = xrec_load(r), a1 = xrec_load(r + 1), a2 = xrec_load(r + 2), a3 = xrec_load(r + 3);
+          if ((a0 >> 32) == want && (a1 >> 32) == want && (a2 >> 32) == want && (a3 >> 32) == want) {
+            Tf[nc[q]] = __longlong_as_double((long long) ((a0 << 32) | (a1 & 0xffffffffull)));
+            Kf[nc[q]] = __longlong_as_double((long long) ((a2 << 32) | (a3 & 0xffffffffull)));
+            todo &= ~(1u << q);
+          }
+        }
+      if (__all(todo == 0)) break;
+      if (__any(wall_clock64() - tloop > PERSIST_SPIN_TICKS || ld_flag(P.gate) == 3u)) {
+        if (lane == 0) {
+          __hip_atomic_store(P.gate, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(P.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(P.counters + CNT_TTM_TIMEOUT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
 }
 
 // CFL_maxdt (imd_ttm_3D.c:2637-2691): min over cells and +x,+y,+z faces
@@ -1307,6 +1434,7 @@ void imdgpu_ttm_free(imdgpu_ctx *ctx)
   if (t->d_pflags) (void) hipFree(t->d_pflags);
   if (t->d_ufd_part) (void) hipFree(t->d_ufd_part);
   if (t->d_prec) (void) hipFree(t->d_prec);
+  if (t->d_xrec) (void) hipFree(t->d_xrec);
   if (t->d_pstat) (void) hipFree(t->d_pstat);
   if (t->h_pstat) (void) hipHostFree(t->h_pstat);
   if (t->ev_pstat) (void) hipEventDestroy(t->ev_pstat);
@@ -1843,6 +1971,7 @@ long long imdgpu_ttm_persist_info(imdgpu_ctx *ctx, int which)
     t->pstat_pending = 0;
     if (t->h_pstat[0] == 0) { if (++t->persist_ok >= 2 && t->persist == 1) t->persist = 2; } else t->persist = 0;
   }
+  if (which == 2) return t->xrec_ready ? (t->xrec_fine ? 2 : 1) : 0;
   return which == 0 ? t->persist : t->persist_ok;
 }
 
@@ -1874,9 +2003,11 @@ static int persist_mode(imdgpu_ctx *ctx, TtmState *t)
   return t->persist;
 }
 
-static int launch_persist(imdgpu_ctx *ctx, TtmState *t, const Lat &L, double tau, int mode)
+static int launch_persist(imdgpu_ctx *ctx, TtmState *t, const Lat &L, double tau, int mode, bool rem = false)
 {
   PersistDev P;
+  P.xrec = rem ? t->d_xrec : nullptr; P.xcells = t->xcells;
+  for (int q = 0; q < 6; q++) { P.peer[q] = rem ? t->peer[q] : nullptr; P.xoff[q] = t->xoff[q]; }
   P.census = t->d_pflags; P.gate = t->d_pflags + 1; P.rec = t->d_prec; P.ncell = t->ncell;
   P.base = t->persist_base; t->persist_base += (unsigned) t->nsub + 1u;
   P.status = t->d_pstat; P.counters = ctx->d_counters;
@@ -1887,11 +2018,13 @@ static int launch_persist(imdgpu_ctx *ctx, TtmState *t, const Lat &L, double tau
   double *T0 = t->temp[t->cur], *T1 = t->temp[t->cur ^ 1], *U0 = t->U[t->cur], *U1 = t->U[t->cur ^ 1];
   double *K0 = t->fd_k[t->kcur], *K1 = t->fd_k[t->kcur ^ 1];
   const bool alone = ctx->stream != ctx->stream2;         // not forked beside the force pass: a stand-alone calc_ttm
-#define PERSIST_LAUNCH(S, W)                                                                                                     \
-  hipLaunchKernelGGL((k_ttm_chain_persist<S, W>), dim3(t->persist_tiles), dim3(64), 0, ctx->stream, L, tau, t->nsub, t->natoms, T0, T1, \
+#define PERSIST_LAUNCH(S, W, R)                                                                                                  \
+  hipLaunchKernelGGL((k_ttm_chain_persist<S, W, R>), dim3(t->persist_tiles), dim3(64), 0, ctx->stream, L, tau, t->nsub, t->natoms, T0, T1, \
                      U0, U1, K0, K1, t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve, P)
-  if (t->have_source) { if (alone) PERSIST_LAUNCH(true, 4); else PERSIST_LAUNCH(true, 6); }
-  else { if (alone) PERSIST_LAUNCH(false, 4); else PERSIST_LAUNCH(false, 6); }
+  if (rem) { if (t->have_source) { if (alone) PERSIST_LAUNCH(true, 4, true); else PERSIST_LAUNCH(true, 6, true); }
+             else { if (alone) PERSIST_LAUNCH(false, 4, true); else PERSIST_LAUNCH(false, 6, true); } }
+  else if (t->have_source) { if (alone) PERSIST_LAUNCH(true, 4, false); else PERSIST_LAUNCH(true, 6, false); }
+  else { if (alone) PERSIST_LAUNCH(false, 4, false); else PERSIST_LAUNCH(false, 6, false); }
 #undef PERSIST_LAUNCH
   HIPCHK(hipGetLastError());
   if (!t->pstat_pending) {                               // feedback for persist_mode; never waited for
@@ -1926,11 +2059,19 @@ extern "C" int imdgpu_ttm_lattice_step(imdgpu_ctx *ctx, int steps)
   NEED_TTM();
   const double tau = ctx->timestep / ((double) t->nsub);
   const bool MBX = t->mb_host != nullptr;
-  if (ctx->ttm_decomposed && !MBX) return imdgpu_fail(ctx, "decomposed TTM lattice: imdgpu_ttm_mailbox_attach first");
+  // decomposed lattice with remote records attached: the persistent kernel does the whole loop, faces included, whenever it
+  // applies (the same decision on every rank: it depends on the lattice shape, the sub-step count and the step number only)
+  const bool can_graph0 = (t->nsub % 2 == 0) && steps >= 1;
+  int rmode = 0;
+  if (ctx->ttm_decomposed && t->xrec_ready && can_graph0 && !(t->fdtd && t->fdtd_on)) { rmode = persist_mode(ctx, t); if (rmode < 0) return 1; }
+  const bool REMK = rmode > 0;
+  if (ctx->ttm_decomposed && !MBX && !REMK) return imdgpu_fail(ctx, "decomposed TTM lattice: imdgpu_ttm_mailbox_attach first (needed whenever the persistent kernel with remote records does not apply: step 0, odd sub-step counts, lattice shapes it does not take)");
   imdgpu_tl_mark(ctx, "ttm_update_fd");
   if (t->laser_on && imdgpu_ttm_laser_rescale(ctx, &t->laser, steps)) return 1;   // update_fd has just zeroed the source
   if (imdgpu_ttm_cell_activation(ctx) || imdgpu_ttm_fillmesh(ctx, steps)) return 1;
-  if (MBX) {                       // first publication of this MD step: natoms, temp, fd_k of my boundary layers
+  if (REMK) {
+    // nothing: the kernel publishes state 0 of its faces itself
+  } else if (MBX) {                // first publication of this MD step: natoms, temp, fd_k of my boundary layers
     hipLaunchKernelGGL(k_ttm_push_faces, dim3(6), dim3(64), 0, ctx->stream, L, t->mbd, 0, 1, t->natoms,
                        t->temp[t->cur], t->fd_k[t->kcur]);
   } else if (imdgpu_ttm_fill_ghost_layers(ctx)) return 1;
@@ -1948,8 +2089,9 @@ extern "C" int imdgpu_ttm_lattice_step(imdgpu_ctx *ctx, int steps)
     const bool can_graph = (t->nsub % 2 == 0) && steps >= 1;      // step 0 re-initialises U: run it un-captured
     const int gi = t->cur;
     int pmode = 0;
-    if (can_graph && !MBX) { pmode = persist_mode(ctx, t); if (pmode < 0) return 1; }
-    if (pmode > 0 && launch_persist(ctx, t, L, tau, pmode)) return 1;
+    if (REMK) { if (launch_persist(ctx, t, L, tau, 2, true)) return 1; pmode = 2; }     // no trial: a failed census is an error on every rank's lattice
+    else if (can_graph && !MBX) { pmode = persist_mode(ctx, t); if (pmode < 0) return 1; }
+    if (!REMK && pmode > 0 && launch_persist(ctx, t, L, tau, pmode)) return 1;
     const int *guard = pmode == 1 ? t->d_pstat : nullptr;
     if (pmode == 2) {
       // trusted: the persistent kernel alone
@@ -1983,7 +2125,10 @@ extern "C" int imdgpu_ttm_lattice_step(imdgpu_ctx *ctx, int steps)
     }
   }
   imdgpu_tl_mark(ctx, "ttm_substeps");
-  if (MBX) {                       // neighbours' final layers into the ghost cells; next MD step = next block of indices
+  if (REMK) {                      // ghost faces of other ranks: written by the kernel; faces of periodic images / open faces: here
+    int nf = (t->dim[1] - 2) * (t->dim[2] - 2) + (t->dim[2] - 2) * (t->dim[0] - 2) + (t->dim[0] - 2) * (t->dim[1] - 2);
+    hipLaunchKernelGGL(k_ttm_ghosts, dim3(nblk(nf, TTM_WG)), dim3(TTM_WG), 0, ctx->stream, L, t->natoms, t->temp[t->cur], t->fd_k[t->kcur], t->xremote);
+  } else if (MBX) {                // neighbours' final layers into the ghost cells; next MD step = next block of indices
     hipLaunchKernelGGL(k_ttm_pull_ghosts, dim3(6), dim3(64), 0, ctx->stream, L, t->mbd, t->nsub, 0, t->natoms,
                        t->temp[t->cur], t->fd_k[t->kcur]);
     hipLaunchKernelGGL(k_ttm_advance_base, dim3(1), dim3(1), 0, ctx->stream, t->d_gbase, t->nsub);
@@ -1991,6 +2136,75 @@ extern "C" int imdgpu_ttm_lattice_step(imdgpu_ctx *ctx, int steps)
   HIPCHK(hipGetLastError());
   // CFL_maxdt: value is informational for the host (diff_substeps is fixed by fd_n_timesteps in the
   // sequence implemented here); computed on demand by imdgpu_ttm_cfl_maxdt to keep the step sync-free
+  return 0;
+}
+
+// ---- decomposed lattice: ghost records in the neighbours' device memory ------------------------------------------
+// Every rank owns one buffer: per parity one record of four granules for every cell of its six ghost faces, then one
+// {tag | natoms} granule per face cell.  The ranks beyond its faces write into it (k_ttm_chain_persist<.., REM = true>).
+static void xrec_layout(TtmState *t)
+{
+  int o = 0;
+  for (int q = 0; q < 6; q++) {
+    const int d = q >> 1;
+    t->xoff[q] = o;
+    o += (t->dim[(d + 1) % 3] - 2) * (t->dim[(d + 2) % 3] - 2);
+  }
+  t->xcells = o;
+}
+extern "C" int imdgpu_ttm_remote_init(imdgpu_ctx *ctx, int coarse, void **dev_ptr, size_t *bytes)
+{
+  NEED_TTM();
+  if (!ctx->ttm_decomposed) return imdgpu_fail(ctx, "ttm_remote_init: set option ttm_decomposed before ttm_init");
+  xrec_layout(t);
+  const size_t n = (size_t) 2 * t->xcells * 4 + t->xcells;
+  if (t->d_xrec) { (void) hipFree(t->d_xrec); t->d_xrec = nullptr; }
+  t->xrec_ready = false;
+  // fine-grained device memory: stores of other GPUs become visible to this GPU's polling loads while the kernels run
+  // (coarse-grained memory is only coherent at kernel boundaries); `coarse` != 0 asks for plain hipMalloc -- enough when all
+  // ranks share ONE GPU (rehearsals), where every access goes through the same L2
+  if (coarse || hipExtMallocWithFlags((void **) &t->d_xrec, n * sizeof(unsigned long long), hipDeviceMallocFinegrained) != hipSuccess) {
+    (void) hipGetLastError();
+    HIPCHK(hipMalloc((void **) &t->d_xrec, n * sizeof(unsigned long long)));
+    t->xrec_fine = false;
+  } else t->xrec_fine = true;
+  t->xrec_bytes = n * sizeof(unsigned long long);
+  HIPCHK(hipMemset(t->d_xrec, 0, t->xrec_bytes));
+  if (dev_ptr) *dev_ptr = t->d_xrec;
+  if (bytes) *bytes = t->xrec_bytes;
+  return 0;
+}
+// the 64-byte IPC handle of my buffer for ranks in OTHER processes (hipIpcMemHandle_t); *fine = 1: fine-grained memory
+extern "C" int imdgpu_ttm_remote_ipc_handle(imdgpu_ctx *ctx, void *handle64, int *fine)
+{
+  NEED_TTM();
+  if (!t->d_xrec) return imdgpu_fail(ctx, "ttm_remote_ipc_handle: imdgpu_ttm_remote_init first");
+  hipIpcMemHandle_t h;
+  static_assert(sizeof(h) == 64, "hipIpcMemHandle_t");
+  if (hipIpcGetMemHandle(&h, t->d_xrec) != hipSuccess) { (void) hipGetLastError(); return imdgpu_fail(ctx, "hipIpcGetMemHandle failed for the ghost-record buffer (%s memory)", t->xrec_fine ? "fine-grained" : "coarse-grained"); }
+  memcpy(handle64, &h, 64);
+  if (fine) *fine = t->xrec_fine ? 1 : 0;
+  return 0;
+}
+extern "C" int imdgpu_ttm_remote_open(imdgpu_ctx *ctx, const void *handle64, void **dev_ptr)
+{
+  HIPCHK(hipSetDevice(ctx->device));
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle64, 64);
+  HIPCHK(hipIpcOpenMemHandle(dev_ptr, h, hipIpcMemLazyEnablePeerAccess));
+  return 0;
+}
+// peer[q]: the ghost-record buffer of the rank beyond face q (2d: +, 2d+1: -) as THIS process addresses it (its own
+// pointer when that rank lives in this process, else what imdgpu_ttm_remote_open returned); NULL = no other rank there
+// (open boundary, or a periodic direction with one rank: resolved locally)
+extern "C" int imdgpu_ttm_remote_attach(imdgpu_ctx *ctx, void *const peer[6])
+{
+  NEED_TTM();
+  if (!t->d_xrec) return imdgpu_fail(ctx, "ttm_remote_attach: imdgpu_ttm_remote_init first");
+  t->xremote = 0;
+  for (int q = 0; q < 6; q++) { t->peer[q] = (unsigned long long *) peer[q]; if (peer[q]) t->xremote |= 1 << q; }
+  t->xrec_ready = true;
+  t->persist = -1; t->persist_ok = 0;           // decide again (the shape test is the same, the kernel variant is not)
   return 0;
 }
 

@@ -33,6 +33,7 @@ SYMBOLS = [
     "imdgpu_dist_unique_id", "imdgpu_dist_init_rccl", "imdgpu_dist_init_callback", "imdgpu_dist_set_plan",
     "imdgpu_dist_halo", "imdgpu_dist_set_ttm_blocks", "imdgpu_dist_md_step", "imdgpu_dist_allreduce_sum",
     "imdgpu_dist_rebuild", "imdgpu_dist_rebuild_count", "imdgpu_dist_step", "imdgpu_dist_calc_forces", "imdgpu_dist_plan_geometry",
+    "imdgpu_ttm_remote_init", "imdgpu_ttm_remote_ipc_handle", "imdgpu_ttm_remote_open", "imdgpu_ttm_remote_attach", "imdgpu_dist_ttm_remote_setup",
     "imdgpu_local_group_create", "imdgpu_local_group_destroy", "imdgpu_local_group_barrier", "imdgpu_local_group_shared", "imdgpu_dist_init_local",
 ]
 
@@ -168,6 +169,11 @@ def load():
     L.imdgpu_dist_set_ttm_blocks.argtypes = [vp, ip]
     L.imdgpu_dist_md_step.argtypes = [vp, C.c_int, ip]
     L.imdgpu_dist_allreduce_sum.argtypes = [vp, dp, C.c_int]
+    L.imdgpu_ttm_remote_init.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.imdgpu_ttm_remote_ipc_handle.argtypes = [vp, vp, ip]
+    L.imdgpu_ttm_remote_open.argtypes = [vp, vp, C.POINTER(vp)]
+    L.imdgpu_ttm_remote_attach.argtypes = [vp, C.POINTER(vp)]
+    L.imdgpu_dist_ttm_remote_setup.argtypes = [vp]
     L.imdgpu_dist_rebuild.argtypes = [vp]
     L.imdgpu_dist_rebuild_count.argtypes = [vp, ip]
     L.imdgpu_dist_step.argtypes = [vp, C.c_int]

@@ -318,6 +318,20 @@ int imdgpu_ttm_lattice_step(imdgpu_ctx *ctx, int steps);
  * (this rank itself for a periodic direction with one rank), -1 = open boundary. */
 int imdgpu_ttm_mailbox_bytes(imdgpu_ctx *ctx, size_t *bytes_per_rank);
 int imdgpu_ttm_mailbox_attach(imdgpu_ctx *ctx, void *host_base, size_t bytes_per_rank, int rank, int nranks, const int nbr[6]);
+/* Decomposed lattice without the host in the loop: every rank owns a buffer of GHOST RECORDS in device memory (per cell of
+ * its six ghost faces and parity four tagged 8-byte granules {tag | half of Te or kappa}, plus {tag | natoms}); the ranks
+ * beyond its faces write their boundary cells' state straight into it from inside the persistent sub-step kernel (stores
+ * over xGMI; system-scope atomics on fine-grained memory) and it polls locally -- ttm_fill_ghost_layers' six MPI_Sendrecv
+ * per sub-step (imd_ttm_3D.c:3314-3504) without a launch, a collective or the host.  Used whenever the persistent kernel
+ * applies (steps >= 1, even sub-step count, block shape); other steps fall back to the mailbox above, which therefore
+ * stays attached.  imdgpu_dist_rebuild sets all of this up by itself (imdgpu_dist_ttm_remote_setup; IMDGPU_TTM_REMOTE=0
+ * keeps the mailbox); the pieces for hosts with their own launcher: */
+int imdgpu_ttm_remote_init(imdgpu_ctx *ctx, int coarse, void **dev_ptr, size_t *bytes);
+int imdgpu_ttm_remote_ipc_handle(imdgpu_ctx *ctx, void *handle64, int *fine_grained);
+int imdgpu_ttm_remote_open(imdgpu_ctx *ctx, const void *handle64, void **dev_ptr);
+/* peer[q]: the buffer of the rank beyond face q (2d: +, 2d+1: -) as this process addresses it, NULL = none */
+int imdgpu_ttm_remote_attach(imdgpu_ctx *ctx, void *const peer[6]);
+int imdgpu_dist_ttm_remote_setup(imdgpu_ctx *ctx);
 /* [calc_ttm] for this rank's block: update_fd, activation, FILLMESH, face publication, the sub-steps */
 int imdgpu_ttm_local_step(imdgpu_ctx *ctx, int steps);
 

@@ -50,7 +50,8 @@ def main():
         d = s.download(fields=("ort", "impuls", "kraft", "nummer", "numneighs"))
         lat = s.ttm_download(fields=("temp", "xi", "natoms")) if ttm else {}
         info = dict(nrebuild=md.nrebuild, transport=ops.transport, list_mode=s.get_info("list_mode"),
-                    persist=s.get_info("ttm_persist_mode") if ttm else -9)
+                    persist=s.get_info("ttm_persist_mode") if ttm else -9, remote=s.get_info("ttm_remote") if ttm else -9,
+                    runs=s.get_info("ttm_persist_runs") if ttm else -9)
         group.barrier()                       # nobody tears its context down while another rank still runs kernels against it
         s.close()
         return dict(d=d, lat=lat, sums=sums, coord=dec.coord, info=info)
@@ -66,6 +67,8 @@ def main():
         out["r%d_nrebuild" % r] = R["info"]["nrebuild"]
         out["r%d_list_mode" % r] = R["info"]["list_mode"]
         out["r%d_persist" % r] = R["info"]["persist"]
+        out["r%d_remote" % r] = R["info"]["remote"]
+        out["r%d_persist_runs" % r] = R["info"]["runs"]
         for k in ("tot_pot_energy", "tot_kin_energy", "virial", "natoms"):
             out["r%d_%s" % (r, k)] = R["sums"][k]
     out["transport"] = np.array(res[0]["info"]["transport"])

@@ -83,12 +83,29 @@ def test_2x2x2_ttm_against_the_reference_on_8_mpi_ranks(decomposed):
             assert np.abs(R["r%d_lat_temp" % r][1:-1, 1:-1, 1:-1] - ref).max() < 1e-10 * np.abs(ref).max()
             assert np.abs(R["r%d_lat_xi" % r][1:-1, 1:-1, 1:-1] - refx).max() < 1e-9 * np.abs(refx).max()
     else:
+        # not the host mailbox: every rank's persistent kernel exchanged its faces through ghost records in its neighbours'
+        # device memory (steps 1 and 2; step 0 runs un-captured through the mailbox)
+        assert all(int(R["r%d_remote" % r]) >= 1 and int(R["r%d_persist" % r]) == 2 and int(R["r%d_persist_runs" % r]) >= 1 for r in range(world)), \
+            [(int(R["r%d_remote" % r]), int(R["r%d_persist" % r]), int(R["r%d_persist_runs" % r])) for r in range(world)]
         full = np.zeros_like(ref)
         for r in range(world):
             blk = R["r%d_lat_temp" % r][1:-1, 1:-1, 1:-1]
             c, n = R["r%d_coord" % r], blk.shape
             full[c[0] * n[0]:(c[0] + 1) * n[0], c[1] * n[1]:(c[1] + 1) * n[1], c[2] * n[2]:(c[2] + 1) * n[2]] = blk
         assert np.abs(full - ref).max() < 1e-10 * np.abs(ref).max()
+        # the ghost shell every rank holds after the last sub-step = its neighbours' boundary cells (ttm_fill_ghost_layers)
+        refg = G["t2_substeps_done_temp"]
+        for r in range(world):
+            lat, c = R["r%d_lat_temp" % r], R["r%d_coord" % r]
+            n = np.array(lat.shape) - 2
+            lo = np.array(c) * n                                              # my first inner cell in the global inner lattice
+            gi = (np.arange(-1, n[0] + 1)[:, None, None] + lo[0]) % ref.shape[0]
+            gj = (np.arange(-1, n[1] + 1)[None, :, None] + lo[1]) % ref.shape[1]
+            gk = (np.arange(-1, n[2] + 1)[None, None, :] + lo[2]) % ref.shape[2]
+            want = ref[gi, gj, gk]
+            for face in (np.s_[0, 1:-1, 1:-1], np.s_[-1, 1:-1, 1:-1], np.s_[1:-1, 0, 1:-1], np.s_[1:-1, -1, 1:-1],
+                         np.s_[1:-1, 1:-1, 0], np.s_[1:-1, 1:-1, -1]):
+                assert np.abs(lat[face] - want[face]).max() < 1e-10 * np.abs(ref).max()
 
 
 @pytest.mark.parametrize("cpu_dim", [(1, 1, 2), (2, 2, 2)])
