@@ -59,7 +59,8 @@ def _worker_body(rank, world, port, case, cpu_dim, nsteps, ttm, q, decomposed=Fa
     sums = md.global_sums()
     d = s.download(fields=("ort", "impuls", "kraft", "nummer", "numneighs"))
     lat = s.ttm_download(fields=("temp", "xi", "natoms", "U", "temp2", "U2", "flux")) if ttm else None
-    q.put((rank, d, sums, md.nrebuild, lat, tuple(dec.coord)))
+    info = (s.get_info("ttm_remote"), s.get_info("ttm_persist_mode"), s.get_info("ttm_persist_runs")) if ttm else (0, 0, 0)
+    q.put((rank, d, sums, md.nrebuild, lat, tuple(dec.coord), info))
     s.close()
     dist.destroy_process_group()
 
@@ -141,6 +142,9 @@ def test_ranks_ttm_decomposed_lattice(cpu_dim):
     The blocks, put together, must equal the reference's lattice after the sub-steps of step 2."""
     res = _run("ttm_2048", cpu_dim, 3, True, decomposed=True)
     G = gu.load("ttm_2048")
+    # ranks in different PROCESSES: the ghost-record buffers are opened through hipIpc handles; steps 1 and 2 ran in the
+    # persistent kernel with the faces written straight into the neighbours' buffers (step 0: the mailbox)
+    assert all(r[6][0] >= 1 and r[6][1] == 2 and r[6][2] >= 1 for r in res), [r[6] for r in res]
     ids = np.concatenate([r[1]["nummer"] for r in res]); pos = np.concatenate([r[1]["ort"] for r in res])
     o, go = np.argsort(ids), np.argsort(G["s3_nummer"])
     assert np.abs(pos[o] - G["s3_ort"][go]).max() < 1e-9
