@@ -1600,7 +1600,7 @@ extern "C" int imdgpu_get_info(imdgpu_ctx *ctx, const char *name, long long *val
     {"fused_embedding", fuse_emb(ctx) ? 1 : 0}, {"ttm_flux", ctx->ttm_flux}, {"ttm_adv", ctx->ttm_adv}, {"ttm_block_width", ctx->ttm_flux ? 10 : 6},
     // bumped whenever a force / list kernel or its data layout changes: committed PMC traffic figures carry the revision
     // they were measured on (profiles/*hbm_traffic*.json "_kernel_rev"), bench.py refuses figures of another revision
-    {"kernel_rev", IMDGPU_KERNEL_REV}, {"pass3_ring", ctx->ttm ? 0 : 4},
+    {"kernel_rev", IMDGPU_KERNEL_REV}, {"pass3_ring", ctx->ttm ? 0 : 4}, {"have_valid_nbl", ctx->have_valid_nbl},
     {"ttm_persist_mode", imdgpu_ttm_persist_info(ctx, 0)}, {"ttm_persist_runs", imdgpu_ttm_persist_info(ctx, 1)},
     // decomposed lattice: 0 = faces through the host mailbox, 1 / 2 = ghost records in the neighbours' device memory (coarse- / fine-grained)
     {"ttm_remote", imdgpu_ttm_persist_info(ctx, 2)}};
@@ -2596,7 +2596,12 @@ int imdgpu_launch_integrate(imdgpu_ctx *ctx)
   return 0;
 }
 
-extern "C" int imdgpu_md_step(imdgpu_ctx *ctx, int steps)
+// The MD step in two halves for hosts that keep their own main loop (level-2 integration, imd_shim.c): what the
+// reference's loop does between calc_forces and check_nblist (imd_main_3d.c:398-812) happens between the two calls.
+//   begin: list maintenance (fix_cells + make_nblist when the list is stale, else the ghost refresh), the force passes,
+//          calc_ttm forked beside them -- everything enqueued, nothing waited for;
+//   end:   move_atoms_{nve,ttm} + check_nblist, then the one host round trip of a step (is the list still valid?).
+extern "C" int imdgpu_md_step_begin(imdgpu_ctx *ctx, int steps)
 {
   HIPCHK(hipSetDevice(ctx->device));
   imdgpu_tl_mark(ctx, "begin");
@@ -2614,10 +2619,19 @@ extern "C" int imdgpu_md_step(imdgpu_ctx *ctx, int steps)
     int rc = launch_forces(ctx);
     ctx->after_pass1 = nullptr;
     if (rc) return 1;
+  } else if (launch_forces(ctx)) return 1;
+  ctx->step_open = 1;
+  return 0;
+}
+extern "C" int imdgpu_md_step_end(imdgpu_ctx *ctx, int steps)
+{
+  HIPCHK(hipSetDevice(ctx->device));
+  if (!ctx->step_open) return imdgpu_fail(ctx, "md_step_end without md_step_begin");
+  ctx->step_open = 0;
+  if (ctx->ttm) {
     HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     if (imdgpu_ttm_move_internal(ctx)) return 1;
   } else {
-    if (launch_forces(ctx)) return 1;
     const int n = ctx->nlocal, nb = nblk(n, 256);
     double h = 0.5 * ctx->nbl_margin;
     ProfScope ps(ctx, PROF_INTEGRATE);
@@ -2634,6 +2648,10 @@ extern "C" int imdgpu_md_step(imdgpu_ctx *ctx, int steps)
   if (ctx->h_counters[CNT_INVALID]) { ctx->have_valid_nbl = 0; ctx->need_fix_cells = 1; }
   if (ctx->h_counters[CNT_TTM_TIMEOUT]) return imdgpu_fail(ctx, "TTM lattice: a sub-step hand-off timed out; the lattice of this step is not valid (IMDGPU_TTM_PERSIST=0 disables the persistent sub-step kernel)");
   return 0;
+}
+extern "C" int imdgpu_md_step(imdgpu_ctx *ctx, int steps)
+{
+  return imdgpu_md_step_begin(ctx, steps) || imdgpu_md_step_end(ctx, steps);
 }
 
 extern "C" int imdgpu_get_sums(imdgpu_ctx *ctx, double sums[8], double *ekin, int *nbl_count)

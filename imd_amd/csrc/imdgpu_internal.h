@@ -134,6 +134,7 @@ struct imdgpu_ctx {
   int tile_balance = 0;             // set by make_nblist when some tiles are (nearly) empty: see block_tile_range
   long long *d_wprefix = nullptr; size_t wprefix_cap = 0;   // [ntiles + 1] cost prefix of the tiles (k_tile_wprefix)
   void *dist = nullptr;
+  int step_open = 0;                  // imdgpu_md_step_begin has enqueued a step that imdgpu_md_step_end has not closed yet
   const int *pass1_guard = nullptr;   // device int: a pass-1 kernel launched AHEAD of the host's look at the list-validity flag returns at once when it is set
 };
 

@@ -1534,6 +1534,7 @@ static int ttm_xfer(imdgpu_ctx *ctx, const imdgpu_ttm_fields *f, bool down)
 {
   NEED_TTM();
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (ctx->step_open) HIPCHK(hipStreamSynchronize(ctx->stream2));   // between md_step_begin and _end the lattice chain runs on the side stream
   if (down && ttm_check_mailbox(ctx)) return 1;
   const size_t n = t->ncell;
   auto X = [&](void *host, void *dev, size_t bytes) -> int {
@@ -1917,6 +1918,7 @@ extern "C" int imdgpu_ttm_diff(imdgpu_ctx *ctx, double tau)
 extern "C" int imdgpu_ttm_cfl_maxdt(imdgpu_ctx *ctx, int steps, double *out)
 {
   NEED_TTM();
+  if (ctx->step_open) HIPCHK(hipStreamSynchronize(ctx->stream2));
   hipLaunchKernelGGL(k_ttm_cfl, dim3(1), dim3(1024), 0, ctx->stream, L, t->natoms, t->fd_k[t->kcur], t->Ce, t->d_red);
   double mx = 0;
   HIPCHK(hipMemcpyAsync(&mx, t->d_red, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

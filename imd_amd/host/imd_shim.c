@@ -287,6 +287,144 @@ static void gather_ghosts(int with_dF)
 #endif
 
 #ifdef NBL
+/* ---- LEVEL 2 (IMD_SHIM_LEVEL=2; one rank, neighbour-list build): the atoms LIVE on the device ---------------------------
+ * The reference's main loop stays what it is (imd_main_3d.c:398-812) -- calc_forces, [calc_ttm,] move_atoms, the writers,
+ * check_nblist -- but its three hot calls only enqueue device work:
+ *   calc_forces(steps) = imdgpu_md_step_begin  (fix_cells + make_nblist when the list is stale, the force passes, calc_ttm
+ *                        forked beside them),
+ *   calc_ttm()         = nothing left to do,
+ *   move_atoms()       = imdgpu_md_step_end    (move_atoms_nve / move_atoms_ttm + check_nblist on the device); the global
+ *                        function pointer `move_atoms` (globals.h:1777) is re-pointed here at the first calc_forces,
+ *   check_nblist()     = have_valid_nbl from the device's flag.
+ * The host's cell arrays are brought up to date only when the host is about to READ them: after move_atoms on checkpoint
+ * steps (write_config, imd_main_3d.c:702-705) and on the last step, after calc_forces on force_int steps, and on the
+ * steps listed in IMD_SHIM_SYNC_STEPS (comma separated; "host looks at the atoms after calc_forces of these steps").
+ * tot_pot_energy / virial / tot_kin_energy follow on eng_int steps (write_eng_file), the lattice l1/l2 on ttm_int steps.
+ * Atoms change cells on the device only; a sync rebuilds the host cells from the device's arrangement (alloc_cell as
+ * needed).  Host-side edits of atoms between syncs are not seen by the device. */
+static int g_level2 = -1, g_dev_atoms = 0;
+static void (*g_host_move_atoms)(void) = NULL;
+#ifdef TTM
+static int g_ttm_ready, g_fdn;                    /* defined with the TTM part below */
+static void lattice_to_host(void);
+#endif
+static int l2_on(void)
+{
+  if (g_level2 < 0) {
+    const char *e = getenv("IMD_SHIM_LEVEL");
+    g_level2 = (e && atoi(e) == 2) ? 1 : 0;
+    if (g_level2 && cpu_dim.x * cpu_dim.y * cpu_dim.z != 1) error("imd_shim: IMD_SHIM_LEVEL=2 serves one rank (several ranks: level 1, or the library's own multi-rank loop imdgpu_dist_step)");
+  }
+  return g_level2;
+}
+static int l2_listed(const char *var, int s)
+{
+  const char *e = getenv(var);
+  if (e == NULL) return 0;
+  while (*e) {
+    char *end; long v = strtol(e, &end, 10);
+    if (end == e) break;
+    if (v == s) return 1;
+    e = end; while (*e == ',' || *e == ' ') e++;
+  }
+  return 0;
+}
+/* device -> host cells: the device's arrangement replaces the host's */
+static void l2_sync_down(void)
+{
+  int nl = 0, ng = 0, k, nc = 0;
+  double sums[8], ek = 0;
+  gpu_check(imdgpu_num_atoms(G, &nl, &ng));
+  ensure_host(nl);
+  gpu_check(imdgpu_download_atoms(G, g_cn, g_ort, g_imp, g_kraft, g_epot, g_rho, g_dF, g_nn, g_num, g_sorte, NULL));
+  for (k = 0; k < NCELLS; k++) {
+    cell *p = CELLPTR(k);
+    int c = g_cn[SHIM_CELLIDX(p)];
+    if (c > p->n_max) alloc_cell(p, c + 8);
+    p->n = c;
+  }
+  (void) cell_offsets();
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+  for (k = 0; k < NCELLS; k++) {
+    cell *p = CELLPTR(k);
+    int i, m = g_off[k];
+    for (i = 0; i < p->n; i++, m++) {
+      ORT(p, i, X) = g_ort[3 * m]; ORT(p, i, Y) = g_ort[3 * m + 1]; ORT(p, i, Z) = g_ort[3 * m + 2];
+      IMPULS(p, i, X) = g_imp[3 * m]; IMPULS(p, i, Y) = g_imp[3 * m + 1]; IMPULS(p, i, Z) = g_imp[3 * m + 2];
+      KRAFT(p, i, X) = g_kraft[3 * m]; KRAFT(p, i, Y) = g_kraft[3 * m + 1]; KRAFT(p, i, Z) = g_kraft[3 * m + 2];
+      POTENG(p, i) = g_epot[m]; NUMMER(p, i) = g_num[m]; SORTE(p, i) = g_sorte[m]; VSORTE(p, i) = g_sorte[m];
+      MASSE(p, i) = masses[g_sorte[m]];
+#ifdef EAM2
+      EAM_RHO(p, i) = g_rho[m]; EAM_DF(p, i) = g_dF[m];
+#endif
+#ifdef TTM
+      NUMNEIGHS(p, i) = g_nn[m];
+#endif
+    }
+  }
+  gpu_check(imdgpu_get_sums(G, sums, &ek, &nc));
+  nbl_count = nc;
+}
+static void l2_move_atoms(void)
+{
+  long long valid = 1;
+  gpu_check(imdgpu_md_step_end(G, steps));
+  gpu_check(imdgpu_get_info(G, "have_valid_nbl", &valid));
+  have_valid_nbl = (int) valid;
+  if ((eng_int > 0 && 0 == steps % eng_int) || steps == steps_max) {
+    double ek = 0; int nc = 0;
+    gpu_check(imdgpu_get_sums(G, NULL, &ek, &nc));
+    tot_kin_energy = ek; nbl_count = nc;
+  }
+  if ((checkpt_int > 0 && 0 == steps % checkpt_int && steps > 0) || steps == steps_max) l2_sync_down();   /* write_config reads the cells */
+#ifdef TTM
+  if ((ttm_int > 0 && 0 == steps % ttm_int) || steps == steps_max) {                                      /* ttm_writeout reads l1 */
+    double mdt = 0.0;
+    gpu_check(imdgpu_ttm_cfl_maxdt(G, steps, &mdt));
+    max_dt_ttm = mdt;
+    lattice_to_host();
+  }
+#endif
+}
+#ifdef TTM
+static void ttm_gpu_init(void);
+#endif
+static void l2_calc_forces(int steps_)
+{
+  double sums[8];
+  int n, is_short = 0;
+  if (!g_dev_atoms) {                             /* first call: the host's arrangement goes to the device once */
+    n = count_atoms();
+    ensure_host(n);
+    gather_cells(1);
+    gpu_check(imdgpu_upload_cells(G, g_cn, n, g_ort, g_imp, g_mas, g_sorte, g_num));
+    g_have_cells = 1; g_dev_atoms = 1;
+    g_host_move_atoms = move_atoms;
+    move_atoms = l2_move_atoms;                   /* the active integrator routine, globals.h:1777 */
+#ifdef TTM
+    if (!g_ttm_ready) ttm_gpu_init();
+#endif
+  }
+  gpu_check(imdgpu_md_step_begin(G, steps_));
+  have_valid_nbl = 1;
+  if ((eng_int > 0 && 0 == steps_ % eng_int) || steps_ == steps_max) {
+    gpu_check(imdgpu_get_sums(G, sums, NULL, NULL));
+    tot_pot_energy = sums[0]; virial = sums[1];
+    vir_xx = vir_yy = vir_zz = vir_xy = vir_yz = vir_zx = 0.0;
+  }
+  (void) is_short;
+  nfc++;
+  if (l2_listed("IMD_SHIM_SYNC_STEPS", steps_)
+#ifdef FORCE
+      || (force_int > 0 && 0 == steps_ % force_int)
+#endif
+     ) l2_sync_down();
+}
+#endif /* NBL: level 2 */
+
+#ifdef NBL
 void make_nblist(void)
 {
   int n = count_atoms(), k, i;
@@ -348,6 +486,7 @@ void check_nblist(void)
   /* same rule on the host copies the integrator just advanced (imd_forces_nbl.c:1062-1092) */
   real max1 = 0.0;
   int k, i;
+  if (G && l2_on() && g_dev_atoms) return;        /* level 2: the device integrator has checked; have_valid_nbl is set by move_atoms */
   for (k = 0; k < NCELLS; k++) {
     cell *p = CELLPTR(k);
     for (i = 0; i < p->n; i++) {
@@ -370,6 +509,7 @@ void calc_forces(int steps)
   int n, k, i, m = 0, is_short = 0;
   gpu_init();
 #ifdef NBL
+  if (l2_on()) { l2_calc_forces(steps); return; }
   if (0 == have_valid_nbl) {
     fix_cells();                                  /* the host's own re-binning, imd_forces_nbl.c:300-308 */
 #ifdef MPI
@@ -636,6 +776,18 @@ void calc_ttm(void)
   double mdt = 0.0;
   gpu_init();
   if (!g_have_cells) error("imd_shim: calc_ttm before calc_forces");
+#ifdef NBL
+  if (l2_on()) {                                   /* level 2: forked beside the force passes by calc_forces */
+    fd_n_timesteps = 100; diff_substeps = fd_n_timesteps;
+    if (l2_listed("IMD_SHIM_SYNC_STEPS", steps)) {  /* the host wants to look at l1/l2 after this calc_ttm */
+      double mdt2 = 0.0;
+      gpu_check(imdgpu_ttm_cfl_maxdt(G, steps, &mdt2));
+      max_dt_ttm = mdt2;
+      lattice_to_host();
+    }
+    return;
+  }
+#endif
   if (!g_ttm_ready) ttm_gpu_init();
   fd_n_timesteps = 100; diff_substeps = fd_n_timesteps;              /* imd_ttm_3D.c:51-52 */
   /* same arrangement as the calc_forces of this step; the momenta are the host integrator's */

@@ -125,6 +125,12 @@ int imdgpu_move_atoms_nve(imdgpu_ctx *ctx, double *tot_kin_energy);
  * check_nblist (main_loop body, imd_main_3d.c:406-812).  Results of the
  * reductions stay on the device until imdgpu_get_sums. */
 int imdgpu_md_step(imdgpu_ctx *ctx, int steps);
+/* The same step in two halves for a host that keeps its OWN main loop (level 2): begin = what calc_forces
+ * [+ calc_ttm] do (imd_main_3d.c:398-534; list maintenance included, nothing waited for), end = move_atoms + check_nblist
+ * (:564,812) and the step's one host round trip.  Between the two the host may do whatever its loop does there; device
+ * results stay on the device until it asks for them (imdgpu_get_sums, imdgpu_download_atoms, imdgpu_ttm_download). */
+int imdgpu_md_step_begin(imdgpu_ctx *ctx, int steps);
+int imdgpu_md_step_end(imdgpu_ctx *ctx, int steps);
 int imdgpu_get_sums(imdgpu_ctx *ctx, double sums[8], double *tot_kin_energy,
                     int *nbl_count);
 

@@ -219,6 +219,79 @@ def test_reference_ttm_main_loop_on_gpu_forces_and_gpu_calc_ttm(eos):
 GPU_TTM_FN = os.path.join(ROOT, "oracle", "_ref", "imd_mpi_eam_ttm3d_nbl_gpufn")
 
 
+@pytest.mark.skipif(not (os.path.exists(CPU) and os.path.exists(GPU)), reason="oracle/_ref binaries not built")
+def test_level2_reference_main_loop_with_the_atoms_on_the_device():
+    """Level 2 (IMD_SHIM_LEVEL=2): the reference's own main loop, but calc_forces only enqueues the device step
+    (imdgpu_md_step_begin), the global `move_atoms` pointer (globals.h:1777) is re-pointed to the device integrator
+    (imdgpu_md_step_end) and check_nblist reads the device's flag; the host's cells are refreshed only where the host reads
+    them (IMD_SHIM_SYNC_STEPS = the probe's steps, the final checkpoint).  Trajectory, energies file and rebuild schedule
+    equal the CPU binary's over 30 steps; the checkpoint written at the end holds the device's atoms."""
+    out = {}
+    for tag, exe, extra in (("cpu", CPU, {}), ("gpu", GPU, dict(IMD_SHIM_LEVEL="2", IMD_SHIM_SYNC_STEPS="0,1,30"))):
+        with tempfile.TemporaryDirectory() as d:
+            potential.write_synthetic_eam_files(d)
+            open(os.path.join(d, "t.param"), "w").write(PARAM.replace("checkpt_int 100000", "checkpt_int 30"))
+            env = dict(os.environ, IMD_PROBE_DIR=d, IMD_PROBE_STEPS="0,1,30", **extra)
+            r = subprocess.run([exe, "-p", "t.param"], cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                               text=True, timeout=300)
+            assert r.returncode == 0, r.stdout[-2000:]
+            out[tag] = {s: po.read_probe(os.path.join(d, "probe.0.%d.bin" % s)) for s in (0, 1, 30)}
+            out[tag]["eng"] = np.loadtxt(os.path.join(d, "out.eng"))
+            out[tag]["chkpt"] = open(os.path.join(d, "out.00001.chkpt")).read().splitlines()
+    for s in (0, 1, 30):
+        a, b = out["gpu"][s], out["cpu"][s]
+        oa, ob = np.argsort(_inner_ids(a)), np.argsort(_inner_ids(b))
+        assert len(oa) == len(ob)
+        assert np.abs(a["kraft"][oa] - b["kraft"][ob]).max() < 1e-9 * max(np.abs(b["kraft"]).max(), 1e-3), "forces differ at step %d" % s
+        assert np.abs(_inner_pos(a)[oa] - _inner_pos(b)[ob]).max() < 1e-9
+        assert np.abs(a["impuls"][oa] - b["impuls"][ob]).max() < 1e-9 * np.abs(b["impuls"]).max()
+        assert abs(a["tot_pot_energy"] - b["tot_pot_energy"]) < 1e-9 * abs(b["tot_pot_energy"])
+    assert out["gpu"][30]["nbl_count"] == out["cpu"][30]["nbl_count"] >= 2
+    assert np.allclose(out["gpu"]["eng"], out["cpu"]["eng"], rtol=1e-6, atol=1e-9)
+    # the checkpoint of step 30 (write_config after move_atoms): same atoms, positions to the file's printed precision
+    def atoms(lines):
+        rows = np.array([[float(v) for v in l.split()] for l in lines if l and not l.startswith("#")])
+        return rows[np.argsort(rows[:, 0])]
+    A, B = atoms(out["gpu"]["chkpt"]), atoms(out["cpu"]["chkpt"])
+    assert A.shape == B.shape and np.array_equal(A[:, 0], B[:, 0])
+    assert np.allclose(A[:, 3:6], B[:, 3:6], rtol=0, atol=2e-6)
+
+
+@pytest.mark.skipif(not (os.path.exists(CPU_TTM) and os.path.exists(GPU_TTM)), reason="oracle/_ref binaries not built")
+def test_level2_reference_ttm_main_loop_with_atoms_and_lattice_on_the_device():
+    """The 3D-TTM program at level 2: calc_forces forks calc_ttm beside the force passes on the device, move_atoms_ttm runs
+    there too; l1/l2 and the cells come back on the probe's steps, on ttm_int steps (ttm_writeout) and at the end.
+    Lattice within 1e-9, atoms within 1e-9, the .ttm files at their printed precision."""
+    out = {}
+    steps = (0, 1, 6, 12)
+    for tag, exe, extra in (("cpu", CPU_TTM, {}), ("gpu", GPU_TTM, dict(IMD_SHIM_LEVEL="2", IMD_SHIM_SYNC_STEPS="0,1,6,12"))):
+        with tempfile.TemporaryDirectory() as d:
+            potential.write_synthetic_eam_files(d)
+            _write_planar_eos(d)
+            open(os.path.join(d, "t.param"), "w").write(PARAM_TTM)
+            env = dict(os.environ, IMD_PROBE_DIR=d, IMD_PROBE_STEPS=",".join(map(str, steps)), **extra)
+            r = subprocess.run([exe, "-p", "t.param"], cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                               text=True, timeout=600)
+            assert r.returncode == 0, r.stdout[-3000:]
+            out[tag] = {s: po.read_probe(os.path.join(d, "probe.0.%d.bin" % s)) for s in steps}
+            out[tag]["lat"] = {s: po.read_ttm_probe(os.path.join(d, "ttm.0.%d.bin" % s))["stages"]["cfl"] for s in steps}
+            out[tag]["ttm_file"] = [np.loadtxt(os.path.join(d, "out.%d.ttm" % k)) for k in (1, 2)]
+    inner = (slice(1, -1),) * 3
+    for s in steps:
+        a, b = out["gpu"]["lat"][s], out["cpu"]["lat"][s]
+        assert np.array_equal(a["lat"]["natoms"][inner], b["lat"]["natoms"][inner])
+        for f in ("temp", "temp2", "U", "U2", "xi", "md_temp", "dens", "vcom", "fd_k", "fd_g", "Ce"):
+            x, y = a["lat"][f][inner], b["lat"][f][inner]
+            assert np.abs(x - y).max() <= 1e-9 * np.abs(y).max(), (s, f)
+        A, B = out["gpu"][s], out["cpu"][s]
+        oa, ob = np.argsort(_inner_ids(A)), np.argsort(_inner_ids(B))
+        assert np.abs(_inner_pos(A)[oa] - _inner_pos(B)[ob]).max() < 1e-9, s
+        assert np.abs(A["impuls"][oa] - B["impuls"][ob]).max() < 1e-9 * np.abs(B["impuls"]).max(), s
+        assert np.array_equal(A["numneighs"][oa], B["numneighs"][ob])
+    for x, y in zip(out["gpu"]["ttm_file"], out["cpu"]["ttm_file"]):
+        assert np.allclose(x, y, rtol=2e-6, atol=1e-12)
+
+
 @pytest.mark.skipif(not (os.path.exists(CPU_TTM) and os.path.exists(GPU_TTM_FN)), reason="oracle/_ref binaries not built")
 def test_reference_calls_the_lattice_functions_one_by_one():
     """The per-function boundary: update_fd, do_cell_activation, do_FILLMESH, ttm_fill_ghost_layers,
