@@ -366,6 +366,18 @@ static void l2_sync_down(void)
   }
   gpu_check(imdgpu_get_sums(G, sums, &ek, &nc));
   nbl_count = nc;
+  /* the list globals tl/tb/cl_off (globals.h:184-188) of the arrangement just handed over, for modules that read them */
+  {
+    int ntb = 0;
+    const int with_list = getenv("IMD_SHIM_NO_NBL_EXPORT") == NULL;
+    if (with_list) gpu_check(imdgpu_export_nblist(G, NULL, NULL, NULL, &ntb));
+    tl = (int *) realloc(tl, (nl + 1) * sizeof(int));
+    tb = (int *) realloc(tb, (ntb + 1) * sizeof(int));
+    cl_off = (int *) realloc(cl_off, nallcells * sizeof(int));
+    if (!tl || !tb || !cl_off) error("imd_shim: cannot allocate neighbor table");
+    if (with_list) { gpu_check(imdgpu_export_nblist(G, tl, tb, cl_off, &ntb)); nb_max = ntb; }
+    else { memset(tl, 0, (nl + 1) * sizeof(int)); tb[0] = 0; memset(cl_off, 0, nallcells * sizeof(int)); }
+  }
 }
 static void l2_move_atoms(void)
 {
