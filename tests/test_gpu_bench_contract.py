@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_line_has_the_contract_fields():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--box", "24", "24", "24", "--steps", "12", "--warmup", "3",
-                        "--cpu-box", "24", "--cpu-steps", "3", "--cpu-box-mpi", "24", "--cpu-steps-mpi", "3"], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                        "--cpu-box", "24", "--cpu-steps", "3", "--cpu-cells-per-rank", "12", "--cpu-steps-mpi", "3"], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -37,6 +37,9 @@ def test_bench_line_has_the_contract_fields():
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0
     if cb["cores"] > 1:          # the reference's MPI + TTM build on the host cores; the one-core NVE figure rides along
         assert "imd_mpi_eam_ttm3d_nbl" in cb["sample"] and cb["serial"]["cores"] == 1 and cb["serial"]["value"] > 0
+        assert "do_ADV on" in cb["sample"] and cb["cores_available"] >= cb["cores"] and "cores_cgroup_quota" in cb
+    assert "do_ADV on" in d["config"]["workload"]                      # the reference's own calc_ttm sequence (imd_ttm_3D.c:57-60)
+    assert "roofline_other" in d and "rebuild_ms" in d
 
 
 def _one_json_line(r):
