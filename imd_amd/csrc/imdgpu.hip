@@ -2654,6 +2654,202 @@ extern "C" int imdgpu_md_step(imdgpu_ctx *ctx, int steps)
   return imdgpu_md_step_begin(ctx, steps) || imdgpu_md_step_end(ctx, steps);
 }
 
+// ---- the reference's cell-pair entry points on host arrays (do_forces, do_forces_eam2, do_embedding_energy) ------------
+// For hosts that keep their own cell-pair loop (imd_main_risc_3d.c:31-182) and call the kernels of imd_forces.c /
+// imd_forces_eam2.c per pair of cells: the same contract -- results are ADDED to the arrays passed in, each pair is visited
+// once, the partner gets the opposite force -- on a pair of small host arrays.  One workgroup per call (cells hold a few
+// dozen atoms); a compatibility path, three orders of magnitude away from the list kernels' throughput.
+struct CellPairArgs {
+  int np, nq, same, ntypes;
+  const double *pos_p, *pos_q, *dF_p, *dF_q;     // xyz interleaved
+  const int *typ_p, *typ_q;
+  double sx, sy, sz;
+  double *f_p, *f_q, *e_p, *e_q, *rho_p, *rho_q;
+  int *nn_p, *nn_q;
+  double *sums;                                  // [0] Epot, [1] virial
+  int *is_short;
+  TabPar pair, rho;
+};
+// which = 1: do_forces (imd_forces.c:33-326: pair term, host electron density, TTM neighbour count);
+// which = 2: do_forces_eam2 (imd_forces_eam2.c:236-369: the EAM force from dF = EAM_DF of both atoms)
+template <int WHICH>
+__global__ void k_cellpair(CellPairArgs a)
+{
+  const int inc = a.ntypes * a.ntypes;
+  double epot = 0, vir = 0;
+  int shortd = 0;
+  for (int i = threadIdx.x; i < a.np; i += blockDim.x) {
+    const double tx = a.pos_p[3 * i] - a.sx, ty = a.pos_p[3 * i + 1] - a.sy, tz = a.pos_p[3 * i + 2] - a.sz;
+    const int pt = a.typ_p[i];
+    double fx = 0, fy = 0, fz = 0, ei = 0, ri = 0;
+    int ni = 0;
+    for (int j = a.same ? i + 1 : 0; j < a.nq; j++) {
+      const double dx = a.pos_q[3 * j] - tx, dy = a.pos_q[3 * j + 1] - ty, dz = a.pos_q[3 * j + 2] - tz;
+      const double r2 = dx * dx + dy * dy + dz * dz;
+      const int qt = a.typ_q[j];
+      if (WHICH == 1) {
+        const int col = pt * a.ntypes + qt, col2 = qt * a.ntypes + pt;
+        if (a.pair.tab && r2 <= a.pair.end[col]) {
+          const Tab3 q = tab3(a.pair.tab, inc, col, a.pair.begin[col], a.pair.end[col], a.pair.invstep[col], r2, shortd);
+          const double pot = tab_val(q), grad = tab_grad(q);
+          fx += dx * grad; fy += dy * grad; fz += dz * grad;
+          atomicAdd(&a.f_q[3 * j], -dx * grad); atomicAdd(&a.f_q[3 * j + 1], -dy * grad); atomicAdd(&a.f_q[3 * j + 2], -dz * grad);
+          epot += pot; ei += 0.5 * pot; atomicAdd(&a.e_q[j], 0.5 * pot);
+          vir -= r2 * grad;
+          if (a.nn_p) { ni++; atomicAdd(&a.nn_q[j], 1); }
+        }
+        if (a.rho.tab) {
+          double rh = 0;
+          if (r2 < a.rho.end[col]) {
+            const Tab3 q = tab3(a.rho.tab, inc, col, a.rho.begin[col], a.rho.end[col], a.rho.invstep[col], r2, shortd);
+            rh = tab_val(q); ri += rh;
+          }
+          if (pt == qt) { if (r2 < a.rho.end[col]) atomicAdd(&a.rho_q[j], rh); }
+          else if (r2 < a.rho.end[col2]) {
+            const Tab3 q = tab3(a.rho.tab, inc, col2, a.rho.begin[col2], a.rho.end[col2], a.rho.invstep[col2], r2, shortd);
+            atomicAdd(&a.rho_q[j], tab_val(q));
+          }
+        }
+      } else {
+        const int col1 = qt * a.ntypes + pt, col2 = pt * a.ntypes + qt;
+        if (r2 < a.rho.end[col1] || r2 < a.rho.end[col2]) {
+          const Tab3 q1 = tab3(a.rho.tab, inc, col1, a.rho.begin[col1], a.rho.end[col1], a.rho.invstep[col1], r2, shortd);
+          const double rsi = tab_grad(q1);
+          double rsj = rsi;
+          if (col1 != col2) { const Tab3 q2 = tab3(a.rho.tab, inc, col2, a.rho.begin[col2], a.rho.end[col2], a.rho.invstep[col2], r2, shortd); rsj = tab_grad(q2); }
+          const double g = 0.5 * (a.dF_p[i] * rsj + a.dF_q[j] * rsi);
+          fx += dx * g; fy += dy * g; fz += dz * g;
+          atomicAdd(&a.f_q[3 * j], -dx * g); atomicAdd(&a.f_q[3 * j + 1], -dy * g); atomicAdd(&a.f_q[3 * j + 2], -dz * g);
+          vir -= r2 * g;
+        }
+      }
+    }
+    atomicAdd(&a.f_p[3 * i], fx); atomicAdd(&a.f_p[3 * i + 1], fy); atomicAdd(&a.f_p[3 * i + 2], fz);
+    if (WHICH == 1) { atomicAdd(&a.e_p[i], ei); if (a.rho.tab) atomicAdd(&a.rho_p[i], ri); if (a.nn_p) atomicAdd(&a.nn_p[i], ni); }
+  }
+  atomicAdd(&a.sums[0], epot); atomicAdd(&a.sums[1], vir);
+  if (shortd) *a.is_short = 1;
+}
+
+// staging: [pos_p 3np][pos_q 3nq][dF_p np][dF_q nq][f_p 3np][f_q 3nq][e_p][e_q][rho_p][rho_q][sums 2] doubles, then ints
+static int cellpair_call(imdgpu_ctx *ctx, int which, int np, const double *ort_p, const int *sorte_p, const double *dF_p, int nq,
+                         const double *ort_q, const int *sorte_q, const double *dF_q, const double pbc[3], int same_cell,
+                         double *kraft_p, double *kraft_q, double *poteng_p, double *poteng_q, double *rho_p, double *rho_q,
+                         int *nn_p, int *nn_q, double *epot, double *virial, int *is_short)
+{
+  HIPCHK(hipSetDevice(ctx->device));
+  if (np <= 0 || nq <= 0) return 0;
+  if (which == 2 && !ctx->rho.present) return imdgpu_fail(ctx, "do_forces_eam2: no rho_h_tab uploaded");
+  const bool same_arr = same_cell != 0;
+  const size_t nd = (size_t) 3 * (np + nq) + (np + nq) + 3 * (np + nq) + 4 * (size_t) (np + nq) + 2, ni = (size_t) 2 * (np + nq) + 1;
+  const size_t bytes = nd * sizeof(double) + ni * sizeof(int);
+  if (bytes > ctx->stage_bytes) {
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->d_stage) (void) hipFree(ctx->d_stage);
+    ctx->stage_bytes = bytes * 2 + 4096;
+    HIPCHK(hipMalloc(&ctx->d_stage, ctx->stage_bytes));
+  }
+  std::vector<double> h(nd, 0.0); std::vector<int> hi(ni, 0);
+  double *d = (double *) ctx->d_stage; int *di = (int *) (d + nd);
+  size_t o = 0;
+  const size_t o_pp = o; memcpy(&h[o], ort_p, 24 * (size_t) np); o += 3 * (size_t) np;
+  const size_t o_pq = o; memcpy(&h[o], ort_q, 24 * (size_t) nq); o += 3 * (size_t) nq;
+  const size_t o_dp = o; if (dF_p) memcpy(&h[o], dF_p, 8 * (size_t) np); o += np;
+  const size_t o_dq = o; if (dF_q) memcpy(&h[o], dF_q, 8 * (size_t) nq); o += nq;
+  const size_t o_fp = o; o += 3 * (size_t) np;
+  const size_t o_fq = o; o += 3 * (size_t) nq;
+  const size_t o_ep = o; o += np; const size_t o_eq = o; o += nq;
+  const size_t o_rp = o; o += np; const size_t o_rq = o; o += nq;
+  const size_t o_s = o;
+  for (int i = 0; i < np; i++) hi[i] = sorte_p ? sorte_p[i] : 0;
+  for (int j = 0; j < nq; j++) hi[np + j] = sorte_q ? sorte_q[j] : 0;
+  HIPCHK(hipMemcpyAsync(d, h.data(), nd * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(di, hi.data(), ni * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  CellPairArgs a;
+  a.np = np; a.nq = nq; a.same = same_cell; a.ntypes = ctx->ntypes;
+  a.pos_p = d + o_pp; a.pos_q = d + o_pq; a.dF_p = d + o_dp; a.dF_q = d + o_dq;
+  a.typ_p = di; a.typ_q = di + np;
+  a.sx = pbc[0]; a.sy = pbc[1]; a.sz = pbc[2];
+  // the same cell passed twice (p == q): ONE set of output arrays, as the reference's pointers alias
+  a.f_p = d + o_fp; a.f_q = same_arr ? d + o_fp : d + o_fq; a.e_p = d + o_ep; a.e_q = same_arr ? d + o_ep : d + o_eq;
+  a.rho_p = d + o_rp; a.rho_q = same_arr ? d + o_rp : d + o_rq;
+  a.nn_p = nn_p ? di + np + nq : nullptr; a.nn_q = nn_p ? (same_arr ? di + np + nq : di + 2 * np + nq) : nullptr;
+  a.sums = d + o_s; a.is_short = di + ni - 1;
+  a.pair = ctx->pair.present ? ctx->pair.par : TabPar{}; a.rho = ctx->rho.present ? ctx->rho.par : TabPar{};
+  if (!ctx->pair.present) a.pair.tab = nullptr;
+  if (!ctx->rho.present) a.rho.tab = nullptr;
+  if (which == 1) hipLaunchKernelGGL((k_cellpair<1>), dim3(1), dim3(64), 0, ctx->stream, a);
+  else hipLaunchKernelGGL((k_cellpair<2>), dim3(1), dim3(64), 0, ctx->stream, a);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(h.data(), d, nd * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(hi.data(), di, ni * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < 3 * np; i++) kraft_p[i] += h[o_fp + i];
+  if (!same_arr) for (int j = 0; j < 3 * nq; j++) kraft_q[j] += h[o_fq + j];
+  if (which == 1) {
+    for (int i = 0; i < np; i++) { if (poteng_p) poteng_p[i] += h[o_ep + i]; if (rho_p) rho_p[i] += h[o_rp + i]; if (nn_p) nn_p[i] += hi[np + nq + i]; }
+    if (!same_arr) for (int j = 0; j < nq; j++) { if (poteng_q) poteng_q[j] += h[o_eq + j]; if (rho_q) rho_q[j] += h[o_rq + j]; if (nn_q) nn_q[j] += hi[2 * np + nq + j]; }
+    if (epot) *epot += h[o_s];
+  }
+  if (virial) *virial += h[o_s + 1];
+  if (is_short && hi[ni - 1]) *is_short = 1;
+  return 0;
+}
+extern "C" int imdgpu_do_forces(imdgpu_ctx *ctx, int np, const double *ort_p, const int *sorte_p, int nq, const double *ort_q,
+                                const int *sorte_q, const double pbc[3], int same_cell, double *kraft_p, double *kraft_q,
+                                double *poteng_p, double *poteng_q, double *eam_rho_p, double *eam_rho_q, int *numneighs_p,
+                                int *numneighs_q, double *epot, double *virial, int *is_short)
+{
+  return cellpair_call(ctx, 1, np, ort_p, sorte_p, nullptr, nq, ort_q, sorte_q, nullptr, pbc, same_cell, kraft_p, kraft_q, poteng_p, poteng_q,
+                       eam_rho_p, eam_rho_q, numneighs_p, numneighs_q, epot, virial, is_short);
+}
+extern "C" int imdgpu_do_forces_eam2(imdgpu_ctx *ctx, int np, const double *ort_p, const int *sorte_p, const double *eam_dF_p, int nq,
+                                     const double *ort_q, const int *sorte_q, const double *eam_dF_q, const double pbc[3], int same_cell,
+                                     double *kraft_p, double *kraft_q, double *virial, int *is_short)
+{
+  return cellpair_call(ctx, 2, np, ort_p, sorte_p, eam_dF_p, nq, ort_q, sorte_q, eam_dF_q, pbc, same_cell, kraft_p, kraft_q, nullptr, nullptr,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, virial, is_short);
+}
+// do_embedding_energy (imd_forces_eam2.c:202-230): F(rho) is ADDED to pot_eng, EAM_DF = 2 F'(rho) written, the sum returned
+__global__ void k_embed_host(int n, int ntypes, const double *rho, const int *type, TabPar emb, double *epot, double *dF, double *sum)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int col = ntypes == 1 ? 0 : type[i], dummy = 0;
+  const Tab3 q = tab3(emb.tab, ntypes, col, emb.begin[col], emb.end[col], emb.invstep[col], rho[i], dummy);
+  epot[i] = tab_val(q); dF[i] = tab_grad(q);
+  (void) sum;
+}
+extern "C" int imdgpu_do_embedding_energy(imdgpu_ctx *ctx, int n, const double *eam_rho, const int *sorte, double *pot_eng, double *eam_dF,
+                                          double *tot_pot_energy)
+{
+  HIPCHK(hipSetDevice(ctx->device));
+  if (!ctx->emb.present) return imdgpu_fail(ctx, "do_embedding_energy: no embed_pot uploaded");
+  if (n <= 0) return 0;
+  const size_t bytes = (size_t) n * (3 * sizeof(double) + sizeof(int));
+  if (bytes > ctx->stage_bytes) {
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->d_stage) (void) hipFree(ctx->d_stage);
+    ctx->stage_bytes = bytes + 4096;
+    HIPCHK(hipMalloc(&ctx->d_stage, ctx->stage_bytes));
+  }
+  double *d = (double *) ctx->d_stage; int *di = (int *) (d + 3 * (size_t) n);
+  std::vector<int> t(n, 0);
+  if (sorte) for (int i = 0; i < n; i++) t[i] = sorte[i];
+  HIPCHK(hipMemcpyAsync(d, eam_rho, (size_t) n * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(di, t.data(), (size_t) n * 4, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_embed_host, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, n, ctx->ntypes, d, di, ctx->emb.par, d + n, d + 2 * (size_t) n, (double *) nullptr);
+  HIPCHK(hipGetLastError());
+  std::vector<double> e(n), g(n);
+  HIPCHK(hipMemcpyAsync(e.data(), d + n, (size_t) n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(g.data(), d + 2 * (size_t) n, (size_t) n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  double s = 0;
+  for (int i = 0; i < n; i++) { pot_eng[i] += e[i]; eam_dF[i] = g[i]; s += e[i]; }      // in atom order, like the reference's loop
+  if (tot_pot_energy) *tot_pot_energy += s;
+  return 0;
+}
+
 extern "C" int imdgpu_get_sums(imdgpu_ctx *ctx, double sums[8], double *ekin, int *nbl_count)
 {
   HIPCHK(hipStreamSynchronize(ctx->stream));

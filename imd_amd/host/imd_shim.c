@@ -599,7 +599,87 @@ void calc_forces(int steps)
   if (is_short) fprintf(stderr, "Short distance, step %d!\n", steps);
 }
 
+#if !defined(NBL) && defined(IMD_SHIM_CELLPAIR_FUNCTIONS)
+/* ---- the cell-pair kernels one by one, under the reference's own names and signatures ----------------------------------
+ *     void do_forces(cell *p, cell *q, vektor pbc, real *Epot, real *Virial, real *Vir_xx, ... real *Vir_xy);
+ *                                                              (prototypes.h:412, imd_forces.c:33)
+ *     void do_forces_eam2(cell *p, cell *q, vektor pbc, real *Virial, real *Vir_xx, ... real *Vir_xy);
+ *                                                              (prototypes.h:417, imd_forces_eam2.c:236)
+ *     void do_embedding_energy(void);                          (prototypes.h:418, imd_forces_eam2.c:202)
+ * for hosts that keep the cell-pair loop of imd_main_risc_3d.c:31-182 (its calc_forces) and call these per pair of cells:
+ * link the shim INSTEAD of imd_forces.o / imd_forces_eam2.o (and compile it with -Dcalc_forces=<unused name>, the host's
+ * own calc_forces stays).  Each call = the two cells' arrays to the device, one small launch, results added on the host:
+ * the contract of the originals at the price of two PCIe round trips per cell pair -- the whole-step calc_forces above is
+ * the fast path. */
+static int *cp_ints(const shortint *a, int n, int **buf, int *cap)
+{
+  int i;
+  if (n > *cap) { *cap = n + 64; *buf = (int *) realloc(*buf, *cap * sizeof(int)); if (!*buf) error("imd_shim: out of memory"); }
+  for (i = 0; i < n; i++) (*buf)[i] = a ? a[i] : 0;
+  return *buf;
+}
+void do_forces(cell *p, cell *q, vektor pbc, real *Epot, real *Virial, real *Vir_xx, real *Vir_yy, real *Vir_zz,
+               real *Vir_yz, real *Vir_zx, real *Vir_xy)
+{
+  static int *tp = NULL, *tq = NULL, ctp = 0, ctq = 0, *np_ = NULL, *nq_ = NULL, cnp = 0, cnq = 0;
+  double sh[3]; int same, is_short = 0, i;
+  gpu_init();
+  sh[0] = pbc.x; sh[1] = pbc.y; sh[2] = pbc.z;
+  same = (p == q) && pbc.x == 0 && pbc.y == 0 && pbc.z == 0;
+  cp_ints(p->sorte, p->n, &tp, &ctp); cp_ints(q->sorte, q->n, &tq, &ctq);
 #ifdef TTM
+  cp_ints(NULL, p->n, &np_, &cnp); cp_ints(NULL, q->n, &nq_, &cnq);
+#endif
+  gpu_check(imdgpu_do_forces(G, p->n, p->ort, tp, q->n, q->ort, tq, sh, same, p->kraft, q->kraft, p->pot_eng, q->pot_eng,
+#ifdef EAM2
+                             p->eam_rho, q->eam_rho,
+#else
+                             NULL, NULL,
+#endif
+#ifdef TTM
+                             np_, same ? np_ : nq_,
+#else
+                             NULL, NULL,
+#endif
+                             Epot, Virial, &is_short));
+#ifdef TTM
+  for (i = 0; i < p->n; i++) NUMNEIGHS(p, i) += np_[i];
+  if (!same) for (i = 0; i < q->n; i++) NUMNEIGHS(q, i) += nq_[i];
+#endif
+  if (is_short) printf("\n Short distance!\n");
+  (void) Vir_xx; (void) Vir_yy; (void) Vir_zz; (void) Vir_yz; (void) Vir_zx; (void) Vir_xy; (void) i; (void) np_; (void) nq_; (void) cnp; (void) cnq;
+}
+#ifdef EAM2
+void do_forces_eam2(cell *p, cell *q, vektor pbc, real *Virial, real *Vir_xx, real *Vir_yy, real *Vir_zz,
+                    real *Vir_yz, real *Vir_zx, real *Vir_xy)
+{
+  static int *tp = NULL, *tq = NULL, ctp = 0, ctq = 0;
+  double sh[3]; int same, is_short = 0;
+  gpu_init();
+  sh[0] = pbc.x; sh[1] = pbc.y; sh[2] = pbc.z;
+  same = (p == q) && pbc.x == 0 && pbc.y == 0 && pbc.z == 0;
+  cp_ints(p->sorte, p->n, &tp, &ctp); cp_ints(q->sorte, q->n, &tq, &ctq);
+  gpu_check(imdgpu_do_forces_eam2(G, p->n, p->ort, tp, p->eam_dF, q->n, q->ort, tq, q->eam_dF, sh, same, p->kraft, q->kraft, Virial, &is_short));
+  if (is_short) printf("\n Short distance!\n");
+  (void) Vir_xx; (void) Vir_yy; (void) Vir_zz; (void) Vir_yz; (void) Vir_zx; (void) Vir_xy;
+}
+void do_embedding_energy(void)
+{
+  static int *tp = NULL, ctp = 0;
+  int k;
+  gpu_init();
+  for (k = 0; k < NCELLS; k++) {
+    cell *p = CELLPTR(k);
+    if (p->n == 0) continue;
+    cp_ints(p->sorte, p->n, &tp, &ctp);
+    gpu_check(imdgpu_do_embedding_energy(G, p->n, p->eam_rho, tp, p->pot_eng, p->eam_dF, &tot_pot_energy));
+  }
+}
+#endif
+#endif /* IMD_SHIM_CELLPAIR_FUNCTIONS */
+
+#ifdef TTM
+
 /* ---- calc_ttm on the device ------------------------------------------------------------------------------- */
 static int     g_ttm_ready = 0, g_fdn = 0;
 static int    *g_fi[2];                               /* natoms, natoms_old */

@@ -17,7 +17,7 @@ SYMBOLS = [
     "imdgpu_set_geometry", "imdgpu_set_params", "imdgpu_upload_tables", "imdgpu_set_restrictions",
     "imdgpu_upload_cells", "imdgpu_upload_atoms", "imdgpu_update_positions", "imdgpu_num_atoms", "imdgpu_download_atoms",
     "imdgpu_fix_cells", "imdgpu_fill_ghosts", "imdgpu_make_nblist", "imdgpu_check_nblist",
-    "imdgpu_calc_forces", "imdgpu_move_atoms_nve", "imdgpu_md_step", "imdgpu_md_step_begin", "imdgpu_md_step_end", "imdgpu_get_sums",
+    "imdgpu_calc_forces", "imdgpu_move_atoms_nve", "imdgpu_do_forces", "imdgpu_do_forces_eam2", "imdgpu_do_embedding_energy", "imdgpu_md_step", "imdgpu_md_step_begin", "imdgpu_md_step_end", "imdgpu_get_sums",
     "imdgpu_export_nblist", "imdgpu_update_momenta", "imdgpu_nblist_stats",
     "imdgpu_profile_enable", "imdgpu_profile_reset", "imdgpu_profile_get",
     "imdgpu_ttm_init", "imdgpu_ttm_dims", "imdgpu_ttm_download", "imdgpu_ttm_upload", "imdgpu_ttm_update_fd", "imdgpu_ttm_adv", "imdgpu_ttm_commflux", "imdgpu_ttm_laser_rescale", "imdgpu_ttm_set_laser", "imdgpu_ttm_get_eabs",
@@ -174,6 +174,9 @@ def load():
     L.imdgpu_ttm_remote_open.argtypes = [vp, vp, C.POINTER(vp)]
     L.imdgpu_ttm_remote_attach.argtypes = [vp, C.POINTER(vp)]
     L.imdgpu_dist_ttm_remote_setup.argtypes = [vp]
+    L.imdgpu_do_forces.argtypes = [vp, C.c_int, dp, ip, C.c_int, dp, ip, dp, C.c_int, dp, dp, dp, dp, dp, dp, ip, ip, dp, dp, ip]
+    L.imdgpu_do_forces_eam2.argtypes = [vp, C.c_int, dp, ip, dp, C.c_int, dp, ip, dp, dp, C.c_int, dp, dp, dp, ip]
+    L.imdgpu_do_embedding_energy.argtypes = [vp, C.c_int, dp, ip, dp, dp, dp]
     L.imdgpu_md_step_begin.argtypes = [vp, C.c_int]
     L.imdgpu_md_step_end.argtypes = [vp, C.c_int]
     L.imdgpu_dist_rebuild.argtypes = [vp]

@@ -134,6 +134,25 @@ int imdgpu_md_step_end(imdgpu_ctx *ctx, int steps);
 int imdgpu_get_sums(imdgpu_ctx *ctx, double sums[8], double *tot_kin_energy,
                     int *nbl_count);
 
+/* The reference's CELL-PAIR kernels on host arrays, for hosts that keep the cell-pair loop of imd_main_risc_3d.c:31-182 and
+ * call them per pair of cells.  Same contract as the originals: results are ADDED to the arrays passed in; every pair is
+ * visited once and the partner gets the opposite force / the same energy half; pbc = the periodic shift of cell q
+ * (the reference's `pbc` vector); same_cell != 0 means p == q with zero shift (j starts at i + 1; pass the same arrays for
+ * p and q).  ort xyz interleaved, sorte may be NULL (all type 0), numneighs NULL unless the TTM neighbour count is wanted.
+ *   [do_forces, imd_forces.c:33-326: pair_pot term (r2 <= end), host electron density (r2 < end), Epot, virial]
+ *   [do_forces_eam2, imd_forces_eam2.c:236-369: EAM force 0.5 (dF_i rho'_j + dF_j rho'_i), virial]
+ *   [do_embedding_energy, imd_forces_eam2.c:202-230: pot_eng += F(rho), eam_dF = 2 F'(rho), tot_pot_energy += sum]
+ * A compatibility path (one small launch and two PCIe round trips per call); the list kernels are the fast path. */
+int imdgpu_do_forces(imdgpu_ctx *ctx, int np, const double *ort_p, const int *sorte_p, int nq, const double *ort_q,
+                     const int *sorte_q, const double pbc[3], int same_cell, double *kraft_p, double *kraft_q,
+                     double *poteng_p, double *poteng_q, double *eam_rho_p, double *eam_rho_q, int *numneighs_p,
+                     int *numneighs_q, double *epot, double *virial, int *is_short);
+int imdgpu_do_forces_eam2(imdgpu_ctx *ctx, int np, const double *ort_p, const int *sorte_p, const double *eam_dF_p, int nq,
+                          const double *ort_q, const int *sorte_q, const double *eam_dF_q, const double pbc[3], int same_cell,
+                          double *kraft_p, double *kraft_q, double *virial, int *is_short);
+int imdgpu_do_embedding_energy(imdgpu_ctx *ctx, int n, const double *eam_rho, const int *sorte, double *pot_eng, double *eam_dF,
+                               double *tot_pot_energy);
+
 /* The Verlet list in the REFERENCE's own format and numbering (half list,
  * tl/tb/cl_off, imd_forces_nbl.c:24-42), rebuilt from the current arrangement.
  * Pass tb==NULL to query sizes: *ntb receives the entry count.  tl has

@@ -152,6 +152,31 @@ build_dropin_cellpair() {
 }
 case " $TARGETS " in *" dropin "*) build_dropin_cellpair ;; esac
 
+# The cell-pair program with do_forces / do_forces_eam2 / do_embedding_energy forwarded ONE BY ONE: the reference's own
+# calc_forces (imd_main_risc_3d.c, unchanged) walks the cell pairs and calls the shim's versions of these names
+# (-DIMD_SHIM_CELLPAIR_FUNCTIONS; imd_forces.c and imd_forces_eam2.c are NOT linked; the shim's whole-step calc_forces is
+# compiled under another name).  tests/test_gpu_dropin.py compares it with oracle/_ref/imd_eam_nve.
+build_dropin_cellpair_fn() {
+  local name="eam_nve_gpufn" defs="-DEAM2 -DNVE"
+  local obj="$OUT/obj_$name" repo="$(cd "$HERE/.." && pwd)"
+  [ -f "$repo/imd_amd/csrc/libimdgpu.so" ] || { echo "libimdgpu.so not built, skipping drop-in" >&2; return 0; }
+  mkdir -p "$obj"
+  local objs=""
+  for s in $COMMON imd_main_risc_3d.c; do
+    local o="$obj/${s%.c}.o"
+    if [ ! -f "$o" ] || [ "$REF/$s" -nt "$o" ]; then $CC $BASEFLAGS $defs -c "$REF/$s" -o "$o" & fi
+    objs="$objs $o"
+  done
+  wait
+  $CC $BASEFLAGS $defs -DIMD_SHIM_CELLPAIR_FUNCTIONS -Dcalc_forces=calc_forces_shim_whole_step -fopenmp -I"$repo/include" \
+      -c "$repo/imd_amd/host/imd_shim.c" -o "$obj/imd_shim.o"
+  $CC $BASEFLAGS $defs -c "$HERE/ref_probe.c" -o "$obj/ref_probe.o"
+  $CC -o "$OUT/imd_$name" $objs "$obj/imd_shim.o" "$obj/ref_probe.o" -Wl,--wrap=calc_forces \
+      "$REF/nn_interpol/libnn.a" -L"$repo/imd_amd/csrc" -limdgpu -Wl,-rpath,/root/repo/imd_amd/csrc -fopenmp -lm
+  echo "built $OUT/imd_$name"
+}
+case " $TARGETS " in *" dropin "*) build_dropin_cellpair_fn ;; esac
+
 # The 3D TTM program on the device: forces through the shim as above AND calc_ttm of the shim (imd_ttm_3D.c compiled
 # with -Dcalc_ttm=calc_ttm_host, no source change; its init_ttm, ttm_writeout, ... stay).  The probe only adds the
 # lattice dump (-DPROBE_TTM_DROPIN) and the two TMM entry points the 3D file needs (see ref_probe_ttm.c).

@@ -217,6 +217,38 @@ def test_reference_ttm_main_loop_on_gpu_forces_and_gpu_calc_ttm(eos):
 
 
 GPU_TTM_FN = os.path.join(ROOT, "oracle", "_ref", "imd_mpi_eam_ttm3d_nbl_gpufn")
+GPU_CP_FN = os.path.join(ROOT, "oracle", "_ref", "imd_eam_nve_gpufn")
+
+
+@pytest.mark.skipif(not (os.path.exists(CPU_CP) and os.path.exists(GPU_CP_FN)), reason="oracle/_ref binaries not built")
+def test_reference_cell_pair_loop_calls_do_forces_on_the_device():
+    """do_forces, do_forces_eam2 and do_embedding_energy under the reference's own names and signatures
+    (prototypes.h:412-418): in this build the reference's OWN calc_forces (imd_main_risc_3d.c:31-182, unchanged) walks the
+    cell pairs and calls them -- imd_forces.o / imd_forces_eam2.o are not linked, the shim's versions send every pair of
+    cells to the device (imdgpu_do_forces / _do_forces_eam2 / _do_embedding_energy) and add the results on the host.
+    Forces, energies, densities and the trajectory over 3 steps equal the CPU build's."""
+    out = {}
+    par = PARAM.replace("box_param 10 10 10", "box_param 6 6 6").replace("maxsteps 30", "maxsteps 3") \
+        .replace("nbl_margin 0.5\n", "").replace("nbl_size 1.5\n", "")
+    for tag, exe in (("cpu", CPU_CP), ("gpu", GPU_CP_FN)):
+        with tempfile.TemporaryDirectory() as d:
+            potential.write_synthetic_eam_files(d)
+            open(os.path.join(d, "t.param"), "w").write(par)
+            env = dict(os.environ, IMD_PROBE_DIR=d, IMD_PROBE_STEPS="0,3")
+            r = subprocess.run([exe, "-p", "t.param"], cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                               text=True, timeout=900)
+            assert r.returncode == 0, r.stdout[-2000:]
+            out[tag] = {s: po.read_probe(os.path.join(d, "probe.0.%d.bin" % s)) for s in (0, 3)}
+    for s in (0, 3):
+        a, b = out["gpu"][s], out["cpu"][s]
+        oa, ob = np.argsort(_inner_ids(a)), np.argsort(_inner_ids(b))
+        assert np.abs(a["kraft"][oa] - b["kraft"][ob]).max() < 1e-9 * max(np.abs(b["kraft"]).max(), 1e-3), s
+        assert np.abs(a["pot_eng"][oa] - b["pot_eng"][ob]).max() < 1e-10
+        assert np.abs(a["eam_rho"][oa] - b["eam_rho"][ob]).max() < 1e-10
+        assert np.abs(a["eam_dF"][oa] - b["eam_dF"][ob]).max() < 1e-10
+        assert abs(a["tot_pot_energy"] - b["tot_pot_energy"]) < 1e-10 * abs(b["tot_pot_energy"])
+        assert abs(a["virial"] - b["virial"]) < 1e-9 * abs(b["virial"])
+        assert np.abs(_inner_pos(a)[oa] - _inner_pos(b)[ob]).max() < 1e-9
 
 
 @pytest.mark.skipif(not (os.path.exists(CPU) and os.path.exists(GPU)), reason="oracle/_ref binaries not built")
