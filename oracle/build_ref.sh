@@ -9,7 +9,7 @@
 # oracle/ref_probe.c, a read-only observation probe attached with ld --wrap.
 #
 # usage: oracle/build_ref.sh [target ...]
-#   targets: eam_nve_nbl  nve_nbl  eam_nve  nve  mpi_eam_nve_nbl  mpi_eam_ttm3d_nbl  mpi_eam_ttm3d_laser_nbl  fdtd_probe  dropin
+#   targets: eam_nve_nbl  nve_nbl  eam_nve  nve  mpi_eam_nve_nbl  mpi_eam_ttm3d_nbl  mpi_eam_ttm3d_laser_nbl  mpi_eam_ttm1d_nbl  fdtd_probe  dropin
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 REF="${IMD_REFERENCE:-/root/reference}"
@@ -45,7 +45,11 @@ build() {
   wait
   $cc $BASEFLAGS $defs -c "$HERE/ref_probe.c" -o "$obj/ref_probe.o"
   local wrap="-Wl,--wrap=calc_forces" extra=""
-  if [[ "$defs" == *-DTTM* ]]; then
+  if [[ "$defs" == *-DTTM1D* ]]; then
+    $cc $BASEFLAGS $defs -c "$HERE/ref_probe_ttm1d.c" -o "$obj/ref_probe_ttm1d.o"
+    extra="$obj/ref_probe_ttm1d.o"
+    wrap="$wrap -Wl,--wrap=calc_ttm -Wl,--wrap=tmm_init -Wl,--wrap=do_tmm"
+  elif [[ "$defs" == *-DTTM* ]]; then
     $cc $BASEFLAGS $defs -c "$HERE/ref_probe_ttm.c" -o "$obj/ref_probe_ttm.o"
     extra="$obj/ref_probe_ttm.o"
     wrap="$wrap -Wl,--wrap=calc_ttm -Wl,--wrap=tmm_init -Wl,--wrap=do_tmm"
@@ -55,7 +59,7 @@ build() {
   echo "built $OUT/imd_$name"
 }
 
-TARGETS="${*:-eam_nve_nbl nve_nbl eam_nve mpi_eam_nve_nbl mpi_eam_ttm3d_nbl mpi_eam_ttm3d_laser_nbl fdtd_probe dropin}"
+TARGETS="${*:-eam_nve_nbl nve_nbl eam_nve mpi_eam_nve_nbl mpi_eam_ttm3d_nbl mpi_eam_ttm3d_laser_nbl mpi_eam_ttm1d_nbl fdtd_probe dropin}"
 for t in $TARGETS; do
   case "$t" in
     eam_nve_nbl) build "$t" "-DNBL -DEAM2 -DNVE" "$COMMON $NBLSRC" "$CC" "" ;;
@@ -74,6 +78,14 @@ for t in $TARGETS; do
       if [ ! -f "$MPIINC/include/mpi.h" ]; then echo "no MPI at $MPIINC, skipping $t" >&2; continue; fi
       build "$t" "-DMPI -DNBL -DEAM2 -DTTM -DTMM -DEOSMODE=1" \
             "$COMMON $NBLSRC imd_mpi_util.c imd_ttm_3D.c imd_interpol.c fminbnd3.c" \
+            "$CC -I$MPIINC/include" "-L$MPIINC/lib -Wl,-rpath,$MPIINC/lib -lmpi" ;;
+    mpi_eam_ttm1d_nbl)
+      # the 1D TTM the reference's Makefile builds (imd_ttm.c with -DTTM1D: position-binned slabs, RHOMIN, virtual lattice);
+      # do_tmm / tmm_init answered by oracle/ref_probe_ttm1d.c (the TMM solver's input files are not in the tree)
+      MPIINC="${MPI_HOME:-/opt/conda}"
+      if [ ! -f "$MPIINC/include/mpi.h" ]; then echo "no MPI at $MPIINC, skipping $t" >&2; continue; fi
+      build "$t" "-DMPI -DNBL -DEAM2 -DTTM -DTMM -DTTM1D" \
+            "$COMMON $NBLSRC imd_mpi_util.c imd_ttm.c imd_interpol.c fminbnd3.c" \
             "$CC -I$MPIINC/include" "-L$MPIINC/lib -Wl,-rpath,$MPIINC/lib -lmpi" ;;
     mpi_eam_ttm3d_laser_nbl)
       # the same with -DLASER (imd_laser.c: Beer-Lambert source laser_rescale_ttm, init_laser, get_surface)

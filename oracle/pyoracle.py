@@ -269,6 +269,44 @@ def read_probe(path):
     return P
 
 
+TTM1D_CELL = ("natoms", "natoms_old", "temp", "xi", "md_temp", "source", "vcomx", "vcomy", "vcomz", "dens", "fd_k", "fd_g", "Z",
+              "Ce", "ne", "U", "temp2", "U2")
+TTM1D_GLOB = ("natomsglobal", "fluxfromleft", "fluxfromright", "vcomxglobal", "vcomyglobal", "vcomzglobal", "xiarr_global")
+TTM1D_VLAT = ("temp", "md_temp", "dens", "fd_k", "fd_g", "Z", "Ce", "ne")
+
+
+def read_ttm1d_probe(path):
+    """dump of oracle/ref_probe_ttm1d.c: the reference's 1D lattice (imd_ttm.c) of one rank, stage by stage"""
+    buf = open(path, "rb").read()
+    assert buf[:8] == b"IMDTT1DP" and buf[-8:] == b"ENDTT1DP", "bad / truncated 1D TTM probe dump"
+    off = [8]
+
+    def ri(n=1):
+        v = np.frombuffer(buf, dtype="<i4", count=n, offset=off[0]); off[0] += 4 * n
+        return v if n > 1 else int(v[0])
+
+    def rd(n=1):
+        v = np.frombuffer(buf, dtype="<f8", count=n, offset=off[0]); off[0] += 8 * n
+        return v.copy() if n > 1 else float(v[0])
+    T = dict(version=ri(), step=ri(), fd_min_atoms=ri(), fd_n_timesteps=ri(), vlatbuffer=ri())
+    for k in ("fd_hx", "fd_hy", "fd_hz", "fd_vol", "neighvol", "atomic_weight", "atomic_charge", "timestep", "vlatdens", "Temin"):
+        T[k] = rd()
+    T["stages"] = {}
+    while buf[off[0]:off[0] + 8] != b"ENDTT1DP":
+        tag = buf[off[0]:off[0] + 16].split(b"\0")[0].decode(); off[0] += 16
+        lx, nx, nv = ri(), ri(), ri()
+        cells = rd(lx * len(TTM1D_CELL)).reshape(lx, len(TTM1D_CELL))
+        glob = rd(nx * len(TTM1D_GLOB)).reshape(nx, len(TTM1D_GLOB))
+        vlat = rd(nv * len(TTM1D_VLAT)).reshape(nv, len(TTM1D_VLAT)) if nv else np.zeros((0, len(TTM1D_VLAT)))
+        sc = rd(4)
+        T["stages"][tag] = dict(cells={k: cells[:, q].copy() for q, k in enumerate(TTM1D_CELL)},
+                                glob={k: glob[:, q].copy() for q, k in enumerate(TTM1D_GLOB)},
+                                vlat={k: vlat[:, q].copy() for q, k in enumerate(TTM1D_VLAT)},
+                                last_active_cell=int(sc[0]), vlattice_proc=int(sc[1]), diff_substeps=int(sc[2]), max_dt_ttm=float(sc[3]))
+        T["local_fd_dim"], T["global_fd_dim"], T["vlatdim"] = lx, nx, nv
+    return T
+
+
 def system_from_probe(P, cap=None, load_outputs=False):
     """Rebuild the reference's cell arrangement (same slots) inside the oracle."""
     cn = P["cell_n"]
@@ -548,3 +586,109 @@ def read_fdtd_probe(path):
         while not rd().startswith("md"):
             pass
     return H
+
+
+# ---------------------------------------------------------------------------
+# 1D TTM oracle (oracle/ttm1d_oracle.c): imd_ttm.c's own variant
+# ---------------------------------------------------------------------------
+class _Ttm1d(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ("nx", "nranks", "vlatdim", "vlatbuffer", "fd_min_atoms", "fd_n_timesteps", "cur", "vcur",
+                                       "last_active", "vlat_proc", "diff_substeps", "adv")] + \
+               [(k, C.c_double) for k in ("hx", "vol", "neighvol", "aw", "ac", "vlatdens", "Temin", "max_dt_ttm", "omega_laser")] + \
+               [("natoms", C.POINTER(C.c_int)), ("natoms_old", C.POINTER(C.c_int)),
+                ("temp", C.POINTER(C.c_double) * 2), ("U", C.POINTER(C.c_double) * 2)] + \
+               [(k, C.POINTER(C.c_double)) for k in ("xi", "md_temp", "source", "dens", "fd_k", "fd_g", "Z", "Ce", "ne")] + \
+               [(k, C.POINTER(C.c_int)) for k in ("fluxl", "fluxr", "totneigh", "natomsglobal")] + \
+               [("vcom", C.POINTER(C.c_double) * 3), ("xiarr", C.POINTER(C.c_double)),
+                ("vtemp", C.POINTER(C.c_double) * 2), ("vmd", C.POINTER(C.c_double) * 2)] + \
+               [(k, C.POINTER(C.c_double)) for k in ("vk", "vg", "vCe", "vZ", "vne")] + [("eos", C.c_void_p)]
+
+
+class OracleTTM1D:
+    """the reference's 1D TTM (imd_ttm.c) on flat atom arrays; lattice arrays are views of length nx + 2 (ghost cells at both ends)"""
+
+    def __init__(self, nx, box, nranks, vlatdim, vlatbuffer, vlatdens, fd_min_atoms, fd_n_timesteps, atomic_weight, atomic_charge,
+                 r2_cut_pair, timestep, eos_cve, eos_ee, adv=True):
+        L = _ttm_lib()
+        ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
+        L.orc_ttm1d_new.restype = C.POINTER(_Ttm1d)
+        L.orc_ttm1d_new.argtypes = [C.c_int] + [C.c_double] * 3 + [C.c_int] * 3 + [C.c_double, C.c_int, C.c_int] + [C.c_double] * 4 + [C.c_void_p]
+        L.orc_ttm1d_free.argtypes = [C.POINTER(_Ttm1d)]
+        L.orc_ttm1d_update_fd.argtypes = [C.POINTER(_Ttm1d), C.c_int, C.c_int, dp, ip, dp, dp, ip, ip]
+        L.orc_ttm1d_adv.argtypes = [C.POINTER(_Ttm1d), C.c_double, C.c_int]
+        L.orc_ttm1d_cell_activation.argtypes = [C.POINTER(_Ttm1d)]
+        L.orc_ttm1d_fillmesh.argtypes = [C.POINTER(_Ttm1d), C.c_int]
+        L.orc_ttm1d_fill_ghosts.argtypes = [C.POINTER(_Ttm1d)]
+        L.orc_ttm1d_cfl.argtypes = [C.POINTER(_Ttm1d), C.c_int, C.c_double]
+        L.orc_ttm1d_diff.argtypes = [C.POINTER(_Ttm1d), C.c_double]
+        L.orc_ttm1d_calc.argtypes = [C.POINTER(_Ttm1d), C.c_int, C.c_double, C.c_int, dp, ip, dp, dp, ip, ip]
+        L.orc_ttm1d_move_atoms.restype = C.c_double
+        L.orc_ttm1d_move_atoms.argtypes = [C.POINTER(_Ttm1d), C.c_double, C.c_int, dp, ip, dp, dp, dp]
+        # a 3D oracle lattice object only to hold the two EOS tables
+        one = np.array([3, 3, 3], np.int32); ext = np.array([1, 1, 1], np.int32); h = np.ones(3); pbc = np.array([1, 1, 1], np.int32)
+        self._holder = L.orc_ttm_new(_ip(one), _ip(ext), _dp(h), _ip(pbc), 1, float(atomic_weight), float(atomic_charge), float(r2_cut_pair))
+        for which, e in ((0, eos_cve), (1, eos_ee)):
+            z = np.ascontiguousarray(e["z"], np.float64).reshape(-1)
+            L.orc_ttm_set_eos(self._holder, which, len(e["x"]), len(e["y"]), float(e["x"][0]), float(e["x"][-1]), float(e["y"][0]),
+                              float(e["y"][-1]), _dp(z))
+        box = np.asarray(box, np.float64).reshape(3, 3)
+        self._p = L.orc_ttm1d_new(int(nx), box[0, 0], box[1, 1], box[2, 2], int(nranks), int(vlatdim), int(vlatbuffer), float(vlatdens),
+                                  int(fd_min_atoms), int(fd_n_timesteps), float(atomic_weight), float(atomic_charge), float(r2_cut_pair),
+                                  float(timestep), C.cast(self._holder, C.c_void_p))
+        self.t = self._p.contents
+        self.t.adv = 1 if adv else 0
+        self.timestep, self.nx, self.L = float(timestep), int(nx), L
+        aa = np.ctypeslib.as_array
+        n2 = self.nx + 2
+        for k in ("natoms", "natoms_old", "xi", "md_temp", "source", "dens", "fd_k", "fd_g", "Z", "Ce", "ne"):
+            setattr(self, k, aa(getattr(self.t, k), (n2,)))
+        for k in ("fluxl", "fluxr", "natomsglobal", "xiarr"):
+            setattr(self, k, aa(getattr(self.t, k), (self.nx,)))
+        self.vcom = [aa(self.t.vcom[d], (self.nx,)) for d in range(3)]
+        self._temp = [aa(self.t.temp[q], (n2,)) for q in (0, 1)]
+        self._U = [aa(self.t.U[q], (n2,)) for q in (0, 1)]
+        nv = int(vlatdim)
+        self._vt = [aa(self.t.vtemp[q], (nv,)) for q in (0, 1)]
+        self._vm = [aa(self.t.vmd[q], (nv,)) for q in (0, 1)]
+        for k in ("vk", "vg", "vCe", "vZ", "vne"):
+            setattr(self, k, aa(getattr(self.t, k), (nv,)))
+        self.fdi = None
+
+    temp = property(lambda self: self._temp[self.t.cur])
+    temp2 = property(lambda self: self._temp[self.t.cur ^ 1])
+    U = property(lambda self: self._U[self.t.cur])
+    U2 = property(lambda self: self._U[self.t.cur ^ 1])
+    vtemp = property(lambda self: self._vt[self.t.vcur])
+    vmd = property(lambda self: self._vm[self.t.vcur])
+
+    def _atoms(self, ort, sorte, impuls, masse, numneighs):
+        self._a = (np.ascontiguousarray(ort, np.float64), np.ascontiguousarray(sorte, np.int32), np.ascontiguousarray(impuls, np.float64),
+                   np.ascontiguousarray(masse, np.float64), np.ascontiguousarray(numneighs, np.int32))
+        if self.fdi is None or len(self.fdi) != len(self._a[0]):
+            self.fdi = np.full(len(self._a[0]), -1, np.int32)
+        return self._a
+
+    def update_fd(self, steps, ort, sorte, impuls, masse, numneighs):
+        o, s, p, m, nn = self._atoms(ort, sorte, impuls, masse, numneighs)
+        self.L.orc_ttm1d_update_fd(self._p, int(steps), len(o), _dp(o), _ip(s), _dp(p), _dp(m), _ip(nn), _ip(self.fdi))
+
+    def adv(self, tau, steps): self.L.orc_ttm1d_adv(self._p, float(tau), int(steps))
+    def cell_activation(self): self.L.orc_ttm1d_cell_activation(self._p)
+    def fillmesh(self, steps): self.L.orc_ttm1d_fillmesh(self._p, int(steps))
+    def fill_ghosts(self): self.L.orc_ttm1d_fill_ghosts(self._p)
+    def cfl(self, steps): self.L.orc_ttm1d_cfl(self._p, int(steps), self.timestep)
+    def diff(self, tau): self.L.orc_ttm1d_diff(self._p, float(tau))
+
+    def calc(self, steps, ort, sorte, impuls, masse, numneighs):
+        o, s, p, m, nn = self._atoms(ort, sorte, impuls, masse, numneighs)
+        return self.L.orc_ttm1d_calc(self._p, int(steps), self.timestep, len(o), _dp(o), _ip(s), _dp(p), _dp(m), _ip(nn), _ip(self.fdi))
+
+    def move_atoms(self, ort, sorte, impuls, kraft, masse):
+        o = np.ascontiguousarray(ort, np.float64); p = np.ascontiguousarray(impuls, np.float64)
+        s = np.ascontiguousarray(sorte, np.int32); k = np.ascontiguousarray(kraft, np.float64); m = np.ascontiguousarray(masse, np.float64)
+        e = self.L.orc_ttm1d_move_atoms(self._p, self.timestep, len(o), _dp(o), _ip(s), _dp(p), _dp(k), _dp(m))
+        return o, p, e
+
+    def close(self):
+        if self._p is not None:
+            self.L.orc_ttm1d_free(self._p); self.L.orc_ttm_free(self._holder); self._p = None

@@ -51,6 +51,7 @@ void orc_ttm_diff(orc_ttm *t, double tau, int diff_substeps);
 void orc_ttm_cfl(orc_ttm *t, int steps, double timestep, int fd_n_timesteps);
 void orc_ttm_calc(orc_ttm *t, orc_sys *s, int steps, int diff_substeps);
 void orc_move_atoms_ttm(orc_sys *s, const orc_ttm *t);
+/* the reference's own 1D variant (imd_ttm.c): oracle/ttm1d_oracle.c; the struct is defined there (and mirrored in pyoracle.py) */
 #ifdef __cplusplus
 }
 #endif

@@ -544,6 +544,77 @@ def run_mpi_case(name, c):
           (name, os.path.getsize(path) / 1024, world, c["dump"], out["s%d_nbl_count" % last], np.abs(out["s%d_kraft" % last]).max()))
 
 
+def run_ttm1d_case():
+    """imd_ttm.c's own 1D TTM (the file the reference's Makefile builds): oracle/_ref/imd_mpi_eam_ttm1d_nbl on TWO ranks (its
+    ttm_fill_ghost_layers and do_COMMFLUX have no one-rank branch), a slab with vacuum on both x sides, do_ADV on; the
+    lattice rows of both ranks assembled into the global row, stage by stage (oracle/ref_probe_ttm1d.c), the global slab
+    arrays, the virtual lattice, and the atoms of every dumped step in rank order."""
+    name, steps, dump = "ttm1d_slab", 20, [0, 1, 2, 8, 9, 20]
+    par = COMMON.format(pbc="0 1 1", seed=12345, cpu="2 1 1").replace("ensemble nve", "ensemble ttm")
+    par += ("box_param 12 6 6\nstarttemp 0.09\nmaxsteps %d\ncore_potential_file phi.pt\nembedding_energy_file F.pt\n"
+            "atomic_e-density_file rho.pt\nnbl_margin 0.5\nnbl_size 1.5\nshiftx_front 8.0\nshiftx_rear 8.0\nmsgbuf_size 3.0\n"
+            "fd_n_timesteps 100\nfd_min_atoms 12\natomic_weight 26.9815\natomic_charge 13\nttm_int 100000\nttmdimx 14\n"
+            "vlatdim 6\nvlatbuffer 1\nI0 1.0\nlambda 800e-9\nlaser_sigma_t 100e-15\nlaser_t_0 1.0\n" % steps)
+    with tempfile.TemporaryDirectory() as top:
+        d = os.path.join(top, "run"); os.mkdir(d)
+        potential.write_synthetic_eam_files(d)
+        eos = write_planar_eos(top)                       # the 1D file reads its tables from the PARENT directory (imd_ttm.c:1121-1123)
+        from imd_amd import ttm as ttm_mod
+        ttm_mod.write_eos_table(os.path.join(top, "EOS_phase_from_r_ti.txt"), dict(x=eos["r"], y=eos["t"], z=np.ones((len(eos["r"]), len(eos["t"])))))
+        open(os.path.join(d, "t.param"), "w").write(par)
+        env = dict(os.environ, IMD_PROBE_DIR=d, IMD_PROBE_STEPS=",".join(map(str, dump)), IMD_PROBE_ADV="1")
+        r = subprocess.run([MPIEXEC, "-n", "2", os.path.join(REFBIN, "imd_mpi_eam_ttm1d_nbl"), "-p", "t.param"], cwd=d, env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            print(r.stdout[-3000:]); raise SystemExit("reference run failed for %s" % name)
+        T = {s: [po.read_ttm1d_probe(os.path.join(d, "ttm1d.%d.%d.bin" % (rk, s))) for rk in (0, 1)] for s in dump}
+        P = {s: [po.read_probe(os.path.join(d, "probe.%d.%d.bin" % (rk, s))) for rk in (0, 1)] for s in dump}
+    T0, P0 = T[0][0], P[0][0]
+    out = dict(case=name, param_file=par, steps=np.array(dump), ref_ranks=2)
+    for k in ("ntypes", "global_cell_dim", "pbc_dirs", "box", "cellsz", "nbl_margin", "timestep", "natoms", "flags"):
+        out[k] = P0[k]
+    out["cell_dim"] = np.array(P0["global_cell_dim"]) + 2
+    for tk in ("pair_pot", "rho_h_tab", "embed_pot"):
+        for f, v in P0[tk].items():
+            out["%s_%s" % (tk, f)] = v
+    for k in ("fd_min_atoms", "fd_n_timesteps", "vlatbuffer", "fd_hx", "fd_hy", "fd_hz", "fd_vol", "neighvol", "atomic_weight",
+              "atomic_charge", "vlatdens", "Temin", "global_fd_dim", "vlatdim"):
+        out["ttm_" + k] = T0[k]
+    for k, v in eos.items():
+        out["eos_" + k] = v
+    for s in dump:
+        pre = "s%d_" % s
+        cols = {k: [] for k in ("nummer", "sorte", "ort", "masse", "impuls", "kraft", "numneighs")}
+        for Pr in P[s]:
+            start = np.concatenate([[0], np.cumsum(Pr["cell_n"])])
+            idx = np.concatenate([np.arange(start[cc], start[cc + 1]) for cc in Pr["cells"]] + [np.zeros(0, int)]).astype(int)
+            cols["nummer"].append(Pr["all_nummer"][idx]); cols["sorte"].append(Pr["all_sorte"][idx]); cols["ort"].append(Pr["all_ort"][idx])
+            for k in ("masse", "impuls", "kraft", "numneighs"):
+                cols[k].append(Pr[k])
+        for k, v in cols.items():
+            a = np.concatenate(v)
+            out[pre + k] = a.astype(np.int32) if k in ("nummer", "numneighs") else a.astype(np.int8) if k == "sorte" else a
+        out[pre + "nbl_count"] = P[s][0]["nbl_count"]
+        lx = T0["local_fd_dim"]
+        for tag in T[s][0]["stages"]:
+            st = [T[s][rk]["stages"][tag] for rk in (0, 1)]
+            q = "t%d_%s_" % (s, tag)
+            for f in po.TTM1D_CELL:                      # global row = the two ranks' inner rows
+                out[q + f] = np.concatenate([st[0]["cells"][f][1:lx - 1], st[1]["cells"][f][1:lx - 1]])
+            for f in po.TTM1D_GLOB:
+                assert np.array_equal(st[0]["glob"][f], st[1]["glob"][f]) or f == "xiarr_global"
+                out[q + f] = st[0]["glob"][f]
+            vp = st[0]["vlattice_proc"]
+            for f in po.TTM1D_VLAT:
+                out[q + "vlat_" + f] = st[vp]["vlat"][f] if 0 <= vp < 2 else st[0]["vlat"][f]
+            out[q + "scalars"] = np.array([st[0]["last_active_cell"], vp, st[0]["diff_substeps"], st[0]["max_dt_ttm"]])
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("%-20s %8.1f KB  steps=%s stages=%s last_active=%d vlat_proc=%d substeps=%d" %
+          (name, os.path.getsize(path) / 1024, dump, list(T[dump[-1]][0]["stages"]), int(out["t%d_cfl_scalars" % dump[-1]][0]),
+           int(out["t%d_cfl_scalars" % dump[-1]][1]), int(out["t%d_cfl_scalars" % dump[-1]][2])))
+
+
 def run_chkpt_case():
     """Configuration-file fixture (imd_amd/config_io.py) -> tests/golden/chkpt.npz:
     run A writes an ASCII checkpoint after step 10, run B the same state as a binary one (binary_output 1); then
@@ -622,7 +693,7 @@ def run_ttm_file_case():
 
 
 if __name__ == "__main__":
-    names = sys.argv[1:] or (list(CASES) + ["eos_inverse", "eos_grid", "fdtd_1d", "chkpt", "ttm_file"])
+    names = sys.argv[1:] or (list(CASES) + ["eos_inverse", "eos_grid", "fdtd_1d", "chkpt", "ttm_file", "ttm1d_slab"])
     for n in names:
         if n == "eos_inverse":
             run_eos_inverse()
@@ -636,6 +707,8 @@ if __name__ == "__main__":
             run_chkpt_case()
         elif n == "ttm_adv":
             run_adv_case(n, CASES[n])
+        elif n == "ttm1d_slab":
+            run_ttm1d_case()
         elif n.endswith("_mpi8"):
             run_mpi_case(n, CASES[n])
         else:
