@@ -1538,6 +1538,7 @@ extern "C" void imdgpu_destroy(imdgpu_ctx *c)
   imdgpu_prof_resolve(c);
   for (auto e : c->ev_pool) (void) hipEventDestroy(e);
   imdgpu_ttm_free(c);
+  imdgpu_ttm1d_free(c);
   imdgpu_dist_free(c);
   if (c->d_refperm) (void) hipFree(c->d_refperm);
   if (c->d_stage) (void) hipFree(c->d_stage);
@@ -2561,7 +2562,7 @@ static int fork_ttm(imdgpu_ctx *ctx, void *)
 {
   static const int serial = getenv("IMDGPU_TTM_SERIAL") ? atoi(getenv("IMDGPU_TTM_SERIAL")) : 0;   // experiment: calc_ttm alone on the chip
   if (serial) {
-    if (imdgpu_calc_ttm(ctx, ctx->ttm_steps)) return 1;
+    if (ctx->ttm1d ? imdgpu_ttm1d_calc(ctx, ctx->ttm_steps) : imdgpu_calc_ttm(ctx, ctx->ttm_steps)) return 1;
     HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream));
     return 0;
   }
@@ -2569,7 +2570,7 @@ static int fork_ttm(imdgpu_ctx *ctx, void *)
   HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
   hipStream_t main = ctx->stream;
   ctx->stream = ctx->stream2;
-  int rc = imdgpu_calc_ttm(ctx, ctx->ttm_steps);
+  int rc = ctx->ttm1d ? imdgpu_ttm1d_calc(ctx, ctx->ttm_steps) : imdgpu_calc_ttm(ctx, ctx->ttm_steps);
   ctx->stream = main;
   if (rc) return 1;
   HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
@@ -2611,7 +2612,7 @@ extern "C" int imdgpu_md_step_begin(imdgpu_ctx *ctx, int steps)
   } else if (imdgpu_fill_ghosts(ctx)) return 1;
   imdgpu_tl_mark(ctx, "list");
   if (!ctx->rho.present && zero_eam_partials(ctx)) return 1;
-  if (ctx->ttm) {
+  if (ctx->ttm || ctx->ttm1d) {
     // calc_ttm needs only pass 1's neighbour counts and the momenta: it runs on the second stream,
     // concurrently with the embedding pass and the EAM force pass; move_atoms_ttm joins the two
     ctx->ttm_steps = steps;
@@ -2628,7 +2629,10 @@ extern "C" int imdgpu_md_step_end(imdgpu_ctx *ctx, int steps)
   HIPCHK(hipSetDevice(ctx->device));
   if (!ctx->step_open) return imdgpu_fail(ctx, "md_step_end without md_step_begin");
   ctx->step_open = 0;
-  if (ctx->ttm) {
+  if (ctx->ttm1d) {
+    HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    if (imdgpu_ttm1d_move_internal(ctx)) return 1;
+  } else if (ctx->ttm) {
     HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     if (imdgpu_ttm_move_internal(ctx)) return 1;
   } else {

@@ -125,6 +125,7 @@ struct imdgpu_ctx {
 
   // TTM state lives in imdgpu_ttm.hip
   struct TtmState *ttm = nullptr;
+  void *ttm1d = nullptr;             // the reference's own 1D variant (imd_ttm.c), imdgpu_ttm1d_* (end of imdgpu_ttm.hip)
   // native multi-GPU step (imdgpu_dist.hip)
   // host-buffer boundary (level-1 integration): device-side reordering between the device's tile-major atom order and the
   // host's cell order, staged through one device buffer; the permutation is rebuilt when the cell tables change
@@ -227,6 +228,8 @@ int imdgpu_launch_integrate(imdgpu_ctx *ctx);
 int imdgpu_ttm_step_internal(imdgpu_ctx *ctx, int steps);
 int imdgpu_ttm_move_internal(imdgpu_ctx *ctx);
 void imdgpu_ttm_free(imdgpu_ctx *ctx);
+void imdgpu_ttm1d_free(imdgpu_ctx *ctx);
+int imdgpu_ttm1d_move_internal(imdgpu_ctx *ctx);
 void imdgpu_ttm_set_persist(imdgpu_ctx *ctx, int value);
 long long imdgpu_ttm_persist_info(imdgpu_ctx *ctx, int which);
 void imdgpu_dist_free(imdgpu_ctx *ctx);

@@ -2665,3 +2665,483 @@ static int fdtd_lattice_loop(imdgpu_ctx *ctx, TtmState *t, const Lat &L, int ste
   S->t_SI += nsub * tau_f;
   return 0;
 }
+
+// =====================================================================================================================
+// The reference's OWN 1D two-temperature model (imd_ttm.c, the file its Makefile builds for ttm targets, Makefile:185;
+// -DTTM1D) -- SURVEY 8(f)4.  What differs from the 3D file: atoms are binned into slabs by POSITION
+// ((int)(x / fd_h.x), imd_ttm.c:296-298) and the slab sums are global arrays known to every rank (:325-334); a cell is
+// active when natoms >= fd_min_atoms AND dens > RHOMIN (= 2 kg/m^3, :69); a static VIRTUAL LATTICE of vlatdim cells
+// continues the row behind the last active cell (:1013-1024, 1595-1650); the number of diffusion sub-steps follows the
+// stability limit (:97-99); U is taken from the EOS after the loop (:119-133); move_atoms_ttm takes xi and v_com of the slab
+// an atom is in NOW (imd_integrate.c:649-760).  The row is ONE global array here (the reference cuts it by rank id; its
+// rank-layout behaviour that shows in results -- every cell of the rank owning the last active cell takes the virtual
+// lattice's first cell as +x neighbour, :1535-1540 -- is reproduced through `ref_ranks`).  Not included: do_tmm (the
+// transfer-matrix Helmholtz solver; its input files are not in the tree), COLRAD, ELECPRESS, BALLISTIC.
+// Device: two atom sweeps with wave-reduced atomics (slab sums), then the WHOLE lattice part of calc_ttm -- reconstruction,
+// do_ADV, activation, FILLMESH, CFL_maxdt, the data-dependent number of sub-steps, the EOS update -- in ONE single-
+// workgroup launch, a thread per cell (real and virtual), neighbours through LDS: the row has at most ~1000 cells and the
+// loop is sequential in time, like the Maxwell-solver loop of 4.7.
+// =====================================================================================================================
+#define T1D_MAX 1024
+#define T1D_RHOMIN 2.0
+struct Ttm1dState {
+  int nx = 0, nv = 0, fd_min_atoms = 0, fd_n = 0, vlatbuffer = 0, ref_ranks = 1, adv = 0;
+  double hx = 0, vol = 0, neighvol = 0, aw = 0, ac = 0, vlatdens = 0, Temin = 1e-3;
+  int *natoms = nullptr, *natoms_old = nullptr;                      // [nx + 2]
+  double *temp[2]{}, *U[2]{}, *xi = nullptr, *md_temp = nullptr, *source = nullptr, *dens = nullptr, *fd_k = nullptr, *fd_g = nullptr,
+         *Z = nullptr, *Ce = nullptr, *ne = nullptr;                   // [nx + 2]
+  int *gi = nullptr;                                                  // [4 nx]: natomsglobal, totneigh, fluxl, fluxr
+  double *gd = nullptr;                                               // [5 nx]: vcom x, y, z, mdtemp sums, xiarr
+  double *vt[2]{}, *vm[2]{}, *vk = nullptr, *vg = nullptr, *vCe = nullptr, *vZ = nullptr, *vne = nullptr;   // [nv]
+  int *sc_i = nullptr; double *sc_d = nullptr;                        // scalars: cur, vcur, last_active, vlat_proc, nsub ; max_dt_ttm
+  double *cve_z = nullptr, *ee_z = nullptr;
+  EosDev cve{}, ee{};
+  Lat L{};
+};
+struct T1dDev {
+  int nx, nv, fd_min_atoms, fd_n, vlatbuffer, ref_ranks;
+  double hx, vol, neighvol, aw, vlatdens, Temin;
+  int *natoms, *natoms_old;
+  double *temp0, *temp1, *U0, *U1, *xi, *md_temp, *source, *dens, *fd_k, *fd_g, *Z, *Ce, *ne;
+  int *gi; double *gd;
+  double *vt0, *vt1, *vm0, *vm1, *vk, *vg, *vCe, *vZ, *vne;
+  int *sc_i; double *sc_d;
+};
+__device__ __forceinline__ int t1d_slab(double x, double hx, int nx)
+{
+  int g = (int) (x / hx);
+  g = g > nx - 1 ? nx - 1 : g;
+  return g < 0 ? 0 : g;
+}
+// the two atom sweeps of update_fd (:271-324 and :376-403).  Atoms are sorted by cell, so the lanes of a wave mostly share
+// a slab: one shuffle reduction + one atomic per wave and quantity then; lanes of a mixed wave add for themselves.
+template <int PHASE>
+__global__ void k_ttm1d_bin(int n, int cap, int ntypes, int steps, double hx, int nx, const double4 *pos, const int *type, const double *p,
+                            const double *mass, const int *numneighs, int *fdc, int *gi, double *gd)
+{
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool on = a < n && (ntypes == 1 || type[a] == 0);
+  int g = -1;
+  double v[4] = {0, 0, 0, 0}; int iv[3] = {0, 0, 0};
+  if (on) {
+    g = t1d_slab(pos[a].x, hx, nx);
+    const double px = p[a], py = p[(size_t) cap + a], pz = p[2 * (size_t) cap + a];
+    if (PHASE == 1) {
+      v[0] = px; v[1] = py; v[2] = pz;
+      iv[0] = numneighs[a];
+      const int old = fdc[a];
+      if (steps > 0 && old != g) { if (old > g) iv[2] = 1; else iv[1] = 1; }       // from the right / from the left
+      fdc[a] = g;
+    } else {
+      const double m = mass[a], ux = px / m - gd[g], uy = py / m - gd[nx + g], uz = pz / m - gd[2 * nx + g];
+      v[3] = m * (ux * ux); v[3] += m * (uy * uy); v[3] += m * (uz * uz);
+    }
+  }
+  const int g0 = __shfl(g, 0, 64);
+  if (__all(g == g0)) {
+    if (g0 < 0) return;
+    int cnt = 1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      cnt += __shfl_down(cnt, o, 64);
+      for (int q = 0; q < 4; q++) v[q] += __shfl_down(v[q], o, 64);
+      for (int q = 0; q < 3; q++) iv[q] += __shfl_down(iv[q], o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+      if (PHASE == 1) {
+        atomicAdd(&gi[g0], cnt); atomicAdd(&gi[nx + g0], iv[0]);
+        if (iv[1]) atomicAdd(&gi[2 * nx + g0], iv[1]);
+        if (iv[2]) atomicAdd(&gi[3 * nx + g0], iv[2]);
+        atomicAdd(&gd[g0], v[0]); atomicAdd(&gd[nx + g0], v[1]); atomicAdd(&gd[2 * nx + g0], v[2]);
+      } else atomicAdd(&gd[3 * nx + g0], v[3]);
+    }
+  } else if (on) {
+    if (PHASE == 1) {
+      atomicAdd(&gi[g], 1); atomicAdd(&gi[nx + g], iv[0]);
+      if (iv[1]) atomicAdd(&gi[2 * nx + g], 1);
+      if (iv[2]) atomicAdd(&gi[3 * nx + g], 1);
+      atomicAdd(&gd[g], v[0]); atomicAdd(&gd[nx + g], v[1]); atomicAdd(&gd[2 * nx + g], v[2]);
+    } else atomicAdd(&gd[3 * nx + g], v[3]);
+  }
+}
+// v_com = sum p / (natoms * atomic_weight) (:350-372)
+__global__ void k_ttm1d_vcom(int nx, double aw, const int *gi, double *gd)
+{
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nx) return;
+  const double tm = (double) gi[g] * aw;
+  for (int d = 0; d < 3; d++) gd[d * nx + g] = tm > 0 ? gd[d * nx + g] / tm : 0.0;
+}
+
+// stages (bit mask): 1 the tail of update_fd (lattice from the slab sums, step-0 initialisation, virtual-lattice bookkeeping),
+// 2 do_ADV, 4 do_cell_activation + do_FILLMESH + ghost cells, 8 CFL_maxdt and the sub-step count, 16 ONE do_DIFF,
+// 32 do_FILLMESH + ghost cells, 64 the loop (diff_substeps x (do_DIFF, do_FILLMESH, ghosts)), 128 the EOS update of U
+__global__ __launch_bounds__(T1D_MAX) void k_ttm1d_calc(T1dDev D, Lat L, EosDev cve, EosDev ee, int steps, double timestep, int stages)
+{
+  __shared__ double sT[T1D_MAX + 2], sK[T1D_MAX + 2], sD[T1D_MAX + 2], sU[T1D_MAX + 2], vT[T1D_MAX], vK[T1D_MAX], red[16];
+  __shared__ int sN[T1D_MAX + 2], ired[16], s_last, s_nsub;
+  __shared__ double s_maxdt;
+  const int tid = threadIdx.x, nx = D.nx, nv = D.nv, lane = tid & 63, wv = tid >> 6;
+  const bool cellt = tid < nx, vlatt = tid >= nx && tid < nx + nv;
+  const int c = tid + 1, g = tid, vi = tid - nx;                       // lattice index / slab index / virtual-lattice index
+  int cur = D.sc_i[0], vcur = D.sc_i[1], last_active = D.sc_i[2], vlat_proc = D.sc_i[3], nsub = D.sc_i[4];
+  double max_dt = D.sc_d[0];
+  double *T[2] = {D.temp0, D.temp1}, *U[2] = {D.U0, D.U1}, *VT[2] = {D.vt0, D.vt1}, *VM[2] = {D.vm0, D.vm1};
+  const int amin = D.fd_min_atoms;
+  auto act = [&](int n, double d) { return n >= amin && d > T1D_RHOMIN; };
+  auto act_ge = [&](int n, double d) { return !(n < amin || d < T1D_RHOMIN); };
+  const double AMU_J2EV = 26.9815 * C_AMU * C_J2EV;
+  // ---- stage 1: update_fd's reconstruction (:409-470), step-0 initialisation (:493-503), VLATTICE (:507-542) -----------
+  if (stages & 1) {
+    if (tid == 0) { T[cur][0] = 0.0; T[cur][nx + 1] = 0.0; }                         // :245-246 at the global ends
+    int cand = -5000;
+    if (cellt) {
+      D.source[c] = 0.0; D.natoms_old[c] = D.natoms[c]; D.xi[c] = 0.0;
+      const int n = D.gi[g];
+      double dn = 0.0, mt = 0.0;
+      if (n > 0) {
+        dn = ((double) D.gi[nx + g]) / ((double) n) * D.aw / D.neighvol * 1660.53907;
+        if (dn == 0) dn = (double) n * D.aw / D.vol * 1660.53907;
+        mt = D.gd[3 * nx + g] / (3.0 * (double) n);
+        if (act(n, dn)) cand = g - D.vlatbuffer;
+      }
+      D.natoms[c] = n; D.dens[c] = dn; D.md_temp[c] = mt;
+      if (steps < 1) { D.natoms_old[c] = n; if (act(n, dn)) { T[0][c] = mt; T[1][c] = mt; } }
+      D.gd[4 * nx + g] = 0.0;                                                         // xiarr
+    }
+    if (steps == 0) {                                                                 // VLATTICE_STATIC: once
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { const int t2 = __shfl_down(cand, o, 64); cand = t2 > cand ? t2 : cand; }
+      if (lane == 0) ired[wv] = cand;
+      __syncthreads();
+      if (tid == 0) { int m = -5000; for (int q = 0; q < (int) (blockDim.x >> 6); q++) m = ired[q] > m ? ired[q] : m; s_last = m; }
+      __syncthreads();
+      last_active = s_last;
+    }
+    vlat_proc = (int) (((double) last_active * D.ref_ranks) / ((double) nx));
+    if (cellt && g > last_active) D.natoms[c] = -1;
+    __syncthreads();
+  }
+  // ---- stage 2: do_ADV (:1208-1309; do_COMMFLUX is nothing on one global row) -----------------------------------------
+  if ((stages & 2) && steps >= 1) {
+    if (cellt) sU[c] = U[cur][c];
+    if (tid == 0) { sU[0] = U[cur][0]; sU[nx + 1] = U[cur][nx + 1]; }
+    __syncthreads();
+    if (cellt) {
+      const double Nold = (double) D.natoms_old[c], Nnew = (double) D.natoms[c];
+      if (Nnew > 0) {
+        const double fr_here = D.gi[3 * nx + g], fl_next = g + 1 < nx ? D.gi[2 * nx + g + 1] : 0.0, fl_here = D.gi[2 * nx + g],
+                     fr_prev = g > 0 ? D.gi[3 * nx + g - 1] : 0.0;
+        const double u2 = sU[c] * Nold / Nnew + 1.0 * (+fr_here * sU[c + 1] - fl_next * sU[c] + fl_here * sU[c - 1] - fr_prev * sU[c]) / Nnew;
+        U[cur ^ 1][c] = u2;
+        if (act(D.natoms[c], D.dens[c])) T[cur ^ 1][c] = d_te_from_r_ee(ee, D.dens[c], u2 / AMU_J2EV) / 11604.5;
+      } else if (Nnew < 1) { U[cur ^ 1][c] = 0.0; T[cur ^ 1][c] = 0.0; }
+    }
+    cur ^= 1;
+    __syncthreads();
+  }
+  // own cell's state in registers from here on
+  int nat = 0; double Te = 0, Te2 = 0, u = 0, u2 = 0, x = 0, Tl = 0, dn = 0, src = 0, kk = 0, gg = 0, ce = 0, Zc = 0, nec = 0;
+  double vTe = 0, vTe2 = 0, vTl = 0, vTl2 = 0, vkk = 0, vgg = 0, vce = 0, vZc = 0, vnec = 0;
+  if (cellt) { nat = D.natoms[c]; Te = T[cur][c]; Te2 = T[cur ^ 1][c]; u = U[cur][c]; u2 = U[cur ^ 1][c]; x = D.xi[c]; Tl = D.md_temp[c]; dn = D.dens[c];
+               src = D.source[c]; kk = D.fd_k[c]; gg = D.fd_g[c]; ce = D.Ce[c]; Zc = D.Z[c]; nec = D.ne[c]; }
+  if (vlatt) { vTe = VT[vcur][vi]; vTe2 = VT[vcur ^ 1][vi]; vTl = VM[vcur][vi]; vTl2 = VM[vcur ^ 1][vi]; vkk = D.vk[vi]; vgg = D.vg[vi]; vce = D.vCe[vi];
+               vZc = D.vZ[vi]; vnec = D.vne[vi]; }
+  double xiarr = cellt ? D.gd[4 * nx + g] : 0.0;
+  // natoms / dens of the row do not change below: in LDS once (ghost cells: the global ends)
+  if (cellt) { sN[c] = nat; sD[c] = dn; }
+  if (tid == 0) { sN[0] = D.natoms[0]; sN[nx + 1] = D.natoms[nx + 1]; sD[0] = D.dens[0]; sD[nx + 1] = D.dens[nx + 1]; sT[0] = T[cur][0]; sT[nx + 1] = T[cur][nx + 1];
+                  sK[0] = D.fd_k[0]; sK[nx + 1] = D.fd_k[nx + 1]; }
+  __syncthreads();
+  auto fillmesh = [&]() {                                                              // do_FILLMESH (:629-850), own cell
+    if (cellt && !(g > last_active)) {
+      if (act(nat, dn)) {
+        const MeshOut o = mesh_props(L, cve, Te, Tl, dn);
+        Zc = o.Z; nec = o.ne; ce = o.Ce; kk = o.k; gg = o.g;
+        if (steps < 1) { u = eos_ee(ee, dn, Te * 11604.5) * AMU_J2EV; u2 = u; }
+      } else { kk = 0; gg = 0; Zc = 0; nec = 0; ce = 0; Te = 0.0; }
+    }
+    if (vlatt) { const MeshOut o = mesh_props(L, cve, vTe, vTl, D.vlatdens); vZc = o.Z; vnec = o.ne; vkk = o.k; vce = o.Ce; vgg = o.g; }
+  };
+  auto publish = [&]() {                                                               // what the neighbours read: temp, fd_k (ttm_fill_ghost_layers: natoms 0 at the ends)
+    __syncthreads();
+    if (cellt) { sT[c] = Te; sK[c] = kk; }
+    if (vlatt) { vT[vi] = vTe; vK[vi] = vkk; }
+    if (tid == 0) { sN[0] = 0; sN[nx + 1] = 0; }
+    __syncthreads();
+  };
+  // ---- stage 4: do_cell_activation (:1311-1425) + FILLMESH + ghosts ---------------------------------------------------
+  if (stages & 4) {
+    publish();
+    if (cellt) {
+      const int nold = D.natoms_old[c];
+      if (nold >= amin && nat < amin && dn > T1D_RHOMIN) x = 0.0;
+      else if (nold < amin && nat >= amin && dn > T1D_RHOMIN && !(g > last_active)) {
+        if (isnan(Te) || Te <= D.Temin) {
+          int nn = 0; double e = 0.0;
+          if (sN[c + 1] >= amin && sD[c + 1] >= T1D_RHOMIN) { e += sT[c + 1] * sT[c + 1]; nn++; }
+          if (sN[c - 1] >= amin && sD[c - 1] >= T1D_RHOMIN) { e += sT[c - 1] * sT[c - 1]; nn++; }
+          if (nn != 0) { Te = sqrt(e / (double) nn); if (Te < D.Temin) Te = Tl; } else Te = Tl;
+          Te2 = Te;
+          u = eos_ee(ee, dn, Te * 11604.5) * AMU_J2EV; u2 = u;
+        }
+      }
+    }
+    fillmesh();
+    publish();
+  }
+  // ---- stage 8: CFL_maxdt (:2444-2481) and the sub-step count (:97-99) ------------------------------------------------
+  if (stages & 8) {
+    double mx = 1e9;
+    if (cellt && act(nat, dn)) { const int m = (sN[c + 1] >= amin && sD[c + 1] >= T1D_RHOMIN) ? c + 1 : c; mx = ce * (D.hx * D.hx) / (kk + sK[m]); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmin(mx, __shfl_down(mx, o, 64));
+    if (lane == 0) red[wv] = mx;
+    __syncthreads();
+    if (tid == 0) {
+      double m = 1e9;
+      for (int q = 0; q < (int) (blockDim.x >> 6); q++) m = fmin(m, red[q]);
+      m = (steps > 0 ? m : timestep / (double) D.fd_n) * 0.9;
+      int ns = (int) (timestep / m);
+      s_maxdt = m; s_nsub = ns > D.fd_n ? ns : D.fd_n;
+    }
+    __syncthreads();
+    max_dt = s_maxdt; nsub = s_nsub;
+  }
+  // ---- stages 16 / 32 / 64: do_DIFF (:1473-1680), FILLMESH, the loop ---------------------------------------------------
+  const int per = nx / D.ref_ranks;
+  double Ci = 8.589449886e+02; Ci *= D.vlatdens; Ci *= 11604.5; Ci *= 1e-30; Ci *= C_J2EV;
+  const double invxsq = 1.0 / (D.hx * D.hx);
+  auto diff = [&](double tau) {
+    const double xi_fac = 26.9815 * C_AMU / 3.0 * 1e30 / ((double) nsub);
+    if (cellt && !(g > last_active) && !(nat < amin || dn < T1D_RHOMIN)) {
+      const int xmin = act_ge(sN[c - 1], sD[c - 1]) ? c - 1 : c, xmax = act_ge(sN[c + 1], sD[c + 1]) ? c + 1 : c;
+      double xmaxTe = sT[xmax], xminTe = sT[xmin], xmaxk = sK[xmax], xmink = sK[xmin];
+      if (g / per == vlat_proc) { xmaxTe = vT[0]; xmaxk = vK[0]; }                     // :1535-1540: every cell of that rank of the reference
+      const double Tn = tau / ce * ((((kk + xmaxk) / 2 * (xmaxTe - Te) * invxsq) - ((kk + xmink) / 2 * (Te - xminTe) * invxsq)) - gg * (Te - Tl) + src) + Te;
+      u2 = u + (Tn - Te) * ce * D.vol / ((double) nat);
+      const double dxi = (Tn - Tl) * xi_fac * gg / Tl / dn;
+      x += dxi; xiarr += dxi;
+      Te2 = Tn;
+    }
+    if (vlatt) {
+      const int cl = last_active + 1;
+      const double xminTe = vi == 0 ? sT[cl] : vT[vi - 1], xmink = vi == 0 ? sK[cl] : vK[vi - 1];
+      const double xmaxTe = vi < nv - 1 ? vT[vi + 1] : vT[vi], xmaxk = vi < nv - 1 ? vK[vi + 1] : vK[vi];
+      vTe2 = tau / vce * (((vkk + xmaxk) / 2 * (xmaxTe - vTe) * invxsq) - ((vkk + xmink) / 2 * (vTe - xminTe) * invxsq) - vgg * (vTe - vTl)) + vTe;
+      vTl2 = vTl + tau / Ci * vgg * (vTe - vTl);
+    }
+    // l1 <-> l2, vlattice1 <-> vlattice2 (:1654-1662): the registers change places
+    { double t2 = Te; Te = Te2; Te2 = t2; t2 = u; u = u2; u2 = t2; t2 = vTe; vTe = vTe2; vTe2 = t2; t2 = vTl; vTl = vTl2; vTl2 = t2; }
+    cur ^= 1; vcur ^= 1;
+  };
+  const double tau = timestep / ((double) (nsub > 0 ? nsub : 1));
+  if (stages & 16) { diff(tau); if (!(stages & 32)) publish(); }
+  if (stages & 32) { fillmesh(); publish(); }
+  if (stages & 64) for (int s = 0; s < nsub; s++) { diff(tau); fillmesh(); publish(); }
+  // ---- stage 128: U from the EOS after the loop (:119-133) ------------------------------------------------------------
+  if ((stages & 128) && cellt && nat >= amin && dn >= T1D_RHOMIN) { u = eos_ee(ee, dn, Te * 11604.5) * AMU_J2EV; u2 = u; }
+  // ---- back to memory -------------------------------------------------------------------------------------------------
+  if (cellt) { T[cur][c] = Te; T[cur ^ 1][c] = Te2; U[cur][c] = u; U[cur ^ 1][c] = u2; D.xi[c] = x; D.fd_k[c] = kk; D.fd_g[c] = gg; D.Ce[c] = ce; D.Z[c] = Zc;
+               D.ne[c] = nec; D.gd[4 * nx + g] = xiarr; }
+  if (vlatt) { VT[vcur][vi] = vTe; VT[vcur ^ 1][vi] = vTe2; VM[vcur][vi] = vTl; VM[vcur ^ 1][vi] = vTl2; D.vk[vi] = vkk; D.vg[vi] = vgg; D.vCe[vi] = vce;
+               D.vZ[vi] = vZc; D.vne[vi] = vnec; }
+  if (tid == 0) { D.natoms[0] = sN[0]; D.natoms[nx + 1] = sN[nx + 1];
+                  D.sc_i[0] = cur; D.sc_i[1] = vcur; D.sc_i[2] = last_active; D.sc_i[3] = vlat_proc; D.sc_i[4] = nsub; D.sc_d[0] = max_dt; }
+}
+
+// move_atoms_ttm, the TTM1D branch (imd_integrate.c:649-760) + check_nblist: xi and v_com of the slab the atom is in now
+__global__ void k_move_ttm1d(int n, int cap, int ntypes, double hx, int nx, double4 *pos, const int *type, double *p, double *f, const double *mass,
+                             const double *restr, double dt, const double *ref, const double *gd, double *partials)
+{
+  __shared__ double scratch[2 * 16];
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double s0 = 0, s1 = 0;
+  if (i < n) {
+    const size_t c1 = cap, c2 = 2 * (size_t) cap;
+    double4 q = pos[i];
+    const int t = ntypes == 1 ? 0 : type[i];
+    double fxi = 0, vx = 0, vy = 0, vz = 0;
+    if (t == 0) { const int g = t1d_slab(q.x, hx, nx); fxi = gd[4 * nx + g]; vx = gd[g]; vy = gd[nx + g]; vz = gd[2 * nx + g]; }
+    double fx = f[i], fy = f[c1 + i], fz = f[c2 + i];
+    double px = p[i], py = p[c1 + i], pz = p[c2 + i], m = mass[i];
+    const double e1 = px * px + py * py + pz * pz;
+    if (restr) { fx *= restr[3 * t]; fy *= restr[3 * t + 1]; fz *= restr[3 * t + 2]; f[i] = fx; f[c1 + i] = fy; f[c2 + i] = fz; }
+    px += dt * (fx + fxi * m * (px / m - vx));
+    py += dt * (fy + fxi * m * (py / m - vy));
+    pz += dt * (fz + fxi * m * (pz / m - vz));
+    const double e2 = px * px + py * py + pz * pz;
+    s0 = (e1 + e2) / (4 * m);
+    const double tmp = dt / m;
+    q.x += tmp * px; q.y += tmp * py; q.z += tmp * pz;
+    pos[i] = q;
+    p[i] = px; p[c1 + i] = py; p[c2 + i] = pz;
+    const double dx = q.x - ref[i], dy = q.y - ref[c1 + i], dz = q.z - ref[c2 + i];
+    s1 = dx * dx + dy * dy + dz * dz;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_down(s0, o, 64); s1 = fmax(s1, __shfl_down(s1, o, 64)); }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if (lane == 0) { scratch[w] = s0; scratch[16 + w] = s1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double e = 0, mx = 0;
+    for (int q2 = 0; q2 < nw; q2++) { e += scratch[q2]; mx = fmax(mx, scratch[16 + q2]); }
+    partials[(size_t) blockIdx.x * 2] = e; partials[(size_t) blockIdx.x * 2 + 1] = mx;
+  }
+}
+
+#define T1D(ctx) ((Ttm1dState *) (ctx)->ttm1d)
+void imdgpu_ttm1d_free(imdgpu_ctx *ctx)
+{
+  Ttm1dState *t = T1D(ctx);
+  if (!t) return;
+  void *p[] = {t->natoms, t->natoms_old, t->temp[0], t->temp[1], t->U[0], t->U[1], t->xi, t->md_temp, t->source, t->dens, t->fd_k, t->fd_g, t->Z, t->Ce,
+               t->ne, t->gi, t->gd, t->vt[0], t->vt[1], t->vm[0], t->vm[1], t->vk, t->vg, t->vCe, t->vZ, t->vne, t->sc_i, t->sc_d, t->cve_z, t->ee_z};
+  for (void *q : p) if (q) (void) hipFree(q);
+  delete t;
+  ctx->ttm1d = nullptr;
+}
+static T1dDev t1d_dev(const Ttm1dState *t)
+{
+  T1dDev D;
+  D.nx = t->nx; D.nv = t->nv; D.fd_min_atoms = t->fd_min_atoms; D.fd_n = t->fd_n; D.vlatbuffer = t->vlatbuffer; D.ref_ranks = t->ref_ranks;
+  D.hx = t->hx; D.vol = t->vol; D.neighvol = t->neighvol; D.aw = t->aw; D.vlatdens = t->vlatdens; D.Temin = t->Temin;
+  D.natoms = t->natoms; D.natoms_old = t->natoms_old; D.temp0 = t->temp[0]; D.temp1 = t->temp[1]; D.U0 = t->U[0]; D.U1 = t->U[1]; D.xi = t->xi;
+  D.md_temp = t->md_temp; D.source = t->source; D.dens = t->dens; D.fd_k = t->fd_k; D.fd_g = t->fd_g; D.Z = t->Z; D.Ce = t->Ce; D.ne = t->ne;
+  D.gi = t->gi; D.gd = t->gd; D.vt0 = t->vt[0]; D.vt1 = t->vt[1]; D.vm0 = t->vm[0]; D.vm1 = t->vm[1]; D.vk = t->vk; D.vg = t->vg; D.vCe = t->vCe;
+  D.vZ = t->vZ; D.vne = t->vne; D.sc_i = t->sc_i; D.sc_d = t->sc_d;
+  return D;
+}
+extern "C" int imdgpu_ttm1d_init(imdgpu_ctx *ctx, const imdgpu_ttm1d_params *par)
+{
+  HIPCHK(hipSetDevice(ctx->device));
+  if (!ctx->have_geometry) return imdgpu_fail(ctx, "ttm1d_init: set_geometry first");
+  if (!ctx->pair.present) return imdgpu_fail(ctx, "ttm1d_init: pair_pot needed (neighvol from pair_pot.end[0])");
+  if (ctx->external_halo) return imdgpu_fail(ctx, "ttm1d_init: the 1D TTM serves one rank (the slab sums of several ranks would need an all-reduce per step)");
+  if (ctx->ttm) return imdgpu_fail(ctx, "ttm1d_init: a 3D lattice is attached to this context already");
+  if (par->nx < 2 || par->nx + par->vlatdim > T1D_MAX || par->vlatdim < 1) return imdgpu_fail(ctx, "ttm1d_init: 2 <= ttmdimx, 1 <= vlatdim, ttmdimx + vlatdim <= %d", T1D_MAX);
+  if (par->ref_ranks < 1 || par->nx % par->ref_ranks) return imdgpu_fail(ctx, "ttm1d_init: ttmdimx must be a multiple of ref_ranks (imd_ttm.c:962-965)");
+  if (!par->cve_z || !par->ee_z) return imdgpu_fail(ctx, "ttm1d_init: EOS tables missing");
+  imdgpu_ttm1d_free(ctx);
+  Ttm1dState *t = new Ttm1dState();
+  ctx->ttm1d = t;
+  t->nx = par->nx; t->nv = par->vlatdim; t->fd_min_atoms = par->fd_min_atoms; t->fd_n = par->fd_n_timesteps; t->vlatbuffer = par->vlatbuffer;
+  t->ref_ranks = par->ref_ranks; t->adv = par->adv; t->aw = par->atomic_weight; t->ac = par->atomic_charge; t->vlatdens = par->vlatdens;
+  t->hx = ctx->box[0] / par->nx; t->vol = t->hx * ctx->box[4] * ctx->box[8];                          // init_ttm :972-976
+  t->neighvol = pow(sqrt(ctx->pair.par.end[0]), 3.0) * 4.0 / 3.0 * M_PI;                              // :979
+  const size_t n2 = (size_t) t->nx + 2, nv = t->nv;
+  if (dev_alloc(ctx, &t->natoms, n2) || dev_alloc(ctx, &t->natoms_old, n2) || dev_alloc(ctx, &t->xi, n2) || dev_alloc(ctx, &t->md_temp, n2) ||
+      dev_alloc(ctx, &t->source, n2) || dev_alloc(ctx, &t->dens, n2) || dev_alloc(ctx, &t->fd_k, n2) || dev_alloc(ctx, &t->fd_g, n2) ||
+      dev_alloc(ctx, &t->Z, n2) || dev_alloc(ctx, &t->Ce, n2) || dev_alloc(ctx, &t->ne, n2) || dev_alloc(ctx, &t->gi, 4 * (size_t) t->nx) ||
+      dev_alloc(ctx, &t->gd, 5 * (size_t) t->nx) || dev_alloc(ctx, &t->vk, nv) || dev_alloc(ctx, &t->vg, nv) || dev_alloc(ctx, &t->vCe, nv) ||
+      dev_alloc(ctx, &t->vZ, nv) || dev_alloc(ctx, &t->vne, nv) || dev_alloc(ctx, &t->sc_i, 8) || dev_alloc(ctx, &t->sc_d, 8)) return 1;
+  for (int q = 0; q < 2; q++) if (dev_alloc(ctx, &t->temp[q], n2) || dev_alloc(ctx, &t->U[q], n2) || dev_alloc(ctx, &t->vt[q], nv) || dev_alloc(ctx, &t->vm[q], nv)) return 1;
+  void *zi[] = {t->natoms, t->natoms_old}; for (void *p : zi) HIPCHK(hipMemset(p, 0, n2 * sizeof(int)));
+  void *zd[] = {t->temp[0], t->temp[1], t->U[0], t->U[1], t->xi, t->md_temp, t->source, t->dens, t->fd_k, t->fd_g, t->Z, t->Ce, t->ne};
+  for (void *p : zd) HIPCHK(hipMemset(p, 0, n2 * sizeof(double)));
+  HIPCHK(hipMemset(t->gi, 0, 4 * (size_t) t->nx * sizeof(int))); HIPCHK(hipMemset(t->gd, 0, 5 * (size_t) t->nx * sizeof(double)));
+  void *zv[] = {t->vk, t->vg, t->vCe, t->vZ, t->vne}; for (void *p : zv) HIPCHK(hipMemset(p, 0, nv * sizeof(double)));
+  { std::vector<double> v(nv, 0.0264);                                                                    // :1017-1023
+    for (int q = 0; q < 2; q++) { HIPCHK(hipMemcpy(t->vt[q], v.data(), nv * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(t->vm[q], v.data(), nv * 8, hipMemcpyHostToDevice)); } }
+  { int si[8] = {0, 0, -5000, 0, par->fd_n_timesteps, 0, 0, 0}; double sd[8] = {ctx->timestep / (double) par->fd_n_timesteps, 0, 0, 0, 0, 0, 0, 0};   // :978
+    HIPCHK(hipMemcpy(t->sc_i, si, sizeof si, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(t->sc_d, sd, sizeof sd, hipMemcpyHostToDevice)); }
+  const size_t nc = (size_t) par->cve_nx * par->cve_ny, ne = (size_t) par->ee_nx * par->ee_ny;
+  if (dev_alloc(ctx, &t->cve_z, nc) || dev_alloc(ctx, &t->ee_z, ne)) return 1;
+  HIPCHK(hipMemcpy(t->cve_z, par->cve_z, nc * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(t->ee_z, par->ee_z, ne * 8, hipMemcpyHostToDevice));
+  t->cve = EosDev{par->cve_nx, par->cve_ny, par->cve_xmin, par->cve_xmax, par->cve_ymin, par->cve_ymax, t->cve_z, nullptr};
+  t->ee = EosDev{par->ee_nx, par->ee_ny, par->ee_xmin, par->ee_xmax, par->ee_ymin, par->ee_ymax, t->ee_z, nullptr};
+  Lat &L = t->L;
+  memset(&L, 0, sizeof L);
+  L.fd_min_atoms = t->fd_min_atoms; L.vol = t->vol; L.neighvol = t->neighvol; L.atomic_weight = t->aw; L.atomic_charge = t->ac; L.omega_laser = 0.0;
+  L.Temin = t->Temin; L.inv_z0_43 = 1e-3 / pow(t->ac, 4.0 / 3.0); L.inv_z0am = 1e-3 / (t->ac * t->aw); L.inv_awamu = 1.0 / (t->aw * C_AMU);
+  ctx->count_ttm = 1;
+  ctx->reserve_cus = 1;                           // the single-workgroup lattice launch needs a CU beside the persistent force kernels (4.7)
+  HIPCHK(hipMemset(ctx->fdc, 0xff, (size_t) ctx->cap_local * sizeof(int)));
+  return 0;
+}
+#define NEED_T1D()                                                                   \
+  Ttm1dState *t = T1D(ctx);                                                          \
+  if (!t) return imdgpu_fail(ctx, "imdgpu_ttm1d_init first");                       \
+  HIPCHK(hipSetDevice(ctx->device))
+static int t1d_update_fd_sums(imdgpu_ctx *ctx, Ttm1dState *t, int steps)
+{
+  const int n = ctx->nlocal, nx = t->nx;
+  HIPCHK(hipMemsetAsync(t->gi, 0, 4 * (size_t) nx * sizeof(int), ctx->stream));
+  HIPCHK(hipMemsetAsync(t->gd, 0, 4 * (size_t) nx * sizeof(double), ctx->stream));            // v_com sums and md_temp sums; xiarr is cleared by stage 1
+  ProfScope ps(ctx, PROF_TTM_UPDATE);
+  hipLaunchKernelGGL((k_ttm1d_bin<1>), dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, n, ctx->cap_local, ctx->ntypes, steps, t->hx, nx, ctx->pos, ctx->type,
+                     ctx->p, ctx->mass, ctx->numneighs, ctx->fdc, t->gi, t->gd);
+  hipLaunchKernelGGL(k_ttm1d_vcom, dim3(nblk(nx, 256)), dim3(256), 0, ctx->stream, nx, t->aw, t->gi, t->gd);
+  hipLaunchKernelGGL((k_ttm1d_bin<2>), dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, n, ctx->cap_local, ctx->ntypes, steps, t->hx, nx, ctx->pos, ctx->type,
+                     ctx->p, ctx->mass, ctx->numneighs, ctx->fdc, t->gi, t->gd);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+// function-level entry: the stages of k_ttm1d_calc (bit 0 = update_fd incl. the atom sweeps)
+extern "C" int imdgpu_ttm1d_stage(imdgpu_ctx *ctx, int steps, int stages)
+{
+  NEED_T1D();
+  if ((stages & 1) && t1d_update_fd_sums(ctx, t, steps)) return 1;
+  ProfScope ps(ctx, PROF_TTM_DIFF);
+  hipLaunchKernelGGL(k_ttm1d_calc, dim3(1), dim3(T1D_MAX), 0, ctx->stream, t1d_dev(t), t->L, t->cve, t->ee, steps, ctx->timestep, stages);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+// [calc_ttm, imd_ttm.c:75-155, without do_tmm]
+extern "C" int imdgpu_ttm1d_calc(imdgpu_ctx *ctx, int steps)
+{
+  NEED_T1D();
+  return imdgpu_ttm1d_stage(ctx, steps, 1 | (t->adv ? 2 : 0) | 4 | 8 | 64 | 128);
+}
+int imdgpu_ttm1d_move_internal(imdgpu_ctx *ctx)
+{
+  NEED_T1D();
+  const int n = ctx->nlocal, nb = nblk(n, 256);
+  const double h = 0.5 * ctx->nbl_margin;
+  ProfScope ps(ctx, PROF_INTEGRATE);
+  hipLaunchKernelGGL(k_move_ttm1d, dim3(nb), dim3(256), 0, ctx->stream, n, ctx->cap_local, ctx->ntypes, t->hx, t->nx, ctx->pos, ctx->type, ctx->p, ctx->f,
+                     ctx->mass, ctx->restr_identity ? nullptr : ctx->d_restr, ctx->timestep, ctx->ref, t->gd, ctx->partials);
+  hipLaunchKernelGGL(k_reduce_move, dim3(1), dim3(1024), 0, ctx->stream, nb, ctx->partials, ctx->d_sums, h * h, ctx->d_counters, 1);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+extern "C" int imdgpu_ttm1d_move_atoms(imdgpu_ctx *ctx, double *ekin)
+{
+  if (imdgpu_ttm1d_move_internal(ctx)) return 1;
+  HIPCHK(hipMemcpyAsync(ctx->h_sums, ctx->d_sums, SUM_N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (ekin) *ekin = ctx->h_sums[SUM_EKIN];
+  return 0;
+}
+static int t1d_xfer(imdgpu_ctx *ctx, const imdgpu_ttm1d_fields *f, bool down)
+{
+  NEED_T1D();
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (ctx->step_open) HIPCHK(hipStreamSynchronize(ctx->stream2));
+  int si[8]; double sd[8];
+  HIPCHK(hipMemcpy(si, t->sc_i, sizeof si, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(sd, t->sc_d, sizeof sd, hipMemcpyDeviceToHost));
+  const int cur = si[0], vcur = si[1];
+  const size_t n2 = (size_t) t->nx + 2, nx = t->nx, nv = t->nv;
+  auto X = [&](void *host, void *dev, size_t bytes) -> int {
+    if (!host) return 0;
+    if (down) HIPCHK(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost)); else HIPCHK(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice));
+    return 0;
+  };
+  if (X(f->natoms, t->natoms, n2 * 4) || X(f->natoms_old, t->natoms_old, n2 * 4) || X(f->temp, t->temp[cur], n2 * 8) || X(f->temp2, t->temp[cur ^ 1], n2 * 8) ||
+      X(f->U, t->U[cur], n2 * 8) || X(f->U2, t->U[cur ^ 1], n2 * 8) || X(f->xi, t->xi, n2 * 8) || X(f->md_temp, t->md_temp, n2 * 8) || X(f->source, t->source, n2 * 8) ||
+      X(f->dens, t->dens, n2 * 8) || X(f->fd_k, t->fd_k, n2 * 8) || X(f->fd_g, t->fd_g, n2 * 8) || X(f->Z, t->Z, n2 * 8) || X(f->Ce, t->Ce, n2 * 8) || X(f->ne, t->ne, n2 * 8) ||
+      X(f->natomsglobal, t->gi, nx * 4) || X(f->fluxfromleft, t->gi + 2 * nx, nx * 4) || X(f->fluxfromright, t->gi + 3 * nx, nx * 4) ||
+      X(f->vcomglobal, t->gd, 3 * nx * 8) || X(f->xiarr_global, t->gd + 4 * nx, nx * 8) ||
+      X(f->vlat_temp, t->vt[vcur], nv * 8) || X(f->vlat_md_temp, t->vm[vcur], nv * 8) || X(f->vlat_fd_k, t->vk, nv * 8) || X(f->vlat_fd_g, t->vg, nv * 8) ||
+      X(f->vlat_Ce, t->vCe, nv * 8))
+    return 1;
+  if (f->scalars) {
+    if (down) { f->scalars[0] = si[2]; f->scalars[1] = si[3]; f->scalars[2] = si[4]; f->scalars[3] = sd[0]; }
+    else { si[2] = (int) f->scalars[0]; si[3] = (int) f->scalars[1]; si[4] = (int) f->scalars[2]; sd[0] = f->scalars[3];
+           HIPCHK(hipMemcpy(t->sc_i, si, sizeof si, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(t->sc_d, sd, sizeof sd, hipMemcpyHostToDevice)); }
+  }
+  return 0;
+}
+extern "C" int imdgpu_ttm1d_download(imdgpu_ctx *ctx, const imdgpu_ttm1d_fields *f) { return t1d_xfer(ctx, f, true); }
+extern "C" int imdgpu_ttm1d_upload(imdgpu_ctx *ctx, const imdgpu_ttm1d_fields *f) { return t1d_xfer(ctx, f, false); }

@@ -33,6 +33,7 @@ SYMBOLS = [
     "imdgpu_dist_unique_id", "imdgpu_dist_init_rccl", "imdgpu_dist_init_callback", "imdgpu_dist_set_plan",
     "imdgpu_dist_halo", "imdgpu_dist_set_ttm_blocks", "imdgpu_dist_md_step", "imdgpu_dist_allreduce_sum",
     "imdgpu_dist_rebuild", "imdgpu_dist_rebuild_count", "imdgpu_dist_step", "imdgpu_dist_calc_forces", "imdgpu_dist_plan_geometry",
+    "imdgpu_ttm1d_init", "imdgpu_ttm1d_calc", "imdgpu_ttm1d_stage", "imdgpu_ttm1d_move_atoms", "imdgpu_ttm1d_download", "imdgpu_ttm1d_upload",
     "imdgpu_ttm_remote_init", "imdgpu_ttm_remote_ipc_handle", "imdgpu_ttm_remote_open", "imdgpu_ttm_remote_attach", "imdgpu_dist_ttm_remote_setup",
     "imdgpu_local_group_create", "imdgpu_local_group_destroy", "imdgpu_local_group_barrier", "imdgpu_local_group_shared", "imdgpu_dist_init_local",
 ]
@@ -58,6 +59,28 @@ class TtmParamsC(C.Structure):
                 ("cve_ymin", C.c_double), ("cve_ymax", C.c_double), ("cve_z", C.POINTER(C.c_double)),
                 ("ee_nx", C.c_int), ("ee_ny", C.c_int), ("ee_xmin", C.c_double), ("ee_xmax", C.c_double),
                 ("ee_ymin", C.c_double), ("ee_ymax", C.c_double), ("ee_z", C.POINTER(C.c_double))]
+
+
+class Ttm1dParamsC(C.Structure):
+    """imdgpu_ttm1d_params"""
+    _fields_ = [("nx", C.c_int), ("fd_min_atoms", C.c_int), ("fd_n_timesteps", C.c_int), ("vlatdim", C.c_int), ("vlatbuffer", C.c_int),
+                ("ref_ranks", C.c_int), ("adv", C.c_int), ("vlatdens", C.c_double), ("atomic_weight", C.c_double), ("atomic_charge", C.c_double),
+                ("cve_nx", C.c_int), ("cve_ny", C.c_int), ("cve_xmin", C.c_double), ("cve_xmax", C.c_double),
+                ("cve_ymin", C.c_double), ("cve_ymax", C.c_double), ("cve_z", C.POINTER(C.c_double)),
+                ("ee_nx", C.c_int), ("ee_ny", C.c_int), ("ee_xmin", C.c_double), ("ee_xmax", C.c_double),
+                ("ee_ymin", C.c_double), ("ee_ymax", C.c_double), ("ee_z", C.POINTER(C.c_double))]
+
+
+TTM1D_INT = ("natoms", "natoms_old")
+TTM1D_DBL = ("temp", "temp2", "U", "U2", "xi", "md_temp", "source", "dens", "fd_k", "fd_g", "Z", "Ce", "ne")
+TTM1D_GINT = ("natomsglobal", "fluxfromleft", "fluxfromright")
+TTM1D_REST = ("vcomglobal", "xiarr_global", "vlat_temp", "vlat_md_temp", "vlat_fd_k", "vlat_fd_g", "vlat_Ce", "scalars")
+
+
+class Ttm1dFieldsC(C.Structure):
+    """imdgpu_ttm1d_fields"""
+    _fields_ = [(k, C.POINTER(C.c_int)) for k in TTM1D_INT] + [(k, C.POINTER(C.c_double)) for k in TTM1D_DBL] + \
+               [(k, C.POINTER(C.c_int)) for k in TTM1D_GINT] + [(k, C.POINTER(C.c_double)) for k in TTM1D_REST]
 
 
 TTM_FIELDS = ("natoms", "natoms_old", "temp", "temp2", "xi", "md_temp", "source", "vcom", "dens", "fd_k", "fd_g",
@@ -169,6 +192,12 @@ def load():
     L.imdgpu_dist_set_ttm_blocks.argtypes = [vp, ip]
     L.imdgpu_dist_md_step.argtypes = [vp, C.c_int, ip]
     L.imdgpu_dist_allreduce_sum.argtypes = [vp, dp, C.c_int]
+    L.imdgpu_ttm1d_init.argtypes = [vp, C.POINTER(Ttm1dParamsC)]
+    L.imdgpu_ttm1d_calc.argtypes = [vp, C.c_int]
+    L.imdgpu_ttm1d_stage.argtypes = [vp, C.c_int, C.c_int]
+    L.imdgpu_ttm1d_move_atoms.argtypes = [vp, dp]
+    L.imdgpu_ttm1d_download.argtypes = [vp, C.POINTER(Ttm1dFieldsC)]
+    L.imdgpu_ttm1d_upload.argtypes = [vp, C.POINTER(Ttm1dFieldsC)]
     L.imdgpu_ttm_remote_init.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.imdgpu_ttm_remote_ipc_handle.argtypes = [vp, vp, ip]
     L.imdgpu_ttm_remote_open.argtypes = [vp, vp, C.POINTER(vp)]

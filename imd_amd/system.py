@@ -10,7 +10,8 @@ import ctypes as C
 import numpy as np
 
 from . import lib as _lib
-from .lib import TTM_FIELDS, TTM_INT_FIELDS, FdtdParamsC, ImdGpuError, LaserParamsC, PotTableC, TtmFieldsC, TtmParamsC
+from .lib import (TTM1D_DBL, TTM1D_GINT, TTM1D_INT, TTM_FIELDS, TTM_INT_FIELDS, FdtdParamsC, ImdGpuError, LaserParamsC, PotTableC,
+                  Ttm1dFieldsC, Ttm1dParamsC, TtmFieldsC, TtmParamsC)
 
 
 def _dp(a):
@@ -270,6 +271,61 @@ class GpuSystem:
             keep.append(a)
             setattr(F, n, _ip(a) if n in TTM_INT_FIELDS else _dp(a))
         self._ck(self.L.imdgpu_ttm_upload(self.h, C.byref(F)))
+
+    # -- the reference's own 1D TTM (imd_ttm.c, -DTTM1D) -------------------------------------
+    def init_ttm1d(self, ttmdimx, fd_min_atoms, fd_n_timesteps, vlatdim, vlatbuffer, vlatdens, atomic_weight, atomic_charge, eos_cve, eos_ee,
+                   ref_ranks=1, adv=True):
+        """init_ttm of imd_ttm.c (:955-1206): ttmdimx slabs along x, a virtual lattice of vlatdim cells behind the sample"""
+        P = Ttm1dParamsC()
+        P.nx, P.fd_min_atoms, P.fd_n_timesteps, P.vlatdim, P.vlatbuffer = int(ttmdimx), int(fd_min_atoms), int(fd_n_timesteps), int(vlatdim), int(vlatbuffer)
+        P.ref_ranks, P.adv, P.vlatdens, P.atomic_weight, P.atomic_charge = int(ref_ranks), 1 if adv else 0, float(vlatdens), float(atomic_weight), float(atomic_charge)
+        zc = np.ascontiguousarray(eos_cve["z"], dtype=np.float64); ze = np.ascontiguousarray(eos_ee["z"], dtype=np.float64)
+        self._keep.append((zc, ze))
+        P.cve_nx, P.cve_ny = zc.shape
+        P.cve_xmin, P.cve_xmax, P.cve_ymin, P.cve_ymax = (float(eos_cve["x"][0]), float(eos_cve["x"][-1]), float(eos_cve["y"][0]), float(eos_cve["y"][-1]))
+        P.cve_z = _dp(zc)
+        P.ee_nx, P.ee_ny = ze.shape
+        P.ee_xmin, P.ee_xmax, P.ee_ymin, P.ee_ymax = (float(eos_ee["x"][0]), float(eos_ee["x"][-1]), float(eos_ee["y"][0]), float(eos_ee["y"][-1]))
+        P.ee_z = _dp(ze)
+        self._ck(self.L.imdgpu_ttm1d_init(self.h, C.byref(P)))
+        self.ttm1d_nx, self.ttm1d_nv = int(ttmdimx), int(vlatdim)
+
+    def ttm1d_calc(self, steps):
+        self._ck(self.L.imdgpu_ttm1d_calc(self.h, int(steps)))
+
+    def ttm1d_stage(self, steps, stages):
+        self._ck(self.L.imdgpu_ttm1d_stage(self.h, int(steps), int(stages)))
+
+    def ttm1d_move_atoms(self):
+        e = C.c_double()
+        self._ck(self.L.imdgpu_ttm1d_move_atoms(self.h, C.byref(e)))
+        return e.value
+
+    def _ttm1d_shapes(self):
+        nx, nv = self.ttm1d_nx, self.ttm1d_nv
+        sh = {k: (nx + 2,) for k in TTM1D_INT + TTM1D_DBL}
+        sh.update({k: (nx,) for k in TTM1D_GINT + ("xiarr_global",)})
+        sh.update(vcomglobal=(3, nx), scalars=(4,))
+        sh.update({k: (nv,) for k in ("vlat_temp", "vlat_md_temp", "vlat_fd_k", "vlat_fd_g", "vlat_Ce")})
+        return sh
+
+    def ttm1d_download(self):
+        F, out = Ttm1dFieldsC(), {}
+        for k, shp in self._ttm1d_shapes().items():
+            isint = k in TTM1D_INT + TTM1D_GINT
+            out[k] = np.zeros(shp, np.int32 if isint else np.float64)
+            setattr(F, k, _ip(out[k]) if isint else _dp(out[k]))
+        self._ck(self.L.imdgpu_ttm1d_download(self.h, C.byref(F)))
+        return out
+
+    def ttm1d_upload(self, **fields):
+        F, keep, sh = Ttm1dFieldsC(), [], self._ttm1d_shapes()
+        for k, v in fields.items():
+            isint = k in TTM1D_INT + TTM1D_GINT
+            a = np.ascontiguousarray(v, np.int32 if isint else np.float64).reshape(sh[k])
+            keep.append(a)
+            setattr(F, k, _ip(a) if isint else _dp(a))
+        self._ck(self.L.imdgpu_ttm1d_upload(self.h, C.byref(F)))
 
     def EOS_te_from_r_ee(self, r, e):
         """imd_ttm_3D.c:2786: vectorised over host arrays, K."""

@@ -286,6 +286,48 @@ int imdgpu_calc_ttm(imdgpu_ctx *ctx, int steps);
 /* [move_atoms_ttm, imd_integrate.c:581-811] */
 int imdgpu_move_atoms_ttm(imdgpu_ctx *ctx, double *tot_kin_energy);
 
+/* ---- the reference's OWN 1D two-temperature model (imd_ttm.c; the file its Makefile builds, -DTTM1D) ------------------
+ * Atoms binned into ttmdimx slabs by position ((int)(x / fd_h.x), imd_ttm.c:296-298), slab sums as global arrays, activity =
+ * natoms >= fd_min_atoms && dens > RHOMIN (2 kg/m^3, :69), a static virtual lattice of vlatdim cells behind the last active
+ * cell (:1013-1024,1595-1650), diffusion sub-steps from the stability limit (:97-99), U from the EOS after the loop
+ * (:119-133); move_atoms_ttm takes xi / v_com of the slab an atom is in now (imd_integrate.c:649-760).  One rank; no do_tmm
+ * (its input files are not part of the tree).  ref_ranks: how many ranks the REFERENCE run to be reproduced cut the row
+ * into (every cell of the piece that holds the last active cell takes the virtual lattice as +x neighbour, :1535-1540).
+ * Lattice arrays: ttmdimx + 2 entries (ghost cells at both ends), global slab arrays: ttmdimx, virtual lattice: vlatdim. */
+typedef struct {
+  int    nx;                      /* ttmdimx (globals.h:1172) */
+  int    fd_min_atoms, fd_n_timesteps, vlatdim, vlatbuffer, ref_ranks, adv;
+  double vlatdens, atomic_weight, atomic_charge;
+  int    cve_nx, cve_ny;
+  double cve_xmin, cve_xmax, cve_ymin, cve_ymax;
+  const double *cve_z;
+  int    ee_nx, ee_ny;
+  double ee_xmin, ee_xmax, ee_ymin, ee_ymax;
+  const double *ee_z;
+} imdgpu_ttm1d_params;
+typedef struct {
+  int    *natoms, *natoms_old;
+  double *temp, *temp2, *U, *U2, *xi, *md_temp, *source, *dens, *fd_k, *fd_g, *Z, *Ce, *ne;
+  int    *natomsglobal, *fluxfromleft, *fluxfromright;
+  double *vcomglobal;             /* 3 x ttmdimx: x, y, z */
+  double *xiarr_global;
+  double *vlat_temp, *vlat_md_temp, *vlat_fd_k, *vlat_fd_g, *vlat_Ce;
+  double *scalars;                /* 4: last_active_cell_global, cur_vlattice_proc, diff_substeps, max_dt_ttm */
+} imdgpu_ttm1d_fields;
+/* [init_ttm, imd_ttm.c:955-1206] */
+int imdgpu_ttm1d_init(imdgpu_ctx *ctx, const imdgpu_ttm1d_params *par);
+/* [calc_ttm, imd_ttm.c:75-155]: update_fd, do_ADV, do_cell_activation, do_FILLMESH, CFL_maxdt, the loop, the EOS update of U;
+ * imdgpu_md_step runs it beside the force passes like the 3D calc_ttm when a 1D lattice is attached */
+int imdgpu_ttm1d_calc(imdgpu_ctx *ctx, int steps);
+/* function level: bit 0 [update_fd :161-548], 1 [do_ADV :1208-1309], 2 [do_cell_activation :1311-1425 + do_FILLMESH :629-850 +
+ * ghosts], 3 [CFL_maxdt :2444-2481 + the sub-step count :97-99], 4 [one do_DIFF :1473-1680], 5 [do_FILLMESH + ghosts],
+ * 6 [the loop], 7 [U from the EOS, :119-133] */
+int imdgpu_ttm1d_stage(imdgpu_ctx *ctx, int steps, int stages);
+/* [move_atoms_ttm, TTM1D branch, imd_integrate.c:649-760] */
+int imdgpu_ttm1d_move_atoms(imdgpu_ctx *ctx, double *tot_kin_energy);
+int imdgpu_ttm1d_download(imdgpu_ctx *ctx, const imdgpu_ttm1d_fields *f);
+int imdgpu_ttm1d_upload(imdgpu_ctx *ctx, const imdgpu_ttm1d_fields *f);
+
 /* ---- multi-GPU spatial decomposition (one rank per GPU) --------------------- */
 /* The reference's Plimpton exchange (send_cells / send_forces, imd_comm_force_3d.c:
  * 222-396,569-715) and atom migration (fix_cells -> send_atoms, imd_fix_cells_3d.c:
