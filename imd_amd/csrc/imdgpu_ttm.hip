@@ -2870,9 +2870,9 @@ __global__ __launch_bounds__(T1D_MAX) void k_ttm1d_calc(T1dDev D, Lat L, EosDev 
     if (tid == 0) { sN[0] = 0; sN[nx + 1] = 0; }
     __syncthreads();
   };
+  publish();                        // the row's temp / fd_k as they stand, for whichever stage comes first
   // ---- stage 4: do_cell_activation (:1311-1425) + FILLMESH + ghosts ---------------------------------------------------
   if (stages & 4) {
-    publish();
     if (cellt) {
       const int nold = D.natoms_old[c];
       if (nold >= amin && nat < amin && dn > T1D_RHOMIN) x = 0.0;
