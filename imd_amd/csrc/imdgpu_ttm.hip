@@ -367,10 +367,15 @@ __global__ void k_ttm_update_fd(Lat L, int steps, int cap, const int *cell_start
   }
   neigh = wsumi(neigh);
   if (fdc) {
+    // atoms change FD columns rarely: the eight wave reductions only when some lane of this wave saw a crossing
+    int anyf = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) anyf |= fl[q];
+    const bool crossing = __any(anyf != 0);
 #pragma unroll
     for (int q = 0; q < 8; q++) {
-      fl[q] = wsumi(fl[q]);
-      if (lane == 0 && flux) flux[(size_t) q * ncell + c] = fl[q];
+      if (crossing) fl[q] = wsumi(fl[q]);
+      if (lane == 0 && flux) flux[(size_t) q * ncell + c] = crossing ? fl[q] : 0;
     }
   }
   sx = wsum(sx); sy = wsum(sy); sz = wsum(sz); sm = wsum(sm);
