@@ -46,6 +46,9 @@ def parse():
                     help="config 5: `--laser` / `--laser beer` = Beer-Lambert source laser_rescale_ttm (imd_laser.c:715) in every\n"
                          "step; `--laser fdtd` = the 1D Maxwell solver (imd_fdtd.c) on a slab: open x with vacuum in front of and\n"
                          "behind the atoms, ONE row of FD cells along x (fd_ext 1 ny nz), pulse centred on the timed region")
+    ap.add_argument("--dl-tables", action="store_true",
+                    help="with --laser fdtd: the cells' Drude-Lorentz parameters from fitDL's tricubic tables in every FILLMESH\n"
+                         "(imd_ttm_3D.c:600,2919-2968; synthetic tables, DL1..5.txt are not part of the reference tree) instead of constants")
     ap.add_argument("--slab", action="store_true",
                     help="config 4's geometry: open x with 12 MD cells of vacuum in front of and behind the atoms (pbc 0 1 1)")
     ap.add_argument("--cpu-box", type=int, default=48, help="unit cells per direction of the CPU sample")
@@ -129,6 +132,9 @@ def build_system(args, rank, world, device):
             # solver is active during the whole timed region; source 30 cells in front of the surface
             sysm.init_fdtd(I0=2e15, lam=800e-9, sigma_t=60e-15, t_0=150 * 0.1 * 10.18e-15, srcx=25 * (box[0, 0] / gdim[0]) * 1e-10,
                            bw=15, Sc=1.0)
+            if args.dl_tables:
+                from imd_amd import tricub
+                sysm.fdtd_set_dl_tables(tricub.synthetic_dl_tables(500.0, 6000.0))
         elif args.laser:          # a gentle pulse along x peaking at step 150: mu = 1/(20 A), 0.4 eV/A^2 fluence, sigma_t = 5 time units
             sig_t, mu, sig_e = 5.0, 0.05, 0.4
             sysm.set_laser(direction=(1, 0, 0), offset=0.0, mu=mu, p_peak=mu * sig_e / sig_t / np.sqrt(2 * np.pi),
@@ -493,7 +499,8 @@ def main():
                                                                        "100 x (do_DIFF, FILLMESH, ghosts)" % (" ".join(str(v) for v in sysm.fd_ext), "on" if adv_on(args) else "off")) +
                                     (", slab: open x with vacuum on both sides" if args.slab else "") +
                                     (", Beer-Lambert laser source (laser_rescale_ttm)" if args.laser == "beer" else
-                                     ", 1D Maxwell solver as laser source (do_fdtd; slab, open x, one row of FD cells)" if args.laser == "fdtd" else "")),
+                                     ", 1D Maxwell solver as laser source (do_fdtd; slab, open x, one row of FD cells%s)" %
+                                     (", fitDL from tricubic tables" if args.dl_tables else "") if args.laser == "fdtd" else "")),
                        "atoms_per_gpu": natoms, "cells": list(gdim), "half_list_entries_per_atom": M,
                        "max_neighbours": maxn, "list_rebuilds_in_timed_region": rebuilds,
                        "kernel_family": "lds_tiles" if sysm.get_info("list_mode") == 1 else "global_gather",

@@ -2333,15 +2333,146 @@ int imdgpu_ttm_step_internal(imdgpu_ctx *ctx, int steps)
 #define F_MU0 1.256637061435917e-06
 #define F_C0 3.0e8
 
+// ---- fitDL: the cell's Drude-Lorentz parameters from five tables over (rho, lg Te, lg Ti) ------------------------------
+// [do_tricubinterp, imd_interpol.c:740-957; tricub_get_coeff(_stacked) :1088,:1150; tricub_eval :1108; fitDL,
+// imd_ttm_3D.c:2919-2968].  The cell search assumes nodes at the cell centres; the differences at the 8 corners are
+// un-normalised and clamped at the table's ends; a = A x with A the Lekien-Marsden matrix = the tensor product of the 1D
+// cubic Hermite basis (HERM below: coefficients of f0, f1, f0', f1' in powers of t; pinned against the reference's matrix
+// through the golden vectors).  tricub_eval passes x^i, y^j, z^k through INT variables, so every power is truncated
+// towards zero: with all three scaled coordinates inside (-1, 1) only a[0] = f[i1][j1][k1] survives -- the common case,
+// answered by one load; everything else (the upper end of an axis, tables with nodes elsewhere) takes the general path,
+// which forms only the coefficients that carry weight, each as the reference's sum over the 64 corner values in order.
+struct TricubDev {
+  int is, js, ks, same;
+  double xmin, xmax, ymin, ymax, zmin, zmax, dx, dy, dz;
+  const double *x, *y, *z, *f;                   // f[(i*js + j)*ks + k]
+};
+struct TricubIdx { int nd[3][2], pm[3][2][2]; };  // [axis][corner bit] = i1 / i2; [axis][corner bit][0 min, 1 max]
+__device__ const int HERM[4][4] = {{1, 0, 0, 0}, {0, 0, 1, 0}, {-3, 3, -2, -1}, {2, -2, 1, 1}};
+
+// corner value / difference number q = 8 * type + corner of tricub_get_coeff's 64-vector (nested z( y( x(.) ) ))
+__device__ __noinline__ double tricub_corner(const TricubDev &T, const TricubIdx &I, int q)
+{
+  const int ty = q >> 3, c = q & 7;
+  const int der[3] = {(ty == 1 || ty == 4 || ty == 5 || ty == 7) ? 1 : 0, (ty == 2 || ty == 4 || ty == 6 || ty == 7) ? 1 : 0,
+                      (ty == 3 || ty == 5 || ty == 6 || ty == 7) ? 1 : 0};
+  const int b[3] = {c & 1, (c >> 1) & 1, (c >> 2) & 1};
+  double vz[2] = {0.0, 0.0};
+  for (int kz = 0; kz < (der[2] ? 2 : 1); kz++) {
+    const int kk = der[2] ? I.pm[2][b[2]][1 - kz] : I.nd[2][b[2]];
+    double vy[2] = {0.0, 0.0};
+    for (int jy = 0; jy < (der[1] ? 2 : 1); jy++) {
+      const int jj = der[1] ? I.pm[1][b[1]][1 - jy] : I.nd[1][b[1]];
+      const size_t row = (size_t) jj * T.ks + kk, pl = (size_t) T.js * T.ks;
+      vy[jy] = der[0] ? (T.f[I.pm[0][b[0]][1] * pl + row] - T.f[I.pm[0][b[0]][0] * pl + row]) : T.f[I.nd[0][b[0]] * pl + row];
+    }
+    vz[kz] = der[1] ? (vy[0] - vy[1]) : vy[0];
+  }
+  return der[2] ? (vz[0] - vz[1]) : vz[0];
+}
+
+__device__ __noinline__ double tricub_general(const TricubDev &T, const TricubIdx &I, const double *sc)
+{
+  int w[3][4];
+  for (int ax = 0; ax < 3; ax++) {               // t4 = pow(x, i) etc. stored in int (tricub_eval :1134-1136)
+    const double v = sc[ax];
+    w[ax][0] = 1; w[ax][1] = (int) v; w[ax][2] = (int) (v * v); w[ax][3] = (int) (v * v * v);
+  }
+  double s4 = 0.0;
+  for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) for (int k = 0; k < 4; k++) {
+    const int wt = w[0][i] * w[1][j] * w[2][k];
+    if (wt == 0) continue;                       // a * 0.0 adds nothing (finite tables)
+    double acc = 0.0;                            // a[i + 4j + 16k], tricub_get_coeff_stacked :1150-1164
+    for (int q = 0; q < 64; q++) {
+      const int tq = q >> 3, cq = q & 7;
+      const int dxq = (tq == 1 || tq == 4 || tq == 5 || tq == 7), dyq = (tq == 2 || tq == 4 || tq == 6 || tq == 7),
+                dzq = (tq == 3 || tq == 5 || tq == 6 || tq == 7);
+      const int A = HERM[i][(cq & 1) + 2 * dxq] * HERM[j][((cq >> 1) & 1) + 2 * dyq] * HERM[k][((cq >> 2) & 1) + 2 * dzq];
+      if (A != 0) acc += (double) A * tricub_corner(T, I, q);
+    }
+    s4 = s4 + acc * (double) wt;
+  }
+  return 0.0 + s4;
+}
+
+// cell search of do_tricubinterp (:752-808, :940-951): the node below per axis and the scaled coordinates
+struct TricubCell { int lo[3], hi[3]; double sc[3]; bool inside, fast; };
+__device__ __forceinline__ TricubCell tricub_locate(const TricubDev &T, double xp, double yp, double zp)
+{
+  TricubCell c;
+  c.inside = !(xp > T.xmax || xp < T.xmin || yp > T.ymax || yp < T.ymin || zp < T.zmin || zp > T.zmax);      // :752-757 (no message)
+  c.fast = true;
+  if (!c.inside) return c;
+  const int n[3] = {T.is, T.js, T.ks};
+  const double p[3] = {xp, yp, zp};
+  const double *nodes[3] = {T.x, T.y, T.z};
+  c.lo[0] = (int) floor((xp - (T.xmin + T.dx / 2)) / (T.xmax - T.xmin) * (double) T.is);                        // :772-774
+  c.lo[1] = (int) floor((yp - (T.ymin + T.dy / 2)) / (T.ymax - T.ymin) * (double) T.js);
+  c.lo[2] = (int) floor((zp - (T.zmin + T.dz / 2)) / (T.zmax - T.zmin) * (double) T.ks);
+  for (int ax = 0; ax < 3; ax++) {
+    c.lo[ax] = max(c.lo[ax], 0);
+    c.hi[ax] = max(min(c.lo[ax] + 1, n[ax] - 1), 0);
+    const double x1 = nodes[ax][c.lo[ax]], x2 = nodes[ax][c.hi[ax]];
+    // |(p - x1) / (x2 - x1)| < 1 exactly when |p - x1| < |x2 - x1| (a correctly rounded quotient of doubles cannot reach 1
+    // from below): the common case needs no division; the quotient itself only on the general path
+    const bool in1 = (x2 - x1 != 0) && fabs(p[ax] - x1) < fabs(x2 - x1);
+    c.sc[ax] = in1 ? 0.0 : ((x2 - x1 == 0) ? 1.0 : (p[ax] - x1) / (x2 - x1));                                      // :940-951
+    c.fast = c.fast && in1;
+  }
+  return c;
+}
+
+__device__ __forceinline__ double tricub_value(const TricubDev &T, const TricubCell &c)
+{
+  if (!c.inside) return -1;
+  if (c.fast) return 0.0 + T.f[((size_t) c.lo[0] * T.js + c.lo[1]) * T.ks + c.lo[2]];      // a[0] alone: 1 * f[i1][j1][k1]
+  const int n[3] = {T.is, T.js, T.ks};
+  TricubIdx I;
+  for (int ax = 0; ax < 3; ax++) {
+    I.nd[ax][0] = c.lo[ax]; I.nd[ax][1] = c.hi[ax];
+    for (int b = 0; b < 2; b++) { I.pm[ax][b][0] = max(I.nd[ax][b] - 1, 0); I.pm[ax][b][1] = min(I.nd[ax][b] + 1, n[ax] - 1); }   // :795-808
+  }
+  return tricub_general(T, I, c.sc);
+}
+
+__device__ __forceinline__ double tricub_lookup(const TricubDev &T, double xp, double yp, double zp)
+{
+  return tricub_value(T, tricub_locate(T, xp, yp, zp));
+}
+
+#define F_HBAREV 6.582119487171653e-16      // globals.h:485
+// fitDL for one cell: DL[0..4] from the tables, DL[5] the plasma frequency of the cell's electron density (:2939-2960).
+// tab[0].same: the five tables share dimensions, ranges and nodes (one grid, five quantities): one cell search for all
+__device__ __forceinline__ void fit_dl(const TricubDev *tab, double temp, double md_temp, double dens, double ne, double *DL)
+{
+  const double Te = fmax(temp, 0.0259), Ti = fmax(md_temp, 0.0259);
+  double lgTe = log10(Te), lgTi = log10(Ti);
+  lgTi = fmax(lgTi, -1.587504); lgTe = fmax(lgTe, -1.587504);
+  lgTe = fmin(lgTe, tab[0].ymax); lgTi = fmin(lgTi, tab[0].zmax);
+  if (tab[0].same) {
+    const TricubCell c = tricub_locate(tab[0], dens, lgTe, lgTi);
+    DL[0] = tricub_value(tab[0], c);
+    for (int q = 1; q < 5; q++) DL[q] = tricub_value(tab[q], c) / F_HBAREV;
+  } else {
+    DL[0] = tricub_lookup(tab[0], dens, lgTe, lgTi);
+    for (int q = 1; q < 5; q++) DL[q] = tricub_lookup(tab[q], dens, lgTe, lgTi) / F_HBAREV;
+  }
+  DL[5] = sqrt(ne * C_ECHARGE * C_ECHARGE / C_ECONST / C_EMASS);
+}
+
 struct FdtdDev {
-  int nx, fd_min_atoms, srcx_int, containssrc, dl_mode;     // dl_mode 0: constants + plasma frequency from ne; 1: per-cell array as is
+  int nx, fd_min_atoms, srcx_int, containssrc, dl_mode;     // dl_mode 0: constants + plasma frequency from ne; 1: per-cell array as is; 2: fitDL's tables
   double dt, dx, Nlambdax, Imp0, E0, t0, sigma_t_squared, DLc[5];
   double *E, *H, *J, *Jl, *P, *sig, *Jo, *Jlo, *DL;
+  const TricubDev *tab;                                     // five tables in device memory (dl_mode 2)
 };
 struct FdtdState {
   FdtdDev d{};
   double E0_init = 0, omega_laser = 0, t_SI = 0;
   int bw = 0, on = 0;
+  TricubDev *d_tab = nullptr;
+  TricubDev h_tab[5] = {};
+  std::vector<void *> tab_bufs;
 };
 
 static void imdgpu_fdtd_free(TtmState *t)
@@ -2349,6 +2480,8 @@ static void imdgpu_fdtd_free(TtmState *t)
   if (!t->fdtd) return;
   void *ptrs[] = {t->fdtd->d.E, t->fdtd->d.H, t->fdtd->d.J, t->fdtd->d.Jl, t->fdtd->d.P, t->fdtd->d.sig, t->fdtd->d.Jo, t->fdtd->d.Jlo, t->fdtd->d.DL};
   for (void *p : ptrs) if (p) (void) hipFree(p);
+  for (void *p : t->fdtd->tab_bufs) (void) hipFree(p);
+  if (t->fdtd->d_tab) (void) hipFree(t->fdtd->d_tab);
   delete t->fdtd;
   t->fdtd = nullptr; t->fdtd_on = 0;
 }
@@ -2435,6 +2568,10 @@ __global__ __launch_bounds__(MAXT) void k_ttm_fdtd_chain(Lat L, FdtdDev F, int n
       Te = T1[cell]; Tprev = T2[cell]; U = U1[cell]; Uprev = U2[cell]; xiv = xi[cell]; ce = Ce[cell]; kk = fd_k[cell]; g = fd_g[cell];
       Tl = md_temp[cell]; rho = dens[cell]; Zv = Zo[cell]; nev = neo[cell];
       if (F.dl_mode == 0 && c.active) c.DL[5] = sqrt(nev * C_ECHARGE * C_ECHARGE / C_ECONST / C_EMASS);      // fitDL, :2960
+      if (F.dl_mode == 2) {                       // the state the FILLMESH before the loop left (imd_ttm_3D.c:600)
+        for (int q = 0; q < 6; q++) c.DL[q] = F.DL[6 * i + q];
+        if (c.active) fit_dl(F.tab, Te, Tl, rho, nev, c.DL);
+      }
     }
     sN[i] = nat;
   }
@@ -2464,6 +2601,7 @@ __global__ __launch_bounds__(MAXT) void k_ttm_fdtd_chain(Lat L, FdtdDev F, int n
             Zv = o.Z; nev = o.ne; ce = o.Ce; kk = o.k; g = o.g;
             if (steps < 1) { U = eos_ee(ee, rho, Te * 11604.5) * 26.9815 * C_AMU * C_J2EV; Uprev = U; }
             if (F.dl_mode == 0) c.DL[5] = sqrt(nev * C_ECHARGE * C_ECHARGE / C_ECONST / C_EMASS);
+            else if (F.dl_mode == 2) fit_dl(F.tab, Te, Tl, rho, nev, c.DL);
           }
         }
         __syncthreads();
@@ -2473,7 +2611,7 @@ __global__ __launch_bounds__(MAXT) void k_ttm_fdtd_chain(Lat L, FdtdDev F, int n
   }
   if (have) {
     F.E[i] = c.E; F.H[i] = c.H; F.J[i] = c.J; F.Jl[i] = c.Jl; F.P[i] = c.P; F.Jo[i] = c.Jo; F.Jlo[i] = c.Jlo;
-    if (F.dl_mode == 0 && F.DL) for (int q = 0; q < 6; q++) F.DL[6 * i + q] = c.DL[q];
+    if (F.dl_mode != 1 && F.DL) for (int q = 0; q < 6; q++) F.DL[6 * i + q] = c.DL[q];
     if (WITH_TTM && inner) {
       source[cell] = c.src;
       if (c.active) { T1[cell] = Te; T2[cell] = Tprev; U1[cell] = U; U2[cell] = Uprev; xi[cell] = xiv; Ce[cell] = ce; fd_k[cell] = kk;
@@ -2552,7 +2690,7 @@ extern "C" int imdgpu_ttm_fdtd_set_dl(imdgpu_ctx *ctx, const double *DL)
 {
   NEED_TTM();
   if (!t->fdtd) return imdgpu_fail(ctx, "ttm_fdtd_set_dl: imdgpu_ttm_fdtd_init first");
-  t->fdtd->d.dl_mode = DL ? 1 : 0;
+  t->fdtd->d.dl_mode = DL ? 1 : (t->fdtd->d.tab ? 2 : 0);
   if (DL) HIPCHK(hipMemcpy(t->fdtd->d.DL, DL, 6 * (size_t) t->fdtd->d.nx * sizeof(double), hipMemcpyHostToDevice));
   return 0;
 }
@@ -2582,10 +2720,106 @@ extern "C" int imdgpu_ttm_fdtd_fields(imdgpu_ctx *ctx, int which, double *out)
   NEED_TTM();
   if (!t->fdtd) return imdgpu_fail(ctx, "ttm_fdtd_fields: imdgpu_ttm_fdtd_init first");
   const FdtdDev &F = t->fdtd->d;
-  double *src[] = {F.E, F.H, F.J, F.Jl, F.P, F.sig, F.Jo, F.Jlo};
-  if (which < 0 || which > 7) return imdgpu_fail(ctx, "ttm_fdtd_fields: which = 0..7");
+  double *src[] = {F.E, F.H, F.J, F.Jl, F.P, F.sig, F.Jo, F.Jlo, F.DL};
+  if (which < 0 || which > 8) return imdgpu_fail(ctx, "ttm_fdtd_fields: which = 0..8");
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  HIPCHK(hipMemcpy(out, src[which], F.nx * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(out, src[which], (which == 8 ? 6 : 1) * (size_t) F.nx * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// fitDL's five tables (DL1.txt .. DL5.txt as read_tricub_interp keeps them, imd_ttm_3D.c:1245-1249): from now on every
+// FILLMESH of the solver loop looks the cell's DL[0..4] up at (dens, lg Te, lg Ti).  tabs = NULL: back to the constants.
+extern "C" int imdgpu_ttm_fdtd_set_dl_tables(imdgpu_ctx *ctx, const imdgpu_tricub_table *tabs)
+{
+  NEED_TTM();
+  FdtdState *S = t->fdtd;
+  if (!S) return imdgpu_fail(ctx, "ttm_fdtd_set_dl_tables: imdgpu_ttm_fdtd_init first");
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  for (void *p : S->tab_bufs) (void) hipFree(p);
+  S->tab_bufs.clear();
+  if (!tabs) { S->d.dl_mode = 0; S->d.tab = nullptr; return 0; }
+  for (int q = 0; q < 5; q++) {
+    const imdgpu_tricub_table &h = tabs[q];
+    if (h.is < 1 || h.js < 1 || h.ks < 1 || !h.x || !h.y || !h.z || !h.f) return imdgpu_fail(ctx, "ttm_fdtd_set_dl_tables: empty table");
+    TricubDev &d = S->h_tab[q];
+    d.is = h.is; d.js = h.js; d.ks = h.ks;
+    d.xmin = h.range[0]; d.xmax = h.range[1]; d.ymin = h.range[2]; d.ymax = h.range[3]; d.zmin = h.range[4]; d.zmax = h.range[5];
+    d.dx = (d.xmax - d.xmin) / ((double) d.is);                  // read_tricub_interp, imd_interpol.c:1008-1010
+    d.dy = (d.ymax - d.ymin) / ((double) d.js);
+    d.dz = (d.zmax - d.zmin) / ((double) d.ks);
+    const size_t nn[4] = {(size_t) h.is, (size_t) h.js, (size_t) h.ks, (size_t) h.is * h.js * h.ks};
+    const double *hs[4] = {h.x, h.y, h.z, h.f};
+    const double **ds[4] = {&d.x, &d.y, &d.z, &d.f};
+    for (int a = 0; a < 4; a++) {
+      void *buf = nullptr;
+      HIPCHK(hipMalloc(&buf, nn[a] * sizeof(double)));
+      S->tab_bufs.push_back(buf);
+      HIPCHK(hipMemcpy(buf, hs[a], nn[a] * sizeof(double), hipMemcpyHostToDevice));
+      *ds[a] = (const double *) buf;
+    }
+  }
+  int same = 1;                                                  // one grid for all five quantities?
+  for (int q = 1; q < 5 && same; q++) {
+    const imdgpu_tricub_table &a = tabs[0], &b = tabs[q];
+    same = a.is == b.is && a.js == b.js && a.ks == b.ks && !memcmp(a.range, b.range, sizeof(a.range)) &&
+           !memcmp(a.x, b.x, a.is * sizeof(double)) && !memcmp(a.y, b.y, a.js * sizeof(double)) && !memcmp(a.z, b.z, a.ks * sizeof(double));
+  }
+  for (int q = 0; q < 5; q++) S->h_tab[q].same = same;
+  if (!S->d_tab) HIPCHK(hipMalloc((void **) &S->d_tab, 5 * sizeof(TricubDev)));
+  HIPCHK(hipMemcpy(S->d_tab, S->h_tab, 5 * sizeof(TricubDev), hipMemcpyHostToDevice));
+  S->d.tab = S->d_tab; S->d.dl_mode = 2;
+  return 0;
+}
+
+__global__ void k_tricub_lookup(const TricubDev *tab, int which, int n, const double *xyz, double *out)
+{
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n) out[q] = tricub_lookup(tab[which], xyz[3 * q], xyz[3 * q + 1], xyz[3 * q + 2]);
+}
+__global__ void k_fit_dl(const TricubDev *tab, int n, const double *temp, const double *md_temp, const double *dens, const double *ne,
+                         double *DL)
+{
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n) { double d[6]; fit_dl(tab, temp[q], md_temp[q], dens[q], ne[q], d); for (int a = 0; a < 6; a++) DL[6 * q + a] = d[a]; }
+}
+
+// the device's do_tricubinterp on table `which` (0..4) at n points (x, y, z triples), -1 outside the table like the reference
+extern "C" int imdgpu_ttm_fdtd_dl_lookup(imdgpu_ctx *ctx, int which, int n, const double *xyz, double *out)
+{
+  NEED_TTM();
+  if (!t->fdtd || t->fdtd->d.dl_mode != 2) return imdgpu_fail(ctx, "ttm_fdtd_dl_lookup: imdgpu_ttm_fdtd_set_dl_tables first");
+  if (which < 0 || which > 4) return imdgpu_fail(ctx, "ttm_fdtd_dl_lookup: table 0..4");
+  if (n <= 0) return 0;
+  double *d_in = nullptr, *d_out = nullptr;
+  HIPCHK(hipMalloc((void **) &d_in, 3 * (size_t) n * sizeof(double)));
+  HIPCHK(hipMalloc((void **) &d_out, (size_t) n * sizeof(double)));
+  HIPCHK(hipMemcpy(d_in, xyz, 3 * (size_t) n * sizeof(double), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_tricub_lookup, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, t->fdtd->d.tab, which, n, d_in, d_out);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpy(out, d_out, (size_t) n * sizeof(double), hipMemcpyDeviceToHost));
+  (void) hipFree(d_in); (void) hipFree(d_out);
+  return 0;
+}
+
+// the device's fitDL for n cells given (temp, md_temp, dens, ne): DL[6 n] out
+extern "C" int imdgpu_ttm_fdtd_fitdl(imdgpu_ctx *ctx, int n, const double *temp, const double *md_temp, const double *dens,
+                                     const double *ne, double *DL)
+{
+  NEED_TTM();
+  if (!t->fdtd || t->fdtd->d.dl_mode != 2) return imdgpu_fail(ctx, "ttm_fdtd_fitdl: imdgpu_ttm_fdtd_set_dl_tables first");
+  if (n <= 0) return 0;
+  double *d_in = nullptr, *d_out = nullptr;
+  HIPCHK(hipMalloc((void **) &d_in, 4 * (size_t) n * sizeof(double)));
+  HIPCHK(hipMalloc((void **) &d_out, 6 * (size_t) n * sizeof(double)));
+  const double *hs[4] = {temp, md_temp, dens, ne};
+  for (int a = 0; a < 4; a++) HIPCHK(hipMemcpy(d_in + (size_t) a * n, hs[a], (size_t) n * sizeof(double), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_fit_dl, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, t->fdtd->d.tab, n, d_in, d_in + n, d_in + 2 * (size_t) n,
+                     d_in + 3 * (size_t) n, d_out);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpy(DL, d_out, 6 * (size_t) n * sizeof(double), hipMemcpyDeviceToHost));
+  (void) hipFree(d_in); (void) hipFree(d_out);
   return 0;
 }
 

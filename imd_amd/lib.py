@@ -29,7 +29,8 @@ SYMBOLS = [
     "imdgpu_ttm_lattice_step", "imdgpu_ttm_mailbox_bytes", "imdgpu_ttm_mailbox_attach", "imdgpu_ttm_local_step",
     "imdgpu_host_alloc", "imdgpu_host_free",
     "imdgpu_ttm_fdtd_init", "imdgpu_ttm_fdtd_set_dl", "imdgpu_ttm_fdtd_substeps", "imdgpu_ttm_fdtd_fields",
-    "imdgpu_ttm_fdtd_get", "imdgpu_ttm_fdtd_set_time",
+    "imdgpu_ttm_fdtd_get", "imdgpu_ttm_fdtd_set_time", "imdgpu_ttm_fdtd_set_dl_tables", "imdgpu_ttm_fdtd_dl_lookup",
+    "imdgpu_ttm_fdtd_fitdl",
     "imdgpu_dist_unique_id", "imdgpu_dist_init_rccl", "imdgpu_dist_init_callback", "imdgpu_dist_set_plan",
     "imdgpu_dist_halo", "imdgpu_dist_set_ttm_blocks", "imdgpu_dist_md_step", "imdgpu_dist_allreduce_sum",
     "imdgpu_dist_rebuild", "imdgpu_dist_rebuild_count", "imdgpu_dist_step", "imdgpu_dist_calc_forces", "imdgpu_dist_plan_geometry",
@@ -97,6 +98,11 @@ class FdtdParamsC(C.Structure):
     """imdgpu_fdtd_params"""
     _fields_ = [("I0", C.c_double), ("lam", C.c_double), ("sigma_t", C.c_double), ("t_0", C.c_double), ("srcx", C.c_double),
                 ("bw", C.c_int), ("Sc", C.c_double), ("DL", C.c_double * 5)]
+
+
+class TricubTableC(C.Structure):
+    """imdgpu_tricub_table"""
+    _fields_ = [("is_", C.c_int), ("js", C.c_int), ("ks", C.c_int), ("range", C.c_double * 6)] + [(n, C.POINTER(C.c_double)) for n in "xyzf"]
 
 
 class TtmFieldsC(C.Structure):
@@ -184,6 +190,9 @@ def load():
     L.imdgpu_ttm_fdtd_fields.argtypes = [vp, C.c_int, dp]
     L.imdgpu_ttm_fdtd_get.argtypes = [vp, dp, dp, ip, dp]
     L.imdgpu_ttm_fdtd_set_time.argtypes = [vp, C.c_double]
+    L.imdgpu_ttm_fdtd_set_dl_tables.argtypes = [vp, C.POINTER(TricubTableC)]
+    L.imdgpu_ttm_fdtd_dl_lookup.argtypes = [vp, C.c_int, C.c_int, dp, dp]
+    L.imdgpu_ttm_fdtd_fitdl.argtypes = [vp, C.c_int, dp, dp, dp, dp, dp]
     L.imdgpu_dist_unique_id.argtypes = [C.c_char_p, C.c_int]
     L.imdgpu_dist_init_rccl.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.c_int]
     L.imdgpu_dist_init_callback.argtypes = [vp, C.c_int, C.c_int, vp, vp]

@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import lib as _lib
-from .lib import (TTM1D_DBL, TTM1D_GINT, TTM1D_INT, TTM_FIELDS, TTM_INT_FIELDS, FdtdParamsC, ImdGpuError, LaserParamsC, PotTableC,
+from .lib import (TTM1D_DBL, TTM1D_GINT, TTM1D_INT, TTM_FIELDS, TTM_INT_FIELDS, FdtdParamsC, ImdGpuError, LaserParamsC, PotTableC, TricubTableC,
                   Ttm1dFieldsC, Ttm1dParamsC, TtmFieldsC, TtmParamsC)
 
 
@@ -393,6 +393,39 @@ class GpuSystem:
     def fdtd_set_dl(self, DL):
         a = None if DL is None else np.ascontiguousarray(DL, dtype=np.float64)
         self._ck(self.L.imdgpu_ttm_fdtd_set_dl(self.h, None if a is None else _dp(a)))
+
+    def fdtd_set_dl_tables(self, tabs):
+        """fitDL's tables DL1..DL5 (imd_amd.tricub.TricubTable each, or paths of files in the reference's layout); None: constants"""
+        from . import tricub
+        if tabs is None:
+            self._ck(self.L.imdgpu_ttm_fdtd_set_dl_tables(self.h, None)); return
+        tabs = [tricub.read_table(t) if isinstance(t, str) else t for t in tabs]
+        if len(tabs) != 5:
+            raise ValueError("fitDL takes five tables (DL1 .. DL5)")
+        arr = (TricubTableC * 5)()
+        for a, t in zip(arr, tabs):
+            a.is_, a.js, a.ks = t.dims
+            a.range[:] = [float(v) for v in t.range]
+            a.x, a.y, a.z, a.f = _dp(t.x), _dp(t.y), _dp(t.z), _dp(t.f)
+        self._ck(self.L.imdgpu_ttm_fdtd_set_dl_tables(self.h, arr))
+
+    def fdtd_dl_lookup(self, which, xyz):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+        out = np.zeros(len(xyz))
+        self._ck(self.L.imdgpu_ttm_fdtd_dl_lookup(self.h, int(which), len(xyz), _dp(xyz), _dp(out)))
+        return out
+
+    def fdtd_fitdl(self, temp, md_temp, dens, ne):
+        a = [np.ascontiguousarray(v, dtype=np.float64) for v in (temp, md_temp, dens, ne)]
+        out = np.zeros((len(a[0]), 6))
+        self._ck(self.L.imdgpu_ttm_fdtd_fitdl(self.h, len(a[0]), _dp(a[0]), _dp(a[1]), _dp(a[2]), _dp(a[3]), _dp(out)))
+        return out
+
+    def fdtd_cell_dl(self):
+        """DL[nx, 6] of the row's cells as the last solver loop left them"""
+        out = np.zeros((self.fd_dim[0], 6))
+        self._ck(self.L.imdgpu_ttm_fdtd_fields(self.h, 8, _dp(out)))
+        return out
 
     def do_fdtd(self, t_SI, nsub, tau_FDTD, laser_timefun):
         """nsub x do_fdtd(t) (imd_fdtd.c:128-306), t advancing by tau_FDTD"""

@@ -271,10 +271,22 @@ typedef struct imdgpu_fdtd_params { double I0, lambda, sigma_t, t_0, srcx; int b
 int imdgpu_ttm_fdtd_init(imdgpu_ctx *ctx, const imdgpu_fdtd_params *p);
 /* per-cell parameters DL[6] for every cell of the row (ghost cells included) instead of the constants; NULL: back */
 int imdgpu_ttm_fdtd_set_dl(imdgpu_ctx *ctx, const double *DL);
+/* [fitDL, imd_ttm_3D.c:2919-2968 (imd_ttm.c:2867-2916); read_tricub_interp / do_tricubinterp, imd_interpol.c:959-1084,
+ * :740-957] the five tables DL1.txt .. DL5.txt over (rho [kg/m^3], lg Te [eV], lg Ti [eV]) as read_tricub_interp keeps
+ * them: is x js x ks nodes, range = xmin xmax ymin ymax zmin zmax (line 2 of the file), node coordinates x[is], y[js],
+ * z[ks], values f[(i*js + j)*ks + k].  With tables set, every do_FILLMESH of the solver loop takes the cell's
+ * DL[0] = eps_inf and DL[1..4] (table value / hbar[eV s]) from them at (dens, lg max(Te, 0.0259), lg max(Ti, 0.0259)),
+ * clamped like fitDL; a look-up outside a table yields -1 as in the reference.  tabs = NULL: back to the constants. */
+typedef struct imdgpu_tricub_table { int is, js, ks; double range[6]; const double *x, *y, *z, *f; } imdgpu_tricub_table;
+int imdgpu_ttm_fdtd_set_dl_tables(imdgpu_ctx *ctx, const imdgpu_tricub_table *tabs /* [5] */);
+/* the device's do_tricubinterp on table `which` (0..4) at n points (x, y, z triples); its fitDL for n cells -> DL[6 n] */
+int imdgpu_ttm_fdtd_dl_lookup(imdgpu_ctx *ctx, int which, int n, const double *xyz, double *out);
+int imdgpu_ttm_fdtd_fitdl(imdgpu_ctx *ctx, int n, const double *temp, const double *md_temp, const double *dens, const double *ne,
+                          double *DL);
 /* [do_fdtd(t), imd_fdtd.c:128-306] nsub times from t_SI on (t += tau_FDTD after each) with the envelope value
  * laser_timefun held fixed as calc_ttm does within an MD step (:98); the dissipated power goes to the lattice's source */
 int imdgpu_ttm_fdtd_substeps(imdgpu_ctx *ctx, double t_SI, int nsub, double tau_FDTD, double laser_timefun);
-/* which: 0 Ezx, 1 Hy, 2 Jzx, 3 Jlzx, 4 Pzx, 5 sigmay, 6/7 Jzx/Jlzx of the sub-step before; nx values */
+/* which: 0 Ezx, 1 Hy, 2 Jzx, 3 Jlzx, 4 Pzx, 5 sigmay, 6/7 Jzx/Jlzx of the sub-step before: nx values; 8: the cells' DL[6], 6 nx values */
 int imdgpu_ttm_fdtd_fields(imdgpu_ctx *ctx, int which, double *out);
 int imdgpu_ttm_fdtd_get(imdgpu_ctx *ctx, double *dt_FDTD, double *E0, int *srcx_int, double *t_SI);
 int imdgpu_ttm_fdtd_set_time(imdgpu_ctx *ctx, double t_SI);

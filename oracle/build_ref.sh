@@ -9,7 +9,7 @@
 # oracle/ref_probe.c, a read-only observation probe attached with ld --wrap.
 #
 # usage: oracle/build_ref.sh [target ...]
-#   targets: eam_nve_nbl  nve_nbl  eam_nve  nve  mpi_eam_nve_nbl  mpi_eam_ttm3d_nbl  mpi_eam_ttm3d_laser_nbl  mpi_eam_ttm1d_nbl  fdtd_probe  dropin
+#   targets: eam_nve_nbl  nve_nbl  eam_nve  nve  mpi_eam_nve_nbl  mpi_eam_ttm3d_nbl  mpi_eam_ttm3d_laser_nbl  mpi_eam_ttm1d_nbl  fdtd_probe  tricub_probe  dropin
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 REF="${IMD_REFERENCE:-/root/reference}"
@@ -59,7 +59,7 @@ build() {
   echo "built $OUT/imd_$name"
 }
 
-TARGETS="${*:-eam_nve_nbl nve_nbl eam_nve mpi_eam_nve_nbl mpi_eam_ttm3d_nbl mpi_eam_ttm3d_laser_nbl mpi_eam_ttm1d_nbl fdtd_probe dropin}"
+TARGETS="${*:-eam_nve_nbl nve_nbl eam_nve mpi_eam_nve_nbl mpi_eam_ttm3d_nbl mpi_eam_ttm3d_laser_nbl mpi_eam_ttm1d_nbl fdtd_probe tricub_probe dropin}"
 for t in $TARGETS; do
   case "$t" in
     eam_nve_nbl) build "$t" "-DNBL -DEAM2 -DNVE" "$COMMON $NBLSRC" "$CC" "" ;;
@@ -107,6 +107,19 @@ for t in $TARGETS; do
       $CC -o "$OUT/ref_probe_fdtd" "$obj/ref_probe_fdtd.o" "$obj/imd_fdtd.o" "$obj/imd_misc.o" \
           -L$MPIINC/lib -Wl,-rpath,$MPIINC/lib -lmpi -lm
       echo "built $OUT/ref_probe_fdtd" ;;
+    tricub_probe)
+      # the reference's tricubic table look-up behind fitDL at function level (see oracle/ref_probe_tricub.c):
+      # imd_interpol.c + imd_misc.c (error()) from the reference and the libnn.a it ships, the harness as MAIN
+      MPIINC="${MPI_HOME:-/opt/conda}"
+      if [ ! -f "$MPIINC/include/mpi.h" ]; then echo "no MPI at $MPIINC, skipping $t" >&2; continue; fi
+      obj="$OUT/obj_tricub_probe"; mkdir -p "$obj"
+      FD="-DMPI -DNBL -DEAM2 -DTTM -DTMM -DEOSMODE=1 -DFDTD"
+      $CC -I$MPIINC/include $BASEFLAGS $FD -c "$REF/imd_interpol.c" -o "$obj/imd_interpol.o"
+      $CC -I$MPIINC/include $BASEFLAGS $FD -c "$REF/imd_misc.c" -o "$obj/imd_misc.o"
+      $CC -I$MPIINC/include $BASEFLAGS $FD -c "$HERE/ref_probe_tricub.c" -o "$obj/ref_probe_tricub.o"
+      $CC -o "$OUT/ref_probe_tricub" "$obj/ref_probe_tricub.o" "$obj/imd_interpol.o" "$obj/imd_misc.o" \
+          "$REF/nn_interpol/libnn.a" -L$MPIINC/lib -Wl,-rpath,$MPIINC/lib -lmpi -lm
+      echo "built $OUT/ref_probe_tricub" ;;
     dropin) ;;    # built below
     *) echo "unknown target $t" >&2; exit 1 ;;
   esac

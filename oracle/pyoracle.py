@@ -692,3 +692,45 @@ class OracleTTM1D:
     def close(self):
         if self._p is not None:
             self.L.orc_ttm1d_free(self._p); self.L.orc_ttm_free(self._holder); self._p = None
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# tricubic table look-up behind fitDL (oracle/tricub_oracle.c)
+class OracleTricub:
+    """do_tricubinterp on one table (imd_interpol.c:740-957); table = imd_amd.tricub.TricubTable or the same fields"""
+    def __init__(self, rng, x, y, z, f):
+        L = lib()
+        L.orc_tricub_new.restype = C.c_void_p
+        L.orc_tricub_new.argtypes = [C.c_int] * 3 + [C.c_void_p] * 5
+        L.orc_tricub_free.argtypes = [C.c_void_p]
+        L.orc_tricub_eval_n.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        f = np.ascontiguousarray(f, dtype=np.float64)
+        a = [np.ascontiguousarray(v, dtype=np.float64) for v in (rng, x, y, z)]
+        self.ymax, self.zmax = float(a[0][3]), float(a[0][5])
+        self._p = L.orc_tricub_new(f.shape[0], f.shape[1], f.shape[2], *[v.ctypes.data for v in a], f.ctypes.data)
+
+    def eval(self, xyz):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+        out = np.empty(len(xyz))
+        lib().orc_tricub_eval_n(self._p, len(xyz), xyz.ctypes.data, out.ctypes.data)
+        return out
+
+    def close(self):
+        if self._p:
+            lib().orc_tricub_free(self._p)
+            self._p = None
+
+
+def oracle_fitdl(tabs, temp, md_temp, dens, ne):
+    """fitDL (imd_ttm_3D.c:2919-2968) for arrays of cells; tabs = five OracleTricub (DL1..DL5) -> (DL[n, 6], status[n])"""
+    L = lib()
+    L.orc_fitdl.restype = C.c_int
+    L.orc_fitdl.argtypes = [C.c_void_p] + [C.c_double] * 4 + [C.c_void_p]
+    ptrs = (C.c_void_p * 5)(*[t._p for t in tabs])
+    temp, md_temp, dens, ne = (np.atleast_1d(np.asarray(v, dtype=np.float64)) for v in (temp, md_temp, dens, ne))
+    DL = np.empty((len(temp), 6)); st = np.empty(len(temp), dtype=np.int32)
+    row = (C.c_double * 6)()
+    for q in range(len(temp)):
+        st[q] = L.orc_fitdl(ptrs, temp[q], md_temp[q], dens[q], ne[q], row)
+        DL[q] = row[:]
+    return DL, st

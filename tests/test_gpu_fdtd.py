@@ -10,7 +10,7 @@ stable, so the differences stay at rounding level over the 2 600 sub-steps of th
 import numpy as np
 import pytest
 
-from imd_amd import lattice, potential, ttm as ttm_mod
+from imd_amd import lattice, potential, tricub, ttm as ttm_mod
 from imd_amd.system import GpuSystem
 from oracle import pyoracle as po
 from tests import golden_util as gu
@@ -81,9 +81,11 @@ def test_solver_vs_reference_fields():
     f.close(); s.close()
 
 
-def test_solver_loop_with_diffusion_vs_oracle():
+@pytest.mark.parametrize("dl", ["constants", "tables"])
+def test_solver_loop_with_diffusion_vs_oracle(dl):
     """one MD step of calc_ttm's solver loop on a slab: update_fd .. FILLMESH as usual, then 437 x [do_fdtd; do_DIFF;
-    do_FILLMESH] in ONE launch; the oracle runs the same functions one after the other on the host"""
+    do_FILLMESH] in ONE launch; the oracle runs the same functions one after the other on the host.  dl = tables: every
+    FILLMESH takes the cells' Drude-Lorentz parameters from fitDL's tricubic tables (imd_ttm_3D.c:600, :2919-2968)"""
     hx, nxc = 7.0, 120
     # an Al slab of 60 cells behind 40 cells of vacuum (the source sits in the vacuum), 20 cells of vacuum behind it
     nb = (int(round(60 * hx / 4.05)), 5, 5)
@@ -111,6 +113,12 @@ def test_solver_loop_with_diffusion_vs_oracle():
     ot.set_eos(1, len(ee["x"]), len(ee["y"]), ee["x"][0], ee["x"][-1], ee["y"][0], ee["y"][-1], ee["z"])
     of = po.OracleFDTD(nxc + 2, hx, par["I0"], par["lam"], par["sigma_t"], par["t_0"], par["srcx"], par["bw"], par["Sc"])
     ot.t.omega_laser = of.f.omega_laser                    # init_fdtd sets the global the wide-range model reads
+    otabs = None
+    if dl == "tables":
+        tabs = tricub.synthetic_dl_tables(1500.0, 4000.0)
+        s.fdtd_set_dl_tables(tabs)
+        otabs = [po.OracleTricub(t_.range, t_.x, t_.y, t_.z, t_.f) for t_ in tabs]
+    dl_seen = []
     AMU, ECH, ECONST, EMASS = 1.6605390402e-27, 1.60217662e-19, 8.841941282883075e-12, 9.10938356e-31
     for step in (0, 1):                                     # step 0 re-initialises U in FILLMESH; step 1 is the regular path
         ot.update_fd(step); ot.cell_activation(); ot.fillmesh(step); ot.fill_ghosts()
@@ -122,8 +130,15 @@ def test_solver_loop_with_diffusion_vs_oracle():
         t = of_t
         for sub in range(nsub):
             act = of.natoms >= 5
-            of.DL[act, :5] = GpuSystem.AL_DRUDE_LORENTZ
-            of.DL[act, 5] = np.sqrt(ot.ne[:, 1, 1][act] * ECH * ECH / ECONST / EMASS)
+            if otabs is None:
+                of.DL[act, :5] = GpuSystem.AL_DRUDE_LORENTZ
+                of.DL[act, 5] = np.sqrt(ot.ne[:, 1, 1][act] * ECH * ECH / ECONST / EMASS)
+            else:                                               # fitDL at the end of the FILLMESH just done
+                d6, st = po.oracle_fitdl(otabs, ot.temp[:, 1, 1][act], ot.md_temp[:, 1, 1][act], ot.dens[:, 1, 1][act], ot.ne[:, 1, 1][act])
+                assert (st == 0).all()
+                of.DL[act] = d6
+                if sub % 100 == 0:
+                    dl_seen.append(d6[:, 1].copy())
             if of.f.laser_active:
                 of.step(t)
                 ot.source[:, 1, 1] = of.source
@@ -143,9 +158,20 @@ def test_solver_loop_with_diffusion_vs_oracle():
             assert _rel(lat[k][row], getattr(ot, k)[row]) < 1e-9, (step, k)
         assert abs(s.get_eabs() - ot.t.eabs) <= 1e-9 * abs(ot.t.eabs)
         assert abs(s.fdtd_info()["t_SI"] - t) < 1e-9 * t
+        if otabs is not None:
+            # the cells' parameters after the last FILLMESH of the loop: table nodes, so equal or one node apart
+            act = of.natoms >= 5
+            d6, _ = po.oracle_fitdl(otabs, ot.temp[:, 1, 1][act], ot.md_temp[:, 1, 1][act], ot.dens[:, 1, 1][act], ot.ne[:, 1, 1][act])
+            got = s.fdtd_cell_dl()[act]
+            assert (got[:, :5] == d6[:, :5]).mean() > 0.98 and _rel(got[:, 5], d6[:, 5]) < 1e-9
         if step == 0:
             # the electrons did heat up where the field got in, and only there
             assert lat["temp"][row].max() > 1.05 * ot.md_temp[row].max()
+    if otabs is not None:
+        # the look-up did move with the electrons heating up: the Drude damping of some cell changed during the pulse
+        assert max(np.abs(a_ - dl_seen[0]).max() for a_ in dl_seen[1:]) > 0.0
+        for t_ in otabs:
+            t_.close()
     of.close(); ot.close(); o.close(); s.close()
 
 
