@@ -62,9 +62,13 @@ def parse():
     ap.add_argument("--cpu-all-timeout", type=float, default=240.0, help="give the all-core CPU sample up after this many seconds")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal: host-staged halos)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks on cuda:0")
-    ap.add_argument("--ttm-decomposed", action="store_true",
-                    help="several ranks: one TTM lattice block per rank, faces through the shared-memory mailbox (default: the\n"
-                         "lattice is replicated, one all-gather per step; see DESIGN.md 5)")
+    ap.add_argument("--ttm-lattice", choices=["auto", "decomposed", "replicated"], default=None,
+                    help="several ranks: `decomposed` = one TTM lattice block per rank, the faces as ghost records written into the\n"
+                         "neighbours' device memory from inside the sub-step kernel (host mailbox if that cannot be set up);\n"
+                         "`replicated` = every rank diffuses the whole lattice, one all-gather per step; `auto` (default with\n"
+                         "more than one rank) = both are built and timed for a few steps before the warm-up, the faster one that\n"
+                         "works on every rank runs the benchmark (DESIGN.md 5).  One rank: replicated = the plain lattice.")
+    ap.add_argument("--ttm-decomposed", action="store_true", help="= --ttm-lattice decomposed")
     ap.add_argument("--init-dist", action="store_true",
                     help="rehearsal with --force-distributed: a ONE-rank torch.distributed process group on --backend, so that the\n"
                          "host layer's nccl code path (object broadcast of the RCCL ids, all-reduces on device tensors) executes")
@@ -73,7 +77,10 @@ def parse():
     return ap.parse_args()
 
 
-def build_system(args, rank, world, device):
+TRIAL_WARM, TRIAL_STEPS = 6, 24          # `--ttm-lattice auto`: steps of each candidate before / inside its timing
+
+
+def build_system(args, rank, world, device, decomposed=False):
     """One rank's share: its own block of args.box FCC unit cells (weak scaling); the ranks form the most
     cubic grid (8 -> 2x2x2: six faces on six different xGMI links)."""
     from imd_amd import lattice, potential
@@ -120,7 +127,7 @@ def build_system(args, rank, world, device):
     sysm = GpuSystem(box, pbc, cell_dim, 1, cellsz, nbl_margin, 0.1, device=device, global_cell_dim=gdim,
                      cpu_dim=cpu_dim, my_coord=coord, count_ttm_neighbours=ttm,
                      external_halo=args.force_distributed,
-                     ttm_decomposed=ttm and (world > 1 or args.force_distributed) and args.ttm_decomposed)
+                     ttm_decomposed=ttm and (world > 1 or args.force_distributed) and decomposed)
     sysm.upload_tables(pair, rho, emb)
     if ttm and adv_on(args):
         sysm.set_option("ttm_adv", 1)            # calc_ttm's own sequence: update_fd, do_ADV(1.0), activation, ... (:57-60)
@@ -422,17 +429,65 @@ def main():
             dist.init_process_group(args.backend, rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    sysm, md, natoms, gdim, cpu_dim = build_system(args, rank, world, local)
-    do_step = md.md_step if md is not None else sysm.md_step
-
-    def barrier():
-        sysm.synchronize()
+    def barrier(s=None):
+        (s or sysm).synchronize()
         torch.cuda.synchronize()
         if dist.is_initialized():
             dist.barrier()
 
-    step = 0
-    for _ in range(args.warmup):
+    def agree_max(v):
+        if not dist.is_initialized():
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    mode = "decomposed" if args.ttm_decomposed else args.ttm_lattice
+    if mode is None:
+        mode = "auto" if (world > 1 and not args.no_ttm) else "replicated"
+    step, lattice_trial = 0, None
+    if mode == "auto" and world > 1 and not args.no_ttm:
+        # both lattice modes for a few steps on the real workload; every rank takes part in both and in the verdict.  A mode
+        # that fails anywhere (the library reports set-up and time-out failures on all ranks alike) is out.
+        lattice_trial, cands = {}, {}
+        for m in ("decomposed", "replicated"):
+            ms, err, built = 1e30, None, None
+            try:
+                built = build_system(args, rank, world, local, decomposed=(m == "decomposed"))
+                for st in range(TRIAL_WARM):
+                    built[1].md_step(st)
+                barrier(built[0]); t0 = time.perf_counter()
+                for st in range(TRIAL_WARM, TRIAL_WARM + TRIAL_STEPS):
+                    built[1].md_step(st)
+                barrier(built[0])
+                ms = (time.perf_counter() - t0) / TRIAL_STEPS * 1e3
+            except Exception as e:          # noqa: BLE001 -- whatever it was, this mode is out
+                err = "%s: %s" % (type(e).__name__, str(e)[:300])
+            ms = agree_max(ms)
+            if ms >= 1e29:
+                if built is not None:
+                    try:
+                        built[0].close()
+                    except Exception:       # noqa: BLE001
+                        pass
+                lattice_trial[m] = {"ok": False, "error": err or "failed on another rank"}
+            else:
+                remote = built[0].get_info("ttm_remote") if m == "decomposed" else 0
+                lattice_trial[m] = {"ok": True, "ms_per_step": ms, "steps": TRIAL_STEPS,
+                                    "faces": ("ghost records in the neighbours' device memory" if remote else "host mailbox") if m == "decomposed" else "all-gather"}
+                cands[m] = (ms, built)
+        if not cands:
+            raise SystemExit("bench.py: neither lattice mode ran: %s" % json.dumps(lattice_trial))
+        mode = min(cands, key=lambda k: cands[k][0])
+        for k, (_, b) in cands.items():
+            if k != mode:
+                b[0].close()
+        sysm, md, natoms, gdim, cpu_dim = cands[mode][1]
+        step = TRIAL_WARM + TRIAL_STEPS
+    else:
+        sysm, md, natoms, gdim, cpu_dim = build_system(args, rank, world, local, decomposed=(mode == "decomposed"))
+    do_step = md.md_step if md is not None else sysm.md_step
+    while step < args.warmup:
         do_step(step); step += 1
     barrier()
     sysm.profile(not args.no_kernel_timing); sysm.profile_reset()
@@ -482,6 +537,11 @@ def main():
             return {"bound": "hbm", "kernel": label, "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
                     "traffic": tr, "traffic_source": src, "algorithmic_bytes_per_launch": byts, "avg_launch_ms": avg,
                     "launches": n, "kernel_rev": krev}
+        lattice_note = ""
+        if md is not None and not args.no_ttm:
+            lattice_note = (", TTM lattice decomposed (one block per rank, faces: %s)" %
+                            ("ghost records in the neighbours' device memory" if sysm.get_info("ttm_remote") else "host mailbox")
+                            if mode == "decomposed" else ", TTM lattice replicated (one all-gather per step)")
         r1, r3 = price("pass1"), price("pass3")
         dom, other = (r3, r1) if prof["pass3"][1] >= prof["pass1"][1] else (r1, r3)
         n_nbl, ms_nbl = prof["nblist"]
@@ -507,14 +567,16 @@ def main():
                        "tile": [sysm.get_info("tile_x"), sysm.get_info("tile_y"), sysm.get_info("tile_z")],
                        "tile_info": {k: sysm.get_info(k) for k in ("ntiles", "tile_cap", "slot_cap", "max_halo",
                                                                    "tile_threads", "lds_pass1", "lds_pass3", "W")},
-                       "parallelism": ("%dx%dx%d ranks, 1 rank/GPU, direct 26-neighbour ghost-cell halo, native step (%s)"
-                                       % (tuple(cpu_dim) + (md.ops.transport,))) if md is not None else "single GPU"},
+                       "parallelism": ("%dx%dx%d ranks, 1 rank/GPU, direct 26-neighbour ghost-cell halo, native step (%s)%s"
+                                       % (tuple(cpu_dim) + (md.ops.transport, lattice_note))) if md is not None else "single GPU"},
             "roofline": dom, "roofline_other": other,
             "kernel_ms_per_step": {k: v[1] / args.steps for k, v in prof.items() if v[0]},
             "rebuild_ms": {"rebuilds": rebuilds, "make_nblist_ms_each": ms_nbl / max(n_nbl, 1), "fix_cells_ms_each": ms_fix / max(n_fix, 1),
                            "amortised_ms_per_step": (ms_nbl + ms_fix) / args.steps},
             "energy": {"epot_per_atom": sums["tot_pot_energy"] / natoms, "ekin_per_atom": sums["tot_kin_energy"] / natoms},
         }
+        if lattice_trial is not None:
+            out["lattice_trial"] = dict(lattice_trial, chosen=mode)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
             out["cpu_baseline"]["gpu_over_cpu_atom_steps"] = out["atom_steps_per_s"] / out["cpu_baseline"]["value"]

@@ -913,6 +913,11 @@ extern "C" int imdgpu_ttm_remote_init(imdgpu_ctx *ctx, int coarse, void **dev_pt
 extern "C" int imdgpu_ttm_remote_ipc_handle(imdgpu_ctx *ctx, void *handle64, int *fine);
 extern "C" int imdgpu_ttm_remote_open(imdgpu_ctx *ctx, const void *handle64, void **dev_ptr);
 extern "C" int imdgpu_ttm_remote_attach(imdgpu_ctx *ctx, void *const peer[6]);
+extern "C" int imdgpu_ttm_remote_detach(imdgpu_ctx *ctx);
+extern "C" int imdgpu_ttm_remote_ping(imdgpu_ctx *ctx, int phase, unsigned word, int *bad);
+// Collective and failure-safe: a rank on which a step fails keeps taking part in the exchanges and every rank returns the
+// same verdict (an error on ALL ranks if it failed on one), so that the host can fall back together -- e.g. to the
+// replicated lattice -- instead of one rank leaving the others inside a collective.
 extern "C" int imdgpu_dist_ttm_remote_setup(imdgpu_ctx *ctx)
 {
   NEED_DIST();
@@ -924,9 +929,12 @@ extern "C" int imdgpu_dist_ttm_remote_setup(imdgpu_ctx *ctx)
   char bus[16] = {0};
   (void) hipDeviceGetPCIBusId(bus, 16, ctx->device);
   long long pid = (long long) getpid();
+  int bad = 0;
+  std::string why;
+  auto failed = [&](const char *what) { if (!bad) { bad = 1; why = std::string(what) + ": " + ctx->err; } };
   // round 1: who lives where
   memcpy(&mine[0], &pid, 8); memcpy(&mine[4], bus, 16);
-  if (dist_allgather_host(ctx, D, mine.data(), W, all.data())) return 1;
+  if (dist_allgather_host(ctx, D, mine.data(), W, all.data())) return 1;          // the transport itself: fails everywhere
   bool all_same_gpu = true, other_process = false;
   for (int d = 0; d < 3; d++)
     for (int side = 0; side < 2; side++) {
@@ -938,33 +946,56 @@ extern "C" int imdgpu_dist_ttm_remote_setup(imdgpu_ctx *ctx)
     }
   void *ptr = nullptr; size_t bytes = 0;
   const bool force_coarse = getenv("IMDGPU_TTM_REMOTE_COARSE") != nullptr;
-  if (imdgpu_ttm_remote_init(ctx, force_coarse ? 1 : 0, &ptr, &bytes)) return 1;
   unsigned char handle[64] = {0};
   int fine = 0;
-  if (other_process && imdgpu_ttm_remote_ipc_handle(ctx, handle, &fine)) {
-    // no IPC handle for fine-grained memory on this driver: plain device memory is enough when every neighbour shares my GPU
-    if (!all_same_gpu) return 1;
-    if (imdgpu_ttm_remote_init(ctx, 1, &ptr, &bytes) || imdgpu_ttm_remote_ipc_handle(ctx, handle, &fine)) return 1;
+  if (getenv("IMDGPU_TTM_REMOTE_FAIL") && atoi(getenv("IMDGPU_TTM_REMOTE_FAIL")) == D->rank + 1) {   // test hook: this rank cannot set up
+    imdgpu_fail(ctx, "IMDGPU_TTM_REMOTE_FAIL"); failed("test hook");
   }
-  memcpy(&mine[1], &ptr, 8); mine[2] = fine; memcpy(&mine[6], handle, 64);
+  if (!bad && imdgpu_ttm_remote_init(ctx, force_coarse ? 1 : 0, &ptr, &bytes)) failed("buffer");
+  if (!bad && other_process && imdgpu_ttm_remote_ipc_handle(ctx, handle, &fine)) {
+    // no IPC handle for fine-grained memory on this driver: plain device memory is enough when every neighbour shares my GPU
+    if (!all_same_gpu) failed("IPC handle");
+    else if (imdgpu_ttm_remote_init(ctx, 1, &ptr, &bytes) || imdgpu_ttm_remote_ipc_handle(ctx, handle, &fine)) failed("IPC handle (coarse)");
+  }
+  memcpy(&mine[1], &ptr, 8); mine[2] = fine; mine[3] = bad; memcpy(&mine[6], handle, 64);
   if (dist_allgather_host(ctx, D, mine.data(), W, all.data())) return 1;
+  for (int r = 0; r < N; r++) if (all[(size_t) W * r + 3] != 0.0 && !bad) { bad = 1; why = "rank " + std::to_string(r) + " could not provide its buffer"; }
   void *peer[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   std::map<int, void *> opened;
-  for (int d = 0; d < 3; d++)
-    for (int side = 0; side < 2; side++) {                 // face 2d: towards +d (my high neighbour), 2d+1: towards -d
+  for (int d = 0; d < 3 && !bad; d++)
+    for (int side = 0; side < 2 && !bad; side++) {         // face 2d: towards +d (my high neighbour), 2d+1: towards -d
       const int nb = side ? P->lo[d] : P->hi[d], q = 2 * d + side;
       if (nb < 0 || nb == D->rank) continue;
       auto it = opened.find(nb);
       if (it != opened.end()) { peer[q] = it->second; continue; }
       long long p2; void *rp; memcpy(&p2, &all[(size_t) W * nb], 8); memcpy(&rp, &all[(size_t) W * nb + 1], 8);
       void *mapped = rp;
-      if (p2 != pid && imdgpu_ttm_remote_open(ctx, &all[(size_t) W * nb + 6], &mapped)) return 1;
+      if (p2 != pid && imdgpu_ttm_remote_open(ctx, &all[(size_t) W * nb + 6], &mapped)) { failed("opening a neighbour's IPC handle"); break; }
       opened[nb] = mapped; peer[q] = mapped;
     }
-  if (imdgpu_ttm_remote_attach(ctx, peer)) return 1;
-  // nobody starts writing before every rank has zeroed and attached its buffer
-  int one = 1;
-  return dist_max_int(ctx, D, &one);
+  if (!bad && imdgpu_ttm_remote_attach(ctx, peer)) failed("attach");
+  // nobody starts writing before every rank has zeroed and attached its buffer -- and everybody learns whether all could
+  int anybad = bad;
+  if (dist_max_int(ctx, D, &anybad)) return 1;
+  // ping: every rank stores a word into the spare granule of each neighbour's buffer from a kernel (system-scope store, as
+  // the sub-step kernel does), all ranks meet, every rank reads what its neighbours wrote with the kernel's own polling load
+  if (!anybad) {
+    const unsigned word = 0x5eed0000u + (unsigned) P->nrebuild;
+    if (imdgpu_ttm_remote_ping(ctx, 0, word, nullptr)) failed("ping store");
+    int one = bad;
+    if (dist_max_int(ctx, D, &one)) return 1;
+    int pbad = 0;
+    if (!one && imdgpu_ttm_remote_ping(ctx, 1, word, &pbad)) failed("ping load");
+    if (pbad && !bad) { bad = 1; why = "a neighbour's store into my ghost records did not arrive (peer access / coherence)"; }
+    anybad = bad || one;
+    if (dist_max_int(ctx, D, &anybad)) return 1;
+  }
+  if (anybad) {
+    (void) imdgpu_ttm_remote_detach(ctx);
+    return imdgpu_fail(ctx, "dist_ttm_remote_setup: ghost records in the neighbours' device memory are not available (%s)",
+                       bad ? why.c_str() : "failed on another rank");
+  }
+  return 0;
 }
 
 // The whole rebuild of one rank (collective: every rank calls it).  After it the list is valid and imdgpu_dist_md_step runs.
@@ -995,7 +1026,12 @@ extern "C" int imdgpu_dist_rebuild(imdgpu_ctx *ctx)
             P->ms[0], P->ms[1], P->ms[2], P->ms[3], P->ms[4]);
   }
   if (ctx->ttm && ctx->ttm_decomposed && P->nrebuild == 0 && D->nranks > 1 && !(getenv("IMDGPU_TTM_REMOTE") && atoi(getenv("IMDGPU_TTM_REMOTE")) == 0)) {
-    if (imdgpu_dist_ttm_remote_setup(ctx)) return 1;                  // decomposed lattice: faces through ghost records in the neighbours' memory
+    // decomposed lattice: faces through ghost records in the neighbours' memory; if that cannot be set up (the verdict is the
+    // same on every rank) the host mailbox keeps carrying them -- slower, not wrong
+    if (imdgpu_dist_ttm_remote_setup(ctx)) {
+      if (ctx->err.find("dist_ttm_remote_setup") == std::string::npos) return 1;          // the transport itself failed
+      if (D->rank == 0) fprintf(stderr, "imdgpu: %s; the decomposed lattice stays on the host mailbox\n", ctx->err.c_str());
+    }
   }
   if (ctx->ttm && !ctx->ttm_decomposed && !D->d_ttm_offs) {          // replicated lattice: where every rank's update_fd block goes
     int ld[3];

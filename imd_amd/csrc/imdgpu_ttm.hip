@@ -2164,7 +2164,7 @@ extern "C" int imdgpu_ttm_remote_init(imdgpu_ctx *ctx, int coarse, void **dev_pt
   NEED_TTM();
   if (!ctx->ttm_decomposed) return imdgpu_fail(ctx, "ttm_remote_init: set option ttm_decomposed before ttm_init");
   xrec_layout(t);
-  const size_t n = (size_t) 2 * t->xcells * 4 + t->xcells;
+  const size_t n = (size_t) 2 * t->xcells * 4 + t->xcells + 8;          // + one spare granule per face (imdgpu_ttm_remote_ping)
   if (t->d_xrec) { (void) hipFree(t->d_xrec); t->d_xrec = nullptr; }
   t->xrec_ready = false;
   // fine-grained device memory: stores of other GPUs become visible to this GPU's polling loads while the kernels run
@@ -2212,6 +2212,48 @@ extern "C" int imdgpu_ttm_remote_attach(imdgpu_ctx *ctx, void *const peer[6])
   for (int q = 0; q < 6; q++) { t->peer[q] = (unsigned long long *) peer[q]; if (peer[q]) t->xremote |= 1 << q; }
   t->xrec_ready = true;
   t->persist = -1; t->persist_ok = 0;           // decide again (the shape test is the same, the kernel variant is not)
+  return 0;
+}
+
+extern "C" int imdgpu_ttm_remote_detach(imdgpu_ctx *ctx)
+{
+  NEED_TTM();
+  for (int q = 0; q < 6; q++) t->peer[q] = nullptr;
+  t->xremote = 0; t->xrec_ready = false;
+  t->persist = -1; t->persist_ok = 0;
+  return 0;
+}
+// phase 0: store `word` (tagged with the face) into the spare granule of every neighbour's buffer, with the store the sub-step
+// kernel uses; phase 1 (after all ranks met): read my own spare granules with its polling load; *bad = faces whose word is
+// missing.  Run once at set-up: a peer mapping that cannot be written, or stores that never become visible, show up here and
+// not as a time-out in the middle of a run.
+__global__ void k_xrec_ping(int phase, unsigned word, unsigned mask, size_t spare, unsigned long long *mine, unsigned long long *p0,
+                            unsigned long long *p1, unsigned long long *p2, unsigned long long *p3, unsigned long long *p4,
+                            unsigned long long *p5, int *bad)
+{
+  unsigned long long *peer[6] = {p0, p1, p2, p3, p4, p5};
+  const int q = threadIdx.x;
+  if (q >= 6 || !(mask >> q & 1u)) return;
+  if (phase == 0) __hip_atomic_store(peer[q] + spare + (q ^ 1), ((unsigned long long) word << 32) | (unsigned) (q ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  else if (xrec_load(mine + spare + q) != (((unsigned long long) word << 32) | (unsigned) q)) atomicOr(bad, 1 << q);
+}
+extern "C" int imdgpu_ttm_remote_ping(imdgpu_ctx *ctx, int phase, unsigned word, int *bad)
+{
+  NEED_TTM();
+  if (!t->d_xrec || !t->xrec_ready) return imdgpu_fail(ctx, "ttm_remote_ping: imdgpu_ttm_remote_attach first");
+  int *d_bad = nullptr;
+  HIPCHK(hipMalloc((void **) &d_bad, sizeof(int)));
+  HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream));
+  const size_t spare = (size_t) 2 * t->xcells * 4 + t->xcells;
+  hipLaunchKernelGGL(k_xrec_ping, dim3(1), dim3(64), 0, ctx->stream, phase, word, (unsigned) t->xremote, spare, t->d_xrec, t->peer[0], t->peer[1],
+                     t->peer[2], t->peer[3], t->peer[4], t->peer[5], d_bad);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  int h = 0;
+  if (e == hipSuccess) e = hipMemcpy(&h, d_bad, sizeof(int), hipMemcpyDeviceToHost);
+  (void) hipFree(d_bad);
+  if (e != hipSuccess) return imdgpu_fail(ctx, "ttm_remote_ping: %s", hipGetErrorString(e));
+  if (bad) *bad = h;
   return 0;
 }
 

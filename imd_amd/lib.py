@@ -35,7 +35,7 @@ SYMBOLS = [
     "imdgpu_dist_halo", "imdgpu_dist_set_ttm_blocks", "imdgpu_dist_md_step", "imdgpu_dist_allreduce_sum",
     "imdgpu_dist_rebuild", "imdgpu_dist_rebuild_count", "imdgpu_dist_step", "imdgpu_dist_calc_forces", "imdgpu_dist_plan_geometry",
     "imdgpu_ttm1d_init", "imdgpu_ttm1d_calc", "imdgpu_ttm1d_stage", "imdgpu_ttm1d_move_atoms", "imdgpu_ttm1d_download", "imdgpu_ttm1d_upload",
-    "imdgpu_ttm_remote_init", "imdgpu_ttm_remote_ipc_handle", "imdgpu_ttm_remote_open", "imdgpu_ttm_remote_attach", "imdgpu_dist_ttm_remote_setup",
+    "imdgpu_ttm_remote_init", "imdgpu_ttm_remote_ipc_handle", "imdgpu_ttm_remote_open", "imdgpu_ttm_remote_attach", "imdgpu_dist_ttm_remote_setup", "imdgpu_ttm_remote_detach", "imdgpu_ttm_remote_ping",
     "imdgpu_local_group_create", "imdgpu_local_group_destroy", "imdgpu_local_group_barrier", "imdgpu_local_group_shared", "imdgpu_dist_init_local",
 ]
 
@@ -212,6 +212,8 @@ def load():
     L.imdgpu_ttm_remote_open.argtypes = [vp, vp, C.POINTER(vp)]
     L.imdgpu_ttm_remote_attach.argtypes = [vp, C.POINTER(vp)]
     L.imdgpu_dist_ttm_remote_setup.argtypes = [vp]
+    L.imdgpu_ttm_remote_detach.argtypes = [vp]
+    L.imdgpu_ttm_remote_ping.argtypes = [vp, C.c_int, C.c_uint, ip]
     L.imdgpu_do_forces.argtypes = [vp, C.c_int, dp, ip, C.c_int, dp, ip, dp, C.c_int, dp, dp, dp, dp, dp, dp, ip, ip, dp, dp, ip]
     L.imdgpu_do_forces_eam2.argtypes = [vp, C.c_int, dp, ip, dp, C.c_int, dp, ip, dp, dp, C.c_int, dp, dp, dp, ip]
     L.imdgpu_do_embedding_energy.argtypes = [vp, C.c_int, dp, ip, dp, dp, dp]

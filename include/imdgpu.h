@@ -410,6 +410,12 @@ int imdgpu_ttm_remote_ipc_handle(imdgpu_ctx *ctx, void *handle64, int *fine_grai
 int imdgpu_ttm_remote_open(imdgpu_ctx *ctx, const void *handle64, void **dev_ptr);
 /* peer[q]: the buffer of the rank beyond face q (2d: +, 2d+1: -) as this process addresses it, NULL = none */
 int imdgpu_ttm_remote_attach(imdgpu_ctx *ctx, void *const peer[6]);
+int imdgpu_ttm_remote_detach(imdgpu_ctx *ctx);
+/* set-up self-test: phase 0 stores `word` into a spare granule of every neighbour's buffer (the sub-step kernel's store),
+ * phase 1 -- after all ranks met -- reads the own spare granules with its polling load; *bad = bit mask of faces without it */
+int imdgpu_ttm_remote_ping(imdgpu_ctx *ctx, int phase, unsigned word, int *bad);
+/* collective and failure-safe: if any rank cannot provide, open or reach a buffer, EVERY rank returns the error (and stays on
+ * the mailbox); imdgpu_dist_rebuild then prints the reason and goes on with the mailbox */
 int imdgpu_dist_ttm_remote_setup(imdgpu_ctx *ctx);
 /* [calc_ttm] for this rank's block: update_fd, activation, FILLMESH, face publication, the sub-steps */
 int imdgpu_ttm_local_step(imdgpu_ctx *ctx, int steps);

@@ -59,6 +59,15 @@ def test_bench_spawns_its_ranks_and_refuses_a_mismatch():
     d = _one_json_line(subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600))
     assert d["n_gpus"] == 2 and d["atoms_total"] == 2 * d["config"]["atoms_per_gpu"] and "cpu_baseline" not in d
     assert "2x1x1 ranks" in d["config"]["parallelism"] and "native step" in d["config"]["parallelism"]
+    # several ranks: both lattice modes are tried before the warm-up and the faster one that works everywhere runs the benchmark
+    lt = d["lattice_trial"]
+    assert lt["decomposed"]["ok"] and lt["replicated"]["ok"] and lt["chosen"] in ("decomposed", "replicated")
+    assert lt["decomposed"]["faces"] == "ghost records in the neighbours' device memory"
+    assert ("TTM lattice " + lt["chosen"]) in d["config"]["parallelism"]
+    # one rank cannot set its ghost-record buffer up: EVERY rank learns it and the decomposed lattice stays on the host mailbox
+    d2 = _one_json_line(subprocess.run(cmd + ["--ttm-lattice", "decomposed"], cwd=ROOT, env=dict(env, IMDGPU_TTM_REMOTE_FAIL="2"),
+                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600))
+    assert "faces: host mailbox" in d2["config"]["parallelism"] and d2["value"] > 0 and "lattice_trial" not in d2
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"], cwd=ROOT,
                          env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                          text=True, timeout=300)

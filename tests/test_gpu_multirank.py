@@ -145,6 +145,7 @@ def test_ranks_ttm_decomposed_lattice(cpu_dim):
     # ranks in different PROCESSES: the ghost-record buffers are opened through hipIpc handles; steps 1 and 2 ran in the
     # persistent kernel with the faces written straight into the neighbours' buffers (step 0: the mailbox)
     assert all(r[6][0] >= 1 and r[6][1] == 2 and r[6][2] >= 1 for r in res), [r[6] for r in res]
+    print("ttm_remote (2 = fine-grained memory behind the IPC handle, 1 = coarse), persist mode, runs:", [r[6] for r in res])
     ids = np.concatenate([r[1]["nummer"] for r in res]); pos = np.concatenate([r[1]["ort"] for r in res])
     o, go = np.argsort(ids), np.argsort(G["s3_nummer"])
     assert np.abs(pos[o] - G["s3_ort"][go]).max() < 1e-9
