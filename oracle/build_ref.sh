@@ -9,7 +9,7 @@
 # oracle/ref_probe.c, a read-only observation probe attached with ld --wrap.
 #
 # usage: oracle/build_ref.sh [target ...]
-#   targets: eam_nve_nbl  nve_nbl  eam_nve  nve  mpi_eam_nve_nbl  mpi_eam_ttm3d_nbl  mpi_eam_ttm3d_laser_nbl  mpi_eam_ttm1d_nbl  fdtd_probe  tricub_probe  dropin
+#   targets: eam_nve_nbl  nve_nbl  eam_nve  nve  mpi_eam_nve_nbl  mpi_eam_ttm3d_nbl  mpi_eam_ttm3d_laser_nbl  mpi_eam_ttm1d_nbl  mpi_eam_ttm1d_tmm_nbl  fdtd_probe  tricub_probe  dropin
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 REF="${IMD_REFERENCE:-/root/reference}"
@@ -48,7 +48,8 @@ build() {
   if [[ "$defs" == *-DTTM1D* ]]; then
     $cc $BASEFLAGS $defs -c "$HERE/ref_probe_ttm1d.c" -o "$obj/ref_probe_ttm1d.o"
     extra="$obj/ref_probe_ttm1d.o"
-    wrap="$wrap -Wl,--wrap=calc_ttm -Wl,--wrap=tmm_init -Wl,--wrap=do_tmm"
+    if [[ "$srcs" == *imd_tmm.c* ]]; then wrap="$wrap -Wl,--wrap=calc_ttm"          # the reference's own tmm_init / do_tmm
+    else wrap="$wrap -Wl,--wrap=calc_ttm -Wl,--wrap=tmm_init -Wl,--wrap=do_tmm"; fi
   elif [[ "$defs" == *-DTTM* ]]; then
     $cc $BASEFLAGS $defs -c "$HERE/ref_probe_ttm.c" -o "$obj/ref_probe_ttm.o"
     extra="$obj/ref_probe_ttm.o"
@@ -59,7 +60,7 @@ build() {
   echo "built $OUT/imd_$name"
 }
 
-TARGETS="${*:-eam_nve_nbl nve_nbl eam_nve mpi_eam_nve_nbl mpi_eam_ttm3d_nbl mpi_eam_ttm3d_laser_nbl mpi_eam_ttm1d_nbl fdtd_probe tricub_probe dropin}"
+TARGETS="${*:-eam_nve_nbl nve_nbl eam_nve mpi_eam_nve_nbl mpi_eam_ttm3d_nbl mpi_eam_ttm3d_laser_nbl mpi_eam_ttm1d_nbl mpi_eam_ttm1d_tmm_nbl fdtd_probe tricub_probe dropin}"
 for t in $TARGETS; do
   case "$t" in
     eam_nve_nbl) build "$t" "-DNBL -DEAM2 -DNVE" "$COMMON $NBLSRC" "$CC" "" ;;
@@ -86,6 +87,15 @@ for t in $TARGETS; do
       if [ ! -f "$MPIINC/include/mpi.h" ]; then echo "no MPI at $MPIINC, skipping $t" >&2; continue; fi
       build "$t" "-DMPI -DNBL -DEAM2 -DTTM -DTMM -DTTM1D" \
             "$COMMON $NBLSRC imd_mpi_util.c imd_ttm.c imd_interpol.c fminbnd3.c" \
+            "$CC -I$MPIINC/include" "-L$MPIINC/lib -Wl,-rpath,$MPIINC/lib -lmpi" ;;
+    mpi_eam_ttm1d_tmm_nbl)
+      # the same with the reference's own transfer-matrix Helmholtz solver as laser source (imd_tmm.c: tmm_init, do_tmm,
+      # tmm_get_epsilon): the configuration the reference's Makefile target imd_mpi_eam_ttm_tmm_nbl describes.  Its input
+      # files (../alu_eps_bb.dat, ../K12.dat) are not in the tree: the fixtures write synthetic ones (tests/golden/make_golden.py)
+      MPIINC="${MPI_HOME:-/opt/conda}"
+      if [ ! -f "$MPIINC/include/mpi.h" ]; then echo "no MPI at $MPIINC, skipping $t" >&2; continue; fi
+      build "$t" "-DMPI -DNBL -DEAM2 -DTTM -DTMM -DTTM1D" \
+            "$COMMON $NBLSRC imd_mpi_util.c imd_ttm.c imd_interpol.c fminbnd3.c imd_tmm.c" \
             "$CC -I$MPIINC/include" "-L$MPIINC/lib -Wl,-rpath,$MPIINC/lib -lmpi" ;;
     mpi_eam_ttm3d_laser_nbl)
       # the same with -DLASER (imd_laser.c: Beer-Lambert source laser_rescale_ttm, init_laser, get_surface)

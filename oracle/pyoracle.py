@@ -601,7 +601,14 @@ class _Ttm1d(C.Structure):
                [(k, C.POINTER(C.c_int)) for k in ("fluxl", "fluxr", "totneigh", "natomsglobal")] + \
                [("vcom", C.POINTER(C.c_double) * 3), ("xiarr", C.POINTER(C.c_double)),
                 ("vtemp", C.POINTER(C.c_double) * 2), ("vmd", C.POINTER(C.c_double) * 2)] + \
-               [(k, C.POINTER(C.c_double)) for k in ("vk", "vg", "vCe", "vZ", "vne")] + [("eos", C.c_void_p)]
+               [(k, C.POINTER(C.c_double)) for k in ("vk", "vg", "vCe", "vZ", "vne")] + [("eos", C.c_void_p)] + \
+               [(k, C.c_int) for k in ("tmm_on", "laser_active", "ecut", "eps_bb_rows", "K12_rows")] + \
+               [(k, C.c_double) for k in ("I0", "lam", "t0", "sigma_t", "t1", "sigma_t1", "abs_threshold", "laser_threshold", "k0", "tmm_time",
+                                          "I_t", "refl", "trans", "absorbed", "eabs")] + \
+               [(k, C.POINTER(C.c_double)) for k in ("eps_re", "eps_im", "qabs", "eps_bb", "K12")] + \
+               [("tmm_active", C.POINTER(C.c_int)), ("km", C.c_void_p), ("phase_nx", C.c_int), ("phase_ny", C.c_int)] + \
+               [(k, C.c_double) for k in ("phase_xmin", "phase_xmax", "phase_ymin", "phase_ymax")] + \
+               [("phase_z", C.POINTER(C.c_double)), ("phase_diag", C.c_void_p)]
 
 
 class OracleTTM1D:
@@ -671,6 +678,27 @@ class OracleTTM1D:
     def update_fd(self, steps, ort, sorte, impuls, masse, numneighs):
         o, s, p, m, nn = self._atoms(ort, sorte, impuls, masse, numneighs)
         self.L.orc_ttm1d_update_fd(self._p, int(steps), len(o), _dp(o), _ip(s), _dp(p), _dp(m), _ip(nn), _ip(self.fdi))
+
+    def tmm_init(self, I0, lam, sigma_t, t0, eps_bb, K12, phase, sigma_t1=0.0, t1=0.0, abs_threshold=20.0, laser_threshold=1e-5):
+        """tmm_init (imd_tmm.c:98-191); eps_bb [rows, 3], K12 [rows, 2], phase = dict(x, y, z) like the EOS tables"""
+        L = self.L
+        dp = C.POINTER(C.c_double)
+        L.orc_ttm1d_tmm_init.argtypes = [C.POINTER(_Ttm1d)] + [C.c_double] * 8 + [C.c_int, dp, C.c_int, dp, C.c_int, C.c_int, dp, dp]
+        L.orc_ttm1d_do_tmm.argtypes = [C.POINTER(_Ttm1d), C.c_int]
+        eb = np.ascontiguousarray(eps_bb, np.float64); k12 = np.ascontiguousarray(K12, np.float64)
+        pz = np.ascontiguousarray(phase["z"], np.float64).reshape(-1)
+        rng = np.array([phase["x"][0], phase["x"][-1], phase["y"][0], phase["y"][-1]], np.float64)
+        L.orc_ttm1d_tmm_init(self._p, float(I0), float(lam), float(sigma_t), float(t0), float(sigma_t1), float(t1), float(abs_threshold),
+                             float(laser_threshold), len(eb), _dp(eb), len(k12), _dp(k12), len(phase["x"]), len(phase["y"]), _dp(rng), _dp(pz))
+        aa = np.ctypeslib.as_array
+        for k in ("eps_re", "eps_im", "qabs"):
+            setattr(self, k, aa(getattr(self.t, k), (self.nx,)))
+        self.tmm_active = aa(self.t.tmm_active, (self.nx,))
+
+    def do_tmm(self, steps):
+        rc = self.L.orc_ttm1d_do_tmm(self._p, int(steps))
+        if rc:
+            raise RuntimeError("Sample is too short for TMM")
 
     def adv(self, tau, steps): self.L.orc_ttm1d_adv(self._p, float(tau), int(steps))
     def cell_activation(self): self.L.orc_ttm1d_cell_activation(self._p)

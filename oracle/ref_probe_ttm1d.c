@@ -6,7 +6,9 @@
  * build of the real reference (oracle/build_ref.sh mpi_eam_ttm1d_nbl: -DTTM -DTMM -DTTM1D with imd_ttm.c) with
  * ld --wrap=calc_ttm, like ref_probe_ttm.c for the 3D file.  What is left out of the sequence is do_tmm, the transfer-
  * matrix Helmholtz solver for the laser field (imd_tmm.c; its input files alu_eps_bb.dat / K12.dat are not part of the
- * tree): tmm_init / do_tmm are answered with "no laser", so node.source stays 0.  Everything else is the reference's code:
+ * tree): in the build mpi_eam_ttm1d_nbl tmm_init / do_tmm are answered with "no laser", so node.source stays 0; in the
+ * build mpi_eam_ttm1d_tmm_nbl imd_tmm.c is linked and, with IMD_PROBE_TMM set, do_tmm runs at the top of every sub-step as
+ * in calc_ttm (:113) on synthetic input files, its arrays dumped to tmm.<rank>.<step>.bin.  Everything else is the reference's code:
  * update_fd, do_ADV (IMD_PROBE_ADV; needs two ranks, do_COMMFLUX has no one-rank branch), do_cell_activation, do_FILLMESH,
  * ttm_fill_ghost_layers, CFL_maxdt, do_DIFF with the virtual lattice, the xi all-gather and the EOS update of U that
  * calc_ttm itself does after the loop (:110-133, restated here because it is not a function).
@@ -62,9 +64,28 @@ static void dump_stage(const char *tag)
   wd((double) last_active_cell_global); wd((double) cur_vlattice_proc); wd((double) diff_substeps); wd(max_dt_ttm);
 }
 
+/* do_tmm's state after a call: what rank 0 solved (eps, active cells, Qabs over the global row), my cells' source, scalars */
+static FILE *mf = NULL;
+static void dump_tmm(int sub)
+{
+  int i;
+  double v;
+  if (!mf) return;
+  fwrite(&sub, sizeof(int), 1, mf);
+  for (i = 0; i < global_fd_dim.x; i++) { v = tmm_eps_real_arr_global[i]; fwrite(&v, 8, 1, mf); }
+  for (i = 0; i < global_fd_dim.x; i++) { v = tmm_eps_imag_arr_global[i]; fwrite(&v, 8, 1, mf); }
+  for (i = 0; i < global_fd_dim.x; i++) { v = (double) tmm_active_cell_global[i]; fwrite(&v, 8, 1, mf); }
+  for (i = 0; i < global_fd_dim.x; i++) { v = tmm_Qabs[i]; fwrite(&v, 8, 1, mf); }
+  for (i = 0; i < local_fd_dim.x; i++) { v = l1[i].source; fwrite(&v, 8, 1, mf); }
+  v = I_t; fwrite(&v, 8, 1, mf); v = tmm_time; fwrite(&v, 8, 1, mf); v = tmm_refl; fwrite(&v, 8, 1, mf);
+  v = tmm_trans; fwrite(&v, 8, 1, mf); v = tmm_abs; fwrite(&v, 8, 1, mf); v = (double) laser_active; fwrite(&v, 8, 1, mf);
+  v = Eabs_local; fwrite(&v, 8, 1, mf);
+}
+
 void __wrap_calc_ttm(void)
 {
   int i, dumping = want(steps);
+  const int with_tmm = getenv("IMD_PROBE_TMM") != NULL;
   double tau_DIFF;
   if (dumping) {
     char fn[1024];
@@ -87,7 +108,22 @@ void __wrap_calc_ttm(void)
   diff_substeps = MAX(fd_n_timesteps, (int) (timestep / max_dt_ttm));                 /* imd_ttm.c:98-99 */
   tau_DIFF = timestep / ((double) diff_substeps);
   if (dumping) dump_stage("cfl");
+  if (dumping && with_tmm) {
+    char fn[1024];
+    const char *dir = getenv("IMD_PROBE_DIR");
+    double hd[8];
+    sprintf(fn, "%s/tmm.%d.%d.bin", dir ? dir : ".", myid, steps);
+    mf = fopen(fn, "wb");
+    fwrite("IMDTMM1P", 1, 8, mf);
+    hd[0] = global_fd_dim.x; hd[1] = local_fd_dim.x; hd[2] = diff_substeps; hd[3] = k0; hd[4] = omega_laser; hd[5] = tmm_time;
+    hd[6] = fd_h.x; hd[7] = tmm_absorption_threshold;
+    fwrite(hd, 8, 8, mf);
+  }
   for (i = 0; i < diff_substeps; i++) {
+    if (with_tmm) {
+      do_tmm(tau_DIFF);                                                                  /* imd_ttm.c:113 */
+      if (dumping && (i < 2 || i == diff_substeps - 1)) dump_tmm(i);
+    }
     tmm_time += tau_DIFF * 10.18 * 1.0e-15;
     do_DIFF(tau_DIFF);
     if (dumping && i == 0) dump_stage("diff_only1");
@@ -103,6 +139,7 @@ void __wrap_calc_ttm(void)
       l2[i].U = l1[i].U;
       tot_elec_energy_local += l1[i].U * ((double) l1[i].natoms);
     }
+  if (mf) { int end = -1; fwrite(&end, sizeof(int), 1, mf); fclose(mf); mf = NULL; }
   if (dumping) {
     dump_stage("substeps_done");
     fwrite("ENDTT1DP", 1, 8, tf);

@@ -13,10 +13,11 @@
  * owns the last active cell takes the virtual lattice's first cell as its +x neighbour (:1535-1540; `nranks` says how the
  * reference was cut).  Not reproduced (undefined or layout-dependent, cannot occur in the fixtures): reads of natomsglobal[-1] /
  * [nx] when the sample touches the box ends (:441,452, 1232-1235); freshly activated cells AT a rank boundary see a ghost
- * temperature that update_fd has just zeroed (:245-246).  Left out: do_tmm (TMM Helmholtz solver: input files not in the tree),
+ * temperature that update_fd has just zeroed (:245-246).  do_tmm (imd_tmm.c) is at the end of this file.  Left out:
  * COLRAD, ELECPRESS, BALLISTIC, FEG EOS mode (EOSMODE 0).
  */
 #include "ttm_oracle.h"
+#include <complex.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -36,6 +37,13 @@ typedef struct {
   /* virtual lattice (:1013-1024) */
   double *vtemp[2], *vmd[2], *vk, *vg, *vCe, *vZ, *vne;
   orc_ttm *eos;                         /* holder of the two EOS tables */
+  /* transfer-matrix laser source (imd_tmm.c), see the end of this file */
+  int tmm_on, laser_active, ecut, eps_bb_rows, K12_rows;
+  double I0, lambda, t0, sigma_t, t1, sigma_t1, abs_threshold, laser_threshold, k0, tmm_time, I_t, refl, trans, absorbed, eabs;
+  double *eps_re, *eps_im, *qabs, *eps_bb, *K12;
+  int *tmm_active;
+  double complex *km;
+  orc_eos phase;
 } orc_ttm1d;
 
 static void *za(size_t n, size_t s) { void *p = calloc(n ? n : 1, s); if (!p) abort(); return p; }
@@ -71,6 +79,7 @@ void orc_ttm1d_free(orc_ttm1d *t)
   for (q = 0; q < (int) (sizeof p / sizeof p[0]); q++) free(p[q]);
   for (q = 0; q < 2; q++) { free(t->temp[q]); free(t->U[q]); free(t->vtemp[q]); free(t->vmd[q]); }
   for (q = 0; q < 3; q++) free(t->vcom[q]);
+  if (t->tmm_on) { free(t->eps_re); free(t->eps_im); free(t->qabs); free(t->tmm_active); free(t->km); free(t->eps_bb); free(t->K12); free(t->phase.z); }
   free(t);
 }
 static int active(const orc_ttm1d *t, int c) { return t->natoms[c] >= t->fd_min_atoms && t->dens[c] > RHOMIN; }          /* e.g. :662 */
@@ -182,6 +191,7 @@ void orc_ttm1d_cell_activation(orc_ttm1d *t)
 void orc_ttm1d_fillmesh(orc_ttm1d *t, int steps)
 {
   const int nx = t->nx, c0 = t->cur;
+  const double om = t->laser_active ? t->omega_laser : 0.0;       /* bMax (:2207-2213): omega_las only while the laser is active */
   int g, i;
   for (g = 0; g < nx; g++) {
     const int c = g + 1;
@@ -191,8 +201,8 @@ void orc_ttm1d_fillmesh(orc_ttm1d *t, int steps)
       t->Z[c] = orc_mean_charge(TeK, t->dens[c], t->ac, t->aw);
       t->ne[c] = t->Z[c] * t->dens[c] / (t->aw * AMU);
       { double z = orc_eos_cve(t->eos, t->dens[c], TeK); t->Ce[c] = z; }
-      t->fd_k[c] = orc_get_kappa(t->temp[c0][c], t->md_temp[c], t->ne[c], t->Z[c], t->omega_laser);
-      t->fd_g[c] = orc_get_gamma(t->temp[c0][c], t->md_temp[c], t->ne[c], t->Z[c], t->omega_laser);
+      t->fd_k[c] = orc_get_kappa(t->temp[c0][c], t->md_temp[c], t->ne[c], t->Z[c], om);
+      t->fd_g[c] = orc_get_gamma(t->temp[c0][c], t->md_temp[c], t->ne[c], t->Z[c], om);
       if (steps < 1) t->U[0][c] = t->U[1][c] = orc_eos_ee(t->eos, t->dens[c], TeK) * 26.9815 * AMU * J2EV;      /* :760-764 */
     } else { t->fd_k[c] = t->fd_g[c] = t->Z[c] = t->ne[c] = t->Ce[c] = 0.0; t->temp[c0][c] = 0.0; }          /* :806-814 */
   }
@@ -200,9 +210,9 @@ void orc_ttm1d_fillmesh(orc_ttm1d *t, int steps)
     const double Te = t->vtemp[t->vcur][i], Ti = t->vmd[t->vcur][i];
     t->vZ[i] = orc_mean_charge(Te * 11604.5, t->vlatdens, t->ac, t->aw);
     t->vne[i] = t->vZ[i] * t->vlatdens / (t->aw * AMU);
-    t->vk[i] = orc_get_kappa(Te, Ti, t->vne[i], t->vZ[i], t->omega_laser);
+    t->vk[i] = orc_get_kappa(Te, Ti, t->vne[i], t->vZ[i], om);
     t->vCe[i] = orc_eos_cve(t->eos, t->vlatdens, Te * 11604.5);
-    t->vg[i] = orc_get_gamma(Te, Ti, t->vne[i], t->vZ[i], t->omega_laser);
+    t->vg[i] = orc_get_gamma(Te, Ti, t->vne[i], t->vZ[i], om);
   }
 }
 
@@ -237,6 +247,7 @@ void orc_ttm1d_diff(orc_ttm1d *t, double tau)
     int xmin, xmax;
     double xmaxTe, xminTe, xmaxk, xmink, Ce;
     if (g > t->last_active) continue;
+    if (t->laser_active) t->eabs += t->source[c] * t->vol * tau;                           /* :1515-1518 */
     if (t->natoms[c] < t->fd_min_atoms || t->dens[c] < RHOMIN) continue;
     xmin = active_ge(t, c - 1) ? c - 1 : c;
     xmax = active_ge(t, c + 1) ? c + 1 : c;
@@ -269,7 +280,8 @@ void orc_ttm1d_diff(orc_ttm1d *t, double tau)
   t->cur ^= 1; t->vcur ^= 1;                                                               /* :1654-1662 */
 }
 
-/* calc_ttm (:75-155) without do_tmm; returns the number of sub-steps */
+int orc_ttm1d_do_tmm(orc_ttm1d *t, int steps);
+/* calc_ttm (:75-155); returns the number of sub-steps */
 int orc_ttm1d_calc(orc_ttm1d *t, int steps, double timestep, int n, const double *ort, const int *sorte, const double *impuls,
                    const double *masse, const int *numneighs, int *fdi)
 {
@@ -284,7 +296,11 @@ int orc_ttm1d_calc(orc_ttm1d *t, int steps, double timestep, int n, const double
   t->diff_substeps = (int) (timestep / t->max_dt_ttm);                                    /* :98-99 */
   if (t->fd_n_timesteps > t->diff_substeps) t->diff_substeps = t->fd_n_timesteps;
   tau = timestep / ((double) t->diff_substeps);
-  for (i = 0; i < t->diff_substeps; i++) { orc_ttm1d_diff(t, tau); orc_ttm1d_fillmesh(t, steps); orc_ttm1d_fill_ghosts(t); }
+  for (i = 0; i < t->diff_substeps; i++) {
+    if (t->tmm_on) orc_ttm1d_do_tmm(t, steps);                                             /* :113-117 */
+    t->tmm_time += tau * 10.18 * 1.0e-15;
+    orc_ttm1d_diff(t, tau); orc_ttm1d_fillmesh(t, steps); orc_ttm1d_fill_ghosts(t);
+  }
   for (g = 1; g <= t->nx; g++)                                                             /* :119-133 */
     if (t->natoms[g] >= t->fd_min_atoms && t->dens[g] >= RHOMIN)
       t->U[0][g] = t->U[1][g] = orc_eos_ee(t->eos, t->dens[g], t->temp[t->cur][g] * 11604.5) * 26.9815 * AMU * J2EV;
@@ -308,4 +324,171 @@ double orc_ttm1d_move_atoms(const orc_ttm1d *t, double timestep, int n, double *
     for (d = 0; d < 3; d++) ort[3 * a + d] += tmp * impuls[3 * a + d];
   }
   return ekin;
+}
+
+
+/* ---- the transfer-matrix laser source of the 1D model: imd_tmm.c (tmm_init :98-191, do_tmm :193-455, tmm_get_epsilon
+ * :501-586, tmm_K1 / tmm_K2 :662-695, Runge5 / EE :36-96) -----------------------------------------------------------------
+ * Pinned against the reference's own functions by tests/golden/ttm1d_tmm_slab.npz (oracle/_ref/imd_mpi_eam_ttm1d_tmm_nbl on
+ * two ranks with synthetic alu_eps_bb.dat / K12.dat / EOS_phase_from_r_ti.txt).  Complex arithmetic is C99's, compiled by the
+ * same compiler as the reference (multiplication inline, division through libgcc's __divdc3), so the restatement can be
+ * bit-exact.  Reproduced as the source has it: `(int) nu * 30 - 1` in tmm_K1/K2 truncates nu BEFORE the product; tmm_Qabs keeps
+ * entries of cells beyond the current absorption depth from earlier calls; nothing happens before step 2. */
+void orc_ttm1d_tmm_init(orc_ttm1d *t, double I0, double lambda, double sigma_t, double t0, double sigma_t1, double t1,
+                        double abs_threshold, double laser_threshold, int eps_bb_rows, const double *eps_bb, int K12_rows,
+                        const double *K12, int pnx, int pny, const double *prange, const double *pz)
+{
+  const int nx = t->nx;
+  t->tmm_on = 1; t->I0 = I0; t->lambda = lambda; t->sigma_t = sigma_t; t->t0 = t0; t->sigma_t1 = sigma_t1; t->t1 = t1;
+  t->abs_threshold = abs_threshold; t->laser_threshold = laser_threshold;
+  t->eps_re = za(nx, 8); t->eps_im = za(nx, 8); t->qabs = za(nx, 8); t->tmm_active = za(nx, sizeof(int)); t->km = za(nx, sizeof(double complex));
+  t->eps_bb_rows = eps_bb_rows; t->eps_bb = za(3 * (size_t) eps_bb_rows, 8); memcpy(t->eps_bb, eps_bb, 24 * (size_t) eps_bb_rows);
+  t->K12_rows = K12_rows; t->K12 = za(2 * (size_t) K12_rows, 8); memcpy(t->K12, K12, 16 * (size_t) K12_rows);
+  t->phase.nx = pnx; t->phase.ny = pny; t->phase.xmin = prange[0]; t->phase.xmax = prange[1]; t->phase.ymin = prange[2]; t->phase.ymax = prange[3];
+  t->phase.z = za((size_t) pnx * pny, 8); memcpy(t->phase.z, pz, 8 * (size_t) pnx * pny); t->phase.diag = NULL;
+  t->omega_laser = 2.0 * M_PI * (3.0e8 / lambda);                                         /* :152-153 (c0 = 3e8, globals.h:499) */
+  t->k0 = 2.0 * M_PI / lambda; t->k0 /= 1e10;                                              /* :154-155 */
+  t->tmm_time = 0.0; t->laser_active = 0;
+}
+
+static double tmm_K(const orc_ttm1d *t, int col, double nu)
+{
+  if (nu < 1.0 / 30.0) return 1;
+  if (nu < 50) {
+    int i = (int) nu * 30 - 1;
+    if (i < 0) i = 0;
+    if (i > 1498) i = 1498;
+    return t->K12[2 * i + col] + (30 * nu - i - 1) * (t->K12[2 * (i + 1) + col] - t->K12[2 * i + col]);
+  }
+  return col == 0 ? 315.0 / 8.0 / (nu * nu) - 675675.0 / 64.0 / (nu * nu * nu * nu) : 6.0 / (nu * nu) - 720.0 / (nu * nu * nu * nu);
+}
+
+static void tmm_get_epsilon(const orc_ttm1d *t, double Te, double Ti, double Z, double Ne, double *re, double *img)
+{
+  const double LIGHTSPEED = 2.998e8, AMU_ = 1.660539040200000e-27, A4p = 0.2;            /* globals.h:325 */
+  const double complex un = 1, im = I;
+  double omega_las, Ncr, Ni, TF, nu_met, nu_max, nu_pl, ksi, phase;
+  double complex ebb_l, ebb_r, epsilon_bb, epsilon_met, epsilon_pl, epsilon_wr;
+  int il = 0, ir = 0, id;
+  Te *= 11604.52500617; Ti *= 11604.52500617;
+  omega_las = (2.0 * M_PI * LIGHTSPEED / t->lambda);
+  Ni = Ne / Z;
+  for (id = 0; t->lambda * 1e6 > t->eps_bb[3 * id]; id++) { il = id; ir = id + 1; }
+  orc_wr_tmm_rates(omega_las, t->laser_active ? omega_las : 0.0, Te, Ti, Z, Ne, &Ncr, &TF, &nu_met, &nu_max, &nu_pl);
+  ksi = 0.75 * sqrt(M_PI) * nu_pl / omega_las;
+  ebb_l = t->eps_bb[3 * il + 1] + I * t->eps_bb[3 * il + 2]; ebb_r = t->eps_bb[3 * ir + 1] + I * t->eps_bb[3 * ir + 2];
+  epsilon_bb = ebb_l + (ebb_r - ebb_l) / (t->eps_bb[3 * ir] - t->eps_bb[3 * il]) * (t->lambda * 1e6 - t->eps_bb[3 * il]);
+  {                                                                                        /* EOS_phase_from_r_ti (imd_ttm.c:2594-2637): bounds, round */
+    double r = Ni * 26.9815 * AMU_, tt = Ti;
+    r = r > t->phase.xmax ? t->phase.xmax : r; r = r < t->phase.xmin ? t->phase.xmin : r;
+    tt = tt > t->phase.ymax ? t->phase.ymax : tt; tt = tt < t->phase.ymin ? t->phase.ymin : tt;
+    phase = (double) ((int) round(orc_eos_lookup(&t->phase, r, tt)));
+  }
+  if (fabs(phase) == 3 || fabs(phase) == 4 || fabs(phase) == 5) epsilon_bb = 0 * I * 0;
+  epsilon_met = epsilon_bb + un - Ne / Ncr / (un + im * (nu_met < nu_max ? nu_met : nu_max) / omega_las);
+  epsilon_pl = un - Ne / Ncr * (tmm_K(t, 0, ksi) - im * nu_pl / omega_las * tmm_K(t, 1, ksi));
+  epsilon_wr = epsilon_pl + (epsilon_met - epsilon_pl) * exp(-A4p * Te / TF);
+  *re = creal(epsilon_wr); *img = cimag(epsilon_wr);
+}
+
+static void cmatmul(const double complex *a, const double complex *b, double complex *p)
+{
+  p[0] = a[0] * b[0] + a[2] * b[1]; p[1] = a[1] * b[0] + a[3] * b[1]; p[2] = a[0] * b[2] + a[2] * b[3]; p[3] = a[1] * b[2] + a[3] * b[3];
+}
+static double tmm_EE(double z, double delta, double complex kl, double complex Bplus, double complex Bminus)
+{
+  const double complex im = 0 + I * 1;
+  const double phi1 = creal(delta * z * kl * im), phi2 = cimag(delta * z * kl * im);
+  const double complex eiphi = exp(phi1) * cos(phi2) + I * exp(phi1) * sin(phi2);
+  const double complex Ez = (Bplus * eiphi + Bminus / eiphi), Ey = 0;
+  return creal(Ez) * creal(Ez) + cimag(Ez) * cimag(Ez) + creal(Ey) * creal(Ey) + cimag(Ey) * cimag(Ey);
+}
+static double tmm_Runge5(double delta, double complex kl, double complex Bplus, double complex Bminus)
+{
+  double dx = 1, cur_xpos = 0, result = 0, k1, k3, k4, k5;
+  const double errval = 1e-5;
+  while (cur_xpos < 1 && dx > 1e-5) {
+    double ERR;
+    k1 = dx / 3.0 * tmm_EE(cur_xpos, delta, kl, Bplus, Bminus);
+    k3 = dx / 3.0 * tmm_EE(cur_xpos + dx / 3.0, delta, kl, Bplus, Bminus);
+    k4 = dx / 3.0 * tmm_EE(cur_xpos + 0.5 * dx, delta, kl, Bplus, Bminus);
+    k5 = dx / 3.0 * tmm_EE(cur_xpos + dx, delta, kl, Bplus, Bminus);
+    ERR = k1 - 4.5 * k3 + 4 * k4 - 0.5 * k5;
+    if (ERR < 5.0 / 32 * errval) { result += 0.5 * (k1 + 4 * k4 + k5); cur_xpos += dx; dx *= 1.1; }
+    else if (ERR > 5 * errval) { dx *= 0.5; continue; }
+    else { result += 0.5 * (k1 + 4 * k4 + k5); cur_xpos += dx; }
+    if (cur_xpos + dx > 1) dx = 1 - cur_xpos;
+  }
+  return result;
+}
+
+/* do_tmm (:193-455).  Returns 0, or 1 when the sample is too short for the absorption threshold (the reference aborts). */
+int orc_ttm1d_do_tmm(orc_ttm1d *t, int steps)
+{
+  const int nx = t->nx, c0 = t->cur;
+  const double Imp = 3.769911184307751e+02;
+  double complex Cinv[4], Pmat[4], tmpmat[4], tmpmat2[4], Emat[4], kl, kr, eiphi, BR, BT, B0;
+  double phi1, phi2, dx, ecut_thresh = exp(-t->abs_threshold);
+  int g, j, ecut = 0, tooshort = 1;
+  t->I_t = t->I0 * exp(-pow(t->tmm_time - t->t0, 2) / (t->sigma_t * t->sigma_t));
+  t->I_t += t->I0 * exp(-pow(t->tmm_time - t->t1, 2) / (t->sigma_t1 * t->sigma_t1));
+  if (steps < 2) return 0;
+  if (sqrt(2.0 * t->I_t * Imp) < t->laser_threshold * sqrt(2 * t->I0 * Imp)) { t->laser_active = 0; return 0; }
+  t->laser_active = 1;
+  for (g = 0; g < nx; g++) {                                                               /* :212-254 */
+    const int c = g + 1;
+    if (t->natoms[c] < t->fd_min_atoms || t->dens[c] < RHOMIN) { t->eps_re[g] = 0.0; t->eps_im[g] = 0.0; t->tmm_active[g] = 0; continue; }
+    tmm_get_epsilon(t, t->temp[c0][c], t->md_temp[c], t->Z[c], t->ne[c], &t->eps_re[g], &t->eps_im[g]);
+    t->tmm_active[g] = 1;
+  }
+  for (g = 0; g < nx / t->nranks; g++) if (t->eps_re[g] == 0) t->eps_re[g] = 1.0;         /* :264-273: rank 0's cells only */
+  BR = BT = 0.0 + I * 0; B0 = 1.0 + I * 0;
+  t->km[0] = t->k0;                                                                        /* :296-306 */
+  for (g = 1; g < nx - 1; g++) t->km[g] = t->tmm_active[g] == 0 ? t->k0 : t->k0 * csqrt(t->eps_re[g] + I * t->eps_im[g]);
+  Emat[0] = 1.0 + I * 0; Emat[1] = 0; Emat[2] = 0; Emat[3] = 1.0 + I * 0.0;
+  for (g = 0; g < nx - 1; g++) {                                                           /* :310-375 */
+    dx = g == 0 ? 1e10 : t->hx;
+    kl = t->km[g]; kr = t->km[g + 1];
+    phi1 = creal(dx * kl * I); phi2 = cimag(dx * kl * I);
+    eiphi = exp(phi1) * cos(phi2) + I * exp(phi1) * sin(phi2);
+    Pmat[0] = eiphi; Pmat[2] = 1.0 / eiphi; Pmat[1] = eiphi; Pmat[3] = -Pmat[2];
+    Cinv[0] = 0.5; Cinv[2] = 0.5 * kl / kr; Cinv[1] = 0.5; Cinv[3] = -Cinv[2];
+    cmatmul(Cinv, Pmat, tmpmat); cmatmul(tmpmat, Emat, tmpmat2);
+    for (j = 0; j < 4; j++) Emat[j] = tmpmat2[j];
+    BR = -Emat[1] * B0 / Emat[3];
+    BT = Emat[0] * B0 + Emat[2] * BR;
+    if (creal(BT) * creal(BT) + cimag(BT) * cimag(BT) < ecut_thresh) { tooshort = 0; ecut = g + 1; break; }
+  }
+  if (tooshort) return 1;
+  {
+    const double complex tmpr0 = BR / B0;
+    t->refl = creal(tmpr0) * creal(tmpr0) + cimag(tmpr0) * cimag(tmpr0);
+    t->trans = creal(BT) * creal(BT) + cimag(BT) * cimag(BT);
+    t->absorbed = 1.0 - t->refl - t->trans;
+  }
+  {                                                                                        /* :377-445 */
+    double complex *Bplus = za(ecut + 1, sizeof(double complex)), *Bminus = za(ecut + 1, sizeof(double complex)), Fvec[2], tmpvec[2];
+    Fvec[0] = B0; Fvec[1] = BR; Bplus[0] = B0; Bminus[0] = BR;
+    for (g = 0; g < ecut; g++) {
+      dx = g == 0 ? 1e10 : t->hx;
+      kl = t->km[g]; kr = t->km[g + 1];
+      phi1 = creal(dx * kl * I); phi2 = cimag(dx * kl * I);
+      eiphi = exp(phi1) * cos(phi2) + I * exp(phi1) * sin(phi2);
+      Pmat[0] = eiphi; Pmat[2] = 1.0 / eiphi; Pmat[1] = eiphi; Pmat[3] = -Pmat[2];
+      Cinv[0] = 0.5; Cinv[2] = 0.5 * kl / kr; Cinv[1] = 0.5; Cinv[3] = -Cinv[2];
+      cmatmul(Cinv, Pmat, tmpmat);
+      tmpvec[0] = tmpmat[0] * Fvec[0] + tmpmat[2] * Fvec[1]; tmpvec[1] = tmpmat[1] * Fvec[0] + tmpmat[3] * Fvec[1];   /* matmul(tmpmat, Fvec, tmpvec): the first column of matmul's product */
+      Fvec[0] = tmpvec[0]; Fvec[1] = tmpvec[1];
+      Bplus[g + 1] = Fvec[0]; Bminus[g + 1] = Fvec[1];
+    }
+    for (g = 0; g < ecut; g++) {
+      dx = g == 0 ? 1e10 : t->hx;
+      t->qabs[g] = t->I_t * t->k0 * t->eps_im[g] * tmm_Runge5(dx, t->km[g], Bplus[g], Bminus[g]);
+      t->qabs[g] *= 1e10; t->qabs[g] *= 6.3538562638e-26;
+    }
+    free(Bplus); free(Bminus);
+  }
+  t->ecut = ecut;
+  for (g = 0; g < nx; g++) t->source[g + 1] = t->qabs[g];                                   /* scatter, :448-453 */
+  return 0;
 }

@@ -211,6 +211,24 @@ static double nupl(double omega_las, double Z, double ni, double ne, double Te)
   return 1.863839656495274e-40 * Z * ne * coulomb / pow(BOLTZMAN * Te, 1.5);
 }
 
+/* the collision rates tmm_get_epsilon needs (imd_tmm.c:501-538): its own TF and VF expressions, numet / numax / nupl and
+ * ne_cr as above (imd_ttm.c:2219-2222, 2282-2305); temperatures in K.  omega_coul: the frequency bMax sees (imd_ttm.c:2207-2213:
+ * omega_las while the laser is active, else the plasma frequency alone = pass 0) */
+void orc_wr_tmm_rates(double omega_las, double omega_coul, double Te, double Ti, double Z, double Ne, double *Ncr, double *TF,
+                      double *nu_met, double *nu_max, double *nu_pl)
+{
+  const double A1p = 4.41, A2p = 0.8, A3p = 0.7;
+  const double Ni = Ne / Z, EF = fermi_E(Ne), VF = sqrt(2 * EF / EMASS);
+  *Ncr = ECONST * EMASS * omega_las * omega_las / ECHARGE / ECHARGE;
+  *TF = 2.0 * EF / (3.0 * BOLTZMAN);
+  *nu_met = numet(A1p, A2p, Te, Ti, *TF);
+  *nu_max = numax(A3p, VF, Te, Ni);
+  {
+    double coulomb = coulomb_log(omega_coul, Z, Ni, Te);            /* nupl(omega_las, ..): omega_las enters through bMax only */
+    *nu_pl = 1.863839656495274e-40 * Z * Ne * coulomb / pow(BOLTZMAN * Te, 1.5);
+  }
+}
+
 /* MeanCharge (More fit), :2399-2473; temp in K, rho in kg/m^3 */
 double orc_mean_charge(double temp, double rho, double z0, double am)
 {

@@ -39,6 +39,8 @@ double orc_eos_te_from_r_ee(const orc_ttm *t, double r, double e);
 double orc_mean_charge(double temp, double rho, double z0, double am);
 double orc_get_gamma(double Te, double Ti, double Ne, double Z, double omega_laser);
 double orc_get_kappa(double Te, double Ti, double Ne, double Z, double omega_laser);
+void orc_wr_tmm_rates(double omega_las, double omega_coul, double Te, double Ti, double Z, double Ne, double *Ncr, double *TF,
+                      double *nu_met, double *nu_max, double *nu_pl);
 void orc_ttm_update_fd(orc_ttm *t, orc_sys *s, int steps);
 void orc_ttm_adv(orc_ttm *t, double tau, int steps);
 /* laser_rescale_ttm (imd_laser.c:715-788), non-LASERYZ branch; the globals it reads are the arguments */

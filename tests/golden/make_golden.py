@@ -544,33 +544,96 @@ def run_mpi_case(name, c):
           (name, os.path.getsize(path) / 1024, world, c["dump"], out["s%d_nbl_count" % last], np.abs(out["s%d_kraft" % last]).max()))
 
 
-def run_ttm1d_case():
+TMM_CASE = dict(I0=2.0e15, lam=800e-9, sigma_t=8e-15, t0=6e-15, abs_threshold=4.5)
+
+
+def tmm_phase_table(eos):
+    """EOS_phase_from_r_ti stand-in: phase 1 below 1000 K, 3 above 1150 K, linear in Ti between (constant along the density:
+    planar inside every grid cell, so every triangulation of the grid interpolates alike)"""
+    t = np.asarray(eos["t"], np.float64)
+    ph = np.clip(1.0 + 2.0 * (t - 1000.0) / 150.0, 1.0, 3.0)
+    return dict(x=eos["r"], y=eos["t"], z=np.repeat(ph[None, :], len(eos["r"]), axis=0))
+
+
+def read_tmm_probe(path):
+    """tmm.<rank>.<step>.bin of oracle/ref_probe_ttm1d.c: do_tmm's state after sub-steps 0, 1 and the last of an MD step"""
+    b = open(path, "rb").read()
+    assert b[:8] == b"IMDTMM1P"
+    hd = np.frombuffer(b, dtype=np.float64, count=8, offset=8)
+    n, nl, o, recs = int(hd[0]), int(hd[1]), 72, {}
+    while True:
+        sub = int(np.frombuffer(b, dtype=np.int32, count=1, offset=o)[0]); o += 4
+        if sub < 0:
+            break
+        m = 4 * n + nl + 7
+        a = np.frombuffer(b, dtype=np.float64, count=m, offset=o); o += 8 * m
+        recs[sub] = dict(eps_re=a[:n], eps_im=a[n:2 * n], active=a[2 * n:3 * n], qabs=a[3 * n:4 * n], source=a[4 * n:4 * n + nl], scalars=a[4 * n + nl:])
+    return dict(nx=n, nlocal=nl, nsub=int(hd[2]), k0=hd[3], omega_laser=hd[4], tmm_time=hd[5], hx=hd[6], abs_threshold=hd[7], subs=recs)
+
+
+def run_ttm1d_case(tmm=False):
     """imd_ttm.c's own 1D TTM (the file the reference's Makefile builds): oracle/_ref/imd_mpi_eam_ttm1d_nbl on TWO ranks (its
     ttm_fill_ghost_layers and do_COMMFLUX have no one-rank branch), a slab with vacuum on both x sides, do_ADV on; the
     lattice rows of both ranks assembled into the global row, stage by stage (oracle/ref_probe_ttm1d.c), the global slab
-    arrays, the virtual lattice, and the atoms of every dumped step in rank order."""
-    name, steps, dump = "ttm1d_slab", 20, [0, 1, 2, 8, 9, 20]
+    arrays, the virtual lattice, and the atoms of every dumped step in rank order.
+    tmm: the build with the reference's own transfer-matrix laser source (imd_tmm.c; oracle/_ref/imd_mpi_eam_ttm1d_tmm_nbl):
+    do_tmm at the top of every sub-step as in calc_ttm (:113), a 19 fs pulse peaking at 6 fs, on a longer slab; synthetic
+    alu_eps_bb.dat / K12.dat / phase table (imd_amd/tmm.py) -> ttm1d_tmm_slab.npz with do_tmm's arrays after sub-steps 0, 1, last."""
+    if tmm:
+        name, steps, dump = "ttm1d_tmm_slab", 12, [0, 1, 2, 3, 8, 12]
+    else:
+        name, steps, dump = "ttm1d_slab", 20, [0, 1, 2, 8, 9, 20]
     par = COMMON.format(pbc="0 1 1", seed=12345, cpu="2 1 1").replace("ensemble nve", "ensemble ttm")
-    par += ("box_param 12 6 6\nstarttemp 0.09\nmaxsteps %d\ncore_potential_file phi.pt\nembedding_energy_file F.pt\n"
+    par += ("box_param %s 6 6\nstarttemp 0.09\nmaxsteps %d\ncore_potential_file phi.pt\nembedding_energy_file F.pt\n"
             "atomic_e-density_file rho.pt\nnbl_margin 0.5\nnbl_size 1.5\nshiftx_front 8.0\nshiftx_rear 8.0\nmsgbuf_size 3.0\n"
-            "fd_n_timesteps 100\nfd_min_atoms 12\natomic_weight 26.9815\natomic_charge 13\nttm_int 100000\nttmdimx 14\n"
-            "vlatdim 6\nvlatbuffer 1\nI0 1.0\nlambda 800e-9\nlaser_sigma_t 100e-15\nlaser_t_0 1.0\n" % steps)
+            "fd_n_timesteps 100\nfd_min_atoms 12\natomic_weight 26.9815\natomic_charge 13\nttm_int 100000\nttmdimx %s\n"
+            "vlatdim 6\nvlatbuffer 1\n" % ("24" if tmm else "12", steps, "26" if tmm else "14"))
+    if tmm:
+        c = TMM_CASE
+        par += "I0 %r\nlambda %r\nlaser_sigma_t %r\nlaser_t_0 %r\ntmm_threshold %r\n" % (c["I0"], c["lam"], c["sigma_t"], c["t0"], c["abs_threshold"])
+    else:
+        par += "I0 1.0\nlambda 800e-9\nlaser_sigma_t 100e-15\nlaser_t_0 1.0\n"
     with tempfile.TemporaryDirectory() as top:
         d = os.path.join(top, "run"); os.mkdir(d)
         potential.write_synthetic_eam_files(d)
         eos = write_planar_eos(top)                       # the 1D file reads its tables from the PARENT directory (imd_ttm.c:1121-1123)
         from imd_amd import ttm as ttm_mod
-        ttm_mod.write_eos_table(os.path.join(top, "EOS_phase_from_r_ti.txt"), dict(x=eos["r"], y=eos["t"], z=np.ones((len(eos["r"]), len(eos["t"])))))
+        phase = tmm_phase_table(eos) if tmm else dict(x=eos["r"], y=eos["t"], z=np.ones((len(eos["r"]), len(eos["t"]))))
+        ttm_mod.write_eos_table(os.path.join(top, "EOS_phase_from_r_ti.txt"), phase)
+        if tmm:
+            from imd_amd import tmm as tmm_mod
+            tmm_mod.write_arr(os.path.join(top, "alu_eps_bb.dat"), tmm_mod.synthetic_eps_bb())
+            tmm_mod.write_arr(os.path.join(top, "K12.dat"), tmm_mod.synthetic_K12())
         open(os.path.join(d, "t.param"), "w").write(par)
         env = dict(os.environ, IMD_PROBE_DIR=d, IMD_PROBE_STEPS=",".join(map(str, dump)), IMD_PROBE_ADV="1")
-        r = subprocess.run([MPIEXEC, "-n", "2", os.path.join(REFBIN, "imd_mpi_eam_ttm1d_nbl"), "-p", "t.param"], cwd=d, env=env,
-                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if tmm:
+            env["IMD_PROBE_TMM"] = "1"
+        r = subprocess.run([MPIEXEC, "-n", "2", os.path.join(REFBIN, "imd_mpi_eam_ttm1d_tmm_nbl" if tmm else "imd_mpi_eam_ttm1d_nbl"), "-p", "t.param"],
+                           cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             print(r.stdout[-3000:]); raise SystemExit("reference run failed for %s" % name)
         T = {s: [po.read_ttm1d_probe(os.path.join(d, "ttm1d.%d.%d.bin" % (rk, s))) for rk in (0, 1)] for s in dump}
         P = {s: [po.read_probe(os.path.join(d, "probe.%d.%d.bin" % (rk, s))) for rk in (0, 1)] for s in dump}
+        M = {s: [read_tmm_probe(os.path.join(d, "tmm.%d.%d.bin" % (rk, s))) for rk in (0, 1)] for s in dump} if tmm else None
     T0, P0 = T[0][0], P[0][0]
     out = dict(case=name, param_file=par, steps=np.array(dump), ref_ranks=2)
+    if tmm:
+        from imd_amd import tmm as tmm_mod
+        for k, v in TMM_CASE.items():
+            out["tmm_" + k] = v
+        out["tmm_eps_bb"] = tmm_mod.synthetic_eps_bb(); out["tmm_K12"] = tmm_mod.synthetic_K12(); out["tmm_phase_z"] = phase["z"]
+        out["tmm_k0"] = M[dump[0]][0]["k0"]; out["tmm_omega_laser"] = M[dump[0]][0]["omega_laser"]
+        for s in dump:
+            m0, m1 = M[s]
+            lx = m0["nlocal"]
+            out["m%d_tmm_time" % s] = m0["tmm_time"]; out["m%d_nsub" % s] = m0["nsub"]
+            for sub, rec in m0["subs"].items():
+                q = "m%d_sub%d_" % (s, sub)
+                for f in ("eps_re", "eps_im", "active", "qabs"):          # rank 0 holds what it solved (MPI_Reduce to 0)
+                    out[q + f] = rec[f]
+                out[q + "source"] = np.concatenate([rec["source"][1:lx - 1], m1["subs"][sub]["source"][1:lx - 1]])
+                out[q + "scalars"] = rec["scalars"]                        # I_t, tmm_time, refl, trans, abs, laser_active, Eabs_local (rank 0)
+                out[q + "eabs"] = rec["scalars"][6] + m1["subs"][sub]["scalars"][6]
     for k in ("ntypes", "global_cell_dim", "pbc_dirs", "box", "cellsz", "nbl_margin", "timestep", "natoms", "flags"):
         out[k] = P0[k]
     out["cell_dim"] = np.array(P0["global_cell_dim"]) + 2
@@ -762,7 +825,7 @@ def run_ttm_file_case():
 
 
 if __name__ == "__main__":
-    names = sys.argv[1:] or (list(CASES) + ["eos_inverse", "eos_grid", "fdtd_1d", "chkpt", "ttm_file", "ttm1d_slab", "tricub"])
+    names = sys.argv[1:] or (list(CASES) + ["eos_inverse", "eos_grid", "fdtd_1d", "chkpt", "ttm_file", "ttm1d_slab", "ttm1d_tmm_slab", "tricub"])
     for n in names:
         if n == "eos_inverse":
             run_eos_inverse()
@@ -778,6 +841,8 @@ if __name__ == "__main__":
             run_adv_case(n, CASES[n])
         elif n == "ttm1d_slab":
             run_ttm1d_case()
+        elif n == "ttm1d_tmm_slab":
+            run_ttm1d_case(tmm=True)
         elif n == "tricub":
             run_tricub_case()
         elif n.endswith("_mpi8"):
