@@ -11,6 +11,7 @@
 #include "imdgpu_internal.h"
 
 #include <cmath>
+#include <complex>
 #include <cstring>
 #include <vector>
 
@@ -2978,16 +2979,140 @@ struct Ttm1dState {
   double *cve_z = nullptr, *ee_z = nullptr;
   EosDev cve{}, ee{};
   Lat L{};
+  struct TmmDev *tmm = nullptr;                                       // transfer-matrix laser source (imdgpu_ttm1d_tmm_init), host copy
+  double omega_laser_tmm = 0;
+  double *tmm_K12 = nullptr, *tmm_phase_z = nullptr, *tmm_q = nullptr, *tmm_eps = nullptr, *tmm_sc = nullptr, *tmm_bf = nullptr;
+  int *tmm_act = nullptr;
+};
+// do_tmm's parameters and device arrays (imd_tmm.c); see tmm_* below
+struct TmmDev {
+  int on;
+  double I0, t0, sig2, t1, sig1_2, ecut_thresh, laser_threshold, k0, omega_las, omega_laser, ebb_re, ebb_im, lambda;
+  const double *K12;                 // [1500][2]
+  EosDev phase;
+  double *q, *eps, *sc, *bf;         // q[nx]: tmm_Qabs (persists between calls); eps[2 nx]; sc[8]: tmm_time, laser_active, eabs, I_t, refl, trans, abs, ecut; bf[4 nx]
+  int *act;                          // [nx]
 };
 struct T1dDev {
   int nx, nv, fd_min_atoms, fd_n, vlatbuffer, ref_ranks;
   double hx, vol, neighvol, aw, vlatdens, Temin;
+  TmmDev M;
   int *natoms, *natoms_old;
   double *temp0, *temp1, *U0, *U1, *xi, *md_temp, *source, *dens, *fd_k, *fd_g, *Z, *Ce, *ne;
   int *gi; double *gd;
   double *vt0, *vt1, *vm0, *vm1, *vk, *vg, *vCe, *vZ, *vne;
   int *sc_i; double *sc_d;
 };
+// ---- complex arithmetic as the reference's compiler does it (C99 double complex under gcc on x86-64: products inline,
+// quotients through libgcc's __divdc3 = Smith's method; csqrt like glibc's) ---------------------------------------------
+struct cpx { double re, im; };
+__device__ __forceinline__ cpx c_mk(double a, double b) { cpx r; r.re = a; r.im = b; return r; }
+__device__ __forceinline__ cpx c_add(cpx a, cpx b) { return c_mk(a.re + b.re, a.im + b.im); }
+__device__ __forceinline__ cpx c_sub(cpx a, cpx b) { return c_mk(a.re - b.re, a.im - b.im); }
+__device__ __forceinline__ cpx c_neg(cpx a) { return c_mk(-a.re, -a.im); }
+__device__ __forceinline__ cpx c_mul(cpx a, cpx b) { return c_mk(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
+__device__ __forceinline__ cpx c_scale(double f, cpx a) { return c_mk(f * a.re, f * a.im); }
+__device__ __forceinline__ cpx c_div(cpx n, cpx dd)
+{
+  const double a = n.re, b = n.im, c = dd.re, d = dd.im;
+  if (fabs(c) < fabs(d)) {
+    const double ratio = c / d, denom = (c * ratio) + d;
+    return c_mk(((a * ratio) + b) / denom, ((b * ratio) - a) / denom);
+  }
+  const double ratio = d / c, denom = (d * ratio) + c;
+  return c_mk(((b * ratio) + a) / denom, (b - (a * ratio)) / denom);
+}
+__device__ __forceinline__ double c_abs2(cpx a) { return a.re * a.re + a.im * a.im; }
+__device__ __forceinline__ cpx c_sqrt(cpx z)
+{
+  if (z.re == 0.0 && z.im == 0.0) return c_mk(0.0, z.im);
+  const double d = hypot(z.re, z.im);
+  double r, sI;
+  if (z.re > 0) { r = sqrt(0.5 * (d + z.re)); sI = 0.5 * (z.im / r); }
+  else { sI = sqrt(0.5 * (d - z.re)); r = fabs(0.5 * (z.im / sI)); sI = copysign(sI, z.im); }
+  return c_mk(r, sI);
+}
+// eiphi of do_tmm / EE: exp(Re(dx k i)) (cos(Im(dx k i)) + i sin(..)), dx k i = (-dx Im k) + i (dx Re k)
+__device__ __forceinline__ cpx tmm_eiphi(double dx, cpx k)
+{
+  const double phi1 = -(dx * k.im), phi2 = dx * k.re, e = exp(phi1);
+  return c_mk(e * cos(phi2), e * sin(phi2));
+}
+// tmm_K1 / tmm_K2 (imd_tmm.c:662-695): `(int) nu * 30 - 1` truncates nu BEFORE the product, as the source has it
+__device__ __forceinline__ double tmm_K(const double *K12, int col, double nu)
+{
+  if (nu < 1.0 / 30.0) return 1;
+  if (nu < 50) {
+    int i = (int) nu * 30 - 1;
+    if (i < 0) i = 0;
+    if (i > 1498) i = 1498;
+    return K12[2 * i + col] + (30 * nu - i - 1) * (K12[2 * (i + 1) + col] - K12[2 * i + col]);
+  }
+  return col == 0 ? 315.0 / 8.0 / (nu * nu) - 675675.0 / 64.0 / (nu * nu * nu * nu) : 6.0 / (nu * nu) - 720.0 / (nu * nu * nu * nu);
+}
+// tmm_get_epsilon (imd_tmm.c:501-555): the wide-range permittivity of a cell at the laser wavelength; Te, Ti in eV.
+// The interband term epsilon_bb at the wavelength is a constant of the run (interpolated on the host, :531-540).
+__device__ cpx tmm_epsilon(const TmmDev &M, bool laser_active, double Te, double Ti, double Z, double Ne)
+{
+  Te *= 11604.52500617; Ti *= 11604.52500617;
+  const double A1p = 4.41, A2p = 0.8, A3p = 0.7, A4p = 0.2;
+  const double omega_las = M.omega_las;
+  const double Ncr = C_ECONST * C_EMASS * omega_las * omega_las / C_ECHARGE / C_ECHARGE;                     // ne_cr
+  const double Ni = Ne / Z;
+  const double EF = C_HBAR * C_HBAR * pow(3.0 * C_PI * C_PI * Ne, 2.0 / 3.0) / 2.0 / C_EMASS;               // fermi_E
+  const double TF = 2.0 * EF / (3.0 * C_BOLTZMAN), VF = sqrt(2 * EF / C_EMASS);
+  const double nu_met = 1.309202957843054e+11 * (A1p * Ti + A2p * Te * Te / TF);                            // numet
+  const double rws = pow(3.0 / (4 * C_PI * Ni), 1.0 / 3.0);                                                 // r0(ni)
+  const double nu_max = A3p / rws * sqrt(VF * VF + C_BOLTZMAN * Te / C_EMASS);                              // numax
+  double nu_pl;
+  {                                                                                                         // nupl -> coulomb_log -> bMax / bMin
+    const double ftz = 2.0 * (C_HBAR * C_HBAR * pow(3.0 * C_PI * C_PI * (Ni * Z), 2.0 / 3.0) / 2.0 / C_EMASS) / (3.0 * C_BOLTZMAN);
+    const double teff = sqrt(Te * Te + ftz * ftz);
+    const double wpl = sqrt((Ni * Z) * C_ECHARGE * C_ECHARGE / C_EMASS / C_ECONST);
+    const double bmax = fmax(rws, sqrt(C_BOLTZMAN * teff / (C_EMASS)) / (laser_active ? fmax(omega_las, wpl) : wpl));
+    const double bmin = fmax(Z * C_ECHARGE * C_ECHARGE / (C_BOLTZMAN * Te), C_HBAR / sqrt(2 * C_EMASS * C_BOLTZMAN * Te));
+    const double coulomb = fmax(2.0, log(bmax / bmin));
+    nu_pl = 1.863839656495274e-40 * Z * Ne * coulomb / pow(C_BOLTZMAN * Te, 1.5);
+  }
+  const double ksi = 0.75 * sqrt(C_PI) * nu_pl / omega_las;
+  cpx ebb = c_mk(M.ebb_re, M.ebb_im);
+  {                                                                                                         // EOS_phase_from_r_ti (imd_ttm.c:2594-2637)
+    const double ph = (double) ((int) round(eos_lookup(M.phase, Ni * 26.9815 * C_AMU, Ti)));
+    if (fabs(ph) == 3 || fabs(ph) == 4 || fabs(ph) == 5) ebb = c_mk(0.0, 0.0);
+  }
+  const cpx un = c_mk(1.0, 0.0);
+  // epsilon_met = epsilon_bb + 1 - Ne / Ncr / (1 + i min(nu_met, nu_max) / omega_las): real / complex through the quotient rule
+  const cpx dm = c_add(un, c_mk(0.0 * (fmin(nu_met, nu_max) / omega_las), fmin(nu_met, nu_max) / omega_las));
+  const cpx emet = c_sub(c_add(ebb, un), c_div(c_mk(Ne / Ncr, 0.0), dm));
+  const double K1 = tmm_K(M.K12, 0, ksi), K2 = tmm_K(M.K12, 1, ksi);
+  const cpx epl = c_sub(un, c_scale(Ne / Ncr, c_mk(K1, -(nu_pl / omega_las * K2))));
+  const double w = exp(-A4p * Te / TF);
+  return c_add(epl, c_scale(w, c_sub(emet, epl)));
+}
+// EE and Runge5 (imd_tmm.c:36-96): |E|^2 inside a layer and its adaptive integral over the layer
+__device__ __forceinline__ double tmm_EE(double z, double delta, cpx kl, cpx Bp, cpx Bm)
+{
+  const cpx e = tmm_eiphi(delta * z, kl);
+  const cpx Ez = c_add(c_mul(Bp, e), c_div(Bm, e));
+  return Ez.re * Ez.re + Ez.im * Ez.im + 0.0 * 0.0 + 0.0 * 0.0;
+}
+__device__ double tmm_runge5(double delta, cpx kl, cpx Bp, cpx Bm)
+{
+  double dx = 1, cur_xpos = 0, result = 0;
+  const double errval = 1e-5;
+  int guard = 0;
+  while (cur_xpos < 1 && dx > 1e-5 && guard++ < 100000) {
+    const double k1 = dx / 3.0 * tmm_EE(cur_xpos, delta, kl, Bp, Bm), k3 = dx / 3.0 * tmm_EE(cur_xpos + dx / 3.0, delta, kl, Bp, Bm),
+                 k4 = dx / 3.0 * tmm_EE(cur_xpos + 0.5 * dx, delta, kl, Bp, Bm), k5 = dx / 3.0 * tmm_EE(cur_xpos + dx, delta, kl, Bp, Bm);
+    const double ERR = k1 - 4.5 * k3 + 4 * k4 - 0.5 * k5;
+    if (ERR < 5.0 / 32 * errval) { result += 0.5 * (k1 + 4 * k4 + k5); cur_xpos += dx; dx *= 1.1; }
+    else if (ERR > 5 * errval) { dx *= 0.5; continue; }
+    else { result += 0.5 * (k1 + 4 * k4 + k5); cur_xpos += dx; }
+    if (cur_xpos + dx > 1) dx = 1 - cur_xpos;
+  }
+  return result;
+}
+
 __device__ __forceinline__ int t1d_slab(double x, double hx, int nx)
 {
   int g = (int) (x / hx);
@@ -3059,9 +3184,11 @@ __global__ void k_ttm1d_vcom(int nx, double aw, const int *gi, double *gd)
 // 32 do_FILLMESH + ghost cells, 64 the loop (diff_substeps x (do_DIFF, do_FILLMESH, ghosts)), 128 the EOS update of U
 __global__ __launch_bounds__(T1D_MAX) void k_ttm1d_calc(T1dDev D, Lat L, EosDev cve, EosDev ee, int steps, double timestep, int stages)
 {
+  // stage 256: ONE do_tmm (the transfer-matrix laser source) on the lattice as it stands
   __shared__ double sT[T1D_MAX + 2], sK[T1D_MAX + 2], sD[T1D_MAX + 2], sU[T1D_MAX + 2], vT[T1D_MAX], vK[T1D_MAX], red[16];
-  __shared__ int sN[T1D_MAX + 2], ired[16], s_last, s_nsub;
-  __shared__ double s_maxdt;
+  __shared__ int sN[T1D_MAX + 2], ired[16], s_last, s_nsub, s_ecut;
+  __shared__ double s_maxdt, s_tmm[8];
+  extern __shared__ double sM[];                 // do_tmm: the interface matrices Cinv P (8 doubles each), then Bplus / Bminus in their place
   const int tid = threadIdx.x, nx = D.nx, nv = D.nv, lane = tid & 63, wv = tid >> 6;
   const bool cellt = tid < nx, vlatt = tid >= nx && tid < nx + nv;
   const int c = tid + 1, g = tid, vi = tid - nx;                       // lattice index / slab index / virtual-lattice index
@@ -3134,7 +3261,13 @@ __global__ __launch_bounds__(T1D_MAX) void k_ttm1d_calc(T1dDev D, Lat L, EosDev 
   if (tid == 0) { sN[0] = D.natoms[0]; sN[nx + 1] = D.natoms[nx + 1]; sD[0] = D.dens[0]; sD[nx + 1] = D.dens[nx + 1]; sT[0] = T[cur][0]; sT[nx + 1] = T[cur][nx + 1];
                   sK[0] = D.fd_k[0]; sK[nx + 1] = D.fd_k[nx + 1]; }
   __syncthreads();
+  // transfer-matrix laser source (imd_tmm.c), state across the launches of a run
+  const TmmDev &M = D.M;
+  double tmm_time = 0.0, qab = 0.0, eacc = 0.0;
+  bool laser_active = false;
+  if (M.on) { tmm_time = M.sc[0]; laser_active = M.sc[1] != 0.0; if (cellt) qab = M.q[g]; }
   auto fillmesh = [&]() {                                                              // do_FILLMESH (:629-850), own cell
+    L.omega_laser = laser_active ? M.omega_laser : 0.0;                                // bMax (:2207-2213): omega_las only while the laser is active
     if (cellt && !(g > last_active)) {
       if (act(nat, dn)) {
         const MeshOut o = mesh_props(L, cve, Te, Tl, dn);
@@ -3195,6 +3328,7 @@ __global__ __launch_bounds__(T1D_MAX) void k_ttm1d_calc(T1dDev D, Lat L, EosDev 
   const double invxsq = 1.0 / (D.hx * D.hx);
   auto diff = [&](double tau) {
     const double xi_fac = 26.9815 * C_AMU / 3.0 * 1e30 / ((double) nsub);
+    if (laser_active && cellt && !(g > last_active)) eacc += src * D.vol * tau;       // :1515-1518
     if (cellt && !(g > last_active) && !(nat < amin || dn < T1D_RHOMIN)) {
       const int xmin = act_ge(sN[c - 1], sD[c - 1]) ? c - 1 : c, xmax = act_ge(sN[c + 1], sD[c + 1]) ? c + 1 : c;
       double xmaxTe = sT[xmax], xminTe = sT[xmin], xmaxk = sK[xmax], xmink = sK[xmin];
@@ -3216,15 +3350,106 @@ __global__ __launch_bounds__(T1D_MAX) void k_ttm1d_calc(T1dDev D, Lat L, EosDev 
     { double t2 = Te; Te = Te2; Te2 = t2; t2 = u; u = u2; u2 = t2; t2 = vTe; vTe = vTe2; vTe2 = t2; t2 = vTl; vTl = vTl2; vTl2 = t2; }
     cur ^= 1; vcur ^= 1;
   };
+  // do_tmm (imd_tmm.c:193-455): permittivity per cell, the stack's transfer matrices up to the absorption depth, the field
+  // amplitudes of every layer, the absorbed power per layer -> source.  The reference solves on rank 0 and scatters; here the
+  // per-cell parts (permittivity, interface matrix, Runge5 quadrature) are the cells' threads, the two recursions over the
+  // layers -- the matrix product that finds the absorption depth, the amplitude vector -- run on thread 0 in the reference's order.
+  auto tmm = [&]() {
+    const double Imp = 3.769911184307751e+02;
+    double I_t = M.I0 * exp(-((tmm_time - M.t0) * (tmm_time - M.t0)) / M.sig2);
+    I_t += M.I0 * exp(-((tmm_time - M.t1) * (tmm_time - M.t1)) / M.sig1_2);
+    if (tid == 0) M.sc[3] = I_t;
+    if (steps < 2) return;
+    if (sqrt(2.0 * I_t * Imp) < M.laser_threshold * sqrt(2 * M.I0 * Imp)) { laser_active = false; return; }
+    laser_active = true;
+    cpx km = c_mk(0.0, 0.0);                                                         // km[nx - 1] is never set (:296-306)
+    if (cellt) {
+      const bool a = !(nat < amin || dn < T1D_RHOMIN);
+      cpx e = c_mk(0.0, 0.0);
+      if (a) e = tmm_epsilon(M, true, Te, Tl, Zc, nec);
+      M.eps[g] = e.re; M.eps[nx + g] = e.im; M.act[g] = a ? 1 : 0;
+      if (g < nx - 1) {                                                               // :296-306
+        if (g == 0 || !a) km = c_mk(M.k0, 0.0);
+        else { const cpx sq = c_sqrt(e); km = c_mk(M.k0 * sq.re, M.k0 * sq.im); }       // k0 * csqrt(eps): real x complex
+      }
+      sM[8 * g] = km.re; sM[8 * g + 1] = km.im;
+    }
+    __syncthreads();
+    cpx kr = c_mk(0.0, 0.0);
+    if (cellt && g < nx - 1) kr = c_mk(sM[8 * (g + 1)], sM[8 * (g + 1) + 1]);
+    __syncthreads();
+    if (cellt && g < nx - 1) {                                                        // tmpmat = Cinv P of interface g -> g + 1 (:318-336)
+      const double dx = g == 0 ? 1e10 : D.hx;
+      const cpx e = tmm_eiphi(dx, km), ie = c_div(c_mk(1.0, 0.0), e), r = c_div(c_scale(0.5, km), kr);
+      const cpx P0 = e, P2 = ie, P1 = e, P3 = c_neg(ie), C0 = c_mk(0.5, 0.0), C2 = r, C1 = c_mk(0.5, 0.0), C3 = c_neg(r);
+      const cpx t0 = c_add(c_mul(C0, P0), c_mul(C2, P1)), t1 = c_add(c_mul(C1, P0), c_mul(C3, P1));
+      const cpx t2 = c_add(c_mul(C0, P2), c_mul(C2, P3)), t3 = c_add(c_mul(C1, P2), c_mul(C3, P3));
+      double *m = sM + 8 * g;
+      m[0] = t0.re; m[1] = t0.im; m[2] = t1.re; m[3] = t1.im; m[4] = t2.re; m[5] = t2.im; m[6] = t3.re; m[7] = t3.im;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      cpx E0 = c_mk(1.0, 0.0), E1 = c_mk(0.0, 0.0), E2 = c_mk(0.0, 0.0), E3 = c_mk(1.0, 0.0), BR = c_mk(0.0, 0.0), BT = c_mk(0.0, 0.0);
+      const cpx B0 = c_mk(1.0, 0.0);
+      int ecut = 0;
+      for (int i = 0; i < nx - 1; i++) {                                              // :310-358
+        const double *m = sM + 8 * i;
+        const cpx a0 = c_mk(m[0], m[1]), a1 = c_mk(m[2], m[3]), a2 = c_mk(m[4], m[5]), a3 = c_mk(m[6], m[7]);
+        const cpx n0 = c_add(c_mul(a0, E0), c_mul(a2, E1)), n1 = c_add(c_mul(a1, E0), c_mul(a3, E1));
+        const cpx n2 = c_add(c_mul(a0, E2), c_mul(a2, E3)), n3 = c_add(c_mul(a1, E2), c_mul(a3, E3));
+        E0 = n0; E1 = n1; E2 = n2; E3 = n3;
+        BR = c_div(c_mul(c_neg(E1), B0), E3);
+        BT = c_add(c_mul(E0, B0), c_mul(E2, BR));
+        if (c_abs2(BT) < M.ecut_thresh) { ecut = i + 1; break; }
+      }
+      s_ecut = ecut;
+      if (ecut > 0) {
+        const cpx r0 = c_div(BR, B0);
+        M.sc[4] = c_abs2(r0); M.sc[5] = c_abs2(BT); M.sc[6] = 1.0 - c_abs2(r0) - c_abs2(BT); M.sc[7] = (double) ecut;
+        cpx F0 = B0, F1 = BR;                                                         // :377-420: Bplus / Bminus of layer i + 1 into the slot of interface i
+        s_tmm[0] = F0.re; s_tmm[1] = F0.im; s_tmm[2] = F1.re; s_tmm[3] = F1.im;
+        for (int i = 0; i < ecut; i++) {
+          double *m = sM + 8 * i;
+          const cpx a0 = c_mk(m[0], m[1]), a1 = c_mk(m[2], m[3]), a2 = c_mk(m[4], m[5]), a3 = c_mk(m[6], m[7]);
+          const cpx n0 = c_add(c_mul(a0, F0), c_mul(a2, F1)), n1 = c_add(c_mul(a1, F0), c_mul(a3, F1));
+          F0 = n0; F1 = n1;
+          m[0] = F0.re; m[1] = F0.im; m[2] = F1.re; m[3] = F1.im;
+        }
+      } else D.sc_i[5] = 1;                                                           // "Sample is too short for TMM": the host reports it
+    }
+    __syncthreads();
+    const int ecut = s_ecut;
+    if (cellt && g < ecut) {                                                          // :424-441
+      const cpx Bp = g == 0 ? c_mk(s_tmm[0], s_tmm[1]) : c_mk(sM[8 * (g - 1)], sM[8 * (g - 1) + 1]);
+      const cpx Bm = g == 0 ? c_mk(s_tmm[2], s_tmm[3]) : c_mk(sM[8 * (g - 1) + 2], sM[8 * (g - 1) + 3]);
+      if (M.bf) { M.bf[4 * g] = Bp.re; M.bf[4 * g + 1] = Bp.im; M.bf[4 * g + 2] = Bm.re; M.bf[4 * g + 3] = Bm.im; }
+      const double dx = g == 0 ? 1e10 : D.hx;
+      qab = I_t * M.k0 * M.eps[nx + g] * tmm_runge5(dx, km, Bp, Bm);
+      qab *= 1e10; qab *= 6.3538562638e-26;
+    }
+    if (ecut > 0 && cellt) src = qab;                                                 // the scatter of tmm_Qabs, entries beyond ecut as earlier calls left them (:448-453)
+    __syncthreads();
+  };
   const double tau = timestep / ((double) (nsub > 0 ? nsub : 1));
+  if (stages & 256) tmm();                                                            // one do_tmm by itself (function level)
   if (stages & 16) { diff(tau); if (!(stages & 32)) publish(); }
   if (stages & 32) { fillmesh(); publish(); }
-  if (stages & 64) for (int s = 0; s < nsub; s++) { diff(tau); fillmesh(); publish(); }
+  if (stages & 64) for (int s = 0; s < nsub; s++) {
+    if (M.on) { tmm(); tmm_time += tau * 10.18 * 1.0e-15; }                           // imd_ttm.c:113-117
+    diff(tau); fillmesh(); publish();
+  }
   // ---- stage 128: U from the EOS after the loop (:119-133) ------------------------------------------------------------
   if ((stages & 128) && cellt && nat >= amin && dn >= T1D_RHOMIN) { u = eos_ee(ee, dn, Te * 11604.5) * AMU_J2EV; u2 = u; }
   // ---- back to memory -------------------------------------------------------------------------------------------------
   if (cellt) { T[cur][c] = Te; T[cur ^ 1][c] = Te2; U[cur][c] = u; U[cur ^ 1][c] = u2; D.xi[c] = x; D.fd_k[c] = kk; D.fd_g[c] = gg; D.Ce[c] = ce; D.Z[c] = Zc;
                D.ne[c] = nec; D.gd[4 * nx + g] = xiarr; }
+  if (M.on) {
+    if (cellt) { D.source[c] = src; M.q[g] = qab; }
+    __syncthreads();                                                                  // Eabs_local of this launch, summed in cell order by one thread
+    sT[cellt ? c : 0] = cellt ? eacc : 0.0;
+    __syncthreads();
+    if (tid == 0) { double e = 0.0; for (int q = 1; q <= nx; q++) e += sT[q]; M.sc[2] += e; M.sc[0] = tmm_time; M.sc[1] = laser_active ? 1.0 : 0.0; }
+  }
   if (vlatt) { VT[vcur][vi] = vTe; VT[vcur ^ 1][vi] = vTe2; VM[vcur][vi] = vTl; VM[vcur ^ 1][vi] = vTl2; D.vk[vi] = vkk; D.vg[vi] = vgg; D.vCe[vi] = vce;
                D.vZ[vi] = vZc; D.vne[vi] = vnec; }
   if (tid == 0) { D.natoms[0] = sN[0]; D.natoms[nx + 1] = sN[nx + 1];
@@ -3280,6 +3505,9 @@ void imdgpu_ttm1d_free(imdgpu_ctx *ctx)
   void *p[] = {t->natoms, t->natoms_old, t->temp[0], t->temp[1], t->U[0], t->U[1], t->xi, t->md_temp, t->source, t->dens, t->fd_k, t->fd_g, t->Z, t->Ce,
                t->ne, t->gi, t->gd, t->vt[0], t->vt[1], t->vm[0], t->vm[1], t->vk, t->vg, t->vCe, t->vZ, t->vne, t->sc_i, t->sc_d, t->cve_z, t->ee_z};
   for (void *q : p) if (q) (void) hipFree(q);
+  void *p2[] = {t->tmm_K12, t->tmm_phase_z, t->tmm_q, t->tmm_eps, t->tmm_sc, t->tmm_bf, t->tmm_act};
+  for (void *q : p2) if (q) (void) hipFree(q);
+  delete t->tmm;
   delete t;
   ctx->ttm1d = nullptr;
 }
@@ -3292,6 +3520,7 @@ static T1dDev t1d_dev(const Ttm1dState *t)
   D.md_temp = t->md_temp; D.source = t->source; D.dens = t->dens; D.fd_k = t->fd_k; D.fd_g = t->fd_g; D.Z = t->Z; D.Ce = t->Ce; D.ne = t->ne;
   D.gi = t->gi; D.gd = t->gd; D.vt0 = t->vt[0]; D.vt1 = t->vt[1]; D.vm0 = t->vm[0]; D.vm1 = t->vm[1]; D.vk = t->vk; D.vg = t->vg; D.vCe = t->vCe;
   D.vZ = t->vZ; D.vne = t->vne; D.sc_i = t->sc_i; D.sc_d = t->sc_d;
+  if (t->tmm) D.M = *t->tmm; else { memset(&D.M, 0, sizeof D.M); }
   return D;
 }
 extern "C" int imdgpu_ttm1d_init(imdgpu_ctx *ctx, const imdgpu_ttm1d_params *par)
@@ -3365,15 +3594,93 @@ extern "C" int imdgpu_ttm1d_stage(imdgpu_ctx *ctx, int steps, int stages)
   NEED_T1D();
   if ((stages & 1) && t1d_update_fd_sums(ctx, t, steps)) return 1;
   ProfScope ps(ctx, PROF_TTM_DIFF);
-  hipLaunchKernelGGL(k_ttm1d_calc, dim3(1), dim3(T1D_MAX), 0, ctx->stream, t1d_dev(t), t->L, t->cve, t->ee, steps, ctx->timestep, stages);
+  if ((stages & 256) && !t->tmm) return imdgpu_fail(ctx, "ttm1d_stage: stage 256 (do_tmm) needs imdgpu_ttm1d_tmm_init");
+  const size_t dyn = t->tmm ? (size_t) 8 * t->nx * sizeof(double) : 0;            // the interface matrices of do_tmm
+  hipLaunchKernelGGL(k_ttm1d_calc, dim3(1), dim3(T1D_MAX), dyn, ctx->stream, t1d_dev(t), t->L, t->cve, t->ee, steps, ctx->timestep, stages);
   HIPCHK(hipGetLastError());
   return 0;
 }
-// [calc_ttm, imd_ttm.c:75-155, without do_tmm]
+// [calc_ttm, imd_ttm.c:75-155; do_tmm at the top of every sub-step once imdgpu_ttm1d_tmm_init has been called]
 extern "C" int imdgpu_ttm1d_calc(imdgpu_ctx *ctx, int steps)
 {
   NEED_T1D();
   return imdgpu_ttm1d_stage(ctx, steps, 1 | (t->adv ? 2 : 0) | 4 | 8 | 64 | 128);
+}
+
+// [tmm_init, imd_tmm.c:98-191] the transfer-matrix Helmholtz solver as laser source of the 1D model.  eps_bb: the rows of
+// alu_eps_bb.dat (lambda [um], Re, Im), K12: the 1500 rows of K12.dat, phase: EOS_phase_from_r_ti's table.
+extern "C" int imdgpu_ttm1d_tmm_init(imdgpu_ctx *ctx, const imdgpu_tmm_params *p)
+{
+  NEED_T1D();
+  if (!p || !p->eps_bb || !p->K12 || !p->phase.z) return imdgpu_fail(ctx, "ttm1d_tmm_init: parameters and the three tables are needed");
+  if (p->K12_rows < 1500) return imdgpu_fail(ctx, "ttm1d_tmm_init: K12 needs 1500 rows (tmm_K1 / tmm_K2 index up to row 1499, imd_tmm.c:662-695)");
+  if (p->eps_bb_rows < 2 || !(p->lambda * 1e6 > p->eps_bb[0]) || !(p->lambda * 1e6 <= p->eps_bb[3 * (p->eps_bb_rows - 1)]))
+    return imdgpu_fail(ctx, "ttm1d_tmm_init: lambda = %g um lies outside the interband table (%g .. %g um)", p->lambda * 1e6, p->eps_bb[0],
+                       p->eps_bb[3 * (p->eps_bb_rows - 1)]);
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const int nx = t->nx;
+  if (!t->tmm) t->tmm = new TmmDev();
+  TmmDev &M = *t->tmm;
+  void *old[] = {t->tmm_K12, t->tmm_phase_z, t->tmm_q, t->tmm_eps, t->tmm_sc, t->tmm_bf, t->tmm_act};
+  for (void *q : old) if (q) (void) hipFree(q);
+  const size_t nph = (size_t) p->phase.nx * p->phase.ny;
+  if (dev_alloc(ctx, &t->tmm_K12, 2 * (size_t) p->K12_rows) || dev_alloc(ctx, &t->tmm_phase_z, nph) || dev_alloc(ctx, &t->tmm_q, nx) ||
+      dev_alloc(ctx, &t->tmm_eps, 2 * (size_t) nx) || dev_alloc(ctx, &t->tmm_sc, 8) || dev_alloc(ctx, &t->tmm_bf, 4 * (size_t) nx) ||
+      dev_alloc(ctx, &t->tmm_act, nx)) return 1;
+  HIPCHK(hipMemcpy(t->tmm_K12, p->K12, 2 * (size_t) p->K12_rows * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(t->tmm_phase_z, p->phase.z, nph * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(t->tmm_q, 0, nx * sizeof(double))); HIPCHK(hipMemset(t->tmm_eps, 0, 2 * (size_t) nx * sizeof(double)));
+  HIPCHK(hipMemset(t->tmm_sc, 0, 8 * sizeof(double))); HIPCHK(hipMemset(t->tmm_bf, 0, 4 * (size_t) nx * sizeof(double)));
+  HIPCHK(hipMemset(t->tmm_act, 0, nx * sizeof(int)));
+  M.on = 1; M.I0 = p->I0; M.t0 = p->laser_t_0; M.sig2 = p->laser_sigma_t * p->laser_sigma_t; M.t1 = p->laser_t_1;
+  M.sig1_2 = p->laser_sigma_t1 * p->laser_sigma_t1;
+  M.ecut_thresh = exp(-p->tmm_threshold); M.laser_threshold = p->tmm_laser_threshold; M.lambda = p->lambda;
+  M.k0 = 2.0 * M_PI / p->lambda; M.k0 /= 1e10;                                     // :154-155
+  M.omega_laser = 2.0 * M_PI * (3.0e8 / p->lambda);                                // :152-153 with c0 = 3e8 (globals.h:499): what FILLMESH's Coulomb logarithm sees
+  M.omega_las = (2.0 * M_PI * 2.998e8 / p->lambda);                                // tmm_get_epsilon's own, with LIGHTSPEED (:508, globals.h:325)
+  {                                                                                // epsilon_bb at the wavelength (:519-540), evaluated once
+    int il = 0, ir = 0;
+    for (int id = 0; p->lambda * 1e6 > p->eps_bb[3 * id]; id++) { il = id; ir = id + 1; }
+    const std::complex<double> l(p->eps_bb[3 * il + 1], p->eps_bb[3 * il + 2]), r(p->eps_bb[3 * ir + 1], p->eps_bb[3 * ir + 2]);
+    const double dxl = p->eps_bb[3 * ir] - p->eps_bb[3 * il], w = p->lambda * 1e6 - p->eps_bb[3 * il];
+    const std::complex<double> d = r - l;
+    const std::complex<double> e = l + std::complex<double>(d.real() / dxl * w, d.imag() / dxl * w);
+    M.ebb_re = e.real(); M.ebb_im = e.imag();
+  }
+  M.K12 = t->tmm_K12;
+  M.phase.nx = p->phase.nx; M.phase.ny = p->phase.ny; M.phase.xmin = p->phase.xmin; M.phase.xmax = p->phase.xmax;
+  M.phase.ymin = p->phase.ymin; M.phase.ymax = p->phase.ymax; M.phase.z = t->tmm_phase_z; M.phase.diag = nullptr;
+  M.q = t->tmm_q; M.eps = t->tmm_eps; M.sc = t->tmm_sc; M.bf = t->tmm_bf; M.act = t->tmm_act;
+  const size_t dyn = (size_t) 8 * nx * sizeof(double);
+  HIPCHK(hipFuncSetAttribute((const void *) k_ttm1d_calc, hipFuncAttributeMaxDynamicSharedMemorySize, (int) dyn));
+  t->omega_laser_tmm = M.omega_laser;
+  return 0;
+}
+// do_tmm's state: scalars[8] = tmm_time [s], laser_active, Eabs_local [eV], I_t, reflectivity, transmission, absorption, ecut;
+// eps_re / eps_im / qabs [nx] (tmm_Qabs as the last call left it), active [nx]; NULL = skip.  too_short: a call found the
+// sample too short for the absorption threshold (the reference aborts there)
+extern "C" int imdgpu_ttm1d_tmm_get(imdgpu_ctx *ctx, double *scalars, double *eps_re, double *eps_im, double *qabs, int *active, int *too_short)
+{
+  NEED_T1D();
+  if (!t->tmm) return imdgpu_fail(ctx, "ttm1d_tmm_get: imdgpu_ttm1d_tmm_init first");
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (ctx->step_open) HIPCHK(hipStreamSynchronize(ctx->stream2));
+  const size_t nx = t->nx;
+  if (scalars) HIPCHK(hipMemcpy(scalars, t->tmm_sc, 8 * sizeof(double), hipMemcpyDeviceToHost));
+  if (eps_re) HIPCHK(hipMemcpy(eps_re, t->tmm_eps, nx * sizeof(double), hipMemcpyDeviceToHost));
+  if (eps_im) HIPCHK(hipMemcpy(eps_im, t->tmm_eps + nx, nx * sizeof(double), hipMemcpyDeviceToHost));
+  if (qabs) HIPCHK(hipMemcpy(qabs, t->tmm_q, nx * sizeof(double), hipMemcpyDeviceToHost));
+  if (active) HIPCHK(hipMemcpy(active, t->tmm_act, nx * sizeof(int), hipMemcpyDeviceToHost));
+  if (too_short) { int si[8]; HIPCHK(hipMemcpy(si, t->sc_i, sizeof si, hipMemcpyDeviceToHost)); *too_short = si[5]; }
+  return 0;
+}
+extern "C" int imdgpu_ttm1d_tmm_set_time(imdgpu_ctx *ctx, double tmm_time)
+{
+  NEED_T1D();
+  if (!t->tmm) return imdgpu_fail(ctx, "ttm1d_tmm_set_time: imdgpu_ttm1d_tmm_init first");
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpy(t->tmm_sc, &tmm_time, sizeof(double), hipMemcpyHostToDevice));
+  return 0;
 }
 int imdgpu_ttm1d_move_internal(imdgpu_ctx *ctx)
 {

@@ -34,7 +34,7 @@ SYMBOLS = [
     "imdgpu_dist_unique_id", "imdgpu_dist_init_rccl", "imdgpu_dist_init_callback", "imdgpu_dist_set_plan",
     "imdgpu_dist_halo", "imdgpu_dist_set_ttm_blocks", "imdgpu_dist_md_step", "imdgpu_dist_allreduce_sum",
     "imdgpu_dist_rebuild", "imdgpu_dist_rebuild_count", "imdgpu_dist_step", "imdgpu_dist_calc_forces", "imdgpu_dist_plan_geometry",
-    "imdgpu_ttm1d_init", "imdgpu_ttm1d_calc", "imdgpu_ttm1d_stage", "imdgpu_ttm1d_move_atoms", "imdgpu_ttm1d_download", "imdgpu_ttm1d_upload",
+    "imdgpu_ttm1d_init", "imdgpu_ttm1d_calc", "imdgpu_ttm1d_stage", "imdgpu_ttm1d_move_atoms", "imdgpu_ttm1d_download", "imdgpu_ttm1d_upload", "imdgpu_ttm1d_tmm_init", "imdgpu_ttm1d_tmm_get", "imdgpu_ttm1d_tmm_set_time",
     "imdgpu_ttm_remote_init", "imdgpu_ttm_remote_ipc_handle", "imdgpu_ttm_remote_open", "imdgpu_ttm_remote_attach", "imdgpu_dist_ttm_remote_setup", "imdgpu_ttm_remote_detach", "imdgpu_ttm_remote_ping",
     "imdgpu_local_group_create", "imdgpu_local_group_destroy", "imdgpu_local_group_barrier", "imdgpu_local_group_shared", "imdgpu_dist_init_local",
 ]
@@ -98,6 +98,19 @@ class FdtdParamsC(C.Structure):
     """imdgpu_fdtd_params"""
     _fields_ = [("I0", C.c_double), ("lam", C.c_double), ("sigma_t", C.c_double), ("t_0", C.c_double), ("srcx", C.c_double),
                 ("bw", C.c_int), ("Sc", C.c_double), ("DL", C.c_double * 5)]
+
+
+class _TmmPhaseC(C.Structure):
+    _fields_ = [("nx", C.c_int), ("ny", C.c_int), ("xmin", C.c_double), ("xmax", C.c_double), ("ymin", C.c_double), ("ymax", C.c_double),
+                ("z", C.POINTER(C.c_double))]
+
+
+class TmmParamsC(C.Structure):
+    """imdgpu_tmm_params"""
+    _fields_ = [(k, C.c_double) for k in ("I0", "lam", "laser_sigma_t", "laser_t_0", "laser_sigma_t1", "laser_t_1", "tmm_threshold",
+                                          "tmm_laser_threshold")] + \
+               [("eps_bb_rows", C.c_int), ("eps_bb", C.POINTER(C.c_double)), ("K12_rows", C.c_int), ("K12", C.POINTER(C.c_double)),
+                ("phase", _TmmPhaseC)]
 
 
 class TricubTableC(C.Structure):
@@ -207,6 +220,9 @@ def load():
     L.imdgpu_ttm1d_move_atoms.argtypes = [vp, dp]
     L.imdgpu_ttm1d_download.argtypes = [vp, C.POINTER(Ttm1dFieldsC)]
     L.imdgpu_ttm1d_upload.argtypes = [vp, C.POINTER(Ttm1dFieldsC)]
+    L.imdgpu_ttm1d_tmm_init.argtypes = [vp, C.POINTER(TmmParamsC)]
+    L.imdgpu_ttm1d_tmm_get.argtypes = [vp, dp, dp, dp, dp, ip, ip]
+    L.imdgpu_ttm1d_tmm_set_time.argtypes = [vp, C.c_double]
     L.imdgpu_ttm_remote_init.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.imdgpu_ttm_remote_ipc_handle.argtypes = [vp, vp, ip]
     L.imdgpu_ttm_remote_open.argtypes = [vp, vp, C.POINTER(vp)]

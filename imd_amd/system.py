@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import lib as _lib
-from .lib import (TTM1D_DBL, TTM1D_GINT, TTM1D_INT, TTM_FIELDS, TTM_INT_FIELDS, FdtdParamsC, ImdGpuError, LaserParamsC, PotTableC, TricubTableC,
+from .lib import (TTM1D_DBL, TTM1D_GINT, TTM1D_INT, TTM_FIELDS, TTM_INT_FIELDS, FdtdParamsC, ImdGpuError, LaserParamsC, PotTableC, TmmParamsC, TricubTableC,
                   Ttm1dFieldsC, Ttm1dParamsC, TtmFieldsC, TtmParamsC)
 
 
@@ -289,6 +289,37 @@ class GpuSystem:
         P.ee_z = _dp(ze)
         self._ck(self.L.imdgpu_ttm1d_init(self.h, C.byref(P)))
         self.ttm1d_nx, self.ttm1d_nv = int(ttmdimx), int(vlatdim)
+
+    def init_ttm1d_tmm(self, I0, lam, laser_sigma_t, laser_t_0, eps_bb, K12, phase, laser_sigma_t1=0.0, laser_t_1=0.0, tmm_threshold=20.0,
+                       tmm_laser_threshold=1e-5):
+        """tmm_init (imd_tmm.c:98-191): the transfer-matrix laser source of the 1D model; eps_bb [rows, 3] / K12 [1500, 2] as
+        imd_amd.tmm.read_arr gives them (or paths of alu_eps_bb.dat / K12.dat), phase = dict(x, y, z) like the EOS tables"""
+        from . import tmm as tmm_mod
+        eb = np.ascontiguousarray(tmm_mod.read_arr(eps_bb, 3) if isinstance(eps_bb, str) else eps_bb, dtype=np.float64)
+        k12 = np.ascontiguousarray(tmm_mod.read_arr(K12, 2) if isinstance(K12, str) else K12, dtype=np.float64)
+        pz = np.ascontiguousarray(phase["z"], dtype=np.float64)
+        P = TmmParamsC()
+        P.I0, P.lam, P.laser_sigma_t, P.laser_t_0, P.laser_sigma_t1, P.laser_t_1 = (float(I0), float(lam), float(laser_sigma_t), float(laser_t_0),
+                                                                                   float(laser_sigma_t1), float(laser_t_1))
+        P.tmm_threshold, P.tmm_laser_threshold = float(tmm_threshold), float(tmm_laser_threshold)
+        P.eps_bb_rows, P.eps_bb, P.K12_rows, P.K12 = len(eb), _dp(eb), len(k12), _dp(k12)
+        P.phase.nx, P.phase.ny = pz.shape
+        P.phase.xmin, P.phase.xmax, P.phase.ymin, P.phase.ymax = (float(phase["x"][0]), float(phase["x"][-1]), float(phase["y"][0]), float(phase["y"][-1]))
+        P.phase.z = _dp(pz)
+        self._ck(self.L.imdgpu_ttm1d_tmm_init(self.h, C.byref(P)))
+
+    def ttm1d_tmm_state(self):
+        """do_tmm's state after the last call: scalars, permittivity, active cells, tmm_Qabs"""
+        nx = self.ttm1d_nx
+        sc, er, ei, q = np.zeros(8), np.zeros(nx), np.zeros(nx), np.zeros(nx)
+        act = np.zeros(nx, np.int32)
+        short = C.c_int()
+        self._ck(self.L.imdgpu_ttm1d_tmm_get(self.h, _dp(sc), _dp(er), _dp(ei), _dp(q), _ip(act), C.byref(short)))
+        return dict(tmm_time=sc[0], laser_active=int(sc[1]), eabs=sc[2], I_t=sc[3], refl=sc[4], trans=sc[5], absorbed=sc[6], ecut=int(sc[7]),
+                    eps_re=er, eps_im=ei, qabs=q, active=act, too_short=short.value)
+
+    def ttm1d_tmm_set_time(self, tmm_time):
+        self._ck(self.L.imdgpu_ttm1d_tmm_set_time(self.h, float(tmm_time)))
 
     def ttm1d_calc(self, steps):
         self._ck(self.L.imdgpu_ttm1d_calc(self.h, int(steps)))

@@ -333,8 +333,29 @@ int imdgpu_ttm1d_init(imdgpu_ctx *ctx, const imdgpu_ttm1d_params *par);
 int imdgpu_ttm1d_calc(imdgpu_ctx *ctx, int steps);
 /* function level: bit 0 [update_fd :161-548], 1 [do_ADV :1208-1309], 2 [do_cell_activation :1311-1425 + do_FILLMESH :629-850 +
  * ghosts], 3 [CFL_maxdt :2444-2481 + the sub-step count :97-99], 4 [one do_DIFF :1473-1680], 5 [do_FILLMESH + ghosts],
- * 6 [the loop], 7 [U from the EOS, :119-133] */
+ * 6 [the loop], 7 [U from the EOS, :119-133], 8 [one do_tmm, imd_tmm.c:193-455: needs imdgpu_ttm1d_tmm_init] */
 int imdgpu_ttm1d_stage(imdgpu_ctx *ctx, int steps, int stages);
+/* ---- the transfer-matrix Helmholtz solver as laser source of the 1D model (imd_tmm.c; the reference's Makefile target
+ * imd_mpi_eam_ttm_tmm_nbl): [tmm_init :98-191].  SI units like the parameter file: I0 [W/m^2], lambda [m], laser_sigma_t /
+ * laser_t_0 and the second pulse laser_sigma_t1 / laser_t_1 [s], tmm_threshold (absorption depth: stop where the transmitted
+ * intensity falls below exp(-tmm_threshold)), tmm_laser_threshold (field strength relative to the peak below which the laser
+ * counts as off; globals.h:453,479).  Tables: eps_bb = rows of ../alu_eps_bb.dat (lambda [um], Re, Im of the interband
+ * permittivity, ascending), K12 = the 1500 rows of ../K12.dat (K1, K2 at nu = (row + 1) / 30), phase = the grid of
+ * ../EOS_phase_from_r_ti.txt (density [kg/m^3] x Ti [K], x slowest).  After this call imdgpu_ttm1d_calc (and imdgpu_md_step
+ * with a 1D lattice) runs do_tmm [:193-455, tmm_get_epsilon :501-586] at the top of every diffusion sub-step as calc_ttm does
+ * (imd_ttm.c:113): the absorbed power per cell becomes the source of do_DIFF, Eabs_local is booked (:1515-1518). */
+typedef struct imdgpu_tmm_params {
+  double I0, lambda, laser_sigma_t, laser_t_0, laser_sigma_t1, laser_t_1, tmm_threshold, tmm_laser_threshold;
+  int eps_bb_rows; const double *eps_bb;      /* [rows][3] */
+  int K12_rows;    const double *K12;         /* [rows][2] */
+  struct { int nx, ny; double xmin, xmax, ymin, ymax; const double *z; } phase;
+} imdgpu_tmm_params;
+int imdgpu_ttm1d_tmm_init(imdgpu_ctx *ctx, const imdgpu_tmm_params *p);
+/* scalars[8]: tmm_time [s], laser_active, Eabs_local [eV], I_t, tmm_refl, tmm_trans, tmm_abs, absorption depth in cells;
+ * eps_re / eps_im / qabs (tmm_Qabs) / active: nx values each as the last do_tmm left them; too_short: a call found the sample
+ * too short for tmm_threshold (the reference aborts there).  NULL = skip */
+int imdgpu_ttm1d_tmm_get(imdgpu_ctx *ctx, double *scalars, double *eps_re, double *eps_im, double *qabs, int *active, int *too_short);
+int imdgpu_ttm1d_tmm_set_time(imdgpu_ctx *ctx, double tmm_time);
 /* [move_atoms_ttm, TTM1D branch, imd_integrate.c:649-760] */
 int imdgpu_ttm1d_move_atoms(imdgpu_ctx *ctx, double *tot_kin_energy);
 int imdgpu_ttm1d_download(imdgpu_ctx *ctx, const imdgpu_ttm1d_fields *f);
