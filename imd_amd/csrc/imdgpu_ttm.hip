@@ -3026,7 +3026,7 @@ __device__ __forceinline__ double c_abs2(cpx a) { return a.re * a.re + a.im * a.
 __device__ __forceinline__ cpx c_sqrt(cpx z)
 {
   if (z.re == 0.0 && z.im == 0.0) return c_mk(0.0, z.im);
-  const double d = hypot(z.re, z.im);
+  const double d = sqrt(z.re * z.re + z.im * z.im);          // permittivities: no overflow to guard against (glibc: hypot)
   double r, sI;
   if (z.re > 0) { r = sqrt(0.5 * (d + z.re)); sI = 0.5 * (z.im / r); }
   else { sI = sqrt(0.5 * (d - z.re)); r = fabs(0.5 * (z.im / sI)); sI = copysign(sI, z.im); }
@@ -3037,6 +3037,14 @@ __device__ __forceinline__ cpx tmm_eiphi(double dx, cpx k)
 {
   const double phi1 = -(dx * k.im), phi2 = dx * k.re, e = exp(phi1);
   return c_mk(e * cos(phi2), e * sin(phi2));
+}
+// eiphi and 1 / eiphi = exp(-phi1) (cos - i sin) from one exp and one sincos (the reference divides: last-bit differences)
+__device__ __forceinline__ void tmm_eiphi2(double dx, cpx k, cpx *e, cpx *ie)
+{
+  const double phi1 = -(dx * k.im), phi2 = dx * k.re, m = exp(phi1), im = 1.0 / m;
+  double sn, cs;
+  sincos(phi2, &sn, &cs);
+  *e = c_mk(m * cs, m * sn); *ie = c_mk(im * cs, -(im * sn));
 }
 // tmm_K1 / tmm_K2 (imd_tmm.c:662-695): `(int) nu * 30 - 1` truncates nu BEFORE the product, as the source has it
 __device__ __forceinline__ double tmm_K(const double *K12, int col, double nu)
@@ -3059,20 +3067,23 @@ __device__ cpx tmm_epsilon(const TmmDev &M, bool laser_active, double Te, double
   const double omega_las = M.omega_las;
   const double Ncr = C_ECONST * C_EMASS * omega_las * omega_las / C_ECHARGE / C_ECHARGE;                     // ne_cr
   const double Ni = Ne / Z;
-  const double EF = C_HBAR * C_HBAR * pow(3.0 * C_PI * C_PI * Ne, 2.0 / 3.0) / 2.0 / C_EMASS;               // fermi_E
+  // x^(2/3), x^(1/3), x^1.5 as cbrt / sqrt forms (pow costs ~250 instructions here; the results differ in the last bit)
+  const double cbn = cbrt(3.0 * C_PI * C_PI * Ne);
+  const double EF = C_HBAR * C_HBAR * (cbn * cbn) / 2.0 / C_EMASS;                                          // fermi_E
   const double TF = 2.0 * EF / (3.0 * C_BOLTZMAN), VF = sqrt(2 * EF / C_EMASS);
   const double nu_met = 1.309202957843054e+11 * (A1p * Ti + A2p * Te * Te / TF);                            // numet
-  const double rws = pow(3.0 / (4 * C_PI * Ni), 1.0 / 3.0);                                                 // r0(ni)
+  const double rws = cbrt(3.0 / (4 * C_PI * Ni));                                                           // r0(ni)
   const double nu_max = A3p / rws * sqrt(VF * VF + C_BOLTZMAN * Te / C_EMASS);                              // numax
   double nu_pl;
   {                                                                                                         // nupl -> coulomb_log -> bMax / bMin
-    const double ftz = 2.0 * (C_HBAR * C_HBAR * pow(3.0 * C_PI * C_PI * (Ni * Z), 2.0 / 3.0) / 2.0 / C_EMASS) / (3.0 * C_BOLTZMAN);
+    const double ftz = TF;                                                            // fermi_T(ni * Z): ni Z = Ne up to the last bit
     const double teff = sqrt(Te * Te + ftz * ftz);
     const double wpl = sqrt((Ni * Z) * C_ECHARGE * C_ECHARGE / C_EMASS / C_ECONST);
     const double bmax = fmax(rws, sqrt(C_BOLTZMAN * teff / (C_EMASS)) / (laser_active ? fmax(omega_las, wpl) : wpl));
     const double bmin = fmax(Z * C_ECHARGE * C_ECHARGE / (C_BOLTZMAN * Te), C_HBAR / sqrt(2 * C_EMASS * C_BOLTZMAN * Te));
     const double coulomb = fmax(2.0, log(bmax / bmin));
-    nu_pl = 1.863839656495274e-40 * Z * Ne * coulomb / pow(C_BOLTZMAN * Te, 1.5);
+    const double kT = C_BOLTZMAN * Te;
+    nu_pl = 1.863839656495274e-40 * Z * Ne * coulomb / (kT * sqrt(kT));
   }
   const double ksi = 0.75 * sqrt(C_PI) * nu_pl / omega_las;
   cpx ebb = c_mk(M.ebb_re, M.ebb_im);
@@ -3092,8 +3103,9 @@ __device__ cpx tmm_epsilon(const TmmDev &M, bool laser_active, double Te, double
 // EE and Runge5 (imd_tmm.c:36-96): |E|^2 inside a layer and its adaptive integral over the layer
 __device__ __forceinline__ double tmm_EE(double z, double delta, cpx kl, cpx Bp, cpx Bm)
 {
-  const cpx e = tmm_eiphi(delta * z, kl);
-  const cpx Ez = c_add(c_mul(Bp, e), c_div(Bm, e));
+  cpx e, ie;
+  tmm_eiphi2(delta * z, kl, &e, &ie);
+  const cpx Ez = c_add(c_mul(Bp, e), c_mul(Bm, ie));
   return Ez.re * Ez.re + Ez.im * Ez.im + 0.0 * 0.0 + 0.0 * 0.0;
 }
 __device__ double tmm_runge5(double delta, cpx kl, cpx Bp, cpx Bm)
@@ -3182,16 +3194,23 @@ __global__ void k_ttm1d_vcom(int nx, double aw, const int *gi, double *gd)
 // stages (bit mask): 1 the tail of update_fd (lattice from the slab sums, step-0 initialisation, virtual-lattice bookkeeping),
 // 2 do_ADV, 4 do_cell_activation + do_FILLMESH + ghost cells, 8 CFL_maxdt and the sub-step count, 16 ONE do_DIFF,
 // 32 do_FILLMESH + ghost cells, 64 the loop (diff_substeps x (do_DIFF, do_FILLMESH, ghosts)), 128 the EOS update of U
-__global__ __launch_bounds__(T1D_MAX) void k_ttm1d_calc(T1dDev D, Lat L, EosDev cve, EosDev ee, int steps, double timestep, int stages)
+// MAXT: threads of the one workgroup (>= ttmdimx + vlatdim): 256 / 512 leave every wave 512 / 256 registers -- the cell's
+// state, the wide-range model and do_tmm's complex arithmetic stay out of scratch memory --, 1024 spills (the loop is
+// latency-bound: 29 us per sub-step with 319 spilled registers against 10 without, 135 active cells)
+template <int MAXT>
+__global__ __launch_bounds__(MAXT) void k_ttm1d_calc(T1dDev D, Lat L, EosDev cve, EosDev ee, int steps, double timestep, int stages)
 {
   // stage 256: ONE do_tmm (the transfer-matrix laser source) on the lattice as it stands
-  __shared__ double sT[T1D_MAX + 2], sK[T1D_MAX + 2], sD[T1D_MAX + 2], sU[T1D_MAX + 2], vT[T1D_MAX], vK[T1D_MAX], red[16];
-  __shared__ int sN[T1D_MAX + 2], ired[16], s_last, s_nsub, s_ecut;
+  __shared__ double sT[MAXT + 2], sK[MAXT + 2], sD[MAXT + 2], sU[MAXT + 2], vT[MAXT], vK[MAXT], red[16];
+  __shared__ int sN[MAXT + 2], ired[16], s_last, s_nsub, s_ecut;
   __shared__ double s_maxdt, s_tmm[8];
   extern __shared__ double sM[];                 // do_tmm: the interface matrices Cinv P (8 doubles each), then Bplus / Bminus in their place
   const int tid = threadIdx.x, nx = D.nx, nv = D.nv, lane = tid & 63, wv = tid >> 6;
-  const bool cellt = tid < nx, vlatt = tid >= nx && tid < nx + nv;
-  const int c = tid + 1, g = tid, vi = tid - nx;                       // lattice index / slab index / virtual-lattice index
+  // the virtual lattice's threads start at a wave boundary: a wave that held cells of both kinds would walk the wide-range
+  // model twice per sub-step (once per branch) and every barrier would wait for it (25 -> 13 us per sub-step)
+  const int vbase = (nx + 63) & ~63;
+  const bool cellt = tid < nx, vlatt = tid >= vbase && tid < vbase + nv;
+  const int c = tid + 1, g = tid, vi = tid - vbase;                    // lattice index / slab index / virtual-lattice index
   int cur = D.sc_i[0], vcur = D.sc_i[1], last_active = D.sc_i[2], vlat_proc = D.sc_i[3], nsub = D.sc_i[4];
   double max_dt = D.sc_d[0];
   double *T[2] = {D.temp0, D.temp1}, *U[2] = {D.U0, D.U1}, *VT[2] = {D.vt0, D.vt1}, *VM[2] = {D.vm0, D.vm1};
@@ -3378,53 +3397,74 @@ __global__ __launch_bounds__(T1D_MAX) void k_ttm1d_calc(T1dDev D, Lat L, EosDev 
     cpx kr = c_mk(0.0, 0.0);
     if (cellt && g < nx - 1) kr = c_mk(sM[8 * (g + 1)], sM[8 * (g + 1) + 1]);
     __syncthreads();
-    if (cellt && g < nx - 1) {                                                        // tmpmat = Cinv P of interface g -> g + 1 (:318-336)
+    cpx p0 = c_mk(1.0, 0.0), p1 = c_mk(0.0, 0.0), p2 = c_mk(0.0, 0.0), p3 = c_mk(1.0, 0.0);
+    const bool iface = cellt && g < nx - 1;
+    if (iface) {                                                                      // tmpmat = Cinv P of interface g -> g + 1 (:318-336)
       const double dx = g == 0 ? 1e10 : D.hx;
-      const cpx e = tmm_eiphi(dx, km), ie = c_div(c_mk(1.0, 0.0), e), r = c_div(c_scale(0.5, km), kr);
+      cpx e, ie;
+      tmm_eiphi2(dx, km, &e, &ie);
+      const cpx r = c_div(c_scale(0.5, km), kr);
       const cpx P0 = e, P2 = ie, P1 = e, P3 = c_neg(ie), C0 = c_mk(0.5, 0.0), C2 = r, C1 = c_mk(0.5, 0.0), C3 = c_neg(r);
-      const cpx t0 = c_add(c_mul(C0, P0), c_mul(C2, P1)), t1 = c_add(c_mul(C1, P0), c_mul(C3, P1));
-      const cpx t2 = c_add(c_mul(C0, P2), c_mul(C2, P3)), t3 = c_add(c_mul(C1, P2), c_mul(C3, P3));
-      double *m = sM + 8 * g;
-      m[0] = t0.re; m[1] = t0.im; m[2] = t1.re; m[3] = t1.im; m[4] = t2.re; m[5] = t2.im; m[6] = t3.re; m[7] = t3.im;
+      p0 = c_add(c_mul(C0, P0), c_mul(C2, P1)); p1 = c_add(c_mul(C1, P0), c_mul(C3, P1));
+      p2 = c_add(c_mul(C0, P2), c_mul(C2, P3)); p3 = c_add(c_mul(C1, P2), c_mul(C3, P3));
     }
+    // E_g = M_g M_(g-1) ... M_0 for every interface at once: an inclusive scan of 2x2 complex products (the reference multiplies
+    // them one after the other, :310-345; the product is associative, the roundings differ in the last bits)
+    double *mine = sM + 8 * g;
+    if (iface) { mine[0] = p0.re; mine[1] = p0.im; mine[2] = p1.re; mine[3] = p1.im; mine[4] = p2.re; mine[5] = p2.im; mine[6] = p3.re; mine[7] = p3.im; }
+    __syncthreads();
+    for (int d = 1; d < nx - 1; d <<= 1) {
+      cpx q0 = c_mk(1.0, 0.0), q1 = c_mk(0.0, 0.0), q2 = c_mk(0.0, 0.0), q3 = c_mk(1.0, 0.0);
+      const bool on = iface && g >= d;
+      if (on) { const double *o = sM + 8 * (g - d); q0 = c_mk(o[0], o[1]); q1 = c_mk(o[2], o[3]); q2 = c_mk(o[4], o[5]); q3 = c_mk(o[6], o[7]); }
+      __syncthreads();
+      if (on) {
+        const cpx n0 = c_add(c_mul(p0, q0), c_mul(p2, q1)), n1 = c_add(c_mul(p1, q0), c_mul(p3, q1));
+        const cpx n2 = c_add(c_mul(p0, q2), c_mul(p2, q3)), n3 = c_add(c_mul(p1, q2), c_mul(p3, q3));
+        p0 = n0; p1 = n1; p2 = n2; p3 = n3;
+        mine[0] = p0.re; mine[1] = p0.im; mine[2] = p1.re; mine[3] = p1.im; mine[4] = p2.re; mine[5] = p2.im; mine[6] = p3.re; mine[7] = p3.im;
+      }
+      __syncthreads();
+    }
+    // reflected / transmitted amplitude behind every interface (:347-348, B0 = 1) and the first one below the threshold (:350-356)
+    cpx BR = c_mk(0.0, 0.0), BT = c_mk(0.0, 0.0);
+    int first = 1 << 30;
+    if (iface) {
+      BR = c_div(c_neg(p1), p3);
+      BT = c_add(p0, c_mul(p2, BR));
+      if (c_abs2(BT) < M.ecut_thresh) first = g;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int t2 = __shfl_down(first, o, 64); first = t2 < first ? t2 : first; }
+    if (lane == 0) ired[wv] = first;
     __syncthreads();
     if (tid == 0) {
-      cpx E0 = c_mk(1.0, 0.0), E1 = c_mk(0.0, 0.0), E2 = c_mk(0.0, 0.0), E3 = c_mk(1.0, 0.0), BR = c_mk(0.0, 0.0), BT = c_mk(0.0, 0.0);
-      const cpx B0 = c_mk(1.0, 0.0);
-      int ecut = 0;
-      for (int i = 0; i < nx - 1; i++) {                                              // :310-358
-        const double *m = sM + 8 * i;
-        const cpx a0 = c_mk(m[0], m[1]), a1 = c_mk(m[2], m[3]), a2 = c_mk(m[4], m[5]), a3 = c_mk(m[6], m[7]);
-        const cpx n0 = c_add(c_mul(a0, E0), c_mul(a2, E1)), n1 = c_add(c_mul(a1, E0), c_mul(a3, E1));
-        const cpx n2 = c_add(c_mul(a0, E2), c_mul(a2, E3)), n3 = c_add(c_mul(a1, E2), c_mul(a3, E3));
-        E0 = n0; E1 = n1; E2 = n2; E3 = n3;
-        BR = c_div(c_mul(c_neg(E1), B0), E3);
-        BT = c_add(c_mul(E0, B0), c_mul(E2, BR));
-        if (c_abs2(BT) < M.ecut_thresh) { ecut = i + 1; break; }
-      }
-      s_ecut = ecut;
-      if (ecut > 0) {
-        const cpx r0 = c_div(BR, B0);
-        M.sc[4] = c_abs2(r0); M.sc[5] = c_abs2(BT); M.sc[6] = 1.0 - c_abs2(r0) - c_abs2(BT); M.sc[7] = (double) ecut;
-        cpx F0 = B0, F1 = BR;                                                         // :377-420: Bplus / Bminus of layer i + 1 into the slot of interface i
-        s_tmm[0] = F0.re; s_tmm[1] = F0.im; s_tmm[2] = F1.re; s_tmm[3] = F1.im;
-        for (int i = 0; i < ecut; i++) {
-          double *m = sM + 8 * i;
-          const cpx a0 = c_mk(m[0], m[1]), a1 = c_mk(m[2], m[3]), a2 = c_mk(m[4], m[5]), a3 = c_mk(m[6], m[7]);
-          const cpx n0 = c_add(c_mul(a0, F0), c_mul(a2, F1)), n1 = c_add(c_mul(a1, F0), c_mul(a3, F1));
-          F0 = n0; F1 = n1;
-          m[0] = F0.re; m[1] = F0.im; m[2] = F1.re; m[3] = F1.im;
-        }
-      } else D.sc_i[5] = 1;                                                           // "Sample is too short for TMM": the host reports it
+      int m = 1 << 30;
+      for (int q = 0; q < (int) (blockDim.x >> 6); q++) m = ired[q] < m ? ired[q] : m;
+      s_ecut = m == (1 << 30) ? 0 : m + 1;
+      if (m == (1 << 30)) D.sc_i[5] = 1;                                              // "Sample is too short for TMM": the host reports it
     }
     __syncthreads();
     const int ecut = s_ecut;
-    if (cellt && g < ecut) {                                                          // :424-441
-      const cpx Bp = g == 0 ? c_mk(s_tmm[0], s_tmm[1]) : c_mk(sM[8 * (g - 1)], sM[8 * (g - 1) + 1]);
-      const cpx Bm = g == 0 ? c_mk(s_tmm[2], s_tmm[3]) : c_mk(sM[8 * (g - 1) + 2], sM[8 * (g - 1) + 3]);
+    if (iface && g == ecut - 1) {
+      s_tmm[0] = 1.0; s_tmm[1] = 0.0; s_tmm[2] = BR.re; s_tmm[3] = BR.im;
+      M.sc[4] = c_abs2(BR); M.sc[5] = c_abs2(BT); M.sc[6] = 1.0 - c_abs2(BR) - c_abs2(BT); M.sc[7] = (double) ecut;      // tmm_refl, tmm_trans, tmm_abs (:366-370)
+    }
+    __syncthreads();
+    if (cellt && g < ecut) {                                                          // amplitudes in layer g: E_(g-1) (B0, BR) (:377-420), then :424-441
+      const cpx F0 = c_mk(s_tmm[0], s_tmm[1]), F1 = c_mk(s_tmm[2], s_tmm[3]);
+      cpx Bp = F0, Bm = F1;
+      if (g > 0) {
+        const double *o = sM + 8 * (g - 1);
+        const cpx a0 = c_mk(o[0], o[1]), a1 = c_mk(o[2], o[3]), a2 = c_mk(o[4], o[5]), a3 = c_mk(o[6], o[7]);
+        Bp = c_add(c_mul(a0, F0), c_mul(a2, F1)); Bm = c_add(c_mul(a1, F0), c_mul(a3, F1));
+      }
       if (M.bf) { M.bf[4 * g] = Bp.re; M.bf[4 * g + 1] = Bp.im; M.bf[4 * g + 2] = Bm.re; M.bf[4 * g + 3] = Bm.im; }
       const double dx = g == 0 ? 1e10 : D.hx;
-      qab = I_t * M.k0 * M.eps[nx + g] * tmm_runge5(dx, km, Bp, Bm);
+      // cells without absorption (vacuum: eps_imag = 0) get 0 x a finite integral; the quadrature of layer 0 (1e10 A of vacuum:
+      // the integrand oscillates 1e6 times) would otherwise halve its step 17 times on one thread for that zero
+      const double ei = M.eps[nx + g];
+      qab = ei == 0.0 ? 0.0 : I_t * M.k0 * ei * tmm_runge5(dx, km, Bp, Bm);
       qab *= 1e10; qab *= 6.3538562638e-26;
     }
     if (ecut > 0 && cellt) src = qab;                                                 // the scatter of tmm_Qabs, entries beyond ecut as earlier calls left them (:448-453)
@@ -3530,7 +3570,8 @@ extern "C" int imdgpu_ttm1d_init(imdgpu_ctx *ctx, const imdgpu_ttm1d_params *par
   if (!ctx->pair.present) return imdgpu_fail(ctx, "ttm1d_init: pair_pot needed (neighvol from pair_pot.end[0])");
   if (ctx->external_halo) return imdgpu_fail(ctx, "ttm1d_init: the 1D TTM serves one rank (the slab sums of several ranks would need an all-reduce per step)");
   if (ctx->ttm) return imdgpu_fail(ctx, "ttm1d_init: a 3D lattice is attached to this context already");
-  if (par->nx < 2 || par->nx + par->vlatdim > T1D_MAX || par->vlatdim < 1) return imdgpu_fail(ctx, "ttm1d_init: 2 <= ttmdimx, 1 <= vlatdim, ttmdimx + vlatdim <= %d", T1D_MAX);
+  if (par->nx < 2 || ((par->nx + 63) & ~63) + par->vlatdim > T1D_MAX || par->vlatdim < 1)
+    return imdgpu_fail(ctx, "ttm1d_init: 2 <= ttmdimx, 1 <= vlatdim, ttmdimx (rounded up to 64) + vlatdim <= %d", T1D_MAX);
   if (par->ref_ranks < 1 || par->nx % par->ref_ranks) return imdgpu_fail(ctx, "ttm1d_init: ttmdimx must be a multiple of ref_ranks (imd_ttm.c:962-965)");
   if (!par->cve_z || !par->ee_z) return imdgpu_fail(ctx, "ttm1d_init: EOS tables missing");
   imdgpu_ttm1d_free(ctx);
@@ -3596,7 +3637,10 @@ extern "C" int imdgpu_ttm1d_stage(imdgpu_ctx *ctx, int steps, int stages)
   ProfScope ps(ctx, PROF_TTM_DIFF);
   if ((stages & 256) && !t->tmm) return imdgpu_fail(ctx, "ttm1d_stage: stage 256 (do_tmm) needs imdgpu_ttm1d_tmm_init");
   const size_t dyn = t->tmm ? (size_t) 8 * t->nx * sizeof(double) : 0;            // the interface matrices of do_tmm
-  hipLaunchKernelGGL(k_ttm1d_calc, dim3(1), dim3(T1D_MAX), dyn, ctx->stream, t1d_dev(t), t->L, t->cve, t->ee, steps, ctx->timestep, stages);
+  const int need = ((t->nx + 63) & ~63) + t->nv;
+  if (need <= 256) hipLaunchKernelGGL((k_ttm1d_calc<256>), dim3(1), dim3(256), dyn, ctx->stream, t1d_dev(t), t->L, t->cve, t->ee, steps, ctx->timestep, stages);
+  else if (need <= 512) hipLaunchKernelGGL((k_ttm1d_calc<512>), dim3(1), dim3(512), dyn, ctx->stream, t1d_dev(t), t->L, t->cve, t->ee, steps, ctx->timestep, stages);
+  else hipLaunchKernelGGL((k_ttm1d_calc<T1D_MAX>), dim3(1), dim3(T1D_MAX), dyn, ctx->stream, t1d_dev(t), t->L, t->cve, t->ee, steps, ctx->timestep, stages);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -3652,7 +3696,9 @@ extern "C" int imdgpu_ttm1d_tmm_init(imdgpu_ctx *ctx, const imdgpu_tmm_params *p
   M.phase.ymin = p->phase.ymin; M.phase.ymax = p->phase.ymax; M.phase.z = t->tmm_phase_z; M.phase.diag = nullptr;
   M.q = t->tmm_q; M.eps = t->tmm_eps; M.sc = t->tmm_sc; M.bf = t->tmm_bf; M.act = t->tmm_act;
   const size_t dyn = (size_t) 8 * nx * sizeof(double);
-  HIPCHK(hipFuncSetAttribute((const void *) k_ttm1d_calc, hipFuncAttributeMaxDynamicSharedMemorySize, (int) dyn));
+  HIPCHK(hipFuncSetAttribute((const void *) k_ttm1d_calc<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) dyn));
+  HIPCHK(hipFuncSetAttribute((const void *) k_ttm1d_calc<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) dyn));
+  HIPCHK(hipFuncSetAttribute((const void *) k_ttm1d_calc<T1D_MAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) dyn));
   t->omega_laser_tmm = M.omega_laser;
   return 0;
 }
