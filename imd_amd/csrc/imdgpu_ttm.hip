@@ -3155,31 +3155,33 @@ __global__ void k_ttm1d_bin(int n, int cap, int ntypes, int steps, double hx, in
       v[3] = m * (ux * ux); v[3] += m * (uy * uy); v[3] += m * (uz * uz);
     }
   }
-  const int g0 = __shfl(g, 0, 64);
-  if (__all(g == g0)) {
-    if (g0 < 0) return;
-    int cnt = 1;
+  // one round per slab present in the wave (atoms are sorted by MD cell: a wave spans two or three slabs): the lanes of that
+  // slab are summed by shuffles (the others contribute zeros), the round's leader adds once per quantity -- hardware
+  // fp64 atomics (a compare-and-swap loop per lane took 1.1 ms for 370 000 atoms: every lane of the chip on ~100 addresses)
+  unsigned long long todo = __ballot(on);
+  while (todo) {
+    const int lead = __ffsll((long long) todo) - 1;
+    const int g0 = __shfl(g, lead, 64);
+    const bool mine = on && g == g0;
+    int cnt = mine ? 1 : 0;
+    double w[4]; int iw[3];
+    for (int q = 0; q < 4; q++) w[q] = mine ? v[q] : 0.0;
+    for (int q = 0; q < 3; q++) iw[q] = mine ? iv[q] : 0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-      cnt += __shfl_down(cnt, o, 64);
-      for (int q = 0; q < 4; q++) v[q] += __shfl_down(v[q], o, 64);
-      for (int q = 0; q < 3; q++) iv[q] += __shfl_down(iv[q], o, 64);
+      cnt += __shfl_xor(cnt, o, 64);
+      for (int q = 0; q < (PHASE == 1 ? 3 : 4); q++) if (PHASE == 1 || q == 3) w[q] += __shfl_xor(w[q], o, 64);
+      if (PHASE == 1) for (int q = 0; q < 3; q++) iw[q] += __shfl_xor(iw[q], o, 64);
     }
-    if ((threadIdx.x & 63) == 0) {
+    if ((int) (threadIdx.x & 63) == lead) {
       if (PHASE == 1) {
-        atomicAdd(&gi[g0], cnt); atomicAdd(&gi[nx + g0], iv[0]);
-        if (iv[1]) atomicAdd(&gi[2 * nx + g0], iv[1]);
-        if (iv[2]) atomicAdd(&gi[3 * nx + g0], iv[2]);
-        atomicAdd(&gd[g0], v[0]); atomicAdd(&gd[nx + g0], v[1]); atomicAdd(&gd[2 * nx + g0], v[2]);
-      } else atomicAdd(&gd[3 * nx + g0], v[3]);
+        atomicAdd(&gi[g0], cnt); atomicAdd(&gi[nx + g0], iw[0]);
+        if (iw[1]) atomicAdd(&gi[2 * nx + g0], iw[1]);
+        if (iw[2]) atomicAdd(&gi[3 * nx + g0], iw[2]);
+        unsafeAtomicAdd(&gd[g0], w[0]); unsafeAtomicAdd(&gd[nx + g0], w[1]); unsafeAtomicAdd(&gd[2 * nx + g0], w[2]);
+      } else unsafeAtomicAdd(&gd[3 * nx + g0], w[3]);
     }
-  } else if (on) {
-    if (PHASE == 1) {
-      atomicAdd(&gi[g], 1); atomicAdd(&gi[nx + g], iv[0]);
-      if (iv[1]) atomicAdd(&gi[2 * nx + g], 1);
-      if (iv[2]) atomicAdd(&gi[3 * nx + g], 1);
-      atomicAdd(&gd[g], v[0]); atomicAdd(&gd[nx + g], v[1]); atomicAdd(&gd[2 * nx + g], v[2]);
-    } else atomicAdd(&gd[3 * nx + g], v[3]);
+    todo &= ~__ballot(mine);
   }
 }
 // v_com = sum p / (natoms * atomic_weight) (:350-372)
