@@ -9,7 +9,7 @@
 # oracle/ref_probe.c, a read-only observation probe attached with ld --wrap.
 #
 # usage: oracle/build_ref.sh [target ...]
-#   targets: eam_nve_nbl  nve_nbl  eam_nve  nve  mpi_eam_nve_nbl  mpi_eam_ttm3d_nbl  mpi_eam_ttm3d_laser_nbl  mpi_eam_ttm1d_nbl  mpi_eam_ttm1d_tmm_nbl  fdtd_probe  tricub_probe  dropin
+#   targets: eam_nve_nbl  nve_nbl  eam_nve  nve  mpi_eam_nve_nbl  mpi_eam_ttm3d_nbl  mpi_eam_ttm3d_laser_nbl  mpi_eam_ttm1d_nbl  mpi_eam_ttm1d_tmm_nbl  mpi_eam_ttm1d_tmm_ep_nbl  fdtd_probe  tricub_probe  dropin
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 REF="${IMD_REFERENCE:-/root/reference}"
@@ -60,7 +60,7 @@ build() {
   echo "built $OUT/imd_$name"
 }
 
-TARGETS="${*:-eam_nve_nbl nve_nbl eam_nve mpi_eam_nve_nbl mpi_eam_ttm3d_nbl mpi_eam_ttm3d_laser_nbl mpi_eam_ttm1d_nbl mpi_eam_ttm1d_tmm_nbl fdtd_probe tricub_probe dropin}"
+TARGETS="${*:-eam_nve_nbl nve_nbl eam_nve mpi_eam_nve_nbl mpi_eam_ttm3d_nbl mpi_eam_ttm3d_laser_nbl mpi_eam_ttm1d_nbl mpi_eam_ttm1d_tmm_nbl mpi_eam_ttm1d_tmm_ep_nbl fdtd_probe tricub_probe dropin}"
 for t in $TARGETS; do
   case "$t" in
     eam_nve_nbl) build "$t" "-DNBL -DEAM2 -DNVE" "$COMMON $NBLSRC" "$CC" "" ;;
@@ -95,6 +95,14 @@ for t in $TARGETS; do
       MPIINC="${MPI_HOME:-/opt/conda}"
       if [ ! -f "$MPIINC/include/mpi.h" ]; then echo "no MPI at $MPIINC, skipping $t" >&2; continue; fi
       build "$t" "-DMPI -DNBL -DEAM2 -DTTM -DTMM -DTTM1D" \
+            "$COMMON $NBLSRC imd_mpi_util.c imd_ttm.c imd_interpol.c fminbnd3.c imd_tmm.c" \
+            "$CC -I$MPIINC/include" "-L$MPIINC/lib -Wl,-rpath,$MPIINC/lib -lmpi" ;;
+    mpi_eam_ttm1d_tmm_ep_nbl)
+      # the same with -DELECPRESS (commented out in imd_ttm.c:60 and imd_integrate.c:25: the command line defines it for both):
+      # do_electronic_pressure (imd_ttm.c:553-623) and the extra force of move_atoms_ttm (imd_integrate.c:657-743)
+      MPIINC="${MPI_HOME:-/opt/conda}"
+      if [ ! -f "$MPIINC/include/mpi.h" ]; then echo "no MPI at $MPIINC, skipping $t" >&2; continue; fi
+      build "$t" "-DMPI -DNBL -DEAM2 -DTTM -DTMM -DTTM1D -DELECPRESS" \
             "$COMMON $NBLSRC imd_mpi_util.c imd_ttm.c imd_interpol.c fminbnd3.c imd_tmm.c" \
             "$CC -I$MPIINC/include" "-L$MPIINC/lib -Wl,-rpath,$MPIINC/lib -lmpi" ;;
     mpi_eam_ttm3d_laser_nbl)

@@ -608,7 +608,10 @@ class _Ttm1d(C.Structure):
                [(k, C.POINTER(C.c_double)) for k in ("eps_re", "eps_im", "qabs", "eps_bb", "K12")] + \
                [("tmm_active", C.POINTER(C.c_int)), ("km", C.c_void_p), ("phase_nx", C.c_int), ("phase_ny", C.c_int)] + \
                [(k, C.c_double) for k in ("phase_xmin", "phase_xmax", "phase_ymin", "phase_ymax")] + \
-               [("phase_z", C.POINTER(C.c_double)), ("phase_diag", C.c_void_p)]
+               [("phase_z", C.POINTER(C.c_double)), ("phase_diag", C.c_void_p)] + \
+               [("ep_on", C.c_int), ("box_xx", C.c_double), ("epress", C.POINTER(C.c_double)), ("epress_deriv", C.POINTER(C.c_double)),
+                ("pe_nx", C.c_int), ("pe_ny", C.c_int)] + [(k, C.c_double) for k in ("pe_xmin", "pe_xmax", "pe_ymin", "pe_ymax")] + \
+               [("pe_z", C.POINTER(C.c_double)), ("pe_diag", C.c_void_p)]
 
 
 class OracleTTM1D:
@@ -694,6 +697,20 @@ class OracleTTM1D:
         for k in ("eps_re", "eps_im", "qabs"):
             setattr(self, k, aa(getattr(self.t, k), (self.nx,)))
         self.tmm_active = aa(self.t.tmm_active, (self.nx,))
+
+    def set_epress(self, pe):
+        """-DELECPRESS: the table of EOS_pe_from_r_te (Pa) as dict(x, y, z)"""
+        L = self.L
+        dp = C.POINTER(C.c_double)
+        L.orc_ttm1d_set_epress.argtypes = [C.POINTER(_Ttm1d), C.c_int, C.c_int, dp, dp]
+        L.orc_ttm1d_elec_pressure.argtypes = [C.POINTER(_Ttm1d), C.c_int]
+        pz = np.ascontiguousarray(pe["z"], np.float64).reshape(-1)
+        rng = np.array([pe["x"][0], pe["x"][-1], pe["y"][0], pe["y"][-1]], np.float64)
+        L.orc_ttm1d_set_epress(self._p, len(pe["x"]), len(pe["y"]), _dp(rng), _dp(pz))
+        aa = np.ctypeslib.as_array
+        self.epress = aa(self.t.epress, (self.nx,)); self.epress_deriv = aa(self.t.epress_deriv, (self.nx,))
+
+    def elec_pressure(self, steps): self.L.orc_ttm1d_elec_pressure(self._p, int(steps))
 
     def do_tmm(self, steps):
         rc = self.L.orc_ttm1d_do_tmm(self._p, int(steps))

@@ -132,6 +132,19 @@ void __wrap_calc_ttm(void)
     if (dumping && i == 0) dump_stage("substep1");
   }
   MPI_Allgather(&xiarr_local[1], local_fd_dim.x - 2, MPI_DOUBLE, &xiarr_global[0], local_fd_dim.x - 2, MPI_DOUBLE, cpugrid);   /* :110-111 */
+#ifdef ELECPRESS
+  do_electronic_pressure();                                                                                                        /* :127-129 */
+  if (dumping) {                                      /* epress_global (all-reduced) and this rank's share of epress_deriv */
+    char fn[1024];
+    const char *dir = getenv("IMD_PROBE_DIR");
+    FILE *ef;
+    sprintf(fn, "%s/epress.%d.%d.bin", dir ? dir : ".", myid, steps);
+    ef = fopen(fn, "wb");
+    fwrite(epress_global, sizeof(double), global_fd_dim.x, ef);
+    fwrite(epress_deriv, sizeof(double), global_fd_dim.x, ef);
+    fclose(ef);
+  }
+#endif
   tot_elec_energy_local = 0;                                                                                                       /* :119-133 */
   for (i = 1; i < local_fd_dim.x - 1; ++i)
     if (l1[i].natoms >= fd_min_atoms && l1[i].dens >= 2 /* RHOMIN */) {

@@ -44,6 +44,11 @@ typedef struct {
   int *tmm_active;
   double complex *km;
   orc_eos phase;
+  /* electron pressure (-DELECPRESS): do_electronic_pressure (:553-623) and move_atoms_ttm's extra force */
+  int ep_on;
+  double box_xx;
+  double *epress, *epress_deriv;
+  orc_eos pe;
 } orc_ttm1d;
 
 static void *za(size_t n, size_t s) { void *p = calloc(n ? n : 1, s); if (!p) abort(); return p; }
@@ -57,6 +62,7 @@ orc_ttm1d *orc_ttm1d_new(int nx, double box_xx, double box_yy, double box_zz, in
   t->nx = nx; t->nranks = nranks; t->vlatdim = vlatdim; t->vlatbuffer = vlatbuffer; t->vlatdens = vlatdens;
   t->fd_min_atoms = fd_min_atoms; t->fd_n_timesteps = fd_n_timesteps; t->aw = atomic_weight; t->ac = atomic_charge;
   t->hx = box_xx / nx; t->vol = t->hx * box_yy * box_zz;                                    /* init_ttm :972-976 */
+  t->box_xx = box_xx;
   t->neighvol = pow(sqrt(r2_cut_pair), 3.0) * 4.0 / 3.0 * M_PI;                           /* :979 */
   t->max_dt_ttm = timestep / (double) fd_n_timesteps;                                     /* :978 */
   t->Temin = 1e-3; t->eos = eos_holder; t->last_active = -5000; t->vlat_proc = 0;
@@ -79,6 +85,7 @@ void orc_ttm1d_free(orc_ttm1d *t)
   for (q = 0; q < (int) (sizeof p / sizeof p[0]); q++) free(p[q]);
   for (q = 0; q < 2; q++) { free(t->temp[q]); free(t->U[q]); free(t->vtemp[q]); free(t->vmd[q]); }
   for (q = 0; q < 3; q++) free(t->vcom[q]);
+  if (t->ep_on) { free(t->epress); free(t->epress_deriv); free(t->pe.z); }
   if (t->tmm_on) { free(t->eps_re); free(t->eps_im); free(t->qabs); free(t->tmm_active); free(t->km); free(t->eps_bb); free(t->K12); free(t->phase.z); }
   free(t);
 }
@@ -281,6 +288,7 @@ void orc_ttm1d_diff(orc_ttm1d *t, double tau)
 }
 
 int orc_ttm1d_do_tmm(orc_ttm1d *t, int steps);
+void orc_ttm1d_elec_pressure(orc_ttm1d *t, int steps);
 /* calc_ttm (:75-155); returns the number of sub-steps */
 int orc_ttm1d_calc(orc_ttm1d *t, int steps, double timestep, int n, const double *ort, const int *sorte, const double *impuls,
                    const double *masse, const int *numneighs, int *fdi)
@@ -301,6 +309,7 @@ int orc_ttm1d_calc(orc_ttm1d *t, int steps, double timestep, int n, const double
     t->tmm_time += tau * 10.18 * 1.0e-15;
     orc_ttm1d_diff(t, tau); orc_ttm1d_fillmesh(t, steps); orc_ttm1d_fill_ghosts(t);
   }
+  if (t->ep_on) orc_ttm1d_elec_pressure(t, steps);                                        /* :127-129 */
   for (g = 1; g <= t->nx; g++)                                                             /* :119-133 */
     if (t->natoms[g] >= t->fd_min_atoms && t->dens[g] >= RHOMIN)
       t->U[0][g] = t->U[1][g] = orc_eos_ee(t->eos, t->dens[g], t->temp[t->cur][g] * 11604.5) * 26.9815 * AMU * J2EV;
@@ -318,6 +327,14 @@ double orc_ttm1d_move_atoms(const orc_ttm1d *t, double timestep, int n, double *
     if (!sorte || sorte[a] == 0) { const int g = slab(t, ort[3 * a]); xi = t->xiarr[g]; for (d = 0; d < 3; d++) vc[d] = t->vcom[d][g]; }
     for (d = 0; d < 3; d++) e1 += impuls[3 * a + d] * impuls[3 * a + d];
     for (d = 0; d < 3; d++) impuls[3 * a + d] += timestep * (kraft[3 * a + d] + xi * masse[a] * (impuls[3 * a + d] / masse[a] - vc[d]));
+    if (t->ep_on && (!sorte || sorte[a] == 0)) {                                           /* imd_integrate.c:657-659,741-743 */
+      /* every rank of the reference fills epress_deriv for ITS share of the row only (:596-620): an atom feels the force if
+         the rank that owns it also owns its slab (nranks = how the reference run was cut; ownership taken from the position) */
+      const int g = slab(t, ort[3 * a]);
+      int md_rank = (int) (ort[3 * a] / (t->box_xx / t->nranks));
+      md_rank = md_rank < 0 ? 0 : md_rank > t->nranks - 1 ? t->nranks - 1 : md_rank;
+      if (md_rank == g / (t->nx / t->nranks)) impuls[3 * a] -= timestep * t->epress_deriv[g];
+    }
     for (d = 0; d < 3; d++) e2 += impuls[3 * a + d] * impuls[3 * a + d];
     ekin += (e1 + e2) / (4 * masse[a]);
     tmp = timestep / masse[a];
@@ -491,4 +508,34 @@ int orc_ttm1d_do_tmm(orc_ttm1d *t, int steps)
   t->ecut = ecut;
   for (g = 0; g < nx; g++) t->source[g + 1] = t->qabs[g];                                   /* scatter, :448-453 */
   return 0;
+}
+
+
+/* ---- electron pressure (-DELECPRESS): do_electronic_pressure, :553-623; EOS_pe_from_r_te, :2638-2693 (table in Pa) ---------- */
+void orc_ttm1d_set_epress(orc_ttm1d *t, int pnx, int pny, const double *prange, const double *pz)
+{
+  t->ep_on = 1;
+  t->epress = za(t->nx, 8); t->epress_deriv = za(t->nx, 8);
+  t->pe.nx = pnx; t->pe.ny = pny; t->pe.xmin = prange[0]; t->pe.xmax = prange[1]; t->pe.ymin = prange[2]; t->pe.ymax = prange[3];
+  t->pe.z = za((size_t) pnx * pny, 8); memcpy(t->pe.z, pz, 8 * (size_t) pnx * pny); t->pe.diag = NULL;
+}
+void orc_ttm1d_elec_pressure(orc_ttm1d *t, int steps)
+{
+  const int nx = t->nx, c0 = t->cur;
+  int g;
+  for (g = 0; g < nx; g++) { t->epress[g] = 0.0; t->epress_deriv[g] = 0.0; }
+  for (g = 0; g < nx; g++) {
+    const int c = g + 1;
+    double r, tt;
+    if (t->dens[c] < RHOMIN || t->natoms[c] < t->fd_min_atoms) continue;
+    if (g > t->last_active) continue;
+    r = t->dens[c]; tt = t->temp[c0][c] * 11604.5;
+    r = r > t->pe.xmax ? t->pe.xmax : r; r = r < t->pe.xmin ? t->pe.xmin : r;
+    tt = tt > t->pe.ymax ? t->pe.ymax : tt; tt = tt < t->pe.ymin ? t->pe.ymin : tt;
+    t->epress[g] = orc_eos_lookup(&t->pe, r, tt) * 6.242e-12;                               /* Pa -> eV/A^3, :2692 */
+  }
+  for (g = 1; g < nx - 1; g++) {
+    if (g > t->last_active) continue;
+    if (steps > 1) t->epress_deriv[g] = (t->epress[g + 1] - t->epress[g - 1]) / 2.0 / t->hx / (t->natoms[g + 1] / t->vol);
+  }
 }

@@ -571,7 +571,14 @@ def read_tmm_probe(path):
     return dict(nx=n, nlocal=nl, nsub=int(hd[2]), k0=hd[3], omega_laser=hd[4], tmm_time=hd[5], hx=hd[6], abs_threshold=hd[7], subs=recs)
 
 
-def run_ttm1d_case(tmm=False):
+def epress_table(eos):
+    """EOS_pe_from_r_te stand-in [Pa; the look-up converts to eV/A^3, imd_ttm.c:2692], planar in (rho, Te): 4.8 GPa at solid
+    density and 1000 K -- a pressure whose gradient across the slab's surfaces pushes on the atoms there with a few 0.01 eV/A"""
+    R, T = np.meshgrid(eos["r"], eos["t"], indexing="ij")
+    return dict(x=eos["r"], y=eos["t"], z=1.9e6 * R - 9.6e8 + 6.4e5 * T)
+
+
+def run_ttm1d_case(tmm=False, ep=False):
     """imd_ttm.c's own 1D TTM (the file the reference's Makefile builds): oracle/_ref/imd_mpi_eam_ttm1d_nbl on TWO ranks (its
     ttm_fill_ghost_layers and do_COMMFLUX have no one-rank branch), a slab with vacuum on both x sides, do_ADV on; the
     lattice rows of both ranks assembled into the global row, stage by stage (oracle/ref_probe_ttm1d.c), the global slab
@@ -579,7 +586,10 @@ def run_ttm1d_case(tmm=False):
     tmm: the build with the reference's own transfer-matrix laser source (imd_tmm.c; oracle/_ref/imd_mpi_eam_ttm1d_tmm_nbl):
     do_tmm at the top of every sub-step as in calc_ttm (:113), a 19 fs pulse peaking at 6 fs, on a longer slab; synthetic
     alu_eps_bb.dat / K12.dat / phase table (imd_amd/tmm.py) -> ttm1d_tmm_slab.npz with do_tmm's arrays after sub-steps 0, 1, last."""
-    if tmm:
+    if ep:
+        tmm = True
+        name, steps, dump = "ttm1d_ep_slab", 8, [0, 1, 2, 3, 4, 8]
+    elif tmm:
         name, steps, dump = "ttm1d_tmm_slab", 12, [0, 1, 2, 3, 8, 12]
     else:
         name, steps, dump = "ttm1d_slab", 20, [0, 1, 2, 8, 9, 20]
@@ -600,6 +610,8 @@ def run_ttm1d_case(tmm=False):
         from imd_amd import ttm as ttm_mod
         phase = tmm_phase_table(eos) if tmm else dict(x=eos["r"], y=eos["t"], z=np.ones((len(eos["r"]), len(eos["t"]))))
         ttm_mod.write_eos_table(os.path.join(top, "EOS_phase_from_r_ti.txt"), phase)
+        if ep:
+            ttm_mod.write_eos_table(os.path.join(top, "EOS_pe_from_r_te.txt"), epress_table(eos))
         if tmm:
             from imd_amd import tmm as tmm_mod
             tmm_mod.write_arr(os.path.join(top, "alu_eps_bb.dat"), tmm_mod.synthetic_eps_bb())
@@ -608,15 +620,23 @@ def run_ttm1d_case(tmm=False):
         env = dict(os.environ, IMD_PROBE_DIR=d, IMD_PROBE_STEPS=",".join(map(str, dump)), IMD_PROBE_ADV="1")
         if tmm:
             env["IMD_PROBE_TMM"] = "1"
-        r = subprocess.run([MPIEXEC, "-n", "2", os.path.join(REFBIN, "imd_mpi_eam_ttm1d_tmm_nbl" if tmm else "imd_mpi_eam_ttm1d_nbl"), "-p", "t.param"],
+        exe = "imd_mpi_eam_ttm1d_tmm_ep_nbl" if ep else "imd_mpi_eam_ttm1d_tmm_nbl" if tmm else "imd_mpi_eam_ttm1d_nbl"
+        r = subprocess.run([MPIEXEC, "-n", "2", os.path.join(REFBIN, exe), "-p", "t.param"],
                            cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             print(r.stdout[-3000:]); raise SystemExit("reference run failed for %s" % name)
         T = {s: [po.read_ttm1d_probe(os.path.join(d, "ttm1d.%d.%d.bin" % (rk, s))) for rk in (0, 1)] for s in dump}
         P = {s: [po.read_probe(os.path.join(d, "probe.%d.%d.bin" % (rk, s))) for rk in (0, 1)] for s in dump}
         M = {s: [read_tmm_probe(os.path.join(d, "tmm.%d.%d.bin" % (rk, s))) for rk in (0, 1)] for s in dump} if tmm else None
+        E = {s: [np.fromfile(os.path.join(d, "epress.%d.%d.bin" % (rk, s))).reshape(2, -1) for rk in (0, 1)] for s in dump} if ep else None
     T0, P0 = T[0][0], P[0][0]
     out = dict(case=name, param_file=par, steps=np.array(dump), ref_ranks=2)
+    if ep:
+        out["epress_z"] = epress_table(eos)["z"]
+        for s in dump:                                   # epress_global is all-reduced; every rank computes epress_deriv for ITS share of the row only (:596-620)
+            assert np.array_equal(E[s][0][0], E[s][1][0])
+            out["e%d_epress_global" % s] = E[s][0][0]
+            out["e%d_epress_deriv_rank0" % s] = E[s][0][1]; out["e%d_epress_deriv_rank1" % s] = E[s][1][1]
     if tmm:
         from imd_amd import tmm as tmm_mod
         for k, v in TMM_CASE.items():
@@ -825,7 +845,7 @@ def run_ttm_file_case():
 
 
 if __name__ == "__main__":
-    names = sys.argv[1:] or (list(CASES) + ["eos_inverse", "eos_grid", "fdtd_1d", "chkpt", "ttm_file", "ttm1d_slab", "ttm1d_tmm_slab", "tricub"])
+    names = sys.argv[1:] or (list(CASES) + ["eos_inverse", "eos_grid", "fdtd_1d", "chkpt", "ttm_file", "ttm1d_slab", "ttm1d_tmm_slab", "ttm1d_ep_slab", "tricub"])
     for n in names:
         if n == "eos_inverse":
             run_eos_inverse()
@@ -843,6 +863,8 @@ if __name__ == "__main__":
             run_ttm1d_case()
         elif n == "ttm1d_tmm_slab":
             run_ttm1d_case(tmm=True)
+        elif n == "ttm1d_ep_slab":
+            run_ttm1d_case(ep=True)
         elif n == "tricub":
             run_tricub_case()
         elif n.endswith("_mpi8"):
