@@ -2979,6 +2979,8 @@ struct Ttm1dState {
   double *cve_z = nullptr, *ee_z = nullptr;
   EosDev cve{}, ee{};
   Lat L{};
+  EosDev pe{}; double *pe_z = nullptr; int ep_on = 0;                  // -DELECPRESS: EOS_pe_from_r_te's table (imdgpu_ttm1d_set_epress)
+  double box_xx = 0;
   struct TmmDev *tmm = nullptr;                                       // transfer-matrix laser source (imdgpu_ttm1d_tmm_init), host copy
   double omega_laser_tmm = 0;
   double *tmm_K12 = nullptr, *tmm_phase_z = nullptr, *tmm_q = nullptr, *tmm_eps = nullptr, *tmm_sc = nullptr, *tmm_bf = nullptr;
@@ -2994,8 +2996,9 @@ struct TmmDev {
   int *act;                          // [nx]
 };
 struct T1dDev {
-  int nx, nv, fd_min_atoms, fd_n, vlatbuffer, ref_ranks;
+  int nx, nv, fd_min_atoms, fd_n, vlatbuffer, ref_ranks, ep_on;
   double hx, vol, neighvol, aw, vlatdens, Temin;
+  EosDev pe;
   TmmDev M;
   int *natoms, *natoms_old;
   double *temp0, *temp1, *U0, *U1, *xi, *md_temp, *source, *dens, *fd_k, *fd_g, *Z, *Ce, *ne;
@@ -3480,6 +3483,21 @@ __global__ __launch_bounds__(MAXT) void k_ttm1d_calc(T1dDev D, Lat L, EosDev cve
     if (M.on) { tmm(); tmm_time += tau * 10.18 * 1.0e-15; }                           // imd_ttm.c:113-117
     diff(tau); fillmesh(); publish();
   }
+  // ---- -DELECPRESS: do_electronic_pressure after the loop (:127-129, 553-623), part of stage 128 --------------------------
+  // pressure of every active cell from the EOS, its centred difference per atom density -> gd[6 nx + g] for move_atoms_ttm
+  if ((stages & 128) && D.ep_on) {
+    __syncthreads();
+    double pr = 0.0;
+    if (cellt && !(dn < T1D_RHOMIN || nat < amin) && !(g > last_active)) pr = eos_lookup(D.pe, dn, Te * 11604.5) * 6.242e-12;
+    if (cellt) { sT[c] = pr; D.gd[5 * nx + g] = pr; }
+    __syncthreads();
+    if (cellt) {
+      double dv = 0.0;
+      if (g >= 1 && g < nx - 1 && !(g > last_active) && steps > 1) dv = (sT[c + 1] - sT[c - 1]) / 2.0 / D.hx / ((double) nat / D.vol);
+      D.gd[6 * nx + g] = dv;
+    }
+    __syncthreads();
+  }
   // ---- stage 128: U from the EOS after the loop (:119-133) ------------------------------------------------------------
   if ((stages & 128) && cellt && nat >= amin && dn >= T1D_RHOMIN) { u = eos_ee(ee, dn, Te * 11604.5) * AMU_J2EV; u2 = u; }
   // ---- back to memory -------------------------------------------------------------------------------------------------
@@ -3500,8 +3518,11 @@ __global__ __launch_bounds__(MAXT) void k_ttm1d_calc(T1dDev D, Lat L, EosDev cve
 
 // move_atoms_ttm, the TTM1D branch (imd_integrate.c:649-760) + check_nblist: xi and v_com of the slab the atom is in now
 __global__ void k_move_ttm1d(int n, int cap, int ntypes, double hx, int nx, double4 *pos, const int *type, double *p, double *f, const double *mass,
-                             const double *restr, double dt, const double *ref, const double *gd, double *partials)
+                             const double *restr, double dt, const double *ref, const double *gd, double *partials, int ep_ranks, double box_xx)
 {
+  // ep_ranks > 0: -DELECPRESS, the pressure force of the atom's slab (imd_integrate.c:657-659,741-743).  Every rank of the
+  // reference fills epress_deriv for ITS share of the row only (imd_ttm.c:596-620), so an atom feels the force if the rank that
+  // owns it also owns its slab: ep_ranks says how the run to be reproduced was cut (1: every atom)
   __shared__ double scratch[2 * 16];
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   double s0 = 0, s1 = 0;
@@ -3509,8 +3530,15 @@ __global__ void k_move_ttm1d(int n, int cap, int ntypes, double hx, int nx, doub
     const size_t c1 = cap, c2 = 2 * (size_t) cap;
     double4 q = pos[i];
     const int t = ntypes == 1 ? 0 : type[i];
-    double fxi = 0, vx = 0, vy = 0, vz = 0;
-    if (t == 0) { const int g = t1d_slab(q.x, hx, nx); fxi = gd[4 * nx + g]; vx = gd[g]; vy = gd[nx + g]; vz = gd[2 * nx + g]; }
+    double fxi = 0, vx = 0, vy = 0, vz = 0, epf = 0;
+    if (t == 0) {
+      const int g = t1d_slab(q.x, hx, nx); fxi = gd[4 * nx + g]; vx = gd[g]; vy = gd[nx + g]; vz = gd[2 * nx + g];
+      if (ep_ranks > 0) {
+        int mdr = (int) (q.x / (box_xx / ep_ranks));
+        mdr = mdr < 0 ? 0 : mdr > ep_ranks - 1 ? ep_ranks - 1 : mdr;
+        if (mdr == g / (nx / ep_ranks)) epf = gd[6 * nx + g];
+      }
+    }
     double fx = f[i], fy = f[c1 + i], fz = f[c2 + i];
     double px = p[i], py = p[c1 + i], pz = p[c2 + i], m = mass[i];
     const double e1 = px * px + py * py + pz * pz;
@@ -3518,6 +3546,7 @@ __global__ void k_move_ttm1d(int n, int cap, int ntypes, double hx, int nx, doub
     px += dt * (fx + fxi * m * (px / m - vx));
     py += dt * (fy + fxi * m * (py / m - vy));
     pz += dt * (fz + fxi * m * (pz / m - vz));
+    if (ep_ranks > 0 && t == 0) px -= dt * epf;
     const double e2 = px * px + py * py + pz * pz;
     s0 = (e1 + e2) / (4 * m);
     const double tmp = dt / m;
@@ -3547,7 +3576,7 @@ void imdgpu_ttm1d_free(imdgpu_ctx *ctx)
   void *p[] = {t->natoms, t->natoms_old, t->temp[0], t->temp[1], t->U[0], t->U[1], t->xi, t->md_temp, t->source, t->dens, t->fd_k, t->fd_g, t->Z, t->Ce,
                t->ne, t->gi, t->gd, t->vt[0], t->vt[1], t->vm[0], t->vm[1], t->vk, t->vg, t->vCe, t->vZ, t->vne, t->sc_i, t->sc_d, t->cve_z, t->ee_z};
   for (void *q : p) if (q) (void) hipFree(q);
-  void *p2[] = {t->tmm_K12, t->tmm_phase_z, t->tmm_q, t->tmm_eps, t->tmm_sc, t->tmm_bf, t->tmm_act};
+  void *p2[] = {t->tmm_K12, t->tmm_phase_z, t->tmm_q, t->tmm_eps, t->tmm_sc, t->tmm_bf, t->tmm_act, t->pe_z};
   for (void *q : p2) if (q) (void) hipFree(q);
   delete t->tmm;
   delete t;
@@ -3563,6 +3592,7 @@ static T1dDev t1d_dev(const Ttm1dState *t)
   D.gi = t->gi; D.gd = t->gd; D.vt0 = t->vt[0]; D.vt1 = t->vt[1]; D.vm0 = t->vm[0]; D.vm1 = t->vm[1]; D.vk = t->vk; D.vg = t->vg; D.vCe = t->vCe;
   D.vZ = t->vZ; D.vne = t->vne; D.sc_i = t->sc_i; D.sc_d = t->sc_d;
   if (t->tmm) D.M = *t->tmm; else { memset(&D.M, 0, sizeof D.M); }
+  D.ep_on = t->ep_on; D.pe = t->pe;
   return D;
 }
 extern "C" int imdgpu_ttm1d_init(imdgpu_ctx *ctx, const imdgpu_ttm1d_params *par)
@@ -3582,12 +3612,13 @@ extern "C" int imdgpu_ttm1d_init(imdgpu_ctx *ctx, const imdgpu_ttm1d_params *par
   t->nx = par->nx; t->nv = par->vlatdim; t->fd_min_atoms = par->fd_min_atoms; t->fd_n = par->fd_n_timesteps; t->vlatbuffer = par->vlatbuffer;
   t->ref_ranks = par->ref_ranks; t->adv = par->adv; t->aw = par->atomic_weight; t->ac = par->atomic_charge; t->vlatdens = par->vlatdens;
   t->hx = ctx->box[0] / par->nx; t->vol = t->hx * ctx->box[4] * ctx->box[8];                          // init_ttm :972-976
+  t->box_xx = ctx->box[0];
   t->neighvol = pow(sqrt(ctx->pair.par.end[0]), 3.0) * 4.0 / 3.0 * M_PI;                              // :979
   const size_t n2 = (size_t) t->nx + 2, nv = t->nv;
   if (dev_alloc(ctx, &t->natoms, n2) || dev_alloc(ctx, &t->natoms_old, n2) || dev_alloc(ctx, &t->xi, n2) || dev_alloc(ctx, &t->md_temp, n2) ||
       dev_alloc(ctx, &t->source, n2) || dev_alloc(ctx, &t->dens, n2) || dev_alloc(ctx, &t->fd_k, n2) || dev_alloc(ctx, &t->fd_g, n2) ||
       dev_alloc(ctx, &t->Z, n2) || dev_alloc(ctx, &t->Ce, n2) || dev_alloc(ctx, &t->ne, n2) || dev_alloc(ctx, &t->gi, 4 * (size_t) t->nx) ||
-      dev_alloc(ctx, &t->gd, 5 * (size_t) t->nx) || dev_alloc(ctx, &t->vk, nv) || dev_alloc(ctx, &t->vg, nv) || dev_alloc(ctx, &t->vCe, nv) ||
+      dev_alloc(ctx, &t->gd, 7 * (size_t) t->nx) || dev_alloc(ctx, &t->vk, nv) || dev_alloc(ctx, &t->vg, nv) || dev_alloc(ctx, &t->vCe, nv) ||
       dev_alloc(ctx, &t->vZ, nv) || dev_alloc(ctx, &t->vne, nv) || dev_alloc(ctx, &t->sc_i, 8) || dev_alloc(ctx, &t->sc_d, 8)) return 1;
   for (int q = 0; q < 2; q++) if (dev_alloc(ctx, &t->temp[q], n2) || dev_alloc(ctx, &t->U[q], n2) || dev_alloc(ctx, &t->vt[q], nv) || dev_alloc(ctx, &t->vm[q], nv)) return 1;
   void *zi[] = {t->natoms, t->natoms_old}; for (void *p : zi) HIPCHK(hipMemset(p, 0, n2 * sizeof(int)));
@@ -3737,9 +3768,38 @@ int imdgpu_ttm1d_move_internal(imdgpu_ctx *ctx)
   const double h = 0.5 * ctx->nbl_margin;
   ProfScope ps(ctx, PROF_INTEGRATE);
   hipLaunchKernelGGL(k_move_ttm1d, dim3(nb), dim3(256), 0, ctx->stream, n, ctx->cap_local, ctx->ntypes, t->hx, t->nx, ctx->pos, ctx->type, ctx->p, ctx->f,
-                     ctx->mass, ctx->restr_identity ? nullptr : ctx->d_restr, ctx->timestep, ctx->ref, t->gd, ctx->partials);
+                     ctx->mass, ctx->restr_identity ? nullptr : ctx->d_restr, ctx->timestep, ctx->ref, t->gd, ctx->partials,
+                     t->ep_on ? t->ref_ranks : 0, t->box_xx);
   hipLaunchKernelGGL(k_reduce_move, dim3(1), dim3(1024), 0, ctx->stream, nb, ctx->partials, ctx->d_sums, h * h, ctx->d_counters, 1);
   HIPCHK(hipGetLastError());
+  return 0;
+}
+// -DELECPRESS [EOS_pe_from_r_te's table, imd_ttm.c:1133-1135,2638-2693, in Pa]: from now on calc_ttm ends with
+// do_electronic_pressure (:127-129) and move_atoms_ttm adds the pressure force; z = NULL switches it off again
+extern "C" int imdgpu_ttm1d_set_epress(imdgpu_ctx *ctx, int nx, int ny, double xmin, double xmax, double ymin, double ymax, const double *z)
+{
+  NEED_T1D();
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (t->pe_z) { (void) hipFree(t->pe_z); t->pe_z = nullptr; }
+  t->ep_on = 0;
+  if (!z) return 0;
+  if (nx < 2 || ny < 2) return imdgpu_fail(ctx, "ttm1d_set_epress: a table of at least 2 x 2 nodes");
+  if (dev_alloc(ctx, &t->pe_z, (size_t) nx * ny)) return 1;
+  HIPCHK(hipMemcpy(t->pe_z, z, (size_t) nx * ny * sizeof(double), hipMemcpyHostToDevice));
+  t->pe.nx = nx; t->pe.ny = ny; t->pe.xmin = xmin; t->pe.xmax = xmax; t->pe.ymin = ymin; t->pe.ymax = ymax; t->pe.z = t->pe_z; t->pe.diag = nullptr;
+  HIPCHK(hipMemset(t->gd + 5 * (size_t) t->nx, 0, 2 * (size_t) t->nx * sizeof(double)));
+  t->ep_on = 1;
+  return 0;
+}
+// epress_global and epress_deriv [ttmdimx values each] as the last calc_ttm left them
+extern "C" int imdgpu_ttm1d_epress_get(imdgpu_ctx *ctx, double *epress, double *epress_deriv)
+{
+  NEED_T1D();
+  if (!t->ep_on) return imdgpu_fail(ctx, "ttm1d_epress_get: imdgpu_ttm1d_set_epress first");
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (ctx->step_open) HIPCHK(hipStreamSynchronize(ctx->stream2));
+  if (epress) HIPCHK(hipMemcpy(epress, t->gd + 5 * (size_t) t->nx, t->nx * sizeof(double), hipMemcpyDeviceToHost));
+  if (epress_deriv) HIPCHK(hipMemcpy(epress_deriv, t->gd + 6 * (size_t) t->nx, t->nx * sizeof(double), hipMemcpyDeviceToHost));
   return 0;
 }
 extern "C" int imdgpu_ttm1d_move_atoms(imdgpu_ctx *ctx, double *ekin)

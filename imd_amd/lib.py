@@ -34,7 +34,7 @@ SYMBOLS = [
     "imdgpu_dist_unique_id", "imdgpu_dist_init_rccl", "imdgpu_dist_init_callback", "imdgpu_dist_set_plan",
     "imdgpu_dist_halo", "imdgpu_dist_set_ttm_blocks", "imdgpu_dist_md_step", "imdgpu_dist_allreduce_sum",
     "imdgpu_dist_rebuild", "imdgpu_dist_rebuild_count", "imdgpu_dist_step", "imdgpu_dist_calc_forces", "imdgpu_dist_plan_geometry",
-    "imdgpu_ttm1d_init", "imdgpu_ttm1d_calc", "imdgpu_ttm1d_stage", "imdgpu_ttm1d_move_atoms", "imdgpu_ttm1d_download", "imdgpu_ttm1d_upload", "imdgpu_ttm1d_tmm_init", "imdgpu_ttm1d_tmm_get", "imdgpu_ttm1d_tmm_set_time",
+    "imdgpu_ttm1d_init", "imdgpu_ttm1d_calc", "imdgpu_ttm1d_stage", "imdgpu_ttm1d_move_atoms", "imdgpu_ttm1d_download", "imdgpu_ttm1d_upload", "imdgpu_ttm1d_tmm_init", "imdgpu_ttm1d_tmm_get", "imdgpu_ttm1d_tmm_set_time", "imdgpu_ttm1d_set_epress", "imdgpu_ttm1d_epress_get",
     "imdgpu_ttm_remote_init", "imdgpu_ttm_remote_ipc_handle", "imdgpu_ttm_remote_open", "imdgpu_ttm_remote_attach", "imdgpu_dist_ttm_remote_setup", "imdgpu_ttm_remote_detach", "imdgpu_ttm_remote_ping",
     "imdgpu_local_group_create", "imdgpu_local_group_destroy", "imdgpu_local_group_barrier", "imdgpu_local_group_shared", "imdgpu_dist_init_local",
 ]
@@ -223,6 +223,8 @@ def load():
     L.imdgpu_ttm1d_tmm_init.argtypes = [vp, C.POINTER(TmmParamsC)]
     L.imdgpu_ttm1d_tmm_get.argtypes = [vp, dp, dp, dp, dp, ip, ip]
     L.imdgpu_ttm1d_tmm_set_time.argtypes = [vp, C.c_double]
+    L.imdgpu_ttm1d_set_epress.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, dp]
+    L.imdgpu_ttm1d_epress_get.argtypes = [vp, dp, dp]
     L.imdgpu_ttm_remote_init.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.imdgpu_ttm_remote_ipc_handle.argtypes = [vp, vp, ip]
     L.imdgpu_ttm_remote_open.argtypes = [vp, vp, C.POINTER(vp)]

@@ -318,6 +318,20 @@ class GpuSystem:
         return dict(tmm_time=sc[0], laser_active=int(sc[1]), eabs=sc[2], I_t=sc[3], refl=sc[4], trans=sc[5], absorbed=sc[6], ecut=int(sc[7]),
                     eps_re=er, eps_im=ei, qabs=q, active=act, too_short=short.value)
 
+    def ttm1d_set_epress(self, pe):
+        """-DELECPRESS: the table of EOS_pe_from_r_te [Pa] as dict(x, y, z) like the EOS tables; None: off"""
+        if pe is None:
+            self._ck(self.L.imdgpu_ttm1d_set_epress(self.h, 0, 0, 0.0, 0.0, 0.0, 0.0, None)); return
+        z = np.ascontiguousarray(pe["z"], dtype=np.float64)
+        self._ck(self.L.imdgpu_ttm1d_set_epress(self.h, z.shape[0], z.shape[1], float(pe["x"][0]), float(pe["x"][-1]), float(pe["y"][0]),
+                                                float(pe["y"][-1]), _dp(z)))
+
+    def ttm1d_epress(self):
+        nx = self.ttm1d_nx
+        a, b = np.zeros(nx), np.zeros(nx)
+        self._ck(self.L.imdgpu_ttm1d_epress_get(self.h, _dp(a), _dp(b)))
+        return a, b
+
     def ttm1d_tmm_set_time(self, tmm_time):
         self._ck(self.L.imdgpu_ttm1d_tmm_set_time(self.h, float(tmm_time)))
 

@@ -356,6 +356,13 @@ int imdgpu_ttm1d_tmm_init(imdgpu_ctx *ctx, const imdgpu_tmm_params *p);
  * too short for tmm_threshold (the reference aborts there).  NULL = skip */
 int imdgpu_ttm1d_tmm_get(imdgpu_ctx *ctx, double *scalars, double *eps_re, double *eps_im, double *qabs, int *active, int *too_short);
 int imdgpu_ttm1d_tmm_set_time(imdgpu_ctx *ctx, double tmm_time);
+/* -DELECPRESS of the reference (commented out at imd_ttm.c:60 / imd_integrate.c:25; a build flag there, a call here): the table of
+ * EOS_pe_from_r_te [Pa over density x Te[K], x slowest; imd_ttm.c:1133-1135,2638-2693].  calc_ttm then ends with
+ * [do_electronic_pressure :553-623] and move_atoms_ttm subtracts timestep * epress_deriv[slab] from p_x [imd_integrate.c:657-659,
+ * 741-743].  With ref_ranks > 1 an atom feels the force only if the rank that owns it (by position) also owns its slab, as in
+ * the reference, where every rank fills epress_deriv for its own share of the row.  z = NULL: off */
+int imdgpu_ttm1d_set_epress(imdgpu_ctx *ctx, int nx, int ny, double xmin, double xmax, double ymin, double ymax, const double *z);
+int imdgpu_ttm1d_epress_get(imdgpu_ctx *ctx, double *epress_global, double *epress_deriv);
 /* [move_atoms_ttm, TTM1D branch, imd_integrate.c:649-760] */
 int imdgpu_ttm1d_move_atoms(imdgpu_ctx *ctx, double *tot_kin_energy);
 int imdgpu_ttm1d_download(imdgpu_ctx *ctx, const imdgpu_ttm1d_fields *f);
