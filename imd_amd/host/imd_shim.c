@@ -393,9 +393,11 @@ static void l2_move_atoms(void)
   if ((checkpt_int > 0 && 0 == steps % checkpt_int && steps > 0) || steps == steps_max) l2_sync_down();   /* write_config reads the cells */
 #ifdef TTM
   if ((ttm_int > 0 && 0 == steps % ttm_int) || steps == steps_max) {                                      /* ttm_writeout reads l1 */
+#ifndef TTM1D
     double mdt = 0.0;
     gpu_check(imdgpu_ttm_cfl_maxdt(G, steps, &mdt));
     max_dt_ttm = mdt;
+#endif
     lattice_to_host();
   }
 #endif
@@ -678,7 +680,165 @@ void do_embedding_energy(void)
 #endif
 #endif /* IMD_SHIM_CELLPAIR_FUNCTIONS */
 
-#ifdef TTM
+#if defined(TTM) && defined(TTM1D)
+
+/* ---- imd_ttm.c's own 1D model (-DTTM1D, what the reference's Makefile builds; with imd_tmm.c as laser source) ------------
+ * Build: the reference's sources with -Dcalc_ttm=calc_ttm_host on imd_ttm.c and its ttm_fill_ghost_layers made a weak symbol
+ * in the object file (objcopy; the file compiled -fPIC so that init_ttm's own calls bind at link time) -- no source change --,
+ * imd_forces_nbl.c left out; this file provides calc_forces, calc_ttm and ttm_fill_ghost_layers.  The reference's 1D program cannot even initialise on one rank (init_ttm ends with
+ * ttm_fill_ghost_layers, whose one-rank case receives from a rank that does not exist, imd_ttm.c:1193-1199,3264-3360); with the
+ * lattice on the device one rank is all there is to it (the row is ONE array), so the ghost fill of the host
+ * lattice has nothing to do.  init_ttm / tmm_init stay the reference's: they read the tables, which go to the library from the
+ * reference's own memory.  IMD_SHIM_REF_RANKS=n reproduces what a run cut into n ranks does differently (the virtual lattice
+ * as +x neighbour of every cell of its rank, imd_ttm.c:1535-1540; who feels the electron-pressure force, :596-620). */
+static int     g_ttm_ready = 0, g_fdn = 0;
+static int    *g_fi[5];                               /* natoms, natoms_old, natomsglobal, fluxfromleft, fluxfromright */
+static double *g_fd[22];
+
+static void eos_grid(const nn_interp *nn, const char *what, int *nx, int *ny, double **z)
+{
+  int n = nn->npoints, js = 1, q;
+  while (js < n && nn->points[js].x == nn->points[0].x) js++;
+  if (n <= 0 || n % js != 0) error_str("imd_shim: EOS table %s is not a regular grid", (char *) what);
+  *ny = js; *nx = n / js;
+  *z = (double *) malloc(n * sizeof(double));
+  if (NULL == *z) error("imd_shim: cannot allocate EOS grid");
+  for (q = 0; q < n; q++) {
+    if (nn->points[q].x != nn->points[(q / js) * js].x || nn->points[q].y != nn->points[q % js].y)
+      error_str("imd_shim: EOS table %s is not a regular grid", (char *) what);
+    (*z)[q] = nn->points[q].z;
+  }
+}
+
+void ttm_fill_ghost_layers(void) { }
+
+/* the device row -> l1/l2 (index i = global cell + 1), the global slab arrays move_atoms_ttm reads (xiarr_global, vcom*global:
+ * imd_integrate.c:651-656,737-739), the bookkeeping scalars, and what the reference prints per step */
+static void lattice_to_host(void)
+{
+  imdgpu_ttm1d_fields F;
+  const int nx = global_fd_dim.x;
+  int i;
+  double sc[4];
+  memset(&F, 0, sizeof(F));
+  F.natoms = g_fi[0]; F.natoms_old = g_fi[1]; F.natomsglobal = g_fi[2]; F.fluxfromleft = g_fi[3]; F.fluxfromright = g_fi[4];
+  F.temp = g_fd[0]; F.temp2 = g_fd[1]; F.U = g_fd[2]; F.U2 = g_fd[3]; F.xi = g_fd[4]; F.md_temp = g_fd[5]; F.source = g_fd[6];
+  F.dens = g_fd[7]; F.fd_k = g_fd[8]; F.fd_g = g_fd[9]; F.Z = g_fd[10]; F.Ce = g_fd[11]; F.ne = g_fd[12];
+  F.vcomglobal = g_fd[13]; F.xiarr_global = g_fd[14];
+  F.vlat_temp = g_fd[15]; F.vlat_md_temp = g_fd[16]; F.vlat_fd_k = g_fd[17]; F.vlat_fd_g = g_fd[18]; F.vlat_Ce = g_fd[19];
+  F.scalars = sc;
+  gpu_check(imdgpu_ttm1d_download(G, &F));
+  for (i = 0; i < nx + 2; i++) {
+    ttm_Element *e = &l1[i], *e2 = &l2[i];
+    e->natoms = e2->natoms = F.natoms[i]; e->natoms_old = e2->natoms_old = F.natoms_old[i];
+    e->temp = F.temp[i]; e2->temp = F.temp2[i]; e->U = F.U[i]; e2->U = F.U2[i];
+    e->xi = e2->xi = F.xi[i]; e->md_temp = e2->md_temp = F.md_temp[i]; e->source = e2->source = F.source[i];
+    e->dens = e2->dens = F.dens[i]; e->fd_k = F.fd_k[i]; e->fd_g = F.fd_g[i]; e->Z = F.Z[i]; e->Ce = F.Ce[i]; e->ne = F.ne[i];
+  }
+  for (i = 0; i < nx; i++) {
+    natomsglobal[i] = F.natomsglobal[i]; fluxfromleftglobal[i] = F.fluxfromleft[i]; fluxfromrightglobal[i] = F.fluxfromright[i];
+    vcomxglobal[i] = F.vcomglobal[i]; vcomyglobal[i] = F.vcomglobal[nx + i]; vcomzglobal[i] = F.vcomglobal[2 * nx + i];
+    xiarr_global[i] = F.xiarr_global[i];
+    l1[i + 1].vcomx = l2[i + 1].vcomx = vcomxglobal[i]; l1[i + 1].vcomy = l2[i + 1].vcomy = vcomyglobal[i];
+    l1[i + 1].vcomz = l2[i + 1].vcomz = vcomzglobal[i];
+  }
+  for (i = 0; i < vlatdim; i++) {
+    vlattice1[i].temp = F.vlat_temp[i]; vlattice1[i].md_temp = F.vlat_md_temp[i]; vlattice1[i].fd_k = F.vlat_fd_k[i];
+    vlattice1[i].fd_g = F.vlat_fd_g[i]; vlattice1[i].Ce = F.vlat_Ce[i];
+  }
+  last_active_cell_global = (int) sc[0]; cur_vlattice_proc = (int) sc[1]; diff_substeps = (int) sc[2]; max_dt_ttm = sc[3];
+#ifdef ELECPRESS
+  gpu_check(imdgpu_ttm1d_epress_get(G, epress_global, epress_deriv));
+#endif
+#ifdef TMM
+  if (I0 > 0) {
+    double ts[8];
+    int too_short = 0;
+    gpu_check(imdgpu_ttm1d_tmm_get(G, ts, NULL, NULL, tmm_Qabs, NULL, &too_short));
+    if (too_short) error("Sample is too short for TMM.Consider reducing tmm_threshold.");       /* imd_tmm.c:362 */
+    tmm_time = ts[0]; laser_active = ts[1] != 0.0; Eabs_local = ts[2]; I_t = ts[3]; tmm_refl = ts[4]; tmm_trans = ts[5]; tmm_abs = ts[6];
+  }
+#endif
+}
+
+static void ttm_gpu_init(void)
+{
+  imdgpu_ttm1d_params par;
+  double *zc, *ze;
+  const int nx = global_fd_dim.x;
+  int k;
+  const char *rr = getenv("IMD_SHIM_REF_RANKS");
+  if (cpu_dim.x * cpu_dim.y * cpu_dim.z != 1) error("imd_shim: the 1D model on the device serves one rank (it IS the whole row)");
+  memset(&par, 0, sizeof(par));
+  par.nx = nx; par.fd_min_atoms = fd_min_atoms; par.fd_n_timesteps = fd_n_timesteps; par.vlatdim = vlatdim; par.vlatbuffer = vlatbuffer;
+  par.ref_ranks = rr ? atoi(rr) : 1;
+  par.adv = getenv("IMD_SHIM_TTM_NOADV") ? 0 : 1;          /* calc_ttm calls do_ADV(1.0) (ADVMODE 1, imd_ttm.c:96-98) */
+  par.vlatdens = vlatdens; par.atomic_weight = atomic_weight; par.atomic_charge = atomic_charge;
+  eos_grid(&intp_cve_from_r_te, "EOS_cve_from_r_te", &par.cve_nx, &par.cve_ny, &zc);
+  eos_grid(&intp_ee_from_r_tesqrt, "EOS_ee_from_r_tesqrt", &par.ee_nx, &par.ee_ny, &ze);
+  par.cve_xmin = intp_cve_from_r_te.xmin; par.cve_xmax = intp_cve_from_r_te.xmax;
+  par.cve_ymin = intp_cve_from_r_te.ymin; par.cve_ymax = intp_cve_from_r_te.ymax; par.cve_z = zc;
+  par.ee_xmin = intp_ee_from_r_tesqrt.xmin; par.ee_xmax = intp_ee_from_r_tesqrt.xmax;
+  par.ee_ymin = intp_ee_from_r_tesqrt.ymin; par.ee_ymax = intp_ee_from_r_tesqrt.ymax; par.ee_z = ze;
+  gpu_check(imdgpu_ttm1d_init(G, &par));
+  free(zc); free(ze);
+#ifdef TMM
+  if (I0 > 0) {                                            /* tmm_init has read the tables (imd_tmm.c:117-118) */
+    imdgpu_tmm_params tp;
+    double *eb = (double *) malloc(3 * (size_t) eps_bb_rows * sizeof(double)), *k12 = (double *) malloc(2 * (size_t) K12_rows * sizeof(double)), *pz;
+    int i;
+    memset(&tp, 0, sizeof(tp));
+    for (i = 0; i < eps_bb_rows; i++) { eb[3 * i] = eps_bb_data[i][0]; eb[3 * i + 1] = eps_bb_data[i][1]; eb[3 * i + 2] = eps_bb_data[i][2]; }
+    for (i = 0; i < K12_rows; i++) { k12[2 * i] = K12[i][0]; k12[2 * i + 1] = K12[i][1]; }
+    tp.I0 = I0; tp.lambda = lambda; tp.laser_sigma_t = laser_sigma_t; tp.laser_t_0 = laser_t_0; tp.laser_sigma_t1 = laser_sigma_t1;
+    tp.laser_t_1 = laser_t_1; tp.tmm_threshold = tmm_absorption_threshold; tp.tmm_laser_threshold = tmm_laser_threshold;
+    tp.eps_bb_rows = eps_bb_rows; tp.eps_bb = eb; tp.K12_rows = K12_rows; tp.K12 = k12;
+    eos_grid(&intp_phase_from_r_ti, "EOS_phase_from_r_ti", &tp.phase.nx, &tp.phase.ny, &pz);
+    tp.phase.xmin = intp_phase_from_r_ti.xmin; tp.phase.xmax = intp_phase_from_r_ti.xmax;
+    tp.phase.ymin = intp_phase_from_r_ti.ymin; tp.phase.ymax = intp_phase_from_r_ti.ymax; tp.phase.z = pz;
+    gpu_check(imdgpu_ttm1d_tmm_init(G, &tp));
+    gpu_check(imdgpu_ttm1d_tmm_set_time(G, tmm_time));     /* a restart sets it in init_ttm (:1184) */
+    free(eb); free(k12); free(pz);
+  }
+#endif
+#ifdef ELECPRESS
+  {
+    double *pz;
+    int pnx, pny;
+    eos_grid(&intp_pe_from_r_te, "EOS_pe_from_r_te", &pnx, &pny, &pz);
+    gpu_check(imdgpu_ttm1d_set_epress(G, pnx, pny, intp_pe_from_r_te.xmin, intp_pe_from_r_te.xmax, intp_pe_from_r_te.ymin,
+                                      intp_pe_from_r_te.ymax, pz));
+    free(pz);
+  }
+#endif
+  g_fdn = nx + 2;
+  for (k = 0; k < 2; k++) g_fi[k] = (int *) malloc((nx + 2) * sizeof(int));
+  for (k = 2; k < 5; k++) g_fi[k] = (int *) malloc(nx * sizeof(int));
+  for (k = 0; k < 22; k++) g_fd[k] = (double *) malloc((k == 13 ? 3 : 1) * (size_t) (nx + 2 + vlatdim) * sizeof(double));
+  g_ttm_ready = 1;
+}
+
+void calc_ttm(void)
+{
+  int n;
+  gpu_init();
+  if (!g_have_cells) error("imd_shim: calc_ttm before calc_forces");
+#ifdef NBL
+  if (l2_on()) {                                   /* level 2: forked beside the force passes by calc_forces */
+    if (l2_listed("IMD_SHIM_SYNC_STEPS", steps)) lattice_to_host();
+    return;
+  }
+#endif
+  if (!g_ttm_ready) ttm_gpu_init();
+  n = count_atoms();
+  ensure_host(n);
+  gather_cells(1);
+  gpu_check(imdgpu_update_momenta(G, n, g_imp));    /* positions are the ones of this step's calc_forces; the momenta the host integrator's */
+  gpu_check(imdgpu_ttm1d_calc(G, steps));
+  lattice_to_host();                                /* l1/l2 and the global arrays move_atoms_ttm reads (xiarr_global, vcom*global, epress_deriv) */
+}
+
+#elif defined(TTM)
 
 /* ---- calc_ttm on the device ------------------------------------------------------------------------------- */
 static int     g_ttm_ready = 0, g_fdn = 0;

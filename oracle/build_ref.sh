@@ -258,6 +258,38 @@ case " $TARGETS " in *" dropin "*) build_dropin_ttm ;; esac
 # (-Dname=name_host, no source change), so the probe's calc_ttm sequence (ref_probe_ttm.c: the reference's own call order,
 # function by function) calls the shim's versions of exactly these names.  tests/test_gpu_dropin.py compares it with the CPU
 # build, whose probe drives the reference's own functions in the same order.
+# The reference's own Makefile configuration -- imd_ttm.c's 1D model with the transfer-matrix laser source, here also with
+# -DELECPRESS -- with calc_forces / calc_ttm on the GPU: imd_ttm.c compiled with -Dcalc_ttm=calc_ttm_host, its
+# ttm_fill_ghost_layers weakened in the object file (no source change), the shim provides both (imd_shim.c, TTM1D block).
+build_dropin_ttm1d() {
+  local name="mpi_eam_ttm1d_tmm_ep_nbl_gpu" defs="-DMPI -DNBL -DEAM2 -DTTM -DTMM -DTTM1D -DELECPRESS"
+  local obj="$OUT/obj_$name" repo="$(cd "$HERE/.." && pwd)"
+  local MPIINC="${MPI_HOME:-/opt/conda}"
+  [ -f "$repo/imd_amd/csrc/libimdgpu.so" ] || { echo "libimdgpu.so not built, skipping drop-in" >&2; return 0; }
+  [ -f "$MPIINC/include/mpi.h" ] || { echo "no MPI at $MPIINC, skipping $name" >&2; return 0; }
+  local cc="$CC -I$MPIINC/include"
+  mkdir -p "$obj"
+  local objs=""
+  for s in $COMMON imd_geom_mpi_3d.c imd_comm_force_3d.c imd_fix_cells_3d.c imd_mpiio.c imd_mpi_util.c imd_interpol.c fminbnd3.c imd_tmm.c; do
+    local o="$obj/${s%.c}.o"
+    if [ ! -f "$o" ] || [ "$REF/$s" -nt "$o" ]; then $cc $BASEFLAGS $defs -c "$REF/$s" -o "$o" & fi
+    objs="$objs $o"
+  done
+  # calc_ttm: renamed by -D (its only caller is the main loop).  ttm_fill_ghost_layers is also called from INSIDE imd_ttm.c
+  # (init_ttm, :1193-1199): compiled position-independent, so that those calls bind at link time, and its definition made weak
+  # -- the shim's definition is the one every call reaches
+  $cc $BASEFLAGS $defs -fPIC -Dcalc_ttm=calc_ttm_host -c "$REF/imd_ttm.c" -o "$obj/imd_ttm.o" &
+  wait
+  objcopy --weaken-symbol=ttm_fill_ghost_layers "$obj/imd_ttm.o"
+  $cc $BASEFLAGS $defs -fopenmp -I"$repo/include" -c "$repo/imd_amd/host/imd_shim.c" -o "$obj/imd_shim.o"
+  $cc $BASEFLAGS $defs -c "$HERE/ref_probe.c" -o "$obj/ref_probe.o"
+  $cc -o "$OUT/imd_$name" $objs "$obj/imd_ttm.o" "$obj/imd_shim.o" "$obj/ref_probe.o" -Wl,--wrap=calc_forces \
+      "$REF/nn_interpol/libnn.a" -L"$repo/imd_amd/csrc" -limdgpu -Wl,-rpath,/root/repo/imd_amd/csrc -fopenmp \
+      -Wl,-rpath-link,/usr/lib/x86_64-linux-gnu "$MPIINC/lib/libmpi.so" -Wl,-rpath,"$MPIINC/lib" -lm
+  echo "built $OUT/imd_$name"
+}
+case " $TARGETS " in *" dropin "*) build_dropin_ttm1d ;; esac
+
 build_dropin_ttm_fn() {
   local name="mpi_eam_ttm3d_nbl_gpufn" defs="-DMPI -DNBL -DEAM2 -DTTM -DTMM -DEOSMODE=1"
   local obj="$OUT/obj_$name" repo="$(cd "$HERE/.." && pwd)"

@@ -490,3 +490,58 @@ def test_reference_mpi_ttm_program_on_gpu(cpu_dim):
             assert np.array_equal(ia[oa], ib[ob])
             assert np.abs(_inner_pos(A)[oa] - _inner_pos(B)[ob]).max() < 1e-9, (rk, s)
             assert np.array_equal(A["numneighs"][oa], B["numneighs"][ob])
+
+
+GPU_TTM1D = os.path.join(ROOT, "oracle", "_ref", "imd_mpi_eam_ttm1d_tmm_ep_nbl_gpu")
+
+
+@pytest.mark.skipif(not os.path.exists(GPU_TTM1D), reason="oracle/_ref binaries not built")
+@pytest.mark.parametrize("level", [1, 2])
+def test_reference_1d_program_with_its_laser_source_on_the_device(level):
+    """The configuration the reference's Makefile builds -- imd_ttm.c's 1D model (-DTTM1D) with the transfer-matrix laser source
+    of imd_tmm.c, here also with -DELECPRESS -- as a drop-in: the reference's main loop, init_ttm / tmm_init (they read the
+    tables), its integrator (level 1) or the device's (level 2), with calc_forces and calc_ttm on the GPU.  The CPU side is
+    tests/golden/ttm1d_ep_slab.npz: the same input run by the unmodified program on TWO ranks (it cannot run on one:
+    ttm_fill_ghost_layers); IMD_SHIM_REF_RANKS=2 reproduces what the cut into two ranks does to the virtual lattice's
+    neighbours.  Atoms of step 8 away from that run's rank boundary (the pressure force there depends on which rank owned an
+    atom at the last re-binning)."""
+    from imd_amd import tmm as tmm_mod, ttm as ttm_mod
+    from tests import golden_util as gu
+    from tests.golden import make_golden as mg
+    from imd_amd import config_io
+    G = gu.load("ttm1d_ep_slab")
+    # the two-rank run drew its initial velocities per rank: the one-rank program starts from that run's atoms of step 0
+    # (a binary checkpoint in the reference's own format) instead of generating its own
+    par = str(G["param_file"]).replace("cpu_dim 2 1 1", "cpu_dim 1 1 1").replace("coordname _fcc", "coordname in.chkpt\nbox_from_header 1")
+    par = par.replace("shiftx_front 8.0", "shiftx_front 0.0").replace("shiftx_rear 8.0", "shiftx_rear 0.0")
+    assert "cpu_dim 1 1 1" in par and "in.chkpt" in par
+    with tempfile.TemporaryDirectory() as top:
+        d = os.path.join(top, "run"); os.mkdir(d)
+        potential.write_synthetic_eam_files(d)
+        config_io.write_config(os.path.join(d, "in.chkpt"), G["s0_nummer"], G["s0_sorte"], G["s0_masse"], G["s0_ort"], G["s0_impuls"],
+                               np.zeros(len(G["s0_nummer"])), G["box"], (0, 1, 1), binary=True)
+        eos = mg.write_planar_eos(top)
+        ttm_mod.write_eos_table(os.path.join(top, "EOS_phase_from_r_ti.txt"), mg.tmm_phase_table(eos))
+        ttm_mod.write_eos_table(os.path.join(top, "EOS_pe_from_r_te.txt"), mg.epress_table(eos))
+        tmm_mod.write_arr(os.path.join(top, "alu_eps_bb.dat"), tmm_mod.synthetic_eps_bb())
+        tmm_mod.write_arr(os.path.join(top, "K12.dat"), tmm_mod.synthetic_K12())
+        open(os.path.join(d, "t.param"), "w").write(par)
+        env = dict(os.environ, IMD_PROBE_DIR=d, IMD_PROBE_STEPS="0,4,8", IMD_SHIM_REF_RANKS="2", IMD_SHIM_LEVEL=str(level),
+                   IMD_SHIM_SYNC_STEPS="0,4,8")
+        r = subprocess.run([GPU_TTM1D, "-p", "t.param"], cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                           timeout=300)
+        assert r.returncode == 0, r.stdout[-3000:]
+        P = {s: po.read_probe(os.path.join(d, "probe.0.%d.bin" % s)) for s in (0, 4, 8)}
+    box = np.diag(G["box"])
+    for s, tol in ((0, 1e-12), (4, 1e-8), (8, 1e-7)):
+        ids, pos = _inner_ids(P[s]), _inner_pos(P[s])
+        a, b = np.argsort(ids), np.argsort(G["s%d_nummer" % s])
+        assert np.array_equal(ids[a], G["s%d_nummer" % s][b])
+        ref = G["s%d_ort" % s][b]
+        far = np.abs(ref[:, 0] - box[0] / 2) > 1.0
+        dx = pos[a] - ref; dx[:, 1:] -= np.round(dx[:, 1:] / box[1:]) * box[1:]
+        assert np.abs(dx[far]).max() < tol, (level, s, np.abs(dx[far]).max())
+    # the laser and the pressure did act: the same atoms without them are elsewhere (the fixture of the run without the flag)
+    T = gu.load("ttm1d_tmm_slab")
+    a, b = np.argsort(_inner_ids(P[8])), np.argsort(T["s8_nummer"])
+    assert np.abs(_inner_pos(P[8])[a] - T["s8_ort"][b]).max() > 1e-4
