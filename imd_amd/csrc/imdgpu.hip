@@ -2585,6 +2585,7 @@ int imdgpu_launch_forces_phase(imdgpu_ctx *ctx, int phase)
 }
 int imdgpu_launch_integrate(imdgpu_ctx *ctx)
 {
+  if (ctx->ttm1d) return imdgpu_ttm1d_move_internal(ctx);
   if (ctx->ttm) return imdgpu_ttm_move_internal(ctx);
   const int n = ctx->nlocal, nb = nblk(n, 256);
   double h = 0.5 * ctx->nbl_margin;

@@ -352,6 +352,7 @@ extern "C" int imdgpu_dist_set_ttm_blocks(imdgpu_ctx *ctx, const int *offs)
 }
 
 // the lattice half of a step on the side stream (forked after pass 1, joined before the integrator)
+static int dist_ttm1d_chain(imdgpu_ctx *ctx, DistState *D, int steps);
 static int dist_ttm_chain(imdgpu_ctx *ctx, DistState *D, int steps)
 {
   HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
@@ -417,10 +418,14 @@ extern "C" int imdgpu_dist_md_step(imdgpu_ctx *ctx, int steps, int *rebuild_need
   // halo group in device order on EVERY rank, so the two communicators can never wait for each other crosswise, whatever
   // the CUs admit side by side (the embedding pass is folded into pass 1, so nothing of substance sits between pass 1
   // and this point; the EAM force pass below waits for the gather anyway).
-  if (ctx->ttm && dist_ttm_chain(ctx, D, steps)) return 1;
+  if (ctx->ttm1d) {
+    if (dist_ttm1d_chain(ctx, D, steps)) return 1;
+    HIPCHK(hipStreamWaitEvent(ctx->stream, D->ev_gathered, 0));
+  }
+  else if (ctx->ttm && dist_ttm_chain(ctx, D, steps)) return 1;
   if (ctx->ttm && !ctx->ttm_decomposed) HIPCHK(hipStreamWaitEvent(ctx->stream, D->ev_gathered, 0));
   if (imdgpu_launch_forces_phase(ctx, 3)) return 1;
-  if (ctx->ttm) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+  if (ctx->ttm || ctx->ttm1d) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
   if (imdgpu_launch_integrate(ctx)) return 1;
   // next step's position halo and the global validity flag; then pass 1 of the next step, guarded by that flag, so the
   // device has work while the host reads the flag
@@ -459,6 +464,35 @@ void imdgpu_dist_cancel_ahead(imdgpu_ctx *ctx)
 {
   DistState *D = DS(ctx);
   if (D) { D->spec_pass1 = false; D->halo_ready = false; }
+}
+
+// The 1D model on several ranks: every rank bins ITS atoms into the slabs, the slab sums are added up over the ranks (what the
+// reference does with MPI_Allreduce on natomsglobal, vcom*global, ..., imd_ttm.c:325-334,340-347,404-407) and every rank then
+// runs the same lattice launch on the whole row.  Lattice stream, second communicator, like the replicated 3D lattice's gather.
+int imdgpu_dist_sum_dev(imdgpu_ctx *ctx, double *d, int n)
+{
+  DistState *D = DS(ctx);
+  if (!D || D->nranks == 1 || n <= 0) return 0;
+  if (D->comm) { NCCLCHK(g_rccl.AllReduce(d, d, (size_t) n, ncclDouble, ncclSum, D->comm2, ctx->stream)); }
+  else {
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (D->cb(D->cb_user, 3, d, d, n, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 8)) return imdgpu_fail(ctx, "dist: the host transport failed (sum)");
+  }
+  HIPCHK(hipEventRecord(D->ev_gathered, ctx->stream));       // the EAM force pass waits for the collectives, not for the lattice
+  return 0;
+}
+static int dist_ttm1d_chain(imdgpu_ctx *ctx, DistState *D, int steps)
+{
+  HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
+  HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+  hipStream_t main = ctx->stream;
+  ctx->stream = ctx->stream2;
+  HIPCHK(hipEventRecord(D->ev_gathered, ctx->stream));         // one rank: nothing to wait for
+  const int rc = imdgpu_ttm1d_calc(ctx, steps);
+  ctx->stream = main;
+  if (rc) return 1;
+  HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
+  return 0;
 }
 
 // sums over the ranks of n doubles on the host (energies; not on the per-step path)

@@ -230,6 +230,8 @@ int imdgpu_ttm_move_internal(imdgpu_ctx *ctx);
 void imdgpu_ttm_free(imdgpu_ctx *ctx);
 void imdgpu_ttm1d_free(imdgpu_ctx *ctx);
 int imdgpu_ttm1d_move_internal(imdgpu_ctx *ctx);
+// sum over the ranks of n doubles in device memory, in place, on ctx->stream (the lattice stream when forked); nothing on one rank
+int imdgpu_dist_sum_dev(imdgpu_ctx *ctx, double *d, int n);
 void imdgpu_ttm_set_persist(imdgpu_ctx *ctx, int value);
 long long imdgpu_ttm_persist_info(imdgpu_ctx *ctx, int which);
 void imdgpu_dist_free(imdgpu_ctx *ctx);

@@ -2979,6 +2979,7 @@ struct Ttm1dState {
   double *cve_z = nullptr, *ee_z = nullptr;
   EosDev cve{}, ee{};
   Lat L{};
+  double *sumbuf = nullptr;                                           // several ranks: the slab sums on their way through the all-reduce
   EosDev pe{}; double *pe_z = nullptr; int ep_on = 0;                  // -DELECPRESS: EOS_pe_from_r_te's table (imdgpu_ttm1d_set_epress)
   double box_xx = 0;
   struct TmmDev *tmm = nullptr;                                       // transfer-matrix laser source (imdgpu_ttm1d_tmm_init), host copy
@@ -3576,7 +3577,7 @@ void imdgpu_ttm1d_free(imdgpu_ctx *ctx)
   void *p[] = {t->natoms, t->natoms_old, t->temp[0], t->temp[1], t->U[0], t->U[1], t->xi, t->md_temp, t->source, t->dens, t->fd_k, t->fd_g, t->Z, t->Ce,
                t->ne, t->gi, t->gd, t->vt[0], t->vt[1], t->vm[0], t->vm[1], t->vk, t->vg, t->vCe, t->vZ, t->vne, t->sc_i, t->sc_d, t->cve_z, t->ee_z};
   for (void *q : p) if (q) (void) hipFree(q);
-  void *p2[] = {t->tmm_K12, t->tmm_phase_z, t->tmm_q, t->tmm_eps, t->tmm_sc, t->tmm_bf, t->tmm_act, t->pe_z};
+  void *p2[] = {t->tmm_K12, t->tmm_phase_z, t->tmm_q, t->tmm_eps, t->tmm_sc, t->tmm_bf, t->tmm_act, t->pe_z, t->sumbuf};
   for (void *q : p2) if (q) (void) hipFree(q);
   delete t->tmm;
   delete t;
@@ -3600,7 +3601,6 @@ extern "C" int imdgpu_ttm1d_init(imdgpu_ctx *ctx, const imdgpu_ttm1d_params *par
   HIPCHK(hipSetDevice(ctx->device));
   if (!ctx->have_geometry) return imdgpu_fail(ctx, "ttm1d_init: set_geometry first");
   if (!ctx->pair.present) return imdgpu_fail(ctx, "ttm1d_init: pair_pot needed (neighvol from pair_pot.end[0])");
-  if (ctx->external_halo) return imdgpu_fail(ctx, "ttm1d_init: the 1D TTM serves one rank (the slab sums of several ranks would need an all-reduce per step)");
   if (ctx->ttm) return imdgpu_fail(ctx, "ttm1d_init: a 3D lattice is attached to this context already");
   if (par->nx < 2 || ((par->nx + 63) & ~63) + par->vlatdim > T1D_MAX || par->vlatdim < 1)
     return imdgpu_fail(ctx, "ttm1d_init: 2 <= ttmdimx, 1 <= vlatdim, ttmdimx (rounded up to 64) + vlatdim <= %d", T1D_MAX);
@@ -3648,17 +3648,36 @@ extern "C" int imdgpu_ttm1d_init(imdgpu_ctx *ctx, const imdgpu_ttm1d_params *par
   Ttm1dState *t = T1D(ctx);                                                          \
   if (!t) return imdgpu_fail(ctx, "imdgpu_ttm1d_init first");                       \
   HIPCHK(hipSetDevice(ctx->device))
+// several ranks: the integer slab sums travel as doubles beside the momentum sums (exact far beyond any atom count)
+__global__ void k_ttm1d_pack(int nx, int dir, int *gi, double *gd, double *buf)
+{
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= 7 * nx) return;
+  if (dir == 0) buf[q] = q < 4 * nx ? (double) gi[q] : gd[q - 4 * nx];
+  else if (q < 4 * nx) gi[q] = (int) buf[q];
+  else gd[q - 4 * nx] = buf[q];
+}
 static int t1d_update_fd_sums(imdgpu_ctx *ctx, Ttm1dState *t, int steps)
 {
   const int n = ctx->nlocal, nx = t->nx;
+  const bool many = ctx->dist != nullptr && ctx->cpu_dim[0] * ctx->cpu_dim[1] * ctx->cpu_dim[2] > 1;
   HIPCHK(hipMemsetAsync(t->gi, 0, 4 * (size_t) nx * sizeof(int), ctx->stream));
   HIPCHK(hipMemsetAsync(t->gd, 0, 4 * (size_t) nx * sizeof(double), ctx->stream));            // v_com sums and md_temp sums; xiarr is cleared by stage 1
   ProfScope ps(ctx, PROF_TTM_UPDATE);
-  hipLaunchKernelGGL((k_ttm1d_bin<1>), dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, n, ctx->cap_local, ctx->ntypes, steps, t->hx, nx, ctx->pos, ctx->type,
-                     ctx->p, ctx->mass, ctx->numneighs, ctx->fdc, t->gi, t->gd);
+  if (n > 0)
+    hipLaunchKernelGGL((k_ttm1d_bin<1>), dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, n, ctx->cap_local, ctx->ntypes, steps, t->hx, nx, ctx->pos, ctx->type,
+                       ctx->p, ctx->mass, ctx->numneighs, ctx->fdc, t->gi, t->gd);
+  if (many) {                                       // [MPI_Allreduce of the slab arrays, imd_ttm.c:325-334,340-347]
+    if (!t->sumbuf && dev_alloc(ctx, &t->sumbuf, 7 * (size_t) nx)) return 1;
+    hipLaunchKernelGGL(k_ttm1d_pack, dim3(nblk(7 * nx, 256)), dim3(256), 0, ctx->stream, nx, 0, t->gi, t->gd, t->sumbuf);
+    if (imdgpu_dist_sum_dev(ctx, t->sumbuf, 7 * nx)) return 1;
+    hipLaunchKernelGGL(k_ttm1d_pack, dim3(nblk(7 * nx, 256)), dim3(256), 0, ctx->stream, nx, 1, t->gi, t->gd, t->sumbuf);
+  }
   hipLaunchKernelGGL(k_ttm1d_vcom, dim3(nblk(nx, 256)), dim3(256), 0, ctx->stream, nx, t->aw, t->gi, t->gd);
-  hipLaunchKernelGGL((k_ttm1d_bin<2>), dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, n, ctx->cap_local, ctx->ntypes, steps, t->hx, nx, ctx->pos, ctx->type,
-                     ctx->p, ctx->mass, ctx->numneighs, ctx->fdc, t->gi, t->gd);
+  if (n > 0)
+    hipLaunchKernelGGL((k_ttm1d_bin<2>), dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, n, ctx->cap_local, ctx->ntypes, steps, t->hx, nx, ctx->pos, ctx->type,
+                       ctx->p, ctx->mass, ctx->numneighs, ctx->fdc, t->gi, t->gd);
+  if (many && imdgpu_dist_sum_dev(ctx, t->gd + 3 * (size_t) nx, nx)) return 1;             // [:404-407] the md_temp sums
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -16,6 +16,9 @@ sys.path.insert(0, ROOT)
 def main():
     case, cpu_dim, nsteps = sys.argv[1], tuple(int(v) for v in sys.argv[2:5]), int(sys.argv[5])
     ttm, decomposed, outpath = bool(int(sys.argv[6])), bool(int(sys.argv[7])), sys.argv[8]
+    ttm1d = int(sys.argv[6]) == 2                 # imd_ttm.c's 1D model (with its laser source / electron pressure if the fixture has them)
+    if ttm1d:
+        ttm = False
     from tests import golden_util as gu
     from imd_amd.parallel import Decomposition, DistributedMD, GpuOps, LocalGroup
     from imd_amd.system import GpuSystem
@@ -33,13 +36,23 @@ def main():
         mine = np.all(c // (np.array(dec.dim) - 2) == np.array(dec.coord), axis=1)
         s = GpuSystem(G["box"], G["pbc_dirs"], dec.dim, ntypes, float(G["cellsz"]), float(G["nbl_margin"]), float(G["timestep"]),
                       device=0, global_cell_dim=dec.gdim, cpu_dim=cpu_dim, my_coord=dec.coord, ttm_decomposed=decomposed,
-                      count_ttm_neighbours=ttm)
+                      count_ttm_neighbours=ttm or ttm1d)
         s.upload_tables(gu.table(G, "pair_pot"), gu.table(G, "rho_h_tab"), gu.table(G, "embed_pot"))
         if ttm:
             s.init_ttm(G["ttm_fd_ext"], int(G["ttm_fd_min_atoms"]), int(G["ttm_diff_substeps"]), float(G["ttm_atomic_weight"]),
                        float(G["ttm_atomic_charge"]), dict(x=G["eos_r"], y=G["eos_t"], z=G["eos_cve"]),
                        dict(x=G["eos_r"], y=G["eos_ts"], z=G["eos_ee"]), float(G["ttm_omega_laser"]))
         s.upload_atoms(pos[mine], mom[mine], mass[mine], G["s0_sorte"][mine].astype(np.int32) if ntypes > 1 else None, ident[mine])
+        if ttm1d:
+            s.init_ttm1d(int(G["ttm_global_fd_dim"]), int(G["ttm_fd_min_atoms"]), int(G["ttm_fd_n_timesteps"]), int(G["ttm_vlatdim"]),
+                         int(G["ttm_vlatbuffer"]), float(G["ttm_vlatdens"]), float(G["ttm_atomic_weight"]), float(G["ttm_atomic_charge"]),
+                         dict(x=G["eos_r"], y=G["eos_t"], z=G["eos_cve"]), dict(x=G["eos_r"], y=G["eos_ts"], z=G["eos_ee"]),
+                         ref_ranks=int(G["ref_ranks"]), adv=True)
+            if "tmm_I0" in G:
+                s.init_ttm1d_tmm(float(G["tmm_I0"]), float(G["tmm_lam"]), float(G["tmm_sigma_t"]), float(G["tmm_t0"]), G["tmm_eps_bb"], G["tmm_K12"],
+                                 dict(x=G["eos_r"], y=G["eos_t"], z=G["tmm_phase_z"]), tmm_threshold=float(G["tmm_abs_threshold"]))
+            if "epress_z" in G:
+                s.ttm1d_set_epress(dict(x=G["eos_r"], y=G["eos_t"], z=G["epress_z"]))
         ops = GpuOps(s, 0)
         md = DistributedMD(dec, ops, ttm=ttm, local_group=group)
         assert md.native_rebuild
@@ -49,6 +62,10 @@ def main():
         sums = md.global_sums()
         d = s.download(fields=("ort", "impuls", "kraft", "nummer", "numneighs"))
         lat = s.ttm_download(fields=("temp", "xi", "natoms")) if ttm else {}
+        if ttm1d:                              # calc_ttm of the step after the last: collective (the slab sums), every rank calls it
+            s.ttm1d_calc(nsteps)
+            L1 = s.ttm1d_download()
+            lat = {k: L1[k] for k in ("temp", "xi", "natoms", "md_temp", "dens", "U", "source", "natomsglobal", "xiarr_global")}
         info = dict(nrebuild=md.nrebuild, transport=ops.transport, list_mode=s.get_info("list_mode"),
                     persist=s.get_info("ttm_persist_mode") if ttm else -9, remote=s.get_info("ttm_remote") if ttm else -9,
                     runs=s.get_info("ttm_persist_runs") if ttm else -9)

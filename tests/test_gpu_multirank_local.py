@@ -151,3 +151,37 @@ def test_c_host_without_python_drives_the_ranks(args):
                            env=dict(os.environ, GPU_MAX_HW_QUEUES="32"))
         assert r.returncode == 0, r.stdout[-3000:]
         assert "max |dx|" in r.stdout
+
+
+@pytest.mark.parametrize("cpu_dim", [(2, 1, 1), (4, 1, 1)])
+def test_1d_model_on_several_ranks_against_the_reference_on_two(cpu_dim):
+    """imd_ttm.c's 1D model (transfer-matrix laser source, electron pressure) on several ranks: every rank bins ITS atoms, the
+    slab sums are added over the ranks (the reference's MPI_Allreduce of natomsglobal / vcom*global / ..., imd_ttm.c:325-347,
+    404-407), every rank runs the same lattice launch on the whole row and integrates its atoms.  Expected values: the
+    reference ITSELF on two ranks (tests/golden/ttm1d_ep_slab.npz) -- for 2x1x1 the very decomposition of that run."""
+    G = gu.load("ttm1d_ep_slab")
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "res.npz")
+        env = dict(os.environ, GPU_MAX_HW_QUEUES="32", PYTHONPATH=ROOT)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "local_ranks_worker.py"), "ttm1d_ep_slab"] + [str(v) for v in cpu_dim] +
+                           ["8", "2", "0", out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+        assert r.returncode == 0, "local ranks %s failed:\n%s" % (str(cpu_dim), r.stdout[-4000:])
+        R = dict(np.load(out))
+    world = int(np.prod(cpu_dim))
+    ids, pos, mom = _cat(R, world, "nummer"), _cat(R, world, "ort"), _cat(R, world, "impuls")
+    assert len(ids) == len(G["s8_nummer"]) == len(np.unique(ids))
+    o, go = np.argsort(ids), np.argsort(G["s8_nummer"])
+    box = np.diag(G["box"])
+    far = np.abs(G["s8_ort"][go][:, 0] - box[0] / 2) > 1.0          # the pressure force near the reference's rank boundary: owner by last re-binning
+    dx = pos[o] - G["s8_ort"][go]; dx[:, 1:] -= np.round(dx[:, 1:] / box[1:]) * box[1:]
+    assert np.abs(dx[far]).max() < 1e-7
+    assert np.abs(mom[o] - G["s8_impuls"][go])[far].max() < 1e-7 * np.abs(G["s8_impuls"]).max()
+    # every rank holds the same row, the reference's after step 8's calc_ttm
+    for rk in range(world):
+        assert np.array_equal(R["r%d_lat_natomsglobal" % rk], G["t8_substeps_done_natomsglobal"].astype(int))
+        for f in ("temp", "md_temp", "dens", "U", "source"):
+            ref = G["t8_substeps_done_" + f]
+            assert np.abs(R["r%d_lat_%s" % (rk, f)][1:-1] - ref).max() <= 1e-6 * np.abs(ref).max(), (rk, f)
+        if rk:
+            for f in ("temp", "xi", "md_temp"):
+                assert np.abs(R["r%d_lat_%s" % (rk, f)] - R["r0_lat_" + f]).max() <= 1e-12 * max(np.abs(R["r0_lat_" + f]).max(), 1e-300), (rk, f)
