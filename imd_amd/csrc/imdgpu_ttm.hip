@@ -2980,6 +2980,7 @@ struct Ttm1dState {
   EosDev cve{}, ee{};
   Lat L{};
   double *sumbuf = nullptr;                                           // several ranks: the slab sums on their way through the all-reduce
+  double *part = nullptr, *ovf = nullptr; int *gmin = nullptr; size_t part_cap = 0;   // update_fd's block partials
   EosDev pe{}; double *pe_z = nullptr; int ep_on = 0;                  // -DELECPRESS: EOS_pe_from_r_te's table (imdgpu_ttm1d_set_epress)
   double box_xx = 0;
   struct TmmDev *tmm = nullptr;                                       // transfer-matrix laser source (imdgpu_ttm1d_tmm_init), host copy
@@ -3135,57 +3136,106 @@ __device__ __forceinline__ int t1d_slab(double x, double hx, int nx)
   g = g > nx - 1 ? nx - 1 : g;
   return g < 0 ? 0 : g;
 }
-// the two atom sweeps of update_fd (:271-324 and :376-403).  Atoms are sorted by cell, so the lanes of a wave mostly share
-// a slab: one shuffle reduction + one atomic per wave and quantity then; lanes of a mixed wave add for themselves.
+// the two atom sweeps of update_fd (:271-324 and :376-403), without atomics and in a fixed order (the same sums bit for bit
+// from run to run).  Atoms are sorted by MD cell, x slowest: a block's run of consecutive atoms lies in a few neighbouring
+// slabs.  Sweep kernel: every wave sums its atoms per slab by shuffles -- one round per slab present in the wave -- into its
+// own LDS row of a T1D_WIN-slab window that starts at the block's lowest slab; the block adds its waves' rows in wave order
+// and writes ONE partial per (block, window slab, quantity).  Combine kernel: a workgroup per slab adds the partials of
+// the blocks whose window covers it, in block order.  (The first version added per lane with compare-and-swap loops: 1.1 ms
+// for 370 000 atoms; per wave and slab with hardware fp64 atomics: 2.6 ms for 10 million, every wave of the chip on ~250
+// addresses.)  An atom beyond its block's window (tiny systems: a block spans many cell layers) falls back to an atomic.
+#define T1D_WIN 16
+#define T1D_NQ(PHASE) ((PHASE) == 1 ? 7 : 1)
 template <int PHASE>
-__global__ void k_ttm1d_bin(int n, int cap, int ntypes, int steps, double hx, int nx, const double4 *pos, const int *type, const double *p,
-                            const double *mass, const int *numneighs, int *fdc, int *gi, double *gd)
+__global__ __launch_bounds__(256) void k_ttm1d_bin(int n, int apt, int cap, int ntypes, int steps, double hx, int nx, const double4 *pos, const int *type,
+                                                   const double *p, const double *mass, const int *numneighs, int *fdc, const double *gd, double *part,
+                                                   int *gmin_out, double *ovf)
 {
-  const int a = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool on = a < n && (ntypes == 1 || type[a] == 0);
-  int g = -1;
-  double v[4] = {0, 0, 0, 0}; int iv[3] = {0, 0, 0};
-  if (on) {
-    g = t1d_slab(pos[a].x, hx, nx);
-    const double px = p[a], py = p[(size_t) cap + a], pz = p[2 * (size_t) cap + a];
-    if (PHASE == 1) {
-      v[0] = px; v[1] = py; v[2] = pz;
-      iv[0] = numneighs[a];
-      const int old = fdc[a];
-      if (steps > 0 && old != g) { if (old > g) iv[2] = 1; else iv[1] = 1; }       // from the right / from the left
-      fdc[a] = g;
-    } else {
-      const double m = mass[a], ux = px / m - gd[g], uy = py / m - gd[nx + g], uz = pz / m - gd[2 * nx + g];
-      v[3] = m * (ux * ux); v[3] += m * (uy * uy); v[3] += m * (uz * uz);
+  constexpr int NQ = T1D_NQ(PHASE);
+  __shared__ double acc[4][T1D_WIN][NQ];
+  __shared__ int smin[4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int base = blockIdx.x * 256 * apt;
+  for (int q = tid; q < 4 * T1D_WIN * NQ; q += 256) (&acc[0][0][0])[q] = 0.0;
+  // the block's lowest slab
+  int gm = 1 << 30;
+  for (int j = 0; j < apt; j++) {
+    const int a = base + j * 256 + tid;
+    if (a < n && (ntypes == 1 || type[a] == 0)) { const int g = t1d_slab(pos[a].x, hx, nx); gm = g < gm ? g : gm; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const int t2 = __shfl_xor(gm, o, 64); gm = t2 < gm ? t2 : gm; }
+  if (lane == 0) smin[wv] = gm;
+  __syncthreads();
+  gm = min(min(smin[0], smin[1]), min(smin[2], smin[3]));
+  for (int j = 0; j < apt; j++) {
+    const int a = base + j * 256 + tid;
+    const bool on = a < n && (ntypes == 1 || type[a] == 0);
+    int g = -1;
+    double v[NQ];
+    for (int q = 0; q < NQ; q++) v[q] = 0.0;
+    if (on) {
+      g = t1d_slab(pos[a].x, hx, nx);
+      const double px = p[a], py = p[(size_t) cap + a], pz = p[2 * (size_t) cap + a];
+      if (PHASE == 1) {
+        v[0] = 1.0; v[1] = (double) numneighs[a]; v[NQ - 3] = px; v[NQ - 2] = py; v[NQ - 1] = pz;
+        const int old = fdc[a];
+        if (steps > 0 && old != g) { if (old > g) v[3 % NQ] = 1.0; else v[2 % NQ] = 1.0; }     // from the right / from the left
+        fdc[a] = g;
+      } else {
+        const double m = mass[a], ux = px / m - gd[g], uy = py / m - gd[nx + g], uz = pz / m - gd[2 * nx + g];
+        v[0] = m * (ux * ux); v[0] += m * (uy * uy); v[0] += m * (uz * uz);
+      }
+    }
+    unsigned long long todo = __ballot(on);
+    while (todo) {                                   // one round per slab present in the wave
+      const int lead = __ffsll((long long) todo) - 1;
+      const int g0 = __shfl(g, lead, 64);
+      const bool mine = on && g == g0;
+      double w[NQ];
+      for (int q = 0; q < NQ; q++) w[q] = mine ? v[q] : 0.0;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1)
+        for (int q = 0; q < NQ; q++) w[q] += __shfl_xor(w[q], o, 64);
+      if (lane == lead) {
+        const int l = g0 - gm;
+        if (l < T1D_WIN) for (int q = 0; q < NQ; q++) acc[wv][l][q] += w[q];
+        else for (int q = 0; q < NQ; q++) unsafeAtomicAdd(&ovf[(size_t) q * nx + g0], w[q]);
+      }
+      todo &= ~__ballot(mine);
     }
   }
-  // one round per slab present in the wave (atoms are sorted by MD cell: a wave spans two or three slabs): the lanes of that
-  // slab are summed by shuffles (the others contribute zeros), the round's leader adds once per quantity -- hardware
-  // fp64 atomics (a compare-and-swap loop per lane took 1.1 ms for 370 000 atoms: every lane of the chip on ~100 addresses)
-  unsigned long long todo = __ballot(on);
-  while (todo) {
-    const int lead = __ffsll((long long) todo) - 1;
-    const int g0 = __shfl(g, lead, 64);
-    const bool mine = on && g == g0;
-    int cnt = mine ? 1 : 0;
-    double w[4]; int iw[3];
-    for (int q = 0; q < 4; q++) w[q] = mine ? v[q] : 0.0;
-    for (int q = 0; q < 3; q++) iw[q] = mine ? iv[q] : 0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      cnt += __shfl_xor(cnt, o, 64);
-      for (int q = 0; q < (PHASE == 1 ? 3 : 4); q++) if (PHASE == 1 || q == 3) w[q] += __shfl_xor(w[q], o, 64);
-      if (PHASE == 1) for (int q = 0; q < 3; q++) iw[q] += __shfl_xor(iw[q], o, 64);
+  __syncthreads();
+  for (int q = tid; q < T1D_WIN * NQ; q += 256) {
+    const int l = q / NQ, k = q % NQ;
+    part[((size_t) blockIdx.x * T1D_WIN + l) * NQ + k] = ((acc[0][l][k] + acc[1][l][k]) + acc[2][l][k]) + acc[3][l][k];
+  }
+  if (tid == 0) gmin_out[blockIdx.x] = gm;
+}
+// slab g = the partials of the blocks whose window covers it, in block order; PHASE 1 -> gi (natoms, neighbours, flux from the
+// left / right) and gd (momentum sums), PHASE 2 -> gd[3 nx + g]
+template <int PHASE>
+__global__ __launch_bounds__(256) void k_ttm1d_combine(int nblocks, int nx, const double *part, const int *gmin, const double *ovf, int *gi, double *gd)
+{
+  constexpr int NQ = T1D_NQ(PHASE);
+  __shared__ double red[256];
+  const int g = blockIdx.x, tid = threadIdx.x;
+  double s[NQ];
+  for (int q = 0; q < NQ; q++) s[q] = 0.0;
+  for (int b = tid; b < nblocks; b += 256) {
+    const int l = g - gmin[b];
+    if (l >= 0 && l < T1D_WIN) for (int q = 0; q < NQ; q++) s[q] += part[((size_t) b * T1D_WIN + l) * NQ + q];
+  }
+  for (int q = 0; q < NQ; q++) {
+    red[tid] = s[q];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    if (tid == 0) {
+      const double r = red[0] + ovf[(size_t) q * nx + g];
+      if (PHASE == 1) { if (q < 4) gi[q * nx + g] = (int) r; else gd[(q - 4) * nx + g] = r; }
+      else gd[3 * nx + g] = r;
     }
-    if ((int) (threadIdx.x & 63) == lead) {
-      if (PHASE == 1) {
-        atomicAdd(&gi[g0], cnt); atomicAdd(&gi[nx + g0], iw[0]);
-        if (iw[1]) atomicAdd(&gi[2 * nx + g0], iw[1]);
-        if (iw[2]) atomicAdd(&gi[3 * nx + g0], iw[2]);
-        unsafeAtomicAdd(&gd[g0], w[0]); unsafeAtomicAdd(&gd[nx + g0], w[1]); unsafeAtomicAdd(&gd[2 * nx + g0], w[2]);
-      } else unsafeAtomicAdd(&gd[3 * nx + g0], w[3]);
-    }
-    todo &= ~__ballot(mine);
+    __syncthreads();
   }
 }
 // v_com = sum p / (natoms * atomic_weight) (:350-372)
@@ -3577,7 +3627,7 @@ void imdgpu_ttm1d_free(imdgpu_ctx *ctx)
   void *p[] = {t->natoms, t->natoms_old, t->temp[0], t->temp[1], t->U[0], t->U[1], t->xi, t->md_temp, t->source, t->dens, t->fd_k, t->fd_g, t->Z, t->Ce,
                t->ne, t->gi, t->gd, t->vt[0], t->vt[1], t->vm[0], t->vm[1], t->vk, t->vg, t->vCe, t->vZ, t->vne, t->sc_i, t->sc_d, t->cve_z, t->ee_z};
   for (void *q : p) if (q) (void) hipFree(q);
-  void *p2[] = {t->tmm_K12, t->tmm_phase_z, t->tmm_q, t->tmm_eps, t->tmm_sc, t->tmm_bf, t->tmm_act, t->pe_z, t->sumbuf};
+  void *p2[] = {t->tmm_K12, t->tmm_phase_z, t->tmm_q, t->tmm_eps, t->tmm_sc, t->tmm_bf, t->tmm_act, t->pe_z, t->sumbuf, t->part, t->ovf, t->gmin};
   for (void *q : p2) if (q) (void) hipFree(q);
   delete t->tmm;
   delete t;
@@ -3661,12 +3711,24 @@ static int t1d_update_fd_sums(imdgpu_ctx *ctx, Ttm1dState *t, int steps)
 {
   const int n = ctx->nlocal, nx = t->nx;
   const bool many = ctx->dist != nullptr && ctx->cpu_dim[0] * ctx->cpu_dim[1] * ctx->cpu_dim[2] > 1;
-  HIPCHK(hipMemsetAsync(t->gi, 0, 4 * (size_t) nx * sizeof(int), ctx->stream));
-  HIPCHK(hipMemsetAsync(t->gd, 0, 4 * (size_t) nx * sizeof(double), ctx->stream));            // v_com sums and md_temp sums; xiarr is cleared by stage 1
+  // atoms per block: 2048 where a block then still lies within a few cell layers (>= 64 blocks per... small systems: 256)
+  const int apt = n >= 256 * 64 * 8 ? 8 : (n >= 256 * 64 * 2 ? 2 : 1);
+  const int nb = n > 0 ? nblk(n, 256 * apt) : 0;
+  if ((size_t) nb > t->part_cap) {
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (t->part) (void) hipFree(t->part);
+    if (t->gmin) (void) hipFree(t->gmin);
+    t->part = nullptr; t->gmin = nullptr;
+    t->part_cap = (size_t) nb + nb / 8 + 16;
+    if (dev_alloc(ctx, &t->part, t->part_cap * T1D_WIN * 7) || dev_alloc(ctx, &t->gmin, t->part_cap)) return 1;
+  }
+  if (!t->ovf && dev_alloc(ctx, &t->ovf, 7 * (size_t) nx)) return 1;
+  HIPCHK(hipMemsetAsync(t->ovf, 0, 7 * (size_t) nx * sizeof(double), ctx->stream));
   ProfScope ps(ctx, PROF_TTM_UPDATE);
-  if (n > 0)
-    hipLaunchKernelGGL((k_ttm1d_bin<1>), dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, n, ctx->cap_local, ctx->ntypes, steps, t->hx, nx, ctx->pos, ctx->type,
-                       ctx->p, ctx->mass, ctx->numneighs, ctx->fdc, t->gi, t->gd);
+  if (nb > 0)
+    hipLaunchKernelGGL((k_ttm1d_bin<1>), dim3(nb), dim3(256), 0, ctx->stream, n, apt, ctx->cap_local, ctx->ntypes, steps, t->hx, nx, ctx->pos, ctx->type,
+                       ctx->p, ctx->mass, ctx->numneighs, ctx->fdc, t->gd, t->part, t->gmin, t->ovf);
+  hipLaunchKernelGGL((k_ttm1d_combine<1>), dim3(nx), dim3(256), 0, ctx->stream, nb, nx, t->part, t->gmin, t->ovf, t->gi, t->gd);
   if (many) {                                       // [MPI_Allreduce of the slab arrays, imd_ttm.c:325-334,340-347]
     if (!t->sumbuf && dev_alloc(ctx, &t->sumbuf, 7 * (size_t) nx)) return 1;
     hipLaunchKernelGGL(k_ttm1d_pack, dim3(nblk(7 * nx, 256)), dim3(256), 0, ctx->stream, nx, 0, t->gi, t->gd, t->sumbuf);
@@ -3674,9 +3736,11 @@ static int t1d_update_fd_sums(imdgpu_ctx *ctx, Ttm1dState *t, int steps)
     hipLaunchKernelGGL(k_ttm1d_pack, dim3(nblk(7 * nx, 256)), dim3(256), 0, ctx->stream, nx, 1, t->gi, t->gd, t->sumbuf);
   }
   hipLaunchKernelGGL(k_ttm1d_vcom, dim3(nblk(nx, 256)), dim3(256), 0, ctx->stream, nx, t->aw, t->gi, t->gd);
-  if (n > 0)
-    hipLaunchKernelGGL((k_ttm1d_bin<2>), dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, n, ctx->cap_local, ctx->ntypes, steps, t->hx, nx, ctx->pos, ctx->type,
-                       ctx->p, ctx->mass, ctx->numneighs, ctx->fdc, t->gi, t->gd);
+  HIPCHK(hipMemsetAsync(t->ovf, 0, (size_t) nx * sizeof(double), ctx->stream));
+  if (nb > 0)
+    hipLaunchKernelGGL((k_ttm1d_bin<2>), dim3(nb), dim3(256), 0, ctx->stream, n, apt, ctx->cap_local, ctx->ntypes, steps, t->hx, nx, ctx->pos, ctx->type,
+                       ctx->p, ctx->mass, ctx->numneighs, ctx->fdc, t->gd, t->part, t->gmin, t->ovf);
+  hipLaunchKernelGGL((k_ttm1d_combine<2>), dim3(nx), dim3(256), 0, ctx->stream, nb, nx, t->part, t->gmin, t->ovf, t->gi, t->gd);
   if (many && imdgpu_dist_sum_dev(ctx, t->gd + 3 * (size_t) nx, nx)) return 1;             // [:404-407] the md_temp sums
   HIPCHK(hipGetLastError());
   return 0;
