@@ -132,7 +132,7 @@ def test_twenty_md_steps_with_the_1d_ttm_follow_the_reference():
     g.calc_forces(20); g.ttm1d_calc(20)
     lat = g.ttm1d_download()
     _check(lat, G, 20, "substeps_done", ("natoms", "temp", "U", "md_temp", "dens"), 1e-8)
-    # xi accumulates (Te - Tl): a relative 1e-11 on md_temp (the slab sums are atomics: their order differs from run to run, and
+    # xi accumulates (Te - Tl): a relative 1e-11 on md_temp (the device sums the slabs in another order than the reference, and
     # twenty MD steps amplify the last bit) is 1e-8 on xi
     _check(lat, G, 20, "substeps_done", ("xi",), 1e-6)
     assert int(lat["scalars"][2]) == int(G["t20_substeps_done_scalars"][2])
