@@ -125,6 +125,7 @@ struct imdgpu_ctx {
 
   // TTM state lives in imdgpu_ttm.hip
   struct TtmState *ttm = nullptr;
+  int eos_bilinear = 0;              // option "eos_bilinear": plain bilinear EOS look-up instead of the reference's triangles
   void *ttm1d = nullptr;             // the reference's own 1D variant (imd_ttm.c), imdgpu_ttm1d_* (end of imdgpu_ttm.hip)
   // native multi-GPU step (imdgpu_dist.hip)
   // host-buffer boundary (level-1 integration): device-side reordering between the device's tile-major atom order and the

@@ -10,12 +10,26 @@
 // the fused sub-step kernel; `cur` selects l1.
 #include "imdgpu_internal.h"
 
+#include <algorithm>
 #include <cmath>
 #include <complex>
 #include <cstring>
 #include <vector>
 
 struct EosDev { int nx, ny; double xmin, xmax, ymin, ymax; const double *z; const unsigned char *diag; };   // diag: see eos_lookup
+
+// the reference's triangulation of a table grid (imdgpu_eos_triangulation, further down) on the device, attached to the table
+extern "C" int imdgpu_eos_triangulation(int nx, int ny, unsigned char *diag);
+static int eos_attach_triangulation(imdgpu_ctx *ctx, EosDev &e, unsigned char **store)
+{
+  std::vector<unsigned char> d((size_t) (e.nx - 1) * (e.ny - 1));
+  if (e.nx < 2 || e.ny < 2 || imdgpu_eos_triangulation(e.nx, e.ny, d.data())) return imdgpu_fail(ctx, "EOS table: no triangulation for a %d x %d grid", e.nx, e.ny);
+  if (*store) { (void) hipFree(*store); *store = nullptr; }
+  HIPCHK(hipMalloc((void **) store, d.size()));
+  HIPCHK(hipMemcpy(*store, d.data(), d.size(), hipMemcpyHostToDevice));
+  e.diag = *store;
+  return 0;
+}
 
 // descriptor of the shared-memory mailbox of a decomposed lattice (explained above the kernels that use it)
 struct MailboxDev {
@@ -1507,6 +1521,8 @@ extern "C" int imdgpu_ttm_init(imdgpu_ctx *ctx, const imdgpu_ttm_params *par)
   HIPCHK(hipMemcpy(t->ee_z, par->ee_z, ne * sizeof(double), hipMemcpyHostToDevice));
   t->cve = {par->cve_nx, par->cve_ny, par->cve_xmin, par->cve_xmax, par->cve_ymin, par->cve_ymax, t->cve_z, nullptr};
   t->ee = {par->ee_nx, par->ee_ny, par->ee_xmin, par->ee_xmax, par->ee_ymin, par->ee_ymax, t->ee_z, nullptr};
+  // the look-up is the reference's: linear on the triangles nn-c builds over the table nodes (option eos_bilinear: in the grid cell)
+  if (!ctx->eos_bilinear && (eos_attach_triangulation(ctx, t->cve, &t->eos_diag[0]) || eos_attach_triangulation(ctx, t->ee, &t->eos_diag[1]))) return 1;
   ctx->count_ttm = 1;
   return 0;
 }
@@ -1751,6 +1767,163 @@ extern "C" int imdgpu_ttm_eos_te_from_r_ee(imdgpu_ctx *ctx, int n, const double 
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipMemcpy(te_out, d + 2 * (size_t) n, n * sizeof(double), hipMemcpyDeviceToHost));
   HIPCHK(hipFree(d));
+  return 0;
+}
+
+// ---- which diagonal the reference's triangulation puts into every cell of a table grid -------------------------------------
+// The reference interpolates its EOS tables with nn-c (v1.86.2, shipped as the binary nn_interpol/libnn.a only): linear on a
+// Delaunay triangulation that nn-c's delaunay_build gets from J. R. Shewchuk's Triangle -- divide-and-conquer (Guibas &
+// Stolfi) with alternating cuts (Dwyer), exact predicates.  On a rectilinear grid every cell is a cocircular quadrilateral, so
+// the diagonals are decided by that algorithm's tie rules alone -- not by the coordinates: any spacing, uniform or not, gives
+// the same map (measured against libnn.a on 96 grids, tests/golden/eos_triangulation.npz).  Restated here from the published
+// algorithm on the integer grid (i, j):
+//   * vertices sorted by (x, y); the array is cut at n/2 BY COUNT, the halves re-partitioned along the other axis (ties by the
+//     first), recursively, down to sets of two or three, which are ordered by (x, y) again [Triangle: alternateaxes];
+//   * two vertices: an edge; three: a triangle, or two edges when collinear;
+//   * merge of a left / right pair (cut along x): handles = the (x, y)-smallest and -largest hull vertex of each half; of a
+//     lower / upper pair (cut along y): the (y, x)-smallest and -largest [Triangle shifts its handles from the x extremes to the
+//     y extremes by walking the hull while the next vertex is STRICTLY lower / higher: the first end of the bottom / top edge];
+//     lower common tangent with strict orientation tests; zip upwards; a candidate edge goes only if the next candidate's far
+//     vertex is STRICTLY inside the circle (incircle > 0), and of two valid candidates the right one is taken only if the left
+//     candidate's circle STRICTLY contains the right candidate's vertex -- a tie goes to the left candidate.
+// Quad-edge structure after Guibas & Stolfi; predicates in integers (exact).  diag as imdgpu_ttm_set_eos_triangulation takes it.
+namespace {
+struct GridDelaunay {
+  typedef long long I;
+  int ny;
+  std::vector<int> onext, org;            // directed edge e = 4 * quad + r; org of the primal edges (r = 0, 2) = vertex id i * ny + j
+  std::vector<char> alive;
+  static int rot(int e) { return (e & ~3) | ((e + 1) & 3); }
+  static int sym(int e) { return (e & ~3) | ((e + 2) & 3); }
+  static int irot(int e) { return (e & ~3) | ((e + 3) & 3); }
+  int dest(int e) const { return org[sym(e)]; }
+  int oprev(int e) const { return rot(onext[rot(e)]); }
+  int lnext(int e) const { return rot(onext[irot(e)]); }
+  int rprev(int e) const { return onext[sym(e)]; }
+  int make_edge(int a, int b)
+  {
+    const int e = (int) onext.size();
+    onext.resize(e + 4); org.resize(e + 4, -1); alive.push_back(1);
+    onext[e] = e; onext[e + 2] = e + 2; onext[e + 1] = e + 3; onext[e + 3] = e + 1;
+    org[e] = a; org[e + 2] = b;
+    return e;
+  }
+  void splice(int a, int b)
+  {
+    const int al = rot(onext[a]), be = rot(onext[b]);
+    std::swap(onext[a], onext[b]);
+    std::swap(onext[al], onext[be]);
+  }
+  int connect(int a, int b)
+  {
+    const int e = make_edge(dest(a), org[b]);
+    splice(e, lnext(a));
+    splice(sym(e), b);
+    return e;
+  }
+  void kill(int e)
+  {
+    splice(e, oprev(e));
+    splice(sym(e), oprev(sym(e)));
+    alive[e >> 2] = 0;
+  }
+  I X(int v) const { return v / ny; }
+  I Y(int v) const { return v % ny; }
+  I ccw(int a, int b, int c) const { return (X(b) - X(a)) * (Y(c) - Y(a)) - (Y(b) - Y(a)) * (X(c) - X(a)); }
+  __int128 incircle(int a, int b, int c, int d) const
+  {
+    const I adx = X(a) - X(d), ady = Y(a) - Y(d), bdx = X(b) - X(d), bdy = Y(b) - Y(d), cdx = X(c) - X(d), cdy = Y(c) - Y(d);
+    const __int128 ad = adx * adx + ady * ady, bd = bdx * bdx + bdy * bdy, cd = cdx * cdx + cdy * cdy;
+    return (__int128) adx * (bdy * cd - bd * cdy) - (__int128) ady * (bdx * cd - bd * cdx) + ad * (__int128) (bdx * cdy - bdy * cdx);
+  }
+  bool rightof(int p, int e) const { return ccw(p, dest(e), org[e]) > 0; }
+  bool leftof(int p, int e) const { return ccw(p, org[e], dest(e)) > 0; }
+  bool less_axis(int a, int b, int axis) const
+  {
+    const I ka = axis ? Y(a) : X(a), kb = axis ? Y(b) : X(b);
+    if (ka != kb) return ka < kb;
+    return (axis ? X(a) : Y(a)) < (axis ? X(b) : Y(b));
+  }
+  void arrange(int *p, int n, int axis)
+  {
+    if (n <= 3) { std::sort(p, p + n, [&](int a, int b) { return less_axis(a, b, 0); }); return; }
+    std::sort(p, p + n, [&](int a, int b) { return less_axis(a, b, axis); });
+    const int d = n >> 1;
+    if (n - d >= 2) { if (d >= 2) arrange(p, d, 1 - axis); arrange(p + d, n - d, 1 - axis); }
+  }
+  // ccw hull edge out of the frame's smallest hull vertex, cw hull edge out of its largest, from any ccw hull edge h
+  void handles(int h, int axis, int *lo, int *hi) const
+  {
+    int best_lo = h, best_hi = h, e = h;
+    do {
+      if (less_axis(org[e], org[best_lo], axis)) best_lo = e;
+      if (less_axis(dest(best_hi), dest(e), axis)) best_hi = e;
+      e = rprev(e);
+    } while (e != h);
+    *lo = best_lo; *hi = sym(best_hi);
+  }
+  int build(const int *p, int n, int axis)          // returns a ccw hull edge (the outside on its right)
+  {
+    if (n == 2) return make_edge(p[0], p[1]);
+    if (n == 3) {
+      const int a = make_edge(p[0], p[1]), b = make_edge(p[1], p[2]);
+      splice(sym(a), b);
+      const I area = ccw(p[0], p[1], p[2]);
+      if (area > 0) { connect(b, a); return a; }
+      if (area < 0) { const int c = connect(b, a); return sym(c); }
+      return a;
+    }
+    const int d = n >> 1;
+    const int hl = build(p, d, 1 - axis), hr = build(p + d, n - d, 1 - axis);
+    int ldo, ldi, rdi, rdo;
+    handles(hl, axis, &ldo, &ldi);
+    handles(hr, axis, &rdi, &rdo);
+    for (;;) {                                      // lower common tangent
+      if (leftof(org[rdi], ldi)) ldi = lnext(ldi);
+      else if (rightof(org[ldi], rdi)) rdi = rprev(rdi);
+      else break;
+    }
+    int basel = connect(sym(rdi), ldi);
+    if (org[ldi] == org[ldo]) ldo = sym(basel);
+    for (;;) {
+      int lcand = onext[sym(basel)];
+      if (rightof(dest(lcand), basel))
+        while (incircle(dest(basel), org[basel], dest(lcand), dest(onext[lcand])) > 0) { const int t2 = onext[lcand]; kill(lcand); lcand = t2; }
+      int rcand = oprev(basel);
+      if (rightof(dest(rcand), basel))
+        while (incircle(dest(basel), org[basel], dest(rcand), dest(oprev(rcand))) > 0) { const int t2 = oprev(rcand); kill(rcand); rcand = t2; }
+      const bool lv = rightof(dest(lcand), basel), rv = rightof(dest(rcand), basel);
+      if (!lv && !rv) break;
+      if (!lv || (rv && incircle(dest(lcand), org[lcand], org[rcand], dest(rcand)) > 0)) basel = connect(rcand, sym(basel));
+      else basel = connect(sym(basel), sym(lcand));
+    }
+    return ldo;
+  }
+};
+}
+// diag[(nx-1)*(ny-1)], cell (ix, iy) at ix*(ny-1)+iy: 1 = split along (ix+1,iy)-(ix,iy+1), 2 = along (ix,iy)-(ix+1,iy+1).  Host only.
+extern "C" int imdgpu_eos_triangulation(int nx, int ny, unsigned char *diag)
+{
+  if (nx < 2 || ny < 2 || !diag || (long long) nx * ny > 50000000LL) return 1;
+  GridDelaunay G;
+  G.ny = ny;
+  const int n = nx * ny;
+  G.onext.reserve(16 * (size_t) n); G.org.reserve(16 * (size_t) n); G.alive.reserve(4 * (size_t) n);
+  std::vector<int> p(n);
+  for (int q = 0; q < n; q++) p[q] = q;             // (x, y) order already
+  const int d = n >> 1;
+  if (n - d >= 2) { if (d >= 2) G.arrange(p.data(), d, 1); G.arrange(p.data() + d, n - d, 1); }
+  G.build(p.data(), n, 0);
+  memset(diag, 0, (size_t) (nx - 1) * (ny - 1));
+  for (size_t k = 0; k < G.alive.size(); k++) {
+    if (!G.alive[k]) continue;
+    int a = G.org[4 * k], b = G.org[4 * k + 2];
+    if (a / ny > b / ny) std::swap(a, b);
+    const int ia = a / ny, ja = a % ny, ib = b / ny, jb = b % ny;
+    if (ib == ia + 1 && jb == ja + 1) diag[(size_t) ia * (ny - 1) + ja] = 2;
+    else if (ib == ia + 1 && jb == ja - 1) diag[(size_t) ia * (ny - 1) + jb] = 1;
+  }
+  for (size_t q = 0; q < (size_t) (nx - 1) * (ny - 1); q++) if (!diag[q]) return 2;      // every cell of a Delaunay triangulation of a grid is split
   return 0;
 }
 
@@ -2979,6 +3152,7 @@ struct Ttm1dState {
   double *cve_z = nullptr, *ee_z = nullptr;
   EosDev cve{}, ee{};
   Lat L{};
+  unsigned char *diag[4]{};                                           // triangulation maps of the cve, ee, phase and pressure tables
   double *sumbuf = nullptr;                                           // several ranks: the slab sums on their way through the all-reduce
   double *part = nullptr, *ovf = nullptr; int *gmin = nullptr; size_t part_cap = 0;   // update_fd's block partials
   EosDev pe{}; double *pe_z = nullptr; int ep_on = 0;                  // -DELECPRESS: EOS_pe_from_r_te's table (imdgpu_ttm1d_set_epress)
@@ -3627,7 +3801,7 @@ void imdgpu_ttm1d_free(imdgpu_ctx *ctx)
   void *p[] = {t->natoms, t->natoms_old, t->temp[0], t->temp[1], t->U[0], t->U[1], t->xi, t->md_temp, t->source, t->dens, t->fd_k, t->fd_g, t->Z, t->Ce,
                t->ne, t->gi, t->gd, t->vt[0], t->vt[1], t->vm[0], t->vm[1], t->vk, t->vg, t->vCe, t->vZ, t->vne, t->sc_i, t->sc_d, t->cve_z, t->ee_z};
   for (void *q : p) if (q) (void) hipFree(q);
-  void *p2[] = {t->tmm_K12, t->tmm_phase_z, t->tmm_q, t->tmm_eps, t->tmm_sc, t->tmm_bf, t->tmm_act, t->pe_z, t->sumbuf, t->part, t->ovf, t->gmin};
+  void *p2[] = {t->tmm_K12, t->tmm_phase_z, t->tmm_q, t->tmm_eps, t->tmm_sc, t->tmm_bf, t->tmm_act, t->pe_z, t->sumbuf, t->part, t->ovf, t->gmin, t->diag[0], t->diag[1], t->diag[2], t->diag[3]};
   for (void *q : p2) if (q) (void) hipFree(q);
   delete t->tmm;
   delete t;
@@ -3685,6 +3859,7 @@ extern "C" int imdgpu_ttm1d_init(imdgpu_ctx *ctx, const imdgpu_ttm1d_params *par
   HIPCHK(hipMemcpy(t->cve_z, par->cve_z, nc * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(t->ee_z, par->ee_z, ne * 8, hipMemcpyHostToDevice));
   t->cve = EosDev{par->cve_nx, par->cve_ny, par->cve_xmin, par->cve_xmax, par->cve_ymin, par->cve_ymax, t->cve_z, nullptr};
   t->ee = EosDev{par->ee_nx, par->ee_ny, par->ee_xmin, par->ee_xmax, par->ee_ymin, par->ee_ymax, t->ee_z, nullptr};
+  if (!ctx->eos_bilinear && (eos_attach_triangulation(ctx, t->cve, &t->diag[0]) || eos_attach_triangulation(ctx, t->ee, &t->diag[1]))) return 1;
   Lat &L = t->L;
   memset(&L, 0, sizeof L);
   L.fd_min_atoms = t->fd_min_atoms; L.vol = t->vol; L.neighvol = t->neighvol; L.atomic_weight = t->aw; L.atomic_charge = t->ac; L.omega_laser = 0.0;
@@ -3810,6 +3985,7 @@ extern "C" int imdgpu_ttm1d_tmm_init(imdgpu_ctx *ctx, const imdgpu_tmm_params *p
   M.K12 = t->tmm_K12;
   M.phase.nx = p->phase.nx; M.phase.ny = p->phase.ny; M.phase.xmin = p->phase.xmin; M.phase.xmax = p->phase.xmax;
   M.phase.ymin = p->phase.ymin; M.phase.ymax = p->phase.ymax; M.phase.z = t->tmm_phase_z; M.phase.diag = nullptr;
+  if (!ctx->eos_bilinear && eos_attach_triangulation(ctx, M.phase, &t->diag[2])) return 1;
   M.q = t->tmm_q; M.eps = t->tmm_eps; M.sc = t->tmm_sc; M.bf = t->tmm_bf; M.act = t->tmm_act;
   const size_t dyn = (size_t) 8 * nx * sizeof(double);
   HIPCHK(hipFuncSetAttribute((const void *) k_ttm1d_calc<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) dyn));
@@ -3870,6 +4046,7 @@ extern "C" int imdgpu_ttm1d_set_epress(imdgpu_ctx *ctx, int nx, int ny, double x
   if (dev_alloc(ctx, &t->pe_z, (size_t) nx * ny)) return 1;
   HIPCHK(hipMemcpy(t->pe_z, z, (size_t) nx * ny * sizeof(double), hipMemcpyHostToDevice));
   t->pe.nx = nx; t->pe.ny = ny; t->pe.xmin = xmin; t->pe.xmax = xmax; t->pe.ymin = ymin; t->pe.ymax = ymax; t->pe.z = t->pe_z; t->pe.diag = nullptr;
+  if (!ctx->eos_bilinear && eos_attach_triangulation(ctx, t->pe, &t->diag[3])) return 1;
   HIPCHK(hipMemset(t->gd + 5 * (size_t) t->nx, 0, 2 * (size_t) t->nx * sizeof(double)));
   t->ep_on = 1;
   return 0;

@@ -968,6 +968,9 @@ static void ttm_gpu_init(void)
     gpu_check(imdgpu_ttm_set_eos_triangulation(G, 0, dc));
     gpu_check(imdgpu_ttm_set_eos_triangulation(G, 1, de));
     free(dc); free(de);
+  } else {                                             /* experiment: the plain bilinear rule (the library's default is its own restatement of the triangulation) */
+    gpu_check(imdgpu_ttm_set_eos_triangulation(G, 0, NULL));
+    gpu_check(imdgpu_ttm_set_eos_triangulation(G, 1, NULL));
   }
 #ifdef MPI
   if (g_multi) {

@@ -22,7 +22,7 @@ SYMBOLS = [
     "imdgpu_profile_enable", "imdgpu_profile_reset", "imdgpu_profile_get",
     "imdgpu_ttm_init", "imdgpu_ttm_dims", "imdgpu_ttm_download", "imdgpu_ttm_upload", "imdgpu_ttm_update_fd", "imdgpu_ttm_adv", "imdgpu_ttm_commflux", "imdgpu_ttm_laser_rescale", "imdgpu_ttm_set_laser", "imdgpu_ttm_get_eabs",
     "imdgpu_ttm_cell_activation", "imdgpu_ttm_fillmesh", "imdgpu_ttm_fill_ghost_layers", "imdgpu_ttm_diff",
-    "imdgpu_ttm_cfl_maxdt", "imdgpu_calc_ttm", "imdgpu_move_atoms_ttm", "imdgpu_ttm_eos_te_from_r_ee", "imdgpu_ttm_eos_lookup", "imdgpu_ttm_set_eos_triangulation",
+    "imdgpu_ttm_cfl_maxdt", "imdgpu_calc_ttm", "imdgpu_move_atoms_ttm", "imdgpu_ttm_eos_te_from_r_ee", "imdgpu_ttm_eos_lookup", "imdgpu_ttm_set_eos_triangulation", "imdgpu_eos_triangulation",
     "imdgpu_get_cell_tables", "imdgpu_upload_ghosts", "imdgpu_update_ghosts", "imdgpu_device_count", "imdgpu_autotile", "imdgpu_set_ghost_layout", "imdgpu_halo_gather", "imdgpu_halo_gather2", "imdgpu_halo_scatter",
     "imdgpu_migrate_scan", "imdgpu_migrate_gather", "imdgpu_migrate_apply", "imdgpu_forces_phase", "imdgpu_integrate",
     "imdgpu_get_invalid", "imdgpu_invalidate", "imdgpu_ttm_local_block", "imdgpu_ttm_apply_blocks",
@@ -196,6 +196,7 @@ def load():
     L.imdgpu_ttm_eos_te_from_r_ee.argtypes = [vp, C.c_int, dp, dp, dp]
     L.imdgpu_ttm_eos_lookup.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp]
     L.imdgpu_ttm_set_eos_triangulation.argtypes = [vp, C.c_int, C.c_char_p]
+    L.imdgpu_eos_triangulation.argtypes = [C.c_int, C.c_int, C.c_void_p]
     L.imdgpu_move_atoms_ttm.argtypes = [vp, dp]
     L.imdgpu_ttm_fdtd_init.argtypes = [vp, C.POINTER(FdtdParamsC)]
     L.imdgpu_ttm_fdtd_set_dl.argtypes = [vp, dp]

@@ -254,6 +254,12 @@ int imdgpu_ttm_eos_te_from_r_ee(imdgpu_ctx *ctx, int n, const double *r, const d
  * triangle's plane as the reference's.  diag: (nx-1)*(ny-1) bytes, cell (ix, iy) at ix*(ny-1)+iy: 1 = diagonal
  * (ix+1,iy)-(ix,iy+1), 2 = diagonal (ix,iy)-(ix+1,iy+1), 0 = unknown (bilinear in that cell); NULL = bilinear everywhere. */
 int imdgpu_ttm_set_eos_triangulation(imdgpu_ctx *ctx, int which /*0 cve, 1 ee*/, const unsigned char *diag);
+/* The same map WITHOUT the reference's interpolator: nn-c builds its triangulation with Shewchuk's Triangle (divide-and-conquer
+ * with alternating cuts, exact predicates); on a rectilinear grid the diagonals follow from that algorithm's tie rules alone,
+ * whatever the node spacing.  Restated from the published algorithm (imdgpu_ttm.hip: GridDelaunay) and equal to libnn.a's
+ * result on every grid tried (tests/golden/eos_triangulation.npz).  Host only, no context.  imdgpu_ttm_init and
+ * imdgpu_ttm1d_init apply it to their tables by default (option "eos_bilinear" = 1 before init: plain bilinear look-up). */
+int imdgpu_eos_triangulation(int nx, int ny, unsigned char *diag /* (nx-1)*(ny-1) bytes, coding as above */);
 /* [lpi_interpolate_point as called at :2722 (which = 1: ee(r, sqrt T) table) and :2759 (which = 0: cve(r, T) table)]
  * the raw table look-up for n points (x, y) in the table's own coordinates on host arrays, no unit factors.  Rule:
  * bilinear inside the grid cell; the reference's rule is linear on a Delaunay triangulation of the same nodes, which

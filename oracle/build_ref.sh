@@ -9,7 +9,7 @@
 # oracle/ref_probe.c, a read-only observation probe attached with ld --wrap.
 #
 # usage: oracle/build_ref.sh [target ...]
-#   targets: eam_nve_nbl  nve_nbl  eam_nve  nve  mpi_eam_nve_nbl  mpi_eam_ttm3d_nbl  mpi_eam_ttm3d_laser_nbl  mpi_eam_ttm1d_nbl  mpi_eam_ttm1d_tmm_nbl  mpi_eam_ttm1d_tmm_ep_nbl  fdtd_probe  tricub_probe  dropin
+#   targets: eam_nve_nbl  nve_nbl  eam_nve  nve  mpi_eam_nve_nbl  mpi_eam_ttm3d_nbl  mpi_eam_ttm3d_laser_nbl  mpi_eam_ttm1d_nbl  mpi_eam_ttm1d_tmm_nbl  mpi_eam_ttm1d_tmm_ep_nbl  fdtd_probe  tricub_probe  tri_probe  dropin
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 REF="${IMD_REFERENCE:-/root/reference}"
@@ -60,7 +60,7 @@ build() {
   echo "built $OUT/imd_$name"
 }
 
-TARGETS="${*:-eam_nve_nbl nve_nbl eam_nve mpi_eam_nve_nbl mpi_eam_ttm3d_nbl mpi_eam_ttm3d_laser_nbl mpi_eam_ttm1d_nbl mpi_eam_ttm1d_tmm_nbl mpi_eam_ttm1d_tmm_ep_nbl fdtd_probe tricub_probe dropin}"
+TARGETS="${*:-eam_nve_nbl nve_nbl eam_nve mpi_eam_nve_nbl mpi_eam_ttm3d_nbl mpi_eam_ttm3d_laser_nbl mpi_eam_ttm1d_nbl mpi_eam_ttm1d_tmm_nbl mpi_eam_ttm1d_tmm_ep_nbl fdtd_probe tricub_probe tri_probe dropin}"
 for t in $TARGETS; do
   case "$t" in
     eam_nve_nbl) build "$t" "-DNBL -DEAM2 -DNVE" "$COMMON $NBLSRC" "$CC" "" ;;
@@ -138,6 +138,10 @@ for t in $TARGETS; do
       $CC -o "$OUT/ref_probe_tricub" "$obj/ref_probe_tricub.o" "$obj/imd_interpol.o" "$obj/imd_misc.o" \
           "$REF/nn_interpol/libnn.a" -L$MPIINC/lib -Wl,-rpath,$MPIINC/lib -lmpi -lm
       echo "built $OUT/ref_probe_tricub" ;;
+    tri_probe)
+      # the reference's triangulator (nn-c inside nn_interpol/libnn.a) asked directly which diagonal splits every cell of a grid
+      $CC -O1 -w -I"$REF/nn_interpol" -o "$OUT/ref_probe_tri" "$HERE/ref_probe_tri.c" "$REF/nn_interpol/libnn.a" -lm
+      echo "built $OUT/ref_probe_tri" ;;
     dropin) ;;    # built below
     *) echo "unknown target $t" >&2; exit 1 ;;
   esac

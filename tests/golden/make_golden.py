@@ -767,6 +767,47 @@ def run_tricub_case():
     print("%-20s %8.1f KB" % ("tricub", os.path.getsize(path) / 1024))
 
 
+def eos_triangulation_grids():
+    """96 rectilinear grids: every size from 2x2 to 6x6, random sizes up to 45 x 45, the sizes of the fixtures' tables; uniform
+    spacing, geometric / quadratic spacing and random node positions (the map must not depend on the coordinates)"""
+    r = np.random.default_rng(11)
+    sizes = [(a, b) for a in range(2, 7) for b in range(2, 7)] + [(40, 24), (32, 32), (3, 60), (60, 3)]
+    sizes += [(9, 11)] * 3 + [(24, 40)] * 3 + [(13, 17)] * 3              # the same size with all three kinds of coordinates
+    base = len(sizes)
+    sizes += [(int(a), int(b)) for a, b in r.integers(2, 46, size=(96 - len(sizes), 2))]
+    out = []
+    for q, (nx, ny) in enumerate(sizes):
+        kind = (q - 29) % 3 if 29 <= q < base else q % 3
+        if kind == 0:
+            x, y = np.linspace(500.0, 4500.0, nx), np.linspace(1.0, 245.0, ny)
+        elif kind == 1:
+            x, y = 500.0 * 1.17 ** np.arange(nx), np.linspace(1.0, 245.0, ny) ** 2 / 50.0
+        else:
+            x, y = np.sort(r.uniform(0.0, 100.0, nx)), np.sort(r.uniform(0.0, 3.0, ny))
+        out.append((nx, ny, x, y))
+    return out
+
+
+def run_eos_triangulation_case():
+    """which diagonal the reference's triangulator (nn-c / Triangle inside nn_interpol/libnn.a) puts into every
+    cell of a table grid, asked of the archive directly (oracle/ref_probe_tri.c) -> tests/golden/eos_triangulation.npz"""
+    exe = os.path.join(REFBIN, "ref_probe_tri")
+    o = {}
+    with tempfile.TemporaryDirectory() as d:
+        for q, (nx, ny, x, y) in enumerate(eos_triangulation_grids()):
+            with open(os.path.join(d, "g.txt"), "w") as fh:
+                fh.write("%d %d\n%s\n%s\n" % (nx, ny, " ".join("%.17g" % v for v in x), " ".join("%.17g" % v for v in y)))
+            r = subprocess.run([exe, os.path.join(d, "g.txt")], stdout=subprocess.PIPE, text=True)
+            rows = r.stdout.split()
+            assert r.returncode == 0 and len(rows) == nx - 1 and all(len(w) == ny - 1 for w in rows) and "?" not in r.stdout
+            o["g%d_x" % q] = x; o["g%d_y" % q] = y
+            o["g%d_diag" % q] = np.array([[1 if c == "/" else 2 for c in w] for w in rows], np.uint8)
+        o["n"] = q + 1
+    path = os.path.join(OUT, "eos_triangulation.npz")
+    np.savez_compressed(path, **o)
+    print("%-20s %8.1f KB  %d grids" % ("eos_triangulation", os.path.getsize(path) / 1024, int(o["n"])))
+
+
 def run_chkpt_case():
     """Configuration-file fixture (imd_amd/config_io.py) -> tests/golden/chkpt.npz:
     run A writes an ASCII checkpoint after step 10, run B the same state as a binary one (binary_output 1); then
@@ -845,7 +886,7 @@ def run_ttm_file_case():
 
 
 if __name__ == "__main__":
-    names = sys.argv[1:] or (list(CASES) + ["eos_inverse", "eos_grid", "fdtd_1d", "chkpt", "ttm_file", "ttm1d_slab", "ttm1d_tmm_slab", "ttm1d_ep_slab", "tricub"])
+    names = sys.argv[1:] or (list(CASES) + ["eos_inverse", "eos_grid", "fdtd_1d", "chkpt", "ttm_file", "ttm1d_slab", "ttm1d_tmm_slab", "ttm1d_ep_slab", "tricub", "eos_triangulation"])
     for n in names:
         if n == "eos_inverse":
             run_eos_inverse()
@@ -865,6 +906,8 @@ if __name__ == "__main__":
             run_ttm1d_case(tmm=True)
         elif n == "ttm1d_ep_slab":
             run_ttm1d_case(ep=True)
+        elif n == "eos_triangulation":
+            run_eos_triangulation_case()
         elif n == "tricub":
             run_tricub_case()
         elif n.endswith("_mpi8"):
