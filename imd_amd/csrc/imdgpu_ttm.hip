@@ -566,10 +566,10 @@ __global__ void k_ttm_apply_blocks(Lat L, int steps, int nblocks, const int *off
 // ---------------------------------------------------------------------------
 // Table look-up.  The reference interpolates LINEARLY ON A TRIANGULATION of the table's nodes (nn-c lpi_interpolate_point,
 // imd_ttm_3D.c:2722,2759); which diagonal splits a grid cell is a property of its triangulator.  With a
-// triangulation map (e.diag, one byte per grid cell: 1 = diagonal (i+1,j)-(i,j+1), 2 = diagonal (i,j)-(i+1,j+1); the
-// level-1 shim reads it off the reference's own interpolator, imdgpu_ttm_set_eos_triangulation) the look-up is that
-// triangle's plane; without one (0) it is bilinear, which agrees at nodes and on cell edges and differs inside a cell
-// by at most a quarter of the cell's twist.
+// triangulation map (e.diag, one byte per grid cell: 1 = diagonal (i+1,j)-(i,j+1), 2 = diagonal (i,j)-(i+1,j+1); derived by
+// imdgpu_eos_triangulation at init -- the default --, or read off the reference's own interpolator by the level-1 shim and
+// handed over, imdgpu_ttm_set_eos_triangulation) the look-up is that triangle's plane; without one (0) it is bilinear, which
+// agrees at nodes and on cell edges and differs inside a cell by at most a quarter of the cell's twist.
 __device__ double eos_lookup(const EosDev &e, double x, double y)
 {
   double fx = (x - e.xmin) / (e.xmax - e.xmin) * (e.nx - 1);

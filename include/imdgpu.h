@@ -261,9 +261,10 @@ int imdgpu_ttm_set_eos_triangulation(imdgpu_ctx *ctx, int which /*0 cve, 1 ee*/,
  * imdgpu_ttm1d_init apply it to their tables by default (option "eos_bilinear" = 1 before init: plain bilinear look-up). */
 int imdgpu_eos_triangulation(int nx, int ny, unsigned char *diag /* (nx-1)*(ny-1) bytes, coding as above */);
 /* [lpi_interpolate_point as called at :2722 (which = 1: ee(r, sqrt T) table) and :2759 (which = 0: cve(r, T) table)]
- * the raw table look-up for n points (x, y) in the table's own coordinates on host arrays, no unit factors.  Rule:
- * bilinear inside the grid cell; the reference's rule is linear on a Delaunay triangulation of the same nodes, which
- * agrees at nodes and on cell edges and differs inside a cell by at most |z00 + z11 - z10 - z01| / 4 */
+ * the raw table look-up for n points (x, y) in the table's own coordinates on host arrays, no unit factors.  Rule: the
+ * reference's -- linear on the triangle of nn-c's Delaunay triangulation of the table nodes (imdgpu_eos_triangulation, applied
+ * by imdgpu_ttm_init).  After imdgpu_ttm_set_eos_triangulation(.., NULL) or with option eos_bilinear: bilinear inside the grid
+ * cell, which agrees at nodes and on cell edges and differs inside a cell by at most |z00 + z11 - z10 - z01| / 4 */
 int imdgpu_ttm_eos_lookup(imdgpu_ctx *ctx, int which, int n, const double *x, const double *y, double *z_out);
 /* ---- 1D Maxwell solver as laser source (BASELINE config 5; imd_fdtd.c) ---------------------------------------------
  * [init_fdtd :594-763, init_pml :765-859] on a lattice of ONE row of FD cells (fd_ext spans all MD cells in y and z),
