@@ -52,6 +52,8 @@ def test_shim_compiles_in_every_build_variant_of_the_reference():
         variants["MPI NBL"] = ["-DMPI", "-DNBL", "-DEAM2", "-DNVE", "-I" + mpi]
         variants["MPI TTM"] = ["-DMPI", "-DNBL", "-DEAM2", "-DTTM", "-DTMM", "-DEOSMODE=1", "-I" + mpi]
         variants["MPI TTM LASER"] = ["-DMPI", "-DNBL", "-DEAM2", "-DTTM", "-DTMM", "-DEOSMODE=1", "-DLASER", "-I" + mpi]
+        variants["MPI TTM1D TMM (the reference's Makefile configuration)"] = ["-DMPI", "-DNBL", "-DEAM2", "-DTTM", "-DTMM", "-DTTM1D", "-I" + mpi]
+        variants["MPI TTM1D TMM ELECPRESS"] = ["-DMPI", "-DNBL", "-DEAM2", "-DTTM", "-DTMM", "-DTTM1D", "-DELECPRESS", "-I" + mpi]
     for name, flags in variants.items():
         r = subprocess.run(["gcc", "-fsyntax-only", "-fcommon", "-w", "-I" + ref, "-I" + os.path.join(ROOT, "include")] + flags +
                            [os.path.join(ROOT, "imd_amd", "host", "imd_shim.c")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
