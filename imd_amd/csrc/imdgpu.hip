@@ -2653,6 +2653,7 @@ extern "C" int imdgpu_md_step_end(imdgpu_ctx *ctx, int steps)
   tl_flush(ctx, steps);
   if (ctx->h_counters[CNT_INVALID]) { ctx->have_valid_nbl = 0; ctx->need_fix_cells = 1; }
   if (ctx->h_counters[CNT_TTM_TIMEOUT]) return imdgpu_fail(ctx, "TTM lattice: a sub-step hand-off timed out; the lattice of this step is not valid (IMDGPU_TTM_PERSIST=0 disables the persistent sub-step kernel)");
+  if (ctx->h_counters[CNT_TMM_SHORT]) return imdgpu_fail(ctx, "Sample is too short for TMM. Consider reducing tmm_threshold.");      // imd_tmm.c:362: the reference aborts
   return 0;
 }
 extern "C" int imdgpu_md_step(imdgpu_ctx *ctx, int steps)

@@ -197,7 +197,7 @@ Geo imdgpu_make_geo(const imdgpu_ctx *c);
 
 // device counters (ints) and d_sums slots shared by the translation units
 enum { CNT_MAXNBR = 0, CNT_IS_SHORT = 1, CNT_OUTSIDE = 2, CNT_NGHOST = 3, CNT_INVALID = 4, CNT_MAXOWN = 5,
-       CNT_MAXHALO = 6, CNT_TTM_TIMEOUT = 7, CNT_N = 16 };
+       CNT_MAXHALO = 6, CNT_TTM_TIMEOUT = 7, CNT_TMM_SHORT = 12, CNT_N = 16 };     // 8..10: scratch of the migration
 enum { SUM_EPOT = 0, SUM_VIRIAL = 1, SUM_EKIN = 8, SUM_MAXDISP = 9, SUM_N = 16 };
 
 // sum of kinetic partials, max of displacement partials; decides list validity

@@ -3181,6 +3181,7 @@ struct T1dDev {
   int *gi; double *gd;
   double *vt0, *vt1, *vm0, *vm1, *vk, *vg, *vCe, *vZ, *vne;
   int *sc_i; double *sc_d;
+  int *counters;                     // the context's step counters (CNT_TMM_SHORT)
 };
 // ---- complex arithmetic as the reference's compiler does it (C99 double complex under gcc on x86-64: products inline,
 // quotients through libgcc's __divdc3 = Smith's method; csqrt like glibc's) ---------------------------------------------
@@ -3672,7 +3673,7 @@ __global__ __launch_bounds__(MAXT) void k_ttm1d_calc(T1dDev D, Lat L, EosDev cve
       int m = 1 << 30;
       for (int q = 0; q < (int) (blockDim.x >> 6); q++) m = ired[q] < m ? ired[q] : m;
       s_ecut = m == (1 << 30) ? 0 : m + 1;
-      if (m == (1 << 30)) D.sc_i[5] = 1;                                              // "Sample is too short for TMM": the host reports it
+      if (m == (1 << 30)) { D.sc_i[5] = 1; D.counters[CNT_TMM_SHORT] = 1; }           // "Sample is too short for TMM": the host reports it
     }
     __syncthreads();
     const int ecut = s_ecut;
@@ -3817,9 +3818,11 @@ static T1dDev t1d_dev(const Ttm1dState *t)
   D.gi = t->gi; D.gd = t->gd; D.vt0 = t->vt[0]; D.vt1 = t->vt[1]; D.vm0 = t->vm[0]; D.vm1 = t->vm[1]; D.vk = t->vk; D.vg = t->vg; D.vCe = t->vCe;
   D.vZ = t->vZ; D.vne = t->vne; D.sc_i = t->sc_i; D.sc_d = t->sc_d;
   if (t->tmm) D.M = *t->tmm; else { memset(&D.M, 0, sizeof D.M); }
+  D.counters = nullptr;
   D.ep_on = t->ep_on; D.pe = t->pe;
   return D;
 }
+static T1dDev t1d_dev_ctx(const imdgpu_ctx *ctx, const Ttm1dState *t) { T1dDev D = t1d_dev(t); D.counters = ctx->d_counters; return D; }
 extern "C" int imdgpu_ttm1d_init(imdgpu_ctx *ctx, const imdgpu_ttm1d_params *par)
 {
   HIPCHK(hipSetDevice(ctx->device));
@@ -3929,9 +3932,9 @@ extern "C" int imdgpu_ttm1d_stage(imdgpu_ctx *ctx, int steps, int stages)
   if ((stages & 256) && !t->tmm) return imdgpu_fail(ctx, "ttm1d_stage: stage 256 (do_tmm) needs imdgpu_ttm1d_tmm_init");
   const size_t dyn = t->tmm ? (size_t) 8 * t->nx * sizeof(double) : 0;            // the interface matrices of do_tmm
   const int need = ((t->nx + 63) & ~63) + t->nv;
-  if (need <= 256) hipLaunchKernelGGL((k_ttm1d_calc<256>), dim3(1), dim3(256), dyn, ctx->stream, t1d_dev(t), t->L, t->cve, t->ee, steps, ctx->timestep, stages);
-  else if (need <= 512) hipLaunchKernelGGL((k_ttm1d_calc<512>), dim3(1), dim3(512), dyn, ctx->stream, t1d_dev(t), t->L, t->cve, t->ee, steps, ctx->timestep, stages);
-  else hipLaunchKernelGGL((k_ttm1d_calc<T1D_MAX>), dim3(1), dim3(T1D_MAX), dyn, ctx->stream, t1d_dev(t), t->L, t->cve, t->ee, steps, ctx->timestep, stages);
+  if (need <= 256) hipLaunchKernelGGL((k_ttm1d_calc<256>), dim3(1), dim3(256), dyn, ctx->stream, t1d_dev_ctx(ctx, t), t->L, t->cve, t->ee, steps, ctx->timestep, stages);
+  else if (need <= 512) hipLaunchKernelGGL((k_ttm1d_calc<512>), dim3(1), dim3(512), dyn, ctx->stream, t1d_dev_ctx(ctx, t), t->L, t->cve, t->ee, steps, ctx->timestep, stages);
+  else hipLaunchKernelGGL((k_ttm1d_calc<T1D_MAX>), dim3(1), dim3(T1D_MAX), dyn, ctx->stream, t1d_dev_ctx(ctx, t), t->L, t->cve, t->ee, steps, ctx->timestep, stages);
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -100,3 +100,17 @@ def test_without_the_tables_nothing_changes_and_stage_needs_init():
     with pytest.raises(ImdGpuError):
         g.ttm1d_tmm_state()
     g.close()
+
+
+def test_a_sample_too_short_for_the_threshold_is_an_error_like_in_the_reference():
+    """imd_tmm.c:355-363: when the transmitted intensity never falls below exp(-tmm_threshold) inside the sample the reference
+    aborts ("Sample is too short for TMM"); the MD step fails with the same words"""
+    from imd_amd.lib import ImdGpuError
+    G = gu.load("ttm1d_tmm_slab")
+    g = _gpu(G, 0)
+    g.init_ttm1d_tmm(float(G["tmm_I0"]), float(G["tmm_lam"]), float(G["tmm_sigma_t"]), float(G["tmm_t0"]), G["tmm_eps_bb"], G["tmm_K12"],
+                     dict(x=G["eos_r"], y=G["eos_t"], z=G["tmm_phase_z"]), tmm_threshold=20.0)
+    g.md_step(0); g.md_step(1)                      # nothing happens before step 2
+    with pytest.raises(ImdGpuError, match="too short for TMM"):
+        g.md_step(2)
+    g.close()
