@@ -1112,7 +1112,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
       const unsigned g = ld_flag(P.gate);
       if (g == 1u) { go = 1; break; }
       if (g >= 2u) break;
-      if (wall_clock64() - t0 > PERSIST_CENSUS_TICKS) {
+      // trusted (no guarded launch chain behind this kernel any more; earlier launches have shown that all workgroups fit): a
+      // late arrival can only mean that something else holds compute units for the moment -- wait ten times longer before
+      // giving the step up
+      if (wall_clock64() - t0 > (P.trusted ? PERSIST_SPIN_TICKS : PERSIST_CENSUS_TICKS)) {
         unsigned expect = 0;
         if (__hip_atomic_compare_exchange_strong(P.gate, &expect, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
           __hip_atomic_store(P.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
