@@ -3355,10 +3355,10 @@ __global__ __launch_bounds__(256) void k_ttm1d_bin(int n, int apt, int cap, int 
     if (on) {
       g = t1d_slab(pos[a].x, hx, nx);
       const double px = p[a], py = p[(size_t) cap + a], pz = p[2 * (size_t) cap + a];
-      if (PHASE == 1) {
-        v[0] = 1.0; v[1] = (double) numneighs[a]; v[NQ - 3] = px; v[NQ - 2] = py; v[NQ - 1] = pz;
+      if constexpr (PHASE == 1) {                     // 0 atoms, 1 neighbours, 2 / 3 arrived from the left / right, 4..6 momentum
+        v[0] = 1.0; v[1] = (double) numneighs[a]; v[4] = px; v[5] = py; v[6] = pz;
         const int old = fdc[a];
-        if (steps > 0 && old != g) { if (old > g) v[3 % NQ] = 1.0; else v[2 % NQ] = 1.0; }     // from the right / from the left
+        if (steps > 0 && old != g) v[old > g ? 3 : 2] = 1.0;
         fdc[a] = g;
       } else {
         const double m = mass[a], ux = px / m - gd[g], uy = py / m - gd[nx + g], uz = pz / m - gd[2 * nx + g];
