@@ -16,7 +16,6 @@
 #define MU0 1.256637061435917e-06
 #define C0 3.0e8
 
-static double maxd(double a, double b) { return a > b ? a : b; }
 static double mind(double a, double b) { return a < b ? a : b; }
 
 orc_fdtd *orc_fdtd_new(int nx, double fd_h_x_angstrom, double I0, double lambda, double sigma_t, double t0, double srcx,

@@ -103,8 +103,10 @@ double orc_eos_lookup(const orc_eos *e, double x, double y)
   double fy = (y - e->ymin) / (e->ymax - e->ymin) * (e->ny - 1);
   int ix, iy;
   double tx, ty, z00, z01, z10, z11;
-  if (fx < 0) fx = 0; if (fx > e->nx - 1) fx = e->nx - 1;
-  if (fy < 0) fy = 0; if (fy > e->ny - 1) fy = e->ny - 1;
+  if (fx < 0) fx = 0;
+  if (fx > e->nx - 1) fx = e->nx - 1;
+  if (fy < 0) fy = 0;
+  if (fy > e->ny - 1) fy = e->ny - 1;
   ix = (int) fx; iy = (int) fy;
   if (ix > e->nx - 2) ix = e->nx - 2;
   if (iy > e->ny - 2) iy = e->ny - 2;
