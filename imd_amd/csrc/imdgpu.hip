@@ -1320,7 +1320,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) P3_ATTR void k_pass3_tile(TileArgs
       double xi, yi, zi, wi;
       LPOS_RDW(sp, sw, a.slot_cap, slot, xi, yi, zi, wi)
       const int it = NT1 ? 0 : ts[slot];
-      double fx = 0, fy = 0, fz = 0, vir = 0, r2min = 1e300;
+      double fx = 0, fy = 0, fz = 0, vir = 0;
       int sgn = 0;
       // list words: PFD groups of four slots in flight (only ~3 waves/SIMD are resident, so the HBM stream
       // of the list needs memory-level parallelism from each wave)

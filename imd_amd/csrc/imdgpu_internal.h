@@ -202,7 +202,7 @@ enum { SUM_EPOT = 0, SUM_VIRIAL = 1, SUM_EKIN = 8, SUM_MAXDISP = 9, SUM_N = 16 }
 
 // sum of kinetic partials, max of displacement partials; decides list validity
 // (max > (0.5*margin)^2  =>  invalid; imd_forces_nbl.c:1091).  One block.
-static __global__ void k_reduce_move(int nb, const double *partials, double *sums, double limit2, int *counters,
+[[maybe_unused]] static __global__ void k_reduce_move(int nb, const double *partials, double *sums, double limit2, int *counters,
                                      int write_ekin)
 {
   __shared__ double scratch[2 * 16];
