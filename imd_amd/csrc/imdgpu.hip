@@ -637,6 +637,14 @@ __global__ __launch_bounds__(1024) void k_tile_wprefix(int ntiles, int CPT, cons
   for (int t = t0; t < t1; t++) { wprefix[t] = acc; const int o = istart[(size_t) (t + 1) * CPT] - istart[(size_t) t * CPT]; acc += o > 0 ? o + TILE_FIXED_COST : 0; }
 }
 
+// make EXTRA=-DPLANE_CAP=n: the staged-position planes have the compile-time stride n (>= the largest tile's staged atoms):
+// the y / z plane reads then are immediate offsets of the x read's address (one address computation per neighbour instead of
+// three); the host sizes slot_cap = n.  Default: the stride is the kernel argument slot_cap.
+#ifdef PLANE_CAP
+#define SLOTCAP(a) (PLANE_CAP)
+#else
+#define SLOTCAP(a) ((a).slot_cap)
+#endif
 // halo-cell table + prefix (hstart/hsrc) and staging of positions into LDS as x, y, z planes of slot_cap
 // doubles (NC = 4: + dF plane sw).  Used by the list build; the force passes stage from the plan it writes.  The last slot (slot_cap-1) is a far-away dummy that pads the
 // neighbour list, so the inner loops need no "valid entry" test.  All threads of the block call it.
@@ -659,9 +667,9 @@ __device__ __forceinline__ void tile_stage(const TileArgs &a, TileCtx &T, double
     hstart[h + 1] = cnt; hsrc[h] = src;
   }
   if (tid == 0) {
-    sp[a.slot_cap - 1] = 1e150; sp[2 * a.slot_cap - 1] = 1e150; sp[3 * a.slot_cap - 1] = 1e150;
-    if (NC == 4) sw[a.slot_cap - 1] = 0.0;
-    if (WITH_T) ts[a.slot_cap - 1] = 0;
+    sp[SLOTCAP(a) - 1] = 1e150; sp[2 * SLOTCAP(a) - 1] = 1e150; sp[3 * SLOTCAP(a) - 1] = 1e150;
+    if (NC == 4) sw[SLOTCAP(a) - 1] = 0.0;
+    if (WITH_T) ts[SLOTCAP(a) - 1] = 0;
   }
   __syncthreads();
   if (tid < 64) {
@@ -686,13 +694,13 @@ __device__ __forceinline__ void tile_stage(const TileArgs &a, TileCtx &T, double
       sl[u] = -1;
       if (h < T.nh) {
         int s = hstart[h], n = hstart[h + 1] - s;
-        if (l < n && s + l < a.slot_cap - 1) { sl[u] = s + l; p[u] = a.pos[hsrc[h] + l]; if (WITH_T) tt[u] = a.type[hsrc[h] + l]; }
+        if (l < n && s + l < SLOTCAP(a) - 1) { sl[u] = s + l; p[u] = a.pos[hsrc[h] + l]; if (WITH_T) tt[u] = a.type[hsrc[h] + l]; }
       }
     }
 #pragma unroll
     for (int u = 0; u < 4; u++)
       if (sl[u] >= 0) {
-        sp[sl[u]] = p[u].x; sp[a.slot_cap + sl[u]] = p[u].y; sp[2 * a.slot_cap + sl[u]] = p[u].z;
+        sp[sl[u]] = p[u].x; sp[SLOTCAP(a) + sl[u]] = p[u].y; sp[2 * SLOTCAP(a) + sl[u]] = p[u].z;
         if (NC == 4) sw[sl[u]] = p[u].w;
         if (WITH_T) ts[sl[u]] = tt[u];
       }
@@ -700,9 +708,9 @@ __device__ __forceinline__ void tile_stage(const TileArgs &a, TileCtx &T, double
   for (int h = hw; h < T.nh; h += nhw) {                    // rare: cells with more than 32 atoms
     int s = hstart[h], n = hstart[h + 1] - s, src = hsrc[h];
     for (int e = l + 32; e < n; e += 32)
-      if (s + e < a.slot_cap - 1) {
+      if (s + e < SLOTCAP(a) - 1) {
         double4 q = a.pos[src + e];
-        sp[s + e] = q.x; sp[a.slot_cap + s + e] = q.y; sp[2 * a.slot_cap + s + e] = q.z;
+        sp[s + e] = q.x; sp[SLOTCAP(a) + s + e] = q.y; sp[2 * SLOTCAP(a) + s + e] = q.z;
         if (NC == 4) sw[s + e] = q.w;
         if (WITH_T) ts[s + e] = a.type[src + e];
       }
@@ -754,7 +762,7 @@ __device__ __forceinline__ int own_slot(const TileArgs &a, const TileCtx &T, int
 #endif
 __device__ __forceinline__ void stage_issue(const TileArgs &a, int tile, int nsl, int (&IDX)[STG])
 {
-  const int *src = a.tsrc + (size_t) tile * a.slot_cap;
+  const int *src = a.tsrc + (size_t) tile * SLOTCAP(a);
 #pragma unroll
   for (int u = 0; u < STG; u++) { const int s = threadIdx.x + u * blockDim.x; IDX[u] = s < nsl ? src[s] : -1; }
 }
@@ -769,23 +777,23 @@ __device__ __forceinline__ void stage_commit(const TileArgs &a, int tile, int ns
   for (int u = 0; u < STG; u++) {
     const int s = threadIdx.x + u * blockDim.x;
     if (IDX[u] >= 0) {
-      if (WITH_W) LPOS_STW(sp, sw, a.slot_cap, s, P[u].x, P[u].y, P[u].z, P[u].w * wscale)
-      else LPOS_ST(sp, sw, a.slot_cap, s, P[u].x, P[u].y, P[u].z)
+      if (WITH_W) LPOS_STW(sp, sw, SLOTCAP(a), s, P[u].x, P[u].y, P[u].z, P[u].w * wscale)
+      else LPOS_ST(sp, sw, SLOTCAP(a), s, P[u].x, P[u].y, P[u].z)
       if (WITH_T) ts[s] = TT[u];
     }
   }
-  const int *src = a.tsrc + (size_t) tile * a.slot_cap;
+  const int *src = a.tsrc + (size_t) tile * SLOTCAP(a);
   for (int s = threadIdx.x + STG * blockDim.x; s < nsl; s += blockDim.x) {
     const int gi = src[s];
     const double4 q = a.pos[gi];
-    if (WITH_W) LPOS_STW(sp, sw, a.slot_cap, s, q.x, q.y, q.z, q.w * wscale)
-    else LPOS_ST(sp, sw, a.slot_cap, s, q.x, q.y, q.z)
+    if (WITH_W) LPOS_STW(sp, sw, SLOTCAP(a), s, q.x, q.y, q.z, q.w * wscale)
+    else LPOS_ST(sp, sw, SLOTCAP(a), s, q.x, q.y, q.z)
     if (WITH_T) ts[s] = a.type[gi];
   }
   if (threadIdx.x == 0) {                          // the far-away dummy that pads the neighbour rows
-    if (WITH_W) LPOS_STW(sp, sw, a.slot_cap, a.slot_cap - 1, 1e150, 1e150, 1e150, 0.0)
-    else LPOS_ST(sp, sw, a.slot_cap, a.slot_cap - 1, 1e150, 1e150, 1e150)
-    if (WITH_T) ts[a.slot_cap - 1] = 0;
+    if (WITH_W) LPOS_STW(sp, sw, SLOTCAP(a), SLOTCAP(a) - 1, 1e150, 1e150, 1e150, 0.0)
+    else LPOS_ST(sp, sw, SLOTCAP(a), SLOTCAP(a) - 1, 1e150, 1e150, 1e150)
+    if (WITH_T) ts[SLOTCAP(a) - 1] = 0;
   }
 }
 
@@ -815,32 +823,32 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile(TileArgs a)
 {
   extern __shared__ double lds[];
   double *sp = lds;
-  int *hstart = (int *) (sp + 3 * (size_t) a.slot_cap), *hsrc = hstart + NH_MAX + 1;
+  int *hstart = (int *) (sp + 3 * (size_t) SLOTCAP(a)), *hsrc = hstart + NH_MAX + 1;
   TileCtx T;
   int t0, t1;
   block_tile_range(a.ntiles, a.wprefix, a.balance, t0, t1);
-  const unsigned short dummy = (unsigned short) (a.slot_cap - 1);
+  const unsigned short dummy = (unsigned short) (SLOTCAP(a) - 1);
   int mmax = 0;
   for (T.tile = t0; T.tile < t1; T.tile++) {
   __syncthreads();
   tile_stage<3, false>(a, T, sp, nullptr, hstart, hsrc);
   {                                                  // the staging plan of this tile for the force passes
-    int *src = a.tsrc + (size_t) T.tile * a.slot_cap;
+    int *src = a.tsrc + (size_t) T.tile * SLOTCAP(a);
     const int hw = threadIdx.x >> 5, l = threadIdx.x & 31, nhw = blockDim.x >> 5;
     for (int h = hw; h < T.nh; h += nhw) {
       const int s0 = hstart[h], n = hstart[h + 1] - s0, g0 = hsrc[h];
-      for (int e = l; e < n; e += 32) if (s0 + e < a.slot_cap - 1) src[s0 + e] = g0 + e;
+      for (int e = l; e < n; e += 32) if (s0 + e < SLOTCAP(a) - 1) src[s0 + e] = g0 + e;
     }
     if (threadIdx.x == 0) {
       const int tot = hstart[T.nh];
-      a.tinfo[T.tile] = make_int4(tot < a.slot_cap - 1 ? tot : a.slot_cap - 1, T.own_start, T.nown, 0);
+      a.tinfo[T.tile] = make_int4(tot < SLOTCAP(a) - 1 ? tot : SLOTCAP(a) - 1, T.own_start, T.nown, 0);
     }
   }
   for (int o = threadIdx.x; o < T.nown; o += blockDim.x) {
     const int i = T.own_start + o;
     int lx, ly, lz;
     const int slot = own_slot(a, T, i, hstart, hsrc, lx, ly, lz);
-    const double *sx = sp, *sy = sp + a.slot_cap, *sz = sp + 2 * a.slot_cap;
+    const double *sx = sp, *sy = sp + SLOTCAP(a), *sz = sp + 2 * SLOTCAP(a);
     const double xi = sx[slot], yi = sy[slot], zi = sz[slot];
     a.ref[i] = xi; a.ref[a.cap + i] = yi; a.ref[2 * (size_t) a.cap + i] = zi;
     unsigned long long *lp = (unsigned long long *) (a.nbr16 + (size_t) T.tile * a.W4 * a.tile_cap + o);
@@ -936,7 +944,7 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile(TileArgs a)
 // the barriers, so their latency is hidden as well.
 #define TILE_PROLOGUE(WITH_W, WITH_T, SW, TS, WSCALE)                                                                 \
     T.own_start = info.y; T.nown = info.z;                                                                       \
-    const unsigned dw = (unsigned) (a.slot_cap - 1) * 0x10001u;                                                  \
+    const unsigned dw = (unsigned) (SLOTCAP(a) - 1) * 0x10001u;                                                  \
     const uint2 dummyw = make_uint2(dw, dw);                                                                     \
     const size_t lbase = (size_t) T.tile * a.W4 * a.tile_cap;                                                    \
     unsigned ow0 = 0; uint2 w0 = dummyw, w1 = dummyw;                                                            \
@@ -1039,7 +1047,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile(TileArgs a)
   double *tr = tp + (PAIR ? a.pair.nrows * a.pair.ncols : 0);
   double *sp = tr + (EAM ? a.rho.nrows * a.rho.ncols : 0);
   sp += ((size_t) sp >> 3) & 1;                         // 16-byte records (LPOS_*): tables may hold an odd number of doubles
-  double *scratch = sp + 3 * (size_t) a.slot_cap;
+  double *scratch = sp + 3 * (size_t) SLOTCAP(a);
   int *ts = (int *) (scratch + 64);
   TileCtx T;
   int t0, t1;
@@ -1063,7 +1071,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile(TileArgs a)
       const int i = T.own_start + o;
       OWN_PROLOGUE
       double xi, yi, zi;
-      LPOS_RD(sp, sp, a.slot_cap, slot, xi, yi, zi)
+      LPOS_RD(sp, sp, SLOTCAP(a), slot, xi, yi, zi)
       const int it = NT1 ? 0 : ts[slot];
       double fx = 0, fy = 0, fz = 0, ee = 0, rr = 0, vir = 0, r2min = 1e300;
       int nb = 0;
@@ -1075,7 +1083,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile(TileArgs a)
         double dx[UNR], dy[UNR], dz[UNR], r2[UNR];
 #pragma unroll
         for (int e = 0; e < UNR; e++) {                                   // phase 1: positions from LDS, all reads first
-          LPOS_RD(sp, sp, a.slot_cap, j[e], dx[e], dy[e], dz[e])
+          LPOS_RD(sp, sp, SLOTCAP(a), j[e], dx[e], dy[e], dz[e])
         }
         SCHED_BARRIER;
 #pragma unroll
@@ -1184,7 +1192,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
   double2 *tm = (double2 *) lds;                                // (nrows + 3) rows
   const int nrows = a.pair.nrows, kz = nrows;
   double *sp = lds + 2 * (size_t) (nrows + 3);
-  double *scratch = sp + 3 * (size_t) a.slot_cap;
+  double *scratch = sp + 3 * (size_t) SLOTCAP(a);
   TileCtx T;
   int t0, t1;
   block_tile_range(a.ntiles, a.wprefix, a.balance, t0, t1);
@@ -1210,7 +1218,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
       const int i = T.own_start + o;
       OWN_PROLOGUE
       double xi, yi, zi;
-      LPOS_RD(sp, sp, a.slot_cap, slot, xi, yi, zi)
+      LPOS_RD(sp, sp, SLOTCAP(a), slot, xi, yi, zi)
       double fx = 0, fy = 0, fz = 0, ee = 0, rr = 0, vir = 0;
       int nb = 0, sgn = 0;
       LIST_WORDS_BEGIN
@@ -1219,7 +1227,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
         double2 A[UNR], B[UNR], C[UNR];
         PRIO_HI;
 #pragma unroll
-        for (int e = 0; e < UNR; e++) LPOS_RD(sp, sp, a.slot_cap, j[e], dx[e], dy[e], dz[e])
+        for (int e = 0; e < UNR; e++) LPOS_RD(sp, sp, SLOTCAP(a), j[e], dx[e], dy[e], dz[e])
         PRIO_LO;
         SCHED_BARRIER;
 #pragma unroll
@@ -1292,8 +1300,8 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) P3_ATTR void k_pass3_tile(TileArgs
   double *tr = lds;                                      // rho_h_tab, one type: + zero rows for r2 >= end (no mask)
   double *sp = tr + a.rho.nrows * a.rho.ncols + 4;      // (x, y) records, then (z, dF) records (LPOS_*) ...
   sp += ((size_t) sp >> 3) & 1;
-  double *sw = sp + 3 * (size_t) a.slot_cap;             // ... and dF in its own array (fewer bank conflicts than 32 B records)
-  double *scratch = sw + a.slot_cap;
+  double *sw = sp + 3 * (size_t) SLOTCAP(a);             // ... and dF in its own array (fewer bank conflicts than 32 B records)
+  double *scratch = sw + SLOTCAP(a);
   int *ts = (int *) (scratch + 64);
   TileCtx T;
   int t0, t1;
@@ -1318,7 +1326,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) P3_ATTR void k_pass3_tile(TileArgs
       const int i = T.own_start + o;
       OWN_PROLOGUE
       double xi, yi, zi, wi;
-      LPOS_RDW(sp, sw, a.slot_cap, slot, xi, yi, zi, wi)
+      LPOS_RDW(sp, sw, SLOTCAP(a), slot, xi, yi, zi, wi)
       const int it = NT1 ? 0 : ts[slot];
       double fx = 0, fy = 0, fz = 0, vir = 0;
       int sgn = 0;
@@ -1330,7 +1338,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) P3_ATTR void k_pass3_tile(TileArgs
         double dx[UNR], dy[UNR], dz[UNR], wj[UNR], r2[UNR];
         PRIO_HI;
 #pragma unroll
-        for (int e = 0; e < UNR; e++) LPOS_RDW(sp, sw, a.slot_cap, j[e], dx[e], dy[e], dz[e], wj[e])
+        for (int e = 0; e < UNR; e++) LPOS_RDW(sp, sw, SLOTCAP(a), j[e], dx[e], dy[e], dz[e], wj[e])
         PRIO_LO;
         SCHED_BARRIER;
 #pragma unroll
@@ -1741,6 +1749,10 @@ static int autotile(imdgpu_ctx *ctx)
     }
     if (maxown > TILE_MAXTHREADS) continue;
     int slot_cap = (int) ((maxhalo + 1 + 63) / 64 * 64);
+#ifdef PLANE_CAP
+    if (slot_cap > PLANE_CAP) continue;
+    slot_cap = PLANE_CAP;
+#endif
     if (std::max(tile_lds_bytes_for(ctx, slot_cap, 1), tile_lds_bytes_for(ctx, slot_cap, 3)) > LDS_LIMIT) continue;
     // score: atoms per workgroup round, discounted by the wave imbalance over the 4 SIMDs and by the
     // per-tile staging cost (grows with staged/own atoms; weight fitted on MI355X timings)
@@ -2312,6 +2324,10 @@ extern "C" int imdgpu_make_nblist(imdgpu_ctx *ctx)
       hipLaunchKernelGGL(k_tile_wprefix, dim3(1), dim3(1024), 0, ctx->stream, ctx->ntiles, g.CPT, ctx->istart, ctx->d_wprefix);
     }
     ctx->slot_cap = (ctx->h_counters[CNT_MAXHALO] + 1 + 63) / 64 * 64;      // + far-away dummy slot
+#ifdef PLANE_CAP
+    if (ctx->slot_cap > PLANE_CAP) return imdgpu_fail(ctx, "make_nblist: a tile stages %d atoms, the library was built with PLANE_CAP=%d", ctx->slot_cap, PLANE_CAP);
+    ctx->slot_cap = PLANE_CAP;
+#endif
     ctx->max_halo = ctx->h_counters[CNT_MAXHALO];
     if (tile_cap != ctx->tile_cap) { ctx->tile_cap = tile_cap; ctx->nbr16_cap = 0; }
     ctx->tile_threads = std::min(TILE_MAXTHREADS, ctx->tile_cap);
