@@ -3133,8 +3133,9 @@ static int fdtd_lattice_loop(imdgpu_ctx *ctx, TtmState *t, const Lat &L, int ste
 // stability limit (:97-99); U is taken from the EOS after the loop (:119-133); move_atoms_ttm takes xi and v_com of the slab
 // an atom is in NOW (imd_integrate.c:649-760).  The row is ONE global array here (the reference cuts it by rank id; its
 // rank-layout behaviour that shows in results -- every cell of the rank owning the last active cell takes the virtual
-// lattice's first cell as +x neighbour, :1535-1540 -- is reproduced through `ref_ranks`).  Not included: do_tmm (the
-// transfer-matrix Helmholtz solver; its input files are not in the tree), COLRAD, ELECPRESS, BALLISTIC.
+// lattice's first cell as +x neighbour, :1535-1540 -- is reproduced through `ref_ranks`).  do_tmm (the transfer-matrix
+// Helmholtz solver of imd_tmm.c, the model's laser source) and -DELECPRESS are included (imdgpu_ttm1d_tmm_init,
+// imdgpu_ttm1d_set_epress); not included: COLRAD, BALLISTIC.
 // Device: two atom sweeps with wave-reduced atomics (slab sums), then the WHOLE lattice part of calc_ttm -- reconstruction,
 // do_ADV, activation, FILLMESH, CFL_maxdt, the data-dependent number of sub-steps, the EOS update -- in ONE single-
 // workgroup launch, a thread per cell (real and virtual), neighbours through LDS: the row has at most ~1000 cells and the

@@ -13,8 +13,8 @@
  * owns the last active cell takes the virtual lattice's first cell as its +x neighbour (:1535-1540; `nranks` says how the
  * reference was cut).  Not reproduced (undefined or layout-dependent, cannot occur in the fixtures): reads of natomsglobal[-1] /
  * [nx] when the sample touches the box ends (:441,452, 1232-1235); freshly activated cells AT a rank boundary see a ghost
- * temperature that update_fd has just zeroed (:245-246).  do_tmm (imd_tmm.c) is at the end of this file.  Left out:
- * COLRAD, ELECPRESS, BALLISTIC, FEG EOS mode (EOSMODE 0).
+ * temperature that update_fd has just zeroed (:245-246).  do_tmm (imd_tmm.c) and -DELECPRESS are at the end of this
+ * file.  Left out: COLRAD, BALLISTIC, FEG EOS mode (EOSMODE 0).
  */
 #include "ttm_oracle.h"
 #include <complex.h>
