@@ -51,6 +51,42 @@ __global__ void k_b128(const int *idx, long long *out, double *sink)
   if (acc == 12345.678) sink[0] = acc;
 }
 
+// no-return fp64 atomics (ds_add_f64) of one wave: what an in-tile Newton-3 scatter would cost
+__global__ void k_atom(const int *idx, long long *out, double *sink)
+{
+  extern __shared__ double lds[];
+  for (int i = threadIdx.x; i < 8192; i += blockDim.x) lds[i] = 0;
+  __syncthreads();
+  const int a = idx[threadIdx.x & 63];
+  const double v = 1.0 + threadIdx.x;
+  long long t0 = clock64();
+  for (int r = 0; r < REP; r++) {
+#pragma unroll
+    for (int u = 0; u < 8; u++) unsafeAtomicAdd(&lds[a & 8191], v);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  long long t1 = clock64();
+  if ((threadIdx.x & 63) == 0) out[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
+  __syncthreads();
+  if (lds[threadIdx.x] == 12345.678) sink[0] = 1;
+}
+static int run_atom(const char *name, const std::vector<int> &idx, int waves, int *d_idx, long long *d_out, double *d_sink)
+{
+  CK(hipMemcpy(d_idx, idx.data(), 64 * sizeof(int), hipMemcpyHostToDevice));
+  for (int it = 0; it < 2; it++) {
+    hipLaunchKernelGGL(k_atom, dim3(1), dim3(64 * waves), 65536, 0, d_idx, d_out, d_sink);
+    CK(hipDeviceSynchronize());
+  }
+  long long h[32];
+  CK(hipMemcpy(h, d_out, sizeof(long long) * waves, hipMemcpyDeviceToHost));
+  double worst = 0;
+  for (int w = 0; w < waves; w++) worst = h[w] > worst ? (double) h[w] : worst;
+  printf("add64 %-44s waves %2d: %7.2f clock64 ticks per atomic per wave, %7.2f per atomic of the CU\n", name, waves,
+         worst / (REP * 8.0), worst / (REP * 8.0 * waves));
+  return 0;
+}
+
 static int run(const char *name, const std::vector<int> &idx, int waves, bool b128, int *d_idx, long long *d_out, double *d_sink)
 {
   CK(hipMemcpy(d_idx, idx.data(), 64 * sizeof(int), hipMemcpyHostToDevice));
@@ -74,8 +110,20 @@ int main()
   CK(hipMalloc(&d_idx, 64 * sizeof(int))); CK(hipMalloc(&d_out, 64 * sizeof(long long))); CK(hipMalloc(&d_sink, 8));
   CK(hipFuncSetAttribute((const void *) k_b64, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
   CK(hipFuncSetAttribute((const void *) k_b128, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  CK(hipFuncSetAttribute((const void *) k_atom, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
   std::vector<int> v(64);
   srand(12345);
+  if (getenv("PROBE_ATOMICS")) {
+    for (int waves : {1, 11, 16}) {
+      for (int l = 0; l < 64; l++) v[l] = l;                 run_atom("lane (consecutive)", v, waves, d_idx, d_out, d_sink);
+      for (int l = 0; l < 64; l++) v[l] = l / 2;             run_atom("lane pairs share an address", v, waves, d_idx, d_out, d_sink);
+      for (int l = 0; l < 64; l++) v[l] = 0;                 run_atom("all lanes one address", v, waves, d_idx, d_out, d_sink);
+      for (int t = 0; t < 3; t++) { for (int l = 0; l < 64; l++) v[l] = rand() % 704; run_atom("random slots of 704", v, waves, d_idx, d_out, d_sink); }
+      for (int t = 0; t < 2; t++) { for (int l = 0; l < 64; l++) v[l] = rand() % 3136; run_atom("random slots of 3136", v, waves, d_idx, d_out, d_sink); }
+      for (int t = 0; t < 2; t++) { for (int l = 0; l < 64; l++) v[l] = rand() % 3136; run("random slots of 3136", v, waves, false, d_idx, d_out, d_sink); }
+    }
+    return 0;
+  }
   for (int waves : {1, 16}) {
     for (int b128 = 0; b128 < 2; b128++) {
       const int nb = b128 ? 16 : 32;       // granules per 256 B
