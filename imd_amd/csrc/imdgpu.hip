@@ -573,6 +573,9 @@ struct TileArgs {
   TabPar pair, rho, emb;
   double4 *posw;                  // pos again, writable: the fused embedding pass stores F'(rho) in .w
   const double *merged;           // interleaved (phi,rho) table + 3 zero rows, or nullptr
+  const double2 *coef3;           // gradient coefficients of rho_h_tab (ctx->d_coef3): ncoef rows, the last one zero
+  int ncoef, klo;                 // k_pass3_tile_coef keeps rows [klo, ncoef) in LDS and steps aside when a pair fell below klo
+  int p3_fallback;                // k_pass3_tile: 1 = run only when k_pass3_tile_coef steps aside
   double *f, *epot, *rhoh, *ref;
   int *numneighs;
   double *partials;
@@ -1198,6 +1201,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
   block_tile_range(a.ntiles, a.wprefix, a.balance, t0, t1);
   double sums[3] = {0.0, 0.0, 0.0};        // pair energy, virial, embedding energy
   int is_short = 0;
+  int kmn = 0x7fffffff;                    // lowest table row of any pair: tells the EAM force pass which rows it needs
   if (t0 < t1) {
     const double2 *src = (const double2 *) a.merged;
     for (int k = threadIdx.x; k < nrows + 3; k += 4 * blockDim.x) {
@@ -1235,6 +1239,14 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
           dx[e] -= xi; dy[e] -= yi; dz[e] -= zi;
           r2[e] = dx[e] * dx[e] + dy[e] * dy[e] + dz[e] * dz[e];          // unfused: the reference's r2
           tab_index_open(c, r2[e], k[e], chi[e], sgn);
+        }
+#if UNR == 4
+        kmn = min(min(kmn, k[0]), k[1]); kmn = min(min(kmn, k[2]), k[3]);  // v_min3_i32
+#else
+        kmn = min(min(kmn, k[0]), k[1]);
+#endif
+#pragma unroll
+        for (int e = 0; e < UNR; e++) {
           const bool in = r2[e] <= c.end;                                 // pair: <= end (imd_forces_nbl.c:489); rho(end) = 0 exactly
           if (TTMN) nb += in ? 1 : 0;
           k[e] = in ? k[e] : kz;
@@ -1283,6 +1295,9 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
     if (FEMB) a.partials[(size_t) blockIdx.x * IMDGPU_NPART + 2] = sums[2];
   }
   if (is_short) a.counters[CNT_IS_SHORT] = 1;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(kmn, o, 64); kmn = t < kmn ? t : kmn; }
+  if ((threadIdx.x & 63) == 0 && kmn != 0x7fffffff) atomicMax(&a.counters[CNT_KNEG], 0x7fffffff - kmn);
 }
 
 // 144 VGPRs: three waves per SIMD then leave 80 registers free on EVERY SIMD, which is what one wave of the TTM
@@ -1297,6 +1312,7 @@ template <bool NT1, int RING>
 __global__ __launch_bounds__(TILE_MAXTHREADS) P3_ATTR void k_pass3_tile(TileArgs a)
 {
   extern __shared__ double lds[];
+  if (a.p3_fallback && 0x7fffffff - a.counters[CNT_KNEG] >= a.klo) return;     // k_pass3_tile_coef did this step
   double *tr = lds;                                      // rho_h_tab, one type: + zero rows for r2 >= end (no mask)
   double *sp = tr + a.rho.nrows * a.rho.ncols + 4;      // (x, y) records, then (z, dF) records (LPOS_*) ...
   sp += ((size_t) sp >> 3) & 1;
@@ -1405,10 +1421,101 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) P3_ATTR void k_pass3_tile(TileArgs
   if (is_short) a.counters[CNT_IS_SHORT] = 1;
 }
 
+// The EAM force pass for one atom type on a table grid shared with pair_pot (the merged pass 1 ran): the gradient of
+// rho_h_tab needs two numbers per table row, A_k = dv_k - d2v_k / 2 and B_k = d2v_k (grad = A_k + chi B_k is
+// DERIV_FUNC2's dv + (chi - 1/2) d2v, potaccess.h:591-621, up to one rounding), so one aligned 16-byte LDS read per
+// neighbour replaces three 8-byte reads of consecutive rows, and three VALU instructions go with them.  Twice the bytes
+// per row do not fit beside the four position planes for a 4000-row table: the kernel keeps rows [klo, ncoef) -- the
+// lowest rows belong to distances no pair of a condensed sample reaches -- and pass 1 reports the lowest row any pair of
+// THIS step fell into (CNT_KNEG): when that lies below klo this kernel returns at once and k_pass3_tile, launched right
+// behind it with p3_fallback set, does the step.  is_short is pass 1's business here (same pairs, same grid).
+template <int RING>
+__global__ __launch_bounds__(TILE_MAXTHREADS) P3_ATTR void k_pass3_tile_coef(TileArgs a)
+{
+  extern __shared__ double lds[];
+  if (0x7fffffff - a.counters[CNT_KNEG] < a.klo) return;
+  double *sp = lds;
+  double *sw = sp + 3 * (size_t) SLOTCAP(a);
+  double *scratch = sw + SLOTCAP(a);
+  double2 *tc = (double2 *) (scratch + 64);              // rows klo .. ncoef-1
+  tc += ((size_t) tc >> 3) & 1;
+  const double2 *tcb = tc - a.klo;                       // indexed by the row number itself
+  TileCtx T;
+  int t0, t1;
+  block_tile_range(a.ntiles, a.wprefix, a.balance, t0, t1);
+  double sums[1] = {0.0};
+  if (t0 < t1) {
+    const double2 *src = a.coef3 + a.klo;
+    const int nr = a.ncoef - a.klo;
+    for (int k = threadIdx.x; k < nr; k += 4 * blockDim.x) {
+      double2 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { int q = k + u * blockDim.x; if (q < nr) v[u] = src[q]; }
+#pragma unroll
+      for (int u = 0; u < 4; u++) { int q = k + u * blockDim.x; if (q < nr) tc[q] = v[u]; }
+    }
+  }
+  const double wscale = a.rho.invstep[0];                // dF staged as dF * invstep: grad = (w_i + w_j) (A + chi B)
+  const int kz = a.ncoef - 1;
+  const double begin = a.rho.begin[0], end = a.rho.end[0], istep = a.rho.invstep[0];
+  int4 info = make_int4(0, 0, 0, 0);
+  int IDX[STG];
+  if (t0 < t1) { info = a.tinfo[t0]; stage_issue(a, t0, info.x, IDX); }
+  for (T.tile = t0; T.tile < t1; T.tile++) {
+    TILE_PROLOGUE(true, false, sw, nullptr, wscale)
+    for (int o = threadIdx.x; o < T.nown; o += blockDim.x) {
+      const int i = T.own_start + o;
+      OWN_PROLOGUE
+      double xi, yi, zi, wi;
+      LPOS_RDW(sp, sw, SLOTCAP(a), slot, xi, yi, zi, wi)
+      double fx = 0, fy = 0, fz = 0, vir = 0;
+      LIST_WORDS_BEGIN
+        double dx[UNR], dy[UNR], dz[UNR], wj[UNR], r2[UNR], ch[UNR];
+        int kr[UNR];
+        double2 AB[UNR];
+        PRIO_HI;
+#pragma unroll
+        for (int e = 0; e < UNR; e++) LPOS_RDW(sp, sw, SLOTCAP(a), j[e], dx[e], dy[e], dz[e], wj[e])
+        PRIO_LO;
+        SCHED_BARRIER;
+#pragma unroll
+        for (int e = 0; e < UNR; e++) {
+          dx[e] -= xi; dy[e] -= yi; dz[e] -= zi;
+          r2[e] = dx[e] * dx[e] + dy[e] * dy[e] + dz[e] * dz[e];
+          const double q = fmax(r2[e] - begin, 0.0) * istep;
+          kr[e] = (int) q;
+          ch[e] = __builtin_amdgcn_fract(q);
+          kr[e] = (r2[e] < end) ? kr[e] : kz;                              // rho': r2 < end (imd_forces_nbl.c:868)
+        }
+        SCHED_BARRIER;
+        PRIO_HI;
+#pragma unroll
+        for (int e = 0; e < UNR; e++) AB[e] = tcb[kr[e]];
+        PRIO_LO;
+        SCHED_BARRIER;
+#pragma unroll
+        for (int e = 0; e < UNR; e++) {
+#pragma clang fp contract(fast)
+          const double grad = (wi + wj[e]) * fma(ch[e], AB[e].y, AB[e].x);
+          fx += dx[e] * grad; fy += dy[e] * grad; fz += dz[e] * grad;
+          vir += r2[e] * grad;
+        }
+        HALF_END
+      LIST_WORDS_END(RING)
+      a.f[i] += fx; a.f[a.cap + i] += fy; a.f[2 * (size_t) a.cap + i] += fz;
+      sums[0] += -0.5 * vir;
+    }
+    TILE_EPILOGUE
+  }
+  block_sum<1>(sums, scratch);
+  if (threadIdx.x == 0) a.partials[(size_t) blockIdx.x * IMDGPU_NPART + 3] = sums[0];
+}
+
 // Deterministic final reduction of the per-block partial sums
 // (tot_pot_energy, virial: imd_forces_nbl.c:319-328,:496,:521,:760,:943).
-__global__ void k_reduce_force_sums(int nb1, int nb2, const double *partials, double *sums)
+__global__ void k_reduce_force_sums(int nb1, int nb2, const double *partials, double *sums, int *counters)
 {
+  if (threadIdx.x == 0) counters[CNT_KNEG] = 0;          // both guarded EAM force kernels of this step are through
   __shared__ double scratch[4 * 16];
   double v[4] = {0, 0, 0, 0};
   for (int b = threadIdx.x; b < nb1; b += blockDim.x) {
@@ -1584,6 +1691,8 @@ extern "C" int imdgpu_set_option(imdgpu_ctx *ctx, const char *name, int value)
   }
   if (!strcmp(name, "ttm_flux")) { ctx->ttm_flux = value ? 1 : 0; if (!value) ctx->ttm_adv = 0; return 0; }
   if (!strcmp(name, "ttm_adv")) { ctx->ttm_adv = value ? 1 : 0; if (value) ctx->ttm_flux = 1; return 0; }
+  if (!strcmp(name, "p3_coef")) { ctx->p3_coef = value ? 1 : 0; return 0; }
+  if (!strcmp(name, "p3_klo")) { ctx->p3_klo = value > 0 ? value : 0; return 0; }           // tests: which rows k_pass3_tile_coef holds      // 0: the EAM force pass always reads three table rows
   if (!strcmp(name, "eos_bilinear")) { ctx->eos_bilinear = value ? 1 : 0; return 0; }    // before ttm_init / ttm1d_init
   if (!strcmp(name, "ttm_persist")) { imdgpu_ttm_set_persist(ctx, value < 0 ? -1 : (value ? 1 : 0)); return 0; }
   if (!strcmp(name, "ttm_decomposed")) {         // before ttm_init
@@ -1600,9 +1709,14 @@ extern "C" int imdgpu_set_option(imdgpu_ctx *ctx, const char *name, int value)
 }
 
 static bool fuse_emb(const imdgpu_ctx *ctx);
+static size_t p3_coef_lds(const imdgpu_ctx *ctx, int &klo);
 extern "C" int imdgpu_get_info(imdgpu_ctx *ctx, const char *name, long long *value)
 {
+  int klo_now = 0;
+  const bool coef_on = p3_coef_lds(ctx, klo_now) != 0;
   struct { const char *n; long long v; } tab[] = {
+    // rows of the gradient-coefficient table the EAM force pass holds in LDS and the first of them (0 / -1: three-row form)
+    {"p3_coef_rows", coef_on ? ctx->ncoef - klo_now : 0}, {"p3_coef_klo", coef_on ? klo_now : -1},
     {"list_mode", ctx->list_mode}, {"mode", ctx->mode}, {"tile_cap", ctx->tile_cap}, {"slot_cap", ctx->slot_cap},
     {"max_halo", ctx->max_halo}, {"W", ctx->W}, {"tile_x", ctx->tile[0]}, {"tile_y", ctx->tile[1]}, {"tile_z", ctx->tile[2]},
     {"ntiles", ctx->ntiles}, {"tile_threads", ctx->tile_threads}, {"nlocal", ctx->nlocal}, {"nghost", ctx->nghost},
@@ -1895,6 +2009,7 @@ extern "C" int imdgpu_upload_tables(imdgpu_ctx *ctx, const imdgpu_pot_table *pai
   if (rho && rho->ncols != nn) return imdgpu_fail(ctx, "rho_h_tab has %d columns, expected %d", rho->ncols, nn);
   if (emb && emb->ncols != ctx->ntypes) return imdgpu_fail(ctx, "embed_pot has %d columns, expected %d", emb->ncols, ctx->ntypes);
   if (ctx->d_merged) { (void) hipFree(ctx->d_merged); ctx->d_merged = nullptr; }
+  if (ctx->d_coef3) { (void) hipFree(ctx->d_coef3); ctx->d_coef3 = nullptr; ctx->ncoef = 0; }
   if (pair && rho && ctx->ntypes == 1 && pair->maxsteps == rho->maxsteps && pair->begin[0] == rho->begin[0] &&
       pair->end[0] == rho->end[0] && pair->invstep[0] == rho->invstep[0]) {
     const int R = pair->maxsteps + 2;
@@ -1902,6 +2017,17 @@ extern "C" int imdgpu_upload_tables(imdgpu_ctx *ctx, const imdgpu_pot_table *pai
     for (int k = 0; k < R; k++) { m[2 * k] = pair->table[k]; m[2 * k + 1] = rho->table[k]; }
     HIPCHK(hipMalloc((void **) &ctx->d_merged, m.size() * sizeof(double)));
     HIPCHK(hipMemcpy(ctx->d_merged, m.data(), m.size() * sizeof(double), hipMemcpyHostToDevice));
+    // gradient coefficients of rho_h_tab for k_pass3_tile_coef: rows 0 .. maxsteps-1 (row k needs table rows k .. k+2), then a zero row
+    const int NC = rho->maxsteps + 1;
+    std::vector<double> cf(2 * (size_t) NC, 0.0);
+    for (int k = 0; k + 1 < NC; k++) {
+      const double p0 = rho->table[k], p1 = rho->table[k + 1], p2 = rho->table[k + 2];
+      const double dv = p1 - p0, d2v = (p2 - 2 * p1) + p0;
+      cf[2 * k] = dv - 0.5 * d2v; cf[2 * k + 1] = d2v;
+    }
+    HIPCHK(hipMalloc((void **) &ctx->d_coef3, cf.size() * sizeof(double)));
+    HIPCHK(hipMemcpy(ctx->d_coef3, cf.data(), cf.size() * sizeof(double), hipMemcpyHostToDevice));
+    ctx->ncoef = NC;
   }
   // tables larger than the LDS (several atom types: ntypes^2 columns) are read in place by the global-gather
   // kernels (k_pass1_gt / k_pass3_gt); the tile kernels need them in LDS, make_nblist then picks list_mode 0
@@ -2250,6 +2376,7 @@ static TileArgs make_tile_args(imdgpu_ctx *ctx)
   a.tsrc = ctx->tsrc; a.ownw = ctx->ownw; a.tinfo = (int4 *) ctx->tinfo;
   { static const int dbg = getenv("IMDGPU_DBG") ? atoi(getenv("IMDGPU_DBG")) : 0; a.dbg = dbg; }
   a.pair = ctx->pair.par; a.rho = ctx->rho.par; a.emb = ctx->emb.par; a.posw = ctx->pos; a.merged = ctx->d_merged;
+  a.coef3 = (const double2 *) ctx->d_coef3; a.ncoef = ctx->ncoef; a.klo = 0; a.p3_fallback = 0;
   a.f = ctx->f; a.epot = ctx->epot; a.rhoh = ctx->rhoh; a.ref = ctx->ref; a.numneighs = ctx->numneighs;
   a.partials = ctx->partials; a.counters = ctx->d_counters; a.cellsz = ctx->cellsz; a.guard = nullptr;
   a.balance = ctx->tile_balance; a.wprefix = ctx->d_wprefix;
@@ -2432,6 +2559,22 @@ extern "C" int imdgpu_check_nblist(imdgpu_ctx *ctx, int *valid)
 // used when an external halo exchange (multi-rank) has to run between the passes
 // the embedding pass is folded into pass 1 whenever the merged-table tile kernel runs (one atom type, pair and rho on the
 // same grid); IMDGPU_FUSE_EMB=0 keeps the separate k_pass2 (experiments)
+static bool fuse_emb(const imdgpu_ctx *ctx);
+// LDS bytes of k_pass3_tile_coef and the first coefficient row it holds; 0 = not applicable (several types, tables on
+// different grids, the option off, or more than a quarter of the rows would have to stay out)
+static size_t p3_coef_lds(const imdgpu_ctx *ctx, int &klo)
+{
+  static const int env = getenv("IMDGPU_P3_COEF") ? atoi(getenv("IMDGPU_P3_COEF")) : 1;
+  if (!env || !ctx->p3_coef || ctx->list_mode != 1 || ctx->ntypes != 1 || !ctx->pair.present || !ctx->rho.present ||
+      !ctx->d_merged || !ctx->d_coef3) return 0;
+  const size_t fixed = align8((4 * (size_t) ctx->slot_cap + 64 + 2) * 8);
+  if (fixed + 64 * 16 > LDS_LIMIT) return 0;
+  const int fit = (int) ((LDS_LIMIT - fixed) / 16);
+  klo = ctx->ncoef > fit ? ctx->ncoef - fit : 0;
+  if (klo > ctx->ncoef / 4) return 0;
+  if (ctx->p3_klo > klo) klo = ctx->p3_klo < ctx->ncoef - 1 ? ctx->p3_klo : ctx->ncoef - 1;
+  return fixed + (size_t) (ctx->ncoef - klo) * 16;
+}
 static bool fuse_emb(const imdgpu_ctx *ctx)
 {
   static const int on = getenv("IMDGPU_FUSE_EMB") ? atoi(getenv("IMDGPU_FUSE_EMB")) : 1;
@@ -2516,6 +2659,23 @@ static int launch_forces(imdgpu_ctx *ctx, int phase = 0)
     HIPCHK(hipFuncSetAttribute((const void *) k_pass3_tile<N, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) l)); \
     hipLaunchKernelGGL((k_pass3_tile<N, R>), dim3(nb), dim3(B), l, ctx->stream, ta);                                 \
   } while (0)
+      // one type behind the merged pass 1: the coefficient form first, the three-row form behind it as its stand-in for
+      // steps in which a pair fell below the rows the LDS holds (both look at CNT_KNEG and one of them returns at once)
+      int klo = 0;
+      const size_t lc = p3_coef_lds(ctx, klo);
+      if (lc) {
+        ta.klo = klo;
+#define L3C(R)                                                                                                       \
+  do {                                                                                                               \
+    HIPCHK(hipFuncSetAttribute((const void *) k_pass3_tile_coef<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lc)); \
+    hipLaunchKernelGGL((k_pass3_tile_coef<R>), dim3(nb), dim3(B), lc, ctx->stream, ta);                              \
+  } while (0)
+        // 132 VGPRs with the register ring: three waves per SIMD still leave the 80 a wave of the lattice chain needs
+        static const int ring = getenv("IMDGPU_P3_RING") ? atoi(getenv("IMDGPU_P3_RING")) : 4;
+        if (ring == 0) L3C(0); else L3C(4);
+#undef L3C
+        ta.p3_fallback = 1;
+      }
       if (ctx->ttm) { if (NT1) L3(true, 0); else L3(false, 0); }
       else { if (NT1) L3(true, 4); else L3(false, 4); }
 #undef L3
@@ -2525,7 +2685,7 @@ static int launch_forces(imdgpu_ctx *ctx, int phase = 0)
   }
   if (phase == 0 || phase == 3) {
     ProfScope ps(ctx, PROF_REDUCE);
-    hipLaunchKernelGGL(k_reduce_force_sums, dim3(1), dim3(1024), 0, ctx->stream, nb, EAM ? nb2 : 0, ctx->partials, ctx->d_sums);
+    hipLaunchKernelGGL(k_reduce_force_sums, dim3(1), dim3(1024), 0, ctx->stream, nb, EAM ? nb2 : 0, ctx->partials, ctx->d_sums, ctx->d_counters);
   }
   imdgpu_tl_mark(ctx, "pass3");
   HIPCHK(hipGetLastError());

@@ -55,6 +55,11 @@ struct imdgpu_ctx {
   double cellsz = 0, nbl_margin = 0, timestep = 0;
   DevTable pair, rho, emb;
   double *d_merged = nullptr;     // (phi,rho) interleaved + 3 zero rows when both share one r^2 grid
+  // one atom type, merged tables: the gradient of rho_h_tab as two coefficients per row, (dv - d2v/2, d2v), + one zero row:
+  // what the EAM force pass reads instead of three table rows (k_pass3_tile_coef)
+  double *d_coef3 = nullptr; int ncoef = 0;
+  int p3_coef = 1;                // option "p3_coef": 0 keeps k_pass3_tile for every step
+  int p3_klo = 0;                 // option "p3_klo" (tests): keep at least this many of the lowest rows out of the LDS
   double *d_restr = nullptr;      // ntypes*3
   int restr_identity = 1;         // every factor is 1: the integrators need not write the (unchanged) forces back
 
@@ -197,7 +202,8 @@ Geo imdgpu_make_geo(const imdgpu_ctx *c);
 
 // device counters (ints) and d_sums slots shared by the translation units
 enum { CNT_MAXNBR = 0, CNT_IS_SHORT = 1, CNT_OUTSIDE = 2, CNT_NGHOST = 3, CNT_INVALID = 4, CNT_MAXOWN = 5,
-       CNT_MAXHALO = 6, CNT_TTM_TIMEOUT = 7, CNT_TMM_SHORT = 12, CNT_N = 16 };     // 8..10: scratch of the migration
+       CNT_MAXHALO = 6, CNT_TTM_TIMEOUT = 7, CNT_TMM_SHORT = 12, CNT_KNEG = 13, CNT_N = 16 };     // 8..10: scratch of the migration
+// CNT_KNEG: INT_MAX - (lowest table row any pair of this step's pass 1 fell into); zeroed by k_reduce_force_sums
 enum { SUM_EPOT = 0, SUM_VIRIAL = 1, SUM_EKIN = 8, SUM_MAXDISP = 9, SUM_N = 16 };
 
 // sum of kinetic partials, max of displacement partials; decides list validity

@@ -1130,6 +1130,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
   }
   go = __shfl(go, 0, 64);
   if (!go) return;                                     // nothing of the lattice has been touched
+  if (L.wave_prio) __builtin_amdgcn_s_setprio(2);      // IMDGPU_TTM_PRIO: experiment
   // ---- neighbours ------------------------------------------------------------------------------------------------
   // per direction: nc = cell index of the neighbour, or -1 = mirror (outside an open boundary or an inactive cell; the
   // ghost shell is resolved on the fly as in k_ttm_diff<.., WRAP = true>); intile bit = the neighbour is a lane of this wave
@@ -2205,10 +2206,12 @@ static int launch_persist(imdgpu_ctx *ctx, TtmState *t, const Lat &L, double tau
 #define PERSIST_LAUNCH(S, W, R)                                                                                                  \
   hipLaunchKernelGGL((k_ttm_chain_persist<S, W, R>), dim3(t->persist_tiles), dim3(64), 0, ctx->stream, L, tau, t->nsub, t->natoms, T0, T1, \
                      U0, U1, K0, K1, t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve, P)
-  if (rem) { if (t->have_source) { if (alone) PERSIST_LAUNCH(true, 4, true); else PERSIST_LAUNCH(true, 6, true); }
-             else { if (alone) PERSIST_LAUNCH(false, 4, true); else PERSIST_LAUNCH(false, 6, true); } }
-  else if (t->have_source) { if (alone) PERSIST_LAUNCH(true, 4, false); else PERSIST_LAUNCH(true, 6, false); }
-  else { if (alone) PERSIST_LAUNCH(false, 4, false); else PERSIST_LAUNCH(false, 6, false); }
+  static const int wpe_env = getenv("IMDGPU_TTM_WPE") ? atoi(getenv("IMDGPU_TTM_WPE")) : 6;
+  const int wpe = alone ? 4 : (wpe_env == 5 ? 5 : 6);
+#define PERSIST_W(S, R) { if (wpe == 4) PERSIST_LAUNCH(S, 4, R); else if (wpe == 5) PERSIST_LAUNCH(S, 5, R); else PERSIST_LAUNCH(S, 6, R); }
+  if (rem) { if (t->have_source) PERSIST_W(true, true) else PERSIST_W(false, true) }
+  else if (t->have_source) PERSIST_W(true, false) else PERSIST_W(false, false)
+#undef PERSIST_W
 #undef PERSIST_LAUNCH
   HIPCHK(hipGetLastError());
   if (!t->pstat_pending) {                               // feedback for persist_mode; never waited for
