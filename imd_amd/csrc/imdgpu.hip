@@ -1430,7 +1430,11 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) P3_ATTR void k_pass3_tile(TileArgs
 // THIS step fell into (CNT_KNEG): when that lies below klo this kernel returns at once and k_pass3_tile, launched right
 // behind it with p3_fallback set, does the step.  is_short is pass 1's business here (same pairs, same grid).
 template <int RING>
-__global__ __launch_bounds__(TILE_MAXTHREADS) P3_ATTR void k_pass3_tile_coef(TileArgs a)
+// four waves per SIMD's worth of registers (<= 128; two spilled with the register ring): three waves of this kernel then leave
+// every SIMD the 128 registers a wave of the lattice chain's spill-free build needs (k_ttm_chain_persist<.., 4, ..>).  Measured
+// at 10 M atoms + TTM: 132 registers beside the 80-register chain 4.82 ms per step, beside the 96-register chain 4.67,
+// 128 beside the 128-register chain 4.62 (profiles/r03_kernel_variants.json)
+__global__ __launch_bounds__(TILE_MAXTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_pass3_tile_coef(TileArgs a)
 {
   extern __shared__ double lds[];
   if (0x7fffffff - a.counters[CNT_KNEG] < a.klo) return;
@@ -2575,6 +2579,9 @@ static size_t p3_coef_lds(const imdgpu_ctx *ctx, int &klo)
   if (ctx->p3_klo > klo) klo = ctx->p3_klo < ctx->ncoef - 1 ? ctx->p3_klo : ctx->ncoef - 1;
   return fixed + (size_t) (ctx->ncoef - klo) * 16;
 }
+// does the EAM force pass of this context run in its coefficient form (128 registers)?  The lattice chain forked beside it
+// picks its register budget by this
+int imdgpu_p3_coef_active(const imdgpu_ctx *ctx) { int klo; return p3_coef_lds(ctx, klo) != 0; }
 static bool fuse_emb(const imdgpu_ctx *ctx)
 {
   static const int on = getenv("IMDGPU_FUSE_EMB") ? atoi(getenv("IMDGPU_FUSE_EMB")) : 1;

@@ -230,6 +230,7 @@ enum { SUM_EPOT = 0, SUM_VIRIAL = 1, SUM_EKIN = 8, SUM_MAXDISP = 9, SUM_N = 16 }
 int imdgpu_ensure_capacity(imdgpu_ctx *ctx, int nlocal, int ntot);
 int imdgpu_launch_forces_phase(imdgpu_ctx *ctx, int phase);
 int imdgpu_launch_integrate(imdgpu_ctx *ctx);
+int imdgpu_p3_coef_active(const imdgpu_ctx *ctx);
 
 // TTM entry points called from imdgpu_md_step
 int imdgpu_ttm_step_internal(imdgpu_ctx *ctx, int steps);

@@ -1082,8 +1082,9 @@ __device__ __forceinline__ int face_index(const Lat &L, int q, int i, int j, int
 }
 
 // WPE = waves per SIMD the register budget is cut for: 6 (80 VGPRs, 52 of them spilled to scratch) is what fits beside three
-// 144-register waves of the force pass -- the forked chain of an MD step; 4 (128 VGPRs, no spills: 0.76 instead of 0.83 ms)
-// is what a stand-alone calc_ttm runs, alone on the chip
+// 144-register waves of the three-row EAM force pass; 4 (128 VGPRs, no spills: 0.76 instead of 0.83 ms alone) is what a
+// stand-alone calc_ttm runs and what fits beside the 128-register coefficient form of the force pass (the usual case); 5 (96
+// VGPRs) is kept for experiments
 // REM: the lattice is this rank's BLOCK of a decomposed lattice; faces towards other ranks go through PersistDev::xrec / peer
 template <bool SRC, int WPE, bool REM>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_ttm_chain_persist(
@@ -2206,8 +2207,10 @@ static int launch_persist(imdgpu_ctx *ctx, TtmState *t, const Lat &L, double tau
 #define PERSIST_LAUNCH(S, W, R)                                                                                                  \
   hipLaunchKernelGGL((k_ttm_chain_persist<S, W, R>), dim3(t->persist_tiles), dim3(64), 0, ctx->stream, L, tau, t->nsub, t->natoms, T0, T1, \
                      U0, U1, K0, K1, t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve, P)
-  static const int wpe_env = getenv("IMDGPU_TTM_WPE") ? atoi(getenv("IMDGPU_TTM_WPE")) : 6;
-  const int wpe = alone ? 4 : (wpe_env == 5 ? 5 : 6);
+  // register budget: 128 (no spills) alone on the chip and beside the coefficient form of the EAM force pass, whose three
+  // 128-register waves leave exactly that on every SIMD; 80 beside the three-row form (138 registers).  IMDGPU_TTM_WPE=4|5|6 overrides.
+  static const int wpe_env = getenv("IMDGPU_TTM_WPE") ? atoi(getenv("IMDGPU_TTM_WPE")) : 0;
+  const int wpe = alone ? 4 : (wpe_env >= 4 && wpe_env <= 6 ? wpe_env : (imdgpu_p3_coef_active(ctx) ? 4 : 6));
 #define PERSIST_W(S, R) { if (wpe == 4) PERSIST_LAUNCH(S, 4, R); else if (wpe == 5) PERSIST_LAUNCH(S, 5, R); else PERSIST_LAUNCH(S, 6, R); }
   if (rem) { if (t->have_source) PERSIST_W(true, true) else PERSIST_W(false, true) }
   else if (t->have_source) PERSIST_W(true, false) else PERSIST_W(false, false)
