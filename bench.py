@@ -529,8 +529,9 @@ def main():
                 label = kn + (" (pass 1: pair + rho, embedding pass folded in)" if fused else " (pass 1: pair + rho)")
             else:
                 byts = natoms * (84.0 + 4.0 * M)
-                kn = ("k_pass3_tile<true, %d>" % sysm.get_info("pass3_ring")) if tiles else "k_pass3"     # one atom type here
-                label = kn + " (pass 3: EAM force pass)"
+                coef = tiles and sysm.get_info("p3_coef_rows") > 0          # one atom type here
+                kn = "k_pass3_tile_coef<4>" if coef else (("k_pass3_tile<true, %d>" % sysm.get_info("pass3_ring")) if tiles else "k_pass3")
+                label = kn + (" (pass 3: EAM force pass, gradient-coefficient table)" if coef else " (pass 3: EAM force pass)")
             avg = ms / max(n, 1)
             a = byts / (avg * 1e-3) / 1e9 if n else 0.0
             tr, src = measured_traffic(kn, natoms, krev)

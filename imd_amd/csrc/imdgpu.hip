@@ -554,7 +554,7 @@ __global__ __launch_bounds__(512) void k_pass3_gt(ForceArgs a)
 // neighbour list holds 16-bit LDS slot numbers (4 per 8-byte load, ELL-transposed
 // per tile).  HBM sees: list (2 B/entry), own-atom outputs, one staging pass.
 // ===========================================================================
-#define IMDGPU_KERNEL_REV 4
+#define IMDGPU_KERNEL_REV 5
 #define LDS_LIMIT (160 * 1024)
 #define TABLE_LDS_LIMIT (150 * 1024)                 // global-gather kernels: tables beyond this stay in global memory
 #define NH_MAX 512                                   // halo cells per tile (<= 6*6*6 = 216 for tiles up to 4^3)
@@ -2571,6 +2571,7 @@ static size_t p3_coef_lds(const imdgpu_ctx *ctx, int &klo)
   static const int env = getenv("IMDGPU_P3_COEF") ? atoi(getenv("IMDGPU_P3_COEF")) : 1;
   if (!env || !ctx->p3_coef || ctx->list_mode != 1 || ctx->ntypes != 1 || !ctx->pair.present || !ctx->rho.present ||
       !ctx->d_merged || !ctx->d_coef3) return 0;
+  if (imdgpu_ttm_chain_needs_lds(ctx)) return 0;      // this kernel leaves no LDS to anything beside it
   const size_t fixed = align8((4 * (size_t) ctx->slot_cap + 64 + 2) * 8);
   if (fixed + 64 * 16 > LDS_LIMIT) return 0;
   const int fit = (int) ((LDS_LIMIT - fixed) / 16);

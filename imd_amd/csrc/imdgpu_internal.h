@@ -231,6 +231,7 @@ int imdgpu_ensure_capacity(imdgpu_ctx *ctx, int nlocal, int ntot);
 int imdgpu_launch_forces_phase(imdgpu_ctx *ctx, int phase);
 int imdgpu_launch_integrate(imdgpu_ctx *ctx);
 int imdgpu_p3_coef_active(const imdgpu_ctx *ctx);
+int imdgpu_ttm_chain_needs_lds(const imdgpu_ctx *ctx);
 
 // TTM entry points called from imdgpu_md_step
 int imdgpu_ttm_step_internal(imdgpu_ctx *ctx, int steps);

@@ -2189,6 +2189,19 @@ static int persist_mode(imdgpu_ctx *ctx, TtmState *t)
   return t->persist;
 }
 
+// Does the lattice work that is forked beside the EAM force pass need LDS of its own?  The coefficient form of that pass
+// (k_pass3_tile_coef) fills the CU's 160 KB, so kernels with LDS tiles would have to wait for its workgroups to end: the
+// launch chain of the sub-steps (lattices the persistent kernel does not take: 10 M-atom slab, measured 6.12 -> 6.94 ms
+// per step) and the 1D model's single workgroup.  The persistent sub-step kernel and the Maxwell-solver loop use none.
+int imdgpu_ttm_chain_needs_lds(const imdgpu_ctx *ctx)
+{
+  if (ctx->ttm1d) return 1;
+  const TtmState *t = ctx->ttm;
+  if (!t) return 0;
+  if (t->fdtd && t->fdtd_on) return 0;
+  return t->persist > 0 ? 0 : 1;
+}
+
 static int launch_persist(imdgpu_ctx *ctx, TtmState *t, const Lat &L, double tau, int mode, bool rem = false)
 {
   PersistDev P;
