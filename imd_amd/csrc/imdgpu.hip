@@ -1312,7 +1312,10 @@ template <bool NT1, int RING>
 __global__ __launch_bounds__(TILE_MAXTHREADS) P3_ATTR void k_pass3_tile(TileArgs a)
 {
   extern __shared__ double lds[];
-  if (a.p3_fallback && 0x7fffffff - a.counters[CNT_KNEG] >= a.klo) return;     // k_pass3_tile_coef did this step
+  if (a.p3_fallback) {                                   // did k_pass3_tile_coef do this step?  (same test as there)
+    const int kneg = a.counters[CNT_KNEG];
+    if (kneg != 0 && 0x7fffffff - kneg >= a.klo) return;
+  }
   double *tr = lds;                                      // rho_h_tab, one type: + zero rows for r2 >= end (no mask)
   double *sp = tr + a.rho.nrows * a.rho.ncols + 4;      // (x, y) records, then (z, dF) records (LPOS_*) ...
   sp += ((size_t) sp >> 3) & 1;
@@ -1427,8 +1430,8 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) P3_ATTR void k_pass3_tile(TileArgs
 // neighbour replaces three 8-byte reads of consecutive rows, and three VALU instructions go with them.  Twice the bytes
 // per row do not fit beside the four position planes for a 4000-row table: the kernel keeps rows [klo, ncoef) -- the
 // lowest rows belong to distances no pair of a condensed sample reaches -- and pass 1 reports the lowest row any pair of
-// THIS step fell into (CNT_KNEG): when that lies below klo this kernel returns at once and k_pass3_tile, launched right
-// behind it with p3_fallback set, does the step.  is_short is pass 1's business here (same pairs, same grid).
+// THIS step fell into (CNT_KNEG): when that lies below klo -- or when no pass 1 has reported since the last force pass --
+// this kernel returns at once and k_pass3_tile, launched right behind it with p3_fallback set, does the step.  is_short is pass 1's business here (same pairs, same grid).
 template <int RING>
 // four waves per SIMD's worth of registers (<= 128; two spilled with the register ring): three waves of this kernel then leave
 // every SIMD the 128 registers a wave of the lattice chain's spill-free build needs (k_ttm_chain_persist<.., 4, ..>).  Measured
@@ -1437,7 +1440,10 @@ template <int RING>
 __global__ __launch_bounds__(TILE_MAXTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_pass3_tile_coef(TileArgs a)
 {
   extern __shared__ double lds[];
-  if (0x7fffffff - a.counters[CNT_KNEG] < a.klo) return;
+  {                                                      // no report from a pass 1 of this step (0), or a pair below the rows held here
+    const int kneg = a.counters[CNT_KNEG];
+    if (kneg == 0 || 0x7fffffff - kneg < a.klo) return;
+  }
   double *sp = lds;
   double *sw = sp + 3 * (size_t) SLOTCAP(a);
   double *scratch = sw + SLOTCAP(a);
