@@ -53,13 +53,18 @@ int  imdgpu_set_stream(imdgpu_ctx *ctx, void *hip_stream);
 int  imdgpu_synchronize(imdgpu_ctx *ctx);
 /* tuning knobs: "mode" = 1 LDS-tiled force kernels (default), 0 global-gather kernels;
  * "ttm_persist" = 1 (default) all diffusion sub-steps of an MD step in one persistent launch where that applies,
- * 0 the captured chain of one launch per sub-step (same results bit for bit), -1 back to the default */
+ * 0 the captured chain of one launch per sub-step (same results bit for bit), -1 back to the default;
+ * "p3_coef" = 1 (default) the EAM force pass (do_forces_eam2, imd_forces_nbl.c:789-985) reads DERIV_FUNC2's gradient
+ * (potaccess.h:591-621) as one coefficient pair per table row where that applies (one atom type, pair_pot and rho_h_tab on
+ * one r^2 grid, nothing with LDS tiles of its own beside it), 0 always as three table rows; the two agree to rounding */
 int  imdgpu_set_option(imdgpu_ctx *ctx, const char *name, int value);
 /* introspection: "list_mode" (kernel family of the current list), "tile_cap", "slot_cap", "W", "ntiles", ...,
  * "fused_embedding" (1: the embedding pass runs inside the pass-1 kernel of the current list),
  * "ttm_flux", "ttm_adv", "ttm_block_width" (doubles per FD cell in imdgpu_ttm_local_block's records),
  * "ttm_persist_mode" (0 launch chain, 1 persistent kernel on trial with the chain behind it, 2 persistent kernel alone,
- * -1 not decided yet), "ttm_persist_runs" (persistent launches that came through), "kernel_rev" */
+ * -1 not decided yet), "ttm_persist_runs" (persistent launches that came through), "kernel_rev",
+ * "p3_coef_rows" / "p3_coef_klo" (rows of the gradient-coefficient table the EAM force pass holds in LDS and the first
+ * of them; 0 / -1: the three-row form) */
 int  imdgpu_get_info(imdgpu_ctx *ctx, const char *name, long long *value);
 
 /* ---- set-up -------------------------------------------------------------- */
