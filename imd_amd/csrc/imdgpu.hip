@@ -822,6 +822,9 @@ __global__ void k_tile_stats(int ntiles, Geo g, const int *cell_cnt, const int *
 }
 
 // Verlet list build, tile form.  Same predicate / same candidate order as k_nbl_build.
+#ifndef NBL_GROUP
+#define NBL_GROUP 4               // candidates in flight per thread (a power of two <= 32)
+#endif
 __global__ __launch_bounds__(1024) void k_nbl_build_tile(TileArgs a)
 {
   extern __shared__ double lds[];
@@ -870,20 +873,20 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile(TileArgs a)
           for (int j0 = s; j0 < e; j0 += 32) {
             const int cnt = e - j0 < 32 ? e - j0 : 32;
             unsigned mask = 0;
-            // reads may run up to 3 slots past the cell (the next cell's atoms or the planes' padding): their bits are
+            // reads may run up to NBL_GROUP - 1 slots past the cell (the next cell's atoms or the planes' padding): their bits are
             // cleared below, so the loop needs no per-candidate bounds or self tests
-            for (int u0 = 0; u0 < cnt; u0 += 4) {
+            for (int u0 = 0; u0 < cnt; u0 += NBL_GROUP) {
               const double *px = sx + j0 + u0, *py = sy + j0 + u0, *pz = sz + j0 + u0;
-              double r2[4];
+              double r2[NBL_GROUP];
 #pragma unroll
-              for (int u = 0; u < 4; u++) {
+              for (int u = 0; u < NBL_GROUP; u++) {
                 const double ex = px[u] - xi, ey = py[u] - yi, ez = pz[u] - zi;
                 r2[u] = ex * ex + ey * ey + ez * ez;          // unfused, as the reference (imd_forces_nbl.c:218-222)
               }
-              unsigned four = 0;
+              unsigned grp = 0;
 #pragma unroll
-              for (int u = 0; u < 4; u++) four |= (r2[u] < a.cellsz) ? (1u << u) : 0u;
-              mask |= four << u0;
+              for (int u = 0; u < NBL_GROUP; u++) grp |= (r2[u] < a.cellsz) ? (1u << u) : 0u;
+              mask |= grp << u0;
             }
             mask &= cnt == 32 ? 0xffffffffu : ((1u << cnt) - 1u);
             if (slot >= j0 && slot < j0 + 32) mask &= ~(1u << (slot - j0));   // not its own neighbour
