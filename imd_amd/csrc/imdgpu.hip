@@ -1705,7 +1705,7 @@ extern "C" int imdgpu_set_option(imdgpu_ctx *ctx, const char *name, int value)
   if (!strcmp(name, "ttm_flux")) { ctx->ttm_flux = value ? 1 : 0; if (!value) ctx->ttm_adv = 0; return 0; }
   if (!strcmp(name, "ttm_adv")) { ctx->ttm_adv = value ? 1 : 0; if (value) ctx->ttm_flux = 1; return 0; }
   if (!strcmp(name, "p3_coef")) { ctx->p3_coef = value ? 1 : 0; return 0; }
-  if (!strcmp(name, "p3_klo")) { ctx->p3_klo = value > 0 ? value : 0; return 0; }           // tests: which rows k_pass3_tile_coef holds      // 0: the EAM force pass always reads three table rows
+  if (!strcmp(name, "p3_klo")) { ctx->p3_klo = value > 0 ? value : 0; return 0; }           // tests: which rows k_pass3_tile_coef holds
   if (!strcmp(name, "eos_bilinear")) { ctx->eos_bilinear = value ? 1 : 0; return 0; }    // before ttm_init / ttm1d_init
   if (!strcmp(name, "ttm_persist")) { imdgpu_ttm_set_persist(ctx, value < 0 ? -1 : (value ? 1 : 0)); return 0; }
   if (!strcmp(name, "ttm_decomposed")) {         // before ttm_init

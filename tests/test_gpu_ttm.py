@@ -19,10 +19,13 @@ def _eos(G):
     return (dict(x=G["eos_r"], y=G["eos_t"], z=G["eos_cve"]), dict(x=G["eos_r"], y=G["eos_ts"], z=G["eos_ee"]))
 
 
-def _gpu(G, step=0):
+def _gpu(G, step=0, tile=None):
     pre = "s%d_" % step
     s = GpuSystem(G["box"], G["pbc_dirs"], G["cell_dim"], int(G["ntypes"]), float(G["cellsz"]), float(G["nbl_margin"]),
                   float(G["timestep"]))
+    if tile:
+        for ax, v in zip("xyz", tile):
+            s.set_option("tile_" + ax, v)
     s.upload_tables(gu.table(G, "pair_pot"), gu.table(G, "rho_h_tab"), gu.table(G, "embed_pot"))
     cell_n = np.zeros(int(np.prod(G["cell_dim"])), np.int32)
     cell_n[G["cells"]] = G[pre + "cell_n"][G["cells"]]
@@ -122,6 +125,32 @@ def test_ttm_vs_oracle_same_inputs():
         ref = getattr(t, f)
         assert np.abs(d[f][inner] - ref[inner]).max() <= TOL * np.abs(ref[inner]).max(), f
     s.close()
+
+
+def test_update_fd_walks_agree():
+    """update_fd (imd_ttm_3D.c:233-488) walks the eight MD cells of an FD cell either cell by cell or, where the z-neighbour
+    cells are consecutive in the atom arrays (tiles even along z), as four runs of atoms.  Same atoms, other lane sums:
+    integers equal, md_temp / v_com / dens equal to rounding -- and each walk within the bar of the reference's own values."""
+    G = gu.load("ttm_6912_ext2")
+    inner = (slice(1, -1),) * 3
+    out = []
+    for tile in ((2, 2, 2), (3, 3, 3)):
+        s = _gpu(G, tile=tile)
+        assert s.get_info("tile_z") == tile[2]
+        s.calc_forces(0)
+        s.update_fd(0)
+        out.append(s.ttm_download(fields=("natoms", "md_temp", "dens", "vcom")))
+        s.close()
+    a, b = out
+    assert np.array_equal(a["natoms"][inner], b["natoms"][inner])
+    assert np.array_equal(a["dens"][inner], b["dens"][inner])                  # integer sums and one division
+    for f in ("md_temp", "vcom"):
+        x, y = np.asarray(a[f]), np.asarray(b[f])
+        assert np.abs(x - y).max() <= 1e-13 * np.abs(y).max(), f
+    ref = G["t0_update_fd_md_temp"] if "t0_update_fd_md_temp" in G else None
+    if ref is not None:
+        for d in out:
+            assert np.abs(d["md_temp"][inner] - ref[inner]).max() <= TOL * np.abs(ref[inner]).max()
 
 
 def test_inverse_eos_vs_reference_and_oracle():
