@@ -79,7 +79,7 @@ struct TtmState {
   unsigned *d_pflags = nullptr;          // census word, gate word
   unsigned long long *d_prec = nullptr;  // hand-off records [2][ncell][4]
   unsigned persist_base = 0;             // tag of state 0 of the next launch
-  int *d_pstat = nullptr, *h_pstat = nullptr;   // status of the last launch (device word / pinned copy)
+  int *d_pstat = nullptr, *h_pstat = nullptr;   // status of the last launch (device word: the four ints behind d_pflags' sixteen / pinned copy)
   hipEvent_t ev_pstat = nullptr;
   const int *graph_guard[2] = {nullptr, nullptr};
   double *d_ufd_part = nullptr; size_t ufd_part_cap = 0;   // partial sums of the chunked update_fd
@@ -1502,7 +1502,6 @@ void imdgpu_ttm_free(imdgpu_ctx *ctx)
   if (t->d_ufd_part) (void) hipFree(t->d_ufd_part);
   if (t->d_prec) (void) hipFree(t->d_prec);
   if (t->d_xrec) (void) hipFree(t->d_xrec);
-  if (t->d_pstat) (void) hipFree(t->d_pstat);
   if (t->h_pstat) (void) hipHostFree(t->h_pstat);
   if (t->ev_pstat) (void) hipEventDestroy(t->ev_pstat);
   imdgpu_fdtd_free(t);
@@ -2214,7 +2213,9 @@ static int persist_mode(imdgpu_ctx *ctx, TtmState *t)
     for (int d = 0; d < 3; d++) if ((t->dim[d] - 2) % PT == 1) shape_ok = false;
     t->persist = (env && shape_ok && t->persist_tiles <= PERSIST_MAX_TILES) ? 1 : 0;
     if (t->persist && !t->d_pflags) {
-      if (dev_alloc(ctx, &t->d_pflags, 16) || dev_alloc(ctx, &t->d_pstat, 4) || dev_alloc(ctx, &t->d_prec, (size_t) 2 * t->ncell * 4)) return -1;
+      // census / gate words and the status words in one allocation: one memset per launch instead of two
+      if (dev_alloc(ctx, &t->d_pflags, 16 + 4) || dev_alloc(ctx, &t->d_prec, (size_t) 2 * t->ncell * 4)) return -1;
+      t->d_pstat = (int *) (t->d_pflags + 16);
       if (hipMemsetAsync(t->d_prec, 0, (size_t) 2 * t->ncell * 4 * sizeof(unsigned long long), ctx->stream) != hipSuccess) return -1;
       t->persist_base = 1;
       if (hipHostMalloc((void **) &t->h_pstat, 4 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
@@ -2254,8 +2255,7 @@ static int launch_persist(imdgpu_ctx *ctx, TtmState *t, const Lat &L, double tau
   P.status = t->d_pstat; P.counters = ctx->d_counters;
   for (int d = 0; d < 3; d++) P.nt[d] = (t->dim[d] - 2 + PT - 1) / PT;
   P.ntiles = t->persist_tiles; P.trusted = mode == 2;
-  HIPCHK(hipMemsetAsync(t->d_pflags, 0, 16 * sizeof(unsigned), ctx->stream));
-  HIPCHK(hipMemsetAsync(t->d_pstat, 0, 4 * sizeof(int), ctx->stream));
+  HIPCHK(hipMemsetAsync(t->d_pflags, 0, (16 + 4) * sizeof(unsigned), ctx->stream));     // d_pstat follows d_pflags
   double *T0 = t->temp[t->cur], *T1 = t->temp[t->cur ^ 1], *U0 = t->U[t->cur], *U1 = t->U[t->cur ^ 1];
   double *K0 = t->fd_k[t->kcur], *K1 = t->fd_k[t->kcur ^ 1];
   const bool alone = ctx->stream != ctx->stream2;         // not forked beside the force pass: a stand-alone calc_ttm
