@@ -520,17 +520,18 @@ def main():
         ttmn = "true" if not args.no_ttm else "false"
         tiles = sysm.get_info("list_mode") == 1
         krev = sysm.get_info("kernel_rev")
+        fcap = sysm.get_info("fast_cap")          # plane stride the neighbour loops are compiled for (template argument; 0: run time)
 
         def price(which):
             n, ms = prof[which]
             if which == "pass1":
                 byts = natoms * (72.0 + 4.0 * M + (32.0 if fused else 0.0))
-                kn = ("k_pass1_tile_merged<%s, %s>" % (ttmn, "true" if fused else "false")) if tiles else "k_pass1"
+                kn = ("k_pass1_tile_merged<%s, %s, %d>" % (ttmn, "true" if fused else "false", fcap)) if tiles else "k_pass1"
                 label = kn + (" (pass 1: pair + rho, embedding pass folded in)" if fused else " (pass 1: pair + rho)")
             else:
                 byts = natoms * (84.0 + 4.0 * M)
                 coef = tiles and sysm.get_info("p3_coef_rows") > 0          # one atom type here
-                kn = "k_pass3_tile_coef<4>" if coef else (("k_pass3_tile<true, %d>" % sysm.get_info("pass3_ring")) if tiles else "k_pass3")
+                kn = ("k_pass3_tile_coef<4, %d>" % fcap) if coef else (("k_pass3_tile<true, %d, %d>" % (sysm.get_info("pass3_ring"), fcap)) if tiles else "k_pass3")
                 label = kn + (" (pass 3: EAM force pass, gradient-coefficient table)" if coef else " (pass 3: EAM force pass)")
             avg = ms / max(n, 1)
             a = byts / (avg * 1e-3) / 1e9 if n else 0.0

@@ -554,7 +554,7 @@ __global__ __launch_bounds__(512) void k_pass3_gt(ForceArgs a)
 // neighbour list holds 16-bit LDS slot numbers (4 per 8-byte load, ELL-transposed
 // per tile).  HBM sees: list (2 B/entry), own-atom outputs, one staging pass.
 // ===========================================================================
-#define IMDGPU_KERNEL_REV 5
+#define IMDGPU_KERNEL_REV 6
 #define LDS_LIMIT (160 * 1024)
 #define TABLE_LDS_LIMIT (150 * 1024)                 // global-gather kernels: tables beyond this stay in global memory
 #define NH_MAX 512                                   // halo cells per tile (<= 6*6*6 = 216 for tiles up to 4^3)
@@ -640,14 +640,17 @@ __global__ __launch_bounds__(1024) void k_tile_wprefix(int ntiles, int CPT, cons
   for (int t = t0; t < t1; t++) { wprefix[t] = acc; const int o = istart[(size_t) (t + 1) * CPT] - istart[(size_t) t * CPT]; acc += o > 0 ? o + TILE_FIXED_COST : 0; }
 }
 
-// make EXTRA=-DPLANE_CAP=n: the staged-position planes have the compile-time stride n (>= the largest tile's staged atoms):
-// the y / z plane reads then are immediate offsets of the x read's address (one address computation per neighbour instead of
-// three); the host sizes slot_cap = n.  Default: the stride is the kernel argument slot_cap.
-#ifdef PLANE_CAP
-#define SLOTCAP(a) (PLANE_CAP)
-#else
 #define SLOTCAP(a) ((a).slot_cap)
-#endif
+// FAST_CAP: the plane stride the neighbour loops of the force kernels are ALSO compiled for as a constant (template
+// parameter CAP; 0 = the run-time stride a.slot_cap).  With a constant stride the y / z (/ dF) reads of a neighbour are
+// immediate offsets of the x read's address -- two (pass 3: three) address computations fewer per neighbour -- and being
+// volatile LDS reads they stay three ds_read_b64 (left to itself the compiler pairs them into ds_read2st64_b64, which
+// costs more under random slots than it saves: +4..7 %, profiles/r03_kernel_variants.json).  Measured, 10 M atoms + TTM:
+// pass 1 1.896 -> 1.854 ms, pass 3 1.656 -> 1.624, the lattice chain beside it 1.57 -> 1.42, the step 4.57 -> 4.49 ms.
+// make_nblist rounds slot_cap up to FAST_CAP whenever the largest tile stages fewer atoms and the LDS holds the wider planes
+// (3136 = 49 x 64 slots is what a 2 x 4 x 4 tile of a condensed sample needs: ~21 atoms in each of its 4 x 6 x 6 cells).
+#define FAST_CAP 3136
+typedef __attribute__((address_space(3))) const volatile double lds_cvdouble;
 // halo-cell table + prefix (hstart/hsrc) and staging of positions into LDS as x, y, z planes of slot_cap
 // doubles (NC = 4: + dF plane sw).  Used by the list build; the force passes stage from the plan it writes.  The last slot (slot_cap-1) is a far-away dummy that pads the
 // neighbour list, so the inner loops need no "valid entry" test.  All threads of the block call it.
@@ -763,6 +766,23 @@ __device__ __forceinline__ int own_slot(const TileArgs &a, const TileCtx &T, int
 #define LPOS_ST(sp, sw, cap, s, X, Y, Z) { (sp)[s] = (X); (sp)[(cap) + (s)] = (Y); (sp)[2 * (size_t) (cap) + (s)] = (Z); }
 #define LPOS_STW(sp, sw, cap, s, X, Y, Z, W) { (sp)[s] = (X); (sp)[(cap) + (s)] = (Y); (sp)[2 * (size_t) (cap) + (s)] = (Z); (sw)[s] = (W); }
 #endif
+// a neighbour's staged record in the loops of the force kernels: CAP = 0 the macros above, CAP > 0 the constant stride (FAST_CAP)
+template <int CAP>
+__device__ __forceinline__ void nbr_rd(const double *sp, int cap, int j, double &X, double &Y, double &Z)
+{
+#ifndef POSXY
+  if constexpr (CAP > 0) { lds_cvdouble *q = (lds_cvdouble *) (sp + j); X = q[0]; Y = q[CAP]; Z = q[2 * CAP]; } else
+#endif
+  LPOS_RD(sp, sp, cap, j, X, Y, Z)
+}
+template <int CAP>
+__device__ __forceinline__ void nbr_rdw(const double *sp, const double *sw, int cap, int j, double &X, double &Y, double &Z, double &W)
+{
+#ifndef POSXY
+  if constexpr (CAP > 0) { lds_cvdouble *q = (lds_cvdouble *) (sp + j); X = q[0]; Y = q[CAP]; Z = q[2 * CAP]; W = q[3 * CAP]; } else
+#endif
+  LPOS_RDW(sp, sw, cap, j, X, Y, Z, W)
+}
 __device__ __forceinline__ void stage_issue(const TileArgs &a, int tile, int nsl, int (&IDX)[STG])
 {
   const int *src = a.tsrc + (size_t) tile * SLOTCAP(a);
@@ -1190,7 +1210,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile(TileArgs a)
 // FEMB: the embedding pass (pass 2, imd_forces_nbl.c:748-783) is folded into the epilogue -- with the full list rho of an
 // own atom is complete when its neighbour loop ends, so F(rho) and F'(rho) can be taken right there: no k_pass2 launch,
 // rho is not re-read, epot is written once.
-template <bool TTMN, bool FEMB>
+template <bool TTMN, bool FEMB, int CAP>
 __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs a)
 {
   extern __shared__ double lds[];
@@ -1234,7 +1254,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
         double2 A[UNR], B[UNR], C[UNR];
         PRIO_HI;
 #pragma unroll
-        for (int e = 0; e < UNR; e++) LPOS_RD(sp, sp, SLOTCAP(a), j[e], dx[e], dy[e], dz[e])
+        for (int e = 0; e < UNR; e++) nbr_rd<CAP>(sp, SLOTCAP(a), j[e], dx[e], dy[e], dz[e]);
         PRIO_LO;
         SCHED_BARRIER;
 #pragma unroll
@@ -1311,7 +1331,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
 #else
 #define P3_ATTR
 #endif
-template <bool NT1, int RING>
+template <bool NT1, int RING, int CAP>
 __global__ __launch_bounds__(TILE_MAXTHREADS) P3_ATTR void k_pass3_tile(TileArgs a)
 {
   extern __shared__ double lds[];
@@ -1360,7 +1380,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) P3_ATTR void k_pass3_tile(TileArgs
         double dx[UNR], dy[UNR], dz[UNR], wj[UNR], r2[UNR];
         PRIO_HI;
 #pragma unroll
-        for (int e = 0; e < UNR; e++) LPOS_RDW(sp, sw, SLOTCAP(a), j[e], dx[e], dy[e], dz[e], wj[e])
+        for (int e = 0; e < UNR; e++) nbr_rdw<CAP>(sp, sw, SLOTCAP(a), j[e], dx[e], dy[e], dz[e], wj[e]);
         PRIO_LO;
         SCHED_BARRIER;
 #pragma unroll
@@ -1435,7 +1455,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) P3_ATTR void k_pass3_tile(TileArgs
 // lowest rows belong to distances no pair of a condensed sample reaches -- and pass 1 reports the lowest row any pair of
 // THIS step fell into (CNT_KNEG): when that lies below klo -- or when no pass 1 has reported since the last force pass --
 // this kernel returns at once and k_pass3_tile, launched right behind it with p3_fallback set, does the step.  is_short is pass 1's business here (same pairs, same grid).
-template <int RING>
+template <int RING, int CAP>
 // four waves per SIMD's worth of registers (<= 128; two spilled with the register ring): three waves of this kernel then leave
 // every SIMD the 128 registers a wave of the lattice chain's spill-free build needs (k_ttm_chain_persist<.., 4, ..>).  Measured
 // at 10 M atoms + TTM: 132 registers beside the 80-register chain 4.82 ms per step, beside the 96-register chain 4.67,
@@ -1488,7 +1508,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) __attribute__((amdgpu_waves_per_eu
         double2 AB[UNR];
         PRIO_HI;
 #pragma unroll
-        for (int e = 0; e < UNR; e++) LPOS_RDW(sp, sw, SLOTCAP(a), j[e], dx[e], dy[e], dz[e], wj[e])
+        for (int e = 0; e < UNR; e++) nbr_rdw<CAP>(sp, sw, SLOTCAP(a), j[e], dx[e], dy[e], dz[e], wj[e]);
         PRIO_LO;
         SCHED_BARRIER;
 #pragma unroll
@@ -1730,6 +1750,8 @@ extern "C" int imdgpu_get_info(imdgpu_ctx *ctx, const char *name, long long *val
   struct { const char *n; long long v; } tab[] = {
     // rows of the gradient-coefficient table the EAM force pass holds in LDS and the first of them (0 / -1: three-row form)
     {"p3_coef_rows", coef_on ? ctx->ncoef - klo_now : 0}, {"p3_coef_klo", coef_on ? klo_now : -1},
+    // plane stride the neighbour loops of the running force kernels are compiled for (0: the run-time stride slot_cap)
+    {"fast_cap", (ctx->list_mode == 1 && ctx->slot_cap == FAST_CAP && !(getenv("IMDGPU_FAST_CAP") && !atoi(getenv("IMDGPU_FAST_CAP")))) ? FAST_CAP : 0},
     {"list_mode", ctx->list_mode}, {"mode", ctx->mode}, {"tile_cap", ctx->tile_cap}, {"slot_cap", ctx->slot_cap},
     {"max_halo", ctx->max_halo}, {"W", ctx->W}, {"tile_x", ctx->tile[0]}, {"tile_y", ctx->tile[1]}, {"tile_z", ctx->tile[2]},
     {"ntiles", ctx->ntiles}, {"tile_threads", ctx->tile_threads}, {"nlocal", ctx->nlocal}, {"nghost", ctx->nghost},
@@ -1876,10 +1898,7 @@ static int autotile(imdgpu_ctx *ctx)
     }
     if (maxown > TILE_MAXTHREADS) continue;
     int slot_cap = (int) ((maxhalo + 1 + 63) / 64 * 64);
-#ifdef PLANE_CAP
-    if (slot_cap > PLANE_CAP) continue;
-    slot_cap = PLANE_CAP;
-#endif
+    if (slot_cap < FAST_CAP && std::max(tile_lds_bytes_for(ctx, FAST_CAP, 1), tile_lds_bytes_for(ctx, FAST_CAP, 3)) <= LDS_LIMIT) slot_cap = FAST_CAP;
     if (std::max(tile_lds_bytes_for(ctx, slot_cap, 1), tile_lds_bytes_for(ctx, slot_cap, 3)) > LDS_LIMIT) continue;
     // score: atoms per workgroup round, discounted by the wave imbalance over the 4 SIMDs and by the
     // per-tile staging cost (grows with staged/own atoms; weight fitted on MI355X timings)
@@ -2464,10 +2483,9 @@ extern "C" int imdgpu_make_nblist(imdgpu_ctx *ctx)
       hipLaunchKernelGGL(k_tile_wprefix, dim3(1), dim3(1024), 0, ctx->stream, ctx->ntiles, g.CPT, ctx->istart, ctx->d_wprefix);
     }
     ctx->slot_cap = (ctx->h_counters[CNT_MAXHALO] + 1 + 63) / 64 * 64;      // + far-away dummy slot
-#ifdef PLANE_CAP
-    if (ctx->slot_cap > PLANE_CAP) return imdgpu_fail(ctx, "make_nblist: a tile stages %d atoms, the library was built with PLANE_CAP=%d", ctx->slot_cap, PLANE_CAP);
-    ctx->slot_cap = PLANE_CAP;
-#endif
+    // ... rounded up to the stride the force kernels' neighbour loops are also compiled for, if the LDS holds the wider planes
+    if (ctx->slot_cap < FAST_CAP && std::max(tile_lds_bytes_for(ctx, FAST_CAP, 1), tile_lds_bytes_for(ctx, FAST_CAP, 3)) <= LDS_LIMIT)
+      ctx->slot_cap = FAST_CAP;
     ctx->max_halo = ctx->h_counters[CNT_MAXHALO];
     if (tile_cap != ctx->tile_cap) { ctx->tile_cap = tile_cap; ctx->nbr16_cap = 0; }
     ctx->tile_threads = std::min(TILE_MAXTHREADS, ctx->tile_cap);
@@ -2615,6 +2633,8 @@ static int launch_forces(imdgpu_ctx *ctx, int phase = 0)
   if (nb > ctx->npart_blocks) return imdgpu_fail(ctx, "internal: partials too small");
   TileArgs ta;
   if (TILE) { ta = make_tile_args(ctx); ta.guard = ctx->pass1_guard; }
+  static const int fastcap_env = getenv("IMDGPU_FAST_CAP") ? atoi(getenv("IMDGPU_FAST_CAP")) : 1;
+  const bool fastcap = fastcap_env && TILE && ctx->slot_cap == FAST_CAP;       // the neighbour loops compiled for this plane stride
   size_t lds1 = ((PAIR ? a.pair.nrows * a.pair.ncols : 0) + (EAM ? a.rho.nrows * a.rho.ncols : 0) + 64) * sizeof(double);
   if (phase == 0 || phase == 1) {
     HIPCHK(hipMemsetAsync(ctx->d_counters + CNT_IS_SHORT, 0, sizeof(int), ctx->stream));
@@ -2632,14 +2652,16 @@ static int launch_forces(imdgpu_ctx *ctx, int phase = 0)
 #define L1E(P, E) do { if (TT) L1T(P, E, true); else L1T(P, E, false); } while (0)
     if (TILE && PAIR && EAM && NT1 && ctx->d_merged) {
       size_t l = tile_lds_bytes(ctx, 1);
-#define LM(T, F)                                                                                                     \
+#define LMC(T, F, C)                                                                                                 \
   do {                                                                                                               \
-    HIPCHK(hipFuncSetAttribute((const void *) k_pass1_tile_merged<T, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) l)); \
-    hipLaunchKernelGGL((k_pass1_tile_merged<T, F>), dim3(nb), dim3(B), l, ctx->stream, ta);                          \
+    HIPCHK(hipFuncSetAttribute((const void *) k_pass1_tile_merged<T, F, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) l)); \
+    hipLaunchKernelGGL((k_pass1_tile_merged<T, F, C>), dim3(nb), dim3(B), l, ctx->stream, ta);                       \
   } while (0)
+#define LM(T, F) do { if (fastcap) LMC(T, F, FAST_CAP); else LMC(T, F, 0); } while (0)
       if (TT) { if (fuse_emb(ctx)) LM(true, true); else LM(true, false); }
       else { if (fuse_emb(ctx)) LM(false, true); else LM(false, false); }
 #undef LM
+#undef LMC
     } else if (PAIR && EAM) L1E(true, true); else if (PAIR) L1E(true, false); else L1E(false, true);
 #undef L1E
 #undef L1T
@@ -2671,31 +2693,35 @@ static int launch_forces(imdgpu_ctx *ctx, int phase = 0)
       size_t l = tile_lds_bytes(ctx, 3);
       // with a lattice attached its sub-step chain runs beside this pass and needs 80 registers on every SIMD: the
       // leaner list walk (142 VGPRs) then; the register ring (148) otherwise
-#define L3(N, R)                                                                                                     \
+#define L3K(N, R, C)                                                                                                 \
   do {                                                                                                               \
-    HIPCHK(hipFuncSetAttribute((const void *) k_pass3_tile<N, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) l)); \
-    hipLaunchKernelGGL((k_pass3_tile<N, R>), dim3(nb), dim3(B), l, ctx->stream, ta);                                 \
+    HIPCHK(hipFuncSetAttribute((const void *) k_pass3_tile<N, R, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) l)); \
+    hipLaunchKernelGGL((k_pass3_tile<N, R, C>), dim3(nb), dim3(B), l, ctx->stream, ta);                              \
   } while (0)
+#define L3(N, R) do { if (fastcap) L3K(N, R, FAST_CAP); else L3K(N, R, 0); } while (0)
       // one type behind the merged pass 1: the coefficient form first, the three-row form behind it as its stand-in for
       // steps in which a pair fell below the rows the LDS holds (both look at CNT_KNEG and one of them returns at once)
       int klo = 0;
       const size_t lc = p3_coef_lds(ctx, klo);
       if (lc) {
         ta.klo = klo;
-#define L3C(R)                                                                                                       \
+#define L3CK(R, C)                                                                                                   \
   do {                                                                                                               \
-    HIPCHK(hipFuncSetAttribute((const void *) k_pass3_tile_coef<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lc)); \
-    hipLaunchKernelGGL((k_pass3_tile_coef<R>), dim3(nb), dim3(B), lc, ctx->stream, ta);                              \
+    HIPCHK(hipFuncSetAttribute((const void *) k_pass3_tile_coef<R, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lc)); \
+    hipLaunchKernelGGL((k_pass3_tile_coef<R, C>), dim3(nb), dim3(B), lc, ctx->stream, ta);                           \
   } while (0)
+#define L3C(R) do { if (fastcap) L3CK(R, FAST_CAP); else L3CK(R, 0); } while (0)
         // 132 VGPRs with the register ring: three waves per SIMD still leave the 80 a wave of the lattice chain needs
         static const int ring = getenv("IMDGPU_P3_RING") ? atoi(getenv("IMDGPU_P3_RING")) : 4;
         if (ring == 0) L3C(0); else L3C(4);
 #undef L3C
+#undef L3CK
         ta.p3_fallback = 1;
       }
       if (ctx->ttm) { if (NT1) L3(true, 0); else L3(false, 0); }
       else { if (NT1) L3(true, 4); else L3(false, 4); }
 #undef L3
+#undef L3K
     } else if (lds3 > TABLE_LDS_LIMIT) hipLaunchKernelGGL(k_pass3_gt, dim3(nb), dim3(B), 0, ctx->stream, a);
     else if (NT1) hipLaunchKernelGGL((k_pass3<true>), dim3(nb), dim3(B), lds3, ctx->stream, a);
     else hipLaunchKernelGGL((k_pass3<false>), dim3(nb), dim3(B), lds3, ctx->stream, a);
