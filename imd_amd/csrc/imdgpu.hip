@@ -650,6 +650,11 @@ __global__ __launch_bounds__(1024) void k_tile_wprefix(int ntiles, int CPT, cons
 // make_nblist rounds slot_cap up to FAST_CAP whenever the largest tile stages fewer atoms and the LDS holds the wider planes
 // (3136 = 49 x 64 slots is what a 2 x 4 x 4 tile of a condensed sample needs: ~21 atoms in each of its 4 x 6 x 6 cells).
 #define FAST_CAP 3136
+// The 16-bit entries of the tile lists are the neighbour's slot TIMES 8: its byte offset inside a plane of staged doubles
+// (slot_cap <= 6826 by the LDS size, so 8 * slot < 65536).  With the planes at the start of the workgroup's LDS the
+// extracted half-word IS the address of the x read -- one shift-and-add per neighbour less in each force pass (measured on one
+// box, three runs each: step 4.523 -> 4.509 ms; within the noise of a single run, kept because it is free).
+#define NBR_SCALE 8
 typedef __attribute__((address_space(3))) const volatile double lds_cvdouble;
 // halo-cell table + prefix (hstart/hsrc) and staging of positions into LDS as x, y, z planes of slot_cap
 // doubles (NC = 4: + dF plane sw).  Used by the list build; the force passes stage from the plan it writes.  The last slot (slot_cap-1) is a far-away dummy that pads the
@@ -766,23 +771,30 @@ __device__ __forceinline__ int own_slot(const TileArgs &a, const TileCtx &T, int
 #define LPOS_ST(sp, sw, cap, s, X, Y, Z) { (sp)[s] = (X); (sp)[(cap) + (s)] = (Y); (sp)[2 * (size_t) (cap) + (s)] = (Z); }
 #define LPOS_STW(sp, sw, cap, s, X, Y, Z, W) { (sp)[s] = (X); (sp)[(cap) + (s)] = (Y); (sp)[2 * (size_t) (cap) + (s)] = (Z); (sw)[s] = (W); }
 #endif
-// a neighbour's staged record in the loops of the force kernels: CAP = 0 the macros above, CAP > 0 the constant stride (FAST_CAP)
+// a neighbour's staged record in the loops of the force kernels, by its list entry jb = slot * NBR_SCALE (a byte offset):
+// CAP = 0 the run-time plane stride, CAP > 0 the constant stride (FAST_CAP)
 template <int CAP>
-__device__ __forceinline__ void nbr_rd(const double *sp, int cap, int j, double &X, double &Y, double &Z)
+__device__ __forceinline__ void nbr_rd(const double *sp, int cap, int jb, double &X, double &Y, double &Z)
 {
-#ifndef POSXY
-  if constexpr (CAP > 0) { lds_cvdouble *q = (lds_cvdouble *) (sp + j); X = q[0]; Y = q[CAP]; Z = q[2 * CAP]; } else
+#ifdef POSXY
+  LPOS_RD(sp, sp, cap, jb / NBR_SCALE, X, Y, Z)
+#else
+  if constexpr (CAP > 0) { lds_cvdouble *q = (lds_cvdouble *) ((const char *) sp + jb); X = q[0]; Y = q[CAP]; Z = q[2 * CAP]; }
+  else { const double *q = (const double *) ((const char *) sp + jb); X = q[0]; Y = q[cap]; Z = q[2 * (size_t) cap]; }
 #endif
-  LPOS_RD(sp, sp, cap, j, X, Y, Z)
 }
 template <int CAP>
-__device__ __forceinline__ void nbr_rdw(const double *sp, const double *sw, int cap, int j, double &X, double &Y, double &Z, double &W)
+__device__ __forceinline__ void nbr_rdw(const double *sp, const double *sw, int cap, int jb, double &X, double &Y, double &Z, double &W)
 {
-#ifndef POSXY
-  if constexpr (CAP > 0) { lds_cvdouble *q = (lds_cvdouble *) (sp + j); X = q[0]; Y = q[CAP]; Z = q[2 * CAP]; W = q[3 * CAP]; } else
+#ifdef POSXY
+  LPOS_RDW(sp, sw, cap, jb / NBR_SCALE, X, Y, Z, W)
+#else
+  if constexpr (CAP > 0) { lds_cvdouble *q = (lds_cvdouble *) ((const char *) sp + jb); X = q[0]; Y = q[CAP]; Z = q[2 * CAP]; W = q[3 * CAP]; }
+  else { const double *q = (const double *) ((const char *) sp + jb); X = q[0]; Y = q[cap]; Z = q[2 * (size_t) cap]; W = *(const double *) ((const char *) sw + jb); }
 #endif
-  LPOS_RDW(sp, sw, cap, j, X, Y, Z, W)
 }
+// the type of the atom in a neighbour's slot (several atom types)
+__device__ __forceinline__ int nbr_type(const int *ts, int jb) { return *(const int *) ((const char *) ts + jb / (NBR_SCALE / 4)); }
 __device__ __forceinline__ void stage_issue(const TileArgs &a, int tile, int nsl, int (&IDX)[STG])
 {
   const int *src = a.tsrc + (size_t) tile * SLOTCAP(a);
@@ -853,7 +865,7 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile(TileArgs a)
   TileCtx T;
   int t0, t1;
   block_tile_range(a.ntiles, a.wprefix, a.balance, t0, t1);
-  const unsigned short dummy = (unsigned short) (SLOTCAP(a) - 1);
+  const unsigned short dummy = (unsigned short) ((SLOTCAP(a) - 1) * NBR_SCALE);      // list entries: slot * NBR_SCALE (see NBR_SCALE)
   int mmax = 0;
   for (T.tile = t0; T.tile < t1; T.tile++) {
   __syncthreads();
@@ -914,7 +926,7 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile(TileArgs a)
             while (mask) {                                   // ascending j: the reference's order inside a cell
               const int j = j0 + __builtin_ctz(mask);
               mask &= mask - 1;
-              w = (w >> 16) | ((unsigned long long) j << 48);
+              w = (w >> 16) | ((unsigned long long) (j * NBR_SCALE) << 48);
               m++;
               if ((m & 3) == 0) {
                 if ((m >> 2) <= a.W4) lp[(size_t) ((m >> 2) - 1) * a.tile_cap] = w;
@@ -970,7 +982,7 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile(TileArgs a)
 // the barriers, so their latency is hidden as well.
 #define TILE_PROLOGUE(WITH_W, WITH_T, SW, TS, WSCALE)                                                                 \
     T.own_start = info.y; T.nown = info.z;                                                                       \
-    const unsigned dw = (unsigned) (SLOTCAP(a) - 1) * 0x10001u;                                                  \
+    const unsigned dw = (unsigned) ((SLOTCAP(a) - 1) * NBR_SCALE) * 0x10001u;                                    \
     const uint2 dummyw = make_uint2(dw, dw);                                                                     \
     const size_t lbase = (size_t) T.tile * a.W4 * a.tile_cap;                                                    \
     unsigned ow0 = 0; uint2 w0 = dummyw, w1 = dummyw;                                                            \
@@ -1109,7 +1121,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile(TileArgs a)
         double dx[UNR], dy[UNR], dz[UNR], r2[UNR];
 #pragma unroll
         for (int e = 0; e < UNR; e++) {                                   // phase 1: positions from LDS, all reads first
-          LPOS_RD(sp, sp, SLOTCAP(a), j[e], dx[e], dy[e], dz[e])
+          nbr_rd<0>(sp, SLOTCAP(a), j[e], dx[e], dy[e], dz[e]);
         }
         SCHED_BARRIER;
 #pragma unroll
@@ -1156,7 +1168,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile(TileArgs a)
 #pragma unroll
           for (int e = 0; e < UNR; e++) {
 #pragma clang fp contract(fast)
-            const int jt = ts[j[e]], col = it * nt + jt;
+            const int jt = nbr_type(ts, j[e]), col = it * nt + jt;
             if (TTMN) nb += (r2[e] <= pend0 && it == 0 && jt == 0) ? 1 : 0;
             if (PAIR) {
               const TabK c = {a.pair.begin[col], a.pair.end[col], a.pair.invstep[col], 2 * a.pair.invstep[col]};
@@ -1215,10 +1227,10 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
 {
   extern __shared__ double lds[];
   if (a.guard && *a.guard) return;
-  double2 *tm = (double2 *) lds;                                // (nrows + 3) rows
   const int nrows = a.pair.nrows, kz = nrows;
-  double *sp = lds + 2 * (size_t) (nrows + 3);
+  double *sp = lds;                                             // the planes first: a list entry is the address of its x read (NBR_SCALE)
   double *scratch = sp + 3 * (size_t) SLOTCAP(a);
+  double2 *tm = (double2 *) (scratch + 64);                     // (nrows + 3) rows; slot_cap is a multiple of 64: 16-byte aligned
   TileCtx T;
   int t0, t1;
   block_tile_range(a.ntiles, a.wprefix, a.balance, t0, t1);
@@ -1414,7 +1426,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) P3_ATTR void k_pass3_tile(TileArgs
 #pragma unroll
           for (int e = 0; e < UNR; e++) {
 #pragma clang fp contract(fast)
-            const int jt = ts[j[e]], col1 = jt * nt + it, col2 = it * nt + jt;
+            const int jt = nbr_type(ts, j[e]), col1 = jt * nt + it, col2 = it * nt + jt;
             const TabK c1 = {a.rho.begin[col1], a.rho.end[col1], a.rho.invstep[col1], 2 * a.rho.invstep[col1]};
             const TabK c2 = {a.rho.begin[col2], a.rho.end[col2], a.rho.invstep[col2], 2 * a.rho.invstep[col2]};
             int k; double chi;
