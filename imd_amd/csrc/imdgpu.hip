@@ -1349,7 +1349,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) P3_ATTR void k_pass3_tile(TileArgs
   extern __shared__ double lds[];
   if (a.p3_fallback) {                                   // did k_pass3_tile_coef do this step?  (same test as there)
     const int kneg = a.counters[CNT_KNEG];
-    if (kneg != 0 && 0x7fffffff - kneg >= a.klo) return;
+    if (kneg != 0 && 0x7fffffff - kneg >= a.klo + 1) return;
   }
   double *tr = lds;                                      // rho_h_tab, one type: + zero rows for r2 >= end (no mask)
   double *sp = tr + a.rho.nrows * a.rho.ncols + 4;      // (x, y) records, then (z, dF) records (LPOS_*) ...
@@ -1477,7 +1477,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) __attribute__((amdgpu_waves_per_eu
   extern __shared__ double lds[];
   {                                                      // no report from a pass 1 of this step (0), or a pair below the rows held here
     const int kneg = a.counters[CNT_KNEG];
-    if (kneg == 0 || 0x7fffffff - kneg < a.klo) return;
+    if (kneg == 0 || 0x7fffffff - kneg < a.klo + 1) return;
   }
   double *sp = lds;
   double *sw = sp + 3 * (size_t) SLOTCAP(a);
@@ -1526,7 +1526,14 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
         for (int e = 0; e < UNR; e++) {
           dx[e] -= xi; dy[e] -= yi; dz[e] -= zi;
+#ifdef P3C_UNFUSED_R2
           r2[e] = dx[e] * dx[e] + dy[e] * dy[e] + dz[e] * dz[e];
+#else
+          // fused: r2 may differ from pass 1's (the reference's unfused expression) in the last bit.  Nothing here is an
+          // integer or a list decision -- the cut-off test gates a term that is continuous in r2 -- and a row index that
+          // lands one below pass 1's is covered by the guard's margin of one row
+          r2[e] = fma(dz[e], dz[e], fma(dy[e], dy[e], dx[e] * dx[e]));
+#endif
           const double q = fmax(r2[e] - begin, 0.0) * istep;
           kr[e] = (int) q;
           ch[e] = __builtin_amdgcn_fract(q);
