@@ -17,6 +17,7 @@ def _run(case, persist, nsteps):
     G = gu.load(case)
     s = _gpu(G)
     s.set_option("ttm_persist", persist)
+    s.set_option("p3_coef", 0)            # the same EAM force kernel in both runs (its coefficient form goes with the persistent kernel only)
     out = []
     for st in range(nsteps):
         s.md_step(st)
@@ -90,6 +91,7 @@ def _big(persist, nb=(64, 64, 40), nsteps=6, voids=False):
     g.upload_atoms(pos, mom, 26.9815)
     ttm_mod.attach_default(g, fd_ext=(2, 2, 2), diff_substeps=100, fd_min_atoms=5)
     g.set_option("ttm_persist", persist)
+    g.set_option("p3_coef", 0)            # the same EAM force kernel in both runs
     for st in range(nsteps):
         g.md_step(st)
     lat = g.ttm_download()
@@ -156,6 +158,7 @@ def test_stand_alone_calc_ttm_with_the_same_bits(case):
         G = gu.load(case)
         s = _gpu(G)
         s.set_option("ttm_persist", persist)
+        s.set_option("p3_coef", 0)
         for st in range(5):
             s.calc_forces(st); s.calc_ttm(st); s.move_atoms_ttm()
         res.append((s.ttm_download(), s.download(fields=("ort", "impuls")), s.get_info("ttm_persist_mode")))
