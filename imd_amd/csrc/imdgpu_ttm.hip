@@ -2262,10 +2262,12 @@ static int launch_persist(imdgpu_ctx *ctx, TtmState *t, const Lat &L, double tau
 #define PERSIST_LAUNCH(S, W, R)                                                                                                  \
   hipLaunchKernelGGL((k_ttm_chain_persist<S, W, R>), dim3(t->persist_tiles), dim3(64), 0, ctx->stream, L, tau, t->nsub, t->natoms, T0, T1, \
                      U0, U1, K0, K1, t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve, P)
-  // register budget: 128 (no spills) alone on the chip and beside the coefficient form of the EAM force pass, whose three
-  // 128-register waves leave exactly that on every SIMD; 80 beside the three-row form (138 registers).  IMDGPU_TTM_WPE=4|5|6 overrides.
+  // register budget: 128 (no spills) alone on the chip; beside the coefficient form of the EAM force pass, whose three
+  // 128-register waves leave 128 on every SIMD, 96 -- measured with the final force kernels: 128 ends the chain 0.27 ms before
+  // the pass (1.33 / 1.59 ms), 96 costs the pass less and both end together (1.47 / 1.58; step 4.49 -> 4.48 ms), 80 makes the
+  // chain the longer one again (1.62 / 1.52; 4.58); 80 beside the three-row form (138 registers).  IMDGPU_TTM_WPE=4|5|6 overrides.
   static const int wpe_env = getenv("IMDGPU_TTM_WPE") ? atoi(getenv("IMDGPU_TTM_WPE")) : 0;
-  const int wpe = alone ? 4 : (wpe_env >= 4 && wpe_env <= 6 ? wpe_env : (imdgpu_p3_coef_active(ctx) ? 4 : 6));
+  const int wpe = alone ? 4 : (wpe_env >= 4 && wpe_env <= 6 ? wpe_env : (imdgpu_p3_coef_active(ctx) ? 5 : 6));
 #define PERSIST_W(S, R) { if (wpe == 4) PERSIST_LAUNCH(S, 4, R); else if (wpe == 5) PERSIST_LAUNCH(S, 5, R); else PERSIST_LAUNCH(S, 6, R); }
   if (rem) { if (t->have_source) PERSIST_W(true, true) else PERSIST_W(false, true) }
   else if (t->have_source) PERSIST_W(true, false) else PERSIST_W(false, false)
