@@ -2242,6 +2242,8 @@ int imdgpu_ttm_chain_needs_lds(const imdgpu_ctx *ctx)
   const TtmState *t = ctx->ttm;
   if (!t) return 0;
   if (t->fdtd && t->fdtd_on) return 0;
+  if (ctx->ttm_decomposed && !t->xrec_ready) return 1;      // faces through the host mailbox: one launch per sub-step
+  if (t->nsub % 2) return 1;                                // an odd number of sub-steps stays on the launch loop
   return t->persist > 0 ? 0 : 1;
 }
 
