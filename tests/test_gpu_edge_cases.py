@@ -87,6 +87,40 @@ def test_edge_case_both_families_vs_oracle(name):
             assert info["W"] > 96 and info["tile_cap"] >= 64
 
 
+@pytest.mark.parametrize("dist,short", [(1.2, 1), (1.6, 0)])
+def test_a_pair_far_inside_the_first_shell(dist, short):
+    """Two atoms at 1.2 A: below the first table row (r_begin = 1.5 A) -- PAIR_INT2 clamps the argument and raises is_short
+    (potaccess.h:331, imd_forces_nbl.c:673,986-993).  At 1.6 A: inside the table, but below the rows the coefficient form of
+    the EAM force pass keeps in LDS (r < 1.71 A with the 4000-row table and 3136 slots), so that step is the three-row kernel's.
+    Forces, densities, energy against the oracle either way; the flag as the reference sets it."""
+    c = _case((12, 12, 12), 4.05, jitter=0.02, seed=3)
+    c["pos"][1] = c["pos"][0] + np.array([dist, 0.0, 0.0])
+    o = po.OracleSystem(c["dim"], 64, 1, c["box"], c["pbc"], c["cellsz"], 0.5, 0.1)
+    for w, t in enumerate(c["tabs"]):
+        o.set_table(w, t.as_dict())
+    L = np.diag(c["box"])
+    o.fill_from_positions(c["pos"] % L, c["mom"], 26.9815)
+    o.calc_forces(0)
+    idn = np.argsort(o.gather_inner("nummer"))
+    fo, ro = o.gather_inner("kraft")[idn], o.gather_inner("rho")[idn]
+    assert o.s.is_short == short
+    for mode in (0, 1):
+        s = GpuSystem(c["box"], c["pbc"], c["dim"], 1, c["cellsz"], 0.5, 0.1)
+        s.set_option("mode", mode)
+        s.upload_tables(*c["tabs"])
+        s.upload_atoms(c["pos"], c["mom"], 26.9815)
+        r = s.calc_forces(0)
+        d = s.download(fields=("kraft", "nummer", "eam_rho"))
+        if mode == 1:
+            assert s.get_info("p3_coef_klo") > 31, "the 1.6 A pair must lie below the rows held in LDS for this test to mean anything"
+        s.close()
+        k = np.argsort(d["nummer"])
+        assert r["is_short"] == short, mode
+        assert np.abs(d["kraft"][k] - fo).max() < 1e-9 * np.abs(fo).max(), mode
+        assert np.abs(d["eam_rho"][k] - ro).max() < 1e-11 * np.abs(ro).max()
+        assert abs(r["tot_pot_energy"] - o.s.tot_pot_energy) < 1e-11 * abs(o.s.tot_pot_energy)
+
+
 def test_host_integrator_hand_over_of_positions_and_momenta():
     """imdgpu_update_positions / imdgpu_update_momenta: a host that integrates itself (shim, level 1) hands over the
     arrays in the cell order download() reports; the device holds exactly those values at the same atoms."""
