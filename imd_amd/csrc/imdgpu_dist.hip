@@ -93,6 +93,7 @@ struct DistState {
   double *ttm_blk = nullptr, *ttm_all = nullptr; size_t ttm_blk_cap = 0, ttm_all_cap = 0;
   int *d_ttm_offs = nullptr;
   hipEvent_t ev_gathered = nullptr;
+  double *fluxbuf = nullptr; size_t flux_cap = 0;   // do_COMMFLUX: [to lo | to hi | from lo | from hi], 5 doubles per face cell
 };
 
 static DistState *DS(imdgpu_ctx *ctx) { return (DistState *) ctx->dist; }
@@ -105,7 +106,7 @@ void imdgpu_dist_free(imdgpu_ctx *ctx)
   if (!D) return;
   if (D->comm && g_rccl.CommDestroy) (void) g_rccl.CommDestroy(D->comm);
   if (D->comm2 && g_rccl.CommDestroy) (void) g_rccl.CommDestroy(D->comm2);
-  void *ptrs[] = {D->d_send_idx, D->d_seg_of, D->d_self_dst, D->d_recv_self, D->d_shift, D->sendbuf, D->recvbuf, D->d_flag, D->ttm_blk, D->ttm_all, D->d_ttm_offs};
+  void *ptrs[] = {D->d_send_idx, D->d_seg_of, D->d_self_dst, D->d_recv_self, D->d_shift, D->sendbuf, D->recvbuf, D->d_flag, D->ttm_blk, D->ttm_all, D->d_ttm_offs, D->fluxbuf};
   for (void *p : ptrs) if (p) (void) hipFree(p);
   if (D->h_flag) (void) hipHostFree(D->h_flag);
   if (D->ev_flag) (void) hipEventDestroy(D->ev_flag);
@@ -353,6 +354,7 @@ extern "C" int imdgpu_dist_set_ttm_blocks(imdgpu_ctx *ctx, const int *offs)
 
 // the lattice half of a step on the side stream (forked after pass 1, joined before the integrator)
 static int dist_ttm1d_chain(imdgpu_ctx *ctx, DistState *D, int steps);
+static int dist_commflux(imdgpu_ctx *ctx, DistState *D);
 static int dist_ttm_chain(imdgpu_ctx *ctx, DistState *D, int steps)
 {
   HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
@@ -361,7 +363,16 @@ static int dist_ttm_chain(imdgpu_ctx *ctx, DistState *D, int steps)
   ctx->stream = ctx->stream2;
   int rc = 0;
   if (ctx->ttm_decomposed) {
-    if (ctx->ttm_adv) rc = imdgpu_fail(ctx, "dist_md_step: decomposed lattice with advection is driven by the host layer");
+    if (ctx->ttm_adv) {
+      // calc_ttm's order (imd_ttm_3D.c:57-60): update_fd, do_ADV -- whose first act is do_COMMFLUX (:1325) --, then the rest.
+      // The exchange is a collective's worth of transport kernels: like the replicated lattice's all-gather it must be
+      // through before the persistent EAM force pass takes every CU, so that pass waits for ev_gathered (dist_md_step)
+      rc = imdgpu_ttm_update_fd(ctx, steps);
+      if (!rc) rc = dist_commflux(ctx, D);
+      if (!rc && hipEventRecord(D->ev_gathered, ctx->stream) != hipSuccess) rc = 1;
+      if (!rc) rc = imdgpu_ttm_adv(ctx, 1.0, steps);
+      if (!rc) rc = imdgpu_ttm_lattice_step(ctx, steps);
+    }
     else rc = imdgpu_ttm_local_step(ctx, steps);
   } else {
     int nb = 0;
@@ -423,7 +434,7 @@ extern "C" int imdgpu_dist_md_step(imdgpu_ctx *ctx, int steps, int *rebuild_need
     HIPCHK(hipStreamWaitEvent(ctx->stream, D->ev_gathered, 0));
   }
   else if (ctx->ttm && dist_ttm_chain(ctx, D, steps)) return 1;
-  if (ctx->ttm && !ctx->ttm_decomposed) HIPCHK(hipStreamWaitEvent(ctx->stream, D->ev_gathered, 0));
+  if (ctx->ttm && (!ctx->ttm_decomposed || ctx->ttm_adv)) HIPCHK(hipStreamWaitEvent(ctx->stream, D->ev_gathered, 0));
   if (imdgpu_launch_forces_phase(ctx, 3)) return 1;
   if (ctx->ttm || ctx->ttm1d) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
   if (imdgpu_launch_integrate(ctx)) return 1;
@@ -680,8 +691,9 @@ static int plan_static(imdgpu_ctx *ctx, DistState *D, PlanState *P)
 // generic point-to-point batch of the rebuild: byte-addressed segments of two device buffers.  Messages to THIS rank are
 // copied on the device (the k-th self send is the k-th self receive); empty messages are not posted (both sides know).
 struct P2P { std::vector<int> sp, rp; std::vector<long long> so, sc, ro, rc; };
-static int dist_p2p(imdgpu_ctx *ctx, DistState *D, char *sendbuf, char *recvbuf, const P2P &m)
+static int dist_p2p(imdgpu_ctx *ctx, DistState *D, char *sendbuf, char *recvbuf, const P2P &m, bool lattice_comm = false)
 {
+  ncclComm_t comm = lattice_comm ? D->comm2 : D->comm;    // the lattice stream has its own communicator (one stream per communicator)
   std::vector<int> sp, rp; std::vector<long long> so, sc, ro, rc;
   std::vector<size_t> self_s, self_r;
   for (size_t k = 0; k < m.sp.size(); k++) {
@@ -699,16 +711,50 @@ static int dist_p2p(imdgpu_ctx *ctx, DistState *D, char *sendbuf, char *recvbuf,
     if (m.sc[a] > 0) HIPCHK(hipMemcpyAsync(recvbuf + m.ro[b], sendbuf + m.so[a], (size_t) m.sc[a], hipMemcpyDeviceToDevice, ctx->stream));
   }
   if (sp.empty() && rp.empty()) return 0;
-  if (D->comm) {
+  if (comm) {
     NCCLCHK(g_rccl.GroupStart());
-    for (size_t s = 0; s < sp.size(); s++) NCCLCHK(g_rccl.Send(sendbuf + so[s], (size_t) sc[s], ncclChar, sp[s], D->comm, ctx->stream));
-    for (size_t s = 0; s < rp.size(); s++) NCCLCHK(g_rccl.Recv(recvbuf + ro[s], (size_t) rc[s], ncclChar, rp[s], D->comm, ctx->stream));
+    for (size_t s = 0; s < sp.size(); s++) NCCLCHK(g_rccl.Send(sendbuf + so[s], (size_t) sc[s], ncclChar, sp[s], comm, ctx->stream));
+    for (size_t s = 0; s < rp.size(); s++) NCCLCHK(g_rccl.Recv(recvbuf + ro[s], (size_t) rc[s], ncclChar, rp[s], comm, ctx->stream));
     NCCLCHK(g_rccl.GroupEnd());
     return 0;
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (D->cb(D->cb_user, 0, sendbuf, recvbuf, (int) sp.size(), sp.data(), so.data(), sc.data(), (int) rp.size(), rp.data(), ro.data(), rc.data(), 1))
-    return imdgpu_fail(ctx, "dist: the host transport failed (rebuild)");
+    return imdgpu_fail(ctx, "dist: the host transport failed (point-to-point batch)");
+  return 0;
+}
+
+// do_COMMFLUX (imd_ttm_3D.c:667-995, the part compiled without ADV2D) inside the native step, decomposed lattice: my boundary
+// columns i = 1 / i = lx-2 of {flux[8], U} go into the x neighbours' ghost columns -- one pack launch per side, ONE batch of at
+// most two sends and two receives on the lattice stream (its own communicator), one unpack launch per side.  Like the
+// reference the ranks at the two ends of the x range exchange with their inner neighbour only: no wrap-around even with
+// periodic x (:724-760), the ghost columns there keep flux 0 / U 0 of init_ttm (:1136-1157).  ctx->stream is the lattice stream.
+static int dist_commflux(imdgpu_ctx *ctx, DistState *D)
+{
+  const int Px = ctx->cpu_dim[0], cx = ctx->my_coord[0];
+  if (Px == 1 || D->nranks == 1) return 0;
+  int n = 0;
+  if (imdgpu_ttm_commflux(ctx, 0, 0, nullptr, &n)) return 1;
+  const size_t seg = (size_t) n * 5;                      // doubles per face: eight int counters in four doubles, then U
+  if (4 * seg > D->flux_cap) {
+    if (D->fluxbuf) (void) hipFree(D->fluxbuf);
+    D->fluxbuf = nullptr; D->flux_cap = 0;
+    HIPCHK(hipMalloc((void **) &D->fluxbuf, 4 * seg * sizeof(double)));
+    D->flux_cap = 4 * seg;
+  }
+  int nb[3] = {cx, ctx->my_coord[1], ctx->my_coord[2]};
+  nb[0] = cx - 1; const int lo = cx > 0 ? rank_of(nb, ctx->cpu_dim) : -1;
+  nb[0] = cx + 1; const int hi = cx < Px - 1 ? rank_of(nb, ctx->cpu_dim) : -1;
+  double *b = D->fluxbuf;
+  if (lo >= 0 && imdgpu_ttm_commflux(ctx, 0, 0, b, nullptr)) return 1;
+  if (hi >= 0 && imdgpu_ttm_commflux(ctx, 1, 0, b + seg, nullptr)) return 1;
+  P2P m;
+  const long long bytes = (long long) (seg * sizeof(double));
+  if (lo >= 0) { m.sp.push_back(lo); m.so.push_back(0); m.sc.push_back(bytes); m.rp.push_back(lo); m.ro.push_back(2 * bytes); m.rc.push_back(bytes); }
+  if (hi >= 0) { m.sp.push_back(hi); m.so.push_back(bytes); m.sc.push_back(bytes); m.rp.push_back(hi); m.ro.push_back(3 * bytes); m.rc.push_back(bytes); }
+  if (dist_p2p(ctx, D, (char *) b, (char *) b, m, true)) return 1;
+  if (lo >= 0 && imdgpu_ttm_commflux(ctx, 0, 1, b + 2 * seg, nullptr)) return 1;
+  if (hi >= 0 && imdgpu_ttm_commflux(ctx, 1, 1, b + 3 * seg, nullptr)) return 1;
   return 0;
 }
 // MAX over the ranks of one host int (collective decisions of the rebuild)

@@ -699,13 +699,16 @@ __global__ void k_ttm_eos_lookup(int n, EosDev tab, const double *x, const doubl
 // As compiled in the reference (ADVMODE 1, ADV2D undefined): upwind in x only, lattice plane k = 1 only (:1327); the
 // new energy per atom goes to l2, an active cell gets its temperature from the inverse EOS, and the host swaps
 // l1 <-> l2 afterwards.  One thread per cell of the plane; the Brent minimiser dominates (about 40 EOS look-ups).
+// A lattice replicated on a grid of ranks holds the blocks of all of them: every rank of the reference advects the plane
+// k = 1 of ITS block, i.e. the global planes 1 + m ldim_z, m < cpu_dim.z -- nplanes of them, kstride apart.
 __global__ __launch_bounds__(64) void k_ttm_adv(Lat L, EosDev ee, double tau, const int *natoms, const int *natoms_old,
                                                 const int *flux, int ncell, const double *dens, const double *U1,
-                                                double *U2, double *T2)
+                                                double *U2, double *T2, int nplanes, int kstride)
 {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x, nj = L.dim[1] - 2;
-  if (t >= (L.dim[0] - 2) * nj) return;
-  const int i = t / nj + 1, j = t % nj + 1, k = 1;
+  const int t0 = blockIdx.x * blockDim.x + threadIdx.x, nj = L.dim[1] - 2, per = (L.dim[0] - 2) * nj;
+  if (t0 >= per * nplanes) return;
+  const int t = t0 % per, k = 1 + (t0 / per) * kstride;
+  const int i = t / nj + 1, j = t % nj + 1;
   const int c = fidx(L, i, j, k), xp = fidx(L, i + 1, j, k), xm = fidx(L, i - 1, j, k);
   const double Nold = (double) natoms_old[c], Nnew = (double) natoms[c];
   if (Nnew > 0) {
@@ -2063,9 +2066,11 @@ extern "C" int imdgpu_ttm_adv(imdgpu_ctx *ctx, double tau, int steps)
   if (!ctx->ttm_flux) return imdgpu_fail(ctx, "ttm_adv: needs the atom-flux counters of update_fd (option ttm_flux or ttm_adv)");
   if (t->dim[2] < 3) return imdgpu_fail(ctx, "ttm_adv: lattice has no plane k = 1");
   if (steps < 1) return 0;                               // :1323
-  const int n = (t->dim[0] - 2) * (t->dim[1] - 2);
+  // replicated lattice of several ranks: the plane k = 1 of every rank's block along z (see k_ttm_adv)
+  const int nplanes = (ctx->external_halo && !ctx->ttm_decomposed) ? ctx->cpu_dim[2] : 1;
+  const int n = (t->dim[0] - 2) * (t->dim[1] - 2) * nplanes;
   hipLaunchKernelGGL(k_ttm_adv, dim3(nblk(n, 64)), dim3(64), 0, ctx->stream, L, t->ee, tau, t->natoms, t->natoms_old,
-                     t->flux, t->ncell, t->dens, t->U[t->cur], t->U[t->cur ^ 1], t->temp[t->cur ^ 1]);
+                     t->flux, t->ncell, t->dens, t->U[t->cur], t->U[t->cur ^ 1], t->temp[t->cur ^ 1], nplanes, t->ldim[2]);
   HIPCHK(hipGetLastError());
   t->cur ^= 1;                                           // l1 <-> l2 as a whole, :1454-1456
   return 0;

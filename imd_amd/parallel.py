@@ -560,35 +560,11 @@ class DistributedMD:
         self.valid = True
         self.nrebuild += 1
 
-    def _commflux(self):
-        """do_COMMFLUX (imd_ttm_3D.c:667-995, without ADV2D) on the decomposed lattice: my boundary columns of {flux[8], U}
-        go into the x neighbours' ghost columns.  Like the reference, the ranks at the two ends of the x range exchange
-        with their inner neighbour only -- no wrap-around even with periodic x (:724-760)."""
-        dec, ops = self.dec, self.ops
-        P, cx = dec.cpu_dim[0], dec.coord[0]
-        if P == 1:
-            return
-        lo = dec.lo[0] if cx > 0 else None
-        hi = dec.hi[0] if cx < P - 1 else None
-        n = ops.ttm_commflux_cells() * 5
-        send_lo = ops.ttm_commflux(0, 0) if lo is not None else None
-        send_hi = ops.ttm_commflux(1, 0) if hi is not None else None
-        sub = _Neighbours(dec, 0, lo, hi)
-        from_lo, from_hi = _exchange(sub, 0, send_lo, send_hi, (n, torch.float64), (n, torch.float64))
-        if from_lo is not None:
-            ops.ttm_commflux(0, 1, from_lo)
-        if from_hi is not None:
-            ops.ttm_commflux(1, 1, from_hi)
-
     # -- one MD step ------------------------------------------------------------------------------
     def md_step(self, step):
         ops = self.ops
         if not self.valid:
             self.rebuild()
-        if self.ttm and self.ttm_decomposed and self.ttm_adv:
-            if self.local_group is not None:
-                raise RuntimeError("decomposed lattice with advection: the do_COMMFLUX exchange is driven over torch.distributed")
-            return self._md_step_host(step)          # do_COMMFLUX sits between update_fd and do_ADV: host-driven variant
         if ops.dist_md_step(step):                   # some rank's list became invalid during this step
             self.valid = False
 
@@ -602,30 +578,6 @@ class DistributedMD:
         ops.forces_phase(1); ops.forces_phase(2)
         self.plan.exchange(ops, 1)
         ops.forces_phase(3)
-
-    def _md_step_host(self, step):
-        """The same step with the phases called one by one from the host (needed only where an exchange of the host layer
-        sits inside the lattice chain: decomposed lattice WITH advection); one flag round trip per step."""
-        ops = self.ops
-        self.plan.exchange(ops, 3)
-        ops.forces_phase(1)
-        ops.ttm_fork()
-        ops.ttm_update_fd(step)
-        self._commflux()
-        ops.ttm_adv(1.0, step)
-        ops.ttm_lattice_step(step)
-        ops.ttm_unfork()
-        ops.forces_phase(2)
-        self.plan.exchange(ops, 1)                   # dF of the ghost atoms  [send_cells(copy_dF)]
-        ops.forces_phase(3)
-        ops.ttm_join()
-        ops.integrate()
-        flag = torch.tensor([ops.get_invalid()], dtype=torch.int32, device=ops.device)
-        if self.world > 1:
-            all_reduce_(flag, dist.ReduceOp.MAX)     # MPI_Allreduce MAX of check_nblist
-        if int(flag.item()):
-            self.valid = False
-            ops.invalidate()
 
     def global_sums(self):
         s = self.ops.get_sums()
@@ -920,30 +872,6 @@ class GpuOps:
     def ttm_block_dims(self):
         return tuple((self.s.cell_dim[d] - 2) // self.s.fd_ext[d] for d in range(3))
 
-    # the TTM lattice chain on its own (high priority) stream: library kernels and the all-gather follow torch's
-    # current stream, so fork = side waits for main and becomes current; unfork = back to main; join = main waits
-    def ttm_fork(self):
-        if not hasattr(self, "side"):
-            self.side = torch.cuda.Stream(self.device, priority=-1)
-        self.side.wait_stream(self.stream)
-        torch.cuda.set_stream(self.side)
-        self.s.set_stream(self.side.cuda_stream)
-
-    def ttm_mark_gathered(self):
-        if not hasattr(self, "_ev_gathered"):
-            self._ev_gathered = torch.cuda.Event()
-        self._ev_gathered.record(self.side)
-
-    def ttm_wait_gathered(self):
-        self.stream.wait_event(self._ev_gathered)
-
-    def ttm_unfork(self):
-        torch.cuda.set_stream(self.stream)
-        self.s.set_stream(self.stream.cuda_stream)
-
-    def ttm_join(self):
-        self.stream.wait_stream(self.side)
-
     def ttm_is_decomposed(self):
         return bool(getattr(self.s, "ttm_decomposed", False))
 
@@ -959,28 +887,8 @@ class GpuOps:
         arr = (C.c_int * 6)(*[int(v) for v in nbr])
         self._ck(self.L.imdgpu_ttm_mailbox_attach(self.h, C.c_void_p(base), per, int(rank), int(world), arr))
 
-    def ttm_local_step(self, step):
-        self._ck(self.L.imdgpu_ttm_local_step(self.h, int(step)))
-
-    def ttm_update_fd(self, step):
-        self._ck(self.L.imdgpu_ttm_update_fd(self.h, int(step)))
-
-    def ttm_commflux_cells(self):
-        n = self.C.c_int()
-        self._ck(self.L.imdgpu_ttm_commflux(self.h, 0, 0, None, self.C.byref(n)))
-        return n.value
-
-    def ttm_commflux(self, side, unpack, buf=None):
-        if buf is None:
-            buf = torch.empty(self.ttm_commflux_cells() * 5, dtype=torch.float64, device=self.device)
-        self._ck(self.L.imdgpu_ttm_commflux(self.h, int(side), int(unpack), self.C.c_void_p(buf.data_ptr()), None))
-        return buf
-
     def ttm_has_adv(self):
         return bool(self.s.get_info("ttm_adv"))
-
-    def ttm_adv(self, tau, step):
-        self._ck(self.L.imdgpu_ttm_adv(self.h, float(tau), int(step)))
 
     def ttm_local_block(self, step):
         C = self.C

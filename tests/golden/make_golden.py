@@ -105,6 +105,16 @@ CASES = {
     # the same grid with the 3D TTM: eight lattice blocks of 4^3 FD cells with MPI ghost faces, assembled into the 8^3 lattice
     "ttm_16384_mpi8": dict(binary="imd_mpi_eam_ttm3d_nbl", box="16 16 16", temp=0.03, steps=3, dump=[0, 1, 2, 3], full=[],
                            pot="eam", nbl=True, cpu="2 2 2", extra="msgbuf_size 3.0\n", ttm=dict(fd_ext="1 1 1", n=100, min_atoms=5)),
+    # ... and with do_ADV / do_COMMFLUX on that grid (the headline's sequence on config 4's geometry: a slab with open x on
+    # 2 x 2 x 2 ranks).  24 unit cells + 4.5 / 3.5 half lattice constants of vacuum in front / behind: 16 MD = FD cells of 3.5 half
+    # lattice constants along x, so every second cell boundary -- the boundary between the two ranks along x among them -- lies ON
+    # a lattice plane and atoms change FD cells, and ranks, in both directions at every list rebuild; 8 x 4 x 4 FD cells per rank,
+    # surface cells switch on and off; every rank advects the plane k = 1 of ITS block (imd_ttm_3D.c:1327), do_COMMFLUX
+    # carries {flux, U} across the rank boundary (:667-995).  All steps are dumped, a few kept.
+    "ttm_adv_mpi8": dict(binary="imd_mpi_eam_ttm3d_nbl", box="24 16 16", temp=0.12, steps=27, dump=None, full=[],
+                         pot="eam", nbl=True, cpu="2 2 2", pbc="0 1 1", adv=True,
+                         extra="msgbuf_size 3.0\nshiftx_front 9.1125\nshiftx_rear 7.0875\n",
+                         ttm=dict(fd_ext="1 1 1", n=100, min_atoms=5), env=dict(IMD_PROBE_ADV="1")),
     "eam_cellpair_2048": dict(binary="imd_eam_nve", box="8 8 8", temp=0.0258, steps=10, dump=[0, 10], full=[0, 10],
                               pot="eam", nbl=False),
 }
@@ -472,6 +482,9 @@ def run_mpi_case(name, c):
     in the global lattice (inner cells; the outer ghost shell stays zero)."""
     cpu = [int(v) for v in c["cpu"].split()]
     world = cpu[0] * cpu[1] * cpu[2]
+    adv = bool(c.get("adv"))
+    if adv:
+        c = dict(c, dump=list(range(c["steps"] + 1)))
     with tempfile.TemporaryDirectory() as d:
         par, eos = write_inputs(c, d)
         env = dict(os.environ, IMD_PROBE_DIR=d, IMD_PROBE_STEPS=",".join(map(str, c["dump"])))
@@ -483,6 +496,13 @@ def run_mpi_case(name, c):
             raise SystemExit("reference run failed for %s" % name)
         P = {s: [po.read_probe(os.path.join(d, "probe.%d.%d.bin" % (rk, s))) for rk in range(world)] for s in c["dump"]}
         T = {s: [po.read_ttm_probe(os.path.join(d, "ttm.%d.%d.bin" % (rk, s))) for rk in range(world)] for s in c["dump"]} if "ttm" in c else {}
+    if adv:            # keep the first and the last step, and the steps at which atoms changed FD cells (with the step before each)
+        fluxsum = {s: sum(int(T[s][rk]["stages"]["flux"]["flux"][1:-1, 1:-1, 1:-1].sum()) for rk in range(world)) for s in c["dump"]}
+        moved = [s for s in c["dump"] if fluxsum[s] > 0]
+        assert len(moved) >= 2 and moved[-1] < c["dump"][-1], "atoms must change FD cells at two steps at least: %s" % moved
+        keep = sorted(set([0, c["dump"][-1]] + [s for m in moved for s in (m - 1, m, m + 1) if 0 <= s <= c["dump"][-1]]))
+        P = {s: P[s] for s in keep}; T = {s: T[s] for s in keep}
+        c = dict(c, dump=keep)
     P0 = P[c["dump"][0]][0]
     out = dict(case=name, param_file=par, steps=np.array(c["dump"]), full_steps=np.array([], int), cpu_dim=np.array(cpu))
     for k in ("ntypes", "global_cell_dim", "pbc_dirs", "box", "cellsz", "nbl_margin", "timestep", "natoms", "flags"):
@@ -522,12 +542,26 @@ def run_mpi_case(name, c):
         out["ttm_fd_dim"] = gd
         for k, v in eos.items():
             out["eos_" + k] = v
+        def assemble(get):
+            a0 = get(0)
+            g = np.zeros(tuple(gd) + a0.shape[3:], a0.dtype)
+            for rk in range(world):
+                co = (rk // (cpu[1] * cpu[2]), (rk // cpu[2]) % cpu[1], rk % cpu[2])
+                sl = tuple(slice(1 + co[q] * ld[q], 1 + (co[q] + 1) * ld[q]) for q in range(3))
+                g[sl] = get(rk)[1:-1, 1:-1, 1:-1]
+            return g
+        if adv:
+            out["flux_steps"] = np.array(moved)
         for s in c["dump"]:
+            if adv:
+                out["t%d_flux" % s] = assemble(lambda rk: T[s][rk]["stages"]["flux"]["flux"]).astype(np.int16)
+                for f in ("temp", "U", "temp2", "U2", "natoms"):
+                    out["t%d_adv_%s" % (s, f)] = assemble(lambda rk: T[s][rk]["stages"]["adv"]["lat"][f])
             for tag in ("update_fd", "substeps_done"):
                 for f in po.TTM_REC.names:
                     if tag == "update_fd" and f not in ("natoms", "md_temp", "dens", "temp", "xi"):
                         continue
-                    if tag == "substeps_done" and f not in ("natoms", "temp", "xi", "fd_k", "fd_g", "Ce", "U", "md_temp", "dens"):
+                    if tag == "substeps_done" and f not in ("natoms", "temp", "xi", "fd_k", "fd_g", "Ce", "U", "md_temp", "dens") + (("temp2", "U2") if adv else ()):
                         continue
                     a0 = T[s][0]["stages"][tag]["lat"][f]
                     g = np.zeros(tuple(gd) + a0.shape[3:], a0.dtype)
@@ -540,8 +574,9 @@ def run_mpi_case(name, c):
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **out)
     last = c["dump"][-1]
-    print("%-20s %8.1f KB  ranks=%d steps=%s nbl_count(last)=%d maxF=%.3g" %
-          (name, os.path.getsize(path) / 1024, world, c["dump"], out["s%d_nbl_count" % last], np.abs(out["s%d_kraft" % last]).max()))
+    print("%-20s %8.1f KB  ranks=%d steps=%s nbl_count(last)=%d maxF=%.3g%s" %
+          (name, os.path.getsize(path) / 1024, world, c["dump"], out["s%d_nbl_count" % last], np.abs(out["s%d_kraft" % last]).max(),
+           "  steps with flux=%s" % moved if adv else ""))
 
 
 TMM_CASE = dict(I0=2.0e15, lam=800e-9, sigma_t=8e-15, t0=6e-15, abs_threshold=4.5)

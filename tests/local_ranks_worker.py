@@ -3,7 +3,8 @@ in-process transport, native rebuild and native step) and stores what every rank
 tests/test_gpu_multirank_local.py as ONE child process per case -- a GPU box admits only a few processes on its card, so
 the 2x2x2 grid of BASELINE config 4 cannot be rehearsed with a process per rank.
 
-usage: python tests/local_ranks_worker.py <case> <cx> <cy> <cz> <nsteps> <ttm 0|1> <decomposed 0|1> <out.npz>"""
+usage: python tests/local_ranks_worker.py <case> <cx> <cy> <cz> <nsteps> <ttm 0|1|2|3> <decomposed 0|1> <out.npz>
+(ttm: 1 = the 3D lattice, 2 = imd_ttm.c's 1D model, 3 = the 3D lattice with do_ADV / do_COMMFLUX in every step)"""
 import os
 import sys
 
@@ -17,6 +18,7 @@ def main():
     case, cpu_dim, nsteps = sys.argv[1], tuple(int(v) for v in sys.argv[2:5]), int(sys.argv[5])
     ttm, decomposed, outpath = bool(int(sys.argv[6])), bool(int(sys.argv[7])), sys.argv[8]
     ttm1d = int(sys.argv[6]) == 2                 # imd_ttm.c's 1D model (with its laser source / electron pressure if the fixture has them)
+    adv = int(sys.argv[6]) == 3                   # calc_ttm with do_ADV(1.0) after update_fd, as the reference compiles it (ADVMODE 1)
     if ttm1d:
         ttm = False
     from tests import golden_util as gu
@@ -38,6 +40,8 @@ def main():
                       device=0, global_cell_dim=dec.gdim, cpu_dim=cpu_dim, my_coord=dec.coord, ttm_decomposed=decomposed,
                       count_ttm_neighbours=ttm or ttm1d)
         s.upload_tables(gu.table(G, "pair_pot"), gu.table(G, "rho_h_tab"), gu.table(G, "embed_pot"))
+        if adv:
+            s.set_option("ttm_adv", 1)
         if ttm:
             s.init_ttm(G["ttm_fd_ext"], int(G["ttm_fd_min_atoms"]), int(G["ttm_diff_substeps"]), float(G["ttm_atomic_weight"]),
                        float(G["ttm_atomic_charge"]), dict(x=G["eos_r"], y=G["eos_t"], z=G["eos_cve"]),
@@ -61,7 +65,7 @@ def main():
         md.calc_forces()
         sums = md.global_sums()
         d = s.download(fields=("ort", "impuls", "kraft", "nummer", "numneighs"))
-        lat = s.ttm_download(fields=("temp", "xi", "natoms")) if ttm else {}
+        lat = s.ttm_download(fields=("temp", "xi", "natoms") + (("U", "temp2", "U2", "flux") if adv else ())) if ttm else {}
         if ttm1d:                              # calc_ttm of the step after the last: collective (the slab sums), every rank calls it
             s.ttm1d_calc(nsteps)
             L1 = s.ttm1d_download()

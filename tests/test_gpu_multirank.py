@@ -177,7 +177,7 @@ def test_two_ranks_ttm_with_advection():
 
 def test_two_ranks_ttm_with_advection_on_the_decomposed_lattice():
     """The same run with one lattice block per rank (option ttm_decomposed): do_COMMFLUX's exchange of the boundary
-    columns of {flux[8], U} (imd_ttm_3D.c:667-995; imdgpu_ttm_commflux + the host layer's P2P exchange, no wrap-around at
+    columns of {flux[8], U} (imd_ttm_3D.c:667-995; dist_commflux inside imdgpu_dist_md_step, no wrap-around at
     the ends of the x range) feeds do_ADV; the per-atom FD cell index is global, so atoms that change ranks are counted
     like in the reference.  Every rank's block equals its part of the reference lattice of step 48."""
     res = _run("ttm_adv", (2, 1, 1), 49, True, decomposed=True, adv=True)

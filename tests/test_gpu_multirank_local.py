@@ -21,12 +21,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(case, cpu_dim, nsteps, ttm=False, decomposed=False):
+def _run(case, cpu_dim, nsteps, ttm=False, decomposed=False, adv=False):
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "res.npz")
         env = dict(os.environ, GPU_MAX_HW_QUEUES="32", PYTHONPATH=ROOT)     # 8 ranks x 2 streams: polling lattice kernels of different ranks must not share a queue
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "local_ranks_worker.py"), case] + [str(v) for v in cpu_dim] +
-                           [str(nsteps), str(int(ttm)), str(int(decomposed)), out], env=env, stdout=subprocess.PIPE,
+                           [str(nsteps), str(3 if adv else int(ttm)), str(int(decomposed)), out], env=env, stdout=subprocess.PIPE,
                            stderr=subprocess.STDOUT, text=True, timeout=900)
         assert r.returncode == 0, "local ranks %s failed:\n%s" % (str(cpu_dim), r.stdout[-4000:])
         R = dict(np.load(out))
@@ -106,6 +106,42 @@ def test_2x2x2_ttm_against_the_reference_on_8_mpi_ranks(decomposed):
             for face in (np.s_[0, 1:-1, 1:-1], np.s_[-1, 1:-1, 1:-1], np.s_[1:-1, 0, 1:-1], np.s_[1:-1, -1, 1:-1],
                          np.s_[1:-1, 1:-1, 0], np.s_[1:-1, 1:-1, -1]):
                 assert np.abs(lat[face] - want[face]).max() < 1e-10 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("decomposed", [False, True])
+def test_2x2x2_ttm_with_advection_against_the_reference_on_8_mpi_ranks(decomposed):
+    """The headline's calc_ttm sequence (update_fd, do_ADV with do_COMMFLUX, activation, FILLMESH, 100 sub-steps) on config 4's
+    layout: an open-x slab on 2 x 2 x 2 ranks, 27 steps through the NATIVE step (imdgpu_dist_md_step; nothing of the step is
+    driven from Python) with three list rebuilds at which atoms change FD cells -- also across the rank boundary along x, in
+    both directions -- against the reference's own `mpiexec -n 8` run with IMD_PROBE_ADV (tests/golden/ttm_adv_mpi8.npz).
+    Replicated lattice: every rank advects the plane k = 1 of every rank block, like the eight ranks of the reference do
+    between them; decomposed lattice: do_COMMFLUX's columns travel as one point-to-point batch inside the step
+    (imdgpu_dist.hip: dist_commflux; imd_ttm_3D.c:667-995,1321-1458)."""
+    G = gu.load("ttm_adv_mpi8")
+    last = int(G["steps"][-1])
+    assert last == 27 and int(G["t25_flux"].sum()) > 0 and int(G["t17_flux"][8:10].sum()) > 0     # flux next to the rank boundary (cells 8 | 9)
+    R, world = _run("ttm_adv_mpi8", (2, 2, 2), last, ttm=True, decomposed=decomposed, adv=True)
+    o, go = _check_atoms(R, world, G, last, forces=False)
+    nn = _cat(R, world, "numneighs")
+    assert np.array_equal(nn[o], G["s%d_numneighs" % last][go])
+    assert all(int(R["r%d_nrebuild" % r]) >= 4 for r in range(world))
+    inner = (slice(1, -1),) * 3
+    pre = "t%d_" % (last - 1)
+    for r in range(world):
+        lat = {k: R["r%d_lat_%s" % (r, k)] for k in ("temp", "xi", "natoms", "U", "temp2", "U2", "flux")}
+        if decomposed:
+            c, n = R["r%d_coord" % r], np.array(lat["temp"].shape) - 2
+            sl = tuple(slice(1 + c[q] * n[q], 1 + (c[q] + 1) * n[q]) for q in range(3))
+        else:
+            sl = inner
+        assert np.array_equal(lat["flux"][inner], G[pre + "flux"][sl]), r
+        assert np.array_equal(lat["natoms"][inner], G[pre + "substeps_done_natoms"][sl]), r
+        for f in ("temp", "U", "temp2", "U2", "xi"):
+            a, b = lat[f][inner], G[pre + "substeps_done_" + f][sl]
+            assert np.abs(a - b).max() <= 2e-8 * np.abs(G[pre + "substeps_done_" + f][inner]).max(), (r, f)   # the inverse EOS's tolerance (test_gpu_ttm)
+    if decomposed:        # the faces went through ghost records in the neighbours' device memory, not through the host
+        assert all(int(R["r%d_remote" % r]) >= 1 and int(R["r%d_persist" % r]) == 2 for r in range(world)), \
+            [(int(R["r%d_remote" % r]), int(R["r%d_persist" % r])) for r in range(world)]
 
 
 @pytest.mark.parametrize("cpu_dim", [(1, 1, 2), (2, 2, 2)])
