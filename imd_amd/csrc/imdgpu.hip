@@ -1747,6 +1747,7 @@ extern "C" int imdgpu_set_option(imdgpu_ctx *ctx, const char *name, int value)
   if (!strcmp(name, "p3_klo")) { ctx->p3_klo = value > 0 ? value : 0; return 0; }           // tests: which rows k_pass3_tile_coef holds
   if (!strcmp(name, "eos_bilinear")) { ctx->eos_bilinear = value ? 1 : 0; return 0; }    // before ttm_init / ttm1d_init
   if (!strcmp(name, "ttm_persist")) { imdgpu_ttm_set_persist(ctx, value < 0 ? -1 : (value ? 1 : 0)); return 0; }
+  if (!strcmp(name, "ttm_persist_miss")) { ctx->ttm_persist_miss = value; return 0; }      // tests: the MD step whose persistent launch cannot complete its census
   if (!strcmp(name, "ttm_decomposed")) {         // before ttm_init
     if (ctx->ttm) return imdgpu_fail(ctx, "ttm_decomposed must be set before ttm_init");
     ctx->ttm_decomposed = value ? 1 : 0;
@@ -1781,7 +1782,9 @@ extern "C" int imdgpu_get_info(imdgpu_ctx *ctx, const char *name, long long *val
     {"kernel_rev", IMDGPU_KERNEL_REV}, {"pass3_ring", ctx->ttm ? 0 : 4}, {"have_valid_nbl", ctx->have_valid_nbl},
     {"ttm_persist_mode", imdgpu_ttm_persist_info(ctx, 0)}, {"ttm_persist_runs", imdgpu_ttm_persist_info(ctx, 1)},
     // decomposed lattice: 0 = faces through the host mailbox, 1 / 2 = ghost records in the neighbours' device memory (coarse- / fine-grained)
-    {"ttm_remote", imdgpu_ttm_persist_info(ctx, 2)}};
+    {"ttm_remote", imdgpu_ttm_persist_info(ctx, 2)},
+    // MD steps whose sub-steps the host issued again through the launch chain because the persistent kernel had stepped aside
+    {"ttm_persist_redone", imdgpu_ttm_persist_info(ctx, 3)}};
   for (auto &e : tab) if (!strcmp(name, e.n)) { *value = e.v; return 0; }
   return imdgpu_fail(ctx, "unknown info %s", name);
 }
@@ -2889,8 +2892,23 @@ extern "C" int imdgpu_md_step_end(imdgpu_ctx *ctx, int steps)
   imdgpu_tl_mark(ctx, "move");
   HIPCHK(hipStreamSynchronize(ctx->stream));
   tl_flush(ctx, steps);
+  if (ctx->ttm) {
+    // the persistent sub-step kernel of this step stepped aside (status 1: nothing of the lattice touched, the integrator above
+    // returned at once on the same word): its sub-steps have been issued through the launch chain; now the integrator again
+    const int r = imdgpu_ttm_persist_settle(ctx);
+    if (r < 0) return 1;
+    if (r == 1) {
+      if (imdgpu_ttm_move_internal(ctx)) return 1;
+      HIPCHK(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, CNT_N * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+  }
   if (ctx->h_counters[CNT_INVALID]) { ctx->have_valid_nbl = 0; ctx->need_fix_cells = 1; }
-  if (ctx->h_counters[CNT_TTM_TIMEOUT]) return imdgpu_fail(ctx, "TTM lattice: a sub-step hand-off timed out; the lattice of this step is not valid (IMDGPU_TTM_PERSIST=0 disables the persistent sub-step kernel)");
+  if (ctx->h_counters[CNT_TTM_TIMEOUT]) {
+    // reported once: the context stays usable -- e.g. with option ttm_persist = 0 and a lattice uploaded again
+    HIPCHK(hipMemsetAsync(ctx->d_counters + CNT_TTM_TIMEOUT, 0, sizeof(int), ctx->stream));
+    return imdgpu_fail(ctx, "TTM lattice: a sub-step hand-off timed out inside the loop; the lattice of this step is not valid (option ttm_persist = 0 / IMDGPU_TTM_PERSIST=0 disables the persistent sub-step kernel)");
+  }
   if (ctx->h_counters[CNT_TMM_SHORT]) return imdgpu_fail(ctx, "Sample is too short for TMM. Consider reducing tmm_threshold.");      // imd_tmm.c:362: the reference aborts
   return 0;
 }

@@ -124,9 +124,9 @@ static int dist_new(imdgpu_ctx *ctx, int nranks, int rank)
   D->nranks = nranks; D->rank = rank;
   ctx->dist = D;
   HIPCHK(hipSetDevice(ctx->device));
-  HIPCHK(hipMalloc((void **) &D->d_flag, 4 * sizeof(int)));
-  HIPCHK(hipMemset(D->d_flag, 0, 4 * sizeof(int)));
-  HIPCHK(hipHostMalloc((void **) &D->h_flag, 4 * sizeof(int)));
+  HIPCHK(hipMalloc((void **) &D->d_flag, 8 * sizeof(int)));       // [0..3]: the step's flags (dist_flag_allreduce), [4]: scratch of dist_max_int
+  HIPCHK(hipMemset(D->d_flag, 0, 8 * sizeof(int)));
+  HIPCHK(hipHostMalloc((void **) &D->h_flag, 8 * sizeof(int)));
   HIPCHK(hipMalloc((void **) &D->d_shift, 3 * MAXSEG * sizeof(double)));
   HIPCHK(hipEventCreateWithFlags(&D->ev_flag, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&D->ev_gathered, hipEventDisableTiming));
@@ -331,14 +331,21 @@ extern "C" int imdgpu_dist_halo(imdgpu_ctx *ctx, int what)
 
 // MAX over the ranks of this rank's list-validity flag (check_nblist's MPI_Allreduce, imd_forces_nbl.c:1087) -> d_flag[0]
 // flag[1]: a time-out of the lattice's hand-offs (persistent sub-step kernel, mailbox) on ANY rank fails the step everywhere
-__global__ void k_dist_flag_in(const int *counters, int *flag) { flag[0] = counters[CNT_INVALID]; flag[1] = counters[CNT_TTM_TIMEOUT]; }
+// flag[2]: the persistent sub-step kernel of some rank stepped aside in trusted mode (its status word; nothing of that rank's
+// lattice was touched and its integrator returned at once): every rank repeats the tail of the step after that rank has
+// re-issued its sub-steps.  flag[3] = flag[0] | flag[2]: what the guarded pass 1 enqueued ahead looks at.
+__global__ void k_dist_flag_in(const int *counters, const int *pstat, int *flag)
+{
+  const int soft = (pstat && *pstat == 1) ? 1 : 0;
+  flag[0] = counters[CNT_INVALID]; flag[1] = counters[CNT_TTM_TIMEOUT]; flag[2] = soft; flag[3] = (counters[CNT_INVALID] || soft) ? 1 : 0;
+}
 static int dist_flag_allreduce(imdgpu_ctx *ctx, DistState *D)
 {
-  hipLaunchKernelGGL(k_dist_flag_in, dim3(1), dim3(1), 0, ctx->stream, ctx->d_counters, D->d_flag);
+  hipLaunchKernelGGL(k_dist_flag_in, dim3(1), dim3(1), 0, ctx->stream, ctx->d_counters, ctx->ttm ? imdgpu_ttm_persist_guard(ctx) : nullptr, D->d_flag);
   if (D->nranks == 1 && !D->self_comm) return 0;
-  if (D->comm) { NCCLCHK(g_rccl.AllReduce(D->d_flag, D->d_flag, 2, ncclInt, ncclMax, D->comm, ctx->stream)); return 0; }
+  if (D->comm) { NCCLCHK(g_rccl.AllReduce(D->d_flag, D->d_flag, 4, ncclInt, ncclMax, D->comm, ctx->stream)); return 0; }
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  if (D->cb(D->cb_user, 1, D->d_flag, D->d_flag, 2, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 4))
+  if (D->cb(D->cb_user, 1, D->d_flag, D->d_flag, 4, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 4))
     return imdgpu_fail(ctx, "dist: the host transport failed (all-reduce)");
   return 0;
 }
@@ -440,30 +447,45 @@ extern "C" int imdgpu_dist_md_step(imdgpu_ctx *ctx, int steps, int *rebuild_need
   if (imdgpu_launch_integrate(ctx)) return 1;
   // next step's position halo and the global validity flag; then pass 1 of the next step, guarded by that flag, so the
   // device has work while the host reads the flag
-  if (imdgpu_dist_halo(ctx, 3)) return 1;
-  if (dist_flag_allreduce(ctx, D)) return 1;
-  HIPCHK(hipMemcpyAsync(D->h_flag, D->d_flag, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipEventRecord(D->ev_flag, ctx->stream));
   const bool spec = !getenv("IMDGPU_NO_SPECULATION");
-  if (spec) {
-    ctx->pass1_guard = D->d_flag;
-    int rc = imdgpu_launch_forces_phase(ctx, 1);
-    ctx->pass1_guard = nullptr;
-    if (rc) return 1;
+  auto drop_ahead = [&]() {           // the guarded launch did nothing: it must not count as a pass-1 launch in the kernel timings
+    for (size_t q = ctx->ev_pending.size(); q-- > 0;)
+      if (ctx->ev_pending[q].id == PROF_PASS1) {
+        ctx->ev_pool.push_back(ctx->ev_pending[q].a); ctx->ev_pool.push_back(ctx->ev_pending[q].b);
+        ctx->ev_pending.erase(ctx->ev_pending.begin() + q);
+        break;
+      }
+  };
+  for (int round = 0;; round++) {
+    if (imdgpu_dist_halo(ctx, 3)) return 1;
+    if (dist_flag_allreduce(ctx, D)) return 1;
+    HIPCHK(hipMemcpyAsync(D->h_flag, D->d_flag, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipEventRecord(D->ev_flag, ctx->stream));
+    if (spec) {
+      ctx->pass1_guard = D->d_flag + 3;
+      int rc = imdgpu_launch_forces_phase(ctx, 1);
+      ctx->pass1_guard = nullptr;
+      if (rc) return 1;
+    }
+    HIPCHK(hipEventSynchronize(D->ev_flag));
+    // how this rank's persistent sub-step kernel went (replicated lattice, trusted mode): a launch that stepped aside has
+    // its sub-steps issued through the launch chain now, the integrator -- which returned at once on the status word -- again;
+    // EVERY rank then repeats the halo, the flags and the pass enqueued ahead, because some rank's positions were not moved
+    const int r = ctx->ttm ? imdgpu_ttm_persist_settle(ctx) : 0;
+    if (r < 0) return 1;
+    if (r == 1 && imdgpu_launch_integrate(ctx)) return 1;
+    if (!D->h_flag[2]) break;
+    if (round > 0) return imdgpu_fail(ctx, "dist_md_step: the persistent sub-step kernel's status did not clear after the step was re-issued");
+    if (spec) drop_ahead();
   }
-  HIPCHK(hipEventSynchronize(D->ev_flag));
-  if (D->h_flag[1])                 // like imdgpu_md_step: the lattice of this step was not (or only half) advanced on some rank
+  if (D->h_flag[1]) {               // like imdgpu_md_step: the lattice of this step was not (or only half) advanced on some rank
+    HIPCHK(hipMemsetAsync(ctx->d_counters + CNT_TTM_TIMEOUT, 0, sizeof(int), ctx->stream));      // reported once
     return imdgpu_fail(ctx, "TTM: a hand-off between lattice blocks timed out on some rank (persistent sub-step kernel or mailbox): the lattice of this step is not valid");
+  }
   const int invalid = D->h_flag[0];
   if (invalid) {
     ctx->have_valid_nbl = 0; ctx->need_fix_cells = 1; D->have_plan = false;
-    if (spec)                       // the guarded launch did nothing: it must not count as a pass-1 launch in the kernel timings
-      for (size_t q = ctx->ev_pending.size(); q-- > 0;)
-        if (ctx->ev_pending[q].id == PROF_PASS1) {
-          ctx->ev_pool.push_back(ctx->ev_pending[q].a); ctx->ev_pool.push_back(ctx->ev_pending[q].b);
-          ctx->ev_pending.erase(ctx->ev_pending.begin() + q);
-          break;
-        }
+    if (spec) drop_ahead();
   }
   else { D->halo_ready = true; D->spec_pass1 = spec; }
   if (rebuild_needed) *rebuild_needed = invalid;
@@ -761,14 +783,14 @@ static int dist_commflux(imdgpu_ctx *ctx, DistState *D)
 static int dist_max_int(imdgpu_ctx *ctx, DistState *D, int *v)
 {
   if (D->nranks == 1) return 0;
-  HIPCHK(hipMemcpyAsync(D->d_flag + 2, v, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-  if (D->comm) NCCLCHK(g_rccl.AllReduce(D->d_flag + 2, D->d_flag + 2, 1, ncclInt, ncclMax, D->comm, ctx->stream));
+  HIPCHK(hipMemcpyAsync(D->d_flag + 4, v, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  if (D->comm) NCCLCHK(g_rccl.AllReduce(D->d_flag + 4, D->d_flag + 4, 1, ncclInt, ncclMax, D->comm, ctx->stream));
   else {
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    if (D->cb(D->cb_user, 1, D->d_flag + 2, D->d_flag + 2, 1, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 4))
+    if (D->cb(D->cb_user, 1, D->d_flag + 4, D->d_flag + 4, 1, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 4))
       return imdgpu_fail(ctx, "dist: the host transport failed (all-reduce)");
   }
-  HIPCHK(hipMemcpyAsync(v, D->d_flag + 2, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(v, D->d_flag + 4, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return 0;
 }

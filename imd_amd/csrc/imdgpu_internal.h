@@ -101,6 +101,7 @@ struct imdgpu_ctx {
   int ttm_flux = 0;               // update_fd also counts the atoms that changed FD cells (imd_ttm_3D.c:335-370)
   int ttm_adv = 0;                // calc_ttm runs do_ADV after update_fd (imd_ttm_3D.c:57-60); implies ttm_flux
   int ttm_persist_opt = -1;       // option ttm_persist: the persistent sub-step kernel on (1) / off (0) / default (-1)
+  int ttm_persist_miss = -1;      // option ttm_persist_miss (tests): the persistent launch of this MD step waits for one workgroup too many
   int ttm_decomposed = 0;         // several ranks: one TTM lattice block per rank, faces through the shared-memory mailbox
   int external_halo = 0;          // ghost atoms are supplied through imdgpu_halo_scatter (multi-rank decomposition)
   int *mig_idx[2]{nullptr, nullptr}; int mig_n[2]{0, 0}, mig_cap = 0; int *mig_flag = nullptr;
@@ -242,6 +243,8 @@ int imdgpu_ttm1d_move_internal(imdgpu_ctx *ctx);
 // sum over the ranks of n doubles in device memory, in place, on ctx->stream (the lattice stream when forked); nothing on one rank
 int imdgpu_dist_sum_dev(imdgpu_ctx *ctx, double *d, int n);
 void imdgpu_ttm_set_persist(imdgpu_ctx *ctx, int value);
+int imdgpu_ttm_persist_settle(imdgpu_ctx *ctx);            // 0 nothing, 1 the stepped-aside launch's sub-steps were re-issued (launch the integrator again), -1 error
+const int *imdgpu_ttm_persist_guard(imdgpu_ctx *ctx);      // status word a guarded integrator looks at, or null
 long long imdgpu_ttm_persist_info(imdgpu_ctx *ctx, int which);
 void imdgpu_dist_free(imdgpu_ctx *ctx);
 void imdgpu_dist_cancel_ahead(imdgpu_ctx *ctx);

@@ -76,6 +76,9 @@ struct TtmState {
   // persistent sub-step kernel (k_ttm_chain_persist): 0 = off, 1 = trial (the captured launch chain follows every launch,
   // guarded by the kernel's status word), 2 = trusted (launch chain dropped)
   int persist = -1, persist_ok = 0, persist_tiles = 0, pstat_pending = 0;
+  int pstat_mode = 0;                    // mode of the launch whose status is pending: 1 trial, 2 trusted, 3 trusted with remote records
+  int persist_miss_run = 0, persist_redone = 0;   // launches in a row that stepped aside; steps re-issued through the launch chain
+  int *d_pbbox = nullptr;                // bounding box of the active cells (k_ttm_fillmesh -> k_ttm_chain_persist), behind d_pflags' words
   unsigned *d_pflags = nullptr;          // census word, gate word
   unsigned long long *d_prec = nullptr;  // hand-off records [2][ncell][4]
   unsigned persist_base = 0;             // tag of state 0 of the next launch
@@ -849,19 +852,38 @@ __device__ __forceinline__ MeshOut mesh_props(const Lat &L, const EosDev &cve, d
   return o;
 }
 
+// bbox (may be null): six ints, zeroed before the launch, that receive the bounding box of the ACTIVE cells for the persistent
+// sub-step kernel, which anchors its blocks there -- [d] = max of (BBOX_BIG - coordinate), [3 + d] = max of the coordinate
+// (inner coordinates 1 ..; all zero = no active cell).  One wave reduction and six atomics per wave.
+#define BBOX_BIG (1 << 20)
 __global__ void k_ttm_fillmesh(Lat L, int steps, EosDev cve, EosDev ee, const int *natoms, const double *temp,
                                const double *md_temp, const double *dens, double *Z, double *ne, double *Ce,
-                               double *fd_k, double *fd_g, double *U0, double *U1)
+                               double *fd_k, double *fd_g, double *U0, double *U1, int *bbox)
 {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int ni = L.dim[0] - 2, nj = L.dim[1] - 2, nk = L.dim[2] - 2;
-  if (t >= ni * nj * nk) return;
-  const int c = fidx(L, t / (nk * nj) + 1, (t / nk) % nj + 1, t % nk + 1);
-  if (natoms[c] >= L.fd_min_atoms) {
-    MeshOut o = mesh_props(L, cve, temp[c], md_temp[c], dens[c]);
-    Z[c] = o.Z; ne[c] = o.ne; Ce[c] = o.Ce; fd_k[c] = o.k; fd_g[c] = o.g;
-    if (steps < 1) { double u = eos_ee(ee, dens[c], temp[c] * 11604.5) * 26.9815 * C_AMU * C_J2EV; U0[c] = u; U1[c] = u; }
-  } else { fd_k[c] = 0.0; fd_g[c] = 0.0; Z[c] = 0.0; ne[c] = 0.0; Ce[c] = 0.0; }
+  int v[6] = {0, 0, 0, 0, 0, 0};
+  if (t < ni * nj * nk) {
+    const int i = t / (nk * nj) + 1, j = (t / nk) % nj + 1, k = t % nk + 1;
+    const int c = fidx(L, i, j, k);
+    if (natoms[c] >= L.fd_min_atoms) {
+      MeshOut o = mesh_props(L, cve, temp[c], md_temp[c], dens[c]);
+      Z[c] = o.Z; ne[c] = o.ne; Ce[c] = o.Ce; fd_k[c] = o.k; fd_g[c] = o.g;
+      if (steps < 1) { double u = eos_ee(ee, dens[c], temp[c] * 11604.5) * 26.9815 * C_AMU * C_J2EV; U0[c] = u; U1[c] = u; }
+      v[0] = BBOX_BIG - i; v[1] = BBOX_BIG - j; v[2] = BBOX_BIG - k; v[3] = i; v[4] = j; v[5] = k;
+    } else { fd_k[c] = 0.0; fd_g[c] = 0.0; Z[c] = 0.0; ne[c] = 0.0; Ce[c] = 0.0; }
+  }
+  if (bbox) {
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_down(v[q], o, 64); v[q] = w > v[q] ? w : v[q]; }
+    }
+    if ((threadIdx.x & 63) == 0 && v[3] > 0) {
+#pragma unroll
+      for (int q = 0; q < 6; q++) atomicMax(bbox + q, v[q]);
+    }
+  }
 }
 
 // do_cell_activation (imd_ttm_3D.c:1468-1596).  The reference walks the cells in order (i outer, k inner) and writes
@@ -1093,8 +1115,10 @@ struct PersistDev {
   unsigned *census, *gate;              // zeroed before every launch
   unsigned long long *rec;              // [2][ncell][4] granules
   int *status, *counters;
-  int nt[3], ntiles, trusted, ncell;
+  int trusted, ncell;
   unsigned base;                        // tag of state 0 of this launch
+  const int *bbox;                      // bounding box of the active cells, as k_ttm_fillmesh leaves it (device; this step's)
+  int extra_census;                     // test hook (option ttm_persist_miss): workgroups the census waits for in vain
   // decomposed lattice (REM): the cells beyond a rank boundary live on ANOTHER GPU.  Every rank owns a buffer of ghost
   // records -- per face cell and parity the same four granules as `rec`, then one granule {tag | natoms} per face cell --
   // which its neighbours write straight into (system-scope stores over xGMI, or the same memory when ranks share a GPU)
@@ -1138,10 +1162,44 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     double *neo, EosDev cve, PersistDev P)
 {
   const int lane = threadIdx.x, tile = blockIdx.x;
-  const int tz = tile % P.nt[2], ty = (tile / P.nt[2]) % P.nt[1], tx = tile / (P.nt[2] * P.nt[1]);
+  // The blocks are anchored on the bounding box of the ACTIVE cells of this step (k_ttm_fillmesh): a slab with vacuum, or the
+  // share of it a rank holds, needs blocks for its filled layers only, and the box moves with the surfaces.  Per dimension
+  // the box of n layers is cut into ceil(n / 4) blocks of four layers -- with n = 4 q + 1 the last two are three and two
+  // layers wide, so no block is ONE layer wide (a cell of such a block would have both its neighbours of that dimension
+  // in other blocks; the hand-off below knows one per dimension).  Cells outside the box are inactive: FILLMESH has
+  // zeroed what the launch chain would zero for them.  The kernel steps aside (status 1, nothing touched: the launch chain
+  // does the step) when the box needs more blocks than the launch brought -- all of them must be resident at once -- or is
+  // one layer thin.
+  int lo[3], nn[3], nb[3];
+  bool aside = false, none = false;
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    int a = BBOX_BIG - P.bbox[d], b = P.bbox[3 + d];
+    if (b == 0) { a = 1; none = true; }                                            // no active cell at all
+    lo[d] = a; nn[d] = b - a + 1; nb[d] = (nn[d] + PT - 1) / PT;
+    if (nn[d] == 1) aside = true;
+  }
+  if (none) return;                                                                // nothing active, nothing to do: status stays 0
+  const int ntiles = nb[0] * nb[1] * nb[2];
+  if (ntiles > (int) gridDim.x) aside = true;
+  if (aside) {
+    if (tile == 0 && lane == 0) {
+      __hip_atomic_store(P.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (REM) __hip_atomic_store(P.counters + CNT_TTM_TIMEOUT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // other ranks' kernels are waiting for this one's records
+    }
+    return;
+  }
+  if (tile >= ntiles) return;
+  const int tb[3] = {tile / (nb[2] * nb[1]), (tile / nb[2]) % nb[1], tile % nb[2]};
   const int l3[3] = {lane >> 4, (lane >> 2) & 3, lane & 3};
-  const int i = tx * PT + l3[0] + 1, j = ty * PT + l3[1] + 1, k = tz * PT + l3[2] + 1;
-  const bool inside = i <= L.dim[0] - 2 && j <= L.dim[1] - 2 && k <= L.dim[2] - 2;
+  int bs[3], bw[3];
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    if ((nn[d] & 3) == 1 && tb[d] >= nb[d] - 2) { bs[d] = PT * (nb[d] - 2) + (tb[d] == nb[d] - 1 ? 3 : 0); bw[d] = tb[d] == nb[d] - 1 ? 2 : 3; }
+    else { bs[d] = PT * tb[d]; bw[d] = nn[d] - bs[d] < PT ? nn[d] - bs[d] : PT; }
+  }
+  const int i = lo[0] + bs[0] + l3[0], j = lo[1] + bs[1] + l3[1], k = lo[2] + bs[2] + l3[2];
+  const bool inside = l3[0] < bw[0] && l3[1] < bw[1] && l3[2] < bw[2];
   const int m = L.fd_min_atoms, c = inside ? fidx(L, i, j, k) : 0;
   const int nat = inside ? natoms[c] : 0;
   const bool active = inside && nat >= m;
@@ -1150,7 +1208,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
   if (lane == 0) {
     const unsigned long long t0 = wall_clock64();
     const unsigned n = __hip_atomic_fetch_add(P.census, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-    if (n == (unsigned) P.ntiles) {
+    if (n == (unsigned) (ntiles + P.extra_census)) {
       unsigned expect = 0;
       __hip_atomic_compare_exchange_strong(P.gate, &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -1164,8 +1222,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
       if (wall_clock64() - t0 > (P.trusted ? PERSIST_SPIN_TICKS : PERSIST_CENSUS_TICKS)) {
         unsigned expect = 0;
         if (__hip_atomic_compare_exchange_strong(P.gate, &expect, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+          // status 1 = nothing of the lattice has been touched: the guarded launch chain behind this kernel (trial) or the
+          // host (trusted: the integrator is guarded by the same word and the step's lattice part is issued again) does the step.
+          // With faces through other ranks' records (REM) their kernels are waiting for this one: an error on every rank
           __hip_atomic_store(P.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (P.trusted) __hip_atomic_store(P.counters + CNT_TTM_TIMEOUT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (REM) __hip_atomic_store(P.counters + CNT_TTM_TIMEOUT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           break;
         }
         if (expect == 1u) go = 1;
@@ -1184,20 +1245,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
   unsigned intile = 0, rem = 0;                        // rem bit q: the neighbour in direction q is a cell of another rank
   const unsigned long long tloop = wall_clock64();
   if (REM) {
-    // every inner cell on a face towards another rank tells that rank its atom count (activity decides mirror or flux) and,
-    // if active, its state 0; then the ghost cells' counts are awaited -- all of it tagged with this launch's base
+    // every ACTIVE inner cell on a face towards another rank gives that rank its state 0; the atom counts of all face cells
+    // (activity decides mirror or flux) have gone out before this launch (k_ttm_xrec_counts: the blocks of this kernel cover
+    // the active cells only) -- all of it tagged with this launch's base; the ghost cells' counts are awaited below
 #pragma unroll
     for (int q = 0; q < 6; q++) {
       const int d = q >> 1, me = d == 0 ? i : d == 1 ? j : k;
       if (!inside || P.peer[q] == nullptr || me != ((q & 1) ? 1 : L.dim[d] - 2)) continue;
       rem |= 1u << q;
-      const int f = P.xoff[q ^ 1] + face_index(L, q, i, j, k);                    // my cell in the peer's face q ^ 1
       if (active) {
-        unsigned long long *r = P.peer[q] + (size_t) f * 4;                       // parity 0
+        unsigned long long *r = P.peer[q] + (size_t) (P.xoff[q ^ 1] + face_index(L, q, i, j, k)) * 4;      // my cell in the peer's face q ^ 1, parity 0
         xrec_store(r, P.base, T0[c]); xrec_store(r + 2, P.base, K0[c]);
       }
-      __hip_atomic_store(P.peer[q] + (size_t) 2 * P.xcells * 4 + f, ((unsigned long long) P.base << 32) | (unsigned) nat,
-                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 #pragma unroll
@@ -1223,8 +1282,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
         __hip_atomic_store(P.counters + CNT_TTM_TIMEOUT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         gn = 0;
       }
-      natoms[gc] = gn;                                 // the ghost shell of the arrays follows (downloads, CFL_maxdt)
-      if (gn >= m) cell = gc;
+      if (gn >= m) cell = gc;                          // (the ghost shell of the arrays follows in k_ttm_xrec_final)
       nc[q] = cell;
       continue;
     }
@@ -1233,17 +1291,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     if (!empty) { cell = fidx(L, g[0], g[1], g[2]); if (natoms[cell] < m) cell = -1; }
     nc[q] = cell;
     const int ln = l3[d] + dir;
-    if (ln >= 0 && ln < PT && g[d] == (d == 0 ? i : d == 1 ? j : k) + dir) intile |= 1u << q;    // same block and not wrapped
+    if (ln >= 0 && ln < bw[d] && g[d] == (d == 0 ? i : d == 1 ? j : k) + dir) intile |= 1u << q;    // same block and not wrapped
   }
   if (inside && !active) { K0[c] = 0.0; K1[c] = 0.0; fd_g[c] = 0.0; Ce[c] = 0.0; Zo[c] = 0.0; neo[c] = 0.0; }   // what the chain's launches write (nobody reads an inactive cell)
-  // which ghost cells beyond a rank boundary are active: their final state is fetched into the arrays' ghost shell at the end
-  unsigned gact = 0;
-  if (REM) {
-#pragma unroll
-    for (int q = 0; q < 6; q++) if ((rem >> q & 1u) && nc[q] >= 0) gact |= 1u << q;
-  }
   const bool any_active = __ballot(active) != 0ull;
-  if (!any_active && !(REM && __ballot(gact != 0) != 0ull)) return;   // a block without an active cell: nothing to compute, never read
+  if (!any_active) return;                             // a block without an active cell: nothing to compute, never read
   // at most ONE neighbour per dimension lies in another block or on another rank (the host does not use this kernel for
   // lattices with a one-cell-wide last block): xc[d] = its cell -- for a cell of another rank: its record in xrec -- or -1
   // (bit d of xany: there is one; bit d of xrm: it is a record of xrec)
@@ -1354,37 +1406,68 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     }
   }
   if (active) { xi[c] = x; Ce[c] = ce; fd_g[c] = g; }
-  if (REM && gact != 0) {
-    // ttm_fill_ghost_layers after the last sub-step (imd_ttm_3D.c:70,3314-3504): the final state of the active cells beyond
-    // my faces goes into the ghost shell of the arrays that hold the final state (what the next step's cell activation,
-    // CFL_maxdt and downloads read)
-    const unsigned long long want = (unsigned long long) (P.base + (unsigned) nsub);
-    const unsigned long long *X = P.xrec + (size_t) (nsub & 1) * P.xcells * 4;
-    double *Tf = (nsub & 1) ? T1 : T0, *Kf = (nsub & 1) ? K1 : K0;
-    unsigned todo = gact;
-    for (;;) {
+}
+
+// Decomposed lattice with ghost records, the two ends of a launch that do not follow the blocks of k_ttm_chain_persist (which
+// cover the ACTIVE cells only).  One thread per face cell of the faces with another rank beyond them.
+//  counts: every inner face cell tells the rank beyond its atom count, tagged with the launch's base -- active or not: the
+//          count decides between mirror and flux on the other side (what ttm_fill_ghost_layers' natoms plane does).
+//  final:  ttm_fill_ghost_layers after the last sub-step (imd_ttm_3D.c:70,3314-3504): count and, for active cells, final
+//          (Te, kappa) of every cell beyond my faces go into the ghost shell of the arrays (what the next step's cell
+//          activation, CFL_maxdt and downloads read).  Runs behind the persistent kernel; skipped when that stepped aside.
+__device__ __forceinline__ bool xface_cell(const Lat &L, const PersistDev &P, int t, int &q, int &f, int (&g)[3])
+{
+  q = -1;
 #pragma unroll
-      for (int q = 0; q < 6; q++)
-        if (todo >> q & 1u) {
-          const unsigned long long *r = X + (size_t) (P.xoff[q] + face_index(L, q, i, j, k)) * 4;
-          const unsigned long long a0 = xrec_load(r), a1 = xrec_load(r + 1), a2 = xrec_load(r + 2), a3 = xrec_load(r + 3);
-          if ((a0 >> 32) == want && (a1 >> 32) == want && (a2 >> 32) == want && (a3 >> 32) == want) {
-            Tf[nc[q]] = __longlong_as_double((long long) ((a0 << 32) | (a1 & 0xffffffffull)));
-            Kf[nc[q]] = __longlong_as_double((long long) ((a2 << 32) | (a3 & 0xffffffffull)));
-            todo &= ~(1u << q);
-          }
-        }
-      if (__all(todo == 0)) break;
-      if (__any(wall_clock64() - tloop > PERSIST_SPIN_TICKS || ld_flag(P.gate) == 3u)) {
-        if (lane == 0) {
-          __hip_atomic_store(P.gate, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(P.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(P.counters + CNT_TTM_TIMEOUT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+  for (int u = 0; u < 6; u++) {
+    const int d = u >> 1, nf = (L.dim[(d + 1) % 3] - 2) * (L.dim[(d + 2) % 3] - 2);
+    if (q < 0 && t >= P.xoff[u] && t < P.xoff[u] + nf) q = u;
+  }
+  if (q < 0 || P.peer[q] == nullptr) return false;
+  f = t - P.xoff[q];
+  const int d = q >> 1, n2 = d == 2 ? L.dim[1] - 2 : L.dim[2] - 2, a = f / n2 + 1, b = f % n2 + 1;
+  g[d] = (q & 1) ? 1 : L.dim[d] - 2;
+  if (d == 0) { g[1] = a; g[2] = b; } else if (d == 1) { g[0] = a; g[2] = b; } else { g[0] = a; g[1] = b; }
+  return true;
+}
+__global__ __launch_bounds__(64) void k_ttm_xrec_counts(Lat L, PersistDev P, const int *natoms)
+{
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  int q, f, g[3];
+  if (t >= P.xcells || !xface_cell(L, P, t, q, f, g)) return;
+  __hip_atomic_store(P.peer[q] + (size_t) 2 * P.xcells * 4 + P.xoff[q ^ 1] + f,
+                     ((unsigned long long) P.base << 32) | (unsigned) natoms[fidx(L, g[0], g[1], g[2])], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ __launch_bounds__(64) void k_ttm_xrec_final(Lat L, PersistDev P, int nsub, int *natoms, double *Tf, double *Kf)
+{
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  int q, f, g[3];
+  if (t >= P.xcells || !xface_cell(L, P, t, q, f, g)) return;
+  if (__hip_atomic_load(P.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+  g[q >> 1] += (q & 1) ? -1 : 1;
+  const int gc = fidx(L, g[0], g[1], g[2]);
+  const unsigned long long t0 = wall_clock64();
+  const unsigned long long *rn = P.xrec + (size_t) 2 * P.xcells * 4 + P.xoff[q] + f;
+  const unsigned long long *r = P.xrec + ((size_t) (nsub & 1) * P.xcells + P.xoff[q] + f) * 4;
+  const unsigned long long want = (unsigned long long) (P.base + (unsigned) nsub);
+  int gn = -1;
+  for (;;) {
+    if (gn < 0) { const unsigned long long v = xrec_load(rn); if ((unsigned) (v >> 32) == P.base) { gn = (int) (unsigned) v; natoms[gc] = gn; } }
+    if (gn >= 0) {
+      if (gn < L.fd_min_atoms) return;
+      const unsigned long long a0 = xrec_load(r), a1 = xrec_load(r + 1), a2 = xrec_load(r + 2), a3 = xrec_load(r + 3);
+      if ((a0 >> 32) == want && (a1 >> 32) == want && (a2 >> 32) == want && (a3 >> 32) == want) {
+        Tf[gc] = __longlong_as_double((long long) ((a0 << 32) | (a1 & 0xffffffffull)));
+        Kf[gc] = __longlong_as_double((long long) ((a2 << 32) | (a3 & 0xffffffffull)));
         return;
       }
-      __builtin_amdgcn_s_sleep(2);
     }
+    if (wall_clock64() - t0 > PERSIST_SPIN_TICKS || ld_flag(P.gate) == 3u) {          // the rank beyond never came this far: loudly
+      __hip_atomic_store(P.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(P.counters + CNT_TTM_TIMEOUT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    __builtin_amdgcn_s_sleep(2);
   }
 }
 
@@ -1416,8 +1499,11 @@ __global__ void k_ttm_cfl(Lat L, const int *natoms, const double *fd_k, const do
 __global__ void k_move_ttm(int n, int cap, Lat L, Geo g, double4 *pos, const int *type, const int *acell,
                            double *p, double *f, const double *mass, const double *restr, int ntypes, double dt,
                            const double *ref, const int *natoms, const double *xi, const double *vcom, int ncell,
-                           double *partials)
+                           double *partials, const int *skip_if)
 {
+  // skip_if: status word of the persistent sub-step kernel of this step -- non-zero = it stepped aside and xi is not this
+  // step's yet: nothing moves, the host issues the sub-steps through the launch chain and this kernel again
+  if (skip_if && *skip_if != 0) return;
   __shared__ double scratch[2 * 16];
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   double s0 = 0, s1 = 0;
@@ -1595,9 +1681,13 @@ static int ttm_check_mailbox(imdgpu_ctx *ctx)
   int flag = 0;
   HIPCHK(hipMemcpyAsync(&flag, ctx->d_counters + CNT_TTM_TIMEOUT, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  if (flag)
+  if (flag) {
+    // reported once: the caller may switch the persistent kernel off (option ttm_persist) or detach the remote records and
+    // go on from a lattice it uploads again -- the flag must not fail every later call of this context
+    (void) hipMemsetAsync(ctx->d_counters + CNT_TTM_TIMEOUT, 0, sizeof(int), ctx->stream);
     return imdgpu_fail(ctx, "TTM lattice: a sub-step hand-off timed out (mailbox: a neighbour rank did not publish its faces; or the "
-                            "persistent sub-step kernel lost residency, IMDGPU_TTM_PERSIST=0 disables it); the lattice of this step is not valid");
+                            "persistent sub-step kernel's hand-offs stalled, option ttm_persist = 0 disables it); the lattice of this step is not valid");
+  }
   return 0;
 }
 
@@ -1606,6 +1696,7 @@ static int ttm_xfer(imdgpu_ctx *ctx, const imdgpu_ttm_fields *f, bool down)
   NEED_TTM();
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (ctx->step_open) HIPCHK(hipStreamSynchronize(ctx->stream2));   // between md_step_begin and _end the lattice chain runs on the side stream
+  if (!ctx->step_open && imdgpu_ttm_persist_settle(ctx) < 0) return 1;
   if (down && ttm_check_mailbox(ctx)) return 1;
   const size_t n = t->ncell;
   auto X = [&](void *host, void *dev, size_t bytes) -> int {
@@ -1739,6 +1830,7 @@ __global__ __launch_bounds__(64) void k_ttm_ufd_combine(Lat L, int steps, const 
 extern "C" int imdgpu_ttm_update_fd(imdgpu_ctx *ctx, int steps)
 {
   NEED_TTM();
+  if (imdgpu_ttm_persist_settle(ctx) < 0) return 1;      // the previous step's persistent launch, if nobody has looked yet (no-op inside imdgpu_md_step)
   ProfScope ps(ctx, PROF_TTM_UPDATE);
   if (t->ext[0] * t->ext[1] * t->ext[2] > 64) {             // FD cells over many MD cells: a workgroup per FD cell
     if (ctx->ttm_flux) return imdgpu_fail(ctx, "update_fd: the flux bookkeeping (ttm_flux / ttm_adv) is not available for FD cells of more than 64 MD cells");
@@ -1781,6 +1873,7 @@ extern "C" int imdgpu_ttm_local_block(imdgpu_ctx *ctx, int steps, double *dev_ou
   const int nb = t->ldim[0] * t->ldim[1] * t->ldim[2];
   if (ncells_block) *ncells_block = nb;
   if (!dev_out) return 0;
+  if (imdgpu_ttm_persist_settle(ctx) < 0) return 1;
   ProfScope ps(ctx, PROF_TTM_UPDATE);
   hipLaunchKernelGGL(k_ttm_update_fd, dim3(nblk((long long) nb * 64, TTM_WG)), dim3(TTM_WG), 0, ctx->stream, L, steps,
                      ctx->cap_local, ctx->cell_start, ctx->cell_cnt, ctx->numneighs, ctx->p, ctx->mass, t->natoms,
@@ -2089,15 +2182,19 @@ extern "C" int imdgpu_ttm_cell_activation(imdgpu_ctx *ctx)
   return 0;
 }
 
-extern "C" int imdgpu_ttm_fillmesh(imdgpu_ctx *ctx, int steps)
+static int ttm_fillmesh(imdgpu_ctx *ctx, TtmState *t, const Lat &L, int steps, int *bbox)
 {
-  NEED_TTM();
   ProfScope ps(ctx, PROF_TTM_FILL);
   hipLaunchKernelGGL(k_ttm_fillmesh, dim3(nblk(t->ninner, TTM_WG)), dim3(TTM_WG), 0, ctx->stream, L, steps, t->cve, t->ee,
                      t->natoms, t->temp[t->cur], t->md_temp, t->dens, t->Z, t->ne, t->Ce, t->fd_k[t->kcur], t->fd_g,
-                     t->U[t->cur], t->U[t->cur ^ 1]);
+                     t->U[t->cur], t->U[t->cur ^ 1], bbox);
   HIPCHK(hipGetLastError());
   return 0;
+}
+extern "C" int imdgpu_ttm_fillmesh(imdgpu_ctx *ctx, int steps)
+{
+  NEED_TTM();
+  return ttm_fillmesh(ctx, t, L, steps, nullptr);
 }
 
 extern "C" int imdgpu_ttm_fill_ghost_layers(imdgpu_ctx *ctx)
@@ -2149,6 +2246,7 @@ extern "C" int imdgpu_ttm_cfl_maxdt(imdgpu_ctx *ctx, int steps, double *out)
 {
   NEED_TTM();
   if (ctx->step_open) HIPCHK(hipStreamSynchronize(ctx->stream2));
+  else if (imdgpu_ttm_persist_settle(ctx) < 0) return 1;
   hipLaunchKernelGGL(k_ttm_cfl, dim3(1), dim3(1024), 0, ctx->stream, L, t->natoms, t->fd_k[t->kcur], t->Ce, t->d_red);
   double mx = 0;
   HIPCHK(hipMemcpyAsync(&mx, t->d_red, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -2162,7 +2260,7 @@ extern "C" int imdgpu_ttm_cfl_maxdt(imdgpu_ctx *ctx, int steps, double *out)
 // One fused sub-step: do_DIFF + do_FILLMESH (own cell, new temperature) in one
 // launch, then the ghost faces.  fd_k is double buffered because the stencil of
 // the same launch still needs the neighbours' old kappa.
-static int launch_substep_fused(imdgpu_ctx *ctx, TtmState *t, const Lat &L, double tau, int steps, int sub = 0, const int *guard = nullptr)
+static int launch_substep_fused(imdgpu_ctx *ctx, TtmState *t, const Lat &L, double tau, int steps, int sub, const int *guard)
 {
   const int flags = (sub == t->nsub - 1 ? 1 : 0) | (t->have_source ? 2 : 0);
   if (t->mb_host) {
@@ -2183,27 +2281,35 @@ static int launch_substep_fused(imdgpu_ctx *ctx, TtmState *t, const Lat &L, doub
   return 0;
 }
 
-// The persistent sub-step kernel, when it applies: one rank's whole lattice (no mailbox), no Maxwell solver, an even
-// number of sub-steps, at most PERSIST_MAX_TILES blocks (all of them must be resident at once).  IMDGPU_TTM_PERSIST=0
-// switches it off.  Trial mode: the captured launch chain follows, each of its kernels guarded by the status word (0 = the
-// persistent kernel did the step), until two launches in a row came through; from then on the chain is dropped and a
-// failed census is an error (CNT_TTM_TIMEOUT), as is a time-out inside the loop at any time.
+// The persistent sub-step kernel, when it applies: no host mailbox, no Maxwell solver, an even number of sub-steps, steps >= 1,
+// and a lattice whose ACTIVE region fits PERSIST_MAX_TILES blocks (all of them must be resident at once; the kernel anchors its
+// blocks on the bounding box of the active cells and decides per launch, on the device).  IMDGPU_TTM_PERSIST=0 switches it off.
+//   trial   (1): the captured launch chain follows, each of its kernels guarded by the status word (0 = the persistent kernel
+//                did the step), until two launches in a row came through;
+//   trusted (2): the chain is dropped.  A launch that steps aside (status 1: census not complete in time because co-tenants
+//                hold compute units, or an active region that has outgrown the launch) has touched nothing: the integrator is
+//                guarded by the same status word, and the host issues that step's sub-steps through the launch chain and the
+//                integrator again (imdgpu_ttm_persist_settle).  Three misses in a row switch the kernel off for the context.
+//   A time-out INSIDE the loop (status 2) is an error at any time (CNT_TTM_TIMEOUT, reported once by the host).
 // option "ttm_persist" (0 / 1; -1 = the default, IMDGPU_TTM_PERSIST or on) and the info words "ttm_persist_mode" (0 off,
-// 1 trial, 2 trusted, -1 not decided yet) / "ttm_persist_runs" (launches that came through)
+// 1 trial, 2 trusted, -1 not decided yet) / "ttm_persist_runs" (launches that came through) / "ttm_persist_redone"
 void imdgpu_ttm_set_persist(imdgpu_ctx *ctx, int value)
 {
   ctx->ttm_persist_opt = value;
-  if (ctx->ttm) { ctx->ttm->persist = value == 0 ? 0 : -1; ctx->ttm->persist_ok = 0; }
+  if (ctx->ttm) {
+    TtmState *t = ctx->ttm;
+    (void) imdgpu_ttm_persist_settle(ctx);
+    t->persist = value == 0 ? 0 : -1; t->persist_ok = 0; t->persist_miss_run = 0;
+    (void) hipMemsetAsync(ctx->d_counters + CNT_TTM_TIMEOUT, 0, sizeof(int), ctx->stream);    // a reported time-out does not outlive the switch
+  }
 }
 long long imdgpu_ttm_persist_info(imdgpu_ctx *ctx, int which)
 {
   TtmState *t = ctx->ttm;
   if (!t) return -1;
-  if (t->persist > 0 && t->pstat_pending && hipEventQuery(t->ev_pstat) == hipSuccess) {
-    t->pstat_pending = 0;
-    if (t->h_pstat[0] == 0) { if (++t->persist_ok >= 2 && t->persist == 1) t->persist = 2; } else t->persist = 0;
-  }
+  if (!ctx->step_open) (void) imdgpu_ttm_persist_settle(ctx);
   if (which == 2) return t->xrec_ready ? (t->xrec_fine ? 2 : 1) : 0;
+  if (which == 3) return t->persist_redone;
   return which == 0 ? t->persist : t->persist_ok;
 }
 
@@ -2213,28 +2319,59 @@ static int persist_mode(imdgpu_ctx *ctx, TtmState *t)
     static const int envv = getenv("IMDGPU_TTM_PERSIST") ? atoi(getenv("IMDGPU_TTM_PERSIST")) : 1;
     const int env = ctx->ttm_persist_opt >= 0 ? ctx->ttm_persist_opt : envv;
     const int nt[3] = {(t->dim[0] - 2 + PT - 1) / PT, (t->dim[1] - 2 + PT - 1) / PT, (t->dim[2] - 2 + PT - 1) / PT};
-    t->persist_tiles = nt[0] * nt[1] * nt[2];
-    bool shape_ok = true;                                 // a one-cell-wide last block would need two out-of-block neighbours per dimension
-    for (int d = 0; d < 3; d++) if ((t->dim[d] - 2) % PT == 1) shape_ok = false;
-    t->persist = (env && shape_ok && t->persist_tiles <= PERSIST_MAX_TILES) ? 1 : 0;
+    const long long full = (long long) nt[0] * nt[1] * nt[2];
+    bool shape_ok = true;                                 // a lattice one layer thin stays on the launch chain (the kernel would step aside every time)
+    for (int d = 0; d < 3; d++) if (t->dim[d] - 2 < 2) shape_ok = false;
+    // the launch brings at most PERSIST_MAX_TILES blocks; a lattice with vacuum may need fewer blocks than it has (the
+    // kernel decides, per launch); one that is four times the limit is not worth the attempts
+    t->persist_tiles = (int) std::min<long long>(full, PERSIST_MAX_TILES);
+    t->persist = (env && shape_ok && full <= 4LL * PERSIST_MAX_TILES) ? 1 : 0;
     if (t->persist && !t->d_pflags) {
-      // census / gate words and the status words in one allocation: one memset per launch instead of two
-      if (dev_alloc(ctx, &t->d_pflags, 16 + 4) || dev_alloc(ctx, &t->d_prec, (size_t) 2 * t->ncell * 4)) return -1;
+      // census / gate words, the status words and the active cells' bounding box in one allocation
+      if (dev_alloc(ctx, &t->d_pflags, 16 + 4 + 8) || dev_alloc(ctx, &t->d_prec, (size_t) 2 * t->ncell * 4)) return -1;
       t->d_pstat = (int *) (t->d_pflags + 16);
+      t->d_pbbox = (int *) (t->d_pflags + 20);
       if (hipMemsetAsync(t->d_prec, 0, (size_t) 2 * t->ncell * 4 * sizeof(unsigned long long), ctx->stream) != hipSuccess) return -1;
       t->persist_base = 1;
       if (hipHostMalloc((void **) &t->h_pstat, 4 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
           hipEventCreateWithFlags(&t->ev_pstat, hipEventDisableTiming) != hipSuccess) { imdgpu_fail(ctx, "persistent TTM kernel: host allocations failed"); return -1; }
-      if (hipMemsetAsync(t->d_pstat, 0, 4 * sizeof(int), ctx->stream) != hipSuccess) return -1;
+      if (hipMemsetAsync(t->d_pstat, 0, (4 + 8) * sizeof(int), ctx->stream) != hipSuccess) return -1;
       t->h_pstat[0] = 0;
     }
   }
-  if (t->persist > 0 && t->pstat_pending && hipEventQuery(t->ev_pstat) == hipSuccess) {   // how the previous launch went
-    t->pstat_pending = 0;
-    if (t->h_pstat[0] == 0) { if (++t->persist_ok >= 2 && t->persist == 1) t->persist = 2; }
-    else t->persist = 0;                                // census failed (co-tenants on the GPU): the launch chain from now on
-  }
   return t->persist;
+}
+
+// How did the last launch of the persistent sub-step kernel go?  Waits for its status word (the launch itself has long
+// ended wherever this is called: after the step's synchronisation, or at the next call that touches the lattice).
+// Returns 0 = nothing to do, 1 = it had stepped aside in trusted mode and the sub-steps of that step have now been issued
+// through the launch chain on ctx->stream (a caller whose integrator was guarded by the status word launches it again),
+// -1 = error.
+int imdgpu_ttm_persist_settle(imdgpu_ctx *ctx)
+{
+  TtmState *t = ctx->ttm;
+  if (!t || !t->pstat_pending) return 0;
+  if (hipSetDevice(ctx->device) != hipSuccess || hipEventSynchronize(t->ev_pstat) != hipSuccess) { imdgpu_fail(ctx, "persistent TTM kernel: waiting for its status failed"); return -1; }
+  t->pstat_pending = 0;
+  const int st = t->h_pstat[0], mode = t->pstat_mode;
+  if (st == 0) { t->persist_miss_run = 0; if (++t->persist_ok >= 2 && t->persist == 1) t->persist = 2; return 0; }
+  if (st != 1 || mode == 3) return 0;                    // a time-out inside the loop, or with other ranks waiting: CNT_TTM_TIMEOUT tells
+  t->persist_ok = 0;
+  if (++t->persist_miss_run >= 3 && t->persist > 0) t->persist = 0;   // co-tenants for good, or a lattice that outgrew the launch: the chain from now on
+  if (mode != 2) return 0;                               // trial: the guarded chain behind the kernel has done the step
+  const Lat L = make_lat(t);
+  const double tau = ctx->timestep / ((double) t->nsub);
+  if (hipMemsetAsync(t->d_pstat, 0, sizeof(int), ctx->stream) != hipSuccess) { imdgpu_fail(ctx, "persistent TTM kernel: re-issue failed"); return -1; }
+  for (int i = 0; i < t->nsub; i++) if (launch_substep_fused(ctx, t, L, tau, 1, i, nullptr)) return -1;
+  if (imdgpu_ttm_fill_ghost_layers(ctx)) return -1;
+  t->persist_redone++;
+  return 1;
+}
+// device word an integrator enqueued behind the lattice chain must look at (see k_move_ttm), or null
+const int *imdgpu_ttm_persist_guard(imdgpu_ctx *ctx)
+{
+  TtmState *t = ctx->ttm;
+  return (t && t->pstat_pending && t->pstat_mode == 2) ? t->d_pstat : nullptr;
 }
 
 // Does the lattice work that is forked beside the EAM force pass need LDS of its own?  The coefficient form of that pass
@@ -2252,7 +2389,7 @@ int imdgpu_ttm_chain_needs_lds(const imdgpu_ctx *ctx)
   return t->persist > 0 ? 0 : 1;
 }
 
-static int launch_persist(imdgpu_ctx *ctx, TtmState *t, const Lat &L, double tau, int mode, bool rem = false)
+static int launch_persist(imdgpu_ctx *ctx, TtmState *t, const Lat &L, double tau, int mode, int steps, bool rem = false)
 {
   PersistDev P;
   P.xrec = rem ? t->d_xrec : nullptr; P.xcells = t->xcells;
@@ -2260,12 +2397,14 @@ static int launch_persist(imdgpu_ctx *ctx, TtmState *t, const Lat &L, double tau
   P.census = t->d_pflags; P.gate = t->d_pflags + 1; P.rec = t->d_prec; P.ncell = t->ncell;
   P.base = t->persist_base; t->persist_base += (unsigned) t->nsub + 1u;
   P.status = t->d_pstat; P.counters = ctx->d_counters;
-  for (int d = 0; d < 3; d++) P.nt[d] = (t->dim[d] - 2 + PT - 1) / PT;
-  P.ntiles = t->persist_tiles; P.trusted = mode == 2;
-  HIPCHK(hipMemsetAsync(t->d_pflags, 0, (16 + 4) * sizeof(unsigned), ctx->stream));     // d_pstat follows d_pflags
+  P.trusted = mode == 2; P.bbox = t->d_pbbox;
+  P.extra_census = (ctx->ttm_persist_miss >= 0 && ctx->ttm_persist_miss == steps) ? 1 : 0;   // test hook: a census that cannot complete
+  HIPCHK(hipMemsetAsync(t->d_pflags, 0, (16 + 4) * sizeof(unsigned), ctx->stream));     // d_pstat follows d_pflags (the bounding box behind it stays)
   double *T0 = t->temp[t->cur], *T1 = t->temp[t->cur ^ 1], *U0 = t->U[t->cur], *U1 = t->U[t->cur ^ 1];
   double *K0 = t->fd_k[t->kcur], *K1 = t->fd_k[t->kcur ^ 1];
   const bool alone = ctx->stream != ctx->stream2;         // not forked beside the force pass: a stand-alone calc_ttm
+  if (rem)                                                // every face cell's atom count to the rank beyond it, active or not
+    hipLaunchKernelGGL(k_ttm_xrec_counts, dim3(nblk(t->xcells, 64)), dim3(64), 0, ctx->stream, L, P, t->natoms);
 #define PERSIST_LAUNCH(S, W, R)                                                                                                  \
   hipLaunchKernelGGL((k_ttm_chain_persist<S, W, R>), dim3(t->persist_tiles), dim3(64), 0, ctx->stream, L, tau, t->nsub, t->natoms, T0, T1, \
                      U0, U1, K0, K1, t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve, P)
@@ -2280,12 +2419,14 @@ static int launch_persist(imdgpu_ctx *ctx, TtmState *t, const Lat &L, double tau
   else if (t->have_source) PERSIST_W(true, false) else PERSIST_W(false, false)
 #undef PERSIST_W
 #undef PERSIST_LAUNCH
+  if (rem)                                                // ttm_fill_ghost_layers after the last sub-step, for the faces with a rank beyond them
+    hipLaunchKernelGGL(k_ttm_xrec_final, dim3(nblk(t->xcells, 64)), dim3(64), 0, ctx->stream, L, P, t->nsub, t->natoms,
+                       (t->nsub & 1) ? T1 : T0, (t->nsub & 1) ? K1 : K0);
   HIPCHK(hipGetLastError());
-  if (!t->pstat_pending) {                               // feedback for persist_mode; never waited for
-    HIPCHK(hipMemcpyAsync(t->h_pstat, t->d_pstat, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipEventRecord(t->ev_pstat, ctx->stream));
-    t->pstat_pending = 1;
-  }
+  // the status of every launch goes to the host; it is looked at after the step's synchronisation (imdgpu_ttm_persist_settle)
+  HIPCHK(hipMemcpyAsync(t->h_pstat, t->d_pstat, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipEventRecord(t->ev_pstat, ctx->stream));
+  t->pstat_pending = 1; t->pstat_mode = rem ? 3 : mode;
   return 0;
 }
 
@@ -2313,16 +2454,24 @@ extern "C" int imdgpu_ttm_lattice_step(imdgpu_ctx *ctx, int steps)
   NEED_TTM();
   const double tau = ctx->timestep / ((double) t->nsub);
   const bool MBX = t->mb_host != nullptr;
-  // decomposed lattice with remote records attached: the persistent kernel does the whole loop, faces included, whenever it
-  // applies (the same decision on every rank: it depends on the lattice shape, the sub-step count and the step number only)
-  const bool can_graph0 = (t->nsub % 2 == 0) && steps >= 1;
-  int rmode = 0;
-  if (ctx->ttm_decomposed && t->xrec_ready && can_graph0 && !(t->fdtd && t->fdtd_on)) { rmode = persist_mode(ctx, t); if (rmode < 0) return 1; }
-  const bool REMK = rmode > 0;
-  if (ctx->ttm_decomposed && !MBX && !REMK) return imdgpu_fail(ctx, "decomposed TTM lattice: imdgpu_ttm_mailbox_attach first (needed whenever the persistent kernel with remote records does not apply: step 0, odd sub-step counts, lattice shapes it does not take)");
+  const bool fdtd = t->fdtd && t->fdtd_on;
+  if (imdgpu_ttm_persist_settle(ctx) < 0) return 1;       // a stand-alone caller's previous launch (no-op inside imdgpu_md_step)
+  // the sub-step loop never returns to the host: nsub even => the ping-pong state after the loop equals the state before
+  // it, so one persistent launch / one captured hipGraph serves every MD step; step 0 re-initialises U: run it un-captured
+  const bool can_graph = (t->nsub % 2 == 0) && steps >= 1;
+  // The persistent kernel does the whole loop whenever it applies: one rank's whole lattice, or this rank's block of a
+  // decomposed lattice with remote records attached (faces included; the same decision on every rank: it depends on the
+  // lattice shape, the sub-step count and the step number only).  Decided BEFORE FILLMESH, which leaves it the bounding box
+  // of the active cells.
+  int pmode = 0;
+  if (can_graph && !fdtd && (ctx->ttm_decomposed ? t->xrec_ready : !MBX)) { pmode = persist_mode(ctx, t); if (pmode < 0) return 1; }
+  const bool REMK = ctx->ttm_decomposed && pmode > 0;
+  if (ctx->ttm_decomposed && !MBX && !REMK) return imdgpu_fail(ctx, "decomposed TTM lattice: imdgpu_ttm_mailbox_attach first (needed whenever the persistent kernel with remote records does not apply: step 0, odd sub-step counts)");
   imdgpu_tl_mark(ctx, "ttm_update_fd");
   if (t->laser_on && imdgpu_ttm_laser_rescale(ctx, &t->laser, steps)) return 1;   // update_fd has just zeroed the source
-  if (imdgpu_ttm_cell_activation(ctx) || imdgpu_ttm_fillmesh(ctx, steps)) return 1;
+  if (imdgpu_ttm_cell_activation(ctx)) return 1;
+  if (pmode > 0) HIPCHK(hipMemsetAsync(t->d_pbbox, 0, 8 * sizeof(int), ctx->stream));
+  if (ttm_fillmesh(ctx, t, L, steps, pmode > 0 ? t->d_pbbox : nullptr)) return 1;
   if (REMK) {
     // nothing: the kernel publishes state 0 of its faces itself
   } else if (MBX) {                // first publication of this MD step: natoms, temp, fd_k of my boundary layers
@@ -2330,7 +2479,7 @@ extern "C" int imdgpu_ttm_lattice_step(imdgpu_ctx *ctx, int steps)
                        t->temp[t->cur], t->fd_k[t->kcur]);
   } else if (imdgpu_ttm_fill_ghost_layers(ctx)) return 1;
   imdgpu_tl_mark(ctx, "ttm_fillmesh");
-  if (t->fdtd && t->fdtd_on) {                               // config 5: the Maxwell solver drives the source inside the loop
+  if (fdtd) {                                                // config 5: the Maxwell solver drives the source inside the loop
     if (fdtd_lattice_loop(ctx, t, L, steps)) return 1;
     imdgpu_tl_mark(ctx, "ttm_diff");
     return 0;
@@ -2338,16 +2487,11 @@ extern "C" int imdgpu_ttm_lattice_step(imdgpu_ctx *ctx, int steps)
   if (book_eabs(ctx, t, L, tau, t->nsub)) return 1;          // one 64-thread workgroup, once per MD step
   {
     ProfScope ps(ctx, PROF_TTM_DIFF);
-    // the sub-step loop never returns to the host: nsub even => the ping-pong state after the loop equals
-    // the state before it, so one captured hipGraph replays every MD step
-    const bool can_graph = (t->nsub % 2 == 0) && steps >= 1;      // step 0 re-initialises U: run it un-captured
     const int gi = t->cur;
-    int pmode = 0;
-    if (REMK) { if (launch_persist(ctx, t, L, tau, 2, true)) return 1; pmode = 2; }     // no trial: a failed census is an error on every rank's lattice
-    else if (can_graph && !MBX) { pmode = persist_mode(ctx, t); if (pmode < 0) return 1; }
-    if (!REMK && pmode > 0 && launch_persist(ctx, t, L, tau, pmode)) return 1;
-    const int *guard = pmode == 1 ? t->d_pstat : nullptr;
-    if (pmode == 2) {
+    if (REMK) { if (launch_persist(ctx, t, L, tau, 2, steps, true)) return 1; }     // no trial: other ranks wait for this one's records
+    else if (pmode > 0 && launch_persist(ctx, t, L, tau, pmode, steps)) return 1;
+    const int *guard = (pmode == 1 && !REMK) ? t->d_pstat : nullptr;
+    if (pmode == 2 || REMK) {
       // trusted: the persistent kernel alone
     } else if (can_graph && t->graph[gi] && t->graph_kcur[gi] == t->kcur && t->graph_tau[gi] == tau && t->graph_src[gi] == t->have_source &&
                t->graph_guard[gi] == guard) {
@@ -2375,11 +2519,11 @@ extern "C" int imdgpu_ttm_lattice_step(imdgpu_ctx *ctx, int steps)
       t->graph_kcur[gi] = k0; t->graph_tau[gi] = tau; t->graph_src[gi] = t->have_source; t->graph_guard[gi] = guard;
       HIPCHK(hipGraphLaunch(t->graph[gi], ctx->stream));
     } else {
-      for (int i = 0; i < t->nsub; i++) launch_substep_fused(ctx, t, L, tau, steps, i);
+      for (int i = 0; i < t->nsub; i++) launch_substep_fused(ctx, t, L, tau, steps, i, nullptr);
     }
   }
   imdgpu_tl_mark(ctx, "ttm_substeps");
-  if (REMK) {                      // ghost faces of other ranks: written by the kernel; faces of periodic images / open faces: here
+  if (REMK) {                      // ghost faces of other ranks: written by k_ttm_xrec_final; faces of periodic images / open faces: here
     int nf = (t->dim[1] - 2) * (t->dim[2] - 2) + (t->dim[2] - 2) * (t->dim[0] - 2) + (t->dim[0] - 2) * (t->dim[1] - 2);
     hipLaunchKernelGGL(k_ttm_ghosts, dim3(nblk(nf, TTM_WG)), dim3(TTM_WG), 0, ctx->stream, L, t->natoms, t->temp[t->cur], t->fd_k[t->kcur], t->xremote);
   } else if (MBX) {                // neighbours' final layers into the ghost cells; next MD step = next block of indices
@@ -2574,7 +2718,7 @@ static int launch_move_ttm(imdgpu_ctx *ctx, double limit2)
   ProfScope ps(ctx, PROF_INTEGRATE);
   hipLaunchKernelGGL(k_move_ttm, dim3(nb), dim3(256), 0, ctx->stream, n, ctx->cap_local, L, imdgpu_make_geo(ctx),
                      ctx->pos, ctx->type, ctx->acell, ctx->p, ctx->f, ctx->mass, ctx->restr_identity ? nullptr : ctx->d_restr, ctx->ntypes, ctx->timestep,
-                     ctx->ref, t->natoms, t->xi, t->vcom, t->ncell, ctx->partials);
+                     ctx->ref, t->natoms, t->xi, t->vcom, t->ncell, ctx->partials, imdgpu_ttm_persist_guard(ctx));
   hipLaunchKernelGGL(k_reduce_move, dim3(1), dim3(1024), 0, ctx->stream, nb, ctx->partials, ctx->d_sums, limit2,
                      ctx->d_counters, 1);
   HIPCHK(hipGetLastError());
@@ -2583,6 +2727,7 @@ static int launch_move_ttm(imdgpu_ctx *ctx, double limit2)
 
 extern "C" int imdgpu_move_atoms_ttm(imdgpu_ctx *ctx, double *ekin)
 {
+  if (imdgpu_ttm_persist_settle(ctx) < 0) return 1;      // a stand-alone calc_ttm's persistent launch that stepped aside: the chain, now
   if (launch_move_ttm(ctx, 1e300)) return 1;
   HIPCHK(hipMemcpyAsync(ctx->h_sums, ctx->d_sums, 16 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));

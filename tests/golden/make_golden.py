@@ -115,6 +115,11 @@ CASES = {
                          pot="eam", nbl=True, cpu="2 2 2", pbc="0 1 1", adv=True,
                          extra="msgbuf_size 3.0\nshiftx_front 9.1125\nshiftx_rear 7.0875\n",
                          ttm=dict(fd_ext="1 1 1", n=100, min_atoms=5), env=dict(IMD_PROBE_ADV="1")),
+    # a slab with vacuum on TWO ranks along x, 3D TTM: 10 x 4 x 4 FD cells, FIVE layers per rank (an extent of 4 q + 1) of which
+    # the outer ones are empty -- what a rank of BASELINE config 4 holds (45 x 39 x 39 FD cells, six layers of vacuum)
+    "ttm_slab_mpi2": dict(binary="imd_mpi_eam_ttm3d_nbl", box="14 8 8", temp=0.03, steps=3, dump=[0, 1, 2, 3], full=[],
+                          pot="eam", nbl=True, cpu="2 1 1", pbc="0 1 1", extra="msgbuf_size 3.0\nshiftx_front 8.0\nshiftx_rear 8.0\n",
+                          ttm=dict(fd_ext="1 1 1", n=100, min_atoms=5)),
     "eam_cellpair_2048": dict(binary="imd_eam_nve", box="8 8 8", temp=0.0258, steps=10, dump=[0, 10], full=[0, 10],
                               pot="eam", nbl=False),
 }
@@ -945,7 +950,7 @@ if __name__ == "__main__":
             run_eos_triangulation_case()
         elif n == "tricub":
             run_tricub_case()
-        elif n.endswith("_mpi8"):
+        elif n.endswith("_mpi8") or n.endswith("_mpi2"):
             run_mpi_case(n, CASES[n])
         else:
             run_case(n, CASES[n])

@@ -57,6 +57,9 @@ def main():
                                  dict(x=G["eos_r"], y=G["eos_t"], z=G["tmm_phase_z"]), tmm_threshold=float(G["tmm_abs_threshold"]))
             if "epress_z" in G:
                 s.ttm1d_set_epress(dict(x=G["eos_r"], y=G["eos_t"], z=G["epress_z"]))
+        miss = os.environ.get("IMD_TEST_PERSIST_MISS", "")         # "<rank>:<step>": that rank's persistent sub-step launch of that step steps aside
+        if miss and int(miss.split(":")[0]) == rank:
+            s.set_option("ttm_persist_miss", int(miss.split(":")[1]))
         ops = GpuOps(s, 0)
         md = DistributedMD(dec, ops, ttm=ttm, local_group=group)
         assert md.native_rebuild
@@ -65,6 +68,7 @@ def main():
         md.calc_forces()
         sums = md.global_sums()
         d = s.download(fields=("ort", "impuls", "kraft", "nummer", "numneighs"))
+        redone = s.get_info("ttm_persist_redone") if ttm else 0
         lat = s.ttm_download(fields=("temp", "xi", "natoms") + (("U", "temp2", "U2", "flux") if adv else ())) if ttm else {}
         if ttm1d:                              # calc_ttm of the step after the last: collective (the slab sums), every rank calls it
             s.ttm1d_calc(nsteps)
@@ -72,7 +76,7 @@ def main():
             lat = {k: L1[k] for k in ("temp", "xi", "natoms", "md_temp", "dens", "U", "source", "natomsglobal", "xiarr_global")}
         info = dict(nrebuild=md.nrebuild, transport=ops.transport, list_mode=s.get_info("list_mode"),
                     persist=s.get_info("ttm_persist_mode") if ttm else -9, remote=s.get_info("ttm_remote") if ttm else -9,
-                    runs=s.get_info("ttm_persist_runs") if ttm else -9)
+                    runs=s.get_info("ttm_persist_runs") if ttm else -9, redone=redone)
         group.barrier()                       # nobody tears its context down while another rank still runs kernels against it
         s.close()
         return dict(d=d, lat=lat, sums=sums, coord=dec.coord, info=info)
@@ -90,6 +94,7 @@ def main():
         out["r%d_persist" % r] = R["info"]["persist"]
         out["r%d_remote" % r] = R["info"]["remote"]
         out["r%d_persist_runs" % r] = R["info"]["runs"]
+        out["r%d_persist_redone" % r] = R["info"]["redone"]
         for k in ("tot_pot_energy", "tot_kin_energy", "virial", "natoms"):
             out["r%d_%s" % (r, k)] = R["sums"][k]
     out["transport"] = np.array(res[0]["info"]["transport"])

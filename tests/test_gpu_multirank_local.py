@@ -21,10 +21,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(case, cpu_dim, nsteps, ttm=False, decomposed=False, adv=False):
+def _run(case, cpu_dim, nsteps, ttm=False, decomposed=False, adv=False, env=None):
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "res.npz")
-        env = dict(os.environ, GPU_MAX_HW_QUEUES="32", PYTHONPATH=ROOT)     # 8 ranks x 2 streams: polling lattice kernels of different ranks must not share a queue
+        env = dict(os.environ, GPU_MAX_HW_QUEUES="32", PYTHONPATH=ROOT, **(env or {}))     # 8 ranks x 2 streams: polling lattice kernels of different ranks must not share a queue
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "local_ranks_worker.py"), case] + [str(v) for v in cpu_dim] +
                            [str(nsteps), str(3 if adv else int(ttm)), str(int(decomposed)), out], env=env, stdout=subprocess.PIPE,
                            stderr=subprocess.STDOUT, text=True, timeout=900)
@@ -142,6 +142,44 @@ def test_2x2x2_ttm_with_advection_against_the_reference_on_8_mpi_ranks(decompose
     if decomposed:        # the faces went through ghost records in the neighbours' device memory, not through the host
         assert all(int(R["r%d_remote" % r]) >= 1 and int(R["r%d_persist" % r]) == 2 for r in range(world)), \
             [(int(R["r%d_remote" % r]), int(R["r%d_persist" % r])) for r in range(world)]
+
+
+def test_slab_on_two_ranks_with_five_layers_each_takes_the_remote_records():
+    """what a rank of BASELINE config 4 holds, at fixture size: a slab with vacuum on 2 x 1 x 1 ranks, FIVE FD layers per rank
+    (an extent of 4 q + 1, the outer layer empty).  The persistent kernel anchors its blocks on the filled layers and hands
+    the face over through ghost records in the neighbour's device memory; lattice of step 2 and atoms of step 3 against the
+    reference's own two-rank run (tests/golden/ttm_slab_mpi2.npz); ttm_fill_ghost_layers imd_ttm_3D.c:3314-3504"""
+    G = gu.load("ttm_slab_mpi2")
+    R, world = _run("ttm_slab_mpi2", (2, 1, 1), 3, ttm=True, decomposed=True)
+    _check_atoms(R, world, G, 3, forces=False)
+    assert all(int(R["r%d_remote" % r]) >= 1 and int(R["r%d_persist" % r]) == 2 and int(R["r%d_persist_runs" % r]) >= 1 for r in range(world)), \
+        [(int(R["r%d_remote" % r]), int(R["r%d_persist" % r]), int(R["r%d_persist_runs" % r])) for r in range(world)]
+    ref = G["t2_substeps_done_temp"]
+    nat = G["t2_substeps_done_natoms"]
+    for r in range(world):
+        lat, latn = R["r%d_lat_temp" % r], R["r%d_lat_natoms" % r]
+        n = lat.shape[0] - 2
+        assert n == 5
+        sl = slice(r * n, r * n + n + 2)                  # my block with its ghost columns in the global lattice (x only is split)
+        act = nat[sl][1:-1, 1:-1, 1:-1] >= 5
+        assert np.array_equal(latn[1:-1, 1:-1, 1:-1], nat[sl][1:-1, 1:-1, 1:-1])
+        assert np.abs(lat[1:-1, 1:-1, 1:-1] - ref[sl][1:-1, 1:-1, 1:-1])[act].max() < 1e-10 * np.abs(ref).max()
+        face = (-1 if r == 0 else 0, slice(1, -1), slice(1, -1))      # the ghost column towards the other rank
+        assert np.array_equal(latn[face], nat[sl][face])
+        assert np.abs(lat[face] - ref[sl][face]).max() < 1e-10 * np.abs(ref).max()
+
+
+def test_a_missed_census_on_one_of_eight_ranks_is_repeated_by_all():
+    """fail soft on several ranks (replicated lattice): rank 3's persistent launch of step 4 steps aside; its status rides in the
+    step's flag all-reduce, that rank issues its sub-steps through the launch chain and integrates again, every rank repeats
+    halo, flags and the pass enqueued ahead -- the atoms of all ranks equal the undisturbed run's, bit for bit"""
+    A, world = _run("ttm_16384_mpi8", (2, 2, 2), 7, ttm=True)
+    B, _ = _run("ttm_16384_mpi8", (2, 2, 2), 7, ttm=True, env=dict(IMD_TEST_PERSIST_MISS="3:4"))
+    assert int(B["r3_persist_redone"]) == 1 and all(int(B["r%d_persist_redone" % r]) == 0 for r in range(world) if r != 3)
+    assert all(int(B["r%d_persist" % r]) == 2 for r in range(world))
+    for r in range(world):
+        for k in ("nummer", "ort", "impuls", "lat_temp", "lat_xi"):
+            assert np.array_equal(A["r%d_%s" % (r, k)], B["r%d_%s" % (r, k)]), (r, k)
 
 
 @pytest.mark.parametrize("cpu_dim", [(1, 1, 2), (2, 2, 2)])
