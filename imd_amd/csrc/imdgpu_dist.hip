@@ -1017,6 +1017,7 @@ extern "C" int imdgpu_ttm_remote_open(imdgpu_ctx *ctx, const void *handle64, voi
 extern "C" int imdgpu_ttm_remote_attach(imdgpu_ctx *ctx, void *const peer[6]);
 extern "C" int imdgpu_ttm_remote_detach(imdgpu_ctx *ctx);
 extern "C" int imdgpu_ttm_remote_ping(imdgpu_ctx *ctx, int phase, unsigned word, int *bad);
+int imdgpu_ttm_remote_is_fine(imdgpu_ctx *ctx);
 // Collective and failure-safe: a rank on which a step fails keeps taking part in the exchanges and every rank returns the
 // same verdict (an error on ALL ranks if it failed on one), so that the host can fall back together -- e.g. to the
 // replicated lattice -- instead of one rank leaving the others inside a collective.
@@ -1026,7 +1027,7 @@ extern "C" int imdgpu_dist_ttm_remote_setup(imdgpu_ctx *ctx)
   PlanState *P = PS(ctx);
   if (!ctx->ttm || !ctx->ttm_decomposed) return imdgpu_fail(ctx, "dist_ttm_remote_setup: needs a decomposed TTM lattice");
   if (plan_static(ctx, D, P)) return 1;
-  const int N = D->nranks, W = 14;                       // per rank: pid, pointer, fine flag, need-coarse flag, 2 x bus id, 8 x handle
+  const int N = D->nranks, W = 15;                       // per rank: pid, pointer, fine flag, failed flag, 2 x bus id, 8 x handle, device ordinal
   std::vector<double> mine(W, 0.0), all((size_t) W * N, 0.0);
   char bus[16] = {0};
   (void) hipDeviceGetPCIBusId(bus, 16, ctx->device);
@@ -1035,7 +1036,7 @@ extern "C" int imdgpu_dist_ttm_remote_setup(imdgpu_ctx *ctx)
   std::string why;
   auto failed = [&](const char *what) { if (!bad) { bad = 1; why = std::string(what) + ": " + ctx->err; } };
   // round 1: who lives where
-  memcpy(&mine[0], &pid, 8); memcpy(&mine[4], bus, 16);
+  memcpy(&mine[0], &pid, 8); memcpy(&mine[4], bus, 16); mine[14] = ctx->device;
   if (dist_allgather_host(ctx, D, mine.data(), W, all.data())) return 1;          // the transport itself: fails everywhere
   bool all_same_gpu = true, other_process = false;
   for (int d = 0; d < 3; d++)
@@ -1059,6 +1060,11 @@ extern "C" int imdgpu_dist_ttm_remote_setup(imdgpu_ctx *ctx)
     if (!all_same_gpu) failed("IPC handle");
     else if (imdgpu_ttm_remote_init(ctx, 1, &ptr, &bytes) || imdgpu_ttm_remote_ipc_handle(ctx, handle, &fine)) failed("IPC handle (coarse)");
   }
+  fine = imdgpu_ttm_remote_is_fine(ctx);
+  // A buffer that another GPU writes into while this GPU's kernel polls it must be FINE-GRAINED (coarse-grained device memory is
+  // coherent at kernel boundaries only: the one-shot ping below would pass and the sub-step kernel's polls could still spin on
+  // stale lines).  Plain memory is accepted only when every rank beyond my faces shares my GPU (one L2 serves all).  
+  if (!bad && !all_same_gpu && !fine) { imdgpu_fail(ctx, "no fine-grained device memory for the ghost records (hipExtMallocWithFlags) and a neighbour rank lives on another GPU"); failed("buffer"); }
   memcpy(&mine[1], &ptr, 8); mine[2] = fine; mine[3] = bad; memcpy(&mine[6], handle, 64);
   if (dist_allgather_host(ctx, D, mine.data(), W, all.data())) return 1;
   for (int r = 0; r < N; r++) if (all[(size_t) W * r + 3] != 0.0 && !bad) { bad = 1; why = "rank " + std::to_string(r) + " could not provide its buffer"; }
@@ -1071,8 +1077,22 @@ extern "C" int imdgpu_dist_ttm_remote_setup(imdgpu_ctx *ctx)
       auto it = opened.find(nb);
       if (it != opened.end()) { peer[q] = it->second; continue; }
       long long p2; void *rp; memcpy(&p2, &all[(size_t) W * nb], 8); memcpy(&rp, &all[(size_t) W * nb + 1], 8);
+      const bool same_gpu = memcmp(&all[(size_t) W * nb + 4], bus, 16) == 0;
+      if (!same_gpu && all[(size_t) W * nb + 2] == 0.0) {   // the gathered flag: that rank's buffer is coarse-grained and I would write it from another GPU
+        imdgpu_fail(ctx, "rank %d's ghost records are not fine-grained memory", nb); failed("neighbour buffer"); break;
+      }
       void *mapped = rp;
-      if (p2 != pid && imdgpu_ttm_remote_open(ctx, &all[(size_t) W * nb + 6], &mapped)) { failed("opening a neighbour's IPC handle"); break; }
+      if (p2 != pid) { if (imdgpu_ttm_remote_open(ctx, &all[(size_t) W * nb + 6], &mapped)) { failed("opening a neighbour's IPC handle"); break; } }
+      else if (!same_gpu) {
+        // a rank of THIS process on another device: its pointer is only usable with peer access (the ping kernel's store
+        // would otherwise fault instead of failing the set-up)
+        const int pdev = (int) all[(size_t) W * nb + 14];
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, ctx->device, pdev) != hipSuccess || !can) { (void) hipGetLastError(); imdgpu_fail(ctx, "device %d cannot access device %d", ctx->device, pdev); failed("peer access"); break; }
+        const hipError_t e = hipDeviceEnablePeerAccess(pdev, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { (void) hipGetLastError(); imdgpu_fail(ctx, "hipDeviceEnablePeerAccess(%d): %s", pdev, hipGetErrorString(e)); failed("peer access"); break; }
+        (void) hipGetLastError();
+      }
       opened[nb] = mapped; peer[q] = mapped;
     }
   if (!bad && imdgpu_ttm_remote_attach(ctx, peer)) failed("attach");

@@ -78,7 +78,7 @@ struct TtmState {
   int persist = -1, persist_ok = 0, persist_tiles = 0, pstat_pending = 0;
   int pstat_mode = 0;                    // mode of the launch whose status is pending: 1 trial, 2 trusted, 3 trusted with remote records
   int persist_miss_run = 0, persist_redone = 0;   // launches in a row that stepped aside; steps re-issued through the launch chain
-  int *d_pbbox = nullptr;                // bounding box of the active cells (k_ttm_fillmesh -> k_ttm_chain_persist), behind d_pflags' words
+  int *d_pbbox = nullptr;                // dim[0] + dim[1] + dim[2] marks of the active cells' extent (k_ttm_fillmesh -> k_ttm_chain_persist)
   unsigned *d_pflags = nullptr;          // census word, gate word
   unsigned long long *d_prec = nullptr;  // hand-off records [2][ncell][4]
   unsigned persist_base = 0;             // tag of state 0 of the next launch
@@ -852,17 +852,18 @@ __device__ __forceinline__ MeshOut mesh_props(const Lat &L, const EosDev &cve, d
   return o;
 }
 
-// bbox (may be null): six ints, zeroed before the launch, that receive the bounding box of the ACTIVE cells for the persistent
-// sub-step kernel, which anchors its blocks there -- [d] = max of (BBOX_BIG - coordinate), [3 + d] = max of the coordinate
-// (inner coordinates 1 ..; all zero = no active cell).  One wave reduction and six atomics per wave.
-#define BBOX_BIG (1 << 20)
+// occ (may be null): dim[0] + dim[1] + dim[2] ints, zeroed before the launch, in which every wave MARKS the lowest and the highest
+// inner coordinate of its active cells per dimension (plain stores of 1 spread over ~130 words: six atomics per wave on six
+// words cost 60 us at config 3's lattice, serialised in L2).  The persistent sub-step kernel reads the bounding box of the active
+// cells off the marks -- first and last marked coordinate per dimension -- and anchors its blocks there.
 __global__ void k_ttm_fillmesh(Lat L, int steps, EosDev cve, EosDev ee, const int *natoms, const double *temp,
                                const double *md_temp, const double *dens, double *Z, double *ne, double *Ce,
-                               double *fd_k, double *fd_g, double *U0, double *U1, int *bbox)
+                               double *fd_k, double *fd_g, double *U0, double *U1, int *occ)
 {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int ni = L.dim[0] - 2, nj = L.dim[1] - 2, nk = L.dim[2] - 2;
-  int v[6] = {0, 0, 0, 0, 0, 0};
+  const int BIG = 1 << 20;
+  int v[6] = {0, 0, 0, 0, 0, 0};            // max of (BIG - coordinate) = the lowest coordinate, max of the coordinate
   if (t < ni * nj * nk) {
     const int i = t / (nk * nj) + 1, j = (t / nk) % nj + 1, k = t % nk + 1;
     const int c = fidx(L, i, j, k);
@@ -870,18 +871,19 @@ __global__ void k_ttm_fillmesh(Lat L, int steps, EosDev cve, EosDev ee, const in
       MeshOut o = mesh_props(L, cve, temp[c], md_temp[c], dens[c]);
       Z[c] = o.Z; ne[c] = o.ne; Ce[c] = o.Ce; fd_k[c] = o.k; fd_g[c] = o.g;
       if (steps < 1) { double u = eos_ee(ee, dens[c], temp[c] * 11604.5) * 26.9815 * C_AMU * C_J2EV; U0[c] = u; U1[c] = u; }
-      v[0] = BBOX_BIG - i; v[1] = BBOX_BIG - j; v[2] = BBOX_BIG - k; v[3] = i; v[4] = j; v[5] = k;
+      v[0] = BIG - i; v[1] = BIG - j; v[2] = BIG - k; v[3] = i; v[4] = j; v[5] = k;
     } else { fd_k[c] = 0.0; fd_g[c] = 0.0; Z[c] = 0.0; ne[c] = 0.0; Ce[c] = 0.0; }
   }
-  if (bbox) {
+  if (occ) {
 #pragma unroll
     for (int q = 0; q < 6; q++) {
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_down(v[q], o, 64); v[q] = w > v[q] ? w : v[q]; }
     }
     if ((threadIdx.x & 63) == 0 && v[3] > 0) {
+      int off = 0;
 #pragma unroll
-      for (int q = 0; q < 6; q++) atomicMax(bbox + q, v[q]);
+      for (int d = 0; d < 3; d++) { occ[off + BIG - v[d]] = 1; occ[off + v[3 + d]] = 1; off += L.dim[d]; }
     }
   }
 }
@@ -1108,7 +1110,10 @@ __global__ __launch_bounds__(DT_X *DT_Y *DT_Z) void k_ttm_diff(
 // touched the lattice (status 1: the guarded launch chain behind this kernel does the step instead).  Spins inside the
 // loop are bounded as well (status 2 + CNT_TTM_TIMEOUT: the lattice of this step is not valid, reported by the host).
 #define PT 4
-#define PERSIST_MAX_TILES 1024
+// Blocks that can be resident at once.  Beside a force pass of eleven waves per CU (three SIMDs with three of its waves, one
+// with two) every SIMD has the registers for one wave of this kernel and the fourth for two: 5 x 256.  (Fewer fit beside a
+// larger force workgroup, more when the kernel runs alone; a launch whose blocks do not all arrive steps aside, see below.)
+#define PERSIST_MAX_TILES 1280
 #define PERSIST_CENSUS_TICKS 20000000ull       // 0.2 s of the 100 MHz s_memrealtime counter
 #define PERSIST_SPIN_TICKS 200000000ull        // 2 s
 struct PersistDev {
@@ -1117,7 +1122,7 @@ struct PersistDev {
   int *status, *counters;
   int trusted, ncell;
   unsigned base;                        // tag of state 0 of this launch
-  const int *bbox;                      // bounding box of the active cells, as k_ttm_fillmesh leaves it (device; this step's)
+  const int *bbox;                      // marks of the active cells' lowest / highest coordinates, as k_ttm_fillmesh leaves them (device; this step's)
   int extra_census;                     // test hook (option ttm_persist_miss): workgroups the census waits for in vain
   // decomposed lattice (REM): the cells beyond a rank boundary live on ANOTHER GPU.  Every rank owns a buffer of ghost
   // records -- per face cell and parity the same four granules as `rec`, then one granule {tag | natoms} per face cell --
@@ -1172,12 +1177,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
   // one layer thin.
   int lo[3], nn[3], nb[3];
   bool aside = false, none = false;
+  {
+    const int *occ = P.bbox;                                                       // the marks k_ttm_fillmesh left, dimension after dimension
 #pragma unroll
-  for (int d = 0; d < 3; d++) {
-    int a = BBOX_BIG - P.bbox[d], b = P.bbox[3 + d];
-    if (b == 0) { a = 1; none = true; }                                            // no active cell at all
-    lo[d] = a; nn[d] = b - a + 1; nb[d] = (nn[d] + PT - 1) / PT;
-    if (nn[d] == 1) aside = true;
+    for (int d = 0; d < 3; d++) {
+      int a = 1 << 20, b = 0;
+      for (int base = 1; base <= L.dim[d] - 2; base += 64) {
+        const int x = base + lane;
+        const unsigned long long mk = __ballot(x <= L.dim[d] - 2 && occ[x] != 0);
+        if (mk) { const int f = base + __ffsll((long long) mk) - 1, l = base + 63 - __clzll((long long) mk); a = f < a ? f : a; b = l > b ? l : b; }
+      }
+      occ += L.dim[d];
+      if (b == 0) { a = 1; none = true; }                                          // no active cell at all
+      lo[d] = a; nn[d] = b - a + 1; nb[d] = (nn[d] + PT - 1) / PT;
+      if (nn[d] == 1) aside = true;
+    }
   }
   if (none) return;                                                                // nothing active, nothing to do: status stays 0
   const int ntiles = nb[0] * nb[1] * nb[2];
@@ -1588,6 +1602,7 @@ void imdgpu_ttm_free(imdgpu_ctx *ctx)
   if (t->d_gbase) (void) hipFree(t->d_gbase);
   if (t->d_facecnt) (void) hipFree(t->d_facecnt);
   if (t->d_pflags) (void) hipFree(t->d_pflags);
+  if (t->d_pbbox) (void) hipFree(t->d_pbbox);
   if (t->d_ufd_part) (void) hipFree(t->d_ufd_part);
   if (t->d_prec) (void) hipFree(t->d_prec);
   if (t->d_xrec) (void) hipFree(t->d_xrec);
@@ -2328,14 +2343,14 @@ static int persist_mode(imdgpu_ctx *ctx, TtmState *t)
     t->persist = (env && shape_ok && full <= 4LL * PERSIST_MAX_TILES) ? 1 : 0;
     if (t->persist && !t->d_pflags) {
       // census / gate words, the status words and the active cells' bounding box in one allocation
-      if (dev_alloc(ctx, &t->d_pflags, 16 + 4 + 8) || dev_alloc(ctx, &t->d_prec, (size_t) 2 * t->ncell * 4)) return -1;
+      if (dev_alloc(ctx, &t->d_pflags, 16 + 4) || dev_alloc(ctx, &t->d_prec, (size_t) 2 * t->ncell * 4) ||
+          dev_alloc(ctx, &t->d_pbbox, (size_t) t->dim[0] + t->dim[1] + t->dim[2])) return -1;
       t->d_pstat = (int *) (t->d_pflags + 16);
-      t->d_pbbox = (int *) (t->d_pflags + 20);
       if (hipMemsetAsync(t->d_prec, 0, (size_t) 2 * t->ncell * 4 * sizeof(unsigned long long), ctx->stream) != hipSuccess) return -1;
       t->persist_base = 1;
       if (hipHostMalloc((void **) &t->h_pstat, 4 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
           hipEventCreateWithFlags(&t->ev_pstat, hipEventDisableTiming) != hipSuccess) { imdgpu_fail(ctx, "persistent TTM kernel: host allocations failed"); return -1; }
-      if (hipMemsetAsync(t->d_pstat, 0, (4 + 8) * sizeof(int), ctx->stream) != hipSuccess) return -1;
+      if (hipMemsetAsync(t->d_pstat, 0, 4 * sizeof(int), ctx->stream) != hipSuccess) return -1;
       t->h_pstat[0] = 0;
     }
   }
@@ -2399,7 +2414,7 @@ static int launch_persist(imdgpu_ctx *ctx, TtmState *t, const Lat &L, double tau
   P.status = t->d_pstat; P.counters = ctx->d_counters;
   P.trusted = mode == 2; P.bbox = t->d_pbbox;
   P.extra_census = (ctx->ttm_persist_miss >= 0 && ctx->ttm_persist_miss == steps) ? 1 : 0;   // test hook: a census that cannot complete
-  HIPCHK(hipMemsetAsync(t->d_pflags, 0, (16 + 4) * sizeof(unsigned), ctx->stream));     // d_pstat follows d_pflags (the bounding box behind it stays)
+  HIPCHK(hipMemsetAsync(t->d_pflags, 0, (16 + 4) * sizeof(unsigned), ctx->stream));     // d_pstat follows d_pflags
   double *T0 = t->temp[t->cur], *T1 = t->temp[t->cur ^ 1], *U0 = t->U[t->cur], *U1 = t->U[t->cur ^ 1];
   double *K0 = t->fd_k[t->kcur], *K1 = t->fd_k[t->kcur ^ 1];
   const bool alone = ctx->stream != ctx->stream2;         // not forked beside the force pass: a stand-alone calc_ttm
@@ -2470,7 +2485,7 @@ extern "C" int imdgpu_ttm_lattice_step(imdgpu_ctx *ctx, int steps)
   imdgpu_tl_mark(ctx, "ttm_update_fd");
   if (t->laser_on && imdgpu_ttm_laser_rescale(ctx, &t->laser, steps)) return 1;   // update_fd has just zeroed the source
   if (imdgpu_ttm_cell_activation(ctx)) return 1;
-  if (pmode > 0) HIPCHK(hipMemsetAsync(t->d_pbbox, 0, 8 * sizeof(int), ctx->stream));
+  if (pmode > 0) HIPCHK(hipMemsetAsync(t->d_pbbox, 0, ((size_t) t->dim[0] + t->dim[1] + t->dim[2]) * sizeof(int), ctx->stream));
   if (ttm_fillmesh(ctx, t, L, steps, pmode > 0 ? t->d_pbbox : nullptr)) return 1;
   if (REMK) {
     // nothing: the kernel publishes state 0 of its faces itself
@@ -2572,6 +2587,7 @@ extern "C" int imdgpu_ttm_remote_init(imdgpu_ctx *ctx, int coarse, void **dev_pt
   if (bytes) *bytes = t->xrec_bytes;
   return 0;
 }
+int imdgpu_ttm_remote_is_fine(imdgpu_ctx *ctx) { return (ctx->ttm && ctx->ttm->d_xrec && ctx->ttm->xrec_fine) ? 1 : 0; }
 // the 64-byte IPC handle of my buffer for ranks in OTHER processes (hipIpcMemHandle_t); *fine = 1: fine-grained memory
 extern "C" int imdgpu_ttm_remote_ipc_handle(imdgpu_ctx *ctx, void *handle64, int *fine)
 {

@@ -303,6 +303,7 @@ static void gather_ghosts(int with_dF)
  * Atoms change cells on the device only; a sync rebuilds the host cells from the device's arrangement (alloc_cell as
  * needed).  Host-side edits of atoms between syncs are not seen by the device. */
 static int g_level2 = -1, g_dev_atoms = 0;
+static long g_moves = 0, g_synced_moves = -1;    /* integrator calls on the device / the one after which the host cells were last refreshed */
 static void (*g_host_move_atoms)(void) = NULL;
 #ifdef TTM
 static int g_ttm_ready, g_fdn;                    /* defined with the TTM part below */
@@ -314,6 +315,14 @@ static int l2_on(void)
     const char *e = getenv("IMD_SHIM_LEVEL");
     g_level2 = (e && atoi(e) == 2) ? 1 : 0;
     if (g_level2 && cpu_dim.x * cpu_dim.y * cpu_dim.z != 1) error("imd_shim: IMD_SHIM_LEVEL=2 serves one rank (several ranks: level 1, or the library's own multi-rank loop imdgpu_dist_step)");
+#ifndef IMD_SHIM_WRAP_WRITERS
+    /* Without the writer wrappers (below) the host cells are refreshed on checkpt_int / eng_int / ttm_int / force_int steps and at
+     * steps_max only: a run that ends on maxwalltime or a stop file, a `write` file, or any of the other periodic writers would
+     * put the atoms of the LAST refresh into its file (imd_main_3d.c:715-722,838-860,1964-2007) -- refused rather than wrong */
+    if (g_level2 && (maxwalltime > 0 || stop_int > 0 || watch_int > 0 || dist_int > 0 || pic_int > 0))
+      error("imd_shim: IMD_SHIM_LEVEL=2 with maxwalltime / stop_int / watch_int / dist_int / pic_int needs the shim built with "
+            "-DIMD_SHIM_WRAP_WRITERS and linked with -Wl,--wrap=write_config,--wrap=write_config_select,--wrap=write_distrib,--wrap=write_pictures (INTEGRATION.md)");
+#endif
   }
   return g_level2;
 }
@@ -366,6 +375,7 @@ static void l2_sync_down(void)
   }
   gpu_check(imdgpu_get_sums(G, sums, &ek, &nc));
   nbl_count = nc;
+  g_synced_moves = g_moves;
   /* the list globals tl/tb/cl_off (globals.h:184-188) of the arrangement just handed over, for modules that read them */
   {
     int ntb = 0;
@@ -383,6 +393,7 @@ static void l2_move_atoms(void)
 {
   long long valid = 1;
   gpu_check(imdgpu_md_step_end(G, steps));
+  g_moves++;
   gpu_check(imdgpu_get_info(G, "have_valid_nbl", &valid));
   have_valid_nbl = (int) valid;
   if ((eng_int > 0 && 0 == steps % eng_int) || steps == steps_max) {
@@ -436,6 +447,31 @@ static void l2_calc_forces(int steps_)
 #endif
      ) l2_sync_down();
 }
+
+#ifdef IMD_SHIM_WRAP_WRITERS
+/* Level 2: EVERY writer of the reference that walks the host cells first gets the device's atoms (and, with the TTM, its
+ * lattice) -- whatever decides that it runs: checkpt_int, the last step, a `write` file (check_write, imd_main_3d.c:838-843),
+ * a stop file or maxwalltime (check_stop / check_walltime call write_config(-1, steps), :1964-2007), dist_int, pic_int, the
+ * *_int of write_config_select's callers.  Link with -Wl,--wrap=write_config,--wrap=write_config_select,--wrap=write_distrib,
+ * --wrap=write_pictures; nothing is copied when the cells are already those of the last integrator call.   */
+static void l2_fresh(void)
+{
+  if (g_level2 != 1 || !g_dev_atoms || g_synced_moves == g_moves) return;
+  l2_sync_down();
+#ifdef TTM
+  if (g_ttm_ready) lattice_to_host();
+#endif
+}
+void __real_write_config(int fzhlr, int steps_);
+void __wrap_write_config(int fzhlr, int steps_) { l2_fresh(); __real_write_config(fzhlr, steps_); }
+void __real_write_config_select(int fzhlr, char *suffix, void (*write_atoms_fun)(FILE *), void (*write_header_fun)(FILE *));
+void __wrap_write_config_select(int fzhlr, char *suffix, void (*write_atoms_fun)(FILE *), void (*write_header_fun)(FILE *))
+{ l2_fresh(); __real_write_config_select(fzhlr, suffix, write_atoms_fun, write_header_fun); }
+void __real_write_distrib(int steps_);
+void __wrap_write_distrib(int steps_) { l2_fresh(); __real_write_distrib(steps_); }
+void __real_write_pictures(int steps_);
+void __wrap_write_pictures(int steps_) { l2_fresh(); __real_write_pictures(steps_); }
+#endif
 #endif /* NBL: level 2 */
 
 #ifdef NBL

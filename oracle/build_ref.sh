@@ -166,9 +166,11 @@ build_dropin() {
     objs="$objs $o"
   done
   wait
-  $CC $BASEFLAGS $defs -fopenmp -I"$repo/include" -c "$repo/imd_amd/host/imd_shim.c" -o "$obj/imd_shim.o"
+  $CC $BASEFLAGS $defs -DIMD_SHIM_WRAP_WRITERS -fopenmp -I"$repo/include" -c "$repo/imd_amd/host/imd_shim.c" -o "$obj/imd_shim.o"
   $CC $BASEFLAGS $defs -c "$HERE/ref_probe.c" -o "$obj/ref_probe.o"
+  # --wrap=write_config...: level 2 hands the device's atoms to every writer of the reference (imd_shim.c: IMD_SHIM_WRAP_WRITERS)
   $CC -o "$OUT/imd_$name" $objs "$obj/imd_shim.o" "$obj/ref_probe.o" -Wl,--wrap=calc_forces \
+      -Wl,--wrap=write_config -Wl,--wrap=write_config_select -Wl,--wrap=write_distrib -Wl,--wrap=write_pictures \
       "$REF/nn_interpol/libnn.a" -L"$repo/imd_amd/csrc" -limdgpu -Wl,-rpath,/root/repo/imd_amd/csrc -fopenmp -lm
   echo "built $OUT/imd_$name"
 }

@@ -62,7 +62,7 @@ def test_bench_spawns_its_ranks_and_refuses_a_mismatch():
     # several ranks: both lattice modes are tried before the warm-up and the faster one that works everywhere runs the benchmark
     lt = d["lattice_trial"]
     assert lt["decomposed"]["ok"] and lt["replicated"]["ok"] and lt["chosen"] in ("decomposed", "replicated")
-    assert lt["decomposed"]["faces"] == "ghost records in the neighbours' device memory"
+    assert lt["decomposed"]["faces"].startswith("ghost records in the neighbours' device memory")
     assert ("TTM lattice " + lt["chosen"]) in d["config"]["parallelism"]
     # one rank cannot set its ghost-record buffer up: EVERY rank learns it and the decomposed lattice stays on the host mailbox
     d2 = _one_json_line(subprocess.run(cmd + ["--ttm-lattice", "decomposed"], cwd=ROOT, env=dict(env, IMDGPU_TTM_REMOTE_FAIL="2"),

@@ -289,6 +289,37 @@ def test_level2_reference_main_loop_with_the_atoms_on_the_device():
     assert np.allclose(A[:, 3:6], B[:, 3:6], rtol=0, atol=2e-6)
 
 
+@pytest.mark.skipif(not (os.path.exists(CPU) and os.path.exists(GPU)), reason="oracle/_ref binaries not built")
+def test_level2_a_stop_file_writes_the_atoms_the_device_holds():
+    """the reference's main loop also writes atoms outside the periodic steps -- check_stop / check_walltime call
+    write_config(-1, steps) and end the run (imd_main_3d.c:1964-2007), check_write answers a `write` file (:838-843).  At level 2
+    the host cells are stale between refreshes; the shim's writer wrappers (IMD_SHIM_WRAP_WRITERS, ld --wrap=write_config ...)
+    hand every writer the device's atoms first.  A run that finds a stop file after its first step: the file it leaves equals
+    the CPU binary's -- atoms AFTER that step's integrator, not the ones uploaded."""
+    out = {}
+    for tag, exe, extra in (("cpu", CPU, {}), ("gpu", GPU, dict(IMD_SHIM_LEVEL="2"))):
+        with tempfile.TemporaryDirectory() as d:
+            potential.write_synthetic_eam_files(d)
+            open(os.path.join(d, "t.param"), "w").write(PARAM + "stop_int 1\n")
+            open(os.path.join(d, "stop"), "w").write("")
+            env = dict(os.environ, IMD_PROBE_DIR=d, IMD_PROBE_STEPS="99", **extra)      # the probe stays out of this run
+            r = subprocess.run([exe, "-p", "t.param"], cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+            assert r.returncode == 0 and "Stop file found after 0 steps" in r.stdout, r.stdout[-2000:]
+            out[tag] = open(os.path.join(d, "out-final.chkpt")).read().splitlines()
+
+    def atoms(lines):
+        rows = np.array([[float(v) for v in l.split()] for l in lines if l and not l.startswith("#")])
+        return rows[np.argsort(rows[:, 0])]
+    A, B = atoms(out["gpu"]), atoms(out["cpu"])
+    assert A.shape == B.shape and np.array_equal(A[:, 0], B[:, 0])
+    assert np.allclose(A[:, 3:6], B[:, 3:6], rtol=0, atol=2e-6)
+    # ... and those are not the uploaded positions: the first step moved the atoms by far more than the file's precision
+    from imd_amd import lattice
+    p0 = lattice.fcc_positions((10, 10, 10))
+    moved = np.abs((A[:, 3:6] / (4.05 / 2) - 0.5) - np.round(A[:, 3:6] / (4.05 / 2) - 0.5)).max() * (4.05 / 2)
+    assert moved > 1e-3 and len(p0) == len(A)
+
+
 @pytest.mark.skipif(not (os.path.exists(CPU_TTM) and os.path.exists(GPU_TTM)), reason="oracle/_ref binaries not built")
 def test_level2_reference_ttm_main_loop_with_atoms_and_lattice_on_the_device():
     """The 3D-TTM program at level 2: calc_forces forks calc_ttm beside the force passes on the device, move_atoms_ttm runs

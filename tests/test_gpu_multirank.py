@@ -18,22 +18,24 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, case, cpu_dim, nsteps, ttm, q, decomposed=False, adv=False):
+def _worker(rank, world, port, case, cpu_dim, nsteps, ttm, q, decomposed=False, adv=False, backend="gloo"):
     try:
-        _worker_body(rank, world, port, case, cpu_dim, nsteps, ttm, q, decomposed, adv)
+        _worker_body(rank, world, port, case, cpu_dim, nsteps, ttm, q, decomposed, adv, backend)
     except BaseException:
         import traceback
         q.put((rank, "ERROR", traceback.format_exc(), 0, None))
 
 
-def _worker_body(rank, world, port, case, cpu_dim, nsteps, ttm, q, decomposed=False, adv=False):
+def _worker_body(rank, world, port, case, cpu_dim, nsteps, ttm, q, decomposed=False, adv=False, backend="gloo"):
+    """backend gloo: all ranks on cuda:0, host-staged transport; nccl: rank r on cuda:r, the library's RCCL transport"""
     import torch
     import torch.distributed as dist
     from imd_amd.parallel import Decomposition, DistributedMD, GpuOps
     from imd_amd.system import GpuSystem
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
+    dev = rank if backend == "nccl" else 0
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     G = gu.load(case)
     dec = Decomposition(rank, cpu_dim, G["global_cell_dim"], G["box"], G["pbc_dirs"])
     pos, mom, mass, ident = G["s0_ort"], G["s0_impuls"], G["s0_masse"], G["s0_nummer"]
@@ -42,7 +44,8 @@ def _worker_body(rank, world, port, case, cpu_dim, nsteps, ttm, q, decomposed=Fa
     mine = np.all(c // (np.array(dec.dim) - 2) == np.array(dec.coord), axis=1)
     ntypes = int(G["ntypes"])
     s = GpuSystem(G["box"], G["pbc_dirs"], dec.dim, ntypes, float(G["cellsz"]), float(G["nbl_margin"]), float(G["timestep"]),
-                  device=0, global_cell_dim=dec.gdim, cpu_dim=cpu_dim, my_coord=dec.coord, ttm_decomposed=decomposed)
+                  device=dev, global_cell_dim=dec.gdim, cpu_dim=cpu_dim, my_coord=dec.coord, ttm_decomposed=decomposed,
+                  external_halo=(world == 1))
     s.upload_tables(gu.table(G, "pair_pot"), gu.table(G, "rho_h_tab"), gu.table(G, "embed_pot"))
     if adv:
         s.set_option("ttm_adv", 1)
@@ -51,8 +54,10 @@ def _worker_body(rank, world, port, case, cpu_dim, nsteps, ttm, q, decomposed=Fa
                    float(G["ttm_atomic_charge"]), dict(x=G["eos_r"], y=G["eos_t"], z=G["eos_cve"]),
                    dict(x=G["eos_r"], y=G["eos_ts"], z=G["eos_ee"]), float(G["ttm_omega_laser"]))
     s.upload_atoms(pos[mine], mom[mine], mass[mine], G["s0_sorte"][mine].astype(np.int32) if ntypes > 1 else None, ident[mine])
-    ops = GpuOps(s, 0)
+    ops = GpuOps(s, dev)
     md = DistributedMD(dec, ops, ttm=ttm)
+    if backend == "nccl":
+        assert ops.transport == "rccl", ops.transport
     for st in range(nsteps):
         md.md_step(st)
     md.calc_forces()
@@ -60,23 +65,23 @@ def _worker_body(rank, world, port, case, cpu_dim, nsteps, ttm, q, decomposed=Fa
     d = s.download(fields=("ort", "impuls", "kraft", "nummer", "numneighs"))
     lat = s.ttm_download(fields=("temp", "xi", "natoms", "U", "temp2", "U2", "flux")) if ttm else None
     info = (s.get_info("ttm_remote"), s.get_info("ttm_persist_mode"), s.get_info("ttm_persist_runs")) if ttm else (0, 0, 0)
-    q.put((rank, d, sums, md.nrebuild, lat, tuple(dec.coord), info))
+    q.put((rank, d, sums, md.nrebuild, lat, tuple(dec.coord), info, ops.transport))
     s.close()
     dist.destroy_process_group()
 
 
-def _run(case, cpu_dim, nsteps, ttm, decomposed=False, adv=False):
+def _run(case, cpu_dim, nsteps, ttm, decomposed=False, adv=False, backend="gloo"):
     world = int(np.prod(cpu_dim))
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, case, cpu_dim, nsteps, ttm, q, decomposed, adv)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, cpu_dim, nsteps, ttm, q, decomposed, adv, backend)) for r in range(world)]
     for p in procs:
         p.start()
     res = []
     try:
         for _ in range(world):
-            r = q.get(timeout=150)
+            r = q.get(timeout=300)
             assert r[1] != "ERROR", "rank %d failed:\n%s" % (r[0], r[2])
             res.append(r)
     finally:
@@ -261,7 +266,7 @@ def test_two_ranks_one_in_vacuum():
     res = []
     try:
         for _ in range(2):
-            r = q.get(timeout=150)
+            r = q.get(timeout=300)
             assert r[1] != "ERROR", "rank %d failed:\n%s" % (r[0], r[2])
             res.append(r)
     finally:
