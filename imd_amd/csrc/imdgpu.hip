@@ -554,7 +554,7 @@ __global__ __launch_bounds__(512) void k_pass3_gt(ForceArgs a)
 // neighbour list holds 16-bit LDS slot numbers (4 per 8-byte load, ELL-transposed
 // per tile).  HBM sees: list (2 B/entry), own-atom outputs, one staging pass.
 // ===========================================================================
-#define IMDGPU_KERNEL_REV 7
+#define IMDGPU_KERNEL_REV 8
 #define LDS_LIMIT (160 * 1024)
 #define TABLE_LDS_LIMIT (150 * 1024)                 // global-gather kernels: tables beyond this stay in global memory
 #define NH_MAX 512                                   // halo cells per tile (<= 6*6*6 = 216 for tiles up to 4^3)
@@ -582,6 +582,7 @@ struct TileArgs {
   int *counters;
   double cellsz;
   const int *guard;               // pass 1 launched ahead of the host's look at the list-validity flag: *guard != 0 -> return at once
+  float nbl_eps;                  // k_nbl_build_tile32: |r2 - cellsz| below which the single-precision test is not trusted (host: make_tile_args)
   int balance;                    // block ranges cut by cost (boxes with vacuum, moving surfaces) instead of by tiles
   const long long *wprefix;       // [ntiles + 1] cost prefix (k_tile_wprefix), read when balance is set
 };
@@ -943,6 +944,162 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile(TileArgs a)
     a.ownw[(size_t) T.tile * a.tile_cap + o] = (unsigned) slot | ((unsigned) (m < 4 * a.W4 ? m : 4 * a.W4) << 16);
     mmax = m > mmax ? m : mmax;
   }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { int v = __shfl_down(mmax, o, 64); mmax = v > mmax ? v : mmax; }
+  if ((threadIdx.x & 63) == 0 && mmax > 0) atomicMax(&a.counters[CNT_MAXNBR], mmax);
+}
+
+// The list build again, with the distance tests in SINGLE precision and an exact stand-in where that could matter
+// (kernel_rev 8; VERDICT r3 item 8: the build issued 2.1e9 VALU wave-instructions per rebuild, four times pass 1).
+// The membership test is the reference's `r2 < cellsz` on its unfused double-precision r2 (imd_forces_nbl.c:218-224), and the
+// list must come out bit for bit.  Almost every candidate is far from the threshold: positions are staged as FLOATS
+// relative to the tile's first staged atom (|coordinate| < 64 A: error <= 2^-24 * 64 per coordinate, <= 2e-4 in r2 at the list
+// radius), four consecutive candidates come with three ds_read_b128, the squared distances with packed fp32 arithmetic (two
+// candidates per instruction), and the accepted ones are shifted into the lane's bit mask through the SIGN of r2 - cellsz (one
+// v_alignbit per candidate).  A chunk of 32 candidates in which ANY lane of the wave saw |r2 - cellsz| < eps (a rigorous bound of
+// the single-precision error from the tile's extent, ~5e-4: one chunk in ~100) is done again by the whole wave with the reference's expression on the double-precision positions (global
+// memory, through the staging plan this workgroup has just written) -- the decision is then the reference's, exactly.
+// Same candidate order as k_nbl_build_tile (neighbour cells in the order of cnbrs[c].nq[], j ascending), same outputs.
+typedef float nbl_f2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(1024) void k_nbl_build_tile32(TileArgs a)
+{
+  extern __shared__ double lds[];
+  float *fx = (float *) lds, *fy = fx + SLOTCAP(a), *fz = fy + SLOTCAP(a);
+  int *hstart = (int *) (fz + SLOTCAP(a)), *hsrc = hstart + NH_MAX + 1;
+  TileCtx T;
+  int t0, t1;
+  block_tile_range(a.ntiles, a.wprefix, a.balance, t0, t1);
+  const unsigned short dummy = (unsigned short) ((SLOTCAP(a) - 1) * NBR_SCALE);
+  const float cth = (float) a.cellsz;
+  int mmax = 0;
+  for (T.tile = t0; T.tile < t1; T.tile++) {
+    __syncthreads();
+    // ---- halo-cell table and prefix (as tile_stage) ----
+    const Geo &g = a.g;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    {
+      const int tz = T.tile % g.ntz, q = T.tile / g.ntz, ty = q % g.nty, tx = q / g.nty;
+      T.hx = g.bx + 2; T.hy = g.by + 2; T.hz = g.bz + 2; T.nh = T.hx * T.hy * T.hz;
+      for (int h = tid; h < T.nh; h += nthr) {
+        int c = h % T.hz, r = h / T.hz, b = r % T.hy, aa = r / T.hy;
+        int fxc = tx * g.bx + aa, fyc = ty * g.by + b, fzc = tz * g.bz + c;
+        int cnt = 0, src = 0;
+        if (fxc < g.dim[0] && fyc < g.dim[1] && fzc < g.dim[2]) {
+          int lin = (fxc * g.dim[1] + fyc) * g.dim[2] + fzc;
+          cnt = a.cell_cnt[lin]; src = a.cell_start[lin];
+        }
+        hstart[h + 1] = cnt; hsrc[h] = src;
+      }
+      __syncthreads();
+      if (tid < 64) {
+        int carry = 0;
+        for (int base = 0; base < T.nh; base += 64) {
+          int idx = base + tid, v = idx < T.nh ? hstart[idx + 1] : 0;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(v, o, 64); if (tid >= o) v += t; }
+          if (idx < T.nh) hstart[idx + 1] = v + carry;
+          carry += __shfl(v, 63, 64);
+        }
+        if (tid == 0) hstart[0] = 0;
+      }
+      __syncthreads();
+    }
+    T.own_start = a.istart[T.tile * g.CPT];
+    T.nown = a.istart[(T.tile + 1) * g.CPT] - T.own_start;
+    const int tot = hstart[T.nh] < SLOTCAP(a) - 1 ? hstart[T.nh] : SLOTCAP(a) - 1;
+    // origin: the tile's first own atom (any point inside the staged region does)
+    const double4 org = a.pos[T.nown > 0 ? T.own_start : 0];
+    int *src = a.tsrc + (size_t) T.tile * SLOTCAP(a);
+    {   // positions as floats relative to the origin; the staging plan of the force passes
+      const int hw = tid >> 5, l = tid & 31, nhw = nthr >> 5;
+      for (int h = hw; h < T.nh; h += nhw) {
+        const int s0 = hstart[h], n = hstart[h + 1] - s0, g0 = hsrc[h];
+        for (int e = l; e < n; e += 32)
+          if (s0 + e < SLOTCAP(a) - 1) {
+            const double4 q = a.pos[g0 + e];
+            fx[s0 + e] = (float) (q.x - org.x); fy[s0 + e] = (float) (q.y - org.y); fz[s0 + e] = (float) (q.z - org.z);
+            src[s0 + e] = g0 + e;
+          }
+      }
+      for (int s = tot + tid; s < ((tot + 3) & ~3) + 4 && s < SLOTCAP(a); s += nthr) { fx[s] = 1e30f; fy[s] = 1e30f; fz[s] = 1e30f; }   // what an aligned group may read behind the last atom
+      if (tid == 0) a.tinfo[T.tile] = make_int4(tot, T.own_start, T.nown, 0);
+    }
+    __syncthreads();                                   // planes and plan complete (the plan is read back by the exact stand-in)
+    for (int o = tid; o < T.nown; o += nthr) {
+      const int i = T.own_start + o;
+      int lx, ly, lz;
+      const int slot = own_slot(a, T, i, hstart, hsrc, lx, ly, lz);
+      const double4 pi = a.pos[i];
+      a.ref[i] = pi.x; a.ref[a.cap + i] = pi.y; a.ref[2 * (size_t) a.cap + i] = pi.z;
+      const float xi = fx[slot], yi = fy[slot], zi = fz[slot];
+      const nbl_f2 xi2 = {xi, xi}, yi2 = {yi, yi}, zi2 = {zi, zi}, cth2 = {cth, cth};
+      unsigned long long *lp = (unsigned long long *) (a.nbr16 + (size_t) T.tile * a.W4 * a.tile_cap + o);
+      const unsigned long long dummy64 = (unsigned long long) dummy * 0x0001000100010001ull;
+      unsigned long long w = dummy64;
+      int m = 0;
+      for (int dx = 0; dx <= ((a.dbg & 4) ? -1 : 2); dx++)
+        for (int dy = 0; dy <= 2; dy++)
+          for (int dz = 0; dz <= 2; dz++) {
+            const int h = ((lx + dx) * T.hy + (ly + dy)) * T.hz + (lz + dz);
+            const int s = hstart[h], e = hstart[h + 1];
+            for (int j0 = s & ~3; j0 < e; j0 += 32) {
+              // bit 31 - u of `mask` = candidate j0 + u (shifted in through the sign of r2 - cellsz, first candidate highest)
+              unsigned mask = 0;
+              float near = 1e30f;
+              const int ngrp = (e - j0 + 3) >> 2 < 8 ? (e - j0 + 3) >> 2 : 8;
+              for (int q = 0; q < ngrp; q++) {
+                const float4 X = *(const float4 *) (fx + j0 + 4 * q), Y = *(const float4 *) (fy + j0 + 4 * q), Z = *(const float4 *) (fz + j0 + 4 * q);
+                nbl_f2 ax = {X.x, X.y}, bx = {X.z, X.w}, ay = {Y.x, Y.y}, by = {Y.z, Y.w}, az = {Z.x, Z.y}, bz = {Z.z, Z.w};
+                ax -= xi2; bx -= xi2; ay -= yi2; by -= yi2; az -= zi2; bz -= zi2;
+                nbl_f2 ra = ax * ax, rb = bx * bx;
+                ra = __builtin_elementwise_fma(ay, ay, ra); rb = __builtin_elementwise_fma(by, by, rb);
+                ra = __builtin_elementwise_fma(az, az, ra); rb = __builtin_elementwise_fma(bz, bz, rb);
+                ra -= cth2; rb -= cth2;                                  // negative = inside
+                mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(ra.x), 31);
+                mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(ra.y), 31);
+                mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(rb.x), 31);
+                mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(rb.y), 31);
+                near = fminf(fminf(near, fabsf(ra.x)), fabsf(ra.y));
+                near = fminf(fminf(near, fabsf(rb.x)), fabsf(rb.y));
+              }
+              mask <<= 32 - 4 * ngrp;                                    // first candidate of the chunk in bit 31
+              // candidates of this chunk that exist and are not the atom itself
+              const int lo = s > j0 ? s - j0 : 0, hi = e - j0 < 32 ? e - j0 : 32;          // [lo, hi) within the chunk
+              unsigned valid = (lo == 0 ? 0xffffffffu : (0xffffffffu >> lo)) & (hi == 32 ? 0xffffffffu : ~(0xffffffffu >> hi));
+              if (slot >= j0 && slot < j0 + 32) valid &= ~(0x80000000u >> (slot - j0));
+              if (__any(near < a.nbl_eps)) {
+                // some lane of the wave is close to the threshold in this chunk: the reference's own expression for everybody
+                mask = 0;
+                for (int u = lo; u < hi; u++) {
+                  const double4 pj = a.pos[src[j0 + u]];
+                  const double ex = pj.x - pi.x, ey = pj.y - pi.y, ez = pj.z - pi.z;
+                  const double r2 = ex * ex + ey * ey + ez * ez;        // unfused (the file is compiled -ffp-contract=off)
+                  mask |= (r2 < a.cellsz) ? (0x80000000u >> u) : 0u;
+                }
+              }
+              mask &= valid;
+              if (a.dbg & 8) mask = 0;
+              while (mask) {                                             // ascending j: the reference's order inside a cell
+                const int b = __clz((int) mask);
+                mask &= ~(0x80000000u >> b);
+                w = (w >> 16) | ((unsigned long long) ((j0 + b) * NBR_SCALE) << 48);
+                m++;
+                if ((m & 3) == 0) {
+                  if ((m >> 2) <= a.W4) lp[(size_t) ((m >> 2) - 1) * a.tile_cap] = w;
+                  w = dummy64;
+                }
+              }
+            }
+          }
+      if ((m & 3) != 0 && (m >> 2) < a.W4) {
+        for (int q = m & 3; q < 4; q++) w = (w >> 16) | ((unsigned long long) dummy << 48);
+        lp[(size_t) (m >> 2) * a.tile_cap] = w;
+      }
+      a.nbr_cnt[i] = m < 4 * a.W4 ? m : 4 * a.W4;
+      a.ownw[(size_t) T.tile * a.tile_cap + o] = (unsigned) slot | ((unsigned) (m < 4 * a.W4 ? m : 4 * a.W4) << 16);
+      mmax = m > mmax ? m : mmax;
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { int v = __shfl_down(mmax, o, 64); mmax = v > mmax ? v : mmax; }
@@ -2434,6 +2591,20 @@ static TileArgs make_tile_args(imdgpu_ctx *ctx)
   a.f = ctx->f; a.epot = ctx->epot; a.rhoh = ctx->rhoh; a.ref = ctx->ref; a.numneighs = ctx->numneighs;
   a.partials = ctx->partials; a.counters = ctx->d_counters; a.cellsz = ctx->cellsz; a.guard = nullptr;
   a.balance = ctx->tile_balance; a.wprefix = ctx->d_wprefix;
+  {
+    // k_nbl_build_tile32: how far the single-precision r2 can be from the reference's.  Staged coordinates are relative to an
+    // atom of the tile, so |coordinate| <= M = the extent of tile + halo (+ 1 A); converting costs <= 2^-23 M each, a
+    // difference of two of them 2^-22 M + its own rounding, and r2 = dx^2 + dy^2 + dz^2 near the list radius R moves by
+    // 2 (|dx| + |dy| + |dz|) times that (<= 2 sqrt(3) R) plus the roundings of its six operations.  Half again as margin.
+    double M = 0;
+    for (int c = 0; c < 3; c++) {
+      double e = 1.0;
+      for (int d = 0; d < 3; d++) e += fabs(ctx->box[3 * d + c]) * (double) (ctx->tile[d] + 2) / (double) std::max(1, ctx->gdim[d]);
+      M = std::max(M, e);
+    }
+    const double u = 1.0 / 8388608.0, R = sqrt(ctx->cellsz), ddx = 2 * M * u + R * u;
+    a.nbl_eps = (float) (1.5 * (2 * 1.7320508 * R * ddx + 6 * 0.5 * u * ctx->cellsz));
+  }
   return a;
 }
 
@@ -2540,6 +2711,11 @@ extern "C" int imdgpu_make_nblist(imdgpu_ctx *ctx)
       ProfScope ps(ctx, PROF_NBLIST);
       // the build needs only the position planes (about half the LDS of a force pass): two workgroups per CU
       const int bgrid = 2 * lds <= LDS_LIMIT ? std::min(ctx->ntiles, 2 * tile_grid(ctx)) : tile_grid(ctx);
+      static const int nbl32 = getenv("IMDGPU_NBL32") ? atoi(getenv("IMDGPU_NBL32")) : 1;     // 0: the all-double build kernel
+      if (nbl32) {
+        HIPCHK(hipFuncSetAttribute((const void *) k_nbl_build_tile32, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+        hipLaunchKernelGGL(k_nbl_build_tile32, dim3(bgrid), dim3(ctx->tile_threads), lds, ctx->stream, a);
+      } else
       hipLaunchKernelGGL(k_nbl_build_tile, dim3(bgrid), dim3(ctx->tile_threads), lds, ctx->stream, a);
     } else {
       if (ctx->nbr_cap < (size_t) ctx->W * stride) {
