@@ -1507,6 +1507,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) P3_ATTR void k_pass3_tile(TileArgs
   if (a.p3_fallback) {                                   // did k_pass3_tile_coef do this step?  (same test as there)
     const int kneg = a.counters[CNT_KNEG];
     if (kneg != 0 && 0x7fffffff - kneg >= a.klo + 1) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&a.counters[CNT_P3_STANDIN], 1);    // this pass is the stand-in's (get_info "p3_standin_passes")
   }
   double *tr = lds;                                      // rho_h_tab, one type: + zero rows for r2 >= end (no mask)
   double *sp = tr + a.rho.nrows * a.rho.ncols + 4;      // (x, y) records, then (z, dF) records (LPOS_*) ...
@@ -1941,7 +1942,9 @@ extern "C" int imdgpu_get_info(imdgpu_ctx *ctx, const char *name, long long *val
     // decomposed lattice: 0 = faces through the host mailbox, 1 / 2 = ghost records in the neighbours' device memory (coarse- / fine-grained)
     {"ttm_remote", imdgpu_ttm_persist_info(ctx, 2)},
     // MD steps whose sub-steps the host issued again through the launch chain because the persistent kernel had stepped aside
-    {"ttm_persist_redone", imdgpu_ttm_persist_info(ctx, 3)}};
+    {"ttm_persist_redone", imdgpu_ttm_persist_info(ctx, 3)},
+    // EAM force passes so far in which the three-row kernel stood in for the coefficient form (as of the last md_step / calc_forces)
+    {"p3_standin_passes", ctx->h_counters ? ctx->h_counters[CNT_P3_STANDIN] : 0}};
   for (auto &e : tab) if (!strcmp(name, e.n)) { *value = e.v; return 0; }
   return imdgpu_fail(ctx, "unknown info %s", name);
 }

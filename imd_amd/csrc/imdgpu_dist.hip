@@ -370,17 +370,14 @@ static int dist_ttm_chain(imdgpu_ctx *ctx, DistState *D, int steps)
   ctx->stream = ctx->stream2;
   int rc = 0;
   if (ctx->ttm_decomposed) {
-    if (ctx->ttm_adv) {
-      // calc_ttm's order (imd_ttm_3D.c:57-60): update_fd, do_ADV -- whose first act is do_COMMFLUX (:1325) --, then the rest.
-      // The exchange is a collective's worth of transport kernels: like the replicated lattice's all-gather it must be
-      // through before the persistent EAM force pass takes every CU, so that pass waits for ev_gathered (dist_md_step)
-      rc = imdgpu_ttm_update_fd(ctx, steps);
-      if (!rc) rc = dist_commflux(ctx, D);
-      if (!rc && hipEventRecord(D->ev_gathered, ctx->stream) != hipSuccess) rc = 1;
-      if (!rc) rc = imdgpu_ttm_adv(ctx, 1.0, steps);
-      if (!rc) rc = imdgpu_ttm_lattice_step(ctx, steps);
-    }
-    else rc = imdgpu_ttm_local_step(ctx, steps);
+    // calc_ttm's order (imd_ttm_3D.c:57-60): update_fd, do_ADV -- whose first act is do_COMMFLUX (:1325) --, then the rest.
+    // The exchange is a collective's worth of transport kernels: like the replicated lattice's all-gather it must be
+    // through before the persistent EAM force pass takes every CU, so that pass waits for ev_gathered (dist_md_step)
+    rc = imdgpu_ttm_update_fd(ctx, steps);
+    if (!rc && ctx->ttm_adv) rc = dist_commflux(ctx, D);
+    if (!rc && hipEventRecord(D->ev_gathered, ctx->stream) != hipSuccess) rc = 1;
+    if (!rc && ctx->ttm_adv) rc = imdgpu_ttm_adv(ctx, 1.0, steps);
+    if (!rc) rc = imdgpu_ttm_lattice_step(ctx, steps);
   } else {
     int nb = 0;
     long long width = 0;
@@ -431,17 +428,31 @@ extern "C" int imdgpu_dist_md_step(imdgpu_ctx *ctx, int steps, int *rebuild_need
   }
   D->spec_pass1 = false; D->halo_ready = false;
   if (imdgpu_launch_forces_phase(ctx, 2)) return 1;
-  if (ctx->rho.present && imdgpu_dist_halo(ctx, 1)) return 1;          // dF of the ghost atoms  [send_cells(copy_dF), :786]
-  // The lattice chain is forked AFTER the dF halo: its all-gather (second communicator, lattice stream) then follows the
-  // halo group in device order on EVERY rank, so the two communicators can never wait for each other crosswise, whatever
-  // the CUs admit side by side (the embedding pass is folded into pass 1, so nothing of substance sits between pass 1
-  // and this point; the EAM force pass below waits for the gather anyway).
-  if (ctx->ttm1d) {
-    if (dist_ttm1d_chain(ctx, D, steps)) return 1;
+  if (ctx->ttm && ctx->ttm_decomposed && !ctx->ttm1d) {
+    // Decomposed lattice: the chain's head (update_fd, with do_ADV the do_COMMFLUX batch on the lattice stream's own
+    // communicator) is forked FIRST and the dF halo runs beside it on the main stream -- between pass 1 and the EAM force pass
+    // the chip is otherwise idle, so the halo's 8 bytes per ghost atom travel behind update_fd's 0.2 ms instead of in front
+    // of them, and transport kernels of both communicators find room side by side whatever their order on a rank.  The force
+    // pass, persistent on every CU, starts once that head is through (ev_gathered): update_fd beside it would crawl
+    //  and an exchange not yet resident would wait for the pass to end.
+    if (dist_ttm_chain(ctx, D, steps)) return 1;
+    if (ctx->rho.present && imdgpu_dist_halo(ctx, 1)) return 1;        // dF of the ghost atoms  [send_cells(copy_dF), :786]
     HIPCHK(hipStreamWaitEvent(ctx->stream, D->ev_gathered, 0));
+  } else {
+    if (ctx->rho.present && imdgpu_dist_halo(ctx, 1)) return 1;        // dF of the ghost atoms  [send_cells(copy_dF), :786]
+    // Replicated lattice / 1D model: the chain is forked AFTER the dF halo: its all-gather (second communicator, lattice
+    // stream) then follows the halo group in device order on EVERY rank, so the two communicators can never wait for each
+    // other crosswise (the embedding pass is folded into pass 1, so nothing of substance sits between pass 1 and this
+    // point; the EAM force pass below waits for the gather anyway).
+    if (ctx->ttm1d) {
+      if (dist_ttm1d_chain(ctx, D, steps)) return 1;
+      HIPCHK(hipStreamWaitEvent(ctx->stream, D->ev_gathered, 0));
+    }
+    else if (ctx->ttm) {
+      if (dist_ttm_chain(ctx, D, steps)) return 1;
+      HIPCHK(hipStreamWaitEvent(ctx->stream, D->ev_gathered, 0));
+    }
   }
-  else if (ctx->ttm && dist_ttm_chain(ctx, D, steps)) return 1;
-  if (ctx->ttm && (!ctx->ttm_decomposed || ctx->ttm_adv)) HIPCHK(hipStreamWaitEvent(ctx->stream, D->ev_gathered, 0));
   if (imdgpu_launch_forces_phase(ctx, 3)) return 1;
   if (ctx->ttm || ctx->ttm1d) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
   if (imdgpu_launch_integrate(ctx)) return 1;

@@ -203,8 +203,9 @@ Geo imdgpu_make_geo(const imdgpu_ctx *c);
 
 // device counters (ints) and d_sums slots shared by the translation units
 enum { CNT_MAXNBR = 0, CNT_IS_SHORT = 1, CNT_OUTSIDE = 2, CNT_NGHOST = 3, CNT_INVALID = 4, CNT_MAXOWN = 5,
-       CNT_MAXHALO = 6, CNT_TTM_TIMEOUT = 7, CNT_TMM_SHORT = 12, CNT_KNEG = 13, CNT_N = 16 };     // 8..10: scratch of the migration
+       CNT_MAXHALO = 6, CNT_TTM_TIMEOUT = 7, CNT_TMM_SHORT = 12, CNT_KNEG = 13, CNT_P3_STANDIN = 14, CNT_N = 16 };     // 8..10: scratch of the migration
 // CNT_KNEG: INT_MAX - (lowest table row any pair of this step's pass 1 fell into); zeroed by k_reduce_force_sums
+// CNT_P3_STANDIN: force passes in which k_pass3_tile stood in for k_pass3_tile_coef (a pair below the rows it holds); never zeroed
 enum { SUM_EPOT = 0, SUM_VIRIAL = 1, SUM_EKIN = 8, SUM_MAXDISP = 9, SUM_N = 16 };
 
 // sum of kinetic partials, max of displacement partials; decides list validity

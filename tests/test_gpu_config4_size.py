@@ -36,6 +36,7 @@ def test_config4_80M_atom_slab_with_ttm_on_one_gpu():
     s.upload_tables(pair, rho, emb)
     s.upload_atoms(pos, mom, 26.9815)
     del pos, mom
+    s.set_option("ttm_adv", 1)                 # calc_ttm as bench.py --slab runs it: do_ADV(1.0) after update_fd
     ttm_mod.attach_default(s, fd_ext=(2, 2, 2), diff_substeps=100, fd_min_atoms=5)
     s.calc_forces(0)
     assert s.get_info("list_mode") == 1                                   # the LDS-tile kernels
@@ -53,10 +54,13 @@ def test_config4_80M_atom_slab_with_ttm_on_one_gpu():
     for st in range(4):
         s.md_step(st)
     assert s.num_atoms()[0] == n
-    lat = s.ttm_download(fields=("natoms", "md_temp", "temp", "xi"))
+    lat = s.ttm_download(fields=("natoms", "natoms_old", "md_temp", "temp", "xi", "U", "flux"))
     inner = (slice(1, -1),) * 3
     nat = lat["natoms"][inner]
     assert int(nat.sum()) == n                                            # every atom sits in exactly one FD cell
+    assert int(lat["natoms_old"][inner].sum()) == n                       # do_ADV's two counts: atoms conserved, arrivals cover the gains
+    assert (lat["flux"][inner] >= 0).all() and (lat["flux"][inner].sum(axis=-1) >= np.maximum(nat - lat["natoms_old"][inner], 0)).all()
+    assert np.isfinite(lat["U"][inner]).all() and (lat["U"][inner][nat >= 5] > 0).all()
     act = nat >= 5
     assert act.sum() == (gd0[0] // 2) * (gd0[1] // 2) * (gd0[2] // 2)     # the slab's cells are active, the vacuum's are not
     assert not act[: nvac // 2].any() and not act[-(nvac // 2):].any()

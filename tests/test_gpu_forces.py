@@ -234,7 +234,7 @@ def test_large_system_properties():
 
 def test_bench_size_properties_with_ttm():
     """BASELINE config 3 at full size (136^3 unit cells = 10 061 824 atoms, EAM + 3D TTM fd_ext 2 2 2, 100 sub-steps):
-    properties that need no oracle run -- the two kernel families agree on every force, the total force vanishes, the
+    the sequence bench.py times, do_ADV included -- properties that need no oracle run: the two kernel families agree on every force, the total force vanishes, the
     symmetric list is even; after device-resident MD+TTM steps every atom sits in exactly one FD cell (sum natoms = N),
     the lattice temperature of the FD cells averages to 2/3 of the kinetic energy per atom (in the frame of each
     cell's centre of mass, hence a little below), electron temperatures stay within the initial thermal spread,
@@ -264,12 +264,20 @@ def test_bench_size_properties_with_ttm():
         ent, mx = s.nblist_stats()
         assert ent % 2 == 0
         if mode == 1:
+            s.set_option("ttm_adv", 1)             # the benchmarked sequence: calc_ttm with do_ADV(1.0) after update_fd (bench.py's default)
             ttm_mod.attach_default(s, fd_ext=(2, 2, 2), diff_substeps=100, fd_min_atoms=5)
             for st in range(4):
                 s.md_step(st)
-            lat = s.ttm_download(fields=("natoms", "md_temp", "temp", "xi"))
+            lat = s.ttm_download(fields=("natoms", "natoms_old", "md_temp", "temp", "xi", "U", "flux"))
             inner = (slice(1, -1),) * 3
             assert int(lat["natoms"][inner].sum()) == n
+            # do_ADV's inputs and outputs: every atom that changed its FD cell was counted once as an arrival (so the arrivals
+            # cover every cell's net gain), atoms are conserved between the two counts, the transported energy stays finite
+            # and positive where there are atoms
+            assert int(lat["natoms_old"][inner].sum()) == n
+            gain = np.maximum(lat["natoms"][inner] - lat["natoms_old"][inner], 0)
+            assert (lat["flux"][inner] >= 0).all() and (lat["flux"][inner].sum(axis=-1) >= gain).all()
+            assert np.isfinite(lat["U"][inner]).all() and (lat["U"][inner][lat["natoms"][inner] >= 5] > 0).all()
             ekin = s.get_sums()["tot_kin_energy"] / n
             tl = lat["md_temp"][inner]
             assert 0.90 * (2.0 / 3.0) * ekin < tl.mean() < 1.02 * (2.0 / 3.0) * ekin
