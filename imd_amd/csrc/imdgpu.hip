@@ -1038,11 +1038,13 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile32(TileArgs a)
       const unsigned long long dummy64 = (unsigned long long) dummy * 0x0001000100010001ull;
       unsigned long long w = dummy64;
       int m = 0;
+      // the three neighbour cells dz = 0, 1, 2 of a (dx, dy) pair are consecutive halo cells, so their atoms are ONE run of
+      // slots: nine runs of ~63 candidates instead of 27 cells of ~21 -- the same candidates in the same order (cells by dz,
+      // atoms ascending inside a cell), a third of the per-run bookkeeping and fuller chunks
       for (int dx = 0; dx <= ((a.dbg & 4) ? -1 : 2); dx++)
-        for (int dy = 0; dy <= 2; dy++)
-          for (int dz = 0; dz <= 2; dz++) {
-            const int h = ((lx + dx) * T.hy + (ly + dy)) * T.hz + (lz + dz);
-            const int s = hstart[h], e = hstart[h + 1];
+        for (int dy = 0; dy <= 2; dy++) {
+            const int h = ((lx + dx) * T.hy + (ly + dy)) * T.hz + lz;
+            const int s = hstart[h], e = hstart[h + 3];
             for (int j0 = s & ~3; j0 < e; j0 += 32) {
               // bit 31 - u of `mask` = candidate j0 + u (shifted in through the sign of r2 - cellsz, first candidate highest)
               unsigned mask = 0;

@@ -795,16 +795,27 @@ __global__ void k_ttm_commflux(Lat L, int side, int unpack, int *flux, int ncell
 // for kappa and gamma; pow(a,b) with run-time exponents is exp(b*log(a)) with the logarithms shared (7 pow ->
 // 4 log + 6 exp), x^(2/3) and x^(1/3) use cbrt.  Differences to the reference are rounding-level (<=1e-13).
 struct MeshOut { double Z, ne, Ce, k, g; };
-__device__ __forceinline__ MeshOut mesh_props(const Lat &L, const EosDev &cve, double Te, double Tl, double dens)
+// What of a cell's FILLMESH depends on its density and lattice temperature only: constant over the sub-steps of an MD step, so the
+// sub-step loops (persistent kernel, Maxwell-solver loop) take it once per launch (one of the four logarithms among it).
+// mesh_props = mesh_pre + mesh_eval: the same operations in the same order either way, the same bits.
+struct MeshPre { double dens, TiK, r0, lr; };
+__device__ __forceinline__ MeshPre mesh_pre(const Lat &L, double Tl, double dens)
+{
+  MeshPre q;
+  q.dens = dens; q.TiK = Tl * 11604.5;
+  q.r0 = dens * L.inv_z0am;
+  q.lr = log(q.r0);
+  return q;
+}
+__device__ __forceinline__ MeshOut mesh_eval(const Lat &L, const EosDev &cve, const MeshPre &q, double Te)
 {
   MeshOut o;
-  const double TeK = Te * 11604.5, TiK = Tl * 11604.5;
+  const double TeK = Te * 11604.5, TiK = q.TiK, dens = q.dens;
   {
     const double YA1 = 0.003323, YA2 = 0.971832, YA3 = 0.926148e-5, YA4 = 3.10165, YB0 = -1.7630, YB1 = 1.43175,
                  YB2 = 0.315463, YC1 = 0.036666667, YC2 = 0.983333333, YAL = 0.143139e2, YBE = 0.6624e0;
     const double t0 = TeK * L.inv_z0_43;
-    const double r0 = dens * L.inv_z0am;
-    const double lt = log(t0), lr = log(r0);
+    const double lt = log(t0), lr = q.lr;
     const double ytf = t0 / (1.0 + t0);
     const double ya = YA1 * exp(YA2 * lt) + YA3 * exp(YA4 * lt);
     const double yb = -exp(YB0 + YB1 * ytf + YB2 * ytf * ytf);
@@ -850,6 +861,10 @@ __device__ __forceinline__ MeshOut mesh_props(const Lat &L, const EosDev &cve, d
     o.g = 2.783313120645740e-74 / (m_atom * C_AMU) * Ne * nu_eff;
   }
   return o;
+}
+__device__ __forceinline__ MeshOut mesh_props(const Lat &L, const EosDev &cve, double Te, double Tl, double dens)
+{
+  return mesh_eval(L, cve, mesh_pre(L, Tl, dens), Te);
 }
 
 // occ (may be null): dim[0] + dim[1] + dim[2] ints, zeroed before the launch, in which every wave MARKS the lowest and the highest
@@ -1334,6 +1349,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     if (SRC) src = source[c];
   }
   const double invsq[3] = {L.invhsq[0], L.invhsq[1], L.invhsq[2]};
+  const MeshPre mpre = mesh_pre(L, Tl, dn);              // density and lattice temperature do not change inside an MD step
   if (!REM) { (void) tloop; }
   for (int s = 0; any_active && s < nsub; s++) {
     double xT[3], xK[3];
@@ -1398,7 +1414,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
       double *Tw = (s & 1) ? T0 : T1, *Kw = (s & 1) ? K0 : K1, *Uw = (s & 1) ? U0 : U1;
       u = u + (Tn - Te) * ce * L.vol / ((double) nat);
       x += (Tn - Tl) * L.xi_fac * g / (Tl * dn);
-      const MeshOut o = mesh_props(L, cve, Tn, Tl, dn);
+      const MeshOut o = mesh_eval(L, cve, mpre, Tn);
       ce = o.Ce; kk = o.k; g = o.g; Te = Tn;
       if ((xany & ~xrm) != 0 && s + 1 < nsub) {         // a lane with a neighbour in another block publishes state s + 1
         unsigned long long *r = P.rec + ((size_t) ((s + 1) & 1) * P.ncell + c) * 4;
@@ -2938,8 +2954,31 @@ static void imdgpu_fdtd_free(TtmState *t)
 
 // one do_fdtd(t) for the cell of this thread; all threads of the block call it (two barriers inside).  sH / sE: LDS rows.
 struct FdtdCell { double E, H, J, Jl, P, Jo, Jlo, src, sig, DL[6]; int active; };
+// K: what of the update depends on the cell's conductivity and on DL[0..4] only -- twelve divisions -- taken once per launch where
+// those parameters do not change inside an MD step (dl_mode 0 and 1; with fitDL's tables they follow the electron temperature:
+// K = nullptr, everything per sub-step as the reference writes it, imd_fdtd.c:178-286)
+struct FdtdCoef { double hy1, hy2, ezx1, ezx2, Cb, CD1, CL1, CD2, CL2, wL2e, w02, qeL, gpe, inv_dx; };
+__device__ __forceinline__ FdtdCoef fdtd_coef(const FdtdDev &F, const FdtdCell &c)
+{
+  FdtdCoef K;
+  const double dt = F.dt, dx = F.dx;
+  const double sigmastary = c.sig * F_MU0 / F_EPS0;
+  K.hy1 = (F_MU0 - 0.5 * dt * sigmastary) / (F_MU0 + 0.5 * dt * sigmastary);
+  K.hy2 = (dt / dx) / (F_MU0 + 0.5 * dt * sigmastary);
+  K.ezx1 = (F_EPS0 - 0.5 * dt * c.sig) / (F_EPS0 + 0.5 * dt * c.sig);
+  K.ezx2 = (dt / dx) / (F_EPS0 + 0.5 * dt * c.sig);
+  K.Cb = dt / F_EPS0 / c.DL[0];
+  const double gamma_p = c.DL[1], omegapl_L = c.DL[2], Omega0_L = c.DL[3], Gamma_L = c.DL[4];
+  K.CD1 = (2 - dt * gamma_p) / (2 + dt * gamma_p); K.CL1 = (2 - dt * Gamma_L) / (2 + dt * Gamma_L);
+  K.CD2 = 2 * dt / (2 + dt * gamma_p); K.CL2 = 2 * dt / (2 + dt * Gamma_L);
+  const double wL2 = omegapl_L * omegapl_L;
+  K.wL2e = wL2 * F_EPS0; K.w02 = Omega0_L * Omega0_L;
+  K.qeL = Gamma_L / F_EPS0 / wL2; K.gpe = gamma_p / F_EPS0;
+  K.inv_dx = 1.0 / dx;
+  return K;
+}
 __device__ __forceinline__ void fdtd_step(const FdtdDev &F, FdtdCell &c, int i, bool have, bool inner, double t, double laser_timefun,
-                                          double *sH, double *sE)
+                                          double *sH, double *sE, const FdtdCoef *K = nullptr)
 {
   const double dt = F.dt, dx = F.dx;
   const double wt = 2.0 * C_PI * (F_C0 / (dx * F.Nlambdax));
@@ -2954,11 +2993,15 @@ __device__ __forceinline__ void fdtd_step(const FdtdDev &F, FdtdCell &c, int i, 
   if (inner) {                                                               // E: n -> n+1, :178-231
     const double Hm = sH[i - 1];
     if (c.active) {
-      const double Cb = dt / F_EPS0 / c.DL[0];
       c.Jo = c.J; c.Jlo = c.Jl;
-      c.E = c.E + Cb * (c.H - Hm) / dx - Cb * c.J - Cb * c.Jl;
+      if (K) c.E = c.E + K->Cb * (c.H - Hm) * K->inv_dx - K->Cb * c.J - K->Cb * c.Jl;
+      else {
+        const double Cb = dt / F_EPS0 / c.DL[0];
+        c.E = c.E + Cb * (c.H - Hm) / dx - Cb * c.J - Cb * c.Jl;
+      }
       c.P = c.P + dt * c.Jl;
-    } else {
+    } else if (K) c.E = K->ezx1 * c.E + K->ezx2 * (c.H - Hm);
+    else {
       const double ezx1 = (F_EPS0 - 0.5 * dt * c.sig) / (F_EPS0 + 0.5 * dt * c.sig);
       const double ezx2 = (dt / dx) / (F_EPS0 + 0.5 * dt * c.sig);
       c.E = ezx1 * c.E + ezx2 * (c.H - Hm);
@@ -2966,7 +3009,17 @@ __device__ __forceinline__ void fdtd_step(const FdtdDev &F, FdtdCell &c, int i, 
   }
   if (have) sE[i] = c.E;
   __syncthreads();
-  if (inner) {                                                               // H: -> n+3/2, currents, power, :236-286
+  if (inner && K) {                                                          // H: -> n+3/2, currents, power, :236-286, coefficients from K
+    c.H = K->hy1 * c.H + K->hy2 * (sE[i + 1] - c.E);
+    if (c.active) {
+      const double wD2 = c.DL[5] * c.DL[5];
+      c.J = K->CD1 * c.J + K->CD2 * (wD2 * F_EPS0 * c.E);
+      c.Jl = K->CL1 * c.Jl + K->CL2 * (K->wL2e * c.E - K->w02 * c.P);
+      const double Jz = (c.J + c.Jo) * 0.5, Jlz = 0.5 * (c.Jl + c.Jlo);
+      const double qe = K->gpe * (Jz * Jz) / wD2 + K->qeL * (Jlz * Jlz);
+      c.src = 6.3538562638e-26 * qe;                                          // W/m^3 -> IMD units
+    }
+  } else if (inner) {
     const double sigmastary = c.sig * F_MU0 / F_EPS0;
     const double hy1 = (F_MU0 - 0.5 * dt * sigmastary) / (F_MU0 + 0.5 * dt * sigmastary);
     const double hy2 = (dt / dx) / (F_MU0 + 0.5 * dt * sigmastary);
@@ -3030,8 +3083,15 @@ __global__ __launch_bounds__(MAXT) void k_ttm_fdtd_chain(Lat L, FdtdDev F, int n
   const int ilo = i == 1 ? (L.pbc[0] == 1 ? nx - 2 : -1) : i - 1, ihi = i == nx - 2 ? (L.pbc[0] == 1 ? 1 : -1) : i + 1;
   const bool lo_ok = inner && ilo >= 0 && sN[ilo] >= m, hi_ok = inner && ihi >= 0 && sN[ihi] >= m;
   double t = t_SI;
+  // constant inside an MD step: the solver's coefficients unless fitDL's tables move DL[0..4] with the electron temperature,
+  // the cell's density and lattice temperature (mesh_pre), two reciprocals of the diffusion update
+  const bool hoist = F.dl_mode != 2;
+  FdtdCoef K{};
+  if (hoist && have) K = fdtd_coef(F, c);
+  const MeshPre mpre = mesh_pre(L, (WITH_TTM && inner && c.active) ? Tl : 1.0, (WITH_TTM && inner && c.active) ? rho : 1.0);
+  const double inv_nat = nat > 0 ? 1.0 / ((double) nat) : 0.0, inv_tlrho = (WITH_TTM && inner && c.active) ? 1.0 / (Tl * rho) : 0.0;
   for (int s = 0; s < nsub; s++) {
-    if (laser_active) fdtd_step(F, c, i, have, inner, t, laser_timefun, sH, sE);       // uniform: laser_active is a kernel argument
+    if (laser_active) fdtd_step(F, c, i, have, inner, t, laser_timefun, sH, sE, hoist ? &K : nullptr);       // uniform: laser_active is a kernel argument
     if (WITH_TTM) {
       for (int q = 0; q < ndiff; q++) {
         if (have) { sT[i] = Te; sK[i] = kk; }
@@ -3044,10 +3104,10 @@ __global__ __launch_bounds__(MAXT) void k_ttm_fdtd_chain(Lat L, FdtdDev F, int n
             const double Tn = tau_diff / ce * ((((kk + xaK) / 2 * (xaT - Te) * L.invhsq[0]) - ((kk + xbK) / 2 * (Te - xbT) * L.invhsq[0]))
                                                - g * (Te - Tl) + c.src) + Te;
             Tprev = Te; Uprev = U;
-            U = U + (Tn - Te) * ce * L.vol / ((double) nat);
-            xiv += (Tn - Tl) * L.xi_fac * g / (Tl * rho);
+            U = U + (Tn - Te) * ce * L.vol * inv_nat;
+            xiv += (Tn - Tl) * L.xi_fac * g * inv_tlrho;
             Te = Tn;
-            MeshOut o = mesh_props(L, cve, Te, Tl, rho);
+            MeshOut o = mesh_eval(L, cve, mpre, Te);
             Zv = o.Z; nev = o.ne; ce = o.Ce; kk = o.k; g = o.g;
             if (steps < 1) { U = eos_ee(ee, rho, Te * 11604.5) * 26.9815 * C_AMU * C_J2EV; Uprev = U; }
             if (F.dl_mode == 0) c.DL[5] = sqrt(nev * C_ECHARGE * C_ECHARGE / C_ECONST / C_EMASS);
