@@ -69,7 +69,7 @@ void imdgpu_tl_mark(imdgpu_ctx *c, const char *name)
   (void) hipEventRecord(e, c->stream);
   c->tl.push_back({name, e});
 }
-static void tl_flush(imdgpu_ctx *c, int steps)
+void imdgpu_tl_flush(imdgpu_ctx *c, int steps)
 {
   if (!c->tl_on || c->tl.empty()) return;
   (void) hipDeviceSynchronize();
@@ -3072,7 +3072,7 @@ extern "C" int imdgpu_md_step_end(imdgpu_ctx *ctx, int steps)
   HIPCHK(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, CNT_N * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   imdgpu_tl_mark(ctx, "move");
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  tl_flush(ctx, steps);
+  imdgpu_tl_flush(ctx, steps);
   if (ctx->ttm) {
     // the persistent sub-step kernel of this step stepped aside (status 1: nothing of the lattice touched, the integrator above
     // returned at once on the same word): its sub-steps have been issued through the launch chain; now the integrator again

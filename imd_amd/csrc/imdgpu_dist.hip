@@ -441,6 +441,7 @@ extern "C" int imdgpu_dist_md_step(imdgpu_ctx *ctx, int steps, int *rebuild_need
     //  and an exchange not yet resident would wait for the pass to end.
     if (dist_ttm_chain(ctx, D, steps)) return 1;
     if (ctx->rho.present && imdgpu_dist_halo(ctx, 1)) return 1;        // dF of the ghost atoms  [send_cells(copy_dF), :786]
+    imdgpu_tl_mark(ctx, "dF_halo");
     HIPCHK(hipStreamWaitEvent(ctx->stream, D->ev_gathered, 0));
   } else {
     if (ctx->rho.present && imdgpu_dist_halo(ctx, 1)) return 1;        // dF of the ghost atoms  [send_cells(copy_dF), :786]
@@ -460,6 +461,7 @@ extern "C" int imdgpu_dist_md_step(imdgpu_ctx *ctx, int steps, int *rebuild_need
   if (imdgpu_launch_forces_phase(ctx, 3)) return 1;
   if (ctx->ttm || ctx->ttm1d) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
   if (imdgpu_launch_integrate(ctx)) return 1;
+  imdgpu_tl_mark(ctx, "move");
   // next step's position halo and the global validity flag; then pass 1 of the next step, guarded by that flag, so the
   // device has work while the host reads the flag
   const bool spec = !getenv("IMDGPU_NO_SPECULATION");
@@ -493,6 +495,7 @@ extern "C" int imdgpu_dist_md_step(imdgpu_ctx *ctx, int steps, int *rebuild_need
     if (round > 0) return imdgpu_fail(ctx, "dist_md_step: the persistent sub-step kernel's status did not clear after the step was re-issued");
     if (spec) drop_ahead();
   }
+  if (ctx->tl_on) { imdgpu_tl_mark(ctx, "halo+flag+pass1ahead"); imdgpu_tl_flush(ctx, steps); }
   if (D->h_flag[1]) {               // like imdgpu_md_step: the lattice of this step was not (or only half) advanced on some rank
     HIPCHK(hipMemsetAsync(ctx->d_counters + CNT_TTM_TIMEOUT, 0, sizeof(int), ctx->stream));      // reported once
     return imdgpu_fail(ctx, "TTM: a hand-off between lattice blocks timed out on some rank (persistent sub-step kernel or mailbox): the lattice of this step is not valid");

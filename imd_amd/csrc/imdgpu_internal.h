@@ -162,6 +162,7 @@ struct ProfScope {
 };
 void imdgpu_prof_resolve(imdgpu_ctx *c);
 void imdgpu_tl_mark(imdgpu_ctx *c, const char *name);     // no-op unless IMDGPU_TIMELINE is set
+void imdgpu_tl_flush(imdgpu_ctx *c, int steps);            // prints and clears the marks of a step (synchronises the device)
 
 template <typename T>
 static inline int dev_alloc(imdgpu_ctx *ctx, T **p, size_t n)

@@ -908,13 +908,29 @@ __global__ void k_ttm_fillmesh(Lat L, int steps, EosDev cve, EosDev ee, const in
 // comes earlier in that order sees the neighbour's NEW temperature.  Two kernels keep that: the first, parallel, does
 // what is order independent (xi = 0 of deactivated cells) and collects the cells that need the fallback (rare:
 // usually none); the second, one wave, puts them into the reference's order and processes them one after the other.
+// X (decomposed lattice with ghost records, steps the persistent sub-step kernel will take): every inner cell on a face with
+// another rank beyond it tells that rank its atom count, tagged with the coming launch's base -- active or not: the count
+// decides between mirror and flux on the other side (the natoms plane of ttm_fill_ghost_layers).  Done HERE, by the kernel
+// that walks all inner cells anyway: a launch of its own for it was measured to sit 1.2 ms in the queue beside the freshly
+// started force pass (profiles/r04_persist_rem_variants.json).
+struct XPub { unsigned long long *peer[6]; int xoff[6], xcells; unsigned base; };
 __global__ void k_ttm_activation(Lat L, const int *natoms, const int *natoms_old, const double *T1, double *xi,
-                                 int *cand, int *ncand)
+                                 int *cand, int *ncand, XPub X)
 {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int ni = L.dim[0] - 2, nj = L.dim[1] - 2, nk = L.dim[2] - 2;
   if (t >= ni * nj * nk) return;
   const int i = t / (nk * nj) + 1, j = (t / nk) % nj + 1, k = t % nk + 1, c = fidx(L, i, j, k), m = L.fd_min_atoms;
+  if (X.xcells > 0) {
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+      const int d = q >> 1, me = d == 0 ? i : d == 1 ? j : k;
+      if (X.peer[q] == nullptr || me != ((q & 1) ? 1 : L.dim[d] - 2)) continue;
+      const int f = d == 0 ? (j - 1) * nk + (k - 1) : d == 1 ? (i - 1) * nk + (k - 1) : (i - 1) * nj + (j - 1);      // face_index
+      __hip_atomic_store(X.peer[q] + (size_t) 2 * X.xcells * 4 + X.xoff[q ^ 1] + f, ((unsigned long long) X.base << 32) | (unsigned) natoms[c],
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
   if (natoms_old[c] >= m && natoms[c] < m) xi[c] = 0.0;
   else if (natoms_old[c] < m && natoms[c] >= m) {
     const double tc = T1[c];
@@ -1170,6 +1186,7 @@ __device__ __forceinline__ int face_index(const Lat &L, int q, int i, int j, int
   return d == 0 ? (j - 1) * (L.dim[2] - 2) + (k - 1) : d == 1 ? (i - 1) * (L.dim[2] - 2) + (k - 1) : (i - 1) * (L.dim[1] - 2) + (j - 1);
 }
 
+
 // WPE = waves per SIMD the register budget is cut for: 6 (80 VGPRs, 52 of them spilled to scratch) is what fits beside three
 // 144-register waves of the three-row EAM force pass; 4 (128 VGPRs, no spills: 0.76 instead of 0.83 ms alone) is what a
 // stand-alone calc_ttm runs and what fits beside the 128-register coefficient form of the force pass (the usual case); 5 (96
@@ -1275,7 +1292,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
   const unsigned long long tloop = wall_clock64();
   if (REM) {
     // every ACTIVE inner cell on a face towards another rank gives that rank its state 0; the atom counts of all face cells
-    // (activity decides mirror or flux) have gone out before this launch (k_ttm_xrec_counts: the blocks of this kernel cover
+    // (activity decides mirror or flux) have gone out before this launch (k_ttm_activation: the blocks of this kernel cover
     // the active cells only) -- all of it tagged with this launch's base; the ghost cells' counts are awaited below
 #pragma unroll
     for (int q = 0; q < 6; q++) {
@@ -1342,10 +1359,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
   // an inactive cell of a partly active block computes nothing and is a mirror for its neighbours, which therefore
   // publish no record on its account: it must not wait for any (rough surfaces, voids, craters across a block face)
   if (!active) xany = 0;
+  // what the loop keeps of all this (registers are what this kernel is short of: one wave per SIMD beside the force pass, and a
+  // spilled value reloaded inside the sub-step's dependent chain costs a memory round trip nothing hides): one bit per
+  // direction "there is a neighbour" instead of its cell number, and -- REM -- per dimension the record of this cell in the
+  // buffer of the rank beyond (a cell has at most one face per dimension towards another rank: the lattice is at least two
+  // cells wide) with the side it lies on
+  unsigned nvalid = 0;
+#pragma unroll
+  for (int q = 0; q < 6; q++) if (nc[q] >= 0) nvalid |= 1u << q;
+  // a cell on a face towards another rank publishes to that rank whether the cell beyond is active or not: pidx[d] = its
+  // record in that rank's buffer (-1: no such face in dimension d), bit 19 + d of the flags = the face is the low one
+  int pidx[3] = {-1, -1, -1};
+  unsigned pside = 0;
+  if (REM) {
+#pragma unroll
+    for (int q = 0; q < 6; q++) if (rem >> q & 1u) { pidx[q >> 1] = P.xoff[q ^ 1] + face_index(L, q, i, j, k); pside |= (unsigned) (q & 1) << (q >> 1); }
+  }
+  // the loop's flags in one word: bits 0-5 "there is a neighbour in direction q", 6-11 "... and it is a lane of this wave",
+  // 12-14 "dimension d has a neighbour in another block / on another rank", 15-17 "... on another rank", 18 "this cell publishes
+  // to a rank", 19-21 "on its low face of dimension d"
+  const unsigned fl = nvalid | (intile << 6) | (xany << 12) | (xrm << 15) | ((REM && rem != 0) ? 1u << 18 : 0u) | (pside << 19);
   // ---- the sub-step loop -------------------------------------------------------------------------------------------
-  double Te = 0, kk = 0, ce = 1, g = 0, Tl = 1, dn = 1, src = 0, u = 0, x = 0;
+  // U and xi are accumulated in the arrays, not in registers: nothing of the temperature chain waits for them (their loads are
+  // issued at the top of a sub-step and used at its end), and the four registers go to the chain -- same operations, same bits
+  double Te = 0, kk = 0, ce = 1, g = 0, Tl = 1, dn = 1, src = 0;
   if (active) {
-    Te = T0[c]; kk = K0[c]; ce = Ce[c]; g = fd_g[c]; Tl = md_temp[c]; dn = dens[c]; u = U0[c]; x = xi[c];
+    Te = T0[c]; kk = K0[c]; ce = Ce[c]; g = fd_g[c]; Tl = md_temp[c]; dn = dens[c];
     if (SRC) src = source[c];
   }
   const double invsq[3] = {L.invhsq[0], L.invhsq[1], L.invhsq[2]};
@@ -1353,17 +1392,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
   if (!REM) { (void) tloop; }
   for (int s = 0; any_active && s < nsub; s++) {
     double xT[3], xK[3];
+    double u = 0, x = 0;
+    if (active) { u = ((s & 1) ? U1 : U0)[c]; x = xi[c]; }
     // (1) the neighbours in other blocks: state 0 from the arrays, later states from their records once the tags are there
     //     (cells of other ranks: every state from their records in xrec)
-    unsigned todo = (s == 0) ? (xany & xrm) : xany;
+    const unsigned fxany = fl >> 12 & 7u, fxrm = fl >> 15 & 7u;
+    unsigned todo = (s == 0) ? (fxany & fxrm) : fxany;
     if (s == 0) {
 #pragma unroll
-      for (int d = 0; d < 3; d++) { xT[d] = Te; xK[d] = kk; if ((xany & ~xrm) >> d & 1u) { xT[d] = T0[xc[d]]; xK[d] = K0[xc[d]]; } }
+      for (int d = 0; d < 3; d++) { xT[d] = Te; xK[d] = kk; if ((fxany & ~fxrm) >> d & 1u) { xT[d] = T0[xc[d]]; xK[d] = K0[xc[d]]; } }
     } else {
 #pragma unroll
       for (int d = 0; d < 3; d++) { xT[d] = Te; xK[d] = kk; }
     }
-    if (s > 0 || (REM && todo != 0) || REM) {
+    if (s > 0 || REM) {
       const unsigned long long want = (unsigned long long) (P.base + (unsigned) s);
       const unsigned long long *R = P.rec + (size_t) (s & 1) * P.ncell * 4;
       const unsigned long long *X = REM ? P.xrec + (size_t) (s & 1) * P.xcells * 4 : nullptr;
@@ -1371,9 +1413,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 #pragma unroll
         for (int d = 0; d < 3; d++)
           if (todo >> d & 1u) {
-            const unsigned long long *r = (REM && (xrm >> d & 1u)) ? X + (size_t) xc[d] * 4 : R + (size_t) xc[d] * 4;
+            const unsigned long long *r = (REM && (fxrm >> d & 1u)) ? X + (size_t) xc[d] * 4 : R + (size_t) xc[d] * 4;
             unsigned long long a0, a1, a2, a3;
-            if (REM && (xrm >> d & 1u)) { a0 = xrec_load(r); a1 = xrec_load(r + 1); a2 = xrec_load(r + 2); a3 = xrec_load(r + 3); }
+            if (REM && (fxrm >> d & 1u)) { a0 = xrec_load(r); a1 = xrec_load(r + 1); a2 = xrec_load(r + 2); a3 = xrec_load(r + 3); }
             else {
               a0 = __hip_atomic_load(r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); a1 = __hip_atomic_load(r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               a2 = __hip_atomic_load(r + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); a3 = __hip_atomic_load(r + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1403,8 +1445,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
       const int d = q >> 1, st = d == 0 ? 16 : d == 1 ? 4 : 1, srcl = lane + ((q & 1) ? -st : st);
       const double sT = __shfl(Te, srcl & 63, 64), sK = __shfl(kk, srcl & 63, 64);
       double nT = Te, nK = kk;
-      if (nc[q] >= 0) {
-        if (intile >> q & 1u) { nT = sT; nK = sK; } else { nT = xT[d]; nK = xK[d]; }
+      if (fl >> q & 1u) {
+        if (fl >> (6 + q) & 1u) { nT = sT; nK = sK; } else { nT = xT[d]; nK = xK[d]; }
       }
       const double term = (q & 1) ? ((kk + nK) / 2 * (Te - nT) * invsq[d]) : ((kk + nK) / 2 * (nT - Te) * invsq[d]);
       flux = q == 0 ? term : ((q & 1) ? flux - term : flux + term);
@@ -1414,34 +1456,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
       double *Tw = (s & 1) ? T0 : T1, *Kw = (s & 1) ? K0 : K1, *Uw = (s & 1) ? U0 : U1;
       u = u + (Tn - Te) * ce * L.vol / ((double) nat);
       x += (Tn - Tl) * L.xi_fac * g / (Tl * dn);
+      // the arrays follow as in the launch chain (ping-pong): nobody in this launch reads them after state 0.  Stored BEFORE
+      // FILLMESH, whose registers they would otherwise sit in for nothing
+      Tw[c] = Tn; Uw[c] = u; xi[c] = x;
       const MeshOut o = mesh_eval(L, cve, mpre, Tn);
       ce = o.Ce; kk = o.k; g = o.g; Te = Tn;
-      if ((xany & ~xrm) != 0 && s + 1 < nsub) {         // a lane with a neighbour in another block publishes state s + 1
+      if ((fxany & ~fxrm) != 0 && s + 1 < nsub) {       // a lane with a neighbour in another block publishes state s + 1
         unsigned long long *r = P.rec + ((size_t) ((s + 1) & 1) * P.ncell + c) * 4;
         rec_store(r, P.base + (unsigned) (s + 1), Te);
         rec_store(r + 2, P.base + (unsigned) (s + 1), kk);
       }
-      if (REM && rem != 0) {                            // ... and to the ranks beyond its faces, the final state included
+      if (REM && (fl >> 18 & 1u)) {                     // ... and to the ranks beyond its faces, the final state included
 #pragma unroll
-        for (int q = 0; q < 6; q++)
-          if (rem >> q & 1u) {
-            unsigned long long *r = P.peer[q] + ((size_t) ((s + 1) & 1) * P.xcells + P.xoff[q ^ 1] + face_index(L, q, i, j, k)) * 4;
+        for (int d = 0; d < 3; d++)
+          if (pidx[d] >= 0) {
+            unsigned long long *base = (fl >> (19 + d) & 1u) ? P.peer[2 * d + 1] : P.peer[2 * d];
+            unsigned long long *r = base + ((size_t) ((s + 1) & 1) * P.xcells + pidx[d]) * 4;
             xrec_store(r, P.base + (unsigned) (s + 1), Te);
             xrec_store(r + 2, P.base + (unsigned) (s + 1), kk);
           }
       }
-      // the arrays follow as in the launch chain (ping-pong): nobody in this launch reads them after state 0
-      Tw[c] = Te; Kw[c] = kk; Uw[c] = u;
+      Kw[c] = kk;
       if (s == nsub - 1) { Zo[c] = o.Z; neo[c] = o.ne; }
     }
   }
-  if (active) { xi[c] = x; Ce[c] = ce; fd_g[c] = g; }
+  if (active) { Ce[c] = ce; fd_g[c] = g; }
 }
 
 // Decomposed lattice with ghost records, the two ends of a launch that do not follow the blocks of k_ttm_chain_persist (which
 // cover the ACTIVE cells only).  One thread per face cell of the faces with another rank beyond them.
-//  counts: every inner face cell tells the rank beyond its atom count, tagged with the launch's base -- active or not: the
-//          count decides between mirror and flux on the other side (what ttm_fill_ghost_layers' natoms plane does).
+//  counts: every inner face cell's atom count goes out with k_ttm_activation (see there).
 //  final:  ttm_fill_ghost_layers after the last sub-step (imd_ttm_3D.c:70,3314-3504): count and, for active cells, final
 //          (Te, kappa) of every cell beyond my faces go into the ghost shell of the arrays (what the next step's cell
 //          activation, CFL_maxdt and downloads read).  Runs behind the persistent kernel; skipped when that stepped aside.
@@ -1459,14 +1503,6 @@ __device__ __forceinline__ bool xface_cell(const Lat &L, const PersistDev &P, in
   g[d] = (q & 1) ? 1 : L.dim[d] - 2;
   if (d == 0) { g[1] = a; g[2] = b; } else if (d == 1) { g[0] = a; g[2] = b; } else { g[0] = a; g[1] = b; }
   return true;
-}
-__global__ __launch_bounds__(64) void k_ttm_xrec_counts(Lat L, PersistDev P, const int *natoms)
-{
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  int q, f, g[3];
-  if (t >= P.xcells || !xface_cell(L, P, t, q, f, g)) return;
-  __hip_atomic_store(P.peer[q] + (size_t) 2 * P.xcells * 4 + P.xoff[q ^ 1] + f,
-                     ((unsigned long long) P.base << 32) | (unsigned) natoms[fidx(L, g[0], g[1], g[2])], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __global__ __launch_bounds__(64) void k_ttm_xrec_final(Lat L, PersistDev P, int nsub, int *natoms, double *Tf, double *Kf)
 {
@@ -2200,17 +2236,26 @@ extern "C" int imdgpu_ttm_adv(imdgpu_ctx *ctx, double tau, int steps)
   return 0;
 }
 
-extern "C" int imdgpu_ttm_cell_activation(imdgpu_ctx *ctx)
+static int ttm_cell_activation(imdgpu_ctx *ctx, TtmState *t, const Lat &L, bool publish_counts)
 {
-  NEED_TTM();
+  XPub X{};
+  if (publish_counts) {
+    for (int q = 0; q < 6; q++) { X.peer[q] = t->peer[q]; X.xoff[q] = t->xoff[q]; }
+    X.xcells = t->xcells; X.base = t->persist_base;        // the base of the persistent launch that follows in this step
+  }
   hipLaunchKernelGGL(k_ttm_activation, dim3(nblk(t->ninner, TTM_WG)), dim3(TTM_WG), 0, ctx->stream, L, t->natoms,
-                     t->natoms_old, t->temp[t->cur], t->xi, t->d_cand, t->d_cand + 2 * (size_t) t->ninner);
+                     t->natoms_old, t->temp[t->cur], t->xi, t->d_cand, t->d_cand + 2 * (size_t) t->ninner, X);
   hipLaunchKernelGGL(k_ttm_activation_seq, dim3(1), dim3(64), 0, ctx->stream, L, t->ee, t->natoms, t->temp[t->cur],
                      t->temp[t->cur ^ 1], t->U[t->cur], t->U[t->cur ^ 1], t->md_temp, t->dens, t->d_cand,
                      t->d_cand + t->ninner, t->d_cand + 2 * (size_t) t->ninner,
                      getenv("IMDGPU_ACT_RANKSORT_MAX") ? atoi(getenv("IMDGPU_ACT_RANKSORT_MAX")) : 1024);
   HIPCHK(hipGetLastError());
   return 0;
+}
+extern "C" int imdgpu_ttm_cell_activation(imdgpu_ctx *ctx)
+{
+  NEED_TTM();
+  return ttm_cell_activation(ctx, t, L, false);
 }
 
 static int ttm_fillmesh(imdgpu_ctx *ctx, TtmState *t, const Lat &L, int steps, int *bbox)
@@ -2420,22 +2465,27 @@ int imdgpu_ttm_chain_needs_lds(const imdgpu_ctx *ctx)
   return t->persist > 0 ? 0 : 1;
 }
 
-static int launch_persist(imdgpu_ctx *ctx, TtmState *t, const Lat &L, double tau, int mode, int steps, bool rem = false)
+// the descriptor of the NEXT launch (its tag base is taken, not advanced: launch_persist does that)
+static PersistDev persist_dev(imdgpu_ctx *ctx, TtmState *t, int mode, int steps, bool rem)
 {
   PersistDev P;
   P.xrec = rem ? t->d_xrec : nullptr; P.xcells = t->xcells;
   for (int q = 0; q < 6; q++) { P.peer[q] = rem ? t->peer[q] : nullptr; P.xoff[q] = t->xoff[q]; }
   P.census = t->d_pflags; P.gate = t->d_pflags + 1; P.rec = t->d_prec; P.ncell = t->ncell;
-  P.base = t->persist_base; t->persist_base += (unsigned) t->nsub + 1u;
+  P.base = t->persist_base;
   P.status = t->d_pstat; P.counters = ctx->d_counters;
   P.trusted = mode == 2; P.bbox = t->d_pbbox;
   P.extra_census = (ctx->ttm_persist_miss >= 0 && ctx->ttm_persist_miss == steps) ? 1 : 0;   // test hook: a census that cannot complete
+  return P;
+}
+static int launch_persist(imdgpu_ctx *ctx, TtmState *t, const Lat &L, double tau, int mode, int steps, bool rem = false)
+{
+  const PersistDev P = persist_dev(ctx, t, mode, steps, rem);
+  t->persist_base += (unsigned) t->nsub + 1u;
   HIPCHK(hipMemsetAsync(t->d_pflags, 0, (16 + 4) * sizeof(unsigned), ctx->stream));     // d_pstat follows d_pflags
   double *T0 = t->temp[t->cur], *T1 = t->temp[t->cur ^ 1], *U0 = t->U[t->cur], *U1 = t->U[t->cur ^ 1];
   double *K0 = t->fd_k[t->kcur], *K1 = t->fd_k[t->kcur ^ 1];
   const bool alone = ctx->stream != ctx->stream2;         // not forked beside the force pass: a stand-alone calc_ttm
-  if (rem)                                                // every face cell's atom count to the rank beyond it, active or not
-    hipLaunchKernelGGL(k_ttm_xrec_counts, dim3(nblk(t->xcells, 64)), dim3(64), 0, ctx->stream, L, P, t->natoms);
 #define PERSIST_LAUNCH(S, W, R)                                                                                                  \
   hipLaunchKernelGGL((k_ttm_chain_persist<S, W, R>), dim3(t->persist_tiles), dim3(64), 0, ctx->stream, L, tau, t->nsub, t->natoms, T0, T1, \
                      U0, U1, K0, K1, t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve, P)
@@ -2499,8 +2549,9 @@ extern "C" int imdgpu_ttm_lattice_step(imdgpu_ctx *ctx, int steps)
   const bool REMK = ctx->ttm_decomposed && pmode > 0;
   if (ctx->ttm_decomposed && !MBX && !REMK) return imdgpu_fail(ctx, "decomposed TTM lattice: imdgpu_ttm_mailbox_attach first (needed whenever the persistent kernel with remote records does not apply: step 0, odd sub-step counts)");
   imdgpu_tl_mark(ctx, "ttm_update_fd");
+  static const bool force_rem = getenv("IMDGPU_TTM_FORCE_REM") != nullptr;        // experiment: the remote-record build of the kernel on one rank's whole lattice
   if (t->laser_on && imdgpu_ttm_laser_rescale(ctx, &t->laser, steps)) return 1;   // update_fd has just zeroed the source
-  if (imdgpu_ttm_cell_activation(ctx)) return 1;
+  if (ttm_cell_activation(ctx, t, L, REMK)) return 1;      // with remote records: also every face cell's atom count to the rank beyond
   if (pmode > 0) HIPCHK(hipMemsetAsync(t->d_pbbox, 0, ((size_t) t->dim[0] + t->dim[1] + t->dim[2]) * sizeof(int), ctx->stream));
   if (ttm_fillmesh(ctx, t, L, steps, pmode > 0 ? t->d_pbbox : nullptr)) return 1;
   if (REMK) {
@@ -2520,7 +2571,7 @@ extern "C" int imdgpu_ttm_lattice_step(imdgpu_ctx *ctx, int steps)
     ProfScope ps(ctx, PROF_TTM_DIFF);
     const int gi = t->cur;
     if (REMK) { if (launch_persist(ctx, t, L, tau, 2, steps, true)) return 1; }     // no trial: other ranks wait for this one's records
-    else if (pmode > 0 && launch_persist(ctx, t, L, tau, pmode, steps)) return 1;
+    else if (pmode > 0 && launch_persist(ctx, t, L, tau, pmode, steps, force_rem)) return 1;
     const int *guard = (pmode == 1 && !REMK) ? t->d_pstat : nullptr;
     if (pmode == 2 || REMK) {
       // trusted: the persistent kernel alone
