@@ -53,7 +53,10 @@ int  imdgpu_set_stream(imdgpu_ctx *ctx, void *hip_stream);
 int  imdgpu_synchronize(imdgpu_ctx *ctx);
 /* tuning knobs: "mode" = 1 LDS-tiled force kernels (default), 0 global-gather kernels;
  * "ttm_persist" = 1 (default) all diffusion sub-steps of an MD step in one persistent launch where that applies,
- * 0 the captured chain of one launch per sub-step (same results bit for bit), -1 back to the default;
+ * 0 the captured chain of one launch per sub-step (same results bit for bit), -1 back to the default (a persistent launch
+ * that cannot run -- its workgroups not all resident in time, or an active region beyond its 1280 blocks -- touches nothing
+ * and the step is issued again through the chain: "ttm_persist_redone" counts those; setting the option also clears a
+ * reported hand-off time-out); "ttm_persist_miss" = MD step whose persistent launch is made to step aside (tests);
  * "p3_coef" = 1 (default) the EAM force pass (do_forces_eam2, imd_forces_nbl.c:789-985) reads DERIV_FUNC2's gradient
  * (potaccess.h:591-621) as one coefficient pair per table row where that applies (one atom type, pair_pot and rho_h_tab on
  * one r^2 grid, nothing with LDS tiles of its own beside it), 0 always as three table rows; the two agree to rounding */
@@ -62,7 +65,9 @@ int  imdgpu_set_option(imdgpu_ctx *ctx, const char *name, int value);
  * "fused_embedding" (1: the embedding pass runs inside the pass-1 kernel of the current list),
  * "ttm_flux", "ttm_adv", "ttm_block_width" (doubles per FD cell in imdgpu_ttm_local_block's records),
  * "ttm_persist_mode" (0 launch chain, 1 persistent kernel on trial with the chain behind it, 2 persistent kernel alone,
- * -1 not decided yet), "ttm_persist_runs" (persistent launches that came through), "kernel_rev",
+ * -1 not decided yet), "ttm_persist_runs" (persistent launches in a row that came through), "ttm_persist_redone" (MD steps
+ * re-issued through the launch chain), "p3_standin_passes" (EAM force passes in which the three-row kernel stood in for the
+ * coefficient form), "kernel_rev",
  * "p3_coef_rows" / "p3_coef_klo" (rows of the gradient-coefficient table the EAM force pass holds in LDS and the first
  * of them; 0 / -1: the three-row form) */
 int  imdgpu_get_info(imdgpu_ctx *ctx, const char *name, long long *value);
@@ -217,9 +222,10 @@ int imdgpu_ttm_update_fd(imdgpu_ctx *ctx, int steps);
  * FD cells, as the reference compiles it (ADVMODE 1 without ADV2D): x direction, lattice plane k = 1, then l1 <-> l2.
  * Needs update_fd's flux counters (option "ttm_flux"; option "ttm_adv" sets it and makes imdgpu_calc_ttm call
  * imdgpu_ttm_adv(1.0) after update_fd like calc_ttm :57-60).  On a lattice held as a whole (one rank, or the
- * replicated lattice of several ranks) do_COMMFLUX has nothing to move; on the decomposed lattice the host exchanges
- * the x faces of {flux[8], U} with imdgpu_ttm_commflux between update_fd and imdgpu_ttm_adv (ranks at the ends of the
- * x range do not wrap around, :724-760). */
+ * replicated lattice of several ranks: there every rank block's plane k = 1 is advected, as the ranks of the reference
+ * do between them) do_COMMFLUX has nothing to move; on the decomposed lattice imdgpu_dist_md_step exchanges the x faces
+ * of {flux[8], U} itself between update_fd and do_ADV (imdgpu_ttm_commflux is the pack / unpack half for hosts with a
+ * transport of their own; ranks at the ends of the x range do not wrap around, :724-760). */
 int imdgpu_ttm_adv(imdgpu_ctx *ctx, double tau, int steps);
 /* [do_COMMFLUX :667-995] dev_buf: 5 doubles per inner (j,k) = the eight counters as ints, then U.  unpack 0: side 0 packs
  * my column i = 1, side 1 my column lx-2; unpack 1: side 0 fills my ghost column i = 0, side 1 the ghost column lx-1 */
