@@ -72,6 +72,9 @@ def parse():
     ap.add_argument("--init-dist", action="store_true",
                     help="rehearsal with --force-distributed: a ONE-rank torch.distributed process group on --backend, so that the\n"
                          "host layer's nccl code path (object broadcast of the RCCL ids, all-reduces on device tensors) executes")
+    ap.add_argument("--halo-overlap", type=int, default=0,
+                    help="several ranks (or --force-distributed): pass 1 of the next step starts on interior tiles while its\n"
+                         "position halo travels on a stream of its own; the value = CUs the first launch leaves to the transport")
     ap.add_argument("--force-distributed", action="store_true",
                     help="rehearsal: run the multi-rank host layer (halo plan, gather/scatter, fork/join) on one rank")
     return ap.parse_args()
@@ -129,6 +132,8 @@ def build_system(args, rank, world, device, decomposed=False):
                      external_halo=args.force_distributed,
                      ttm_decomposed=ttm and (world > 1 or args.force_distributed) and decomposed)
     sysm.upload_tables(pair, rho, emb)
+    if args.halo_overlap > 0:
+        sysm.set_option("halo_overlap", args.halo_overlap)
     if ttm and adv_on(args):
         sysm.set_option("ttm_adv", 1)            # calc_ttm's own sequence: update_fd, do_ADV(1.0), activation, ... (:57-60)
     if ttm:
@@ -520,7 +525,10 @@ def main():
     entries, maxn = sysm.nblist_stats()
     M = entries / (2.0 * natoms)                       # half-list entries per atom
     prof = {k: sysm.profile_get(k) for k in ("pass1", "pass2", "pass3", "ghosts", "nblist", "fix_cells", "integrate",
-                                             "reduce", "ttm_update_fd", "ttm_diff", "ttm_fillmesh")}
+                                             "reduce", "ttm_update_fd", "ttm_diff", "ttm_fillmesh", "pass1b")}
+    overlap_passes = sysm.get_info("halo_overlap_passes")
+    if prof["pass1b"][0]:          # option halo_overlap: pass 1 ran as two launches from one tile queue; one pass = both
+        prof["pass1"] = (max(prof["pass1"][0], 1), prof["pass1"][1] + prof["pass1b"][1])
     sysm.profile(False)
     if rank == 0:
         # The two force passes share the top of the profile; `roofline` prices whichever of them took longer in THIS run
@@ -539,6 +547,9 @@ def main():
                 byts = natoms * (72.0 + 4.0 * M + (32.0 if fused else 0.0))
                 kn = ("k_pass1_tile_merged<%s, %s, %d>" % (ttmn, "true" if fused else "false", fcap)) if tiles else "k_pass1"
                 label = kn + (" (pass 1: pair + rho, embedding pass folded in)" if fused else " (pass 1: pair + rho)")
+                if prof["pass1b"][0]:
+                    kn = kn[:-1] + ", true>"
+                    label = kn + " (pass 1 from a tile queue under the position halo, two launches per pass: pair + rho, embedding pass folded in)"
             else:
                 byts = natoms * (84.0 + 4.0 * M)
                 # the coefficient form steps aside at run time when a pair falls below the rows it holds; the three-row kernel
@@ -557,8 +568,10 @@ def main():
                     "traffic": tr, "traffic_source": src, "algorithmic_bytes_per_launch": byts, "avg_launch_ms": avg,
                     "launches": n, "kernel_rev": krev}
         lattice_note = ""
+        if md is not None and overlap_passes > 0:
+            lattice_note += ", position halo under interior tiles of pass 1 (%d passes)" % overlap_passes
         if md is not None and not args.no_ttm:
-            lattice_note = (", TTM lattice decomposed (one block per rank, faces: %s)" %
+            lattice_note += (", TTM lattice decomposed (one block per rank, faces: %s)" %
                             ("ghost records in the neighbours' device memory" if sysm.get_info("ttm_remote") else "host mailbox")
                             if mode == "decomposed" else ", TTM lattice replicated (one all-gather per step)")
         r1, r3 = price("pass1"), price("pass3")

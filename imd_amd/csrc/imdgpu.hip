@@ -86,7 +86,7 @@ void imdgpu_tl_flush(imdgpu_ctx *c, int steps)
 
 static const char *prof_names[PROF_COUNT] = {
   "pass1", "pass2", "pass3", "ghosts", "nblist", "fix_cells", "integrate", "check", "reduce",
-  "ttm_update_fd", "ttm_diff", "ttm_fillmesh"};
+  "ttm_update_fd", "ttm_diff", "ttm_fillmesh", "pass1b"};
 
 Geo imdgpu_make_geo(const imdgpu_ctx *c)
 {
@@ -582,6 +582,10 @@ struct TileArgs {
   int *counters;
   double cellsz;
   const int *guard;               // pass 1 launched ahead of the host's look at the list-validity flag: *guard != 0 -> return at once
+  // k_pass1_tile_merged<.., DYN = true> (multi-rank step with the position halo in flight, imdgpu_dist.hip): tiles are taken from
+  // a work queue -- INTERIOR tiles (no ghost cell in their halo) first, boundary tiles only once *halo_flag >= halo_want --,
+  // tile_map[position] = tile, positions [0, n_interior) interior; dyn[0..7] / dyn[8..15] = per-XCD counters of the two classes
+  const int *tile_map; int n_interior; int *dyn; const int *halo_flag; int halo_want, part_off;
   float nbl_eps;                  // k_nbl_build_tile32: |r2 - cellsz| below which the single-precision test is not trusted (host: make_tile_args)
   int balance;                    // block ranges cut by cost (boxes with vacuum, moving surfaces) instead of by tiles
   const long long *wprefix;       // [ntiles + 1] cost prefix (k_tile_wprefix), read when balance is set
@@ -1139,7 +1143,9 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile32(TileArgs a)
 // Tile loop plumbing shared by the force kernels (see stage_issue / stage_commit).  The first list words and the
 // (slot, count) word of the thread's own atom do not depend on the staged positions: they are requested before
 // the barriers, so their latency is hidden as well.
-#define TILE_PROLOGUE(WITH_W, WITH_T, SW, TS, WSCALE)                                                                 \
+#define TILE_PROLOGUE(WITH_W, WITH_T, SW, TS, WSCALE) TILE_PROLOGUE_N(WITH_W, WITH_T, SW, TS, WSCALE, , (T.tile + 1 < t1 ? T.tile + 1 : -1))
+/* BETWEEN: statements between the two barriers (every thread is through with the previous tile); NEXT: the tile after this one, or -1 */
+#define TILE_PROLOGUE_N(WITH_W, WITH_T, SW, TS, WSCALE, BETWEEN, NEXT)                                             \
     T.own_start = info.y; T.nown = info.z;                                                                       \
     const unsigned dw = (unsigned) ((SLOTCAP(a) - 1) * NBR_SCALE) * 0x10001u;                                    \
     const uint2 dummyw = make_uint2(dw, dw);                                                                     \
@@ -1150,10 +1156,12 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile32(TileArgs a)
       ow0 = a.ownw[(size_t) T.tile * a.tile_cap + threadIdx.x]; w0 = lq[0]; w1 = lq[(size_t) a.tile_cap];       \
     }                                                                                                            \
     __syncthreads();                              /* every wave is done with the previous tile's LDS */          \
+    BETWEEN                                                                                                      \
     if (!(a.dbg & 2)) stage_commit<WITH_W, WITH_T>(a, T.tile, info.x, IDX, sp, SW, TS, WSCALE);                                          \
     __syncthreads();                                                                                             \
+    const int next_tile = NEXT;                                                                                  \
     int4 info_next = info;                                                                                       \
-    if (T.tile + 1 < t1) info_next = a.tinfo[T.tile + 1];
+    if (next_tile >= 0) info_next = a.tinfo[next_tile];
 #define OWN_PROLOGUE                                                                                             \
       const uint2 *lp = (const uint2 *) (a.nbr16 + lbase + o);                                                   \
       unsigned ow = ow0, c0x = w0.x, c0y = w0.y, c1x = w1.x, c1y = w1.y;   /* scalars: uint2 selects end up in scratch */ \
@@ -1210,7 +1218,7 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile32(TileArgs a)
 #define HALF_END SCHED_BARRIER; }
 #endif
 #define TILE_EPILOGUE                                                                                            \
-    if (T.tile + 1 < t1) stage_issue(a, T.tile + 1, info_next.x, IDX);                                           \
+    if (next_tile >= 0) stage_issue(a, next_tile, info_next.x, IDX);                                             \
     info = info_next;
 
 struct TabK { double begin, end, istep, istep2; };      // one column of a table (NT1 fast path)
@@ -1381,7 +1389,15 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile(TileArgs a)
 // FEMB: the embedding pass (pass 2, imd_forces_nbl.c:748-783) is folded into the epilogue -- with the full list rho of an
 // own atom is complete when its neighbour loop ends, so F(rho) and F'(rho) can be taken right there: no k_pass2 launch,
 // rho is not re-read, epot is written once.
-template <bool TTMN, bool FEMB, int CAP>
+// DYN: the tiles come from a work queue instead of a fixed range per workgroup (see TileArgs::tile_map): the position halo of a
+// multi-rank step is still in flight when this pass starts, so interior tiles go first and a workgroup that runs out of them
+// takes boundary tiles only if the halo has landed (a device word the halo's last kernel sets) -- otherwise it LEAVES (no spin: a
+// spinning persistent grid would keep the halo's kernels from being placed) and a second launch behind the halo's event takes
+// what is left.  Chunks of DYN_CHUNK consecutive positions (tiles that are neighbours along z: their halos overlap in L2), one
+// counter per XCD and class with stealing, so the blocks of an XCD still walk neighbouring tiles.  Energies are summed per
+// workgroup in the order the queue hands the tiles out: they differ from run to run in the last bits (forces do not).
+#define DYN_CHUNK 8
+template <bool TTMN, bool FEMB, int CAP, bool DYN = false>
 __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs a)
 {
   extern __shared__ double lds[];
@@ -1391,7 +1407,34 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
   double *scratch = sp + 3 * (size_t) SLOTCAP(a);
   double2 *tm = (double2 *) (scratch + 64);                     // (nrows + 3) rows; slot_cap is a multiple of 64: 16-byte aligned
   TileCtx T;
-  int t0, t1;
+  int t0 = 0, t1 = 0;
+  // ---- DYN: the queue ------------------------------------------------------------------------------------------------
+  __shared__ int s_dyn[2];                 // the chunk thread 0 has just taken: [begin, end) positions, or -1
+  int q_phase = 0, q_k = 0;                // thread 0: class being drained (0 interior, 1 boundary), XCDs tried so far in it
+  auto grab = [&]() {                      // thread 0 only
+    const int x0 = blockIdx.x & 7, nI = a.n_interior, nB = a.ntiles - a.n_interior;
+    for (;;) {
+      // acquire: the ghost positions the unpack kernel wrote (another XCD, its own L2) are read with plain loads after this
+      if (q_phase == 1 && q_k == 0 && a.halo_flag && __hip_atomic_load(a.halo_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < a.halo_want) break;
+      const int n = q_phase ? nB : nI, base = q_phase ? nI : 0;
+      for (; q_k < 8; q_k++) {
+        const int x = (x0 + q_k) & 7;
+        const int lo = (int) ((long long) n * x / 8), hi = (int) ((long long) n * (x + 1) / 8);
+        const int p = lo + atomicAdd(&a.dyn[8 * q_phase + x], DYN_CHUNK);
+        if (p < hi) { s_dyn[0] = base + p; s_dyn[1] = base + (p + DYN_CHUNK < hi ? p + DYN_CHUNK : hi); return; }
+      }
+      if (q_phase == 1) break;
+      q_phase = 1; q_k = 0;
+    }
+    s_dyn[0] = -1; s_dyn[1] = -1;
+  };
+  int pos = -1, pos_end = -1;
+  if constexpr (DYN) {
+    if (threadIdx.x == 0) grab();
+    __syncthreads();
+    pos = s_dyn[0]; pos_end = s_dyn[1];
+    t1 = pos >= 0 ? 1 : 0;                 // "this workgroup has work": the table is loaded below
+  } else
   block_tile_range(a.ntiles, a.wprefix, a.balance, t0, t1);
   double sums[3] = {0.0, 0.0, 0.0};        // pair energy, virial, embedding energy
   int is_short = 0;
@@ -1409,9 +1452,17 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
   const TabK c = {a.pair.begin[0], a.pair.end[0], a.pair.invstep[0], 2 * a.pair.invstep[0]};
   int4 info = make_int4(0, 0, 0, 0);
   int IDX[STG];
-  if (t0 < t1) { info = a.tinfo[t0]; stage_issue(a, t0, info.x, IDX); }
-  for (T.tile = t0; T.tile < t1; T.tile++) {
-    TILE_PROLOGUE(false, false, nullptr, nullptr, 1.0)
+  if constexpr (DYN) { T.tile = pos >= 0 ? a.tile_map[pos] : 0; t0 = 0; t1 = pos >= 0 ? 1 : 0; if (pos >= 0) { info = a.tinfo[T.tile]; stage_issue(a, T.tile, info.x, IDX); } }
+  else { if (t0 < t1) { info = a.tinfo[t0]; stage_issue(a, t0, info.x, IDX); } T.tile = t0; }
+  while (DYN ? pos >= 0 : T.tile < t1) {
+    // DYN: on the last tile of its chunk thread 0 takes the next chunk between the prologue's barriers (everybody is through
+    // with the previous iteration's read of s_dyn by then), all threads read it behind the second barrier
+    const bool last_of_chunk = DYN && pos + 1 >= pos_end;
+    TILE_PROLOGUE_N(false, false, nullptr, nullptr, 1.0,
+                    if (DYN && last_of_chunk && threadIdx.x == 0) grab();,
+                    (DYN ? (last_of_chunk ? (s_dyn[0] >= 0 ? a.tile_map[s_dyn[0]] : -1) : a.tile_map[pos + 1]) : (T.tile + 1 < t1 ? T.tile + 1 : -1)))
+    int npos = pos + 1, npos_end = pos_end;
+    if (DYN && last_of_chunk) { npos = s_dyn[0]; npos_end = s_dyn[1]; }
     for (int o = threadIdx.x; o < T.nown; o += blockDim.x) {
       const int i = T.own_start + o;
       OWN_PROLOGUE
@@ -1481,12 +1532,15 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
       sums[0] += ee; sums[1] += vir;
     }
     TILE_EPILOGUE
+    if constexpr (DYN) { pos = next_tile >= 0 ? npos : -1; pos_end = npos_end; T.tile = next_tile >= 0 ? next_tile : 0; }
+    else T.tile++;
   }
   block_sum<3>(sums, scratch);
   if (threadIdx.x == 0) {
-    a.partials[(size_t) blockIdx.x * IMDGPU_NPART + 0] = sums[0];
-    a.partials[(size_t) blockIdx.x * IMDGPU_NPART + 1] = sums[1];
-    if (FEMB) a.partials[(size_t) blockIdx.x * IMDGPU_NPART + 2] = sums[2];
+    const size_t pb = (size_t) blockIdx.x + (DYN ? (size_t) a.part_off : 0);
+    a.partials[pb * IMDGPU_NPART + 0] = sums[0];
+    a.partials[pb * IMDGPU_NPART + 1] = sums[1];
+    if (FEMB) a.partials[pb * IMDGPU_NPART + 2] = sums[2];
   }
   if (is_short) a.counters[CNT_IS_SHORT] = 1;
 #pragma unroll
@@ -1725,7 +1779,8 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) __attribute__((amdgpu_waves_per_eu
 
 // Deterministic final reduction of the per-block partial sums
 // (tot_pot_energy, virial: imd_forces_nbl.c:319-328,:496,:521,:760,:943).
-__global__ void k_reduce_force_sums(int nb1, int nb2, const double *partials, double *sums, int *counters)
+// nb1: workgroups of pass 1 (slots 0, 1), nb2: of the embedding pass (slot 2), nb3: of the EAM force pass (slot 3)
+__global__ void k_reduce_force_sums(int nb1, int nb2, int nb3, const double *partials, double *sums, int *counters)
 {
   if (threadIdx.x == 0) counters[CNT_KNEG] = 0;          // both guarded EAM force kernels of this step are through
   __shared__ double scratch[4 * 16];
@@ -1733,8 +1788,8 @@ __global__ void k_reduce_force_sums(int nb1, int nb2, const double *partials, do
   for (int b = threadIdx.x; b < nb1; b += blockDim.x) {
     v[0] += partials[(size_t) b * IMDGPU_NPART + 0];
     v[1] += partials[(size_t) b * IMDGPU_NPART + 1];
-    v[3] += partials[(size_t) b * IMDGPU_NPART + 3];
   }
+  for (int b = threadIdx.x; b < nb3; b += blockDim.x) v[3] += partials[(size_t) b * IMDGPU_NPART + 3];
   for (int b = threadIdx.x; b < nb2; b += blockDim.x) v[2] += partials[(size_t) b * IMDGPU_NPART + 2];
   block_sum<4>(v, scratch);
   if (threadIdx.x == 0) {
@@ -1870,6 +1925,8 @@ extern "C" void imdgpu_destroy(imdgpu_ctx *c)
   if (c->d_refperm) (void) hipFree(c->d_refperm);
   if (c->d_stage) (void) hipFree(c->d_stage);
   if (c->d_wprefix) (void) hipFree(c->d_wprefix);
+  if (c->d_tile_map) (void) hipFree(c->d_tile_map);
+  if (c->d_dyn) (void) hipFree(c->d_dyn);
   void *ptrs[] = {c->pos, c->type, c->id, c->acell, c->p, c->f, c->ref, c->mass, c->epot, c->rhoh, c->numneighs,
                   c->pos2, c->type2, c->id2, c->p2, c->mass2, c->nn2, c->fdc, c->fdc2, c->keys, c->keys2, c->perm, c->perm2,
                   c->cub_tmp, c->cell_start, c->cell_cnt, c->icnt, c->istart, c->gcell_lin, c->gcell_src,
@@ -1907,6 +1964,9 @@ extern "C" int imdgpu_set_option(imdgpu_ctx *ctx, const char *name, int value)
   if (!strcmp(name, "p3_klo")) { ctx->p3_klo = value > 0 ? value : 0; return 0; }           // tests: which rows k_pass3_tile_coef holds
   if (!strcmp(name, "eos_bilinear")) { ctx->eos_bilinear = value ? 1 : 0; return 0; }    // before ttm_init / ttm1d_init
   if (!strcmp(name, "ttm_persist")) { imdgpu_ttm_set_persist(ctx, value < 0 ? -1 : (value ? 1 : 0)); return 0; }
+  // several ranks: pass 1 of the next step starts on interior tiles while its position halo travels (imdgpu_dist.hip); the value is
+  // the number of CUs the first launch leaves to the transport's kernels
+  if (!strcmp(name, "halo_overlap")) { ctx->halo_overlap = value < 0 ? 0 : (value > 64 ? 64 : value); ctx->dyn_ntiles = -1; imdgpu_dist_cancel_ahead(ctx); return 0; }
   if (!strcmp(name, "ttm_persist_miss")) { ctx->ttm_persist_miss = value; return 0; }      // tests: the MD step whose persistent launch cannot complete its census
   if (!strcmp(name, "ttm_decomposed")) {         // before ttm_init
     if (ctx->ttm) return imdgpu_fail(ctx, "ttm_decomposed must be set before ttm_init");
@@ -1946,7 +2006,8 @@ extern "C" int imdgpu_get_info(imdgpu_ctx *ctx, const char *name, long long *val
     // MD steps whose sub-steps the host issued again through the launch chain because the persistent kernel had stepped aside
     {"ttm_persist_redone", imdgpu_ttm_persist_info(ctx, 3)},
     // EAM force passes so far in which the three-row kernel stood in for the coefficient form (as of the last md_step / calc_forces)
-    {"p3_standin_passes", ctx->h_counters ? ctx->h_counters[CNT_P3_STANDIN] : 0}};
+    {"p3_standin_passes", ctx->h_counters ? ctx->h_counters[CNT_P3_STANDIN] : 0},
+    {"halo_overlap_passes", ctx->dyn_seq}, {"halo_overlap_interior_tiles", ctx->dyn_ntiles == ctx->ntiles ? ctx->n_interior : -1}};       // pass-1 launch pairs under a position halo in flight (option halo_overlap)
   for (auto &e : tab) if (!strcmp(name, e.n)) { *value = e.v; return 0; }
   return imdgpu_fail(ctx, "unknown info %s", name);
 }
@@ -1994,7 +2055,7 @@ static int setup_tiles(imdgpu_ctx *ctx)
     src[q] = x[0] >= 0 ? xyz_to_key(x[0], x[1], x[2], g) : -1;
   }
   HIPCHK(hipMemcpy(ctx->gcell_src, src.data(), ng * sizeof(int), hipMemcpyHostToDevice));
-  int nb = std::max(nblk(ctx->cap_local, 256) + 8, ((ctx->ntiles + 7) / 8) * 8 + 8);
+  int nb = std::max(nblk(ctx->cap_local, 256) + 8, 2 * (((ctx->ntiles + 7) / 8) * 8 + 8));    // twice: pass 1 in two launches (imdgpu_launch_pass1_dyn)
   if (nb > ctx->npart_blocks) {
     if (dev_alloc(ctx, &ctx->partials, (size_t) nb * IMDGPU_NPART)) return 1;
     ctx->npart_blocks = nb;
@@ -2270,7 +2331,7 @@ static int ensure_atom_capacity(imdgpu_ctx *ctx, int nlocal, int ntot)
     HIPCHK(hipMemset(ctx->numneighs, 0, cap * sizeof(int)));
     HIPCHK(hipMemset(ctx->ref, 0, 3 * (size_t) cap * sizeof(double)));
     ctx->cap_local = cap;
-    int nb = std::max(nblk(cap, 256) + 8, ((ctx->ntiles + 7) / 8) * 8 + 8);
+    int nb = std::max(nblk(cap, 256) + 8, 2 * (((ctx->ntiles + 7) / 8) * 8 + 8));
     if (dev_alloc(ctx, &ctx->partials, (size_t) nb * IMDGPU_NPART)) return 1;
     ctx->npart_blocks = nb;
     ctx->nbr_cap = 0;                        // list must be re-allocated for the new stride
@@ -2840,6 +2901,7 @@ static int launch_forces(imdgpu_ctx *ctx, int phase = 0)
   const bool fastcap = fastcap_env && TILE && ctx->slot_cap == FAST_CAP;       // the neighbour loops compiled for this plane stride
   size_t lds1 = ((PAIR ? a.pair.nrows * a.pair.ncols : 0) + (EAM ? a.rho.nrows * a.rho.ncols : 0) + 64) * sizeof(double);
   if (phase == 0 || phase == 1) {
+    ctx->dyn_nb[0] = ctx->dyn_nb[1] = 0;
     HIPCHK(hipMemsetAsync(ctx->d_counters + CNT_IS_SHORT, 0, sizeof(int), ctx->stream));
     ProfScope ps(ctx, PROF_PASS1);
 #define L1(P, E, T, N)                                                                                          \
@@ -2931,9 +2993,77 @@ static int launch_forces(imdgpu_ctx *ctx, int phase = 0)
   }
   if (phase == 0 || phase == 3) {
     ProfScope ps(ctx, PROF_REDUCE);
-    hipLaunchKernelGGL(k_reduce_force_sums, dim3(1), dim3(1024), 0, ctx->stream, nb, EAM ? nb2 : 0, ctx->partials, ctx->d_sums, ctx->d_counters);
+    const int nbd = ctx->dyn_nb[0] + ctx->dyn_nb[1];          // pass 1 ran in its two-launch form (imdgpu_launch_pass1_dyn): embedding fused
+    hipLaunchKernelGGL(k_reduce_force_sums, dim3(1), dim3(1024), 0, ctx->stream, nbd ? nbd : nb, EAM ? (nbd ? nbd : nb2) : 0, nb, ctx->partials,
+                       ctx->d_sums, ctx->d_counters);
   }
   imdgpu_tl_mark(ctx, "pass3");
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---- pass 1 from a tile queue (k_pass1_tile_merged<.., DYN>) -----------------------------------------------------------------
+int imdgpu_pass1_dyn_ready(const imdgpu_ctx *ctx)
+{
+  return ctx->halo_overlap > 0 && ctx->list_mode == 1 && ctx->pair.present && ctx->rho.present && ctx->ntypes == 1 && ctx->d_merged &&
+         fuse_emb(ctx) && ctx->d_tile_map && ctx->dyn_ntiles == ctx->ntiles && !ctx->after_pass1;
+}
+int imdgpu_pass1_dyn_prepare(imdgpu_ctx *ctx, const int remote[3])
+{
+  ctx->dyn_ntiles = -1;
+  if (ctx->halo_overlap <= 0 || ctx->list_mode != 1) return 0;
+  HIPCHK(hipSetDevice(ctx->device));
+  const int *nt = ctx->ntile;
+  std::vector<int> map((size_t) ctx->ntiles);
+  size_t nI = 0;
+  for (int pass = 0; pass < 2; pass++)              // interior tiles in tile order (z fastest), then the boundary tiles
+    for (int t = 0, w = (int) nI; t < ctx->ntiles; t++) {
+      const int c[3] = {t / (nt[1] * nt[2]), (t / nt[2]) % nt[1], t % nt[2]};
+      bool bnd = false;
+      for (int d = 0; d < 3; d++) bnd = bnd || (remote[d] && (c[d] == 0 || c[d] == nt[d] - 1));
+      if (pass == 0 && !bnd) map[nI++] = t;
+      if (pass == 1 && bnd) map[(size_t) w++] = t;
+    }
+  if (ctx->tile_map_cap < map.size()) { if (dev_alloc(ctx, &ctx->d_tile_map, map.size())) return 1; ctx->tile_map_cap = map.size(); }
+  if (!ctx->d_dyn) { if (dev_alloc(ctx, &ctx->d_dyn, 32)) return 1; HIPCHK(hipMemset(ctx->d_dyn, 0, 32 * sizeof(int))); }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpy(ctx->d_tile_map, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
+  ctx->n_interior = (int) nI; ctx->dyn_ntiles = ctx->ntiles;
+  return 0;
+}
+int imdgpu_launch_pass1_dyn(imdgpu_ctx *ctx, int part)
+{
+  if (!imdgpu_pass1_dyn_ready(ctx)) return imdgpu_fail(ctx, "internal: pass 1 has no tile queue");
+  const bool TT = ctx->count_ttm != 0;
+  static const int fastcap_env = getenv("IMDGPU_FAST_CAP") ? atoi(getenv("IMDGPU_FAST_CAP")) : 1;
+  const bool fastcap = fastcap_env && ctx->slot_cap == FAST_CAP;
+  const int B = ctx->tile_threads, full = tile_grid(ctx);
+  // the first launch leaves halo_overlap CUs alone: the transport's kernels (RCCL's, the unpack) need somewhere to run
+  const int nb = part == 0 ? std::max(1, full - ctx->halo_overlap) : full;
+  if (part == 0) {
+    HIPCHK(hipMemsetAsync(ctx->d_counters + CNT_IS_SHORT, 0, sizeof(int), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_dyn, 0, 16 * sizeof(int), ctx->stream));
+    ctx->dyn_seq++;
+    ctx->dyn_nb[0] = nb; ctx->dyn_nb[1] = 0;
+  } else ctx->dyn_nb[1] = nb;
+  if (ctx->dyn_nb[0] + ctx->dyn_nb[1] > ctx->npart_blocks) return imdgpu_fail(ctx, "internal: partials too small");
+  TileArgs ta = make_tile_args(ctx);
+  ta.guard = ctx->pass1_guard;
+  ta.tile_map = ctx->d_tile_map; ta.n_interior = ctx->n_interior; ta.dyn = ctx->d_dyn;
+  ta.halo_flag = part == 0 ? ctx->d_dyn + 16 : nullptr; ta.halo_want = ctx->dyn_seq; ta.part_off = part == 0 ? 0 : ctx->dyn_nb[0];
+  const size_t l = tile_lds_bytes(ctx, 1);
+  {
+    ProfScope ps(ctx, part == 0 ? PROF_PASS1 : PROF_PASS1B);
+#define LD(T, C)                                                                                                     \
+  do {                                                                                                               \
+    HIPCHK(hipFuncSetAttribute((const void *) k_pass1_tile_merged<T, true, C, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) l)); \
+    hipLaunchKernelGGL((k_pass1_tile_merged<T, true, C, true>), dim3(nb), dim3(B), l, ctx->stream, ta);              \
+  } while (0)
+    if (TT) { if (fastcap) LD(true, FAST_CAP); else LD(true, 0); }
+    else { if (fastcap) LD(false, FAST_CAP); else LD(false, 0); }
+#undef LD
+  }
+  imdgpu_tl_mark(ctx, part == 0 ? "pass1A" : "pass1B");
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -71,6 +71,9 @@ static const char *rccl_load()
 struct DistState {
   int nranks = 1, rank = 0;
   ncclComm_t comm = nullptr, comm2 = nullptr;      // comm: halo + flag on the main stream; comm2: TTM all-gather on the lattice stream
+  ncclComm_t comm3 = nullptr;                      // the position halo on its own stream under interior tiles of pass 1 (option halo_overlap)
+  hipStream_t stream3 = nullptr; hipEvent_t ev_fork3 = nullptr, ev_halo = nullptr;
+  int remote[3]{0, 0, 0};                          // dimension d has a neighbour rank other than this one (or the self-message rehearsal is on)
   imdgpu_exchange_fn cb = nullptr; void *cb_user = nullptr;
   // plan of the current list (atoms)
   int nsend = 0, nrecv = 0;
@@ -106,6 +109,10 @@ void imdgpu_dist_free(imdgpu_ctx *ctx)
   if (!D) return;
   if (D->comm && g_rccl.CommDestroy) (void) g_rccl.CommDestroy(D->comm);
   if (D->comm2 && g_rccl.CommDestroy) (void) g_rccl.CommDestroy(D->comm2);
+  if (D->comm3 && g_rccl.CommDestroy) (void) g_rccl.CommDestroy(D->comm3);
+  if (D->stream3) (void) hipStreamDestroy(D->stream3);
+  if (D->ev_fork3) (void) hipEventDestroy(D->ev_fork3);
+  if (D->ev_halo) (void) hipEventDestroy(D->ev_halo);
   void *ptrs[] = {D->d_send_idx, D->d_seg_of, D->d_self_dst, D->d_recv_self, D->d_shift, D->sendbuf, D->recvbuf, D->d_flag, D->ttm_blk, D->ttm_all, D->d_ttm_offs, D->fluxbuf};
   for (void *p : ptrs) if (p) (void) hipFree(p);
   if (D->h_flag) (void) hipHostFree(D->h_flag);
@@ -130,16 +137,21 @@ static int dist_new(imdgpu_ctx *ctx, int nranks, int rank)
   HIPCHK(hipMalloc((void **) &D->d_shift, 3 * MAXSEG * sizeof(double)));
   HIPCHK(hipEventCreateWithFlags(&D->ev_flag, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&D->ev_gathered, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&D->ev_fork3, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&D->ev_halo, hipEventDisableTiming));
+  HIPCHK(hipStreamCreateWithFlags(&D->stream3, hipStreamNonBlocking));
   D->self_comm = getenv("IMDGPU_DIST_SELF_COMM") != nullptr;   // rehearsal: self-neighbour segments go through the transport too
   return 0;
 }
 
-// rank 0: two RCCL unique ids (2 x 128 bytes), to be broadcast to the other ranks by the launcher (MPI_Bcast, a file, ...)
+// rank 0: RCCL unique ids of 128 bytes each, as many as the buffer holds (two at least, three at most), to be broadcast to the other
+// ranks by the launcher (MPI_Bcast, a file, ...).  The third one gives the position halo its own communicator (option halo_overlap).
 extern "C" int imdgpu_dist_unique_id(void *out, int nbytes)
 {
   const char *e = rccl_load();
   if (e || nbytes < 2 * (int) sizeof(ncclUniqueId)) return 1;
-  for (int k = 0; k < 2; k++) {
+  const int n = nbytes >= 3 * (int) sizeof(ncclUniqueId) ? 3 : 2;
+  for (int k = 0; k < n; k++) {
     ncclUniqueId id;
     if (g_rccl.GetUniqueId(&id) != ncclSuccess) return 1;
     memcpy((char *) out + k * sizeof(id), &id, sizeof(id));
@@ -151,12 +163,14 @@ extern "C" int imdgpu_dist_init_rccl(imdgpu_ctx *ctx, int nranks, int rank, cons
 {
   const char *e = rccl_load();
   if (e) return imdgpu_fail(ctx, "dist_init_rccl: %s", e);
-  if (nbytes != 2 * (int) sizeof(ncclUniqueId)) return imdgpu_fail(ctx, "dist_init_rccl: unique id must be %d bytes (imdgpu_dist_unique_id)", 2 * (int) sizeof(ncclUniqueId));
+  const int n = nbytes / (int) sizeof(ncclUniqueId);
+  if ((n != 2 && n != 3) || nbytes != n * (int) sizeof(ncclUniqueId))
+    return imdgpu_fail(ctx, "dist_init_rccl: unique id must be 2 or 3 x %d bytes (imdgpu_dist_unique_id)", (int) sizeof(ncclUniqueId));
   if (dist_new(ctx, nranks, rank)) return 1;
-  for (int k = 0; k < 2; k++) {
+  for (int k = 0; k < n; k++) {
     ncclUniqueId id;
     memcpy(&id, (const char *) unique_id + k * sizeof(id), sizeof(id));
-    ncclResult_t r = g_rccl.CommInitRank(k ? &DS(ctx)->comm2 : &DS(ctx)->comm, nranks, id, rank);
+    ncclResult_t r = g_rccl.CommInitRank(k == 0 ? &DS(ctx)->comm : k == 1 ? &DS(ctx)->comm2 : &DS(ctx)->comm3, nranks, id, rank);
     if (r != ncclSuccess) return imdgpu_fail(ctx, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(r));
   }
   return 0;
@@ -285,8 +299,9 @@ __global__ void k_dist_unpack(int what, long long n, int nlocal, const unsigned 
   else { const double *q = in + 3 * m; pos[i].x = q[0]; pos[i].y = q[1]; pos[i].z = q[2]; }
 }
 // one exchange of `w` doubles per atom following the plan, on the context's stream
-static int dist_exchange(imdgpu_ctx *ctx, DistState *D, int w)
+static int dist_exchange(imdgpu_ctx *ctx, DistState *D, int w, ncclComm_t comm = nullptr)
 {
+  if (!comm) comm = D->comm;
   std::vector<long long> so, sc, ro, rc; std::vector<int> sp, rp;
   // consecutive segments of one peer are one message (the plan lays the segments out peer by peer); an empty segment does
   // not break a stretch (it occupies no buffer space), both sides see the same counts and merge alike
@@ -303,8 +318,8 @@ static int dist_exchange(imdgpu_ctx *ctx, DistState *D, int w)
   if (sp.empty() && rp.empty()) return 0;
   if (D->comm) {
     NCCLCHK(g_rccl.GroupStart());
-    for (size_t s = 0; s < sp.size(); s++) NCCLCHK(g_rccl.Send(D->sendbuf + so[s], (size_t) sc[s], ncclDouble, sp[s], D->comm, ctx->stream));
-    for (size_t s = 0; s < rp.size(); s++) NCCLCHK(g_rccl.Recv(D->recvbuf + ro[s], (size_t) rc[s], ncclDouble, rp[s], D->comm, ctx->stream));
+    for (size_t s = 0; s < sp.size(); s++) NCCLCHK(g_rccl.Send(D->sendbuf + so[s], (size_t) sc[s], ncclDouble, sp[s], comm, ctx->stream));
+    for (size_t s = 0; s < rp.size(); s++) NCCLCHK(g_rccl.Recv(D->recvbuf + ro[s], (size_t) rc[s], ncclDouble, rp[s], comm, ctx->stream));
     NCCLCHK(g_rccl.GroupEnd());
     return 0;
   }
@@ -315,23 +330,31 @@ static int dist_exchange(imdgpu_ctx *ctx, DistState *D, int w)
   return 0;
 }
 
-extern "C" int imdgpu_dist_halo(imdgpu_ctx *ctx, int what)
+// parts: 1 = the gather (send buffer; ghost atoms this rank supplies to itself are written in place), 2 = messages + unpack
+static int dist_halo_parts(imdgpu_ctx *ctx, DistState *D, int what, int parts, ncclComm_t comm = nullptr)
 {
-  NEED_DIST();
   if (!D->have_plan) return imdgpu_fail(ctx, "dist_halo: no plan (imdgpu_dist_set_plan after the ghost layout)");
   if (what < 0 || what > 3) return imdgpu_fail(ctx, "dist_halo: what must be 0..3");
   const int w = what_width(what);
   ProfScope ps(ctx, PROF_GHOSTS);
-  if (D->nsend_atoms > 0)
+  if ((parts & 1) && D->nsend_atoms > 0)
     hipLaunchKernelGGL(k_dist_gather, dim3(nblk(D->nsend_atoms, 256)), dim3(256), 0, ctx->stream, what, D->nsend_atoms, D->d_send_idx,
                        D->d_seg_of, D->d_self_dst, D->d_shift, ctx->pos, ctx->type, D->sendbuf);
-  if (dist_exchange(ctx, D, w)) return 1;
-  if (D->nrecv_atoms > D->nself_atoms)                    // something did arrive through the buffers
-    hipLaunchKernelGGL(k_dist_unpack, dim3(nblk(D->nrecv_atoms, 256)), dim3(256), 0, ctx->stream, what, D->nrecv_atoms, ctx->nlocal,
-                       D->d_recv_self, D->recvbuf, ctx->pos, ctx->type);
+  if (parts & 2) {
+    if (dist_exchange(ctx, D, w, comm)) return 1;
+    if (D->nrecv_atoms > D->nself_atoms)                    // something did arrive through the buffers
+      hipLaunchKernelGGL(k_dist_unpack, dim3(nblk(D->nrecv_atoms, 256)), dim3(256), 0, ctx->stream, what, D->nrecv_atoms, ctx->nlocal,
+                         D->d_recv_self, D->recvbuf, ctx->pos, ctx->type);
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }
+extern "C" int imdgpu_dist_halo(imdgpu_ctx *ctx, int what)
+{
+  NEED_DIST();
+  return dist_halo_parts(ctx, D, what, 3);
+}
+__global__ void k_dist_set_word(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 
 // MAX over the ranks of this rank's list-validity flag (check_nblist's MPI_Allreduce, imd_forces_nbl.c:1087) -> d_flag[0]
 // flag[1]: a time-out of the lattice's hand-offs (persistent sub-step kernel, mailbox) on ANY rank fails the step everywhere
@@ -466,18 +489,47 @@ extern "C" int imdgpu_dist_md_step(imdgpu_ctx *ctx, int steps, int *rebuild_need
   // device has work while the host reads the flag
   const bool spec = !getenv("IMDGPU_NO_SPECULATION");
   auto drop_ahead = [&]() {           // the guarded launch did nothing: it must not count as a pass-1 launch in the kernel timings
-    for (size_t q = ctx->ev_pending.size(); q-- > 0;)
-      if (ctx->ev_pending[q].id == PROF_PASS1) {
-        ctx->ev_pool.push_back(ctx->ev_pending[q].a); ctx->ev_pool.push_back(ctx->ev_pending[q].b);
-        ctx->ev_pending.erase(ctx->ev_pending.begin() + q);
-        break;
-      }
+    for (int id : {(int) PROF_PASS1B, (int) PROF_PASS1})
+      for (size_t q = ctx->ev_pending.size(); q-- > 0;)
+        if (ctx->ev_pending[q].id == id) {
+          ctx->ev_pool.push_back(ctx->ev_pending[q].a); ctx->ev_pool.push_back(ctx->ev_pending[q].b);
+          ctx->ev_pending.erase(ctx->ev_pending.begin() + q);
+          break;
+        }
   };
+  // Option halo_overlap: the position halo travels on its own stream (and communicator) while pass 1 -- in its queue form, two
+  // launches -- works through the tiles whose halo cells hold no atom of another rank; see k_pass1_tile_merged<.., DYN>.
+  // Order on the main stream: gather (it also writes the ghost atoms this rank supplies to itself), the flags' all-reduce (the
+  // guard of both launches), launch A; on the halo stream behind the gather: messages, unpack, "landed" word; launch B behind that.
+  if (spec && ctx->halo_overlap > 0 && ctx->dyn_ntiles != ctx->ntiles && imdgpu_pass1_dyn_prepare(ctx, D->remote)) return 1;
+  const bool overlap = spec && imdgpu_pass1_dyn_ready(ctx) && (!D->comm || D->comm3);
   for (int round = 0;; round++) {
-    if (imdgpu_dist_halo(ctx, 3)) return 1;
+    if (overlap) { if (dist_halo_parts(ctx, D, 3, 1)) return 1; }
+    else if (imdgpu_dist_halo(ctx, 3)) return 1;
     if (dist_flag_allreduce(ctx, D)) return 1;
     HIPCHK(hipMemcpyAsync(D->h_flag, D->d_flag, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipEventRecord(D->ev_flag, ctx->stream));
+    if (overlap) {
+      HIPCHK(hipEventRecord(D->ev_fork3, ctx->stream));
+      ctx->pass1_guard = D->d_flag + 3;
+      int rc = imdgpu_launch_pass1_dyn(ctx, 0);
+      hipStream_t main = ctx->stream;
+      if (!rc) {
+        ctx->stream = D->stream3;
+        if (hipStreamWaitEvent(ctx->stream, D->ev_fork3, 0) != hipSuccess) rc = imdgpu_fail(ctx, "hipStreamWaitEvent failed");
+        if (!rc) rc = dist_halo_parts(ctx, D, 3, 2, D->comm3);
+        if (!rc) {
+          hipLaunchKernelGGL(k_dist_set_word, dim3(1), dim3(1), 0, ctx->stream, ctx->d_dyn + 16, ctx->dyn_seq);
+          if (hipEventRecord(D->ev_halo, ctx->stream) != hipSuccess) rc = imdgpu_fail(ctx, "hipEventRecord failed");
+        }
+        imdgpu_tl_mark(ctx, "halo3");
+        ctx->stream = main;
+      }
+      if (!rc && hipStreamWaitEvent(ctx->stream, D->ev_halo, 0) != hipSuccess) rc = imdgpu_fail(ctx, "hipStreamWaitEvent failed");
+      if (!rc) rc = imdgpu_launch_pass1_dyn(ctx, 1);
+      ctx->pass1_guard = nullptr;
+      if (rc) return 1;
+    } else
     if (spec) {
       ctx->pass1_guard = D->d_flag + 3;
       int rc = imdgpu_launch_forces_phase(ctx, 1);
@@ -1166,6 +1218,8 @@ extern "C" int imdgpu_dist_rebuild(imdgpu_ctx *ctx)
   if (ctx->ntypes > 1 && imdgpu_dist_halo(ctx, 2)) return 1;
   if (T) { HIPCHK(hipStreamSynchronize(ctx->stream)); P->ms[3] = ms_since(t); }
   if (imdgpu_make_nblist(ctx)) return 1;
+  for (int d = 0; d < 3; d++) D->remote[d] = ctx->cpu_dim[d] > 1 || D->self_comm;
+  if (imdgpu_pass1_dyn_prepare(ctx, D->remote)) return 1;       // option halo_overlap: the queue order of the tiles
   if (T) {
     HIPCHK(hipStreamSynchronize(ctx->stream)); P->ms[4] = ms_since(t);
     fprintf(stderr, "[dist rebuild %d, native] ms: migrate %.2f, fix_cells %.2f, plan %.2f, exchange %.2f, make_nblist %.2f\n", P->nrebuild,

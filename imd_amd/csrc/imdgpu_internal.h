@@ -27,7 +27,7 @@ struct DevTable {
 enum ProfId {
   PROF_PASS1 = 0, PROF_PASS2, PROF_PASS3, PROF_GHOSTS, PROF_NBLIST, PROF_FIXCELLS,
   PROF_INTEGRATE, PROF_CHECK, PROF_REDUCE, PROF_TTM_UPDATE, PROF_TTM_DIFF,
-  PROF_TTM_FILL, PROF_COUNT
+  PROF_TTM_FILL, PROF_PASS1B, PROF_COUNT
 };
 
 struct ProfPending { hipEvent_t a, b; int id; };
@@ -144,6 +144,12 @@ struct imdgpu_ctx {
   void *dist = nullptr;
   int step_open = 0;                  // imdgpu_md_step_begin has enqueued a step that imdgpu_md_step_end has not closed yet
   const int *pass1_guard = nullptr;   // device int: a pass-1 kernel launched AHEAD of the host's look at the list-validity flag returns at once when it is set
+  // pass 1 under the position halo (option "halo_overlap", imdgpu_dist.hip): tiles from a work queue, interior ones first
+  int halo_overlap = 0;               // option: 0 off, n > 0: on, the first launch leaves n CUs to the transport's kernels
+  int *d_tile_map = nullptr; size_t tile_map_cap = 0; int dyn_ntiles = -1, n_interior = 0;   // queue order of the tiles (imdgpu_pass1_dyn_prepare)
+  int *d_dyn = nullptr;               // [0..15] queue counters, [16] "the halo of launch pair number n has landed"
+  int dyn_seq = 0;                    // launch pairs so far
+  int dyn_nb[2]{0, 0};                // workgroups of the two launches of the pass 1 now in d_partials (0, 0: the one-launch form)
 };
 
 int imdgpu_fail(imdgpu_ctx *c, const char *fmt, ...);
@@ -233,6 +239,12 @@ enum { SUM_EPOT = 0, SUM_VIRIAL = 1, SUM_EKIN = 8, SUM_MAXDISP = 9, SUM_N = 16 }
 int imdgpu_ensure_capacity(imdgpu_ctx *ctx, int nlocal, int ntot);
 int imdgpu_launch_forces_phase(imdgpu_ctx *ctx, int phase);
 int imdgpu_launch_integrate(imdgpu_ctx *ctx);
+// pass 1 in two launches from a tile queue: remote[d] != 0 = the ghost cells at the two ends of dimension d arrive through the
+// transport (everything else is in place when the first launch starts).  prepare: once per list; ready: this context's pass 1 has
+// the queue form; launch(part 0): interior tiles, boundary tiles as far as the halo word allows; launch(part 1): the rest
+int imdgpu_pass1_dyn_prepare(imdgpu_ctx *ctx, const int remote[3]);
+int imdgpu_pass1_dyn_ready(const imdgpu_ctx *ctx);
+int imdgpu_launch_pass1_dyn(imdgpu_ctx *ctx, int part);
 int imdgpu_p3_coef_active(const imdgpu_ctx *ctx);
 int imdgpu_ttm_chain_needs_lds(const imdgpu_ctx *ctx);
 

@@ -805,12 +805,12 @@ class GpuOps:
         if use_rccl:
             uid = [None]
             if rank == 0:
-                buf = C.create_string_buffer(256)
-                self._ck(self.L.imdgpu_dist_unique_id(buf, 256))
+                buf = C.create_string_buffer(384)          # three ids: halo + flags, lattice, the position halo under pass 1
+                self._ck(self.L.imdgpu_dist_unique_id(buf, 384))
                 uid[0] = bytes(buf.raw)
             if dist.is_initialized():
                 dist.broadcast_object_list(uid, src=0)
-            self._ck(self.L.imdgpu_dist_init_rccl(self.h, world, rank, uid[0], 256))
+            self._ck(self.L.imdgpu_dist_init_rccl(self.h, world, rank, uid[0], 384))
             self.transport = "rccl"
         else:
             self._cb = make_host_transport(self, rank, world)

@@ -60,6 +60,8 @@ def main():
         miss = os.environ.get("IMD_TEST_PERSIST_MISS", "")         # "<rank>:<step>": that rank's persistent sub-step launch of that step steps aside
         if miss and int(miss.split(":")[0]) == rank:
             s.set_option("ttm_persist_miss", int(miss.split(":")[1]))
+        if os.environ.get("IMD_TEST_HALO_OVERLAP"):                # pass 1 in its queue form under the position halo
+            s.set_option("halo_overlap", int(os.environ["IMD_TEST_HALO_OVERLAP"]))
         ops = GpuOps(s, 0)
         md = DistributedMD(dec, ops, ttm=ttm, local_group=group)
         assert md.native_rebuild
@@ -76,7 +78,8 @@ def main():
             lat = {k: L1[k] for k in ("temp", "xi", "natoms", "md_temp", "dens", "U", "source", "natomsglobal", "xiarr_global")}
         info = dict(nrebuild=md.nrebuild, transport=ops.transport, list_mode=s.get_info("list_mode"),
                     persist=s.get_info("ttm_persist_mode") if ttm else -9, remote=s.get_info("ttm_remote") if ttm else -9,
-                    runs=s.get_info("ttm_persist_runs") if ttm else -9, redone=redone)
+                    runs=s.get_info("ttm_persist_runs") if ttm else -9, redone=redone, overlapped=s.get_info("halo_overlap_passes"),
+                    interior=s.get_info("halo_overlap_interior_tiles"), ntiles=s.get_info("ntiles"))
         group.barrier()                       # nobody tears its context down while another rank still runs kernels against it
         s.close()
         return dict(d=d, lat=lat, sums=sums, coord=dec.coord, info=info)
@@ -95,6 +98,9 @@ def main():
         out["r%d_remote" % r] = R["info"]["remote"]
         out["r%d_persist_runs" % r] = R["info"]["runs"]
         out["r%d_persist_redone" % r] = R["info"]["redone"]
+        out["r%d_overlapped" % r] = R["info"]["overlapped"]
+        out["r%d_interior_tiles" % r] = R["info"]["interior"]
+        out["r%d_ntiles" % r] = R["info"]["ntiles"]
         for k in ("tot_pot_energy", "tot_kin_energy", "virial", "natoms"):
             out["r%d_%s" % (r, k)] = R["sums"][k]
     out["transport"] = np.array(res[0]["info"]["transport"])

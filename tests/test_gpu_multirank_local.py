@@ -191,6 +191,40 @@ def test_z_split_and_cube_on_the_single_domain_fixture(cpu_dim):
     _check_atoms(R, world, G, 20)
 
 
+@pytest.mark.parametrize("cpu_dim", [(2, 1, 1), (2, 2, 2)])
+def test_pass1_under_the_position_halo(cpu_dim):
+    """option halo_overlap: the position halo of the next step travels on its own stream while pass 1 -- tiles from a work queue,
+    two launches -- starts on the tiles that need no atom of another rank.  Same trajectory as the reference's 8-rank run; on
+    2x1x1 the middle tile layers along x are interior, on 2x2x2 every tile waits for the halo (the second launch does it all)"""
+    G = gu.load("eam_nbl_16384_mpi8")
+    env = dict(IMD_TEST_HALO_OVERLAP="8")
+    if cpu_dim == (2, 1, 1):
+        env["IMDGPU_TILE"] = "1,2,2"            # four cells per rank along x: four tile layers, the middle two interior
+    R, world = _run("eam_nbl_16384_mpi8", cpu_dim, 20, env=env)
+    _check_atoms(R, world, G, 20)
+    assert all(int(R["r%d_overlapped" % r]) >= 15 for r in range(world)), [int(R["r%d_overlapped" % r]) for r in range(world)]
+    inner = [int(R["r%d_interior_tiles" % r]) for r in range(world)]
+    assert all(v >= 0 for v in inner)
+    if cpu_dim == (2, 1, 1):
+        assert all(0 < v < int(R["r%d_ntiles" % r]) for r, v in enumerate(inner)), inner
+
+
+def test_pass1_under_the_position_halo_with_the_lattice():
+    """the same with the TTM lattice chain forked beside the force pass (decomposed lattice, 2x2x2)"""
+    G = gu.load("ttm_16384_mpi8")
+    R, world = _run("ttm_16384_mpi8", (2, 2, 2), 3, ttm=True, decomposed=True, env=dict(IMD_TEST_HALO_OVERLAP="8"))
+    o, go = _check_atoms(R, world, G, 3, forces=False)
+    assert np.array_equal(_cat(R, world, "numneighs")[o], G["s3_numneighs"][go])
+    assert all(int(R["r%d_overlapped" % r]) >= 2 for r in range(world))
+    ref = G["t2_substeps_done_temp"][1:-1, 1:-1, 1:-1]
+    full = np.zeros_like(ref)
+    for r in range(world):
+        blk = R["r%d_lat_temp" % r][1:-1, 1:-1, 1:-1]
+        c, n = R["r%d_coord" % r], blk.shape
+        full[c[0] * n[0]:(c[0] + 1) * n[0], c[1] * n[1]:(c[1] + 1) * n[1], c[2] * n[2]:(c[2] + 1) * n[2]] = blk
+    assert np.abs(full - ref).max() < 1e-10 * np.abs(ref).max()
+
+
 @pytest.mark.parametrize("decomposed", [False, True])
 def test_z_split_ttm(decomposed):
     G = gu.load("ttm_2048")
