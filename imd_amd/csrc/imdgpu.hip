@@ -583,9 +583,9 @@ struct TileArgs {
   double cellsz;
   const int *guard;               // pass 1 launched ahead of the host's look at the list-validity flag: *guard != 0 -> return at once
   // k_pass1_tile_merged<.., DYN = true> (multi-rank step with the position halo in flight, imdgpu_dist.hip): tiles are taken from
-  // a work queue -- INTERIOR tiles (no ghost cell in their halo) first, boundary tiles only once *halo_flag >= halo_want --,
-  // tile_map[position] = tile, positions [0, n_interior) interior; dyn[0..7] / dyn[8..15] = per-XCD counters of the two classes
-  const int *tile_map; int n_interior; int *dyn; const int *halo_flag; int halo_want, part_off;
+  // a work queue, tile_map[position] = tile, positions [0, n_interior) = INTERIOR tiles (no cell of another rank in their halo),
+  // the rest boundary tiles; dyn[0..7] / dyn[8..15] = per-XCD counters of the two classes; a launch takes classes <= dyn_last
+  const int *tile_map; int n_interior; int *dyn; int dyn_last, part_off;
   float nbl_eps;                  // k_nbl_build_tile32: |r2 - cellsz| below which the single-precision test is not trusted (host: make_tile_args)
   int balance;                    // block ranges cut by cost (boxes with vacuum, moving surfaces) instead of by tiles
   const long long *wprefix;       // [ntiles + 1] cost prefix (k_tile_wprefix), read when balance is set
@@ -1389,14 +1389,17 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile(TileArgs a)
 // FEMB: the embedding pass (pass 2, imd_forces_nbl.c:748-783) is folded into the epilogue -- with the full list rho of an
 // own atom is complete when its neighbour loop ends, so F(rho) and F'(rho) can be taken right there: no k_pass2 launch,
 // rho is not re-read, epot is written once.
-// DYN: the tiles come from a work queue instead of a fixed range per workgroup (see TileArgs::tile_map): the position halo of a
-// multi-rank step is still in flight when this pass starts, so interior tiles go first and a workgroup that runs out of them
-// takes boundary tiles only if the halo has landed (a device word the halo's last kernel sets) -- otherwise it LEAVES (no spin: a
-// spinning persistent grid would keep the halo's kernels from being placed) and a second launch behind the halo's event takes
-// what is left.  Chunks of DYN_CHUNK consecutive positions (tiles that are neighbours along z: their halos overlap in L2), one
-// counter per XCD and class with stealing, so the blocks of an XCD still walk neighbouring tiles.  Energies are summed per
-// workgroup in the order the queue hands the tiles out: they differ from run to run in the last bits (forces do not).
+// DYN: the tiles come from a work queue instead of a fixed range per workgroup (see TileArgs::tile_map).  The position halo of a
+// multi-rank step is still in flight when this pass starts: launch A takes the interior tiles and ends; launch B, behind the
+// halo's event, takes the boundary tiles.  (A first version let A's workgroups go on with boundary tiles once a device word said
+// the halo had landed: the few workgroups still busy at that moment then did ALL boundary tiles alone -- 16 ms instead of 2 --
+// while B waited behind A in stream order.  A kernel boundary also makes the unpacked ghost atoms visible without any fence.)
+// Chunks of consecutive positions (tiles that are neighbours along z: their halos overlap in L1/L2), DYN_CHUNK at first, fewer
+// as a range runs empty (a chunk is 0.03 ms of work per tile: the last chunks decide how long the slowest workgroup runs); one
+// counter per XCD and class, other XCDs' ranges when the own one is empty.  Energies are summed per workgroup in the order the
+// queue hands the tiles out: they differ from run to run in the last bits (forces, rho, list checks do not).
 #define DYN_CHUNK 8
+__device__ __forceinline__ int dyn_next_tile(const int *tile_map, int pos) { return pos >= 0 ? __builtin_amdgcn_readfirstlane(tile_map[pos]) : -1; }
 template <bool TTMN, bool FEMB, int CAP, bool DYN = false>
 __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs a)
 {
@@ -1409,22 +1412,27 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
   TileCtx T;
   int t0 = 0, t1 = 0;
   // ---- DYN: the queue ------------------------------------------------------------------------------------------------
-  __shared__ int s_dyn[2];                 // the chunk thread 0 has just taken: [begin, end) positions, or -1
+  // the chunk thread 0 has just taken: [begin, end) positions, or -1.  In the tail of the reduction scratch (block_sum<3> uses 48 of
+  // its 64 doubles, and only after the loop) -- NOT a static __shared__ array: that would move the dynamic region by 8 bytes and
+  // every 16-byte table read (ds_read_b128) off its alignment, which costs the pass a factor of three
+  int *s_dyn = (int *) (scratch + 62);
   int q_phase = 0, q_k = 0;                // thread 0: class being drained (0 interior, 1 boundary), XCDs tried so far in it
   auto grab = [&]() {                      // thread 0 only
     const int x0 = blockIdx.x & 7, nI = a.n_interior, nB = a.ntiles - a.n_interior;
     for (;;) {
-      // acquire: the ghost positions the unpack kernel wrote (another XCD, its own L2) are read with plain loads after this
-      if (q_phase == 1 && q_k == 0 && a.halo_flag && __hip_atomic_load(a.halo_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < a.halo_want) break;
       const int n = q_phase ? nB : nI, base = q_phase ? nI : 0;
       for (; q_k < 8; q_k++) {
         const int x = (x0 + q_k) & 7;
         const int lo = (int) ((long long) n * x / 8), hi = (int) ((long long) n * (x + 1) / 8);
-        const int p = lo + atomicAdd(&a.dyn[8 * q_phase + x], DYN_CHUNK);
-        if (p < hi) { s_dyn[0] = base + p; s_dyn[1] = base + (p + DYN_CHUNK < hi ? p + DYN_CHUNK : hi); return; }
+        int *cnt = &a.dyn[8 * q_phase + x];
+        const int left = hi - lo - __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // a hint: may be stale
+        if (left <= 0) continue;
+        const int c = left >= 64 * DYN_CHUNK ? DYN_CHUNK : (left >= 64 ? left >> 6 : 1);                      // ~ left / (2 x workgroups of an XCD)
+        const int p = lo + atomicAdd(cnt, c);
+        if (p < hi) { s_dyn[0] = base + p; s_dyn[1] = base + (p + c < hi ? p + c : hi); return; }
       }
-      if (q_phase == 1) break;
-      q_phase = 1; q_k = 0;
+      if (q_phase >= a.dyn_last) break;
+      q_phase++; q_k = 0;
     }
     s_dyn[0] = -1; s_dyn[1] = -1;
   };
@@ -1432,7 +1440,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
   if constexpr (DYN) {
     if (threadIdx.x == 0) grab();
     __syncthreads();
-    pos = s_dyn[0]; pos_end = s_dyn[1];
+    pos = __builtin_amdgcn_readfirstlane(s_dyn[0]); pos_end = __builtin_amdgcn_readfirstlane(s_dyn[1]);     // uniform: scalar registers
     t1 = pos >= 0 ? 1 : 0;                 // "this workgroup has work": the table is loaded below
   } else
   block_tile_range(a.ntiles, a.wprefix, a.balance, t0, t1);
@@ -1452,7 +1460,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
   const TabK c = {a.pair.begin[0], a.pair.end[0], a.pair.invstep[0], 2 * a.pair.invstep[0]};
   int4 info = make_int4(0, 0, 0, 0);
   int IDX[STG];
-  if constexpr (DYN) { T.tile = pos >= 0 ? a.tile_map[pos] : 0; t0 = 0; t1 = pos >= 0 ? 1 : 0; if (pos >= 0) { info = a.tinfo[T.tile]; stage_issue(a, T.tile, info.x, IDX); } }
+  if constexpr (DYN) { T.tile = pos >= 0 ? __builtin_amdgcn_readfirstlane(a.tile_map[pos]) : 0; t0 = 0; t1 = pos >= 0 ? 1 : 0; if (pos >= 0) { info = a.tinfo[T.tile]; stage_issue(a, T.tile, info.x, IDX); } }
   else { if (t0 < t1) { info = a.tinfo[t0]; stage_issue(a, t0, info.x, IDX); } T.tile = t0; }
   while (DYN ? pos >= 0 : T.tile < t1) {
     // DYN: on the last tile of its chunk thread 0 takes the next chunk between the prologue's barriers (everybody is through
@@ -1460,9 +1468,9 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
     const bool last_of_chunk = DYN && pos + 1 >= pos_end;
     TILE_PROLOGUE_N(false, false, nullptr, nullptr, 1.0,
                     if (DYN && last_of_chunk && threadIdx.x == 0) grab();,
-                    (DYN ? (last_of_chunk ? (s_dyn[0] >= 0 ? a.tile_map[s_dyn[0]] : -1) : a.tile_map[pos + 1]) : (T.tile + 1 < t1 ? T.tile + 1 : -1)))
+                    (DYN ? dyn_next_tile(a.tile_map, last_of_chunk ? __builtin_amdgcn_readfirstlane(s_dyn[0]) : pos + 1) : (T.tile + 1 < t1 ? T.tile + 1 : -1)))
     int npos = pos + 1, npos_end = pos_end;
-    if (DYN && last_of_chunk) { npos = s_dyn[0]; npos_end = s_dyn[1]; }
+    if (DYN && last_of_chunk) { npos = __builtin_amdgcn_readfirstlane(s_dyn[0]); npos_end = __builtin_amdgcn_readfirstlane(s_dyn[1]); }
     for (int o = threadIdx.x; o < T.nown; o += blockDim.x) {
       const int i = T.own_start + o;
       OWN_PROLOGUE
@@ -3050,7 +3058,7 @@ int imdgpu_launch_pass1_dyn(imdgpu_ctx *ctx, int part)
   TileArgs ta = make_tile_args(ctx);
   ta.guard = ctx->pass1_guard;
   ta.tile_map = ctx->d_tile_map; ta.n_interior = ctx->n_interior; ta.dyn = ctx->d_dyn;
-  ta.halo_flag = part == 0 ? ctx->d_dyn + 16 : nullptr; ta.halo_want = ctx->dyn_seq; ta.part_off = part == 0 ? 0 : ctx->dyn_nb[0];
+  ta.dyn_last = part; ta.part_off = part == 0 ? 0 : ctx->dyn_nb[0];
   const size_t l = tile_lds_bytes(ctx, 1);
   {
     ProfScope ps(ctx, part == 0 ? PROF_PASS1 : PROF_PASS1B);

@@ -342,6 +342,7 @@ static int dist_halo_parts(imdgpu_ctx *ctx, DistState *D, int what, int parts, n
                        D->d_seg_of, D->d_self_dst, D->d_shift, ctx->pos, ctx->type, D->sendbuf);
   if (parts & 2) {
     if (dist_exchange(ctx, D, w, comm)) return 1;
+    if (parts == 2) imdgpu_tl_mark(ctx, "halo3_msgs");
     if (D->nrecv_atoms > D->nself_atoms)                    // something did arrive through the buffers
       hipLaunchKernelGGL(k_dist_unpack, dim3(nblk(D->nrecv_atoms, 256)), dim3(256), 0, ctx->stream, what, D->nrecv_atoms, ctx->nlocal,
                          D->d_recv_self, D->recvbuf, ctx->pos, ctx->type);
@@ -354,7 +355,6 @@ extern "C" int imdgpu_dist_halo(imdgpu_ctx *ctx, int what)
   NEED_DIST();
   return dist_halo_parts(ctx, D, what, 3);
 }
-__global__ void k_dist_set_word(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 
 // MAX over the ranks of this rank's list-validity flag (check_nblist's MPI_Allreduce, imd_forces_nbl.c:1087) -> d_flag[0]
 // flag[1]: a time-out of the lattice's hand-offs (persistent sub-step kernel, mailbox) on ANY rank fails the step everywhere
@@ -500,7 +500,8 @@ extern "C" int imdgpu_dist_md_step(imdgpu_ctx *ctx, int steps, int *rebuild_need
   // Option halo_overlap: the position halo travels on its own stream (and communicator) while pass 1 -- in its queue form, two
   // launches -- works through the tiles whose halo cells hold no atom of another rank; see k_pass1_tile_merged<.., DYN>.
   // Order on the main stream: gather (it also writes the ghost atoms this rank supplies to itself), the flags' all-reduce (the
-  // guard of both launches), launch A; on the halo stream behind the gather: messages, unpack, "landed" word; launch B behind that.
+  // guard of both launches), launch A (interior tiles); on the halo stream behind the gather: messages, unpack; launch B (boundary
+  // tiles) behind that.
   if (spec && ctx->halo_overlap > 0 && ctx->dyn_ntiles != ctx->ntiles && imdgpu_pass1_dyn_prepare(ctx, D->remote)) return 1;
   const bool overlap = spec && imdgpu_pass1_dyn_ready(ctx) && (!D->comm || D->comm3);
   for (int round = 0;; round++) {
@@ -512,19 +513,18 @@ extern "C" int imdgpu_dist_md_step(imdgpu_ctx *ctx, int steps, int *rebuild_need
     if (overlap) {
       HIPCHK(hipEventRecord(D->ev_fork3, ctx->stream));
       ctx->pass1_guard = D->d_flag + 3;
-      int rc = imdgpu_launch_pass1_dyn(ctx, 0);
+      static const int dexp = getenv("IMDGPU_DYN_EXP") ? atoi(getenv("IMDGPU_DYN_EXP")) : 0;    // experiments: 2 = the halo in front of launch A on the main stream
+      int rc = (dexp & 2) ? 0 : imdgpu_launch_pass1_dyn(ctx, 0);
       hipStream_t main = ctx->stream;
       if (!rc) {
-        ctx->stream = D->stream3;
+        if (!(dexp & 2)) ctx->stream = D->stream3;
         if (hipStreamWaitEvent(ctx->stream, D->ev_fork3, 0) != hipSuccess) rc = imdgpu_fail(ctx, "hipStreamWaitEvent failed");
         if (!rc) rc = dist_halo_parts(ctx, D, 3, 2, D->comm3);
-        if (!rc) {
-          hipLaunchKernelGGL(k_dist_set_word, dim3(1), dim3(1), 0, ctx->stream, ctx->d_dyn + 16, ctx->dyn_seq);
-          if (hipEventRecord(D->ev_halo, ctx->stream) != hipSuccess) rc = imdgpu_fail(ctx, "hipEventRecord failed");
-        }
+        if (!rc && hipEventRecord(D->ev_halo, ctx->stream) != hipSuccess) rc = imdgpu_fail(ctx, "hipEventRecord failed");
         imdgpu_tl_mark(ctx, "halo3");
         ctx->stream = main;
       }
+      if (!rc && (dexp & 2)) rc = imdgpu_launch_pass1_dyn(ctx, 0);
       if (!rc && hipStreamWaitEvent(ctx->stream, D->ev_halo, 0) != hipSuccess) rc = imdgpu_fail(ctx, "hipStreamWaitEvent failed");
       if (!rc) rc = imdgpu_launch_pass1_dyn(ctx, 1);
       ctx->pass1_guard = nullptr;

@@ -147,7 +147,7 @@ struct imdgpu_ctx {
   // pass 1 under the position halo (option "halo_overlap", imdgpu_dist.hip): tiles from a work queue, interior ones first
   int halo_overlap = 0;               // option: 0 off, n > 0: on, the first launch leaves n CUs to the transport's kernels
   int *d_tile_map = nullptr; size_t tile_map_cap = 0; int dyn_ntiles = -1, n_interior = 0;   // queue order of the tiles (imdgpu_pass1_dyn_prepare)
-  int *d_dyn = nullptr;               // [0..15] queue counters, [16] "the halo of launch pair number n has landed"
+  int *d_dyn = nullptr;               // [0..15] queue counters
   int dyn_seq = 0;                    // launch pairs so far
   int dyn_nb[2]{0, 0};                // workgroups of the two launches of the pass 1 now in d_partials (0, 0: the one-launch form)
 };
@@ -241,7 +241,7 @@ int imdgpu_launch_forces_phase(imdgpu_ctx *ctx, int phase);
 int imdgpu_launch_integrate(imdgpu_ctx *ctx);
 // pass 1 in two launches from a tile queue: remote[d] != 0 = the ghost cells at the two ends of dimension d arrive through the
 // transport (everything else is in place when the first launch starts).  prepare: once per list; ready: this context's pass 1 has
-// the queue form; launch(part 0): interior tiles, boundary tiles as far as the halo word allows; launch(part 1): the rest
+// the queue form; launch(part 0): the interior tiles; launch(part 1): the rest
 int imdgpu_pass1_dyn_prepare(imdgpu_ctx *ctx, const int remote[3]);
 int imdgpu_pass1_dyn_ready(const imdgpu_ctx *ctx);
 int imdgpu_launch_pass1_dyn(imdgpu_ctx *ctx, int part);

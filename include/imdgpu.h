@@ -57,6 +57,10 @@ int  imdgpu_synchronize(imdgpu_ctx *ctx);
  * that cannot run -- its workgroups not all resident in time, or an active region beyond its 1280 blocks -- touches nothing
  * and the step is issued again through the chain: "ttm_persist_redone" counts those; setting the option also clears a
  * reported hand-off time-out); "ttm_persist_miss" = MD step whose persistent launch is made to step aside (tests);
+ * "halo_overlap" = N > 0 (several ranks; default 0): pass 1 of the next step is enqueued as two launches from a tile queue -- the
+ * tiles with no cell of another rank in their halo on all but N CUs while the position halo [send_cells(copy_cell),
+ * imd_forces_nbl.c:311] travels on its own stream, the boundary tiles behind it; same results, measured slower on one GPU
+ * (DESIGN 5), needs the third communicator id on the RCCL transport;
  * "p3_coef" = 1 (default) the EAM force pass (do_forces_eam2, imd_forces_nbl.c:789-985) reads DERIV_FUNC2's gradient
  * (potaccess.h:591-621) as one coefficient pair per table row where that applies (one atom type, pair_pot and rho_h_tab on
  * one r^2 grid, nothing with LDS tiles of its own beside it), 0 always as three table rows; the two agree to rounding */
@@ -480,7 +484,8 @@ int imdgpu_ttm_local_step(imdgpu_ctx *ctx, int steps);
 typedef int (*imdgpu_exchange_fn)(void *user, int op, void *dev_send, void *dev_recv, int nsend, const int *send_peer,
                                   const long long *send_off, const long long *send_cnt, int nrecv, const int *recv_peer,
                                   const long long *recv_off, const long long *recv_cnt, int elem_bytes);
-/* rank 0 makes the communicator ids (nbytes >= 256: two ncclUniqueId), the launcher hands them to every rank */
+/* rank 0 makes the communicator ids -- nbytes = 256: two ncclUniqueId (halos + flags; lattice stream), nbytes = 384: a third one
+ * for the position halo on its own stream (option "halo_overlap") --, the launcher hands them to every rank; init takes 256 or 384 */
 int imdgpu_dist_unique_id(void *out, int nbytes);
 int imdgpu_dist_init_rccl(imdgpu_ctx *ctx, int nranks, int rank, const void *unique_id, int nbytes);
 int imdgpu_dist_init_callback(imdgpu_ctx *ctx, int nranks, int rank, imdgpu_exchange_fn fn, void *user);
