@@ -554,7 +554,7 @@ __global__ __launch_bounds__(512) void k_pass3_gt(ForceArgs a)
 // neighbour list holds 16-bit LDS slot numbers (4 per 8-byte load, ELL-transposed
 // per tile).  HBM sees: list (2 B/entry), own-atom outputs, one staging pass.
 // ===========================================================================
-#define IMDGPU_KERNEL_REV 8
+#define IMDGPU_KERNEL_REV 9
 #define LDS_LIMIT (160 * 1024)
 #define TABLE_LDS_LIMIT (150 * 1024)                 // global-gather kernels: tables beyond this stay in global memory
 #define NH_MAX 512                                   // halo cells per tile (<= 6*6*6 = 216 for tiles up to 4^3)
@@ -747,13 +747,7 @@ __device__ __forceinline__ int own_slot(const TileArgs &a, const TileCtx &T, int
   return hstart[h] + (i - hsrc[h]);
 }
 
-// ---- staging from the plan (force passes) ------------------------------------------------------------
-// stage_issue: the slot -> atom index loads (STG ints per thread), called BEFORE the barrier that ends the previous
-// tile so that this round trip overlaps the wait for the slower waves.  stage_commit: position gathers and LDS
-// writes (x, y, z planes: conflict-free ds_read_b64 gathers), between two barriers (holding the records themselves in registers across the barrier spills: the
-// force loops use every VGPR three waves per SIMD allow).  STG entries per thread cover STG*blockDim slots;
-// anything beyond (never at the tile shapes autotile picks) is staged by a plain loop.
-#define STG 5
+// ---- staging from the plan (force passes): see "staging AHEAD" below ------------------------------------
 // LDS layout of the staged positions.  Default: x, y, z (, dF) planes of 8-byte records.  make EXTRA=-DPOSXY: (x, y) pairs in
 // one plane of 16-byte records and z in a plane of its own -- pass 3: (z, dF) pairs in the second plane --, i.e. one
 // ds_read_b128 + one ds_read_b64 per neighbour (pass 3: two ds_read_b128) instead of three (four) ds_read_b64.  Measured in
@@ -800,43 +794,6 @@ __device__ __forceinline__ void nbr_rdw(const double *sp, const double *sw, int 
 }
 // the type of the atom in a neighbour's slot (several atom types)
 __device__ __forceinline__ int nbr_type(const int *ts, int jb) { return *(const int *) ((const char *) ts + jb / (NBR_SCALE / 4)); }
-__device__ __forceinline__ void stage_issue(const TileArgs &a, int tile, int nsl, int (&IDX)[STG])
-{
-  const int *src = a.tsrc + (size_t) tile * SLOTCAP(a);
-#pragma unroll
-  for (int u = 0; u < STG; u++) { const int s = threadIdx.x + u * blockDim.x; IDX[u] = s < nsl ? src[s] : -1; }
-}
-template <bool WITH_W, bool WITH_T>
-__device__ __forceinline__ void stage_commit(const TileArgs &a, int tile, int nsl, const int (&IDX)[STG],
-                                             double *sp, double *sw, int *ts, double wscale = 1.0)
-{
-  double4 P[STG]; int TT[STG];
-#pragma unroll
-  for (int u = 0; u < STG; u++) if (IDX[u] >= 0) { P[u] = a.pos[IDX[u]]; if (WITH_T) TT[u] = a.type[IDX[u]]; }
-#pragma unroll
-  for (int u = 0; u < STG; u++) {
-    const int s = threadIdx.x + u * blockDim.x;
-    if (IDX[u] >= 0) {
-      if (WITH_W) LPOS_STW(sp, sw, SLOTCAP(a), s, P[u].x, P[u].y, P[u].z, P[u].w * wscale)
-      else LPOS_ST(sp, sw, SLOTCAP(a), s, P[u].x, P[u].y, P[u].z)
-      if (WITH_T) ts[s] = TT[u];
-    }
-  }
-  const int *src = a.tsrc + (size_t) tile * SLOTCAP(a);
-  for (int s = threadIdx.x + STG * blockDim.x; s < nsl; s += blockDim.x) {
-    const int gi = src[s];
-    const double4 q = a.pos[gi];
-    if (WITH_W) LPOS_STW(sp, sw, SLOTCAP(a), s, q.x, q.y, q.z, q.w * wscale)
-    else LPOS_ST(sp, sw, SLOTCAP(a), s, q.x, q.y, q.z)
-    if (WITH_T) ts[s] = a.type[gi];
-  }
-  if (threadIdx.x == 0) {                          // the far-away dummy that pads the neighbour rows
-    if (WITH_W) LPOS_STW(sp, sw, SLOTCAP(a), SLOTCAP(a) - 1, 1e150, 1e150, 1e150, 0.0)
-    else LPOS_ST(sp, sw, SLOTCAP(a), SLOTCAP(a) - 1, 1e150, 1e150, 1e150)
-    if (WITH_T) ts[SLOTCAP(a) - 1] = 0;
-  }
-}
-
 // per tile: own atoms and staged atoms, for sizing tile_cap / slot_cap
 __global__ void k_tile_stats(int ntiles, Geo g, const int *cell_cnt, const int *istart, int *counters)
 {
@@ -1140,28 +1097,9 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile32(TileArgs a)
 #define PRIO_LO
 #endif
 
-// Tile loop plumbing shared by the force kernels (see stage_issue / stage_commit).  The first list words and the
+// Tile loop plumbing shared by the force kernels (staging: "staging AHEAD" below).  The first list words and the
 // (slot, count) word of the thread's own atom do not depend on the staged positions: they are requested before
 // the barriers, so their latency is hidden as well.
-#define TILE_PROLOGUE(WITH_W, WITH_T, SW, TS, WSCALE) TILE_PROLOGUE_N(WITH_W, WITH_T, SW, TS, WSCALE, , (T.tile + 1 < t1 ? T.tile + 1 : -1))
-/* BETWEEN: statements between the two barriers (every thread is through with the previous tile); NEXT: the tile after this one, or -1 */
-#define TILE_PROLOGUE_N(WITH_W, WITH_T, SW, TS, WSCALE, BETWEEN, NEXT)                                             \
-    T.own_start = info.y; T.nown = info.z;                                                                       \
-    const unsigned dw = (unsigned) ((SLOTCAP(a) - 1) * NBR_SCALE) * 0x10001u;                                    \
-    const uint2 dummyw = make_uint2(dw, dw);                                                                     \
-    const size_t lbase = (size_t) T.tile * a.W4 * a.tile_cap;                                                    \
-    unsigned ow0 = 0; uint2 w0 = dummyw, w1 = dummyw;                                                            \
-    if ((int) threadIdx.x < T.nown) {                                                                            \
-      const uint2 *lq = (const uint2 *) (a.nbr16 + lbase + threadIdx.x);                                         \
-      ow0 = a.ownw[(size_t) T.tile * a.tile_cap + threadIdx.x]; w0 = lq[0]; w1 = lq[(size_t) a.tile_cap];       \
-    }                                                                                                            \
-    __syncthreads();                              /* every wave is done with the previous tile's LDS */          \
-    BETWEEN                                                                                                      \
-    if (!(a.dbg & 2)) stage_commit<WITH_W, WITH_T>(a, T.tile, info.x, IDX, sp, SW, TS, WSCALE);                                          \
-    __syncthreads();                                                                                             \
-    const int next_tile = NEXT;                                                                                  \
-    int4 info_next = info;                                                                                       \
-    if (next_tile >= 0) info_next = a.tinfo[next_tile];
 #define OWN_PROLOGUE                                                                                             \
       const uint2 *lp = (const uint2 *) (a.nbr16 + lbase + o);                                                   \
       unsigned ow = ow0, c0x = w0.x, c0y = w0.y, c1x = w1.x, c1y = w1.y;   /* scalars: uint2 selects end up in scratch */ \
@@ -1183,12 +1121,26 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile32(TileArgs a)
 //            their own count walk dummy words, which costs the SIMD nothing).  Measured -8 % (pass 1) / -4 % (pass 3):
 //            the list is a 2 GB stream per pass and its latency, not only the LDS gathers, is what the waves wait for.
 // Lanes past their own count get the dummy word either way.
+// experiment (make EXTRA=-DWAVE_FAIR): a wave's priority falls as it gets through its list (3, 2, 1, 0 by quarters), so the waves
+// a SIMD would serve last (it prefers its oldest wave) catch up and the workgroup's waves reach the barrier together
+#ifdef WAVE_FAIR
+#define WAVE_FAIR_BEGIN const int wf1 = (nwu + 3) >> 2, wf2 = (nwu + 1) >> 1, wf3 = (3 * nwu + 3) >> 2; __builtin_amdgcn_s_setprio(3);
+#define WAVE_FAIR_STEP if (w >= wf1) { if (w >= wf3) __builtin_amdgcn_s_setprio(0); else if (w >= wf2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2); }
+#define WAVE_FAIR_END __builtin_amdgcn_s_setprio(0);
+#else
+#define WAVE_FAIR_BEGIN
+#define WAVE_FAIR_STEP
+#define WAVE_FAIR_END
+#endif
+template <int S> struct RingSlot { static constexpr int value = S; };
 #define LIST_WORDS_BEGIN                                                                                         \
-      auto body = [&](const unsigned curx, const unsigned cury) __attribute__((always_inline)) {                 \
+      auto body = [&](const unsigned curx, const unsigned cury, auto ring_slot) __attribute__((always_inline)) { \
+        constexpr int RSLOT = decltype(ring_slot)::value;       /* which of the four ring registers this word came from */ \
+        (void) RSLOT;                                                                                            \
         const int j4[4] = {(int) (curx & 0xffffu), (int) (curx >> 16), (int) (cury & 0xffffu), (int) (cury >> 16)};     \
         HALF_BEGIN
 #define RING_LOAD(DX, DY, W) { DX = dw; DY = dw; if ((W) < n4) { const uint2 q = lp[(size_t) (W) * a.tile_cap]; DX = q.x; DY = q.y; } }
-#define RING_STEP(RX, RY) if (w >= nwu) break; body(RX, RY); RING_LOAD(RX, RY, w + 4) w++;
+#define RING_STEP(RX, RY, S) if (w >= nwu) break; body(RX, RY, RingSlot<S>{}); RING_LOAD(RX, RY, w + 4) w++;
 #define LIST_WORDS_END(RING)                                                                                     \
       };                                                                                                         \
       if constexpr ((RING) == 0) {                                                                               \
@@ -1199,7 +1151,7 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile32(TileArgs a)
           }                                                                                                      \
           const unsigned curx = (k4 & 1) ? c1x : c0x, cury = (k4 & 1) ? c1y : c0y;                               \
           if (k4 & 1) { c0x = m0x; c0y = m0y; c1x = m1x; c1y = m1y; }   /* odd trip: hand over (loads are ~8 neighbours old) */ \
-          body(curx, cury);                                                                                      \
+          body(curx, cury, RingSlot<0>{});                                                                       \
         }                                                                                                        \
       } else {                                                                                                   \
         int nwu = n4;                                                                                            \
@@ -1208,7 +1160,9 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile32(TileArgs a)
         unsigned r2x, r2y, r3x, r3y;                                                                             \
         RING_LOAD(r2x, r2y, 2) RING_LOAD(r3x, r3y, 3)                                                            \
         int w = 0;                                                                                               \
-        for (;;) { RING_STEP(c0x, c0y) RING_STEP(c1x, c1y) RING_STEP(r2x, r2y) RING_STEP(r3x, r3y) }             \
+        WAVE_FAIR_BEGIN                                                                                          \
+        for (;;) { WAVE_FAIR_STEP RING_STEP(c0x, c0y, 0) RING_STEP(c1x, c1y, 1) RING_STEP(r2x, r2y, 2) RING_STEP(r3x, r3y, 3) } \
+        WAVE_FAIR_END                                                                                            \
       }
 #if UNR == 4
 #define HALF_BEGIN { const int *j = j4;
@@ -1217,8 +1171,82 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile32(TileArgs a)
 #define HALF_BEGIN _Pragma("unroll") for (int hh = 0; hh < 4 / UNR; hh++) { const int j[2] = {j4[2 * hh], j4[2 * hh + 1]};
 #define HALF_END SCHED_BARRIER; }
 #endif
-#define TILE_EPILOGUE                                                                                            \
-    if (next_tile >= 0) stage_issue(a, next_tile, info_next.x, IDX);                                             \
+// ---- staging AHEAD, by the waves that are through first (the one-type force kernels) --------------------------------------------
+// The waves of a workgroup do not finish a tile together: the SIMDs serve their oldest wave first, wave 0 is through with its atoms
+// a third earlier than the last one (phase timing, make EXTRA=-DPHASE_TIMING: 0.94 vs 1.37 ms of the pass) and used to idle at the
+// barrier, after which ALL waves went through the staging's two dependent round trips (slot -> atom index, atom -> position)
+// together: 3.2 us of a 30-us tile with the LDS pipe idle.  Now a wave that is through takes the next SA chunks of 64 slots of the
+// NEXT tile from a counter in the LDS, loads their indices and positions into registers (free once its neighbour loop is over)
+// and goes to the barrier; the first ceil(slots / 64 / SA) waves to finish cover the whole tile, the last ones find the counter
+// exhausted and arrive at the barrier with nothing to wait for.  Behind the barrier the held records are written to the planes;
+// chunks nobody took (more than SA * waves: tiles beyond autotile's shapes) are staged by a plain loop.  Two counters, used in
+// turns: the one the next grab will use is zeroed between the barriers of the tile before.
+#define SA 8
+#define AHEAD_DECL(SCRATCH)                                                                                      \
+  int ah_c0 = 0, ah_par = 0; int ah_idx[SA], ah_T[SA]; double4 ah_P[SA];                                          \
+  _Pragma("unroll") for (int u = 0; u < SA; u++) { ah_idx[u] = -1; ah_T[u] = 0; ah_P[u] = make_double4(0, 0, 0, 0); } \
+  int *ah_cnt = (int *) ((SCRATCH) + 60);                                                                        \
+  if (threadIdx.x == 0) { ah_cnt[0] = 0; ah_cnt[1] = 0; }                                                         \
+  __syncthreads();
+#define AHEAD_GRAB(NT, NSL, WITH_T)                                                                              \
+  {                                                                                                              \
+    int c_ = 0;                                                                                                  \
+    if ((threadIdx.x & 63) == 0) c_ = atomicAdd(&ah_cnt[ah_par], SA);                                            \
+    ah_c0 = __builtin_amdgcn_readfirstlane(c_);                                                                  \
+    const int *src_ = a.tsrc + (size_t) (NT) * SLOTCAP(a);                                                       \
+    _Pragma("unroll") for (int u = 0; u < SA; u++) { const int s_ = (ah_c0 + u) * 64 + (int) (threadIdx.x & 63); ah_idx[u] = s_ < (NSL) ? src_[s_] : -1; } \
+    /* every record is assigned on every path (a guarded load here, zeros where the grab is skipped): otherwise the registers */ \
+    /* count as live through the neighbour loop, which has none to spare */                                      \
+    _Pragma("unroll") for (int u = 0; u < SA; u++) ah_P[u] = a.pos[ah_idx[u] >= 0 ? ah_idx[u] : 0];             \
+    if (WITH_T) { _Pragma("unroll") for (int u = 0; u < SA; u++) ah_T[u] = a.type[ah_idx[u] >= 0 ? ah_idx[u] : 0]; } \
+  }
+#define TILE_PROLOGUE_A(WITH_W, WITH_T, SW, TS, WSCALE, PRE, BETWEEN, MID, NEXT)                                 \
+    T.own_start = info.y; T.nown = info.z;                                                                       \
+    const unsigned dw = (unsigned) ((SLOTCAP(a) - 1) * NBR_SCALE) * 0x10001u;                                    \
+    const uint2 dummyw = make_uint2(dw, dw);                                                                     \
+    const size_t lbase = (size_t) T.tile * a.W4 * a.tile_cap;                                                    \
+    unsigned ow0 = 0; uint2 w0 = dummyw, w1 = dummyw;                                                            \
+    if ((int) threadIdx.x < T.nown) {                                                                            \
+      const uint2 *lq = (const uint2 *) (a.nbr16 + lbase + threadIdx.x);                                         \
+      ow0 = a.ownw[(size_t) T.tile * a.tile_cap + threadIdx.x]; w0 = lq[0]; w1 = lq[(size_t) a.tile_cap];       \
+    }                                                                                                            \
+    PRE                                                                                                          \
+    __syncthreads();                              /* every wave is done with the previous tile's LDS */          \
+    BETWEEN                                                                                                      \
+    {                                                                                                            \
+      double *const sw_ = (double *) (SW); int *const ts_ = (int *) (TS);                                        \
+      _Pragma("unroll") for (int u = 0; u < SA; u++)                                                             \
+        if (ah_idx[u] >= 0) {                                                                                    \
+          const int s_ = (ah_c0 + u) * 64 + (int) (threadIdx.x & 63);                                            \
+          if (WITH_W) LPOS_STW(sp, sw_, SLOTCAP(a), s_, ah_P[u].x, ah_P[u].y, ah_P[u].z, ah_P[u].w * (WSCALE))    \
+          else LPOS_ST(sp, sw_, SLOTCAP(a), s_, ah_P[u].x, ah_P[u].y, ah_P[u].z)                                  \
+          if (WITH_T) ts_[s_] = ah_T[u];                                                                         \
+        }                                                                                                        \
+      const int cfin_ = ah_cnt[ah_par];           /* every wave has grabbed: chunks from here on are nobody's */ \
+      const int *src_ = a.tsrc + (size_t) T.tile * SLOTCAP(a);                                                   \
+      for (int s_ = cfin_ * 64 + (int) threadIdx.x; s_ < info.x; s_ += blockDim.x) {                             \
+        const int gi_ = src_[s_];                                                                                \
+        const double4 q_ = a.pos[gi_];                                                                           \
+        if (WITH_W) LPOS_STW(sp, sw_, SLOTCAP(a), s_, q_.x, q_.y, q_.z, q_.w * (WSCALE))                          \
+        else LPOS_ST(sp, sw_, SLOTCAP(a), s_, q_.x, q_.y, q_.z)                                                   \
+        if (WITH_T) ts_[s_] = a.type[gi_];                                                                       \
+      }                                                                                                          \
+      if (threadIdx.x == 0) {                     /* the far-away dummy that pads the neighbour rows */          \
+        if (WITH_W) LPOS_STW(sp, sw_, SLOTCAP(a), SLOTCAP(a) - 1, 1e150, 1e150, 1e150, 0.0)                       \
+        else LPOS_ST(sp, sw_, SLOTCAP(a), SLOTCAP(a) - 1, 1e150, 1e150, 1e150)                                    \
+        if (WITH_T) ts_[SLOTCAP(a) - 1] = 0;                                                                     \
+        ah_cnt[ah_par ^ 1] = 0;                                                                                  \
+      }                                                                                                          \
+    }                                                                                                            \
+    MID                                                                                                          \
+    __syncthreads();                                                                                             \
+    ah_par ^= 1;                                                                                                 \
+    const int next_tile = NEXT;                                                                                  \
+    int4 info_next = info;                                                                                       \
+    if (next_tile >= 0) info_next = a.tinfo[next_tile];
+#define TILE_EPILOGUE_A(WITH_T)                                                                                  \
+    if (next_tile >= 0) AHEAD_GRAB(next_tile, info_next.x, WITH_T)                                               \
+    else { _Pragma("unroll") for (int u = 0; u < SA; u++) { ah_idx[u] = -1; ah_T[u] = 0; ah_P[u] = make_double4(0, 0, 0, 0); } }  \
     info = info_next;
 
 struct TabK { double begin, end, istep, istep2; };      // one column of a table (NT1 fast path)
@@ -1264,10 +1292,10 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile(TileArgs a)
     if (EAM) lds_load_table(tr, a.rho);
   }
   int4 info = make_int4(0, 0, 0, 0);
-  int IDX[STG];
-  if (t0 < t1) { info = a.tinfo[t0]; stage_issue(a, t0, info.x, IDX); }
+  AHEAD_DECL(scratch)
+  if (t0 < t1) { info = a.tinfo[t0]; AHEAD_GRAB(t0, info.x, !NT1) }
   for (T.tile = t0; T.tile < t1; T.tile++) {     // uniform per block
-    TILE_PROLOGUE(false, !NT1, nullptr, ts, 1.0)
+    TILE_PROLOGUE_A(false, !NT1, nullptr, ts, 1.0, , , , (T.tile + 1 < t1 ? T.tile + 1 : -1))
     const int nt = a.ntypes, inc = NT1 ? 1 : nt * nt;
     const double pend0 = PAIR ? a.pair.end[0] : 0.0;
     const TabK cp = {a.pair.begin[0], a.pair.end[0], a.pair.invstep[0], 2 * a.pair.invstep[0]};
@@ -1372,7 +1400,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile(TileArgs a)
       if (TTMN) a.numneighs[i] = nb;
       sums[0] += ee; sums[1] += vir;
     }
-    TILE_EPILOGUE
+    TILE_EPILOGUE_A(!NT1)
   }
   block_sum<2>(sums, scratch);
   if (threadIdx.x == 0) {
@@ -1398,7 +1426,29 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile(TileArgs a)
 // as a range runs empty (a chunk is 0.03 ms of work per tile: the last chunks decide how long the slowest workgroup runs); one
 // counter per XCD and class, other XCDs' ranges when the own one is empty.  Energies are summed per workgroup in the order the
 // queue hands the tiles out: they differ from run to run in the last bits (forces, rho, list checks do not).
+// make EXTRA="-DPHASE_TIMING [-DPH_THREAD=640]": where one thread of every workgroup of k_pass1_tile_merged spends its time (100 MHz
+// clock, summed over the workgroups and the launches of a run, printed by imdgpu_destroy): 0 loop top, 1 first loads issued + the previous
+// atom's embedding finished, 2 first barrier, 3 staging, 4 second barrier (+ next tile's info), 5 the own atom, 6 epilogue
+#ifdef PHASE_TIMING
+#ifndef PH_THREAD
+#define PH_THREAD 0
+#endif
+__device__ unsigned long long g_phase[8];
+#define PH_DECL unsigned long long ph[7] = {0, 0, 0, 0, 0, 0, 0}, ph_last = wall_clock64();
+#define PH(n) if (threadIdx.x == PH_THREAD) { const unsigned long long t_ = wall_clock64(); ph[n] += t_ - ph_last; ph_last = t_; }
+#define PH_END if (threadIdx.x == PH_THREAD) { for (int q_ = 0; q_ < 7; q_++) atomicAdd(&g_phase[q_], ph[q_]); atomicAdd(&g_phase[7], 1ull); }
+#else
+#define PH_DECL
+#define PH(n)
+#define PH_END
+#endif
 #define DYN_CHUNK 8
+// P1_GROWS_PAT = decimal digits d0 d1 d2 d3: of the four neighbours of a list word from ring register s, d_s take their table rows
+// from global memory instead of the LDS (see the neighbour loop of k_pass1_tile_merged)
+#ifndef P1_GROWS_PAT
+#define P1_GROWS_PAT 0
+#endif
+#define P1_GROWS {(P1_GROWS_PAT) / 1000 % 10, (P1_GROWS_PAT) / 100 % 10, (P1_GROWS_PAT) / 10 % 10, (P1_GROWS_PAT) % 10}
 __device__ __forceinline__ int dyn_next_tile(const int *tile_map, int pos) { return pos >= 0 ? __builtin_amdgcn_readfirstlane(tile_map[pos]) : -1; }
 template <bool TTMN, bool FEMB, int CAP, bool DYN = false>
 __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs a)
@@ -1458,17 +1508,37 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
     }
   }
   const TabK c = {a.pair.begin[0], a.pair.end[0], a.pair.invstep[0], 2 * a.pair.invstep[0]};
+  // embedding energy and its derivative of the atom just finished (FEMB), completed one tile later: see the end of the atom loop
+  const double emb_begin = FEMB ? a.emb.begin[0] : 0, emb_end = FEMB ? a.emb.end[0] : 0, emb_istep = FEMB ? a.emb.invstep[0] : 0;
+  int pend_i = -1;
+  double pend_chi = 0, pend_p0 = 0, pend_p1 = 0, pend_p2 = 0, pend_ee = 0;
+  auto emb_finish = [&]() {
+    if (FEMB && pend_i >= 0) {
+      Tab3 q;
+      q.p0 = pend_p0; q.dv = pend_p1 - pend_p0; q.d2v = pend_p2 - 2 * pend_p1 + pend_p0; q.chi = pend_chi; q.istep = emb_istep;
+      const double pe = tab_val(q);
+      a.posw[pend_i].w = tab_grad(q);
+      a.epot[pend_i] = pend_ee + pe;
+      sums[2] += pe;
+      pend_i = -1;
+    }
+  };
+  PH_DECL
   int4 info = make_int4(0, 0, 0, 0);
-  int IDX[STG];
-  if constexpr (DYN) { T.tile = pos >= 0 ? __builtin_amdgcn_readfirstlane(a.tile_map[pos]) : 0; t0 = 0; t1 = pos >= 0 ? 1 : 0; if (pos >= 0) { info = a.tinfo[T.tile]; stage_issue(a, T.tile, info.x, IDX); } }
-  else { if (t0 < t1) { info = a.tinfo[t0]; stage_issue(a, t0, info.x, IDX); } T.tile = t0; }
+  AHEAD_DECL(scratch)
+  if constexpr (DYN) { T.tile = pos >= 0 ? __builtin_amdgcn_readfirstlane(a.tile_map[pos]) : 0; t0 = 0; t1 = pos >= 0 ? 1 : 0; if (pos >= 0) { info = a.tinfo[T.tile]; AHEAD_GRAB(T.tile, info.x, false) } }
+  else { if (t0 < t1) { info = a.tinfo[t0]; AHEAD_GRAB(t0, info.x, false) } T.tile = t0; }
   while (DYN ? pos >= 0 : T.tile < t1) {
     // DYN: on the last tile of its chunk thread 0 takes the next chunk between the prologue's barriers (everybody is through
     // with the previous iteration's read of s_dyn by then), all threads read it behind the second barrier
     const bool last_of_chunk = DYN && pos + 1 >= pos_end;
-    TILE_PROLOGUE_N(false, false, nullptr, nullptr, 1.0,
-                    if (DYN && last_of_chunk && threadIdx.x == 0) grab();,
+    PH(0)
+    TILE_PROLOGUE_A(false, false, nullptr, nullptr, 1.0,
+                    emb_finish(); PH(1),
+                    PH(2) if (DYN && last_of_chunk && threadIdx.x == 0) grab();,
+                    PH(3),
                     (DYN ? dyn_next_tile(a.tile_map, last_of_chunk ? __builtin_amdgcn_readfirstlane(s_dyn[0]) : pos + 1) : (T.tile + 1 < t1 ? T.tile + 1 : -1)))
+    PH(4)
     int npos = pos + 1, npos_end = pos_end;
     if (DYN && last_of_chunk) { npos = __builtin_amdgcn_readfirstlane(s_dyn[0]); npos_end = __builtin_amdgcn_readfirstlane(s_dyn[1]); }
     for (int o = threadIdx.x; o < T.nown; o += blockDim.x) {
@@ -1476,6 +1546,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
       OWN_PROLOGUE
       double xi, yi, zi;
       LPOS_RD(sp, sp, SLOTCAP(a), slot, xi, yi, zi)
+      emb_finish();                                        // (a second own atom of this thread in one tile: never at autotile's shapes)
       double fx = 0, fy = 0, fz = 0, ee = 0, rr = 0, vir = 0;
       int nb = 0, sgn = 0;
       LIST_WORDS_BEGIN
@@ -1507,7 +1578,13 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
         SCHED_BARRIER;
         PRIO_HI;
 #pragma unroll
-        for (int e = 0; e < UNR; e++) { A[e] = tm[k[e]]; B[e] = tm[k[e] + 1]; C[e] = tm[k[e] + 2]; }
+        for (int e = 0; e < UNR; e++) {
+          // the three rows of a neighbour: from the table in the LDS, or -- for P1_GROWS[ring slot] of the word's four neighbours --
+          // from its copy in global memory through the vector L1 / L2: the LDS pipe is what this pass waits for, the texture path idles
+          constexpr int growsN[4] = P1_GROWS;
+          if (e < growsN[RSLOT]) { const double2 *g = (const double2 *) a.merged + k[e]; A[e] = g[0]; B[e] = g[1]; C[e] = g[2]; }
+          else { A[e] = tm[k[e]]; B[e] = tm[k[e] + 1]; C[e] = tm[k[e] + 2]; }
+        }
         PRIO_LO;
         SCHED_BARRIER;
 #pragma unroll
@@ -1529,20 +1606,25 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
       a.f[i] = fx; a.f[a.cap + i] = fy; a.f[2 * (size_t) a.cap + i] = fz;
       a.rhoh[i] = rr;
       if (FEMB) {                                           // PAIR_INT on embed_pot, :757-760; EAM_DF into pos.w
-        int dummy = 0;
-        const Tab3 q = tab3(a.emb.tab, 1, 0, a.emb.begin[0], a.emb.end[0], a.emb.invstep[0], rr, dummy);
-        const double pe = tab_val(q);
-        a.posw[i].w = tab_grad(q);
-        a.epot[i] = ee + pe;
-        sums[2] += pe;
+        // tab3's index and its three row loads now; value, gradient and their stores in emb_finish, in front of the next tile's
+        // first barrier: the rows travel together with that tile's first loads instead of in a round trip of their own
+        double ea = (rr < emb_end ? rr : emb_end) - emb_begin;
+        ea = (ea < 0 ? 0 : ea) * emb_istep;
+        const int ek = (int) ea;
+        const double *ep = a.emb.tab + ek;
+        pend_chi = ea - ek; pend_p0 = ep[0]; pend_p1 = ep[1]; pend_p2 = ep[2]; pend_ee = ee; pend_i = i;
       } else a.epot[i] = ee;
       if (TTMN) a.numneighs[i] = nb;
       sums[0] += ee; sums[1] += vir;
     }
-    TILE_EPILOGUE
+    PH(5)
+    TILE_EPILOGUE_A(false)
+    PH(6)
     if constexpr (DYN) { pos = next_tile >= 0 ? npos : -1; pos_end = npos_end; T.tile = next_tile >= 0 ? next_tile : 0; }
     else T.tile++;
   }
+  emb_finish();
+  PH_END
   block_sum<3>(sums, scratch);
   if (threadIdx.x == 0) {
     const size_t pb = (size_t) blockIdx.x + (DYN ? (size_t) a.part_off : 0);
@@ -1592,10 +1674,10 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) P3_ATTR void k_pass3_tile(TileArgs
   const double wscale = NT1 ? a.rho.invstep[0] : 1.0;
   const int kz = a.rho.nrows * a.rho.ncols;
   int4 info = make_int4(0, 0, 0, 0);
-  int IDX[STG];
-  if (t0 < t1) { info = a.tinfo[t0]; stage_issue(a, t0, info.x, IDX); }
+  AHEAD_DECL(scratch)
+  if (t0 < t1) { info = a.tinfo[t0]; AHEAD_GRAB(t0, info.x, !NT1) }
   for (T.tile = t0; T.tile < t1; T.tile++) {
-    TILE_PROLOGUE(true, !NT1, sw, ts, wscale)
+    TILE_PROLOGUE_A(true, !NT1, sw, ts, wscale, , , , (T.tile + 1 < t1 ? T.tile + 1 : -1))
     const int nt = a.ntypes, inc = NT1 ? 1 : nt * nt;
     const TabK cr = {a.rho.begin[0], a.rho.end[0], a.rho.invstep[0], 2 * a.rho.invstep[0]};
     for (int o = threadIdx.x; o < T.nown; o += blockDim.x) {
@@ -1674,7 +1756,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) P3_ATTR void k_pass3_tile(TileArgs
       a.f[i] += fx; a.f[a.cap + i] += fy; a.f[2 * (size_t) a.cap + i] += fz;
       sums[0] += vir;
     }
-    TILE_EPILOGUE
+    TILE_EPILOGUE_A(!NT1)
   }
   block_sum<1>(sums, scratch);
   if (threadIdx.x == 0) a.partials[(size_t) blockIdx.x * IMDGPU_NPART + 3] = sums[0];
@@ -1726,10 +1808,10 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) __attribute__((amdgpu_waves_per_eu
   const int kz = a.ncoef - 1;
   const double begin = a.rho.begin[0], end = a.rho.end[0], istep = a.rho.invstep[0];
   int4 info = make_int4(0, 0, 0, 0);
-  int IDX[STG];
-  if (t0 < t1) { info = a.tinfo[t0]; stage_issue(a, t0, info.x, IDX); }
+  AHEAD_DECL(scratch)
+  if (t0 < t1) { info = a.tinfo[t0]; AHEAD_GRAB(t0, info.x, false) }
   for (T.tile = t0; T.tile < t1; T.tile++) {
-    TILE_PROLOGUE(true, false, sw, nullptr, wscale)
+    TILE_PROLOGUE_A(true, false, sw, nullptr, wscale, , , , (T.tile + 1 < t1 ? T.tile + 1 : -1))
     for (int o = threadIdx.x; o < T.nown; o += blockDim.x) {
       const int i = T.own_start + o;
       OWN_PROLOGUE
@@ -1779,7 +1861,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) __attribute__((amdgpu_waves_per_eu
       a.f[i] += fx; a.f[a.cap + i] += fy; a.f[2 * (size_t) a.cap + i] += fz;
       sums[0] += -0.5 * vir;
     }
-    TILE_EPILOGUE
+    TILE_EPILOGUE_A(false)
   }
   block_sum<1>(sums, scratch);
   if (threadIdx.x == 0) a.partials[(size_t) blockIdx.x * IMDGPU_NPART + 3] = sums[0];
@@ -1922,6 +2004,16 @@ extern "C" int imdgpu_create(imdgpu_ctx **out, int device)
 
 extern "C" void imdgpu_destroy(imdgpu_ctx *c)
 {
+#ifdef PHASE_TIMING
+  {
+    unsigned long long h[8];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof(h)) == hipSuccess && h[7]) {
+      fprintf(stderr, "[imdgpu phases] thread %d of k_pass1_tile_merged, us per workgroup-launch:", PH_THREAD);
+      for (int q = 0; q < 7; q++) fprintf(stderr, " %d=%.1f", q, h[q] * 0.01 / (double) h[7]);
+      fprintf(stderr, "  (%llu workgroup-launches)\n", h[7]);
+    }
+  }
+#endif
   if (!c) return;
   (void) hipSetDevice(c->device);
   (void) hipDeviceSynchronize();
