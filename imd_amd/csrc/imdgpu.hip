@@ -1123,7 +1123,12 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile32(TileArgs a)
 // Lanes past their own count get the dummy word either way.
 // experiment (make EXTRA=-DWAVE_FAIR): a wave's priority falls as it gets through its list (3, 2, 1, 0 by quarters), so the waves
 // a SIMD would serve last (it prefers its oldest wave) catch up and the workgroup's waves reach the barrier together
-#ifdef WAVE_FAIR
+#if defined(WAVE_FAIR) && WAVE_FAIR >= 2
+// WAVE_FAIR = n >= 2: the first n waves keep the top priority (they finish early and do the staging ahead), the others share fairly
+#define WAVE_FAIR_BEGIN const bool wf_early = (int) (threadIdx.x >> 6) < WAVE_FAIR; const int wf1 = (nwu + 2) / 3, wf2 = (2 * nwu + 2) / 3; if (wf_early) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);
+#define WAVE_FAIR_STEP if (!wf_early && w >= wf1) { if (w >= wf2) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
+#define WAVE_FAIR_END __builtin_amdgcn_s_setprio(0);
+#elif defined(WAVE_FAIR)
 #define WAVE_FAIR_BEGIN const int wf1 = (nwu + 3) >> 2, wf2 = (nwu + 1) >> 1, wf3 = (3 * nwu + 3) >> 2; __builtin_amdgcn_s_setprio(3);
 #define WAVE_FAIR_STEP if (w >= wf1) { if (w >= wf3) __builtin_amdgcn_s_setprio(0); else if (w >= wf2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2); }
 #define WAVE_FAIR_END __builtin_amdgcn_s_setprio(0);
@@ -1181,7 +1186,9 @@ template <int S> struct RingSlot { static constexpr int value = S; };
 // exhausted and arrive at the barrier with nothing to wait for.  Behind the barrier the held records are written to the planes;
 // chunks nobody took (more than SA * waves: tiles beyond autotile's shapes) are staged by a plain loop.  Two counters, used in
 // turns: the one the next grab will use is zeroed between the barriers of the tile before.
+#ifndef SA
 #define SA 8
+#endif
 #define AHEAD_DECL(SCRATCH)                                                                                      \
   int ah_c0 = 0, ah_par = 0; int ah_idx[SA], ah_T[SA]; double4 ah_P[SA];                                          \
   _Pragma("unroll") for (int u = 0; u < SA; u++) { ah_idx[u] = -1; ah_T[u] = 0; ah_P[u] = make_double4(0, 0, 0, 0); } \
@@ -1810,13 +1817,21 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) __attribute__((amdgpu_waves_per_eu
   int4 info = make_int4(0, 0, 0, 0);
   AHEAD_DECL(scratch)
   if (t0 < t1) { info = a.tinfo[t0]; AHEAD_GRAB(t0, info.x, false) }
+  // f += (this pass's force) is a read-modify-write: the read is issued when an atom is through, the sum and the store follow in
+  // front of the next tile's first barrier, under that tile's first loads (like the embedding look-up of pass 1)
+  int pf_i = -1;
+  double pf_x = 0, pf_y = 0, pf_z = 0, pf_ox = 0, pf_oy = 0, pf_oz = 0;
+  auto f_finish = [&]() {
+    if (pf_i >= 0) { a.f[pf_i] = pf_ox + pf_x; a.f[a.cap + pf_i] = pf_oy + pf_y; a.f[2 * (size_t) a.cap + pf_i] = pf_oz + pf_z; pf_i = -1; }
+  };
   for (T.tile = t0; T.tile < t1; T.tile++) {
-    TILE_PROLOGUE_A(true, false, sw, nullptr, wscale, , , , (T.tile + 1 < t1 ? T.tile + 1 : -1))
+    TILE_PROLOGUE_A(true, false, sw, nullptr, wscale, f_finish();, , , (T.tile + 1 < t1 ? T.tile + 1 : -1))
     for (int o = threadIdx.x; o < T.nown; o += blockDim.x) {
       const int i = T.own_start + o;
       OWN_PROLOGUE
       double xi, yi, zi, wi;
       LPOS_RDW(sp, sw, SLOTCAP(a), slot, xi, yi, zi, wi)
+      f_finish();
       double fx = 0, fy = 0, fz = 0, vir = 0;
       LIST_WORDS_BEGIN
         double dx[UNR], dy[UNR], dz[UNR], wj[UNR], r2[UNR], ch[UNR];
@@ -1858,11 +1873,12 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) __attribute__((amdgpu_waves_per_eu
         }
         HALF_END
       LIST_WORDS_END(RING)
-      a.f[i] += fx; a.f[a.cap + i] += fy; a.f[2 * (size_t) a.cap + i] += fz;
+      pf_ox = a.f[i]; pf_oy = a.f[a.cap + i]; pf_oz = a.f[2 * (size_t) a.cap + i]; pf_x = fx; pf_y = fy; pf_z = fz; pf_i = i;
       sums[0] += -0.5 * vir;
     }
     TILE_EPILOGUE_A(false)
   }
+  f_finish();
   block_sum<1>(sums, scratch);
   if (threadIdx.x == 0) a.partials[(size_t) blockIdx.x * IMDGPU_NPART + 3] = sums[0];
 }

@@ -1199,6 +1199,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     double *neo, EosDev cve, PersistDev P)
 {
   const int lane = threadIdx.x, tile = blockIdx.x;
+#ifdef PERSIST_PRIO
+  // experiment: a sub-step's arithmetic at a raised priority (its few hundred instructions queue behind the force pass's three
+  // waves on the SIMD otherwise), the polls for the neighbours' records at priority 0 (a spinning wave must not take issue slots)
+#define PRIO_WORK __builtin_amdgcn_s_setprio(PERSIST_PRIO)
+#define PRIO_POLL __builtin_amdgcn_s_setprio(0)
+#else
+#define PRIO_WORK
+#define PRIO_POLL
+#endif
   // The blocks are anchored on the bounding box of the ACTIVE cells of this step (k_ttm_fillmesh): a slab with vacuum, or the
   // share of it a rank holds, needs blocks for its filled layers only, and the box moves with the surfaces.  Per dimension
   // the box of n layers is cut into ceil(n / 4) blocks of four layers -- with n = 4 q + 1 the last two are three and two
@@ -1409,7 +1418,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
       const unsigned long long want = (unsigned long long) (P.base + (unsigned) s);
       const unsigned long long *R = P.rec + (size_t) (s & 1) * P.ncell * 4;
       const unsigned long long *X = REM ? P.xrec + (size_t) (s & 1) * P.xcells * 4 : nullptr;
-      for (;;) {
+      PRIO_POLL;
+      for (int spin = 0;; spin++) {
 #pragma unroll
         for (int d = 0; d < 3; d++)
           if (todo >> d & 1u) {
@@ -1427,7 +1437,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             }
           }
         if (__all(todo == 0)) break;
-        if (__any(wall_clock64() - tloop > PERSIST_SPIN_TICKS || ld_flag(P.gate) == 3u)) {   // a neighbour never came: give up, loudly
+        if ((spin & 31) == 31 && __any(wall_clock64() - tloop > PERSIST_SPIN_TICKS || ld_flag(P.gate) == 3u)) {   // a neighbour never came: give up, loudly
           if (lane == 0) {
             __hip_atomic_store(P.gate, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(P.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1437,6 +1447,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
         }
         __builtin_amdgcn_s_sleep(1);
       }
+      PRIO_WORK;
     }
     // (2) the six flux terms in the reference's order; neighbours inside the block by lane shuffle, mirror = own values
     double flux = 0;
