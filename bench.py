@@ -545,10 +545,10 @@ def main():
             n, ms = prof[which]
             if which == "pass1":
                 byts = natoms * (72.0 + 4.0 * M + (32.0 if fused else 0.0))
-                kn = ("k_pass1_tile_merged<%s, %s, %d>" % (ttmn, "true" if fused else "false", fcap)) if tiles else "k_pass1"
+                kn = ("k_pass1_tile_merged<%s, %s, %d, false>" % (ttmn, "true" if fused else "false", fcap)) if tiles else "k_pass1"
                 label = kn + (" (pass 1: pair + rho, embedding pass folded in)" if fused else " (pass 1: pair + rho)")
                 if prof["pass1b"][0]:
-                    kn = kn[:-1] + ", true>"
+                    kn = kn.replace(", false>", ", true>")
                     label = kn + " (pass 1 from a tile queue under the position halo, two launches per pass: pair + rho, embedding pass folded in)"
             else:
                 byts = natoms * (84.0 + 4.0 * M)

@@ -3039,15 +3039,29 @@ __device__ __forceinline__ FdtdCoef fdtd_coef(const FdtdDev &F, const FdtdCell &
   K.inv_dx = 1.0 / dx;
   return K;
 }
+// the two source terms of a solver step at time t: what the soft source adds to E at the source cell and what the TF/SF
+// correction takes from H in the cell in front of it (fdtd_softsource, imd_fdtd.c:78-83,114-122; :293-303)
+__device__ __forceinline__ double fdtd_hinc(const FdtdDev &F, double t, double laser_timefun)
+{
+  const double wt = 2.0 * C_PI * (F_C0 / (F.dx * F.Nlambdax));
+  return laser_timefun * sin(wt * (t + F.dt)) / F.Imp0;
+}
+__device__ __forceinline__ double fdtd_einc(const FdtdDev &F, double t)
+{
+  const double wt = 2.0 * C_PI * (F_C0 / (F.dx * F.Nlambdax));
+  const double d = t - F.t0;
+  return sin(wt * t) * exp(-0.5 * (d * d) / F.sigma_t_squared) * F.E0;
+}
+// pre (may be null): {Hinc, Einc} of this step, evaluated ahead for all steps of the launch by as many threads (k_ttm_fdtd_chain):
+// a sine, and a sine times an exponential, on the critical path of every one of the ~430 steps of an MD step otherwise
 __device__ __forceinline__ void fdtd_step(const FdtdDev &F, FdtdCell &c, int i, bool have, bool inner, double t, double laser_timefun,
-                                          double *sH, double *sE, const FdtdCoef *K = nullptr)
+                                          double *sH, double *sE, const FdtdCoef *K = nullptr, const double *pre = nullptr)
 {
   const double dt = F.dt, dx = F.dx;
-  const double wt = 2.0 * C_PI * (F_C0 / (dx * F.Nlambdax));
   const int ilocal = F.srcx_int + 1;
   if (F.containssrc == 1 && i == ilocal) {                                   // fdtd_softsource, :78-83,114-122 (ilocal < nx)
     const double ezy2 = (dt / dx) / (F_EPS0);
-    const double Hinc = laser_timefun * sin(wt * (t + dt)) / F.Imp0;
+    const double Hinc = pre ? pre[0] : fdtd_hinc(F, t, laser_timefun);
     c.E += ezy2 * Hinc;
   }
   if (have) sH[i] = c.H;                     // every thread of the block passes the two barriers (threads past the row idle)
@@ -3099,8 +3113,7 @@ __device__ __forceinline__ void fdtd_step(const FdtdDev &F, FdtdCell &c, int i, 
     }
   }
   if (F.containssrc && i == ilocal - 1) {                                    // TF/SF: no wave towards -x, :293-303
-    const double d = t - F.t0;
-    const double Einc = sin(wt * t) * exp(-0.5 * (d * d) / F.sigma_t_squared) * F.E0;
+    const double Einc = pre ? pre[1] : fdtd_einc(F, t);
     c.H -= (dt / dx) / (F_MU0) * Einc;
   }
 }
@@ -3111,7 +3124,7 @@ template <bool WITH_TTM, int MAXT>
 __global__ __launch_bounds__(MAXT) void k_ttm_fdtd_chain(Lat L, FdtdDev F, int nsub, int ndiff, double t_SI, double tau_fdtd,
     double tau_diff, int laser_active, double laser_timefun, int steps, const int *natoms, double *T1, double *T2, double *U1,
     double *U2, double *fd_k, double *Ce, double *fd_g, const double *md_temp, double *source, const double *dens, double *xi,
-    double *Zo, double *neo, EosDev cve, EosDev ee, double *eabs)
+    double *Zo, double *neo, EosDev cve, EosDev ee, double *eabs, int npre)
 {
   extern __shared__ double fl[];
   const int nx = F.nx, i = threadIdx.x;
@@ -3152,8 +3165,21 @@ __global__ __launch_bounds__(MAXT) void k_ttm_fdtd_chain(Lat L, FdtdDev F, int n
   if (hoist && have) K = fdtd_coef(F, c);
   const MeshPre mpre = mesh_pre(L, (WITH_TTM && inner && c.active) ? Tl : 1.0, (WITH_TTM && inner && c.active) ? rho : 1.0);
   const double inv_nat = nat > 0 ? 1.0 / ((double) nat) : 0.0, inv_tlrho = (WITH_TTM && inner && c.active) ? 1.0 / (Tl * rho) : 0.0;
+  // the source terms of all nsub steps ahead: the times as the loop accumulates them (one thread, nsub additions), then one step
+  // per thread.  Room for them in the LDS behind the row's arrays when the launch brought it (npre >= nsub).
+  double *sPre = (double *) (sN + nx + (nx & 1));
+  const bool pre = laser_active && F.containssrc && npre >= nsub;
+  if (pre) {
+    if (i == 0) { double tq = t_SI; for (int q = 0; q < nsub; q++) { sPre[2 * q] = tq; tq += tau_fdtd; } }
+    __syncthreads();
+    for (int q = i; q < nsub; q += blockDim.x) {
+      const double tq = sPre[2 * q];
+      sPre[2 * q] = fdtd_hinc(F, tq, laser_timefun); sPre[2 * q + 1] = fdtd_einc(F, tq);
+    }
+    __syncthreads();
+  }
   for (int s = 0; s < nsub; s++) {
-    if (laser_active) fdtd_step(F, c, i, have, inner, t, laser_timefun, sH, sE, hoist ? &K : nullptr);       // uniform: laser_active is a kernel argument
+    if (laser_active) fdtd_step(F, c, i, have, inner, t, laser_timefun, sH, sE, hoist ? &K : nullptr, pre ? sPre + 2 * s : nullptr);       // uniform: laser_active is a kernel argument
     if (WITH_TTM) {
       for (int q = 0; q < ndiff; q++) {
         if (have) { sT[i] = Te; sK[i] = kk; }
@@ -3433,10 +3459,11 @@ extern "C" int imdgpu_ttm_fdtd_substeps(imdgpu_ctx *ctx, double t_SI, int nsub, 
   double *row = nullptr;
   HIPCHK(hipMalloc((void **) &row, F.nx * sizeof(double)));
   HIPCHK(hipMemsetAsync(row, 0, F.nx * sizeof(double), ctx->stream));
-#define FD_BARE(MT) hipLaunchKernelGGL((k_ttm_fdtd_chain<false, MT>), dim3(1), dim3(thr), (4 * F.nx + F.nx / 2 + 2) * sizeof(double), ctx->stream, L, F, nsub, 0, \
+  const int npre = nsub <= 4096 ? nsub : 0;               // source terms evaluated ahead (LDS: 16 bytes per step)
+#define FD_BARE(MT) hipLaunchKernelGGL((k_ttm_fdtd_chain<false, MT>), dim3(1), dim3(thr), (4 * F.nx + F.nx / 2 + 2 + 2 + 2 * npre) * sizeof(double), ctx->stream, L, F, nsub, 0, \
                      t_SI, tau_FDTD, 0.0, 1, laser_timefun, 1, t->natoms, (double *) nullptr, (double *) nullptr, (double *) nullptr, \
                      (double *) nullptr, (double *) nullptr, (double *) nullptr, (double *) nullptr, (const double *) nullptr, row, \
-                     (const double *) nullptr, (double *) nullptr, (double *) nullptr, (double *) nullptr, t->cve, t->ee, (double *) nullptr)
+                     (const double *) nullptr, (double *) nullptr, (double *) nullptr, (double *) nullptr, t->cve, t->ee, (double *) nullptr, npre)
   if (thr <= 256) FD_BARE(256); else FD_BARE(1024);
 #undef FD_BARE
   HIPCHK(hipGetLastError());
@@ -3466,10 +3493,11 @@ static int fdtd_lattice_loop(imdgpu_ctx *ctx, TtmState *t, const Lat &L, int ste
   const int thr = (F.nx + 63) / 64 * 64;
   t->laser_active = active;
   ProfScope ps(ctx, PROF_TTM_DIFF);
-#define FD_LOOP(MT) hipLaunchKernelGGL((k_ttm_fdtd_chain<true, MT>), dim3(1), dim3(thr), (4 * F.nx + F.nx / 2 + 2) * sizeof(double), ctx->stream, L2, F, nsub, ndiff, \
+  const int npre = nsub <= 4096 ? nsub : 0;
+#define FD_LOOP(MT) hipLaunchKernelGGL((k_ttm_fdtd_chain<true, MT>), dim3(1), dim3(thr), (4 * F.nx + F.nx / 2 + 2 + 2 + 2 * npre) * sizeof(double), ctx->stream, L2, F, nsub, ndiff, \
                      S->t_SI, tau_f, tau_d, active, timefun, steps, t->natoms, t->temp[t->cur], t->temp[t->cur ^ 1], t->U[t->cur], \
                      t->U[t->cur ^ 1], t->fd_k[t->kcur], t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve, \
-                     t->ee, t->d_eabs)
+                     t->ee, t->d_eabs, npre)
   if (thr <= 256) FD_LOOP(256); else FD_LOOP(1024);
 #undef FD_LOOP
   HIPCHK(hipGetLastError());
