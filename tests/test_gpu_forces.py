@@ -289,3 +289,20 @@ def test_bench_size_properties_with_ttm():
     assert np.abs(f0 - f1).max() < 1e-11 * max(np.abs(f0).max(), 1e-3)
     assert np.array_equal(res[0][1], res[1][1])
     assert np.abs(f1.sum(axis=0)).max() < 1e-6
+
+
+@pytest.mark.parametrize("tile", ["1,1,2", "3,4,4"])
+def test_parity_cases_under_other_tile_shapes(tile):
+    """the force / list / trajectory parity cases again with the tile shape forced (IMDGPU_TILE): tiny tiles (many tiles per
+    workgroup, every wave stages ahead) and tiles with more own atoms than threads (a thread takes a second atom: the work a
+    force pass defers to the next tile's prologue -- embedding look-up, force read-modify-write -- is completed in between)"""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, IMDGPU_TILE=tile)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k",
+                        "forces_vs_reference_golden or neighbour_list_bit_exact or trajectory_vs_reference or forces_vs_oracle"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
