@@ -554,7 +554,7 @@ __global__ __launch_bounds__(512) void k_pass3_gt(ForceArgs a)
 // neighbour list holds 16-bit LDS slot numbers (4 per 8-byte load, ELL-transposed
 // per tile).  HBM sees: list (2 B/entry), own-atom outputs, one staging pass.
 // ===========================================================================
-#define IMDGPU_KERNEL_REV 9
+#define IMDGPU_KERNEL_REV 10
 #define LDS_LIMIT (160 * 1024)
 #define TABLE_LDS_LIMIT (150 * 1024)                 // global-gather kernels: tables beyond this stay in global memory
 #define NH_MAX 512                                   // halo cells per tile (<= 6*6*6 = 216 for tiles up to 4^3)
@@ -1200,12 +1200,15 @@ template <int S> struct RingSlot { static constexpr int value = S; };
     int c_ = 0;                                                                                                  \
     if ((threadIdx.x & 63) == 0) c_ = atomicAdd(&ah_cnt[ah_par], SA);                                            \
     ah_c0 = __builtin_amdgcn_readfirstlane(c_);                                                                  \
-    const int *src_ = a.tsrc + (size_t) (NT) * SLOTCAP(a);                                                       \
-    _Pragma("unroll") for (int u = 0; u < SA; u++) { const int s_ = (ah_c0 + u) * 64 + (int) (threadIdx.x & 63); ah_idx[u] = s_ < (NSL) ? src_[s_] : -1; } \
-    /* every record is assigned on every path (a guarded load here, zeros where the grab is skipped): otherwise the registers */ \
-    /* count as live through the neighbour loop, which has none to spare */                                      \
-    _Pragma("unroll") for (int u = 0; u < SA; u++) ah_P[u] = a.pos[ah_idx[u] >= 0 ? ah_idx[u] : 0];             \
-    if (WITH_T) { _Pragma("unroll") for (int u = 0; u < SA; u++) ah_T[u] = a.type[ah_idx[u] >= 0 ? ah_idx[u] : 0]; } \
+    /* every record is assigned on every path (a guarded load, or zeros): otherwise the registers count as live through the */ \
+    /* neighbour loop, which has none to spare.  A wave that finds the counter exhausted -- the LAST waves to finish, the ones */ \
+    /* the workgroup waits for -- issues no load at all */                                                       \
+    if (ah_c0 * 64 < (NSL)) {                                                                                    \
+      const int *src_ = a.tsrc + (size_t) (NT) * SLOTCAP(a);                                                     \
+      _Pragma("unroll") for (int u = 0; u < SA; u++) { const int s_ = (ah_c0 + u) * 64 + (int) (threadIdx.x & 63); ah_idx[u] = s_ < (NSL) ? src_[s_] : -1; } \
+      _Pragma("unroll") for (int u = 0; u < SA; u++) ah_P[u] = a.pos[ah_idx[u] >= 0 ? ah_idx[u] : 0];           \
+      if (WITH_T) { _Pragma("unroll") for (int u = 0; u < SA; u++) ah_T[u] = a.type[ah_idx[u] >= 0 ? ah_idx[u] : 0]; } \
+    } else { _Pragma("unroll") for (int u = 0; u < SA; u++) { ah_idx[u] = -1; ah_T[u] = 0; ah_P[u] = make_double4(0, 0, 0, 0); } } \
   }
 #define TILE_PROLOGUE_A(WITH_W, WITH_T, SW, TS, WSCALE, PRE, BETWEEN, MID, NEXT)                                 \
     T.own_start = info.y; T.nown = info.z;                                                                       \
@@ -1541,10 +1544,11 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
     const bool last_of_chunk = DYN && pos + 1 >= pos_end;
     PH(0)
     TILE_PROLOGUE_A(false, false, nullptr, nullptr, 1.0,
-                    emb_finish(); PH(1),
+                    PH(1),
                     PH(2) if (DYN && last_of_chunk && threadIdx.x == 0) grab();,
                     PH(3),
                     (DYN ? dyn_next_tile(a.tile_map, last_of_chunk ? __builtin_amdgcn_readfirstlane(s_dyn[0]) : pos + 1) : (T.tile + 1 < t1 ? T.tile + 1 : -1)))
+    emb_finish();                        // the previous tile's atom: its rows have had both barriers' time to arrive
     PH(4)
     int npos = pos + 1, npos_end = pos_end;
     if (DYN && last_of_chunk) { npos = __builtin_amdgcn_readfirstlane(s_dyn[0]); npos_end = __builtin_amdgcn_readfirstlane(s_dyn[1]); }
@@ -1825,7 +1829,8 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) __attribute__((amdgpu_waves_per_eu
     if (pf_i >= 0) { a.f[pf_i] = pf_ox + pf_x; a.f[a.cap + pf_i] = pf_oy + pf_y; a.f[2 * (size_t) a.cap + pf_i] = pf_oz + pf_z; pf_i = -1; }
   };
   for (T.tile = t0; T.tile < t1; T.tile++) {
-    TILE_PROLOGUE_A(true, false, sw, nullptr, wscale, f_finish();, , , (T.tile + 1 < t1 ? T.tile + 1 : -1))
+    TILE_PROLOGUE_A(true, false, sw, nullptr, wscale, , , , (T.tile + 1 < t1 ? T.tile + 1 : -1))
+    f_finish();                          // the previous tile's atom: its old force has had both barriers' time to arrive
     for (int o = threadIdx.x; o < T.nown; o += blockDim.x) {
       const int i = T.own_start + o;
       OWN_PROLOGUE
