@@ -2079,8 +2079,9 @@ extern "C" int imdgpu_set_option(imdgpu_ctx *ctx, const char *name, int value)
     ctx->tile[name[5] - 'x'] = value; ctx->autotiled = 1;
     return ctx->have_geometry ? setup_tiles(ctx) : 0;
   }
-  if (!strcmp(name, "ttm_flux")) { ctx->ttm_flux = value ? 1 : 0; if (!value) ctx->ttm_adv = 0; return 0; }
-  if (!strcmp(name, "ttm_adv")) { ctx->ttm_adv = value ? 1 : 0; if (value) ctx->ttm_flux = 1; return 0; }
+  // (cells_epoch: the atoms' FD-cell memory may be stale when the bookkeeping comes back on, see imdgpu_ttm_update_fd)
+  if (!strcmp(name, "ttm_flux")) { ctx->ttm_flux = value ? 1 : 0; if (!value) ctx->ttm_adv = 0; ctx->cells_epoch++; return 0; }
+  if (!strcmp(name, "ttm_adv")) { ctx->ttm_adv = value ? 1 : 0; if (value) ctx->ttm_flux = 1; ctx->cells_epoch++; return 0; }
   if (!strcmp(name, "p3_coef")) { ctx->p3_coef = value ? 1 : 0; return 0; }
   if (!strcmp(name, "p3_klo")) { ctx->p3_klo = value > 0 ? value : 0; return 0; }           // tests: which rows k_pass3_tile_coef holds
   if (!strcmp(name, "eos_bilinear")) { ctx->eos_bilinear = value ? 1 : 0; return 0; }    // before ttm_init / ttm1d_init

@@ -86,6 +86,8 @@ struct TtmState {
   hipEvent_t ev_pstat = nullptr;
   const int *graph_guard[2] = {nullptr, nullptr};
   double *d_ufd_part = nullptr; size_t ufd_part_cap = 0;   // partial sums of the chunked update_fd
+  long long fdc_epoch = -1;         // ctx->cells_epoch at the last update_fd that did the flux bookkeeping (imdgpu_ttm_update_fd)
+  int flux_zero = 0;                // the flux counters are known to be all zero
   // decomposed lattice, faces through ghost RECORDS in the neighbours' device memory (imdgpu_ttm_remote_*)
   unsigned long long *d_xrec = nullptr; size_t xrec_bytes = 0; int xoff[6]{}, xcells = 0; bool xrec_fine = false;
   unsigned long long *peer[6]{}; int xremote = 0; bool xrec_ready = false;
@@ -1797,6 +1799,7 @@ static int ttm_xfer(imdgpu_ctx *ctx, const imdgpu_ttm_fields *f, bool down)
     } else {
       for (size_t c = 0; c < n; c++) for (int q = 0; q < 8; q++) h[q * n + c] = f->flux[8 * c + q];
       HIPCHK(hipMemcpy(t->flux, h.data(), 8 * n * 4, hipMemcpyHostToDevice));
+      t->flux_zero = 0;
     }
   }
   if (f->vcom) {                       // planes <-> interleaved
@@ -1935,11 +1938,22 @@ extern "C" int imdgpu_ttm_update_fd(imdgpu_ctx *ctx, int steps)
     HIPCHK(hipGetLastError());
     return 0;
   }
+  // The flux bookkeeping (imd_ttm_3D.c:335-370) compares the FD cell an atom is counted in with the one it was counted in last
+  // time.  Atoms are counted by the MD cell they are binned in, and between two re-binnings nobody changes cells: every counter
+  // is zero and every atom's memory would be rewritten with what it holds.  So only the first update_fd behind a re-binning (or
+  // an upload, a migration, a change of the option) does that part -- 12 of the 52 bytes per atom the kernel moves, and its
+  // eight reductions per FD cell; the others leave the counters at zero.
+  const bool track = ctx->ttm_flux != 0, redo = track && (t->fdc_epoch != ctx->cells_epoch || steps < 1);
+  if (track && !redo && !t->flux_zero) {
+    HIPCHK(hipMemsetAsync(t->flux, 0, 8 * (size_t) t->ncell * sizeof(int), ctx->stream));
+    t->flux_zero = 1;
+  }
   hipLaunchKernelGGL(k_ttm_update_fd, dim3(nblk((long long) t->ldim[0] * t->ldim[1] * t->ldim[2] * 64, TTM_WG)), dim3(TTM_WG), 0, ctx->stream, L, steps,
                      ctx->cap_local, ctx->cell_start, ctx->cell_cnt, ctx->numneighs, ctx->p, ctx->mass, t->natoms,
                      t->natoms_old, t->temp[0], t->temp[1], t->xi, t->md_temp, t->source, t->vcom, t->dens, t->ncell,
-                     (double *) nullptr, ctx->ttm_flux ? ctx->fdc : (int *) nullptr, ctx->ttm_flux ? t->flux : (int *) nullptr);
+                     (double *) nullptr, redo ? ctx->fdc : (int *) nullptr, redo ? t->flux : (int *) nullptr);
   HIPCHK(hipGetLastError());
+  if (redo) { t->fdc_epoch = ctx->cells_epoch; t->flux_zero = 0; }
   return 0;
 }
 
@@ -1971,6 +1985,7 @@ extern "C" int imdgpu_ttm_apply_blocks(imdgpu_ctx *ctx, int steps, const double 
                      dev_offs, t->ldim[0], t->ldim[1], t->ldim[2], dev_in, t->natoms, t->natoms_old, t->temp[0], t->temp[1],
                      t->xi, t->md_temp, t->source, t->vcom, t->dens, t->ncell, ctx->ttm_flux ? t->flux : (int *) nullptr);
   HIPCHK(hipGetLastError());
+  t->flux_zero = 0;
   return 0;
 }
 
@@ -2227,6 +2242,7 @@ extern "C" int imdgpu_ttm_commflux(imdgpu_ctx *ctx, int side, int unpack, double
   hipLaunchKernelGGL(k_ttm_commflux, dim3(nblk(n, TTM_WG)), dim3(TTM_WG), 0, ctx->stream, L, side, unpack, t->flux, t->ncell,
                      t->U[t->cur], dev_buf);
   HIPCHK(hipGetLastError());
+  if (unpack) t->flux_zero = 0;               // a neighbour's counters in the ghost column
   return 0;
 }
 
