@@ -1687,8 +1687,14 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) P3_ATTR void k_pass3_tile(TileArgs
   int4 info = make_int4(0, 0, 0, 0);
   AHEAD_DECL(scratch)
   if (t0 < t1) { info = a.tinfo[t0]; AHEAD_GRAB(t0, info.x, !NT1) }
+  int pf_i = -1;                          // f += (this pass's force): read issued when an atom is through, completed one tile later
+  double pf_x = 0, pf_y = 0, pf_z = 0, pf_ox = 0, pf_oy = 0, pf_oz = 0;
+  auto f_finish = [&]() {
+    if (pf_i >= 0) { a.f[pf_i] = pf_ox + pf_x; a.f[a.cap + pf_i] = pf_oy + pf_y; a.f[2 * (size_t) a.cap + pf_i] = pf_oz + pf_z; pf_i = -1; }
+  };
   for (T.tile = t0; T.tile < t1; T.tile++) {
     TILE_PROLOGUE_A(true, !NT1, sw, ts, wscale, , , , (T.tile + 1 < t1 ? T.tile + 1 : -1))
+    f_finish();                          // the previous tile's atom (see k_pass3_tile_coef)
     const int nt = a.ntypes, inc = NT1 ? 1 : nt * nt;
     const TabK cr = {a.rho.begin[0], a.rho.end[0], a.rho.invstep[0], 2 * a.rho.invstep[0]};
     for (int o = threadIdx.x; o < T.nown; o += blockDim.x) {
@@ -1696,6 +1702,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) P3_ATTR void k_pass3_tile(TileArgs
       OWN_PROLOGUE
       double xi, yi, zi, wi;
       LPOS_RDW(sp, sw, SLOTCAP(a), slot, xi, yi, zi, wi)
+      f_finish();
       const int it = NT1 ? 0 : ts[slot];
       double fx = 0, fy = 0, fz = 0, vir = 0;
       int sgn = 0;
@@ -1764,11 +1771,12 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) P3_ATTR void k_pass3_tile(TileArgs
         HALF_END
       LIST_WORDS_END(RING)
       if (NT1) { is_short |= sgn < 0 ? 1 : 0; vir *= -0.5; }
-      a.f[i] += fx; a.f[a.cap + i] += fy; a.f[2 * (size_t) a.cap + i] += fz;
+      pf_ox = a.f[i]; pf_oy = a.f[a.cap + i]; pf_oz = a.f[2 * (size_t) a.cap + i]; pf_x = fx; pf_y = fy; pf_z = fz; pf_i = i;
       sums[0] += vir;
     }
     TILE_EPILOGUE_A(!NT1)
   }
+  f_finish();
   block_sum<1>(sums, scratch);
   if (threadIdx.x == 0) a.partials[(size_t) blockIdx.x * IMDGPU_NPART + 3] = sums[0];
   if (is_short) a.counters[CNT_IS_SHORT] = 1;
