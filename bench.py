@@ -49,6 +49,13 @@ def parse():
     ap.add_argument("--dl-tables", action="store_true",
                     help="with --laser fdtd: the cells' Drude-Lorentz parameters from fitDL's tricubic tables in every FILLMESH\n"
                          "(imd_ttm_3D.c:600,2919-2968; synthetic tables, DL1..5.txt are not part of the reference tree) instead of constants")
+    ap.add_argument("--tables", choices=["shared", "distinct"], default="shared",
+                    help="one atom type: `shared` = phi and rho tabulated on ONE r^2 grid (default; files written by one tool);\n"
+                         "`distinct` = phi, rho and F on three different grids (begin, end, step, rows: potential.EAM_GRIDS) -- the\n"
+                         "general pot_table_t of the reference (types.h:537-549), pass 1 in its distinct-grids form")
+    ap.add_argument("--types", type=int, choices=[1, 2], default=1,
+                    help="2 = two atom types on the Cu3Au (L1_2) decoration of the FCC lattice: 4-column pair / density tables of\n"
+                         "3000-4000 rows with per-column begin / end / step (potential.write_synthetic_eam_files_2types), 2-column F")
     ap.add_argument("--slab", action="store_true",
                     help="config 4's geometry: open x with 12 MD cells of vacuum in front of and behind the atoms (pbc 0 1 1)")
     ap.add_argument("--cpu-box", type=int, default=48, help="unit cells per direction of the CPU sample")
@@ -89,7 +96,15 @@ def build_system(args, rank, world, device, decomposed=False):
     from imd_amd import lattice, potential
     from imd_amd.system import GpuSystem, global_cell_dim
     a = 4.05
-    pair, rho, emb, r2cut = potential.synthetic_eam_tables()
+    if args.types == 2:
+        with tempfile.TemporaryDirectory() as d:
+            potential.write_synthetic_eam_files_2types(d)
+            pair, c1 = potential.read_pot_table(os.path.join(d, "phi.pt"), 4, True)
+            rho, c2 = potential.read_pot_table(os.path.join(d, "rho.pt"), 4, True)
+            emb, _ = potential.read_pot_table(os.path.join(d, "F.pt"), 2, False)
+        r2cut = max(c1, c2)
+    else:
+        pair, rho, emb, r2cut = potential.synthetic_eam_tables(grids=args.tables)
     nbl_margin = 0.5
     cellsz = (np.sqrt(r2cut) + nbl_margin) ** 2
     ttm = not args.no_ttm
@@ -127,7 +142,7 @@ def build_system(args, rank, world, device, decomposed=False):
         else:
             gdim = global_cell_dim(box, cellsz, cd)
     cell_dim = tuple(gdim[d] // cpu_dim[d] + 2 for d in range(3))
-    sysm = GpuSystem(box, pbc, cell_dim, 1, cellsz, nbl_margin, 0.1, device=device, global_cell_dim=gdim,
+    sysm = GpuSystem(box, pbc, cell_dim, args.types, cellsz, nbl_margin, 0.1, device=device, global_cell_dim=gdim,
                      cpu_dim=cpu_dim, my_coord=coord, count_ttm_neighbours=ttm,
                      external_halo=args.force_distributed,
                      ttm_decomposed=ttm and (world > 1 or args.force_distributed) and decomposed)
@@ -152,9 +167,18 @@ def build_system(args, rank, world, device, decomposed=False):
             sysm.set_laser(direction=(1, 0, 0), offset=0.0, mu=mu, p_peak=mu * sig_e / sig_t / np.sqrt(2 * np.pi),
                            t_0=15.0, sigma_t_squared=sig_t * sig_t)
     pos = lattice.fcc_positions(args.box, a) + np.array([coord[d] * args.box[d] * a for d in range(3)]) + np.array([shift_x, 0.0, 0.0])
-    mom = lattice.maxwell_momenta(len(pos), 26.9815, args.temp, seed=12345 + rank)
     ident = np.arange(len(pos), dtype=np.int64) + rank * len(pos)
-    sysm.upload_atoms(pos, mom, 26.9815, None, (ident % (2 ** 31 - 1)).astype(np.int32))
+    if args.types == 2:
+        # L1_2: the cube corners of every FCC unit cell are type 1 (a quarter of the atoms), the face centres type 0
+        half = np.rint((pos - np.array([shift_x, 0.0, 0.0])) / (a / 2.0) - 0.5).astype(np.int64)
+        sorte = np.all(half % 2 == 0, axis=1).astype(np.int32)
+        masse = np.where(sorte == 1, 63.546, 26.9815)
+        mom = lattice.maxwell_momenta(len(pos), 1.0, args.temp, seed=12345 + rank) * np.sqrt(masse)[:, None]
+        mom -= mom.mean(axis=0, keepdims=True)
+        sysm.upload_atoms(pos, mom, masse, sorte, (ident % (2 ** 31 - 1)).astype(np.int32))
+    else:
+        mom = lattice.maxwell_momenta(len(pos), 26.9815, args.temp, seed=12345 + rank)
+        sysm.upload_atoms(pos, mom, 26.9815, None, (ident % (2 ** 31 - 1)).astype(np.int32))
     md = None
     if world > 1 or args.force_distributed:
         from imd_amd.parallel import Decomposition, DistributedMD, GpuOps
@@ -233,7 +257,7 @@ def cpu_baseline_mpi_ttm(args, nranks_want, per_rank_cells, steps, timeout):
     from imd_amd import potential, ttm as ttm_mod
     exe = os.path.join(ROOT, "oracle", "_ref", "imd_mpi_eam_ttm3d_nbl")
     mpiexec = _find_mpiexec()
-    if args.no_ttm or not os.path.exists(exe) or mpiexec is None:
+    if args.no_ttm or not os.path.exists(exe) or mpiexec is None or args.types != 1:
         return None
     cpu_dim = _rank_grid(nranks_want)
     nranks = cpu_dim[0] * cpu_dim[1] * cpu_dim[2]
@@ -241,7 +265,7 @@ def cpu_baseline_mpi_ttm(args, nranks_want, per_rank_cells, steps, timeout):
     natoms = 4 * nb[0] * nb[1] * nb[2]
     adv = adv_on(args) and cpu_dim[0] >= 2
     with tempfile.TemporaryDirectory() as d:
-        potential.write_synthetic_eam_files(d)
+        potential.write_synthetic_eam_files(d, grids=args.tables)
         cve, ee = ttm_mod.synthetic_eos()
         ttm_mod.write_eos_table(os.path.join(d, "EOS_cve_from_r_te.txt"), cve)
         ttm_mod.write_eos_table(os.path.join(d, "EOS_ee_from_r_tesqrt.txt"), ee)
@@ -326,7 +350,7 @@ def cpu_baseline_serial(args):
     natoms = 4 * nb ** 3
     if os.path.exists(exe):
         with tempfile.TemporaryDirectory() as d:
-            potential.write_synthetic_eam_files(d)
+            potential.write_synthetic_eam_files(d, grids=args.tables)
             open(os.path.join(d, "b.param"), "w").write(
                 "coordname _fcc\noutfiles out\nensemble nve\nmaxsteps %d\ntimestep 0.1\nntypes 1\ntotal_types 1\n"
                 "masses 26.9815\ntypes 0\nbox_param %d %d %d\nbox_unit 4.05\npbc_dirs 1 1 1\nstarttemp %g\nseed 12345\n"
@@ -352,7 +376,7 @@ def cpu_baseline_serial(args):
     from imd_amd import lattice
     pos = lattice.fcc_positions((nb, nb, nb))
     box = lattice.fcc_box((nb, nb, nb))
-    pair, rho, emb, r2cut = potential.synthetic_eam_tables()
+    pair, rho, emb, r2cut = potential.synthetic_eam_tables(grids=args.tables)
     cellsz = (np.sqrt(r2cut) + 0.5) ** 2
     gd = po.global_cell_dim(box, cellsz)
     s = po.OracleSystem([g + 2 for g in gd], 48, 1, box, (1, 1, 1), cellsz, 0.5, 0.1)
@@ -540,15 +564,24 @@ def main():
         tiles = sysm.get_info("list_mode") == 1
         krev = sysm.get_info("kernel_rev")
         fcap = sysm.get_info("fast_cap")          # plane stride the neighbour loops are compiled for (template argument; 0: run time)
+        p1form = sysm.get_info("pass1_form")      # 2: one type, shared grid (interleaved table); 1: one type, distinct grids; 0: general kernels
+        nt1 = "true" if args.types == 1 else "false"
 
         def price(which):
             n, ms = prof[which]
             if which == "pass1":
                 byts = natoms * (72.0 + 4.0 * M + (32.0 if fused else 0.0))
-                kn = ("k_pass1_tile_merged<%s, %s, %d, false>" % (ttmn, "true" if fused else "false", fcap)) if tiles else "k_pass1"
+                if tiles and p1form:
+                    kn = "k_pass1_tile_merged<%s, %s, %d, false, %s>" % (ttmn, "true" if fused else "false", fcap, "true" if p1form == 1 else "false")
+                elif tiles:
+                    kn = "k_pass1_tile<true, true, %s, %s>" % (ttmn, nt1)
+                else:
+                    kn = ("k_pass1_gt<true, true, %s>" % ttmn) if sysm.get_info("global_tables_in_place") else ("k_pass1<true, true, %s, %s>" % (ttmn, nt1))
                 label = kn + (" (pass 1: pair + rho, embedding pass folded in)" if fused else " (pass 1: pair + rho)")
+                if p1form == 1:
+                    label += " [phi and rho on different grids]"
                 if prof["pass1b"][0]:
-                    kn = kn.replace(", false>", ", true>")
+                    kn = kn.replace(", false, false>", ", true, false>")
                     label = kn + " (pass 1 from a tile queue under the position halo, two launches per pass: pair + rho, embedding pass folded in)"
             else:
                 byts = natoms * (84.0 + 4.0 * M)
@@ -557,7 +590,7 @@ def main():
                 # in the timed region, else the stand-in, and say how often
                 standin = sysm.get_info("p3_standin_passes") - standin0
                 coef = tiles and sysm.get_info("p3_coef_rows") > 0 and standin == 0          # one atom type here
-                kn = ("k_pass3_tile_coef<4, %d>" % fcap) if coef else (("k_pass3_tile<true, %d, %d>" % (sysm.get_info("pass3_ring"), fcap)) if tiles else "k_pass3")
+                kn = ("k_pass3_tile_coef<4, %d>" % fcap) if coef else (("k_pass3_tile<%s, %d, %d>" % (nt1, sysm.get_info("pass3_ring"), fcap)) if tiles else ("k_pass3_gt" if sysm.get_info("global_tables_in_place") else "k_pass3<%s>" % nt1))
                 label = kn + (" (pass 3: EAM force pass, gradient-coefficient table)" if coef else " (pass 3: EAM force pass)")
                 if standin > 0:
                     label += " [stood in for the coefficient form in %d of %d passes]" % (standin, n)
@@ -585,8 +618,10 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "atom_steps_per_s": natoms * world * args.steps / dt, "atoms_total": natoms * world,
             "config": {"workload": "FCC Al %dx%dx%d unit cells per GPU (%d atoms/GPU), synthetic tabulated EAM "
-                                   "(r_c 6.5 A), nbl_margin 0.5, dt 0.1, T0 %.4f eV, %s" %
-                                   (args.box[0], args.box[1], args.box[2], natoms, args.temp,
+                                   "(r_c 6.5 A%s), nbl_margin 0.5, dt 0.1, T0 %.4f eV, %s" %
+                                   (args.box[0], args.box[1], args.box[2], natoms,
+                                    "; TWO atom types on the L1_2 decoration, 4-column tables with per-column grids" if args.types == 2 else
+                                    ("; phi, rho, F on three different grids" if args.tables == "distinct" else ""), args.temp,
                                     "NVE, no TTM" if args.no_ttm else ("3D TTM fd_ext %s, diff_substeps 100, calc_ttm = update_fd, do_ADV %s, activation, FILLMESH, "
                                                                        "100 x (do_DIFF, FILLMESH, ghosts)" % (" ".join(str(v) for v in sysm.fd_ext), "on" if adv_on(args) else "off")) +
                                     (", slab: open x with vacuum on both sides" if args.slab else "") +

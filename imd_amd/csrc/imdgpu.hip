@@ -1453,22 +1453,26 @@ __device__ unsigned long long g_phase[8];
 #define PH_END
 #endif
 #define DYN_CHUNK 8
-// P1_GROWS_PAT = decimal digits d0 d1 d2 d3: of the four neighbours of a list word from ring register s, d_s take their table rows
-// from global memory instead of the LDS (see the neighbour loop of k_pass1_tile_merged)
-#ifndef P1_GROWS_PAT
-#define P1_GROWS_PAT 0
-#endif
-#define P1_GROWS {(P1_GROWS_PAT) / 1000 % 10, (P1_GROWS_PAT) / 100 % 10, (P1_GROWS_PAT) / 10 % 10, (P1_GROWS_PAT) % 10}
 __device__ __forceinline__ int dyn_next_tile(const int *tile_map, int pos) { return pos >= 0 ? __builtin_amdgcn_readfirstlane(tile_map[pos]) : -1; }
-template <bool TTMN, bool FEMB, int CAP, bool DYN = false>
+// DG ("distinct grids"): pair_pot and rho_h_tab each on its OWN r^2 grid (begin, end, step and row count per table,
+// types.h:537-549; three files with three headers, read_pot_table2, imd_potential.c:394-466).  The two tables then sit one behind the
+// other in the LDS, each followed by its three zero rows; a neighbour costs two index computations and six 8-byte row reads instead
+// of one and three 16-byte ones, everything else -- staging ahead, the folded embedding pass, the row report for the EAM force
+// pass (in rows of rho_h_tab, the table that pass reads) -- is shared.  Cut-offs as the reference has them: pair r2 <= end
+// (imd_forces_nbl.c:489), density r2 < end (:550), neighbour count r2 <= pair_pot.end[0] (:473).
+template <bool TTMN, bool FEMB, int CAP, bool DYN = false, bool DG = false>
 __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs a)
 {
   extern __shared__ double lds[];
   if (a.guard && *a.guard) return;
+  static_assert(!(DG && DYN), "the tile queue exists for the shared-grid form only");
   const int nrows = a.pair.nrows, kz = nrows;
+  const int nrows_r = a.rho.nrows, kzr = nrows_r;
   double *sp = lds;                                             // the planes first: a list entry is the address of its x read (NBR_SCALE)
   double *scratch = sp + 3 * (size_t) SLOTCAP(a);
   double2 *tm = (double2 *) (scratch + 64);                     // (nrows + 3) rows; slot_cap is a multiple of 64: 16-byte aligned
+  double *tp = (double *) tm, *tr = tp + nrows + 3;             // DG: pair_pot's rows + 3 zero rows, then rho_h_tab's + 3
+  (void) tp; (void) tr; (void) kzr;
   TileCtx T;
   int t0 = 0, t1 = 0;
   // ---- DYN: the queue ------------------------------------------------------------------------------------------------
@@ -1508,6 +1512,10 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
   int is_short = 0;
   int kmn = 0x7fffffff;                    // lowest table row of any pair: tells the EAM force pass which rows it needs
   if (t0 < t1) {
+    if constexpr (DG) {
+      for (int k = threadIdx.x; k < nrows + 3; k += blockDim.x) tp[k] = k < nrows ? a.pair.tab[k] : 0.0;
+      for (int k = threadIdx.x; k < nrows_r + 3; k += blockDim.x) tr[k] = k < nrows_r ? a.rho.tab[k] : 0.0;
+    } else {
     const double2 *src = (const double2 *) a.merged;
     for (int k = threadIdx.x; k < nrows + 3; k += 4 * blockDim.x) {
       double2 v[4];
@@ -1516,8 +1524,11 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
 #pragma unroll
       for (int u = 0; u < 4; u++) { int q = k + u * blockDim.x; if (q < nrows + 3) tm[q] = v[u]; }
     }
+    }
   }
   const TabK c = {a.pair.begin[0], a.pair.end[0], a.pair.invstep[0], 2 * a.pair.invstep[0]};
+  const TabK cr = {a.rho.begin[0], a.rho.end[0], a.rho.invstep[0], 2 * a.rho.invstep[0]};
+  (void) cr;
   // embedding energy and its derivative of the atom just finished (FEMB), completed one tile later: see the end of the atom loop
   const double emb_begin = FEMB ? a.emb.begin[0] : 0, emb_end = FEMB ? a.emb.end[0] : 0, emb_istep = FEMB ? a.emb.invstep[0] : 0;
   int pend_i = -1;
@@ -1563,12 +1574,58 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
       LIST_WORDS_BEGIN
         double dx[UNR], dy[UNR], dz[UNR], r2[UNR], chi[UNR];
         int k[UNR];
-        double2 A[UNR], B[UNR], C[UNR];
         PRIO_HI;
 #pragma unroll
         for (int e = 0; e < UNR; e++) nbr_rd<CAP>(sp, SLOTCAP(a), j[e], dx[e], dy[e], dz[e]);
         PRIO_LO;
         SCHED_BARRIER;
+        if constexpr (DG) {
+          int kr[UNR];
+          double chr[UNR], P0[UNR], P1[UNR], P2[UNR], R0[UNR], R1[UNR], R2[UNR];
+#pragma unroll
+          for (int e = 0; e < UNR; e++) {
+            dx[e] -= xi; dy[e] -= yi; dz[e] -= zi;
+            r2[e] = dx[e] * dx[e] + dy[e] * dy[e] + dz[e] * dz[e];          // unfused: the reference's r2
+            tab_index_open(c, r2[e], k[e], chi[e], sgn);
+            tab_index_open(cr, r2[e], kr[e], chr[e], sgn);
+          }
+#if UNR == 4
+          kmn = min(min(kmn, kr[0]), kr[1]); kmn = min(min(kmn, kr[2]), kr[3]);   // in rows of rho_h_tab: the EAM force pass's table
+#else
+          kmn = min(min(kmn, kr[0]), kr[1]);
+#endif
+#pragma unroll
+          for (int e = 0; e < UNR; e++) {
+            const bool in = r2[e] <= c.end;                                 // pair: <= end (imd_forces_nbl.c:489)
+            if (TTMN) nb += in ? 1 : 0;
+            k[e] = in ? k[e] : kz;
+            kr[e] = r2[e] < cr.end ? kr[e] : kzr;                           // density: < end (:550)
+          }
+          SCHED_BARRIER;
+          PRIO_HI;
+#pragma unroll
+          for (int e = 0; e < UNR; e++) {                                   // volatile: six ds_read_b64, not three ds_read2_b64 (FAST_CAP's note)
+            lds_cvdouble *qp = (lds_cvdouble *) (tp + k[e]), *qr = (lds_cvdouble *) (tr + kr[e]);
+            P0[e] = qp[0]; P1[e] = qp[1]; P2[e] = qp[2];
+            R0[e] = qr[0]; R1[e] = qr[1]; R2[e] = qr[2];
+          }
+          PRIO_LO;
+          SCHED_BARRIER;
+#pragma unroll
+          for (int e = 0; e < UNR; e++) {
+#pragma clang fp contract(fast)
+            const double g = chi[e] - 0.5, h = fma(0.5 * g, g, -0.125);      // h = chi (chi - 1) / 2
+            const double gq = chr[e] - 0.5, hq = fma(0.5 * gq, gq, -0.125);
+            const double dvp = P1[e] - P0[e], d2p = (P2[e] - 2 * P1[e]) + P0[e];
+            const double dvr = R1[e] - R0[e], d2r = (R2[e] - 2 * R1[e]) + R0[e];
+            const double gr = dvp + g * d2p;                                  // grad / (2 invstep): scaled once per atom
+            rr += R0[e] + chr[e] * dvr + hq * d2r;
+            fx += dx[e] * gr; fy += dy[e] * gr; fz += dz[e] * gr;
+            ee += P0[e] + chi[e] * dvp + h * d2p;                             // halved once per atom
+            vir += r2[e] * gr;
+          }
+        } else {
+        double2 A[UNR], B[UNR], C[UNR];
 #pragma unroll
         for (int e = 0; e < UNR; e++) {
           dx[e] -= xi; dy[e] -= yi; dz[e] -= zi;
@@ -1589,13 +1646,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
         SCHED_BARRIER;
         PRIO_HI;
 #pragma unroll
-        for (int e = 0; e < UNR; e++) {
-          // the three rows of a neighbour: from the table in the LDS, or -- for P1_GROWS[ring slot] of the word's four neighbours --
-          // from its copy in global memory through the vector L1 / L2: the LDS pipe is what this pass waits for, the texture path idles
-          constexpr int growsN[4] = P1_GROWS;
-          if (e < growsN[RSLOT]) { const double2 *g = (const double2 *) a.merged + k[e]; A[e] = g[0]; B[e] = g[1]; C[e] = g[2]; }
-          else { A[e] = tm[k[e]]; B[e] = tm[k[e] + 1]; C[e] = tm[k[e] + 2]; }
-        }
+        for (int e = 0; e < UNR; e++) { A[e] = tm[k[e]]; B[e] = tm[k[e] + 1]; C[e] = tm[k[e] + 2]; }
         PRIO_LO;
         SCHED_BARRIER;
 #pragma unroll
@@ -1609,6 +1660,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
           fx += dx[e] * gr; fy += dy[e] * gr; fz += dz[e] * gr;
           ee += A[e].x + chi[e] * dvp + h * d2p;                            // halved once per atom
           vir += r2[e] * gr;
+        }
         }
         HALF_END
       LIST_WORDS_END(4)
@@ -2091,6 +2143,8 @@ extern "C" int imdgpu_set_option(imdgpu_ctx *ctx, const char *name, int value)
   if (!strcmp(name, "ttm_flux")) { ctx->ttm_flux = value ? 1 : 0; if (!value) ctx->ttm_adv = 0; ctx->cells_epoch++; return 0; }
   if (!strcmp(name, "ttm_adv")) { ctx->ttm_adv = value ? 1 : 0; if (value) ctx->ttm_flux = 1; ctx->cells_epoch++; return 0; }
   if (!strcmp(name, "p3_coef")) { ctx->p3_coef = value ? 1 : 0; return 0; }
+  // tests, before upload_tables: pair_pot and rho_h_tab are kept apart even on a shared grid (the distinct-grids form of pass 1)
+  if (!strcmp(name, "no_merge")) { ctx->no_merge = value ? 1 : 0; return 0; }
   if (!strcmp(name, "p3_klo")) { ctx->p3_klo = value > 0 ? value : 0; return 0; }           // tests: which rows k_pass3_tile_coef holds
   if (!strcmp(name, "eos_bilinear")) { ctx->eos_bilinear = value ? 1 : 0; return 0; }    // before ttm_init / ttm1d_init
   if (!strcmp(name, "ttm_persist")) { imdgpu_ttm_set_persist(ctx, value < 0 ? -1 : (value ? 1 : 0)); return 0; }
@@ -2112,6 +2166,7 @@ extern "C" int imdgpu_set_option(imdgpu_ctx *ctx, const char *name, int value)
 }
 
 static bool fuse_emb(const imdgpu_ctx *ctx);
+static bool p1_onetype(const imdgpu_ctx *ctx);
 static size_t p3_coef_lds(const imdgpu_ctx *ctx, int &klo);
 extern "C" int imdgpu_get_info(imdgpu_ctx *ctx, const char *name, long long *value)
 {
@@ -2126,7 +2181,13 @@ extern "C" int imdgpu_get_info(imdgpu_ctx *ctx, const char *name, long long *val
     {"max_halo", ctx->max_halo}, {"W", ctx->W}, {"tile_x", ctx->tile[0]}, {"tile_y", ctx->tile[1]}, {"tile_z", ctx->tile[2]},
     {"ntiles", ctx->ntiles}, {"tile_threads", ctx->tile_threads}, {"nlocal", ctx->nlocal}, {"nghost", ctx->nghost},
     {"lds_pass1", (long long) ctx->lds_need[1]}, {"lds_pass3", (long long) ctx->lds_need[3]}, {"nbl_count", ctx->nbl_count},
-    {"fused_embedding", fuse_emb(ctx) ? 1 : 0}, {"ttm_flux", ctx->ttm_flux}, {"ttm_adv", ctx->ttm_adv}, {"ttm_block_width", ctx->ttm_flux ? 10 : 6},
+    {"fused_embedding", fuse_emb(ctx) ? 1 : 0},
+    // which pass 1 runs: 2 = one type, pair_pot and rho_h_tab interleaved on their shared grid; 1 = one type, each table on its own grid;
+    // 0 = the general kernels (several types, pair only, ...)
+    {"pass1_form", p1_onetype(ctx) ? (ctx->d_merged ? 2 : 1) : 0},
+    // global-gather family: the tables are too large for the LDS and are read in place through L2 (k_pass1_gt / k_pass3_gt)
+    {"global_tables_in_place", ctx->list_mode == 0 && ((size_t) (ctx->pair.present ? ctx->pair.par.nrows * ctx->pair.par.ncols : 0) +
+                                                       (ctx->rho.present ? ctx->rho.par.nrows * ctx->rho.par.ncols : 0) + 64) * sizeof(double) > TABLE_LDS_LIMIT}, {"ttm_flux", ctx->ttm_flux}, {"ttm_adv", ctx->ttm_adv}, {"ttm_block_width", ctx->ttm_flux ? 10 : 6},
     // bumped whenever a force / list kernel or its data layout changes: committed PMC traffic figures carry the revision
     // they were measured on (profiles/*hbm_traffic*.json "_kernel_rev"), bench.py refuses figures of another revision
     {"kernel_rev", IMDGPU_KERNEL_REV}, {"pass3_ring", ctx->ttm ? 0 : 4}, {"have_valid_nbl", ctx->have_valid_nbl},
@@ -2417,13 +2478,15 @@ extern "C" int imdgpu_upload_tables(imdgpu_ctx *ctx, const imdgpu_pot_table *pai
   if (emb && emb->ncols != ctx->ntypes) return imdgpu_fail(ctx, "embed_pot has %d columns, expected %d", emb->ncols, ctx->ntypes);
   if (ctx->d_merged) { (void) hipFree(ctx->d_merged); ctx->d_merged = nullptr; }
   if (ctx->d_coef3) { (void) hipFree(ctx->d_coef3); ctx->d_coef3 = nullptr; ctx->ncoef = 0; }
-  if (pair && rho && ctx->ntypes == 1 && pair->maxsteps == rho->maxsteps && pair->begin[0] == rho->begin[0] &&
+  if (pair && rho && ctx->ntypes == 1 && !ctx->no_merge && pair->maxsteps == rho->maxsteps && pair->begin[0] == rho->begin[0] &&
       pair->end[0] == rho->end[0] && pair->invstep[0] == rho->invstep[0]) {
     const int R = pair->maxsteps + 2;
     std::vector<double> m(2 * (size_t) (R + 3), 0.0);
     for (int k = 0; k < R; k++) { m[2 * k] = pair->table[k]; m[2 * k + 1] = rho->table[k]; }
     HIPCHK(hipMalloc((void **) &ctx->d_merged, m.size() * sizeof(double)));
     HIPCHK(hipMemcpy(ctx->d_merged, m.data(), m.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
+  if (pair && rho && ctx->ntypes == 1) {
     // gradient coefficients of rho_h_tab for k_pass3_tile_coef: rows 0 .. maxsteps-1 (row k needs table rows k .. k+2), then a zero row
     const int NC = rho->maxsteps + 1;
     std::vector<double> cf(2 * (size_t) NC, 0.0);
@@ -2987,11 +3050,16 @@ extern "C" int imdgpu_check_nblist(imdgpu_ctx *ctx, int *valid)
 static bool fuse_emb(const imdgpu_ctx *ctx);
 // LDS bytes of k_pass3_tile_coef and the first coefficient row it holds; 0 = not applicable (several types, tables on
 // different grids, the option off, or more than a quarter of the rows would have to stay out)
+// pass 1 is k_pass1_tile_merged: one atom type, pair_pot and rho_h_tab both present, tile kernels -- on a shared grid (d_merged) or
+// each table on its own (the DG form).  That kernel folds the embedding pass in and reports the lowest row of rho_h_tab a pair fell into
+static bool p1_onetype(const imdgpu_ctx *ctx)
+{
+  return ctx->list_mode == 1 && ctx->ntypes == 1 && ctx->pair.present && ctx->rho.present;
+}
 static size_t p3_coef_lds(const imdgpu_ctx *ctx, int &klo)
 {
   static const int env = getenv("IMDGPU_P3_COEF") ? atoi(getenv("IMDGPU_P3_COEF")) : 1;
-  if (!env || !ctx->p3_coef || ctx->list_mode != 1 || ctx->ntypes != 1 || !ctx->pair.present || !ctx->rho.present ||
-      !ctx->d_merged || !ctx->d_coef3) return 0;
+  if (!env || !ctx->p3_coef || !p1_onetype(ctx) || !ctx->d_coef3) return 0;
   if (imdgpu_ttm_chain_needs_lds(ctx)) return 0;      // this kernel leaves no LDS to anything beside it
   const size_t fixed = align8((4 * (size_t) ctx->slot_cap + 64 + 2) * 8);
   if (fixed + 64 * 16 > LDS_LIMIT) return 0;
@@ -3007,7 +3075,7 @@ int imdgpu_p3_coef_active(const imdgpu_ctx *ctx) { int klo; return p3_coef_lds(c
 static bool fuse_emb(const imdgpu_ctx *ctx)
 {
   static const int on = getenv("IMDGPU_FUSE_EMB") ? atoi(getenv("IMDGPU_FUSE_EMB")) : 1;
-  return on && ctx->list_mode == 1 && ctx->pair.present && ctx->rho.present && ctx->ntypes == 1 && ctx->d_merged != nullptr;
+  return on && p1_onetype(ctx);
 }
 
 static int launch_forces(imdgpu_ctx *ctx, int phase = 0)
@@ -3045,18 +3113,21 @@ static int launch_forces(imdgpu_ctx *ctx, int phase = 0)
   } while (0)
 #define L1T(P, E, T) do { if (NT1) L1(P, E, T, true); else L1(P, E, T, false); } while (0)
 #define L1E(P, E) do { if (TT) L1T(P, E, true); else L1T(P, E, false); } while (0)
-    if (TILE && PAIR && EAM && NT1 && ctx->d_merged) {
+    if (p1_onetype(ctx)) {
       size_t l = tile_lds_bytes(ctx, 1);
-#define LMC(T, F, C)                                                                                                 \
+      const bool dg = ctx->d_merged == nullptr;         // each table on its own grid
+#define LMCD(T, F, C, D)                                                                                             \
   do {                                                                                                               \
-    HIPCHK(hipFuncSetAttribute((const void *) k_pass1_tile_merged<T, F, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) l)); \
-    hipLaunchKernelGGL((k_pass1_tile_merged<T, F, C>), dim3(nb), dim3(B), l, ctx->stream, ta);                       \
+    HIPCHK(hipFuncSetAttribute((const void *) k_pass1_tile_merged<T, F, C, false, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) l)); \
+    hipLaunchKernelGGL((k_pass1_tile_merged<T, F, C, false, D>), dim3(nb), dim3(B), l, ctx->stream, ta);             \
   } while (0)
+#define LMC(T, F, C) do { if (dg) LMCD(T, F, C, true); else LMCD(T, F, C, false); } while (0)
 #define LM(T, F) do { if (fastcap) LMC(T, F, FAST_CAP); else LMC(T, F, 0); } while (0)
       if (TT) { if (fuse_emb(ctx)) LM(true, true); else LM(true, false); }
       else { if (fuse_emb(ctx)) LM(false, true); else LM(false, false); }
 #undef LM
 #undef LMC
+#undef LMCD
     } else if (PAIR && EAM) L1E(true, true); else if (PAIR) L1E(true, false); else L1E(false, true);
 #undef L1E
 #undef L1T

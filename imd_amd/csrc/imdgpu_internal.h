@@ -58,6 +58,7 @@ struct imdgpu_ctx {
   // one atom type, merged tables: the gradient of rho_h_tab as two coefficients per row, (dv - d2v/2, d2v), + one zero row:
   // what the EAM force pass reads instead of three table rows (k_pass3_tile_coef)
   double *d_coef3 = nullptr; int ncoef = 0;
+  int no_merge = 0;               // option "no_merge" (tests, before upload_tables): keep the tables apart even on a shared grid
   int p3_coef = 1;                // option "p3_coef": 0 keeps k_pass3_tile for every step
   int p3_klo = 0;                 // option "p3_klo" (tests): keep at least this many of the lowest rows out of the LDS
   double *d_restr = nullptr;      // ntypes*3

@@ -205,42 +205,68 @@ def synthetic_eam_functions():
     return phi, rho, emb
 
 
-def synthetic_eam_tables(n=4000, r_begin=1.5, r_cut=6.5, rho_max=40.0):
+# grids of the one-type synthetic EAM: (r_begin, r_cut, rows) of phi and of rho, (rho_max, rows) of F.
+# "shared": phi and rho on ONE r**2 grid (files written by one tool); "distinct": three files with three headers --
+# different begin, end, step and row count each (hand-made EAM files; the manual's phi/rho/f.zhakov.pt are three files)
+EAM_GRIDS = {
+    "shared": dict(phi=(1.5, 6.5, 4000), rho=(1.5, 6.5, 4000), emb=(40.0, 4000)),
+    "distinct": dict(phi=(1.5, 6.5, 4000), rho=(1.7, 6.3, 3500), emb=(45.0, 3000)),
+}
+
+
+def _eam_columns(grids):
+    """analytic functions sampled on the grids of EAM_GRIDS[grids]: [(begin, end, step, values)] for phi, rho, F"""
+    phi, rho, emb = synthetic_eam_functions()
+    g = EAM_GRIDS[grids]
+    out = []
+    for fn, (rb, rc, n) in ((phi, g["phi"]), (rho, g["rho"])):
+        b2, e2 = rb ** 2, rc ** 2
+        step = (e2 - b2) / (n - 1)
+        r = np.sqrt(b2 + step * np.arange(n))
+        out.append((b2, e2, step, fn(r if rc == 6.5 else r * 6.5 / rc)))     # the analytic cut-off sits at 6.5: squeezed to rc
+    rho_max, n = g["emb"]
+    ps = rho_max / (n - 1)
+    out.append((0.0, rho_max, ps, emb(ps * np.arange(n))))
+    return out
+
+
+def synthetic_eam_tables(n=4000, r_begin=1.5, r_cut=6.5, rho_max=40.0, grids="shared"):
     """(pair_pot, rho_h_tab, embed_pot, cellsz) tabulated like the reference would
     hold them after read_pot_table (shifted to zero at r_cut, 2 pad rows)."""
-    phi, rho, emb = synthetic_eam_functions()
-    b2, e2 = r_begin ** 2, r_cut ** 2
-    step = (e2 - b2) / (n - 1)
-    r = np.sqrt(b2 + step * np.arange(n))
+    if grids == "shared" and (n, r_begin, r_cut, rho_max) != (4000, 1.5, 6.5, 40.0):
+        cols = _eam_columns_custom(n, r_begin, r_cut, rho_max)
+    else:
+        cols = _eam_columns(grids)
     out = []
-    for fn in (phi, rho):
-        t = np.zeros((n + 2, 1))
-        v = fn(r)
-        t[:n, 0] = v - v[-1] if v[-1] != 0.0 else v
-        pt = PotTable(np.array([b2]), np.array([e2]), np.array([step]), np.array([1.0 / step]),
-                      np.array([n], np.int32), 1, n, t.reshape(-1).copy())
+    for which, (b, e, step, v) in enumerate(cols):
+        m = len(v)
+        t = np.zeros((m + 2, 1))
+        t[:m, 0] = v - v[-1] if (which < 2 and v[-1] != 0.0) else v
+        pt = PotTable(np.array([b]), np.array([e]), np.array([step]), np.array([1.0 / step]),
+                      np.array([m], np.int32), 1, m, t.reshape(-1).copy())
         init_threepoint(pt.table, 1, pt.len)
         out.append(pt)
-    ps = rho_max / (n - 1)
-    t = np.zeros((n + 2, 1))
-    t[:n, 0] = emb(ps * np.arange(n))
-    pe = PotTable(np.array([0.0]), np.array([rho_max]), np.array([ps]), np.array([1.0 / ps]),
-                  np.array([n], np.int32), 1, n, t.reshape(-1).copy())
-    init_threepoint(pe.table, 1, pe.len)
-    return out[0], out[1], pe, e2
+    return out[0], out[1], out[2], max(cols[0][1], cols[1][1])
 
 
-def write_synthetic_eam_files(dirname, n=4000, r_begin=1.5, r_cut=6.5, rho_max=40.0):
-    """phi.pt / rho.pt / F.pt in IMD format 2 for the reference binary."""
-    import os
+def _eam_columns_custom(n, r_begin, r_cut, rho_max):
     phi, rho, emb = synthetic_eam_functions()
     b2, e2 = r_begin ** 2, r_cut ** 2
     step = (e2 - b2) / (n - 1)
     r = np.sqrt(b2 + step * np.arange(n))
-    write_pot_table2(os.path.join(dirname, "phi.pt"), [b2], [e2], [step], [phi(r)])
-    write_pot_table2(os.path.join(dirname, "rho.pt"), [b2], [e2], [step], [rho(r)])
     ps = rho_max / (n - 1)
-    write_pot_table2(os.path.join(dirname, "F.pt"), [0.0], [rho_max], [ps], [emb(ps * np.arange(n))])
+    return [(b2, e2, step, phi(r)), (b2, e2, step, rho(r)), (0.0, rho_max, ps, emb(ps * np.arange(n)))]
+
+
+def write_synthetic_eam_files(dirname, n=4000, r_begin=1.5, r_cut=6.5, rho_max=40.0, grids="shared"):
+    """phi.pt / rho.pt / F.pt in IMD format 2 for the reference binary."""
+    import os
+    if grids == "shared" and (n, r_begin, r_cut, rho_max) != (4000, 1.5, 6.5, 40.0):
+        cols = _eam_columns_custom(n, r_begin, r_cut, rho_max)
+    else:
+        cols = _eam_columns(grids)
+    for fn, (b, e, step, v) in zip(("phi.pt", "rho.pt", "F.pt"), cols):
+        write_pot_table2(os.path.join(dirname, fn), [b], [e], [step], [v])
 
 
 def write_synthetic_eam_files_2types(dirname, rows=1.0):

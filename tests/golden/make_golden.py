@@ -49,6 +49,13 @@ CASES = {
     # EAM, Verlet list, serial: config-2 physics at fixture size
     "eam_nbl_2048": dict(binary="imd_eam_nve_nbl", box="8 8 8", temp=0.06, steps=40, dump=[0, 1, 2, 20, 40],
                          full=[0, 40], pot="eam", nbl=True),
+    # one atom type with phi, rho and F on THREE DIFFERENT grids (begin, end, step, row count; potential.EAM_GRIDS["distinct"]):
+    # separate files with separate headers, the normal state of hand-made EAM tables (read_pot_table2, imd_potential.c:394-466)
+    "eam_nbl_2048_dg": dict(binary="imd_eam_nve_nbl", box="8 8 8", temp=0.06, steps=40, dump=[0, 1, 2, 20, 40],
+                            full=[0, 40], pot="eam_dg", nbl=True),
+    # ... and with the 3D TTM (neighbour counts against pair_pot.end, the embedding pass folded into pass 1, both EAM force kernels)
+    "ttm_2048_dg": dict(binary="imd_mpi_eam_ttm3d_nbl", box="8 8 8", temp=0.03, steps=3, dump=[0, 1, 2, 3], full=[],
+                        pot="eam_dg", nbl=True, ttm=dict(fd_ext="1 1 1", n=100, min_atoms=5)),
     # slab: open boundary in x (pbc_dirs 0 1 1) with vacuum on both sides
     "eam_nbl_slab": dict(binary="imd_eam_nve_nbl", box="8 6 6", temp=0.03, steps=10, dump=[0, 10], full=[0],
                          pot="eam", nbl=True, pbc="0 1 1", extra="shiftx_front 6.0\nshiftx_rear 6.0\n"),
@@ -153,8 +160,8 @@ def write_inputs(c, d):
     if c["pot"].startswith("eam2types"):
         potential.write_synthetic_eam_files_2types(d, rows=0.15 if c["pot"].endswith("coarse") else 1.0)
         par += "core_potential_file phi.pt\nembedding_energy_file F.pt\natomic_e-density_file rho.pt\n"
-    elif c["pot"] == "eam":
-        potential.write_synthetic_eam_files(d)
+    elif c["pot"] in ("eam", "eam_dg"):
+        potential.write_synthetic_eam_files(d, grids="distinct" if c["pot"] == "eam_dg" else "shared")
         par += "core_potential_file phi.pt\nembedding_energy_file F.pt\natomic_e-density_file rho.pt\n"
     elif c["pot"] == "pair1":       # the LJ table of config 1, handed over as a format-1 potential file
         pt, _ = potential.create_lj_table(0.392, 2.62, 6.0, 1.5, 731)

@@ -39,6 +39,7 @@ def _relmax(a, b, floor=1e-300):
 
 
 @pytest.mark.parametrize("case,step,eam", [("eam_nbl_2048", 0, True), ("eam_nbl_2048", 40, True),
+                                           ("eam_nbl_2048_dg", 0, True), ("eam_nbl_2048_dg", 40, True),
                                            ("lj_nbl_2048", 20, False), ("eam_nbl_slab", 10, True),
                                            ("eam2_l12_nbl", 0, True), ("eam2_l12_nbl", 20, True),
                                            ("eam2_l12_coarse", 0, True), ("eam2_l12_coarse", 20, True)])
@@ -46,6 +47,11 @@ def test_forces_vs_reference_golden(case, step, eam):
     G = gu.load(case)
     s = _gpu_from_golden(G, step)
     r = s.calc_forces(step)
+    if case.endswith("_dg"):             # one type, phi / rho / F on three different grids: the distinct-grids pass 1 with the embedding
+        assert (s.get_info("pass1_form"), s.get_info("fused_embedding")) == (1, 1)     # pass folded in, the coefficient form of the force pass
+        assert s.get_info("p3_coef_rows") > 0 and s.get_info("p3_standin_passes") == 0
+    elif case.startswith("eam_nbl"):
+        assert s.get_info("pass1_form") == 2
     d = s.download()
     pre = "s%d_" % step
     assert np.array_equal(d["nummer"], G[pre + "nummer"])
@@ -79,7 +85,7 @@ def test_cellpair_entry_vs_reference_golden(step):
     s.close()
 
 
-@pytest.mark.parametrize("case", ["eam_nbl_2048", "lj_nbl_2048", "eam_nbl_slab", "eam2_l12_nbl"])
+@pytest.mark.parametrize("case", ["eam_nbl_2048", "eam_nbl_2048_dg", "lj_nbl_2048", "eam_nbl_slab", "eam2_l12_nbl"])
 def test_neighbour_list_bit_exact(case):
     """make_nblist on the reference's step-0 arrangement, exported in the
     reference's own tl/tb/cl_off format, equals the reference's list exactly."""
@@ -97,8 +103,9 @@ def test_neighbour_list_bit_exact(case):
     s.close()
 
 
-def test_forces_vs_oracle_same_inputs():
-    G = gu.load("eam_nbl_2048")
+@pytest.mark.parametrize("case", ["eam_nbl_2048", "eam_nbl_2048_dg"])
+def test_forces_vs_oracle_same_inputs(case):
+    G = gu.load(case)
     o = gu.oracle_from_golden(G, 20)
     o.s.have_valid_nbl = 0
     o.calc_forces(20)
@@ -135,7 +142,7 @@ def test_rebinning_unsorted_upload_matches_by_id():
     s.close()
 
 
-@pytest.mark.parametrize("case,last", [("eam_nbl_2048", 40), ("eam_nbl_slab", 10), ("eam2_l12_nbl", 20)])
+@pytest.mark.parametrize("case,last", [("eam_nbl_2048", 40), ("eam_nbl_2048_dg", 40), ("eam_nbl_slab", 10), ("eam2_l12_nbl", 20)])
 def test_trajectory_vs_reference(case, last):
     """Device-resident MD loop (forces, leap-frog, list check, re-binning) from
     the reference's step-0 state reproduces the reference's trajectory."""
@@ -155,9 +162,33 @@ def test_trajectory_vs_reference(case, last):
     assert _relmax(d["impuls"][order], G[pre + "impuls"][gorder]) < 1e-9
     assert _relmax(d["kraft"][order], G[pre + "kraft"][gorder]) < 1e-8
     assert abs(r["tot_pot_energy"] - float(G[pre + "tot_pot_energy"])) < 1e-9 * abs(float(G[pre + "tot_pot_energy"]))
-    if case == "eam_nbl_2048":
+    if case.startswith("eam_nbl_2048"):
         assert s.get_sums()["nbl_count"] == int(G[pre + "nbl_count"])
     s.close()
+
+
+def test_shared_grid_tables_through_the_distinct_grids_kernel():
+    """option no_merge: pair_pot and rho_h_tab of the shared-grid fixture kept apart, so the SAME inputs go through the
+    distinct-grids form of pass 1 (two indices, six 8-byte row reads) -- equal to the interleaved form to rounding, and to the golden"""
+    G = gu.load("eam_nbl_2048")
+    out = []
+    for nm in (0, 1):
+        s = GpuSystem(G["box"], G["pbc_dirs"], G["cell_dim"], 1, float(G["cellsz"]), float(G["nbl_margin"]), float(G["timestep"]))
+        s.set_option("no_merge", nm)
+        s.upload_tables(gu.table(G, "pair_pot"), gu.table(G, "rho_h_tab"), gu.table(G, "embed_pot"))
+        cell_n = np.zeros(int(np.prod(G["cell_dim"])), np.int32)
+        cell_n[G["cells"]] = G["s40_cell_n"][G["cells"]]
+        s.upload_cells(cell_n, G["s40_ort"], G["s40_impuls"], G["s40_masse"], G["s40_sorte"].astype(np.int32), G["s40_nummer"])
+        r = s.calc_forces(40)
+        assert s.get_info("pass1_form") == (1 if nm else 2)
+        out.append((s.download(), r))
+        s.close()
+    (d0, r0), (d1, r1) = out
+    assert _relmax(d1["kraft"], G["s40_kraft"]) < FTOL
+    assert _relmax(d1["kraft"], d0["kraft"]) < 1e-12 and _relmax(d1["eam_rho"], d0["eam_rho"]) < 1e-13
+    assert _relmax(d1["pot_eng"], d0["pot_eng"]) < 1e-13 and _relmax(d1["eam_dF"], d0["eam_dF"]) < 1e-12
+    assert abs(r1["tot_pot_energy"] - r0["tot_pot_energy"]) < 1e-12 * abs(r0["tot_pot_energy"])
+    assert abs(r1["virial"] - r0["virial"]) < 1e-11 * abs(r0["virial"])
 
 
 def test_check_nblist_threshold():
@@ -171,7 +202,8 @@ def test_check_nblist_threshold():
     s.close()
 
 
-@pytest.mark.parametrize("mode,case", [(0, "eam_nbl_2048"), (1, "eam_nbl_2048"), (0, "eam2_l12_nbl"), (1, "eam2_l12_nbl"),
+@pytest.mark.parametrize("mode,case", [(0, "eam_nbl_2048"), (1, "eam_nbl_2048"), (0, "eam_nbl_2048_dg"), (1, "eam_nbl_2048_dg"),
+                                       (0, "eam2_l12_nbl"), (1, "eam2_l12_nbl"),
                                        (0, "eam2_l12_coarse"), (1, "eam2_l12_coarse")])
 def test_both_kernel_modes_match_reference(mode, case):
     G = gu.load(case)
@@ -301,7 +333,7 @@ def test_parity_cases_under_other_tile_shapes(tile):
     import sys
     env = dict(os.environ, IMDGPU_TILE=tile)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k",
-                        "forces_vs_reference_golden or neighbour_list_bit_exact or trajectory_vs_reference or forces_vs_oracle"],
+                        "forces_vs_reference_golden or neighbour_list_bit_exact or trajectory_vs_reference or forces_vs_oracle or distinct_grids_kernel"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:]

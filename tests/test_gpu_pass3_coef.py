@@ -1,4 +1,5 @@
-"""EAM force pass in its two forms (one atom type, pair_pot and rho_h_tab on one r^2 grid): k_pass3_tile_coef reads
+"""EAM force pass in its two forms (one atom type; pair_pot and rho_h_tab on one r^2 grid or -- case *_dg -- each on its own: the
+coefficients are rho_h_tab's and the rows pass 1 reports are rows of rho_h_tab): k_pass3_tile_coef reads
 one (A, B) coefficient pair per neighbour from the rows [klo, ncoef) it holds in LDS; k_pass3_tile reads three
 table rows and stands in whenever a pair of the step falls below row klo (pass 1 reports the lowest row).  Both are
 DERIV_FUNC2 (potaccess.h:591-621) and agree to rounding (1e-11 of max|F|); the stand-in IS the three-row kernel, so a step it takes
@@ -11,7 +12,7 @@ from tests.test_gpu_forces import FTOL, _gpu_from_golden, _relmax
 
 pytestmark = pytest.mark.gpu
 
-CASES = [("eam_nbl_2048", 40), ("eam_nbl_slab", 10), ("eam_nbl_2048", 0)]
+CASES = [("eam_nbl_2048", 40), ("eam_nbl_slab", 10), ("eam_nbl_2048", 0), ("eam_nbl_2048_dg", 40)]
 
 
 def _forces(G, step, **opts):
@@ -47,7 +48,7 @@ def test_coefficient_form_against_three_row_form_and_golden(case, step):
     assert rc["is_short"] == ro["is_short"] == 0
 
 
-@pytest.mark.parametrize("case,step", CASES[:2])
+@pytest.mark.parametrize("case,step", CASES[:2] + CASES[3:])
 def test_pairs_below_the_rows_in_lds_fall_back_to_the_three_row_kernel(case, step):
     G = gu.load(case)
     do, ro, _ = _forces(G, step, p3_coef=0)

@@ -21,14 +21,14 @@ def _relmax(a, b):
     return np.abs(a - b).max() / np.abs(b).max()
 
 
-def _setup(nbn, ttmn, seed=3, cd=(1, 1, 1), temp=0.02):
+def _setup(nbn, ttmn, seed=3, cd=(1, 1, 1), temp=0.02, grids="shared"):
     nb = (nbn,) * 3
     box = lattice.fcc_box(nb)
     pos = lattice.fcc_positions(nb)
     rng = np.random.default_rng(seed)
     pos = (pos + rng.normal(scale=0.06, size=pos.shape)) % np.diag(box)
     mom = lattice.maxwell_momenta(len(pos), 26.9815, temp, seed=seed)
-    pair, rho, emb, r2cut = potential.synthetic_eam_tables()
+    pair, rho, emb, r2cut = potential.synthetic_eam_tables(grids=grids)
     cellsz = (np.sqrt(r2cut) + 0.5) ** 2
     dim = [g + 2 for g in global_cell_dim(box, cellsz, cd)]
     o = po.OracleSystem(dim, 64, 1, box, (1, 1, 1), cellsz, 0.5, 0.1)
@@ -64,12 +64,16 @@ def _compare_forces(o, g, ttmn):
     return float(np.abs(d["kraft"] - fo).max() / np.abs(fo).max())
 
 
-@pytest.mark.parametrize("ttmn", [False, True])
-def test_config2_forces_and_list_vs_oracle_1M(ttmn):
-    """64^3 unit cells = 1 048 576 atoms (BASELINE config 2), tile kernels with the embedding pass fused."""
-    o, g, _ = _setup(64, ttmn)
+@pytest.mark.parametrize("ttmn,grids", [(False, "shared"), (True, "shared"), (False, "distinct"), (True, "distinct")])
+def test_config2_forces_and_list_vs_oracle_1M(ttmn, grids):
+    """64^3 unit cells = 1 048 576 atoms (BASELINE config 2), tile kernels with the embedding pass fused; grids = "distinct":
+    phi, rho and F tabulated on three different grids (begin, end, step, rows: potential.EAM_GRIDS), i.e. the distinct-grids
+    form of pass 1 and the coefficient form of the force pass on rho_h_tab's own grid"""
+    o, g, _ = _setup(64, ttmn, grids=grids)
     err = _compare_forces(o, g, ttmn)
-    print("1M atoms, ttm neighbours %s: max force error / max|F| = %.3e" % (ttmn, err))
+    assert g.get_info("pass1_form") == (2 if grids == "shared" else 1)
+    assert g.get_info("p3_coef_rows") > 0 and g.get_info("p3_standin_passes") == 0
+    print("1M atoms, ttm neighbours %s, %s grids: max force error / max|F| = %.3e" % (ttmn, grids, err))
     # the device's symmetric LDS-slot list, exported in the reference's half-list format, is the oracle's list
     tl, tb, cl_off = g.export_nblist()
     assert np.array_equal(cl_off, o.cl_off[:-1])
@@ -128,10 +132,11 @@ def test_config2_calc_ttm_vs_oracle_1M():
     g.close(); ot.close(); o.close()
 
 
-def test_trajectory_vs_oracle_442k():
+@pytest.mark.parametrize("grids", ["shared", "distinct"])
+def test_trajectory_vs_oracle_442k(grids):
     """48^3 unit cells = 442 368 atoms, 25 device-resident NVE steps (forces, leap-frog, list checks, two
     re-binnings + list rebuilds) against the oracle's loop of the same reference functions; compared by atom number."""
-    o, g, _ = _setup(48, False, seed=7, temp=0.08)      # hot enough for list rebuilds at steps 9 and 23
+    o, g, _ = _setup(48, False, seed=7, temp=0.08, grids=grids)      # hot enough for list rebuilds at steps 9 and 23
     nsteps = 25
     for st in range(nsteps):
         # main loop of the reference (imd_main_3d.c): calc_forces [fix_cells + make_nblist when the list is invalid,

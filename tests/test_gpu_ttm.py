@@ -54,7 +54,7 @@ def _cmp(d, st, tag, fields=None):
             assert err < TOL, "%s: %s rel err %.3e" % (tag, f, err)
 
 
-@pytest.mark.parametrize("case", ["ttm_2048", "ttm_6912_ext2", "ttm_slab", "ttm_2types"])
+@pytest.mark.parametrize("case", ["ttm_2048", "ttm_2048_dg", "ttm_6912_ext2", "ttm_slab", "ttm_2types"])
 def test_ttm_stages_vs_reference(case):
     """update_fd / do_FILLMESH / ghosts / do_DIFF / CFL_maxdt one by one at step 0."""
     G = gu.load(case)
@@ -81,7 +81,7 @@ def test_ttm_stages_vs_reference(case):
     s.close()
 
 
-@pytest.mark.parametrize("case", ["ttm_2048", "ttm_slab", "ttm_2types"])
+@pytest.mark.parametrize("case", ["ttm_2048", "ttm_2048_dg", "ttm_slab", "ttm_2types"])
 def test_ttm_md_trajectory_vs_reference(case):
     """Full device-resident loop (forces -> calc_ttm [fused sub-steps, hipGraph] ->
     move_atoms_ttm) against the reference's lattice and atoms at later steps."""

@@ -5,6 +5,7 @@ import os
 import tempfile
 
 import numpy as np
+import pytest
 
 from imd_amd import potential
 from tests import golden_util as gu
@@ -22,12 +23,22 @@ def test_lj_table_creation_bit_exact():
     assert np.array_equal(pt.table, t["table"])
 
 
-def test_eam_files_read_back_like_the_reference():
+@pytest.mark.parametrize("case,grids", [("eam_nbl_2048", "shared"), ("eam_nbl_2048_dg", "distinct")])
+def test_eam_files_read_back_like_the_reference(case, grids):
     """write_synthetic_eam_files -> read_pot_table (format 2, tabulated in r^2 / rho, cut-off shift, two extrapolated
-    rows) gives the tables the reference holds after reading the same files."""
-    G = gu.load("eam_nbl_2048")
+    rows) gives the tables the reference holds after reading the same files -- also when phi, rho and F come with three
+    different headers (begin, end, step, row count), and synthetic_eam_tables (what bench.py and the size tests hand the
+    device) holds the same bits."""
+    G = gu.load(case)
+    direct = potential.synthetic_eam_tables(grids=grids)
+    for pt, key in zip(direct[:3], ("pair_pot", "rho_h_tab", "embed_pot")):
+        t = gu.table(G, key)
+        for f in ("begin", "end", "invstep"):
+            assert np.array_equal(getattr(pt, f), t[f]), (key, f)
+        assert np.array_equal(pt.table, t["table"]), key
+    assert direct[3] == float(max(G["pair_pot_end"][0], G["rho_h_tab_end"][0]))
     with tempfile.TemporaryDirectory() as d:
-        potential.write_synthetic_eam_files(d)
+        potential.write_synthetic_eam_files(d, grids=grids)
         for fn, key, radial in (("phi.pt", "pair_pot", True), ("rho.pt", "rho_h_tab", True), ("F.pt", "embed_pot", False)):
             pt, _ = potential.read_pot_table(os.path.join(d, fn), 1, radial)
             t = gu.table(G, key)

@@ -31,7 +31,7 @@ def _cmp(t, st, tag):
             assert np.abs(a - ref).max() <= 1e-12 * max(np.abs(ref).max(), 1e-300), "%s: %s" % (tag, f)
 
 
-@pytest.mark.parametrize("case", ["ttm_2048", "ttm_6912_ext2", "ttm_slab", "ttm_2types"])
+@pytest.mark.parametrize("case", ["ttm_2048", "ttm_2048_dg", "ttm_6912_ext2", "ttm_slab", "ttm_2types"])
 def test_ttm_trajectory_against_reference(case):
     G = gu.load(case)
     s = gu.oracle_from_golden(G, 0)

@@ -18,7 +18,7 @@ def _check_outputs(s, G, step, eam=True):
     assert s.s.virial == float(G[pre + "virial"])
 
 
-@pytest.mark.parametrize("case,eam", [("eam_nbl_2048", True), ("lj_nbl_2048", False), ("eam_nbl_slab", True),
+@pytest.mark.parametrize("case,eam", [("eam_nbl_2048", True), ("eam_nbl_2048_dg", True), ("lj_nbl_2048", False), ("eam_nbl_slab", True),
                                       ("eam2_l12_nbl", True), ("eam2_l12_coarse", True)])
 def test_list_and_forces_at_step0(case, eam):
     G = gu.load(case)
@@ -39,7 +39,7 @@ def test_cell_stencil_matches_reference():
     assert (G["cnbrs"][:, 1:] < 0).any()
 
 
-@pytest.mark.parametrize("case,eam,last", [("eam_nbl_2048", True, 40), ("lj_nbl_2048", False, 20),
+@pytest.mark.parametrize("case,eam,last", [("eam_nbl_2048", True, 40), ("eam_nbl_2048_dg", True, 40), ("lj_nbl_2048", False, 20),
                                            ("eam_nbl_slab", True, 10), ("eam2_l12_nbl", True, 20)])
 def test_trajectory_bit_exact(case, eam, last):
     """calc_forces -> move_atoms_nve -> check_nblist for `last` steps, incl. list
