@@ -571,7 +571,9 @@ def main():
             n, ms = prof[which]
             if which == "pass1":
                 byts = natoms * (72.0 + 4.0 * M + (32.0 if fused else 0.0))
-                if tiles and p1form:
+                if tiles and p1form == 3:
+                    kn = "k_pass1_tile_rec<%s, %d>" % (ttmn, fcap)
+                elif tiles and p1form:
                     kn = "k_pass1_tile_merged<%s, %s, %d, false, %s>" % (ttmn, "true" if fused else "false", fcap, "true" if p1form == 1 else "false")
                 elif tiles:
                     kn = "k_pass1_tile<true, true, %s, %s>" % (ttmn, nt1)
@@ -580,6 +582,8 @@ def main():
                 label = kn + (" (pass 1: pair + rho, embedding pass folded in)" if fused else " (pass 1: pair + rho)")
                 if p1form == 1:
                     label += " [phi and rho on different grids]"
+                if p1form == 3:
+                    label += " [several atom types, table rows as coefficient records through L2]"
                 if prof["pass1b"][0]:
                     kn = kn.replace(", false, false>", ", true, false>")
                     label = kn + " (pass 1 from a tile queue under the position halo, two launches per pass: pair + rho, embedding pass folded in)"
@@ -590,7 +594,7 @@ def main():
                 # in the timed region, else the stand-in, and say how often
                 standin = sysm.get_info("p3_standin_passes") - standin0
                 coef = tiles and sysm.get_info("p3_coef_rows") > 0 and standin == 0          # one atom type here
-                kn = ("k_pass3_tile_coef<4, %d>" % fcap) if coef else (("k_pass3_tile<%s, %d, %d>" % (nt1, sysm.get_info("pass3_ring"), fcap)) if tiles else ("k_pass3_gt" if sysm.get_info("global_tables_in_place") else "k_pass3<%s>" % nt1))
+                kn = ("k_pass3_tile_rec<%d>" % fcap) if (tiles and p1form == 3) else ("k_pass3_tile_coef<4, %d>" % fcap) if coef else (("k_pass3_tile<%s, %d, %d>" % (nt1, sysm.get_info("pass3_ring"), fcap)) if tiles else ("k_pass3_gt" if sysm.get_info("global_tables_in_place") else "k_pass3<%s>" % nt1))
                 label = kn + (" (pass 3: EAM force pass, gradient-coefficient table)" if coef else " (pass 3: EAM force pass)")
                 if standin > 0:
                     label += " [stood in for the coefficient form in %d of %d passes]" % (standin, n)

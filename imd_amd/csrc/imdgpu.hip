@@ -576,6 +576,10 @@ struct TileArgs {
   const double2 *coef3;           // gradient coefficients of rho_h_tab (ctx->d_coef3): ncoef rows, the last one zero
   int ncoef, klo;                 // k_pass3_tile_coef keeps rows [klo, ncoef) in LDS and steps aside when a pair fell below klo
   int p3_fallback;                // k_pass3_tile: 1 = run only when k_pass3_tile_coef steps aside
+  // several atom types with tables too large for the LDS (k_pass1_tile_rec / k_pass3_tile_rec): per column and row one aligned record
+  // of interpolation coefficients, read in place through L2 -- recP / recR[col * nrec + k] = (p0, dv, d2v, 0) of pair_pot / rho_h_tab,
+  // rec3[col * nrec3 + k] = invstep * (dv - d2v / 2, d2v) of rho_h_tab; the last record of every column is zero
+  const double4 *recP, *recR; const double2 *rec3; int nrecP, nrecR;
   double *f, *epot, *rhoh, *ref;
   int *numneighs;
   double *partials;
@@ -1281,6 +1285,24 @@ __device__ __forceinline__ void tab_index_open(const TabK &c, double arg, int &k
   chi = __builtin_amdgcn_fract(a);
 }
 
+// ... and with (arg - begin) * istep as ONE fused multiply-add, a = arg * istep + c0, c0 = -begin * istep: one instruction less per
+// look-up.  `a` differs from the reference's product by a rounding error; it matters only where a lies within that error of an
+// integer, i.e. of a table node, where the three-point rule is continuous (value) or jumps by a third difference (gradient):
+// ~1e-16 relative, seven orders inside the 1e-9 bar.  sgn collects the sign of a: the is_short flag may differ from the
+// reference's for a pair whose r^2 lies within one rounding error of the table's begin.  (The force passes' neighbour loops are
+// bound by the NUMBER of vector instructions, not by the LDS: the distinct-grids form has 50 % more LDS reads and 29 % more vector
+// instructions than the shared-grid form and takes 31 % longer -- profiles/r05_pass1_forms.json.)
+struct TabF { double c0, istep, end; };
+__device__ __forceinline__ TabF tabf(const TabPar &t, int col) { return {-t.begin[col] * t.invstep[col], t.invstep[col], t.end[col]}; }
+__device__ __forceinline__ void tab_index_fma(const TabF &c, double arg, int &k, double &chi, int &sgn)
+{
+  double a = fma(arg, c.istep, c.c0);
+  sgn |= __double2hiint(a);
+  a = fmax(a, 0.0);
+  k = (int) a;
+  chi = __builtin_amdgcn_fract(a);
+}
+
 template <bool PAIR, bool EAM, bool TTMN, bool NT1>
 __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile(TileArgs a)
 {
@@ -1527,8 +1549,8 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
     }
   }
   const TabK c = {a.pair.begin[0], a.pair.end[0], a.pair.invstep[0], 2 * a.pair.invstep[0]};
-  const TabK cr = {a.rho.begin[0], a.rho.end[0], a.rho.invstep[0], 2 * a.rho.invstep[0]};
-  (void) cr;
+  const TabF cf = tabf(a.pair, 0), crf = tabf(a.rho, 0);
+  (void) crf;
   // embedding energy and its derivative of the atom just finished (FEMB), completed one tile later: see the end of the atom loop
   const double emb_begin = FEMB ? a.emb.begin[0] : 0, emb_end = FEMB ? a.emb.end[0] : 0, emb_istep = FEMB ? a.emb.invstep[0] : 0;
   int pend_i = -1;
@@ -1569,7 +1591,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
       double xi, yi, zi;
       LPOS_RD(sp, sp, SLOTCAP(a), slot, xi, yi, zi)
       emb_finish();                                        // (a second own atom of this thread in one tile: never at autotile's shapes)
-      double fx = 0, fy = 0, fz = 0, ee = 0, rr = 0, vir = 0;
+      double fx = 0, fy = 0, fz = 0, ee = 0, rr = 0, vir = 0, ee0 = 0, rr0 = 0;
       int nb = 0, sgn = 0;
       LIST_WORDS_BEGIN
         double dx[UNR], dy[UNR], dz[UNR], r2[UNR], chi[UNR];
@@ -1586,8 +1608,8 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
           for (int e = 0; e < UNR; e++) {
             dx[e] -= xi; dy[e] -= yi; dz[e] -= zi;
             r2[e] = dx[e] * dx[e] + dy[e] * dy[e] + dz[e] * dz[e];          // unfused: the reference's r2
-            tab_index_open(c, r2[e], k[e], chi[e], sgn);
-            tab_index_open(cr, r2[e], kr[e], chr[e], sgn);
+            tab_index_fma(cf, r2[e], k[e], chi[e], sgn);
+            tab_index_fma(crf, r2[e], kr[e], chr[e], sgn);
           }
 #if UNR == 4
           kmn = min(min(kmn, kr[0]), kr[1]); kmn = min(min(kmn, kr[2]), kr[3]);   // in rows of rho_h_tab: the EAM force pass's table
@@ -1599,7 +1621,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
             const bool in = r2[e] <= c.end;                                 // pair: <= end (imd_forces_nbl.c:489)
             if (TTMN) nb += in ? 1 : 0;
             k[e] = in ? k[e] : kz;
-            kr[e] = r2[e] < cr.end ? kr[e] : kzr;                           // density: < end (:550)
+            kr[e] = r2[e] < crf.end ? kr[e] : kzr;                          // density: < end (:550)
           }
           SCHED_BARRIER;
           PRIO_HI;
@@ -1614,14 +1636,13 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
 #pragma unroll
           for (int e = 0; e < UNR; e++) {
 #pragma clang fp contract(fast)
-            const double g = chi[e] - 0.5, h = fma(0.5 * g, g, -0.125);      // h = chi (chi - 1) / 2
-            const double gq = chr[e] - 0.5, hq = fma(0.5 * gq, gq, -0.125);
+            // value = p0 + chi (dv + (chi - 1) / 2 d2v); gradient / (2 invstep) = dv + (chi - 1/2) d2v = gr; value = p0 + chi (gr - chi d2v / 2)
             const double dvp = P1[e] - P0[e], d2p = (P2[e] - 2 * P1[e]) + P0[e];
             const double dvr = R1[e] - R0[e], d2r = (R2[e] - 2 * R1[e]) + R0[e];
-            const double gr = dvp + g * d2p;                                  // grad / (2 invstep): scaled once per atom
-            rr += R0[e] + chr[e] * dvr + hq * d2r;
+            const double gr = fma(chi[e] - 0.5, d2p, dvp);                    // scaled by 2 invstep once per atom
+            ee = fma(chi[e], fma(-0.5 * chi[e], d2p, gr), ee); ee0 += P0[e];  // halved once per atom
+            rr = fma(chr[e], fma(fma(0.5, chr[e], -0.5), d2r, dvr), rr); rr0 += R0[e];
             fx += dx[e] * gr; fy += dy[e] * gr; fz += dz[e] * gr;
-            ee += P0[e] + chi[e] * dvp + h * d2p;                             // halved once per atom
             vir += r2[e] * gr;
           }
         } else {
@@ -1630,7 +1651,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
         for (int e = 0; e < UNR; e++) {
           dx[e] -= xi; dy[e] -= yi; dz[e] -= zi;
           r2[e] = dx[e] * dx[e] + dy[e] * dy[e] + dz[e] * dz[e];          // unfused: the reference's r2
-          tab_index_open(c, r2[e], k[e], chi[e], sgn);
+          tab_index_fma(cf, r2[e], k[e], chi[e], sgn);
         }
 #if UNR == 4
         kmn = min(min(kmn, k[0]), k[1]); kmn = min(min(kmn, k[2]), k[3]);  // v_min3_i32
@@ -1664,6 +1685,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
         }
         HALF_END
       LIST_WORDS_END(4)
+      if constexpr (DG) { ee += ee0; rr += rr0; }
       fx *= c.istep2; fy *= c.istep2; fz *= c.istep2; ee *= 0.5; vir *= -0.5 * c.istep2;
       is_short |= sgn < 0 ? 1 : 0;
       a.f[i] = fx; a.f[a.cap + i] = fy; a.f[2 * (size_t) a.cap + i] = fz;
@@ -1877,7 +1899,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) __attribute__((amdgpu_waves_per_eu
   }
   const double wscale = a.rho.invstep[0];                // dF staged as dF * invstep: grad = (w_i + w_j) (A + chi B)
   const int kz = a.ncoef - 1;
-  const double begin = a.rho.begin[0], end = a.rho.end[0], istep = a.rho.invstep[0];
+  const double end = a.rho.end[0], istep = a.rho.invstep[0], c0 = -a.rho.begin[0] * a.rho.invstep[0];
   int4 info = make_int4(0, 0, 0, 0);
   AHEAD_DECL(scratch)
   if (t0 < t1) { info = a.tinfo[t0]; AHEAD_GRAB(t0, info.x, false) }
@@ -1918,7 +1940,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) __attribute__((amdgpu_waves_per_eu
           // lands one below pass 1's is covered by the guard's margin of one row
           r2[e] = fma(dz[e], dz[e], fma(dy[e], dy[e], dx[e] * dx[e]));
 #endif
-          const double q = fmax(r2[e] - begin, 0.0) * istep;
+          const double q = fmax(fma(r2[e], istep, c0), 0.0);               // tab_index_fma without the sign (pass 1 reports is_short)
           kr[e] = (int) q;
           ch[e] = __builtin_amdgcn_fract(q);
           kr[e] = (r2[e] < end) ? kr[e] : kz;                              // rho': r2 < end (imd_forces_nbl.c:868)
@@ -1946,6 +1968,226 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) __attribute__((amdgpu_waves_per_eu
   f_finish();
   block_sum<1>(sums, scratch);
   if (threadIdx.x == 0) a.partials[(size_t) blockIdx.x * IMDGPU_NPART + 3] = sums[0];
+}
+
+// ---- several atom types, tables beyond the LDS: positions and types in the LDS, table rows as coefficient records through L2 ----
+// Two atom types at production table sizes (2 tables x 4 columns x 4002 rows = 256 KB) cannot sit beside a tile; the global-gather
+// family then paid nine divergent loads per neighbour (position, type, 2 x 3 table rows).  Here the tile is staged like in every other
+// tile kernel (three LDS reads + the type), the per-column parameters (begin, step, end, record offset: types.h:537-549, one set per
+// column) come from a small LDS array, and a table look-up is ONE aligned 32-byte record (p0, dv, d2v) -- dv = p1 - p0 and
+// d2v = p2 - 2 p1 + p0 formed on the host with the reference's own roundings (potaccess.h:338-344) -- i.e. two loads of one L2 sector
+// instead of three rows 32 bytes apart.  Column as the reference has it: col = it * ntypes + jt for the pair term and for the
+// density atom i receives (imd_forces_nbl.c:457-470,550); cut-offs <= / < per column (:489,:550); the embedding pass of the own atom
+// (:748-783, column = its type) is folded in as in k_pass1_tile_merged.
+struct ColPar { double c0, istep, end; int boff, kz; };     // c0 = -begin * invstep; boff: first record of the column; kz: its zero record
+template <bool TTMN, int CAP>
+__global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_rec(TileArgs a)
+{
+  extern __shared__ double lds[];
+  if (a.guard && *a.guard) return;
+  double *sp = lds;
+  double *scratch = sp + 3 * (size_t) SLOTCAP(a);
+  int *ts = (int *) (scratch + 64);
+  ColPar *parP = (ColPar *) (ts + SLOTCAP(a)), *parR = parP + IMDGPU_MAXCOL;      // slot_cap is a multiple of 64: 16-byte aligned
+  TileCtx T;
+  int t0, t1;
+  block_tile_range(a.ntiles, a.wprefix, a.balance, t0, t1);
+  const int nt = a.ntypes, ncol = nt * nt;
+  if ((int) threadIdx.x < ncol) {
+    const int c = threadIdx.x;
+    parP[c] = {-a.pair.begin[c] * a.pair.invstep[c], a.pair.invstep[c], a.pair.end[c], c * a.nrecP, c * a.nrecP + a.nrecP - 1};
+    parR[c] = {-a.rho.begin[c] * a.rho.invstep[c], a.rho.invstep[c], a.rho.end[c], c * a.nrecR, c * a.nrecR + a.nrecR - 1};
+  }
+  const double pend0 = a.pair.end[0];
+  double sums[3] = {0.0, 0.0, 0.0};        // pair energy, virial, embedding energy
+  int is_short = 0;
+  int pend_i = -1, pend_t = 0;
+  double pend_chi = 0, pend_p0 = 0, pend_p1 = 0, pend_p2 = 0, pend_ee = 0;
+  auto emb_finish = [&]() {
+    if (pend_i >= 0) {
+      Tab3 q;
+      q.p0 = pend_p0; q.dv = pend_p1 - pend_p0; q.d2v = pend_p2 - 2 * pend_p1 + pend_p0; q.chi = pend_chi; q.istep = a.emb.invstep[pend_t];
+      const double pe = tab_val(q);
+      a.posw[pend_i].w = tab_grad(q);
+      a.epot[pend_i] = pend_ee + pe;
+      sums[2] += pe;
+      pend_i = -1;
+    }
+  };
+  int4 info = make_int4(0, 0, 0, 0);
+  AHEAD_DECL(scratch)
+  if (t0 < t1) { info = a.tinfo[t0]; AHEAD_GRAB(t0, info.x, true) }
+  for (T.tile = t0; T.tile < t1; T.tile++) {
+    TILE_PROLOGUE_A(false, true, nullptr, ts, 1.0, , , , (T.tile + 1 < t1 ? T.tile + 1 : -1))
+    emb_finish();
+    for (int o = threadIdx.x; o < T.nown; o += blockDim.x) {
+      const int i = T.own_start + o;
+      OWN_PROLOGUE
+      double xi, yi, zi;
+      LPOS_RD(sp, sp, SLOTCAP(a), slot, xi, yi, zi)
+      emb_finish();
+      const int it = ts[slot], itn = it * nt;
+      double fx = 0, fy = 0, fz = 0, ee = 0, rr = 0, vir = 0, ee0 = 0, rr0 = 0;
+      int nb = 0, sgn = 0;
+      LIST_WORDS_BEGIN
+        double dx[UNR], dy[UNR], dz[UNR], r2[UNR], chp[UNR], chr[UNR], isp[UNR];
+        int col[UNR], kp[UNR], kr[UNR];
+        double4 P[UNR], R[UNR];
+#pragma unroll
+        for (int e = 0; e < UNR; e++) { nbr_rd<CAP>(sp, SLOTCAP(a), j[e], dx[e], dy[e], dz[e]); col[e] = itn + nbr_type(ts, j[e]); }
+        SCHED_BARRIER;
+#pragma unroll
+        for (int e = 0; e < UNR; e++) {
+          dx[e] -= xi; dy[e] -= yi; dz[e] -= zi;
+          r2[e] = dx[e] * dx[e] + dy[e] * dy[e] + dz[e] * dz[e];          // unfused: the reference's r2
+          const ColPar cp = parP[col[e]], cr = parR[col[e]];
+          double ap = fma(r2[e], cp.istep, cp.c0), ar = fma(r2[e], cr.istep, cr.c0);
+          sgn |= __double2hiint(ap) | __double2hiint(ar);                 // r2 below a table's begin (is_short; see tab_index_fma)
+          ap = fmax(ap, 0.0); ar = fmax(ar, 0.0);
+          const bool inp = r2[e] <= cp.end;                               // pair: <= end (imd_forces_nbl.c:489)
+          if (TTMN) nb += (r2[e] <= pend0 && col[e] == 0) ? 1 : 0;        // both of type 0 (:473-476)
+          // a look-up beyond its column's cut-off (list skin, padding: a quarter of the entries) loads nothing: the texture path's cost
+          // goes with the number of lanes that ask
+          kp[e] = inp ? cp.boff + (int) ap : -1; chp[e] = __builtin_amdgcn_fract(ap); isp[e] = cp.istep;
+          kr[e] = r2[e] < cr.end ? cr.boff + (int) ar : -1; chr[e] = __builtin_amdgcn_fract(ar);          // density: < end (:550)
+        }
+        SCHED_BARRIER;
+#pragma unroll
+        for (int e = 0; e < UNR; e++) {
+          P[e] = make_double4(0, 0, 0, 0); R[e] = make_double4(0, 0, 0, 0);
+          if (kp[e] >= 0) { const double2 q = ((const double2 *) a.recP)[2 * (size_t) kp[e]]; P[e].x = q.x; P[e].y = q.y; P[e].z = ((const double *) a.recP)[4 * (size_t) kp[e] + 2]; }
+          if (kr[e] >= 0) { const double2 q = ((const double2 *) a.recR)[2 * (size_t) kr[e]]; R[e].x = q.x; R[e].y = q.y; R[e].z = ((const double *) a.recR)[4 * (size_t) kr[e] + 2]; }
+        }
+        SCHED_BARRIER;
+#pragma unroll
+        for (int e = 0; e < UNR; e++) {
+#pragma clang fp contract(fast)
+          const double gr = fma(chp[e] - 0.5, P[e].z, P[e].y) * isp[e];     // grad / 2: doubled once per atom
+          ee = fma(chp[e], fma(chp[e] - 1.0, 0.5 * P[e].z, P[e].y), ee); ee0 += P[e].x;      // halved once per atom
+          rr = fma(chr[e], fma(chr[e] - 1.0, 0.5 * R[e].z, R[e].y), rr); rr0 += R[e].x;
+          fx += dx[e] * gr; fy += dy[e] * gr; fz += dz[e] * gr;
+          vir += r2[e] * gr;
+        }
+        HALF_END
+      LIST_WORDS_END(4)
+      ee = 0.5 * (ee + ee0); rr += rr0;
+      fx *= 2.0; fy *= 2.0; fz *= 2.0; vir = -vir;                        // vir -= r2 grad / 2, grad = 2 gr
+      is_short |= sgn < 0 ? 1 : 0;
+      a.f[i] = fx; a.f[a.cap + i] = fy; a.f[2 * (size_t) a.cap + i] = fz;
+      a.rhoh[i] = rr;
+      {                                                     // PAIR_INT on embed_pot, column = the atom's type (:757-760); EAM_DF into pos.w
+        double ea = (rr < a.emb.end[it] ? rr : a.emb.end[it]) - a.emb.begin[it];
+        ea = (ea < 0 ? 0 : ea) * a.emb.invstep[it];
+        const int ek = (int) ea;
+        const double *ep = a.emb.tab + (size_t) ek * nt + it;
+        pend_chi = ea - ek; pend_p0 = ep[0]; pend_p1 = ep[nt]; pend_p2 = ep[2 * nt]; pend_ee = ee; pend_i = i; pend_t = it;
+      }
+      if (TTMN) a.numneighs[i] = nb;
+      sums[0] += ee; sums[1] += vir;
+    }
+    TILE_EPILOGUE_A(true)
+  }
+  emb_finish();
+  block_sum<3>(sums, scratch);
+  if (threadIdx.x == 0) {
+    a.partials[(size_t) blockIdx.x * IMDGPU_NPART + 0] = sums[0];
+    a.partials[(size_t) blockIdx.x * IMDGPU_NPART + 1] = sums[1];
+    a.partials[(size_t) blockIdx.x * IMDGPU_NPART + 2] = sums[2];
+  }
+  if (is_short) a.counters[CNT_IS_SHORT] = 1;
+}
+
+// The EAM force pass of the same family: grad = (dF_i rho'_j + dF_j rho'_i) / 2 with rho'_i from column jt * ntypes + it and rho'_j
+// from column it * ntypes + jt, both evaluated -- at min(r2, end) like DERIV_FUNC2 does (potaccess.h:601) -- whenever r2 lies inside
+// EITHER column's range (imd_forces_nbl.c:843-877).  A look-up is one 16-byte record invstep * (dv - d2v / 2, d2v).
+template <int CAP>
+__global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass3_tile_rec(TileArgs a)
+{
+  extern __shared__ double lds[];
+  double *sp = lds;
+  double *sw = sp + 3 * (size_t) SLOTCAP(a);
+  double *scratch = sw + SLOTCAP(a);
+  int *ts = (int *) (scratch + 64);
+  ColPar *par = (ColPar *) (ts + SLOTCAP(a));
+  TileCtx T;
+  int t0, t1;
+  block_tile_range(a.ntiles, a.wprefix, a.balance, t0, t1);
+  const int nt = a.ntypes, ncol = nt * nt;
+  if ((int) threadIdx.x < ncol) {
+    const int c = threadIdx.x;
+    par[c] = {-a.rho.begin[c] * a.rho.invstep[c], a.rho.invstep[c], a.rho.end[c], c * a.nrecR, c * a.nrecR + a.nrecR - 1};
+  }
+  double sums[1] = {0.0};
+  int is_short = 0;
+  int4 info = make_int4(0, 0, 0, 0);
+  AHEAD_DECL(scratch)
+  if (t0 < t1) { info = a.tinfo[t0]; AHEAD_GRAB(t0, info.x, true) }
+  int pf_i = -1;
+  double pf_x = 0, pf_y = 0, pf_z = 0, pf_ox = 0, pf_oy = 0, pf_oz = 0;
+  auto f_finish = [&]() {
+    if (pf_i >= 0) { a.f[pf_i] = pf_ox + pf_x; a.f[a.cap + pf_i] = pf_oy + pf_y; a.f[2 * (size_t) a.cap + pf_i] = pf_oz + pf_z; pf_i = -1; }
+  };
+  for (T.tile = t0; T.tile < t1; T.tile++) {
+    TILE_PROLOGUE_A(true, true, sw, ts, 1.0, , , , (T.tile + 1 < t1 ? T.tile + 1 : -1))
+    f_finish();
+    for (int o = threadIdx.x; o < T.nown; o += blockDim.x) {
+      const int i = T.own_start + o;
+      OWN_PROLOGUE
+      double xi, yi, zi, wi;
+      LPOS_RDW(sp, sw, SLOTCAP(a), slot, xi, yi, zi, wi)
+      f_finish();
+      const int it = ts[slot], itn = it * nt;
+      double fx = 0, fy = 0, fz = 0, vir = 0;
+      int sgn = 0;
+      LIST_WORDS_BEGIN
+        double dx[UNR], dy[UNR], dz[UNR], wj[UNR], r2[UNR], c1[UNR], c2[UNR];
+        int jt[UNR], k1[UNR], k2[UNR];
+        double2 A1[UNR], A2[UNR];
+#pragma unroll
+        for (int e = 0; e < UNR; e++) { nbr_rdw<CAP>(sp, sw, SLOTCAP(a), j[e], dx[e], dy[e], dz[e], wj[e]); jt[e] = nbr_type(ts, j[e]); }
+        SCHED_BARRIER;
+#pragma unroll
+        for (int e = 0; e < UNR; e++) {
+          dx[e] -= xi; dy[e] -= yi; dz[e] -= zi;
+          r2[e] = dx[e] * dx[e] + dy[e] * dy[e] + dz[e] * dz[e];
+          const ColPar p1 = par[jt[e] * nt + it], p2 = par[itn + jt[e]];
+          const bool in = (r2[e] < p1.end) || (r2[e] < p2.end);
+          double a1 = fma(fmin(r2[e], p1.end), p1.istep, p1.c0), a2 = fma(fmin(r2[e], p2.end), p2.istep, p2.c0);
+          sgn |= in ? (__double2hiint(a1) | __double2hiint(a2)) : 0;
+          a1 = fmax(a1, 0.0); a2 = fmax(a2, 0.0);
+          // beyond both cut-offs: nothing is loaded; atoms of one type: one look-up serves both terms (col1 == col2, :858-860)
+          k1[e] = in ? p1.boff + (int) a1 : -1; c1[e] = __builtin_amdgcn_fract(a1);
+          k2[e] = (in && jt[e] != it) ? p2.boff + (int) a2 : -1; c2[e] = __builtin_amdgcn_fract(a2);
+        }
+        SCHED_BARRIER;
+#pragma unroll
+        for (int e = 0; e < UNR; e++) {
+          A1[e] = make_double2(0, 0);
+          if (k1[e] >= 0) A1[e] = a.rec3[k1[e]];
+          A2[e] = A1[e];
+          if (k2[e] >= 0) A2[e] = a.rec3[k2[e]];
+        }
+        SCHED_BARRIER;
+#pragma unroll
+        for (int e = 0; e < UNR; e++) {
+#pragma clang fp contract(fast)
+          // rho' = 2 invstep (dv + (chi - 1/2) d2v): the records carry invstep (A + chi B), the 2 cancels the 1/2 of the force term
+          const double grad = wi * fma(c2[e], A2[e].y, A2[e].x) + wj[e] * fma(c1[e], A1[e].y, A1[e].x);
+          fx += dx[e] * grad; fy += dy[e] * grad; fz += dz[e] * grad;
+          vir += r2[e] * grad;                                              // d . f = grad r2
+        }
+        HALF_END
+      LIST_WORDS_END(4)
+      is_short |= sgn < 0 ? 1 : 0;
+      pf_ox = a.f[i]; pf_oy = a.f[a.cap + i]; pf_oz = a.f[2 * (size_t) a.cap + i]; pf_x = fx; pf_y = fy; pf_z = fz; pf_i = i;
+      sums[0] += -0.5 * vir;
+    }
+    TILE_EPILOGUE_A(true)
+  }
+  f_finish();
+  block_sum<1>(sums, scratch);
+  if (threadIdx.x == 0) a.partials[(size_t) blockIdx.x * IMDGPU_NPART + 3] = sums[0];
+  if (is_short) a.counters[CNT_IS_SHORT] = 1;
 }
 
 // Deterministic final reduction of the per-block partial sums
@@ -2112,7 +2354,7 @@ extern "C" void imdgpu_destroy(imdgpu_ctx *c)
                   c->pos2, c->type2, c->id2, c->p2, c->mass2, c->nn2, c->fdc, c->fdc2, c->keys, c->keys2, c->perm, c->perm2,
                   c->cub_tmp, c->cell_start, c->cell_cnt, c->icnt, c->istart, c->gcell_lin, c->gcell_src,
                   c->gcell_shift, c->gcnt, c->gstart, c->ghost_src, c->ghost_code, c->d_counters, c->nbr,
-                  c->nbr_cnt, c->nbr16, c->tsrc, c->ownw, c->tinfo, c->d_merged, c->partials, c->d_sums, c->pair.d_tab, c->rho.d_tab, c->emb.d_tab, c->d_restr};
+                  c->nbr_cnt, c->nbr16, c->tsrc, c->ownw, c->tinfo, c->d_merged, c->d_coef3, c->d_recP, c->d_recR, c->d_rec3, c->partials, c->d_sums, c->pair.d_tab, c->rho.d_tab, c->emb.d_tab, c->d_restr};
   for (void *p : ptrs) if (p) (void) hipFree(p);
   if (c->h_counters) (void) hipHostFree(c->h_counters);
   if (c->h_sums) (void) hipHostFree(c->h_sums);
@@ -2145,6 +2387,9 @@ extern "C" int imdgpu_set_option(imdgpu_ctx *ctx, const char *name, int value)
   if (!strcmp(name, "p3_coef")) { ctx->p3_coef = value ? 1 : 0; return 0; }
   // tests, before upload_tables: pair_pot and rho_h_tab are kept apart even on a shared grid (the distinct-grids form of pass 1)
   if (!strcmp(name, "no_merge")) { ctx->no_merge = value ? 1 : 0; return 0; }
+  // several atom types: 0 = never the record kernels (tables beyond the LDS then select the global-gather family), 1 = when the tables
+  // do not fit the LDS beside a tile (default), 2 = whenever there are several types
+  if (!strcmp(name, "tile_rec")) { ctx->tile_rec_opt = value < 0 ? 0 : (value > 2 ? 2 : value); ctx->have_valid_nbl = 0; return 0; }
   if (!strcmp(name, "p3_klo")) { ctx->p3_klo = value > 0 ? value : 0; return 0; }           // tests: which rows k_pass3_tile_coef holds
   if (!strcmp(name, "eos_bilinear")) { ctx->eos_bilinear = value ? 1 : 0; return 0; }    // before ttm_init / ttm1d_init
   if (!strcmp(name, "ttm_persist")) { imdgpu_ttm_set_persist(ctx, value < 0 ? -1 : (value ? 1 : 0)); return 0; }
@@ -2184,7 +2429,7 @@ extern "C" int imdgpu_get_info(imdgpu_ctx *ctx, const char *name, long long *val
     {"fused_embedding", fuse_emb(ctx) ? 1 : 0},
     // which pass 1 runs: 2 = one type, pair_pot and rho_h_tab interleaved on their shared grid; 1 = one type, each table on its own grid;
     // 0 = the general kernels (several types, pair only, ...)
-    {"pass1_form", p1_onetype(ctx) ? (ctx->d_merged ? 2 : 1) : 0},
+    {"pass1_form", p1_onetype(ctx) ? (ctx->d_merged ? 2 : 1) : (ctx->list_mode == 1 && ctx->tile_rec ? 3 : 0)},
     // global-gather family: the tables are too large for the LDS and are read in place through L2 (k_pass1_gt / k_pass3_gt)
     {"global_tables_in_place", ctx->list_mode == 0 && ((size_t) (ctx->pair.present ? ctx->pair.par.nrows * ctx->pair.par.ncols : 0) +
                                                        (ctx->rho.present ? ctx->rho.par.nrows * ctx->rho.par.ncols : 0) + 64) * sizeof(double) > TABLE_LDS_LIMIT}, {"ttm_flux", ctx->ttm_flux}, {"ttm_adv", ctx->ttm_adv}, {"ttm_block_width", ctx->ttm_flux ? 10 : 6},
@@ -2499,8 +2744,35 @@ extern "C" int imdgpu_upload_tables(imdgpu_ctx *ctx, const imdgpu_pot_table *pai
     HIPCHK(hipMemcpy(ctx->d_coef3, cf.data(), cf.size() * sizeof(double), hipMemcpyHostToDevice));
     ctx->ncoef = NC;
   }
-  // tables larger than the LDS (several atom types: ntypes^2 columns) are read in place by the global-gather
-  // kernels (k_pass1_gt / k_pass3_gt); the tile kernels need them in LDS, make_nblist then picks list_mode 0
+  // several atom types: coefficient records per column and row for the tile kernels that read the tables through L2
+  // (k_pass1_tile_rec / k_pass3_tile_rec; make_nblist picks them when the tables do not fit the LDS beside a tile)
+  for (void **q : {(void **) &ctx->d_recP, (void **) &ctx->d_recR, (void **) &ctx->d_rec3}) if (*q) { (void) hipFree(*q); *q = nullptr; }
+  ctx->nrecP = ctx->nrecR = 0;
+  if (pair && rho && ctx->ntypes > 1) {
+    auto records = [&](const imdgpu_pot_table *t, std::vector<double> &rec, std::vector<double> *rec3, int &nrec) {
+      const int nc = t->ncols, R = t->maxsteps + 2;
+      nrec = R - 1;                                   // rows 0 .. R-3 (row k needs table rows k .. k+2) + one zero record
+      rec.assign((size_t) nc * nrec * 4, 0.0);
+      if (rec3) rec3->assign((size_t) nc * nrec * 2, 0.0);
+      for (int c = 0; c < nc; c++)
+        for (int k = 0; k + 2 < R; k++) {
+          const double p0 = t->table[(size_t) k * nc + c], p1 = t->table[(size_t) (k + 1) * nc + c], p2 = t->table[(size_t) (k + 2) * nc + c];
+          const double dv = p1 - p0, d2v = (p2 - 2 * p1) + p0;            // potaccess.h:338-344
+          double *r = &rec[((size_t) c * nrec + k) * 4];
+          r[0] = p0; r[1] = dv; r[2] = d2v;
+          if (rec3) { double *q = &(*rec3)[((size_t) c * nrec + k) * 2]; q[0] = t->invstep[c] * (dv - 0.5 * d2v); q[1] = t->invstep[c] * d2v; }
+        }
+    };
+    std::vector<double> rp, rr, r3;
+    records(pair, rp, nullptr, ctx->nrecP);
+    records(rho, rr, &r3, ctx->nrecR);
+    HIPCHK(hipMalloc((void **) &ctx->d_recP, rp.size() * sizeof(double)));
+    HIPCHK(hipMemcpy(ctx->d_recP, rp.data(), rp.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void **) &ctx->d_recR, rr.size() * sizeof(double)));
+    HIPCHK(hipMemcpy(ctx->d_recR, rr.data(), rr.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void **) &ctx->d_rec3, r3.size() * sizeof(double)));
+    HIPCHK(hipMemcpy(ctx->d_rec3, r3.data(), r3.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
   return 0;
 }
 
@@ -2847,6 +3119,8 @@ static TileArgs make_tile_args(imdgpu_ctx *ctx)
   { static const int dbg = getenv("IMDGPU_DBG") ? atoi(getenv("IMDGPU_DBG")) : 0; a.dbg = dbg; }
   a.pair = ctx->pair.par; a.rho = ctx->rho.par; a.emb = ctx->emb.par; a.posw = ctx->pos; a.merged = ctx->d_merged;
   a.coef3 = (const double2 *) ctx->d_coef3; a.ncoef = ctx->ncoef; a.klo = 0; a.p3_fallback = 0;
+  a.recP = (const double4 *) ctx->d_recP; a.recR = (const double4 *) ctx->d_recR; a.rec3 = (const double2 *) ctx->d_rec3;
+  a.nrecP = ctx->nrecP; a.nrecR = ctx->nrecR;
   a.f = ctx->f; a.epot = ctx->epot; a.rhoh = ctx->rhoh; a.ref = ctx->ref; a.numneighs = ctx->numneighs;
   a.partials = ctx->partials; a.counters = ctx->d_counters; a.cellsz = ctx->cellsz; a.guard = nullptr;
   a.balance = ctx->tile_balance; a.wprefix = ctx->d_wprefix;
@@ -2871,7 +3145,7 @@ static size_t tile_lds_bytes(const imdgpu_ctx *ctx, int which /*0 build, 1 pass1
 static size_t tile_lds_bytes_for(const imdgpu_ctx *ctx, int slot_cap, int which)
 {
   imdgpu_ctx tmp;                       // only the sizing fields are read
-  tmp.ntypes = ctx->ntypes; tmp.slot_cap = slot_cap;
+  tmp.ntypes = ctx->ntypes; tmp.slot_cap = slot_cap; tmp.tile_rec = ctx->tile_rec;
   tmp.pair.present = ctx->pair.present; tmp.pair.par = ctx->pair.par;
   tmp.rho.present = ctx->rho.present; tmp.rho.par = ctx->rho.par;
   return tile_lds_bytes(&tmp, which);
@@ -2882,6 +3156,8 @@ static size_t tile_lds_bytes(const imdgpu_ctx *ctx, int which /*0 build, 1 pass1
   size_t tp = ctx->pair.present ? (size_t) ctx->pair.par.nrows * ctx->pair.par.ncols : 0;
   size_t tr = ctx->rho.present ? (size_t) ctx->rho.par.nrows * ctx->rho.par.ncols : 0;
   if (which == 0) return align8((size_t) 3 * ctx->slot_cap * 8 + (size_t) (2 * NH_MAX + 1) * sizeof(int));
+  if (ctx->tile_rec)                    // tables through L2: planes, scratch, types, per-column parameters
+    return align8(((which == 1 ? 3 : 4) * (size_t) ctx->slot_cap + 64) * 8 + ints + (which == 1 ? 2 : 1) * IMDGPU_MAXCOL * sizeof(ColPar));
   if (which == 1) return align8((tp + tr + 6 + 2 + 3 * (size_t) ctx->slot_cap + 64) * 8 + ints);
   return align8((tr + 4 + 2 + 4 * (size_t) ctx->slot_cap + 64) * 8 + ints);
 }
@@ -2911,8 +3187,13 @@ extern "C" int imdgpu_make_nblist(imdgpu_ctx *ctx)
   ctx->list_mode = ctx->mode;
   // the tile kernels keep the potential tables in LDS next to the staged positions: tables that leave no room for
   // even a one-cell tile (several atom types) select the global-gather kernels (reported by get_info("list_mode"))
-  if (ctx->list_mode == 1 && std::max(tile_lds_bytes_for(ctx, 1024, 1), tile_lds_bytes_for(ctx, 1024, 3)) > LDS_LIMIT)
-    ctx->list_mode = 0;
+  ctx->tile_rec = 0;
+  if (ctx->list_mode == 1 && std::max(tile_lds_bytes_for(ctx, 1024, 1), tile_lds_bytes_for(ctx, 1024, 3)) > LDS_LIMIT) {
+    // several atom types with pair_pot and rho_h_tab: the tile kernels that read coefficient records through L2; else global gather
+    if (ctx->d_recP && ctx->d_recR && ctx->d_rec3 && ctx->tile_rec_opt) ctx->tile_rec = 1;
+    else ctx->list_mode = 0;
+  }
+  if (ctx->list_mode == 1 && ctx->tile_rec_opt == 2 && ctx->d_recP && ctx->d_recR && ctx->d_rec3) ctx->tile_rec = 1;   // option: also when the tables would fit
   if (ctx->list_mode == 1 && !ctx->autotiled && !getenv("IMDGPU_TILE") && !ctx->external_halo) {
     if (autotile(ctx)) return 1;
     g = make_geo(ctx);
@@ -3075,7 +3356,7 @@ int imdgpu_p3_coef_active(const imdgpu_ctx *ctx) { int klo; return p3_coef_lds(c
 static bool fuse_emb(const imdgpu_ctx *ctx)
 {
   static const int on = getenv("IMDGPU_FUSE_EMB") ? atoi(getenv("IMDGPU_FUSE_EMB")) : 1;
-  return on && p1_onetype(ctx);
+  return on && (p1_onetype(ctx) || (ctx->list_mode == 1 && ctx->tile_rec));
 }
 
 static int launch_forces(imdgpu_ctx *ctx, int phase = 0)
@@ -3113,7 +3394,17 @@ static int launch_forces(imdgpu_ctx *ctx, int phase = 0)
   } while (0)
 #define L1T(P, E, T) do { if (NT1) L1(P, E, T, true); else L1(P, E, T, false); } while (0)
 #define L1E(P, E) do { if (TT) L1T(P, E, true); else L1T(P, E, false); } while (0)
-    if (p1_onetype(ctx)) {
+    if (TILE && ctx->tile_rec) {
+      size_t l = tile_lds_bytes(ctx, 1);
+#define LR(T, C)                                                                                                     \
+  do {                                                                                                               \
+    HIPCHK(hipFuncSetAttribute((const void *) k_pass1_tile_rec<T, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) l)); \
+    hipLaunchKernelGGL((k_pass1_tile_rec<T, C>), dim3(nb), dim3(B), l, ctx->stream, ta);                             \
+  } while (0)
+      if (TT) { if (fastcap) LR(true, FAST_CAP); else LR(true, 0); }
+      else { if (fastcap) LR(false, FAST_CAP); else LR(false, 0); }
+#undef LR
+    } else if (p1_onetype(ctx)) {
       size_t l = tile_lds_bytes(ctx, 1);
       const bool dg = ctx->d_merged == nullptr;         // each table on its own grid
 #define LMCD(T, F, C, D)                                                                                             \
@@ -3155,7 +3446,16 @@ static int launch_forces(imdgpu_ctx *ctx, int phase = 0)
     if (ctx->ufd_pending) { HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_ufd, 0)); ctx->ufd_pending = 0; }
     size_t lds3 = ((size_t) a.rho.nrows * a.rho.ncols + 64) * sizeof(double);
     ProfScope ps(ctx, PROF_PASS3);
-    if (TILE) {
+    if (TILE && ctx->tile_rec) {
+      size_t l = tile_lds_bytes(ctx, 3);
+      if (fastcap) {
+        HIPCHK(hipFuncSetAttribute((const void *) k_pass3_tile_rec<FAST_CAP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) l));
+        hipLaunchKernelGGL((k_pass3_tile_rec<FAST_CAP>), dim3(nb), dim3(B), l, ctx->stream, ta);
+      } else {
+        HIPCHK(hipFuncSetAttribute((const void *) k_pass3_tile_rec<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) l));
+        hipLaunchKernelGGL((k_pass3_tile_rec<0>), dim3(nb), dim3(B), l, ctx->stream, ta);
+      }
+    } else if (TILE) {
       size_t l = tile_lds_bytes(ctx, 3);
       // with a lattice attached its sub-step chain runs beside this pass and needs 80 registers on every SIMD: the
       // leaner list walk (142 VGPRs) then; the register ring (148) otherwise

@@ -58,6 +58,10 @@ struct imdgpu_ctx {
   // one atom type, merged tables: the gradient of rho_h_tab as two coefficients per row, (dv - d2v/2, d2v), + one zero row:
   // what the EAM force pass reads instead of three table rows (k_pass3_tile_coef)
   double *d_coef3 = nullptr; int ncoef = 0;
+  // several atom types: coefficient records of pair_pot / rho_h_tab per column and row (k_pass1_tile_rec / k_pass3_tile_rec)
+  double *d_recP = nullptr, *d_recR = nullptr, *d_rec3 = nullptr; int nrecP = 0, nrecR = 0;
+  int tile_rec = 0;               // this list's force kernels are the record kernels (set by make_nblist)
+  int tile_rec_opt = 1;           // option "tile_rec": 0 never, 1 when the tables do not fit the LDS beside a tile, 2 whenever several types
   int no_merge = 0;               // option "no_merge" (tests, before upload_tables): keep the tables apart even on a shared grid
   int p3_coef = 1;                // option "p3_coef": 0 keeps k_pass3_tile for every step
   int p3_klo = 0;                 // option "p3_klo" (tests): keep at least this many of the lowest rows out of the LDS

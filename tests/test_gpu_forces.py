@@ -191,6 +191,26 @@ def test_shared_grid_tables_through_the_distinct_grids_kernel():
     assert abs(r1["virial"] - r0["virial"]) < 1e-11 * abs(r0["virial"])
 
 
+@pytest.mark.parametrize("case,opt", [("eam2_l12_nbl", 0), ("eam2_l12_coarse", 2)])
+def test_two_types_other_kernel_choice(case, opt):
+    """option tile_rec: 0 = tables beyond the LDS select the global-gather family (the round-4 behaviour, still the second
+    implementation); 2 = the record kernels also for tables that would fit the LDS.  Same goldens."""
+    G = gu.load(case)
+    for step in (0, 20):
+        s = _gpu_from_golden(G, step)
+        s.set_option("tile_rec", opt)
+        r = s.calc_forces(step)
+        assert (s.get_info("list_mode"), s.get_info("pass1_form")) == ((0, 0) if opt == 0 else (1, 3))
+        d = s.download()
+        pre = "s%d_" % step
+        assert _relmax(d["kraft"], G[pre + "kraft"], floor=1e-3) < FTOL
+        assert _relmax(d["pot_eng"], G[pre + "pot_eng"]) < 1e-11
+        assert _relmax(d["eam_rho"], G[pre + "eam_rho"]) < 1e-11 and _relmax(d["eam_dF"], G[pre + "eam_dF"]) < 1e-11
+        assert abs(r["tot_pot_energy"] - float(G[pre + "tot_pot_energy"])) < 1e-11 * abs(float(G[pre + "tot_pot_energy"]))
+        assert abs(r["virial"] - float(G[pre + "virial"])) < 1e-10 * abs(float(G[pre + "virial"]))
+        s.close()
+
+
 def test_check_nblist_threshold():
     G = gu.load("eam_nbl_2048")
     s = _gpu_from_golden(G, 0)
@@ -210,9 +230,11 @@ def test_both_kernel_modes_match_reference(mode, case):
     s = _gpu_from_golden(G, 20)
     s.set_option("mode", mode)
     r = s.calc_forces(20)
-    # no silent fall-back to the other kernel family -- except, by design, tables that do not fit the LDS beside a
-    # tile (two atom types: 2 x 4 columns x 4002 rows = 256 KB): those run on the global-gather kernels
-    assert s.get_info("list_mode") == (0 if case == "eam2_l12_nbl" else mode)
+    # no silent fall-back to the other kernel family: tables that do not fit the LDS beside a tile (two atom types: 2 x 4 columns x
+    # 4002 rows = 256 KB) run on the tile kernels that read coefficient records through L2 (pass1_form 3)
+    assert s.get_info("list_mode") == mode
+    if mode == 1:
+        assert s.get_info("pass1_form") == {"eam_nbl_2048": 2, "eam_nbl_2048_dg": 1, "eam2_l12_nbl": 3, "eam2_l12_coarse": 0}[case]
     d = s.download()
     assert _relmax(d["kraft"], G["s20_kraft"]) < FTOL
     assert _relmax(d["eam_rho"], G["s20_eam_rho"]) < 1e-11
