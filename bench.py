@@ -82,6 +82,10 @@ def parse():
     ap.add_argument("--halo-overlap", type=int, default=0,
                     help="several ranks (or --force-distributed): pass 1 of the next step starts on interior tiles while its\n"
                          "position halo travels on a stream of its own; the value = CUs the first launch leaves to the transport")
+    ap.add_argument("--hook-remote-fail", type=int, default=0, help=argparse.SUPPRESS)     # test hook: this rank (1-based) cannot set its ghost records up
+    ap.add_argument("--allow-experiments", action="store_true",
+                    help="run although the library was built with experiment macros (imdgpu_get_info(\"experiments\") != 0): the line\n"
+                         "then carries \"experiments\": mask and is not a product measurement")
     ap.add_argument("--force-distributed", action="store_true",
                     help="rehearsal: run the multi-rank host layer (halo plan, gather/scatter, fork/join) on one rank")
     return ap.parse_args()
@@ -147,6 +151,12 @@ def build_system(args, rank, world, device, decomposed=False):
                      external_halo=args.force_distributed,
                      ttm_decomposed=ttm and (world > 1 or args.force_distributed) and decomposed)
     sysm.upload_tables(pair, rho, emb)
+    exp = sysm.get_info("experiments")
+    if exp and not args.allow_experiments:
+        raise SystemExit("bench.py: libimdgpu.so was built with experiment macros (mask %d: see imdgpu_experiment_mask); "
+                         "rebuild without EXTRA flags or pass --allow-experiments" % exp)
+    if args.hook_remote_fail:
+        sysm.set_option("ttm_remote_fail", args.hook_remote_fail)
     if args.halo_overlap > 0:
         sysm.set_option("halo_overlap", args.halo_overlap)
     if ttm and adv_on(args):
@@ -640,7 +650,7 @@ def main():
                                                                    "tile_threads", "lds_pass1", "lds_pass3", "W")},
                        "parallelism": ("%dx%dx%d ranks, 1 rank/GPU, direct 26-neighbour ghost-cell halo, native step (%s)%s"
                                        % (tuple(cpu_dim) + (md.ops.transport, lattice_note))) if md is not None else "single GPU"},
-            "roofline": dom, "roofline_other": other,
+            "roofline": dom, "roofline_other": other, "experiments": sysm.get_info("experiments"),
             "kernel_ms_per_step": {k: v[1] / args.steps for k, v in prof.items() if v[0]},
             "rebuild_ms": {"rebuilds": rebuilds, "make_nblist_ms_each": ms_nbl / max(n_nbl, 1), "fix_cells_ms_each": ms_fix / max(n_fix, 1),
                            "amortised_ms_per_step": (ms_nbl + ms_fix) / args.steps},

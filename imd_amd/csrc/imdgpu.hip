@@ -569,7 +569,7 @@ struct TileArgs {
   // staging plan written by k_nbl_build_tile, valid until the next re-binning: per tile the global index of the atom
   // in every LDS slot, per own atom (slot | neighbour count << 16), per tile {slots, first own atom, own atoms, 0}
   int *tsrc; unsigned *ownw; int4 *tinfo;
-  int dbg;                        // experiments (IMDGPU_DBG): 1 = skip the neighbour loops, 2 = skip the staging
+  int dbg;                        // experiments (IMDGPU_DBG, read only by a library built with -DIMDGPU_EXPERIMENTS; see DBG()): 1 = skip the neighbour loops, 4 / 8 = the list build's candidate loops / appends
   TabPar pair, rho, emb;
   double4 *posw;                  // pos again, writable: the fused embedding pass stores F'(rho) in .w
   const double *merged;           // interleaved (phi,rho) table + 3 zero rows, or nullptr
@@ -595,6 +595,11 @@ struct TileArgs {
   const long long *wprefix;       // [ntiles + 1] cost prefix (k_tile_wprefix), read when balance is set
 };
 
+#ifdef IMDGPU_EXPERIMENTS
+#define DBG(a, bit) ((a).dbg & (bit))
+#else
+#define DBG(a, bit) 0                   // the default build has no switch that skips work
+#endif
 struct TileCtx { int tile, hx, hy, hz, nh, own_start, nown; };
 
 // Persistent workgroups: block b works on a contiguous range of tiles [t0,t1) (consecutive tiles are
@@ -861,7 +866,7 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile(TileArgs a)
     const unsigned long long dummy64 = (unsigned long long) dummy * 0x0001000100010001ull;
     unsigned long long w = dummy64;
     int m = 0;
-    for (int dx = 0; dx <= ((a.dbg & 4) ? -1 : 2); dx++)
+    for (int dx = 0; dx <= (DBG(a, 4) ? -1 : 2); dx++)
       for (int dy = 0; dy <= 2; dy++)
         for (int dz = 0; dz <= 2; dz++) {
           const int h = ((lx + dx) * T.hy + (ly + dy)) * T.hz + (lz + dz);
@@ -888,7 +893,7 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile(TileArgs a)
             }
             mask &= cnt == 32 ? 0xffffffffu : ((1u << cnt) - 1u);
             if (slot >= j0 && slot < j0 + 32) mask &= ~(1u << (slot - j0));   // not its own neighbour
-            if (a.dbg & 8) mask = 0;
+            if (DBG(a, 8)) mask = 0;
             while (mask) {                                   // ascending j: the reference's order inside a cell
               const int j = j0 + __builtin_ctz(mask);
               mask &= mask - 1;
@@ -1006,7 +1011,7 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile32(TileArgs a)
       // the three neighbour cells dz = 0, 1, 2 of a (dx, dy) pair are consecutive halo cells, so their atoms are ONE run of
       // slots: nine runs of ~63 candidates instead of 27 cells of ~21 -- the same candidates in the same order (cells by dz,
       // atoms ascending inside a cell), a third of the per-run bookkeeping and fuller chunks
-      for (int dx = 0; dx <= ((a.dbg & 4) ? -1 : 2); dx++)
+      for (int dx = 0; dx <= (DBG(a, 4) ? -1 : 2); dx++)
         for (int dy = 0; dy <= 2; dy++) {
             const int h = ((lx + dx) * T.hy + (ly + dy)) * T.hz + lz;
             const int s = hstart[h], e = hstart[h + 3];
@@ -1046,7 +1051,7 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile32(TileArgs a)
                 }
               }
               mask &= valid;
-              if (a.dbg & 8) mask = 0;
+              if (DBG(a, 8)) mask = 0;
               while (mask) {                                             // ascending j: the reference's order inside a cell
                 const int b = __clz((int) mask);
                 mask &= ~(0x80000000u >> b);
@@ -1112,7 +1117,7 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile32(TileArgs a)
         const uint2 q0 = lp[0], q1 = lp[(size_t) a.tile_cap];                                                    \
         c0x = q0.x; c0y = q0.y; c1x = q1.x; c1y = q1.y;                                                          \
       }                                                                                                          \
-      const int slot = (int) (ow & 0xffffu), n4 = (a.dbg & 1) ? 0 : ((int) (ow >> 16) + 3) >> 2;                \
+      const int slot = (int) (ow & 0xffffu), n4 = DBG(a, 1) ? 0 : ((int) (ow >> 16) + 3) >> 2;                \
       if (n4 < 1) { c0x = dw; c0y = dw; }                                                                        \
       if (n4 < 2) { c1x = dw; c1y = dw; }
 // The list walk.  LIST_WORDS_BEGIN opens the per-word body (a lambda over one list word = four slots, defines j[UNR]);
@@ -2305,7 +2310,7 @@ extern "C" int imdgpu_create(imdgpu_ctx **out, int device)
   HIPCHK(hipSetDevice(device));
   HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess) ctx->num_cus = pr.multiProcessorCount; }
-  ctx->tl_on = getenv("IMDGPU_TIMELINE") != nullptr;
+  ctx->tl_on = cfg_env("IMDGPU_TIMELINE") != nullptr;
   {
     // the TTM lattice chain (100 tiny dependent launches) runs beside the force passes: give it the queue priority
     int least = 0, greatest = 0;
@@ -2387,6 +2392,9 @@ extern "C" int imdgpu_set_option(imdgpu_ctx *ctx, const char *name, int value)
   if (!strcmp(name, "p3_coef")) { ctx->p3_coef = value ? 1 : 0; return 0; }
   // tests, before upload_tables: pair_pot and rho_h_tab are kept apart even on a shared grid (the distinct-grids form of pass 1)
   if (!strcmp(name, "no_merge")) { ctx->no_merge = value ? 1 : 0; return 0; }
+  if (!strcmp(name, "act_ranksort_max")) { ctx->act_ranksort_max = value; return 0; }       // test hook (do_cell_activation)
+  if (!strcmp(name, "ttm_remote")) { ctx->ttm_remote_opt = value ? 1 : 0; return 0; }        // before the first multi-rank rebuild
+  if (!strcmp(name, "ttm_remote_fail")) { ctx->ttm_remote_fail = value; return 0; }          // test hook
   // several atom types: 0 = never the record kernels (tables beyond the LDS then select the global-gather family), 1 = when the tables
   // do not fit the LDS beside a tile (default), 2 = whenever there are several types
   if (!strcmp(name, "tile_rec")) { ctx->tile_rec_opt = value < 0 ? 0 : (value > 2 ? 2 : value); ctx->have_valid_nbl = 0; return 0; }
@@ -2413,6 +2421,37 @@ extern "C" int imdgpu_set_option(imdgpu_ctx *ctx, const char *name, int value)
 static bool fuse_emb(const imdgpu_ctx *ctx);
 static bool p1_onetype(const imdgpu_ctx *ctx);
 static size_t p3_coef_lds(const imdgpu_ctx *ctx, int &klo);
+// which experiment macros this library was built with (0 = the product build): bit 0 IMDGPU_EXPERIMENTS (environment switches
+// live), 1 PHASE_TIMING, 2 WAVE_FAIR, 3 POSXY, 4 IMDGPU_LDSPRIO, 5 non-default TILE_MAXTHREADS / UNR / SA, 6 IMDGPU_NOSCHED,
+// 7 P3_VGPRS / P3C_UNFUSED_R2, 8 PERSIST_PRIO (imdgpu_ttm.hip)
+int imdgpu_ttm_experiment_mask();
+static long long imdgpu_experiment_mask()
+{
+  long long m = 0;
+#ifdef IMDGPU_EXPERIMENTS
+  m |= 1;
+#endif
+#ifdef PHASE_TIMING
+  m |= 2;
+#endif
+#ifdef WAVE_FAIR
+  m |= 4;
+#endif
+#ifdef POSXY
+  m |= 8;
+#endif
+#ifdef IMDGPU_LDSPRIO
+  m |= 16;
+#endif
+  if (TILE_MAXTHREADS != 768 || UNR != 4 || SA != 8) m |= 32;
+#ifdef IMDGPU_NOSCHED
+  m |= 64;
+#endif
+#if defined(P3_VGPRS) || defined(P3C_UNFUSED_R2)
+  m |= 128;
+#endif
+  return m | imdgpu_ttm_experiment_mask();
+}
 extern "C" int imdgpu_get_info(imdgpu_ctx *ctx, const char *name, long long *value)
 {
   int klo_now = 0;
@@ -2421,7 +2460,7 @@ extern "C" int imdgpu_get_info(imdgpu_ctx *ctx, const char *name, long long *val
     // rows of the gradient-coefficient table the EAM force pass holds in LDS and the first of them (0 / -1: three-row form)
     {"p3_coef_rows", coef_on ? ctx->ncoef - klo_now : 0}, {"p3_coef_klo", coef_on ? klo_now : -1},
     // plane stride the neighbour loops of the running force kernels are compiled for (0: the run-time stride slot_cap)
-    {"fast_cap", (ctx->list_mode == 1 && ctx->slot_cap == FAST_CAP && !(getenv("IMDGPU_FAST_CAP") && !atoi(getenv("IMDGPU_FAST_CAP")))) ? FAST_CAP : 0},
+    {"fast_cap", (ctx->list_mode == 1 && ctx->slot_cap == FAST_CAP && exp_env_int("IMDGPU_FAST_CAP", 1)) ? FAST_CAP : 0},
     {"list_mode", ctx->list_mode}, {"mode", ctx->mode}, {"tile_cap", ctx->tile_cap}, {"slot_cap", ctx->slot_cap},
     {"max_halo", ctx->max_halo}, {"W", ctx->W}, {"tile_x", ctx->tile[0]}, {"tile_y", ctx->tile[1]}, {"tile_z", ctx->tile[2]},
     {"ntiles", ctx->ntiles}, {"tile_threads", ctx->tile_threads}, {"nlocal", ctx->nlocal}, {"nghost", ctx->nghost},
@@ -2429,6 +2468,7 @@ extern "C" int imdgpu_get_info(imdgpu_ctx *ctx, const char *name, long long *val
     {"fused_embedding", fuse_emb(ctx) ? 1 : 0},
     // which pass 1 runs: 2 = one type, pair_pot and rho_h_tab interleaved on their shared grid; 1 = one type, each table on its own grid;
     // 0 = the general kernels (several types, pair only, ...)
+    {"experiments", imdgpu_experiment_mask()},
     {"pass1_form", p1_onetype(ctx) ? (ctx->d_merged ? 2 : 1) : (ctx->list_mode == 1 && ctx->tile_rec ? 3 : 0)},
     // global-gather family: the tables are too large for the LDS and are read in place through L2 (k_pass1_gt / k_pass3_gt)
     {"global_tables_in_place", ctx->list_mode == 0 && ((size_t) (ctx->pair.present ? ctx->pair.par.nrows * ctx->pair.par.ncols : 0) +
@@ -2629,11 +2669,11 @@ extern "C" int imdgpu_set_geometry(imdgpu_ctx *ctx, const double box[9], const i
     int n = D[d] - 2;
     ctx->tile[d] = n >= 3 ? ((n % 3 == 1 && n % 2 == 0) ? 2 : 3) : n;
   }
-  if (const char *e = getenv("IMDGPU_TILE")) {
+  if (const char *e = cfg_env("IMDGPU_TILE")) {
     int a, b, c;
     if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a > 0 && b > 0 && c > 0) { ctx->tile[0] = a; ctx->tile[1] = b; ctx->tile[2] = c; }
   }
-  if (const char *e = getenv("IMDGPU_MODE")) ctx->mode = atoi(e);
+  if (const char *e = cfg_env("IMDGPU_MODE")) ctx->mode = atoi(e);
   // static ghost-cell tables: source inner cell (periodic wrap on this rank) and shift code
   std::vector<int> lin, sh;
   ctx->h_gsrc_xyz.clear();
@@ -3100,7 +3140,7 @@ static size_t align8(size_t b) { return (b + 7) & ~(size_t) 7; }
 // persistent tile kernels: one workgroup per CU (their ~140 KB of LDS admit no second one)
 static int tile_grid(const imdgpu_ctx *ctx)
 {
-  static const int forced = getenv("IMDGPU_TILE_GRID") ? atoi(getenv("IMDGPU_TILE_GRID")) : 0;   // experiments only
+  static const int forced = exp_env_int("IMDGPU_TILE_GRID", 0);
   if (forced > 0) return std::min(ctx->ntiles, forced);
   // reserve_cus: CUs left free by the persistent force kernels for a multi-wave workgroup of the lattice stream that cannot
   // sit beside them on one CU (the single-workgroup Maxwell-solver loop, imdgpu_ttm_fdtd_init)
@@ -3116,7 +3156,7 @@ static TileArgs make_tile_args(imdgpu_ctx *ctx)
   a.pos = ctx->pos; a.type = ctx->type; a.acell = ctx->acell; a.cell_start = ctx->cell_start; a.cell_cnt = ctx->cell_cnt;
   a.istart = ctx->istart; a.nbr16 = (ushort4 *) ctx->nbr16; a.nbr_cnt = ctx->nbr_cnt;
   a.tsrc = ctx->tsrc; a.ownw = ctx->ownw; a.tinfo = (int4 *) ctx->tinfo;
-  { static const int dbg = getenv("IMDGPU_DBG") ? atoi(getenv("IMDGPU_DBG")) : 0; a.dbg = dbg; }
+  { static const int dbg = exp_env_int("IMDGPU_DBG", 0); a.dbg = dbg; }
   a.pair = ctx->pair.par; a.rho = ctx->rho.par; a.emb = ctx->emb.par; a.posw = ctx->pos; a.merged = ctx->d_merged;
   a.coef3 = (const double2 *) ctx->d_coef3; a.ncoef = ctx->ncoef; a.klo = 0; a.p3_fallback = 0;
   a.recP = (const double4 *) ctx->d_recP; a.recR = (const double4 *) ctx->d_recR; a.rec3 = (const double2 *) ctx->d_rec3;
@@ -3168,7 +3208,7 @@ extern "C" int imdgpu_autotile(imdgpu_ctx *ctx, int *changed)
 {
   HIPCHK(hipSetDevice(ctx->device));
   if (changed) *changed = 0;
-  if (ctx->mode != 1 || ctx->autotiled || getenv("IMDGPU_TILE")) { ctx->autotiled = 1; return 0; }
+  if (ctx->mode != 1 || ctx->autotiled || cfg_env("IMDGPU_TILE")) { ctx->autotiled = 1; return 0; }
   const int before[3] = {ctx->tile[0], ctx->tile[1], ctx->tile[2]};
   if (autotile(ctx)) return 1;
   if (changed) *changed = before[0] != ctx->tile[0] || before[1] != ctx->tile[1] || before[2] != ctx->tile[2];
@@ -3194,7 +3234,7 @@ extern "C" int imdgpu_make_nblist(imdgpu_ctx *ctx)
     else ctx->list_mode = 0;
   }
   if (ctx->list_mode == 1 && ctx->tile_rec_opt == 2 && ctx->d_recP && ctx->d_recR && ctx->d_rec3) ctx->tile_rec = 1;   // option: also when the tables would fit
-  if (ctx->list_mode == 1 && !ctx->autotiled && !getenv("IMDGPU_TILE") && !ctx->external_halo) {
+  if (ctx->list_mode == 1 && !ctx->autotiled && !cfg_env("IMDGPU_TILE") && !ctx->external_halo) {
     if (autotile(ctx)) return 1;
     g = make_geo(ctx);
     if (imdgpu_fill_ghosts(ctx)) return 1;
@@ -3208,7 +3248,7 @@ extern "C" int imdgpu_make_nblist(imdgpu_ctx *ctx)
     HIPCHK(hipStreamSynchronize(ctx->stream));
     int tile_cap = (std::max(ctx->h_counters[CNT_MAXOWN], 1) + 63) / 64 * 64;
     {   // uneven occupancy (vacuum, slabs): cut the persistent blocks' tile ranges by atoms, not by tiles
-      static const char *fb = getenv("IMDGPU_TILE_BALANCE");
+      static const char *fb = exp_env("IMDGPU_TILE_BALANCE");
       ctx->tile_balance = fb ? atoi(fb) : ((double) ctx->h_counters[CNT_MAXOWN] * ctx->ntiles > 1.25 * (double) std::max(n, 1));
     }
     if (ctx->tile_balance) {
@@ -3251,7 +3291,7 @@ extern "C" int imdgpu_make_nblist(imdgpu_ctx *ctx)
       ProfScope ps(ctx, PROF_NBLIST);
       // the build needs only the position planes (about half the LDS of a force pass): two workgroups per CU
       const int bgrid = 2 * lds <= LDS_LIMIT ? std::min(ctx->ntiles, 2 * tile_grid(ctx)) : tile_grid(ctx);
-      static const int nbl32 = getenv("IMDGPU_NBL32") ? atoi(getenv("IMDGPU_NBL32")) : 1;     // 0: the all-double build kernel
+      static const int nbl32 = exp_env_int("IMDGPU_NBL32", 1);     // 0: the all-double build kernel
       if (nbl32) {
         HIPCHK(hipFuncSetAttribute((const void *) k_nbl_build_tile32, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
         hipLaunchKernelGGL(k_nbl_build_tile32, dim3(bgrid), dim3(ctx->tile_threads), lds, ctx->stream, a);
@@ -3339,7 +3379,7 @@ static bool p1_onetype(const imdgpu_ctx *ctx)
 }
 static size_t p3_coef_lds(const imdgpu_ctx *ctx, int &klo)
 {
-  static const int env = getenv("IMDGPU_P3_COEF") ? atoi(getenv("IMDGPU_P3_COEF")) : 1;
+  static const int env = exp_env_int("IMDGPU_P3_COEF", 1);
   if (!env || !ctx->p3_coef || !p1_onetype(ctx) || !ctx->d_coef3) return 0;
   if (imdgpu_ttm_chain_needs_lds(ctx)) return 0;      // this kernel leaves no LDS to anything beside it
   const size_t fixed = align8((4 * (size_t) ctx->slot_cap + 64 + 2) * 8);
@@ -3355,7 +3395,7 @@ static size_t p3_coef_lds(const imdgpu_ctx *ctx, int &klo)
 int imdgpu_p3_coef_active(const imdgpu_ctx *ctx) { int klo; return p3_coef_lds(ctx, klo) != 0; }
 static bool fuse_emb(const imdgpu_ctx *ctx)
 {
-  static const int on = getenv("IMDGPU_FUSE_EMB") ? atoi(getenv("IMDGPU_FUSE_EMB")) : 1;
+  static const int on = exp_env_int("IMDGPU_FUSE_EMB", 1);
   return on && (p1_onetype(ctx) || (ctx->list_mode == 1 && ctx->tile_rec));
 }
 
@@ -3376,7 +3416,7 @@ static int launch_forces(imdgpu_ctx *ctx, int phase = 0)
   if (nb > ctx->npart_blocks) return imdgpu_fail(ctx, "internal: partials too small");
   TileArgs ta;
   if (TILE) { ta = make_tile_args(ctx); ta.guard = ctx->pass1_guard; }
-  static const int fastcap_env = getenv("IMDGPU_FAST_CAP") ? atoi(getenv("IMDGPU_FAST_CAP")) : 1;
+  static const int fastcap_env = exp_env_int("IMDGPU_FAST_CAP", 1);
   const bool fastcap = fastcap_env && TILE && ctx->slot_cap == FAST_CAP;       // the neighbour loops compiled for this plane stride
   size_t lds1 = ((PAIR ? a.pair.nrows * a.pair.ncols : 0) + (EAM ? a.rho.nrows * a.rho.ncols : 0) + 64) * sizeof(double);
   if (phase == 0 || phase == 1) {
@@ -3478,7 +3518,7 @@ static int launch_forces(imdgpu_ctx *ctx, int phase = 0)
   } while (0)
 #define L3C(R) do { if (fastcap) L3CK(R, FAST_CAP); else L3CK(R, 0); } while (0)
         // 132 VGPRs with the register ring: three waves per SIMD still leave the 80 a wave of the lattice chain needs
-        static const int ring = getenv("IMDGPU_P3_RING") ? atoi(getenv("IMDGPU_P3_RING")) : 4;
+        static const int ring = exp_env_int("IMDGPU_P3_RING", 4);
         if (ring == 0) L3C(0); else L3C(4);
 #undef L3C
 #undef L3CK
@@ -3536,7 +3576,7 @@ int imdgpu_launch_pass1_dyn(imdgpu_ctx *ctx, int part)
 {
   if (!imdgpu_pass1_dyn_ready(ctx)) return imdgpu_fail(ctx, "internal: pass 1 has no tile queue");
   const bool TT = ctx->count_ttm != 0;
-  static const int fastcap_env = getenv("IMDGPU_FAST_CAP") ? atoi(getenv("IMDGPU_FAST_CAP")) : 1;
+  static const int fastcap_env = exp_env_int("IMDGPU_FAST_CAP", 1);
   const bool fastcap = fastcap_env && ctx->slot_cap == FAST_CAP;
   const int B = ctx->tile_threads, full = tile_grid(ctx);
   // the first launch leaves halo_overlap CUs alone: the transport's kernels (RCCL's, the unpack) need somewhere to run
@@ -3614,7 +3654,7 @@ extern "C" int imdgpu_move_atoms_nve(imdgpu_ctx *ctx, double *ekin)
 
 static int fork_ttm(imdgpu_ctx *ctx, void *)
 {
-  static const int serial = getenv("IMDGPU_TTM_SERIAL") ? atoi(getenv("IMDGPU_TTM_SERIAL")) : 0;   // experiment: calc_ttm alone on the chip
+  static const int serial = exp_env_int("IMDGPU_TTM_SERIAL", 0);   // experiment: calc_ttm alone on the chip
   if (serial) {
     if (ctx->ttm1d ? imdgpu_ttm1d_calc(ctx, ctx->ttm_steps) : imdgpu_calc_ttm(ctx, ctx->ttm_steps)) return 1;
     HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream));

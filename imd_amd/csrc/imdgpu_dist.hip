@@ -140,7 +140,7 @@ static int dist_new(imdgpu_ctx *ctx, int nranks, int rank)
   HIPCHK(hipEventCreateWithFlags(&D->ev_fork3, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&D->ev_halo, hipEventDisableTiming));
   HIPCHK(hipStreamCreateWithFlags(&D->stream3, hipStreamNonBlocking));
-  D->self_comm = getenv("IMDGPU_DIST_SELF_COMM") != nullptr;   // rehearsal: self-neighbour segments go through the transport too
+  D->self_comm = cfg_env("IMDGPU_DIST_SELF_COMM") != nullptr;   // rehearsal: self-neighbour segments go through the transport too
   return 0;
 }
 
@@ -487,7 +487,7 @@ extern "C" int imdgpu_dist_md_step(imdgpu_ctx *ctx, int steps, int *rebuild_need
   imdgpu_tl_mark(ctx, "move");
   // next step's position halo and the global validity flag; then pass 1 of the next step, guarded by that flag, so the
   // device has work while the host reads the flag
-  const bool spec = !getenv("IMDGPU_NO_SPECULATION");
+  const bool spec = !exp_env("IMDGPU_NO_SPECULATION");
   auto drop_ahead = [&]() {           // the guarded launch did nothing: it must not count as a pass-1 launch in the kernel timings
     for (int id : {(int) PROF_PASS1B, (int) PROF_PASS1})
       for (size_t q = ctx->ev_pending.size(); q-- > 0;)
@@ -513,7 +513,7 @@ extern "C" int imdgpu_dist_md_step(imdgpu_ctx *ctx, int steps, int *rebuild_need
     if (overlap) {
       HIPCHK(hipEventRecord(D->ev_fork3, ctx->stream));
       ctx->pass1_guard = D->d_flag + 3;
-      static const int dexp = getenv("IMDGPU_DYN_EXP") ? atoi(getenv("IMDGPU_DYN_EXP")) : 0;    // experiments: 2 = the halo in front of launch A on the main stream
+      static const int dexp = exp_env_int("IMDGPU_DYN_EXP", 0);    // experiments: 2 = the halo in front of launch A on the main stream
       int rc = (dexp & 2) ? 0 : imdgpu_launch_pass1_dyn(ctx, 0);
       hipStream_t main = ctx->stream;
       if (!rc) {
@@ -550,6 +550,10 @@ extern "C" int imdgpu_dist_md_step(imdgpu_ctx *ctx, int steps, int *rebuild_need
   if (ctx->tl_on) { imdgpu_tl_mark(ctx, "halo+flag+pass1ahead"); imdgpu_tl_flush(ctx, steps); }
   if (D->h_flag[1]) {               // like imdgpu_md_step: the lattice of this step was not (or only half) advanced on some rank
     HIPCHK(hipMemsetAsync(ctx->d_counters + CNT_TTM_TIMEOUT, 0, sizeof(int), ctx->stream));      // reported once
+    if (D->h_flag[1] >= 2)
+      return imdgpu_fail(ctx, "TTM, decomposed lattice: the active region of some rank's block is not supported by the persistent sub-step "
+                              "kernel (more blocks of 4 x 4 x 4 FD cells than one launch brings, or a lattice one layer thin): the lattice of this "
+                              "step is not valid; use the replicated lattice (option ttm_decomposed 0) for this run");
     return imdgpu_fail(ctx, "TTM: a hand-off between lattice blocks timed out on some rank (persistent sub-step kernel or mailbox): the lattice of this step is not valid");
   }
   const int invalid = D->h_flag[0];
@@ -652,7 +656,7 @@ static PlanState *PS(imdgpu_ctx *ctx)
   auto it = g_plans.find(ctx);
   if (it != g_plans.end()) return it->second;
   PlanState *p = new PlanState();
-  p->timing = getenv("IMD_DIST_TIMING") != nullptr;
+  p->timing = cfg_env("IMD_DIST_TIMING") != nullptr;
   g_plans[ctx] = p;
   return p;
 }
@@ -1124,10 +1128,10 @@ extern "C" int imdgpu_dist_ttm_remote_setup(imdgpu_ctx *ctx)
       if (p2 != pid) other_process = true;
     }
   void *ptr = nullptr; size_t bytes = 0;
-  const bool force_coarse = getenv("IMDGPU_TTM_REMOTE_COARSE") != nullptr;
+  const bool force_coarse = exp_env("IMDGPU_TTM_REMOTE_COARSE") != nullptr;
   unsigned char handle[64] = {0};
   int fine = 0;
-  if (getenv("IMDGPU_TTM_REMOTE_FAIL") && atoi(getenv("IMDGPU_TTM_REMOTE_FAIL")) == D->rank + 1) {   // test hook: this rank cannot set up
+  if (ctx->ttm_remote_fail == D->rank + 1) {   // test hook: this rank cannot set up
     imdgpu_fail(ctx, "IMDGPU_TTM_REMOTE_FAIL"); failed("test hook");
   }
   if (!bad && imdgpu_ttm_remote_init(ctx, force_coarse ? 1 : 0, &ptr, &bytes)) failed("buffer");
@@ -1225,7 +1229,7 @@ extern "C" int imdgpu_dist_rebuild(imdgpu_ctx *ctx)
     fprintf(stderr, "[dist rebuild %d, native] ms: migrate %.2f, fix_cells %.2f, plan %.2f, exchange %.2f, make_nblist %.2f\n", P->nrebuild,
             P->ms[0], P->ms[1], P->ms[2], P->ms[3], P->ms[4]);
   }
-  if (ctx->ttm && ctx->ttm_decomposed && P->nrebuild == 0 && !(getenv("IMDGPU_TTM_REMOTE") && atoi(getenv("IMDGPU_TTM_REMOTE")) == 0)) {
+  if (ctx->ttm && ctx->ttm_decomposed && P->nrebuild == 0 && ctx->ttm_remote_opt) {
     // decomposed lattice: faces through ghost records in the neighbours' memory; if that cannot be set up (the verdict is the
     // same on every rank) the host mailbox keeps carrying them -- slower, not wrong
     if (imdgpu_dist_ttm_remote_setup(ctx)) {

@@ -321,6 +321,12 @@ extern "C" int imdgpu_forces_phase(imdgpu_ctx *ctx, int phase)
 extern "C" int imdgpu_integrate(imdgpu_ctx *ctx)
 {
   HIPCHK(hipSetDevice(ctx->device));
+  // A host that drives the step piece by piece (imdgpu_calc_ttm / imdgpu_ttm_lattice_step, then this call) has nobody behind it who
+  // would run the integrator AGAIN: the persistent sub-step launch of this step is settled first -- a launch that stepped aside
+  // (status 1) gets its sub-steps through the launch chain now -- so the integrator below is never guarded by its status word and
+  // never skipped (before, one MD step of motion was silently lost).  Costs this entry point one wait for the status
+  // word per step; imdgpu_md_step_end and imdgpu_dist_md_step keep the guarded form and re-run the integrator themselves.
+  if (ctx->ttm && !ctx->step_open && imdgpu_ttm_persist_settle(ctx) < 0) return 1;
   return imdgpu_launch_integrate(ctx);
 }
 

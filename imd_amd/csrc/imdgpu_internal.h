@@ -10,6 +10,23 @@
 #include "../../include/imdgpu.h"
 
 #define IMDGPU_MAXCOL 16          // ntypes <= 4
+
+// Environment names, two classes.
+//  cfg_env: CONFIGURATION, read by every build -- choices among implementations that are all held against the goldens (IMDGPU_TILE,
+//           IMDGPU_MODE), diagnostics that change no result (IMDGPU_TIMELINE, IMD_DIST_TIMING) and the transport of the multi-rank step
+//           (IMDGPU_DIST_TRANSPORT, IMDGPU_DIST_SELF_COMM).
+//  exp_env: EXPERIMENT switches (timing splits that skip work, scheduling knobs, forced failure paths).  They exist only in a library
+//           built with `make EXTRA=-DIMDGPU_EXPERIMENTS`; the default build does not look at the environment for them, so a stray
+//           IMDGPU_DBG=1 cannot turn the force loops off.  imdgpu_get_info("experiments") tells how a library was built (a bit mask,
+//           see imdgpu_experiment_mask), bench.py refuses anything but 0.  Test hooks are options (imdgpu_set_option), not names here.
+#include <cstdlib>
+static inline const char *cfg_env(const char *n) { return getenv(n); }
+#ifdef IMDGPU_EXPERIMENTS
+static inline const char *exp_env(const char *n) { return getenv(n); }
+#else
+static inline const char *exp_env(const char *) { return nullptr; }
+#endif
+static inline int exp_env_int(const char *n, int dflt) { const char *e = exp_env(n); return e ? atoi(e) : dflt; }
 #define IMDGPU_NPART 4            // partial sums per block: e_pair, vir1, e_embed / vir3, spare
 
 struct TabPar {                   // one potential table as kernel argument
@@ -62,6 +79,9 @@ struct imdgpu_ctx {
   double *d_recP = nullptr, *d_recR = nullptr, *d_rec3 = nullptr; int nrecP = 0, nrecR = 0;
   int tile_rec = 0;               // this list's force kernels are the record kernels (set by make_nblist)
   int tile_rec_opt = 1;           // option "tile_rec": 0 never, 1 when the tables do not fit the LDS beside a tile, 2 whenever several types
+  int act_ranksort_max = 1024;    // option "act_ranksort_max" (test hook): above this many simultaneous fallback activations the ordered walk replaces the rank sort
+  int ttm_remote_opt = 1;         // option "ttm_remote": 0 keeps the host mailbox for the decomposed lattice's faces
+  int ttm_remote_fail = 0;        // option "ttm_remote_fail" (test hook): rank + 1 that pretends it cannot set the remote records up
   int no_merge = 0;               // option "no_merge" (tests, before upload_tables): keep the tables apart even on a shared grid
   int p3_coef = 1;                // option "p3_coef": 0 keeps k_pass3_tile for every step
   int p3_klo = 0;                 // option "p3_klo" (tests): keep at least this many of the lowest rows out of the LDS

@@ -1232,8 +1232,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
       }
       occ += L.dim[d];
       if (b == 0) { a = 1; none = true; }                                          // no active cell at all
+      // one layer thin (the first filled layer of a rank's block: material expanding or ablating into an empty block): the
+      // box takes the inactive layer next to it along -- in-box cells without atoms are mirrors like cells outside the box
+      if (b == a && L.dim[d] - 2 >= 2) { if (a > 1) a--; else b++; }
       lo[d] = a; nn[d] = b - a + 1; nb[d] = (nn[d] + PT - 1) / PT;
-      if (nn[d] == 1) aside = true;
+      if (nn[d] == 1) aside = true;                                                // a lattice of one layer in this dimension
     }
   }
   if (none) return;                                                                // nothing active, nothing to do: status stays 0
@@ -1242,7 +1245,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
   if (aside) {
     if (tile == 0 && lane == 0) {
       __hip_atomic_store(P.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (REM) __hip_atomic_store(P.counters + CNT_TTM_TIMEOUT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // other ranks' kernels are waiting for this one's records
+      // other ranks' kernels are waiting for this one's records: an error on every rank (the flag all-reduce takes the maximum).
+      // 2 = "this rank's active region does not fit the launch", told apart from a time-out (1) by the host's message
+      if (REM) __hip_atomic_store(P.counters + CNT_TTM_TIMEOUT, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     return;
   }
@@ -1649,7 +1654,7 @@ static Lat make_lat(const TtmState *t)
   L.inv_awamu = 1.0 / (t->atomic_weight * C_AMU);
   for (int d = 0; d < 3; d++) L.invhsq[d] = 1.0 / (t->h[d] * t->h[d]);
   L.xi_fac = 26.9815 * C_AMU / 3.0 * 1e30 / ((double) t->nsub);
-  { static const int prio = getenv("IMDGPU_TTM_PRIO") ? atoi(getenv("IMDGPU_TTM_PRIO")) : 0; L.wave_prio = prio; }
+  { static const int prio = exp_env_int("IMDGPU_TTM_PRIO", 0); L.wave_prio = prio; }
   return L;
 }
 
@@ -2275,9 +2280,17 @@ static int ttm_cell_activation(imdgpu_ctx *ctx, TtmState *t, const Lat &L, bool 
   hipLaunchKernelGGL(k_ttm_activation_seq, dim3(1), dim3(64), 0, ctx->stream, L, t->ee, t->natoms, t->temp[t->cur],
                      t->temp[t->cur ^ 1], t->U[t->cur], t->U[t->cur ^ 1], t->md_temp, t->dens, t->d_cand,
                      t->d_cand + t->ninner, t->d_cand + 2 * (size_t) t->ninner,
-                     getenv("IMDGPU_ACT_RANKSORT_MAX") ? atoi(getenv("IMDGPU_ACT_RANKSORT_MAX")) : 1024);
+                     ctx->act_ranksort_max);
   HIPCHK(hipGetLastError());
   return 0;
+}
+int imdgpu_ttm_experiment_mask()
+{
+  int m = 0;
+#ifdef PERSIST_PRIO
+  m |= 256;
+#endif
+  return m;
 }
 extern "C" int imdgpu_ttm_cell_activation(imdgpu_ctx *ctx)
 {
@@ -2419,7 +2432,7 @@ long long imdgpu_ttm_persist_info(imdgpu_ctx *ctx, int which)
 static int persist_mode(imdgpu_ctx *ctx, TtmState *t)
 {
   if (t->persist < 0) {
-    static const int envv = getenv("IMDGPU_TTM_PERSIST") ? atoi(getenv("IMDGPU_TTM_PERSIST")) : 1;
+    static const int envv = exp_env_int("IMDGPU_TTM_PERSIST", 1);
     const int env = ctx->ttm_persist_opt >= 0 ? ctx->ttm_persist_opt : envv;
     const int nt[3] = {(t->dim[0] - 2 + PT - 1) / PT, (t->dim[1] - 2 + PT - 1) / PT, (t->dim[2] - 2 + PT - 1) / PT};
     const long long full = (long long) nt[0] * nt[1] * nt[2];
@@ -2520,7 +2533,7 @@ static int launch_persist(imdgpu_ctx *ctx, TtmState *t, const Lat &L, double tau
   // 128-register waves leave 128 on every SIMD, 96 -- measured with the final force kernels: 128 ends the chain 0.27 ms before
   // the pass (1.33 / 1.59 ms), 96 costs the pass less and both end together (1.47 / 1.58; step 4.49 -> 4.48 ms), 80 makes the
   // chain the longer one again (1.62 / 1.52; 4.58); 80 beside the three-row form (138 registers).  IMDGPU_TTM_WPE=4|5|6 overrides.
-  static const int wpe_env = getenv("IMDGPU_TTM_WPE") ? atoi(getenv("IMDGPU_TTM_WPE")) : 0;
+  static const int wpe_env = exp_env_int("IMDGPU_TTM_WPE", 0);
   const int wpe = alone ? 4 : (wpe_env >= 4 && wpe_env <= 6 ? wpe_env : (imdgpu_p3_coef_active(ctx) ? 5 : 6));
 #define PERSIST_W(S, R) { if (wpe == 4) PERSIST_LAUNCH(S, 4, R); else if (wpe == 5) PERSIST_LAUNCH(S, 5, R); else PERSIST_LAUNCH(S, 6, R); }
   if (rem) { if (t->have_source) PERSIST_W(true, true) else PERSIST_W(false, true) }
@@ -2576,7 +2589,7 @@ extern "C" int imdgpu_ttm_lattice_step(imdgpu_ctx *ctx, int steps)
   const bool REMK = ctx->ttm_decomposed && pmode > 0;
   if (ctx->ttm_decomposed && !MBX && !REMK) return imdgpu_fail(ctx, "decomposed TTM lattice: imdgpu_ttm_mailbox_attach first (needed whenever the persistent kernel with remote records does not apply: step 0, odd sub-step counts)");
   imdgpu_tl_mark(ctx, "ttm_update_fd");
-  static const bool force_rem = getenv("IMDGPU_TTM_FORCE_REM") != nullptr;        // experiment: the remote-record build of the kernel on one rank's whole lattice
+  static const bool force_rem = exp_env("IMDGPU_TTM_FORCE_REM") != nullptr;        // experiment: the remote-record build of the kernel on one rank's whole lattice
   if (t->laser_on && imdgpu_ttm_laser_rescale(ctx, &t->laser, steps)) return 1;   // update_fd has just zeroed the source
   if (ttm_cell_activation(ctx, t, L, REMK)) return 1;      // with remote records: also every face cell's atom count to the rank beyond
   if (pmode > 0) HIPCHK(hipMemsetAsync(t->d_pbbox, 0, ((size_t) t->dim[0] + t->dim[1] + t->dim[2]) * sizeof(int), ctx->stream));
@@ -2615,7 +2628,7 @@ extern "C" int imdgpu_ttm_lattice_step(imdgpu_ctx *ctx, int steps)
       // end just before the pass does (IMDGPU_TTM_HIGH = how many)
       // (a lattice of 2x the cells and more -- the replicated lattice of several ranks -- outlasts the pass anyway: every
       // sub-step raised then; measured with 2x / 4x the cells: step 5.72 -> 5.53 / 6.66 -> 6.50 ms)
-      static const int nhigh_env = getenv("IMDGPU_TTM_HIGH") ? atoi(getenv("IMDGPU_TTM_HIGH")) : -1;
+      static const int nhigh_env = exp_env_int("IMDGPU_TTM_HIGH", -1);
       const int nhigh = nhigh_env >= 0 ? nhigh_env : (t->ninner >= 90000 ? t->nsub : 20);
       for (int i = 0; i < t->nsub; i++) {
         Lat Li = L;

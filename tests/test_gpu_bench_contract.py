@@ -65,7 +65,7 @@ def test_bench_spawns_its_ranks_and_refuses_a_mismatch():
     assert lt["decomposed"]["faces"].startswith("ghost records in the neighbours' device memory")
     assert ("TTM lattice " + lt["chosen"]) in d["config"]["parallelism"]
     # one rank cannot set its ghost-record buffer up: EVERY rank learns it and the decomposed lattice stays on the host mailbox
-    d2 = _one_json_line(subprocess.run(cmd + ["--ttm-lattice", "decomposed"], cwd=ROOT, env=dict(env, IMDGPU_TTM_REMOTE_FAIL="2"),
+    d2 = _one_json_line(subprocess.run(cmd + ["--ttm-lattice", "decomposed", "--hook-remote-fail", "2"], cwd=ROOT, env=env,
                                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600))
     assert "faces: host mailbox" in d2["config"]["parallelism"] and d2["value"] > 0 and "lattice_trial" not in d2
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"], cwd=ROOT,

@@ -351,13 +351,13 @@ def test_adjacent_cells_activated_in_the_same_step_follow_the_reference_order():
     s.close(); o.close()
 
 
-def test_cold_lattice_activates_every_cell_in_order(monkeypatch):
+def test_cold_lattice_activates_every_cell_in_order():
     """All cells activated in the same step (a lattice handed over with natoms_old = 0 and Te = 0) with the rank-sort
-    limit lowered to 8 candidates (IMDGPU_ACT_RANKSORT_MAX), so the ordered walk over all cells runs -- the path for
+    limit lowered to 8 candidates (option act_ranksort_max), so the ordered walk over all cells runs -- the path for
     more than 1024 simultaneous activations; still the sequential oracle (1e-14)."""
-    monkeypatch.setenv("IMDGPU_ACT_RANKSORT_MAX", "8")
     G = gu.load("ttm_2048")
     s = _gpu(G)
+    s.set_option("act_ranksort_max", 8)
     so = gu.oracle_from_golden(G, 0)
     o = gu.oracle_ttm_from_golden(G, so)
     pre = "t1_update_fd_"

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Per-sub-step cost of the decomposed TTM lattice's faces on ONE GPU: 2 (or more) ranks as threads of this process
 (imd_amd.parallel.LocalGroup), each with its own context, lattice block and persistent / chained sub-step kernels.
-  mode "mailbox": faces through the host shared-memory mailbox, one launch chain per sub-step (round 2's path, IMDGPU_TTM_REMOTE=0)
+  mode "mailbox": faces through the host shared-memory mailbox, one launch chain per sub-step (round 2's path, TTM_REMOTE=0 in the environment of this tool)
   mode "remote" : ghost records in the neighbours' device memory, written from inside the persistent kernel (round 3)
 Prints the chain's duration per MD step and per sub-step (HIP events around the lattice work on its stream) for rank 0.
-usage: tools/ttm_decomposed_timing.py [cx cy cz] [steps]      (run once per mode: IMDGPU_TTM_REMOTE=0|1 in the environment)"""
+usage: tools/ttm_decomposed_timing.py [cx cy cz] [steps]      (run once per mode: TTM_REMOTE=0|1 in the environment of this tool -> option ttm_remote)"""
 import json
 import os
 import sys
@@ -42,6 +42,8 @@ def main():
         mine = np.all(c // (np.array(dec.dim) - 2) == np.array(dec.coord), axis=1)
         s = GpuSystem(box, (1, 1, 1), dec.dim, 1, cellsz, 0.5, 0.1, device=0, global_cell_dim=dec.gdim, cpu_dim=cpu_dim,
                       my_coord=dec.coord, ttm_decomposed=True, count_ttm_neighbours=True)
+        if os.environ.get("TTM_REMOTE") == "0":
+            s.set_option("ttm_remote", 0)
         s.upload_tables(pair, rho, emb)
         ttm_mod.attach_default(s, fd_ext=(2, 2, 2), diff_substeps=100, fd_min_atoms=5)
         s.upload_atoms(pos[mine], mom[mine], 26.9815, None, ident[mine])
@@ -61,7 +63,7 @@ def main():
         s.close()
         return out
     res = group.run(body, timeout=600)
-    print(json.dumps(dict(cpu_dim=cpu_dim, atoms=len(pos), env_remote=os.environ.get("IMDGPU_TTM_REMOTE", "default"), ranks=res)))
+    print(json.dumps(dict(cpu_dim=cpu_dim, atoms=len(pos), env_remote=os.environ.get("TTM_REMOTE", "default"), ranks=res)))
     group.close()
 
 

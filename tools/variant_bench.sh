@@ -1,6 +1,7 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun): build a kernel variant of libimdgpu.so outside the tree and bench it.
 #   usage: tools/variant_bench.sh <name> "<EXTRA make flags>" "<env assignments>" [bench args...]
+#   (experiment switches of the environment need -DIMDGPU_EXPERIMENTS among the EXTRA flags; bench.py is told --allow-experiments)
 # Results: gpurun_out/variants/<name>.json (the bench line) ; the in-tree library is not touched.
 set -e -o pipefail
 NAME=$1; EXTRA=$2; ENVS=$3; shift 3
@@ -10,7 +11,7 @@ rm -rf "$W"; mkdir -p "$W/imd_amd" "$ROOT/gpurun_out/variants"
 cp -r "$ROOT/imd_amd/csrc" "$W/imd_amd/csrc"; cp -r "$ROOT/include" "$W/include"
 make -s -C "$W/imd_amd/csrc" clean
 make -s -C "$W/imd_amd/csrc" EXTRA="$EXTRA" libimdgpu.so 2> "$ROOT/gpurun_out/variants/$NAME.build.log"
-env $ENVS IMDGPU_LIB="$W/imd_amd/csrc/libimdgpu.so" timeout -k 10 400 python3 bench.py --no-cpu-baseline "$@" \
+env $ENVS IMDGPU_LIB="$W/imd_amd/csrc/libimdgpu.so" timeout -k 10 400 python3 bench.py --no-cpu-baseline --allow-experiments "$@" \
     > "$ROOT/gpurun_out/variants/$NAME.json" 2> "$ROOT/gpurun_out/variants/$NAME.err"
 python3 - "$ROOT/gpurun_out/variants/$NAME.json" "$NAME" <<'PY'
 import json, sys
