@@ -82,6 +82,11 @@ def parse():
     ap.add_argument("--halo-overlap", type=int, default=0,
                     help="several ranks (or --force-distributed): pass 1 of the next step starts on interior tiles while its\n"
                          "position halo travels on a stream of its own; the value = CUs the first launch leaves to the transport")
+    ap.add_argument("--rank-timeout", type=float, default=1500.0,
+                    help="watchdog: seconds a rank (and the parent of self-spawned ranks) gives the whole run before it writes its\n"
+                         "status, exits non-zero and the parent prints every rank's last status; 0 = off")
+    ap.add_argument("--status-dir", default=None, help=argparse.SUPPRESS)      # where the ranks leave their status files (set by the parent)
+    ap.add_argument("--hook-rank-hang", type=int, default=-1, help=argparse.SUPPRESS)     # test hook: this rank sleeps in the warm-up
     ap.add_argument("--hook-remote-fail", type=int, default=0, help=argparse.SUPPRESS)     # test hook: this rank (1-based) cannot set its ghost records up
     ap.add_argument("--allow-experiments", action="store_true",
                     help="run although the library was built with experiment macros (imdgpu_get_info(\"experiments\") != 0): the line\n"
@@ -421,20 +426,104 @@ def measured_traffic(kernel, natoms, kernel_rev):
     return None, None
 
 
+def measured_units(kernel, natoms, kernel_rev):
+    """What bounds the kernel besides HBM: busy fractions of the LDS array and of the vector ALUs during its launches, from the
+    committed SQ counter passes (tools/pmc_sq.sh -> profiles/*sq_counters*.json: lds_busy = SQ_LDS_IDX_ACTIVE / (CUs x cycles),
+    valu_busy = 4 x SQ_ACTIVE_INST_VALU / (SIMDs x cycles), cycles = GRBM_GUI_ACTIVE / 8 of the same launches).  Looked up like the
+    traffic: full kernel name, atoms per GPU and the library's kernel revision must match, else null."""
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*sq_counters*.json")), reverse=True):
+        try:
+            t = json.load(open(f))
+        except Exception:
+            continue
+        if t.get("_atoms_per_gpu") != natoms or t.get("_kernel_rev") != kernel_rev:
+            continue
+        for k, v in t.items():
+            if isinstance(v, dict) and k.replace("void ", "").startswith(kernel) and "valu_busy" in v and "lds_busy" in v:
+                return {"lds": v["lds_busy"], "valu": v["valu_busy"], "lds_bank_conflict_share": v.get("lds_conflict_share"),
+                        "clock_ghz": v.get("clock_ghz_a"), "avg_launch_ms_under_counters": v.get("avg_ns_a", 0) / 1e6,
+                        "source": os.path.relpath(f, ROOT)}
+    return None
+
+
+def _rank_status(args, rank, text):
+    """a rank's last known phase, one small file per rank (the parent prints them when the run times out or fails)"""
+    if args.status_dir:
+        try:
+            with open(os.path.join(args.status_dir, "rank%d.status" % rank), "w") as f:
+                f.write("%s at +%.1f s (pid %d)\n" % (text, time.time() - _T0, os.getpid()))
+        except OSError:
+            pass
+
+
+_T0 = time.time()
+
+
+def _arm_watchdog(args, rank):
+    """A rank that is still running after --rank-timeout seconds says where it is and ends the process with exit code 3 -- no re-exec,
+    no retry: torch.distributed.run then takes the other ranks down and the parent reports (a rank stuck in a collective or a device
+    wait cannot be unwound from Python; ending the process is the only exit every such state has)."""
+    if args.rank_timeout <= 0:
+        return None
+    import threading
+
+    def fire():
+        _rank_status(args, rank, "WATCHDOG: still running after %.0f s; last phase: %s" % (args.rank_timeout, _PHASE[0]))
+        sys.stderr.write("bench.py: rank %d watchdog fired after %.0f s in phase '%s'\n" % (rank, args.rank_timeout, _PHASE[0]))
+        sys.stderr.flush()
+        os._exit(3)
+    t = threading.Timer(args.rank_timeout, fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
+_PHASE = ["start"]
+
+
+def _phase(args, rank, text):
+    _PHASE[0] = text
+    _rank_status(args, rank, text)
+
+
 def _spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (this process has not
-    touched the GPU yet) through torch.distributed.run and relay rank 0's JSON line."""
+    touched the GPU yet) through torch.distributed.run and relay rank 0's JSON line.  The parent is the outer watchdog: when the
+    launcher has not returned --rank-timeout + 60 s after it started, its process group is killed; on any failure every rank's last
+    status goes to stderr and the exit code is non-zero."""
+    import signal
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    sdir = tempfile.mkdtemp(prefix="bench_status_")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
-    line = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
-    if line:
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:] + ["--status-dir", sdir]
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    timed_out = False
+    try:
+        out, _ = p.communicate(timeout=(args.rank_timeout + 60.0) if args.rank_timeout > 0 else None)
+    except subprocess.TimeoutExpired:
+        timed_out = True
+        try:
+            os.killpg(p.pid, signal.SIGKILL)          # the launcher and its ranks: the process group this parent created, nothing else
+        except OSError:
+            pass
+        out, _ = p.communicate()
+    line = [l for l in (out or "").splitlines() if l.startswith("{") and '"metric"' in l]
+    if line and p.returncode == 0 and not timed_out:
         print(line[-1])
     else:
-        sys.stdout.write(r.stdout)
-    raise SystemExit(r.returncode if r.returncode else (0 if line else 1))
+        sys.stdout.write(out or "")
+        sys.stderr.write("bench.py --gpus %d: %s (launcher exit code %s); last status of every rank:\n"
+                         % (args.gpus, "timed out" if timed_out else "failed", p.returncode))
+        for r in range(args.gpus):
+            try:
+                st = open(os.path.join(sdir, "rank%d.status" % r)).read().strip()
+            except OSError:
+                st = "no status file: the rank never got as far as parsing its arguments"
+            sys.stderr.write("  rank %d: %s\n" % (r, st))
+    import shutil
+    shutil.rmtree(sdir, ignore_errors=True)
+    raise SystemExit(0 if (line and p.returncode == 0 and not timed_out) else (p.returncode or 1))
 
 
 def main():
@@ -451,6 +540,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    _phase(args, rank, "started")
+    _arm_watchdog(args, rank)
     if args.gpus != world:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d, "
                          "or without a launcher)" % (args.gpus, world, args.gpus))
@@ -536,9 +627,21 @@ def main():
     else:
         sysm, md, natoms, gdim, cpu_dim = build_system(args, rank, world, local, decomposed=(mode == "decomposed"))
     do_step = md.md_step if md is not None else sysm.md_step
+    _phase(args, rank, "system built (%d atoms on %s), warm-up" % (natoms, sysm.device_identity()))
+    if args.hook_rank_hang == rank:
+        time.sleep(10 ** 6)
     while step < args.warmup:
         do_step(step); step += 1
     barrier()
+    _phase(args, rank, "timed region")
+    # who is who: every rank's GPU (PCI bus id, UUID) and what RCCL itself reports for the communicators the library created
+    ident = "rank %d: %s" % (rank, sysm.device_identity())
+    rccl_here = {"rccl_ranks": sysm.get_info("rccl_ranks"), "rccl_comms": sysm.get_info("rccl_comms"), "rccl_device": sysm.get_info("rccl_device")}
+    if dist.is_initialized():
+        idents, rccls = [None] * world, [None] * world
+        dist.all_gather_object(idents, ident); dist.all_gather_object(rccls, rccl_here)
+    else:
+        idents, rccls = [ident], [rccl_here]
     sysm.profile(not args.no_kernel_timing); sysm.profile_reset()
     nbl0 = sysm.get_sums()["nbl_count"]
     standin0 = sysm.get_info("p3_standin_passes")
@@ -547,6 +650,7 @@ def main():
         do_step(step); step += 1
     barrier()
     dt = time.perf_counter() - t0
+    _phase(args, rank, "timed region done, collecting results")
     if dist.is_initialized():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -611,7 +715,12 @@ def main():
             avg = ms / max(n, 1)
             a = byts / (avg * 1e-3) / 1e9 if n else 0.0
             tr, src = measured_traffic(kn, natoms, krev)
-            return {"bound": "hbm", "kernel": label, "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
+            un = measured_units(kn, natoms, krev)
+            if un is not None:
+                un = dict(un, hbm=a / HBM_PEAK_GBS,
+                          note="fractions of each unit's own peak during the kernel's launches: lds / valu = busy cycles of the LDS array / "
+                               "the vector ALUs (SQ counters of the same kernel revision), hbm = algorithmic bytes over the launch at 8 TB/s")
+            return {"bound": "hbm", "unit_busy": un, "kernel": label, "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
                     "traffic": tr, "traffic_source": src, "algorithmic_bytes_per_launch": byts, "avg_launch_ms": avg,
                     "launches": n, "kernel_rev": krev}
         lattice_note = ""
@@ -649,8 +758,13 @@ def main():
                        "tile_info": {k: sysm.get_info(k) for k in ("ntiles", "tile_cap", "slot_cap", "max_halo",
                                                                    "tile_threads", "lds_pass1", "lds_pass3", "W")},
                        "parallelism": ("%dx%dx%d ranks, 1 rank/GPU, direct 26-neighbour ghost-cell halo, native step (%s)%s"
-                                       % (tuple(cpu_dim) + (md.ops.transport, lattice_note))) if md is not None else "single GPU"},
-            "roofline": dom, "roofline_other": other, "experiments": sysm.get_info("experiments"),
+                                       % (tuple(cpu_dim) + (md.ops.transport, lattice_note))) if md is not None else "single GPU",
+                       # one entry per rank: PCI bus id, UUID, name of its GPU -- N ranks must show N different devices
+                       "devices": idents, "distinct_devices": len({i.split(": ", 1)[1].split(" ")[0] for i in idents})},
+            # what RCCL reports: the smallest ncclCommCount over the communicators the library created on any rank (0 = no RCCL
+            # communicator: single GPU without --force-distributed, or another transport), and that figure per rank
+            "rccl_ranks": min(r["rccl_ranks"] for r in rccls), "rccl": rccls,
+            "roofline": dom, "roofline_other": other, "roofline_unit": dom.get("unit_busy"), "experiments": sysm.get_info("experiments"),
             "kernel_ms_per_step": {k: v[1] / args.steps for k, v in prof.items() if v[0]},
             "rebuild_ms": {"rebuilds": rebuilds, "make_nblist_ms_each": ms_nbl / max(n_nbl, 1), "fix_cells_ms_each": ms_fix / max(n_fix, 1),
                            "amortised_ms_per_step": (ms_nbl + ms_fix) / args.steps},
@@ -665,6 +779,7 @@ def main():
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
+    _phase(args, rank, "done")
     sysm.close()
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -554,7 +554,7 @@ __global__ __launch_bounds__(512) void k_pass3_gt(ForceArgs a)
 // neighbour list holds 16-bit LDS slot numbers (4 per 8-byte load, ELL-transposed
 // per tile).  HBM sees: list (2 B/entry), own-atom outputs, one staging pass.
 // ===========================================================================
-#define IMDGPU_KERNEL_REV 10
+#define IMDGPU_KERNEL_REV 11
 #define LDS_LIMIT (160 * 1024)
 #define TABLE_LDS_LIMIT (150 * 1024)                 // global-gather kernels: tables beyond this stay in global memory
 #define NH_MAX 512                                   // halo cells per tile (<= 6*6*6 = 216 for tiles up to 4^3)
@@ -1945,7 +1945,9 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) __attribute__((amdgpu_waves_per_eu
           // lands one below pass 1's is covered by the guard's margin of one row
           r2[e] = fma(dz[e], dz[e], fma(dy[e], dy[e], dx[e] * dx[e]));
 #endif
-          const double q = fmax(fma(r2[e], istep, c0), 0.0);               // tab_index_fma without the sign (pass 1 reports is_short)
+          // tab_index_fma without the sign and without the clamp at 0: this kernel runs only when pass 1 has seen no pair below row
+          // klo + 1 >= 1 of this table (the guard above), so q >= 1 up to the roundings the guard's margin of one row covers
+          const double q = fma(r2[e], istep, c0);
           kr[e] = (int) q;
           ch[e] = __builtin_amdgcn_fract(q);
           kr[e] = (r2[e] < end) ? kr[e] : kz;                              // rho': r2 < end (imd_forces_nbl.c:868)
@@ -2392,6 +2394,7 @@ extern "C" int imdgpu_set_option(imdgpu_ctx *ctx, const char *name, int value)
   if (!strcmp(name, "p3_coef")) { ctx->p3_coef = value ? 1 : 0; return 0; }
   // tests, before upload_tables: pair_pot and rho_h_tab are kept apart even on a shared grid (the distinct-grids form of pass 1)
   if (!strcmp(name, "no_merge")) { ctx->no_merge = value ? 1 : 0; return 0; }
+  if (!strcmp(name, "df_halo_beside_head")) { ctx->df_halo_beside_head = value < 0 ? -1 : (value ? 1 : 0); return 0; }   // see imdgpu_dist_md_step
   if (!strcmp(name, "act_ranksort_max")) { ctx->act_ranksort_max = value; return 0; }       // test hook (do_cell_activation)
   if (!strcmp(name, "ttm_remote")) { ctx->ttm_remote_opt = value ? 1 : 0; return 0; }        // before the first multi-rank rebuild
   if (!strcmp(name, "ttm_remote_fail")) { ctx->ttm_remote_fail = value; return 0; }          // test hook
@@ -2483,6 +2486,7 @@ extern "C" int imdgpu_get_info(imdgpu_ctx *ctx, const char *name, long long *val
     {"ttm_persist_redone", imdgpu_ttm_persist_info(ctx, 3)},
     // EAM force passes so far in which the three-row kernel stood in for the coefficient form (as of the last md_step / calc_forces)
     {"p3_standin_passes", ctx->h_counters ? ctx->h_counters[CNT_P3_STANDIN] : 0},
+    {"rccl_ranks", imdgpu_dist_rccl_info(ctx, 0)}, {"rccl_comms", imdgpu_dist_rccl_info(ctx, 1)}, {"rccl_device", imdgpu_dist_rccl_info(ctx, 2)},
     {"halo_overlap_passes", ctx->dyn_seq}, {"halo_overlap_interior_tiles", ctx->dyn_ntiles == ctx->ntiles ? ctx->n_interior : -1}};       // pass-1 launch pairs under a position halo in flight (option halo_overlap)
   for (auto &e : tab) if (!strcmp(name, e.n)) { *value = e.v; return 0; }
   return imdgpu_fail(ctx, "unknown info %s", name);
@@ -2494,6 +2498,20 @@ extern "C" int imdgpu_device_count(int *n)
   if (hipGetDeviceCount(&c) != hipSuccess) c = 0;
   if (n) *n = c;
   return c > 0 ? 0 : 1;
+}
+
+// identity of the context's GPU as text: "<PCI bus id> uuid <hex> <name>, <CUs> CUs" -- what bench.py gathers from every rank
+extern "C" int imdgpu_device_identity(imdgpu_ctx *ctx, char *buf, int len)
+{
+  if (!buf || len < 1) return imdgpu_fail(ctx, "device_identity: no buffer");
+  hipDeviceProp_t p;
+  HIPCHK(hipGetDeviceProperties(&p, ctx->device));
+  char bus[64] = "?";
+  (void) hipDeviceGetPCIBusId(bus, sizeof(bus), ctx->device);
+  char uu[40]; int o = 0;
+  for (int q = 0; q < 16; q++) o += snprintf(uu + o, sizeof(uu) - o, "%02x", (unsigned) (unsigned char) p.uuid.bytes[q]);
+  snprintf(buf, (size_t) len, "%s uuid %s %s, %d CUs", bus, uu, p.name, p.multiProcessorCount);
+  return 0;
 }
 
 extern "C" int imdgpu_set_stream(imdgpu_ctx *ctx, void *s)

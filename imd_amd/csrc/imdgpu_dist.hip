@@ -47,6 +47,8 @@ struct RcclApi {
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+  ncclResult_t (*CommCuDevice)(const ncclComm_t, int *) = nullptr;
 };
 static RcclApi g_rccl;
 
@@ -61,6 +63,7 @@ static const char *rccl_load()
   SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
   SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv");
   SYM(AllReduce, "ncclAllReduce"); SYM(AllGather, "ncclAllGather"); SYM(GetErrorString, "ncclGetErrorString");
+  SYM(CommCount, "ncclCommCount"); SYM(CommCuDevice, "ncclCommCuDevice");
 #undef SYM
   g_rccl.h = h;
   return nullptr;
@@ -455,7 +458,13 @@ extern "C" int imdgpu_dist_md_step(imdgpu_ctx *ctx, int steps, int *rebuild_need
   }
   D->spec_pass1 = false; D->halo_ready = false;
   if (imdgpu_launch_forces_phase(ctx, 2)) return 1;
-  if (ctx->ttm && ctx->ttm_decomposed && !ctx->ttm1d) {
+  // Two RCCL communicators in flight at once with no fixed device order across ranks is safe only while both transport kernels are
+  // co-resident on every rank -- which no multi-GPU run has shown yet: on the RCCL transport with more than one rank the
+  // dF halo therefore stays IN FRONT of the fork (the order of the replicated lattice, below) unless option df_halo_beside_head = 1
+  // asks for the overlapped order; the other transports (in-process, host callback, a one-rank communicator) have no such hazard.
+  const bool head_first = ctx->ttm && ctx->ttm_decomposed && !ctx->ttm1d &&
+                          (ctx->df_halo_beside_head > 0 || (ctx->df_halo_beside_head < 0 && !(D->comm && D->nranks > 1)));
+  if (head_first) {
     // Decomposed lattice: the chain's head (update_fd, with do_ADV the do_COMMFLUX batch on the lattice stream's own
     // communicator) is forked FIRST and the dF halo runs beside it on the main stream -- between pass 1 and the EAM force pass
     // the chip is otherwise idle, so the halo's 8 bytes per ghost atom travel behind update_fd's 0.2 ms instead of in front
@@ -1383,4 +1392,27 @@ extern "C" int imdgpu_dist_init_local(imdgpu_ctx *ctx, void *group, int rank)
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipStreamCreateWithFlags(&M->s, hipStreamNonBlocking));
   return imdgpu_dist_init_callback(ctx, G->n, rank, local_exchange, M);
+}
+
+
+// What RCCL itself says about the communicators this context created (bench.py prints it, so that "did RCCL see N ranks on N
+// devices" is in the line): which = 0 -> the SMALLEST ncclCommCount over the communicators (0: none was created: another transport),
+// 1 -> how many communicators exist, 2 -> the HIP device ncclCommCuDevice reports for the main one (-1: none)
+long long imdgpu_dist_rccl_info(imdgpu_ctx *ctx, int which)
+{
+  DistState *D = (DistState *) ctx->dist;
+  if (!D) return which == 2 ? -1 : 0;
+  ncclComm_t cs[3] = {D->comm, D->comm2, D->comm3};
+  int n = 0, mn = 0;
+  for (ncclComm_t c : cs) {
+    if (!c) continue;
+    int cnt = 0;
+    if (g_rccl.CommCount && g_rccl.CommCount(c, &cnt) == ncclSuccess) mn = n == 0 ? cnt : (cnt < mn ? cnt : mn);
+    n++;
+  }
+  if (which == 0) return mn;
+  if (which == 1) return n;
+  int dev = -1;
+  if (D->comm && g_rccl.CommCuDevice && g_rccl.CommCuDevice(D->comm, &dev) != ncclSuccess) dev = -1;
+  return dev;
 }

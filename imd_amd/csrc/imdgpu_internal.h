@@ -82,6 +82,7 @@ struct imdgpu_ctx {
   int act_ranksort_max = 1024;    // option "act_ranksort_max" (test hook): above this many simultaneous fallback activations the ordered walk replaces the rank sort
   int ttm_remote_opt = 1;         // option "ttm_remote": 0 keeps the host mailbox for the decomposed lattice's faces
   int ttm_remote_fail = 0;        // option "ttm_remote_fail" (test hook): rank + 1 that pretends it cannot set the remote records up
+  int df_halo_beside_head = -1;   // option: decomposed lattice, dF halo beside the chain's head (1), in front of the fork (0), by transport (-1)
   int no_merge = 0;               // option "no_merge" (tests, before upload_tables): keep the tables apart even on a shared grid
   int p3_coef = 1;                // option "p3_coef": 0 keeps k_pass3_tile for every step
   int p3_klo = 0;                 // option "p3_klo" (tests): keep at least this many of the lowest rows out of the LDS
@@ -286,4 +287,5 @@ int imdgpu_ttm_persist_settle(imdgpu_ctx *ctx);            // 0 nothing, 1 the s
 const int *imdgpu_ttm_persist_guard(imdgpu_ctx *ctx);      // status word a guarded integrator looks at, or null
 long long imdgpu_ttm_persist_info(imdgpu_ctx *ctx, int which);
 void imdgpu_dist_free(imdgpu_ctx *ctx);
+long long imdgpu_dist_rccl_info(imdgpu_ctx *ctx, int which);
 void imdgpu_dist_cancel_ahead(imdgpu_ctx *ctx);

@@ -24,7 +24,7 @@ SYMBOLS = [
     "imdgpu_ttm_cell_activation", "imdgpu_ttm_fillmesh", "imdgpu_ttm_fill_ghost_layers", "imdgpu_ttm_diff",
     "imdgpu_ttm_cfl_maxdt", "imdgpu_calc_ttm", "imdgpu_move_atoms_ttm", "imdgpu_ttm_eos_te_from_r_ee", "imdgpu_ttm_eos_lookup", "imdgpu_ttm_set_eos_triangulation", "imdgpu_eos_triangulation",
     "imdgpu_get_cell_tables", "imdgpu_upload_ghosts", "imdgpu_update_ghosts", "imdgpu_device_count", "imdgpu_autotile", "imdgpu_set_ghost_layout", "imdgpu_halo_gather", "imdgpu_halo_gather2", "imdgpu_halo_scatter",
-    "imdgpu_migrate_scan", "imdgpu_migrate_gather", "imdgpu_migrate_apply", "imdgpu_forces_phase", "imdgpu_integrate",
+    "imdgpu_migrate_scan", "imdgpu_migrate_gather", "imdgpu_migrate_apply", "imdgpu_forces_phase", "imdgpu_integrate", "imdgpu_device_identity",
     "imdgpu_get_invalid", "imdgpu_invalidate", "imdgpu_ttm_local_block", "imdgpu_ttm_apply_blocks",
     "imdgpu_ttm_lattice_step", "imdgpu_ttm_mailbox_bytes", "imdgpu_ttm_mailbox_attach", "imdgpu_ttm_local_step",
     "imdgpu_host_alloc", "imdgpu_host_free",
@@ -260,6 +260,7 @@ def load():
     L.imdgpu_migrate_apply.argtypes = [vp, vp, C.c_int, vp, C.c_int]
     L.imdgpu_forces_phase.argtypes = [vp, C.c_int]
     L.imdgpu_integrate.argtypes = [vp]
+    L.imdgpu_device_identity.argtypes = [vp, C.c_char_p, C.c_int]
     L.imdgpu_get_invalid.argtypes = [vp, ip]
     L.imdgpu_invalidate.argtypes = [vp]
     L.imdgpu_ttm_local_block.argtypes = [vp, C.c_int, vp, ip]

@@ -113,6 +113,11 @@ class GpuSystem:
         self._ck(self.L.imdgpu_get_info(self.h, name.encode(), C.byref(v)))
         return v.value
 
+    def device_identity(self):
+        buf = C.create_string_buffer(256)
+        self._ck(self.L.imdgpu_device_identity(self.h, buf, 256))
+        return buf.value.decode()
+
     def synchronize(self):
         self._ck(self.L.imdgpu_synchronize(self.h))
 

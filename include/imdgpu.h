@@ -427,6 +427,9 @@ int imdgpu_migrate_apply(imdgpu_ctx *ctx, const void *dev_in_lo, int n_in_lo, co
  * phase 1 = pair + rho pass, 2 = embedding pass, 3 = EAM force pass + sums (calc_forces, imd_forces_nbl.c).
  * With one atom type and pair/rho tables on one grid the embedding pass runs inside phase 1 (get_info
  * "fused_embedding"): F'(rho) of the local atoms is complete after phase 1, phase 2 then only refreshes periodic images. */
+/* Identity of the context's GPU as text ("<PCI bus id> uuid <hex> <name>, <n> CUs"): what a multi-rank host prints so that a reader
+ * sees N ranks on N different devices (no counterpart in the reference, which has no devices; cf. its rank banner, imd.c:80-90). */
+int imdgpu_device_identity(imdgpu_ctx *ctx, char *buf, int len);
 int imdgpu_forces_phase(imdgpu_ctx *ctx, int phase);
 int imdgpu_integrate(imdgpu_ctx *ctx);                 /* move_atoms_{nve|ttm} + displacement check */
 int imdgpu_get_invalid(imdgpu_ctx *ctx, int *flag);    /* check_nblist result of this rank (synchronises) */

@@ -83,3 +83,125 @@ def test_bench_nccl_code_path_on_one_rank():
     env = dict({k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}, IMDGPU_DIST_SELF_COMM="1")
     d = _one_json_line(subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600))
     assert d["n_gpus"] == 1 and "(rccl)" in d["config"]["parallelism"] and d["value"] > 0
+
+
+# ---- the bench modes README / DESIGN quote numbers for: each on a small box, one JSON line, the contract
+# fields, and the kernels the mode is supposed to run ---------------------------------------------------------------------------
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline", "roofline_other", "kernel_ms_per_step", "rebuild_ms", "experiments")
+
+
+def _mode(flags, box=(32, 32, 32), steps=10, warmup=4, env=None, timeout=600):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--box"] + [str(b) for b in box] + ["--steps", str(steps), "--warmup", str(warmup),
+                                                                                              "--no-cpu-baseline"] + list(flags)
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    e.update(env or {})
+    d = _one_json_line(subprocess.run(cmd, cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout))
+    for k in CONTRACT:
+        assert k in d, k
+    assert d["value"] > 0 and d["experiments"] == 0 and d["steps"] == steps and d["n_gpus"] == 1
+    assert d["unit"] == "MD-steps/s" and d["dtype"] == "f64" and "workload" in d["config"]
+    return d
+
+
+def test_bench_mode_slab():
+    """config 4's geometry on one GPU: open x with vacuum; the persistent sub-step kernel on the filled layers + coefficient force pass"""
+    d = _mode(["--slab"])
+    assert "slab: open x" in d["config"]["workload"] and d["config"]["cells"][0] > d["config"]["cells"][1]
+    assert d["config"]["kernel_family"] == "lds_tiles"
+    names = d["roofline"]["kernel"] + d["roofline_other"]["kernel"]
+    assert "k_pass1_tile_merged<true, true" in names and "k_pass3_tile_coef" in names
+    assert "ttm_diff" in d["kernel_ms_per_step"]
+
+
+@pytest.mark.parametrize("dl", [False, True])
+def test_bench_mode_maxwell_solver(dl):
+    """config 5: the 1D Maxwell solver as laser source on a slab (one row of FD cells); --dl-tables: fitDL from tricubic tables"""
+    d = _mode(["--laser", "fdtd"] + (["--dl-tables"] if dl else []), steps=8, warmup=4)
+    w = d["config"]["workload"]
+    assert "1D Maxwell solver" in w and ("fitDL from tricubic tables" in w) == dl and "do_ADV off" in w
+    assert d["kernel_ms_per_step"]["ttm_diff"] > 0                    # the solver + diffusion loop ran in the timed region
+    assert "k_pass3_tile" in d["roofline"]["kernel"] + d["roofline_other"]["kernel"]
+
+
+def test_bench_mode_halo_overlap_on_one_rank():
+    """pass 1 from a tile queue in two launches under the position halo (option halo_overlap), one rank with all 26 segments
+    through RCCL; the line says how many passes took the queue form"""
+    d = _mode(["--halo-overlap", "8", "--force-distributed", "--init-dist", "--backend", "nccl"], env=dict(IMDGPU_DIST_SELF_COMM="1"))
+    p = d["config"]["parallelism"]
+    assert "(rccl)" in p and "position halo under interior tiles of pass 1" in p
+    assert "true, false>" in d["roofline"]["kernel"] + d["roofline_other"]["kernel"]            # k_pass1_tile_merged<.., DYN = true, DG = false>
+    assert d["kernel_ms_per_step"].get("pass1b", 0) > 0
+
+
+def test_bench_mode_decomposed_lattice_on_one_rank():
+    d = _mode(["--ttm-lattice", "decomposed", "--force-distributed"], env=dict(IMDGPU_DIST_SELF_COMM="1"))
+    p = d["config"]["parallelism"]
+    assert "native step" in p and "TTM lattice decomposed" in p and "1x1x1 ranks" in p
+
+
+def test_bench_mode_distinct_grids():
+    """one atom type, phi / rho / F on three different grids: the distinct-grids pass 1, the coefficient force pass on rho's grid"""
+    d = _mode(["--tables", "distinct"])
+    assert "three different grids" in d["config"]["workload"]
+    names = d["roofline"]["kernel"] + " " + d["roofline_other"]["kernel"]
+    assert "false, true>" in names and "k_pass3_tile_coef" in names                              # k_pass1_tile_merged<.., DYN = false, DG = true>
+
+
+def test_bench_mode_two_types():
+    """two atom types with full-size tables (2 x 4 columns x 4002 rows): the record kernels of the tile family, no global gather"""
+    d = _mode(["--types", "2"])
+    assert "TWO atom types" in d["config"]["workload"] and d["config"]["kernel_family"] == "lds_tiles"
+    names = d["roofline"]["kernel"] + " " + d["roofline_other"]["kernel"]
+    assert "k_pass1_tile_rec<true" in names and "k_pass3_tile_rec<" in names
+    assert "pass2" not in d["kernel_ms_per_step"]                     # the embedding pass is folded into pass 1
+
+
+def test_bench_reports_rccl_ranks_and_devices():
+    """what RCCL itself says (ncclCommCount of every communicator the library created) and every rank's GPU
+    (PCI bus id, UUID) are in the line -- here one rank with every message through RCCL: rccl_ranks 1 on one device; without the
+    multi-rank layer no communicator exists and rccl_ranks is 0"""
+    d = _mode(["--force-distributed", "--init-dist", "--backend", "nccl"], env=dict(IMDGPU_DIST_SELF_COMM="1"))
+    assert d["rccl_ranks"] == 1 and d["rccl"][0]["rccl_comms"] >= 2 and d["rccl"][0]["rccl_device"] == 0
+    assert len(d["config"]["devices"]) == 1 and "uuid" in d["config"]["devices"][0] and d["config"]["distinct_devices"] == 1
+    d0 = _mode([])
+    assert d0["rccl_ranks"] == 0 and d0["config"]["devices"][0].startswith("rank 0: ")
+
+
+def test_transports_run_between_the_persistent_launches():
+    """the default multi-rank step issues every transport (dF halo, lattice exchange, position halo, flag
+    all-reduce) on the main stream BETWEEN the persistent force launches, or on the lattice stream in front of an event the
+    force pass waits for -- no RCCL kernel ever has to be placed beside a pass that holds every CU.  Asserted on the device
+    clock (IMDGPU_TIMELINE marks of a one-rank run with every message through RCCL): begin <= pass1 <= pass2 <= dF_halo <=
+    pass3 <= move <= halo+flag+pass1ahead in every step, and the mark set is exactly the documented one."""
+    import re
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-distributed", "--init-dist", "--backend", "nccl", "--ttm-lattice", "decomposed",
+           "--box", "24", "24", "24", "--steps", "6", "--warmup", "3", "--no-cpu-baseline"]
+    env = dict({k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}, IMDGPU_DIST_SELF_COMM="1", IMDGPU_TIMELINE="1")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    _one_json_line(r)
+    steps = [l for l in r.stderr.splitlines() if l.startswith("[imdgpu timeline] step")]
+    assert len(steps) >= 6
+    order = ["begin", "pass1", "pass2", "dF_halo", "pass3", "move", "halo+flag+pass1ahead"]
+    seen = 0
+    for l in steps:
+        marks = dict((k, float(v)) for k, v in re.findall(r"(\S+)=([0-9.]+)", l))
+        if "dF_halo" not in marks:
+            continue                                   # a step that began with a rebuild prints the rebuild's marks
+        seen += 1
+        ts = [marks[k] for k in order if k in marks]
+        assert ts == sorted(ts), l
+        assert marks["dF_halo"] <= marks["pass3"] and marks["move"] <= marks["halo+flag+pass1ahead"], l
+    assert seen >= 3
+
+
+def test_bench_watchdog_reports_a_rank_that_hangs():
+    """a rank that never arrives (test hook: rank 1 sleeps in front of the warm-up) -- every rank's watchdog
+    ends its process with a status, nothing is re-executed, the parent exits non-zero and prints each rank's last phase"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--backend", "gloo", "--box", "16", "16", "16",
+           "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--ttm-lattice", "replicated", "--hook-rank-hang", "1", "--rank-timeout", "45"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=400)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert "last status of every rank" in r.stderr and "rank 1: WATCHDOG" in r.stderr and "warm-up" in r.stderr
