@@ -209,7 +209,12 @@ __global__ void k_gather_sorted(int n, int cap, const int *perm, const int *keys
   p2[i] = p[s]; p2[cap + i] = p[cap + s]; p2[2 * (size_t) cap + i] = p[2 * (size_t) cap + s];
   int k = keys[i];
   acell[i] = k;
-  atomicAdd(&icnt[k], 1);
+  // atoms per key: the keys are sorted, so a key's atoms are one run of consecutive threads -- its first thread subtracts its own
+  // index, its last one adds the index behind it: two atomics per key instead of one per atom (a cell's ~21 atoms adding to ONE
+  // word serialise in the L2's atomic unit: the kernel took 0.70 ms at 10 M atoms, most of it waiting for those)
+  const int kp = i > 0 ? keys[i - 1] : -1, kn = i + 1 < n ? keys[i + 1] : -1;
+  if (kp != k) atomicSub(&icnt[k], i);
+  if (kn != k) atomicAdd(&icnt[k], i + 1);
 }
 
 // cell key -> linear index in the ghost-including cell array
