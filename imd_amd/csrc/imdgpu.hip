@@ -9,6 +9,7 @@
 // r2 = dx*dx+dy*dy+dz*dz, makros.h:361); only summation ORDER differs from the
 // reference (full-list gather instead of half-list scatter).
 #include "imdgpu_internal.h"
+#include <chrono>
 
 #include <hipcub/hipcub.hpp>
 
@@ -3725,8 +3726,16 @@ extern "C" int imdgpu_md_step_begin(imdgpu_ctx *ctx, int steps)
   HIPCHK(hipSetDevice(ctx->device));
   imdgpu_tl_mark(ctx, "begin");
   if (!ctx->have_valid_nbl) {
+    static const bool rt = cfg_env("IMDGPU_REBUILD_TIMING") != nullptr;     // diagnostics: host wall clock of a rebuild's two halves
+    const auto t0 = std::chrono::steady_clock::now();
     if (ctx->need_fix_cells && imdgpu_fix_cells(ctx)) return 1;
+    const auto t1 = std::chrono::steady_clock::now();
     if (imdgpu_make_nblist(ctx)) return 1;
+    if (rt) {
+      const auto t2 = std::chrono::steady_clock::now();
+      fprintf(stderr, "[imdgpu rebuild] step %d: fix_cells %.3f ms, make_nblist %.3f ms (host wall clock, synchronisations included)\n", steps,
+              std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count());
+    }
   } else if (imdgpu_fill_ghosts(ctx)) return 1;
   imdgpu_tl_mark(ctx, "list");
   if (!ctx->rho.present && zero_eam_partials(ctx)) return 1;
