@@ -12,8 +12,8 @@ from oracle import pyoracle as po
 pytestmark = pytest.mark.gpu
 
 
-def _case(nb, a, pbc=(1, 1, 1), jitter=0.05, vacuum=0.0, seed=1):
-    pair, rho, emb, r2cut = potential.synthetic_eam_tables()
+def _case(nb, a, pbc=(1, 1, 1), jitter=0.05, vacuum=0.0, seed=1, grids="shared"):
+    pair, rho, emb, r2cut = potential.synthetic_eam_tables(grids=grids)
     cellsz = (np.sqrt(r2cut) + 0.5) ** 2
     box = lattice.fcc_box(nb, a)
     pos = lattice.fcc_positions(nb, a)
@@ -70,11 +70,12 @@ CASES = {
 }
 
 
+@pytest.mark.parametrize("grids", ["shared", "distinct"])
 @pytest.mark.parametrize("name", list(CASES))
-def test_edge_case_both_families_vs_oracle(name):
+def test_edge_case_both_families_vs_oracle(name, grids):
     k = dict(CASES[name])
     cap = k.pop("cap")
-    c = _case(**k)
+    c = _case(grids=grids, **k)
     fo, ro, eo = _oracle(c, cap)
     scale = np.abs(fo).max()
     for mode in (0, 1):
@@ -87,13 +88,17 @@ def test_edge_case_both_families_vs_oracle(name):
             assert info["W"] > 96 and info["tile_cap"] >= 64
 
 
+@pytest.mark.parametrize("grids", ["shared", "distinct"])
 @pytest.mark.parametrize("dist,short", [(1.2, 1), (1.6, 0)])
-def test_a_pair_far_inside_the_first_shell(dist, short):
+def test_a_pair_far_inside_the_first_shell(dist, short, grids):
     """Two atoms at 1.2 A: below the first table row (r_begin = 1.5 A) -- PAIR_INT2 clamps the argument and raises is_short
     (potaccess.h:331, imd_forces_nbl.c:673,986-993).  At 1.6 A: inside the table, but below the rows the coefficient form of
     the EAM force pass keeps in LDS (r < 1.71 A with the 4000-row table and 3136 slots), so that step is the three-row kernel's.
     Forces, densities, energy against the oracle either way; the flag as the reference sets it."""
-    c = _case((12, 12, 12), 4.05, jitter=0.02, seed=3)
+    # (distinct grids: rho_h_tab begins at 1.7 A, so the 1.6 A pair raises is_short through the DENSITY look-up alone)
+    if grids == "distinct" and dist == 1.6:
+        short = 1
+    c = _case((12, 12, 12), 4.05, jitter=0.02, seed=3, grids=grids)
     c["pos"][1] = c["pos"][0] + np.array([dist, 0.0, 0.0])
     o = po.OracleSystem(c["dim"], 64, 1, c["box"], c["pbc"], c["cellsz"], 0.5, 0.1)
     for w, t in enumerate(c["tabs"]):
@@ -111,7 +116,7 @@ def test_a_pair_far_inside_the_first_shell(dist, short):
         s.upload_atoms(c["pos"], c["mom"], 26.9815)
         r = s.calc_forces(0)
         d = s.download(fields=("kraft", "nummer", "eam_rho"))
-        if mode == 1:
+        if mode == 1 and grids == "shared":
             assert s.get_info("p3_coef_klo") > 31, "the 1.6 A pair must lie below the rows held in LDS for this test to mean anything"
         s.close()
         k = np.argsort(d["nummer"])
@@ -240,3 +245,63 @@ def test_restrictions_scale_the_forces_in_the_integrator():
         if restr[1] == 0.0:
             assert np.abs(d["kraft"][:, 1]).max() == 0.0          # written back scaled
         g.close(); o.close()
+
+
+def _two_type_case(seed=5):
+    """Cu3Au (L1_2) decoration, the full-size two-type tables (4 columns each with its own begin / end / step / rows)"""
+    import os
+    import tempfile
+    nb, a = (12, 12, 12), 4.05
+    with tempfile.TemporaryDirectory() as d:
+        potential.write_synthetic_eam_files_2types(d)
+        pair, c1 = potential.read_pot_table(os.path.join(d, "phi.pt"), 4, True)
+        rho, c2 = potential.read_pot_table(os.path.join(d, "rho.pt"), 4, True)
+        emb, _ = potential.read_pot_table(os.path.join(d, "F.pt"), 2, False)
+    cellsz = (np.sqrt(max(c1, c2)) + 0.5) ** 2
+    box = lattice.fcc_box(nb, a)
+    pos = lattice.fcc_positions(nb, a)
+    half = np.rint(pos / (a / 2.0) - 0.5).astype(np.int64)
+    sorte = np.all(half % 2 == 0, axis=1).astype(np.int32)
+    rng = np.random.default_rng(seed)
+    pos = pos + rng.normal(scale=0.04, size=pos.shape)
+    masse = np.where(sorte == 1, 63.546, 26.9815)
+    mom = lattice.maxwell_momenta(len(pos), 1.0, 0.03, seed=seed) * np.sqrt(masse)[:, None]
+    dim = [g + 2 for g in global_cell_dim(box, cellsz)]
+    return dict(box=box, pos=pos, mom=mom, masse=masse, sorte=sorte, dim=dim, cellsz=cellsz, tabs=(pair, rho, emb))
+
+
+@pytest.mark.parametrize("dist", [None, 1.55, 1.2])
+def test_two_types_record_kernels_and_global_gather_vs_oracle(dist):
+    """Two atom types, tables beyond the LDS: the record kernels of the tile family (k_pass1_tile_rec / k_pass3_tile_rec) and the
+    global-gather family against the oracle -- also with a pair of unlike atoms at 1.55 A (above pair_pot.begin of column 0, BELOW
+    that of the mixed columns, 1.6 A: is_short through the per-column begin, the argument clamped per column, potaccess.h:331) and
+    at 1.2 A (below every column)."""
+    c = _two_type_case()
+    if dist is not None:
+        i = int(np.nonzero(c["sorte"] == 1)[0][3])
+        j = int(np.nonzero(c["sorte"] == 0)[0][5])
+        c["pos"][j] = c["pos"][i] + np.array([0.0, dist, 0.0])
+    o = po.OracleSystem(c["dim"], 64, 2, c["box"], (1, 1, 1), c["cellsz"], 0.5, 0.1)
+    for w, t in enumerate(c["tabs"]):
+        o.set_table(w, t.as_dict())
+    o.fill_from_positions(c["pos"] % np.diag(c["box"]), c["mom"], c["masse"], c["sorte"])
+    o.calc_forces(0)
+    idn = np.argsort(o.gather_inner("nummer"))
+    fo, ro, eo = o.gather_inner("kraft")[idn], o.gather_inner("rho")[idn], o.gather_inner("pot_eng")[idn]
+    assert o.s.is_short == (0 if dist is None else 1)
+    for mode in (0, 1):
+        s = GpuSystem(c["box"], (1, 1, 1), c["dim"], 2, c["cellsz"], 0.5, 0.1)
+        s.set_option("mode", mode)
+        s.upload_tables(*c["tabs"])
+        s.upload_atoms(c["pos"], c["mom"], c["masse"], c["sorte"])
+        r = s.calc_forces(0)
+        assert (s.get_info("list_mode"), s.get_info("pass1_form")) == ((1, 3) if mode else (0, 0))
+        d = s.download(fields=("kraft", "nummer", "eam_rho", "pot_eng"))
+        s.close()
+        k = np.argsort(d["nummer"])
+        assert r["is_short"] == o.s.is_short, mode
+        assert np.abs(d["kraft"][k] - fo).max() < 1e-9 * np.abs(fo).max(), mode
+        assert np.abs(d["eam_rho"][k] - ro).max() < 1e-11 * np.abs(ro).max()
+        assert np.abs(d["pot_eng"][k] - eo).max() < 1e-11 * np.abs(eo).max()
+        assert abs(r["tot_pot_energy"] - o.s.tot_pot_energy) < 1e-11 * abs(o.s.tot_pot_energy)
+        assert abs(r["virial"] - o.s.virial) < 1e-10 * abs(o.s.virial)
