@@ -2655,10 +2655,12 @@ static int autotile(imdgpu_ctx *ctx)
     if (score > bestscore) { bestscore = score; best[0] = bx; best[1] = by; best[2] = bz; }
     cands.push_back({score, {bx, by, bz}});
   }
-  // shapes within 3 % of the best score are equivalent by this model: among them thin in x (the slowest index), then long in
-  // z, then in y -- measured on a 10 M-atom slab: 2x4x4 6.87 ms per step, 4x2x4 (same score) 8.59
+  // shapes within 6 % of the best score are equivalent by this model: among them thin in x (the slowest index), then long in
+  // z, then in y -- measured on a 10 M-atom slab: 2x4x4 6.87 ms per step, 4x2x4 (same score) 8.59; on the Maxwell-solver slab
+  // (148 x 78 x 78 cells: 4x2x4 divides evenly and scores 5 % above 2x4x4, whose last tiles along y and z are half empty)
+  // 2x4x4 7.20 against 7.47 ms per step
   for (const Cand &c : cands)
-    if (c.score >= 0.97 * bestscore) {
+    if (c.score >= 0.94 * bestscore) {
       const bool better = c.b[0] != best[0] ? c.b[0] < best[0] : (c.b[2] != best[2] ? c.b[2] > best[2] : c.b[1] > best[1]);
       if (better) { best[0] = c.b[0]; best[1] = c.b[1]; best[2] = c.b[2]; }
     }
