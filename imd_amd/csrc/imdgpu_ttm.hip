@@ -3489,11 +3489,13 @@ extern "C" int imdgpu_ttm_fdtd_substeps(imdgpu_ctx *ctx, double t_SI, int nsub, 
   HIPCHK(hipMalloc((void **) &row, F.nx * sizeof(double)));
   HIPCHK(hipMemsetAsync(row, 0, F.nx * sizeof(double), ctx->stream));
   const int npre = nsub <= 4096 ? nsub : 0;               // source terms evaluated ahead (LDS: 16 bytes per step)
-#define FD_BARE(MT) hipLaunchKernelGGL((k_ttm_fdtd_chain<false, MT>), dim3(1), dim3(thr), (4 * F.nx + F.nx / 2 + 2 + 2 + 2 * npre) * sizeof(double), ctx->stream, L, F, nsub, 0, \
+  // rows of ~1000 cells with thousands of steps evaluated ahead need more than the 64 KB a launch gets by default
+#define FD_BARE(MT) HIPCHK(hipFuncSetAttribute((const void *) k_ttm_fdtd_chain<false, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ((4 * F.nx + F.nx / 2 + 2 + 2 + 2 * npre) * sizeof(double)))); \
+  hipLaunchKernelGGL((k_ttm_fdtd_chain<false, MT>), dim3(1), dim3(thr), (4 * F.nx + F.nx / 2 + 2 + 2 + 2 * npre) * sizeof(double), ctx->stream, L, F, nsub, 0, \
                      t_SI, tau_FDTD, 0.0, 1, laser_timefun, 1, t->natoms, (double *) nullptr, (double *) nullptr, (double *) nullptr, \
                      (double *) nullptr, (double *) nullptr, (double *) nullptr, (double *) nullptr, (const double *) nullptr, row, \
                      (const double *) nullptr, (double *) nullptr, (double *) nullptr, (double *) nullptr, t->cve, t->ee, (double *) nullptr, npre)
-  if (thr <= 256) FD_BARE(256); else FD_BARE(1024);
+  if (thr <= 256) { FD_BARE(256); } else { FD_BARE(1024); }
 #undef FD_BARE
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -3523,11 +3525,12 @@ static int fdtd_lattice_loop(imdgpu_ctx *ctx, TtmState *t, const Lat &L, int ste
   t->laser_active = active;
   ProfScope ps(ctx, PROF_TTM_DIFF);
   const int npre = nsub <= 4096 ? nsub : 0;
-#define FD_LOOP(MT) hipLaunchKernelGGL((k_ttm_fdtd_chain<true, MT>), dim3(1), dim3(thr), (4 * F.nx + F.nx / 2 + 2 + 2 + 2 * npre) * sizeof(double), ctx->stream, L2, F, nsub, ndiff, \
+#define FD_LOOP(MT) HIPCHK(hipFuncSetAttribute((const void *) k_ttm_fdtd_chain<true, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ((4 * F.nx + F.nx / 2 + 2 + 2 + 2 * npre) * sizeof(double)))); \
+  hipLaunchKernelGGL((k_ttm_fdtd_chain<true, MT>), dim3(1), dim3(thr), (4 * F.nx + F.nx / 2 + 2 + 2 + 2 * npre) * sizeof(double), ctx->stream, L2, F, nsub, ndiff, \
                      S->t_SI, tau_f, tau_d, active, timefun, steps, t->natoms, t->temp[t->cur], t->temp[t->cur ^ 1], t->U[t->cur], \
                      t->U[t->cur ^ 1], t->fd_k[t->kcur], t->Ce, t->fd_g, t->md_temp, t->source, t->dens, t->xi, t->Z, t->ne, t->cve, \
                      t->ee, t->d_eabs, npre)
-  if (thr <= 256) FD_LOOP(256); else FD_LOOP(1024);
+  if (thr <= 256) { FD_LOOP(256); } else { FD_LOOP(1024); }
 #undef FD_LOOP
   HIPCHK(hipGetLastError());
   S->t_SI += nsub * tau_f;
