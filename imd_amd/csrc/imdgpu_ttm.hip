@@ -1049,9 +1049,14 @@ __global__ __launch_bounds__(DT_X *DT_Y *DT_Z) void k_ttm_diff(
   if (run_if && *run_if == 0) return;
   // flags: 1 = store Z and ne (diagnostic fields nothing in the sub-step loop reads: only the last sub-step of an MD
   // step has to), 2 = there is a source term to read.  A large (replicated) lattice is bound by its bytes per cell.
-  __shared__ double sT[DT_X + 2][DT_Y + 2][DT_Z + 2];
-  __shared__ double sK[DT_X + 2][DT_Y + 2][DT_Z + 2];
-  __shared__ int sN[DT_X + 2][DT_Y + 2][DT_Z + 2];
+  // NOLDS (the fused single-rank chain, <true, true>): no LDS tile -- every thread reads its six neighbours where they are (the
+  // lattice is cache resident: 168 B per cell, L1 / L2 hits).  A kernel without LDS can sit beside the coefficient form of the EAM
+  // force pass, which fills the CU's 160 KB: lattices too large for the persistent kernel (80 M atoms on one GPU: 4.7e5 FD cells)
+  // then keep that force pass (imdgpu_ttm_chain_needs_lds).  Same values from the same cells: same bits as the tiled form.
+  constexpr bool NOLDS = FUSE_MESH && WRAP;
+  __shared__ double sT[NOLDS ? 1 : DT_X + 2][NOLDS ? 1 : DT_Y + 2][NOLDS ? 1 : DT_Z + 2];
+  __shared__ double sK[NOLDS ? 1 : DT_X + 2][NOLDS ? 1 : DT_Y + 2][NOLDS ? 1 : DT_Z + 2];
+  __shared__ int sN[NOLDS ? 1 : DT_X + 2][NOLDS ? 1 : DT_Y + 2][NOLDS ? 1 : DT_Z + 2];
   // chain of tiny launches sharing the CUs with the force passes.  Raising the wave priority (1..3, all the same)
   // finishes the chain in 1.4 ms instead of 2.2 but costs the EAM force pass 0.22 ms: measured best is NOT to raise it
   // (180 vs 177 steps/s); IMDGPU_TTM_PRIO keeps the experiment available.
@@ -1062,10 +1067,9 @@ __global__ __launch_bounds__(DT_X *DT_Y *DT_Z) void k_ttm_diff(
   const int nbz = (L.dim[2] - 2 + DT_Z - 1) / DT_Z, nby = (L.dim[1] - 2 + DT_Y - 1) / DT_Y;
   const int bz = blockIdx.x % nbz, by = (blockIdx.x / nbz) % nby, bx = blockIdx.x / (nbz * nby);
   const int i0 = bx * DT_X, j0 = by * DT_Y, k0 = bz * DT_Z;     // tile origin in ghost-including coordinates
-  for (int s = threadIdx.x; s < (DT_X + 2) * (DT_Y + 2) * (DT_Z + 2); s += blockDim.x) {
-    int lz = s % (DT_Z + 2), ly = (s / (DT_Z + 2)) % (DT_Y + 2), lx = s / ((DT_Z + 2) * (DT_Y + 2));
-    int gi = i0 + lx, gj = j0 + ly, gk = k0 + lz;
-    double t = 0, kk = 0; int n = 0;
+  // one cell of the (ghost-including) lattice as the stencil sees it: ghost-shell cells resolved on the fly when WRAP
+  auto cell_of = [&](int gi, int gj, int gk, double &t, double &kk, int &n) {
+    t = 0; kk = 0; n = 0;
     if (gi < L.dim[0] && gj < L.dim[1] && gk < L.dim[2]) {
       bool empty = false;
       if (WRAP) {
@@ -1079,22 +1083,32 @@ __global__ __launch_bounds__(DT_X *DT_Y *DT_Z) void k_ttm_diff(
       }
       if (!empty) { int c = fidx(L, gi, gj, gk); t = T1[c]; kk = fd_k[c]; n = natoms[c]; }
     }
-    sT[lx][ly][lz] = t; sK[lx][ly][lz] = kk; sN[lx][ly][lz] = n;
+  };
+  if constexpr (!NOLDS) {
+    for (int s = threadIdx.x; s < (DT_X + 2) * (DT_Y + 2) * (DT_Z + 2); s += blockDim.x) {
+      int lz = s % (DT_Z + 2), ly = (s / (DT_Z + 2)) % (DT_Y + 2), lx = s / ((DT_Z + 2) * (DT_Y + 2));
+      double t, kk; int n;
+      cell_of(i0 + lx, j0 + ly, k0 + lz, t, kk, n);
+      sT[lx][ly][lz] = t; sK[lx][ly][lz] = kk; sN[lx][ly][lz] = n;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   const int i = i0 + tx + 1, j = j0 + ty + 1, k = k0 + tz + 1;
   if (i > L.dim[0] - 2 || j > L.dim[1] - 2 || k > L.dim[2] - 2) return;
   const int c = fidx(L, i, j, k), m = L.fd_min_atoms;
   const int lx = tx + 1, ly = ty + 1, lz = tz + 1;
-  const int nat = sN[lx][ly][lz];
+  double Te, kk; int nat;
+  if constexpr (NOLDS) cell_of(i, j, k, Te, kk, nat);
+  else { nat = sN[lx][ly][lz]; Te = sT[lx][ly][lz]; kk = sK[lx][ly][lz]; }
   if (nat < m) {
     if (FUSE_MESH) { fd_k_out[c] = 0.0; fd_g[c] = 0.0; Ce[c] = 0.0; if (flags & 1) { Zo[c] = 0.0; neo[c] = 0.0; } }
     return;
   }
-  const double Te = sT[lx][ly][lz], kk = sK[lx][ly][lz];
   const double invxsq = L.invhsq[0], invysq = L.invhsq[1], invzsq = L.invhsq[2];
 #define NB(dx, dy, dz, TT, KK) \
-  double TT, KK; if (sN[lx + dx][ly + dy][lz + dz] < m) { TT = Te; KK = kk; } else { TT = sT[lx + dx][ly + dy][lz + dz]; KK = sK[lx + dx][ly + dy][lz + dz]; }
+  double TT, KK; { int nn_; if constexpr (NOLDS) cell_of(i + dx, j + dy, k + dz, TT, KK, nn_); \
+                   else { nn_ = sN[lx + dx][ly + dy][lz + dz]; TT = sT[lx + dx][ly + dy][lz + dz]; KK = sK[lx + dx][ly + dy][lz + dz]; } \
+                   if (nn_ < m) { TT = Te; KK = kk; } }
   NB(1, 0, 0, xaT, xaK) NB(-1, 0, 0, xbT, xbK) NB(0, 1, 0, yaT, yaK) NB(0, -1, 0, ybT, ybK) NB(0, 0, 1, zaT, zaK) NB(0, 0, -1, zbT, zbK)
 #undef NB
   const double ce = Ce[c], g = fd_g[c], Tl = md_temp[c];
@@ -2491,18 +2505,18 @@ const int *imdgpu_ttm_persist_guard(imdgpu_ctx *ctx)
 }
 
 // Does the lattice work that is forked beside the EAM force pass need LDS of its own?  The coefficient form of that pass
-// (k_pass3_tile_coef) fills the CU's 160 KB, so kernels with LDS tiles would have to wait for its workgroups to end: the
-// launch chain of the sub-steps (lattices the persistent kernel does not take: 10 M-atom slab, measured 6.12 -> 6.94 ms
-// per step) and the 1D model's single workgroup.  The persistent sub-step kernel and the Maxwell-solver loop use none.
+// (k_pass3_tile_coef) fills the CU's 160 KB, so kernels with LDS tiles would have to wait for its workgroups to end (measured in
+// round 3 with the tiled launch chain on the 10 M-atom slab: 6.12 -> 6.94 ms per step).  Since round 5 the single-rank launch
+// chain reads its neighbours in place (k_ttm_diff<true, true>: no LDS), like the persistent kernel and the Maxwell-solver loop;
+// what still needs LDS is the 1D model's single workgroup and the mailbox form of the decomposed lattice.
 int imdgpu_ttm_chain_needs_lds(const imdgpu_ctx *ctx)
 {
   if (ctx->ttm1d) return 1;
   const TtmState *t = ctx->ttm;
   if (!t) return 0;
   if (t->fdtd && t->fdtd_on) return 0;
-  if (ctx->ttm_decomposed && !t->xrec_ready) return 1;      // faces through the host mailbox: one launch per sub-step
-  if (t->nsub % 2) return 1;                                // an odd number of sub-steps stays on the launch loop
-  return t->persist > 0 ? 0 : 1;
+  if (ctx->ttm_decomposed && !t->xrec_ready) return 1;      // faces through the host mailbox: the tiled k_ttm_diff<true, false> per sub-step
+  return 0;                                                 // the persistent kernel, and the single-rank launch chain (k_ttm_diff<true, true>: no LDS)
 }
 
 // the descriptor of the NEXT launch (its tag base is taken, not advanced: launch_persist does that)
