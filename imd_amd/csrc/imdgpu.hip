@@ -1303,6 +1303,16 @@ __device__ __forceinline__ void tab_index_open(const TabK &c, double arg, int &k
 // reference's for a pair whose r^2 lies within one rounding error of the table's begin.  (The force passes' neighbour loops are
 // bound by the NUMBER of vector instructions, not by the LDS: the distinct-grids form has 50 % more LDS reads and 29 % more vector
 // instructions than the shared-grid form and takes 31 % longer -- profiles/r05_pass1_forms.json.)
+// r^2 in the one-type pass 1.  EXACT = true: the reference's unfused expression (SPROD3D, makros.h:361) -- needed when the pass
+// counts neighbours (numneighs of the TTM, an integer decided by r2 <= pair_pot.end[0], imd_forces_nbl.c:473).  Without that count
+// nothing in the pass is a decision on r2 that is not continuous in it (a pair a rounding error beyond the cut-off contributes a
+// term that vanishes there), and two fused multiply-adds save two of the loop's 40 vector instructions.
+template <bool EXACT>
+__device__ __forceinline__ double r2_of(double dx, double dy, double dz)
+{
+  if constexpr (EXACT) return dx * dx + dy * dy + dz * dz;
+  else return fma(dz, dz, fma(dy, dy, dx * dx));
+}
 struct TabF { double c0, istep, end; };
 __device__ __forceinline__ TabF tabf(const TabPar &t, int col) { return {-t.begin[col] * t.invstep[col], t.invstep[col], t.end[col]}; }
 __device__ __forceinline__ void tab_index_fma(const TabF &c, double arg, int &k, double &chi, int &sgn)
@@ -1618,7 +1628,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
 #pragma unroll
           for (int e = 0; e < UNR; e++) {
             dx[e] -= xi; dy[e] -= yi; dz[e] -= zi;
-            r2[e] = dx[e] * dx[e] + dy[e] * dy[e] + dz[e] * dz[e];          // unfused: the reference's r2
+            r2[e] = r2_of<TTMN>(dx[e], dy[e], dz[e]);
             tab_index_fma(cf, r2[e], k[e], chi[e], sgn);
             tab_index_fma(crf, r2[e], kr[e], chr[e], sgn);
           }
@@ -1661,7 +1671,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_merged(TileArgs 
 #pragma unroll
         for (int e = 0; e < UNR; e++) {
           dx[e] -= xi; dy[e] -= yi; dz[e] -= zi;
-          r2[e] = dx[e] * dx[e] + dy[e] * dy[e] + dz[e] * dz[e];          // unfused: the reference's r2
+          r2[e] = r2_of<TTMN>(dx[e], dy[e], dz[e]);
           tab_index_fma(cf, r2[e], k[e], chi[e], sgn);
         }
 #if UNR == 4
@@ -2603,6 +2613,7 @@ static int shrink_tiles(imdgpu_ctx *ctx)
 }
 
 static size_t tile_lds_bytes_for(const imdgpu_ctx *ctx, int slot_cap, int which);
+static size_t align8(size_t b) { return (b + 7) & ~(size_t) 7; }
 
 // Pick the tile shape from the actual cell occupancies: the largest tile (fewest halo atoms staged per own
 // atom, fewest workgroup rounds) whose fullest tile still fits one TILE_MAXTHREADS workgroup and whose
@@ -2652,6 +2663,13 @@ static int autotile(imdgpu_ctx *ctx)
     // ties: long in z (contiguous cell keys), then thin in x (measured on a slab: 2x4x4 25 % faster than 4x2x4)
     double score = (double) ctx->nlocal / ntl / ((waves + 3) / 4) / (1.0 + 0.3 * (double) sumhalo / std::max(1, ctx->nlocal))
                    + 1e-3 * bz + 1e-4 * by - 1e-4 * bx;
+    // one atom type: a halo so large that the gradient-coefficient table of the EAM force pass no longer fits beside its four planes
+    // leaves that pass its three-row form (a quarter slower: a tenth of the step)
+    if (ctx->ntypes == 1 && ctx->d_coef3 && ctx->p3_coef) {
+      const size_t fixed = align8((4 * (size_t) slot_cap + 64 + 2) * 8);
+      const long long fit = fixed + 64 * 16 > LDS_LIMIT ? 0 : (long long) ((LDS_LIMIT - fixed) / 16);
+      if (ctx->ncoef - fit > ctx->ncoef / 4) score *= 0.9;
+    }
     if (score > bestscore) { bestscore = score; best[0] = bx; best[1] = by; best[2] = bz; }
     cands.push_back({score, {bx, by, bz}});
   }
@@ -3162,7 +3180,6 @@ extern "C" int imdgpu_fill_ghosts(imdgpu_ctx *ctx)
   return 0;
 }
 
-static size_t align8(size_t b) { return (b + 7) & ~(size_t) 7; }
 // persistent tile kernels: one workgroup per CU (their ~140 KB of LDS admit no second one)
 static int tile_grid(const imdgpu_ctx *ctx)
 {
