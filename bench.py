@@ -56,6 +56,12 @@ def parse():
     ap.add_argument("--types", type=int, choices=[1, 2], default=1,
                     help="2 = two atom types on the Cu3Au (L1_2) decoration of the FCC lattice: 4-column pair / density tables of\n"
                          "3000-4000 rows with per-column begin / end / step (potential.write_synthetic_eam_files_2types), 2-column F")
+    ap.add_argument("--types2-rows", type=float, default=1.0,
+                    help="with --types 2: scale of the tables' row counts (1.0 = 3000-4000 rows per column: beyond the LDS, record kernels;\n"
+                         "0.3 = 900-1200 rows: all of them sit in the LDS beside a tile)")
+    ap.add_argument("--rec-lds", type=int, default=-1,
+                    help="with --types 2: which tables the record kernels keep in the LDS (option tile_rec_lds; 1 pair_pot and 2 rho_h_tab\n"
+                         "in pass 1, 4 rho_h_tab in pass 3; tables that cannot fit are dropped); default: the library's choice")
     ap.add_argument("--slab", action="store_true",
                     help="config 4's geometry: open x with 12 MD cells of vacuum in front of and behind the atoms (pbc 0 1 1)")
     ap.add_argument("--cpu-box", type=int, default=48, help="unit cells per direction of the CPU sample")
@@ -107,7 +113,7 @@ def build_system(args, rank, world, device, decomposed=False):
     a = 4.05
     if args.types == 2:
         with tempfile.TemporaryDirectory() as d:
-            potential.write_synthetic_eam_files_2types(d)
+            potential.write_synthetic_eam_files_2types(d, rows=args.types2_rows)
             pair, c1 = potential.read_pot_table(os.path.join(d, "phi.pt"), 4, True)
             rho, c2 = potential.read_pot_table(os.path.join(d, "rho.pt"), 4, True)
             emb, _ = potential.read_pot_table(os.path.join(d, "F.pt"), 2, False)
@@ -162,6 +168,8 @@ def build_system(args, rank, world, device, decomposed=False):
                          "rebuild without EXTRA flags or pass --allow-experiments" % exp)
     if args.hook_remote_fail:
         sysm.set_option("ttm_remote_fail", args.hook_remote_fail)
+    if args.rec_lds >= 0:
+        sysm.set_option("tile_rec_lds", args.rec_lds)
     if args.halo_overlap > 0:
         sysm.set_option("halo_overlap", args.halo_overlap)
     if ttm and adv_on(args):
@@ -680,13 +688,14 @@ def main():
         fcap = sysm.get_info("fast_cap")          # plane stride the neighbour loops are compiled for (template argument; 0: run time)
         p1form = sysm.get_info("pass1_form")      # 2: one type, shared grid (interleaved table); 1: one type, distinct grids; 0: general kernels
         nt1 = "true" if args.types == 1 else "false"
+        rec_lds = sysm.get_info("rec_lds")        # several types: which tables the record kernels keep in the LDS (1 phi, 2 rho in pass 1, 4 rho in pass 3)
 
         def price(which):
             n, ms = prof[which]
             if which == "pass1":
                 byts = natoms * (72.0 + 4.0 * M + (32.0 if fused else 0.0))
                 if tiles and p1form == 3:
-                    kn = "k_pass1_tile_rec<%s, %d>" % (ttmn, fcap)
+                    kn = "k_pass1_tile_rec<%s, %d, %s, %s>" % (ttmn, fcap, "true" if rec_lds & 1 else "false", "true" if rec_lds & 2 else "false")
                 elif tiles and p1form:
                     kn = "k_pass1_tile_merged<%s, %s, %d, false, %s>" % (ttmn, "true" if fused else "false", fcap, "true" if p1form == 1 else "false")
                 elif tiles:
@@ -697,7 +706,9 @@ def main():
                 if p1form == 1:
                     label += " [phi and rho on different grids]"
                 if p1form == 3:
-                    label += " [several atom types, table rows as coefficient records through L2]"
+                    label += " [several atom types; in the LDS: %s; through L2 as coefficient records: %s]" % (
+                        " + ".join(n for b, n in ((1, "pair_pot"), (2, "rho_h_tab")) if rec_lds & b) or "no table",
+                        " + ".join(n for b, n in ((1, "pair_pot"), (2, "rho_h_tab")) if not rec_lds & b) or "no table")
                 if prof["pass1b"][0]:
                     kn = kn.replace(", false, false>", ", true, false>")
                     label = kn + " (pass 1 from a tile queue under the position halo, two launches per pass: pair + rho, embedding pass folded in)"
@@ -708,7 +719,7 @@ def main():
                 # in the timed region, else the stand-in, and say how often
                 standin = sysm.get_info("p3_standin_passes") - standin0
                 coef = tiles and sysm.get_info("p3_coef_rows") > 0 and standin == 0          # one atom type here
-                kn = ("k_pass3_tile_rec<%d>" % fcap) if (tiles and p1form == 3) else ("k_pass3_tile_coef<4, %d>" % fcap) if coef else (("k_pass3_tile<%s, %d, %d>" % (nt1, sysm.get_info("pass3_ring"), fcap)) if tiles else ("k_pass3_gt" if sysm.get_info("global_tables_in_place") else "k_pass3<%s>" % nt1))
+                kn = ("k_pass3_tile_rec%s<%d, %s>" % ("" if args.no_ttm else "_lean", fcap, "true" if rec_lds & 4 else "false")) if (tiles and p1form == 3) else ("k_pass3_tile_coef<4, %d>" % fcap) if coef else (("k_pass3_tile<%s, %d, %d>" % (nt1, sysm.get_info("pass3_ring"), fcap)) if tiles else ("k_pass3_gt" if sysm.get_info("global_tables_in_place") else "k_pass3<%s>" % nt1))
                 label = kn + (" (pass 3: EAM force pass, gradient-coefficient table)" if coef else " (pass 3: EAM force pass)")
                 if standin > 0:
                     label += " [stood in for the coefficient form in %d of %d passes]" % (standin, n)

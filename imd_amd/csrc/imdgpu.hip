@@ -574,7 +574,7 @@ struct TileArgs {
   int *nbr_cnt;
   // staging plan written by k_nbl_build_tile, valid until the next re-binning: per tile the global index of the atom
   // in every LDS slot, per own atom (slot | neighbour count << 16), per tile {slots, first own atom, own atoms, 0}
-  int *tsrc; unsigned *ownw; int4 *tinfo;
+  int *tsrc; unsigned *ownw, *ownseg; int4 *tinfo;         // ownseg: several atom types, see NBR_SCALE
   int dbg;                        // experiments (IMDGPU_DBG, read only by a library built with -DIMDGPU_EXPERIMENTS; see DBG()): 1 = skip the neighbour loops, 4 / 8 = the list build's candidate loops / appends
   TabPar pair, rho, emb;
   double4 *posw;                  // pos again, writable: the fused embedding pass stores F'(rho) in .w
@@ -586,6 +586,9 @@ struct TileArgs {
   // of interpolation coefficients, read in place through L2 -- recP / recR[col * nrec + k] = (p0, dv, d2v, 0) of pair_pot / rho_h_tab,
   // rec3[col * nrec3 + k] = invstep * (dv - d2v / 2, d2v) of rho_h_tab; the last record of every column is zero
   const double4 *recP, *recR; const double2 *rec3; int nrecP, nrecR;
+  // ... and the compact form of the same tables for the LDS (every distinct column with its own rows, three zero rows at the end):
+  // comp*[ncomp*] doubles, loff*[col] = first row of column col
+  const double *compP, *compR; int ncompP, ncompR; int loffP[IMDGPU_MAXCOL], loffR[IMDGPU_MAXCOL];
   double *f, *epot, *rhoh, *ref;
   int *numneighs;
   double *partials;
@@ -675,6 +678,11 @@ __global__ __launch_bounds__(1024) void k_tile_wprefix(int ntiles, int CPT, cons
 // extracted half-word IS the address of the x read -- one shift-and-add per neighbour less in each force pass (measured on one
 // box, three runs each: step 4.523 -> 4.509 ms; within the noise of a single run, kept because it is free).
 #define NBR_SCALE 8
+// ... and with several atom types a row is SEGMENTED by the neighbour's type: first the neighbours of type 0 (in the reference's order),
+// padded with dummies to a whole word, then those of type 1, ... -- ownseg[tile * tile_cap + o] holds the end word of segment k in
+// byte k, k < ntypes - 1 (the other bytes stay 0xff: the last segment runs to the row's end, and so do the dummy words behind it).  The record kernels then know the column of a whole list word (four neighbours) from its index
+// and fetch the column's parameters once per word instead of once per neighbour; an entry stays the plain address.  The sums of an
+// atom run over its neighbours type by type instead of cell by cell (rounding-level difference, bar 1e-9).
 typedef __attribute__((address_space(3))) const volatile double lds_cvdouble;
 // halo-cell table + prefix (hstart/hsrc) and staging of positions into LDS as x, y, z planes of slot_cap
 // doubles (NC = 4: + dF plane sw).  Used by the list build; the force passes stage from the plan it writes.  The last slot (slot_cap-1) is a far-away dummy that pads the
@@ -839,6 +847,8 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile(TileArgs a)
   extern __shared__ double lds[];
   double *sp = lds;
   int *hstart = (int *) (sp + 3 * (size_t) SLOTCAP(a)), *hsrc = hstart + NH_MAX + 1;
+  unsigned char *ft = (unsigned char *) (hsrc + NH_MAX);      // several atom types: the type of the atom in every slot
+  const bool typed = a.ntypes > 1;
   TileCtx T;
   int t0, t1;
   block_tile_range(a.ntiles, a.wprefix, a.balance, t0, t1);
@@ -852,8 +862,9 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile(TileArgs a)
     const int hw = threadIdx.x >> 5, l = threadIdx.x & 31, nhw = blockDim.x >> 5;
     for (int h = hw; h < T.nh; h += nhw) {
       const int s0 = hstart[h], n = hstart[h + 1] - s0, g0 = hsrc[h];
-      for (int e = l; e < n; e += 32) if (s0 + e < SLOTCAP(a) - 1) src[s0 + e] = g0 + e;
+      for (int e = l; e < n; e += 32) if (s0 + e < SLOTCAP(a) - 1) { src[s0 + e] = g0 + e; if (typed) ft[s0 + e] = (unsigned char) a.type[g0 + e]; }
     }
+    if (typed) __syncthreads();
     if (threadIdx.x == 0) {
       const int tot = hstart[T.nh];
       a.tinfo[T.tile] = make_int4(tot < SLOTCAP(a) - 1 ? tot : SLOTCAP(a) - 1, T.own_start, T.nown, 0);
@@ -871,7 +882,9 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile(TileArgs a)
     // a partial last word keeps dummies in its low slots)
     const unsigned long long dummy64 = (unsigned long long) dummy * 0x0001000100010001ull;
     unsigned long long w = dummy64;
-    int m = 0;
+    int m = 0, mreal = 0;
+    unsigned segw = 0xffffffffu;
+    for (int pt = 0; pt < (typed ? a.ntypes : 1); pt++) {      // several types: one sweep per neighbour type (NBR segments)
     for (int dx = 0; dx <= (DBG(a, 4) ? -1 : 2); dx++)
       for (int dy = 0; dy <= 2; dy++)
         for (int dz = 0; dz <= 2; dz++) {
@@ -903,8 +916,9 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile(TileArgs a)
             while (mask) {                                   // ascending j: the reference's order inside a cell
               const int j = j0 + __builtin_ctz(mask);
               mask &= mask - 1;
+              if (typed && ft[j] != pt) continue;
               w = (w >> 16) | ((unsigned long long) (j * NBR_SCALE) << 48);
-              m++;
+              m++; mreal++;
               if ((m & 3) == 0) {
                 if ((m >> 2) <= a.W4) lp[(size_t) ((m >> 2) - 1) * a.tile_cap] = w;
                 w = dummy64;
@@ -912,12 +926,16 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile(TileArgs a)
             }
           }
         }
-    if ((m & 3) != 0 && (m >> 2) < a.W4) {
+    if ((m & 3) != 0) {                                      // the segment's (the row's) last word: dummies in the remaining slots
       for (int q = m & 3; q < 4; q++) w = (w >> 16) | ((unsigned long long) dummy << 48);   // entries to the low slots
-      lp[(size_t) (m >> 2) * a.tile_cap] = w;
+      if ((m >> 2) < a.W4) lp[(size_t) (m >> 2) * a.tile_cap] = w;
+      m = (m + 3) & ~3; w = dummy64;
     }
-    a.nbr_cnt[i] = m < 4 * a.W4 ? m : 4 * a.W4;
+    if (pt < a.ntypes - 1) segw = (segw & ~(0xffu << (8 * pt))) | ((unsigned) (m >> 2 < 255 ? m >> 2 : 255) << (8 * pt));
+    }
+    a.nbr_cnt[i] = mreal < 4 * a.W4 ? mreal : 4 * a.W4;
     a.ownw[(size_t) T.tile * a.tile_cap + o] = (unsigned) slot | ((unsigned) (m < 4 * a.W4 ? m : 4 * a.W4) << 16);
+    if (typed) a.ownseg[(size_t) T.tile * a.tile_cap + o] = segw;
     mmax = m > mmax ? m : mmax;
   }
   }
@@ -943,6 +961,8 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile32(TileArgs a)
   extern __shared__ double lds[];
   float *fx = (float *) lds, *fy = fx + SLOTCAP(a), *fz = fy + SLOTCAP(a);
   int *hstart = (int *) (fz + SLOTCAP(a)), *hsrc = hstart + NH_MAX + 1;
+  unsigned char *ft = (unsigned char *) (hsrc + NH_MAX);      // several atom types: the type of the atom in every slot
+  const bool typed = a.ntypes > 1;
   TileCtx T;
   int t0, t1;
   block_tile_range(a.ntiles, a.wprefix, a.balance, t0, t1);
@@ -996,6 +1016,7 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile32(TileArgs a)
             const double4 q = a.pos[g0 + e];
             fx[s0 + e] = (float) (q.x - org.x); fy[s0 + e] = (float) (q.y - org.y); fz[s0 + e] = (float) (q.z - org.z);
             src[s0 + e] = g0 + e;
+            if (typed) ft[s0 + e] = (unsigned char) a.type[g0 + e];
           }
       }
       for (int s = tot + tid; s < ((tot + 3) & ~3) + 4 && s < SLOTCAP(a); s += nthr) { fx[s] = 1e30f; fy[s] = 1e30f; fz[s] = 1e30f; }   // what an aligned group may read behind the last atom
@@ -1013,7 +1034,9 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile32(TileArgs a)
       unsigned long long *lp = (unsigned long long *) (a.nbr16 + (size_t) T.tile * a.W4 * a.tile_cap + o);
       const unsigned long long dummy64 = (unsigned long long) dummy * 0x0001000100010001ull;
       unsigned long long w = dummy64;
-      int m = 0;
+      int m = 0, mreal = 0;
+      unsigned segw = 0xffffffffu;
+      for (int pt = 0; pt < (typed ? a.ntypes : 1); pt++) {      // several types: one sweep per neighbour type (NBR segments)
       // the three neighbour cells dz = 0, 1, 2 of a (dx, dy) pair are consecutive halo cells, so their atoms are ONE run of
       // slots: nine runs of ~63 candidates instead of 27 cells of ~21 -- the same candidates in the same order (cells by dz,
       // atoms ascending inside a cell), a third of the per-run bookkeeping and fuller chunks
@@ -1061,8 +1084,9 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile32(TileArgs a)
               while (mask) {                                             // ascending j: the reference's order inside a cell
                 const int b = __clz((int) mask);
                 mask &= ~(0x80000000u >> b);
+                if (typed && ft[j0 + b] != pt) continue;
                 w = (w >> 16) | ((unsigned long long) ((j0 + b) * NBR_SCALE) << 48);
-                m++;
+                m++; mreal++;
                 if ((m & 3) == 0) {
                   if ((m >> 2) <= a.W4) lp[(size_t) ((m >> 2) - 1) * a.tile_cap] = w;
                   w = dummy64;
@@ -1070,12 +1094,16 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile32(TileArgs a)
               }
             }
           }
-      if ((m & 3) != 0 && (m >> 2) < a.W4) {
+      if ((m & 3) != 0) {                                      // the segment's (the row's) last word: dummies in the remaining slots
         for (int q = m & 3; q < 4; q++) w = (w >> 16) | ((unsigned long long) dummy << 48);
-        lp[(size_t) (m >> 2) * a.tile_cap] = w;
+        if ((m >> 2) < a.W4) lp[(size_t) (m >> 2) * a.tile_cap] = w;
+        m = (m + 3) & ~3; w = dummy64;
       }
-      a.nbr_cnt[i] = m < 4 * a.W4 ? m : 4 * a.W4;
+      if (pt < a.ntypes - 1) segw = (segw & ~(0xffu << (8 * pt))) | ((unsigned) (m >> 2 < 255 ? m >> 2 : 255) << (8 * pt));
+      }
+      a.nbr_cnt[i] = mreal < 4 * a.W4 ? mreal : 4 * a.W4;
       a.ownw[(size_t) T.tile * a.tile_cap + o] = (unsigned) slot | ((unsigned) (m < 4 * a.W4 ? m : 4 * a.W4) << 16);
+      if (typed) a.ownseg[(size_t) T.tile * a.tile_cap + o] = segw;
       mmax = m > mmax ? m : mmax;
     }
   }
@@ -1993,35 +2021,68 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) __attribute__((amdgpu_waves_per_eu
   if (threadIdx.x == 0) a.partials[(size_t) blockIdx.x * IMDGPU_NPART + 3] = sums[0];
 }
 
-// ---- several atom types, tables beyond the LDS: positions and types in the LDS, table rows as coefficient records through L2 ----
-// Two atom types at production table sizes (2 tables x 4 columns x 4002 rows = 256 KB) cannot sit beside a tile; the global-gather
-// family then paid nine divergent loads per neighbour (position, type, 2 x 3 table rows).  Here the tile is staged like in every other
-// tile kernel (three LDS reads + the type), the per-column parameters (begin, step, end, record offset: types.h:537-549, one set per
-// column) come from a small LDS array, and a table look-up is ONE aligned 32-byte record (p0, dv, d2v) -- dv = p1 - p0 and
-// d2v = p2 - 2 p1 + p0 formed on the host with the reference's own roundings (potaccess.h:338-344) -- i.e. two loads of one L2 sector
-// instead of three rows 32 bytes apart.  Column as the reference has it: col = it * ntypes + jt for the pair term and for the
-// density atom i receives (imd_forces_nbl.c:457-470,550); cut-offs <= / < per column (:489,:550); the embedding pass of the own atom
-// (:748-783, column = its type) is folded in as in k_pass1_tile_merged.
-struct ColPar { double c0, istep, end; int boff, kz; };     // c0 = -begin * invstep; boff: first record of the column; kz: its zero record
-template <bool TTMN, int CAP>
+// ---- several atom types: the record kernels --------------------------------------------------------------------------------------
+// Positions in the LDS like everywhere; the neighbour's type rides in the list entry (NBR_TYPE_BITS), the own atom's comes from the
+// atom array; the per-column parameters (begin, step, end: types.h:537-549, one set per column) sit in a small LDS array.  Column as
+// the reference has it: col = it * ntypes + jt for the pair term and for the density atom i receives (imd_forces_nbl.c:457-470,550);
+// cut-offs <= / < per column (:489,:550); the embedding pass of the own atom (:748-783, column = its type) is folded in as in
+// k_pass1_tile_merged.  Where a table's rows come from is decided per table and per launch (make_nblist: rec_lds):
+//   *LDS = true   the table sits in the LDS in COMPACT form -- every distinct column (columns with equal parameters and equal rows
+//                 are kept once: phi_01 = phi_10 of a physical pair potential) with its own len + 2 rows, one behind the other, three
+//                 zero rows at the end; a look-up is three 8-byte reads, dv = p1 - p0 and d2v = p2 - 2 p1 + p0 follow (potaccess.h:338).
+//   *LDS = false  the table does not fit beside the tile (two types at production size: 2 x 4 columns x 4002 rows = 256 KB): a
+//                 look-up is ONE aligned record (p0, dv, d2v) -- the same differences formed on the host -- read in place through
+//                 L2: two loads of one sector instead of three rows 32 bytes apart.  The texture path serves a wave's 64 different
+//                 lines in ~55 cycles per instruction (the LDS in ~7): this form is bound by it.
+// Look-ups beyond their cut-off read zero rows (LDS) or load nothing (L2).
+// A record look-up through L2 is a raw BUFFER load: the look-ups beyond their cut-off (list skin, padding: a quarter of the entries)
+// carry the record index -1, i.e. an offset beyond the buffer's size -- the hardware returns zeros for it and sends nothing to the
+// texture path (whose cost goes with the number of lanes that ask), without a branch around the load.
+typedef unsigned rec_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned rec_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rec_rsrc(const void *p, size_t bytes)
+{
+  return __builtin_amdgcn_make_buffer_rsrc((void *) p, 0, (int) bytes, 0x00020000);        // raw buffer (stride 0), 32-bit data format
+}
+__device__ __forceinline__ double2 rec_ld16(__amdgpu_buffer_rsrc_t r, int byteoff)
+{
+  const rec_u4 q = __builtin_amdgcn_raw_buffer_load_b128(r, byteoff, 0, 0);
+  return make_double2(__hiloint2double((int) q.y, (int) q.x), __hiloint2double((int) q.w, (int) q.z));
+}
+__device__ __forceinline__ double rec_ld8(__amdgpu_buffer_rsrc_t r, int byteoff)
+{
+  const rec_u2 q = __builtin_amdgcn_raw_buffer_load_b64(r, byteoff, 0, 0);
+  return __hiloint2double((int) q.y, (int) q.x);
+}
+struct ColPar { double c0, istep, end; int boff, pad; };    // c0 = -begin * invstep; boff: first row / record of the column
+template <bool TTMN, int CAP, bool PLDS, bool RLDS>
 __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_rec(TileArgs a)
 {
   extern __shared__ double lds[];
   if (a.guard && *a.guard) return;
   double *sp = lds;
   double *scratch = sp + 3 * (size_t) SLOTCAP(a);
-  int *ts = (int *) (scratch + 64);
-  ColPar *parP = (ColPar *) (ts + SLOTCAP(a)), *parR = parP + IMDGPU_MAXCOL;      // slot_cap is a multiple of 64: 16-byte aligned
+  ColPar *parP = (ColPar *) (scratch + 64), *parR = parP + IMDGPU_MAXCOL;      // slot_cap is a multiple of 64: 16-byte aligned
+  double *tp = (double *) (parR + IMDGPU_MAXCOL), *tr = tp + (PLDS ? a.ncompP : 0);
+  (void) tp; (void) tr;
   TileCtx T;
   int t0, t1;
   block_tile_range(a.ntiles, a.wprefix, a.balance, t0, t1);
   const int nt = a.ntypes, ncol = nt * nt;
   if ((int) threadIdx.x < ncol) {
     const int c = threadIdx.x;
-    parP[c] = {-a.pair.begin[c] * a.pair.invstep[c], a.pair.invstep[c], a.pair.end[c], c * a.nrecP, c * a.nrecP + a.nrecP - 1};
-    parR[c] = {-a.rho.begin[c] * a.rho.invstep[c], a.rho.invstep[c], a.rho.end[c], c * a.nrecR, c * a.nrecR + a.nrecR - 1};
+    parP[c] = {-a.pair.begin[c] * a.pair.invstep[c], a.pair.invstep[c], a.pair.end[c], PLDS ? a.loffP[c] : c * a.nrecP, 0};
+    parR[c] = {-a.rho.begin[c] * a.rho.invstep[c], a.rho.invstep[c], a.rho.end[c], RLDS ? a.loffR[c] : c * a.nrecR, 0};
+  }
+  if (t0 < t1) {
+    if (PLDS) for (int k = threadIdx.x; k < a.ncompP; k += blockDim.x) tp[k] = a.compP[k];
+    if (RLDS) for (int k = threadIdx.x; k < a.ncompR; k += blockDim.x) tr[k] = a.compR[k];
   }
   const double pend0 = a.pair.end[0];
+  const int kzP = a.ncompP - 3, kzR = a.ncompR - 3;      // the zero rows of the compact tables
+  (void) kzP; (void) kzR;
+  const __amdgpu_buffer_rsrc_t rsP = rec_rsrc(a.recP, (size_t) ncol * a.nrecP * 32), rsR = rec_rsrc(a.recR, (size_t) ncol * a.nrecR * 32);
+  (void) rsP; (void) rsR;
   double sums[3] = {0.0, 0.0, 0.0};        // pair energy, virial, embedding energy
   int is_short = 0;
   int pend_i = -1, pend_t = 0;
@@ -2039,55 +2100,64 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_rec(TileArgs a)
   };
   int4 info = make_int4(0, 0, 0, 0);
   AHEAD_DECL(scratch)
-  if (t0 < t1) { info = a.tinfo[t0]; AHEAD_GRAB(t0, info.x, true) }
+  if (t0 < t1) { info = a.tinfo[t0]; AHEAD_GRAB(t0, info.x, false) }
   for (T.tile = t0; T.tile < t1; T.tile++) {
-    TILE_PROLOGUE_A(false, true, nullptr, ts, 1.0, , , , (T.tile + 1 < t1 ? T.tile + 1 : -1))
+    TILE_PROLOGUE_A(false, false, nullptr, nullptr, 1.0, , , , (T.tile + 1 < t1 ? T.tile + 1 : -1))
     emb_finish();
     for (int o = threadIdx.x; o < T.nown; o += blockDim.x) {
       const int i = T.own_start + o;
+      const int it = a.type[i], itn = it * nt;
       OWN_PROLOGUE
       double xi, yi, zi;
       LPOS_RD(sp, sp, SLOTCAP(a), slot, xi, yi, zi)
       emb_finish();
-      const int it = ts[slot], itn = it * nt;
       double fx = 0, fy = 0, fz = 0, ee = 0, rr = 0, vir = 0, ee0 = 0, rr0 = 0;
-      int nb = 0, sgn = 0;
+      int nb = 0, sgn = 0, wi = 0;
+      const unsigned segw = a.ownseg[(size_t) T.tile * a.tile_cap + o];
+      const int sg0 = segw & 0xff, sg1 = (segw >> 8) & 0xff, sg2 = (segw >> 16) & 0xff;
       LIST_WORDS_BEGIN
-        double dx[UNR], dy[UNR], dz[UNR], r2[UNR], chp[UNR], chr[UNR], isp[UNR];
-        int col[UNR], kp[UNR], kr[UNR];
-        double4 P[UNR], R[UNR];
+        double dx[UNR], dy[UNR], dz[UNR], r2[UNR], chp[UNR], chr[UNR];
+        int kp[UNR], kr[UNR];
+        double P0[UNR], Pv[UNR], Pw[UNR], R0[UNR], Rv[UNR], Rw[UNR];              // (p0, dv, d2v) of the two look-ups
+        const int col = itn + (wi >= sg0) + (wi >= sg1) + (wi >= sg2);            // this word's neighbours are all of one type
+        wi++;
+        const ColPar cp = parP[col], cr = parR[col];
 #pragma unroll
-        for (int e = 0; e < UNR; e++) { nbr_rd<CAP>(sp, SLOTCAP(a), j[e], dx[e], dy[e], dz[e]); col[e] = itn + nbr_type(ts, j[e]); }
+        for (int e = 0; e < UNR; e++) nbr_rd<CAP>(sp, SLOTCAP(a), j[e], dx[e], dy[e], dz[e]);
         SCHED_BARRIER;
 #pragma unroll
         for (int e = 0; e < UNR; e++) {
           dx[e] -= xi; dy[e] -= yi; dz[e] -= zi;
-          r2[e] = dx[e] * dx[e] + dy[e] * dy[e] + dz[e] * dz[e];          // unfused: the reference's r2
-          const ColPar cp = parP[col[e]], cr = parR[col[e]];
+          r2[e] = r2_of<TTMN>(dx[e], dy[e], dz[e]);
           double ap = fma(r2[e], cp.istep, cp.c0), ar = fma(r2[e], cr.istep, cr.c0);
           sgn |= __double2hiint(ap) | __double2hiint(ar);                 // r2 below a table's begin (is_short; see tab_index_fma)
           ap = fmax(ap, 0.0); ar = fmax(ar, 0.0);
           const bool inp = r2[e] <= cp.end;                               // pair: <= end (imd_forces_nbl.c:489)
-          if (TTMN) nb += (r2[e] <= pend0 && col[e] == 0) ? 1 : 0;        // both of type 0 (:473-476)
-          // a look-up beyond its column's cut-off (list skin, padding: a quarter of the entries) loads nothing: the texture path's cost
-          // goes with the number of lanes that ask
-          kp[e] = inp ? cp.boff + (int) ap : -1; chp[e] = __builtin_amdgcn_fract(ap); isp[e] = cp.istep;
-          kr[e] = r2[e] < cr.end ? cr.boff + (int) ar : -1; chr[e] = __builtin_amdgcn_fract(ar);          // density: < end (:550)
+          if (TTMN) nb += (r2[e] <= pend0 && col == 0) ? 1 : 0;           // both of type 0 (:473-476)
+          kp[e] = inp ? cp.boff + (int) ap : (PLDS ? kzP : -1); chp[e] = __builtin_amdgcn_fract(ap);
+          kr[e] = r2[e] < cr.end ? cr.boff + (int) ar : (RLDS ? kzR : -1); chr[e] = __builtin_amdgcn_fract(ar);      // density: < end (:550)
         }
         SCHED_BARRIER;
 #pragma unroll
         for (int e = 0; e < UNR; e++) {
-          P[e] = make_double4(0, 0, 0, 0); R[e] = make_double4(0, 0, 0, 0);
-          if (kp[e] >= 0) { const double2 q = ((const double2 *) a.recP)[2 * (size_t) kp[e]]; P[e].x = q.x; P[e].y = q.y; P[e].z = ((const double *) a.recP)[4 * (size_t) kp[e] + 2]; }
-          if (kr[e] >= 0) { const double2 q = ((const double2 *) a.recR)[2 * (size_t) kr[e]]; R[e].x = q.x; R[e].y = q.y; R[e].z = ((const double *) a.recR)[4 * (size_t) kr[e] + 2]; }
+          if constexpr (PLDS) { lds_cvdouble *q = (lds_cvdouble *) (tp + kp[e]); P0[e] = q[0]; Pv[e] = q[1]; Pw[e] = q[2]; }
+          else {
+            const double2 q = rec_ld16(rsP, kp[e] * 32); P0[e] = q.x; Pv[e] = q.y; Pw[e] = rec_ld8(rsP, kp[e] * 32 + 16);
+          }
+          if constexpr (RLDS) { lds_cvdouble *q = (lds_cvdouble *) (tr + kr[e]); R0[e] = q[0]; Rv[e] = q[1]; Rw[e] = q[2]; }
+          else {
+            const double2 q = rec_ld16(rsR, kr[e] * 32); R0[e] = q.x; Rv[e] = q.y; Rw[e] = rec_ld8(rsR, kr[e] * 32 + 16);
+          }
         }
         SCHED_BARRIER;
 #pragma unroll
         for (int e = 0; e < UNR; e++) {
 #pragma clang fp contract(fast)
-          const double gr = fma(chp[e] - 0.5, P[e].z, P[e].y) * isp[e];     // grad / 2: doubled once per atom
-          ee = fma(chp[e], fma(chp[e] - 1.0, 0.5 * P[e].z, P[e].y), ee); ee0 += P[e].x;      // halved once per atom
-          rr = fma(chr[e], fma(chr[e] - 1.0, 0.5 * R[e].z, R[e].y), rr); rr0 += R[e].x;
+          if constexpr (PLDS) { const double p1 = Pv[e], p2 = Pw[e]; Pv[e] = p1 - P0[e]; Pw[e] = (p2 - 2 * p1) + P0[e]; }
+          if constexpr (RLDS) { const double p1 = Rv[e], p2 = Rw[e]; Rv[e] = p1 - R0[e]; Rw[e] = (p2 - 2 * p1) + R0[e]; }
+          const double gr = fma(chp[e] - 0.5, Pw[e], Pv[e]) * cp.istep;     // grad / 2: doubled once per atom
+          ee = fma(chp[e], fma(chp[e] - 1.0, 0.5 * Pw[e], Pv[e]), ee); ee0 += P0[e];      // halved once per atom
+          rr = fma(chr[e], fma(chr[e] - 1.0, 0.5 * Rw[e], Rv[e]), rr); rr0 += R0[e];
           fx += dx[e] * gr; fy += dy[e] * gr; fz += dz[e] * gr;
           vir += r2[e] * gr;
         }
@@ -2108,7 +2178,7 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_rec(TileArgs a)
       if (TTMN) a.numneighs[i] = nb;
       sums[0] += ee; sums[1] += vir;
     }
-    TILE_EPILOGUE_A(true)
+    TILE_EPILOGUE_A(false)
   }
   emb_finish();
   block_sum<3>(sums, scratch);
@@ -2122,96 +2192,124 @@ __global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass1_tile_rec(TileArgs a)
 
 // The EAM force pass of the same family: grad = (dF_i rho'_j + dF_j rho'_i) / 2 with rho'_i from column jt * ntypes + it and rho'_j
 // from column it * ntypes + jt, both evaluated -- at min(r2, end) like DERIV_FUNC2 does (potaccess.h:601) -- whenever r2 lies inside
-// EITHER column's range (imd_forces_nbl.c:843-877).  A look-up is one 16-byte record invstep * (dv - d2v / 2, d2v).
-template <int CAP>
-__global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass3_tile_rec(TileArgs a)
+// EITHER column's range (imd_forces_nbl.c:843-877).  RLDS = false: a look-up is one 16-byte record invstep * (dv - d2v / 2, d2v);
+// RLDS = true: three rows of the compact rho_h_tab in the LDS.
+// RING = 0 (beside the lattice chain): 144 registers, so that three waves per SIMD leave the 80 a wave of the chain needs (see k_pass3_tile)
+template <int CAP, bool RLDS, int RING>
+__device__ __forceinline__ void pass3_tile_rec_body(const TileArgs &a)
 {
   extern __shared__ double lds[];
   double *sp = lds;
   double *sw = sp + 3 * (size_t) SLOTCAP(a);
   double *scratch = sw + SLOTCAP(a);
-  int *ts = (int *) (scratch + 64);
-  ColPar *par = (ColPar *) (ts + SLOTCAP(a));
+  ColPar *par = (ColPar *) (scratch + 64);
+  double *tr = (double *) (par + IMDGPU_MAXCOL);
+  (void) tr;
   TileCtx T;
   int t0, t1;
   block_tile_range(a.ntiles, a.wprefix, a.balance, t0, t1);
   const int nt = a.ntypes, ncol = nt * nt;
   if ((int) threadIdx.x < ncol) {
     const int c = threadIdx.x;
-    par[c] = {-a.rho.begin[c] * a.rho.invstep[c], a.rho.invstep[c], a.rho.end[c], c * a.nrecR, c * a.nrecR + a.nrecR - 1};
+    par[c] = {-a.rho.begin[c] * a.rho.invstep[c], a.rho.invstep[c], a.rho.end[c], RLDS ? a.loffR[c] : c * a.nrecR, 0};
   }
+  if (RLDS && t0 < t1) for (int k = threadIdx.x; k < a.ncompR; k += blockDim.x) tr[k] = a.compR[k];
+  const int kzR = a.ncompR - 3;                          // the zero rows of the compact table
+  (void) kzR;
+  const __amdgpu_buffer_rsrc_t rs3 = rec_rsrc(a.rec3, (size_t) ncol * a.nrecR * 16);
+  (void) rs3;
   double sums[1] = {0.0};
   int is_short = 0;
   int4 info = make_int4(0, 0, 0, 0);
   AHEAD_DECL(scratch)
-  if (t0 < t1) { info = a.tinfo[t0]; AHEAD_GRAB(t0, info.x, true) }
+  if (t0 < t1) { info = a.tinfo[t0]; AHEAD_GRAB(t0, info.x, false) }
   int pf_i = -1;
   double pf_x = 0, pf_y = 0, pf_z = 0, pf_ox = 0, pf_oy = 0, pf_oz = 0;
   auto f_finish = [&]() {
     if (pf_i >= 0) { a.f[pf_i] = pf_ox + pf_x; a.f[a.cap + pf_i] = pf_oy + pf_y; a.f[2 * (size_t) a.cap + pf_i] = pf_oz + pf_z; pf_i = -1; }
   };
   for (T.tile = t0; T.tile < t1; T.tile++) {
-    TILE_PROLOGUE_A(true, true, sw, ts, 1.0, , , , (T.tile + 1 < t1 ? T.tile + 1 : -1))
+    TILE_PROLOGUE_A(true, false, sw, nullptr, 1.0, , , , (T.tile + 1 < t1 ? T.tile + 1 : -1))
     f_finish();
     for (int o = threadIdx.x; o < T.nown; o += blockDim.x) {
       const int i = T.own_start + o;
+      const int it = a.type[i], itn = it * nt;
       OWN_PROLOGUE
       double xi, yi, zi, wi;
       LPOS_RDW(sp, sw, SLOTCAP(a), slot, xi, yi, zi, wi)
       f_finish();
-      const int it = ts[slot], itn = it * nt;
       double fx = 0, fy = 0, fz = 0, vir = 0;
-      int sgn = 0;
+      int sgn = 0, wd = 0;
+      constexpr int HB = RING == 0 ? 2 : UNR;
+      const unsigned segw = a.ownseg[(size_t) T.tile * a.tile_cap + o];
+      const int sg0 = segw & 0xff, sg1 = (segw >> 8) & 0xff, sg2 = (segw >> 16) & 0xff;
       LIST_WORDS_BEGIN
-        double dx[UNR], dy[UNR], dz[UNR], wj[UNR], r2[UNR], c1[UNR], c2[UNR];
-        int jt[UNR], k1[UNR], k2[UNR];
-        double2 A1[UNR], A2[UNR];
+        const int jt = (wd >= sg0) + (wd >= sg1) + (wd >= sg2);                   // this word's neighbours are all of one type
+        wd++;
+        const ColPar p1 = par[jt * nt + it], p2 = par[itn + jt];
+        const bool other = jt != it;
+        // HB neighbours at a time: all four where registers are plenty, two and two in the lean form
 #pragma unroll
-        for (int e = 0; e < UNR; e++) { nbr_rdw<CAP>(sp, sw, SLOTCAP(a), j[e], dx[e], dy[e], dz[e], wj[e]); jt[e] = nbr_type(ts, j[e]); }
-        SCHED_BARRIER;
+        for (int h = 0; h < UNR; h += HB) {
+          double dx[HB], dy[HB], dz[HB], wj[HB], r2[HB], c1[HB], c2[HB], g1[HB], g2[HB];
+          int k1[HB], k2[HB];
 #pragma unroll
-        for (int e = 0; e < UNR; e++) {
-          dx[e] -= xi; dy[e] -= yi; dz[e] -= zi;
-          r2[e] = dx[e] * dx[e] + dy[e] * dy[e] + dz[e] * dz[e];
-          const ColPar p1 = par[jt[e] * nt + it], p2 = par[itn + jt[e]];
-          const bool in = (r2[e] < p1.end) || (r2[e] < p2.end);
-          double a1 = fma(fmin(r2[e], p1.end), p1.istep, p1.c0), a2 = fma(fmin(r2[e], p2.end), p2.istep, p2.c0);
-          sgn |= in ? (__double2hiint(a1) | __double2hiint(a2)) : 0;
-          a1 = fmax(a1, 0.0); a2 = fmax(a2, 0.0);
-          // beyond both cut-offs: nothing is loaded; atoms of one type: one look-up serves both terms (col1 == col2, :858-860)
-          k1[e] = in ? p1.boff + (int) a1 : -1; c1[e] = __builtin_amdgcn_fract(a1);
-          k2[e] = (in && jt[e] != it) ? p2.boff + (int) a2 : -1; c2[e] = __builtin_amdgcn_fract(a2);
-        }
-        SCHED_BARRIER;
+          for (int e = 0; e < HB; e++) nbr_rdw<CAP>(sp, sw, SLOTCAP(a), j[h + e], dx[e], dy[e], dz[e], wj[e]);
+          SCHED_BARRIER;
 #pragma unroll
-        for (int e = 0; e < UNR; e++) {
-          A1[e] = make_double2(0, 0);
-          if (k1[e] >= 0) A1[e] = a.rec3[k1[e]];
-          A2[e] = A1[e];
-          if (k2[e] >= 0) A2[e] = a.rec3[k2[e]];
-        }
-        SCHED_BARRIER;
+          for (int e = 0; e < HB; e++) {
+            dx[e] -= xi; dy[e] -= yi; dz[e] -= zi;
+            r2[e] = fma(dz[e], dz[e], fma(dy[e], dy[e], dx[e] * dx[e]));   // fused (nothing here is a decision that is not continuous in r2)
+            const bool in = (r2[e] < p1.end) || (r2[e] < p2.end);
+            double a1 = fma(fmin(r2[e], p1.end), p1.istep, p1.c0), a2 = fma(fmin(r2[e], p2.end), p2.istep, p2.c0);
+            sgn |= in ? (__double2hiint(a1) | __double2hiint(a2)) : 0;
+            a1 = fmax(a1, 0.0); a2 = fmax(a2, 0.0);
+            // beyond both cut-offs: zero rows / nothing is loaded; atoms of one type: one look-up serves both terms (col1 == col2, :858-860)
+            k1[e] = in ? p1.boff + (int) a1 : (RLDS ? kzR : -1); c1[e] = __builtin_amdgcn_fract(a1);
+            k2[e] = (in && (RLDS || other)) ? p2.boff + (int) a2 : (RLDS ? kzR : -1); c2[e] = __builtin_amdgcn_fract(a2);
+          }
+          SCHED_BARRIER;
 #pragma unroll
-        for (int e = 0; e < UNR; e++) {
+          for (int e = 0; e < HB; e++) {
 #pragma clang fp contract(fast)
-          // rho' = 2 invstep (dv + (chi - 1/2) d2v): the records carry invstep (A + chi B), the 2 cancels the 1/2 of the force term
-          const double grad = wi * fma(c2[e], A2[e].y, A2[e].x) + wj[e] * fma(c1[e], A1[e].y, A1[e].x);
-          fx += dx[e] * grad; fy += dy[e] * grad; fz += dz[e] * grad;
-          vir += r2[e] * grad;                                              // d . f = grad r2
+            if constexpr (RLDS) {                     // rho' / 2 = invstep (dv + (chi - 1/2) d2v) from three rows (potaccess.h:601-617)
+              lds_cvdouble *q1 = (lds_cvdouble *) (tr + k1[e]), *q2 = (lds_cvdouble *) (tr + k2[e]);
+              const double u0 = q1[0], u1 = q1[1], u2 = q1[2], v0 = q2[0], v1 = q2[1], v2 = q2[2];
+              const double du = u1 - u0, d2u = (u2 - 2 * u1) + u0, dv = v1 - v0, d2v = (v2 - 2 * v1) + v0;
+              g1[e] = p1.istep * fma(c1[e] - 0.5, d2u, du); g2[e] = p2.istep * fma(c2[e] - 0.5, d2v, dv);
+            } else {                                  // the records carry invstep (dv - d2v / 2, d2v)
+              const double2 A1 = rec_ld16(rs3, k1[e] * 16), A2 = rec_ld16(rs3, k2[e] * 16);
+              g1[e] = fma(c1[e], A1.y, A1.x); g2[e] = other ? fma(c2[e], A2.y, A2.x) : g1[e];
+            }
+          }
+          SCHED_BARRIER;
+#pragma unroll
+          for (int e = 0; e < HB; e++) {
+#pragma clang fp contract(fast)
+            const double grad = wi * g2[e] + wj[e] * g1[e];                 // the 2 of rho' cancels the 1/2 of the force term
+            fx += dx[e] * grad; fy += dy[e] * grad; fz += dz[e] * grad;
+            vir += r2[e] * grad;                                            // d . f = grad r2
+          }
+          if (HB != UNR) SCHED_BARRIER;
         }
         HALF_END
-      LIST_WORDS_END(4)
+      LIST_WORDS_END(RING)
       is_short |= sgn < 0 ? 1 : 0;
       pf_ox = a.f[i]; pf_oy = a.f[a.cap + i]; pf_oz = a.f[2 * (size_t) a.cap + i]; pf_x = fx; pf_y = fy; pf_z = fz; pf_i = i;
       sums[0] += -0.5 * vir;
     }
-    TILE_EPILOGUE_A(true)
+    TILE_EPILOGUE_A(false)
   }
   f_finish();
   block_sum<1>(sums, scratch);
   if (threadIdx.x == 0) a.partials[(size_t) blockIdx.x * IMDGPU_NPART + 3] = sums[0];
   if (is_short) a.counters[CNT_IS_SHORT] = 1;
 }
+
+template <int CAP, bool RLDS>
+__global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass3_tile_rec(TileArgs a) { pass3_tile_rec_body<CAP, RLDS, 4>(a); }
+template <int CAP, bool RLDS>
+__global__ __launch_bounds__(TILE_MAXTHREADS) void k_pass3_tile_rec_lean(TileArgs a) { pass3_tile_rec_body<CAP, RLDS, 0>(a); }
 
 // Deterministic final reduction of the per-block partial sums
 // (tot_pot_energy, virial: imd_forces_nbl.c:319-328,:496,:521,:760,:943).
@@ -2416,7 +2514,8 @@ extern "C" int imdgpu_set_option(imdgpu_ctx *ctx, const char *name, int value)
   if (!strcmp(name, "ttm_remote_fail")) { ctx->ttm_remote_fail = value; return 0; }          // test hook
   // several atom types: 0 = never the record kernels (tables beyond the LDS then select the global-gather family), 1 = when the tables
   // do not fit the LDS beside a tile (default), 2 = whenever there are several types
-  if (!strcmp(name, "tile_rec")) { ctx->tile_rec_opt = value < 0 ? 0 : (value > 2 ? 2 : value); ctx->have_valid_nbl = 0; return 0; }
+  if (!strcmp(name, "tile_rec")) { ctx->tile_rec_opt = value > 0; ctx->have_valid_nbl = 0; ctx->autotiled = 0; return 0; }
+  if (!strcmp(name, "tile_rec_lds")) { ctx->rec_lds_opt = value < 0 ? -1 : (value & 7); ctx->have_valid_nbl = 0; ctx->autotiled = 0; return 0; }
   if (!strcmp(name, "p3_klo")) { ctx->p3_klo = value > 0 ? value : 0; return 0; }           // tests: which rows k_pass3_tile_coef holds
   if (!strcmp(name, "eos_bilinear")) { ctx->eos_bilinear = value ? 1 : 0; return 0; }    // before ttm_init / ttm1d_init
   if (!strcmp(name, "ttm_persist")) { imdgpu_ttm_set_persist(ctx, value < 0 ? -1 : (value ? 1 : 0)); return 0; }
@@ -2488,6 +2587,7 @@ extern "C" int imdgpu_get_info(imdgpu_ctx *ctx, const char *name, long long *val
     // which pass 1 runs: 2 = one type, pair_pot and rho_h_tab interleaved on their shared grid; 1 = one type, each table on its own grid;
     // 0 = the general kernels (several types, pair only, ...)
     {"experiments", imdgpu_experiment_mask()},
+    {"rec_lds", ctx->list_mode == 1 && ctx->tile_rec ? ctx->rec_lds : 0},
     {"pass1_form", p1_onetype(ctx) ? (ctx->d_merged ? 2 : 1) : (ctx->list_mode == 1 && ctx->tile_rec ? 3 : 0)},
     // global-gather family: the tables are too large for the LDS and are read in place through L2 (k_pass1_gt / k_pass3_gt)
     {"global_tables_in_place", ctx->list_mode == 0 && ((size_t) (ctx->pair.present ? ctx->pair.par.nrows * ctx->pair.par.ncols : 0) +
@@ -2830,8 +2930,9 @@ extern "C" int imdgpu_upload_tables(imdgpu_ctx *ctx, const imdgpu_pot_table *pai
   }
   // several atom types: coefficient records per column and row for the tile kernels that read the tables through L2
   // (k_pass1_tile_rec / k_pass3_tile_rec; make_nblist picks them when the tables do not fit the LDS beside a tile)
-  for (void **q : {(void **) &ctx->d_recP, (void **) &ctx->d_recR, (void **) &ctx->d_rec3}) if (*q) { (void) hipFree(*q); *q = nullptr; }
-  ctx->nrecP = ctx->nrecR = 0;
+  for (void **q : {(void **) &ctx->d_recP, (void **) &ctx->d_recR, (void **) &ctx->d_rec3, (void **) &ctx->d_compP, (void **) &ctx->d_compR})
+    if (*q) { (void) hipFree(*q); *q = nullptr; }
+  ctx->nrecP = ctx->nrecR = ctx->ncompP = ctx->ncompR = 0;
   if (pair && rho && ctx->ntypes > 1) {
     auto records = [&](const imdgpu_pot_table *t, std::vector<double> &rec, std::vector<double> *rec3, int &nrec) {
       const int nc = t->ncols, R = t->maxsteps + 2;
@@ -2856,6 +2957,33 @@ extern "C" int imdgpu_upload_tables(imdgpu_ctx *ctx, const imdgpu_pot_table *pai
     HIPCHK(hipMemcpy(ctx->d_recR, rr.data(), rr.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void **) &ctx->d_rec3, r3.size() * sizeof(double)));
     HIPCHK(hipMemcpy(ctx->d_rec3, r3.data(), r3.size() * sizeof(double), hipMemcpyHostToDevice));
+    // the compact form for the LDS: a column that repeats an earlier one (same begin / end / step / length, same rows -- phi_AB = phi_BA
+    // of a pair potential, a density that depends on the neighbour's type only) shares its rows
+    auto compact = [&](const imdgpu_pot_table *t, std::vector<double> &out, int *loff) {
+      const int nc = t->ncols;
+      out.clear();
+      for (int c = 0; c < nc; c++) {
+        const int rows = t->len[c] + 2;
+        int same = -1;
+        for (int b = 0; b < c && same < 0; b++) {
+          if (t->len[b] != t->len[c] || t->begin[b] != t->begin[c] || t->end[b] != t->end[c] || t->invstep[b] != t->invstep[c]) continue;
+          same = b;
+          for (int k = 0; k < rows; k++) if (t->table[(size_t) k * nc + b] != t->table[(size_t) k * nc + c]) { same = -1; break; }
+        }
+        if (same >= 0) { loff[c] = loff[same]; continue; }
+        loff[c] = (int) out.size();
+        for (int k = 0; k < rows; k++) out.push_back(t->table[(size_t) k * nc + c]);
+      }
+      out.insert(out.end(), 3, 0.0);
+    };
+    std::vector<double> cp, cr;
+    compact(pair, cp, ctx->loffP);
+    compact(rho, cr, ctx->loffR);
+    ctx->ncompP = (int) cp.size(); ctx->ncompR = (int) cr.size();
+    HIPCHK(hipMalloc((void **) &ctx->d_compP, cp.size() * sizeof(double)));
+    HIPCHK(hipMemcpy(ctx->d_compP, cp.data(), cp.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void **) &ctx->d_compR, cr.size() * sizeof(double)));
+    HIPCHK(hipMemcpy(ctx->d_compR, cr.data(), cr.size() * sizeof(double), hipMemcpyHostToDevice));
   }
   return 0;
 }
@@ -3199,11 +3327,14 @@ static TileArgs make_tile_args(imdgpu_ctx *ctx)
   a.pos = ctx->pos; a.type = ctx->type; a.acell = ctx->acell; a.cell_start = ctx->cell_start; a.cell_cnt = ctx->cell_cnt;
   a.istart = ctx->istart; a.nbr16 = (ushort4 *) ctx->nbr16; a.nbr_cnt = ctx->nbr_cnt;
   a.tsrc = ctx->tsrc; a.ownw = ctx->ownw; a.tinfo = (int4 *) ctx->tinfo;
+  a.ownseg = ctx->ownw ? ctx->ownw + (size_t) ctx->ntiles * ctx->tile_cap : nullptr;        // allocated behind ownw (several types)
   { static const int dbg = exp_env_int("IMDGPU_DBG", 0); a.dbg = dbg; }
   a.pair = ctx->pair.par; a.rho = ctx->rho.par; a.emb = ctx->emb.par; a.posw = ctx->pos; a.merged = ctx->d_merged;
   a.coef3 = (const double2 *) ctx->d_coef3; a.ncoef = ctx->ncoef; a.klo = 0; a.p3_fallback = 0;
   a.recP = (const double4 *) ctx->d_recP; a.recR = (const double4 *) ctx->d_recR; a.rec3 = (const double2 *) ctx->d_rec3;
   a.nrecP = ctx->nrecP; a.nrecR = ctx->nrecR;
+  a.compP = ctx->d_compP; a.compR = ctx->d_compR; a.ncompP = ctx->ncompP; a.ncompR = ctx->ncompR;
+  memcpy(a.loffP, ctx->loffP, sizeof(a.loffP)); memcpy(a.loffR, ctx->loffR, sizeof(a.loffR));
   a.f = ctx->f; a.epot = ctx->epot; a.rhoh = ctx->rhoh; a.ref = ctx->ref; a.numneighs = ctx->numneighs;
   a.partials = ctx->partials; a.counters = ctx->d_counters; a.cellsz = ctx->cellsz; a.guard = nullptr;
   a.balance = ctx->tile_balance; a.wprefix = ctx->d_wprefix;
@@ -3229,6 +3360,7 @@ static size_t tile_lds_bytes_for(const imdgpu_ctx *ctx, int slot_cap, int which)
 {
   imdgpu_ctx tmp;                       // only the sizing fields are read
   tmp.ntypes = ctx->ntypes; tmp.slot_cap = slot_cap; tmp.tile_rec = ctx->tile_rec;
+  tmp.rec_lds = ctx->rec_lds; tmp.ncompP = ctx->ncompP; tmp.ncompR = ctx->ncompR;
   tmp.pair.present = ctx->pair.present; tmp.pair.par = ctx->pair.par;
   tmp.rho.present = ctx->rho.present; tmp.rho.par = ctx->rho.par;
   return tile_lds_bytes(&tmp, which);
@@ -3238,9 +3370,13 @@ static size_t tile_lds_bytes(const imdgpu_ctx *ctx, int which /*0 build, 1 pass1
   size_t ints = (ctx->ntypes == 1 ? 0 : (size_t) ctx->slot_cap * sizeof(int));      // per-slot types (several types only)
   size_t tp = ctx->pair.present ? (size_t) ctx->pair.par.nrows * ctx->pair.par.ncols : 0;
   size_t tr = ctx->rho.present ? (size_t) ctx->rho.par.nrows * ctx->rho.par.ncols : 0;
-  if (which == 0) return align8((size_t) 3 * ctx->slot_cap * 8 + (size_t) (2 * NH_MAX + 1) * sizeof(int));
-  if (ctx->tile_rec)                    // tables through L2: planes, scratch, types, per-column parameters
-    return align8(((which == 1 ? 3 : 4) * (size_t) ctx->slot_cap + 64) * 8 + ints + (which == 1 ? 2 : 1) * IMDGPU_MAXCOL * sizeof(ColPar));
+  if (which == 0)                       // list build: planes, halo-cell table, per-slot type bytes (several types)
+    return align8((size_t) 3 * ctx->slot_cap * 8 + (size_t) (2 * NH_MAX + 1) * sizeof(int) + (ctx->ntypes == 1 ? 0 : (size_t) ctx->slot_cap));
+  if (ctx->tile_rec) {                  // record kernels: planes, scratch, per-column parameters, the tables this list keeps in the LDS
+    const size_t tabs = which == 1 ? ((ctx->rec_lds & 1) ? ctx->ncompP : 0) + (size_t) ((ctx->rec_lds & 2) ? ctx->ncompR : 0)
+                                   : (size_t) ((ctx->rec_lds & 4) ? ctx->ncompR : 0);
+    return align8(((which == 1 ? 3 : 4) * (size_t) ctx->slot_cap + 64 + tabs) * 8 + (which == 1 ? 2 : 1) * IMDGPU_MAXCOL * sizeof(ColPar));
+  }
   if (which == 1) return align8((tp + tr + 6 + 2 + 3 * (size_t) ctx->slot_cap + 64) * 8 + ints);
   return align8((tr + 4 + 2 + 4 * (size_t) ctx->slot_cap + 64) * 8 + ints);
 }
@@ -3270,13 +3406,29 @@ extern "C" int imdgpu_make_nblist(imdgpu_ctx *ctx)
   ctx->list_mode = ctx->mode;
   // the tile kernels keep the potential tables in LDS next to the staged positions: tables that leave no room for
   // even a one-cell tile (several atom types) select the global-gather kernels (reported by get_info("list_mode"))
-  ctx->tile_rec = 0;
-  if (ctx->list_mode == 1 && std::max(tile_lds_bytes_for(ctx, 1024, 1), tile_lds_bytes_for(ctx, 1024, 3)) > LDS_LIMIT) {
-    // several atom types with pair_pot and rho_h_tab: the tile kernels that read coefficient records through L2; else global gather
-    if (ctx->d_recP && ctx->d_recR && ctx->d_rec3 && ctx->tile_rec_opt) ctx->tile_rec = 1;
-    else ctx->list_mode = 0;
-  }
-  if (ctx->list_mode == 1 && ctx->tile_rec_opt == 2 && ctx->d_recP && ctx->d_recR && ctx->d_rec3) ctx->tile_rec = 1;   // option: also when the tables would fit
+  ctx->tile_rec = 0; ctx->rec_lds = 0;
+  if (ctx->list_mode == 1 && ctx->d_recP && ctx->d_recR && ctx->d_rec3 && ctx->tile_rec_opt) {
+    // several atom types with pair_pot and rho_h_tab: the record kernels.  Which tables they keep in the LDS is settled here, before
+    // the tile shape (whose LDS budget it enters): what fits beside the planes of a FAST_CAP tile -- in pass 3 rho_h_tab beside four
+    // planes, in pass 1 both tables beside three, else the one that fits (pair_pot first)
+    ctx->tile_rec = 1;
+    const size_t free1 = LDS_LIMIT - tile_lds_bytes_for(ctx, FAST_CAP, 1), free3 = LDS_LIMIT - tile_lds_bytes_for(ctx, FAST_CAP, 3);
+    const size_t bP = (size_t) ctx->ncompP * 8, bR = (size_t) ctx->ncompR * 8;
+    int m = 0;
+    if (bR <= free3) m |= 4;
+    if (bP + bR <= free1) m |= 3; else if (bP <= free1) m |= 1; else if (bR <= free1) m |= 2;
+    if (ctx->rec_lds_opt >= 0) {          // forced: keep what can fit at all (beside a 1024-slot tile)
+      m = ctx->rec_lds_opt & 7;
+      ctx->rec_lds = m;
+      if (tile_lds_bytes_for(ctx, 1024, 1) > LDS_LIMIT) m &= ~2;
+      ctx->rec_lds = m;
+      if (tile_lds_bytes_for(ctx, 1024, 1) > LDS_LIMIT) m &= ~1;
+      ctx->rec_lds = m;
+      if (tile_lds_bytes_for(ctx, 1024, 3) > LDS_LIMIT) m &= ~4;
+    }
+    ctx->rec_lds = m;
+  } else if (ctx->list_mode == 1 && std::max(tile_lds_bytes_for(ctx, 1024, 1), tile_lds_bytes_for(ctx, 1024, 3)) > LDS_LIMIT)
+    ctx->list_mode = 0;                  // tables that leave no room for a tile and no record form: the global-gather kernels
   if (ctx->list_mode == 1 && !ctx->autotiled && !cfg_env("IMDGPU_TILE") && !ctx->external_halo) {
     if (autotile(ctx)) return 1;
     g = make_geo(ctx);
@@ -3324,7 +3476,7 @@ extern "C" int imdgpu_make_nblist(imdgpu_ctx *ctx)
         if (dev_alloc(ctx, &ctx->nbr16, need)) return 1;
         ctx->nbr16_cap = need;
       }
-      const size_t need_src = (size_t) ctx->ntiles * ctx->slot_cap, need_own = (size_t) ctx->ntiles * ctx->tile_cap;
+      const size_t need_src = (size_t) ctx->ntiles * ctx->slot_cap, need_own = (size_t) ctx->ntiles * ctx->tile_cap * (ctx->ntypes > 1 ? 2 : 1);
       if (ctx->tsrc_cap < need_src) { if (dev_alloc(ctx, &ctx->tsrc, need_src)) return 1; ctx->tsrc_cap = need_src; }
       if (ctx->ownw_cap < need_own) { if (dev_alloc(ctx, &ctx->ownw, need_own)) return 1; ctx->ownw_cap = need_own; }
       if (ctx->tinfo_cap < (size_t) ctx->ntiles * 4) { if (dev_alloc(ctx, &ctx->tinfo, (size_t) ctx->ntiles * 4)) return 1; ctx->tinfo_cap = (size_t) ctx->ntiles * 4; }
@@ -3479,13 +3631,21 @@ static int launch_forces(imdgpu_ctx *ctx, int phase = 0)
 #define L1E(P, E) do { if (TT) L1T(P, E, true); else L1T(P, E, false); } while (0)
     if (TILE && ctx->tile_rec) {
       size_t l = tile_lds_bytes(ctx, 1);
-#define LR(T, C)                                                                                                     \
+#define LR(T, C, PL, RL)                                                                                             \
   do {                                                                                                               \
-    HIPCHK(hipFuncSetAttribute((const void *) k_pass1_tile_rec<T, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) l)); \
-    hipLaunchKernelGGL((k_pass1_tile_rec<T, C>), dim3(nb), dim3(B), l, ctx->stream, ta);                             \
+    HIPCHK(hipFuncSetAttribute((const void *) k_pass1_tile_rec<T, C, PL, RL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) l)); \
+    hipLaunchKernelGGL((k_pass1_tile_rec<T, C, PL, RL>), dim3(nb), dim3(B), l, ctx->stream, ta);                     \
   } while (0)
-      if (TT) { if (fastcap) LR(true, FAST_CAP); else LR(true, 0); }
-      else { if (fastcap) LR(false, FAST_CAP); else LR(false, 0); }
+#define LRC(T, PL, RL) do { if (fastcap) LR(T, FAST_CAP, PL, RL); else LR(T, 0, PL, RL); } while (0)
+#define LRT(PL, RL) do { if (TT) LRC(true, PL, RL); else LRC(false, PL, RL); } while (0)
+      switch (ctx->rec_lds & 3) {
+        case 3: LRT(true, true); break;
+        case 1: LRT(true, false); break;
+        case 2: LRT(false, true); break;
+        default: LRT(false, false);
+      }
+#undef LRT
+#undef LRC
 #undef LR
     } else if (p1_onetype(ctx)) {
       size_t l = tile_lds_bytes(ctx, 1);
@@ -3531,13 +3691,17 @@ static int launch_forces(imdgpu_ctx *ctx, int phase = 0)
     ProfScope ps(ctx, PROF_PASS3);
     if (TILE && ctx->tile_rec) {
       size_t l = tile_lds_bytes(ctx, 3);
-      if (fastcap) {
-        HIPCHK(hipFuncSetAttribute((const void *) k_pass3_tile_rec<FAST_CAP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) l));
-        hipLaunchKernelGGL((k_pass3_tile_rec<FAST_CAP>), dim3(nb), dim3(B), l, ctx->stream, ta);
-      } else {
-        HIPCHK(hipFuncSetAttribute((const void *) k_pass3_tile_rec<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) l));
-        hipLaunchKernelGGL((k_pass3_tile_rec<0>), dim3(nb), dim3(B), l, ctx->stream, ta);
-      }
+#define LR3(C, RL, K)                                                                                                \
+  do {                                                                                                               \
+    HIPCHK(hipFuncSetAttribute((const void *) K<C, RL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) l));       \
+    hipLaunchKernelGGL((K<C, RL>), dim3(nb), dim3(B), l, ctx->stream, ta);                                           \
+  } while (0)
+      // beside the lattice chain the leaner list walk (see k_pass3_tile)
+#define LR3C(RL, RG) do { if (fastcap) LR3(FAST_CAP, RL, RG); else LR3(0, RL, RG); } while (0)
+      if (ctx->rec_lds & 4) { if (ctx->ttm) LR3C(true, k_pass3_tile_rec_lean); else LR3C(true, k_pass3_tile_rec); }
+      else { if (ctx->ttm) LR3C(false, k_pass3_tile_rec_lean); else LR3C(false, k_pass3_tile_rec); }
+#undef LR3C
+#undef LR3
     } else if (TILE) {
       size_t l = tile_lds_bytes(ctx, 3);
       // with a lattice attached its sub-step chain runs beside this pass and needs 80 registers on every SIMD: the

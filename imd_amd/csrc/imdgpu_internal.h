@@ -78,7 +78,11 @@ struct imdgpu_ctx {
   // several atom types: coefficient records of pair_pot / rho_h_tab per column and row (k_pass1_tile_rec / k_pass3_tile_rec)
   double *d_recP = nullptr, *d_recR = nullptr, *d_rec3 = nullptr; int nrecP = 0, nrecR = 0;
   int tile_rec = 0;               // this list's force kernels are the record kernels (set by make_nblist)
-  int tile_rec_opt = 1;           // option "tile_rec": 0 never, 1 when the tables do not fit the LDS beside a tile, 2 whenever several types
+  int tile_rec_opt = 1;           // option "tile_rec": 0 never (the older several-type tile kernels / global gather), 1 whenever several types
+  // ... and the compact form for the LDS: the distinct columns of each table one behind the other (len + 2 rows each), three zero rows last
+  double *d_compP = nullptr, *d_compR = nullptr; int ncompP = 0, ncompR = 0; int loffP[IMDGPU_MAXCOL] = {0}, loffR[IMDGPU_MAXCOL] = {0};
+  int rec_lds = 0;                // which tables this list's record kernels keep in the LDS: 1 pair_pot (pass 1), 2 rho_h_tab (pass 1), 4 rho_h_tab (pass 3)
+  int rec_lds_opt = -1;           // option "tile_rec_lds": that mask forced (tables that do not fit are dropped from it); -1 = chosen by make_nblist
   int act_ranksort_max = 1024;    // option "act_ranksort_max" (test hook): above this many simultaneous fallback activations the ordered walk replaces the rank sort
   int ttm_remote_opt = 1;         // option "ttm_remote": 0 keeps the host mailbox for the decomposed lattice's faces
   int ttm_remote_fail = 0;        // option "ttm_remote_fail" (test hook): rank + 1 that pretends it cannot set the remote records up

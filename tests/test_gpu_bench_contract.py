@@ -153,7 +153,7 @@ def test_bench_mode_two_types():
     d = _mode(["--types", "2"])
     assert "TWO atom types" in d["config"]["workload"] and d["config"]["kernel_family"] == "lds_tiles"
     names = d["roofline"]["kernel"] + " " + d["roofline_other"]["kernel"]
-    assert "k_pass1_tile_rec<true" in names and "k_pass3_tile_rec<" in names
+    assert "k_pass1_tile_rec<true" in names and "k_pass3_tile_rec_lean<" in names             # _lean: the form that leaves the lattice chain its registers
     assert "pass2" not in d["kernel_ms_per_step"]                     # the embedding pass is folded into pass 1
 
 

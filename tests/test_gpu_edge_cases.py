@@ -272,8 +272,8 @@ def _two_type_case(seed=5):
 
 @pytest.mark.parametrize("dist", [None, 1.55, 1.2])
 def test_two_types_record_kernels_and_global_gather_vs_oracle(dist):
-    """Two atom types, tables beyond the LDS: the record kernels of the tile family (k_pass1_tile_rec / k_pass3_tile_rec) and the
-    global-gather family against the oracle -- also with a pair of unlike atoms at 1.55 A (above pair_pot.begin of column 0, BELOW
+    """Two atom types, tables beyond the LDS: the record kernels of the tile family (k_pass1_tile_rec / k_pass3_tile_rec; tables in the
+    LDS and as records through L2, in every mix that fits) and the global-gather family against the oracle -- also with a pair of unlike atoms at 1.55 A (above pair_pot.begin of column 0, BELOW
     that of the mixed columns, 1.6 A: is_short through the per-column begin, the argument clamped per column, potaccess.h:331) and
     at 1.2 A (below every column)."""
     c = _two_type_case()
@@ -289,13 +289,17 @@ def test_two_types_record_kernels_and_global_gather_vs_oracle(dist):
     idn = np.argsort(o.gather_inner("nummer"))
     fo, ro, eo = o.gather_inner("kraft")[idn], o.gather_inner("rho")[idn], o.gather_inner("pot_eng")[idn]
     assert o.s.is_short == (0 if dist is None else 1)
-    for mode in (0, 1):
+    for mode, lds in ((0, -1), (1, -1), (1, 0), (1, 2), (1, 7)):     # lds: which tables the record kernels keep in the LDS (what cannot fit is dropped)
         s = GpuSystem(c["box"], (1, 1, 1), c["dim"], 2, c["cellsz"], 0.5, 0.1)
         s.set_option("mode", mode)
+        if lds >= 0:
+            s.set_option("tile_rec_lds", lds)
         s.upload_tables(*c["tabs"])
         s.upload_atoms(c["pos"], c["mom"], c["masse"], c["sorte"])
         r = s.calc_forces(0)
         assert (s.get_info("list_mode"), s.get_info("pass1_form")) == ((1, 3) if mode else (0, 0))
+        if mode and lds >= 0:
+            assert s.get_info("rec_lds") & ~lds == 0
         d = s.download(fields=("kraft", "nummer", "eam_rho", "pot_eng"))
         s.close()
         k = np.argsort(d["nummer"])

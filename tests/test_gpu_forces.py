@@ -192,16 +192,24 @@ def test_shared_grid_tables_through_the_distinct_grids_kernel():
     assert abs(r1["virial"] - r0["virial"]) < 1e-11 * abs(r0["virial"])
 
 
-@pytest.mark.parametrize("case,opt", [("eam2_l12_nbl", 0), ("eam2_l12_coarse", 2)])
-def test_two_types_other_kernel_choice(case, opt):
-    """option tile_rec: 0 = tables beyond the LDS select the global-gather family (the round-4 behaviour, still the second
-    implementation); 2 = the record kernels also for tables that would fit the LDS.  Same goldens."""
+@pytest.mark.parametrize("case,rec,lds", [("eam2_l12_nbl", 0, -1), ("eam2_l12_coarse", 0, -1), ("eam2_l12_nbl", 1, 0), ("eam2_l12_coarse", 1, 0),
+                                          ("eam2_l12_coarse", 1, 1), ("eam2_l12_coarse", 1, 2), ("eam2_l12_coarse", 1, 4), ("eam2_l12_coarse", 1, 7)])
+def test_two_types_other_kernel_choice(case, rec, lds):
+    """Several atom types, every form the library has, same goldens.  Option tile_rec = 0: the older kernels -- tables beyond the LDS
+    select the global-gather family (round 4), tables that fit the tile kernels with the full tables and a type per slot in the LDS.
+    tile_rec = 1 (default): the record kernels on type-segmented list rows; option tile_rec_lds forces which tables they keep in the
+    LDS (1 pair_pot and 2 rho_h_tab in pass 1, 4 rho_h_tab in pass 3), the others are coefficient records through L2."""
     G = gu.load(case)
     for step in (0, 20):
         s = _gpu_from_golden(G, step)
-        s.set_option("tile_rec", opt)
+        s.set_option("tile_rec", rec)
+        if lds >= 0:
+            s.set_option("tile_rec_lds", lds)
         r = s.calc_forces(step)
-        assert (s.get_info("list_mode"), s.get_info("pass1_form")) == ((0, 0) if opt == 0 else (1, 3))
+        if rec == 0:
+            assert (s.get_info("list_mode"), s.get_info("pass1_form")) == ((0, 0) if case == "eam2_l12_nbl" else (1, 0))
+        else:
+            assert (s.get_info("list_mode"), s.get_info("pass1_form"), s.get_info("rec_lds")) == (1, 3, lds)
         d = s.download()
         pre = "s%d_" % step
         assert _relmax(d["kraft"], G[pre + "kraft"], floor=1e-3) < FTOL
@@ -231,11 +239,12 @@ def test_both_kernel_modes_match_reference(mode, case):
     s = _gpu_from_golden(G, 20)
     s.set_option("mode", mode)
     r = s.calc_forces(20)
-    # no silent fall-back to the other kernel family: tables that do not fit the LDS beside a tile (two atom types: 2 x 4 columns x
-    # 4002 rows = 256 KB) run on the tile kernels that read coefficient records through L2 (pass1_form 3)
+    # no silent fall-back to the other kernel family: several atom types run on the record kernels of the tile family (pass1_form 3),
+    # with the tables that fit in the LDS (the coarse ones: all; 2 x 4 columns x 4002 rows: pair_pot in pass 1) and the others through L2
     assert s.get_info("list_mode") == mode
     if mode == 1:
-        assert s.get_info("pass1_form") == {"eam_nbl_2048": 2, "eam_nbl_2048_dg": 1, "eam2_l12_nbl": 3, "eam2_l12_coarse": 0}[case]
+        assert s.get_info("pass1_form") == {"eam_nbl_2048": 2, "eam_nbl_2048_dg": 1, "eam2_l12_nbl": 3, "eam2_l12_coarse": 3}[case]
+        assert s.get_info("rec_lds") == {"eam_nbl_2048": 0, "eam_nbl_2048_dg": 0, "eam2_l12_nbl": 1, "eam2_l12_coarse": 7}[case]
     d = s.download()
     assert _relmax(d["kraft"], G["s20_kraft"]) < FTOL
     assert _relmax(d["eam_rho"], G["s20_eam_rho"]) < 1e-11
