@@ -1036,7 +1036,13 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile32(TileArgs a)
       unsigned long long w = dummy64;
       int m = 0, mreal = 0;
       unsigned segw = 0xffffffffu;
-      for (int pt = 0; pt < (typed ? a.ntypes : 1); pt++) {      // several types: one sweep per neighbour type (NBR segments)
+      // several types, the rows segmented by neighbour type (see NBR_SCALE).  Two types: ONE sweep -- the neighbours of type 1 are
+      // collected from the row's END downwards and moved behind the segment of type 0 afterwards (a handful of words per atom);
+      // three and four types: one sweep per type
+      const bool two = a.ntypes == 2;
+      unsigned long long w1 = dummy64;
+      int m1 = 0;
+      for (int pt = 0; pt < (typed && !two ? a.ntypes : 1); pt++) {
       // the three neighbour cells dz = 0, 1, 2 of a (dx, dy) pair are consecutive halo cells, so their atoms are ONE run of
       // slots: nine runs of ~63 candidates instead of 27 cells of ~21 -- the same candidates in the same order (cells by dz,
       // atoms ascending inside a cell), a third of the per-run bookkeeping and fuller chunks
@@ -1084,6 +1090,20 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile32(TileArgs a)
               while (mask) {                                             // ascending j: the reference's order inside a cell
                 const int b = __clz((int) mask);
                 mask &= ~(0x80000000u >> b);
+                if (two) {                                   // one code path for both segments (selects, no divergent branch)
+                  const bool t1 = ft[j0 + b] != 0;
+                  unsigned long long wc = t1 ? w1 : w;
+                  int mc = t1 ? m1 : m;
+                  wc = (wc >> 16) | ((unsigned long long) ((j0 + b) * NBR_SCALE) << 48);
+                  mc++; mreal++;
+                  if ((mc & 3) == 0) {
+                    if ((mc >> 2) <= a.W4) lp[(size_t) (t1 ? a.W4 - (mc >> 2) : (mc >> 2) - 1) * a.tile_cap] = wc;
+                    wc = dummy64;
+                  }
+                  w1 = t1 ? wc : w1; m1 = t1 ? mc : m1;
+                  w = t1 ? w : wc; m = t1 ? m : mc;
+                  continue;
+                }
                 if (typed && ft[j0 + b] != pt) continue;
                 w = (w >> 16) | ((unsigned long long) ((j0 + b) * NBR_SCALE) << 48);
                 m++; mreal++;
@@ -1100,6 +1120,20 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile32(TileArgs a)
         m = (m + 3) & ~3; w = dummy64;
       }
       if (pt < a.ntypes - 1) segw = (segw & ~(0xffu << (8 * pt))) | ((unsigned) (m >> 2 < 255 ? m >> 2 : 255) << (8 * pt));
+      }
+      if (two) {
+        if ((m1 & 3) != 0) {
+          for (int q = m1 & 3; q < 4; q++) w1 = (w1 >> 16) | ((unsigned long long) dummy << 48);
+          m1 = (m1 + 3) & ~3;
+          if ((m1 >> 2) <= a.W4) lp[(size_t) (a.W4 - (m1 >> 2)) * a.tile_cap] = w1;
+        }
+        // the move must not run into words it has yet to read: the row has to hold the second segment twice (else it counts as
+        // full: make_nblist grows W and builds again)
+        const int b0 = m >> 2, n1 = m1 >> 2;
+        if (b0 + 2 * n1 <= a.W4) {
+          for (int q = 0; q < n1; q++) lp[(size_t) (b0 + q) * a.tile_cap] = lp[(size_t) (a.W4 - 1 - q) * a.tile_cap];
+          m += m1;
+        } else m += 2 * m1;
       }
       a.nbr_cnt[i] = mreal < 4 * a.W4 ? mreal : 4 * a.W4;
       a.ownw[(size_t) T.tile * a.tile_cap + o] = (unsigned) slot | ((unsigned) (m < 4 * a.W4 ? m : 4 * a.W4) << 16);
