@@ -560,7 +560,7 @@ __global__ __launch_bounds__(512) void k_pass3_gt(ForceArgs a)
 // neighbour list holds 16-bit LDS slot numbers (4 per 8-byte load, ELL-transposed
 // per tile).  HBM sees: list (2 B/entry), own-atom outputs, one staging pass.
 // ===========================================================================
-#define IMDGPU_KERNEL_REV 12
+#define IMDGPU_KERNEL_REV 13
 #define LDS_LIMIT (160 * 1024)
 #define TABLE_LDS_LIMIT (150 * 1024)                 // global-gather kernels: tables beyond this stay in global memory
 #define NH_MAX 512                                   // halo cells per tile (<= 6*6*6 = 216 for tiles up to 4^3)

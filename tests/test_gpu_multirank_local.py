@@ -46,7 +46,12 @@ def _check_atoms(R, world, G, step, forces=True):
     o, go = np.argsort(ids), np.argsort(G[pre + "nummer"])
     box = np.diag(G["box"])
     dx = pos[o] - G[pre + "ort"][go]; dx -= np.round(dx / box) * box
-    assert np.abs(dx).max() < 1e-9
+    if not np.abs(dx).max() < 1e-9:                   # say where: which ranks hold the deviating atoms, and how the lattice launches went
+        owner = np.concatenate([np.full(len(R["r%d_nummer" % r]), r) for r in range(world)])[o]
+        bad = np.abs(dx).max(axis=1) >= 1e-9
+        info = {k: [int(R["r%d_%s" % (r, k)]) for r in range(world)] for k in ("nrebuild", "persist", "remote", "persist_runs", "persist_redone")}
+        raise AssertionError("positions differ by up to %.3e A: %d atoms, by rank %s; %s" %
+                             (np.abs(dx).max(), int(bad.sum()), np.bincount(owner[bad], minlength=world).tolist(), info))
     if forces:
         frc = _cat(R, world, "kraft")
         assert np.abs(frc[o] - G[pre + "kraft"][go]).max() < 1e-9 * np.abs(G[pre + "kraft"]).max()
