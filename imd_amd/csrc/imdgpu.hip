@@ -956,13 +956,15 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile(TileArgs a)
 // memory, through the staging plan this workgroup has just written) -- the decision is then the reference's, exactly.
 // Same candidate order as k_nbl_build_tile (neighbour cells in the order of cnbrs[c].nq[], j ascending), same outputs.
 typedef float nbl_f2 __attribute__((ext_vector_type(2)));
+// TY: 1 = one atom type (plain rows), 2 = two types (segmented rows from one sweep), 0 = three or four types (a sweep per type)
+template <int TY>
 __global__ __launch_bounds__(1024) void k_nbl_build_tile32(TileArgs a)
 {
   extern __shared__ double lds[];
   float *fx = (float *) lds, *fy = fx + SLOTCAP(a), *fz = fy + SLOTCAP(a);
   int *hstart = (int *) (fz + SLOTCAP(a)), *hsrc = hstart + NH_MAX + 1;
   unsigned char *ft = (unsigned char *) (hsrc + NH_MAX);      // several atom types: the type of the atom in every slot
-  const bool typed = a.ntypes > 1;
+  constexpr bool typed = TY != 1;
   TileCtx T;
   int t0, t1;
   block_tile_range(a.ntiles, a.wprefix, a.balance, t0, t1);
@@ -1039,7 +1041,7 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile32(TileArgs a)
       // several types, the rows segmented by neighbour type (see NBR_SCALE).  Two types: ONE sweep -- the neighbours of type 1 are
       // collected from the row's END downwards and moved behind the segment of type 0 afterwards (a handful of words per atom);
       // three and four types: one sweep per type
-      const bool two = a.ntypes == 2;
+      constexpr bool two = TY == 2;
       unsigned long long w1 = dummy64;
       int m1 = 0;
       for (int pt = 0; pt < (typed && !two ? a.ntypes : 1); pt++) {
@@ -1106,7 +1108,7 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile32(TileArgs a)
                 }
                 if (typed && ft[j0 + b] != pt) continue;
                 w = (w >> 16) | ((unsigned long long) ((j0 + b) * NBR_SCALE) << 48);
-                m++; mreal++;
+                m++; if (typed) mreal++;
                 if ((m & 3) == 0) {
                   if ((m >> 2) <= a.W4) lp[(size_t) ((m >> 2) - 1) * a.tile_cap] = w;
                   w = dummy64;
@@ -1114,12 +1116,13 @@ __global__ __launch_bounds__(1024) void k_nbl_build_tile32(TileArgs a)
               }
             }
           }
+      if (!typed) mreal = m;
       if ((m & 3) != 0) {                                      // the segment's (the row's) last word: dummies in the remaining slots
         for (int q = m & 3; q < 4; q++) w = (w >> 16) | ((unsigned long long) dummy << 48);
         if ((m >> 2) < a.W4) lp[(size_t) (m >> 2) * a.tile_cap] = w;
         m = (m + 3) & ~3; w = dummy64;
       }
-      if (pt < a.ntypes - 1) segw = (segw & ~(0xffu << (8 * pt))) | ((unsigned) (m >> 2 < 255 ? m >> 2 : 255) << (8 * pt));
+      if (typed && pt < a.ntypes - 1) segw = (segw & ~(0xffu << (8 * pt))) | ((unsigned) (m >> 2 < 255 ? m >> 2 : 255) << (8 * pt));
       }
       if (two) {
         if ((m1 & 3) != 0) {
@@ -3522,8 +3525,13 @@ extern "C" int imdgpu_make_nblist(imdgpu_ctx *ctx)
       const int bgrid = 2 * lds <= LDS_LIMIT ? std::min(ctx->ntiles, 2 * tile_grid(ctx)) : tile_grid(ctx);
       static const int nbl32 = exp_env_int("IMDGPU_NBL32", 1);     // 0: the all-double build kernel
       if (nbl32) {
-        HIPCHK(hipFuncSetAttribute((const void *) k_nbl_build_tile32, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-        hipLaunchKernelGGL(k_nbl_build_tile32, dim3(bgrid), dim3(ctx->tile_threads), lds, ctx->stream, a);
+#define LB(TY)                                                                                                       \
+  do {                                                                                                               \
+    HIPCHK(hipFuncSetAttribute((const void *) k_nbl_build_tile32<TY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); \
+    hipLaunchKernelGGL(k_nbl_build_tile32<TY>, dim3(bgrid), dim3(ctx->tile_threads), lds, ctx->stream, a);           \
+  } while (0)
+        if (ctx->ntypes == 1) LB(1); else if (ctx->ntypes == 2) LB(2); else LB(0);
+#undef LB
       } else
       hipLaunchKernelGGL(k_nbl_build_tile, dim3(bgrid), dim3(ctx->tile_threads), lds, ctx->stream, a);
     } else {
