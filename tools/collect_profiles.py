@@ -27,6 +27,8 @@ pairs = [
     ("b_rccl_dec.json", "bench_10M_ttm_force_distributed_rccl_decomposed.json"),
     ("b_rccl_rep.json", "bench_10M_ttm_force_distributed_rccl_replicated.json"),
     ("b_80M.json", "bench_80M_slab_ttm_one_gpu.json"),
+    ("b_3000.json", "bench_10M_ttm_3000_steps.json"),
+    ("b_types2c.json", "bench_10M_ttm_two_types_coarse_tables.json"),
 ]
 for a, b in pairs:
     p = os.path.join(src, a)
