@@ -303,3 +303,34 @@ def write_synthetic_eam_files_2types(dirname, rows=1.0):
     ps = [40.0 / (ne[0] - 1), 55.0 / (ne[1] - 1)]
     write_pot_table2(os.path.join(dirname, "F.pt"), [0.0, 0.0], [40.0, 55.0], ps,
                      [emb(ps[0] * np.arange(ne[0])), 1.15 * emb(0.9 * ps[1] * np.arange(ne[1]))])
+
+
+def write_synthetic_eam_files_ntypes(dirname, ntypes, rows=1.0):
+    """ntypes atom types (3 or 4 here; 2 has its own writer above): pair and density tables with ntypes^2 columns, every column with ITS
+    OWN begin / end / step / length (col = type_i * ntypes + type_j, types.h:537-549); the pair columns are symmetric in (i, j) like a
+    physical pair potential, the density columns are all different; ntypes embedding columns."""
+    import os
+    phi, rho, emb = synthetic_eam_functions()
+    def cut_at(fn, rc):
+        return lambda r: fn(r * 6.5 / rc)
+    def columns(fn, sym):
+        b, e, st, cols = [], [], [], []
+        for i in range(ntypes):
+            for j in range(ntypes):
+                lo, hi = (min(i, j), max(i, j)) if sym else (i, j)
+                k = lo * ntypes + hi
+                rb, rc = 1.5 + 0.05 * ((3 * k) % 5), 6.5 - 0.07 * ((5 * k + 2) % 7)
+                n = int((4000 - 150 * ((7 * k) % 6)) * rows)
+                amp = 1.0 + 0.11 * ((k * 3) % 5) - 0.2
+                b2, e2 = rb * rb, rc * rc
+                step = (e2 - b2) / (n - 1)
+                r = np.sqrt(b2 + step * np.arange(n))
+                b.append(b2); e.append(e2); st.append(step); cols.append(amp * cut_at(fn, rc)(r))
+        return b, e, st, cols
+    write_pot_table2(os.path.join(dirname, "phi.pt"), *columns(phi, True))
+    write_pot_table2(os.path.join(dirname, "rho.pt"), *columns(rho, False))
+    ne = [int((4000 - 300 * t) * rows) for t in range(ntypes)]
+    hi = [40.0 + 6.0 * t for t in range(ntypes)]
+    ps = [hi[t] / (ne[t] - 1) for t in range(ntypes)]
+    write_pot_table2(os.path.join(dirname, "F.pt"), [0.0] * ntypes, hi, ps,
+                     [(1.0 + 0.08 * t) * emb((1.0 - 0.04 * t) * ps[t] * np.arange(ne[t])) for t in range(ntypes)])

@@ -309,3 +309,54 @@ def test_two_types_record_kernels_and_global_gather_vs_oracle(dist):
         assert np.abs(d["pot_eng"][k] - eo).max() < 1e-11 * np.abs(eo).max()
         assert abs(r["tot_pot_energy"] - o.s.tot_pot_energy) < 1e-11 * abs(o.s.tot_pot_energy)
         assert abs(r["virial"] - o.s.virial) < 1e-10 * abs(o.s.virial)
+
+
+@pytest.mark.parametrize("ntypes,rows", [(3, 1.0), (3, 0.12), (4, 1.0), (4, 0.1)])
+def test_three_and_four_types_vs_oracle(ntypes, rows):
+    """Three and four atom types (the most the library takes: ntypes^2 <= 16 columns), every column with its own grid: list rows
+    in three / four segments from one sweep of the list build per type (k_nbl_build_tile32<0>), the record kernels with full-size
+    tables (through L2) and with tables small enough for the LDS, and the global-gather family, against the oracle."""
+    import os
+    import tempfile
+    nb, a = (10, 10, 10), 4.05
+    with tempfile.TemporaryDirectory() as d:
+        potential.write_synthetic_eam_files_ntypes(d, ntypes, rows=rows)
+        pair, c1 = potential.read_pot_table(os.path.join(d, "phi.pt"), ntypes * ntypes, True)
+        rho, c2 = potential.read_pot_table(os.path.join(d, "rho.pt"), ntypes * ntypes, True)
+        emb, _ = potential.read_pot_table(os.path.join(d, "F.pt"), ntypes, False)
+    cellsz = (np.sqrt(max(c1, c2)) + 0.5) ** 2
+    box = lattice.fcc_box(nb, a)
+    pos = lattice.fcc_positions(nb, a)
+    rng = np.random.default_rng(11 + ntypes)
+    sorte = rng.choice(ntypes, size=len(pos), p=[0.5, 0.3, 0.2] if ntypes == 3 else [0.4, 0.3, 0.2, 0.1]).astype(np.int32)
+    pos = pos + rng.normal(scale=0.04, size=pos.shape)
+    masse = np.array([26.9815, 63.546, 58.69, 107.87])[sorte]
+    mom = lattice.maxwell_momenta(len(pos), 1.0, 0.03, seed=3) * np.sqrt(masse)[:, None]
+    dim = [g + 2 for g in global_cell_dim(box, cellsz)]
+    o = po.OracleSystem(dim, 64, ntypes, box, (1, 1, 1), cellsz, 0.5, 0.1)
+    for w, t in enumerate((pair, rho, emb)):
+        o.set_table(w, t.as_dict())
+    o.fill_from_positions(pos % np.diag(box), mom, masse, sorte)
+    o.calc_forces(0)
+    idn = np.argsort(o.gather_inner("nummer"))
+    fo, ro, eo = o.gather_inner("kraft")[idn], o.gather_inner("rho")[idn], o.gather_inner("pot_eng")[idn]
+    for mode, lds in ((0, -1), (1, -1), (1, 0)):
+        s = GpuSystem(box, (1, 1, 1), dim, ntypes, cellsz, 0.5, 0.1)
+        s.set_option("mode", mode)
+        if lds >= 0:
+            s.set_option("tile_rec_lds", lds)
+        s.upload_tables(pair, rho, emb)
+        s.upload_atoms(pos, mom, masse, sorte)
+        r = s.calc_forces(0)
+        assert (s.get_info("list_mode"), s.get_info("pass1_form")) == ((1, 3) if mode else (0, 0))
+        if mode and lds < 0 and rows < 0.5:
+            assert s.get_info("rec_lds") == 7                              # these tables all sit in the LDS
+        d = s.download(fields=("kraft", "nummer", "eam_rho", "pot_eng"))
+        s.close()
+        k = np.argsort(d["nummer"])
+        assert np.abs(d["kraft"][k] - fo).max() < 1e-9 * np.abs(fo).max(), (mode, lds)
+        assert np.abs(d["eam_rho"][k] - ro).max() < 1e-11 * np.abs(ro).max()
+        assert np.abs(d["pot_eng"][k] - eo).max() < 1e-11 * np.abs(eo).max()
+        assert abs(r["tot_pot_energy"] - o.s.tot_pot_energy) < 1e-11 * abs(o.s.tot_pot_energy)
+        assert abs(r["virial"] - o.s.virial) < 1e-10 * abs(o.s.virial)
+    o.close()
