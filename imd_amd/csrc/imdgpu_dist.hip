@@ -343,6 +343,34 @@ static int dist_halo_parts(imdgpu_ctx *ctx, DistState *D, int what, int parts, n
   if ((parts & 1) && D->nsend_atoms > 0)
     hipLaunchKernelGGL(k_dist_gather, dim3(nblk(D->nsend_atoms, 256)), dim3(256), 0, ctx->stream, what, D->nsend_atoms, D->d_send_idx,
                        D->d_seg_of, D->d_self_dst, D->d_shift, ctx->pos, ctx->type, D->sendbuf);
+  static const bool verify = cfg_env("IMDGPU_LOCAL_VERIFY") != nullptr;      // diagnostics: the gather's output against a host evaluation
+  if (verify && (parts & 1) && D->nsend_atoms > 0 && (what == 1 || what == 3)) {
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const size_t n = (size_t) D->nsend_atoms;
+    std::vector<double> s1(n * w), s2(n * w), sh(3 * MAXSEG);
+    std::vector<int> idx(n), sd(n), seg(n);
+    std::vector<double4> pos((size_t) ctx->nlocal + ctx->nghost);
+    HIPCHK(hipMemcpy(s1.data(), D->sendbuf, s1.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(idx.data(), D->d_send_idx, n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(sd.data(), D->d_self_dst, n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(seg.data(), D->d_seg_of, n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(sh.data(), D->d_shift, sh.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(pos.data(), ctx->pos, pos.size() * sizeof(double4), hipMemcpyDeviceToHost));
+    size_t lo = n, hi = 0, nbad = 0;
+    auto expect = [&](size_t m, int c) { const double4 r = pos[idx[m]]; return what == 1 ? r.w : (c == 0 ? r.x : c == 1 ? r.y : r.z) + sh[3 * seg[m] + c]; };
+    for (size_t m = 0; m < n; m++) {
+      if (sd[m] >= 0) continue;
+      for (int c = 0; c < w; c++) if (s1[m * w + c] != expect(m, c)) { lo = std::min(lo, m); hi = m + 1; nbad++; break; }
+    }
+    if (nbad) {
+      usleep(20000);
+      HIPCHK(hipMemcpy(s2.data(), D->sendbuf, s2.size() * 8, hipMemcpyDeviceToHost));
+      size_t still = 0;
+      for (size_t m = lo; m < hi; m++) { if (sd[m] >= 0) continue; for (int c = 0; c < w; c++) if (s2[m * w + c] != expect(m, c)) { still++; break; } }
+      fprintf(stderr, "[imdgpu local verify] rank %d GATHER what %d: %zu of %zu atoms differ from pos[] right after the stream's synchronisation, atoms [%zu, %zu); 20 ms later %zu still differ; first bad: got %.6g expected %.6g\n",
+              D->rank, what, nbad, n, lo, hi, still, s1[lo * w], expect(lo, 0));
+    }
+  }
   if (parts & 2) {
     if (dist_exchange(ctx, D, w, comm)) return 1;
     if (parts == 2) imdgpu_tl_mark(ctx, "halo3_msgs");
@@ -1285,7 +1313,8 @@ extern "C" int imdgpu_dist_calc_forces(imdgpu_ctx *ctx)
 // (several ranks rehearsing on one GPU without a process per rank -- a GPU box admits few processes --, or one process driving
 // the GPUs of a node with peer copies).  Same semantics as the host callback: called with the stream drained; messages
 // between a pair of ranks match in posting order; collectives over all ranks of the group.
-struct LocalPost { int op = -1; char *send = nullptr, *recv = nullptr; int nsend = 0; std::vector<int> sp; std::vector<long long> so, sc; int eb = 0; };
+struct LocalPost { int op = -1; char *send = nullptr, *recv = nullptr; int nsend = 0; std::vector<int> sp; std::vector<long long> so, sc; int eb = 0;
+                   std::vector<char> snap; };        // IMDGPU_LOCAL_VERIFY (diagnostics): the sender's own copy of its send buffer
 struct LocalGroup {
   int n = 0;
   std::mutex mu; std::condition_variable cv;
@@ -1293,7 +1322,11 @@ struct LocalGroup {
   std::vector<LocalPost> post;
   std::map<std::string, std::pair<void *, size_t>> shared;   // named page-locked regions (the TTM face mailbox)
 };
-struct LocalMember { LocalGroup *g; int rank; int device; hipStream_t s = nullptr; };
+// The copies run on the RECEIVING context's current stream -- the one the caller has drained and launches the consumer of the data on --
+// so producer (copy) and consumer (unpack) are ordered in one queue like RCCL's send / receive are.  (Round 5: with the copies on a
+// stream of their own, ordered against the consumer through the host only, one run in ~100 of the 2 x 2 x 2 rehearsal beside another
+// process on the GPU had single 256-atom blocks of a dF message arrive stale in k_dist_unpack.)
+struct LocalMember { LocalGroup *g; int rank; int device; imdgpu_ctx *ctx = nullptr; };
 static int local_barrier(LocalGroup *G)
 {
   std::unique_lock<std::mutex> lk(G->mu);
@@ -1309,10 +1342,18 @@ static int local_exchange(void *user, int op, void *dsend, void *drecv, int nsen
   LocalMember *M = (LocalMember *) user;
   LocalGroup *G = M->g;
   if (hipSetDevice(M->device) != hipSuccess) return 1;
+  const hipStream_t cs = M->ctx->stream;
   LocalPost &me = G->post[M->rank];
   me.op = op; me.send = (char *) dsend; me.recv = (char *) drecv; me.nsend = nsend; me.eb = eb;
   me.sp.clear(); me.so.clear(); me.sc.clear();
   if (op == 0) for (int k = 0; k < nsend; k++) { me.sp.push_back(sp[k]); me.so.push_back(so[k]); me.sc.push_back(sc[k]); }
+  static const bool verify = cfg_env("IMDGPU_LOCAL_VERIFY") != nullptr;      // diagnostics: every message checked against the sender's snapshot
+  if (verify && op == 0) {
+    long long hi = 0;
+    for (int k = 0; k < nsend; k++) hi = std::max(hi, so[k] + sc[k]);
+    me.snap.resize((size_t) hi * eb);
+    if (hi && hipMemcpy(me.snap.data(), dsend, me.snap.size(), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+  }
   if (local_barrier(G)) return 1;
   int rc_ = 0;
   if (op == 0) {
@@ -1324,9 +1365,31 @@ static int local_exchange(void *user, int op, void *dsend, void *drecv, int nsen
       int want = seen[p]++, at = -1;
       for (size_t j = 0; j < o.sp.size(); j++) if (o.sp[j] == M->rank && want-- == 0) { at = (int) j; break; }
       if (at < 0 || o.sc[at] != rc[k] || o.eb != eb || o.op != 0) { rc_ = 1; break; }
-      if (rc[k] > 0 && hipMemcpyAsync((char *) drecv + ro[k] * eb, o.send + o.so[at] * eb, (size_t) rc[k] * eb, hipMemcpyDeviceToDevice, M->s) != hipSuccess) rc_ = 1;
+      if (rc[k] > 0 && hipMemcpyAsync((char *) drecv + ro[k] * eb, o.send + o.so[at] * eb, (size_t) rc[k] * eb, hipMemcpyDeviceToDevice, cs) != hipSuccess) rc_ = 1;
     }
-    if (hipStreamSynchronize(M->s) != hipSuccess) rc_ = 1;
+    if (hipStreamSynchronize(cs) != hipSuccess) rc_ = 1;
+    if (verify && !rc_) {
+      std::vector<int> seen2(G->n, 0);
+      for (int k = 0; k < nrecv; k++) {
+        const int p = rp[k];
+        const LocalPost &o = G->post[p];
+        int want = seen2[p]++, at = -1;
+        for (size_t j = 0; j < o.sp.size(); j++) if (o.sp[j] == M->rank && want-- == 0) { at = (int) j; break; }
+        const size_t bytes = (size_t) rc[k] * eb;
+        std::vector<char> got(bytes), now(bytes);
+        (void) hipMemcpy(got.data(), (char *) drecv + ro[k] * eb, bytes, hipMemcpyDeviceToHost);
+        (void) hipMemcpy(now.data(), o.send + o.so[at] * eb, bytes, hipMemcpyDeviceToHost);
+        const char *snap = o.snap.data() + o.so[at] * eb;
+        size_t a1 = bytes, b1 = 0, a2 = bytes, b2 = 0;
+        for (size_t q = 0; q < bytes; q++) {
+          if (got[q] != snap[q]) { a1 = std::min(a1, q); b1 = q + 1; }
+          if (now[q] != snap[q]) { a2 = std::min(a2, q); b2 = q + 1; }
+        }
+        if (b1 || b2)
+          fprintf(stderr, "[imdgpu local verify] rank %d <- %d message %d (%zu bytes, eb %d): received differs from the sender's snapshot in [%zu, %zu), the sender's buffer NOW differs in [%zu, %zu)\n",
+                  M->rank, p, k, bytes, eb, a1, b1, a2, b2);
+      }
+    }
   } else if (op == 1 || op == 3) {
     const size_t bytes = (size_t) nsend * eb;
     std::vector<char> mine(bytes), other(bytes);
@@ -1342,9 +1405,9 @@ static int local_exchange(void *user, int op, void *dsend, void *drecv, int nsen
   } else if (op == 2) {
     for (int r = 0; r < G->n && !rc_; r++) {
       if (G->post[r].op != 2 || G->post[r].nsend != nsend) { rc_ = 1; break; }
-      if (hipMemcpyAsync((char *) drecv + (size_t) r * nsend * eb, G->post[r].send, (size_t) nsend * eb, hipMemcpyDeviceToDevice, M->s) != hipSuccess) rc_ = 1;
+      if (hipMemcpyAsync((char *) drecv + (size_t) r * nsend * eb, G->post[r].send, (size_t) nsend * eb, hipMemcpyDeviceToDevice, cs) != hipSuccess) rc_ = 1;
     }
-    if (hipStreamSynchronize(M->s) != hipSuccess) rc_ = 1;
+    if (hipStreamSynchronize(cs) != hipSuccess) rc_ = 1;
   } else rc_ = 1;
   if (rc_) { std::lock_guard<std::mutex> lk(G->mu); G->broken = true; G->cv.notify_all(); return 1; }
   if (local_barrier(G)) return 1;                        // nobody reuses a send buffer before every reader is through
@@ -1388,9 +1451,8 @@ extern "C" int imdgpu_dist_init_local(imdgpu_ctx *ctx, void *group, int rank)
   LocalGroup *G = (LocalGroup *) group;
   if (!G || rank < 0 || rank >= G->n) return imdgpu_fail(ctx, "dist_init_local: bad rank %d", rank);
   LocalMember *M = new LocalMember();                    // lives as long as the process (a few bytes per rank)
-  M->g = G; M->rank = rank; M->device = ctx->device;
+  M->g = G; M->rank = rank; M->device = ctx->device; M->ctx = ctx;
   HIPCHK(hipSetDevice(ctx->device));
-  HIPCHK(hipStreamCreateWithFlags(&M->s, hipStreamNonBlocking));
   return imdgpu_dist_init_callback(ctx, G->n, rank, local_exchange, M);
 }
 

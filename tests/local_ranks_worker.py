@@ -60,13 +60,19 @@ def main():
         miss = os.environ.get("IMD_TEST_PERSIST_MISS", "")         # "<rank>:<step>": that rank's persistent sub-step launch of that step steps aside
         if miss and int(miss.split(":")[0]) == rank:
             s.set_option("ttm_persist_miss", int(miss.split(":")[1]))
+        for kv in filter(None, os.environ.get("IMD_TEST_OPTIONS", "").split(",")):      # "name=value,...": library options for this run
+            s.set_option(kv.split("=")[0], int(kv.split("=")[1]))
         if os.environ.get("IMD_TEST_HALO_OVERLAP"):                # pass 1 in its queue form under the position halo
             s.set_option("halo_overlap", int(os.environ["IMD_TEST_HALO_OVERLAP"]))
         ops = GpuOps(s, 0)
         md = DistributedMD(dec, ops, ttm=ttm, local_group=group)
         assert md.native_rebuild
+        trace = {}
         for st in range(nsteps):
             md.md_step(st)
+            if os.environ.get("IMD_TEST_TRACE"):                  # diagnostics: what every step left behind (see tools/)
+                for k, v in s.download(fields=("impuls", "kraft", "pot_eng", "eam_rho", "eam_dF", "nummer")).items():
+                    trace["s%d_%s" % (st, k)] = v
         md.calc_forces()
         sums = md.global_sums()
         d = s.download(fields=("ort", "impuls", "kraft", "nummer", "numneighs"))
@@ -82,6 +88,7 @@ def main():
                     interior=s.get_info("halo_overlap_interior_tiles"), ntiles=s.get_info("ntiles"))
         group.barrier()                       # nobody tears its context down while another rank still runs kernels against it
         s.close()
+        d.update(trace)
         return dict(d=d, lat=lat, sums=sums, coord=dec.coord, info=info)
 
     res = group.run(rank_body, timeout=400)
