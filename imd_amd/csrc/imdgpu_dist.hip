@@ -234,11 +234,11 @@ extern "C" int imdgpu_dist_set_plan(imdgpu_ctx *ctx, int nsend, const int *send_
     D->recv_self_cap = (size_t) (D->nrecv_atoms * 1.2) + 1024;
     HIPCHK(hipMalloc((void **) &D->d_recv_self, D->recv_self_cap));
   }
-  if (D->nsend_atoms > 0) HIPCHK(hipMemcpy(D->d_send_idx, dev_send_idx, D->nsend_atoms * sizeof(int), hipMemcpyDeviceToDevice));
+  if (D->nsend_atoms > 0) HIPCHK(hipMemcpyAsync(D->d_send_idx, dev_send_idx, D->nsend_atoms * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
   {
     std::vector<int> seg((size_t) D->nsend_atoms);
     for (int s = 0; s < nsend; s++) for (long long q = 0; q < D->send_cnt[s]; q++) seg[D->send_off[s] + q] = s;
-    if (D->nsend_atoms > 0) HIPCHK(hipMemcpy(D->d_seg_of, seg.data(), seg.size() * sizeof(int), hipMemcpyHostToDevice));
+    if (D->nsend_atoms > 0) { HIPCHK(hipMemcpyAsync(D->d_seg_of, seg.data(), seg.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream)); }
     // Segments this rank sends to itself (a periodic direction with one rank: all 26 at one rank, the y/z faces of a 2x1x1 grid)
     // never touch the buffers: the gather kernel writes those atoms, shifted, straight into the ghost range, the k-th self
     // segment sent being the k-th self segment received; unpack skips them.
@@ -256,11 +256,12 @@ extern "C" int imdgpu_dist_set_plan(imdgpu_ctx *ctx, int nsend, const int *send_
         D->nself_atoms += D->send_cnt[q];
       }
     }
-    if (D->nsend_atoms > 0) HIPCHK(hipMemcpy(D->d_self_dst, dst.data(), dst.size() * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(D->d_recv_self, rs.data(), rs.size(), hipMemcpyHostToDevice));
+    if (D->nsend_atoms > 0) HIPCHK(hipMemcpyAsync(D->d_self_dst, dst.data(), dst.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(D->d_recv_self, rs.data(), rs.size(), hipMemcpyHostToDevice, ctx->stream));
     double sh[3 * MAXSEG] = {0};
     for (int s = 0; s < 3 * nsend; s++) sh[s] = send_shift[s];
-    HIPCHK(hipMemcpy(D->d_shift, sh, sizeof(sh), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpyAsync(D->d_shift, sh, sizeof(sh), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));            // (the host vectors above go out of scope)
   }
   const size_t ns = (size_t) D->nsend_atoms * 4 + 8, nr = (size_t) D->nrecv_atoms * 4 + 8;
   if (ns > D->sendbuf_cap) { if (D->sendbuf) (void) hipFree(D->sendbuf); D->sendbuf_cap = (size_t) (ns * 1.2); HIPCHK(hipMalloc((void **) &D->sendbuf, D->sendbuf_cap * sizeof(double))); }
@@ -272,34 +273,47 @@ extern "C" int imdgpu_dist_set_plan(imdgpu_ctx *ctx, int nsend, const int *send_
 // what: 0 = (x,y,z,dF) 4 doubles; 1 = dF; 2 = type (as double: one element width for every message); 3 = x,y,z
 static __host__ __device__ __forceinline__ int what_width(int what) { return what == 0 ? 4 : what == 3 ? 3 : 1; }
 
+// The halo kernels store with system scope (write-through, `global_store ... sc0 sc1`): in the eight-ranks-on-one-GPU rehearsal the plain
+// stores of the two workgroups of k_dist_unpack that one XCD ran were, once in ~150 runs beside another process on the GPU, not
+// visible to the host or to the following kernels on other XCDs even 20 ms after the kernel's end (IMDGPU_LOCAL_VERIFY; docs/VARIANTS.md)
+#define WT_STORE(P, V) __hip_atomic_store((P), (V), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+// ... and they read the plan (index lists, self flags: written by the host at every rebuild into buffers the kernels of earlier lists
+// have read) behind a system-scope acquire and with system-scope loads: the two workgroups in question had taken `recv_self` for
+// set -- a stale line of that XCD's L2 -- and returned without writing
+#define SYS_LOAD(P) __hip_atomic_load((P), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
 __global__ void k_dist_gather(int what, long long n, const int *idx, const int *seg_of, const int *self_dst, const double *shift,
                               double4 *pos, int *type, double *out)
 {
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   const long long m = (long long) blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= n) return;
-  const int i = idx[m], g = self_dst[m];                // g >= 0: this atom is its own rank's ghost atom g (nothing to send)
-  if (what == 1) { if (g >= 0) pos[g].w = pos[i].w; else out[m] = pos[i].w; return; }
+  const int i = SYS_LOAD(idx + m), g = SYS_LOAD(self_dst + m);      // g >= 0: this atom is its own rank's ghost atom g (nothing to send)
+  if (what == 1) { if (g >= 0) WT_STORE(&pos[g].w, pos[i].w); else WT_STORE(&out[m], pos[i].w); return; }
   if (what == 2) { if (g >= 0) type[g] = type[i]; else out[m] = (double) type[i]; return; }
-  const double *s = shift + 3 * seg_of[m];
+  const double *sp_ = shift + 3 * SYS_LOAD(seg_of + m);
+  const double s[3] = {SYS_LOAD(sp_), SYS_LOAD(sp_ + 1), SYS_LOAD(sp_ + 2)};
   const double4 r = pos[i];
   if (g >= 0) {
     if (what == 0) pos[g] = make_double4(r.x + s[0], r.y + s[1], r.z + s[2], r.w);
     else { pos[g].x = r.x + s[0]; pos[g].y = r.y + s[1]; pos[g].z = r.z + s[2]; }
     return;
   }
-  if (what == 0) { double *o = out + 4 * m; o[0] = r.x + s[0]; o[1] = r.y + s[1]; o[2] = r.z + s[2]; o[3] = r.w; }
-  else { double *o = out + 3 * m; o[0] = r.x + s[0]; o[1] = r.y + s[1]; o[2] = r.z + s[2]; }
+  if (what == 0) { double *o = out + 4 * m; WT_STORE(o, r.x + s[0]); WT_STORE(o + 1, r.y + s[1]); WT_STORE(o + 2, r.z + s[2]); WT_STORE(o + 3, r.w); }
+  else { double *o = out + 3 * m; WT_STORE(o, r.x + s[0]); WT_STORE(o + 1, r.y + s[1]); WT_STORE(o + 2, r.z + s[2]); }
 }
 // the receive buffer IS the ghost atoms in order: atom nlocal + m (those of self segments are already in place)
 __global__ void k_dist_unpack(int what, long long n, int nlocal, const unsigned char *recv_self, const double *in, double4 *pos, int *type)
 {
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   const long long m = (long long) blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= n || recv_self[m]) return;
+  if (m >= n) return;
+  if ((SYS_LOAD((const unsigned *) (recv_self + (m & ~3ll))) >> (8 * (int) (m & 3))) & 0xffu) return;     // (the buffer is a multiple of four bytes long)
   const long long i = nlocal + m;
-  if (what == 1) pos[i].w = in[m];
+  // write-through stores (system scope): see WT_STORE
+  if (what == 1) WT_STORE(&pos[i].w, in[m]);
   else if (what == 2) type[i] = (int) in[m];
-  else if (what == 0) { const double *q = in + 4 * m; pos[i] = make_double4(q[0], q[1], q[2], q[3]); }
-  else { const double *q = in + 3 * m; pos[i].x = q[0]; pos[i].y = q[1]; pos[i].z = q[2]; }
+  else if (what == 0) { const double *q = in + 4 * m; WT_STORE(&pos[i].x, q[0]); WT_STORE(&pos[i].y, q[1]); WT_STORE(&pos[i].z, q[2]); WT_STORE(&pos[i].w, q[3]); }
+  else { const double *q = in + 3 * m; WT_STORE(&pos[i].x, q[0]); WT_STORE(&pos[i].y, q[1]); WT_STORE(&pos[i].z, q[2]); }
 }
 // one exchange of `w` doubles per atom following the plan, on the context's stream
 static int dist_exchange(imdgpu_ctx *ctx, DistState *D, int w, ncclComm_t comm = nullptr)
@@ -377,6 +391,37 @@ static int dist_halo_parts(imdgpu_ctx *ctx, DistState *D, int what, int parts, n
     if (D->nrecv_atoms > D->nself_atoms)                    // something did arrive through the buffers
       hipLaunchKernelGGL(k_dist_unpack, dim3(nblk(D->nrecv_atoms, 256)), dim3(256), 0, ctx->stream, what, D->nrecv_atoms, ctx->nlocal,
                          D->d_recv_self, D->recvbuf, ctx->pos, ctx->type);
+    if (verify && D->nrecv_atoms > D->nself_atoms && (what == 1 || what == 3)) {        // ... and the unpacked ghost atoms against the receive buffer
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      const size_t n = (size_t) D->nrecv_atoms;
+      std::vector<double> in(n * w);
+      std::vector<double4> gp(n);
+      std::vector<unsigned char> rs(n);
+      HIPCHK(hipMemcpy(in.data(), D->recvbuf, in.size() * 8, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(rs.data(), D->d_recv_self, n, hipMemcpyDeviceToHost));
+      auto count_bad = [&](size_t &lo, size_t &hi) {
+        size_t nb = 0; lo = n; hi = 0;
+        for (size_t m = 0; m < n; m++) {
+          if (rs[m]) continue;
+          const double4 q = gp[m];
+          const bool bad = what == 1 ? q.w != in[m] : (q.x != in[3 * m] || q.y != in[3 * m + 1] || q.z != in[3 * m + 2]);
+          if (bad) { nb++; lo = std::min(lo, m); hi = m + 1; }
+        }
+        return nb;
+      };
+      HIPCHK(hipMemcpy(gp.data(), ctx->pos + ctx->nlocal, n * sizeof(double4), hipMemcpyDeviceToHost));
+      size_t lo, hi;
+      const size_t nb = count_bad(lo, hi);
+      if (nb) {
+        const double got = what == 1 ? gp[lo].w : gp[lo].x, want = what == 1 ? in[lo] : in[3 * lo];
+        usleep(20000);
+        HIPCHK(hipMemcpy(gp.data(), ctx->pos + ctx->nlocal, n * sizeof(double4), hipMemcpyDeviceToHost));
+        size_t lo2, hi2;
+        const size_t nb2 = count_bad(lo2, hi2);
+        fprintf(stderr, "[imdgpu local verify] rank %d UNPACK what %d: %zu of %zu ghost atoms differ from the receive buffer after the stream's synchronisation, atoms [%zu, %zu); 20 ms later %zu; first bad: got %.6g expected %.6g\n",
+                D->rank, what, nb, n, lo, hi, nb2, got, want);
+      }
+    }
   }
   HIPCHK(hipGetLastError());
   return 0;
