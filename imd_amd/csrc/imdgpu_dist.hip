@@ -273,13 +273,12 @@ extern "C" int imdgpu_dist_set_plan(imdgpu_ctx *ctx, int nsend, const int *send_
 // what: 0 = (x,y,z,dF) 4 doubles; 1 = dF; 2 = type (as double: one element width for every message); 3 = x,y,z
 static __host__ __device__ __forceinline__ int what_width(int what) { return what == 0 ? 4 : what == 3 ? 3 : 1; }
 
-// The halo kernels store with system scope (write-through, `global_store ... sc0 sc1`): in the eight-ranks-on-one-GPU rehearsal the plain
-// stores of the two workgroups of k_dist_unpack that one XCD ran were, once in ~150 runs beside another process on the GPU, not
-// visible to the host or to the following kernels on other XCDs even 20 ms after the kernel's end (IMDGPU_LOCAL_VERIFY; docs/VARIANTS.md)
+// The halo kernels store with system scope (write-through) and read the plan (index lists, self flags, shifts: rewritten at every
+// rebuild) with system-scope loads behind a system acquire.  Defensive: in the eight-ranks-on-one-GPU rehearsal, about once in 150
+// runs beside another process on the GPU, the two workgroups of k_dist_unpack (or of k_dist_gather) that ONE XCD ran left no trace
+// -- ghost atoms still at their old values 20 ms after the kernel's end, the receive buffer correct (IMDGPU_LOCAL_VERIFY) -- or
+// acted like the launch before them (positions where dF belongs).  These accesses did not cure it; the cause is open (docs/VARIANTS.md)
 #define WT_STORE(P, V) __hip_atomic_store((P), (V), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
-// ... and they read the plan (index lists, self flags: written by the host at every rebuild into buffers the kernels of earlier lists
-// have read) behind a system-scope acquire and with system-scope loads: the two workgroups in question had taken `recv_self` for
-// set -- a stale line of that XCD's L2 -- and returned without writing
 #define SYS_LOAD(P) __hip_atomic_load((P), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
 __global__ void k_dist_gather(int what, long long n, const int *idx, const int *seg_of, const int *self_dst, const double *shift,
                               double4 *pos, int *type, double *out)
