@@ -273,46 +273,38 @@ extern "C" int imdgpu_dist_set_plan(imdgpu_ctx *ctx, int nsend, const int *send_
 // what: 0 = (x,y,z,dF) 4 doubles; 1 = dF; 2 = type (as double: one element width for every message); 3 = x,y,z
 static __host__ __device__ __forceinline__ int what_width(int what) { return what == 0 ? 4 : what == 3 ? 3 : 1; }
 
-// The halo kernels store with system scope (write-through) and read the plan (index lists, self flags, shifts: rewritten at every
-// rebuild) with system-scope loads behind a system acquire.  Defensive: in the eight-ranks-on-one-GPU rehearsal, about once in 150
-// runs beside another process on the GPU, the two workgroups of k_dist_unpack (or of k_dist_gather) that ONE XCD ran left no trace
-// -- ghost atoms still at their old values 20 ms after the kernel's end, the receive buffer correct (IMDGPU_LOCAL_VERIFY) -- or
-// acted like the launch before them (positions where dF belongs).  These accesses did not cure it; the cause is open (docs/VARIANTS.md)
-#define WT_STORE(P, V) __hip_atomic_store((P), (V), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
-#define SYS_LOAD(P) __hip_atomic_load((P), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+// (Round 5: in the eight-ranks-on-one-GPU rehearsal, about once in 150 runs beside another process on the GPU, the two workgroups of
+// k_dist_unpack or k_dist_gather that ONE XCD ran left no trace, or acted like the launch before them, with every input verified
+// (IMDGPU_LOCAL_VERIFY).  System-scope loads / write-through stores / fences here did not change that and cost 0.4 ms per step at
+// 10 M atoms, so the kernels are plain again; docs/VARIANTS.md has the record.)
 __global__ void k_dist_gather(int what, long long n, const int *idx, const int *seg_of, const int *self_dst, const double *shift,
                               double4 *pos, int *type, double *out)
 {
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   const long long m = (long long) blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= n) return;
-  const int i = SYS_LOAD(idx + m), g = SYS_LOAD(self_dst + m);      // g >= 0: this atom is its own rank's ghost atom g (nothing to send)
-  if (what == 1) { if (g >= 0) WT_STORE(&pos[g].w, pos[i].w); else WT_STORE(&out[m], pos[i].w); return; }
+  const int i = idx[m], g = self_dst[m];                // g >= 0: this atom is its own rank's ghost atom g (nothing to send)
+  if (what == 1) { if (g >= 0) pos[g].w = pos[i].w; else out[m] = pos[i].w; return; }
   if (what == 2) { if (g >= 0) type[g] = type[i]; else out[m] = (double) type[i]; return; }
-  const double *sp_ = shift + 3 * SYS_LOAD(seg_of + m);
-  const double s[3] = {SYS_LOAD(sp_), SYS_LOAD(sp_ + 1), SYS_LOAD(sp_ + 2)};
+  const double *s = shift + 3 * seg_of[m];
   const double4 r = pos[i];
   if (g >= 0) {
     if (what == 0) pos[g] = make_double4(r.x + s[0], r.y + s[1], r.z + s[2], r.w);
     else { pos[g].x = r.x + s[0]; pos[g].y = r.y + s[1]; pos[g].z = r.z + s[2]; }
     return;
   }
-  if (what == 0) { double *o = out + 4 * m; WT_STORE(o, r.x + s[0]); WT_STORE(o + 1, r.y + s[1]); WT_STORE(o + 2, r.z + s[2]); WT_STORE(o + 3, r.w); }
-  else { double *o = out + 3 * m; WT_STORE(o, r.x + s[0]); WT_STORE(o + 1, r.y + s[1]); WT_STORE(o + 2, r.z + s[2]); }
+  if (what == 0) { double *o = out + 4 * m; o[0] = r.x + s[0]; o[1] = r.y + s[1]; o[2] = r.z + s[2]; o[3] = r.w; }
+  else { double *o = out + 3 * m; o[0] = r.x + s[0]; o[1] = r.y + s[1]; o[2] = r.z + s[2]; }
 }
 // the receive buffer IS the ghost atoms in order: atom nlocal + m (those of self segments are already in place)
 __global__ void k_dist_unpack(int what, long long n, int nlocal, const unsigned char *recv_self, const double *in, double4 *pos, int *type)
 {
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   const long long m = (long long) blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= n) return;
-  if ((SYS_LOAD((const unsigned *) (recv_self + (m & ~3ll))) >> (8 * (int) (m & 3))) & 0xffu) return;     // (the buffer is a multiple of four bytes long)
+  if (m >= n || recv_self[m]) return;
   const long long i = nlocal + m;
-  // write-through stores (system scope): see WT_STORE
-  if (what == 1) WT_STORE(&pos[i].w, in[m]);
+  if (what == 1) pos[i].w = in[m];
   else if (what == 2) type[i] = (int) in[m];
-  else if (what == 0) { const double *q = in + 4 * m; WT_STORE(&pos[i].x, q[0]); WT_STORE(&pos[i].y, q[1]); WT_STORE(&pos[i].z, q[2]); WT_STORE(&pos[i].w, q[3]); }
-  else { const double *q = in + 3 * m; WT_STORE(&pos[i].x, q[0]); WT_STORE(&pos[i].y, q[1]); WT_STORE(&pos[i].z, q[2]); }
+  else if (what == 0) { const double *q = in + 4 * m; pos[i] = make_double4(q[0], q[1], q[2], q[3]); }
+  else { const double *q = in + 3 * m; pos[i].x = q[0]; pos[i].y = q[1]; pos[i].z = q[2]; }
 }
 // one exchange of `w` doubles per atom following the plan, on the context's stream
 static int dist_exchange(imdgpu_ctx *ctx, DistState *D, int w, ncclComm_t comm = nullptr)
