@@ -63,7 +63,13 @@ int  imdgpu_synchronize(imdgpu_ctx *ctx);
  * (DESIGN 5), needs the third communicator id on the RCCL transport;
  * "p3_coef" = 1 (default) the EAM force pass (do_forces_eam2, imd_forces_nbl.c:789-985) reads DERIV_FUNC2's gradient
  * (potaccess.h:591-621) as one coefficient pair per table row where that applies (one atom type, pair_pot and rho_h_tab on
- * one r^2 grid, nothing with LDS tiles of its own beside it), 0 always as three table rows; the two agree to rounding */
+ * one r^2 grid, nothing with LDS tiles of its own beside it), 0 always as three table rows; the two agree to rounding;
+ * "tile_rec" = 1 (default) several atom types with pair_pot and rho_h_tab run the record kernels (list rows segmented by the
+ * neighbour's type; PAIR_INT2 / VAL_FUNC2 / DERIV_FUNC2 with the per-column begin / end / step of pot_table_t, potaccess.h:323-354,
+ * 465-495,591-621), 0 the older general kernels (tables and a type per slot in the LDS when they fit, global gather when not);
+ * "tile_rec_lds" = -1 (default) the library decides which tables the record kernels keep in the LDS (what fits beside a tile), else
+ * a mask: 1 pair_pot and 2 rho_h_tab in pass 1, 4 rho_h_tab in the EAM force pass; the rest are read in place through L2 as
+ * coefficient records; tables that cannot fit are dropped from the mask (get_info "rec_lds" says what runs); same results */
 int  imdgpu_set_option(imdgpu_ctx *ctx, const char *name, int value);
 /* introspection: "list_mode" (kernel family of the current list), "tile_cap", "slot_cap", "W", "ntiles", ...,
  * "fused_embedding" (1: the embedding pass runs inside the pass-1 kernel of the current list),
@@ -73,7 +79,8 @@ int  imdgpu_set_option(imdgpu_ctx *ctx, const char *name, int value);
  * re-issued through the launch chain), "p3_standin_passes" (EAM force passes in which the three-row kernel stood in for the
  * coefficient form), "kernel_rev",
  * "p3_coef_rows" / "p3_coef_klo" (rows of the gradient-coefficient table the EAM force pass holds in LDS and the first
- * of them; 0 / -1: the three-row form) */
+ * of them; 0 / -1: the three-row form), "pass1_form" (2 one type on a shared grid, 1 one type with pair_pot and rho_h_tab on
+ * their own grids, 3 several types: record kernels, 0 the general kernels), "rec_lds" (see option "tile_rec_lds") */
 int  imdgpu_get_info(imdgpu_ctx *ctx, const char *name, long long *value);
 
 /* ---- set-up -------------------------------------------------------------- */
