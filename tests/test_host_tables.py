@@ -76,3 +76,30 @@ def test_laser_setup_like_init_laser():
     p = ttm_mod.init_laser(mu=0.05, sigma_e=40.0, sigma_t=0.15, t_0=0.3, direction=(1, 0, 0), offset=off)
     assert p["p_peak"] == float(G["laser_p_peak"]) and p["sigma_t_squared"] == float(G["laser_sigma_t_squared"])
     assert p["mu"] == float(G["laser_mu"]) and p["t_0"] == float(G["laser_t_0"]) and list(p["direction"]) == list(G["laser_dir"])
+
+
+@pytest.mark.parametrize("ntypes", [3, 4])
+def test_ntype_tables_round_trip(tmp_path, ntypes):
+    """write_synthetic_eam_files_ntypes -> read_pot_table (format 2, imd_potential.c:394-466): ntypes^2 columns, every column with its
+    own begin / end / step / length, the two pad rows from the three-point extrapolation; pair columns symmetric in (i, j)"""
+    potential.write_synthetic_eam_files_ntypes(str(tmp_path), ntypes, rows=0.1)
+    nc = ntypes * ntypes
+    pair, c1 = potential.read_pot_table(str(tmp_path / "phi.pt"), nc, True)
+    rho, c2 = potential.read_pot_table(str(tmp_path / "rho.pt"), nc, True)
+    emb, _ = potential.read_pot_table(str(tmp_path / "F.pt"), ntypes, False)
+    assert pair.ncols == rho.ncols == nc and emb.ncols == ntypes
+    assert len(set(pair.len.tolist())) > 1 and len(set(rho.len.tolist())) > 1            # lengths differ between columns
+    assert pair.maxsteps == int(pair.len.max()) and c1 == float(pair.end.max()) and c2 == float(rho.end.max())
+    tp = pair.table.reshape(-1, nc)
+    for i in range(ntypes):
+        for j in range(ntypes):
+            a, b = i * ntypes + j, j * ntypes + i
+            assert pair.len[a] == pair.len[b] and pair.begin[a] == pair.begin[b] and pair.end[a] == pair.end[b]
+            assert np.array_equal(tp[: pair.len[a] + 2, a], tp[: pair.len[b] + 2, b])
+    for t in (pair, rho, emb):
+        tt = t.table.reshape(-1, t.ncols)
+        for c in range(t.ncols):
+            n = int(t.len[c])
+            assert abs(t.begin[c] + (n - 1) * t.step[c] - t.end[c]) < 1e-9 * abs(t.end[c])
+            assert tt[n, c] == 3 * tt[n - 1, c] - 3 * tt[n - 2, c] + tt[n - 3, c]               # init_threepoint (imd_potential.c:1272)
+            assert np.all(tt[n + 2:, c] == 0.0)
