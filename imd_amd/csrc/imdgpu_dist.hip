@@ -277,7 +277,10 @@ static __host__ __device__ __forceinline__ int what_width(int what) { return wha
 // k_dist_unpack or k_dist_gather that ONE XCD ran left no trace, or acted like the launch before them, with every input verified
 // (IMDGPU_LOCAL_VERIFY).  System-scope loads / write-through stores / fences here did not change that and cost 0.4 ms per step at
 // 10 M atoms, so the kernels are plain again; docs/VARIANTS.md has the record.)
-__global__ void k_dist_gather(int what, long long n, const int *idx, const int *seg_of, const int *self_dst, const double *shift,
+// (`what` is a template argument: launches for different kinds of data are different kernels, so that a workgroup which -- as in that
+// anomaly -- ran with the arguments of the previous launch of ITS kernel would still move the right kind of data.)
+template <int what>
+__global__ void k_dist_gather(long long n, const int *idx, const int *seg_of, const int *self_dst, const double *shift,
                               double4 *pos, int *type, double *out)
 {
   const long long m = (long long) blockIdx.x * blockDim.x + threadIdx.x;
@@ -296,7 +299,8 @@ __global__ void k_dist_gather(int what, long long n, const int *idx, const int *
   else { double *o = out + 3 * m; o[0] = r.x + s[0]; o[1] = r.y + s[1]; o[2] = r.z + s[2]; }
 }
 // the receive buffer IS the ghost atoms in order: atom nlocal + m (those of self segments are already in place)
-__global__ void k_dist_unpack(int what, long long n, int nlocal, const unsigned char *recv_self, const double *in, double4 *pos, int *type)
+template <int what>
+__global__ void k_dist_unpack(long long n, int nlocal, const unsigned char *recv_self, const double *in, double4 *pos, int *type)
 {
   const long long m = (long long) blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= n || recv_self[m]) return;
@@ -345,9 +349,11 @@ static int dist_halo_parts(imdgpu_ctx *ctx, DistState *D, int what, int parts, n
   if (what < 0 || what > 3) return imdgpu_fail(ctx, "dist_halo: what must be 0..3");
   const int w = what_width(what);
   ProfScope ps(ctx, PROF_GHOSTS);
+#define HALO_K(K, ...) do { if (what == 0) hipLaunchKernelGGL(K<0>, __VA_ARGS__); else if (what == 1) hipLaunchKernelGGL(K<1>, __VA_ARGS__); \
+                            else if (what == 2) hipLaunchKernelGGL(K<2>, __VA_ARGS__); else hipLaunchKernelGGL(K<3>, __VA_ARGS__); } while (0)
   if ((parts & 1) && D->nsend_atoms > 0)
-    hipLaunchKernelGGL(k_dist_gather, dim3(nblk(D->nsend_atoms, 256)), dim3(256), 0, ctx->stream, what, D->nsend_atoms, D->d_send_idx,
-                       D->d_seg_of, D->d_self_dst, D->d_shift, ctx->pos, ctx->type, D->sendbuf);
+    HALO_K(k_dist_gather, dim3(nblk(D->nsend_atoms, 256)), dim3(256), 0, ctx->stream, D->nsend_atoms, D->d_send_idx,
+           D->d_seg_of, D->d_self_dst, D->d_shift, ctx->pos, ctx->type, D->sendbuf);
   static const bool verify = cfg_env("IMDGPU_LOCAL_VERIFY") != nullptr;      // diagnostics: the gather's output against a host evaluation
   if (verify && (parts & 1) && D->nsend_atoms > 0 && (what == 1 || what == 3)) {
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -380,8 +386,8 @@ static int dist_halo_parts(imdgpu_ctx *ctx, DistState *D, int what, int parts, n
     if (dist_exchange(ctx, D, w, comm)) return 1;
     if (parts == 2) imdgpu_tl_mark(ctx, "halo3_msgs");
     if (D->nrecv_atoms > D->nself_atoms)                    // something did arrive through the buffers
-      hipLaunchKernelGGL(k_dist_unpack, dim3(nblk(D->nrecv_atoms, 256)), dim3(256), 0, ctx->stream, what, D->nrecv_atoms, ctx->nlocal,
-                         D->d_recv_self, D->recvbuf, ctx->pos, ctx->type);
+      HALO_K(k_dist_unpack, dim3(nblk(D->nrecv_atoms, 256)), dim3(256), 0, ctx->stream, D->nrecv_atoms, ctx->nlocal,
+             D->d_recv_self, D->recvbuf, ctx->pos, ctx->type);
     if (verify && D->nrecv_atoms > D->nself_atoms && (what == 1 || what == 3)) {        // ... and the unpacked ghost atoms against the receive buffer
       HIPCHK(hipStreamSynchronize(ctx->stream));
       const size_t n = (size_t) D->nrecv_atoms;
